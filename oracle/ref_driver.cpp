@@ -1,0 +1,353 @@
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin extern "C" driver around the *real* reference classes, compiled by
+// oracle/Makefile straight from the sources under /root/reference (no cmake, no
+// generated headers, no stand-ins) into oracle/_ref/libsdref.so.  It exposes the
+// reference's own
+//   * SubstitutionMatrix / calcLocalAaBiasCorrection   (M/src/commons/SubstitutionMatrix.cpp:12,79)
+//   * Masker + tantan                                   (M/src/commons/Masker.cpp:15, M/lib/tantan/tantan.cpp)
+//   * IndexTable / SequenceLookup build                 (M/src/prefiltering/IndexTable.h:131,342; the
+//     loop below follows IndexBuilder::fillDatabase, M/src/prefiltering/IndexBuilder.cpp:55-239, which itself
+//     cannot be linked because it needs DBReader -> Parameters.cpp -> cmake-generated headers)
+//   * ExtendedSubstitutionMatrix + KmerGenerator        (M/src/prefiltering/KmerGenerator.cpp:107)
+//   * QueryMatcher::matchQuery                          (M/src/prefiltering/QueryMatcher.cpp:85)
+//   * SmithWaterman::ssw_init / ssw_align               (M/src/alignment/StripedSmithWaterman.cpp:1216,238)
+//   * EvalueComputation (ALP)                           (M/src/alignment/EvalueComputation.h:9)
+// so that the restatement in oracle/sd_oracle.cpp and the HIP kernels can be
+// diffed against the reference itself on arbitrary inputs, and so that bench.py can
+// time the reference's AVX2 code as cpu_baseline.kind == "reference".
+//
+// M/ = /root/reference/lib/mmseqs/.  spacedust's ClusterHits.cpp is not linkable
+// (DBReader/LocalParameters), see DESIGN.md.
+#include "SubstitutionMatrix.h"
+#include "Sequence.h"
+#include "Masker.h"
+#include "IndexTable.h"
+#include "SequenceLookup.h"
+#include "ExtendedSubstitutionMatrix.h"
+#include "KmerGenerator.h"
+#include "QueryMatcher.h"
+#include "StripedSmithWaterman.h"
+#include "EvalueComputation.h"
+#include "Indexer.h"
+#include "Util.h"
+#include "Debug.h"
+
+#include <cstring>
+#include <string>
+#include <vector>
+#include <omp.h>
+
+namespace {
+struct RefCtx {
+    SubstitutionMatrix *blosum2;   // blosum62, bitFactor 2, bias 0   (ungapped + SW)
+    SubstitutionMatrix *seed8;     // VTML80,  bitFactor 8, bias 0    (k-mer seeds)
+    ScoreMatrix three, two;
+    bool haveExt;
+    int kmerSize;
+};
+struct RefIndex {
+    RefCtx *ctx;
+    IndexTable *table;
+    SequenceLookup *lookup;
+    size_t nSeq;
+    size_t maxLen;
+    size_t aaSize;
+    size_t masked;
+};
+struct RefPref {
+    RefIndex *idx;
+    QueryMatcher *matcher;
+    Sequence *seq;
+};
+struct RefSW {
+    RefCtx *ctx;
+    SmithWaterman *sw;
+    EvalueComputation *evaluer;
+    Sequence *q;
+    Sequence *t;
+    int8_t *tiny;
+    size_t maxLen;
+};
+}
+
+extern "C" {
+
+void *ref_ctx_create(const char *blosumPath, const char *vtmlPath, int kmerSize) {
+    Debug::setDebugLevel(1);
+    RefCtx *c = new RefCtx();
+    c->blosum2 = new SubstitutionMatrix(blosumPath, 2.0f, 0.0f);
+    c->seed8 = new SubstitutionMatrix(vtmlPath, 8.0f, 0.0f);
+    c->haveExt = false;
+    c->kmerSize = kmerSize;
+    return c;
+}
+
+// which: 0 = blosum62@2, 1 = VTML80@8.  out: short[21*21], pBack double[21], aa2num uint8[256]
+int ref_get_matrix(void *vc, int which, short *out, double *pback, unsigned char *aa2num) {
+    RefCtx *c = (RefCtx *) vc;
+    SubstitutionMatrix *m = which == 0 ? c->blosum2 : c->seed8;
+    for (int i = 0; i < m->alphabetSize; i++)
+        for (int j = 0; j < m->alphabetSize; j++) out[i * m->alphabetSize + j] = m->subMatrix[i][j];
+    for (int i = 0; i < m->alphabetSize; i++) pback[i] = m->pBack[i];
+    for (int i = 0; i < 255; i++) aa2num[i] = m->aa2num[i];
+    aa2num[255] = m->aa2num[(int) 'X'];
+    return m->alphabetSize;
+}
+
+void ref_compbias(void *vc, int which, const unsigned char *num, int L, float scale, float *out) {
+    RefCtx *c = (RefCtx *) vc;
+    SubstitutionMatrix *m = which == 0 ? c->blosum2 : c->seed8;
+    SubstitutionMatrix::calcLocalAaBiasCorrection(m, num, L, out, scale);
+}
+
+static void ensureExt(RefCtx *c) {
+    if (c->haveExt) return;
+    // M/src/prefiltering/Prefiltering.cpp:209-214
+    int a = c->seed8->alphabetSize;
+    c->seed8->alphabetSize = a - 1;
+    c->two = ExtendedSubstitutionMatrix::calcScoreMatrix(*c->seed8, 2);
+    c->three = ExtendedSubstitutionMatrix::calcScoreMatrix(*c->seed8, 3);
+    c->seed8->alphabetSize = a;
+    c->haveExt = true;
+}
+
+// dump of the sorted 3-mer (which=3) or 2-mer (which=2) table
+size_t ref_ext_matrix(void *vc, int which, short *score, unsigned int *index, size_t *rowSize) {
+    RefCtx *c = (RefCtx *) vc;
+    ensureExt(c);
+    ScoreMatrix &s = which == 3 ? c->three : c->two;
+    *rowSize = s.rowSize;
+    if (score != NULL) {
+        memcpy(score, s.score, s.elementSize * s.rowSize * sizeof(short));
+        memcpy(index, s.index, s.elementSize * s.rowSize * sizeof(unsigned int));
+    }
+    return s.elementSize;
+}
+
+// similar k-mer list for one window of kmerSize numeric residues
+size_t ref_kmer_list(void *vc, const unsigned char *window, int thr, size_t *out, size_t cap) {
+    RefCtx *c = (RefCtx *) vc;
+    ensureExt(c);
+    KmerGenerator gen(c->kmerSize, c->seed8->alphabetSize - 1, (short) thr);
+    gen.setDivideStrategy(&c->three, &c->two);
+    std::pair<size_t *, size_t> r = gen.generateKmerList(window);
+    size_t n = std::min(cap, r.second);
+    memcpy(out, r.first, n * sizeof(size_t));
+    return r.second;
+}
+
+// tantan-mask one numeric sequence in place (M/src/commons/Masker.cpp:15-55), returns #masked
+int ref_mask(void *vc, unsigned char *num, int L, double maskProb) {
+    RefCtx *c = (RefCtx *) vc;
+    Sequence s(L + 2, Parameters::DBTYPE_AMINO_ACIDS, c->seed8, c->kmerSize, true, false);
+    memcpy(s.numSequence, num, L);
+    s.L = L;
+    Masker masker(*c->seed8);
+    int n = masker.maskSequence(s, true, maskProb, false, 0);
+    memcpy(num, s.numSequence, L);
+    return n;
+}
+
+// Build masked SequenceLookup + IndexTable for n target sequences given as ASCII
+// (concatenated, offsets[n+1]).  Follows IndexBuilder::fillDatabase (non-profile branch).
+void *ref_index_build(void *vc, const char *seqs, const size_t *offsets, size_t n, int kmerThr,
+                      int mask, double maskProb, int threads) {
+    RefCtx *c = (RefCtx *) vc;
+    RefIndex *ix = new RefIndex();
+    ix->ctx = c;
+    ix->nSeq = n;
+    size_t maxLen = 0, aa = 0;
+    for (size_t i = 0; i < n; i++) {
+        size_t l = offsets[i + 1] - offsets[i];
+        maxLen = std::max(maxLen, l);
+        aa += l;
+    }
+    ix->maxLen = maxLen;
+    ix->aaSize = aa;
+    BaseMatrix &subMat = *c->seed8;
+    const int alphabetSize = subMat.alphabetSize - 1;   // Prefiltering.cpp:530-533
+    ix->table = new IndexTable(alphabetSize, c->kmerSize, false);
+    ix->lookup = new SequenceLookup(n, aa);
+    char *idScoreLookup = new char[subMat.alphabetSize];
+    for (int a = 0; a < subMat.alphabetSize; a++) idScoreLookup[a] = (char) subMat.subMatrix[a][a];
+    size_t maskedResidues = 0, tableSize = 0;
+    std::vector<size_t> seqOff(n + 1, 0);
+    for (size_t i = 0; i < n; i++) seqOff[i + 1] = seqOff[i] + (offsets[i + 1] - offsets[i]);
+#pragma omp parallel num_threads(threads)
+    {
+        Masker masker(subMat);
+        Indexer idxer(alphabetSize, c->kmerSize);
+        Sequence s(maxLen + 2, Parameters::DBTYPE_AMINO_ACIDS, &subMat, c->kmerSize, true, false);
+        unsigned int *buffer = (unsigned int *) malloc((maxLen + 2) * sizeof(unsigned int));
+#pragma omp for schedule(dynamic, 100) reduction(+:maskedResidues, tableSize)
+        for (size_t id = 0; id < n; id++) {
+            s.resetCurrPos();
+            s.mapSequence(id, (unsigned int) id, seqs + offsets[id], (unsigned int) (offsets[id + 1] - offsets[id]));
+            maskedResidues += masker.maskSequence(s, mask != 0, maskProb, false, 0);
+            ix->lookup->addSequence(s.numSequence, s.L, id, seqOff[id]);
+            ix->table->addKmerCount(&s, &idxer, buffer, kmerThr, idScoreLookup);
+            if (Util::overlappingKmers(s.L, s.getEffectiveKmerSize()) > 0) tableSize += 1;
+        }
+        free(buffer);
+    }
+    ix->masked = maskedResidues;
+    ix->table->initMemory(tableSize);
+    ix->table->init();
+#pragma omp parallel num_threads(threads)
+    {
+        Indexer idxer(alphabetSize, c->kmerSize);
+        Sequence s(maxLen + 2, Parameters::DBTYPE_AMINO_ACIDS, &subMat, c->kmerSize, true, false);
+        size_t bufferSize = maxLen + 2;
+        IndexEntryLocalTmp *buffer = (IndexEntryLocalTmp *) malloc(bufferSize * sizeof(IndexEntryLocalTmp));
+#pragma omp for schedule(dynamic, 100)
+        for (size_t id = 0; id < n; id++) {
+            s.resetCurrPos();
+            s.mapSequence(id, (unsigned int) id, ix->lookup->getSequence(id));
+            ix->table->addSequence(&s, &idxer, &buffer, bufferSize, kmerThr, idScoreLookup);
+        }
+        free(buffer);
+    }
+    delete[] idScoreLookup;
+    ix->table->revertPointer();
+    ix->table->sortDBSeqLists();
+    return ix;
+}
+
+size_t ref_index_info(void *vi, size_t *tableSize, size_t *masked) {
+    RefIndex *ix = (RefIndex *) vi;
+    *tableSize = ix->table->getTableSize();
+    *masked = ix->masked;
+    return ix->table->getOffsets()[ix->table->getTableSize()];
+}
+
+// offsets: size_t[tableSize+1]; entries packed {u32 seqId; u16 pos}; lookup: masked numeric residues
+void ref_index_dump(void *vi, size_t *offsets, unsigned char *entries, unsigned char *lookup) {
+    RefIndex *ix = (RefIndex *) vi;
+    size_t ts = ix->table->getTableSize();
+    memcpy(offsets, ix->table->getOffsets(), (ts + 1) * sizeof(size_t));
+    memcpy(entries, ix->table->getEntries(), offsets[ts] * sizeof(IndexEntryLocal));
+    if (lookup != NULL) memcpy(lookup, ix->lookup->getData(), ix->aaSize);
+}
+
+void *ref_prefilter_create(void *vi, int kmerThr, size_t maxQueryLen, size_t maxHits, int minDiagScore,
+                           int compBias) {
+    RefIndex *ix = (RefIndex *) vi;
+    RefCtx *c = ix->ctx;
+    ensureExt(c);
+    RefPref *p = new RefPref();
+    p->idx = ix;
+    size_t maxLen = std::max(ix->maxLen, maxQueryLen) + 2;
+    p->matcher = new QueryMatcher(ix->table, ix->lookup, c->seed8, c->blosum2, (short) kmerThr, c->kmerSize,
+                                  ix->nSeq, (unsigned int) maxLen, maxHits, compBias != 0, 1.0f, true,
+                                  (unsigned int) minDiagScore, false, false);
+    p->matcher->setSubstitutionMatrix(&c->three, &c->two);
+    p->seq = new Sequence(maxLen, Parameters::DBTYPE_AMINO_ACIDS, c->seed8, c->kmerSize, true, compBias != 0);
+    return p;
+}
+
+// out: triples (seqId, score, diagonal as uint16) ; returns count.  stats[0]=kmersPerPos*L stats[1]=dbMatches
+size_t ref_prefilter_query(void *vp, const char *seq, unsigned int L, unsigned int identityId,
+                           unsigned int *outId, int *outScore, unsigned short *outDiag, double *stats) {
+    RefPref *p = (RefPref *) vp;
+    p->seq->mapSequence(0, 0, seq, L);
+    std::pair<hit_t *, size_t> r = p->matcher->matchQuery(p->seq, identityId, false);
+    for (size_t i = 0; i < r.second; i++) {
+        outId[i] = r.first[i].seqId;
+        outScore[i] = r.first[i].prefScore;
+        outDiag[i] = r.first[i].diagonal;
+    }
+    if (stats != NULL) {
+        stats[0] = p->matcher->getStatistics()->kmersPerPos * (double) L;
+        stats[1] = (double) p->matcher->getStatistics()->dbMatches;
+    }
+    return r.second;
+}
+
+void ref_prefilter_destroy(void *vp) {
+    RefPref *p = (RefPref *) vp;
+    delete p->matcher;
+    delete p->seq;
+    delete p;
+}
+
+void ref_index_destroy(void *vi) {
+    RefIndex *ix = (RefIndex *) vi;
+    delete ix->table;
+    delete ix->lookup;
+    delete ix;
+}
+
+void *ref_sw_create(void *vc, size_t maxLen, size_t dbResidues, int compBias) {
+    RefCtx *c = (RefCtx *) vc;
+    RefSW *s = new RefSW();
+    s->ctx = c;
+    s->maxLen = maxLen + 2;
+    BaseMatrix *m = c->blosum2;
+    s->sw = new SmithWaterman(s->maxLen, m->alphabetSize, compBias != 0, 1.0f, Parameters::DBTYPE_AMINO_ACIDS);
+    s->evaluer = new EvalueComputation(dbResidues, m, 11, 1);
+    s->q = new Sequence(s->maxLen, Parameters::DBTYPE_AMINO_ACIDS, m, 0, false, compBias != 0);
+    s->t = new Sequence(s->maxLen, Parameters::DBTYPE_AMINO_ACIDS, m, 0, false, compBias != 0);
+    s->tiny = new int8_t[m->alphabetSize * m->alphabetSize];
+    for (int i = 0; i < m->alphabetSize; i++)
+        for (int j = 0; j < m->alphabetSize; j++) s->tiny[i * m->alphabetSize + j] = (int8_t) m->subMatrix[i][j];
+    return s;
+}
+
+void ref_sw_set_query(void *vs, const char *seq, unsigned int L) {
+    RefSW *s = (RefSW *) vs;
+    s->q->mapSequence(0, 0, seq, L);
+    s->sw->ssw_init(s->q, s->tiny, s->ctx->blosum2);
+}
+
+// out[0..7] = score, qStart, qEnd, tStart, tEnd, identical, cigarLen(backtrace length), 0 ; returns evalue.
+// swMode: 0 score only, 1 score+cov (start positions), 2 score+cov+seqid (backtrace).
+double ref_sw_align(void *vs, const char *tseq, unsigned int tL, int swMode, double evalThr, int covMode,
+                    float covThr, int *out, char *backtrace, size_t btCap, int isIdentity) {
+    RefSW *s = (RefSW *) vs;
+    s->t->mapSequence(1, 1, tseq, tL);
+    std::string bt;
+    s_align a;
+    if (isIdentity) {
+        a = s->sw->scoreIdentical(s->t->numSequence, s->t->L, s->evaluer, swMode, bt);
+    } else {
+        a = s->sw->ssw_align(s->t->numSequence, s->t->numConsensusSequence, s->t->getAlignmentProfile(), s->t->L, bt,
+                             11, 1, (uint8_t) swMode, evalThr, s->evaluer, covMode, covThr, 0.0f, s->q->L / 2, 1);
+    }
+    out[0] = (int) a.score1;
+    out[1] = a.qStartPos1;
+    out[2] = a.qEndPos1;
+    out[3] = a.dbStartPos1;
+    out[4] = a.dbEndPos1;
+    out[5] = (int) a.identicalAACnt;
+    out[6] = (int) bt.size();
+    out[7] = 0;
+    if (backtrace != NULL && btCap > 0) {
+        size_t n = std::min(btCap - 1, bt.size());
+        memcpy(backtrace, bt.data(), n);
+        backtrace[n] = '\0';
+    }
+    if (isIdentity == 0) delete[] a.cigar;
+    return a.evalue;
+}
+
+double ref_evalue(void *vs, double score, double qLen) {
+    return ((RefSW *) vs)->evaluer->computeEvalue(score, qLen);
+}
+double ref_bitscore(void *vs, double score) {
+    return ((RefSW *) vs)->evaluer->computeBitScore(score);
+}
+
+void ref_sw_destroy(void *vs) {
+    RefSW *s = (RefSW *) vs;
+    delete s->sw;
+    delete s->evaluer;
+    delete s->q;
+    delete s->t;
+    delete[] s->tiny;
+    delete s;
+}
+
+unsigned long ref_l2_cache_size() { return Util::getL2CacheSize(); }
+
+}  // extern "C"
