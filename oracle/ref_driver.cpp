@@ -40,8 +40,9 @@
 
 namespace {
 struct RefCtx {
-    SubstitutionMatrix *blosum2;   // blosum62, bitFactor 2, bias 0   (ungapped + SW)
-    SubstitutionMatrix *seed8;     // VTML80,  bitFactor 8, bias 0    (k-mer seeds)
+    SubstitutionMatrix *blosum2;   // blosum62, bitFactor 2, scoreBias 0     (SW; Alignment.cpp:152)
+    SubstitutionMatrix *ungapped2; // blosum62, bitFactor 2, scoreBias -0.2  (diagonal scoring; Prefiltering.cpp:69,991)
+    SubstitutionMatrix *seed8;     // VTML80,  bitFactor 8, scoreBias -0.2   (k-mer seeds; Prefiltering.cpp:68,991)
     ScoreMatrix three, two;
     bool haveExt;
     int kmerSize;
@@ -77,16 +78,17 @@ void *ref_ctx_create(const char *blosumPath, const char *vtmlPath, int kmerSize)
     Debug::setDebugLevel(1);
     RefCtx *c = new RefCtx();
     c->blosum2 = new SubstitutionMatrix(blosumPath, 2.0f, 0.0f);
-    c->seed8 = new SubstitutionMatrix(vtmlPath, 8.0f, 0.0f);
+    c->ungapped2 = new SubstitutionMatrix(blosumPath, 2.0f, -0.2f);
+    c->seed8 = new SubstitutionMatrix(vtmlPath, 8.0f, -0.2f);
     c->haveExt = false;
     c->kmerSize = kmerSize;
     return c;
 }
 
-// which: 0 = blosum62@2, 1 = VTML80@8.  out: short[21*21], pBack double[21], aa2num uint8[256]
+// which: 0 = blosum62@2 (SW), 1 = VTML80@8 (seed), 2 = blosum62@2 bias -0.2 (ungapped).  out: short[21*21], pBack double[21], aa2num uint8[256]
 int ref_get_matrix(void *vc, int which, short *out, double *pback, unsigned char *aa2num) {
     RefCtx *c = (RefCtx *) vc;
-    SubstitutionMatrix *m = which == 0 ? c->blosum2 : c->seed8;
+    SubstitutionMatrix *m = which == 0 ? c->blosum2 : (which == 1 ? c->seed8 : c->ungapped2);
     for (int i = 0; i < m->alphabetSize; i++)
         for (int j = 0; j < m->alphabetSize; j++) out[i * m->alphabetSize + j] = m->subMatrix[i][j];
     for (int i = 0; i < m->alphabetSize; i++) pback[i] = m->pBack[i];
@@ -97,7 +99,7 @@ int ref_get_matrix(void *vc, int which, short *out, double *pback, unsigned char
 
 void ref_compbias(void *vc, int which, const unsigned char *num, int L, float scale, float *out) {
     RefCtx *c = (RefCtx *) vc;
-    SubstitutionMatrix *m = which == 0 ? c->blosum2 : c->seed8;
+    SubstitutionMatrix *m = which == 0 ? c->blosum2 : (which == 1 ? c->seed8 : c->ungapped2);
     SubstitutionMatrix::calcLocalAaBiasCorrection(m, num, L, out, scale);
 }
 
@@ -238,7 +240,7 @@ void *ref_prefilter_create(void *vi, int kmerThr, size_t maxQueryLen, size_t max
     RefPref *p = new RefPref();
     p->idx = ix;
     size_t maxLen = std::max(ix->maxLen, maxQueryLen) + 2;
-    p->matcher = new QueryMatcher(ix->table, ix->lookup, c->seed8, c->blosum2, (short) kmerThr, c->kmerSize,
+    p->matcher = new QueryMatcher(ix->table, ix->lookup, c->seed8, c->ungapped2, (short) kmerThr, c->kmerSize,
                                   ix->nSeq, (unsigned int) maxLen, maxHits, compBias != 0, 1.0f, true,
                                   (unsigned int) minDiagScore, false, false);
     p->matcher->setSubstitutionMatrix(&c->three, &c->two);

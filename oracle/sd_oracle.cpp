@@ -1,0 +1,700 @@
+// oracle/sd_oracle.cpp -- TEST INFRASTRUCTURE.  Plain scalar C++ restatement of the
+// clustersearch hot path (prefilter -> Smith-Waterman -> clusterhits) of soedinglab/spacedust.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+// the product (spacedust_amd/) never does.
+//
+// Pinning: every function here is checked (tests/test_oracle_vs_ref.py, tests/test_golden.py)
+//   * against the real reference classes compiled into oracle/_ref/libsdref.so, and
+//   * against the reference's own known answers on examples/ (index entries 1 784 989, masked
+//     residues 11 546, prefilter/alignment md5s recorded in SURVEY.md 8(c), run_regression.sh counts).
+// Support code that is not on the hot path (matrix derivation, float composition bias, masking,
+// index construction, E-values) is shared with the product's host library (spacedust_amd/csrc/host)
+// and is pinned by the same comparisons.
+//
+// Citations: M/ = /root/reference/lib/mmseqs/, R/ = /root/reference/.
+#include "sd_host.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sd;
+
+namespace {
+
+struct OracleCtx {
+    SubMat blosum2, ungapped2, seed8;   // SW (bias 0); diagonal scoring and seeds (scoreBias -0.2, Prefiltering.cpp:991)
+    ExtMatrix two, three;
+    bool haveExt;
+    int threads;
+};
+
+struct OracleTarget {
+    OracleCtx *ctx;
+    TargetIndex idx;
+    uint32_t nSeq;
+};
+
+// ------------------------------------------------------------------------------------------
+// ungapped diagonal score (M/src/prefiltering/UngappedAlignment.cpp:30-43,416-430)
+// prof: int8 [L][21]
+// ------------------------------------------------------------------------------------------
+int diagScore(const int8_t *prof, int qL, const uint8_t *t, int tL, uint16_t diag16) {
+    const int d = (int16_t) diag16;
+    const unsigned short minDist = (unsigned short) std::min((unsigned short) (0 - diag16), (unsigned short) (diag16 - 0));
+    int maxv = 0, score = 0;
+    if (d >= 0 && (int) minDist < qL) {
+        int n = std::min(tL, qL - (int) minDist);
+        const int8_t *p = prof + (size_t) minDist * ALPH;
+        for (int pos = 0; pos < n; pos++) {
+            score += p[(size_t) pos * ALPH + t[pos]];
+            score = score < 0 ? 0 : score;
+            maxv = score > maxv ? score : maxv;
+        }
+    } else if (d < 0 && (int) minDist < tL) {
+        int n = std::min(tL - (int) minDist, qL);
+        const uint8_t *tt = t + minDist;
+        for (int pos = 0; pos < n; pos++) {
+            score += prof[(size_t) pos * ALPH + tt[pos]];
+            score = score < 0 ? 0 : score;
+            maxv = score > maxv ? score : maxv;
+        }
+    }
+    return maxv;
+}
+
+struct Cand {
+    uint32_t id;
+    uint16_t diag;
+    uint8_t count;
+};
+
+}  // namespace
+
+extern "C" {
+
+void *or_ctx_create(int threads) {
+    OracleCtx *c = new OracleCtx();
+    initSubMat(c->blosum2, MAT_BLOSUM62, 2.0f, 0.0f);
+    initSubMat(c->ungapped2, MAT_BLOSUM62, 2.0f, -0.2f);
+    initSubMat(c->seed8, MAT_VTML80, 8.0f, -0.2f);
+    c->haveExt = false;
+    c->threads = threads;
+    return c;
+}
+
+static void ensureExt(OracleCtx *c) {
+    if (c->haveExt) return;
+    buildExtMatrix(c->seed8, 2, c->two, c->threads);
+    buildExtMatrix(c->seed8, 3, c->three, c->threads);
+    c->haveExt = true;
+}
+
+int or_get_matrix(void *vc, int which, short *out, double *pback, unsigned char *aa2num) {
+    OracleCtx *c = (OracleCtx *) vc;
+    const SubMat &m = which == 0 ? c->blosum2 : (which == 1 ? c->seed8 : c->ungapped2);
+    for (int i = 0; i < ALPH; i++)
+        for (int j = 0; j < ALPH; j++) out[i * ALPH + j] = m.sub[i][j];
+    for (int i = 0; i < ALPH; i++) pback[i] = m.pBack[i];
+    memcpy(aa2num, m.aa2num, 256);
+    return ALPH;
+}
+
+void or_map_sequence(void *vc, const char *seq, size_t len, unsigned char *out) {
+    mapSequence(((OracleCtx *) vc)->seed8, seq, len, out);
+}
+
+void or_compbias(void *vc, int which, const unsigned char *num, int L, float scale, float *out) {
+    OracleCtx *c = (OracleCtx *) vc;
+    calcLocalAaBiasCorrection(which == 0 ? c->blosum2 : (which == 1 ? c->seed8 : c->ungapped2), num, L, out, scale);
+}
+
+size_t or_ext_matrix(void *vc, int which, short *score, unsigned short *index) {
+    OracleCtx *c = (OracleCtx *) vc;
+    ensureExt(c);
+    ExtMatrix &m = which == 3 ? c->three : c->two;
+    if (score != NULL) {
+        memcpy(score, m.score.data(), m.score.size() * sizeof(short));
+        memcpy(index, m.index.data(), m.index.size() * sizeof(unsigned short));
+    }
+    return m.size;
+}
+
+size_t or_kmer_list(void *vc, int k, const unsigned char *window, int thr, unsigned int *out, size_t cap) {
+    OracleCtx *c = (OracleCtx *) vc;
+    ensureExt(c);
+    std::vector<uint32_t> v;
+    generateKmerList(c->three, c->two, k, window, thr, v);
+    size_t n = std::min(cap, v.size());
+    memcpy(out, v.data(), n * sizeof(uint32_t));
+    return v.size();
+}
+
+int or_mask(void *vc, unsigned char *num, int L, double maskProb) {
+    OracleCtx *c = (OracleCtx *) vc;
+    MaskCtx m;
+    initMaskCtx(c->seed8, m);
+    return tantanMask(m, num, L, maskProb);
+}
+
+void *or_target_create(void *vc, const unsigned char *seqs, const uint64_t *offsets, uint32_t nSeq, int k,
+                       int kmerThr, int mask, double maskProb) {
+    OracleCtx *c = (OracleCtx *) vc;
+    OracleTarget *t = new OracleTarget();
+    t->ctx = c;
+    t->nSeq = nSeq;
+    buildTargetIndex(c->seed8, seqs, offsets, nSeq, k, kmerThr, mask != 0, maskProb, c->threads, t->idx);
+    return t;
+}
+
+void or_target_destroy(void *vt) { delete (OracleTarget *) vt; }
+
+uint64_t or_target_info(void *vt, uint64_t *tableSize, uint64_t *masked) {
+    OracleTarget *t = (OracleTarget *) vt;
+    *tableSize = t->idx.tableSize;
+    *masked = t->idx.maskedResidues;
+    return t->idx.entrySeq.size();
+}
+
+void or_target_dump(void *vt, uint32_t *offsets, uint32_t *entrySeq, uint16_t *entryPos, unsigned char *masked) {
+    OracleTarget *t = (OracleTarget *) vt;
+    memcpy(offsets, t->idx.offsets.data(), t->idx.offsets.size() * sizeof(uint32_t));
+    memcpy(entrySeq, t->idx.entrySeq.data(), t->idx.entrySeq.size() * sizeof(uint32_t));
+    memcpy(entryPos, t->idx.entryPos.data(), t->idx.entryPos.size() * sizeof(uint16_t));
+    if (masked != NULL) memcpy(masked, t->idx.masked.data(), t->idx.masked.size());
+}
+
+// ------------------------------------------------------------------------------------------
+// Prefilter, one query (QueryMatcher::matchQuery, M/src/prefiltering/QueryMatcher.cpp:85-211;
+// step numbers refer to SURVEY.md Appendix A.1).
+// Returns the number of result hits; outputs are in the reference's final order.
+// stats: [0] #similar k-mers, [1] #index entries matched, [2] #candidates scored, [3] sum of diagonal lengths
+// ------------------------------------------------------------------------------------------
+int64_t or_prefilter_query(void *vt, const unsigned char *q, int qL, uint32_t identityId, int kmerThr,
+                           uint32_t maxHits, int minDiagScore, uint32_t binSize, int compBias,
+                           uint32_t *outId, int32_t *outScore, uint16_t *outDiag, uint64_t *stats) {
+    OracleTarget *T = (OracleTarget *) vt;
+    OracleCtx *c = T->ctx;
+    ensureExt(c);
+    const TargetIndex &ix = T->idx;
+    const int k = ix.k, span = ix.span;
+    const uint32_t dbSize = T->nSeq;
+    maxHits = std::min(maxHits, dbSize);
+
+    // steps 1-2: composition bias (seed matrix) and diagonal profile
+    std::vector<float> cb(qL > 0 ? qL : 1, 0.0f);
+    if (compBias) calcLocalAaBiasCorrection(c->seed8, q, qL, cb.data(), 1.0f);
+    std::vector<int8_t> prof((size_t) (qL > 0 ? qL : 1) * ALPH);
+    for (int pos = 0; pos < qL; pos++) {
+        float a = cb[pos];
+        float r = (float) ((a < 0.0) ? (double) (a / 4) - 0.5 : (double) (a / 4) + 0.5);
+        int8_t corr = (int8_t) (char) r;
+        for (int aa = 0; aa < ALPH; aa++)
+            prof[(size_t) pos * ALPH + aa] = (int8_t) (c->ungapped2.sub[q[pos]][aa] + corr);
+    }
+
+    // steps 3-5: similar k-mers per position, index lists appended in stream order
+    std::vector<uint32_t> hitSeq;
+    std::vector<uint16_t> hitDiag;
+    std::vector<uint32_t> kmers;
+    uint64_t nKmers = 0;
+    uint8_t window[8];
+    for (int i = 0; i + span <= qL; i++) {
+        bool hasX = false;
+        float bias = 0;
+        for (int p = 0; p < k; p++) {
+            window[p] = q[i + ix.seedPos[p]];
+            hasX |= (window[p] == X_CODE);
+            bias += cb[i + ix.seedPos[p]];
+        }
+        if (hasX) continue;
+        short b = (short) ((bias < 0.0) ? (double) bias - 0.5 : (double) bias + 0.5);
+        short thr = (short) std::max(kmerThr - b, 0);
+        generateKmerList(c->three, c->two, k, window, thr, kmers);
+        nKmers += kmers.size();
+        for (size_t z = 0; z < kmers.size(); z++) {
+            uint32_t a = ix.offsets[kmers[z]], e = ix.offsets[kmers[z] + 1];
+            for (uint32_t x = a; x < e; x++) {
+                hitSeq.push_back(ix.entrySeq[x]);
+                hitDiag.push_back((uint16_t) (i - ix.entryPos[x]));
+            }
+        }
+    }
+    const uint64_t maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;
+    if (hitSeq.size() >= maxDbMatches) return -2;   // overflow path (QueryMatcher.cpp:281-316) not restated
+
+    // step 6: double-diagonal detection, bins ascending, stream order inside a bin
+    // (CacheFriendlyOperations.cpp:38-48,185-272,337-347)
+    const uint32_t mask = binSize - 1;
+    std::vector<std::vector<uint32_t> > binIdx(binSize);
+    for (uint32_t h = 0; h < hitSeq.size(); h++) binIdx[hitSeq[h] & mask].push_back(h);
+    std::vector<uint8_t> prev8(dbSize, 0), mark(dbSize, 0);
+    std::vector<Cand> cands;
+    std::vector<Cand> tmp;
+    for (uint32_t b = 0; b < binSize; b++) {
+        tmp.clear();
+        const std::vector<uint32_t> &v = binIdx[b];
+        for (size_t n = 0; n < v.size(); n++) {
+            const uint32_t id = hitSeq[v[n]];
+            const uint8_t cur = (uint8_t) hitDiag[v[n]];
+            if (cur == prev8[id]) {
+                Cand cd;
+                cd.id = id;
+                cd.diag = hitDiag[v[n]];
+                cd.count = 0;
+                tmp.push_back(cd);
+            }
+            prev8[id] = cur;
+        }
+        for (size_t n = tmp.size(); n-- > 0;) mark[tmp[n].id] = (uint8_t) ((uint8_t) tmp[n].diag + 1);
+        for (size_t n = 0; n < tmp.size(); n++) {
+            if (mark[tmp[n].id] != (uint8_t) tmp[n].diag) cands.push_back(tmp[n]);
+            mark[tmp[n].id] = (uint8_t) tmp[n].diag;
+        }
+    }
+    const uint64_t foundDiagonalsSize = std::max<uint64_t>(1000000, dbSize);
+    if (cands.size() >= foundDiagonalsSize / 2) return -3;   // unsorted branch not restated
+
+    // step 7: ungapped diagonal scores on the masked target sequences
+    uint64_t diagLenSum = 0;
+    for (size_t n = 0; n < cands.size(); n++) {
+        const uint8_t *t = ix.masked.data() + ix.seqOffsets[cands[n].id];
+        int tL = (int) (ix.seqOffsets[cands[n].id + 1] - ix.seqOffsets[cands[n].id]);
+        int s = diagScore(prof.data(), qL, t, tL, cands[n].diag);
+        cands[n].count = (uint8_t) std::min(255, s);
+        int d = (int16_t) cands[n].diag;
+        diagLenSum += d >= 0 ? std::max(0, std::min(tL, qL - d)) : std::max(0, std::min(tL + d, qL));
+    }
+
+    // step 8: keep the per-target maximum (CacheFriendlyOperations.cpp:350-380); the list is already
+    // bin-major and re-binning is stable.
+    std::vector<uint8_t> best(dbSize, 0);
+    std::vector<Cand> kept;
+    {
+        size_t start = 0;
+        while (start < cands.size()) {
+            const uint32_t b = cands[start].id & mask;
+            size_t end = start;
+            while (end < cands.size() && (cands[end].id & mask) == b) end++;
+            for (size_t n = start; n < end; n++) best[cands[n].id] = std::max(best[cands[n].id], cands[n].count);
+            for (size_t n = start; n < end; n++) {
+                bool found = best[cands[n].id] == cands[n].count;
+                if (found) {
+                    kept.push_back(cands[n]);
+                    best[cands[n].id] = 0;
+                }
+            }
+            start = end;
+        }
+    }
+
+    // step 9: score histogram, cut, stable descending counting sort (QueryMatcher.h:206-216, .cpp:498-523)
+    unsigned int scoreSizes[256];
+    memset(scoreSizes, 0, sizeof(scoreSizes));
+    for (size_t n = 0; n < kept.size(); n++) scoreSizes[kept[n].count]++;
+    size_t foundHits = 0;
+    unsigned int diagonalThr = 0;
+    for (diagonalThr = 255; diagonalThr > 0; diagonalThr--) {
+        foundHits += scoreSizes[diagonalThr];
+        if (foundHits >= maxHits) break;
+    }
+    diagonalThr = std::max((unsigned int) minDiagScore, diagonalThr);
+    std::vector<Cand> sorted;
+    auto radix = [&](const std::vector<Cand> &in, unsigned int thr, std::vector<Cand> &out) {
+        out.clear();
+        for (int s = 255; s >= (int) thr; s--)
+            for (size_t n = 0; n < in.size(); n++)
+                if (in[n].count == s) out.push_back(in[n]);
+    };
+    radix(kept, diagonalThr, sorted);
+    const unsigned int maxDiagonalScoreThr = 255;   // UCHAR_MAX - getQueryBias() (= 0)
+    int rescale = 0;
+    unsigned short resThr = (unsigned short) diagonalThr;
+    if (diagonalThr >= maxDiagonalScoreThr) {
+        // rescoreHits (QueryMatcher.cpp:525-544)
+        int maxSelf = diagScore(prof.data(), qL, q, qL, 0);
+        maxSelf = maxSelf - (int) maxDiagonalScoreThr;
+        maxSelf = std::max(1, maxSelf);
+        maxSelf = std::min(maxSelf, (int) USHRT_MAX);
+        float fltMaxSelf = (float) maxSelf;
+        std::vector<Cand> resc;
+        for (size_t n = 0; n < sorted.size() && sorted[n].count >= maxDiagonalScoreThr; n++) {
+            const uint8_t *t = ix.masked.data() + ix.seqOffsets[sorted[n].id];
+            int tL = (int) (ix.seqOffsets[sorted[n].id + 1] - ix.seqOffsets[sorted[n].id]);
+            unsigned int ns = (unsigned int) diagScore(prof.data(), qL, t, tL, sorted[n].diag);
+            ns -= maxDiagonalScoreThr;
+            float sc = (float) std::min(ns, (unsigned int) USHRT_MAX);
+            Cand cd = sorted[n];
+            cd.count = (unsigned char) ((sc / fltMaxSelf) * (float) UCHAR_MAX + 0.5);
+            resc.push_back(cd);
+        }
+        radix(resc, 0, sorted);
+        rescale = maxSelf;
+        resThr = 0;
+    }
+
+    // step 10: result list (QueryMatcher.cpp:364-420) and final order (QueryMatcher.h:38-48)
+    struct Hit {
+        uint32_t id;
+        int score;
+        uint16_t diag;
+    };
+    std::vector<Hit> res;
+    if (identityId != UINT_MAX) {
+        Hit h;
+        h.id = identityId;
+        h.score = USHRT_MAX;
+        h.diag = 0;
+        res.push_back(h);
+    }
+    for (size_t n = 0; n < sorted.size() && res.size() < maxHits; n++) {
+        if (sorted[n].count >= resThr && sorted[n].id != identityId) {
+            Hit h;
+            h.id = sorted[n].id;
+            h.score = sorted[n].count;
+            h.diag = sorted[n].diag;
+            if (rescale != 0) {
+                h.score = (int) (255 + ((unsigned int) sorted[n].count * (unsigned int) rescale / 255));
+            } else if (sorted[n].count >= 255) {
+                const uint8_t *t = ix.masked.data() + ix.seqOffsets[h.id];
+                int tL = (int) (ix.seqOffsets[h.id + 1] - ix.seqOffsets[h.id]);
+                h.score = diagScore(prof.data(), qL, t, tL, h.diag);
+            }
+            res.push_back(h);
+        }
+    }
+    auto cmp = [](const Hit &a, const Hit &b) {
+        if (abs(a.score) > abs(b.score)) return true;
+        if (abs(b.score) > abs(a.score)) return false;
+        return a.id < b.id;
+    };
+    if (res.size() > 1) {
+        if (identityId != UINT_MAX) std::sort(res.begin() + 1, res.end(), cmp);
+        else std::sort(res.begin(), res.end(), cmp);
+    }
+    for (size_t n = 0; n < res.size(); n++) {
+        outId[n] = res[n].id;
+        outScore[n] = res[n].score;
+        outDiag[n] = res[n].diag;
+    }
+    if (stats != NULL) {
+        stats[0] = nKmers;
+        stats[1] = hitSeq.size();
+        stats[2] = cands.size();
+        stats[3] = diagLenSum;
+    }
+    return (int64_t) res.size();
+}
+
+// single diagonal score, for kernel unit tests
+int or_diag_score(const int8_t *prof, int qL, const unsigned char *t, int tL, uint16_t diag) {
+    return diagScore(prof, qL, t, tL, diag);
+}
+
+// ------------------------------------------------------------------------------------------
+// Smith-Waterman score pass (sw_sse2_byte / sw_sse2_word, M/src/alignment/StripedSmithWaterman.cpp:639-940,
+// 943-1214) in scalar form.  `lanes` = 32 reproduces the AVX2 byte kernel, 16 the word kernel:
+// the striped kernels update E from the H that only contains the F of the *same SIMD lane segment*
+// (segLen = ceil(n/lanes) consecutive query rows), then complete H with the lazy-F loop
+// ("disallow adjacent insertion and then deletion", :819,1119).  Derivation in DESIGN.md.
+//   prof: int16 [21][n] linear profile (mat[t][q_j] + compositionBias[j]) of the n query rows used
+//   dir 0: target columns 0..tL-1 ;  dir 1: tL-1 down to 0 (reverse pass)
+//   terminate: stop after the first column whose maximum equals it (0 = never)
+//   overflowAt: byte-mode abort when a new maximum m satisfies m + bias >= 255 (0 = off)
+// out[0] score (255 on byte overflow) out[1] end_db out[2] end_query
+// ------------------------------------------------------------------------------------------
+static void swPass(const int16_t *prof, int n, const uint8_t *t, int tL, int lanes, int dir, int go, int ge,
+                   int terminate, int biasForOverflow, bool byteMode, int *out) {
+    const int segLen = (n + lanes - 1) / lanes;
+    std::vector<int> H(n, 0), Hn(n, 0), E(n, 0), Hmax(n, 0);
+    int maxv = 0;
+    int end_db = byteMode ? -1 : 0;
+    bool overflow = false;
+    int begin = 0, end = tL, step = 1;
+    if (dir == 1) {
+        begin = tL - 1;
+        end = -1;
+        step = -1;
+    }
+    for (int i = begin; i != end; i += step) {
+        const int16_t *p = prof + (size_t) t[i] * n;
+        int Fl = 0, Ff = 0, colMax = 0;
+        for (int q = 0; q < n; q++) {
+            if (q % segLen == 0) Fl = 0;
+            int diag = q > 0 ? H[q - 1] : 0;
+            int h = diag + p[q];
+            if (h < 0) h = 0;
+            int hpre = std::max(std::max(h, E[q]), Fl);
+            int g = std::max(hpre, Ff);
+            Hn[q] = g;
+            colMax = std::max(colMax, g);
+            int open = std::max(hpre - go, 0);
+            E[q] = std::max(std::max(E[q] - ge, 0), open);
+            Fl = std::max(std::max(Fl - ge, 0), open);
+            Ff = std::max(std::max(Ff - ge, 0), std::max(g - go, 0));
+        }
+        H.swap(Hn);
+        if (colMax > maxv) {
+            maxv = colMax;
+            if (byteMode && maxv + biasForOverflow >= 255) {
+                overflow = true;
+                break;
+            }
+            end_db = i;
+            Hmax = H;
+        }
+        if (terminate != 0 && colMax == terminate) break;
+    }
+    int end_query = n - 1;
+    for (int q = 0; q < n; q++) {
+        if (Hmax[q] == maxv) {
+            end_query = std::min(end_query, q);
+            break;
+        }
+    }
+    out[0] = overflow ? 255 : maxv;
+    out[1] = end_db;
+    out[2] = end_query;
+}
+
+int or_sw_pass(const int16_t *prof, int n, const unsigned char *t, int tL, int lanes, int dir, int go, int ge,
+               int terminate, int bias, int byteMode, int *out) {
+    swPass(prof, n, t, tL, lanes, dir, go, ge, terminate, bias, byteMode != 0, out);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// banded traceback (SmithWaterman::banded_sw, StripedSmithWaterman.cpp:1348-1600) on the sub-rectangle
+// q[0..qLen) x t[0..tLen); sc(i,j) = mat[q_i][t_j] + cb[i].  Emits the expanded backtrace string
+// (computerBacktrace, :548-581).  Returns its length, or -1 on a traceback error.
+// The band arrays and the direction matrix are indexed exactly as in the reference (set_u/set_d),
+// including what stale band-edge cells hold.
+// ------------------------------------------------------------------------------------------
+static int bandedTraceback(const SubMat &m, const uint8_t *q, const int8_t *cb, int qLen, const uint8_t *t, int tLen,
+                           int score, int go, int ge, std::string &bt) {
+    int band = abs(tLen - qLen) + 1;
+    std::vector<int> h_b, e_b, h_c;
+    std::vector<int8_t> direction;
+    int64_t width, width_d;
+    int maxv = 0;
+    do {
+        width = (int64_t) band * 2 + 3;
+        width_d = (int64_t) band * 2 + 1;
+        if ((int64_t) h_b.size() < width + 1) {
+            h_b.resize(width + 1, 0);
+            e_b.resize(width + 1, 0);
+            h_c.resize(width + 1, 0);
+        }
+        if ((int64_t) direction.size() < width_d * qLen * 3 + 1) direction.resize(width_d * qLen * 3 + 1, 0);
+        for (int64_t j = 1; j < width - 1; j++) h_b[j] = 0;
+        for (int i = 0; i < qLen; i++) {
+            int beg = 0, end = tLen - 1, u = 0;
+            int j = i - band;
+            beg = beg > j ? beg : j;
+            j = i + band;
+            end = end < j ? end : j;
+            int64_t edge = end + 1 < width - 1 ? end + 1 : width - 1;
+            int f = h_b[0] = e_b[0] = h_b[edge] = e_b[edge] = h_c[0] = 0;
+            int8_t *dl = direction.data() + width_d * i * 3;
+            for (j = beg; j <= end; j++) {
+                auto setU = [&](int ii, int jj) { int x = ii - band; x = x > 0 ? x : 0; return jj - x + 1; };
+                auto setD = [&](int ii, int jj, int p) { int x = ii - band; x = x > 0 ? x : 0; x = jj - x; return x * 3 + p; };
+                u = setU(i, j);
+                int e = setU(i - 1, j);
+                int b = setU(i, j - 1);
+                int d = setU(i - 1, j - 1);
+                int de = setD(i, j, 0), df = setD(i, j, 1), dh = setD(i, j, 2);
+                int temp1 = i == 0 ? -go : h_b[e] - go;
+                int temp2 = i == 0 ? -ge : e_b[e] - ge;
+                e_b[u] = temp1 > temp2 ? temp1 : temp2;
+                dl[de] = temp1 > temp2 ? 3 : 2;
+                temp1 = h_c[b] - go;
+                temp2 = f - ge;
+                f = temp1 > temp2 ? temp1 : temp2;
+                dl[df] = temp1 > temp2 ? 5 : 4;
+                int f1 = f > 0 ? f : 0;
+                int e1 = e_b[u] > 0 ? e_b[u] : 0;
+                temp1 = e1 > f1 ? e1 : f1;
+                temp2 = h_b[d] + m.sub[q[i]][t[j]] + cb[i];
+                h_c[u] = temp1 > temp2 ? temp1 : temp2;
+                if (h_c[u] > maxv) maxv = h_c[u];
+                if (temp1 <= temp2) dl[dh] = 1;
+                else dl[dh] = e1 > f1 ? dl[de] : dl[df];
+            }
+            for (j = 1; j <= u; j++) h_b[j] = h_c[j];
+        }
+        band *= 2;
+    } while (maxv < score);
+    band /= 2;
+
+    // traceback
+    int i = qLen - 1, j = tLen - 1;
+    int state = 2;
+    std::string rev;
+    char op = 'M';
+    const int8_t *dl = direction.data() + width_d * (qLen - 1) * 3;
+    while (i > 0 || j > 0) {
+        int x = i - band;
+        x = x > 0 ? x : 0;
+        x = j - x;
+        int idx = x * 3 + state;
+        switch (dl[idx]) {
+            case 1: --i; --j; state = 2; dl -= width_d * 3; op = 'M'; break;
+            case 2: --i; state = 0; dl -= width_d * 3; op = 'I'; break;
+            case 3: --i; state = 2; dl -= width_d * 3; op = 'I'; break;
+            case 4: --j; state = 1; op = 'D'; break;
+            case 5: --j; state = 2; op = 'D'; break;
+            default: return -1;
+        }
+        rev.push_back(op);
+    }
+    // the reference closes the CIGAR with the first cell: run of `op` is extended by one if it is 'M',
+    // otherwise a single 'M' is added (:1559-1576)
+    rev.push_back('M');
+    bt.assign(rev.rbegin(), rev.rend());
+    return (int) bt.size();
+}
+
+int or_banded_traceback(void *vc, const unsigned char *q, const int8_t *cb, int qLen, const unsigned char *t, int tLen,
+                        int score, int go, int ge, char *out, int cap) {
+    std::string bt;
+    int n = bandedTraceback(((OracleCtx *) vc)->blosum2, q, cb, qLen, t, tLen, score, go, ge, bt);
+    if (n < 0) return n;
+    int c = std::min(cap - 1, n);
+    memcpy(out, bt.data(), c);
+    out[c] = 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// Full pair alignment (ssw_align_private<SEQ_SEQ>, :310-545 + Matcher::getSWResult, Matcher.cpp:60-142)
+// out[0] score [1] qStart [2] qEnd [3] tStart [4] tEnd [5] identical [6] backtrace length [7] word-mode flag
+// returns evalue.  swMode as in the reference (0 score, 1 +coverage/start, 2 +backtrace).
+// ------------------------------------------------------------------------------------------
+double or_sw_align(void *vc, const unsigned char *q, int qL, const unsigned char *t, int tL, uint64_t dbResidues,
+                   int swMode, double evalThr, int covMode, float covThr, int compBias, int isIdentity, int *out,
+                   char *backtrace, int btCap) {
+    OracleCtx *c = (OracleCtx *) vc;
+    const SubMat &m = c->blosum2;
+    const int go = 11, ge = 1;
+    Evaluer ev;
+    initEvaluer(ev, dbResidues);
+    std::vector<int8_t> cb8(qL > 0 ? qL : 1, 0);
+    if (compBias) swCompBias8(m, q, qL, cb8.data());
+    int minCb = 0;
+    for (int i = 0; i < qL; i++) minCb = std::min(minCb, (int) cb8[i]);
+    int matMin = 0;
+    for (int i = 0; i < ALPH; i++)
+        for (int j = 0; j < ALPH; j++) matMin = std::min(matMin, (int) m.sub[i][j]);
+    const int bias = abs(matMin) + abs(minCb);
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    out[1] = -1;
+    out[3] = -1;
+    std::string bt;
+    if (backtrace != NULL && btCap > 0) backtrace[0] = 0;
+
+    if (isIdentity) {
+        // scoreIdentical (:1675-1710)
+        short score = 0;
+        for (int pos = 0; pos < tL; pos++) score += (short) (m.sub[t[pos]][q[pos]] + cb8[pos]);
+        out[0] = (uint32_t) (int) score;
+        out[1] = swMode == 0 ? -1 : 0;
+        out[3] = swMode == 0 ? -1 : 0;
+        out[2] = tL - 1;
+        out[4] = tL - 1;
+        out[5] = tL;
+        out[6] = tL;
+        if (backtrace != NULL) {
+            int cc = std::min(btCap - 1, tL);
+            memset(backtrace, 'M', cc);
+            backtrace[cc] = 0;
+        }
+        return computeEvalue(ev, (double) (uint32_t) (int) score, qL);
+    }
+
+    // forward profile
+    std::vector<int16_t> prof((size_t) ALPH * qL);
+    for (int a = 0; a < ALPH; a++)
+        for (int j = 0; j < qL; j++) prof[(size_t) a * qL + j] = (int16_t) (m.sub[a][q[j]] + cb8[j]);
+    int r[3];
+    int word = 0;
+    swPass(prof.data(), qL, t, tL, 32, 0, go, ge, 255, bias, true, r);
+    if (r[0] == 255) {
+        swPass(prof.data(), qL, t, tL, 16, 0, go, ge, USHRT_MAX, 0, false, r);
+        word = 1;
+    }
+    out[7] = word;
+    const int score1 = r[0], dbEnd = r[1], qEnd = r[2];
+    out[0] = score1;
+    out[4] = dbEnd;
+    out[2] = qEnd;
+    if (dbEnd == -1) return 0.0;
+    double evalue = computeEvalue(ev, score1, qL);
+    bool hasLowerEvalue = evalue > evalThr;
+    float qCov = computeCov(0, qEnd, qL), tCov = computeCov(0, dbEnd, tL);
+    bool hasLowerCoverage = !hasCoverage(covThr, covMode, qCov, tCov);
+    if (swMode == 0 || hasLowerEvalue || hasLowerCoverage) return evalue;
+
+    // reverse pass on query[0..qEnd] reversed x target[0..dbEnd] scanned downwards (:400-463)
+    const int n = qEnd + 1;
+    std::vector<int16_t> rprof((size_t) ALPH * n);
+    for (int a = 0; a < ALPH; a++)
+        for (int j = 0; j < n; j++) rprof[(size_t) a * n + j] = (int16_t) (m.sub[a][q[qEnd - j]] + cb8[qEnd - j]);
+    int rr[3];
+    if (word == 0) swPass(rprof.data(), n, t, dbEnd + 1, 32, 1, go, ge, score1, bias, true, rr);
+    else swPass(rprof.data(), n, t, dbEnd + 1, 16, 1, go, ge, score1, 0, false, rr);
+    if (rr[0] != score1) {
+        out[7] |= 2;   // "Score of forward/backward SW differ" -- fatal in the reference (:466-473)
+        return evalue;
+    }
+    const int dbStart = rr[1], qStart = qEnd - rr[2];
+    out[3] = dbStart;
+    out[1] = qStart;
+    qCov = computeCov(qStart, qEnd, qL);
+    tCov = computeCov(dbStart, dbEnd, tL);
+    hasLowerCoverage = !hasCoverage(covThr, covMode, qCov, tCov);
+    if (swMode == 1 || hasLowerCoverage) return evalue;
+
+    int len = bandedTraceback(m, q + qStart, cb8.data() + qStart, qEnd - qStart + 1, t + dbStart,
+                              dbEnd - dbStart + 1, score1, go, ge, bt);
+    if (len < 0) {
+        out[7] |= 4;
+        return evalue;
+    }
+    int ids = 0, qp = qStart, tp = dbStart;
+    for (size_t x = 0; x < bt.size(); x++) {
+        if (bt[x] == 'M') {
+            ids += (t[tp] == q[qp]);
+            qp++;
+            tp++;
+        } else if (bt[x] == 'I') qp++;
+        else tp++;
+    }
+    out[5] = ids;
+    out[6] = (int) bt.size();
+    if (backtrace != NULL && btCap > 0) {
+        int cc = std::min(btCap - 1, (int) bt.size());
+        memcpy(backtrace, bt.data(), cc);
+        backtrace[cc] = 0;
+    }
+    return evalue;
+}
+
+double or_evalue(uint64_t dbResidues, double score, double qLen) {
+    Evaluer ev;
+    initEvaluer(ev, dbResidues);
+    return computeEvalue(ev, score, qLen);
+}
+double or_bitscore(double score) {
+    Evaluer ev;
+    initEvaluer(ev, 1);
+    return computeBitScore(ev, score);
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+// E-value / bit score for blosum62 with gap open 11, extend 1 -- the preset Gumbel parameters
+// of M/src/alignment/EvalueComputation.h:64-69 evaluated with the finite-size-corrected "area"
+// of M/lib/alp/sls_pvalues.cpp:366-520 (get_appr_tail_prob_with_cov_without_errors with
+// blast_=false, compute_only_area_=true) and evaluePerArea = K exp(-lambda s)
+// (M/lib/alp/sls_alignment_evaluer.hpp:154-157).  Plus the small text helpers of Matcher/Util.
+#include "sd_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace sd {
+
+void initEvaluer(Evaluer &e, uint64_t dbResidues) {
+    // {"blosum62.out", 11, 1, true, {lambda, K, a1, b1, a2, b2, alpha1, beta1, alpha2, beta2, sigma, tau}}
+    e.lambda = 0.27359865037097330642;
+    e.K = 0.044620920658722244834;
+    const double a1 = 1.5938724404943873658, b1 = -19.959867650284412122;
+    const double a2 = 1.5938724404943873658, b2 = -19.959867650284412122;
+    const double alpha1 = 30.455610143099914211, beta1 = -622.28684628915891608;
+    const double alpha2 = 30.455610143099914211, beta2 = -622.28684628915891608;
+    e.sigma = 29.602444874818868215;
+    e.tau = -601.81087985041381216;
+    // sls_alignment_evaluer.cpp:679-721: a_I<-a2, a_J<-a1, alpha_I<-alpha2, alpha_J<-alpha1, b/beta likewise
+    e.aI = a2; e.bI = b2; e.alphaI = alpha2; e.betaI = beta2;
+    e.aJ = a1; e.bJ = b1; e.alphaJ = alpha1; e.betaJ = beta1;
+    // sls_pvalues.cpp:343-361 (nat_cut_off_in_max = 2.0)
+    e.viThr = std::max(2.0 * e.alphaI / e.lambda, 0.0);
+    e.vjThr = std::max(2.0 * e.alphaJ / e.lambda, 0.0);
+    e.cThr = std::max(2.0 * e.sigma / e.lambda, 0.0);
+    e.logK = std::log(e.K);
+    e.dbResidues = (double) dbResidues;
+}
+
+static inline double normalProbability(double x) { return 0.5 * erfc(-sqrt(0.5) * x); }   // sls_basic.hpp:195-198
+
+static double area(const Evaluer &e, double y, double seqlen1, double seqlen2) {
+    // AlignmentEvaluer::area(score, seqlen1, seqlen2) passes m_ = seqlen2_, n_ = seqlen1_
+    const double m_ = seqlen2, n_ = seqlen1;
+    static const double pi = 3.1415926535897932384626433832795;
+    static const double const_val = 1 / sqrt(2.0 * pi);
+    double m_li_y = m_ - (e.aI * y + e.bI);
+    double vi_y = std::max(e.viThr, e.alphaI * y + e.betaI);
+    double sqrt_vi_y = sqrt(vi_y);
+    double m_F = (sqrt_vi_y == 0.0) ? 1e100 : m_li_y / sqrt_vi_y;
+    double P_m_F = normalProbability(m_F);
+    double E_m_F = -const_val * exp(-0.5 * m_F * m_F);
+    double p1 = m_li_y * P_m_F - sqrt_vi_y * E_m_F;
+
+    double n_lj_y = n_ - (e.aJ * y + e.bJ);
+    double vj_y = std::max(e.vjThr, e.alphaJ * y + e.betaJ);
+    double sqrt_vj_y = sqrt(vj_y);
+    double n_F = (sqrt_vj_y == 0.0) ? 1e100 : n_lj_y / sqrt_vj_y;
+    double P_n_F = normalProbability(n_F);
+    double E_n_F = -const_val * exp(-0.5 * n_F * n_F);
+    double p2 = n_lj_y * P_n_F - sqrt_vj_y * E_n_F;
+
+    double c_y = std::max(e.cThr, e.sigma * y + e.tau);
+    return p1 * p2 + c_y * (P_m_F * P_n_F);
+}
+
+double computeEvalue(const Evaluer &e, double score, double qLen) {
+    const double epa = e.K * exp(-e.lambda * score);
+    const double a = area(e, score, qLen, e.dbResidues);
+    return epa * a;
+}
+
+double computeBitScore(const Evaluer &e, double score) { return (e.lambda * score - e.logK) / log(2.0); }
+
+bool canBeCovered(float covThr, int covMode, float queryLength, float targetLength) {
+    switch (covMode) {
+        case 0: return ((queryLength / targetLength >= covThr) && (targetLength / queryLength >= covThr));
+        case 2: return ((targetLength / queryLength) >= covThr);
+        case 1: return ((queryLength / targetLength) >= covThr);
+        case 3: return ((targetLength / queryLength) >= covThr) && (targetLength / queryLength) <= 1.0;
+        case 4: return ((queryLength / targetLength) >= covThr) && (queryLength / targetLength) <= 1.0;
+        case 5: return (std::min(targetLength, queryLength) / std::max(targetLength, queryLength)) >= covThr;
+        default: return true;
+    }
+}
+
+bool hasCoverage(float covThr, int covMode, float queryCov, float targetCov) {
+    switch (covMode) {
+        case 0: return ((queryCov >= covThr) && (targetCov >= covThr));
+        case 2: return (queryCov >= covThr);
+        case 1: return (targetCov >= covThr);
+        default: return true;
+    }
+}
+
+float computeCov(unsigned startPos, unsigned endPos, unsigned len) {
+    return (std::min(len, std::max(startPos, endPos)) - std::min(startPos, endPos) + 1) / (float) len;
+}
+
+char *u32toa(uint32_t v, char *buf) {
+    char tmp[12];
+    int n = 0;
+    do {
+        tmp[n++] = (char) ('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *buf++ = tmp[--n];
+    return buf;
+}
+
+char *i32toa(int32_t v, char *buf) {
+    if (v < 0) {
+        *buf++ = '-';
+        return u32toa((uint32_t) (-(int64_t) v), buf);
+    }
+    return u32toa((uint32_t) v, buf);
+}
+
+char *seqIdToBuffer(float seqId, char *buffer) {
+    // Util::fastSeqIdToBuffer (M/src/commons/Util.cpp:222-251): truncation, not rounding
+    if (seqId == 1.0) {
+        memcpy(buffer, "1.000", 5);
+        return buffer + 5;
+    }
+    *buffer++ = '0';
+    *buffer++ = '.';
+    if (seqId < 0.10) *buffer++ = '0';
+    if (seqId < 0.01) *buffer++ = '0';
+    return i32toa((int) (seqId * 1000), buffer);
+}
+
+std::string compressBacktrace(const char *bt, size_t n) {
+    std::string ret;
+    char state = 'M';
+    size_t counter = 0;
+    char num[16];
+    for (size_t i = 0; i < n; ++i) {
+        if (bt[i] != state) {
+            ret.append(num, u32toa((uint32_t) counter, num) - num);
+            ret.push_back(state);
+            state = bt[i];
+            counter = 1;
+        } else {
+            counter++;
+        }
+    }
+    ret.append(num, u32toa((uint32_t) counter, num) - num);
+    ret.push_back(state);
+    return ret;
+}
+
+}  // namespace sd
