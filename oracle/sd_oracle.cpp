@@ -686,6 +686,213 @@ double or_sw_align(void *vc, const unsigned char *q, int qL, const unsigned char
     return evalue;
 }
 
+// ------------------------------------------------------------------------------------------
+// clusterhits, one (query set, target set) entry (R/src/util/ClusterHits.cpp:295-492), dense K x K
+// restatement with the reference's argmax/tie/stale-dmin behaviour kept literally.
+//   in : K hits (qPos, tPos, strands (bit0 q, bit1 t), pval), Nq, d, cls, alpha, thresholds, lGamma table
+//   out: clusterOf[K] (cluster ordinal in emission order or UINT32_MAX), memberOrder[K] (hit indices grouped
+//        per emitted cluster in node append order), clusterSize/pCO/pMH per emitted cluster; returns #clusters
+// ------------------------------------------------------------------------------------------
+namespace {
+double chLogGamma(double x) {
+    // Lanczos approximation as in ClusterHits.cpp:23-63
+    static const double r10 = 10.900511;
+    static const double dk[11] = {2.48574089138753565546e-5, 1.05142378581721974210, -3.45687097222016235469,
+                                  4.51227709466894823700, -2.98285225323576655721, 1.05639711577126713077,
+                                  -1.95428773191645869583e-1, 1.70970543404441224307e-2, -5.71926117404305781283e-4,
+                                  4.63399473359905636708e-6, -2.71994908488607703910e-9};
+    static const double gc = 2 * sqrt(exp(1.0) / M_PI);
+    if (x < 0.5) return log(M_PI) - log(abs(sin(M_PI * x))) - chLogGamma(1 - x);
+    if (x == 1) return 0.0;
+    double sum = dk[0];
+    sum += dk[1] / (x + 0);
+    sum += dk[2] / (x + 1);
+    sum += dk[3] / (x + 2);
+    sum += dk[4] / (x + 3);
+    sum += dk[5] / (x + 4);
+    sum += dk[6] / (x + 5);
+    sum += dk[7] / (x + 6);
+    sum += dk[8] / (x + 7);
+    sum += dk[9] / (x + 8);
+    sum += dk[10] / (x + 9);
+    return log(gc) + (x - 0.5) * log(x + r10 - 0.5) - (x - 0.5) + log(sum);
+}
+struct ChHit {
+    double pval;
+    unsigned int qPos, tPos;
+    bool qStrand, tStrand;
+    int idx;
+};
+double chClusterPval(const double *lg, int k, int m, double q0 = 0.001) {
+    return 2 * lg[m + 1] - 2 * lg[m - k + 1] - lg[k + 1] + k * log(q0);
+}
+double chOrderingPval(const double *lg, int k, int m) { return log(1 - 1.0 * m / k) - m * log(2) - lg[m + 1]; }
+double chScore(const double *lg, std::vector<ChHit> &c) {
+    if (c.size() == 0) return 0.0;
+    unsigned int iMax = 0, iMin = INT_MAX, jMax = 0, jMin = INT_MAX;
+    for (size_t l = 0; l < c.size(); l++) {
+        iMax = std::max(iMax, c[l].qPos);
+        iMin = std::min(iMin, c[l].qPos);
+        jMax = std::max(jMax, c[l].tPos);
+        jMin = std::min(jMin, c[l].tPos);
+    }
+    int spanI = iMax - iMin + 1, spanJ = jMax - jMin + 1;
+    int span = spanI > spanJ ? spanI : spanJ;
+    int k = (int) c.size();
+    std::sort(c.begin(), c.end(), [](const ChHit &a, const ChHit &b) { return a.qPos < b.qPos; });
+    int m = 0;
+    for (size_t l = 0; l + 1 < c.size(); l++) {
+        bool sameOrder = c[l + 1].tPos > c[l].tPos;
+        bool s1 = c[l].qStrand == c[l].tStrand;
+        bool s2 = c[l + 1].qStrand == c[l + 1].tStrand;
+        if ((s1 == sameOrder) && (s2 == sameOrder)) m++;
+    }
+    return -0.5 * chClusterPval(lg, k, span) - 0.5 * chOrderingPval(lg, k, m);
+}
+bool chCompatible(const std::vector<ChHit> &a, const std::vector<ChHit> &b, unsigned int d) {
+    unsigned int iMax1 = 0, iMin1 = INT_MAX, jMax1 = 0, jMin1 = INT_MAX;
+    for (size_t l = 0; l < a.size(); l++) {
+        iMax1 = std::max(iMax1, a[l].qPos); iMin1 = std::min(iMin1, a[l].qPos);
+        jMax1 = std::max(jMax1, a[l].tPos); jMin1 = std::min(jMin1, a[l].tPos);
+    }
+    unsigned int iMax2 = 0, iMin2 = INT_MAX, jMax2 = 0, jMin2 = INT_MAX;
+    for (size_t l = 0; l < b.size(); l++) {
+        iMax2 = std::max(iMax2, b[l].qPos); iMin2 = std::min(iMin2, b[l].qPos);
+        jMax2 = std::max(jMax2, b[l].tPos); jMin2 = std::min(jMin2, b[l].tPos);
+    }
+    return (std::min(jMin1 - jMax2, jMin2 - jMax1) <= d && std::min(iMin1 - iMax2, iMin2 - iMax1) <= d);   // unsigned
+}
+double chGroupScore(const double *lg, const std::vector<std::vector<int> > &nodes, const std::vector<ChHit> &match,
+                    int i, int j, unsigned int d) {
+    std::vector<ChHit> c1, c2, c;
+    if (nodes[i].size() != 0 && nodes[j].size() != 0) {
+        for (size_t m = 0; m < nodes[i].size(); m++) c1.push_back(match[nodes[i][m]]);
+        for (size_t n = 0; n < nodes[j].size(); n++) c2.push_back(match[nodes[j][n]]);
+        if (chCompatible(c1, c2, d)) {
+            c.insert(c.begin(), c1.begin(), c1.end());
+            c.insert(c.end(), c2.begin(), c2.end());
+        }
+    }
+    return chScore(lg, c);
+}
+double chMultihit(const double *lg, const std::vector<ChHit> &cluster, int Nq, double alpha) {
+    size_t k = 0;
+    double r = 0;
+    double pvalThreshold = alpha / (Nq + 1);
+    double logPvalThr = log(pvalThreshold);
+    for (size_t i = 0; i < cluster.size(); ++i) {
+        double logPvalue = log(cluster[i].pval);
+        if (logPvalue < logPvalThr) {
+            k++;
+            r -= logPvalue - logPvalThr;
+        }
+    }
+    if (r == 0) return 1.0;
+    if (std::isinf(r)) return 0.0;
+    double expMinusR = exp(-r);
+    if (expMinusR == 0) return 0.0;
+    double sum = 0;
+    for (size_t i = 0; i < k - 1; ++i) sum += pow(r, i) / exp(lg[i + 1]);
+    return expMinusR * sum;
+}
+}  // namespace
+
+void or_lgamma_table(double *out, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) out[i] = chLogGamma(i * 1.0);
+}
+
+int or_clusterhits(uint32_t K, const uint32_t *qPos, const uint32_t *tPos, const uint8_t *strands, const double *pval,
+                   uint32_t Nq, uint32_t d, uint32_t cls, double alpha, float pCluThr, float pMHThr,
+                   const double *lg, uint32_t *clusterOf, uint32_t *memberOrder, uint32_t *clusterSize, double *pCO,
+                   double *pMH, double *mergeTrace /* optional: 3 doubles per merge (i1,i2,score) */, uint32_t *nMerges) {
+    for (uint32_t i = 0; i < K; i++) clusterOf[i] = UINT32_MAX;
+    if (nMerges) *nMerges = 0;
+    if (K == 1 || K == 0) return 0;
+    std::vector<ChHit> match(K);
+    for (uint32_t i = 0; i < K; i++) {
+        match[i].pval = pval[i];
+        match[i].qPos = qPos[i];
+        match[i].tPos = tPos[i];
+        match[i].qStrand = strands[i] & 1;
+        match[i].tStrand = (strands[i] >> 1) & 1;
+        match[i].idx = (int) i;
+    }
+    std::vector<std::vector<double> > D(K, std::vector<double>(K, 0.0));
+    std::vector<int> dmin(K, 0);
+    std::vector<std::vector<int> > nodes(K);
+    for (uint32_t n = 0; n < K; n++) nodes[n].push_back(n);
+    for (uint32_t i = 0; i < K; i++) {
+        for (uint32_t j = 0; j < K; j++) {
+            if (i == j) D[i][j] = 0.0;
+            else D[i][j] = chGroupScore(lg, nodes, match, i, j, d);
+            dmin[i] = (D[i][j] > D[i][dmin[i]]) ? j : dmin[i];
+        }
+    }
+    double maxScore = DBL_MAX;
+    bool isFirstIter = true;
+    double sMin = -0.5 * chClusterPval(lg, 2, d + 1) - 0.5 * chOrderingPval(lg, 2, 1);
+    uint32_t merges = 0;
+    while (isFirstIter || (maxScore >= sMin)) {
+        size_t i1 = 0, i2 = 0;
+        for (size_t i = 0; i < K; i++) i1 = (D[i][dmin[i]] > D[i1][dmin[i1]]) ? i : i1;
+        i2 = dmin[i1];
+        maxScore = D[i1][i2];
+        if (maxScore != 0) {
+            if (isFirstIter) isFirstIter = false;
+        } else {
+            break;
+        }
+        if (mergeTrace) {
+            mergeTrace[3 * merges] = (double) i1;
+            mergeTrace[3 * merges + 1] = (double) i2;
+            mergeTrace[3 * merges + 2] = maxScore;
+        }
+        merges++;
+        for (size_t n = 0; n < nodes[i2].size(); n++) nodes[i1].push_back(nodes[i2][n]);
+        nodes[i2].clear();
+        for (size_t j = 0; j < K; j++) {
+            if (i1 == j || i2 == j) {
+                D[i1][j] = 0.0;
+                D[j][i1] = 0.0;
+            } else {
+                D[i1][j] = chGroupScore(lg, nodes, match, (int) i1, (int) j, d);
+                D[j][i1] = D[i1][j];
+            }
+            D[i2][j] = 0.0;
+            D[j][i2] = 0.0;
+            if (j != 0) dmin[i1] = (D[i1][j] > D[i1][dmin[i1]]) ? (int) j : dmin[i1];
+            else dmin[i1] = (int) j;
+            if (j != i1 && j != i2) dmin[j] = (D[j][i1] > D[j][dmin[j]]) ? (int) i1 : dmin[j];
+        }
+    }
+    if (nMerges) *nMerges = merges;
+    int nClu = 0;
+    uint32_t w = 0;
+    for (size_t i = 0; i < nodes.size(); i++) {
+        if (nodes[i].size() >= cls) {
+            std::vector<ChHit> cluster;
+            for (size_t j = 0; j < nodes[i].size(); j++) cluster.push_back(match[nodes[i][j]]);
+            std::vector<ChHit> tmp = cluster;
+            double co = exp(-chScore(lg, tmp));
+            // the reference sorts `cluster` in place (findConservedPairs) before printing, so members
+            // are emitted in ascending qPos order
+            cluster = tmp;
+            double mh = chMultihit(lg, cluster, (int) Nq, alpha);
+            if (co <= pCluThr && mh <= pMHThr) {
+                pCO[nClu] = co;
+                pMH[nClu] = mh;
+                clusterSize[nClu] = (uint32_t) cluster.size();
+                for (size_t j = 0; j < cluster.size(); j++) {
+                    clusterOf[cluster[j].idx] = nClu;
+                    memberOrder[w++] = cluster[j].idx;
+                }
+                nClu++;
+            }
+        }
+    }
+    return nClu;
+}
+
 double or_evalue(uint64_t dbResidues, double score, double qLen) {
     Evaluer ev;
     initEvaluer(ev, dbResidues);
