@@ -1,0 +1,194 @@
+/* spacedust_gpu.h -- C ABI of the MI355X-native clustersearch hot path (libsdgpu.so).
+ *
+ * One handle (sd_ctx) per GPU / per process.  The caller owns every host buffer it passes in
+ * or receives; the library owns device memory behind opaque handles.  Every function returns
+ * 0 on success or a negative SD_E* code and never exits or throws; sd_last_error() gives a
+ * message.  There is NO CPU fallback behind any entry point: without a visible HIP device
+ * sd_ctx_create fails with SD_ENODEVICE.
+ *
+ * Each entry point names the reference interface it replaces (M/ = lib/mmseqs/ of
+ * soedinglab/spacedust, R/ = the repository root); INTEGRATION.md shows the call sites a
+ * maintainer would patch.
+ */
+#ifndef SPACEDUST_GPU_H
+#define SPACEDUST_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SD_OK = 0,
+    SD_ENODEVICE = -1,   /* no HIP device / HIP runtime error at start-up */
+    SD_EHIP = -2,        /* HIP runtime error */
+    SD_EINVAL = -3,      /* bad argument */
+    SD_ENOMEM = -4,      /* device or host allocation failed */
+    SD_EUNSUPPORTED = -5,/* a reference code path that is not implemented on the device (fails loudly) */
+    SD_EMISMATCH = -6    /* forward/backward SW score mismatch (fatal in the reference too) */
+};
+
+typedef struct sd_ctx sd_ctx;
+typedef struct sd_seqset sd_seqset;
+typedef struct sd_target sd_target;
+
+/* ---- context ------------------------------------------------------------------------- */
+int sd_ctx_create(int device, sd_ctx **out);
+void sd_ctx_destroy(sd_ctx *ctx);
+const char *sd_last_error(sd_ctx *ctx);
+int sd_device_name(sd_ctx *ctx, char *buf, size_t cap);
+int sd_synchronize(sd_ctx *ctx);
+
+/* Kernel timing with HIP events on the library's own stream (bench.py roofline leg).
+ * sd_profile_enable(ctx, 1) makes every launch record start/stop events; sd_profile_get returns the
+ * accumulated time and launch count of the kernel family `name` ("sw_score", "prefilter_gather", ...). */
+int sd_profile_enable(sd_ctx *ctx, int on);
+int sd_profile_reset(sd_ctx *ctx);
+int sd_profile_get(sd_ctx *ctx, const char *name, double *totalMs, uint64_t *launches);
+int sd_profile_names(sd_ctx *ctx, char *buf, size_t cap); /* comma separated */
+
+/* ---- sequence sets resident in HBM ----------------------------------------------------
+ * residues: numeric amino acids (0..20, X = 20; M/src/commons/Sequence.cpp:307-324), concatenated;
+ * offsets[n+1].  Replaces DBReader::getData + Sequence::mapSequence on the device side
+ * (M/src/alignment/Alignment.cpp:339,362).  swCompBias (nullable): per residue int8 composition bias of
+ * SmithWaterman::ssw_init (M/src/alignment/StripedSmithWaterman.cpp:1230-1235); NULL = all zero. */
+int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offsets, uint32_t n,
+                     const int8_t *swCompBias, sd_seqset **out);
+void sd_seqset_destroy(sd_seqset *s);
+
+/* ---- Smith-Waterman (align module) ---------------------------------------------------- */
+typedef struct {
+    int32_t gapOpen;       /* 11 */
+    int32_t gapExtend;     /* 1 */
+    int8_t matrix[21 * 21];/* blosum62 at 2 bit-factor, scoreBias 0 (Alignment.cpp:152) */
+    int32_t covMode;       /* Parameters::COV_MODE_* ; clustersearch: 2 (query) */
+    float covThr;          /* 0.8 */
+    double evalThr;        /* 10 */
+    int32_t swMode;        /* Matcher::SCORE_ONLY 0 / SCORE_COV 1 / SCORE_COV_SEQID 2 */
+    uint64_t dbResidues;   /* tdbr->getAminoAcidDBSize() (Alignment.cpp:263) */
+} sd_sw_params;
+
+typedef struct {
+    int32_t score;         /* s_align.score1 */
+    int32_t qStart, qEnd, tStart, tEnd; /* -1 where the reference leaves them unset */
+    int32_t identical;     /* identicalAACnt (0 when no backtrace) */
+    int32_t btLen;         /* backtrace length (alnLength) */
+    int32_t flags;         /* bit0: word (int16) kernel semantics used; bit1: fwd/bwd mismatch */
+    double evalue;
+    uint64_t btOffset;     /* offset of the expanded backtrace (chars M/I/D) in the pool */
+} sd_sw_result;
+
+/* Replaces matcher.initQuery + matcher.getSWResult for a batch of (query,target) pairs
+ * (M/src/alignment/Alignment.cpp:340,379 -> Matcher.cpp:60 -> StripedSmithWaterman.cpp:310-545).
+ * isIdentity[i] != 0 selects scoreIdentical (StripedSmithWaterman.cpp:1675).  btPool receives the
+ * backtraces (caller allocates btCap bytes; *btUsed is set; SD_ENOMEM if too small). */
+int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                      uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
+                      sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed);
+
+/* The score pass alone (sw_sse2_byte / sw_sse2_word semantics, StripedSmithWaterman.cpp:639-1214):
+ * lanes = 32 reproduces the AVX2 byte kernel's lane structure, 16 the word kernel's.  reverse != 0 runs the
+ * start-position pass on query[0..qEnd[i]] reversed x target[0..tEnd[i]] scanned downwards.
+ * out: 3 int32 per pair {max score, end_db (scan position mapped back to a target index, -1 if none), end_query}. */
+int sd_sw_score_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                      uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, int lanes, int reverse,
+                      const int32_t *qEnd, const int32_t *tEnd, int32_t *out);
+
+/* number of DP cells the last sd_sw_* call evaluated on the device, by pass */
+int sd_sw_last_cells(sd_ctx *ctx, uint64_t *forwardCells, uint64_t *reverseCells, uint64_t *tracebackCells);
+
+/* ---- prefilter ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t kmerSize;        /* 6 or 7 */
+    int32_t kmerThr;         /* Prefiltering::getKmerThreshold (Prefiltering.cpp:1005) */
+    int32_t maxHitsPerQuery; /* --max-seqs */
+    int32_t minDiagScore;    /* --min-ungapped-score, must be >= 1 */
+    uint32_t binSize;        /* BINSIZE of CacheFriendlyOperations picked from dbSize vs host L2 (QueryMatcher.cpp:422-450) */
+    int32_t covMode;         /* coverage pre-filter of Prefiltering.cpp:856-863; covThr <= 0 disables */
+    float covThr;
+    int8_t ungappedMatrix[21 * 21]; /* blosum62 at 2 bit-factor, scoreBias -0.2 (Prefiltering.cpp:69,991) */
+} sd_prefilter_params;
+
+typedef struct {
+    uint32_t seqId;   /* hit_t (QueryMatcher.h:33-37) */
+    int32_t score;
+    uint16_t diagonal;
+    uint16_t pad;
+} sd_hit;
+
+/* Target side: replaces Prefiltering::getIndexTable (Prefiltering.cpp:514) -- the k-mer index, the masked
+ * sequence lookup and the sorted 2-mer/3-mer similarity tables are uploaded once and stay resident.
+ *   kmerOffsets[20^k+1] (u32), entrySeq/entryPos: lists sorted by (seqId,pos) (IndexTable.h:182-189)
+ *   maskedResidues/seqOffsets: SequenceLookup (M/src/prefiltering/SequenceLookup.h)
+ *   ext2/ext3: ExtendedSubstitutionMatrix::calcScoreMatrix rows (score int16, index u16), 400x400 and 8000x8000 */
+int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, const uint32_t *entrySeq,
+                     const uint16_t *entryPos, uint64_t nEntries, const uint8_t *maskedResidues,
+                     const uint64_t *seqOffsets, uint32_t nSeq, const int16_t *ext2Score, const uint16_t *ext2Index,
+                     const int16_t *ext3Score, const uint16_t *ext3Index, sd_target **out);
+void sd_target_destroy(sd_target *t);
+
+/* Replaces the per-query loop body of Prefiltering::runSplit (Prefiltering.cpp:817-886), i.e.
+ * QueryMatcher::matchQuery (QueryMatcher.cpp:85) + the coverage pre-filter, for nQ queries at once.
+ *   qKmerBias: per window start i the rounded composition bias of QueryMatcher.cpp:230-240 (int16, same
+ *              offsets as the residues; entries past L-span are ignored)
+ *   qDiagBias: per residue int8 of UngappedAlignment.cpp:392-396
+ *   identityId[q]: index of the query in the target DB or UINT32_MAX
+ * outHits: nQ * maxHitsPerQuery slots (row q at q*maxHitsPerQuery), outCount[nQ].
+ * stats (nullable, 4*nQ u64): #similar k-mers, #index entries, #diagonals scored, sum of diagonal lengths. */
+int sd_prefilter_batch(sd_ctx *ctx, const sd_target *target, const sd_prefilter_params *par, uint32_t nQ,
+                       const uint8_t *qResidues, const uint64_t *qOffsets, const int16_t *qKmerBias,
+                       const int8_t *qDiagBias, const uint32_t *identityId, sd_hit *outHits, uint32_t *outCount,
+                       uint64_t *stats);
+
+/* ---- clusterhits ---------------------------------------------------------------------- */
+typedef struct {
+    uint32_t maxGeneGap;   /* d, --max-gene-gap (3) */
+    uint32_t clusterSize;  /* cls, --cluster-size (2) */
+    double alpha;          /* 1 */
+    float pCluThr, pMHThr; /* 0.01 */
+} sd_ch_params;
+
+/* Replaces the body of the omp-for in clusterhits (R/src/util/ClusterHits.cpp:295-492) for nPairs
+ * (query set, target set) entries.  Hits of entry p are [hitOff[p], hitOff[p+1]).
+ *   strands: bit0 query strand, bit1 target strand (ClusterHits.cpp:346-347)
+ *   lGamma[lGammaLen]: logGamma(i) table (ClusterHits.cpp:267-271), generated by sd_host_lgamma_table
+ * Outputs per hit: clusterOfHit (ordinal of the emitted cluster inside its entry, UINT32_MAX = none) and
+ * rankInCluster (emission order inside the cluster); per entry nClusters; per emitted cluster (slot
+ * hitOff[p]+ordinal) pCO, pMH, size. */
+int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32_t nPairs, const uint64_t *hitOff,
+                         const uint32_t *qPos, const uint32_t *tPos, const uint8_t *strands, const double *pval,
+                         const uint32_t *Nq, const double *lGamma, uint32_t lGammaLen, uint32_t *clusterOfHit,
+                         uint32_t *rankInCluster, uint32_t *nClusters, double *pCO, double *pMH,
+                         uint32_t *clusterSizeOut);
+
+/* ---- host-side stages that stay on the CPU ------------------------------ */
+typedef struct sd_host sd_host;
+int sd_host_create(int threads, sd_host **out);
+void sd_host_destroy(sd_host *h);
+/* which: 0 blosum62@2 (SW), 1 VTML80@8 bias -0.2 (seeds), 2 blosum62@2 bias -0.2 (diagonal scoring) */
+int sd_host_matrix(sd_host *h, int which, int8_t *out21x21, double *pBack21, uint8_t *aa2num256);
+int sd_host_map_sequence(sd_host *h, const char *ascii, uint64_t len, uint8_t *out);
+/* SubstitutionMatrix::calcLocalAaBiasCorrection + the three integer roundings, for n sequences */
+int sd_host_comp_bias(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
+                      int8_t *swBias, int8_t *diagBias, int16_t *kmerBias);
+/* IndexBuilder::fillDatabase (mask + count + fill), returns an index handle to read back */
+typedef struct sd_host_index sd_host_index;
+int sd_host_index_build(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
+                        int kmerThr, int mask, double maskProb, sd_host_index **out);
+int sd_host_index_info(sd_host_index *ix, uint64_t *tableSize, uint64_t *nEntries, uint64_t *maskedResidues);
+int sd_host_index_arrays(sd_host_index *ix, const uint32_t **kmerOffsets, const uint32_t **entrySeq,
+                         const uint16_t **entryPos, const uint8_t **maskedResidues);
+void sd_host_index_destroy(sd_host_index *ix);
+int sd_host_ext_matrix(sd_host *h, int wordLen, const int16_t **score, const uint16_t **index, uint32_t *size);
+int sd_host_kmer_threshold(float sensitivity, int kmerSize);
+unsigned sd_host_bin_size(uint64_t dbSize, uint64_t l2CacheSize); /* l2CacheSize 0 = sysconf of this host */
+int sd_host_lgamma_table(double *out, uint32_t n);
+double sd_host_evalue(uint64_t dbResidues, double score, double qLen);
+double sd_host_bitscore(double score);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

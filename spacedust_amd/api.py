@@ -1,0 +1,219 @@
+"""Thin Python mirror of the C ABI (include/spacedust_gpu.h): Host (CPU stages), Context (one GPU),
+SeqSet / Target (data resident in HBM) and the three hot-path calls.  All compute happens in
+libsdgpu.so; numpy only carries buffers."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SdError, ptr
+
+
+def _check(ctx, rc, what):
+    if rc != 0:
+        msg = ''
+        if ctx is not None:
+            msg = _lib.load().sd_last_error(ctx).decode(errors='replace')
+        raise SdError('%s failed (%d): %s' % (what, rc, msg))
+
+
+class Host:
+    """Host-side stages (sd_host_*): matrices, composition bias, target masking + index, E-values."""
+
+    def __init__(self, threads=0):
+        import os
+        self.L = _lib.load()
+        self.threads = threads or (os.cpu_count() or 1)
+        h = C.c_void_p()
+        _check(None, self.L.sd_host_create(self.threads, C.byref(h)), 'sd_host_create')
+        self.h = h
+
+    def matrix(self, which):
+        m = np.zeros(441, np.int8)
+        pb = np.zeros(21, np.float64)
+        a2n = np.zeros(256, np.uint8)
+        self.L.sd_host_matrix(self.h, which, ptr(m), ptr(pb), ptr(a2n))
+        return m, pb, a2n
+
+    def map_sequences(self, seqs):
+        """list of ASCII protein strings -> (residues uint8, offsets uint64)"""
+        lens = np.fromiter((len(s) for s in seqs), np.uint64, len(seqs))
+        off = np.zeros(len(seqs) + 1, np.uint64)
+        np.cumsum(lens, out=off[1:])
+        blob = ''.join(seqs).encode()
+        out = np.zeros(len(blob), np.uint8)
+        self.L.sd_host_map_sequence(self.h, blob, len(blob), ptr(out))
+        return out, off
+
+    def comp_bias(self, residues, offsets, k=6):
+        n = len(offsets) - 1
+        sw = np.zeros(len(residues), np.int8)
+        dg = np.zeros(len(residues), np.int8)
+        km = np.zeros(len(residues), np.int16)
+        self.L.sd_host_comp_bias(self.h, ptr(residues), ptr(offsets), n, k, ptr(sw), ptr(dg), ptr(km))
+        return sw, dg, km
+
+    def build_index(self, residues, offsets, k=6, kmer_thr=112, mask=True, mask_prob=0.9):
+        return HostIndex(self, residues, offsets, k, kmer_thr, mask, mask_prob)
+
+    def ext_matrix(self, word_len):
+        sp = C.c_void_p()
+        ip = C.c_void_p()
+        n = C.c_uint32()
+        _check(None, self.L.sd_host_ext_matrix(self.h, word_len, C.byref(sp), C.byref(ip), C.byref(n)), 'sd_host_ext_matrix')
+        size = n.value
+        sc = np.ctypeslib.as_array(C.cast(sp, C.POINTER(C.c_int16)), shape=(size * size,))
+        ix = np.ctypeslib.as_array(C.cast(ip, C.POINTER(C.c_uint16)), shape=(size * size,))
+        return sc, ix, size
+
+    def kmer_threshold(self, sensitivity, k):
+        return self.L.sd_host_kmer_threshold(sensitivity, k)
+
+    def bin_size(self, db_size, l2=0):
+        return self.L.sd_host_bin_size(db_size, l2)
+
+    def lgamma_table(self, n):
+        out = np.zeros(n, np.float64)
+        self.L.sd_host_lgamma_table(ptr(out), n)
+        return out
+
+    def evalue(self, db_residues, score, qlen):
+        return self.L.sd_host_evalue(db_residues, float(score), float(qlen))
+
+    def bitscore(self, score):
+        return self.L.sd_host_bitscore(float(score))
+
+
+class HostIndex:
+    def __init__(self, host, residues, offsets, k, kmer_thr, mask, mask_prob):
+        self.host = host
+        self.k = k
+        self.n = len(offsets) - 1
+        self.offsets = np.ascontiguousarray(offsets, np.uint64)
+        residues = np.ascontiguousarray(residues, np.uint8)
+        h = C.c_void_p()
+        _check(None, host.L.sd_host_index_build(host.h, ptr(residues), ptr(self.offsets), self.n, k, kmer_thr,
+                                                1 if mask else 0, mask_prob, C.byref(h)), 'sd_host_index_build')
+        self.h = h
+        ts, ne, mk = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        host.L.sd_host_index_info(h, C.byref(ts), C.byref(ne), C.byref(mk))
+        self.table_size, self.n_entries, self.masked_residues = ts.value, ne.value, mk.value
+        po, ps, pp, pm = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        host.L.sd_host_index_arrays(h, C.byref(po), C.byref(ps), C.byref(pp), C.byref(pm))
+        self.kmer_offsets = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint32)), shape=(self.table_size + 1,))
+        ne1 = max(self.n_entries, 1)
+        self.entry_seq = np.ctypeslib.as_array(C.cast(ps, C.POINTER(C.c_uint32)), shape=(ne1,))[:self.n_entries]
+        self.entry_pos = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint16)), shape=(ne1,))[:self.n_entries]
+        tot = max(int(self.offsets[-1]), 1)
+        self.masked = np.ctypeslib.as_array(C.cast(pm, C.POINTER(C.c_uint8)), shape=(tot,))[:int(self.offsets[-1])]
+
+    def __del__(self):
+        try:
+            self.host.L.sd_host_index_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU (sd_ctx).  Raises SdError when no HIP device is visible -- there is no CPU fallback."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.sd_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise SdError('sd_ctx_create(%d) failed (%d): no usable HIP device; the HIP path has no CPU fallback'
+                          % (device, rc))
+        self.h = h
+
+    def device_name(self):
+        b = C.create_string_buffer(256)
+        self.L.sd_device_name(self.h, b, 256)
+        return b.value.decode()
+
+    def synchronize(self):
+        _check(self.h, self.L.sd_synchronize(self.h), 'sd_synchronize')
+
+    def profile(self, on=True):
+        self.L.sd_profile_enable(self.h, 1 if on else 0)
+        self.L.sd_profile_reset(self.h)
+
+    def profile_report(self):
+        b = C.create_string_buffer(4096)
+        self.L.sd_profile_names(self.h, b, 4096)
+        out = {}
+        for name in filter(None, b.value.decode().split(',')):
+            ms, cnt = C.c_double(), C.c_uint64()
+            self.L.sd_profile_get(self.h, name.encode(), C.byref(ms), C.byref(cnt))
+            out[name] = (ms.value, cnt.value)
+        return out
+
+    def seqset(self, residues, offsets, sw_bias=None):
+        return SeqSet(self, residues, offsets, sw_bias)
+
+    def sw_params(self, matrix, db_residues, sw_mode=2, eval_thr=10.0, cov_mode=2, cov_thr=0.8, gap_open=11,
+                  gap_extend=1):
+        p = _lib.SwParams()
+        p.gapOpen, p.gapExtend = gap_open, gap_extend
+        for i in range(441):
+            p.matrix[i] = int(matrix[i])
+        p.covMode, p.covThr, p.evalThr, p.swMode, p.dbResidues = cov_mode, cov_thr, eval_thr, sw_mode, db_residues
+        return p
+
+    def sw_score(self, par, queries, targets, pair_q, pair_t, lanes=32, reverse=False, q_end=None, t_end=None):
+        pq = np.ascontiguousarray(pair_q, np.uint32)
+        pt = np.ascontiguousarray(pair_t, np.uint32)
+        out = np.zeros((len(pq), 3), np.int32)
+        qe = np.ascontiguousarray(q_end, np.int32) if q_end is not None else None
+        te = np.ascontiguousarray(t_end, np.int32) if t_end is not None else None
+        _check(self.h, self.L.sd_sw_score_batch(self.h, C.byref(par), queries.h, targets.h, len(pq), ptr(pq), ptr(pt),
+                                                lanes, 1 if reverse else 0, ptr(qe), ptr(te), ptr(out)),
+               'sd_sw_score_batch')
+        return out
+
+    def sw_align(self, par, queries, targets, pair_q, pair_t, identity=None, bt_cap=None):
+        pq = np.ascontiguousarray(pair_q, np.uint32)
+        pt = np.ascontiguousarray(pair_t, np.uint32)
+        n = len(pq)
+        idt = np.ascontiguousarray(identity, np.uint8) if identity is not None else np.zeros(n, np.uint8)
+        res = np.zeros(n, _lib.SW_RESULT_DTYPE)
+        if bt_cap is None:
+            ql = (queries.offsets[pq + 1] - queries.offsets[pq]).astype(np.int64)
+            tl = (targets.offsets[pt + 1] - targets.offsets[pt]).astype(np.int64)
+            bt_cap = int((ql + tl).sum()) + 64
+        pool = np.zeros(bt_cap, np.uint8)
+        used = C.c_uint64()
+        _check(self.h, self.L.sd_sw_align_batch(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt),
+                                                ptr(idt), ptr(res), ptr(pool), bt_cap, C.byref(used)),
+               'sd_sw_align_batch')
+        return res, pool[:used.value]
+
+    def sw_cells(self):
+        f, r, t = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.L.sd_sw_last_cells(self.h, C.byref(f), C.byref(r), C.byref(t))
+        return f.value, r.value, t.value
+
+    def __del__(self):
+        try:
+            self.L.sd_ctx_destroy(self.h)
+        except Exception:
+            pass
+
+
+class SeqSet:
+    def __init__(self, ctx, residues, offsets, sw_bias):
+        self.ctx = ctx
+        self.residues = np.ascontiguousarray(residues, np.uint8)
+        self.offsets = np.ascontiguousarray(offsets, np.uint64)
+        self.n = len(self.offsets) - 1
+        b = np.ascontiguousarray(sw_bias, np.int8) if sw_bias is not None else None
+        h = C.c_void_p()
+        _check(ctx.h, ctx.L.sd_seqset_create(ctx.h, ptr(self.residues), ptr(self.offsets), self.n, ptr(b), C.byref(h)),
+               'sd_seqset_create')
+        self.h = h
+
+    def __del__(self):
+        try:
+            self.ctx.L.sd_seqset_destroy(self.h)
+        except Exception:
+            pass

@@ -1,0 +1,61 @@
+"""Build libsdgpu.so in-tree: host stages with g++ (same FP flags as the reference's AVX2 build so the
+double-precision stages contract identically), HIP kernels with hipcc for gfx950, linked by hipcc."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libsdgpu.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+HOST_FLAGS = ['-std=c++17', '-O3', '-mavx2', '-mfma', '-ffp-contract=fast', '-fopenmp', '-fPIC']
+HIP_FLAGS = ['--offload-arch=gfx950', '-std=c++17', '-O3', '-fPIC', '-fopenmp', '-Wno-unused-result']
+
+
+def _newer(src, dst):
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force=False, verbose=False):
+    inc = ['-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(CSRC, 'host'), '-I' + os.path.join(CSRC, 'hip')]
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(ROOT, 'include', 'spacedust_gpu.h')]
+    for d in ('host', 'hip'):
+        headers += [os.path.join(CSRC, d, f) for f in os.listdir(os.path.join(CSRC, d)) if f.endswith(('.h', '.inc'))]
+    newest_hdr = max(os.path.getmtime(h) for h in headers)
+    objs = []
+    jobs = []
+    for f in sorted(os.listdir(os.path.join(CSRC, 'host'))):
+        if f.endswith('.cpp'):
+            src = os.path.join(CSRC, 'host', f)
+            obj = os.path.join(objdir, f[:-4] + '.o')
+            objs.append(obj)
+            if force or _newer(src, obj) or newest_hdr > os.path.getmtime(obj):
+                jobs.append(['g++'] + HOST_FLAGS + inc + ['-c', src, '-o', obj])
+    for f in sorted(os.listdir(os.path.join(CSRC, 'hip'))):
+        if f.endswith('.hip'):
+            src = os.path.join(CSRC, 'hip', f)
+            obj = os.path.join(objdir, f[:-4] + '.hip.o')
+            objs.append(obj)
+            if force or _newer(src, obj) or newest_hdr > os.path.getmtime(obj):
+                jobs.append([HIPCC] + HIP_FLAGS + inc + ['-c', src, '-o', obj])
+    procs = []
+    for cmd in jobs:
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('compile failed: ' + ' '.join(cmd))
+    if jobs or not os.path.exists(OUT):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-fopenmp'] + objs + ['-o', OUT]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

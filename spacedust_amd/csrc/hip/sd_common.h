@@ -1,0 +1,93 @@
+// Internal declarations shared by the HIP translation units of libsdgpu.so.
+#ifndef SD_COMMON_H
+#define SD_COMMON_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "spacedust_gpu.h"
+
+struct sd_profile_entry {
+    double ms = 0.0;
+    uint64_t launches = 0;
+};
+
+struct sd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string lastError;
+    bool profiling = false;
+    std::map<std::string, sd_profile_entry> profile;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    uint64_t cellsFwd = 0, cellsRev = 0, cellsTb = 0;
+    hipDeviceProp_t prop;
+};
+
+struct sd_seqset {
+    sd_ctx *ctx = nullptr;
+    uint32_t n = 0;
+    uint64_t total = 0;
+    uint8_t *dRes = nullptr;      // residues
+    int8_t *dBias = nullptr;      // SW composition bias (int8 per residue)
+    uint64_t *dOff = nullptr;     // offsets n+1
+    std::vector<uint64_t> hOff;   // host copy of the offsets
+    std::vector<int32_t> hMinBias;// per sequence min(0, min cb8)
+    std::vector<uint8_t> hRes;    // host copy (traceback identity count, scoreIdentical)
+    std::vector<int8_t> hBias;
+};
+
+int sdFail(sd_ctx *ctx, int code, const char *fmt, ...);
+
+#define SD_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return sdFail((ctx), SD_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// RAII device buffer
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void **) &p, count * sizeof(T));
+    }
+};
+
+// profiling helpers: bracket a launch with events on ctx->stream
+struct ProfScope {
+    sd_ctx *ctx;
+    const char *name;
+    ProfScope(sd_ctx *c, const char *n) : ctx(c), name(n) {
+        if (ctx->profiling) (void) hipEventRecord(ctx->evStart, ctx->stream);
+    }
+    ~ProfScope() {
+        if (ctx->profiling) {
+            (void) hipEventRecord(ctx->evStop, ctx->stream);
+            (void) hipEventSynchronize(ctx->evStop);
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop);
+            sd_profile_entry &e = ctx->profile[name];
+            e.ms += ms;
+            e.launches += 1;
+        }
+    }
+};
+
+#endif

@@ -1,0 +1,765 @@
+// Smith-Waterman on gfx950: score/end pass, start-position (reverse) pass and banded traceback.
+//
+// Semantics are those of the reference's striped SSE/AVX2 kernels, restated in scalar form in
+// oracle/sd_oracle.cpp (swPass) and derived in DESIGN.md:
+//     Hpre(q) = max(0, G[c-1][q-1] + P, E[q], Fl)        Fl: vertical gap opened inside the same SIMD segment
+//     G(q)    = max(Hpre(q), Ff)                          Ff: exact vertical gap (what the lazy-F loop produces)
+//     E'(q)   = max(E[q]-ge, Hpre(q)-go, 0)               E is opened from Hpre, NOT from G
+//     Fl'     = max(Fl-ge, Hpre(q)-go, 0)  (reset to 0 where q % segLen == 0),  Ff' = max(Ff-ge, G(q)-go, 0)
+// (M/src/alignment/StripedSmithWaterman.cpp:713-871 byte kernel, :1013-1149 word kernel).
+//
+// Mapping to CDNA4: integer DP, no MFMA.  A task (one pair, one pass) is owned by a 32-lane half
+// wavefront; lane l holds RT consecutive query rows in VGPRs and the half-wave sweeps the target as a
+// systolic array (lane l works on column k-l at step k), handing (G, Ff, Fl, residue) of its last row to
+// lane l+1 each step.  The per-task query profile (int8 [21][32*RT]) lives in LDS and is the only
+// indexed operand; every lane reads only its own RT bytes of the row selected by its current target
+// residue.  HBM traffic is the two residue streams (algorithmic bytes qLen + tLen per task), so the
+// kernel is VALU bound; bench.py reports it in GCUPS.
+#include "sd_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "../host/sd_host.h"
+
+namespace {
+
+struct SwTask {
+    uint64_t qOff;     // absolute index (into the residue array) of the first scanned query residue
+    uint64_t tOff;     // absolute index of the first scanned target residue
+    int32_t n;         // query rows used
+    int32_t tL;        // target columns scanned
+    int32_t qStep;     // +1 forward, -1 reverse pass
+    int32_t tStep;
+    int32_t segLen;    // ceil(n / lanes) of the reference kernel being reproduced
+    uint32_t slot;     // output slot
+    uint64_t boundOff; // offset into the strip boundary workspace (multi-strip tasks only)
+};
+
+template <int RT>
+__global__ void __launch_bounds__(64)
+sw_score_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
+                const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
+                int go, int ge, int32_t *__restrict__ out, uint2 *__restrict__ boundary) {
+    constexpr int ROWS = 32 * RT;          // rows per strip
+    constexpr int WORDS = RT / 4;          // profile dwords per lane per residue
+    __shared__ uint32_t prof[2][21][ROWS / 4];
+    __shared__ int8_t smat[441];
+    for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
+    __syncthreads();
+
+    const int grp = threadIdx.x >> 5;
+    const int l = threadIdx.x & 31;
+    const uint32_t taskId = blockIdx.x * 2 + grp;
+    SwTask tk;
+    if (taskId < nTasks) {
+        tk = tasks[taskId];
+    } else {
+        tk.n = 0; tk.tL = 0; tk.qOff = 0; tk.tOff = 0; tk.qStep = 1; tk.tStep = 1; tk.segLen = 1; tk.slot = 0; tk.boundOff = 0;
+    }
+    const int n = tk.n, tL = tk.tL;
+    const int nStrips = (n + ROWS - 1) / ROWS;
+
+    int bestVal = 0, bestCol = -1, bestRow = 0;
+
+    for (int strip = 0; strip < nStrips; strip++) {
+        const int q0 = strip * ROWS + l * RT;
+        // ---- build this lane's slice of the query profile (SmithWaterman::createQueryProfile, :163-187)
+        uint32_t segMask = 0;
+        {
+            int8_t *pb = (int8_t *) &prof[grp][0][0];
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                const int qi = q0 + r;
+                const bool valid = qi < n;
+                int res = 20, cb = 0;
+                if (valid) {
+                    const int64_t idx = (int64_t) tk.qOff + (int64_t) qi * tk.qStep;
+                    res = qRes[idx];
+                    cb = qBias[idx];
+                }
+                if (valid && (qi % tk.segLen) == 0) segMask |= (1u << r);
+#pragma unroll
+                for (int a = 0; a < 21; a++) {
+                    int v = valid ? (int) smat[a * 21 + res] + cb : -64;
+                    pb[a * ROWS + l * RT + r] = (int8_t) v;
+                }
+            }
+        }
+        int H[RT], E[RT];
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            H[r] = 0;
+            E[r] = 0;
+        }
+        int outG = 0, outFf = 0, outFl = 0, curT = 20, prevInG = 0;
+        const bool firstStrip = (strip == 0);
+        const bool lastStrip = (strip == nStrips - 1);
+        uint2 *bnd = boundary + tk.boundOff;
+        if (!firstStrip) __threadfence();   // boundary values of the previous strip must be visible
+        const int steps = (n > 0 && tL > 0) ? tL + 31 : 0;
+        for (int k = 0; k < steps; k++) {
+            const int c = k - l;
+            int inG = __shfl_up(outG, 1, 32);
+            int inFf = __shfl_up(outFf, 1, 32);
+            int inFl = __shfl_up(outFl, 1, 32);
+            int inT = __shfl_up(curT, 1, 32);
+            const bool active = (c >= 0) && (c < tL);
+            if (l == 0) {
+                inG = 0; inFf = 0; inFl = 0;
+                if (active) {
+                    inT = tRes[(int64_t) tk.tOff + (int64_t) c * tk.tStep];
+                    if (!firstStrip) {
+                        unsigned long long w = __hip_atomic_load((unsigned long long *) &bnd[c], __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+                        inG = (int) (w & 0xFFFFu);
+                        inFf = (int) ((w >> 16) & 0xFFFFu);
+                        inFl = (int) ((w >> 32) & 0xFFFFu);
+                    }
+                }
+            }
+            if (active) {
+                curT = inT;
+                int diag = (c == 0) ? 0 : prevInG;
+                prevInG = inG;
+                int Fl = inFl, Ff = inFf;
+                uint32_t pw[WORDS];
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) pw[w] = prof[grp][curT][l * WORDS + w];
+                int cm = 0;
+#pragma unroll
+                for (int r = 0; r < RT; r++) {
+                    const int s = (int) (int8_t) (pw[r >> 2] >> (8 * (r & 3)));
+                    if (segMask & (1u << r)) Fl = 0;
+                    const int old = H[r];
+                    const int h = diag + s;
+                    const int hpre = max(max(h, E[r]), Fl);
+                    const int g = max(hpre, Ff);
+                    const int open = hpre - go;
+                    E[r] = max(max(E[r] - ge, open), 0);
+                    Fl = max(max(Fl - ge, open), 0);
+                    Ff = max(max(Ff - ge, g - go), 0);
+                    H[r] = g;
+                    diag = old;
+                    cm = max(cm, (g << 5) | (31 - r));
+                }
+                outG = H[RT - 1];
+                outFf = Ff;
+                outFl = Fl;
+                if (l == 31 && !lastStrip) {
+                    unsigned long long w = (unsigned long long) (uint32_t) outG | ((unsigned long long) (uint32_t) outFf << 16) |
+                                           ((unsigned long long) (uint32_t) outFl << 32);
+                    __hip_atomic_store((unsigned long long *) &bnd[c], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const int colVal = cm >> 5;
+                if (colVal > bestVal) {
+                    bestVal = colVal;
+                    bestCol = c;
+                    bestRow = q0 + 31 - (cm & 31);
+                }
+            }
+        }
+    }
+    // ---- reduce over the 32 lanes: max value, then smallest column, then smallest row
+    unsigned long long key = ((unsigned long long) (uint32_t) bestVal << 40) |
+                             ((unsigned long long) (uint32_t) (0xFFFFF - (bestCol < 0 ? 0xFFFFF : bestCol)) << 20) |
+                             (unsigned long long) (uint32_t) (0xFFFFF - bestRow);
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(key, off, 32);
+        key = o > key ? o : key;
+    }
+    if (l == 0 && taskId < nTasks) {
+        const int v = (int) (key >> 40);
+        const int col = 0xFFFFF - (int) ((key >> 20) & 0xFFFFF);
+        const int row = 0xFFFFF - (int) (key & 0xFFFFF);
+        out[3 * tk.slot + 0] = v;
+        out[3 * tk.slot + 1] = (v == 0 || col == 0xFFFFF) ? -1 : col;
+        out[3 * tk.slot + 2] = (v == 0) ? n - 1 : row;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Banded traceback, one thread per alignment: SmithWaterman::banded_sw (StripedSmithWaterman.cpp:1348-1600)
+// with its band-coordinate bookkeeping kept literally (what the band-edge cells hold decides ties).
+// One launch evaluates one band width; the host doubles the band of the tasks whose maximum has not
+// reached the alignment score (the reference's do/while, :1492-1493).
+// ---------------------------------------------------------------------------------------------
+struct TbTask {
+    uint64_t qAbs;      // absolute index of query[qStart]
+    uint64_t tAbs;      // absolute index of target[tStart]
+    int32_t qLen, tLen; // sub-rectangle
+    int32_t score;
+    int32_t band;
+    int32_t maxv;       // carried over band doublings
+    uint32_t slot;
+    uint64_t intOff;    // scratch: 3*(width+1) ints
+    uint64_t dirOff;    // scratch: width_d*qLen*3 bytes
+    uint64_t btOff;     // output (reversed while walking, fixed up at the end)
+};
+
+__global__ void __launch_bounds__(64)
+sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
+                    const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
+                    int go, int ge, int32_t *__restrict__ ints, int8_t *__restrict__ dirs, char *__restrict__ bt,
+                    int32_t *__restrict__ res /* per slot: btLen (-2 = band too small, -1 = traceback error), identical */) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nTasks) return;
+    TbTask tk = tasks[id];
+    const int band = tk.band;
+    const int qLen = tk.qLen, tLen = tk.tLen;
+    const long long width = (long long) band * 2 + 3, width_d = (long long) band * 2 + 1;
+    int32_t *h_b = ints + tk.intOff;
+    int32_t *e_b = h_b + (width + 1);
+    int32_t *h_c = e_b + (width + 1);
+    int8_t *direction = dirs + tk.dirOff;
+    const uint8_t *q = qRes + tk.qAbs;
+    const int8_t *cb = qBias + tk.qAbs;
+    const uint8_t *t = tRes + tk.tAbs;
+    int maxv = tk.maxv;
+    for (long long j = 0; j <= width; j++) {
+        h_b[j] = 0;
+        e_b[j] = 0;
+        h_c[j] = 0;
+    }
+    for (int i = 0; i < qLen; i++) {
+        int beg = 0, end = tLen - 1, u = 0;
+        int j = i - band;
+        beg = beg > j ? beg : j;
+        j = i + band;
+        end = end < j ? end : j;
+        const long long edge = end + 1 < width - 1 ? end + 1 : width - 1;
+        int f = 0;
+        h_b[0] = 0; e_b[0] = 0; h_b[edge] = 0; e_b[edge] = 0; h_c[0] = 0;
+        int8_t *dl = direction + width_d * i * 3;
+        const int8_t *mrow = mat + 21 * q[i];
+        const int cbi = cb[i];
+        const int xi = (i - band) > 0 ? (i - band) : 0;          // set_u / set_d offset of row i
+        const int xim = (i - 1 - band) > 0 ? (i - 1 - band) : 0; // of row i-1
+        for (j = beg; j <= end; j++) {
+            u = j - xi + 1;
+            const int e = j - xim + 1;
+            const int b = (j - 1) - xi + 1;
+            const int d = (j - 1) - xim + 1;
+            const int de = (j - xi) * 3, df = de + 1, dh = de + 2;
+            int temp1 = i == 0 ? -go : h_b[e] - go;
+            int temp2 = i == 0 ? -ge : e_b[e] - ge;
+            e_b[u] = temp1 > temp2 ? temp1 : temp2;
+            const int8_t dirE = temp1 > temp2 ? 3 : 2;
+            dl[de] = dirE;
+            temp1 = h_c[b] - go;
+            temp2 = f - ge;
+            f = temp1 > temp2 ? temp1 : temp2;
+            const int8_t dirF = temp1 > temp2 ? 5 : 4;
+            dl[df] = dirF;
+            const int f1 = f > 0 ? f : 0;
+            const int e1 = e_b[u] > 0 ? e_b[u] : 0;
+            temp1 = e1 > f1 ? e1 : f1;
+            temp2 = h_b[d] + mrow[t[j]] + cbi;
+            h_c[u] = temp1 > temp2 ? temp1 : temp2;
+            if (h_c[u] > maxv) maxv = h_c[u];
+            if (temp1 <= temp2) dl[dh] = 1;
+            else dl[dh] = e1 > f1 ? dirE : dirF;
+        }
+        for (j = 1; j <= u; j++) h_b[j] = h_c[j];
+    }
+    tasks[id].maxv = maxv;
+    if (maxv < tk.score) {
+        res[2 * tk.slot] = -2;
+        return;
+    }
+    // traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581)
+    int i = qLen - 1, j = tLen - 1, state = 2;
+    char *o = bt + tk.btOff;
+    int len = 0, ids = 0;
+    const int8_t *dl = direction + width_d * (long long) (qLen - 1) * 3;
+    bool bad = false;
+    while (i > 0 || j > 0) {
+        int x = i - band;
+        x = x > 0 ? x : 0;
+        x = j - x;
+        const int8_t dcode = (i >= 0 && j >= 0) ? dl[x * 3 + state] : 0;
+        switch (dcode) {
+            case 1: ids += (q[i] == t[j]); --i; --j; state = 2; dl -= width_d * 3; o[len++] = 'M'; break;
+            case 2: --i; state = 0; dl -= width_d * 3; o[len++] = 'I'; break;
+            case 3: --i; state = 2; dl -= width_d * 3; o[len++] = 'I'; break;
+            case 4: --j; state = 1; o[len++] = 'D'; break;
+            case 5: --j; state = 2; o[len++] = 'D'; break;
+            default: bad = true; break;
+        }
+        if (bad) break;
+    }
+    if (bad || i != 0 || j != 0) {
+        res[2 * tk.slot] = -1;
+        return;
+    }
+    ids += (q[0] == t[0]);
+    o[len++] = 'M';
+    for (int a = 0, z = len - 1; a < z; a++, z--) {
+        char tmp = o[a];
+        o[a] = o[z];
+        o[z] = tmp;
+    }
+    res[2 * tk.slot] = len;
+    res[2 * tk.slot + 1] = ids;
+}
+
+int rtClass(int n) {
+    if (n <= 128) return 4;
+    if (n <= 256) return 8;
+    if (n <= 512) return 16;
+    return 32;
+}
+
+template <int RT>
+void launchScore(sd_ctx *ctx, const SwTask *dTasks, uint32_t n, const sd_seqset *q, const sd_seqset *t,
+                 const int8_t *dMat, int go, int ge, int32_t *dOut, uint2 *dBound) {
+    if (n == 0) return;
+    dim3 grid((n + 1) / 2), block(64);
+    hipLaunchKernelGGL(sw_score_kernel<RT>, grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes, dMat,
+                       go, ge, dOut, dBound);
+}
+
+// run a list of score tasks (any mix of sizes); results land in hOut[3*slot..]
+int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, const sd_seqset *t, const int8_t *dMat,
+                  int go, int ge, std::vector<int32_t> &hOut, uint32_t nSlots, uint64_t *cells) {
+    hOut.assign((size_t) nSlots * 3, 0);
+    if (tasks.empty()) return SD_OK;
+    // order: RT class, then by tL (two tasks share a wavefront) -- LPT-style, biggest first
+    std::sort(tasks.begin(), tasks.end(), [](const SwTask &a, const SwTask &b) {
+        int ca = rtClass(a.n), cb = rtClass(b.n);
+        if (ca != cb) return ca < cb;
+        if (a.tL != b.tL) return a.tL > b.tL;
+        return a.slot < b.slot;
+    });
+    uint64_t boundTotal = 0;
+    for (size_t i = 0; i < tasks.size(); i++) {
+        *cells += (uint64_t) tasks[i].n * (uint64_t) tasks[i].tL;
+        if (tasks[i].n > 1024) {
+            tasks[i].boundOff = boundTotal;
+            boundTotal += (uint64_t) tasks[i].tL;
+        } else {
+            tasks[i].boundOff = 0;
+        }
+    }
+    DevBuf<SwTask> dTasks;
+    DevBuf<int32_t> dOut;
+    DevBuf<uint2> dBound;
+    SD_HIP(ctx, dTasks.alloc(tasks.size()));
+    SD_HIP(ctx, dOut.alloc((size_t) nSlots * 3));
+    SD_HIP(ctx, dBound.alloc(std::max<uint64_t>(boundTotal, 1)));
+    SD_HIP(ctx, hipMemcpyAsync(dTasks.p, tasks.data(), tasks.size() * sizeof(SwTask), hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(ctx, hipMemsetAsync(dOut.p, 0, (size_t) nSlots * 3 * sizeof(int32_t), ctx->stream));
+    size_t begin = 0;
+    while (begin < tasks.size()) {
+        int c = rtClass(tasks[begin].n);
+        size_t end = begin;
+        while (end < tasks.size() && rtClass(tasks[end].n) == c) end++;
+        uint32_t cnt = (uint32_t) (end - begin);
+        {
+            ProfScope ps(ctx, "sw_score");
+            switch (c) {
+                case 4: launchScore<4>(ctx, dTasks.p + begin, cnt, q, t, dMat, go, ge, dOut.p, dBound.p); break;
+                case 8: launchScore<8>(ctx, dTasks.p + begin, cnt, q, t, dMat, go, ge, dOut.p, dBound.p); break;
+                case 16: launchScore<16>(ctx, dTasks.p + begin, cnt, q, t, dMat, go, ge, dOut.p, dBound.p); break;
+                default: launchScore<32>(ctx, dTasks.p + begin, cnt, q, t, dMat, go, ge, dOut.p, dBound.p); break;
+            }
+        }
+        SD_HIP(ctx, hipGetLastError());
+        begin = end;
+    }
+    SD_HIP(ctx, hipMemcpyAsync(hOut.data(), dOut.p, (size_t) nSlots * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+int sdFail(sd_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->lastError = buf;
+    else fprintf(stderr, "spacedust_gpu: %s\n", buf);
+    return code;
+}
+
+extern "C" {
+
+int sd_ctx_create(int device, sd_ctx **out) {
+    if (out == nullptr) return SD_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        fprintf(stderr, "spacedust_gpu: no HIP device visible (%s); this library has no CPU fallback\n",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return SD_ENODEVICE;
+    }
+    if (device < 0 || device >= count) return SD_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return SD_ENODEVICE;
+    sd_ctx *c = new sd_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SD_EHIP;
+    }
+    (void) hipEventCreate(&c->evStart);
+    (void) hipEventCreate(&c->evStop);
+    (void) hipGetDeviceProperties(&c->prop, device);
+    *out = c;
+    return SD_OK;
+}
+
+void sd_ctx_destroy(sd_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    if (ctx->evStart) (void) hipEventDestroy(ctx->evStart);
+    if (ctx->evStop) (void) hipEventDestroy(ctx->evStop);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *sd_last_error(sd_ctx *ctx) { return ctx ? ctx->lastError.c_str() : "no context"; }
+
+int sd_device_name(sd_ctx *ctx, char *buf, size_t cap) {
+    if (!ctx || !buf || cap == 0) return SD_EINVAL;
+    snprintf(buf, cap, "%s (%s, %d CUs)", ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount);
+    return SD_OK;
+}
+
+int sd_synchronize(sd_ctx *ctx) {
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_profile_enable(sd_ctx *ctx, int on) {
+    ctx->profiling = on != 0;
+    return SD_OK;
+}
+int sd_profile_reset(sd_ctx *ctx) {
+    ctx->profile.clear();
+    return SD_OK;
+}
+int sd_profile_get(sd_ctx *ctx, const char *name, double *totalMs, uint64_t *launches) {
+    auto it = ctx->profile.find(name);
+    if (it == ctx->profile.end()) {
+        *totalMs = 0;
+        *launches = 0;
+        return SD_OK;
+    }
+    *totalMs = it->second.ms;
+    *launches = it->second.launches;
+    return SD_OK;
+}
+int sd_profile_names(sd_ctx *ctx, char *buf, size_t cap) {
+    std::string s;
+    for (auto &kv : ctx->profile) {
+        if (!s.empty()) s += ",";
+        s += kv.first;
+    }
+    snprintf(buf, cap, "%s", s.c_str());
+    return SD_OK;
+}
+
+int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offsets, uint32_t n, const int8_t *swCompBias,
+                     sd_seqset **out) {
+    if (!ctx || !residues || !offsets || !out) return SD_EINVAL;
+    (void) hipSetDevice(ctx->device);
+    sd_seqset *s = new sd_seqset();
+    s->ctx = ctx;
+    s->n = n;
+    s->total = offsets[n];
+    s->hOff.assign(offsets, offsets + n + 1);
+    s->hRes.assign(residues, residues + s->total);
+    if (swCompBias) s->hBias.assign(swCompBias, swCompBias + s->total);
+    else s->hBias.assign(s->total, 0);
+    s->hMinBias.assign(n, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        int m = 0;
+        for (uint64_t x = offsets[i]; x < offsets[i + 1]; x++) m = std::min(m, (int) s->hBias[x]);
+        s->hMinBias[i] = m;
+    }
+    const size_t pad = 64;
+    if (hipMalloc((void **) &s->dRes, s->total + pad) != hipSuccess || hipMalloc((void **) &s->dBias, s->total + pad) != hipSuccess ||
+        hipMalloc((void **) &s->dOff, (n + 1) * sizeof(uint64_t)) != hipSuccess) {
+        sd_seqset_destroy(s);
+        return sdFail(ctx, SD_ENOMEM, "sd_seqset_create: device allocation of %llu bytes failed", (unsigned long long) s->total);
+    }
+    SD_HIP(ctx, hipMemcpy(s->dRes, residues, s->total, hipMemcpyHostToDevice));
+    SD_HIP(ctx, hipMemcpy(s->dBias, s->hBias.data(), s->total, hipMemcpyHostToDevice));
+    SD_HIP(ctx, hipMemcpy(s->dOff, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    *out = s;
+    return SD_OK;
+}
+
+void sd_seqset_destroy(sd_seqset *s) {
+    if (!s) return;
+    if (s->dRes) (void) hipFree(s->dRes);
+    if (s->dBias) (void) hipFree(s->dBias);
+    if (s->dOff) (void) hipFree(s->dOff);
+    delete s;
+}
+
+int sd_sw_last_cells(sd_ctx *ctx, uint64_t *f, uint64_t *r, uint64_t *t) {
+    if (f) *f = ctx->cellsFwd;
+    if (r) *r = ctx->cellsRev;
+    if (t) *t = ctx->cellsTb;
+    return SD_OK;
+}
+
+int sd_sw_score_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                      uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, int lanes, int reverse,
+                      const int32_t *qEnd, const int32_t *tEnd, int32_t *out) {
+    if (!ctx || !par || !queries || !targets || (lanes != 16 && lanes != 32)) return SD_EINVAL;
+    (void) hipSetDevice(ctx->device);
+    DevBuf<int8_t> dMat;
+    SD_HIP(ctx, dMat.alloc(441));
+    SD_HIP(ctx, hipMemcpy(dMat.p, par->matrix, 441, hipMemcpyHostToDevice));
+    std::vector<SwTask> tasks;
+    tasks.reserve(nPairs);
+    for (uint32_t i = 0; i < nPairs; i++) {
+        const uint64_t qo = queries->hOff[pairQ[i]], to = targets->hOff[pairT[i]];
+        const int qL = (int) (queries->hOff[pairQ[i] + 1] - qo), tL = (int) (targets->hOff[pairT[i] + 1] - to);
+        SwTask tk;
+        if (!reverse) {
+            tk.qOff = qo; tk.tOff = to; tk.n = qL; tk.tL = tL; tk.qStep = 1; tk.tStep = 1;
+        } else {
+            if (qEnd[i] < 0 || tEnd[i] < 0 || qEnd[i] >= qL || tEnd[i] >= tL) return sdFail(ctx, SD_EINVAL, "bad end position for pair %u", i);
+            tk.qOff = qo + qEnd[i]; tk.tOff = to + tEnd[i]; tk.n = qEnd[i] + 1; tk.tL = tEnd[i] + 1; tk.qStep = -1; tk.tStep = -1;
+        }
+        tk.segLen = std::max(1, (tk.n + lanes - 1) / lanes);
+        tk.slot = i;
+        tk.boundOff = 0;
+        if (tk.n > 0 && tk.tL > 0) tasks.push_back(tk);
+    }
+    std::vector<int32_t> h;
+    uint64_t cells = 0;
+    int rc = runScoreTasks(ctx, tasks, queries, targets, dMat.p, par->gapOpen, par->gapExtend, h, nPairs, &cells);
+    if (rc != SD_OK) return rc;
+    if (reverse) ctx->cellsRev = cells; else ctx->cellsFwd = cells;
+    for (uint32_t i = 0; i < nPairs; i++) {
+        int v = h[3 * i], col = h[3 * i + 1], row = h[3 * i + 2];
+        out[3 * i] = v;
+        if (!reverse) {
+            out[3 * i + 1] = col;
+            out[3 * i + 2] = row;
+        } else {
+            out[3 * i + 1] = col < 0 ? -1 : tEnd[i] - col;   // scan position -> target index
+            out[3 * i + 2] = row;                            // rows counted from qEnd downwards (reference: qStart = qEnd - read)
+        }
+    }
+    return SD_OK;
+}
+
+int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                      uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
+                      sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed) {
+    if (!ctx || !par || !queries || !targets || !out) return SD_EINVAL;
+    (void) hipSetDevice(ctx->device);
+    const int go = par->gapOpen, ge = par->gapExtend;
+    ctx->cellsFwd = ctx->cellsRev = ctx->cellsTb = 0;
+    sd::Evaluer ev;
+    sd::initEvaluer(ev, par->dbResidues);
+    int matMin = 0;
+    for (int i = 0; i < 441; i++) matMin = std::min(matMin, (int) par->matrix[i]);
+    DevBuf<int8_t> dMat;
+    SD_HIP(ctx, dMat.alloc(441));
+    SD_HIP(ctx, hipMemcpy(dMat.p, par->matrix, 441, hipMemcpyHostToDevice));
+    if (btUsed) *btUsed = 0;
+    uint64_t btPos = 0;
+
+    std::vector<int> qLv(nPairs), tLv(nPairs);
+    for (uint32_t i = 0; i < nPairs; i++) {
+        if (pairQ[i] >= queries->n || pairT[i] >= targets->n) return sdFail(ctx, SD_EINVAL, "pair %u out of range", i);
+        qLv[i] = (int) (queries->hOff[pairQ[i] + 1] - queries->hOff[pairQ[i]]);
+        tLv[i] = (int) (targets->hOff[pairT[i] + 1] - targets->hOff[pairT[i]]);
+        sd_sw_result &r = out[i];
+        r.score = 0; r.qStart = -1; r.qEnd = -1; r.tStart = -1; r.tEnd = -1; r.identical = 0; r.btLen = 0; r.flags = 0;
+        r.evalue = 0.0; r.btOffset = 0;
+    }
+    // ---- identity pairs: scoreIdentical (StripedSmithWaterman.cpp:1675-1710), host side, O(L)
+    for (uint32_t i = 0; i < nPairs; i++) {
+        if (!(isIdentity && isIdentity[i])) continue;
+        const int L = tLv[i];
+        if (qLv[i] != L) return sdFail(ctx, SD_EINVAL, "scoreIdentical has different lengths for pair %u", i);
+        const uint8_t *q = queries->hRes.data() + queries->hOff[pairQ[i]];
+        const int8_t *cb = queries->hBias.data() + queries->hOff[pairQ[i]];
+        const uint8_t *t = targets->hRes.data() + targets->hOff[pairT[i]];
+        short score = 0;
+        for (int p = 0; p < L; p++) score += (short) (par->matrix[t[p] * 21 + q[p]] + cb[p]);
+        sd_sw_result &r = out[i];
+        r.score = (int32_t) (uint32_t) (int) score;
+        r.qStart = par->swMode == 0 ? -1 : 0;
+        r.tStart = par->swMode == 0 ? -1 : 0;
+        r.qEnd = L - 1; r.tEnd = L - 1; r.identical = L; r.btLen = L;
+        r.evalue = sd::computeEvalue(ev, (double) (uint32_t) r.score, qLv[i]);
+        if (btPool) {
+            if (btPos + (uint64_t) L > btCap) return sdFail(ctx, SD_ENOMEM, "backtrace pool too small");
+            memset(btPool + btPos, 'M', L);
+            r.btOffset = btPos;
+            btPos += L;
+        }
+    }
+    // ---- pass 1: forward, byte-kernel lane structure (32 lanes)
+    std::vector<SwTask> tasks;
+    auto fwdTask = [&](uint32_t i, int lanes) {
+        SwTask tk;
+        tk.qOff = queries->hOff[pairQ[i]]; tk.tOff = targets->hOff[pairT[i]];
+        tk.n = qLv[i]; tk.tL = tLv[i]; tk.qStep = 1; tk.tStep = 1;
+        tk.segLen = std::max(1, (tk.n + lanes - 1) / lanes);
+        tk.slot = i; tk.boundOff = 0;
+        return tk;
+    };
+    for (uint32_t i = 0; i < nPairs; i++)
+        if (!(isIdentity && isIdentity[i]) && qLv[i] > 0 && tLv[i] > 0) tasks.push_back(fwdTask(i, 32));
+    std::vector<int32_t> h;
+    int rc = runScoreTasks(ctx, tasks, queries, targets, dMat.p, go, ge, h, nPairs, &ctx->cellsFwd);
+    if (rc != SD_OK) return rc;
+    // ---- pass 2: pairs whose byte score saturates (max + bias >= 255, :881,916,360-368) rerun with the
+    //      word kernel's 16-lane structure
+    std::vector<SwTask> tasks2;
+    std::vector<uint8_t> word(nPairs, 0);
+    for (size_t x = 0; x < tasks.size(); x++) {
+        const uint32_t i = tasks[x].slot;
+        const int bias = std::abs(matMin) + std::abs(queries->hMinBias[pairQ[i]]);
+        if (h[3 * i] + bias >= 255) {
+            word[i] = 1;
+            tasks2.push_back(fwdTask(i, 16));
+        }
+    }
+    std::vector<int32_t> h2;
+    rc = runScoreTasks(ctx, tasks2, queries, targets, dMat.p, go, ge, h2, nPairs, &ctx->cellsFwd);
+    if (rc != SD_OK) return rc;
+    // ---- gates after the score pass (:389-398)
+    std::vector<SwTask> rtasks;
+    for (size_t x = 0; x < tasks.size(); x++) {
+        const uint32_t i = tasks[x].slot;
+        const int32_t *src = word[i] ? &h2[3 * i] : &h[3 * i];
+        sd_sw_result &r = out[i];
+        r.score = src[0];
+        r.tEnd = src[1];
+        r.qEnd = src[2];
+        r.flags = word[i] ? 1 : 0;
+        if (word[i] && r.tEnd == -1) r.tEnd = 0;   // the word kernel initialises end_ref to 0 (:962)
+        if (r.tEnd == -1) { r.evalue = 0.0; continue; }
+        r.evalue = sd::computeEvalue(ev, r.score, qLv[i]);
+        const bool lowE = r.evalue > par->evalThr;
+        const float qCov = sd::computeCov(0, r.qEnd, qLv[i]), tCov = sd::computeCov(0, r.tEnd, tLv[i]);
+        const bool lowCov = !sd::hasCoverage(par->covThr, par->covMode, qCov, tCov);
+        if (par->swMode == 0 || lowE || lowCov) continue;
+        SwTask tk;
+        tk.qOff = queries->hOff[pairQ[i]] + r.qEnd; tk.tOff = targets->hOff[pairT[i]] + r.tEnd;
+        tk.n = r.qEnd + 1; tk.tL = r.tEnd + 1; tk.qStep = -1; tk.tStep = -1;
+        tk.segLen = std::max(1, (tk.n + (word[i] ? 16 : 32) - 1) / (word[i] ? 16 : 32));
+        tk.slot = i; tk.boundOff = 0;
+        rtasks.push_back(tk);
+    }
+    // ---- pass 3: start positions (reverse pass, :400-476)
+    std::vector<int32_t> hr;
+    rc = runScoreTasks(ctx, rtasks, queries, targets, dMat.p, go, ge, hr, nPairs, &ctx->cellsRev);
+    if (rc != SD_OK) return rc;
+    std::vector<TbTask> tb;
+    for (size_t x = 0; x < rtasks.size(); x++) {
+        const uint32_t i = rtasks[x].slot;
+        sd_sw_result &r = out[i];
+        if (hr[3 * i] != r.score) {
+            r.flags |= 2;
+            return sdFail(ctx, SD_EMISMATCH, "Score of forward/backward SW differ: %d %d (pair %u)", r.score, hr[3 * i], i);
+        }
+        r.tStart = r.tEnd - hr[3 * i + 1];
+        r.qStart = r.qEnd - hr[3 * i + 2];
+        const float qCov = sd::computeCov(r.qStart, r.qEnd, qLv[i]), tCov = sd::computeCov(r.tStart, r.tEnd, tLv[i]);
+        const bool lowCov = !sd::hasCoverage(par->covThr, par->covMode, qCov, tCov);
+        if (par->swMode == 1 || lowCov) continue;
+        TbTask t;
+        t.qAbs = queries->hOff[pairQ[i]] + r.qStart;
+        t.tAbs = targets->hOff[pairT[i]] + r.tStart;
+        t.qLen = r.qEnd - r.qStart + 1;
+        t.tLen = r.tEnd - r.tStart + 1;
+        t.score = r.score;
+        t.band = std::abs(t.tLen - t.qLen) + 1;
+        t.maxv = 0;
+        t.slot = i;
+        tb.push_back(t);
+    }
+    // ---- pass 4: banded traceback in chunks that fit the scratch budget
+    if (!tb.empty() && btPool == nullptr) return sdFail(ctx, SD_EINVAL, "swMode 2 needs a backtrace pool");
+    const uint64_t SCRATCH_BUDGET = 6ull << 30;
+    std::vector<TbTask> pending = tb;
+    while (!pending.empty()) {
+        std::sort(pending.begin(), pending.end(), [](const TbTask &a, const TbTask &b) {
+            uint64_t wa = (uint64_t) (2 * a.band + 1) * a.qLen, wb = (uint64_t) (2 * b.band + 1) * b.qLen;
+            if (wa != wb) return wa > wb;
+            return a.slot < b.slot;
+        });
+        std::vector<TbTask> next;
+        size_t pos = 0;
+        while (pos < pending.size()) {
+            uint64_t nInts = 0, nDir = 0, nBt = 0;
+            size_t end = pos;
+            while (end < pending.size()) {
+                TbTask &t = pending[end];
+                const uint64_t width = (uint64_t) t.band * 2 + 3, width_d = (uint64_t) t.band * 2 + 1;
+                const uint64_t ai = 3 * (width + 1), ad = width_d * (uint64_t) t.qLen * 3 + 16, ab = (uint64_t) t.qLen + t.tLen + 2;
+                if (end > pos && (nInts * 4 + nDir + ai * 4 + ad) > SCRATCH_BUDGET) break;
+                t.intOff = nInts; t.dirOff = nDir; t.btOff = nBt;
+                nInts += ai; nDir += ad; nBt += ab;
+                ctx->cellsTb += width_d * (uint64_t) t.qLen;
+                end++;
+            }
+            const uint32_t cnt = (uint32_t) (end - pos);
+            DevBuf<TbTask> dT;
+            DevBuf<int32_t> dInts, dRes;
+            DevBuf<int8_t> dDir;
+            DevBuf<char> dBt;
+            if (dT.alloc(cnt) != hipSuccess || dInts.alloc(nInts) != hipSuccess || dDir.alloc(nDir) != hipSuccess ||
+                dBt.alloc(nBt) != hipSuccess || dRes.alloc((size_t) nPairs * 2) != hipSuccess)
+                return sdFail(ctx, SD_ENOMEM, "traceback scratch allocation failed (%llu bytes)", (unsigned long long) (nInts * 4 + nDir));
+            SD_HIP(ctx, hipMemcpyAsync(dT.p, &pending[pos], cnt * sizeof(TbTask), hipMemcpyHostToDevice, ctx->stream));
+            {
+                ProfScope ps(ctx, "sw_traceback");
+                hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 63) / 64), dim3(64), 0, ctx->stream, dT.p, cnt,
+                                   queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, dInts.p, dDir.p, dBt.p, dRes.p);
+            }
+            SD_HIP(ctx, hipGetLastError());
+            std::vector<TbTask> back(cnt);
+            std::vector<char> hbt(nBt);
+            std::vector<int32_t> hres((size_t) nPairs * 2);
+            SD_HIP(ctx, hipMemcpyAsync(back.data(), dT.p, cnt * sizeof(TbTask), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipMemcpyAsync(hbt.data(), dBt.p, nBt, hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipMemcpyAsync(hres.data(), dRes.p, hres.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (uint32_t x = 0; x < cnt; x++) {
+                const TbTask &t = back[x];
+                const int len = hres[2 * t.slot];
+                if (len == -2) {
+                    TbTask nt = t;
+                    nt.band = t.band * 2;
+                    next.push_back(nt);
+                } else if (len < 0) {
+                    return sdFail(ctx, SD_EHIP, "Trace back error for pair %u", t.slot);
+                } else {
+                    sd_sw_result &r = out[t.slot];
+                    if (btPos + (uint64_t) len > btCap) return sdFail(ctx, SD_ENOMEM, "backtrace pool too small");
+                    memcpy(btPool + btPos, hbt.data() + t.btOff, len);
+                    r.btOffset = btPos;
+                    r.btLen = len;
+                    r.identical = hres[2 * t.slot + 1];
+                    btPos += len;
+                }
+            }
+            pos = end;
+        }
+        pending.swap(next);
+    }
+    if (btUsed) *btUsed = btPos;
+    return SD_OK;
+}
+
+}  // extern "C"

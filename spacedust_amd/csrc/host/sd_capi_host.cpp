@@ -1,0 +1,173 @@
+// C-ABI wrappers of the host-side stages (sd_host_* in include/spacedust_gpu.h).
+#include "sd_host.h"
+#include "spacedust_gpu.h"
+
+#include <cmath>
+#include <cstring>
+#include <unistd.h>
+
+struct sd_host {
+    sd::SubMat blosum2, ungapped2, seed8;
+    sd::ExtMatrix two, three;
+    bool haveTwo = false, haveThree = false;
+    int threads = 1;
+};
+
+struct sd_host_index {
+    sd::TargetIndex idx;
+};
+
+extern "C" {
+
+int sd_host_create(int threads, sd_host **out) {
+    if (!out) return SD_EINVAL;
+    sd_host *h = new sd_host();
+    h->threads = threads > 0 ? threads : 1;
+    sd::initSubMat(h->blosum2, sd::MAT_BLOSUM62, 2.0f, 0.0f);      // Alignment.cpp:152
+    sd::initSubMat(h->ungapped2, sd::MAT_BLOSUM62, 2.0f, -0.2f);   // Prefiltering.cpp:69,991
+    sd::initSubMat(h->seed8, sd::MAT_VTML80, 8.0f, -0.2f);         // Prefiltering.cpp:68,991
+    *out = h;
+    return SD_OK;
+}
+
+void sd_host_destroy(sd_host *h) { delete h; }
+
+static const sd::SubMat &pick(sd_host *h, int which) {
+    return which == 0 ? h->blosum2 : (which == 1 ? h->seed8 : h->ungapped2);
+}
+
+int sd_host_matrix(sd_host *h, int which, int8_t *out, double *pBack, uint8_t *aa2num) {
+    const sd::SubMat &m = pick(h, which);
+    for (int i = 0; i < 21; i++)
+        for (int j = 0; j < 21; j++) out[i * 21 + j] = (int8_t) m.sub[i][j];
+    if (pBack) memcpy(pBack, m.pBack, sizeof(double) * 21);
+    if (aa2num) memcpy(aa2num, m.aa2num, 256);
+    return SD_OK;
+}
+
+int sd_host_map_sequence(sd_host *h, const char *ascii, uint64_t len, uint8_t *out) {
+    sd::mapSequence(h->blosum2, ascii, len, out);
+    return SD_OK;
+}
+
+int sd_host_comp_bias(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
+                      int8_t *swBias, int8_t *diagBias, int16_t *kmerBias) {
+    uint8_t seedPos[8];
+    const int span = sd::spacedPattern(kmerSize, seedPos);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(h->threads)
+    for (uint32_t i = 0; i < n; i++) {
+        const uint8_t *s = residues + offsets[i];
+        const int L = (int) (offsets[i + 1] - offsets[i]);
+        if (swBias) sd::swCompBias8(h->blosum2, s, L, swBias + offsets[i]);
+        if (diagBias) sd::diagCompBias8(h->seed8, s, L, diagBias + offsets[i]);
+        if (kmerBias) {
+            for (int x = 0; x < L; x++) kmerBias[offsets[i] + x] = 0;
+            sd::kmerThrBias16(h->seed8, s, L, seedPos, kmerSize, span, kmerBias + offsets[i]);
+        }
+    }
+    return SD_OK;
+}
+
+int sd_host_index_build(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
+                        int kmerThr, int mask, double maskProb, sd_host_index **out) {
+    if (!out || (kmerSize != 6 && kmerSize != 7)) return SD_EINVAL;
+    sd_host_index *ix = new sd_host_index();
+    sd::buildTargetIndex(h->seed8, residues, offsets, n, kmerSize, kmerThr, mask != 0, maskProb, h->threads, ix->idx);
+    *out = ix;
+    return SD_OK;
+}
+
+int sd_host_index_info(sd_host_index *ix, uint64_t *tableSize, uint64_t *nEntries, uint64_t *maskedResidues) {
+    if (tableSize) *tableSize = ix->idx.tableSize;
+    if (nEntries) *nEntries = ix->idx.entrySeq.size();
+    if (maskedResidues) *maskedResidues = ix->idx.maskedResidues;
+    return SD_OK;
+}
+
+int sd_host_index_arrays(sd_host_index *ix, const uint32_t **kmerOffsets, const uint32_t **entrySeq,
+                         const uint16_t **entryPos, const uint8_t **maskedResidues) {
+    if (kmerOffsets) *kmerOffsets = ix->idx.offsets.data();
+    if (entrySeq) *entrySeq = ix->idx.entrySeq.data();
+    if (entryPos) *entryPos = ix->idx.entryPos.data();
+    if (maskedResidues) *maskedResidues = ix->idx.masked.data();
+    return SD_OK;
+}
+
+void sd_host_index_destroy(sd_host_index *ix) { delete ix; }
+
+int sd_host_ext_matrix(sd_host *h, int wordLen, const int16_t **score, const uint16_t **index, uint32_t *size) {
+    if (wordLen == 2) {
+        if (!h->haveTwo) {
+            sd::buildExtMatrix(h->seed8, 2, h->two, h->threads);
+            h->haveTwo = true;
+        }
+        *score = h->two.score.data(); *index = h->two.index.data(); *size = h->two.size;
+        return SD_OK;
+    }
+    if (wordLen == 3) {
+        if (!h->haveThree) {
+            sd::buildExtMatrix(h->seed8, 3, h->three, h->threads);
+            h->haveThree = true;
+        }
+        *score = h->three.score.data(); *index = h->three.index.data(); *size = h->three.size;
+        return SD_OK;
+    }
+    return SD_EINVAL;
+}
+
+int sd_host_kmer_threshold(float sensitivity, int kmerSize) { return sd::kmerThreshold(sensitivity, kmerSize); }
+
+unsigned sd_host_bin_size(uint64_t dbSize, uint64_t l2CacheSize) {
+    if (l2CacheSize == 0) {
+        // Util::getL2CacheSize (M/src/commons/Util.cpp:317-332)
+        long v = -1;
+#ifdef _SC_LEVEL2_CACHE_SIZE
+        v = sysconf(_SC_LEVEL2_CACHE_SIZE);
+#endif
+        l2CacheSize = v > 0 ? (uint64_t) v : 262144;
+    }
+    return sd::diagonalBinSize(dbSize, l2CacheSize);
+}
+
+static double chLogGamma(double x) {
+    // Lanczos approximation of R/src/util/ClusterHits.cpp:23-63
+    static const double r10 = 10.900511;
+    static const double dk[11] = {2.48574089138753565546e-5, 1.05142378581721974210, -3.45687097222016235469,
+                                  4.51227709466894823700, -2.98285225323576655721, 1.05639711577126713077,
+                                  -1.95428773191645869583e-1, 1.70970543404441224307e-2, -5.71926117404305781283e-4,
+                                  4.63399473359905636708e-6, -2.71994908488607703910e-9};
+    static const double gc = 2 * sqrt(exp(1.0) / M_PI);
+    if (x < 0.5) return log(M_PI) - log(std::abs(sin(M_PI * x))) - chLogGamma(1 - x);
+    if (x == 1) return 0.0;
+    double sum = dk[0];
+    sum += dk[1] / (x + 0);
+    sum += dk[2] / (x + 1);
+    sum += dk[3] / (x + 2);
+    sum += dk[4] / (x + 3);
+    sum += dk[5] / (x + 4);
+    sum += dk[6] / (x + 5);
+    sum += dk[7] / (x + 6);
+    sum += dk[8] / (x + 7);
+    sum += dk[9] / (x + 8);
+    sum += dk[10] / (x + 9);
+    return log(gc) + (x - 0.5) * log(x + r10 - 0.5) - (x - 0.5) + log(sum);
+}
+
+int sd_host_lgamma_table(double *out, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) out[i] = chLogGamma(i * 1.0);
+    return SD_OK;
+}
+
+double sd_host_evalue(uint64_t dbResidues, double score, double qLen) {
+    sd::Evaluer e;
+    sd::initEvaluer(e, dbResidues);
+    return sd::computeEvalue(e, score, qLen);
+}
+
+double sd_host_bitscore(double score) {
+    sd::Evaluer e;
+    sd::initEvaluer(e, 1);
+    return sd::computeBitScore(e, score);
+}
+
+}  // extern "C"

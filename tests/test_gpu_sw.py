@@ -1,0 +1,111 @@
+"""GPU parity: Smith-Waterman HIP kernels (through the C ABI) vs the oracle, bit exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(ps, rng, n_random=150):
+    fam = ps.family
+    pq, pt = [], []
+    # homolog pairs (same family, different proteome), identity pairs, random pairs
+    by_fam = {}
+    for i, f in enumerate(fam):
+        if f >= 0:
+            by_fam.setdefault(int(f), []).append(i)
+    for f, members in by_fam.items():
+        for a in members:
+            for b in members:
+                if a != b:
+                    pq.append(a)
+                    pt.append(b)
+    for i in range(0, ps.n, 7):
+        pq.append(i)
+        pt.append(i)
+    for _ in range(n_random):
+        pq.append(int(rng.integers(ps.n)))
+        pt.append(int(rng.integers(ps.n)))
+    return np.array(pq, np.uint32), np.array(pt, np.uint32)
+
+
+def _seq(ps, i):
+    return ps.residues[int(ps.offsets[i]):int(ps.offsets[i + 1])]
+
+
+def test_sw_score_pass_lanes(gpu, host, oracle, small_proteomes):
+    ps = small_proteomes
+    rng = np.random.default_rng(5)
+    pq, pt = _pairs(ps, rng, 60)
+    pq, pt = pq[:400], pt[:400]
+    sw_bias, _, _ = host.comp_bias(ps.residues, ps.offsets)
+    mat, _, _ = host.matrix(0)
+    ss = gpu.seqset(ps.residues, ps.offsets, sw_bias)
+    par = gpu.sw_params(mat, int(ps.offsets[-1]))
+    m = mat.reshape(21, 21).astype(np.int16)
+    for lanes in (32, 16):
+        out = gpu.sw_score(par, ss, ss, pq, pt, lanes=lanes)
+        for x in range(len(pq)):
+            q, t = _seq(ps, pq[x]), _seq(ps, pt[x])
+            cb = sw_bias[int(ps.offsets[pq[x]]):int(ps.offsets[pq[x] + 1])].astype(np.int16)
+            prof = m[:, q] + cb[None, :]
+            ref = oracle.sw_pass(prof, t, lanes)
+            exp = (ref[0], ref[1] if ref[0] > 0 else -1, ref[2])
+            assert tuple(int(v) for v in out[x]) == exp, (lanes, x, out[x], ref)
+
+
+def test_sw_align_batch_matches_oracle(gpu, host, oracle, small_proteomes):
+    ps = small_proteomes
+    rng = np.random.default_rng(7)
+    pq, pt = _pairs(ps, rng)
+    sw_bias, _, _ = host.comp_bias(ps.residues, ps.offsets)
+    mat, _, _ = host.matrix(0)
+    db = int(ps.offsets[-1])
+    ss = gpu.seqset(ps.residues, ps.offsets, sw_bias)
+    par = gpu.sw_params(mat, db)
+    res, pool = gpu.sw_align(par, ss, ss, pq, pt, identity=(pq == pt))
+    n_bt = 0
+    for x in range(len(pq)):
+        o = oracle.sw_align(_seq(ps, pq[x]), _seq(ps, pt[x]), db, identity=bool(pq[x] == pt[x]))
+        r = res[x]
+        assert int(r['score']) == o['score'], (x, r, o)
+        assert (int(r['qStart']), int(r['qEnd']), int(r['tStart']), int(r['tEnd'])) == \
+               (o['qStart'], o['qEnd'], o['tStart'], o['tEnd']), (x, r, o)
+        assert float(r['evalue']) == o['evalue'], (x, r['evalue'], o['evalue'])
+        assert int(r['btLen']) == o['btLen'], (x, r, o)
+        if o['btLen'] > 0:
+            n_bt += 1
+            bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
+            assert bt == o['backtrace'], (x, bt, o['backtrace'])
+            assert int(r['identical']) == o['identical']
+    assert n_bt > 50
+
+
+def test_sw_long_query_strips(gpu, host, oracle):
+    """queries longer than one 1024-row strip exercise the strip boundary hand-off"""
+    rng = np.random.default_rng(3)
+    bg = np.full(20, 0.05)
+    base = rng.choice(20, 2300, p=bg).astype(np.uint8)
+    mut = base.copy()
+    flip = rng.random(len(mut)) < 0.3
+    mut[flip] = rng.choice(20, int(flip.sum()), p=bg)
+    seqs = [base, mut[:1900], rng.choice(20, 1500, p=bg).astype(np.uint8), base[500:1700].copy()]
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    resid = np.concatenate(seqs)
+    sw_bias, _, _ = host.comp_bias(resid, off)
+    mat, _, _ = host.matrix(0)
+    db = int(off[-1])
+    ss = gpu.seqset(resid, off, sw_bias)
+    par = gpu.sw_params(mat, db, cov_thr=0.0)
+    pq = np.array([0, 1, 0, 2, 3, 0, 1], np.uint32)
+    pt = np.array([1, 0, 2, 0, 0, 3, 3], np.uint32)
+    res, pool = gpu.sw_align(par, ss, ss, pq, pt)
+    for x in range(len(pq)):
+        o = oracle.sw_align(seqs[pq[x]], seqs[pt[x]], db, cov_thr=0.0)
+        r = res[x]
+        got = (int(r['score']), int(r['qStart']), int(r['qEnd']), int(r['tStart']), int(r['tEnd']), int(r['btLen']))
+        exp = (o['score'], o['qStart'], o['qEnd'], o['tStart'], o['tEnd'], o['btLen'])
+        assert got == exp, (x, got, exp)
+        if o['btLen'] > 0:
+            bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
+            assert bt == o['backtrace']
