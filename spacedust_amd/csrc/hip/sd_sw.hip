@@ -200,96 +200,147 @@ struct TbTask {
     uint64_t btOff;     // output (reversed while walking, fixed up at the end)
 };
 
+// Wave-parallel form: a 32-lane half wavefront owns one alignment.  The three band arrays (h_b, e_b, h_c)
+// live in LDS and are indexed exactly like the reference's; a row is processed 32 band cells at a time.
+// The only loop-carried dependence inside a row is the horizontal gap f[j] = max(h_c[j-1]-go, f[j-1]-ge);
+// with T = max(e1, diag) >= 0 it reduces to f[p] = max(-ge, max_{k<p}(T[k]-go+ge*(k+1))) - ge*p, i.e. an
+// exclusive prefix maximum across lanes (cross-lane scan, carried between 32-cell chunks).  Directions are
+// packed to one byte per cell (bit0 dirE==3, bit1 dirF==5, bits2-3: 0 diag / 1 take dirE / 2 take dirF) and
+// written row-major (coalesced); lane 0 then walks the path.
 __global__ void __launch_bounds__(64)
 sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                     const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
-                    int go, int ge, int32_t *__restrict__ ints, int8_t *__restrict__ dirs, char *__restrict__ bt,
+                    int go, int ge, int ldsStride /* ints per array */, int8_t *__restrict__ dirs, char *__restrict__ bt,
                     int32_t *__restrict__ res /* per slot: btLen (-2 = band too small, -1 = traceback error), identical */) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nTasks) return;
-    TbTask tk = tasks[id];
-    const int band = tk.band;
-    const int qLen = tk.qLen, tLen = tk.tLen;
-    const long long width = (long long) band * 2 + 3, width_d = (long long) band * 2 + 1;
-    int32_t *h_b = ints + tk.intOff;
-    int32_t *e_b = h_b + (width + 1);
-    int32_t *h_c = e_b + (width + 1);
-    int8_t *direction = dirs + tk.dirOff;
+    extern __shared__ int32_t lds[];
+    __shared__ int8_t smat[441];
+    for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
+    __syncthreads();
+    const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const uint32_t id = blockIdx.x * 2 + grp;
+    const bool have = id < nTasks;
+    TbTask tk;
+    if (have) tk = tasks[id];
+    else { tk.qLen = 0; tk.tLen = 0; tk.band = 1; tk.score = 0; tk.maxv = 0; tk.qAbs = 0; tk.tAbs = 0; tk.slot = 0; tk.dirOff = 0; tk.btOff = 0; }
+    const int band = tk.band, qLen = tk.qLen, tLen = tk.tLen;
+    const int width = band * 2 + 3, width_d = band * 2 + 1;
+    int32_t *h_b = lds + (size_t) grp * 3 * ldsStride;
+    int32_t *e_b = h_b + ldsStride;
+    int32_t *h_c = e_b + ldsStride;
+    for (int x = l; x <= width && x < ldsStride; x += 32) { h_b[x] = 0; e_b[x] = 0; h_c[x] = 0; }
+    __builtin_amdgcn_wave_barrier();
     const uint8_t *q = qRes + tk.qAbs;
     const int8_t *cb = qBias + tk.qAbs;
     const uint8_t *t = tRes + tk.tAbs;
+    int8_t *direction = dirs + tk.dirOff;
     int maxv = tk.maxv;
-    for (long long j = 0; j <= width; j++) {
-        h_b[j] = 0;
-        e_b[j] = 0;
-        h_c[j] = 0;
-    }
     for (int i = 0; i < qLen; i++) {
-        int beg = 0, end = tLen - 1, u = 0;
-        int j = i - band;
-        beg = beg > j ? beg : j;
-        j = i + band;
-        end = end < j ? end : j;
-        const long long edge = end + 1 < width - 1 ? end + 1 : width - 1;
-        int f = 0;
-        h_b[0] = 0; e_b[0] = 0; h_b[edge] = 0; e_b[edge] = 0; h_c[0] = 0;
-        int8_t *dl = direction + width_d * i * 3;
-        const int8_t *mrow = mat + 21 * q[i];
+        int beg = 0, end = tLen - 1;
+        int jj = i - band; beg = beg > jj ? beg : jj;
+        jj = i + band; end = end < jj ? end : jj;
+        const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+        if (l == 0) { h_b[0] = 0; e_b[0] = 0; h_b[edge] = 0; e_b[edge] = 0; h_c[0] = 0; }
+        __builtin_amdgcn_wave_barrier();
+        const int xi = (i - band) > 0 ? (i - band) : 0;
+        const int xim = (i - 1 - band) > 0 ? (i - 1 - band) : 0;
+        const int W = end - beg + 1;
+        const int8_t *mrow = smat + 21 * q[i];
         const int cbi = cb[i];
-        const int xi = (i - band) > 0 ? (i - band) : 0;          // set_u / set_d offset of row i
-        const int xim = (i - 1 - band) > 0 ? (i - 1 - band) : 0; // of row i-1
-        for (j = beg; j <= end; j++) {
-            u = j - xi + 1;
-            const int e = j - xim + 1;
-            const int b = (j - 1) - xi + 1;
-            const int d = (j - 1) - xim + 1;
-            const int de = (j - xi) * 3, df = de + 1, dh = de + 2;
-            int temp1 = i == 0 ? -go : h_b[e] - go;
-            int temp2 = i == 0 ? -ge : e_b[e] - ge;
-            e_b[u] = temp1 > temp2 ? temp1 : temp2;
-            const int8_t dirE = temp1 > temp2 ? 3 : 2;
-            dl[de] = dirE;
-            temp1 = h_c[b] - go;
-            temp2 = f - ge;
-            f = temp1 > temp2 ? temp1 : temp2;
-            const int8_t dirF = temp1 > temp2 ? 5 : 4;
-            dl[df] = dirF;
-            const int f1 = f > 0 ? f : 0;
-            const int e1 = e_b[u] > 0 ? e_b[u] : 0;
-            temp1 = e1 > f1 ? e1 : f1;
-            temp2 = h_b[d] + mrow[t[j]] + cbi;
-            h_c[u] = temp1 > temp2 ? temp1 : temp2;
-            if (h_c[u] > maxv) maxv = h_c[u];
-            if (temp1 <= temp2) dl[dh] = 1;
-            else dl[dh] = e1 > f1 ? dirE : dirF;
+        int8_t *dl = direction + (long long) width_d * i;
+        int carry = -ge, prevHc = 0, prevF = 0, uLast = 0;
+        for (int p0 = 0; p0 < W; p0 += 32) {
+            const int p = p0 + l;
+            const bool valid = p < W;
+            const int j = beg + p;
+            const int u = j - xi + 1;
+            int T = 0, S = -(1 << 28), eNew = 0, e1 = 0, diag = 0;
+            bool dirE = false;
+            if (valid) {
+                const int e = j - xim + 1, d = (j - 1) - xim + 1;
+                int t1 = i == 0 ? -go : h_b[e] - go;
+                int t2 = i == 0 ? -ge : e_b[e] - ge;
+                eNew = t1 > t2 ? t1 : t2;
+                dirE = t1 > t2;
+                e1 = eNew > 0 ? eNew : 0;
+                diag = h_b[d] + mrow[t[j]] + cbi;
+                T = e1 > diag ? e1 : diag;
+                S = T - go + ge * (p + 1);
+            }
+            // exclusive prefix max of S over the 32 lanes
+            int incl = S;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                int o = __shfl_up(incl, off, 32);
+                if (l >= off) incl = incl > o ? incl : o;
+            }
+            int excl = __shfl_up(incl, 1, 32);
+            if (l == 0) excl = -(1 << 28);
+            int g = carry > excl ? carry : excl;
+            const int f = g - ge * p;
+            const int hcv = T > f ? T : f;
+            int hcP = __shfl_up(hcv, 1, 32), fP = __shfl_up(f, 1, 32);
+            if (l == 0) { hcP = prevHc; fP = prevF; }
+            if (valid) {
+                const bool dirF = (hcP - go) > (fP - ge);
+                const int f1 = f > 0 ? f : 0;
+                const int tmp1 = e1 > f1 ? e1 : f1;
+                int code = (dirE ? 1 : 0) | (dirF ? 2 : 0);
+                if (!(tmp1 <= diag)) code |= (e1 > f1) ? 4 : 8;
+                dl[j - xi] = (int8_t) code;
+                e_b[u] = eNew;
+                h_c[u] = hcv;
+                maxv = hcv > maxv ? hcv : maxv;
+            }
+            // carries to the next chunk
+            const int cm = __shfl(incl, 31, 32);
+            carry = carry > cm ? carry : cm;
+            prevHc = __shfl(hcv, 31, 32);
+            prevF = __shfl(f, 31, 32);
+            const int lastValid = (W - p0) < 32 ? (W - p0 - 1) : 31;
+            uLast = (beg + p0 + lastValid) - xi + 1;
+            __builtin_amdgcn_wave_barrier();
         }
-        for (j = 1; j <= u; j++) h_b[j] = h_c[j];
+        if (W > 0) {
+            for (int x = 1 + l; x <= uLast; x += 32) h_b[x] = h_c[x];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        int o = __shfl_xor(maxv, off, 32);
+        maxv = o > maxv ? o : maxv;
+    }
+    if (!have || l != 0) return;
     tasks[id].maxv = maxv;
     if (maxv < tk.score) {
         res[2 * tk.slot] = -2;
         return;
     }
     // traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581)
+    __threadfence();
     int i = qLen - 1, j = tLen - 1, state = 2;
     char *o = bt + tk.btOff;
     int len = 0, ids = 0;
-    const int8_t *dl = direction + width_d * (long long) (qLen - 1) * 3;
     bool bad = false;
     while (i > 0 || j > 0) {
+        if (i < 0 || j < 0) { bad = true; break; }
         int x = i - band;
         x = x > 0 ? x : 0;
         x = j - x;
-        const int8_t dcode = (i >= 0 && j >= 0) ? dl[x * 3 + state] : 0;
+        if (x < 0 || x >= width_d) { bad = true; break; }
+        const int code = __hip_atomic_load(&direction[(long long) width_d * i + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int dcode;
+        const int dE = (code & 1) ? 3 : 2, dF = (code & 2) ? 5 : 4;
+        if (state == 0) dcode = dE;
+        else if (state == 1) dcode = dF;
+        else dcode = (code & 4) ? dE : ((code & 8) ? dF : 1);
         switch (dcode) {
-            case 1: ids += (q[i] == t[j]); --i; --j; state = 2; dl -= width_d * 3; o[len++] = 'M'; break;
-            case 2: --i; state = 0; dl -= width_d * 3; o[len++] = 'I'; break;
-            case 3: --i; state = 2; dl -= width_d * 3; o[len++] = 'I'; break;
+            case 1: ids += (q[i] == t[j]); --i; --j; state = 2; o[len++] = 'M'; break;
+            case 2: --i; state = 0; o[len++] = 'I'; break;
+            case 3: --i; state = 2; o[len++] = 'I'; break;
             case 4: --j; state = 1; o[len++] = 'D'; break;
-            case 5: --j; state = 2; o[len++] = 'D'; break;
-            default: bad = true; break;
+            default: --j; state = 2; o[len++] = 'D'; break;
         }
-        if (bad) break;
     }
     if (bad || i != 0 || j != 0) {
         res[2 * tk.slot] = -1;
@@ -690,42 +741,51 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     }
     // ---- pass 4: banded traceback in chunks that fit the scratch budget
     if (!tb.empty() && btPool == nullptr) return sdFail(ctx, SD_EINVAL, "swMode 2 needs a backtrace pool");
-    const uint64_t SCRATCH_BUDGET = 6ull << 30;
+    const uint64_t SCRATCH_BUDGET = 8ull << 30;
+    auto widthClass = [](int band) { int w = band * 2 + 3; return w <= 127 ? 128 : (w <= 511 ? 512 : 2048); };
     std::vector<TbTask> pending = tb;
     while (!pending.empty()) {
-        std::sort(pending.begin(), pending.end(), [](const TbTask &a, const TbTask &b) {
-            uint64_t wa = (uint64_t) (2 * a.band + 1) * a.qLen, wb = (uint64_t) (2 * b.band + 1) * b.qLen;
+        for (size_t x = 0; x < pending.size(); x++)
+            if (pending[x].band * 2 + 3 > 2047)
+                return sdFail(ctx, SD_EUNSUPPORTED, "traceback band %d exceeds the LDS-resident limit (pair %u)", pending[x].band, pending[x].slot);
+        std::sort(pending.begin(), pending.end(), [&](const TbTask &a, const TbTask &b) {
+            int ca = widthClass(a.band), cb = widthClass(b.band);
+            if (ca != cb) return ca < cb;
+            uint64_t wa = (uint64_t) ((2 * a.band + 1 + 31) / 32) * a.qLen, wb = (uint64_t) ((2 * b.band + 1 + 31) / 32) * b.qLen;
             if (wa != wb) return wa > wb;
             return a.slot < b.slot;
         });
         std::vector<TbTask> next;
         size_t pos = 0;
         while (pos < pending.size()) {
-            uint64_t nInts = 0, nDir = 0, nBt = 0;
+            uint64_t nDir = 0, nBt = 0;
             size_t end = pos;
-            while (end < pending.size()) {
+            const int cls = widthClass(pending[pos].band);
+            while (end < pending.size() && widthClass(pending[end].band) == cls) {
                 TbTask &t = pending[end];
-                const uint64_t width = (uint64_t) t.band * 2 + 3, width_d = (uint64_t) t.band * 2 + 1;
-                const uint64_t ai = 3 * (width + 1), ad = width_d * (uint64_t) t.qLen * 3 + 16, ab = (uint64_t) t.qLen + t.tLen + 2;
-                if (end > pos && (nInts * 4 + nDir + ai * 4 + ad) > SCRATCH_BUDGET) break;
-                t.intOff = nInts; t.dirOff = nDir; t.btOff = nBt;
-                nInts += ai; nDir += ad; nBt += ab;
+                const uint64_t width_d = (uint64_t) t.band * 2 + 1;
+                const uint64_t ad = width_d * (uint64_t) t.qLen + 16, ab = (uint64_t) t.qLen + t.tLen + 2;
+                if (end > pos && (nDir + ad) > SCRATCH_BUDGET) break;
+                t.intOff = 0; t.dirOff = nDir; t.btOff = nBt;
+                nDir += ad; nBt += ab;
                 ctx->cellsTb += width_d * (uint64_t) t.qLen;
                 end++;
             }
             const uint32_t cnt = (uint32_t) (end - pos);
             DevBuf<TbTask> dT;
-            DevBuf<int32_t> dInts, dRes;
+            DevBuf<int32_t> dRes;
             DevBuf<int8_t> dDir;
             DevBuf<char> dBt;
-            if (dT.alloc(cnt) != hipSuccess || dInts.alloc(nInts) != hipSuccess || dDir.alloc(nDir) != hipSuccess ||
-                dBt.alloc(nBt) != hipSuccess || dRes.alloc((size_t) nPairs * 2) != hipSuccess)
-                return sdFail(ctx, SD_ENOMEM, "traceback scratch allocation failed (%llu bytes)", (unsigned long long) (nInts * 4 + nDir));
+            if (dT.alloc(cnt) != hipSuccess || dDir.alloc(nDir) != hipSuccess || dBt.alloc(nBt) != hipSuccess ||
+                dRes.alloc((size_t) nPairs * 2) != hipSuccess)
+                return sdFail(ctx, SD_ENOMEM, "traceback scratch allocation failed (%llu bytes)", (unsigned long long) nDir);
             SD_HIP(ctx, hipMemcpyAsync(dT.p, &pending[pos], cnt * sizeof(TbTask), hipMemcpyHostToDevice, ctx->stream));
             {
                 ProfScope ps(ctx, "sw_traceback");
-                hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 63) / 64), dim3(64), 0, ctx->stream, dT.p, cnt,
-                                   queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, dInts.p, dDir.p, dBt.p, dRes.p);
+                const int ldsStride = cls + 1;
+                const size_t ldsBytes = (size_t) 2 * 3 * ldsStride * sizeof(int32_t);
+                hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dT.p, cnt,
+                                   queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, ldsStride, dDir.p, dBt.p, dRes.p);
             }
             SD_HIP(ctx, hipGetLastError());
             std::vector<TbTask> back(cnt);
