@@ -217,3 +217,54 @@ class SeqSet:
             self.ctx.L.sd_seqset_destroy(self.h)
         except Exception:
             pass
+
+
+class Target:
+    """Target side of the prefilter resident in HBM (sd_target): k-mer index, masked lookup, 3-mer tables."""
+
+    def __init__(self, ctx, host, index):
+        self.ctx, self.host, self.index = ctx, host, index
+        s2, i2, _ = host.ext_matrix(2)
+        s3, i3, _ = host.ext_matrix(3)
+        h = C.c_void_p()
+        _check(ctx.h, ctx.L.sd_target_create(ctx.h, index.k, ptr(index.kmer_offsets), ptr(index.entry_seq),
+                                             ptr(index.entry_pos), index.n_entries, ptr(index.masked),
+                                             ptr(index.offsets), index.n, ptr(s2), ptr(i2), ptr(s3), ptr(i3),
+                                             C.byref(h)), 'sd_target_create')
+        self.h = h
+        self.n = index.n
+
+    def __del__(self):
+        try:
+            self.ctx.L.sd_target_destroy(self.h)
+        except Exception:
+            pass
+
+
+def prefilter_params(host, n_targets, kmer_thr=112, max_hits=300, min_diag=15, bin_size=None, cov_mode=2,
+                     cov_thr=0.8, k=6):
+    p = _lib.PrefilterParams()
+    p.kmerSize, p.kmerThr, p.maxHitsPerQuery, p.minDiagScore = k, kmer_thr, max_hits, min_diag
+    p.binSize = bin_size if bin_size is not None else host.bin_size(n_targets)
+    p.covMode, p.covThr = cov_mode, cov_thr
+    m, _, _ = host.matrix(2)
+    for i in range(441):
+        p.ungappedMatrix[i] = int(m[i])
+    return p
+
+
+def prefilter(ctx, target, par, residues, offsets, kmer_bias, diag_bias, identity_id, want_stats=False):
+    """sd_prefilter_batch: returns (hits[nQ, maxHits] structured array, counts[nQ], stats[nQ,4] or None)"""
+    residues = np.ascontiguousarray(residues, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    kb = np.ascontiguousarray(kmer_bias, np.int16)
+    db = np.ascontiguousarray(diag_bias, np.int8)
+    ident = np.ascontiguousarray(identity_id, np.uint32)
+    nq = len(offsets) - 1
+    hits = np.zeros((nq, par.maxHitsPerQuery), _lib.HIT_DTYPE)
+    counts = np.zeros(nq, np.uint32)
+    stats = np.zeros((nq, 4), np.uint64) if want_stats else None
+    _check(ctx.h, ctx.L.sd_prefilter_batch(ctx.h, target.h, C.byref(par), nq, ptr(residues), ptr(offsets), ptr(kb),
+                                           ptr(db), ptr(ident), ptr(hits), ptr(counts), ptr(stats)),
+           'sd_prefilter_batch')
+    return hits, counts, stats

@@ -1,0 +1,825 @@
+// k-mer prefilter on gfx950 (QueryMatcher::matchQuery, M/src/prefiltering/QueryMatcher.cpp:85-211) for a
+// batch of queries.  Integer / byte work bound by HBM (and the 256 MB Infinity Cache for the u32 k-mer
+// offset table); no MFMA.  Stages (SURVEY.md A.1 step numbers):
+//   K1 count_kmers   (3-4)  one wavefront per query position: branch-and-bound product of the two sorted
+//                           3-mer rows, counted with per-lane binary searches
+//   K2 emit_kmers    (4-5)  same enumeration, writes every similar k-mer with its index-list (start,len)
+//   K3 gather_hits   (5)    copies the (seqId,pos) index lists into the hit stream: THE HBM-bound stream
+//                           (6 B read + 6 B written per hit, coalesced within a list)
+//   sort             (6)    stable LSD radix sort of the stream by (query,target) -- keeps stream order
+//                           inside a target, which is what the double-diagonal state machine consumes
+//   K4 match_diag    (6)    per hit: same low-8-bit diagonal as the previous hit of the target, and not the
+//                           same as the previous *matched* one (CacheFriendlyOperations.cpp:185-272)
+//   K5 score_diag    (7)    ungapped Kadane score along each candidate diagonal on the masked targets
+//   K6 keep_max      (8)    first element with the per-target maximum (CacheFriendlyOperations.cpp:350-380)
+//   K7 select_hits   (9-11) per query: score histogram, cut at maxHits, order of the cut = (score desc,
+//                           bin = seqId & (BINSIZE-1), stream position), final (score desc, seqId) order,
+//                           coverage pre-filter (Prefiltering.cpp:856-863)
+// The reference's overflow path (> 2*max(1e6,dbSize) hits per query) and the rescoring path
+// (threshold >= 255) are detected and reported as SD_EUNSUPPORTED -- never silently approximated.
+#include "sd_common.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+
+struct sd_target {
+    sd_ctx *ctx = nullptr;
+    int k = 6;
+    uint32_t nSeq = 0;
+    uint64_t nEntries = 0;
+    uint64_t tableSize = 0;
+    uint32_t *dOffsets = nullptr;
+    uint32_t *dEntrySeq = nullptr;
+    uint16_t *dEntryPos = nullptr;
+    uint8_t *dMasked = nullptr;
+    uint64_t *dSeqOff = nullptr;
+    int16_t *dExt3Score = nullptr;
+    uint16_t *dExt3Index = nullptr;
+    int16_t *dExt2Score = nullptr;
+    uint16_t *dExt2Index = nullptr;
+    std::vector<uint64_t> hSeqOff;
+};
+
+namespace {
+
+constexpr int SPAN6 = 10;
+__constant__ uint8_t c_seed6[6] = {0, 1, 3, 5, 8, 9};   // spaced seed 1101010011 (M/src/commons/Sequence.h:23)
+
+// number of entries >= cutoff in a descending row of n int16
+__device__ __forceinline__ int countGE(const int16_t *__restrict__ row, int n, int cutoff) {
+    int lo = 0, hi = n;   // first index with row[idx] < cutoff
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if ((int) row[mid] >= cutoff) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+struct PosInfo {
+    uint32_t q;
+    int i;
+    bool ok;
+    uint32_t idx0, idx1;
+    int thr;
+};
+
+__device__ __forceinline__ PosInfo decodePos(uint64_t p, const uint64_t *__restrict__ posBase, uint32_t nQ,
+                                             const uint8_t *__restrict__ qRes, const uint64_t *__restrict__ qOff,
+                                             const int16_t *__restrict__ kmerBias, int kmerThr) {
+    PosInfo r;
+    // binary search: last q with posBase[q] <= p
+    uint32_t lo = 0, hi = nQ;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (posBase[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    r.q = lo;
+    r.i = (int) (p - posBase[lo]);
+    const uint8_t *s = qRes + qOff[lo] + r.i;
+    uint8_t w[6];
+    bool hasX = false;
+#pragma unroll
+    for (int x = 0; x < 6; x++) {
+        w[x] = s[c_seed6[x]];
+        hasX |= (w[x] >= 20);
+    }
+    r.ok = !hasX;
+    r.idx0 = w[0] + 20u * w[1] + 400u * w[2];
+    r.idx1 = w[3] + 20u * w[4] + 400u * w[5];
+    int b = kmerBias[qOff[lo] + r.i];
+    int t = kmerThr - b;
+    r.thr = t > 0 ? t : 0;
+    return r;
+}
+
+// K1: count similar k-mers per position
+__global__ void __launch_bounds__(256)
+count_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
+                   const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
+                   const int16_t *__restrict__ ext3Score, uint32_t *__restrict__ kmerCount) {
+    const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= nPos) return;
+    PosInfo pi = decodePos(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr);
+    uint32_t total = 0;
+    if (pi.ok) {
+        const int16_t *row0 = ext3Score + (size_t) pi.idx0 * 8000;
+        const int16_t *row1 = ext3Score + (size_t) pi.idx1 * 8000;
+        const int best1 = row1[0];
+        const int cutoff1 = (int) (short) (pi.thr - best1);
+        const int n0 = countGE(row0, 8000, cutoff1);
+        for (int a = lane; a < n0; a += 64) {
+            const int cutoff2 = (int) (short) (pi.thr - (int) row0[a]);
+            total += (uint32_t) countGE(row1, 8000, cutoff2);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0) kmerCount[p] = total;
+}
+
+// K2: emit k-mers (+ index list start/len, + owning position) in the reference's enumeration order
+__global__ void __launch_bounds__(256)
+emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
+                  const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
+                  const int16_t *__restrict__ ext3Score, const uint16_t *__restrict__ ext3Index,
+                  const uint32_t *__restrict__ idxOffsets, const uint64_t *__restrict__ kmerBase,
+                  uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen, uint32_t *__restrict__ kPos) {
+    const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= nPos) return;
+    PosInfo pi = decodePos(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr);
+    if (!pi.ok) return;
+    const int16_t *row0 = ext3Score + (size_t) pi.idx0 * 8000;
+    const int16_t *row1 = ext3Score + (size_t) pi.idx1 * 8000;
+    const uint16_t *ix0 = ext3Index + (size_t) pi.idx0 * 8000;
+    const uint16_t *ix1 = ext3Index + (size_t) pi.idx1 * 8000;
+    const int best1 = row1[0];
+    const int cutoff1 = (int) (short) (pi.thr - best1);
+    const int n0 = countGE(row0, 8000, cutoff1);
+    uint64_t base = kmerBase[p];
+    for (int a0 = 0; a0 < n0; a0 += 64) {
+        const int a = a0 + lane;
+        uint32_t c = 0;
+        if (a < n0) {
+            const int cutoff2 = (int) (short) (pi.thr - (int) row0[a]);
+            c = (uint32_t) countGE(row1, 8000, cutoff2);
+        }
+        // exclusive scan of c over the 64 lanes
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const uint32_t excl = incl - c;
+        const uint32_t chunkTotal = __shfl(incl, 63, 64);
+        if (a < n0) {
+            const uint32_t k0 = ix0[a];
+            uint64_t w = base + excl;
+            for (uint32_t b = 0; b < c; b++) {
+                const uint32_t kmer = k0 + 8000u * (uint32_t) ix1[b];
+                const uint32_t s = idxOffsets[kmer], e = idxOffsets[kmer + 1];
+                kStart[w + b] = s;
+                kLen[w + b] = e - s;
+                kPos[w + b] = (uint32_t) p;
+            }
+        }
+        base += chunkTotal;
+    }
+}
+
+// K3: gather index lists into the hit stream; key = (qLocal << tBits) | seqId, value = stream index
+__global__ void __launch_bounds__(256)
+gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const uint32_t *__restrict__ kLen,
+                   const uint32_t *__restrict__ kPos, const uint64_t *__restrict__ hitBase,
+                   const uint64_t *__restrict__ posBase, uint32_t nQ, const uint32_t *__restrict__ entrySeq,
+                   const uint16_t *__restrict__ entryPos, int tBits, uint32_t *__restrict__ hitKey,
+                   uint32_t *__restrict__ hitVal, uint16_t *__restrict__ hitDiag) {
+    const uint64_t kidx = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t len = 0, start = 0, q = 0;
+    int i = 0;
+    uint64_t base = 0;
+    if (kidx < nKmers) {
+        len = kLen[kidx];
+        if (len) {
+            start = kStart[kidx];
+            base = hitBase[kidx];
+            const uint64_t p = kPos[kidx];
+            uint32_t lo = 0, hi = nQ;
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (posBase[mid] <= p) lo = mid;
+                else hi = mid;
+            }
+            q = lo;
+            i = (int) (p - posBase[lo]);
+        }
+    }
+    // short lists: each lane copies its own; long lists: the wavefront copies them cooperatively
+    const bool isLong = len > 8;
+    if (len && !isLong) {
+        for (uint32_t x = 0; x < len; x++) {
+            const uint32_t sid = entrySeq[start + x];
+            hitKey[base + x] = (q << tBits) | sid;
+            hitVal[base + x] = (uint32_t) (base + x);
+            hitDiag[base + x] = (uint16_t) (i - (int) entryPos[start + x]);
+        }
+    }
+    unsigned long long longMask = __ballot(isLong);
+    while (longMask) {
+        const int src = __ffsll((long long) longMask) - 1;
+        longMask &= longMask - 1;
+        const uint32_t l2 = __shfl(len, src, 64), s2 = __shfl(start, src, 64), q2 = __shfl(q, src, 64);
+        const int i2 = __shfl(i, src, 64);
+        const uint64_t b2 = ((uint64_t) __shfl((uint32_t) (base >> 32), src, 64) << 32) | __shfl((uint32_t) base, src, 64);
+        for (uint32_t x = lane; x < l2; x += 64) {
+            const uint32_t sid = entrySeq[s2 + x];
+            hitKey[b2 + x] = (q2 << tBits) | sid;
+            hitVal[b2 + x] = (uint32_t) (b2 + x);
+            hitDiag[b2 + x] = (uint16_t) (i2 - (int) entryPos[s2 + x]);
+        }
+    }
+}
+
+// K4: double-diagonal match on the (query,target)-sorted stream
+__device__ __forceinline__ bool flagA(uint64_t s, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val,
+                                      const uint16_t *__restrict__ diag) {
+    const uint8_t d8 = (uint8_t) diag[val[s]];
+    const bool first = (s == 0) || (key[s - 1] != key[s]);
+    const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) diag[val[s - 1]];
+    return d8 == prev;
+}
+
+__global__ void __launch_bounds__(256)
+match_diag_kernel(uint64_t nHits, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val,
+                  const uint16_t *__restrict__ diag, uint8_t *__restrict__ emit) {
+    const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nHits) return;
+    bool e = false;
+    if (flagA(s, key, val, diag)) {
+        e = true;
+        const uint8_t d8 = (uint8_t) diag[val[s]];
+        uint64_t x = s;
+        while (x > 0 && key[x - 1] == key[s]) {
+            x--;
+            if (flagA(x, key, val, diag)) {
+                e = ((uint8_t) diag[val[x]]) != d8;
+                break;
+            }
+        }
+    }
+    emit[s] = e ? 1 : 0;
+}
+
+// K5: ungapped diagonal score (UngappedAlignment.cpp:30-43,416-430); candidates are (key,val) pairs
+__global__ void __launch_bounds__(256)
+score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint32_t *__restrict__ cVal,
+                  const uint16_t *__restrict__ hitDiag, int tBits, const uint8_t *__restrict__ qRes,
+                  const uint64_t *__restrict__ qOff, const int8_t *__restrict__ diagBias,
+                  const uint8_t *__restrict__ tMasked, const uint64_t *__restrict__ tOff, const int8_t *__restrict__ mat,
+                  int32_t *__restrict__ cScore, uint32_t *__restrict__ cLen) {
+    __shared__ int8_t smat[441];
+    for (int x = threadIdx.x; x < 441; x += blockDim.x) smat[x] = mat[x];
+    __syncthreads();
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nCand) return;
+    const uint32_t k = cKey[c];
+    const uint32_t q = k >> tBits, sid = k & ((1u << tBits) - 1);
+    const uint16_t d16 = hitDiag[cVal[c]];
+    const int d = (int) (int16_t) d16;
+    const int qL = (int) (qOff[q + 1] - qOff[q]);
+    const int tL = (int) (tOff[sid + 1] - tOff[sid]);
+    const uint16_t minDist = (uint16_t) min((int) (uint16_t) (0 - d16), (int) (uint16_t) d16);
+    const uint8_t *qs = qRes + qOff[q];
+    const int8_t *qb = diagBias + qOff[q];
+    const uint8_t *ts = tMasked + tOff[sid];
+    int n = 0, q0 = 0, t0 = 0;
+    if (d >= 0 && (int) minDist < qL) {
+        n = min(tL, qL - (int) minDist);
+        q0 = minDist;
+    } else if (d < 0 && (int) minDist < tL) {
+        n = min(tL - (int) minDist, qL);
+        t0 = minDist;
+    }
+    int score = 0, best = 0;
+    for (int x = 0; x < n; x++) {
+        const int qr = qs[q0 + x];
+        score += (int) (int8_t) (smat[qr * 21 + ts[t0 + x]] + qb[q0 + x]);
+        score = score < 0 ? 0 : score;
+        best = score > best ? score : best;
+    }
+    cScore[c] = best;
+    cLen[c] = (uint32_t) n;
+}
+
+// K6: keep the first element holding the per-(query,target) maximum of min(255,score)
+__global__ void __launch_bounds__(256)
+keep_max_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const int32_t *__restrict__ cScore,
+                uint8_t *__restrict__ keep) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nCand) return;
+    const uint32_t k = cKey[c];
+    const int mine = min(255, cScore[c]);
+    bool ok = true;
+    // no earlier element with count >= mine, no later element with count > mine
+    for (uint32_t x = c; x > 0 && cKey[x - 1] == k; x--)
+        if (min(255, cScore[x - 1]) >= mine) { ok = false; break; }
+    if (ok)
+        for (uint32_t x = c + 1; x < nCand && cKey[x] == k; x++)
+            if (min(255, cScore[x]) > mine) { ok = false; break; }
+    keep[c] = ok ? 1 : 0;
+}
+
+// K7: one workgroup per query
+constexpr int SEL_CAP = 4096;
+__device__ __forceinline__ void bitonicSort(unsigned long long *keys, uint32_t *pay, int n /* power of two */) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < n / 2; t += blockDim.x) {
+                const int lo = (t / stride) * stride * 2 + (t % stride);
+                const int hi = lo + stride;
+                const bool asc = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == asc) {
+                    keys[lo] = b; keys[hi] = a;
+                    const uint32_t pa = pay[lo]; pay[lo] = pay[hi]; pay[hi] = pa;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256)
+select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, into kept arrays */,
+                   const uint32_t *__restrict__ kKey, const uint32_t *__restrict__ kVal,
+                   const int32_t *__restrict__ kScore, const uint16_t *__restrict__ hitDiag, int tBits,
+                   uint32_t binMask, int maxHits, int minDiag, const uint32_t *__restrict__ identityId,
+                   const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, int covMode, float covThr,
+                   sd_hit *__restrict__ outHits, uint32_t *__restrict__ outCount, int *__restrict__ errFlag) {
+    __shared__ unsigned long long keys[SEL_CAP];
+    __shared__ uint32_t pay[SEL_CAP];
+    __shared__ unsigned int hist[256];
+    __shared__ int sThr, sCnt;
+    const uint32_t q = blockIdx.x;
+    if (q >= nQ) return;
+    const uint32_t beg = kStartOfQ[q], end = kStartOfQ[q + 1];
+    const uint32_t ident = identityId[q];
+    const uint32_t dbSizeCap = (uint32_t) maxHits;
+    for (int x = threadIdx.x; x < 256; x += blockDim.x) hist[x] = 0;
+    __syncthreads();
+    for (uint32_t x = beg + threadIdx.x; x < end; x += blockDim.x) atomicAdd(&hist[min(255, kScore[x])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // computeScoreThreshold (QueryMatcher.h:206-216) then max(minDiagScoreThr, .) (QueryMatcher.cpp:154-155)
+        size_t found = 0;
+        int thr = 255;
+        for (thr = 255; thr > 0; thr--) {
+            found += hist[thr];
+            if (found >= (size_t) dbSizeCap) break;
+        }
+        thr = max(minDiag, thr);
+        sThr = thr;
+        sCnt = 0;
+        if (thr >= 255) atomicExch(errFlag, 1);   // rescoring path (QueryMatcher.cpp:163-170) not on the device
+    }
+    __syncthreads();
+    const int thr = sThr;
+    // collect elements >= thr
+    for (uint32_t x = beg + threadIdx.x; x < end; x += blockDim.x) {
+        const int cnt = min(255, kScore[x]);
+        if (cnt >= thr) {
+            const int slot = atomicAdd(&sCnt, 1);
+            if (slot < SEL_CAP) {
+                const uint32_t sid = kKey[x] & ((1u << tBits) - 1);
+                // order of the cut: count desc, bin asc, stream position asc
+                keys[slot] = ((unsigned long long) (255 - cnt) << 56) | ((unsigned long long) (sid & binMask) << 40) |
+                             (unsigned long long) (kVal[x] & 0xFFFFFFFFFFull);
+                pay[slot] = x;
+            }
+        }
+    }
+    __syncthreads();
+    int n = sCnt;
+    if (n > SEL_CAP) {
+        if (threadIdx.x == 0) atomicExch(errFlag, 2);
+        n = SEL_CAP;
+    }
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int x = n + threadIdx.x; x < np2; x += blockDim.x) { keys[x] = ~0ull; pay[x] = 0xFFFFFFFFu; }
+    __syncthreads();
+    if (np2 > 1) bitonicSort(keys, pay, np2);
+    // take the first (maxHits - hasIdentity) with id != identity (getResult, QueryMatcher.cpp:364-420)
+    // done serially by thread 0 into the key array re-used for the final order
+    __shared__ int sTake;
+    if (threadIdx.x == 0) {
+        int current = (ident != 0xFFFFFFFFu) ? 1 : 0;
+        int take = 0;
+        for (int x = 0; x < n && current < maxHits; x++) {
+            const uint32_t e = pay[x];
+            const uint32_t sid = kKey[e] & ((1u << tBits) - 1);
+            if (sid != ident) {
+                pay[take] = e;
+                // final order: |score| desc, seqId asc (QueryMatcher.h:38-48); true score for saturated counts
+                const int sc = kScore[e];
+                const int cnt = min(255, sc);
+                const int prefScore = cnt >= 255 ? sc : cnt;
+                keys[take] = ((unsigned long long) (0x7FFFFFFFu - (uint32_t) prefScore) << 32) | sid;
+                take++;
+                current++;
+            }
+        }
+        sTake = take;
+    }
+    __syncthreads();
+    const int take = sTake;
+    np2 = 1;
+    while (np2 < take) np2 <<= 1;
+    for (int x = take + threadIdx.x; x < np2; x += blockDim.x) { keys[x] = ~0ull; pay[x] = 0xFFFFFFFFu; }
+    __syncthreads();
+    if (np2 > 1) bitonicSort(keys, pay, np2);
+    if (threadIdx.x == 0) {
+        sd_hit *o = outHits + (size_t) q * maxHits;
+        uint32_t w = 0;
+        const float qLen = (float) (qOff[q + 1] - qOff[q]);
+        auto covered = [&](uint32_t sid) {
+            if (!(covThr > 0.0f)) return true;
+            const float tLen = (float) (tOff[sid + 1] - tOff[sid]);
+            switch (covMode) {   // Util::canBeCovered (Util.cpp:477-494), only the modes runSplit applies
+                case 0: return (qLen / tLen >= covThr) && (tLen / qLen >= covThr);
+                case 2: return (tLen / qLen) >= covThr;
+                case 5: return (fminf(tLen, qLen) / fmaxf(tLen, qLen)) >= covThr;
+                default: return true;
+            }
+        };
+        if (ident != 0xFFFFFFFFu) {
+            if (covered(ident)) {
+                o[w].seqId = ident; o[w].score = 65535; o[w].diagonal = 0; o[w].pad = 0;
+                w++;
+            }
+        }
+        for (int x = 0; x < take; x++) {
+            const uint32_t e = pay[x];
+            const uint32_t sid = kKey[e] & ((1u << tBits) - 1);
+            if (!covered(sid)) continue;
+            const int sc = kScore[e];
+            const int cnt = min(255, sc);
+            o[w].seqId = sid;
+            o[w].score = cnt >= 255 ? sc : cnt;
+            o[w].diagonal = hitDiag[kVal[e]];
+            o[w].pad = 0;
+            w++;
+        }
+        outCount[q] = w;
+    }
+}
+
+__global__ void compact_kernel(uint64_t n, const uint8_t *__restrict__ flag, const uint64_t *__restrict__ pos,
+                               const uint32_t *__restrict__ inKey, const uint32_t *__restrict__ inVal,
+                               const int32_t *__restrict__ inScore, uint32_t *__restrict__ outKey,
+                               uint32_t *__restrict__ outVal, int32_t *__restrict__ outScore) {
+    const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n || !flag[s]) return;
+    const uint64_t w = pos[s];
+    outKey[w] = inKey[s];
+    outVal[w] = inVal[s];
+    if (inScore) outScore[w] = inScore[s];
+}
+
+__global__ void flag_to_u64_kernel(uint64_t n, const uint8_t *__restrict__ flag, uint64_t *__restrict__ out) {
+    const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) out[s] = flag[s];
+}
+
+__global__ void widen_kernel(uint64_t n, const uint32_t *__restrict__ in, uint64_t *__restrict__ out) {
+    const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) out[s] = in[s];
+}
+
+// first kept index of every query (keys are sorted): start[q] = lower_bound(q << tBits)
+__global__ void query_bounds_kernel(uint32_t nQ, uint32_t nKept, const uint32_t *__restrict__ kKey, int tBits,
+                                    uint32_t *__restrict__ start) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nQ) return;
+    if (q == nQ) { start[q] = nKept; return; }
+    uint32_t lo = 0, hi = nKept;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if ((kKey[mid] >> tBits) < q) lo = mid + 1;
+        else hi = mid;
+    }
+    start[q] = lo;
+}
+
+// per-query statistics from per-position / per-candidate data
+__global__ void stats_kernel(uint32_t nQ, const uint64_t *__restrict__ posBase, const uint64_t *__restrict__ kmerBase,
+                             const uint64_t *__restrict__ hitBase, uint64_t nKmers, uint64_t nHits,
+                             uint64_t *__restrict__ stats) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nQ) return;
+    const uint64_t p0 = posBase[q], p1 = posBase[q + 1];
+    const uint64_t k0 = kmerBase[p0], k1 = kmerBase[p1];   // kmerBase has nPos+1 entries
+    stats[4 * q] = k1 - k0;
+    const uint64_t h0 = k0 < nKmers ? hitBase[k0] : nHits, h1 = k1 < nKmers ? hitBase[k1] : nHits;
+    stats[4 * q + 1] = h1 - h0;
+}
+
+__global__ void cand_stats_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint32_t *__restrict__ cLen,
+                                  int tBits, unsigned long long *__restrict__ stats) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nCand) return;
+    const uint32_t q = cKey[c] >> tBits;
+    atomicAdd(&stats[4 * q + 2], 1ull);
+    atomicAdd(&stats[4 * q + 3], (unsigned long long) cLen[c]);
+}
+
+template <typename T>
+int exclusiveScan(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, DevBuf<uint8_t> &tmp) {
+    size_t bytes = 0;
+    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int) n, ctx->stream));
+    if (tmp.n < bytes) SD_HIP(ctx, tmp.alloc(bytes + 256));
+    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int) n, ctx->stream));
+    return SD_OK;
+}
+
+inline unsigned gridFor(uint64_t n, unsigned block) { return (unsigned) ((n + block - 1) / block); }
+
+}  // namespace
+
+extern "C" {
+
+int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, const uint32_t *entrySeq,
+                     const uint16_t *entryPos, uint64_t nEntries, const uint8_t *maskedResidues,
+                     const uint64_t *seqOffsets, uint32_t nSeq, const int16_t *ext2Score, const uint16_t *ext2Index,
+                     const int16_t *ext3Score, const uint16_t *ext3Index, sd_target **out) {
+    if (!ctx || !out || !kmerOffsets || !maskedResidues || !seqOffsets || !ext3Score || !ext3Index) return SD_EINVAL;
+    if (kmerSize != 6) return sdFail(ctx, SD_EUNSUPPORTED, "k=%d: only k=6 (targets < 3.35e9 residues) is implemented on the device", kmerSize);
+    (void) hipSetDevice(ctx->device);
+    sd_target *t = new sd_target();
+    t->ctx = ctx;
+    t->k = kmerSize;
+    t->nSeq = nSeq;
+    t->nEntries = nEntries;
+    t->tableSize = 64000000ull;
+    t->hSeqOff.assign(seqOffsets, seqOffsets + nSeq + 1);
+    const uint64_t total = seqOffsets[nSeq];
+    auto up = [&](void **d, const void *h, size_t bytes) -> bool {
+        if (hipMalloc(d, bytes + 64) != hipSuccess) return false;
+        return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    bool ok = up((void **) &t->dOffsets, kmerOffsets, (t->tableSize + 1) * sizeof(uint32_t));
+    ok = ok && up((void **) &t->dEntrySeq, entrySeq, std::max<uint64_t>(nEntries, 1) * sizeof(uint32_t));
+    ok = ok && up((void **) &t->dEntryPos, entryPos, std::max<uint64_t>(nEntries, 1) * sizeof(uint16_t));
+    ok = ok && up((void **) &t->dMasked, maskedResidues, std::max<uint64_t>(total, 1));
+    ok = ok && up((void **) &t->dSeqOff, seqOffsets, (nSeq + 1) * sizeof(uint64_t));
+    ok = ok && up((void **) &t->dExt3Score, ext3Score, (size_t) 8000 * 8000 * sizeof(int16_t));
+    ok = ok && up((void **) &t->dExt3Index, ext3Index, (size_t) 8000 * 8000 * sizeof(uint16_t));
+    if (ext2Score && ext2Index) {
+        ok = ok && up((void **) &t->dExt2Score, ext2Score, (size_t) 400 * 400 * sizeof(int16_t));
+        ok = ok && up((void **) &t->dExt2Index, ext2Index, (size_t) 400 * 400 * sizeof(uint16_t));
+    }
+    if (!ok) {
+        sd_target_destroy(t);
+        return sdFail(ctx, SD_ENOMEM, "sd_target_create: device allocation/upload failed");
+    }
+    *out = t;
+    return SD_OK;
+}
+
+void sd_target_destroy(sd_target *t) {
+    if (!t) return;
+    void *ptrs[] = {t->dOffsets, t->dEntrySeq, t->dEntryPos, t->dMasked, t->dSeqOff, t->dExt3Score, t->dExt3Index,
+                    t->dExt2Score, t->dExt2Index};
+    for (void *p : ptrs)
+        if (p) (void) hipFree(p);
+    delete t;
+}
+
+int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_params *par, uint32_t nQ,
+                       const uint8_t *qResidues, const uint64_t *qOffsets, const int16_t *qKmerBias,
+                       const int8_t *qDiagBias, const uint32_t *identityId, sd_hit *outHits, uint32_t *outCount,
+                       uint64_t *stats) {
+    if (!ctx || !T || !par || !qResidues || !qOffsets || !qKmerBias || !qDiagBias || !identityId || !outHits || !outCount)
+        return SD_EINVAL;
+    if (par->kmerSize != T->k) return sdFail(ctx, SD_EINVAL, "k-mer size mismatch");
+    if (par->minDiagScore < 1) return sdFail(ctx, SD_EUNSUPPORTED, "minDiagScore must be >= 1");
+    if (par->binSize == 0 || (par->binSize & (par->binSize - 1))) return sdFail(ctx, SD_EINVAL, "binSize must be a power of two");
+    (void) hipSetDevice(ctx->device);
+    const int maxHits = (int) std::min<uint64_t>((uint64_t) par->maxHitsPerQuery, T->nSeq);
+    int tBits = 1;
+    while ((1ull << tBits) < T->nSeq) tBits++;
+    const uint32_t maxBatchQ = 1u << std::min(32 - tBits, 16);
+    const uint64_t maxDbMatches = std::max<uint64_t>(1000000, T->nSeq) * 2;   // QueryMatcher.cpp:43-47
+    const uint64_t HIT_BUDGET = 1ull << 28;    // hits per sub-batch (4 GB of key/value double buffers)
+
+    DevBuf<int8_t> dMat;
+    SD_HIP(ctx, dMat.alloc(441));
+    SD_HIP(ctx, hipMemcpy(dMat.p, par->ungappedMatrix, 441, hipMemcpyHostToDevice));
+    DevBuf<int> dErr;
+    SD_HIP(ctx, dErr.alloc(1));
+    DevBuf<uint8_t> scanTmp, sortTmp;
+
+    uint32_t qBeg = 0;
+    uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 1024);
+    while (qBeg < nQ) {
+        uint32_t bq = std::min<uint32_t>(batchQ, nQ - qBeg);
+        // ---- upload the sub-batch
+        const uint64_t r0 = qOffsets[qBeg], r1 = qOffsets[qBeg + bq];
+        std::vector<uint64_t> hOff(bq + 1), hPos(bq + 1);
+        hPos[0] = 0;
+        for (uint32_t x = 0; x <= bq; x++) hOff[x] = qOffsets[qBeg + x] - r0;
+        for (uint32_t x = 0; x < bq; x++) {
+            const int64_t L = (int64_t) (hOff[x + 1] - hOff[x]);
+            hPos[x + 1] = hPos[x] + (uint64_t) std::max<int64_t>(0, L - SPAN6 + 1);
+        }
+        const uint64_t nPos = hPos[bq];
+        DevBuf<uint8_t> dQ;
+        DevBuf<int16_t> dKB;
+        DevBuf<int8_t> dDB;
+        DevBuf<uint64_t> dQOff, dPosBase;
+        DevBuf<uint32_t> dIdent;
+        SD_HIP(ctx, dQ.alloc(r1 - r0 + 64));
+        SD_HIP(ctx, dKB.alloc(r1 - r0 + 64));
+        SD_HIP(ctx, dDB.alloc(r1 - r0 + 64));
+        SD_HIP(ctx, dQOff.alloc(bq + 1));
+        SD_HIP(ctx, dPosBase.alloc(bq + 1));
+        SD_HIP(ctx, dIdent.alloc(bq));
+        SD_HIP(ctx, hipMemcpyAsync(dQ.p, qResidues + r0, r1 - r0, hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(dKB.p, qKmerBias + r0, (r1 - r0) * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(dDB.p, qDiagBias + r0, r1 - r0, hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(dQOff.p, hOff.data(), (bq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(dPosBase.p, hPos.data(), (bq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(dIdent.p, identityId + qBeg, bq * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(ctx, hipMemsetAsync(dErr.p, 0, sizeof(int), ctx->stream));
+
+        uint64_t nKmers = 0, nHits = 0;
+        DevBuf<uint32_t> dKmerCount;
+        DevBuf<uint64_t> dKmerBase;
+        SD_HIP(ctx, dKmerCount.alloc(nPos + 1));
+        SD_HIP(ctx, dKmerBase.alloc(nPos + 1));
+        SD_HIP(ctx, hipMemsetAsync(dKmerCount.p, 0, (nPos + 1) * sizeof(uint32_t), ctx->stream));
+        if (nPos > 0) {
+            {
+                ProfScope ps(ctx, "prefilter_count_kmers");
+                hipLaunchKernelGGL(count_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                   dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p);
+            }
+            DevBuf<uint64_t> dWide;
+            SD_HIP(ctx, dWide.alloc(nPos + 1));
+            hipLaunchKernelGGL(widen_kernel, dim3(gridFor(nPos + 1, 256)), dim3(256), 0, ctx->stream, nPos + 1, dKmerCount.p, dWide.p);
+            int rc = exclusiveScan(ctx, dWide.p, dKmerBase.p, nPos + 1, scanTmp);
+            if (rc != SD_OK) return rc;
+            SD_HIP(ctx, hipMemcpyAsync(&nKmers, dKmerBase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        DevBuf<uint32_t> dKStart, dKLen, dKPos;
+        DevBuf<uint64_t> dHitBase;
+        SD_HIP(ctx, dKStart.alloc(nKmers + 1));
+        SD_HIP(ctx, dKLen.alloc(nKmers + 1));
+        SD_HIP(ctx, dKPos.alloc(nKmers + 1));
+        SD_HIP(ctx, dHitBase.alloc(nKmers + 1));
+        SD_HIP(ctx, hipMemsetAsync(dKLen.p, 0, (nKmers + 1) * sizeof(uint32_t), ctx->stream));
+        if (nKmers > 0) {
+            {
+                ProfScope ps(ctx, "prefilter_emit_kmers");
+                hipLaunchKernelGGL(emit_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                   dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
+                                   dKmerBase.p, dKStart.p, dKLen.p, dKPos.p);
+            }
+            DevBuf<uint64_t> dWide;
+            SD_HIP(ctx, dWide.alloc(nKmers + 1));
+            hipLaunchKernelGGL(widen_kernel, dim3(gridFor(nKmers + 1, 256)), dim3(256), 0, ctx->stream, nKmers + 1, dKLen.p, dWide.p);
+            int rc = exclusiveScan(ctx, dWide.p, dHitBase.p, nKmers + 1, scanTmp);
+            if (rc != SD_OK) return rc;
+            SD_HIP(ctx, hipMemcpyAsync(&nHits, dHitBase.p + nKmers, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        if (nHits > HIT_BUDGET && bq > 1) {   // too many hits for one sort: halve the sub-batch and retry
+            batchQ = std::max<uint32_t>(1, bq / 2);
+            continue;
+        }
+        if (nHits >= 0xFFFFFFFFull) return sdFail(ctx, SD_EUNSUPPORTED, "more than 2^32 hits in one query batch");
+        std::vector<uint64_t> hStats((size_t) bq * 4, 0);
+        DevBuf<uint64_t> dStats;
+        SD_HIP(ctx, dStats.alloc((size_t) bq * 4));
+        SD_HIP(ctx, hipMemsetAsync(dStats.p, 0, (size_t) bq * 4 * sizeof(uint64_t), ctx->stream));
+        hipLaunchKernelGGL(stats_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
+                           dHitBase.p, nKmers, nHits, dStats.p);
+        // reference overflow path check (per query hits >= maxDbMatches)
+        SD_HIP(ctx, hipMemcpyAsync(hStats.data(), dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t x = 0; x < bq; x++)
+            if (hStats[4 * x + 1] >= maxDbMatches)
+                return sdFail(ctx, SD_EUNSUPPORTED, "query %u: %llu index hits reach the reference's overflow path (QueryMatcher.cpp:281-316), not implemented",
+                              qBeg + x, (unsigned long long) hStats[4 * x + 1]);
+
+        uint32_t nCand = 0, nKept = 0;
+        DevBuf<uint32_t> dKeyA, dKeyB, dValA, dValB;
+        DevBuf<uint16_t> dDiag;
+        DevBuf<uint8_t> dEmit;
+        DevBuf<uint64_t> dEmitPos, dEmit64;
+        DevBuf<uint32_t> dCKey, dCVal, dCLen, dKKey, dKVal, dQStart;
+        DevBuf<int32_t> dCScore, dKScore;
+        DevBuf<uint8_t> dKeep;
+        if (nHits > 0) {
+            SD_HIP(ctx, dKeyA.alloc(nHits));
+            SD_HIP(ctx, dKeyB.alloc(nHits));
+            SD_HIP(ctx, dValA.alloc(nHits));
+            SD_HIP(ctx, dValB.alloc(nHits));
+            SD_HIP(ctx, dDiag.alloc(nHits));
+            {
+                ProfScope ps(ctx, "prefilter_gather_hits");
+                hipLaunchKernelGGL(gather_hits_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKStart.p,
+                                   dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, T->dEntrySeq, T->dEntryPos, tBits, dKeyA.p,
+                                   dValA.p, dDiag.p);
+            }
+            {
+                ProfScope ps(ctx, "prefilter_sort_hits");
+                size_t bytes = 0;
+                int endBit = tBits;
+                uint32_t qb = bq - 1;
+                while (qb) { endBit++; qb >>= 1; }
+                endBit = std::min(32, endBit + 0);
+                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, (int) nHits, 0, endBit, ctx->stream));
+                if (sortTmp.n < bytes) SD_HIP(ctx, sortTmp.alloc(bytes + 256));
+                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sortTmp.p, bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, (int) nHits, 0, endBit, ctx->stream));
+            }
+            SD_HIP(ctx, dEmit.alloc(nHits));
+            SD_HIP(ctx, dEmit64.alloc(nHits + 1));
+            SD_HIP(ctx, dEmitPos.alloc(nHits + 1));
+            {
+                ProfScope ps(ctx, "prefilter_match_diag");
+                hipLaunchKernelGGL(match_diag_kernel, dim3(gridFor(nHits, 256)), dim3(256), 0, ctx->stream, nHits, dKeyB.p, dValB.p,
+                                   dDiag.p, dEmit.p);
+            }
+            SD_HIP(ctx, hipMemsetAsync(dEmit64.p + nHits, 0, sizeof(uint64_t), ctx->stream));
+            hipLaunchKernelGGL(flag_to_u64_kernel, dim3(gridFor(nHits, 256)), dim3(256), 0, ctx->stream, nHits, dEmit.p, dEmit64.p);
+            int rc = exclusiveScan(ctx, dEmit64.p, dEmitPos.p, nHits + 1, scanTmp);
+            if (rc != SD_OK) return rc;
+            uint64_t nc64 = 0;
+            SD_HIP(ctx, hipMemcpyAsync(&nc64, dEmitPos.p + nHits, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            nCand = (uint32_t) nc64;
+        }
+        if (nCand > 0) {
+            SD_HIP(ctx, dCKey.alloc(nCand));
+            SD_HIP(ctx, dCVal.alloc(nCand));
+            SD_HIP(ctx, dCScore.alloc(nCand));
+            SD_HIP(ctx, dCLen.alloc(nCand));
+            hipLaunchKernelGGL(compact_kernel, dim3(gridFor(nHits, 256)), dim3(256), 0, ctx->stream, nHits, dEmit.p, dEmitPos.p,
+                               dKeyB.p, dValB.p, (const int32_t *) nullptr, dCKey.p, dCVal.p, (int32_t *) nullptr);
+            {
+                ProfScope ps(ctx, "prefilter_score_diag");
+                hipLaunchKernelGGL(score_diag_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p,
+                                   dDiag.p, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p);
+            }
+            hipLaunchKernelGGL(cand_stats_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCLen.p, tBits,
+                               (unsigned long long *) dStats.p);
+            SD_HIP(ctx, dKeep.alloc(nCand));
+            {
+                ProfScope ps(ctx, "prefilter_keep_max");
+                hipLaunchKernelGGL(keep_max_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCScore.p, dKeep.p);
+            }
+            DevBuf<uint64_t> dK64, dKPos64;
+            SD_HIP(ctx, dK64.alloc(nCand + 1));
+            SD_HIP(ctx, dKPos64.alloc(nCand + 1));
+            SD_HIP(ctx, hipMemsetAsync(dK64.p + nCand, 0, sizeof(uint64_t), ctx->stream));
+            hipLaunchKernelGGL(flag_to_u64_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, (uint64_t) nCand, dKeep.p, dK64.p);
+            int rc = exclusiveScan(ctx, dK64.p, dKPos64.p, (uint64_t) nCand + 1, scanTmp);
+            if (rc != SD_OK) return rc;
+            uint64_t nk64 = 0;
+            SD_HIP(ctx, hipMemcpyAsync(&nk64, dKPos64.p + nCand, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            nKept = (uint32_t) nk64;
+            SD_HIP(ctx, dKKey.alloc(nKept + 1));
+            SD_HIP(ctx, dKVal.alloc(nKept + 1));
+            SD_HIP(ctx, dKScore.alloc(nKept + 1));
+            if (nKept > 0)
+                hipLaunchKernelGGL(compact_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, (uint64_t) nCand, dKeep.p,
+                                   dKPos64.p, dCKey.p, dCVal.p, dCScore.p, dKKey.p, dKVal.p, dKScore.p);
+        } else {
+            SD_HIP(ctx, dKKey.alloc(1));
+            SD_HIP(ctx, dKVal.alloc(1));
+            SD_HIP(ctx, dKScore.alloc(1));
+            SD_HIP(ctx, dDiag.alloc(std::max<uint64_t>(nHits, 1)));
+        }
+        SD_HIP(ctx, dQStart.alloc(bq + 1));
+        hipLaunchKernelGGL(query_bounds_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, nKept, dKKey.p, tBits, dQStart.p);
+        DevBuf<sd_hit> dOut;
+        DevBuf<uint32_t> dOutCount;
+        SD_HIP(ctx, dOut.alloc((size_t) bq * maxHits));
+        SD_HIP(ctx, dOutCount.alloc(bq));
+        {
+            ProfScope ps(ctx, "prefilter_select_hits");
+            hipLaunchKernelGGL(select_hits_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
+                               dDiag.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
+                               par->covMode, par->covThr, dOut.p, dOutCount.p, dErr.p);
+        }
+        SD_HIP(ctx, hipGetLastError());
+        int hErr = 0;
+        std::vector<sd_hit> hOut((size_t) bq * maxHits);
+        SD_HIP(ctx, hipMemcpyAsync(&hErr, dErr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(hOut.data(), dOut.p, hOut.size() * sizeof(sd_hit), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(outCount + qBeg, dOutCount.p, bq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (stats) SD_HIP(ctx, hipMemcpyAsync(stats + (size_t) qBeg * 4, dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hErr == 1) return sdFail(ctx, SD_EUNSUPPORTED, "a query reached the rescoring path (diagonal threshold >= 255, QueryMatcher.cpp:163-170), not implemented on the device");
+        if (hErr == 2) return sdFail(ctx, SD_EUNSUPPORTED, "more than %d tied candidates at the score cut of one query", SEL_CAP);
+        // the caller's rows are par->maxHitsPerQuery wide
+        for (uint32_t x = 0; x < bq; x++)
+            memcpy(outHits + (size_t) (qBeg + x) * par->maxHitsPerQuery, hOut.data() + (size_t) x * maxHits,
+                   (size_t) std::min<uint32_t>(outCount[qBeg + x], maxHits) * sizeof(sd_hit));
+        qBeg += bq;
+    }
+    return SD_OK;
+}
+
+}  // extern "C"
