@@ -357,3 +357,30 @@ def read_fasta(path):
                 cur.append(line)
     seqs.append(''.join(cur))
     return names, seqs
+
+
+def oracle_clusterhits(orc, q_pos, t_pos, strands, pval, nq, d=3, cls=2, alpha=1.0, p_clu=0.01, p_mh=0.01, lg=None):
+    """or_clusterhits for one entry -> (cluster_of[K], member_order[K], sizes[n], pCO[n], pMH[n], n_merges)"""
+    L = orc.lib
+    L.or_clusterhits.restype = C.c_int
+    L.or_clusterhits.argtypes = [C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
+                                                                   C.c_float, C.c_float] + [C.c_void_p] * 8
+    L.or_lgamma_table.argtypes = [C.c_void_p, C.c_uint32]
+    q_pos = np.ascontiguousarray(q_pos, np.uint32)
+    t_pos = np.ascontiguousarray(t_pos, np.uint32)
+    strands = np.ascontiguousarray(strands, np.uint8)
+    pval = np.ascontiguousarray(pval, np.float64)
+    K = len(q_pos)
+    if lg is None:
+        n = int(max(q_pos.max(initial=0), t_pos.max(initial=0), nq, K)) + 8
+        lg = np.zeros(n)
+        L.or_lgamma_table(_ptr(lg), n)
+    cof = np.zeros(max(K, 1), np.uint32)
+    mo = np.zeros(max(K, 1), np.uint32)
+    cs = np.zeros(max(K, 1), np.uint32)
+    pco = np.zeros(max(K, 1))
+    pmh = np.zeros(max(K, 1))
+    nm = C.c_uint32()
+    n = L.or_clusterhits(K, _ptr(q_pos), _ptr(t_pos), _ptr(strands), _ptr(pval), nq, d, cls, alpha, p_clu, p_mh,
+                         _ptr(lg), _ptr(cof), _ptr(mo), _ptr(cs), _ptr(pco), _ptr(pmh), None, C.byref(nm))
+    return cof[:K], mo, cs[:n], pco[:n], pmh[:n], nm.value

@@ -268,3 +268,29 @@ def prefilter(ctx, target, par, residues, offsets, kmer_bias, diag_bias, identit
                                            ptr(db), ptr(ident), ptr(hits), ptr(counts), ptr(stats)),
            'sd_prefilter_batch')
     return hits, counts, stats
+
+
+def clusterhits(ctx, host, hit_off, q_pos, t_pos, strands, pval, nq, max_gene_gap=3, cluster_size=2, alpha=1.0,
+                p_clu_thr=0.01, p_mh_thr=0.01, lgamma=None):
+    """sd_clusterhits_batch over entries [hit_off[p], hit_off[p+1]).  Returns dict of output arrays."""
+    hit_off = np.ascontiguousarray(hit_off, np.uint64)
+    q_pos = np.ascontiguousarray(q_pos, np.uint32)
+    t_pos = np.ascontiguousarray(t_pos, np.uint32)
+    strands = np.ascontiguousarray(strands, np.uint8)
+    pval = np.ascontiguousarray(pval, np.float64)
+    nq = np.ascontiguousarray(nq, np.uint32)
+    n_pairs = len(hit_off) - 1
+    total = int(hit_off[-1])
+    if lgamma is None:
+        need = int(max(int(q_pos.max(initial=0)), int(t_pos.max(initial=0)), int(nq.max(initial=0)), total)) + 8
+        lgamma = host.lgamma_table(need)
+    par = _lib.ChParams(max_gene_gap, cluster_size, alpha, p_clu_thr, p_mh_thr)
+    out = dict(cluster_of=np.full(total, 0xFFFFFFFF, np.uint32), rank=np.zeros(total, np.uint32),
+               n_clusters=np.zeros(n_pairs, np.uint32), pCO=np.zeros(total, np.float64),
+               pMH=np.zeros(total, np.float64), size=np.zeros(total, np.uint32))
+    _check(ctx.h, ctx.L.sd_clusterhits_batch(ctx.h, C.byref(par), n_pairs, ptr(hit_off), ptr(q_pos), ptr(t_pos),
+                                             ptr(strands), ptr(pval), ptr(nq), ptr(lgamma), len(lgamma),
+                                             ptr(out['cluster_of']), ptr(out['rank']), ptr(out['n_clusters']),
+                                             ptr(out['pCO']), ptr(out['pMH']), ptr(out['size'])),
+           'sd_clusterhits_batch')
+    return out
