@@ -98,6 +98,16 @@ def load():
                                          _vp, _vp, _vp]),
         'sd_clusterhits_batch': (C.c_int, [_vp, C.POINTER(ChParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                            C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
+        'sd_agg_create': (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_int,
+                                    C.c_float, C.c_int, C.c_int, C.POINTER(_vp)]),
+        'sd_agg_destroy': (None, [_vp]),
+        'sd_agg_add': (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+        'sd_agg_finish': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        'sd_agg_stats': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        'sd_agg_get': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+        'sd_agg_write_tsv': (C.c_int, [_vp, C.c_char_p, _vp, _vp, _vp, _vp, _vp, _vp, C.c_char_p, _vp, C.c_char_p, _vp,
+                                       C.c_char_p, _vp, C.c_char_p, _vp, C.c_int, C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint64)]),
     }
     missing = []
     for name, (res, args) in sig.items():
@@ -120,7 +130,8 @@ DECLARED_SYMBOLS = [
     'sd_prefilter_batch', 'sd_clusterhits_batch', 'sd_host_create', 'sd_host_destroy', 'sd_host_matrix',
     'sd_host_map_sequence', 'sd_host_comp_bias', 'sd_host_index_build', 'sd_host_index_info', 'sd_host_index_arrays',
     'sd_host_index_destroy', 'sd_host_ext_matrix', 'sd_host_kmer_threshold', 'sd_host_bin_size',
-    'sd_host_lgamma_table', 'sd_host_evalue', 'sd_host_bitscore',
+    'sd_host_lgamma_table', 'sd_host_evalue', 'sd_host_bitscore', 'sd_agg_create', 'sd_agg_destroy', 'sd_agg_add',
+    'sd_agg_finish', 'sd_agg_stats', 'sd_agg_get', 'sd_agg_write_tsv',
 ]
 
 

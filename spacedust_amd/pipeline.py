@@ -1,0 +1,189 @@
+"""clustersearch --search-mode 0 on one GPU: prefilter -> align -> (host aggregation) -> clusterhits -> TSV.
+
+Mirrors R/data/clustersearch.sh:110-152 (`search` = prefilter + align, then besthitbyset / mergeresultsbyset /
+combinehits fused in sd_agg, `clusterhits`, `summarizeresults`).  All hot-path compute goes through the C ABI of
+libsdgpu.so (HIP); this file only moves buffers and sequences the stages."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import _lib, api
+from ._lib import ptr
+
+
+class SetDB:
+    """What createsetdb provides for one side (R/data/createsetdb.sh): numeric sequences, set membership,
+    gene position / strand from the lookup names, set sizes, source names."""
+
+    def __init__(self, residues, offsets, set_id, pos_in_set, strand, n_sets, names=None, sources=None):
+        self.residues = np.ascontiguousarray(residues, np.uint8)
+        self.offsets = np.ascontiguousarray(offsets, np.uint64)
+        self.set_id = np.ascontiguousarray(set_id, np.uint32)
+        self.pos_in_set = np.ascontiguousarray(pos_in_set, np.uint32)
+        self.strand = np.ascontiguousarray(strand, np.uint8)
+        self.n_sets = int(n_sets)
+        self.n = len(self.offsets) - 1
+        self.set_size = np.bincount(self.set_id, minlength=self.n_sets).astype(np.uint32)
+        self.names = names
+        self.sources = sources
+
+    @staticmethod
+    def from_proteomes(ps, prefix='SYN'):
+        return SetDB(ps.residues, ps.offsets, ps.set_id, ps.pos_in_set, ps.strand, ps.n_sets)
+
+    def lengths(self):
+        return (self.offsets[1:] - self.offsets[:-1]).astype(np.int64)
+
+    def default_names(self, prefix='SYN'):
+        if self.names is None:
+            self.names = ['%s%05d_%d_%d_%d_%d' % (prefix, s, p + 1, p, 100 + 1000 * p if st else 999 + 1000 * p,
+                                                 999 + 1000 * p if st else 100 + 1000 * p)
+                          for s, p, st in zip(self.set_id, self.pos_in_set, self.strand)]
+        if self.sources is None:
+            self.sources = ['%s%05d.faa' % (prefix, s) for s in range(self.n_sets)]
+
+
+def _pack_strings(strs):
+    off = np.zeros(len(strs) + 1, np.uint64)
+    np.cumsum([len(s) for s in strs], out=off[1:])
+    return ''.join(strs).encode(), off
+
+
+class ClusterSearch:
+    """One GPU's worth of the workflow.  The target side (index + sequences) stays resident in HBM; query
+    sets are processed in chunks of whole query proteins."""
+
+    def __init__(self, ctx, host, target_db, sensitivity=5.7, max_seqs=300, eval_thr=10.0, cov_mode=2, cov_thr=0.8,
+                 aln_len_thr=30, max_gene_gap=3, cluster_size=2, alpha=1.0, p_clu_thr=0.01, p_mh_thr=0.01,
+                 filter_self_match=True, bin_size=None, verbose=False):
+        self.ctx, self.host, self.T = ctx, host, target_db
+        self.verbose = verbose
+        self.k = 6
+        self.kmer_thr = host.kmer_threshold(sensitivity, self.k)
+        self.max_seqs = max_seqs
+        self.eval_thr, self.cov_mode, self.cov_thr, self.aln_len_thr = eval_thr, cov_mode, cov_thr, aln_len_thr
+        self.ch = dict(max_gene_gap=max_gene_gap, cluster_size=cluster_size, alpha=alpha, p_clu_thr=p_clu_thr,
+                       p_mh_thr=p_mh_thr)
+        self.filter_self_match = filter_self_match
+        self.timing = {}
+        t0 = time.time()
+        self.t_sw_bias, _, _ = host.comp_bias(target_db.residues, target_db.offsets, self.k)
+        self.index = host.build_index(target_db.residues, target_db.offsets, self.k, self.kmer_thr)
+        self.timing['index_build_s'] = time.time() - t0
+        t0 = time.time()
+        self.target = api.Target(ctx, host, self.index)
+        self.t_seqs = ctx.seqset(target_db.residues, target_db.offsets, self.t_sw_bias)
+        self.timing['upload_s'] = time.time() - t0
+        self.pf_par = api.prefilter_params(host, target_db.n, kmer_thr=self.kmer_thr, max_hits=max_seqs, bin_size=bin_size,
+                                           cov_mode=cov_mode, cov_thr=cov_thr, k=self.k)
+        mat, _, _ = host.matrix(0)
+        self.sw_par = ctx.sw_params(mat, int(target_db.offsets[-1]), sw_mode=2, eval_thr=eval_thr, cov_mode=cov_mode,
+                                    cov_thr=cov_thr)
+        self.stats = dict(prefilter_hits=0, pairs=0, cells_fwd=0, cells_rev=0, cells_tb=0, kmers=0, index_hits=0,
+                          diagonals=0, diag_len=0)
+
+    def search(self, Q, same_db=False, chunk_queries=20000, tsv_path=None, canonical=True, query_range=None):
+        """run the workflow for query set DB Q (optionally only proteins [a,b) = a shard of whole query sets)."""
+        L = self.ctx.L
+        T = self.T
+        a0, b0 = query_range if query_range is not None else (0, Q.n)
+        t_all = time.time()
+        agg = C.c_void_p()
+        api._check(None, L.sd_agg_create(ptr(Q.set_id), Q.n, ptr(T.set_id), T.n, Q.n_sets, T.n_sets, self.eval_thr,
+                                         self.cov_mode, self.cov_thr, self.aln_len_thr, 1 if self.filter_self_match else 0,
+                                         C.byref(agg)), 'sd_agg_create')
+        tl = T.lengths()
+        tm = dict(prefilter=0.0, align=0.0, aggregate=0.0, clusterhits=0.0, bias=0.0)
+        for c0 in range(a0, b0, chunk_queries):
+            c1 = min(b0, c0 + chunk_queries)
+            r0, r1 = int(Q.offsets[c0]), int(Q.offsets[c1])
+            res = Q.residues[r0:r1]
+            off = (Q.offsets[c0:c1 + 1] - Q.offsets[c0]).astype(np.uint64)
+            t0 = time.time()
+            sw_b, dg_b, km_b = self.host.comp_bias(res, off, self.k)
+            tm['bias'] += time.time() - t0
+            ident = (np.arange(c0, c1, dtype=np.uint32) if same_db else np.full(c1 - c0, 0xFFFFFFFF, np.uint32))
+            t0 = time.time()
+            hits, cnt, st = api.prefilter(self.ctx, self.target, self.pf_par, res, off, km_b, dg_b, ident, want_stats=True)
+            tm['prefilter'] += time.time() - t0
+            self.stats['kmers'] += int(st[:, 0].sum())
+            self.stats['index_hits'] += int(st[:, 1].sum())
+            self.stats['diagonals'] += int(st[:, 2].sum())
+            self.stats['diag_len'] += int(st[:, 3].sum())
+            n_pairs = int(cnt.sum())
+            self.stats['prefilter_hits'] += n_pairs
+            if n_pairs == 0:
+                continue
+            # pair list in prefilter order (Alignment.cpp:346-379)
+            mask = np.arange(hits.shape[1])[None, :] < cnt[:, None]
+            pair_q_local = np.repeat(np.arange(c1 - c0, dtype=np.uint32), cnt)
+            pair_t = hits['seqId'][mask].astype(np.uint32)
+            ql = (off[1:] - off[:-1]).astype(np.int32)
+            # Alignment::run coverage pre-check (Alignment.cpp:370-373) is the same test the prefilter applied
+            t0 = time.time()
+            qset = self.ctx.seqset(res, off, sw_b)
+            identity = (pair_q_local + np.uint32(c0) == pair_t) if same_db else np.zeros(n_pairs, bool)
+            r, pool = self.ctx.sw_align(self.sw_par, qset, self.t_seqs, pair_q_local, pair_t, identity=identity)
+            tm['align'] += time.time() - t0
+            f, rv, tb = self.ctx.sw_cells()
+            self.stats['cells_fwd'] += f
+            self.stats['cells_rev'] += rv
+            self.stats['cells_tb'] += tb
+            self.stats['pairs'] += n_pairs
+            t0 = time.time()
+            pair_q = (pair_q_local + np.uint32(c0)).astype(np.uint32)
+            qlen_p = ql[pair_q_local].astype(np.int32)
+            tlen_p = tl[pair_t].astype(np.int32)
+            idt = np.ascontiguousarray(identity, np.uint8)
+            api._check(None, L.sd_agg_add(agg, n_pairs, ptr(pair_q), ptr(pair_t), ptr(r), ptr(idt), ptr(qlen_p),
+                                          ptr(tlen_p), ptr(pool)), 'sd_agg_add')
+            tm['aggregate'] += time.time() - t0
+            del qset
+        t0 = time.time()
+        ne, nh = C.c_uint64(), C.c_uint64()
+        L.sd_agg_finish(agg, C.byref(ne), C.byref(nh))
+        ne, nh = ne.value, nh.value
+        entry_off = np.zeros(ne + 1, np.uint64)
+        eq = np.zeros(max(ne, 1), np.uint32)
+        et = np.zeros(max(ne, 1), np.uint32)
+        hq = np.zeros(max(nh, 1), np.uint32)
+        ht = np.zeros(max(nh, 1), np.uint32)
+        pv = np.zeros(max(nh, 1), np.float64)
+        L.sd_agg_get(agg, ptr(entry_off), ptr(eq), ptr(et), ptr(hq), ptr(ht), ptr(pv))
+        hq, ht, pv, eq, et = hq[:nh], ht[:nh], pv[:nh], eq[:ne], et[:ne]
+        tm['aggregate'] += time.time() - t0
+        t0 = time.time()
+        out = None
+        n_clusters = n_cluster_hits = 0
+        if nh > 0:
+            qp = Q.pos_in_set[hq]
+            tp = T.pos_in_set[ht]
+            sd = (Q.strand[hq] | (T.strand[ht] << 1)).astype(np.uint8)
+            nq = Q.set_size[eq]
+            lg_n = int(max(int(Q.set_size.max()), int(T.set_size.max()), int(qp.max()), int(tp.max()))) + 8
+            out = api.clusterhits(self.ctx, self.host, entry_off, qp, tp, sd, pv, nq, lgamma=self.host.lgamma_table(lg_n),
+                                  **self.ch)
+            n_clusters = int(out['n_clusters'].sum())
+            n_cluster_hits = int((out['cluster_of'] != 0xFFFFFFFF).sum())
+        tm['clusterhits'] += time.time() - t0
+        if tsv_path is not None and out is not None:
+            Q.default_names()
+            T.default_names()
+            qn, qno = _pack_strings(Q.names)
+            tn, tno = _pack_strings(T.names)
+            qs, qso = _pack_strings(Q.sources)
+            ts, tso = _pack_strings(T.sources)
+            nc, nhl = C.c_uint64(), C.c_uint64()
+            api._check(None, L.sd_agg_write_tsv(agg, tsv_path.encode(), ptr(out['cluster_of']), ptr(out['rank']),
+                                                ptr(out['n_clusters']), ptr(out['pCO']), ptr(out['pMH']), ptr(out['size']),
+                                                qn, ptr(qno), tn, ptr(tno), qs, ptr(qso), ts, ptr(tso),
+                                                1 if canonical else 0, C.byref(nc), C.byref(nhl)), 'sd_agg_write_tsv')
+        na, nacc = C.c_uint64(), C.c_uint64()
+        L.sd_agg_stats(agg, C.byref(na), C.byref(nacc))
+        L.sd_agg_destroy(agg)
+        tm['total'] = time.time() - t_all
+        return dict(entries=ne, matched_hits=nh, clusters=n_clusters, cluster_hits=n_cluster_hits, aligned=na.value,
+                    accepted=nacc.value, timing=tm, entry_q=eq, entry_t=et, entry_off=entry_off, cluster_out=out,
+                    hit_q=hq, hit_t=ht)
