@@ -226,7 +226,19 @@ class Ref:
         L.ref_bitscore.argtypes = [_vp, C.c_double]
         L.ref_l2_cache_size.restype = C.c_ulong
         self.k = k
-        self.ctx = L.ref_ctx_create((REF_DATA + 'blosum62.out').encode(), (REF_DATA + 'VTML80.out').encode(), k)
+        if os.path.exists(REF_DATA + 'blosum62.out'):
+            a, b = (REF_DATA + 'blosum62.out').encode(), (REF_DATA + 'VTML80.out').encode()
+        else:
+            # no reference tree on this box: hand the matrix *contents* over in the reference's own
+            # "NAME.out:DATA" form (BaseMatrix::unserialize, M/src/commons/BaseMatrix.cpp:189-214)
+            H = C.CDLL(os.path.join(os.path.dirname(HERE), 'spacedust_amd', 'libsdgpu.so'))
+            buf = C.create_string_buffer(1 << 16)
+            H.sd_host_matrix_text.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+            H.sd_host_matrix_text(0, buf, 1 << 16)
+            a = b'blosum62.out:' + buf.value
+            H.sd_host_matrix_text(1, buf, 1 << 16)
+            b = b'VTML80.out:' + buf.value
+        self.ctx = L.ref_ctx_create(a, b, k)
 
     def matrix(self, which):
         m = np.zeros((21, 21), np.int16)

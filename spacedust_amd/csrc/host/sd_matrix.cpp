@@ -293,3 +293,37 @@ unsigned diagonalBinSize(uint64_t dbsize, uint64_t l2) {
 }
 
 }  // namespace sd
+
+// Text form (.out layout) of the embedded matrix data, for tools that take a matrix file's contents
+// (e.g. handing "blosum62.out:<text>" to the reference's SubstitutionMatrix on a box without /root/reference).
+extern "C" int sd_host_matrix_text(int which, char *buf, size_t cap) {
+    const bool bl = which == 0;
+    const char *alphabet = bl ? BLOSUM62_ALPHABET : VTML80_ALPHABET;
+    const char *lambdaStr = bl ? BLOSUM62_LAMBDA : VTML80_LAMBDA;
+    const char **bg = bl ? BLOSUM62_BACKGROUND : VTML80_BACKGROUND;
+    const char *(*hb)[21] = bl ? BLOSUM62_HALFBITS : VTML80_HALFBITS;
+    std::string s = "# Background (precomputed optional):";
+    for (int i = 0; i < 21; i++) {
+        s += " ";
+        s += bg[i];
+    }
+    s += "\n# Lambda     (precomputed optional): ";
+    s += lambdaStr;
+    s += "\n  ";
+    for (int i = 0; i < 21; i++) {
+        s += " ";
+        s += alphabet[i];
+    }
+    s += "\n";
+    for (int i = 0; i < 21; i++) {
+        s += alphabet[i];
+        for (int j = 0; j < 21; j++) {
+            s += " ";
+            s += hb[i][j];
+        }
+        s += "\n";
+    }
+    if (s.size() + 1 > cap) return -1;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int) s.size();
+}
