@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library loads, exports every symbol include/spacedust_gpu.h declares, fails loudly without
+a GPU, and its host stages agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from spacedust_amd import _lib, api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, 'include', 'spacedust_gpu.h')).read()
+    declared = sorted(set(re.findall(r'\b(sd_[a-z0-9_]+)\s*\(', hdr)))
+    L = _lib.load()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert len(declared) >= 38
+    assert set(_lib.DECLARED_SYMBOLS) <= set(declared)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    L = _lib.load()
+    h = C.c_void_p()
+    assert L.sd_ctx_create(0, C.byref(h)) == -1      # SD_ENODEVICE
+    with pytest.raises(api.SdError):
+        api.Context(0)
+
+
+def test_host_stages_match_oracle(host, oracle, small_proteomes):
+    ps = small_proteomes
+    sw, dg, km = host.comp_bias(ps.residues, ps.offsets)
+    m0 = oracle.matrix(0)[0]
+    for i in range(0, ps.n, 17):
+        a, b = int(ps.offsets[i]), int(ps.offsets[i + 1])
+        seq = ps.residues[a:b]
+        cb0, cb1 = oracle.compbias(0, seq), oracle.compbias(1, seq)
+        exp_sw = np.where(cb0 < 0, cb0.astype(np.float64) - 0.5, cb0.astype(np.float64) + 0.5).astype(np.int8)
+        assert (sw[a:b] == exp_sw).all()
+        q = (cb1 / np.float32(4)).astype(np.float32)
+        exp_dg = np.where(cb1 < 0, q.astype(np.float64) - 0.5, q.astype(np.float64) + 0.5).astype(np.float32).astype(np.int8)
+        assert (dg[a:b] == exp_dg).all()
+    idx = host.build_index(ps.residues, ps.offsets)
+    ot = oracle.target(ps.residues, ps.offsets)
+    o, es, ep, mk = ot.dump()
+    assert idx.n_entries == ot.n_entries and (idx.kmer_offsets == o).all() and (idx.entry_seq == es).all()
+    assert (idx.entry_pos == ep).all() and (idx.masked == mk).all()
+    assert host.kmer_threshold(5.7, 6) == 112 and host.bin_size(5898, 2 << 20) == 2 and host.bin_size(10 ** 7, 2 << 20) == 8
+    lg = host.lgamma_table(10)
+    assert abs(lg[5] - np.log(24.0)) < 1e-10 and np.isinf(lg[0])

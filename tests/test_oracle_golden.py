@@ -1,0 +1,146 @@
+"""CPU: the oracle restatement (and the product's host stages, which share the support code) against golden
+vectors produced by the REAL reference code (tools/make_golden.py -> tests/golden/reference_vectors.npz) on the
+reference's own regression input, and against the reference's known answers."""
+import gzip
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import oracle_clusterhits
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(os.path.join(GOLD, 'reference_vectors.npz'))
+
+
+@pytest.fixture(scope='module')
+def examples(oracle):
+    seqs = []
+    for f in ('NC_000913.faa.gz', 'NC_000915.faa.gz'):
+        cur = None
+        with gzip.open(os.path.join(GOLD, 'examples', f), 'rt') as fh:
+            for line in fh:
+                if line.startswith('>'):
+                    if cur is not None:
+                        seqs.append(''.join(cur))
+                    cur = []
+                else:
+                    cur.append(line.rstrip('\n'))
+        seqs.append(''.join(cur))
+    nums = [oracle.map_sequence(s) for s in seqs]
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    return seqs, nums, off
+
+
+def test_matrices_match_reference(oracle, host, gold):
+    for w, name in ((0, 'blosum62_2'), (1, 'vtml80_8_m02'), (2, 'blosum62_2_m02')):
+        m, pb, a2n = oracle.matrix(w)
+        assert (m == gold['mat_' + name]).all()
+        assert (pb == gold['pback_' + name]).all()
+        assert (a2n[:255] == gold['aa2num']).all()
+        hm, hpb, _ = host.matrix(w)
+        assert (hm.reshape(21, 21) == gold['mat_' + name]).all() and (hpb == gold['pback_' + name]).all()
+
+
+def test_composition_bias_bitwise(oracle, gold, examples):
+    _, nums, _ = examples
+    for w in (0, 1):
+        got = np.concatenate([oracle.compbias(w, nums[i]) for i in gold['cb_sample']])
+        assert (got.view(np.uint32) == gold['cb_%d' % w].view(np.uint32)).all()
+
+
+def test_similar_kmer_lists(oracle, gold):
+    off = gold['kmer_list_off']
+    for i in range(len(gold['kmer_thr'])):
+        got = oracle.kmer_list(gold['kmer_windows'][i], int(gold['kmer_thr'][i]))
+        assert (got == gold['kmer_lists'][off[i]:off[i + 1]]).all()
+
+
+def test_extended_matrices(oracle, gold):
+    for w in (2, 3):
+        sc, ix = oracle.ext_matrix(w)
+        d = hashlib.md5(sc.astype(np.int16).tobytes() + ix.astype(np.uint16).tobytes()).digest()
+        assert (np.frombuffer(d, np.uint8) == gold['ext%d_md5' % w]).all()
+
+
+@pytest.fixture(scope='module')
+def target(oracle, examples):
+    _, nums, off = examples
+    return oracle.target(np.concatenate(nums), off)
+
+
+def test_masking_and_index(oracle, gold, examples, target):
+    _, nums, off = examples
+    # reference known answers on the regression input: 1 784 989 index entries, 11 546 masked residues
+    assert (target.n_entries, target.masked_residues) == (1784989, 11546)
+    assert tuple(int(x) for x in gold['index_stats']) == (1784989, 11546)
+    o, es, ep, mk = target.dump()
+    assert (np.nonzero(mk != np.concatenate(nums))[0] == gold['masked_positions']).all()
+    d = hashlib.md5(o.astype(np.uint32).tobytes() + es.tobytes() + ep.tobytes()).digest()
+    assert (np.frombuffer(d, np.uint8) == gold['index_md5']).all()
+
+
+def test_prefilter_hits(oracle, gold, examples, target):
+    _, nums, _ = examples
+    rows = gold['pf_rows']
+    for q in np.unique(rows[:, 0]):
+        exp = rows[rows[:, 0] == q]
+        ids, sc, dg, _ = target.prefilter(nums[q], identity_id=int(q))
+        assert (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all() and (dg == exp[:, 3]).all(), q
+
+
+def test_smith_waterman_alignments(oracle, gold, examples):
+    _, nums, off = examples
+    rows, ev = gold['sw_rows'], gold['sw_eval']
+    bts = gold['sw_bt'].tobytes().decode().split('\n')
+    db = int(off[-1])
+    for x in range(0, len(rows), 3):
+        q, t, score, qs, qe, ts, te, ident, btl = (int(v) for v in rows[x])
+        o = oracle.sw_align(nums[q], nums[t], db, identity=(q == t))
+        assert (o['score'], o['qStart'], o['qEnd'], o['tStart'], o['tEnd'], o['btLen']) == (score, qs, qe, ts, te, btl), x
+        assert o['evalue'] == ev[x]
+        if btl > 0:
+            assert o['backtrace'] == bts[x] and o['identical'] == ident
+
+
+def test_evalue_bitscore(oracle, host, gold):
+    for s, l, e in gold['evalue_samples']:
+        assert oracle.evalue(1861962, s, l) == e
+        assert host.evalue(1861962, s, l) == e
+    for s, b in gold['bitscore_samples']:
+        assert oracle.bitscore(s) == b and host.bitscore(s) == b
+
+
+def test_clusterhits_regression_known_answers(oracle):
+    """the two match entries of run_regression.sh (K = 732, 551): 108 clusters, 308 member hits, 2 clusters with
+    P < 1E-20 (R/util/run_regression.sh:20-23), and the canonical TSV whose md5 equals the reference binary's."""
+    g = np.load(os.path.join(GOLD, 'config1_matches.npz'))
+    off = g['entry_off']
+    names = g['names'].tobytes().decode().split('\n')
+    text = g['hit_text'].tobytes().decode().split('\n')
+    files = ['NC_000913.faa', 'NC_000915.faa']
+    lines, n_clu, n_hit, n_sig = [], 0, 0, 0
+    for e in range(len(off) - 1):
+        a, b = int(off[e]), int(off[e + 1])
+        cof, mo, cs, pco, pmh, _ = oracle_clusterhits(oracle, g['q_pos'][a:b], g['t_pos'][a:b], g['strands'][a:b],
+                                                      g['pval'][a:b], int(g['nq'][e]))
+        w = 0
+        for c in range(len(cs)):
+            lines.append('%s\t%s\t%.3E\t%.3E\t%d\n' % (files[g['entry_q'][e]], files[g['entry_t'][e]], pco[c], pmh[c], cs[c]))
+            n_sig += pco[c] < 1e-20
+            for j in range(cs[c]):
+                h = a + int(mo[w + j])
+                lines.append('%s\t%s\n' % (names[g['hit_t'][h]], text[h]))
+                n_hit += 1
+            w += cs[c]
+        n_clu += len(cs)
+    assert (n_hit, n_sig, n_clu) == (308, 2, 108)
+    lines.sort(key=lambda s: s.encode())
+    assert hashlib.md5(''.join(lines).encode()).hexdigest() == 'abb28ee37bc130a5f09a9f767ef00ccf'
+    assert ''.join(lines) == open(os.path.join(GOLD, 'config1_canonical.tsv')).read()

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Golden fixtures for the aggregation + clusterhits half of the path: the two (query set, target set) match
+entries of the reference's regression input (K = 732 and 551) with the canonical result TSV whose md5
+(abb28ee3...) equals the reference binary's.  Needs scratch/aln_orc.tsv (scratch/t_sw.py orc)."""
+import hashlib, math, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.pyoracle import Oracle, read_fasta, oracle_clusterhits
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+files = ['NC_000913.faa', 'NC_000915.faa']
+names, setof, pos, strand = [], [], [], []
+for si, f in enumerate(files):
+    n, s = read_fasta('/root/reference/examples/' + f)
+    for i, h in enumerate(n):
+        w = h.replace(' ', '').split('#')
+        acc, st, en, sd = w[0], int(w[1]), int(w[2]), w[3]
+        if sd == '-1': st, en = en, st
+        names.append('%s_%d_%d_%d' % (acc, i, st, en)); setof.append(si); pos.append(i); strand.append(1 if st < en else 0)
+setof = np.array(setof)
+setsize = [int((setof == s).sum()) for s in range(2)]
+aln = {}
+for l in open(os.path.join(ROOT, 'scratch', 'aln_orc.tsv')):
+    w = l.rstrip('\n').split('\t'); aln.setdefault(int(w[0]), []).append(w)
+DBL_MIN = sys.float_info.min
+def logpval(ev):
+    if ev == 0: return math.log(DBL_MIN)
+    if 0 < ev < 10e-4: return math.log(ev)
+    return math.log(1 - math.exp(-ev))
+agg = {}
+for q in sorted(aln):
+    by = {}
+    for w in aln[q]: by.setdefault(int(setof[int(w[1])]), []).append(w)
+    o = []
+    for ts in sorted(by):
+        best, be = None, sys.float_info.max
+        for w in by[ts]:
+            ev = float(w[4])
+            if ev < be: be, best = ev, w
+        ww = list(best); ww[2] = '%.3E' % logpval(be); o.append(ww)
+    agg[q] = o
+entries = []
+for qs in range(2):
+    lines = []
+    for q in np.where(setof == qs)[0]: lines += agg.get(int(q), [])
+    byt = {}
+    for w in lines: byt.setdefault(int(setof[int(w[1])]), []).append(w)
+    for ts in sorted(byt):
+        if ts == qs: continue
+        thr = math.log(10e-7); ent = []
+        for w in byt[ts]:
+            if float(w[2]) < thr:
+                ww = list(w); ww[2] = '%.3E' % math.exp(float(w[2])); ent.append(ww)
+        entries.append((qs, ts, ent))
+orc = Oracle(2)
+outl = []; off = [0]; qp = []; tp = []; sd = []; pv = []; hq = []; ht = []; text = []
+for qs, ts, hits in entries:
+    a = np.array([pos[int(w[0])] for w in hits], np.uint32); b = np.array([pos[int(w[1])] for w in hits], np.uint32)
+    s = np.array([strand[int(w[0])] | (strand[int(w[1])] << 1) for w in hits], np.uint8); p = np.array([float(w[2]) for w in hits])
+    qp.append(a); tp.append(b); sd.append(s); pv.append(p); off.append(off[-1] + len(hits))
+    hq += [int(w[0]) for w in hits]; ht += [int(w[1]) for w in hits]; text += ['\t'.join(w[2:]) for w in hits]
+    cof, mo, cs, pco, pmh, nm = oracle_clusterhits(orc, a, b, s, p, setsize[qs])
+    w0 = 0
+    for c in range(len(cs)):
+        outl.append('%s\t%s\t%.3E\t%.3E\t%d\n' % (files[qs], files[ts], pco[c], pmh[c], cs[c]))
+        for j in range(cs[c]):
+            w = hits[mo[w0 + j]]; outl.append('%s\t%s\n' % (names[int(w[1])], '\t'.join(w[2:])))
+        w0 += cs[c]
+outl.sort(key=lambda s: s.encode())
+md5 = hashlib.md5(''.join(outl).encode()).hexdigest()
+assert md5 == 'abb28ee37bc130a5f09a9f767ef00ccf', md5
+open(os.path.join(GOLD, 'config1_canonical.tsv'), 'w').write(''.join(outl))
+np.savez_compressed(os.path.join(GOLD, 'config1_matches.npz'), entry_off=np.array(off, np.uint64), q_pos=np.concatenate(qp),
+                    t_pos=np.concatenate(tp), strands=np.concatenate(sd), pval=np.concatenate(pv), nq=np.array([setsize[e[0]] for e in entries], np.uint32),
+                    entry_q=np.array([e[0] for e in entries]), entry_t=np.array([e[1] for e in entries]), hit_q=np.array(hq), hit_t=np.array(ht),
+                    hit_text=np.frombuffer('\n'.join(text).encode(), np.uint8), names=np.frombuffer('\n'.join(names).encode(), np.uint8))
+print('ok', md5, len(outl))
