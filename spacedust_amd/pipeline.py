@@ -187,3 +187,37 @@ class ClusterSearch:
         return dict(entries=ne, matched_hits=nh, clusters=n_clusters, cluster_hits=n_cluster_hits, aligned=na.value,
                     accepted=nacc.value, timing=tm, entry_q=eq, entry_t=et, entry_off=entry_off, cluster_out=out,
                     hit_q=hq, hit_t=ht)
+
+
+def shard_query_sets(set_residues, world, rank):
+    """Whole query genome sets -> ranks, greedy by residue count (largest first), so a set's hits stay on one rank
+    through besthitbyset -> combinehits -> clusterhits (they group by query set).  Deterministic:
+    every rank computes the same assignment and keeps its own part (sorted)."""
+    order = sorted(range(len(set_residues)), key=lambda s: (-int(set_residues[s]), s))
+    load = [0] * world
+    mine = []
+    for s in order:
+        r = min(range(world), key=lambda x: (load[x], x))
+        load[r] += int(set_residues[s])
+        if r == rank:
+            mine.append(s)
+    return sorted(mine)
+
+
+def gather_results(local_records, dist, device=None):
+    """Final result gather (the only collective on the path): variable-length int64 record arrays from every rank
+    to all ranks -- all_gather of the lengths, then of the padded payloads (RCCL on GPUs, gloo in the CPU tests)."""
+    import torch
+    world = dist.get_world_size()
+    rec = torch.as_tensor(np.ascontiguousarray(local_records, np.int64).reshape(-1))
+    if device is not None:
+        rec = rec.to(device)
+    n = torch.tensor([rec.numel()], dtype=torch.int64, device=rec.device)
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    m = int(max(int(x.item()) for x in lens))
+    pad = torch.zeros(max(m, 1), dtype=torch.int64, device=rec.device)
+    pad[:rec.numel()] = rec
+    bufs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return [b[:int(l.item())].cpu().numpy() for b, l in zip(bufs, lens)]
