@@ -17,7 +17,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -37,7 +36,8 @@ def parse():
     ap.add_argument('--genes', type=int, default=3000)
     ap.add_argument('--batch', type=int, default=10, help='query proteomes per step')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--cpu-threads', type=int, default=0)
     return ap.parse_args()
 
 
@@ -48,93 +48,21 @@ def algorithmic_bytes(stats, q_len_sum):
     return pref
 
 
-def cpu_baseline(ps, db, cs, args, n_threads, seconds):
-    """bounded sample of the same workload on the host cores: reference QueryMatcher + SmithWaterman per query
-    (kind "reference") when oracle/_ref/libsdref.so is present, else the oracle port; clusterhits by the oracle."""
-    from oracle import pyoracle
-    from spacedust_amd.synth import ALPHABET
-    P = ps.n_sets
-    lut = np.frombuffer(ALPHABET.encode(), np.uint8)
-    kind = 'reference' if pyoracle.ref_available() else 'port'
-    rng = np.random.default_rng(1)
-    sample = rng.choice(ps.n, size=min(ps.n, 4096), replace=False)
-    t_idx0 = time.time()
-    if kind == 'reference':
-        ref = pyoracle.Ref(6)
-        blob = lut[ps.residues].tobytes()
-        rix = ref.index(blob, ps.offsets, kmer_thr=cs.kmer_thr, threads=n_threads)
-        max_len = int(ps.lengths().max())
-    else:
-        orc = pyoracle.Oracle(n_threads)
-        ot = orc.target(ps.residues, ps.offsets, kmer_thr=cs.kmer_thr)
-    t_index = time.time() - t_idx0
-    done = [0] * n_threads
-    pairs = [0] * n_threads
-    cells = [0] * n_threads
-    deadline = time.time() + seconds
-    lens = ps.lengths()
-    db_res = int(ps.offsets[-1])
-
-    def worker(w):
-        if kind == 'reference':
-            pf = rix.prefilter(max_len, max_hits=cs.max_seqs)
-            sw = pyoracle.RefSW(ref, max_len, db_res)
-        for qi in sample[w::n_threads]:
-            if time.time() > deadline:
-                break
-            a, b = int(ps.offsets[qi]), int(ps.offsets[qi + 1])
-            if kind == 'reference':
-                qs = blob[a:b]
-                ids, sc, dg, _ = pf.query(qs, int(qi))
-                sw.set_query(qs)
-                for t in ids:
-                    if float(lens[t]) / float(lens[qi]) < 0.8:
-                        continue
-                    sw.align(blob[int(ps.offsets[t]):int(ps.offsets[t + 1])], identity=(t == qi))
-                    pairs[w] += 1
-                    cells[w] += int(lens[qi]) * int(lens[t])
-            else:
-                ids, sc, dg, _ = ot.prefilter(ps.residues[a:b], identity_id=int(qi), max_hits=cs.max_seqs,
-                                              bin_size=int(cs.pf_par.binSize), kmer_thr=cs.kmer_thr)
-                for t in ids:
-                    if float(lens[t]) / float(lens[qi]) < 0.8:
-                        continue
-                    orc.sw_align(ps.residues[a:b], ps.residues[int(ps.offsets[t]):int(ps.offsets[t + 1])], db_res,
-                                 identity=bool(t == qi))
-                    pairs[w] += 1
-                    cells[w] += int(lens[qi]) * int(lens[t])
-            done[w] += 1
-
-    t0 = time.time()
-    th = [threading.Thread(target=worker, args=(w,)) for w in range(n_threads)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.time() - t0
-    nq = sum(done)
-    q_per_s = nq / dt if dt > 0 else 0.0
-    # all-vs-all of P proteomes: P*genes queries for P*P genome pairs  ->  genes/P queries per genome pair
-    queries_per_pair = ps.n / float(P * P)
-    # clusterhits on the CPU: oracle restatement (the reference's clusterhits() is not linkable), one core per entry
-    orc2 = pyoracle.Oracle(1)
-    ch_t = 0.0
-    ch_n = 0
-    if cs.last_entries is not None:
-        eo, qp, tp, sd, pv, nq_arr = cs.last_entries
-        t1 = time.time()
-        for e in range(min(len(eo) - 1, 8)):
-            x0, x1 = int(eo[e]), int(eo[e + 1])
-            pyoracle.oracle_clusterhits(orc2, qp[x0:x1], tp[x0:x1], sd[x0:x1], pv[x0:x1], int(nq_arr[e]))
-            ch_n += 1
-        ch_t = time.time() - t1
-    ch_per_pair_core = (ch_t / ch_n) if ch_n else 0.0
-    sec_per_pair = queries_per_pair / q_per_s + ch_per_pair_core / n_threads if q_per_s > 0 else float('inf')
-    return dict(value=1.0 / sec_per_pair if sec_per_pair > 0 else 0.0, unit='genome-pairs/s', cores=n_threads, kind=kind,
-                sample='%d query proteins (prefilter + SW vs the full %d-proteome target, %d threads, %.1f s) + %d clusterhits entries by the oracle; index build %.1f s not included'
-                       % (nq, P, n_threads, dt, ch_n, t_index),
-                queries_per_s=q_per_s, sw_gcups=sum(cells) / dt / 1e9 if dt > 0 else 0.0, sw_pairs=sum(pairs),
-                clusterhits_s_per_entry_core=ch_per_pair_core)
+def cpu_baseline_subprocess(args, max_seqs, kmer_thr, bin_size, entries_path, seconds, n_threads):
+    """The baseline leg runs in a child process (niced, hard timeout, a bounded number of threads) so that it can
+    never take the measurement -- or the box -- down with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'cpu_baseline.py'), '--proteomes', str(args.proteomes), '--genes',
+           str(args.genes), '--max-seqs', str(max_seqs), '--kmer-thr', str(kmer_thr), '--bin-size', str(bin_size),
+           '--seconds', str(seconds), '--threads', str(n_threads), '--entries', entries_path]
+    try:
+        out = subprocess.run(['nice', '-n', '10'] + cmd, capture_output=True, text=True, timeout=seconds * 6 + 240)
+        line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+        if out.returncode != 0 or not line:
+            return dict(value=None, unit='genome-pairs/s', cores=0, kind='failed', sample=(out.stderr or out.stdout)[-300:])
+        return json.loads(line[-1])
+    except Exception as e:
+        return dict(value=None, unit='genome-pairs/s', cores=0, kind='failed', sample=repr(e))
 
 
 def main():
@@ -153,7 +81,8 @@ def main():
     from spacedust_amd.synth import make_proteomes
 
     P, B = args.proteomes, args.batch
-    n_threads = max(1, (os.cpu_count() or 1) // max(1, world))
+    # host stages: a bounded share of the cores (never saturate the box)
+    n_threads = max(1, min(64, (os.cpu_count() or 1) // 2) // max(1, world))
     host = Host(n_threads)
     gpu = Context(local_rank if world > 1 else 0)
     t0 = time.time()
@@ -163,6 +92,7 @@ def main():
     max_seqs = max(300, 2 * P)
     cs = ClusterSearch(gpu, host, db, max_seqs=max_seqs, filter_self_match=True)
     cs.last_entries = None
+    kmer_thr_used, bin_size_used = cs.kmer_thr, int(cs.pf_par.binSize)
     n_batches = (P + B - 1) // B
     set_start = ps.set_start
 
@@ -276,10 +206,14 @@ def main():
         'host_cores': os.cpu_count(),
     }
     if not args.no_cpu:
-        try:
-            res['cpu_baseline'] = cpu_baseline(ps, db, cs, args, os.cpu_count() or 1, args.cpu_seconds)
-        except Exception as e:   # the baseline leg must never take the measurement down
-            res['cpu_baseline'] = dict(value=None, unit='genome-pairs/s', cores=0, kind='failed', sample=repr(e))
+        import tempfile
+        ent = os.path.join(tempfile.gettempdir(), 'sd_bench_entries_%d.npz' % os.getpid())
+        if cs.last_entries is not None:
+            np.savez(ent, eo=cs.last_entries[0], qp=cs.last_entries[1], tp=cs.last_entries[2], sd=cs.last_entries[3],
+                     nq=cs.last_entries[5])
+        del cs, gpu
+        res['cpu_baseline'] = cpu_baseline_subprocess(args, max_seqs, kmer_thr_used, bin_size_used, ent, args.cpu_seconds,
+                                                      args.cpu_threads or max(1, min(32, (os.cpu_count() or 4) // 4)))
     print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

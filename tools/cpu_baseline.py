@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""cpu_baseline leg of bench.py (child process): a bounded sample of the same workload on the host cores.
+Prefilter + Smith-Waterman per query protein by the reference's own AVX2 code (oracle/_ref/libsdref.so,
+kind "reference") when that library travelled, else by the oracle port; clusterhits entries by the oracle's
+restatement (the reference's clusterhits() is not linkable).  Prints one JSON object."""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--proteomes', type=int, required=True)
+    ap.add_argument('--genes', type=int, default=3000)
+    ap.add_argument('--max-seqs', type=int, default=300)
+    ap.add_argument('--kmer-thr', type=int, default=112)
+    ap.add_argument('--bin-size', type=int, default=2)
+    ap.add_argument('--seconds', type=float, default=15.0)
+    ap.add_argument('--threads', type=int, default=16)
+    ap.add_argument('--entries', default='')
+    a = ap.parse_args()
+    os.environ['OMP_NUM_THREADS'] = str(a.threads)
+    from oracle import pyoracle
+    from spacedust_amd.synth import make_proteomes, ALPHABET
+    ps = make_proteomes(a.proteomes, genes_per_proteome=a.genes, seed=0x5ED0 + 2)
+    P, n_threads = ps.n_sets, a.threads
+    lut = np.frombuffer(ALPHABET.encode(), np.uint8)
+    kind = 'reference' if pyoracle.ref_available() else 'port'
+    rng = np.random.default_rng(1)
+    sample = rng.choice(ps.n, size=min(ps.n, 8192), replace=False)
+    lens = ps.lengths()
+    db_res = int(ps.offsets[-1])
+    t0 = time.time()
+    if kind == 'reference':
+        ref = pyoracle.Ref(6)
+        blob = lut[ps.residues].tobytes()
+        rix = ref.index(blob, ps.offsets, kmer_thr=a.kmer_thr, threads=n_threads)
+        max_len = int(lens.max())
+    else:
+        orc = pyoracle.Oracle(n_threads)
+        ot = orc.target(ps.residues, ps.offsets, kmer_thr=a.kmer_thr)
+    t_index = time.time() - t0
+    done, pairs, cells = [0] * n_threads, [0] * n_threads, [0] * n_threads
+    if kind == 'reference':
+        warm = rix.prefilter(max_len, max_hits=a.max_seqs)   # builds the shared 2-/3-mer tables once, single caller
+        warm.query(blob[int(ps.offsets[0]):int(ps.offsets[1])], 0)
+    ready = threading.Barrier(n_threads + 1)
+    deadline = [0.0]
+
+    def worker(w):
+        if kind == 'reference':
+            pf = rix.prefilter(max_len, max_hits=a.max_seqs)
+            sw = pyoracle.RefSW(ref, max_len, db_res)
+        ready.wait()
+        ready.wait()
+        for qi in sample[w::n_threads]:
+            if time.time() > deadline[0]:
+                break
+            x, y = int(ps.offsets[qi]), int(ps.offsets[qi + 1])
+            if kind == 'reference':
+                qs = blob[x:y]
+                ids = pf.query(qs, int(qi))[0]
+                sw.set_query(qs)
+            else:
+                ids = ot.prefilter(ps.residues[x:y], identity_id=int(qi), max_hits=a.max_seqs, bin_size=a.bin_size,
+                                   kmer_thr=a.kmer_thr)[0]
+            for t in ids:
+                if float(lens[t]) / float(lens[qi]) < 0.8:
+                    continue
+                tx, ty = int(ps.offsets[t]), int(ps.offsets[t + 1])
+                if kind == 'reference':
+                    sw.align(blob[tx:ty], identity=bool(t == qi))
+                else:
+                    orc.sw_align(ps.residues[x:y], ps.residues[tx:ty], db_res, identity=bool(t == qi))
+                pairs[w] += 1
+                cells[w] += int(lens[qi]) * int(lens[t])
+            done[w] += 1
+
+    th = [threading.Thread(target=worker, args=(w,)) for w in range(n_threads)]
+    for t in th:
+        t.start()
+    ready.wait()               # every worker has built its per-thread matcher / aligner
+    t0 = time.time()
+    deadline[0] = t0 + a.seconds
+    ready.wait()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    nq = sum(done)
+    q_per_s = nq / dt if dt > 0 else 0.0
+    queries_per_pair = ps.n / float(P * P)   # all-vs-all: P*genes queries serve P*P genome pairs
+    ch_per_entry, ch_n = 0.0, 0
+    if a.entries and os.path.exists(a.entries):
+        g = np.load(a.entries)
+        orc2 = pyoracle.Oracle(1)
+        t1 = time.time()
+        for e in range(min(len(g['eo']) - 1, 6)):
+            x0, x1 = int(g['eo'][e]), int(g['eo'][e + 1])
+            pyoracle.oracle_clusterhits(orc2, g['qp'][x0:x1], g['tp'][x0:x1], g['sd'][x0:x1], np.full(x1 - x0, 1e-30), int(g['nq'][e]))
+            ch_n += 1
+        ch_per_entry = (time.time() - t1) / max(ch_n, 1)
+    sec_per_pair = (queries_per_pair / q_per_s if q_per_s > 0 else float('inf')) + ch_per_entry / n_threads
+    print(json.dumps(dict(
+        value=1.0 / sec_per_pair if sec_per_pair > 0 else 0.0, unit='genome-pairs/s', cores=n_threads, kind=kind,
+        sample='%d query proteins: prefilter + SW against the full %d-proteome target with %d threads in %.1f s, plus %d '
+               'clusterhits entries (oracle restatement, 1 core each); reference index build %.1f s not included'
+               % (nq, P, n_threads, dt, ch_n, t_index),
+        queries_per_s=q_per_s, sw_gcups=sum(cells) / dt / 1e9 if dt > 0 else 0.0, sw_pairs=sum(pairs),
+        clusterhits_s_per_entry_core=ch_per_entry)))
+
+
+if __name__ == '__main__':
+    main()
