@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -27,7 +28,47 @@ struct sd_ctx {
     hipEvent_t evStart = nullptr, evStop = nullptr;
     uint64_t cellsFwd = 0, cellsRev = 0, cellsTb = 0;
     hipDeviceProp_t prop;
+    // grow-only device workspace: hipMalloc/hipFree per call cost far more than the kernels they serve
+    struct WsEntry { void *p = nullptr; size_t bytes = 0; };
+    std::map<std::string, WsEntry> ws;
+    std::map<std::string, WsEntry> pinned;
 };
+
+// persistent device buffer `key` of at least count elements (contents undefined after growth)
+template <typename T>
+hipError_t wsGet(sd_ctx *ctx, const char *key, size_t count, T **out) {
+    sd_ctx::WsEntry &e = ctx->ws[key];
+    const size_t need = std::max<size_t>(count, 1) * sizeof(T);
+    if (e.bytes < need) {
+        if (e.p) (void) hipFree(e.p);
+        e.p = nullptr;
+        e.bytes = 0;
+        const size_t grow = need + need / 4 + 256;
+        hipError_t err = hipMalloc(&e.p, grow);
+        if (err != hipSuccess) return err;
+        e.bytes = grow;
+    }
+    *out = (T *) e.p;
+    return hipSuccess;
+}
+
+// persistent pinned host staging buffer
+template <typename T>
+hipError_t pinGet(sd_ctx *ctx, const char *key, size_t count, T **out) {
+    sd_ctx::WsEntry &e = ctx->pinned[key];
+    const size_t need = std::max<size_t>(count, 1) * sizeof(T);
+    if (e.bytes < need) {
+        if (e.p) (void) hipHostFree(e.p);
+        e.p = nullptr;
+        e.bytes = 0;
+        const size_t grow = need + need / 4 + 256;
+        hipError_t err = hipHostMalloc(&e.p, grow, hipHostMallocDefault);
+        if (err != hipSuccess) return err;
+        e.bytes = grow;
+    }
+    *out = (T *) e.p;
+    return hipSuccess;
+}
 
 struct sd_seqset {
     sd_ctx *ctx = nullptr;

@@ -44,6 +44,20 @@ struct sd_target {
 
 namespace {
 
+// device buffer view backed by the context's grow-only workspace (same .p / .alloc() surface as DevBuf)
+template <typename T>
+struct WsView {
+    sd_ctx *ctx;
+    const char *key;
+    T *p = nullptr;
+    size_t n = 0;
+    WsView(sd_ctx *c, const char *k) : ctx(c), key(k) {}
+    hipError_t alloc(size_t count) {
+        n = count;
+        return wsGet(ctx, key, count, &p);
+    }
+};
+
 constexpr int SPAN6 = 10;
 __constant__ uint8_t c_seed6[6] = {0, 1, 3, 5, 8, 9};   // spaced seed 1101010011 (M/src/commons/Sequence.h:23)
 
@@ -598,7 +612,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
     while ((1ull << tBits) < T->nSeq) tBits++;
     const uint32_t maxBatchQ = 1u << std::min(32 - tBits, 16);
     const uint64_t maxDbMatches = std::max<uint64_t>(1000000, T->nSeq) * 2;   // QueryMatcher.cpp:43-47
-    const uint64_t HIT_BUDGET = 1ull << 28;    // hits per sub-batch (4 GB of key/value double buffers)
+    const uint64_t HIT_BUDGET = 1ull << 30;    // hits per sub-batch (16 GB of key/value double buffers; HBM is 288 GB)
 
     DevBuf<int8_t> dMat;
     SD_HIP(ctx, dMat.alloc(441));
@@ -608,7 +622,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
     DevBuf<uint8_t> scanTmp, sortTmp;
 
     uint32_t qBeg = 0;
-    uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 1024);
+    uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 4096);
     while (qBeg < nQ) {
         uint32_t bq = std::min<uint32_t>(batchQ, nQ - qBeg);
         // ---- upload the sub-batch
@@ -621,11 +635,12 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             hPos[x + 1] = hPos[x] + (uint64_t) std::max<int64_t>(0, L - SPAN6 + 1);
         }
         const uint64_t nPos = hPos[bq];
-        DevBuf<uint8_t> dQ;
-        DevBuf<int16_t> dKB;
-        DevBuf<int8_t> dDB;
-        DevBuf<uint64_t> dQOff, dPosBase;
-        DevBuf<uint32_t> dIdent;
+        WsView<uint8_t> dQ(ctx, "pf.dQ");
+        WsView<int16_t> dKB(ctx, "pf.dKB");
+        WsView<int8_t> dDB(ctx, "pf.dDB");
+        WsView<uint64_t> dQOff(ctx, "pf.dQOff");
+        WsView<uint64_t> dPosBase(ctx, "pf.dPosBase");
+        WsView<uint32_t> dIdent(ctx, "pf.dIdent");
         SD_HIP(ctx, dQ.alloc(r1 - r0 + 64));
         SD_HIP(ctx, dKB.alloc(r1 - r0 + 64));
         SD_HIP(ctx, dDB.alloc(r1 - r0 + 64));
@@ -641,8 +656,8 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         SD_HIP(ctx, hipMemsetAsync(dErr.p, 0, sizeof(int), ctx->stream));
 
         uint64_t nKmers = 0, nHits = 0;
-        DevBuf<uint32_t> dKmerCount;
-        DevBuf<uint64_t> dKmerBase;
+        WsView<uint32_t> dKmerCount(ctx, "pf.dKmerCount");
+        WsView<uint64_t> dKmerBase(ctx, "pf.dKmerBase");
         SD_HIP(ctx, dKmerCount.alloc(nPos + 1));
         SD_HIP(ctx, dKmerBase.alloc(nPos + 1));
         SD_HIP(ctx, hipMemsetAsync(dKmerCount.p, 0, (nPos + 1) * sizeof(uint32_t), ctx->stream));
@@ -652,7 +667,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                 hipLaunchKernelGGL(count_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                    dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p);
             }
-            DevBuf<uint64_t> dWide;
+        WsView<uint64_t> dWide(ctx, "pf.dWide");
             SD_HIP(ctx, dWide.alloc(nPos + 1));
             hipLaunchKernelGGL(widen_kernel, dim3(gridFor(nPos + 1, 256)), dim3(256), 0, ctx->stream, nPos + 1, dKmerCount.p, dWide.p);
             int rc = exclusiveScan(ctx, dWide.p, dKmerBase.p, nPos + 1, scanTmp);
@@ -660,8 +675,10 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             SD_HIP(ctx, hipMemcpyAsync(&nKmers, dKmerBase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
-        DevBuf<uint32_t> dKStart, dKLen, dKPos;
-        DevBuf<uint64_t> dHitBase;
+        WsView<uint32_t> dKStart(ctx, "pf.dKStart");
+        WsView<uint32_t> dKLen(ctx, "pf.dKLen");
+        WsView<uint32_t> dKPos(ctx, "pf.dKPos");
+        WsView<uint64_t> dHitBase(ctx, "pf.dHitBase");
         SD_HIP(ctx, dKStart.alloc(nKmers + 1));
         SD_HIP(ctx, dKLen.alloc(nKmers + 1));
         SD_HIP(ctx, dKPos.alloc(nKmers + 1));
@@ -674,7 +691,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                                    dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
                                    dKmerBase.p, dKStart.p, dKLen.p, dKPos.p);
             }
-            DevBuf<uint64_t> dWide;
+        WsView<uint64_t> dWide(ctx, "pf.dWide");
             SD_HIP(ctx, dWide.alloc(nKmers + 1));
             hipLaunchKernelGGL(widen_kernel, dim3(gridFor(nKmers + 1, 256)), dim3(256), 0, ctx->stream, nKmers + 1, dKLen.p, dWide.p);
             int rc = exclusiveScan(ctx, dWide.p, dHitBase.p, nKmers + 1, scanTmp);
@@ -688,7 +705,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         }
         if (nHits >= 0xFFFFFFFFull) return sdFail(ctx, SD_EUNSUPPORTED, "more than 2^32 hits in one query batch");
         std::vector<uint64_t> hStats((size_t) bq * 4, 0);
-        DevBuf<uint64_t> dStats;
+        WsView<uint64_t> dStats(ctx, "pf.dStats");
         SD_HIP(ctx, dStats.alloc((size_t) bq * 4));
         SD_HIP(ctx, hipMemsetAsync(dStats.p, 0, (size_t) bq * 4 * sizeof(uint64_t), ctx->stream));
         hipLaunchKernelGGL(stats_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
@@ -702,13 +719,23 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                               qBeg + x, (unsigned long long) hStats[4 * x + 1]);
 
         uint32_t nCand = 0, nKept = 0;
-        DevBuf<uint32_t> dKeyA, dKeyB, dValA, dValB;
-        DevBuf<uint16_t> dDiag;
-        DevBuf<uint8_t> dEmit;
-        DevBuf<uint64_t> dEmitPos, dEmit64;
-        DevBuf<uint32_t> dCKey, dCVal, dCLen, dKKey, dKVal, dQStart;
-        DevBuf<int32_t> dCScore, dKScore;
-        DevBuf<uint8_t> dKeep;
+        WsView<uint32_t> dKeyA(ctx, "pf.dKeyA");
+        WsView<uint32_t> dKeyB(ctx, "pf.dKeyB");
+        WsView<uint32_t> dValA(ctx, "pf.dValA");
+        WsView<uint32_t> dValB(ctx, "pf.dValB");
+        WsView<uint16_t> dDiag(ctx, "pf.dDiag");
+        WsView<uint8_t> dEmit(ctx, "pf.dEmit");
+        WsView<uint64_t> dEmitPos(ctx, "pf.dEmitPos");
+        WsView<uint64_t> dEmit64(ctx, "pf.dEmit64");
+        WsView<uint32_t> dCKey(ctx, "pf.dCKey");
+        WsView<uint32_t> dCVal(ctx, "pf.dCVal");
+        WsView<uint32_t> dCLen(ctx, "pf.dCLen");
+        WsView<uint32_t> dKKey(ctx, "pf.dKKey");
+        WsView<uint32_t> dKVal(ctx, "pf.dKVal");
+        WsView<uint32_t> dQStart(ctx, "pf.dQStart");
+        WsView<int32_t> dCScore(ctx, "pf.dCScore");
+        WsView<int32_t> dKScore(ctx, "pf.dKScore");
+        WsView<uint8_t> dKeep(ctx, "pf.dKeep");
         if (nHits > 0) {
             SD_HIP(ctx, dKeyA.alloc(nHits));
             SD_HIP(ctx, dKeyB.alloc(nHits));
@@ -768,7 +795,8 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                 ProfScope ps(ctx, "prefilter_keep_max");
                 hipLaunchKernelGGL(keep_max_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCScore.p, dKeep.p);
             }
-            DevBuf<uint64_t> dK64, dKPos64;
+        WsView<uint64_t> dK64(ctx, "pf.dK64");
+        WsView<uint64_t> dKPos64(ctx, "pf.dKPos64");
             SD_HIP(ctx, dK64.alloc(nCand + 1));
             SD_HIP(ctx, dKPos64.alloc(nCand + 1));
             SD_HIP(ctx, hipMemsetAsync(dK64.p + nCand, 0, sizeof(uint64_t), ctx->stream));
@@ -793,8 +821,8 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         }
         SD_HIP(ctx, dQStart.alloc(bq + 1));
         hipLaunchKernelGGL(query_bounds_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, nKept, dKKey.p, tBits, dQStart.p);
-        DevBuf<sd_hit> dOut;
-        DevBuf<uint32_t> dOutCount;
+        WsView<sd_hit> dOut(ctx, "pf.dOut");
+        WsView<uint32_t> dOutCount(ctx, "pf.dOutCount");
         SD_HIP(ctx, dOut.alloc((size_t) bq * maxHits));
         SD_HIP(ctx, dOutCount.alloc(bq));
         {

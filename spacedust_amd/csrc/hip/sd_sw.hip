@@ -313,7 +313,7 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
     if (!have || l != 0) return;
     tasks[id].maxv = maxv;
     if (maxv < tk.score) {
-        res[2 * tk.slot] = -2;
+        res[2 * id] = -2;
         return;
     }
     // traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581)
@@ -343,7 +343,7 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
         }
     }
     if (bad || i != 0 || j != 0) {
-        res[2 * tk.slot] = -1;
+        res[2 * id] = -1;
         return;
     }
     ids += (q[0] == t[0]);
@@ -353,8 +353,8 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
         o[a] = o[z];
         o[z] = tmp;
     }
-    res[2 * tk.slot] = len;
-    res[2 * tk.slot + 1] = ids;
+    res[2 * id] = len;
+    res[2 * id + 1] = ids;
 }
 
 int rtClass(int n) {
@@ -378,13 +378,21 @@ int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, c
                   int go, int ge, std::vector<int32_t> &hOut, uint32_t nSlots, uint64_t *cells) {
     hOut.assign((size_t) nSlots * 3, 0);
     if (tasks.empty()) return SD_OK;
-    // order: RT class, then by tL (two tasks share a wavefront) -- LPT-style, biggest first
-    std::sort(tasks.begin(), tasks.end(), [](const SwTask &a, const SwTask &b) {
-        int ca = rtClass(a.n), cb = rtClass(b.n);
-        if (ca != cb) return ca < cb;
-        if (a.tL != b.tL) return a.tL > b.tL;
-        return a.slot < b.slot;
-    });
+    // order: RT class, then by tL descending (two tasks share a wavefront; biggest first), stable in slot:
+    // one counting-sort pass over (class, 65535 - tL)
+    {
+        auto keyOf = [](const SwTask &t) {
+            const int c = rtClass(t.n);
+            const int ci = c == 4 ? 0 : (c == 8 ? 1 : (c == 16 ? 2 : 3));
+            return (uint32_t) ci * 65536u + (uint32_t) (65535 - std::min(t.tL, 65535));
+        };
+        std::vector<uint32_t> cnt(4 * 65536 + 1, 0);
+        for (size_t i = 0; i < tasks.size(); i++) cnt[keyOf(tasks[i]) + 1]++;
+        for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
+        std::vector<SwTask> sorted(tasks.size());
+        for (size_t i = 0; i < tasks.size(); i++) sorted[cnt[keyOf(tasks[i])]++] = tasks[i];
+        tasks.swap(sorted);
+    }
     uint64_t boundTotal = 0;
     for (size_t i = 0; i < tasks.size(); i++) {
         *cells += (uint64_t) tasks[i].n * (uint64_t) tasks[i].tL;
@@ -395,12 +403,12 @@ int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, c
             tasks[i].boundOff = 0;
         }
     }
-    DevBuf<SwTask> dTasks;
-    DevBuf<int32_t> dOut;
-    DevBuf<uint2> dBound;
-    SD_HIP(ctx, dTasks.alloc(tasks.size()));
-    SD_HIP(ctx, dOut.alloc((size_t) nSlots * 3));
-    SD_HIP(ctx, dBound.alloc(std::max<uint64_t>(boundTotal, 1)));
+    struct { SwTask *p; } dTasks;
+    struct { int32_t *p; } dOut;
+    struct { uint2 *p; } dBound;
+    SD_HIP(ctx, wsGet(ctx, "sw.tasks", tasks.size(), &dTasks.p));
+    SD_HIP(ctx, wsGet(ctx, "sw.out", (size_t) nSlots * 3, &dOut.p));
+    SD_HIP(ctx, wsGet(ctx, "sw.bound", std::max<uint64_t>(boundTotal, 1), &dBound.p));
     SD_HIP(ctx, hipMemcpyAsync(dTasks.p, tasks.data(), tasks.size() * sizeof(SwTask), hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(ctx, hipMemsetAsync(dOut.p, 0, (size_t) nSlots * 3 * sizeof(int32_t), ctx->stream));
     size_t begin = 0;
@@ -473,6 +481,8 @@ void sd_ctx_destroy(sd_ctx *ctx) {
     if (ctx->evStart) (void) hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void) hipEventDestroy(ctx->evStop);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    for (auto &kv : ctx->ws) if (kv.second.p) (void) hipFree(kv.second.p);
+    for (auto &kv : ctx->pinned) if (kv.second.p) (void) hipHostFree(kv.second.p);
     delete ctx;
 }
 
@@ -687,8 +697,10 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     std::vector<int32_t> h2;
     rc = runScoreTasks(ctx, tasks2, queries, targets, dMat.p, go, ge, h2, nPairs, &ctx->cellsFwd);
     if (rc != SD_OK) return rc;
-    // ---- gates after the score pass (:389-398)
+    // ---- gates after the score pass (:389-398); E-values in parallel, task list built serially
     std::vector<SwTask> rtasks;
+    std::vector<uint8_t> goRev(nPairs, 0);
+#pragma omp parallel for schedule(static)
     for (size_t x = 0; x < tasks.size(); x++) {
         const uint32_t i = tasks[x].slot;
         const int32_t *src = word[i] ? &h2[3 * i] : &h[3 * i];
@@ -704,6 +716,12 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
         const float qCov = sd::computeCov(0, r.qEnd, qLv[i]), tCov = sd::computeCov(0, r.tEnd, tLv[i]);
         const bool lowCov = !sd::hasCoverage(par->covThr, par->covMode, qCov, tCov);
         if (par->swMode == 0 || lowE || lowCov) continue;
+        goRev[i] = 1;
+    }
+    for (size_t x = 0; x < tasks.size(); x++) {
+        const uint32_t i = tasks[x].slot;
+        if (!goRev[i]) continue;
+        const sd_sw_result &r = out[i];
         SwTask tk;
         tk.qOff = queries->hOff[pairQ[i]] + r.qEnd; tk.tOff = targets->hOff[pairT[i]] + r.tEnd;
         tk.n = r.qEnd + 1; tk.tL = r.tEnd + 1; tk.qStep = -1; tk.tStep = -1;
@@ -772,12 +790,12 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
                 end++;
             }
             const uint32_t cnt = (uint32_t) (end - pos);
-            DevBuf<TbTask> dT;
-            DevBuf<int32_t> dRes;
-            DevBuf<int8_t> dDir;
-            DevBuf<char> dBt;
-            if (dT.alloc(cnt) != hipSuccess || dDir.alloc(nDir) != hipSuccess || dBt.alloc(nBt) != hipSuccess ||
-                dRes.alloc((size_t) nPairs * 2) != hipSuccess)
+            struct { TbTask *p; } dT;
+            struct { int32_t *p; } dRes;
+            struct { int8_t *p; } dDir;
+            struct { char *p; } dBt;
+            if (wsGet(ctx, "tb.tasks", cnt, &dT.p) != hipSuccess || wsGet(ctx, "tb.dir", nDir, &dDir.p) != hipSuccess ||
+                wsGet(ctx, "tb.bt", nBt, &dBt.p) != hipSuccess || wsGet(ctx, "tb.res", (size_t) cnt * 2, &dRes.p) != hipSuccess)
                 return sdFail(ctx, SD_ENOMEM, "traceback scratch allocation failed (%llu bytes)", (unsigned long long) nDir);
             SD_HIP(ctx, hipMemcpyAsync(dT.p, &pending[pos], cnt * sizeof(TbTask), hipMemcpyHostToDevice, ctx->stream));
             {
@@ -790,14 +808,14 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
             SD_HIP(ctx, hipGetLastError());
             std::vector<TbTask> back(cnt);
             std::vector<char> hbt(nBt);
-            std::vector<int32_t> hres((size_t) nPairs * 2);
+            std::vector<int32_t> hres((size_t) cnt * 2);
             SD_HIP(ctx, hipMemcpyAsync(back.data(), dT.p, cnt * sizeof(TbTask), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipMemcpyAsync(hbt.data(), dBt.p, nBt, hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipMemcpyAsync(hres.data(), dRes.p, hres.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
             for (uint32_t x = 0; x < cnt; x++) {
                 const TbTask &t = back[x];
-                const int len = hres[2 * t.slot];
+                const int len = hres[2 * x];
                 if (len == -2) {
                     TbTask nt = t;
                     nt.band = t.band * 2;
@@ -810,7 +828,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
                     memcpy(btPool + btPos, hbt.data() + t.btOff, len);
                     r.btOffset = btPos;
                     r.btLen = len;
-                    r.identical = hres[2 * t.slot + 1];
+                    r.identical = hres[2 * x + 1];
                     btPos += len;
                 }
             }
