@@ -131,4 +131,21 @@ struct ProfScope {
     }
 };
 
+
+// wall-clock phases on the host side of a call (reported next to the kernel times as "host:<name>")
+#include <chrono>
+struct HostScope {
+    sd_ctx *ctx;
+    std::string name;
+    std::chrono::steady_clock::time_point t0;
+    HostScope(sd_ctx *c, const char *n) : ctx(c), name(std::string("host:") + n), t0(std::chrono::steady_clock::now()) {}
+    ~HostScope() {
+        if (!ctx->profiling) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        sd_profile_entry &e = ctx->profile[name];
+        e.ms += ms;
+        e.launches += 1;
+    }
+};
+
 #endif

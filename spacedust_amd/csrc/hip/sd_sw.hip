@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <numeric>
 
 #include "../host/sd_host.h"
@@ -376,6 +377,7 @@ void launchScore(sd_ctx *ctx, const SwTask *dTasks, uint32_t n, const sd_seqset 
 // run a list of score tasks (any mix of sizes); results land in hOut[3*slot..]
 int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, const sd_seqset *t, const int8_t *dMat,
                   int go, int ge, std::vector<int32_t> &hOut, uint32_t nSlots, uint64_t *cells) {
+    HostScope hsAll(ctx, "score.total");
     hOut.assign((size_t) nSlots * 3, 0);
     if (tasks.empty()) return SD_OK;
     // order: RT class, then by tL descending (two tasks share a wavefront; biggest first), stable in slot:
@@ -635,6 +637,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     if (btUsed) *btUsed = 0;
     uint64_t btPos = 0;
 
+    std::unique_ptr<HostScope> hs(new HostScope(ctx, "align.init"));
     std::vector<int> qLv(nPairs), tLv(nPairs);
     for (uint32_t i = 0; i < nPairs; i++) {
         if (pairQ[i] >= queries->n || pairT[i] >= targets->n) return sdFail(ctx, SD_EINVAL, "pair %u out of range", i);
@@ -667,6 +670,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
             btPos += L;
         }
     }
+    hs.reset(new HostScope(ctx, "align.fwd32"));
     // ---- pass 1: forward, byte-kernel lane structure (32 lanes)
     std::vector<SwTask> tasks;
     auto fwdTask = [&](uint32_t i, int lanes) {
@@ -682,6 +686,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     std::vector<int32_t> h;
     int rc = runScoreTasks(ctx, tasks, queries, targets, dMat.p, go, ge, h, nPairs, &ctx->cellsFwd);
     if (rc != SD_OK) return rc;
+    hs.reset(new HostScope(ctx, "align.fwd16"));
     // ---- pass 2: pairs whose byte score saturates (max + bias >= 255, :881,916,360-368) rerun with the
     //      word kernel's 16-lane structure
     std::vector<SwTask> tasks2;
@@ -697,6 +702,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     std::vector<int32_t> h2;
     rc = runScoreTasks(ctx, tasks2, queries, targets, dMat.p, go, ge, h2, nPairs, &ctx->cellsFwd);
     if (rc != SD_OK) return rc;
+    hs.reset(new HostScope(ctx, "align.gates"));
     // ---- gates after the score pass (:389-398); E-values in parallel, task list built serially
     std::vector<SwTask> rtasks;
     std::vector<uint8_t> goRev(nPairs, 0);
@@ -729,6 +735,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
         tk.slot = i; tk.boundOff = 0;
         rtasks.push_back(tk);
     }
+    hs.reset(new HostScope(ctx, "align.rev"));
     // ---- pass 3: start positions (reverse pass, :400-476)
     std::vector<int32_t> hr;
     rc = runScoreTasks(ctx, rtasks, queries, targets, dMat.p, go, ge, hr, nPairs, &ctx->cellsRev);
@@ -757,6 +764,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
         t.slot = i;
         tb.push_back(t);
     }
+    hs.reset(new HostScope(ctx, "align.traceback"));
     // ---- pass 4: banded traceback in chunks that fit the scratch budget
     if (!tb.empty() && btPool == nullptr) return sdFail(ctx, SD_EINVAL, "swMode 2 needs a backtrace pool");
     const uint64_t SCRATCH_BUDGET = 8ull << 30;
@@ -836,6 +844,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
         }
         pending.swap(next);
     }
+    hs.reset();
     if (btUsed) *btUsed = btPos;
     return SD_OK;
 }

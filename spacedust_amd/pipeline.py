@@ -117,13 +117,17 @@ class ClusterSearch:
             if n_pairs == 0:
                 continue
             # pair list in prefilter order (Alignment.cpp:346-379)
+            t0 = time.time()
             mask = np.arange(hits.shape[1])[None, :] < cnt[:, None]
             pair_q_local = np.repeat(np.arange(c1 - c0, dtype=np.uint32), cnt)
             pair_t = hits['seqId'][mask].astype(np.uint32)
             ql = (off[1:] - off[:-1]).astype(np.int32)
             # Alignment::run coverage pre-check (Alignment.cpp:370-373) is the same test the prefilter applied
+            tm['pairs'] = tm.get('pairs', 0.0) + time.time() - t0
             t0 = time.time()
             qset = self.ctx.seqset(res, off, sw_b)
+            tm['seqset'] = tm.get('seqset', 0.0) + time.time() - t0
+            t0 = time.time()
             identity = (pair_q_local + np.uint32(c0) == pair_t) if same_db else np.zeros(n_pairs, bool)
             r, pool = self.ctx.sw_align(self.sw_par, qset, self.t_seqs, pair_q_local, pair_t, identity=identity)
             tm['align'] += time.time() - t0
