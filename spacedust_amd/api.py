@@ -125,6 +125,7 @@ class Context:
             raise SdError('sd_ctx_create(%d) failed (%d): no usable HIP device; the HIP path has no CPU fallback'
                           % (device, rc))
         self.h = h
+        self.device_index = device
 
     def device_name(self):
         b = C.create_string_buffer(256)

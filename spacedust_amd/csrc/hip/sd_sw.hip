@@ -705,10 +705,12 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     hs.reset(new HostScope(ctx, "align.gates"));
     // ---- gates after the score pass (:389-398); E-values in parallel, task list built serially
     std::vector<SwTask> rtasks;
-    std::vector<uint8_t> goRev(nPairs, 0);
+    std::vector<uint8_t> goRev(nPairs, 0), hasTask(nPairs, 0);
+    for (size_t x = 0; x < tasks.size(); x++) hasTask[tasks[x].slot] = 1;
+    // pair-major (contiguous) so that threads do not share cache lines of out[] / goRev[]
 #pragma omp parallel for schedule(static)
-    for (size_t x = 0; x < tasks.size(); x++) {
-        const uint32_t i = tasks[x].slot;
+    for (uint32_t i = 0; i < nPairs; i++) {
+        if (!hasTask[i]) continue;
         const int32_t *src = word[i] ? &h2[3 * i] : &h[3 * i];
         sd_sw_result &r = out[i];
         r.score = src[0];
@@ -814,13 +816,18 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
                                    queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, ldsStride, dDir.p, dBt.p, dRes.p);
             }
             SD_HIP(ctx, hipGetLastError());
-            std::vector<TbTask> back(cnt);
-            std::vector<char> hbt(nBt);
-            std::vector<int32_t> hres((size_t) cnt * 2);
-            SD_HIP(ctx, hipMemcpyAsync(back.data(), dT.p, cnt * sizeof(TbTask), hipMemcpyDeviceToHost, ctx->stream));
-            SD_HIP(ctx, hipMemcpyAsync(hbt.data(), dBt.p, nBt, hipMemcpyDeviceToHost, ctx->stream));
-            SD_HIP(ctx, hipMemcpyAsync(hres.data(), dRes.p, hres.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            TbTask *back = nullptr;
+            char *hbt = nullptr;
+            int32_t *hres = nullptr;
+            SD_HIP(ctx, pinGet(ctx, "tb.back", cnt, &back));
+            SD_HIP(ctx, pinGet(ctx, "tb.hbt", nBt, &hbt));
+            SD_HIP(ctx, pinGet(ctx, "tb.hres", (size_t) cnt * 2, &hres));
+            SD_HIP(ctx, hipMemcpyAsync(back, dT.p, cnt * sizeof(TbTask), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipMemcpyAsync(hbt, dBt.p, nBt, hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipMemcpyAsync(hres, dRes.p, (size_t) cnt * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            // pool offsets serially (cheap), payload copies in parallel
+            std::vector<uint64_t> dst(cnt, 0);
             for (uint32_t x = 0; x < cnt; x++) {
                 const TbTask &t = back[x];
                 const int len = hres[2 * x];
@@ -831,14 +838,21 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
                 } else if (len < 0) {
                     return sdFail(ctx, SD_EHIP, "Trace back error for pair %u", t.slot);
                 } else {
-                    sd_sw_result &r = out[t.slot];
                     if (btPos + (uint64_t) len > btCap) return sdFail(ctx, SD_ENOMEM, "backtrace pool too small");
-                    memcpy(btPool + btPos, hbt.data() + t.btOff, len);
-                    r.btOffset = btPos;
-                    r.btLen = len;
-                    r.identical = hres[2 * x + 1];
+                    dst[x] = btPos;
                     btPos += len;
                 }
+            }
+#pragma omp parallel for schedule(static)
+            for (uint32_t x = 0; x < cnt; x++) {
+                const int len = hres[2 * x];
+                if (len < 0) continue;
+                const TbTask &t = back[x];
+                sd_sw_result &r = out[t.slot];
+                memcpy(btPool + dst[x], hbt + t.btOff, len);
+                r.btOffset = dst[x];
+                r.btLen = len;
+                r.identical = hres[2 * x + 1];
             }
             pos = end;
         }
