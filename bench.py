@@ -101,7 +101,7 @@ def main():
     def run_step(step_idx, keep=False):
         b = (rank * (args.steps + args.warmup) + step_idx) % n_batches
         s0, s1 = b * B, min(P, (b + 1) * B)
-        out = cs.search(db, same_db=True, query_range=(int(set_start[s0]), int(set_start[s1])), chunk_queries=5000)
+        out = cs.search(db, same_db=True, query_range=(int(set_start[s0]), int(set_start[s1])), chunk_queries=30000)
         if keep and out['cluster_out'] is not None:
             hq, ht = out['hit_q'], out['hit_t']
             cs.last_entries = (out['entry_off'], db.pos_in_set[hq], db.pos_in_set[ht],
@@ -112,7 +112,6 @@ def main():
     for w in range(args.warmup):
         run_step(w)
     gpu.profile(True)
-    cs.ctx_pf.profile(True)
     for k in cs.stats:
         cs.stats[k] = 0
     if dist is not None:
@@ -156,7 +155,6 @@ def main():
             dist.destroy_process_group()
         return
     prof = gpu.profile_report()
-    prof.update(cs.ctx_pf.profile_report())
     kernels = {k: dict(ms=v[0], launches=int(v[1])) for k, v in prof.items()}
     st = cs.stats
     qlen_steps = 0

@@ -59,9 +59,6 @@ class ClusterSearch:
                  aln_len_thr=30, max_gene_gap=3, cluster_size=2, alpha=1.0, p_clu_thr=0.01, p_mh_thr=0.01,
                  filter_self_match=True, bin_size=None, verbose=False):
         self.ctx, self.host, self.T = ctx, host, target_db
-        # the prefilter stage gets its own context (own HIP stream + workspace) so that it can run one chunk ahead
-        # of align/aggregate on a second host thread
-        self.ctx_pf = api.Context(ctx.device_index)
         self.verbose = verbose
         self.k = 6
         self.kmer_thr = host.kmer_threshold(sensitivity, self.k)
@@ -76,7 +73,7 @@ class ClusterSearch:
         self.index = host.build_index(target_db.residues, target_db.offsets, self.k, self.kmer_thr)
         self.timing['index_build_s'] = time.time() - t0
         t0 = time.time()
-        self.target = api.Target(self.ctx_pf, host, self.index)
+        self.target = api.Target(ctx, host, self.index)
         self.t_seqs = ctx.seqset(target_db.residues, target_db.offsets, self.t_sw_bias)
         self.timing['upload_s'] = time.time() - t0
         self.pf_par = api.prefilter_params(host, target_db.n, kmer_thr=self.kmer_thr, max_hits=max_seqs, bin_size=bin_size,
@@ -99,38 +96,18 @@ class ClusterSearch:
                                          C.byref(agg)), 'sd_agg_create')
         tl = T.lengths()
         tm = dict(prefilter=0.0, align=0.0, aggregate=0.0, clusterhits=0.0, bias=0.0)
-        import queue
-        import threading
-        todo = queue.Queue(maxsize=2)
-        err = []
-
-        def producer():
-            try:
-                for c0_ in range(a0, b0, chunk_queries):
-                    c1_ = min(b0, c0_ + chunk_queries)
-                    r0, r1 = int(Q.offsets[c0_]), int(Q.offsets[c1_])
-                    res_ = Q.residues[r0:r1]
-                    off_ = (Q.offsets[c0_:c1_ + 1] - Q.offsets[c0_]).astype(np.uint64)
-                    t0_ = time.time()
-                    sw_b_, dg_b_, km_b_ = self.host.comp_bias(res_, off_, self.k)
-                    tm['bias'] += time.time() - t0_
-                    ident_ = (np.arange(c0_, c1_, dtype=np.uint32) if same_db else np.full(c1_ - c0_, 0xFFFFFFFF, np.uint32))
-                    t0_ = time.time()
-                    hits_, cnt_, st_ = api.prefilter(self.ctx_pf, self.target, self.pf_par, res_, off_, km_b_, dg_b_, ident_,
-                                                     want_stats=True)
-                    tm['prefilter'] += time.time() - t0_
-                    todo.put((c0_, c1_, res_, off_, sw_b_, hits_, cnt_, st_))
-            except Exception as e:   # surface in the consumer
-                err.append(e)
-            todo.put(None)
-
-        th = threading.Thread(target=producer, daemon=True)
-        th.start()
-        while True:
-            item = todo.get()
-            if item is None:
-                break
-            c0, c1, res, off, sw_b, hits, cnt, st = item
+        for c0 in range(a0, b0, chunk_queries):
+            c1 = min(b0, c0 + chunk_queries)
+            r0, r1 = int(Q.offsets[c0]), int(Q.offsets[c1])
+            res = Q.residues[r0:r1]
+            off = (Q.offsets[c0:c1 + 1] - Q.offsets[c0]).astype(np.uint64)
+            t0 = time.time()
+            sw_b, dg_b, km_b = self.host.comp_bias(res, off, self.k)
+            tm['bias'] += time.time() - t0
+            ident = (np.arange(c0, c1, dtype=np.uint32) if same_db else np.full(c1 - c0, 0xFFFFFFFF, np.uint32))
+            t0 = time.time()
+            hits, cnt, st = api.prefilter(self.ctx, self.target, self.pf_par, res, off, km_b, dg_b, ident, want_stats=True)
+            tm['prefilter'] += time.time() - t0
             self.stats['kmers'] += int(st[:, 0].sum())
             self.stats['index_hits'] += int(st[:, 1].sum())
             self.stats['diagonals'] += int(st[:, 2].sum())
@@ -168,9 +145,6 @@ class ClusterSearch:
                                           ptr(tlen_p), ptr(pool)), 'sd_agg_add')
             tm['aggregate'] += time.time() - t0
             del qset
-        th.join()
-        if err:
-            raise err[0]
         t0 = time.time()
         ne, nh = C.c_uint64(), C.c_uint64()
         L.sd_agg_finish(agg, C.byref(ne), C.byref(nh))
