@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <omp.h>
 #include <numeric>
 
 #include "../host/sd_host.h"
@@ -375,64 +376,98 @@ void launchScore(sd_ctx *ctx, const SwTask *dTasks, uint32_t n, const sd_seqset 
 }
 
 // run a list of score tasks (any mix of sizes); results land in hOut[3*slot..]
+// Tasks are ordered by (RT class, tL descending) with a parallel stable counting sort straight into a pinned
+// staging buffer (two tasks share a wavefront, so neighbours should have similar lengths; biggest first).
 int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, const sd_seqset *t, const int8_t *dMat,
-                  int go, int ge, std::vector<int32_t> &hOut, uint32_t nSlots, uint64_t *cells) {
-    HostScope hsAll(ctx, "score.total");
+                  int go, int ge, std::vector<int32_t> &hOut, uint32_t nSlots, uint64_t *cells, const char *tag = "a") {
     hOut.assign((size_t) nSlots * 3, 0);
     if (tasks.empty()) return SD_OK;
-    // order: RT class, then by tL descending (two tasks share a wavefront; biggest first), stable in slot:
-    // one counting-sort pass over (class, 65535 - tL)
+    HostScope hsAll(ctx, "score.total");
+    const size_t n = tasks.size();
+    constexpr int NB = 4 * 1024;
+    auto keyOf = [](const SwTask &t) {
+        const int c = rtClass(t.n);
+        const int ci = c == 4 ? 0 : (c == 8 ? 1 : (c == 16 ? 2 : 3));
+        return (uint32_t) ci * 1024u + (uint32_t) (1023 - std::min(t.tL >> 4, 1023));
+    };
+    SwTask *sorted = nullptr;
+    SD_HIP(ctx, pinGet(ctx, (std::string("sw.tasks.") + tag).c_str(), n, &sorted));
+    uint64_t boundTotal = 0, cellSum = 0;
+    size_t classBegin[5] = {0, 0, 0, 0, 0};
     {
-        auto keyOf = [](const SwTask &t) {
-            const int c = rtClass(t.n);
-            const int ci = c == 4 ? 0 : (c == 8 ? 1 : (c == 16 ? 2 : 3));
-            return (uint32_t) ci * 65536u + (uint32_t) (65535 - std::min(t.tL, 65535));
-        };
-        std::vector<uint32_t> cnt(4 * 65536 + 1, 0);
-        for (size_t i = 0; i < tasks.size(); i++) cnt[keyOf(tasks[i]) + 1]++;
-        for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
-        std::vector<SwTask> sorted(tasks.size());
-        for (size_t i = 0; i < tasks.size(); i++) sorted[cnt[keyOf(tasks[i])]++] = tasks[i];
-        tasks.swap(sorted);
-    }
-    uint64_t boundTotal = 0;
-    for (size_t i = 0; i < tasks.size(); i++) {
-        *cells += (uint64_t) tasks[i].n * (uint64_t) tasks[i].tL;
-        if (tasks[i].n > 1024) {
-            tasks[i].boundOff = boundTotal;
-            boundTotal += (uint64_t) tasks[i].tL;
-        } else {
-            tasks[i].boundOff = 0;
+        int T = 1;
+#pragma omp parallel
+        {
+#pragma omp single
+            T = omp_get_num_threads();
+        }
+        T = std::max(1, std::min(T, 64));
+        std::vector<uint32_t> hist((size_t) T * NB, 0);
+#pragma omp parallel num_threads(T) reduction(+ : cellSum)
+        {
+            const int th = omp_get_thread_num();
+            const size_t lo = n * th / T, hi = n * (th + 1) / T;
+            uint32_t *hh = &hist[(size_t) th * NB];
+            for (size_t i = lo; i < hi; i++) {
+                hh[keyOf(tasks[i])]++;
+                cellSum += (uint64_t) tasks[i].n * (uint64_t) tasks[i].tL;
+            }
+        }
+        // exclusive prefix over (bucket major, thread minor)
+        uint64_t run = 0;
+        for (int bkt = 0; bkt < NB; bkt++) {
+            if ((bkt & 1023) == 0) classBegin[bkt >> 10] = run;
+            for (int th = 0; th < T; th++) {
+                const uint32_t c = hist[(size_t) th * NB + bkt];
+                hist[(size_t) th * NB + bkt] = (uint32_t) run;
+                run += c;
+            }
+        }
+        classBegin[4] = run;
+#pragma omp parallel num_threads(T)
+        {
+            const int th = omp_get_thread_num();
+            const size_t lo = n * th / T, hi = n * (th + 1) / T;
+            uint32_t *hh = &hist[(size_t) th * NB];
+            for (size_t i = lo; i < hi; i++) sorted[hh[keyOf(tasks[i])]++] = tasks[i];
         }
     }
-    struct { SwTask *p; } dTasks;
-    struct { int32_t *p; } dOut;
-    struct { uint2 *p; } dBound;
-    SD_HIP(ctx, wsGet(ctx, "sw.tasks", tasks.size(), &dTasks.p));
-    SD_HIP(ctx, wsGet(ctx, "sw.out", (size_t) nSlots * 3, &dOut.p));
-    SD_HIP(ctx, wsGet(ctx, "sw.bound", std::max<uint64_t>(boundTotal, 1), &dBound.p));
-    SD_HIP(ctx, hipMemcpyAsync(dTasks.p, tasks.data(), tasks.size() * sizeof(SwTask), hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(ctx, hipMemsetAsync(dOut.p, 0, (size_t) nSlots * 3 * sizeof(int32_t), ctx->stream));
-    size_t begin = 0;
-    while (begin < tasks.size()) {
-        int c = rtClass(tasks[begin].n);
-        size_t end = begin;
-        while (end < tasks.size() && rtClass(tasks[end].n) == c) end++;
-        uint32_t cnt = (uint32_t) (end - begin);
+    *cells += cellSum;
+    for (size_t i = classBegin[3]; i < classBegin[4]; i++) {   // multi-strip tasks exist in class 32 only
+        if (sorted[i].n > 1024) {
+            sorted[i].boundOff = boundTotal;
+            boundTotal += (uint64_t) sorted[i].tL;
+        }
+    }
+    SwTask *dTasks = nullptr;
+    int32_t *dOut = nullptr;
+    uint2 *dBound = nullptr;
+    int32_t *hPin = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "sw.tasks", n, &dTasks));
+    SD_HIP(ctx, wsGet(ctx, "sw.out", (size_t) nSlots * 3, &dOut));
+    SD_HIP(ctx, wsGet(ctx, "sw.bound", std::max<uint64_t>(boundTotal, 1), &dBound));
+    SD_HIP(ctx, pinGet(ctx, "sw.hout", (size_t) nSlots * 3, &hPin));
+    SD_HIP(ctx, hipMemcpyAsync(dTasks, sorted, n * sizeof(SwTask), hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(ctx, hipMemsetAsync(dOut, 0, (size_t) nSlots * 3 * sizeof(int32_t), ctx->stream));
+    static const int classes[4] = {4, 8, 16, 32};
+    for (int ci = 0; ci < 4; ci++) {
+        const size_t begin = classBegin[ci], end = classBegin[ci + 1];
+        if (end == begin) continue;
+        const uint32_t cnt = (uint32_t) (end - begin);
         {
             ProfScope ps(ctx, "sw_score");
-            switch (c) {
-                case 4: launchScore<4>(ctx, dTasks.p + begin, cnt, q, t, dMat, go, ge, dOut.p, dBound.p); break;
-                case 8: launchScore<8>(ctx, dTasks.p + begin, cnt, q, t, dMat, go, ge, dOut.p, dBound.p); break;
-                case 16: launchScore<16>(ctx, dTasks.p + begin, cnt, q, t, dMat, go, ge, dOut.p, dBound.p); break;
-                default: launchScore<32>(ctx, dTasks.p + begin, cnt, q, t, dMat, go, ge, dOut.p, dBound.p); break;
+            switch (classes[ci]) {
+                case 4: launchScore<4>(ctx, dTasks + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+                case 8: launchScore<8>(ctx, dTasks + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+                case 16: launchScore<16>(ctx, dTasks + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+                default: launchScore<32>(ctx, dTasks + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
             }
         }
         SD_HIP(ctx, hipGetLastError());
-        begin = end;
     }
-    SD_HIP(ctx, hipMemcpyAsync(hOut.data(), dOut.p, (size_t) nSlots * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipMemcpyAsync(hPin, dOut, (size_t) nSlots * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(hOut.data(), hPin, (size_t) nSlots * 3 * sizeof(int32_t));
     return SD_OK;
 }
 
@@ -681,10 +716,18 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
         tk.slot = i; tk.boundOff = 0;
         return tk;
     };
-    for (uint32_t i = 0; i < nPairs; i++)
-        if (!(isIdentity && isIdentity[i]) && qLv[i] > 0 && tLv[i] > 0) tasks.push_back(fwdTask(i, 32));
+    {
+        // every pair gets a slot-ordered task; identity / empty pairs are dropped with a parallel compaction
+        std::vector<uint32_t> keepIdx(nPairs);
+        uint32_t nKeep = 0;
+        for (uint32_t i = 0; i < nPairs; i++)
+            if (!(isIdentity && isIdentity[i]) && qLv[i] > 0 && tLv[i] > 0) keepIdx[nKeep++] = i;
+        tasks.resize(nKeep);
+#pragma omp parallel for schedule(static)
+        for (uint32_t x = 0; x < nKeep; x++) tasks[x] = fwdTask(keepIdx[x], 32);
+    }
     std::vector<int32_t> h;
-    int rc = runScoreTasks(ctx, tasks, queries, targets, dMat.p, go, ge, h, nPairs, &ctx->cellsFwd);
+    int rc = runScoreTasks(ctx, tasks, queries, targets, dMat.p, go, ge, h, nPairs, &ctx->cellsFwd, "f32");
     if (rc != SD_OK) return rc;
     hs.reset(new HostScope(ctx, "align.fwd16"));
     // ---- pass 2: pairs whose byte score saturates (max + bias >= 255, :881,916,360-368) rerun with the
@@ -700,7 +743,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
         }
     }
     std::vector<int32_t> h2;
-    rc = runScoreTasks(ctx, tasks2, queries, targets, dMat.p, go, ge, h2, nPairs, &ctx->cellsFwd);
+    rc = runScoreTasks(ctx, tasks2, queries, targets, dMat.p, go, ge, h2, nPairs, &ctx->cellsFwd, "f16");
     if (rc != SD_OK) return rc;
     hs.reset(new HostScope(ctx, "align.gates"));
     // ---- gates after the score pass (:389-398); E-values in parallel, task list built serially
@@ -740,7 +783,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     hs.reset(new HostScope(ctx, "align.rev"));
     // ---- pass 3: start positions (reverse pass, :400-476)
     std::vector<int32_t> hr;
-    rc = runScoreTasks(ctx, rtasks, queries, targets, dMat.p, go, ge, hr, nPairs, &ctx->cellsRev);
+    rc = runScoreTasks(ctx, rtasks, queries, targets, dMat.p, go, ge, hr, nPairs, &ctx->cellsRev, "rev");
     if (rc != SD_OK) return rc;
     std::vector<TbTask> tb;
     for (size_t x = 0; x < rtasks.size(); x++) {
@@ -776,13 +819,20 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
         for (size_t x = 0; x < pending.size(); x++)
             if (pending[x].band * 2 + 3 > 2047)
                 return sdFail(ctx, SD_EUNSUPPORTED, "traceback band %d exceeds the LDS-resident limit (pair %u)", pending[x].band, pending[x].slot);
-        std::sort(pending.begin(), pending.end(), [&](const TbTask &a, const TbTask &b) {
-            int ca = widthClass(a.band), cb = widthClass(b.band);
-            if (ca != cb) return ca < cb;
-            uint64_t wa = (uint64_t) ((2 * a.band + 1 + 31) / 32) * a.qLen, wb = (uint64_t) ((2 * b.band + 1 + 31) / 32) * b.qLen;
-            if (wa != wb) return wa > wb;
-            return a.slot < b.slot;
-        });
+        {   // order: LDS width class, then work (row chunks x rows) descending -- stable counting sort
+            auto keyOf = [&](const TbTask &t) {
+                const int c = widthClass(t.band);
+                const int ci = c == 128 ? 0 : (c == 512 ? 1 : 2);
+                const uint64_t work = (uint64_t) ((2 * t.band + 1 + 31) / 32) * (uint64_t) t.qLen;
+                return (uint32_t) ci * 4096u + (uint32_t) (4095 - std::min<uint64_t>(work >> 3, 4095));
+            };
+            std::vector<uint32_t> cnt(3 * 4096 + 1, 0);
+            for (size_t i = 0; i < pending.size(); i++) cnt[keyOf(pending[i]) + 1]++;
+            for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
+            std::vector<TbTask> sortedTb(pending.size());
+            for (size_t i = 0; i < pending.size(); i++) sortedTb[cnt[keyOf(pending[i])]++] = pending[i];
+            pending.swap(sortedTb);
+        }
         std::vector<TbTask> next;
         size_t pos = 0;
         while (pos < pending.size()) {
