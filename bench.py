@@ -163,7 +163,8 @@ def main():
     sw_ms = kernels.get('sw_score', dict(ms=0))['ms']
     cells_sw = st['cells_fwd'] + st['cells_rev']
     b_sw = st['pairs'] * (int(ps.lengths().mean()) * 23 + 24)
-    dom = max(kernels.items(), key=lambda kv: kv[1]['ms'])[0] if kernels else 'none'
+    dev_kernels = {k: v for k, v in kernels.items() if not k.startswith('host:')}
+    dom = max(dev_kernels.items(), key=lambda kv: kv[1]['ms'])[0] if dev_kernels else 'none'
     if dom == 'sw_score':
         alg, per = b_sw, kernels[dom]
     elif dom.startswith('prefilter_'):

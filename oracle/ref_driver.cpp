@@ -353,3 +353,67 @@ void ref_sw_destroy(void *vs) {
 unsigned long ref_l2_cache_size() { return Util::getL2CacheSize(); }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// cpu_baseline driver: the reference's per-query loop bodies (Prefiltering::runSplit :817-886 and
+// Alignment::run :312-514) over a sample of queries with OpenMP threads, each thread owning its
+// QueryMatcher / SmithWaterman exactly as the reference's threads do.  Stops at the deadline.
+// out[0] = queries done, out[1] = pairs aligned, out[2] = forward DP cells, out[3] = seconds
+// ------------------------------------------------------------------------------------------------
+#include <chrono>
+extern "C" int ref_run_queries(void *vi, const char *seqs, const size_t *offsets, const unsigned int *sample,
+                               size_t nSample, int kmerThr, size_t maxHits, int threads, double seconds,
+                               size_t dbResidues, double *out) {
+    RefIndex *ix = (RefIndex *) vi;
+    RefCtx *c = ix->ctx;
+    ensureExt(c);
+    size_t maxLen = ix->maxLen + 2;
+    std::vector<RefPref *> pf(threads);
+    std::vector<RefSW *> sw(threads);
+    for (int t = 0; t < threads; t++) {
+        pf[t] = (RefPref *) ref_prefilter_create(ix, kmerThr, maxLen, maxHits, 15, 1);
+        sw[t] = (RefSW *) ref_sw_create(c, maxLen, dbResidues, 1);
+    }
+    size_t done = 0, pairs = 0, cells = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool stop = false;
+#pragma omp parallel num_threads(threads) reduction(+ : done, pairs, cells)
+    {
+        const int t = omp_get_thread_num();
+        std::vector<unsigned int> ids(maxHits + 2);
+        std::vector<int> sc(maxHits + 2);
+        std::vector<unsigned short> dg(maxHits + 2);
+        int res[8];
+#pragma omp for schedule(dynamic, 1)
+        for (size_t s = 0; s < nSample; s++) {
+            if (stop) continue;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
+                stop = true;
+                continue;
+            }
+            const unsigned int q = sample[s];
+            const char *qs = seqs + offsets[q];
+            const unsigned int qL = (unsigned int) (offsets[q + 1] - offsets[q]);
+            size_t n = ref_prefilter_query(pf[t], qs, qL, q, ids.data(), sc.data(), dg.data(), NULL);
+            ref_sw_set_query(sw[t], qs, qL);
+            for (size_t h = 0; h < n; h++) {
+                const unsigned int tid = ids[h];
+                const unsigned int tL = (unsigned int) (offsets[tid + 1] - offsets[tid]);
+                if (Util::canBeCovered(0.8f, Parameters::COV_MODE_QUERY, (float) qL, (float) tL) == false) continue;
+                ref_sw_align(sw[t], seqs + offsets[tid], tL, 2, 10.0, Parameters::COV_MODE_QUERY, 0.8f, res, NULL, 0, tid == q);
+                pairs++;
+                cells += (size_t) qL * tL;
+            }
+            done++;
+        }
+    }
+    out[3] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    out[0] = (double) done;
+    out[1] = (double) pairs;
+    out[2] = (double) cells;
+    for (int t = 0; t < threads; t++) {
+        ref_prefilter_destroy(pf[t]);
+        ref_sw_destroy(sw[t]);
+    }
+    return 0;
+}

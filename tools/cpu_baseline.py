@@ -48,53 +48,52 @@ def main():
         orc = pyoracle.Oracle(n_threads)
         ot = orc.target(ps.residues, ps.offsets, kmer_thr=a.kmer_thr)
     t_index = time.time() - t0
-    done, pairs, cells = [0] * n_threads, [0] * n_threads, [0] * n_threads
     if kind == 'reference':
-        warm = rix.prefilter(max_len, max_hits=a.max_seqs)   # builds the shared 2-/3-mer tables once, single caller
-        warm.query(blob[int(ps.offsets[0]):int(ps.offsets[1])], 0)
-    ready = threading.Barrier(n_threads + 1)
-    deadline = [0.0]
+        # the reference's per-query loop bodies driven by OpenMP threads inside libsdref (no Python in the loop)
+        import ctypes as C
+        L = ref.lib
+        L.ref_run_queries.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t,
+                                      C.c_int, C.c_double, C.c_size_t, C.c_void_p]
+        out = np.zeros(4, np.float64)
+        smp = np.ascontiguousarray(sample, np.uint32)
+        offs = np.ascontiguousarray(ps.offsets, np.uint64)
+        L.ref_run_queries(rix.h, blob, offs.ctypes.data, smp.ctypes.data, len(smp), a.kmer_thr, a.max_seqs, n_threads,
+                          a.seconds, db_res, out.ctypes.data)
+        nq, npairs, ncells, dt = int(out[0]), int(out[1]), float(out[2]), float(out[3])
+    else:
+        done, pairs, cells = [0] * n_threads, [0] * n_threads, [0] * n_threads
+        ready = threading.Barrier(n_threads + 1)
+        deadline = [0.0]
 
-    def worker(w):
-        if kind == 'reference':
-            pf = rix.prefilter(max_len, max_hits=a.max_seqs)
-            sw = pyoracle.RefSW(ref, max_len, db_res)
-        ready.wait()
-        ready.wait()
-        for qi in sample[w::n_threads]:
-            if time.time() > deadline[0]:
-                break
-            x, y = int(ps.offsets[qi]), int(ps.offsets[qi + 1])
-            if kind == 'reference':
-                qs = blob[x:y]
-                ids = pf.query(qs, int(qi))[0]
-                sw.set_query(qs)
-            else:
+        def worker(w):
+            ready.wait()
+            ready.wait()
+            for qi in sample[w::n_threads]:
+                if time.time() > deadline[0]:
+                    break
+                x, y = int(ps.offsets[qi]), int(ps.offsets[qi + 1])
                 ids = ot.prefilter(ps.residues[x:y], identity_id=int(qi), max_hits=a.max_seqs, bin_size=a.bin_size,
                                    kmer_thr=a.kmer_thr)[0]
-            for t in ids:
-                if float(lens[t]) / float(lens[qi]) < 0.8:
-                    continue
-                tx, ty = int(ps.offsets[t]), int(ps.offsets[t + 1])
-                if kind == 'reference':
-                    sw.align(blob[tx:ty], identity=bool(t == qi))
-                else:
+                for t in ids:
+                    if float(lens[t]) / float(lens[qi]) < 0.8:
+                        continue
+                    tx, ty = int(ps.offsets[t]), int(ps.offsets[t + 1])
                     orc.sw_align(ps.residues[x:y], ps.residues[tx:ty], db_res, identity=bool(t == qi))
-                pairs[w] += 1
-                cells[w] += int(lens[qi]) * int(lens[t])
-            done[w] += 1
+                    pairs[w] += 1
+                    cells[w] += int(lens[qi]) * int(lens[t])
+                done[w] += 1
 
-    th = [threading.Thread(target=worker, args=(w,)) for w in range(n_threads)]
-    for t in th:
-        t.start()
-    ready.wait()               # every worker has built its per-thread matcher / aligner
-    t0 = time.time()
-    deadline[0] = t0 + a.seconds
-    ready.wait()
-    for t in th:
-        t.join()
-    dt = time.time() - t0
-    nq = sum(done)
+        th = [threading.Thread(target=worker, args=(w,)) for w in range(n_threads)]
+        for t in th:
+            t.start()
+        ready.wait()
+        t0 = time.time()
+        deadline[0] = t0 + a.seconds
+        ready.wait()
+        for t in th:
+            t.join()
+        dt = time.time() - t0
+        nq, npairs, ncells = sum(done), sum(pairs), float(sum(cells))
     q_per_s = nq / dt if dt > 0 else 0.0
     queries_per_pair = ps.n / float(P * P)   # all-vs-all: P*genes queries serve P*P genome pairs
     ch_per_entry, ch_n = 0.0, 0
@@ -113,7 +112,7 @@ def main():
         sample='%d query proteins: prefilter + SW against the full %d-proteome target with %d threads in %.1f s, plus %d '
                'clusterhits entries (oracle restatement, 1 core each); reference index build %.1f s not included'
                % (nq, P, n_threads, dt, ch_n, t_index),
-        queries_per_s=q_per_s, sw_gcups=sum(cells) / dt / 1e9 if dt > 0 else 0.0, sw_pairs=sum(pairs),
+        queries_per_s=q_per_s, sw_gcups=ncells / dt / 1e9 if dt > 0 else 0.0, sw_pairs=npairs,
         clusterhits_s_per_entry_core=ch_per_entry)))
 
 
