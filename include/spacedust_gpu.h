@@ -88,6 +88,13 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
                       uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
                       sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed);
 
+/* Same contract and results as sd_sw_align_batch, with the gating / task building between the passes done on
+ * the host (one device round trip per pass).  Kept as the A/B cross-check of the device-resident orchestration
+ * (tests/test_gpu_sw.py); btOffset values may differ, the bytes they point to may not. */
+int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                               uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
+                               sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed);
+
 /* The score pass alone (sw_sse2_byte / sw_sse2_word semantics, StripedSmithWaterman.cpp:639-1214):
  * lanes = 32 reproduces the AVX2 byte kernel's lane structure, 16 the word kernel's.  reverse != 0 runs the
  * start-position pass on query[0..qEnd[i]] reversed x target[0..tEnd[i]] scanned downwards.

@@ -172,7 +172,7 @@ class Context:
                'sd_sw_score_batch')
         return out
 
-    def sw_align(self, par, queries, targets, pair_q, pair_t, identity=None, bt_cap=None):
+    def sw_align(self, par, queries, targets, pair_q, pair_t, identity=None, bt_cap=None, hostpath=False):
         pq = np.ascontiguousarray(pair_q, np.uint32)
         pt = np.ascontiguousarray(pair_t, np.uint32)
         n = len(pq)
@@ -184,9 +184,9 @@ class Context:
             bt_cap = int((ql + tl).sum()) + 64
         pool = np.zeros(bt_cap, np.uint8)
         used = C.c_uint64()
-        _check(self.h, self.L.sd_sw_align_batch(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt),
-                                                ptr(idt), ptr(res), ptr(pool), bt_cap, C.byref(used)),
-               'sd_sw_align_batch')
+        fn = self.L.sd_sw_align_batch_hostpath if hostpath else self.L.sd_sw_align_batch
+        _check(self.h, fn(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt), ptr(idt), ptr(res), ptr(pool),
+                          bt_cap, C.byref(used)), 'sd_sw_align_batch')
         return res, pool[:used.value]
 
     def sw_cells(self):

@@ -17,6 +17,8 @@
 // kernel is VALU bound; bench.py reports it in GCUPS.
 #include "sd_common.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -44,7 +46,8 @@ template <int RT>
 __global__ void __launch_bounds__(64)
 sw_score_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                 const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
-                int go, int ge, int32_t *__restrict__ out, uint2 *__restrict__ boundary) {
+                int go, int ge, int32_t *__restrict__ out, uint2 *__restrict__ boundary,
+                const uint32_t *__restrict__ order /* nullable: task = tasks[order[x]] */) {
     constexpr int ROWS = 32 * RT;          // rows per strip
     constexpr int WORDS = RT / 4;          // profile dwords per lane per residue
     __shared__ uint32_t prof[2][21][ROWS / 4];
@@ -57,7 +60,7 @@ sw_score_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t
     const uint32_t taskId = blockIdx.x * 2 + grp;
     SwTask tk;
     if (taskId < nTasks) {
-        tk = tasks[taskId];
+        tk = tasks[order ? order[taskId] : taskId];
     } else {
         tk.n = 0; tk.tL = 0; tk.qOff = 0; tk.tOff = 0; tk.qStep = 1; tk.tStep = 1; tk.segLen = 1; tk.slot = 0; tk.boundOff = 0;
     }
@@ -213,14 +216,16 @@ __global__ void __launch_bounds__(64)
 sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                     const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
                     int go, int ge, int ldsStride /* ints per array */, int8_t *__restrict__ dirs, char *__restrict__ bt,
-                    int32_t *__restrict__ res /* per slot: btLen (-2 = band too small, -1 = traceback error), identical */) {
+                    int32_t *__restrict__ res /* per task: btLen (-2 = band too small, -1 = traceback error), identical */,
+                    const uint32_t *__restrict__ order /* nullable */) {
     extern __shared__ int32_t lds[];
     __shared__ int8_t smat[441];
     for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
     __syncthreads();
     const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
-    const uint32_t id = blockIdx.x * 2 + grp;
-    const bool have = id < nTasks;
+    const uint32_t lid = blockIdx.x * 2 + grp;
+    const bool have = lid < nTasks;
+    const uint32_t id = have ? (order ? order[lid] : lid) : 0;
     TbTask tk;
     if (have) tk = tasks[id];
     else { tk.qLen = 0; tk.tLen = 0; tk.band = 1; tk.score = 0; tk.maxv = 0; tk.qAbs = 0; tk.tAbs = 0; tk.slot = 0; tk.dirOff = 0; tk.btOff = 0; }
@@ -372,7 +377,16 @@ void launchScore(sd_ctx *ctx, const SwTask *dTasks, uint32_t n, const sd_seqset 
     if (n == 0) return;
     dim3 grid((n + 1) / 2), block(64);
     hipLaunchKernelGGL(sw_score_kernel<RT>, grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes, dMat,
-                       go, ge, dOut, dBound);
+                       go, ge, dOut, dBound, (const uint32_t *) nullptr);
+}
+
+template <int RT>
+void launchScoreIdx(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, uint32_t n, const sd_seqset *q,
+                    const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut, uint2 *dBound) {
+    if (n == 0) return;
+    dim3 grid((n + 1) / 2), block(64);
+    hipLaunchKernelGGL(sw_score_kernel<RT>, grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes, dMat,
+                       go, ge, dOut, dBound, dOrder);
 }
 
 // run a list of score tasks (any mix of sizes); results land in hOut[3*slot..]
@@ -469,6 +483,346 @@ int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, c
     SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(hOut.data(), hPin, (size_t) nSlots * 3 * sizeof(int32_t));
     return SD_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident orchestration of a batch of pairs: task construction, the gates between the passes and
+// the ordering of tasks all happen on the GPU; the host only launches, reads six class boundaries per pass
+// and receives the finished result records + a dense backtrace pool.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t KEY_INVALID = 4u * 1024u;            // sorts after every class
+__device__ __forceinline__ uint32_t scoreKey(int n, int tL) {
+    const int ci = n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3));
+    return (uint32_t) ci * 1024u + (uint32_t) (1023 - min(tL >> 4, 1023));
+}
+
+struct DevGateParams {
+    int go, ge, matMin, swMode, covMode;
+    float covThr;
+    double evalThr;
+    // Gumbel parameters (sd::Evaluer) for the device-side E-value gate
+    double lambda, K, aI, bI, alphaI, betaI, aJ, bJ, alphaJ, betaJ, sigma, tau, viThr, vjThr, cThr, dbResidues;
+};
+
+__device__ double devEvalue(const DevGateParams &e, double y_, double qLen) {
+    const double m_ = e.dbResidues, n_ = qLen;
+    const double const_val = 0.3989422804014327;   // 1/sqrt(2 pi)
+    double tmp = e.aI * y_ + e.bI;
+    double m_li_y = m_ - tmp;
+    double vi_y = fmax(e.viThr, e.alphaI * y_ + e.betaI);
+    double sqrt_vi_y = sqrt(vi_y);
+    double m_F = sqrt_vi_y == 0.0 ? 1e100 : m_li_y / sqrt_vi_y;
+    double P_m_F = 0.5 * erfc(-sqrt(0.5) * m_F);
+    double E_m_F = -const_val * exp(-0.5 * m_F * m_F);
+    double p1 = m_li_y * P_m_F - sqrt_vi_y * E_m_F;
+    tmp = e.aJ * y_ + e.bJ;
+    double n_lj_y = n_ - tmp;
+    double vj_y = fmax(e.vjThr, e.alphaJ * y_ + e.betaJ);
+    double sqrt_vj_y = sqrt(vj_y);
+    double n_F = sqrt_vj_y == 0.0 ? 1e100 : n_lj_y / sqrt_vj_y;
+    double P_n_F = 0.5 * erfc(-sqrt(0.5) * n_F);
+    double E_n_F = -const_val * exp(-0.5 * n_F * n_F);
+    double p2 = n_lj_y * P_n_F - sqrt_vj_y * E_n_F;
+    double c_y = fmax(e.cThr, e.sigma * y_ + e.tau);
+    double area = p1 * p2 + c_y * (P_m_F * P_n_F);
+    return e.K * exp(-e.lambda * y_) * area;
+}
+
+__device__ __forceinline__ float devCov(unsigned int startPos, unsigned int endPos, unsigned int len) {
+    return (min(len, max(startPos, endPos)) - min(startPos, endPos) + 1) / (float) len;
+}
+__device__ __forceinline__ bool devHasCoverage(float covThr, int covMode, float qCov, float tCov) {
+    switch (covMode) {
+        case 0: return (qCov >= covThr) && (tCov >= covThr);
+        case 2: return qCov >= covThr;
+        case 1: return tCov >= covThr;
+        default: return true;
+    }
+}
+
+// forward tasks (32-lane structure) for every non-identity pair
+__global__ void __launch_bounds__(256)
+k_make_fwd(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const uint32_t *__restrict__ pairT,
+           const uint8_t *__restrict__ ident, const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff,
+           SwTask *__restrict__ tasks, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+           sd_sw_result *__restrict__ res) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs) return;
+    const uint64_t qo = qOff[pairQ[i]], to = tOff[pairT[i]];
+    const int qL = (int) (qOff[pairQ[i] + 1] - qo), tL = (int) (tOff[pairT[i] + 1] - to);
+    SwTask tk;
+    tk.qOff = qo; tk.tOff = to; tk.n = qL; tk.tL = tL; tk.qStep = 1; tk.tStep = 1;
+    tk.segLen = max(1, (qL + 31) / 32);
+    tk.slot = i; tk.boundOff = 0;
+    const bool valid = !(ident && ident[i]) && qL > 0 && tL > 0;
+    tasks[i] = tk;
+    keys[i] = valid ? scoreKey(qL, tL) : KEY_INVALID;
+    vals[i] = i;
+    sd_sw_result r;
+    r.score = 0; r.qStart = -1; r.qEnd = -1; r.tStart = -1; r.tEnd = -1; r.identical = 0; r.btLen = 0; r.flags = 0;
+    r.evalue = 0.0; r.btOffset = 0;
+    res[i] = r;
+}
+
+// class boundaries of a sorted key array: b[c] = lower_bound(c*1024), c = 0..4 (b[4] = number of valid tasks)
+__global__ void k_bounds(const uint32_t *__restrict__ keys, uint32_t n, uint32_t step, uint32_t *__restrict__ b, int nb) {
+    const int c = threadIdx.x;
+    if (c >= nb) return;
+    const uint32_t want = (uint32_t) c * step;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (keys[mid] < want) lo = mid + 1;
+        else hi = mid;
+    }
+    b[c] = lo;
+}
+
+// after the 32-lane pass: pairs whose byte score saturates get a 16-lane task (:881,916,360-368)
+__global__ void __launch_bounds__(256)
+k_gate_word(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const int32_t *__restrict__ out32,
+            const int32_t *__restrict__ minBias, int matMin, SwTask *__restrict__ tasks, uint32_t *__restrict__ keys,
+            uint32_t *__restrict__ vals, uint8_t *__restrict__ word, const uint32_t *__restrict__ fwdKeys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs) return;
+    vals[i] = i;
+    bool w = false;
+    if (fwdKeys[i] != KEY_INVALID) {
+        const int mb = minBias[pairQ[i]];
+        const int bias = abs(matMin) + abs(mb);
+        w = out32[3 * i] + bias >= 255;
+    }
+    word[i] = w ? 1 : 0;
+    if (w) {
+        tasks[i].segLen = max(1, (tasks[i].n + 15) / 16);
+        keys[i] = scoreKey(tasks[i].n, tasks[i].tL);
+    } else {
+        keys[i] = KEY_INVALID;
+    }
+}
+
+// gates after the score pass (:389-398) and reverse tasks
+__global__ void __launch_bounds__(256)
+k_gate_rev(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ, const uint32_t *__restrict__ pairT,
+           const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, const int32_t *__restrict__ out32,
+           const int32_t *__restrict__ out16, const uint8_t *__restrict__ word, const uint32_t *__restrict__ fwdKeys,
+           SwTask *__restrict__ tasks, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+           sd_sw_result *__restrict__ res) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs) return;
+    vals[i] = i;
+    keys[i] = KEY_INVALID;
+    if (fwdKeys[i] == KEY_INVALID) return;
+    const int32_t *src = word[i] ? &out16[3 * i] : &out32[3 * i];
+    sd_sw_result r = res[i];
+    r.score = src[0];
+    r.tEnd = src[1];
+    r.qEnd = src[2];
+    r.flags = word[i] ? 1 : 0;
+    if (word[i] && r.tEnd == -1) r.tEnd = 0;   // the word kernel initialises end_ref to 0 (:962)
+    if (r.tEnd == -1) { res[i] = r; return; }
+    const uint64_t qo = qOff[pairQ[i]], to = tOff[pairT[i]];
+    const int qL = (int) (qOff[pairQ[i] + 1] - qo), tL = (int) (tOff[pairT[i] + 1] - to);
+    const double ev = devEvalue(gp, (double) r.score, (double) qL);
+    r.evalue = ev;   // provisional (gate only); the host recomputes it with the reference's arithmetic
+    // a result within 1e-9 of the threshold is passed on and decided by the host's exact value
+    const bool lowE = ev > gp.evalThr * (1.0 + 1e-9);
+    const float qCov = devCov(0, r.qEnd, qL), tCov = devCov(0, r.tEnd, tL);
+    const bool lowCov = !devHasCoverage(gp.covThr, gp.covMode, qCov, tCov);
+    res[i] = r;
+    if (gp.swMode == 0 || lowE || lowCov) return;
+    SwTask tk;
+    tk.qOff = qo + r.qEnd; tk.tOff = to + r.tEnd;
+    tk.n = r.qEnd + 1; tk.tL = r.tEnd + 1; tk.qStep = -1; tk.tStep = -1;
+    const int lanes = word[i] ? 16 : 32;
+    tk.segLen = max(1, (tk.n + lanes - 1) / lanes);
+    tk.slot = i; tk.boundOff = 0;
+    tasks[i] = tk;
+    keys[i] = scoreKey(tk.n, tk.tL);
+}
+
+__device__ __forceinline__ uint32_t tbKey(int band, int qLen) {
+    const int w = band * 2 + 3;
+    const int ci = w <= 127 ? 0 : (w <= 511 ? 1 : 2);
+    const unsigned long long work = (unsigned long long) ((2 * band + 1 + 31) / 32) * (unsigned long long) qLen;
+    return (uint32_t) ci * 4096u + (uint32_t) (4095 - (int) min(work >> 3, 4095ull));
+}
+constexpr uint32_t TBKEY_INVALID = 3u * 4096u;
+
+// start positions (:475-476), second coverage gate (:483-489) and traceback tasks
+__global__ void __launch_bounds__(256)
+k_gate_tb(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ, const uint32_t *__restrict__ pairT,
+          const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, const int32_t *__restrict__ outRev,
+          const uint32_t *__restrict__ revKeys, TbTask *__restrict__ tb, uint32_t *__restrict__ keys,
+          uint32_t *__restrict__ vals, uint64_t *__restrict__ dirBytes, uint64_t *__restrict__ btBytes,
+          sd_sw_result *__restrict__ res, int *__restrict__ errFlag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs) return;
+    vals[i] = i;
+    keys[i] = TBKEY_INVALID;
+    dirBytes[i] = 0;
+    btBytes[i] = 0;
+    if (revKeys[i] == KEY_INVALID) return;
+    sd_sw_result r = res[i];
+    if (outRev[3 * i] != r.score) {
+        r.flags |= 2;
+        res[i] = r;
+        atomicExch(errFlag, 1);
+        return;
+    }
+    r.tStart = r.tEnd - outRev[3 * i + 1];
+    r.qStart = r.qEnd - outRev[3 * i + 2];
+    res[i] = r;
+    const uint64_t qo = qOff[pairQ[i]], to = tOff[pairT[i]];
+    const int qL = (int) (qOff[pairQ[i] + 1] - qo), tL = (int) (tOff[pairT[i] + 1] - to);
+    const float qCov = devCov(r.qStart, r.qEnd, qL), tCov = devCov(r.tStart, r.tEnd, tL);
+    const bool lowCov = !devHasCoverage(gp.covThr, gp.covMode, qCov, tCov);
+    if (gp.swMode == 1 || lowCov) return;
+    TbTask t;
+    t.qAbs = qo + r.qStart; t.tAbs = to + r.tStart;
+    t.qLen = r.qEnd - r.qStart + 1; t.tLen = r.tEnd - r.tStart + 1;
+    t.score = r.score;
+    t.band = abs(t.tLen - t.qLen) + 1;
+    t.maxv = 0; t.slot = i; t.intOff = 0; t.dirOff = 0; t.btOff = 0;
+    tb[i] = t;
+    keys[i] = tbKey(t.band, t.qLen);
+    dirBytes[i] = (uint64_t) (2 * t.band + 1) * (uint64_t) t.qLen + 16;
+    btBytes[i] = (uint64_t) t.qLen + t.tLen + 2;
+}
+
+__global__ void __launch_bounds__(256)
+k_tb_offsets(uint32_t nPairs, const uint32_t *__restrict__ keys, const uint64_t *__restrict__ dirOff,
+             const uint64_t *__restrict__ btOff, TbTask *__restrict__ tb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs || keys[i] == TBKEY_INVALID) return;
+    tb[i].dirOff = dirOff[i];
+    tb[i].btOff = btOff[i];
+}
+
+// after a traceback round: finished tasks publish their result, the others double their band (:1492-1493)
+__global__ void __launch_bounds__(256)
+k_tb_collect(uint32_t nPairs, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, TbTask *__restrict__ tb,
+             const int32_t *__restrict__ tbRes, uint64_t *__restrict__ dirBytes, uint64_t *__restrict__ btLenOut,
+             sd_sw_result *__restrict__ res, int *__restrict__ errFlag, int maxBand) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs) return;
+    vals[i] = i;
+    if (keys[i] == TBKEY_INVALID) { dirBytes[i] = 0; return; }
+    const int len = tbRes[2 * i];
+    if (len == -2) {
+        const int band = tb[i].band * 2;
+        tb[i].band = band;
+        if (band * 2 + 3 > maxBand) { atomicExch(errFlag, 3); keys[i] = TBKEY_INVALID; dirBytes[i] = 0; return; }
+        keys[i] = tbKey(band, tb[i].qLen);
+        dirBytes[i] = (uint64_t) (2 * band + 1) * (uint64_t) tb[i].qLen + 16;
+    } else if (len < 0) {
+        atomicExch(errFlag, 2);
+        keys[i] = TBKEY_INVALID;
+        dirBytes[i] = 0;
+    } else {
+        res[i].btLen = len;
+        res[i].identical = tbRes[2 * i + 1];
+        btLenOut[i] = (uint64_t) len;
+        keys[i] = TBKEY_INVALID;
+        dirBytes[i] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_bt_pack(uint32_t nPairs, const uint64_t *__restrict__ btLen, const uint64_t *__restrict__ dense,
+          const TbTask *__restrict__ tb, const char *__restrict__ bt, char *__restrict__ pool, uint64_t poolBase,
+          sd_sw_result *__restrict__ res) {
+    // one wavefront per pair copies its backtrace into the dense pool
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= nPairs) return;
+    const uint64_t len = btLen[i];
+    if (len == 0) return;
+    const char *src = bt + tb[i].btOff;
+    char *dst = pool + dense[i];
+    for (uint64_t x = lane; x < len; x += 64) dst[x] = src[x];
+    if (lane == 0) res[i].btOffset = poolBase + dense[i];
+}
+
+template <typename T>
+int devExclusiveScan(sd_ctx *ctx, const T *in, T *out, size_t n) {
+    size_t bytes = 0;
+    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int) n, ctx->stream));
+    uint8_t *tmp = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
+    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int) n, ctx->stream));
+    return SD_OK;
+}
+
+int devSortPairs(sd_ctx *ctx, const uint32_t *kIn, uint32_t *kOut, const uint32_t *vIn, uint32_t *vOut, size_t n, int endBit) {
+    size_t bytes = 0;
+    SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kIn, kOut, vIn, vOut, (int) n, 0, endBit, ctx->stream));
+    uint8_t *tmp = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "al.sorttmp", bytes + 256, &tmp));
+    SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, bytes, kIn, kOut, vIn, vOut, (int) n, 0, endBit, ctx->stream));
+    return SD_OK;
+}
+
+__global__ void __launch_bounds__(256)
+k_bound_need(uint32_t nPairs, const SwTask *__restrict__ tasks, const uint32_t *__restrict__ keys, uint64_t *__restrict__ need) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs) return;
+    need[i] = (keys[i] != KEY_INVALID && tasks[i].n > 1024) ? (uint64_t) tasks[i].tL : 0ull;
+}
+__global__ void __launch_bounds__(256)
+k_bound_apply(uint32_t nPairs, SwTask *__restrict__ tasks, const uint64_t *__restrict__ off) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs) return;
+    tasks[i].boundOff = off[i];
+}
+
+// sort (keys,vals) -> order, read the class boundaries, launch one score kernel per RT class
+int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint32_t *dVals, uint32_t *dKeysSorted,
+                uint32_t *dOrder, uint32_t *dBounds, SwTask *dTasks, uint64_t *dScanA, uint64_t *dScanB,
+                const sd_seqset *q, const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut,
+                uint32_t *nValid) {
+    const unsigned grid = (nPairs + 255) / 256;
+    int rc = devSortPairs(ctx, dKeys, dKeysSorted, dVals, dOrder, nPairs, 13);
+    if (rc != SD_OK) return rc;
+    hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1024u, dBounds, 5);
+    // strip hand-off workspace for queries longer than one 1024-row strip
+    hipLaunchKernelGGL(k_bound_need, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dKeys, dScanA);
+    SD_HIP(ctx, hipMemsetAsync(dScanA + nPairs, 0, sizeof(uint64_t), ctx->stream));
+    rc = devExclusiveScan(ctx, dScanA, dScanB, (size_t) nPairs + 1);
+    if (rc != SD_OK) return rc;
+    hipLaunchKernelGGL(k_bound_apply, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dScanB);
+    uint32_t hb[5];
+    uint64_t boundTotal = 0;
+    SD_HIP(ctx, hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipMemcpyAsync(&boundTotal, dScanB + nPairs, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *nValid = hb[4];
+    uint2 *dBound = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "sw.bound", std::max<uint64_t>(boundTotal, 1), &dBound));
+    for (int ci = 0; ci < 4; ci++) {
+        const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
+        if (cnt == 0) continue;
+        ProfScope ps(ctx, "sw_score");
+        switch (ci) {
+            case 0: launchScoreIdx<4>(ctx, dTasks, dOrder + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 1: launchScoreIdx<8>(ctx, dTasks, dOrder + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 2: launchScoreIdx<16>(ctx, dTasks, dOrder + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            default: launchScoreIdx<32>(ctx, dTasks, dOrder + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+        }
+    }
+    SD_HIP(ctx, hipGetLastError());
+    return SD_OK;
+}
+
+__global__ void __launch_bounds__(256)
+k_cells(uint32_t nPairs, const SwTask *__restrict__ tasks, const uint32_t *__restrict__ keys, unsigned long long *__restrict__ acc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    if (i < nPairs && keys[i] != KEY_INVALID) c = (unsigned long long) tasks[i].n * (unsigned long long) tasks[i].tL;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(acc, c);
 }
 
 }  // namespace
@@ -656,6 +1010,250 @@ int sd_sw_score_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
 }
 
 int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                      uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
+                      sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed) {
+    if (!ctx || !par || !queries || !targets || !out) return SD_EINVAL;
+    (void) hipSetDevice(ctx->device);
+    if (btUsed) *btUsed = 0;
+    if (nPairs == 0) return SD_OK;
+    const int go = par->gapOpen, ge = par->gapExtend;
+    ctx->cellsFwd = ctx->cellsRev = ctx->cellsTb = 0;
+    sd::Evaluer ev;
+    sd::initEvaluer(ev, par->dbResidues);
+    int matMin = 0;
+    for (int i = 0; i < 441; i++) matMin = std::min(matMin, (int) par->matrix[i]);
+    for (uint32_t i = 0; i < nPairs; i++)
+        if (pairQ[i] >= queries->n || pairT[i] >= targets->n) return sdFail(ctx, SD_EINVAL, "pair %u out of range", i);
+    std::unique_ptr<HostScope> hs(new HostScope(ctx, "align.upload"));
+    DevGateParams gp;
+    gp.go = go; gp.ge = ge; gp.matMin = matMin; gp.swMode = par->swMode; gp.covMode = par->covMode; gp.covThr = par->covThr;
+    gp.evalThr = par->evalThr;
+    gp.lambda = ev.lambda; gp.K = ev.K; gp.aI = ev.aI; gp.bI = ev.bI; gp.alphaI = ev.alphaI; gp.betaI = ev.betaI;
+    gp.aJ = ev.aJ; gp.bJ = ev.bJ; gp.alphaJ = ev.alphaJ; gp.betaJ = ev.betaJ; gp.sigma = ev.sigma; gp.tau = ev.tau;
+    gp.viThr = ev.viThr; gp.vjThr = ev.vjThr; gp.cThr = ev.cThr; gp.dbResidues = ev.dbResidues;
+
+    const size_t N = nPairs;
+    const unsigned grid = (unsigned) ((N + 255) / 256);
+    int8_t *dMat = nullptr;
+    uint32_t *dPQ = nullptr, *dPT = nullptr, *dKeys = nullptr, *dVals = nullptr, *dKeysS = nullptr, *dOrder = nullptr,
+             *dBounds = nullptr, *dFwdKeys = nullptr, *dRevKeys = nullptr;
+    uint8_t *dIdent = nullptr, *dWord = nullptr;
+    int32_t *dMinBias = nullptr, *dOut32 = nullptr, *dOut16 = nullptr, *dOutRev = nullptr, *dTbRes = nullptr;
+    int *dErr = nullptr;
+    SwTask *dTasks = nullptr;
+    TbTask *dTb = nullptr;
+    sd_sw_result *dRes = nullptr;
+    uint64_t *dScanA = nullptr, *dScanB = nullptr, *dDirBytes = nullptr, *dDirOff = nullptr, *dBtBytes = nullptr,
+             *dBtOff = nullptr, *dBtLen = nullptr, *dDense = nullptr;
+    unsigned long long *dCells = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "al.mat", 448, &dMat));
+    SD_HIP(ctx, wsGet(ctx, "al.pq", N, &dPQ));
+    SD_HIP(ctx, wsGet(ctx, "al.pt", N, &dPT));
+    SD_HIP(ctx, wsGet(ctx, "al.ident", N, &dIdent));
+    SD_HIP(ctx, wsGet(ctx, "al.word", N, &dWord));
+    SD_HIP(ctx, wsGet(ctx, "al.keys", N, &dKeys));
+    SD_HIP(ctx, wsGet(ctx, "al.vals", N, &dVals));
+    SD_HIP(ctx, wsGet(ctx, "al.keyss", N, &dKeysS));
+    SD_HIP(ctx, wsGet(ctx, "al.order", N, &dOrder));
+    SD_HIP(ctx, wsGet(ctx, "al.fwdkeys", N, &dFwdKeys));
+    SD_HIP(ctx, wsGet(ctx, "al.revkeys", N, &dRevKeys));
+    SD_HIP(ctx, wsGet(ctx, "al.bounds", 16, &dBounds));
+    SD_HIP(ctx, wsGet(ctx, "al.minbias", queries->n, &dMinBias));
+    SD_HIP(ctx, wsGet(ctx, "al.out32", N * 3, &dOut32));
+    SD_HIP(ctx, wsGet(ctx, "al.out16", N * 3, &dOut16));
+    SD_HIP(ctx, wsGet(ctx, "al.outrev", N * 3, &dOutRev));
+    SD_HIP(ctx, wsGet(ctx, "al.tbres", N * 2, &dTbRes));
+    SD_HIP(ctx, wsGet(ctx, "al.err", 4, &dErr));
+    SD_HIP(ctx, wsGet(ctx, "al.tasks", N, &dTasks));
+    SD_HIP(ctx, wsGet(ctx, "al.tb", N, &dTb));
+    SD_HIP(ctx, wsGet(ctx, "al.res", N, &dRes));
+    SD_HIP(ctx, wsGet(ctx, "al.scana", N + 1, &dScanA));
+    SD_HIP(ctx, wsGet(ctx, "al.scanb", N + 1, &dScanB));
+    SD_HIP(ctx, wsGet(ctx, "al.dirbytes", N + 1, &dDirBytes));
+    SD_HIP(ctx, wsGet(ctx, "al.diroff", N + 1, &dDirOff));
+    SD_HIP(ctx, wsGet(ctx, "al.btbytes", N + 1, &dBtBytes));
+    SD_HIP(ctx, wsGet(ctx, "al.btoff", N + 1, &dBtOff));
+    SD_HIP(ctx, wsGet(ctx, "al.btlen", N + 1, &dBtLen));
+    SD_HIP(ctx, wsGet(ctx, "al.dense", N + 1, &dDense));
+    SD_HIP(ctx, wsGet(ctx, "al.cells", 4, &dCells));
+    SD_HIP(ctx, hipMemcpyAsync(dMat, par->matrix, 441, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(ctx, hipMemcpyAsync(dPQ, pairQ, N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(ctx, hipMemcpyAsync(dPT, pairT, N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (isIdentity) SD_HIP(ctx, hipMemcpyAsync(dIdent, isIdentity, N, hipMemcpyHostToDevice, ctx->stream));
+    else SD_HIP(ctx, hipMemsetAsync(dIdent, 0, N, ctx->stream));
+    SD_HIP(ctx, hipMemcpyAsync(dMinBias, queries->hMinBias.data(), queries->n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(ctx, hipMemsetAsync(dErr, 0, 4 * sizeof(int), ctx->stream));
+    SD_HIP(ctx, hipMemsetAsync(dCells, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    SD_HIP(ctx, hipMemsetAsync(dOut32, 0, N * 3 * sizeof(int32_t), ctx->stream));
+    SD_HIP(ctx, hipMemsetAsync(dOut16, 0, N * 3 * sizeof(int32_t), ctx->stream));
+    SD_HIP(ctx, hipMemsetAsync(dOutRev, 0, N * 3 * sizeof(int32_t), ctx->stream));
+    SD_HIP(ctx, hipMemsetAsync(dBtLen, 0, (N + 1) * sizeof(uint64_t), ctx->stream));
+
+    // ---- pass 1: forward, byte-kernel lane structure
+    hs.reset(new HostScope(ctx, "align.fwd32"));
+    uint32_t nValid = 0;
+    hipLaunchKernelGGL(k_make_fwd, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dPT, dIdent, queries->dOff, targets->dOff,
+                       dTasks, dFwdKeys, dVals, dRes);
+    hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dFwdKeys, dCells + 0);
+    int rc = devRunScore(ctx, nPairs, dFwdKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go,
+                         ge, dOut32, &nValid);
+    if (rc != SD_OK) return rc;
+    // ---- pass 2: saturated pairs again with the word kernel's 16-lane structure
+    hs.reset(new HostScope(ctx, "align.fwd16"));
+    hipLaunchKernelGGL(k_gate_word, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dOut32, dMinBias, matMin, dTasks, dKeys,
+                       dVals, dWord, dFwdKeys);
+    hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dKeys, dCells + 0);
+    rc = devRunScore(ctx, nPairs, dKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go, ge,
+                     dOut16, &nValid);
+    if (rc != SD_OK) return rc;
+    // ---- gates + pass 3: start positions
+    hs.reset(new HostScope(ctx, "align.rev"));
+    hipLaunchKernelGGL(k_gate_rev, dim3(grid), dim3(256), 0, ctx->stream, nPairs, gp, dPQ, dPT, queries->dOff, targets->dOff, dOut32,
+                       dOut16, dWord, dFwdKeys, dTasks, dRevKeys, dVals, dRes);
+    hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dRevKeys, dCells + 1);
+    rc = devRunScore(ctx, nPairs, dRevKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go, ge,
+                     dOutRev, &nValid);
+    if (rc != SD_OK) return rc;
+    // ---- pass 4: banded traceback, band doubling on the device
+    hs.reset(new HostScope(ctx, "align.traceback"));
+    hipLaunchKernelGGL(k_gate_tb, dim3(grid), dim3(256), 0, ctx->stream, nPairs, gp, dPQ, dPT, queries->dOff, targets->dOff, dOutRev,
+                       dRevKeys, dTb, dKeys, dVals, dDirBytes, dBtBytes, dRes, dErr);
+    SD_HIP(ctx, hipMemsetAsync(dBtBytes + N, 0, sizeof(uint64_t), ctx->stream));
+    rc = devExclusiveScan(ctx, dBtBytes, dBtOff, N + 1);
+    if (rc != SD_OK) return rc;
+    uint64_t btScratch = 0;
+    SD_HIP(ctx, hipMemcpyAsync(&btScratch, dBtOff + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    char *dBt = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "tb.bt", btScratch + 64, &dBt));
+    const uint64_t SCRATCH_BUDGET = 16ull << 30;
+    for (int round = 0; round < 24; round++) {
+        SD_HIP(ctx, hipMemsetAsync(dDirBytes + N, 0, sizeof(uint64_t), ctx->stream));
+        rc = devExclusiveScan(ctx, dDirBytes, dDirOff, N + 1);
+        if (rc != SD_OK) return rc;
+        hipLaunchKernelGGL(k_tb_offsets, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dDirOff, dBtOff, dTb);
+        rc = devSortPairs(ctx, dKeys, dKeysS, dVals, dOrder, nPairs, 14);
+        if (rc != SD_OK) return rc;
+        hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysS, nPairs, 4096u, dBounds, 4);
+        uint32_t hb[4];
+        uint64_t dirTotal = 0;
+        SD_HIP(ctx, hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(&dirTotal, dDirOff + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hb[3] == 0) break;   // nothing left
+        if (dirTotal > SCRATCH_BUDGET) return sdFail(ctx, SD_ENOMEM, "traceback direction scratch of %llu bytes exceeds the budget; use smaller batches", (unsigned long long) dirTotal);
+        int8_t *dDir = nullptr;
+        SD_HIP(ctx, wsGet(ctx, "tb.dir", dirTotal + 64, &dDir));
+        static const int ldsClass[3] = {128, 512, 2048};
+        for (int ci = 0; ci < 3; ci++) {
+            const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
+            if (cnt == 0) continue;
+            ProfScope ps(ctx, "sw_traceback");
+            const int ldsStride = ldsClass[ci] + 1;
+            const size_t ldsBytes = (size_t) 2 * 3 * ldsStride * sizeof(int32_t);
+            hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
+                               queries->dBias, targets->dRes, dMat, go, ge, ldsStride, dDir, dBt, dTbRes, dOrder + begin);
+        }
+        SD_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_tb_collect, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dVals, dTb, dTbRes, dDirBytes, dBtLen,
+                           dRes, dErr, 2047);
+    }
+    // ---- dense backtrace pool + results back to the host
+    hs.reset(new HostScope(ctx, "align.download"));
+    rc = devExclusiveScan(ctx, dBtLen, dDense, N + 1);
+    if (rc != SD_OK) return rc;
+    uint64_t poolBytes = 0;
+    int hErr[4] = {0, 0, 0, 0};
+    unsigned long long hCells[4] = {0, 0, 0, 0};
+    SD_HIP(ctx, hipMemcpyAsync(&poolBytes, dDense + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipMemcpyAsync(hErr, dErr, sizeof(hErr), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipMemcpyAsync(hCells, dCells, sizeof(hCells), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hErr[0] == 1) return sdFail(ctx, SD_EMISMATCH, "Score of forward/backward SW differ (fatal in the reference, StripedSmithWaterman.cpp:466-473)");
+    if (hErr[0] == 2) return sdFail(ctx, SD_EHIP, "Trace back error");
+    if (hErr[0] == 3) return sdFail(ctx, SD_EUNSUPPORTED, "traceback band exceeds the LDS-resident limit");
+    ctx->cellsFwd = hCells[0];
+    ctx->cellsRev = hCells[1];
+    // identity pairs need pool space too (scoreIdentical backtraces are written by the host below)
+    uint64_t identBytes = 0;
+    if (isIdentity && btPool)
+        for (uint32_t i = 0; i < nPairs; i++)
+            if (isIdentity[i]) identBytes += targets->hOff[pairT[i] + 1] - targets->hOff[pairT[i]];
+    if (poolBytes > 0 && btPool == nullptr) return sdFail(ctx, SD_EINVAL, "swMode 2 needs a backtrace pool");
+    if (poolBytes + identBytes > btCap && btPool) return sdFail(ctx, SD_ENOMEM, "backtrace pool too small");
+    char *dPool = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "al.pool", poolBytes + 64, &dPool));
+    if (poolBytes > 0)
+        hipLaunchKernelGGL(k_bt_pack, dim3((nPairs + 3) / 4), dim3(256), 0, ctx->stream, nPairs, dBtLen, dDense, dTb, dBt, dPool,
+                           (uint64_t) 0, dRes);
+    sd_sw_result *hRes = nullptr;
+    char *hPool = nullptr;
+    SD_HIP(ctx, pinGet(ctx, "al.hres", N, &hRes));
+    SD_HIP(ctx, pinGet(ctx, "al.hpool", poolBytes + 64, &hPool));
+    SD_HIP(ctx, hipMemcpyAsync(hRes, dRes, N * sizeof(sd_sw_result), hipMemcpyDeviceToHost, ctx->stream));
+    if (poolBytes > 0) SD_HIP(ctx, hipMemcpyAsync(hPool, dPool, poolBytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hs.reset(new HostScope(ctx, "align.finish"));
+    {
+        const int nth = std::max(1, std::min(omp_get_max_threads(), 64));
+        const size_t blk = (poolBytes + nth - 1) / nth;
+#pragma omp parallel for schedule(static) num_threads(nth)
+        for (int t = 0; t < nth; t++) {
+            const size_t a = std::min<size_t>(poolBytes, (size_t) t * blk), b = std::min<size_t>(poolBytes, a + blk);
+            if (b > a) memcpy(btPool + a, hPool + a, b - a);
+        }
+    }
+    uint64_t btPos = poolBytes;
+    // exact E-values (the device value only served the gate), identity pairs, and the rare results the device
+    // let through because they sat within 1e-9 of the E-value threshold
+#pragma omp parallel for schedule(static)
+    for (uint32_t i = 0; i < nPairs; i++) {
+        sd_sw_result r = hRes[i];
+        if (!(isIdentity && isIdentity[i])) {
+            const int qL = (int) (queries->hOff[pairQ[i] + 1] - queries->hOff[pairQ[i]]);
+            if (r.tEnd != -1 && qL > 0) {
+                r.evalue = sd::computeEvalue(ev, r.score, qL);
+                if (r.evalue > par->evalThr && r.qStart != -1) {   // decided by the host's exact value
+                    r.qStart = -1; r.tStart = -1; r.identical = 0; r.btLen = 0; r.btOffset = 0; r.flags &= 1;
+                }
+            } else {
+                r.evalue = 0.0;
+            }
+        }
+        out[i] = r;
+    }
+    if (isIdentity) {
+        for (uint32_t i = 0; i < nPairs; i++) {
+            if (!isIdentity[i]) continue;
+            // scoreIdentical (StripedSmithWaterman.cpp:1675-1710), host side, O(L)
+            const int L = (int) (targets->hOff[pairT[i] + 1] - targets->hOff[pairT[i]]);
+            const int qL = (int) (queries->hOff[pairQ[i] + 1] - queries->hOff[pairQ[i]]);
+            if (qL != L) return sdFail(ctx, SD_EINVAL, "scoreIdentical has different lengths for pair %u", i);
+            const uint8_t *q = queries->hRes.data() + queries->hOff[pairQ[i]];
+            const int8_t *cb = queries->hBias.data() + queries->hOff[pairQ[i]];
+            const uint8_t *t = targets->hRes.data() + targets->hOff[pairT[i]];
+            short score = 0;
+            for (int p = 0; p < L; p++) score += (short) (par->matrix[t[p] * 21 + q[p]] + cb[p]);
+            sd_sw_result &r = out[i];
+            r.score = (int32_t) (uint32_t) (int) score;
+            r.qStart = par->swMode == 0 ? -1 : 0;
+            r.tStart = par->swMode == 0 ? -1 : 0;
+            r.qEnd = L - 1; r.tEnd = L - 1; r.identical = L; r.btLen = L; r.flags = 0;
+            r.evalue = sd::computeEvalue(ev, (double) (uint32_t) r.score, qL);
+            r.btOffset = 0;
+            if (btPool) {
+                memset(btPool + btPos, 'M', L);
+                r.btOffset = btPos;
+                btPos += L;
+            }
+        }
+    }
+    if (btUsed) *btUsed = btPos;
+    hs.reset();
+    return SD_OK;
+}
+
+int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
                       uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
                       sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed) {
     if (!ctx || !par || !queries || !targets || !out) return SD_EINVAL;
@@ -863,7 +1461,8 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
                 const int ldsStride = cls + 1;
                 const size_t ldsBytes = (size_t) 2 * 3 * ldsStride * sizeof(int32_t);
                 hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dT.p, cnt,
-                                   queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, ldsStride, dDir.p, dBt.p, dRes.p);
+                                   queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, ldsStride, dDir.p, dBt.p, dRes.p,
+                                   (const uint32_t *) nullptr);
             }
             SD_HIP(ctx, hipGetLastError());
             TbTask *back = nullptr;

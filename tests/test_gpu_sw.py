@@ -109,3 +109,27 @@ def test_sw_long_query_strips(gpu, host, oracle):
         if o['btLen'] > 0:
             bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
             assert bt == o['backtrace']
+
+
+def test_sw_device_vs_host_orchestration(gpu, host):
+    """the device-resident gating / task building gives the same records as the host-side one, at a size the
+    oracle would not finish in seconds (all sw modes, all coverage modes)"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=6, genes_per_proteome=260, n_families=400, seed=23)
+    rng = np.random.default_rng(11)
+    pq, pt = _pairs(ps, rng, 4000)
+    sw_bias, _, _ = host.comp_bias(ps.residues, ps.offsets)
+    mat, _, _ = host.matrix(0)
+    db = int(ps.offsets[-1])
+    ss = gpu.seqset(ps.residues, ps.offsets, sw_bias)
+    for sw_mode, cov_mode, ev in ((2, 2, 10.0), (1, 0, 1e-3), (0, 1, 10.0), (2, 3, 1e-5)):
+        par = gpu.sw_params(mat, db, cov_mode=cov_mode, eval_thr=ev, sw_mode=sw_mode)
+        ident = (pq == pt)
+        a, pa = gpu.sw_align(par, ss, ss, pq, pt, identity=ident)
+        b, pb = gpu.sw_align(par, ss, ss, pq, pt, identity=ident, hostpath=True)
+        for f in ('score', 'qStart', 'qEnd', 'tStart', 'tEnd', 'identical', 'btLen', 'flags', 'evalue'):
+            assert np.array_equal(a[f], b[f]), (sw_mode, cov_mode, f, np.flatnonzero(a[f] != b[f])[:5])
+        for x in np.flatnonzero(a['btLen'] > 0)[::7]:
+            sa = pa[int(a['btOffset'][x]):int(a['btOffset'][x]) + int(a['btLen'][x])]
+            sb = pb[int(b['btOffset'][x]):int(b['btOffset'][x]) + int(b['btLen'][x])]
+            assert np.array_equal(sa, sb), x
