@@ -27,20 +27,11 @@
 #include <numeric>
 
 #include "../host/sd_host.h"
+#include "sd_sw_pk.h"
 
 namespace {
 
-struct SwTask {
-    uint64_t qOff;     // absolute index (into the residue array) of the first scanned query residue
-    uint64_t tOff;     // absolute index of the first scanned target residue
-    int32_t n;         // query rows used
-    int32_t tL;        // target columns scanned
-    int32_t qStep;     // +1 forward, -1 reverse pass
-    int32_t tStep;
-    int32_t segLen;    // ceil(n / lanes) of the reference kernel being reproduced
-    uint32_t slot;     // output slot
-    uint64_t boundOff; // offset into the strip boundary workspace (multi-strip tasks only)
-};
+using sdpk::SwTask;
 
 template <int RT>
 __global__ void __launch_bounds__(64)
@@ -364,6 +355,15 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
     res[2 * id + 1] = ids;
 }
 
+template <int RT, bool MULTI>
+void launchScorePk(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, uint32_t n, const sd_seqset *q,
+                   const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut, uint2 *dBound) {
+    if (n == 0) return;
+    dim3 grid((n + 3) / 4), block(64);
+    hipLaunchKernelGGL((sdpk::sw_score_pk_kernel<RT, MULTI>), grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes,
+                       dMat, go, ge, dOut, dBound, dOrder);
+}
+
 int rtClass(int n) {
     if (n <= 128) return 4;
     if (n <= 256) return 8;
@@ -491,9 +491,17 @@ int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, c
 // the ordering of tasks all happen on the GPU; the host only launches, reads six class boundaries per pass
 // and receives the finished result records + a dense backtrace pool.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t KEY_INVALID = 4u * 1024u;            // sorts after every class
-__device__ __forceinline__ uint32_t scoreKey(int n, int tL) {
-    const int ci = n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3));
+constexpr uint32_t N_SCORE_CLASSES = 10;   // 0-5 packed-int16 kernel (by rows / strips), 6-9 int32 kernel (by rows)
+constexpr uint32_t KEY_INVALID = N_SCORE_CLASSES * 1024u;   // sorts after every class
+__device__ __forceinline__ uint32_t scoreKey(int n, int tL, bool int32Kernel) {
+    int ci;
+    if (int32Kernel || tL > 65535) {
+        ci = 6 + (n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3)));
+    } else if (n <= 512) {
+        ci = n <= 128 ? 0 : (n <= 256 ? 1 : 2);
+    } else {
+        ci = min(2 + (n + 511) / 512 - 1, 5);   // 2 strips -> 3, 3 strips -> 4, more -> 5
+    }
     return (uint32_t) ci * 1024u + (uint32_t) (1023 - min(tL >> 4, 1023));
 }
 
@@ -546,7 +554,7 @@ __global__ void __launch_bounds__(256)
 k_make_fwd(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const uint32_t *__restrict__ pairT,
            const uint8_t *__restrict__ ident, const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff,
            SwTask *__restrict__ tasks, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-           sd_sw_result *__restrict__ res) {
+           sd_sw_result *__restrict__ res, int usePk) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPairs) return;
     const uint64_t qo = qOff[pairQ[i]], to = tOff[pairT[i]];
@@ -557,7 +565,7 @@ k_make_fwd(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const uint32_t *
     tk.slot = i; tk.boundOff = 0;
     const bool valid = !(ident && ident[i]) && qL > 0 && tL > 0;
     tasks[i] = tk;
-    keys[i] = valid ? scoreKey(qL, tL) : KEY_INVALID;
+    keys[i] = valid ? scoreKey(qL, tL, !usePk) : KEY_INVALID;
     vals[i] = i;
     sd_sw_result r;
     r.score = 0; r.qStart = -1; r.qEnd = -1; r.tStart = -1; r.tEnd = -1; r.identical = 0; r.btLen = 0; r.flags = 0;
@@ -596,7 +604,7 @@ k_gate_word(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const int32_t *
     word[i] = w ? 1 : 0;
     if (w) {
         tasks[i].segLen = max(1, (tasks[i].n + 15) / 16);
-        keys[i] = scoreKey(tasks[i].n, tasks[i].tL);
+        keys[i] = scoreKey(tasks[i].n, tasks[i].tL, true);
     } else {
         keys[i] = KEY_INVALID;
     }
@@ -608,7 +616,7 @@ k_gate_rev(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ
            const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, const int32_t *__restrict__ out32,
            const int32_t *__restrict__ out16, const uint8_t *__restrict__ word, const uint32_t *__restrict__ fwdKeys,
            SwTask *__restrict__ tasks, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-           sd_sw_result *__restrict__ res) {
+           sd_sw_result *__restrict__ res, int usePk) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPairs) return;
     vals[i] = i;
@@ -639,7 +647,7 @@ k_gate_rev(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ
     tk.segLen = max(1, (tk.n + lanes - 1) / lanes);
     tk.slot = i; tk.boundOff = 0;
     tasks[i] = tk;
-    keys[i] = scoreKey(tk.n, tk.tL);
+    keys[i] = scoreKey(tk.n, tk.tL, word[i] || !usePk);
 }
 
 __device__ __forceinline__ uint32_t tbKey(int band, int qLen) {
@@ -768,7 +776,15 @@ __global__ void __launch_bounds__(256)
 k_bound_need(uint32_t nPairs, const SwTask *__restrict__ tasks, const uint32_t *__restrict__ keys, uint64_t *__restrict__ need) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPairs) return;
-    need[i] = (keys[i] != KEY_INVALID && tasks[i].n > 1024) ? (uint64_t) tasks[i].tL : 0ull;
+    // units of uint2: the packed kernel hands over 16 bytes per column and strips every 512 rows, the int32
+    // kernel 8 bytes and every 1024 rows
+    uint64_t v = 0;
+    if (keys[i] != KEY_INVALID) {
+        const uint32_t ci = keys[i] >> 10;
+        if (ci >= 3 && ci <= 5) v = 2ull * (uint64_t) tasks[i].tL;
+        else if (ci == 9 && tasks[i].n > 1024) v = (uint64_t) tasks[i].tL;
+    }
+    need[i] = v;
 }
 __global__ void __launch_bounds__(256)
 k_bound_apply(uint32_t nPairs, SwTask *__restrict__ tasks, const uint64_t *__restrict__ off) {
@@ -783,32 +799,37 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
                 const sd_seqset *q, const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut,
                 uint32_t *nValid) {
     const unsigned grid = (nPairs + 255) / 256;
-    int rc = devSortPairs(ctx, dKeys, dKeysSorted, dVals, dOrder, nPairs, 13);
+    int rc = devSortPairs(ctx, dKeys, dKeysSorted, dVals, dOrder, nPairs, 14);
     if (rc != SD_OK) return rc;
-    hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1024u, dBounds, 5);
+    hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1024u, dBounds, (int) N_SCORE_CLASSES + 1);
     // strip hand-off workspace for queries longer than one 1024-row strip
     hipLaunchKernelGGL(k_bound_need, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dKeys, dScanA);
     SD_HIP(ctx, hipMemsetAsync(dScanA + nPairs, 0, sizeof(uint64_t), ctx->stream));
     rc = devExclusiveScan(ctx, dScanA, dScanB, (size_t) nPairs + 1);
     if (rc != SD_OK) return rc;
     hipLaunchKernelGGL(k_bound_apply, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dScanB);
-    uint32_t hb[5];
+    uint32_t hb[N_SCORE_CLASSES + 1];
     uint64_t boundTotal = 0;
     SD_HIP(ctx, hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(&boundTotal, dScanB + nPairs, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *nValid = hb[4];
+    *nValid = hb[N_SCORE_CLASSES];
     uint2 *dBound = nullptr;
     SD_HIP(ctx, wsGet(ctx, "sw.bound", std::max<uint64_t>(boundTotal, 1), &dBound));
-    for (int ci = 0; ci < 4; ci++) {
+    for (uint32_t ci = 0; ci < N_SCORE_CLASSES; ci++) {
         const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
         if (cnt == 0) continue;
-        ProfScope ps(ctx, "sw_score");
+        ProfScope ps(ctx, ci < 6 ? "sw_score_pk" : "sw_score");
+        const uint32_t *ord = dOrder + begin;
         switch (ci) {
-            case 0: launchScoreIdx<4>(ctx, dTasks, dOrder + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 1: launchScoreIdx<8>(ctx, dTasks, dOrder + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 2: launchScoreIdx<16>(ctx, dTasks, dOrder + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            default: launchScoreIdx<32>(ctx, dTasks, dOrder + begin, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 0: launchScorePk<4, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 1: launchScorePk<8, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 2: launchScorePk<16, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 3: case 4: case 5: launchScorePk<16, true>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 6: launchScoreIdx<4>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 7: launchScoreIdx<8>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 8: launchScoreIdx<16>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            default: launchScoreIdx<32>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
         }
     }
     SD_HIP(ctx, hipGetLastError());
@@ -1057,7 +1078,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     SD_HIP(ctx, wsGet(ctx, "al.order", N, &dOrder));
     SD_HIP(ctx, wsGet(ctx, "al.fwdkeys", N, &dFwdKeys));
     SD_HIP(ctx, wsGet(ctx, "al.revkeys", N, &dRevKeys));
-    SD_HIP(ctx, wsGet(ctx, "al.bounds", 16, &dBounds));
+    SD_HIP(ctx, wsGet(ctx, "al.bounds", 32, &dBounds));
     SD_HIP(ctx, wsGet(ctx, "al.minbias", queries->n, &dMinBias));
     SD_HIP(ctx, wsGet(ctx, "al.out32", N * 3, &dOut32));
     SD_HIP(ctx, wsGet(ctx, "al.out16", N * 3, &dOut16));
@@ -1091,9 +1112,11 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
 
     // ---- pass 1: forward, byte-kernel lane structure
     hs.reset(new HostScope(ctx, "align.fwd32"));
+    // the packed-int16 kernel's recurrence needs go >= ge (see sd_sw_pk.h); SD_SW_INT32=1 forces the int32 kernel
+    const int usePk = (go >= ge && go < 1024 && ge >= 0 && getenv("SD_SW_INT32") == nullptr) ? 1 : 0;
     uint32_t nValid = 0;
     hipLaunchKernelGGL(k_make_fwd, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dPT, dIdent, queries->dOff, targets->dOff,
-                       dTasks, dFwdKeys, dVals, dRes);
+                       dTasks, dFwdKeys, dVals, dRes, usePk);
     hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dFwdKeys, dCells + 0);
     int rc = devRunScore(ctx, nPairs, dFwdKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go,
                          ge, dOut32, &nValid);
@@ -1109,7 +1132,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     // ---- gates + pass 3: start positions
     hs.reset(new HostScope(ctx, "align.rev"));
     hipLaunchKernelGGL(k_gate_rev, dim3(grid), dim3(256), 0, ctx->stream, nPairs, gp, dPQ, dPT, queries->dOff, targets->dOff, dOut32,
-                       dOut16, dWord, dFwdKeys, dTasks, dRevKeys, dVals, dRes);
+                       dOut16, dWord, dFwdKeys, dTasks, dRevKeys, dVals, dRes, usePk);
     hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dRevKeys, dCells + 1);
     rc = devRunScore(ctx, nPairs, dRevKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go, ge,
                      dOutRev, &nValid);

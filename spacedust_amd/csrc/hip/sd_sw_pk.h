@@ -1,0 +1,346 @@
+// Packed-int16 score pass: the kernel the forward and start-position passes of sd_sw_align_batch run on
+// whenever the score provably fits (byte-kernel lane structure, StripedSmithWaterman.cpp:639-915).
+//
+// Mapping onto a CDNA4 wavefront
+//   * a 32-lane half wavefront owns TWO (query,target) pairs: pair A lives in the low 16 bits of every
+//     DP register, pair B in the high 16 bits, so each v_pk_* instruction advances two cells;
+//   * lane l owns RT consecutive query rows of both pairs and walks the target one column per step,
+//     one column behind lane l-1 (systolic anti-diagonal): the only traffic between lanes is the
+//     (H, F_first, F_lazy, residue) hand-off, done with DPP wave_shr:1 moves -- no LDS, no bpermute;
+//   * the int8 query profiles (21 residues + 1 neutral row) sit in LDS, read as RT/4 dwords per pair and
+//     step; profile bytes are sign-extended and added to the diagonal in one SDWA v_add_u16 per cell;
+//   * target residues are fetched 32 columns at a time (coalesced) and fed to lane 0 with v_readlane.
+// DP state per row pair: H (for the next column's diagonal) and E, both in VGPRs.  The reference's
+// recurrence (see sw_score_kernel) is evaluated with unsigned saturating subtractions, which supply every
+// max(...,0) of the original for free, and with F_first' = max(F_first - ge, Hpre - go), which equals
+// max(F_first - ge, G - go) whenever go >= ge (G - go = max(Hpre - go, F_first - go) <= the former).
+// The column maximum carries the row in its low five bits (g*32 + 31-r, saturating): exact while g < 1024,
+// and a saturated result (1023) is above every byte-kernel overflow threshold, so such pairs are rerun by
+// the caller with the int32 kernel exactly like the reference reruns them with its word kernel.
+#ifndef SD_SW_PK_H
+#define SD_SW_PK_H
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace sdpk {
+
+struct SwTask {
+    uint64_t qOff;     // absolute index (into the residue array) of the first scanned query residue
+    uint64_t tOff;     // absolute index of the first scanned target residue
+    int32_t n;         // query rows used
+    int32_t tL;        // target columns scanned
+    int32_t qStep;     // +1 forward, -1 reverse pass
+    int32_t tStep;
+    int32_t segLen;    // ceil(n / lanes) of the reference kernel being reproduced
+    uint32_t slot;     // output slot
+    uint64_t boundOff; // offset (in uint2 units) into the strip boundary workspace (multi-strip tasks only)
+};
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pkMax(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pkSubSat(uint32_t a, uint32_t b) {   // unsigned, saturating at 0
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pkSub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (s16x2) (__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pkAdd(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (s16x2) (__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pkLshr(uint32_t a, int s) {
+    return __builtin_bit_cast(uint32_t, (u16x2) (__builtin_bit_cast(u16x2, a) >> (u16x2) ((unsigned short) s)));
+}
+__device__ __forceinline__ uint32_t pkAshr(uint32_t a, int s) {
+    return __builtin_bit_cast(uint32_t, (s16x2) (__builtin_bit_cast(s16x2, a) >> (s16x2) ((short) s)));
+}
+// g*32 + code in both halves, saturating to int16
+__device__ __forceinline__ uint32_t pkRowCode(uint32_t g, int code) {
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, 32, %2 op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(g), "s"(code));
+    return r;
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+// h_k = d_k + sext(byte k of pa) in the low half, d_k + sext(byte k of pb) in the high half, k = 0..3.
+// The eight SDWA adds are ordered so that no instruction reads the destination of its predecessor (gfx950
+// needs one wait state after a dst_sel write); the closing s_nop covers the first consumer.
+__device__ __forceinline__ void addProfile4(uint32_t pa, uint32_t pb, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
+                                            uint32_t &h0, uint32_t &h1, uint32_t &h2, uint32_t &h3) {
+    asm("v_add_u16_sdwa %0, %4, sext(%8) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_0\n\t"
+        "v_add_u16_sdwa %1, %5, sext(%8) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_1\n\t"
+        "v_add_u16_sdwa %2, %6, sext(%8) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_2\n\t"
+        "v_add_u16_sdwa %3, %7, sext(%8) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_3\n\t"
+        "v_add_u16_sdwa %0, %4, sext(%9) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_0\n\t"
+        "v_add_u16_sdwa %1, %5, sext(%9) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1\n\t"
+        "v_add_u16_sdwa %2, %6, sext(%9) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_2\n\t"
+        "v_add_u16_sdwa %3, %7, sext(%9) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3\n\t"
+        "s_nop 0"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3)
+        : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(pa), "v"(pb));
+}
+
+__device__ __forceinline__ uint32_t dppShr1(uint32_t v) {
+    // lane i receives lane i-1 (whole wavefront); lane 0 receives 0
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// value (wave-uniform) into one lane of a VGPR
+template <int LANE>
+__device__ __forceinline__ uint32_t writeLane(uint32_t value, uint32_t old) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(LANE));
+    return old;
+}
+__device__ __forceinline__ uint32_t readLane(uint32_t v, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, lane);
+#else
+    (void) lane;
+    return v;
+#endif
+}
+
+constexpr int PK_NEUTRAL = 21;   // profile row of -64s: columns outside the target
+
+// RT rows per lane and pair; ROWS = 32*RT rows per strip.  MULTI: queries longer than one strip.
+template <int RT, bool MULTI>
+__global__ void __launch_bounds__(64)
+sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
+                   const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
+                   int go, int ge, int32_t *__restrict__ out, uint2 *__restrict__ boundary,
+                   const uint32_t *__restrict__ order) {
+    constexpr int ROWS = 32 * RT;
+    constexpr int WORDS = RT / 4;
+    __shared__ uint32_t prof[4][22][ROWS / 4];
+    __shared__ int8_t smat[441];
+    for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x;
+    const int grp = lane >> 5, l = lane & 31;
+    // the four tasks of this wavefront (uniform loads); tasks beyond the end are empty
+    SwTask tk[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const uint32_t id = blockIdx.x * 4 + x;
+        if (id < nTasks) {
+            tk[x] = tasks[order ? order[id] : id];
+        } else {
+            tk[x].n = 0; tk[x].tL = 0; tk[x].qOff = 0; tk[x].tOff = 0; tk[x].qStep = 1; tk[x].tStep = 1; tk[x].segLen = 1;
+            tk[x].slot = 0; tk[x].boundOff = 0;
+        }
+    }
+    const SwTask A = grp ? tk[2] : tk[0];
+    const SwTask B = grp ? tk[3] : tk[1];
+    const bool haveA = blockIdx.x * 4 + 2 * grp < nTasks, haveB = blockIdx.x * 4 + 2 * grp + 1 < nTasks;
+    const int maxN = max(max(tk[0].n, tk[1].n), max(tk[2].n, tk[3].n));
+    const int maxTL = max(max(tk[0].tL, tk[1].tL), max(tk[2].tL, tk[3].tL));
+    const int pairTL = max(A.tL, B.tL);
+    const int nStrips = MULTI ? (maxN + ROWS - 1) / ROWS : (maxN > 0 ? 1 : 0);
+    const int steps = (maxN > 0 && maxTL > 0) ? maxTL + 31 : 0;
+    uint4 *bnd = nullptr;
+    if (MULTI) bnd = (uint4 *) (boundary + (A.tL >= B.tL ? A.boundOff : B.boundOff));
+
+    const uint32_t goP = (uint32_t) go | ((uint32_t) go << 16), geP = (uint32_t) ge | ((uint32_t) ge << 16);
+    unsigned long long keyA = 0, keyB = 0;   // (value, 0xFFFFF - column, 0xFFFFF - row), best over strips
+    const uint32_t *profA = &prof[2 * grp][0][0] + l * WORDS;
+    const uint32_t *profB = &prof[2 * grp + 1][0][0] + l * WORDS;
+
+    for (int strip = 0; strip < nStrips; strip++) {
+        const int q0 = strip * ROWS + l * RT;
+        // ---- query profiles of this strip (SmithWaterman::createQueryProfile, :163-187) and the lazy-F reset rows
+        uint32_t mask[RT];
+        if (strip > 0) __syncthreads();   // the previous strip's profile reads are done
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            const SwTask &T = x ? B : A;
+            uint32_t *pw = &prof[2 * grp + x][0][0] + l * WORDS;
+            int seg = T.segLen > 0 ? q0 % T.segLen : 0;
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) {
+                int res[4], cb[4];
+                bool valid[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int qi = q0 + 4 * w + b;
+                    valid[b] = qi < T.n;
+                    res[b] = 20;
+                    cb[b] = 0;
+                    if (valid[b]) {
+                        const int64_t idx = (int64_t) T.qOff + (int64_t) qi * T.qStep;
+                        res[b] = qRes[idx];
+                        cb[b] = qBias[idx];
+                    }
+                    const bool reset = valid[b] && seg == 0;
+                    seg = (seg + 1 == T.segLen) ? 0 : seg + 1;
+                    const uint32_t m = reset ? 0u : 0xFFFFu;
+                    if (x == 0) mask[4 * w + b] = m;
+                    else mask[4 * w + b] |= m << 16;
+                }
+                for (int a = 0; a < 21; a++) {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int v = valid[b] ? (int) smat[a * 21 + res[b]] + cb[b] : -64;
+                        word |= (uint32_t) (uint8_t) (int8_t) v << (8 * b);
+                    }
+                    pw[a * (ROWS / 4) + w] = word;
+                }
+                pw[PK_NEUTRAL * (ROWS / 4) + w] = 0xC0C0C0C0u;
+            }
+        }
+        __syncthreads();
+
+        uint32_t H[RT], E[RT];
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            H[r] = 0;
+            E[r] = 0;
+        }
+        uint32_t outG = 0, outFf = 0, outFl = 0, prevInG = 0;
+        uint32_t curT = PK_NEUTRAL | (PK_NEUTRAL << 8);
+        uint32_t bestv = 0, bestcm = 0, bestcol = 0;
+        uint32_t ccol = (uint32_t) (-l) & 0xFFFFu;
+        ccol |= ccol << 16;
+        const bool lastStrip = strip == nStrips - 1;
+        const bool readBound = MULTI && strip > 0;
+
+        auto loadChunk = [&](int c0) -> uint32_t {
+            const int col = c0 + l;
+            uint32_t a = PK_NEUTRAL, b = PK_NEUTRAL;
+            if (col < A.tL) a = tRes[(int64_t) A.tOff + (int64_t) col * A.tStep];
+            if (col < B.tL) b = tRes[(int64_t) B.tOff + (int64_t) col * B.tStep];
+            return a | (b << 8);
+        };
+        auto loadBound = [&](int c0) -> uint4 {
+            const int col = c0 + l;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (readBound && col < pairTL) {
+                const unsigned long long lo = __hip_atomic_load((unsigned long long *) &bnd[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hi = __hip_atomic_load((unsigned long long *) &bnd[col] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v.x = (uint32_t) lo; v.y = (uint32_t) (lo >> 32); v.z = (uint32_t) hi;
+            }
+            return v;
+        };
+        if (readBound) __threadfence();   // boundary values of the previous strip must be visible
+
+        uint32_t chunk = loadChunk(0);
+        uint4 bchunk = loadBound(0);
+        for (int k0 = 0; k0 < steps; k0 += 32) {
+            const uint32_t chunkNext = loadChunk(k0 + 32);
+            uint4 bnext = make_uint4(0, 0, 0, 0);
+            if (readBound) bnext = loadBound(k0 + 32);
+            const int iEnd = min(32, steps - k0);
+#pragma unroll 1
+            for (int i = 0; i < iEnd; i++) {
+                // ---- hand-off from lane l-1; lane 0 of each half wavefront takes the target residues (and the
+                //      previous strip's boundary) instead
+                uint32_t inT = dppShr1(curT), inG = dppShr1(outG), inFf = dppShr1(outFf), inFl = dppShr1(outFl);
+                inT = writeLane<0>(readLane(chunk, i), inT);
+                inT = writeLane<32>(readLane(chunk, 32 + i), inT);
+                if (readBound) {
+                    inG = writeLane<0>(readLane(bchunk.x, i), inG);
+                    inFf = writeLane<0>(readLane(bchunk.y, i), inFf);
+                    inFl = writeLane<0>(readLane(bchunk.z, i), inFl);
+                    inG = writeLane<32>(readLane(bchunk.x, 32 + i), inG);
+                    inFf = writeLane<32>(readLane(bchunk.y, 32 + i), inFf);
+                    inFl = writeLane<32>(readLane(bchunk.z, 32 + i), inFl);
+                } else {
+                    inG = writeLane<32>(0, inG);
+                    inFf = writeLane<32>(0, inFf);
+                    inFl = writeLane<32>(0, inFl);
+                }
+                curT = inT;
+                const uint32_t *pa = profA + (curT & 0xFFu) * (ROWS / 4);
+                const uint32_t *pb = profB + (curT >> 8) * (ROWS / 4);
+                uint32_t h[RT];
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) {
+                    const uint32_t d0 = (w == 0) ? prevInG : H[4 * w - 1];
+                    addProfile4(pa[w], pb[w], d0, H[4 * w], H[4 * w + 1], H[4 * w + 2], h[4 * w], h[4 * w + 1], h[4 * w + 2],
+                                h[4 * w + 3]);
+                }
+                prevInG = inG;
+                uint32_t Fl = inFl, Ff = inFf, cm = 0;
+#pragma unroll
+                for (int r = 0; r < RT; r++) {
+                    Fl &= mask[r];
+                    const uint32_t hpre = pkMax(pkMax(h[r], E[r]), Fl);
+                    const uint32_t g = pkMax(hpre, Ff);
+                    const uint32_t open = pkSubSat(hpre, goP);
+                    E[r] = pkMax(pkSubSat(E[r], geP), open);
+                    Fl = pkMax(pkSubSat(Fl, geP), open);
+                    Ff = pkMax(pkSubSat(Ff, geP), open);
+                    H[r] = g;
+                    cm = pkMax(cm, pkRowCode(g, 31 - r));
+                }
+                outG = H[RT - 1];
+                outFf = Ff;
+                outFl = Fl;
+                if (MULTI && !lastStrip && l == 31) {
+                    const int c = k0 + i - 31;
+                    if (c >= 0 && c < pairTL) {
+                        const unsigned long long lo = (unsigned long long) outG | ((unsigned long long) outFf << 32);
+                        __hip_atomic_store((unsigned long long *) &bnd[c], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((unsigned long long *) &bnd[c] + 1, (unsigned long long) outFl, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                // ---- column maximum: a strictly larger value takes over (first column wins, smallest row inside)
+                const uint32_t v = pkLshr(cm, 5);
+                const uint32_t nb = pkMax(bestv, v);
+                const uint32_t m = pkAshr(pkSub(bestv, nb), 15);
+                bestcm = bfi(m, cm, bestcm);
+                bestcol = bfi(m, ccol, bestcol);
+                bestv = nb;
+                ccol = pkAdd(ccol, 0x00010001u);
+            }
+            chunk = chunkNext;
+            bchunk = bnext;
+        }
+        // ---- this strip's candidates
+        {
+            const uint32_t vA = bestv & 0xFFFFu, vB = bestv >> 16;
+            const uint32_t rowA = (uint32_t) (q0 + 31 - (int) (bestcm & 31u)), rowB = (uint32_t) (q0 + 31 - (int) ((bestcm >> 16) & 31u));
+            const uint32_t colA = bestcol & 0xFFFFu, colB = bestcol >> 16;
+            if (vA > 0) {
+                const unsigned long long kk = ((unsigned long long) vA << 40) | ((unsigned long long) (0xFFFFFu - colA) << 20) |
+                                              (unsigned long long) (0xFFFFFu - rowA);
+                keyA = kk > keyA ? kk : keyA;
+            }
+            if (vB > 0) {
+                const unsigned long long kk = ((unsigned long long) vB << 40) | ((unsigned long long) (0xFFFFFu - colB) << 20) |
+                                              (unsigned long long) (0xFFFFFu - rowB);
+                keyB = kk > keyB ? kk : keyB;
+            }
+        }
+    }
+    // ---- reduce over the 32 lanes: max value, then smallest column, then smallest row
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        const unsigned long long oa = __shfl_xor(keyA, off, 32), ob = __shfl_xor(keyB, off, 32);
+        keyA = oa > keyA ? oa : keyA;
+        keyB = ob > keyB ? ob : keyB;
+    }
+    if (l == 0) {
+        if (haveA) {
+            const int v = (int) (keyA >> 40);
+            out[3 * A.slot + 0] = v;
+            out[3 * A.slot + 1] = v == 0 ? -1 : 0xFFFFF - (int) ((keyA >> 20) & 0xFFFFF);
+            out[3 * A.slot + 2] = v == 0 ? A.n - 1 : 0xFFFFF - (int) (keyA & 0xFFFFF);
+        }
+        if (haveB) {
+            const int v = (int) (keyB >> 40);
+            out[3 * B.slot + 0] = v;
+            out[3 * B.slot + 1] = v == 0 ? -1 : 0xFFFFF - (int) ((keyB >> 20) & 0xFFFFF);
+            out[3 * B.slot + 2] = v == 0 ? B.n - 1 : 0xFFFFF - (int) (keyB & 0xFFFFF);
+        }
+    }
+}
+
+}  // namespace sdpk
+#endif
