@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--proteomes', type=int, default=100)
     ap.add_argument('--genes', type=int, default=3000)
     ap.add_argument('--batch', type=int, default=10, help='query proteomes per step')
+    ap.add_argument('--chunk', type=int, default=30000, help='queries per device chunk')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--cpu-threads', type=int, default=0)
@@ -101,7 +102,7 @@ def main():
     def run_step(step_idx, keep=False):
         b = (rank * (args.steps + args.warmup) + step_idx) % n_batches
         s0, s1 = b * B, min(P, (b + 1) * B)
-        out = cs.search(db, same_db=True, query_range=(int(set_start[s0]), int(set_start[s1])), chunk_queries=30000)
+        out = cs.search(db, same_db=True, query_range=(int(set_start[s0]), int(set_start[s1])), chunk_queries=args.chunk)
         if keep and out['cluster_out'] is not None:
             hq, ht = out['hit_q'], out['hit_t']
             cs.last_entries = (out['entry_off'], db.pos_in_set[hq], db.pos_in_set[ht],

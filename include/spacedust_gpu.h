@@ -199,14 +199,15 @@ double sd_host_bitscore(double score);
  * Replaces prefixid -> besthitbyset -> mergeresultsbyset -> combinehits (R/data/clustersearch.sh:121-140) and
  * summarizeresults (:151) without the text DB round trips, keeping their %.3E re-quantisation. */
 typedef struct sd_agg sd_agg;
-int sd_agg_create(const uint32_t *qSetOf, uint32_t nQ, const uint32_t *tSetOf, uint32_t nT, uint32_t nQSets,
-                  uint32_t nTSets, double evalThr, int covMode, float covThr, int alnLenThr, int filterSelfMatch,
-                  sd_agg **out);
+/* qSetOf/qLen: genome set and length of every query protein (DB key order); likewise for the targets */
+int sd_agg_create(const uint32_t *qSetOf, const int32_t *qLen, uint32_t nQ, const uint32_t *tSetOf, const int32_t *tLen,
+                  uint32_t nT, uint32_t nQSets, uint32_t nTSets, double evalThr, int covMode, float covThr, int alnLenThr,
+                  int filterSelfMatch, sd_agg **out);
 void sd_agg_destroy(sd_agg *a);
-/* alignment results of a batch of pairs (pairs of one query contiguous): checkCriteria, compareHits order,
- * best hit per (query protein, target set), log P threshold of combinehits */
-int sd_agg_add(sd_agg *a, uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const sd_sw_result *res,
-               const uint8_t *isIdentity, const int32_t *qLen, const int32_t *tLen, const char *btPool);
+/* alignment results of a batch of pairs (pairs of one query contiguous; query key = qBase + pairQ[i]):
+ * checkCriteria, compareHits order, best hit per (query protein, target set), log P threshold of combinehits */
+int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ, const uint32_t *pairT,
+               const sd_sw_result *res, const uint8_t *isIdentity, const char *btPool);
 int sd_agg_finish(sd_agg *a, uint64_t *nEntries, uint64_t *nHits);
 int sd_agg_stats(sd_agg *a, uint64_t *nAligned, uint64_t *nAccepted);
 int sd_agg_get(sd_agg *a, uint64_t *entryOff, uint32_t *entryQSet, uint32_t *entryTSet, uint32_t *hitQ, uint32_t *hitT,

@@ -100,10 +100,10 @@ def load():
                                          _vp, _vp, _vp]),
         'sd_clusterhits_batch': (C.c_int, [_vp, C.POINTER(ChParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                            C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
-        'sd_agg_create': (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_int,
+        'sd_agg_create': (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_int,
                                     C.c_float, C.c_int, C.c_int, C.POINTER(_vp)]),
         'sd_agg_destroy': (None, [_vp]),
-        'sd_agg_add': (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+        'sd_agg_add': (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
         'sd_agg_finish': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_agg_stats': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_agg_get': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),

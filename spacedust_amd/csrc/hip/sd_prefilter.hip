@@ -17,6 +17,7 @@
 //                           coverage pre-filter (Prefiltering.cpp:856-863)
 // The reference's overflow path (> 2*max(1e6,dbSize) hits per query) and the rescoring path
 // (threshold >= 255) are detected and reported as SD_EUNSUPPORTED -- never silently approximated.
+#include <memory>
 #include "sd_common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -625,6 +626,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
     uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 4096);
     while (qBeg < nQ) {
         uint32_t bq = std::min<uint32_t>(batchQ, nQ - qBeg);
+        std::unique_ptr<HostScope> hs(new HostScope(ctx, "pf.upload_count"));
         // ---- upload the sub-batch
         const uint64_t r0 = qOffsets[qBeg], r1 = qOffsets[qBeg + bq];
         std::vector<uint64_t> hOff(bq + 1), hPos(bq + 1);
@@ -675,6 +677,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             SD_HIP(ctx, hipMemcpyAsync(&nKmers, dKmerBase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
+        hs.reset(new HostScope(ctx, "pf.emit"));
         WsView<uint32_t> dKStart(ctx, "pf.dKStart");
         WsView<uint32_t> dKLen(ctx, "pf.dKLen");
         WsView<uint32_t> dKPos(ctx, "pf.dKPos");
@@ -699,6 +702,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             SD_HIP(ctx, hipMemcpyAsync(&nHits, dHitBase.p + nKmers, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
+        hs.reset(new HostScope(ctx, "pf.stats"));
         if (nHits > HIT_BUDGET && bq > 1) {   // too many hits for one sort: halve the sub-batch and retry
             batchQ = std::max<uint32_t>(1, bq / 2);
             continue;
@@ -718,6 +722,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                 return sdFail(ctx, SD_EUNSUPPORTED, "query %u: %llu index hits reach the reference's overflow path (QueryMatcher.cpp:281-316), not implemented",
                               qBeg + x, (unsigned long long) hStats[4 * x + 1]);
 
+        hs.reset(new HostScope(ctx, "pf.gather_sort_match"));
         uint32_t nCand = 0, nKept = 0;
         WsView<uint32_t> dKeyA(ctx, "pf.dKeyA");
         WsView<uint32_t> dKeyB(ctx, "pf.dKeyB");
@@ -776,6 +781,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
             nCand = (uint32_t) nc64;
         }
+        hs.reset(new HostScope(ctx, "pf.score_keep"));
         if (nCand > 0) {
             SD_HIP(ctx, dCKey.alloc(nCand));
             SD_HIP(ctx, dCVal.alloc(nCand));
@@ -819,6 +825,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             SD_HIP(ctx, dKScore.alloc(1));
             SD_HIP(ctx, dDiag.alloc(std::max<uint64_t>(nHits, 1)));
         }
+        hs.reset(new HostScope(ctx, "pf.select"));
         SD_HIP(ctx, dQStart.alloc(bq + 1));
         hipLaunchKernelGGL(query_bounds_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, nKept, dKKey.p, tBits, dQStart.p);
         WsView<sd_hit> dOut(ctx, "pf.dOut");
@@ -832,6 +839,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                                par->covMode, par->covThr, dOut.p, dOutCount.p, dErr.p);
         }
         SD_HIP(ctx, hipGetLastError());
+        hs.reset(new HostScope(ctx, "pf.download"));
         int hErr = 0;
         std::vector<sd_hit> hOut((size_t) bq * maxHits);
         SD_HIP(ctx, hipMemcpyAsync(&hErr, dErr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -841,10 +849,12 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (hErr == 1) return sdFail(ctx, SD_EUNSUPPORTED, "a query reached the rescoring path (diagonal threshold >= 255, QueryMatcher.cpp:163-170), not implemented on the device");
         if (hErr == 2) return sdFail(ctx, SD_EUNSUPPORTED, "more than %d tied candidates at the score cut of one query", SEL_CAP);
+        hs.reset(new HostScope(ctx, "pf.scatter"));
         // the caller's rows are par->maxHitsPerQuery wide
         for (uint32_t x = 0; x < bq; x++)
             memcpy(outHits + (size_t) (qBeg + x) * par->maxHitsPerQuery, hOut.data() + (size_t) x * maxHits,
                    (size_t) std::min<uint32_t>(outCount[qBeg + x], maxHits) * sizeof(sd_hit));
+        hs.reset();
         qBeg += bq;
     }
     return SD_OK;

@@ -143,6 +143,11 @@ char *seqIdToBuffer(float seqId, char *buffer) {
 
 std::string compressBacktrace(const char *bt, size_t n) {
     std::string ret;
+    compressBacktraceAppend(bt, n, ret);
+    return ret;
+}
+
+void compressBacktraceAppend(const char *bt, size_t n, std::string &ret) {
     char state = 'M';
     size_t counter = 0;
     char num[16];
@@ -158,7 +163,6 @@ std::string compressBacktrace(const char *bt, size_t n) {
     }
     ret.append(num, u32toa((uint32_t) counter, num) - num);
     ret.push_back(state);
-    return ret;
 }
 
 }  // namespace sd

@@ -18,6 +18,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <omp.h>
+#include <parallel/algorithm>
+#include <charconv>
 
 namespace {
 
@@ -29,8 +32,22 @@ struct BestHit {
     char seqIdText[8];
     char evalText[16];
     int32_t qStart, qEnd, qLen, tStart, tEnd, tLen;
-    std::string cigar;
+    uint32_t arena;         // which thread's cigar arena
+    uint32_t cigarLen;
+    uint64_t cigarOff;
 };
+
+// snprintf("%.3E") followed by strtod, i.e. what one reference module writes and the next one parses; to_chars /
+// from_chars produce the same digits and the same double (both are exact conversions), several times faster
+double quantise3E(double v, char *text) {
+    std::to_chars_result r = std::to_chars(text, text + 24, v, std::chars_format::scientific, 3);
+    *r.ptr = '\0';
+    for (char *p = text; p < r.ptr; p++)
+        if (*p == 'e') *p = 'E';
+    double back = 0.0;
+    std::from_chars(text, r.ptr, back);
+    return back;
+}
 
 double computeLogPval(double eval, double logCalibration) {   // besthitbyset.cpp:10-20
     if (eval == 0) return log(DBL_MIN) - logCalibration;
@@ -42,6 +59,7 @@ double computeLogPval(double eval, double logCalibration) {   // besthitbyset.cp
 
 struct sd_agg {
     std::vector<uint32_t> qSetOf, tSetOf;
+    std::vector<int32_t> qLen, tLen;
     uint32_t nQSets = 0, nTSets = 0;
     double evalThr = 10.0;
     int covMode = 2;
@@ -49,7 +67,10 @@ struct sd_agg {
     int alnLenThr = 30;
     float seqIdThr = 0.0f;
     bool filterSelfMatch = true;
-    std::vector<BestHit> best;       // after besthitbyset + combinehits filter, any order until finish()
+    // after besthitbyset + combinehits filter: per worker thread, any order until finish()
+    std::vector<std::vector<BestHit> > tBest;
+    std::vector<std::string> tCigar;
+    std::vector<const BestHit *> best;   // finish(): (qSet, tSet, q) order
     uint64_t nAligned = 0, nAccepted = 0;
     // finish(): entries sorted by (qSet, tSet), hits by query key
     std::vector<uint64_t> entryOff;
@@ -58,13 +79,15 @@ struct sd_agg {
 
 extern "C" {
 
-int sd_agg_create(const uint32_t *qSetOf, uint32_t nQ, const uint32_t *tSetOf, uint32_t nT, uint32_t nQSets,
-                  uint32_t nTSets, double evalThr, int covMode, float covThr, int alnLenThr, int filterSelfMatch,
-                  sd_agg **out) {
-    if (!qSetOf || !tSetOf || !out) return SD_EINVAL;
+int sd_agg_create(const uint32_t *qSetOf, const int32_t *qLen, uint32_t nQ, const uint32_t *tSetOf, const int32_t *tLen,
+                  uint32_t nT, uint32_t nQSets, uint32_t nTSets, double evalThr, int covMode, float covThr, int alnLenThr,
+                  int filterSelfMatch, sd_agg **out) {
+    if (!qSetOf || !tSetOf || !qLen || !tLen || !out) return SD_EINVAL;
     sd_agg *a = new sd_agg();
     a->qSetOf.assign(qSetOf, qSetOf + nQ);
     a->tSetOf.assign(tSetOf, tSetOf + nT);
+    a->qLen.assign(qLen, qLen + nQ);
+    a->tLen.assign(tLen, tLen + nT);
     a->nQSets = nQSets;
     a->nTSets = nTSets;
     a->evalThr = evalThr;
@@ -78,131 +101,161 @@ int sd_agg_create(const uint32_t *qSetOf, uint32_t nQ, const uint32_t *tSetOf, u
 
 void sd_agg_destroy(sd_agg *a) { delete a; }
 
-// pairs of one query must be contiguous.  qLen/tLen per pair.
-int sd_agg_add(sd_agg *a, uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const sd_sw_result *res,
-               const uint8_t *isIdentity, const int32_t *qLen, const int32_t *tLen, const char *btPool) {
-    if (!a || (nPairs && (!pairQ || !pairT || !res || !qLen || !tLen))) return SD_EINVAL;
+// pairs of one query must be contiguous
+int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ, const uint32_t *pairT,
+               const sd_sw_result *res, const uint8_t *isIdentity, const char *btPool) {
+    if (!a || (nPairs && (!pairQ || !pairT || !res))) return SD_EINVAL;
+    {
+        int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+        for (uint32_t i = 0; i < nPairs; i++)
+            bad |= ((uint64_t) qBase + pairQ[i] >= a->qSetOf.size() || pairT[i] >= a->tSetOf.size()) ? 1 : 0;
+        if (bad) return SD_EINVAL;
+    }
     // group boundaries
     std::vector<uint32_t> groupStart;
     for (uint32_t i = 0; i < nPairs; i++)
         if (i == 0 || pairQ[i] != pairQ[i - 1]) groupStart.push_back(i);
     groupStart.push_back(nPairs);
     const size_t nGroups = groupStart.size() - 1;
-    std::vector<std::vector<BestHit> > perGroup(nGroups);
     uint64_t accepted = 0;
     const double logPvalThr = log(10e-7);   // combinehits.cpp:101-103
-#pragma omp parallel for schedule(dynamic, 64) reduction(+ : accepted)
-    for (size_t g = 0; g < nGroups; g++) {
-        struct Cand {
-            uint32_t i;
-            double eval;
-            int bits;
-            int dbLen;
-            uint32_t key;
-            float seqId;
-        };
-        std::vector<Cand> cands;
-        for (uint32_t i = groupStart[g]; i < groupStart[g + 1]; i++) {
-            const sd_sw_result &r = res[i];
-            const bool ident = isIdentity && isIdentity[i];
-            Cand c;
-            c.i = i;
-            c.eval = r.evalue;
-            c.bits = static_cast<int>(sd_host_bitscore((double) (uint32_t) r.score) + 0.5);   // Matcher.cpp:130
-            c.dbLen = tLen[i];
-            c.key = pairT[i];
-            if (ident) {
-                c.seqId = 1.0f;   // Alignment.cpp:382-387
-            } else {
-                if (r.btLen <= 0 || r.qStart < 0 || r.tStart < 0) continue;   // stopped at a gate: fails checkCriteria
-                const float qcov = sd::computeCov(r.qStart, r.qEnd, qLen[i]);
-                const float dbcov = sd::computeCov(r.tStart, r.tEnd, tLen[i]);
-                c.seqId = static_cast<float>(r.identical) / static_cast<float>(r.btLen);   // Util::computeSeqId, SEQ_ID_ALN_LEN
-                const bool ok = (r.evalue <= a->evalThr) && (c.seqId >= a->seqIdThr) &&
-                                sd::hasCoverage(a->covThr, a->covMode, qcov, dbcov) && (r.btLen >= a->alnLenThr);
-                if (!ok) continue;
-            }
-            cands.push_back(c);
-        }
-        accepted += cands.size();
-        // Matcher::compareHits order (Matcher.h:157-168)
-        std::sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) {
+    const int T = std::max(1, std::min(omp_get_max_threads(), 64));
+    if ((int) a->tBest.size() < T) {
+        a->tBest.resize(T);
+        a->tCigar.resize(T);
+    }
+    struct Cand {
+        uint32_t i;
+        double eval;
+        int bits;
+        int dbLen;
+        uint32_t key;
+        float seqId;
+    };
+#pragma omp parallel num_threads(T) reduction(+ : accepted)
+    {
+        const int th = omp_get_thread_num();
+        std::vector<BestHit> &myBest = a->tBest[th];
+        std::string &myCigar = a->tCigar[th];
+        // best candidate per target set: Alignment sorts a query's accepted hits with Matcher::compareHits
+        // (Matcher.h:157-168) and besthitbyset keeps, per set, the first one whose %.3E text E-value is strictly
+        // smaller than what it has (besthitbyset.cpp:88-101).  Rounding to text is monotone, so that is the
+        // compareHits-minimum of the set; no sort and no text round trip are needed to find it.
+        std::vector<Cand> slotBest;
+        std::vector<uint32_t> slotSet, stamp(a->nTSets, 0), slotOf(a->nTSets, 0);
+        std::vector<std::pair<uint32_t, const Cand *> > bestOfSet;
+        uint32_t gen = 0;
+        auto better = [](const Cand &x, const Cand &y) {
             if (x.eval != y.eval) return x.eval < y.eval;
             if (x.bits != y.bits) return x.bits > y.bits;
             if (x.dbLen != y.dbLen) return x.dbLen < y.dbLen;
             return x.key < y.key;
-        });
-        // besthitbyset: first (= smallest text E-value, strict <) hit per target set, sets ascending
-        std::vector<std::pair<uint32_t, const Cand *> > bestOfSet;
-        {
-            std::vector<std::pair<uint32_t, double> > bestEval;
-            for (const Cand &c : cands) {
-                const uint32_t ts = a->tSetOf[c.key];
-                char txt[32];
-                snprintf(txt, sizeof(txt), "%.3E", c.eval);
-                const double ev = strtod(txt, NULL);
-                size_t s = 0;
-                for (; s < bestOfSet.size(); s++)
-                    if (bestOfSet[s].first == ts) break;
-                if (s == bestOfSet.size()) {
-                    bestOfSet.push_back(std::make_pair(ts, (const Cand *) NULL));
-                    bestEval.push_back(std::make_pair(ts, DBL_MAX));
+        };
+#pragma omp for schedule(dynamic, 64)
+        for (size_t g = 0; g < nGroups; g++) {
+            gen++;
+            slotBest.clear();
+            slotSet.clear();
+            const uint32_t q = qBase + pairQ[groupStart[g]];
+            const int32_t qL = a->qLen[q];
+            for (uint32_t i = groupStart[g]; i < groupStart[g + 1]; i++) {
+                const sd_sw_result &r = res[i];
+                const bool ident = isIdentity && isIdentity[i];
+                Cand c;
+                c.i = i;
+                c.eval = r.evalue;
+                c.dbLen = a->tLen[pairT[i]];
+                c.key = pairT[i];
+                if (ident) {
+                    c.seqId = 1.0f;   // Alignment.cpp:382-387
+                } else {
+                    if (r.btLen <= 0 || r.qStart < 0 || r.tStart < 0) continue;   // stopped at a gate: fails checkCriteria
+                    const float qcov = sd::computeCov(r.qStart, r.qEnd, qL);
+                    const float dbcov = sd::computeCov(r.tStart, r.tEnd, c.dbLen);
+                    c.seqId = static_cast<float>(r.identical) / static_cast<float>(r.btLen);   // Util::computeSeqId, SEQ_ID_ALN_LEN
+                    const bool ok = (r.evalue <= a->evalThr) && (c.seqId >= a->seqIdThr) &&
+                                    sd::hasCoverage(a->covThr, a->covMode, qcov, dbcov) && (r.btLen >= a->alnLenThr);
+                    if (!ok) continue;
                 }
-                if (ev < bestEval[s].second) {
-                    bestEval[s].second = ev;
-                    bestOfSet[s].second = &c;
+                c.bits = static_cast<int>(sd_host_bitscore((double) (uint32_t) r.score) + 0.5);   // Matcher.cpp:130
+                accepted++;
+                const uint32_t ts = a->tSetOf[c.key];
+                if (stamp[ts] != gen) {
+                    stamp[ts] = gen;
+                    slotOf[ts] = (uint32_t) slotBest.size();
+                    slotBest.push_back(c);
+                    slotSet.push_back(ts);
+                } else if (better(c, slotBest[slotOf[ts]])) {
+                    slotBest[slotOf[ts]] = c;
                 }
             }
-        }
-        std::sort(bestOfSet.begin(), bestOfSet.end(), [](const std::pair<uint32_t, const Cand *> &x, const std::pair<uint32_t, const Cand *> &y) { return x.first < y.first; });
-        const uint32_t q = pairQ[groupStart[g]];
-        const uint32_t qs = a->qSetOf[q];
-        for (size_t s = 0; s < bestOfSet.size(); s++) {
-            const Cand *c = bestOfSet[s].second;
-            if (c == NULL) continue;
-            const uint32_t ts = bestOfSet[s].first;
-            if (a->filterSelfMatch && qs == ts) continue;   // combinehits.cpp:83
-            const sd_sw_result &r = res[c->i];
-            BestHit b;
-            snprintf(b.evalText, sizeof(b.evalText), "%.3E", c->eval);
-            const double evParsed = strtod(b.evalText, NULL);
-            char lpText[32];
-            snprintf(lpText, sizeof(lpText), "%.3E", computeLogPval(evParsed, log(1)));   // besthitbyset.cpp:129
-            const double logP = strtod(lpText, NULL);
-            if (!(logP < logPvalThr)) continue;                                            // combinehits.cpp:107-112
-            snprintf(b.pvalText, sizeof(b.pvalText), "%.3E", exp(logP));                   // combinehits.cpp:218-221
-            b.pval = strtod(b.pvalText, NULL);
-            char *e = sd::seqIdToBuffer(c->seqId, b.seqIdText);
-            *e = '\0';
-            b.q = q; b.t = c->key; b.qSet = qs; b.tSet = ts;
-            b.qStart = r.qStart; b.qEnd = r.qEnd; b.qLen = qLen[c->i];
-            b.tStart = r.tStart; b.tEnd = r.tEnd; b.tLen = tLen[c->i];
-            if (btPool && r.btLen > 0) b.cigar = sd::compressBacktrace(btPool + r.btOffset, (size_t) r.btLen);
-            perGroup[g].push_back(b);
+            bestOfSet.clear();
+            for (size_t x = 0; x < slotBest.size(); x++) bestOfSet.push_back(std::make_pair(slotSet[x], (const Cand *) &slotBest[x]));
+            std::sort(bestOfSet.begin(), bestOfSet.end(),
+                      [](const std::pair<uint32_t, const Cand *> &x, const std::pair<uint32_t, const Cand *> &y) { return x.first < y.first; });
+            const uint32_t qs = a->qSetOf[q];
+            for (size_t s = 0; s < bestOfSet.size(); s++) {
+                const Cand *c = bestOfSet[s].second;
+                if (c == NULL) continue;
+                const uint32_t ts = bestOfSet[s].first;
+                if (a->filterSelfMatch && qs == ts) continue;   // combinehits.cpp:83
+                const sd_sw_result &r = res[c->i];
+                BestHit b;
+                char evalText[32], lpText[32], pvalText[32];
+                const double evParsed = quantise3E(c->eval, evalText);
+                const double logP = quantise3E(computeLogPval(evParsed, log(1)), lpText);       // besthitbyset.cpp:129
+                if (!(logP < logPvalThr)) continue;                                            // combinehits.cpp:107-112
+                b.pval = quantise3E(exp(logP), pvalText);                                      // combinehits.cpp:218-221
+                memcpy(b.evalText, evalText, sizeof(b.evalText));
+                memcpy(b.pvalText, pvalText, sizeof(b.pvalText));
+                b.evalText[sizeof(b.evalText) - 1] = '\0';
+                b.pvalText[sizeof(b.pvalText) - 1] = '\0';
+                char *e = sd::seqIdToBuffer(c->seqId, b.seqIdText);
+                *e = '\0';
+                b.q = q; b.t = c->key; b.qSet = qs; b.tSet = ts;
+                b.qStart = r.qStart; b.qEnd = r.qEnd; b.qLen = qL;
+                b.tStart = r.tStart; b.tEnd = r.tEnd; b.tLen = c->dbLen;
+                b.arena = (uint32_t) th;
+                b.cigarOff = myCigar.size();
+                b.cigarLen = 0;
+                if (btPool && r.btLen > 0) {
+                    sd::compressBacktraceAppend(btPool + r.btOffset, (size_t) r.btLen, myCigar);
+                    b.cigarLen = (uint32_t) (myCigar.size() - b.cigarOff);
+                }
+                myBest.push_back(b);
+            }
         }
     }
     a->nAligned += nPairs;
     a->nAccepted += accepted;
-    for (size_t g = 0; g < nGroups; g++)
-        for (size_t x = 0; x < perGroup[g].size(); x++) a->best.push_back(std::move(perGroup[g][x]));
     return SD_OK;
 }
 
 // sort into (qSet, tSet) entries; hits inside an entry by query key (mergeresultsbyset order)
 int sd_agg_finish(sd_agg *a, uint64_t *nEntries, uint64_t *nHits) {
-    std::sort(a->best.begin(), a->best.end(), [](const BestHit &x, const BestHit &y) {
-        if (x.qSet != y.qSet) return x.qSet < y.qSet;
-        if (x.tSet != y.tSet) return x.tSet < y.tSet;
-        return x.q < y.q;
+    size_t total = 0;
+    for (size_t t = 0; t < a->tBest.size(); t++) total += a->tBest[t].size();
+    a->best.resize(total);
+    {
+        size_t pos = 0;
+        for (size_t t = 0; t < a->tBest.size(); t++)
+            for (size_t x = 0; x < a->tBest[t].size(); x++) a->best[pos++] = &a->tBest[t][x];
+    }
+    // (qSet, tSet, q) is unique per hit, so the order does not depend on how the hits were spread over threads
+    __gnu_parallel::sort(a->best.begin(), a->best.end(), [](const BestHit *x, const BestHit *y) {
+        if (x->qSet != y->qSet) return x->qSet < y->qSet;
+        if (x->tSet != y->tSet) return x->tSet < y->tSet;
+        return x->q < y->q;
     });
     a->entryOff.clear();
     a->entryQSet.clear();
     a->entryTSet.clear();
     for (size_t i = 0; i < a->best.size(); i++) {
-        if (i == 0 || a->best[i].qSet != a->best[i - 1].qSet || a->best[i].tSet != a->best[i - 1].tSet) {
+        if (i == 0 || a->best[i]->qSet != a->best[i - 1]->qSet || a->best[i]->tSet != a->best[i - 1]->tSet) {
             a->entryOff.push_back(i);
-            a->entryQSet.push_back(a->best[i].qSet);
-            a->entryTSet.push_back(a->best[i].tSet);
+            a->entryQSet.push_back(a->best[i]->qSet);
+            a->entryTSet.push_back(a->best[i]->tSet);
         }
     }
     a->entryOff.push_back(a->best.size());
@@ -222,10 +275,11 @@ int sd_agg_get(sd_agg *a, uint64_t *entryOff, uint32_t *entryQSet, uint32_t *ent
     memcpy(entryOff, a->entryOff.data(), a->entryOff.size() * sizeof(uint64_t));
     memcpy(entryQSet, a->entryQSet.data(), a->entryQSet.size() * sizeof(uint32_t));
     memcpy(entryTSet, a->entryTSet.data(), a->entryTSet.size() * sizeof(uint32_t));
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < a->best.size(); i++) {
-        hitQ[i] = a->best[i].q;
-        hitT[i] = a->best[i].t;
-        pval[i] = a->best[i].pval;
+        hitQ[i] = a->best[i]->q;
+        hitT[i] = a->best[i]->t;
+        pval[i] = a->best[i]->pval;
     }
     return SD_OK;
 }
@@ -258,11 +312,11 @@ int sd_agg_write_tsv(sd_agg *a, const char *path, const uint32_t *clusterOfHit, 
                     (int) (tSourceOff[ts + 1] - tSourceOff[ts]), tSources + tSourceOff[ts], co, mh, clusterSize[off + c]);
             nc++;
             for (uint32_t m = 0; m < clusterSize[off + c]; m++) {
-                const BestHit &b = a->best[off + order[m]];
+                const BestHit &b = *a->best[off + order[m]];
                 if (!canonical) fprintf(f, ">%.*s\t", (int) (qNameOff[b.q + 1] - qNameOff[b.q]), qNames + qNameOff[b.q]);
                 fprintf(f, "%.*s\t%s\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%s\n", (int) (tNameOff[b.t + 1] - tNameOff[b.t]),
                         tNames + tNameOff[b.t], b.pvalText, b.seqIdText, b.evalText, b.qStart, b.qEnd, b.qLen, b.tStart,
-                        b.tEnd, b.tLen, b.cigar.c_str());
+                        b.tEnd, b.tLen, std::string(a->tCigar[b.arena], b.cigarOff, b.cigarLen).c_str());
                 nh++;
             }
             key++;

@@ -118,6 +118,7 @@ char *u32toa(uint32_t v, char *buf);       // returns pointer past the last digi
 char *i32toa(int32_t v, char *buf);
 char *seqIdToBuffer(float seqId, char *buf);
 std::string compressBacktrace(const char *bt, size_t n);
+void compressBacktraceAppend(const char *bt, size_t n, std::string &out);
 
 }  // namespace sd
 #endif

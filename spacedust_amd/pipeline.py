@@ -6,6 +6,7 @@ libsdgpu.so (HIP); this file only moves buffers and sequences the stages."""
 import ctypes as C
 import os
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -91,11 +92,25 @@ class ClusterSearch:
         a0, b0 = query_range if query_range is not None else (0, Q.n)
         t_all = time.time()
         agg = C.c_void_p()
-        api._check(None, L.sd_agg_create(ptr(Q.set_id), Q.n, ptr(T.set_id), T.n, Q.n_sets, T.n_sets, self.eval_thr,
+        tl = T.lengths().astype(np.int32)
+        qlens = Q.lengths().astype(np.int32)
+        api._check(None, L.sd_agg_create(ptr(Q.set_id), ptr(qlens), Q.n, ptr(T.set_id), ptr(tl), T.n, Q.n_sets, T.n_sets,
+                                         self.eval_thr,
                                          self.cov_mode, self.cov_thr, self.aln_len_thr, 1 if self.filter_self_match else 0,
                                          C.byref(agg)), 'sd_agg_create')
-        tl = T.lengths()
-        tm = dict(prefilter=0.0, align=0.0, aggregate=0.0, clusterhits=0.0, bias=0.0)
+        tm = dict(prefilter=0.0, align=0.0, aggregate=0.0, clusterhits=0.0, bias=0.0, aggregate_busy=0.0)
+        # the host-side aggregation of chunk i runs on a worker thread while the GPU stages of chunk i+1 run
+        # (ctypes releases the GIL); one job in flight keeps the order of sd_agg_add calls and bounds memory
+        pool_exec = ThreadPoolExecutor(max_workers=1)
+        pending = None
+
+        def aggregate_job(n_pairs, pair_q_local, pair_t, r, identity, pool, c0):
+            t1 = time.time()
+            idt = np.ascontiguousarray(identity, np.uint8)
+            api._check(None, L.sd_agg_add(agg, n_pairs, c0, ptr(pair_q_local), ptr(pair_t), ptr(r), ptr(idt), ptr(pool)),
+                       'sd_agg_add')
+            return time.time() - t1
+
         for c0 in range(a0, b0, chunk_queries):
             c1 = min(b0, c0 + chunk_queries)
             r0, r1 = int(Q.offsets[c0]), int(Q.offsets[c1])
@@ -137,15 +152,15 @@ class ClusterSearch:
             self.stats['cells_tb'] += tb
             self.stats['pairs'] += n_pairs
             t0 = time.time()
-            pair_q = (pair_q_local + np.uint32(c0)).astype(np.uint32)
-            qlen_p = ql[pair_q_local].astype(np.int32)
-            tlen_p = tl[pair_t].astype(np.int32)
-            idt = np.ascontiguousarray(identity, np.uint8)
-            api._check(None, L.sd_agg_add(agg, n_pairs, ptr(pair_q), ptr(pair_t), ptr(r), ptr(idt), ptr(qlen_p),
-                                          ptr(tlen_p), ptr(pool)), 'sd_agg_add')
+            if pending is not None:
+                tm['aggregate_busy'] += pending.result()
+            pending = pool_exec.submit(aggregate_job, n_pairs, pair_q_local, pair_t, r, identity, pool, c0)
             tm['aggregate'] += time.time() - t0
             del qset
         t0 = time.time()
+        if pending is not None:
+            tm['aggregate_busy'] += pending.result()
+        pool_exec.shutdown()
         ne, nh = C.c_uint64(), C.c_uint64()
         L.sd_agg_finish(agg, C.byref(ne), C.byref(nh))
         ne, nh = ne.value, nh.value
