@@ -355,13 +355,14 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
     res[2 * id + 1] = ids;
 }
 
-template <int RT, bool MULTI>
+template <int RT, int LW, bool MULTI>
 void launchScorePk(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, uint32_t n, const sd_seqset *q,
                    const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut, uint2 *dBound) {
     if (n == 0) return;
-    dim3 grid((n + 3) / 4), block(64);
-    hipLaunchKernelGGL((sdpk::sw_score_pk_kernel<RT, MULTI>), grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes,
-                       dMat, go, ge, dOut, dBound, dOrder);
+    constexpr uint32_t perWave = 2 * (64 / LW);
+    dim3 grid((n + perWave - 1) / perWave), block(64);
+    hipLaunchKernelGGL((sdpk::sw_score_pk_kernel<RT, LW, MULTI>), grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias,
+                       t->dRes, dMat, go, ge, dOut, dBound, dOrder);
 }
 
 int rtClass(int n) {
@@ -491,16 +492,19 @@ int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, c
 // the ordering of tasks all happen on the GPU; the host only launches, reads six class boundaries per pass
 // and receives the finished result records + a dense backtrace pool.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t N_SCORE_CLASSES = 10;   // 0-5 packed-int16 kernel (by rows / strips), 6-9 int32 kernel (by rows)
+// score-pass task classes: 0-7 packed-int16 kernel (rows: <=128, <=256, <=384, <=512, <=768, then 2 / 3 / more
+// strips of 512 rows), 8-11 int32 kernel (rows: <=128, <=256, <=512, more)
+constexpr uint32_t N_SCORE_CLASSES = 12;
+constexpr uint32_t FIRST_INT32_CLASS = 8;
 constexpr uint32_t KEY_INVALID = N_SCORE_CLASSES * 1024u;   // sorts after every class
 __device__ __forceinline__ uint32_t scoreKey(int n, int tL, bool int32Kernel) {
     int ci;
     if (int32Kernel || tL > 65535) {
-        ci = 6 + (n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3)));
-    } else if (n <= 512) {
-        ci = n <= 128 ? 0 : (n <= 256 ? 1 : 2);
+        ci = FIRST_INT32_CLASS + (n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3)));
+    } else if (n <= 768) {
+        ci = n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 384 ? 2 : (n <= 512 ? 3 : 4)));
     } else {
-        ci = min(2 + (n + 511) / 512 - 1, 5);   // 2 strips -> 3, 3 strips -> 4, more -> 5
+        ci = min(5 + (n + 511) / 512 - 2, 7);   // 2 strips -> 5, 3 strips -> 6, more -> 7
     }
     return (uint32_t) ci * 1024u + (uint32_t) (1023 - min(tL >> 4, 1023));
 }
@@ -776,13 +780,13 @@ __global__ void __launch_bounds__(256)
 k_bound_need(uint32_t nPairs, const SwTask *__restrict__ tasks, const uint32_t *__restrict__ keys, uint64_t *__restrict__ need) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPairs) return;
-    // units of uint2: the packed kernel hands over 16 bytes per column and strips every 512 rows, the int32
-    // kernel 8 bytes and every 1024 rows
+    // units of uint2: the packed kernel hands over 16 bytes per column (strips of 512 rows beyond 768 rows), the
+    // int32 kernel 8 bytes (strips of 1024 rows)
     uint64_t v = 0;
     if (keys[i] != KEY_INVALID) {
         const uint32_t ci = keys[i] >> 10;
-        if (ci >= 3 && ci <= 5) v = 2ull * (uint64_t) tasks[i].tL;
-        else if (ci == 9 && tasks[i].n > 1024) v = (uint64_t) tasks[i].tL;
+        if (ci >= 5 && ci < FIRST_INT32_CLASS) v = 2ull * (uint64_t) tasks[i].tL;
+        else if (ci == N_SCORE_CLASSES - 1 && tasks[i].n > 1024) v = (uint64_t) tasks[i].tL;
     }
     need[i] = v;
 }
@@ -819,16 +823,18 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
     for (uint32_t ci = 0; ci < N_SCORE_CLASSES; ci++) {
         const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
         if (cnt == 0) continue;
-        ProfScope ps(ctx, ci < 6 ? "sw_score_pk" : "sw_score");
+        ProfScope ps(ctx, ci < FIRST_INT32_CLASS ? "sw_score_pk" : "sw_score");
         const uint32_t *ord = dOrder + begin;
         switch (ci) {
-            case 0: launchScorePk<4, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 1: launchScorePk<8, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 2: launchScorePk<16, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 3: case 4: case 5: launchScorePk<16, true>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 6: launchScoreIdx<4>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 7: launchScoreIdx<8>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 8: launchScoreIdx<16>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 0: launchScorePk<4, 32, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 1: launchScorePk<8, 32, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 2: launchScorePk<12, 32, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 3: launchScorePk<8, 64, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 4: launchScorePk<12, 64, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 5: case 6: case 7: launchScorePk<8, 64, true>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 8: launchScoreIdx<4>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 9: launchScoreIdx<8>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 10: launchScoreIdx<16>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
             default: launchScoreIdx<32>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
         }
     }

@@ -106,27 +106,30 @@ __device__ __forceinline__ uint32_t readLane(uint32_t v, int lane) {
 
 constexpr int PK_NEUTRAL = 21;   // profile row of -64s: columns outside the target
 
-// RT rows per lane and pair; ROWS = 32*RT rows per strip.  MULTI: queries longer than one strip.
-template <int RT, bool MULTI>
+// RT rows per lane and pair, LW lanes per pair of tasks: LW = 32 puts two pairs (four tasks) on a wavefront,
+// LW = 64 one pair.  ROWS = LW*RT query rows per strip.  MULTI: queries longer than one strip.
+template <int RT, int LW, bool MULTI>
 __global__ void __launch_bounds__(64)
 sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                    const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
                    int go, int ge, int32_t *__restrict__ out, uint2 *__restrict__ boundary,
                    const uint32_t *__restrict__ order) {
-    constexpr int ROWS = 32 * RT;
+    constexpr int ROWS = LW * RT;
     constexpr int WORDS = RT / 4;
-    __shared__ uint32_t prof[4][22][ROWS / 4];
+    constexpr int NGRP = 64 / LW;
+    constexpr int NT = 2 * NGRP;   // tasks per wavefront
+    __shared__ uint32_t prof[NT][22][ROWS / 4];
     __shared__ int8_t smat[441];
     for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
     __syncthreads();
 
     const int lane = threadIdx.x;
-    const int grp = lane >> 5, l = lane & 31;
-    // the four tasks of this wavefront (uniform loads); tasks beyond the end are empty
-    SwTask tk[4];
+    const int grp = lane / LW, l = lane % LW;
+    // the tasks of this wavefront (uniform loads); tasks beyond the end are empty
+    SwTask tk[NT];
 #pragma unroll
-    for (int x = 0; x < 4; x++) {
-        const uint32_t id = blockIdx.x * 4 + x;
+    for (int x = 0; x < NT; x++) {
+        const uint32_t id = blockIdx.x * NT + x;
         if (id < nTasks) {
             tk[x] = tasks[order ? order[id] : id];
         } else {
@@ -134,14 +137,18 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
             tk[x].slot = 0; tk[x].boundOff = 0;
         }
     }
-    const SwTask A = grp ? tk[2] : tk[0];
-    const SwTask B = grp ? tk[3] : tk[1];
-    const bool haveA = blockIdx.x * 4 + 2 * grp < nTasks, haveB = blockIdx.x * 4 + 2 * grp + 1 < nTasks;
-    const int maxN = max(max(tk[0].n, tk[1].n), max(tk[2].n, tk[3].n));
-    const int maxTL = max(max(tk[0].tL, tk[1].tL), max(tk[2].tL, tk[3].tL));
+    const SwTask A = (NGRP == 2 && grp) ? tk[NT - 2] : tk[0];
+    const SwTask B = (NGRP == 2 && grp) ? tk[NT - 1] : tk[1];
+    const bool haveA = blockIdx.x * NT + 2 * grp < nTasks, haveB = blockIdx.x * NT + 2 * grp + 1 < nTasks;
+    int maxN = 0, maxTL = 0;
+#pragma unroll
+    for (int x = 0; x < NT; x++) {
+        maxN = max(maxN, tk[x].n);
+        maxTL = max(maxTL, tk[x].tL);
+    }
     const int pairTL = max(A.tL, B.tL);
     const int nStrips = MULTI ? (maxN + ROWS - 1) / ROWS : (maxN > 0 ? 1 : 0);
-    const int steps = (maxN > 0 && maxTL > 0) ? maxTL + 31 : 0;
+    const int steps = (maxN > 0 && maxTL > 0) ? maxTL + LW - 1 : 0;
     uint4 *bnd = nullptr;
     if (MULTI) bnd = (uint4 *) (boundary + (A.tL >= B.tL ? A.boundOff : B.boundOff));
 
@@ -230,26 +237,28 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
 
         uint32_t chunk = loadChunk(0);
         uint4 bchunk = loadBound(0);
-        for (int k0 = 0; k0 < steps; k0 += 32) {
-            const uint32_t chunkNext = loadChunk(k0 + 32);
+        for (int k0 = 0; k0 < steps; k0 += LW) {
+            const uint32_t chunkNext = loadChunk(k0 + LW);
             uint4 bnext = make_uint4(0, 0, 0, 0);
-            if (readBound) bnext = loadBound(k0 + 32);
-            const int iEnd = min(32, steps - k0);
+            if (readBound) bnext = loadBound(k0 + LW);
+            const int iEnd = min(LW, steps - k0);
 #pragma unroll 1
             for (int i = 0; i < iEnd; i++) {
                 // ---- hand-off from lane l-1; lane 0 of each half wavefront takes the target residues (and the
                 //      previous strip's boundary) instead
                 uint32_t inT = dppShr1(curT), inG = dppShr1(outG), inFf = dppShr1(outFf), inFl = dppShr1(outFl);
                 inT = writeLane<0>(readLane(chunk, i), inT);
-                inT = writeLane<32>(readLane(chunk, 32 + i), inT);
+                if (NGRP == 2) inT = writeLane<32>(readLane(chunk, 32 + i), inT);
                 if (readBound) {
                     inG = writeLane<0>(readLane(bchunk.x, i), inG);
                     inFf = writeLane<0>(readLane(bchunk.y, i), inFf);
                     inFl = writeLane<0>(readLane(bchunk.z, i), inFl);
-                    inG = writeLane<32>(readLane(bchunk.x, 32 + i), inG);
-                    inFf = writeLane<32>(readLane(bchunk.y, 32 + i), inFf);
-                    inFl = writeLane<32>(readLane(bchunk.z, 32 + i), inFl);
-                } else {
+                    if (NGRP == 2) {
+                        inG = writeLane<32>(readLane(bchunk.x, 32 + i), inG);
+                        inFf = writeLane<32>(readLane(bchunk.y, 32 + i), inFf);
+                        inFl = writeLane<32>(readLane(bchunk.z, 32 + i), inFl);
+                    }
+                } else if (NGRP == 2) {
                     inG = writeLane<32>(0, inG);
                     inFf = writeLane<32>(0, inFf);
                     inFl = writeLane<32>(0, inFl);
@@ -281,8 +290,8 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                 outG = H[RT - 1];
                 outFf = Ff;
                 outFl = Fl;
-                if (MULTI && !lastStrip && l == 31) {
-                    const int c = k0 + i - 31;
+                if (MULTI && !lastStrip && l == LW - 1) {
+                    const int c = k0 + i - (LW - 1);
                     if (c >= 0 && c < pairTL) {
                         const unsigned long long lo = (unsigned long long) outG | ((unsigned long long) outFf << 32);
                         __hip_atomic_store((unsigned long long *) &bnd[c], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -319,10 +328,10 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
             }
         }
     }
-    // ---- reduce over the 32 lanes: max value, then smallest column, then smallest row
+    // ---- reduce over the LW lanes: max value, then smallest column, then smallest row
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-        const unsigned long long oa = __shfl_xor(keyA, off, 32), ob = __shfl_xor(keyB, off, 32);
+    for (int off = LW / 2; off >= 1; off >>= 1) {
+        const unsigned long long oa = __shfl_xor(keyA, off, LW), ob = __shfl_xor(keyB, off, LW);
         keyA = oa > keyA ? oa : keyA;
         keyB = ob > keyB ? ob : keyB;
     }
