@@ -157,27 +157,39 @@ def main():
         return
     prof = gpu.profile_report()
     kernels = {k: dict(ms=v[0], launches=int(v[1])) for k, v in prof.items()}
+    # variants of one kernel template ("name.variant") are one kernel for the roofline
+    grouped = {}
+    for k, v in kernels.items():
+        g = grouped.setdefault(k.split('.')[0], dict(ms=0.0, launches=0))
+        g['ms'] += v['ms']
+        g['launches'] += v['launches']
     st = cs.stats
     qlen_steps = 0
     b_pref = algorithmic_bytes(st, int(ps.lengths().mean() * args.steps * B * args.genes))
     pf_ms = sum(v['ms'] for k, v in kernels.items() if k.startswith('prefilter_'))
-    sw_ms = kernels.get('sw_score', dict(ms=0))['ms']
+    sw_ms = sum(v['ms'] for k, v in grouped.items() if k.startswith('sw_score'))
     cells_sw = st['cells_fwd'] + st['cells_rev']
     b_sw = st['pairs'] * (int(ps.lengths().mean()) * 23 + 24)
-    dev_kernels = {k: v for k, v in kernels.items() if not k.startswith('host:')}
+    dev_kernels = {k: v for k, v in grouped.items() if not k.startswith('host:')}
     dom = max(dev_kernels.items(), key=lambda kv: kv[1]['ms'])[0] if dev_kernels else 'none'
-    if dom == 'sw_score':
-        alg, per = b_sw, kernels[dom]
+    if dom.startswith('sw_score'):
+        alg, per = b_sw * grouped[dom]['ms'] / max(sw_ms, 1e-9), grouped[dom]
     elif dom.startswith('prefilter_'):
         share = kernels[dom]['ms'] / pf_ms if pf_ms > 0 else 1.0
-        alg, per = (6 * st['index_hits'] if dom in ('prefilter_gather_hits', 'prefilter_sort_hits') else b_pref * share), kernels[dom]
+        alg, per = (6 * st['index_hits'] if dom in ('prefilter_gather_hits', 'prefilter_sort_hits') else b_pref * share), grouped[dom]
     else:
-        alg, per = 17 * int(summary[1]) + 4 * int(summary[1]), kernels.get(dom, dict(ms=1, launches=1))
+        alg, per = 17 * int(summary[1]) + 4 * int(summary[1]), grouped.get(dom, dict(ms=1, launches=1))
     achieved = (alg / max(per['launches'], 1)) / ((per['ms'] / max(per['launches'], 1)) * 1e-3) / 1e9 if per['ms'] > 0 else 0.0
     roofline = dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                     traffic=None, launches=per['launches'], avg_launch_ms=per['ms'] / max(per['launches'], 1),
-                    note=('sw_score is integer-VALU bound (DP state lives in VGPR/LDS): see sw_gcups; '
-                          'algorithmic bytes = residue streams only') if dom == 'sw_score' else 'algorithmic bytes per SURVEY.md 8(d)')
+                    note=('the score pass is integer-VALU bound (DP state lives in VGPR/LDS): see sw_valu; '
+                          'algorithmic bytes = residue streams only') if dom.startswith('sw_score') else 'algorithmic bytes per SURVEY.md 8(d)')
+    # VALU view of the score pass: lane-instructions of the inner loop per DP cell (counted in the gfx950 ISA of the
+    # dominant variants: packed kernel ~11.1/2 per cell... stated per cell below) against 256 CU x 64 lanes x 2.4 GHz
+    VALU_PEAK = 256 * 64 * 2.4e9
+    INSTR_PER_CELL = 11.1   # sw_score_pk RT=8: 178 instructions per step of 16 cells
+    sw_valu = dict(cells_per_s=cells_sw / (sw_ms * 1e-3) if sw_ms > 0 else 0.0, instr_per_cell=INSTR_PER_CELL, peak_lane_instr_per_s=VALU_PEAK)
+    sw_valu['frac'] = sw_valu['cells_per_s'] * INSTR_PER_CELL / VALU_PEAK
     res = {
         'metric': 'clustersearch throughput (genome-pairs/s; SW GCUPS alongside)',
         'value': pairs_total / dt_max,
@@ -197,6 +209,7 @@ def main():
                    'parallelism': 'query-set sharding x%d, target index replicated, RCCL final gather' % world},
         'roofline': roofline,
         'sw_gcups': cells_sw / sw_ms / 1e6 if sw_ms > 0 else 0.0,
+        'sw_valu': sw_valu,
         'sw_cells': {'forward': st['cells_fwd'], 'reverse': st['cells_rev'], 'traceback': st['cells_tb']},
         'prefilter': {'queries': args.steps * B * args.genes, 'kernel_ms': pf_ms, 'algorithmic_bytes': b_pref,
                       'achieved_GBs': b_pref / pf_ms / 1e6 if pf_ms > 0 else 0.0, 'index_hits': st['index_hits'],

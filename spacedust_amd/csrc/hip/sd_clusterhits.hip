@@ -331,19 +331,19 @@ extern "C" int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32
     for (uint64_t x = 0; x < total; x++) maxPos = std::max(maxPos, std::max(qPos[x], tPos[x]));
     if ((uint64_t) maxPos + 3 > lGammaLen || (uint64_t) maxK + 2 > lGammaLen || par->maxGeneGap + 3 > lGammaLen)
         return sdFail(ctx, SD_EINVAL, "logGamma table too short: %u entries, need %llu", lGammaLen, (unsigned long long) std::max<uint64_t>(maxPos + 3, maxK + 2));
-    DevBuf<ChPair> dPairs;
-    DevBuf<uint32_t> dQ, dT, dScratchU, dNode, dMerges;
-    DevBuf<uint8_t> dS;
-    DevBuf<double> dLg, dScratchD;
-    SD_HIP(ctx, dPairs.alloc(nPairs));
-    SD_HIP(ctx, dQ.alloc(total));
-    SD_HIP(ctx, dT.alloc(total));
-    SD_HIP(ctx, dS.alloc(total));
-    SD_HIP(ctx, dLg.alloc(lGammaLen));
-    SD_HIP(ctx, dScratchU.alloc(total * 9));
-    SD_HIP(ctx, dScratchD.alloc(total));
-    SD_HIP(ctx, dNode.alloc(total));
-    SD_HIP(ctx, dMerges.alloc(nPairs));
+    struct { ChPair *p; } dPairs;
+    struct { uint32_t *p; } dQ, dT, dScratchU, dNode, dMerges;
+    struct { uint8_t *p; } dS;
+    struct { double *p; } dLg, dScratchD;
+    SD_HIP(ctx, wsGet(ctx, "ch.pairs", nPairs, &dPairs.p));
+    SD_HIP(ctx, wsGet(ctx, "ch.q", total, &dQ.p));
+    SD_HIP(ctx, wsGet(ctx, "ch.t", total, &dT.p));
+    SD_HIP(ctx, wsGet(ctx, "ch.s", total, &dS.p));
+    SD_HIP(ctx, wsGet(ctx, "ch.lg", lGammaLen, &dLg.p));
+    SD_HIP(ctx, wsGet(ctx, "ch.scratchU", total * 9, &dScratchU.p));
+    SD_HIP(ctx, wsGet(ctx, "ch.scratchD", total, &dScratchD.p));
+    SD_HIP(ctx, wsGet(ctx, "ch.node", total, &dNode.p));
+    SD_HIP(ctx, wsGet(ctx, "ch.merges", nPairs, &dMerges.p));
     SD_HIP(ctx, hipMemcpyAsync(dPairs.p, hp.data(), nPairs * sizeof(ChPair), hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(dQ.p, qPos, total * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(dT.p, tPos, total * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -356,49 +356,69 @@ extern "C" int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32
                            log(0.001), log(2.0), par->maxGeneGap, dScratchU.p, dScratchD.p, dNode.p, dMerges.p);
     }
     SD_HIP(ctx, hipGetLastError());
-    std::vector<uint32_t> node(total);
-    SD_HIP(ctx, hipMemcpyAsync(node.data(), dNode.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t *node = nullptr;
+    SD_HIP(ctx, pinGet(ctx, "ch.hnode", total, &node));
+    SD_HIP(ctx, hipMemcpyAsync(node, dNode.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // ---- emission (:456-485): nodes in index order, size >= cls, pCO / pMH thresholds
-#pragma omp parallel for schedule(dynamic, 16)
-    for (uint32_t p = 0; p < nPairs; p++) {
-        const uint64_t off = hitOff[p];
-        const uint32_t K = hp[p].K;
-        for (uint32_t h = 0; h < K; h++) {
-            clusterOfHit[off + h] = UINT32_MAX;
-            rankInCluster[off + h] = 0;
-        }
-        nClusters[p] = 0;
-        if (K <= 1) continue;
-        std::vector<std::vector<uint32_t> > members(K);
-        for (uint32_t h = 0; h < K; h++) {
-            const uint32_t n = node[off + h];
-            if (n < K) members[n].push_back(h);
-        }
-        uint32_t nClu = 0;
-        for (uint32_t n = 0; n < K; n++) {
-            if (members[n].size() < par->clusterSize || members[n].empty()) continue;
-            std::vector<HHit> cluster;
-            for (uint32_t h : members[n]) {
-                HHit x;
-                x.pval = pval[off + h]; x.qPos = qPos[off + h]; x.tPos = tPos[off + h];
-                x.qS = strands[off + h] & 1; x.tS = (strands[off + h] >> 1) & 1; x.idx = h;
-                cluster.push_back(x);
+#pragma omp parallel
+    {
+        std::vector<uint32_t> start, items;
+        std::vector<HHit> cluster;
+#pragma omp for schedule(dynamic, 1)
+        for (uint32_t p = 0; p < nPairs; p++) {
+            const uint64_t off = hitOff[p];
+            const uint32_t K = hp[p].K;
+            for (uint32_t h = 0; h < K; h++) {
+                clusterOfHit[off + h] = UINT32_MAX;
+                rankInCluster[off + h] = 0;
             }
-            const double co = exp(-hClusterMatchScore(lGamma, cluster));   // sorts `cluster` by qPos, as the reference does
-            const double mh = hMultihitPval(lGamma, cluster, (int) Nq[p], par->alpha);
-            if (co <= par->pCluThr && mh <= par->pMHThr) {
-                pCO[off + nClu] = co;
-                pMH[off + nClu] = mh;
-                clusterSizeOut[off + nClu] = (uint32_t) cluster.size();
-                for (size_t r = 0; r < cluster.size(); r++) {
-                    clusterOfHit[off + cluster[r].idx] = nClu;
-                    rankInCluster[off + cluster[r].idx] = (uint32_t) r;
+            nClusters[p] = 0;
+            if (K <= 1) continue;
+            // members of every surviving node, hits in index order (counting sort by node)
+            start.assign((size_t) K + 1, 0);
+            items.resize(K);
+            for (uint32_t h = 0; h < K; h++) {
+                const uint32_t n = node[off + h];
+                if (n < K) start[n + 1]++;
+            }
+            for (uint32_t n = 0; n < K; n++) start[n + 1] += start[n];
+            {
+                std::vector<uint32_t> &fill = items;   // filled through a moving cursor kept in `cursor`
+                static thread_local std::vector<uint32_t> cursor;
+                cursor.assign(start.begin(), start.end() - 1);
+                for (uint32_t h = 0; h < K; h++) {
+                    const uint32_t n = node[off + h];
+                    if (n < K) fill[cursor[n]++] = h;
                 }
-                nClu++;
             }
+            uint32_t nClu = 0;
+            for (uint32_t n = 0; n < K; n++) {
+                const uint32_t sz = start[n + 1] - start[n];
+                if (sz < par->clusterSize || sz == 0) continue;
+                cluster.clear();
+                for (uint32_t x = start[n]; x < start[n + 1]; x++) {
+                    const uint32_t h = items[x];
+                    HHit hh;
+                    hh.pval = pval[off + h]; hh.qPos = qPos[off + h]; hh.tPos = tPos[off + h];
+                    hh.qS = strands[off + h] & 1; hh.tS = (strands[off + h] >> 1) & 1; hh.idx = h;
+                    cluster.push_back(hh);
+                }
+                const double co = exp(-hClusterMatchScore(lGamma, cluster));   // sorts `cluster` by qPos, as the reference does
+                const double mh = hMultihitPval(lGamma, cluster, (int) Nq[p], par->alpha);
+                if (co <= par->pCluThr && mh <= par->pMHThr) {
+                    pCO[off + nClu] = co;
+                    pMH[off + nClu] = mh;
+                    clusterSizeOut[off + nClu] = (uint32_t) cluster.size();
+                    for (size_t r = 0; r < cluster.size(); r++) {
+                        clusterOfHit[off + cluster[r].idx] = nClu;
+                        rankInCluster[off + cluster[r].idx] = (uint32_t) r;
+                    }
+                    nClu++;
+                }
+            }
+            nClusters[p] = nClu;
         }
-        nClusters[p] = nClu;
     }
     return SD_OK;
 }

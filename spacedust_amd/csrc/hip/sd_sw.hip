@@ -355,13 +355,13 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
     res[2 * id + 1] = ids;
 }
 
-template <int RT, int LW, bool MULTI>
+template <int RT, int LW, bool MULTI, bool WIDE>
 void launchScorePk(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, uint32_t n, const sd_seqset *q,
                    const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut, uint2 *dBound) {
     if (n == 0) return;
     constexpr uint32_t perWave = 2 * (64 / LW);
     dim3 grid((n + perWave - 1) / perWave), block(64);
-    hipLaunchKernelGGL((sdpk::sw_score_pk_kernel<RT, LW, MULTI>), grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias,
+    hipLaunchKernelGGL((sdpk::sw_score_pk_kernel<RT, LW, MULTI, WIDE>), grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias,
                        t->dRes, dMat, go, ge, dOut, dBound, dOrder);
 }
 
@@ -492,19 +492,24 @@ int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, c
 // the ordering of tasks all happen on the GPU; the host only launches, reads six class boundaries per pass
 // and receives the finished result records + a dense backtrace pool.
 // ---------------------------------------------------------------------------------------------
-// score-pass task classes: 0-7 packed-int16 kernel (rows: <=128, <=256, <=384, <=512, <=768, then 2 / 3 / more
-// strips of 512 rows), 8-11 int32 kernel (rows: <=128, <=256, <=512, more)
-constexpr uint32_t N_SCORE_CLASSES = 12;
-constexpr uint32_t FIRST_INT32_CLASS = 8;
+// score-pass task classes: 0-7 packed-int16 kernel with the five-bit row code, 8-15 the same with the wide row
+// code (rows: <=128, <=256, <=384, <=512, <=768, then 2 / 3 / more strips of 512 rows), 16-19 int32 kernel
+// (rows: <=128, <=256, <=512, more)
+constexpr uint32_t N_SCORE_CLASSES = 20;
+constexpr uint32_t FIRST_WIDE_CLASS = 8;
+constexpr uint32_t FIRST_INT32_CLASS = 16;
+enum ScoreKernel { SCORE_PK = 0, SCORE_PK_WIDE = 1, SCORE_INT32 = 2 };
 constexpr uint32_t KEY_INVALID = N_SCORE_CLASSES * 1024u;   // sorts after every class
-__device__ __forceinline__ uint32_t scoreKey(int n, int tL, bool int32Kernel) {
+__device__ __forceinline__ uint32_t scoreKey(int n, int tL, int kernel) {
     int ci;
-    if (int32Kernel || tL > 65535) {
+    // int16 cells: a score cannot exceed min(n, tL) * (largest profile entry < 40)
+    if (kernel == SCORE_PK_WIDE && min(n, tL) > 800) kernel = SCORE_INT32;
+    if (kernel == SCORE_INT32 || tL > 65535) {
         ci = FIRST_INT32_CLASS + (n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3)));
-    } else if (n <= 768) {
-        ci = n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 384 ? 2 : (n <= 512 ? 3 : 4)));
     } else {
-        ci = min(5 + (n + 511) / 512 - 2, 7);   // 2 strips -> 5, 3 strips -> 6, more -> 7
+        if (n <= 768) ci = n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 384 ? 2 : (n <= 512 ? 3 : 4)));
+        else ci = min(5 + (n + 511) / 512 - 2, 7);   // 2 strips -> 5, 3 strips -> 6, more -> 7
+        if (kernel == SCORE_PK_WIDE) ci += FIRST_WIDE_CLASS;
     }
     return (uint32_t) ci * 1024u + (uint32_t) (1023 - min(tL >> 4, 1023));
 }
@@ -569,7 +574,7 @@ k_make_fwd(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const uint32_t *
     tk.slot = i; tk.boundOff = 0;
     const bool valid = !(ident && ident[i]) && qL > 0 && tL > 0;
     tasks[i] = tk;
-    keys[i] = valid ? scoreKey(qL, tL, !usePk) : KEY_INVALID;
+    keys[i] = valid ? scoreKey(qL, tL, usePk ? SCORE_PK : SCORE_INT32) : KEY_INVALID;
     vals[i] = i;
     sd_sw_result r;
     r.score = 0; r.qStart = -1; r.qEnd = -1; r.tStart = -1; r.tEnd = -1; r.identical = 0; r.btLen = 0; r.flags = 0;
@@ -595,7 +600,7 @@ __global__ void k_bounds(const uint32_t *__restrict__ keys, uint32_t n, uint32_t
 __global__ void __launch_bounds__(256)
 k_gate_word(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const int32_t *__restrict__ out32,
             const int32_t *__restrict__ minBias, int matMin, SwTask *__restrict__ tasks, uint32_t *__restrict__ keys,
-            uint32_t *__restrict__ vals, uint8_t *__restrict__ word, const uint32_t *__restrict__ fwdKeys) {
+            uint32_t *__restrict__ vals, uint8_t *__restrict__ word, const uint32_t *__restrict__ fwdKeys, int usePk) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPairs) return;
     vals[i] = i;
@@ -608,7 +613,7 @@ k_gate_word(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const int32_t *
     word[i] = w ? 1 : 0;
     if (w) {
         tasks[i].segLen = max(1, (tasks[i].n + 15) / 16);
-        keys[i] = scoreKey(tasks[i].n, tasks[i].tL, true);
+        keys[i] = scoreKey(tasks[i].n, tasks[i].tL, usePk ? SCORE_PK_WIDE : SCORE_INT32);
     } else {
         keys[i] = KEY_INVALID;
     }
@@ -651,7 +656,7 @@ k_gate_rev(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ
     tk.segLen = max(1, (tk.n + lanes - 1) / lanes);
     tk.slot = i; tk.boundOff = 0;
     tasks[i] = tk;
-    keys[i] = scoreKey(tk.n, tk.tL, word[i] || !usePk);
+    keys[i] = scoreKey(tk.n, tk.tL, !usePk ? SCORE_INT32 : (word[i] ? SCORE_PK_WIDE : SCORE_PK));
 }
 
 __device__ __forceinline__ uint32_t tbKey(int band, int qLen) {
@@ -785,7 +790,7 @@ k_bound_need(uint32_t nPairs, const SwTask *__restrict__ tasks, const uint32_t *
     uint64_t v = 0;
     if (keys[i] != KEY_INVALID) {
         const uint32_t ci = keys[i] >> 10;
-        if (ci >= 5 && ci < FIRST_INT32_CLASS) v = 2ull * (uint64_t) tasks[i].tL;
+        if (ci < FIRST_INT32_CLASS && (ci & 7) >= 5) v = 2ull * (uint64_t) tasks[i].tL;
         else if (ci == N_SCORE_CLASSES - 1 && tasks[i].n > 1024) v = (uint64_t) tasks[i].tL;
     }
     need[i] = v;
@@ -803,7 +808,7 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
                 const sd_seqset *q, const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut,
                 uint32_t *nValid) {
     const unsigned grid = (nPairs + 255) / 256;
-    int rc = devSortPairs(ctx, dKeys, dKeysSorted, dVals, dOrder, nPairs, 14);
+    int rc = devSortPairs(ctx, dKeys, dKeysSorted, dVals, dOrder, nPairs, 15);
     if (rc != SD_OK) return rc;
     hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1024u, dBounds, (int) N_SCORE_CLASSES + 1);
     // strip hand-off workspace for queries longer than one 1024-row strip
@@ -823,20 +828,34 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
     for (uint32_t ci = 0; ci < N_SCORE_CLASSES; ci++) {
         const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
         if (cnt == 0) continue;
-        ProfScope ps(ctx, ci < FIRST_INT32_CLASS ? "sw_score_pk" : "sw_score");
+        static const char *const names[N_SCORE_CLASSES] = {
+            "sw_score_pk.rt4x32", "sw_score_pk.rt8x32", "sw_score_pk.rt12x32", "sw_score_pk.rt8x64", "sw_score_pk.rt12x64",
+            "sw_score_pk.rt8x64s2", "sw_score_pk.rt8x64s3", "sw_score_pk.rt8x64sN",
+            "sw_score_pk.w_rt4x32", "sw_score_pk.w_rt8x32", "sw_score_pk.w_rt12x32", "sw_score_pk.w_rt8x64", "sw_score_pk.w_rt12x64",
+            "sw_score_pk.w_rt8x64s2", "sw_score_pk.w_rt8x64s3", "sw_score_pk.w_rt8x64sN",
+            "sw_score.rt4", "sw_score.rt8", "sw_score.rt16", "sw_score.rt32"};
+        ProfScope ps(ctx, names[ci]);
         const uint32_t *ord = dOrder + begin;
+#define SD_PK(RT, LW, MULTI, WIDE) launchScorePk<RT, LW, MULTI, WIDE>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound)
         switch (ci) {
-            case 0: launchScorePk<4, 32, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 1: launchScorePk<8, 32, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 2: launchScorePk<12, 32, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 3: launchScorePk<8, 64, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 4: launchScorePk<12, 64, false>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 5: case 6: case 7: launchScorePk<8, 64, true>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 8: launchScoreIdx<4>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 9: launchScoreIdx<8>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 10: launchScoreIdx<16>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 0: SD_PK(4, 32, false, false); break;
+            case 1: SD_PK(8, 32, false, false); break;
+            case 2: SD_PK(12, 32, false, false); break;
+            case 3: SD_PK(8, 64, false, false); break;
+            case 4: SD_PK(12, 64, false, false); break;
+            case 5: case 6: case 7: SD_PK(8, 64, true, false); break;
+            case 8: SD_PK(4, 32, false, true); break;
+            case 9: SD_PK(8, 32, false, true); break;
+            case 10: SD_PK(12, 32, false, true); break;
+            case 11: SD_PK(8, 64, false, true); break;
+            case 12: SD_PK(12, 64, false, true); break;
+            case 13: case 14: case 15: SD_PK(8, 64, true, true); break;
+            case 16: launchScoreIdx<4>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 17: launchScoreIdx<8>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            case 18: launchScoreIdx<16>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
             default: launchScoreIdx<32>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
         }
+#undef SD_PK
     }
     SD_HIP(ctx, hipGetLastError());
     return SD_OK;
@@ -1130,7 +1149,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     // ---- pass 2: saturated pairs again with the word kernel's 16-lane structure
     hs.reset(new HostScope(ctx, "align.fwd16"));
     hipLaunchKernelGGL(k_gate_word, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dOut32, dMinBias, matMin, dTasks, dKeys,
-                       dVals, dWord, dFwdKeys);
+                       dVals, dWord, dFwdKeys, usePk);
     hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dKeys, dCells + 0);
     rc = devRunScore(ctx, nPairs, dKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go, ge,
                      dOut16, &nValid);

@@ -108,7 +108,9 @@ constexpr int PK_NEUTRAL = 21;   // profile row of -64s: columns outside the tar
 
 // RT rows per lane and pair, LW lanes per pair of tasks: LW = 32 puts two pairs (four tasks) on a wavefront,
 // LW = 64 one pair.  ROWS = LW*RT query rows per strip.  MULTI: queries longer than one strip.
-template <int RT, int LW, bool MULTI>
+// WIDE: the column maximum is tracked per task in a 32-bit (value << 16 | 31-r) code instead of the packed
+// five-bit one, which lifts the g < 1024 limit to the int16 range (scores of the reference's word kernel).
+template <int RT, int LW, bool MULTI, bool WIDE>
 __global__ void __launch_bounds__(64)
 sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                    const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
@@ -210,7 +212,8 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
         }
         uint32_t outG = 0, outFf = 0, outFl = 0, prevInG = 0;
         uint32_t curT = PK_NEUTRAL | (PK_NEUTRAL << 8);
-        uint32_t bestv = 0, bestcm = 0, bestcol = 0;
+        uint32_t bestv = 0, bestcm = 0, bestcol = 0;          // packed tracking (!WIDE)
+        uint32_t bestA = 0, bestB = 0, bcolA = 0, bcolB = 0;   // per task (WIDE)
         uint32_t ccol = (uint32_t) (-l) & 0xFFFFu;
         ccol |= ccol << 16;
         const bool lastStrip = strip == nStrips - 1;
@@ -274,7 +277,7 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                                 h[4 * w + 3]);
                 }
                 prevInG = inG;
-                uint32_t Fl = inFl, Ff = inFf, cm = 0;
+                uint32_t Fl = inFl, Ff = inFf, cm = 0, cmA = 0, cmB = 0;
 #pragma unroll
                 for (int r = 0; r < RT; r++) {
                     Fl &= mask[r];
@@ -285,7 +288,12 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                     Fl = pkMax(pkSubSat(Fl, geP), open);
                     Ff = pkMax(pkSubSat(Ff, geP), open);
                     H[r] = g;
-                    cm = pkMax(cm, pkRowCode(g, 31 - r));
+                    if (WIDE) {
+                        cmA = max(cmA, (g << 16) | (uint32_t) (31 - r));
+                        cmB = max(cmB, (g & 0xFFFF0000u) | (uint32_t) (31 - r));
+                    } else {
+                        cm = pkMax(cm, pkRowCode(g, 31 - r));
+                    }
                 }
                 outG = H[RT - 1];
                 outFf = Ff;
@@ -300,12 +308,20 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                     }
                 }
                 // ---- column maximum: a strictly larger value takes over (first column wins, smallest row inside)
-                const uint32_t v = pkLshr(cm, 5);
-                const uint32_t nb = pkMax(bestv, v);
-                const uint32_t m = pkAshr(pkSub(bestv, nb), 15);
-                bestcm = bfi(m, cm, bestcm);
-                bestcol = bfi(m, ccol, bestcol);
-                bestv = nb;
+                if (WIDE) {
+                    const bool upA = cmA > (bestA | 0xFFFFu), upB = cmB > (bestB | 0xFFFFu);
+                    bestA = upA ? cmA : bestA;
+                    bcolA = upA ? ccol : bcolA;
+                    bestB = upB ? cmB : bestB;
+                    bcolB = upB ? ccol : bcolB;
+                } else {
+                    const uint32_t v = pkLshr(cm, 5);
+                    const uint32_t nb = pkMax(bestv, v);
+                    const uint32_t m = pkAshr(pkSub(bestv, nb), 15);
+                    bestcm = bfi(m, cm, bestcm);
+                    bestcol = bfi(m, ccol, bestcol);
+                    bestv = nb;
+                }
                 ccol = pkAdd(ccol, 0x00010001u);
             }
             chunk = chunkNext;
@@ -313,9 +329,10 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
         }
         // ---- this strip's candidates
         {
-            const uint32_t vA = bestv & 0xFFFFu, vB = bestv >> 16;
-            const uint32_t rowA = (uint32_t) (q0 + 31 - (int) (bestcm & 31u)), rowB = (uint32_t) (q0 + 31 - (int) ((bestcm >> 16) & 31u));
-            const uint32_t colA = bestcol & 0xFFFFu, colB = bestcol >> 16;
+            const uint32_t vA = WIDE ? bestA >> 16 : bestv & 0xFFFFu, vB = WIDE ? bestB >> 16 : bestv >> 16;
+            const uint32_t rcA = WIDE ? bestA & 31u : bestcm & 31u, rcB = WIDE ? bestB & 31u : (bestcm >> 16) & 31u;
+            const uint32_t rowA = (uint32_t) (q0 + 31 - (int) rcA), rowB = (uint32_t) (q0 + 31 - (int) rcB);
+            const uint32_t colA = WIDE ? bcolA & 0xFFFFu : bestcol & 0xFFFFu, colB = WIDE ? bcolB >> 16 : bestcol >> 16;
             if (vA > 0) {
                 const unsigned long long kk = ((unsigned long long) vA << 40) | ((unsigned long long) (0xFFFFFu - colA) << 20) |
                                               (unsigned long long) (0xFFFFFu - rowA);

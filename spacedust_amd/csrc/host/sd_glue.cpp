@@ -112,6 +112,8 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
             bad |= ((uint64_t) qBase + pairQ[i] >= a->qSetOf.size() || pairT[i] >= a->tSetOf.size()) ? 1 : 0;
         if (bad) return SD_EINVAL;
     }
+    const bool dbg = getenv("SD_DEBUG_TIMING") != NULL;
+    const double t0 = omp_get_wtime();
     // group boundaries
     std::vector<uint32_t> groupStart;
     for (uint32_t i = 0; i < nPairs; i++)
@@ -125,6 +127,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
         a->tBest.resize(T);
         a->tCigar.resize(T);
     }
+    const double t1 = omp_get_wtime();
     struct Cand {
         uint32_t i;
         double eval;
@@ -136,8 +139,11 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
 #pragma omp parallel num_threads(T) reduction(+ : accepted)
     {
         const int th = omp_get_thread_num();
-        std::vector<BestHit> &myBest = a->tBest[th];
-        std::string &myCigar = a->tCigar[th];
+        // thread-private containers (the shared vectors' headers sit on common cache lines), swapped back at the end
+        std::vector<BestHit> myBest;
+        std::string myCigar;
+        myBest.swap(a->tBest[th]);
+        myCigar.swap(a->tCigar[th]);
         // best candidate per target set: Alignment sorts a query's accepted hits with Matcher::compareHits
         // (Matcher.h:157-168) and besthitbyset keeps, per set, the first one whose %.3E text E-value is strictly
         // smaller than what it has (besthitbyset.cpp:88-101).  Rounding to text is monotone, so that is the
@@ -226,9 +232,13 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                 myBest.push_back(b);
             }
         }
+        myBest.swap(a->tBest[th]);
+        myCigar.swap(a->tCigar[th]);
     }
     a->nAligned += nPairs;
     a->nAccepted += accepted;
+    if (dbg) fprintf(stderr, "[sd_agg_add] pairs %u groups %zu threads %d: setup %.1f ms, parallel %.1f ms\n", nPairs, nGroups, T,
+                     (t1 - t0) * 1e3, (omp_get_wtime() - t1) * 1e3);
     return SD_OK;
 }
 

@@ -5,6 +5,7 @@ combinehits fused in sd_agg, `clusterhits`, `summarizeresults`).  All hot-path c
 libsdgpu.so (HIP); this file only moves buffers and sequences the stages."""
 import ctypes as C
 import os
+import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -176,14 +177,20 @@ class ClusterSearch:
         t0 = time.time()
         out = None
         n_clusters = n_cluster_hits = 0
+        dbg = os.environ.get('SD_DEBUG_TIMING') is not None
         if nh > 0:
             qp = Q.pos_in_set[hq]
             tp = T.pos_in_set[ht]
             sd = (Q.strand[hq] | (T.strand[ht] << 1)).astype(np.uint8)
             nq = Q.set_size[eq]
             lg_n = int(max(int(Q.set_size.max()), int(T.set_size.max()), int(qp.max()), int(tp.max()))) + 8
-            out = api.clusterhits(self.ctx, self.host, entry_off, qp, tp, sd, pv, nq, lgamma=self.host.lgamma_table(lg_n),
-                                  **self.ch)
+            t1 = time.time()
+            lg = self.host.lgamma_table(lg_n)
+            t2 = time.time()
+            out = api.clusterhits(self.ctx, self.host, entry_off, qp, tp, sd, pv, nq, lgamma=lg, **self.ch)
+            if dbg:
+                print('[clusterhits] gather %.1f ms, lgamma(%d) %.1f ms, call %.1f ms' % ((t1 - t0) * 1e3, lg_n, (t2 - t1) * 1e3,
+                                                                                       (time.time() - t2) * 1e3), file=sys.stderr)
             n_clusters = int(out['n_clusters'].sum())
             n_cluster_hits = int((out['cluster_of'] != 0xFFFFFFFF).sum())
         tm['clusterhits'] += time.time() - t0
