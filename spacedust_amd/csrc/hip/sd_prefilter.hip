@@ -188,13 +188,16 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
     }
 }
 
-// K3: gather index lists into the hit stream; key = (qLocal << tBits) | seqId, value = stream index
+// K3: gather index lists into the hit stream; key = (qLocal << tBits) | seqId, value = low 8 bits of the diagonal
+// (all the double-diagonal match needs) << 24 | position of the hit in its query's stream (< 2^24: the caller
+// rejects queries with >= maxDbMatches ~ 2^21 hits).  The full 16-bit diagonal stays in hitDiag, in stream order,
+// and is looked up for the few surviving candidates only.
 __global__ void __launch_bounds__(256)
 gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const uint32_t *__restrict__ kLen,
                    const uint32_t *__restrict__ kPos, const uint64_t *__restrict__ hitBase,
                    const uint64_t *__restrict__ posBase, uint32_t nQ, const uint32_t *__restrict__ entrySeq,
-                   const uint16_t *__restrict__ entryPos, int tBits, uint32_t *__restrict__ hitKey,
-                   uint32_t *__restrict__ hitVal, uint16_t *__restrict__ hitDiag) {
+                   const uint16_t *__restrict__ entryPos, int tBits, const uint64_t *__restrict__ qHitBase,
+                   uint32_t *__restrict__ hitKey, uint32_t *__restrict__ hitVal, uint16_t *__restrict__ hitDiag) {
     const uint64_t kidx = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t len = 0, start = 0, q = 0;
@@ -221,9 +224,10 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
     if (len && !isLong) {
         for (uint32_t x = 0; x < len; x++) {
             const uint32_t sid = entrySeq[start + x];
+            const uint16_t d = (uint16_t) (i - (int) entryPos[start + x]);
             hitKey[base + x] = (q << tBits) | sid;
-            hitVal[base + x] = (uint32_t) (base + x);
-            hitDiag[base + x] = (uint16_t) (i - (int) entryPos[start + x]);
+            hitVal[base + x] = ((uint32_t) (d & 0xFF) << 24) | (uint32_t) (base + x - qHitBase[q]);
+            hitDiag[base + x] = d;
         }
     }
     unsigned long long longMask = __ballot(isLong);
@@ -235,36 +239,36 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
         const uint64_t b2 = ((uint64_t) __shfl((uint32_t) (base >> 32), src, 64) << 32) | __shfl((uint32_t) base, src, 64);
         for (uint32_t x = lane; x < l2; x += 64) {
             const uint32_t sid = entrySeq[s2 + x];
+            const uint16_t d = (uint16_t) (i2 - (int) entryPos[s2 + x]);
             hitKey[b2 + x] = (q2 << tBits) | sid;
-            hitVal[b2 + x] = (uint32_t) (b2 + x);
-            hitDiag[b2 + x] = (uint16_t) (i2 - (int) entryPos[s2 + x]);
+            hitVal[b2 + x] = ((uint32_t) (d & 0xFF) << 24) | (uint32_t) (b2 + x - qHitBase[q2]);
+            hitDiag[b2 + x] = d;
         }
     }
 }
 
 // K4: double-diagonal match on the (query,target)-sorted stream
-__device__ __forceinline__ bool flagA(uint64_t s, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val,
-                                      const uint16_t *__restrict__ diag) {
-    const uint8_t d8 = (uint8_t) diag[val[s]];
+__device__ __forceinline__ bool flagA(uint64_t s, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val) {
+    const uint8_t d8 = (uint8_t) (val[s] >> 24);
     const bool first = (s == 0) || (key[s - 1] != key[s]);
-    const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) diag[val[s - 1]];
+    const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) (val[s - 1] >> 24);
     return d8 == prev;
 }
 
 __global__ void __launch_bounds__(256)
 match_diag_kernel(uint64_t nHits, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val,
-                  const uint16_t *__restrict__ diag, uint8_t *__restrict__ emit) {
+                  uint8_t *__restrict__ emit) {
     const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nHits) return;
     bool e = false;
-    if (flagA(s, key, val, diag)) {
+    if (flagA(s, key, val)) {
         e = true;
-        const uint8_t d8 = (uint8_t) diag[val[s]];
+        const uint8_t d8 = (uint8_t) (val[s] >> 24);
         uint64_t x = s;
         while (x > 0 && key[x - 1] == key[s]) {
             x--;
-            if (flagA(x, key, val, diag)) {
-                e = ((uint8_t) diag[val[x]]) != d8;
+            if (flagA(x, key, val)) {
+                e = ((uint8_t) (val[x] >> 24)) != d8;
                 break;
             }
         }
@@ -272,11 +276,18 @@ match_diag_kernel(uint64_t nHits, const uint32_t *__restrict__ key, const uint32
     emit[s] = e ? 1 : 0;
 }
 
+// hits of query q start at stream position qHitBase[q] (q = nQ: total)
+__global__ void query_hit_base_kernel(uint32_t nQ, const uint64_t *__restrict__ posBase, const uint64_t *__restrict__ kmerBase,
+                                      const uint64_t *__restrict__ hitBase, uint64_t *__restrict__ qHitBase) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q <= nQ) qHitBase[q] = hitBase[kmerBase[posBase[q]]];
+}
+
 // K5: ungapped diagonal score (UngappedAlignment.cpp:30-43,416-430); candidates are (key,val) pairs
 __global__ void __launch_bounds__(256)
 score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint32_t *__restrict__ cVal,
-                  const uint16_t *__restrict__ hitDiag, int tBits, const uint8_t *__restrict__ qRes,
-                  const uint64_t *__restrict__ qOff, const int8_t *__restrict__ diagBias,
+                  const uint16_t *__restrict__ hitDiag, const uint64_t *__restrict__ qHitBase, int tBits,
+                  const uint8_t *__restrict__ qRes, const uint64_t *__restrict__ qOff, const int8_t *__restrict__ diagBias,
                   const uint8_t *__restrict__ tMasked, const uint64_t *__restrict__ tOff, const int8_t *__restrict__ mat,
                   int32_t *__restrict__ cScore, uint32_t *__restrict__ cLen) {
     __shared__ int8_t smat[441];
@@ -286,7 +297,7 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
     if (c >= nCand) return;
     const uint32_t k = cKey[c];
     const uint32_t q = k >> tBits, sid = k & ((1u << tBits) - 1);
-    const uint16_t d16 = hitDiag[cVal[c]];
+    const uint16_t d16 = hitDiag[qHitBase[q] + (cVal[c] & 0xFFFFFFu)];
     const int d = (int) (int16_t) d16;
     const int qL = (int) (qOff[q + 1] - qOff[q]);
     const int tL = (int) (tOff[sid + 1] - tOff[sid]);
@@ -355,7 +366,8 @@ __device__ __forceinline__ void bitonicSort(unsigned long long *keys, uint32_t *
 __global__ void __launch_bounds__(256)
 select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, into kept arrays */,
                    const uint32_t *__restrict__ kKey, const uint32_t *__restrict__ kVal,
-                   const int32_t *__restrict__ kScore, const uint16_t *__restrict__ hitDiag, int tBits,
+                   const int32_t *__restrict__ kScore, const uint16_t *__restrict__ hitDiag,
+                   const uint64_t *__restrict__ qHitBase, int tBits,
                    uint32_t binMask, int maxHits, int minDiag, const uint32_t *__restrict__ identityId,
                    const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, int covMode, float covThr,
                    sd_hit *__restrict__ outHits, uint32_t *__restrict__ outCount, int *__restrict__ errFlag) {
@@ -396,7 +408,7 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
                 const uint32_t sid = kKey[x] & ((1u << tBits) - 1);
                 // order of the cut: count desc, bin asc, stream position asc
                 keys[slot] = ((unsigned long long) (255 - cnt) << 56) | ((unsigned long long) (sid & binMask) << 40) |
-                             (unsigned long long) (kVal[x] & 0xFFFFFFFFFFull);
+                             (unsigned long long) (kVal[x] & 0xFFFFFFu);
                 pay[slot] = x;
             }
         }
@@ -469,7 +481,7 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
             const int cnt = min(255, sc);
             o[w].seqId = sid;
             o[w].score = cnt >= 255 ? sc : cnt;
-            o[w].diagonal = hitDiag[kVal[e]];
+            o[w].diagonal = hitDiag[qHitBase[q] + (kVal[e] & 0xFFFFFFu)];
             o[w].pad = 0;
             w++;
         }
@@ -542,6 +554,21 @@ int exclusiveScan(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, DevBuf<ui
     SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int) n, ctx->stream));
     if (tmp.n < bytes) SD_HIP(ctx, tmp.alloc(bytes + 256));
     SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int) n, ctx->stream));
+    return SD_OK;
+}
+
+// exclusive sum of a narrow array straight into 64-bit offsets (no widened copy)
+template <typename T>
+struct WidenOp {
+    __host__ __device__ __forceinline__ uint64_t operator()(const T &v) const { return (uint64_t) v; }
+};
+template <typename T>
+int exclusiveScanWiden(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, DevBuf<uint8_t> &tmp) {
+    hipcub::TransformInputIterator<uint64_t, WidenOp<T>, const T *> it(in, WidenOp<T>());
+    size_t bytes = 0;
+    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, (int) n, ctx->stream));
+    if (tmp.n < bytes) SD_HIP(ctx, tmp.alloc(bytes + 256));
+    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, it, out, (int) n, ctx->stream));
     return SD_OK;
 }
 
@@ -669,10 +696,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                 hipLaunchKernelGGL(count_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                    dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p);
             }
-        WsView<uint64_t> dWide(ctx, "pf.dWide");
-            SD_HIP(ctx, dWide.alloc(nPos + 1));
-            hipLaunchKernelGGL(widen_kernel, dim3(gridFor(nPos + 1, 256)), dim3(256), 0, ctx->stream, nPos + 1, dKmerCount.p, dWide.p);
-            int rc = exclusiveScan(ctx, dWide.p, dKmerBase.p, nPos + 1, scanTmp);
+            int rc = exclusiveScanWiden(ctx, dKmerCount.p, dKmerBase.p, nPos + 1, scanTmp);
             if (rc != SD_OK) return rc;
             SD_HIP(ctx, hipMemcpyAsync(&nKmers, dKmerBase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -694,10 +718,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                                    dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
                                    dKmerBase.p, dKStart.p, dKLen.p, dKPos.p);
             }
-        WsView<uint64_t> dWide(ctx, "pf.dWide");
-            SD_HIP(ctx, dWide.alloc(nKmers + 1));
-            hipLaunchKernelGGL(widen_kernel, dim3(gridFor(nKmers + 1, 256)), dim3(256), 0, ctx->stream, nKmers + 1, dKLen.p, dWide.p);
-            int rc = exclusiveScan(ctx, dWide.p, dHitBase.p, nKmers + 1, scanTmp);
+            int rc = exclusiveScanWiden(ctx, dKLen.p, dHitBase.p, nKmers + 1, scanTmp);
             if (rc != SD_OK) return rc;
             SD_HIP(ctx, hipMemcpyAsync(&nHits, dHitBase.p + nKmers, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -729,6 +750,8 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         WsView<uint32_t> dValA(ctx, "pf.dValA");
         WsView<uint32_t> dValB(ctx, "pf.dValB");
         WsView<uint16_t> dDiag(ctx, "pf.dDiag");
+        WsView<uint64_t> dQHitBase(ctx, "pf.dQHitBase");
+        SD_HIP(ctx, dQHitBase.alloc(bq + 1));
         WsView<uint8_t> dEmit(ctx, "pf.dEmit");
         WsView<uint64_t> dEmitPos(ctx, "pf.dEmitPos");
         WsView<uint64_t> dEmit64(ctx, "pf.dEmit64");
@@ -747,34 +770,34 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             SD_HIP(ctx, dValA.alloc(nHits));
             SD_HIP(ctx, dValB.alloc(nHits));
             SD_HIP(ctx, dDiag.alloc(nHits));
+            hipLaunchKernelGGL(query_hit_base_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p,
+                               dKmerBase.p, dHitBase.p, dQHitBase.p);
             {
                 ProfScope ps(ctx, "prefilter_gather_hits");
                 hipLaunchKernelGGL(gather_hits_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKStart.p,
-                                   dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, T->dEntrySeq, T->dEntryPos, tBits, dKeyA.p,
-                                   dValA.p, dDiag.p);
+                                   dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, T->dEntrySeq, T->dEntryPos, tBits, dQHitBase.p,
+                                   dKeyA.p, dValA.p, dDiag.p);
             }
             {
                 ProfScope ps(ctx, "prefilter_sort_hits");
+                // Hits arrive grouped by query in emission order.  A stable sort on the target bits alone makes every
+                // (target, query) group contiguous with its emission order intact, which is all match_diag needs; the
+                // few surviving candidates are put back into (query, target) order below.  19 target bits = 3 radix
+                // passes instead of the 4 that (query, target) would take.
                 size_t bytes = 0;
-                int endBit = tBits;
-                uint32_t qb = bq - 1;
-                while (qb) { endBit++; qb >>= 1; }
-                endBit = std::min(32, endBit + 0);
-                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, (int) nHits, 0, endBit, ctx->stream));
+                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, (int) nHits, 0, tBits, ctx->stream));
                 if (sortTmp.n < bytes) SD_HIP(ctx, sortTmp.alloc(bytes + 256));
-                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sortTmp.p, bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, (int) nHits, 0, endBit, ctx->stream));
+                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sortTmp.p, bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, (int) nHits, 0, tBits, ctx->stream));
             }
-            SD_HIP(ctx, dEmit.alloc(nHits));
-            SD_HIP(ctx, dEmit64.alloc(nHits + 1));
+            SD_HIP(ctx, dEmit.alloc(nHits + 1));
             SD_HIP(ctx, dEmitPos.alloc(nHits + 1));
             {
                 ProfScope ps(ctx, "prefilter_match_diag");
                 hipLaunchKernelGGL(match_diag_kernel, dim3(gridFor(nHits, 256)), dim3(256), 0, ctx->stream, nHits, dKeyB.p, dValB.p,
-                                   dDiag.p, dEmit.p);
+                                   dEmit.p);
             }
-            SD_HIP(ctx, hipMemsetAsync(dEmit64.p + nHits, 0, sizeof(uint64_t), ctx->stream));
-            hipLaunchKernelGGL(flag_to_u64_kernel, dim3(gridFor(nHits, 256)), dim3(256), 0, ctx->stream, nHits, dEmit.p, dEmit64.p);
-            int rc = exclusiveScan(ctx, dEmit64.p, dEmitPos.p, nHits + 1, scanTmp);
+            SD_HIP(ctx, hipMemsetAsync(dEmit.p + nHits, 0, 1, ctx->stream));
+            int rc = exclusiveScanWiden(ctx, dEmit.p, dEmitPos.p, nHits + 1, scanTmp);
             if (rc != SD_OK) return rc;
             uint64_t nc64 = 0;
             SD_HIP(ctx, hipMemcpyAsync(&nc64, dEmitPos.p + nHits, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -787,12 +810,27 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             SD_HIP(ctx, dCVal.alloc(nCand));
             SD_HIP(ctx, dCScore.alloc(nCand));
             SD_HIP(ctx, dCLen.alloc(nCand));
-            hipLaunchKernelGGL(compact_kernel, dim3(gridFor(nHits, 256)), dim3(256), 0, ctx->stream, nHits, dEmit.p, dEmitPos.p,
-                               dKeyB.p, dValB.p, (const int32_t *) nullptr, dCKey.p, dCVal.p, (int32_t *) nullptr);
+            {
+                // compact into scratch, then a stable sort on the query bits restores (query, target, emission) order
+                WsView<uint32_t> dCKey0(ctx, "pf.dCKey0");
+                WsView<uint32_t> dCVal0(ctx, "pf.dCVal0");
+                SD_HIP(ctx, dCKey0.alloc(nCand));
+                SD_HIP(ctx, dCVal0.alloc(nCand));
+                hipLaunchKernelGGL(compact_kernel, dim3(gridFor(nHits, 256)), dim3(256), 0, ctx->stream, nHits, dEmit.p, dEmitPos.p,
+                                   dKeyB.p, dValB.p, (const int32_t *) nullptr, dCKey0.p, dCVal0.p, (int32_t *) nullptr);
+                int endBit = tBits;
+                uint32_t qb = bq - 1;
+                while (qb) { endBit++; qb >>= 1; }
+                endBit = std::min(32, std::max(endBit, tBits + 1));
+                size_t bytes = 0;
+                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dCKey0.p, dCKey.p, dCVal0.p, dCVal.p, (int) nCand, tBits, endBit, ctx->stream));
+                if (sortTmp.n < bytes) SD_HIP(ctx, sortTmp.alloc(bytes + 256));
+                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sortTmp.p, bytes, dCKey0.p, dCKey.p, dCVal0.p, dCVal.p, (int) nCand, tBits, endBit, ctx->stream));
+            }
             {
                 ProfScope ps(ctx, "prefilter_score_diag");
                 hipLaunchKernelGGL(score_diag_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p,
-                                   dDiag.p, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p);
+                                   dDiag.p, dQHitBase.p, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p);
             }
             hipLaunchKernelGGL(cand_stats_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCLen.p, tBits,
                                (unsigned long long *) dStats.p);
@@ -835,7 +873,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         {
             ProfScope ps(ctx, "prefilter_select_hits");
             hipLaunchKernelGGL(select_hits_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
-                               dDiag.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
+                               dDiag.p, dQHitBase.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
                                par->covMode, par->covThr, dOut.p, dOutCount.p, dErr.p);
         }
         SD_HIP(ctx, hipGetLastError());

@@ -54,15 +54,24 @@ int sd_host_comp_bias(sd_host *h, const uint8_t *residues, const uint64_t *offse
                       int8_t *swBias, int8_t *diagBias, int16_t *kmerBias) {
     uint8_t seedPos[8];
     const int span = sd::spacedPattern(kmerSize, seedPos);
-#pragma omp parallel for schedule(dynamic, 64) num_threads(h->threads)
-    for (uint32_t i = 0; i < n; i++) {
-        const uint8_t *s = residues + offsets[i];
-        const int L = (int) (offsets[i + 1] - offsets[i]);
-        if (swBias) sd::swCompBias8(h->blosum2, s, L, swBias + offsets[i]);
-        if (diagBias) sd::diagCompBias8(h->seed8, s, L, diagBias + offsets[i]);
-        if (kmerBias) {
-            for (int x = 0; x < L; x++) kmerBias[offsets[i] + x] = 0;
-            sd::kmerThrBias16(h->seed8, s, L, seedPos, kmerSize, span, kmerBias + offsets[i]);
+#pragma omp parallel num_threads(h->threads)
+    {
+        std::vector<float> cbSeed;
+#pragma omp for schedule(dynamic, 64)
+        for (uint32_t i = 0; i < n; i++) {
+            const uint8_t *s = residues + offsets[i];
+            const int L = (int) (offsets[i + 1] - offsets[i]);
+            if (swBias) sd::swCompBias8(h->blosum2, s, L, swBias + offsets[i]);
+            if (diagBias || kmerBias) {
+                // one local correction with the seed matrix serves both roundings
+                cbSeed.resize(L > 0 ? L : 1);
+                sd::calcLocalAaBiasCorrection(h->seed8, s, L, cbSeed.data(), 1.0f);
+                if (diagBias) sd::diagCompBias8From(cbSeed.data(), L, diagBias + offsets[i]);
+                if (kmerBias) {
+                    for (int x = 0; x < L; x++) kmerBias[offsets[i] + x] = 0;
+                    sd::kmerThrBias16From(cbSeed.data(), L, seedPos, kmerSize, span, kmerBias + offsets[i]);
+                }
+            }
         }
     }
     return SD_OK;

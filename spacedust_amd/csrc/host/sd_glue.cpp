@@ -68,7 +68,9 @@ struct sd_agg {
     float seqIdThr = 0.0f;
     bool filterSelfMatch = true;
     // after besthitbyset + combinehits filter: per worker thread, any order until finish()
+    struct HitKey { uint32_t cell, q, idx; };           // cell = qSet * nTSets + tSet
     std::vector<std::vector<BestHit> > tBest;
+    std::vector<std::vector<HitKey> > tKey;
     std::vector<std::string> tCigar;
     std::vector<const BestHit *> best;   // finish(): (qSet, tSet, q) order
     uint64_t nAligned = 0, nAccepted = 0;
@@ -126,6 +128,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
     if ((int) a->tBest.size() < T) {
         a->tBest.resize(T);
         a->tCigar.resize(T);
+        a->tKey.resize(T);
     }
     const double t1 = omp_get_wtime();
     struct Cand {
@@ -142,8 +145,10 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
         // thread-private containers (the shared vectors' headers sit on common cache lines), swapped back at the end
         std::vector<BestHit> myBest;
         std::string myCigar;
+        std::vector<sd_agg::HitKey> myKey;
         myBest.swap(a->tBest[th]);
         myCigar.swap(a->tCigar[th]);
+        myKey.swap(a->tKey[th]);
         // best candidate per target set: Alignment sorts a query's accepted hits with Matcher::compareHits
         // (Matcher.h:157-168) and besthitbyset keeps, per set, the first one whose %.3E text E-value is strictly
         // smaller than what it has (besthitbyset.cpp:88-101).  Rounding to text is monotone, so that is the
@@ -229,11 +234,15 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                     sd::compressBacktraceAppend(btPool + r.btOffset, (size_t) r.btLen, myCigar);
                     b.cigarLen = (uint32_t) (myCigar.size() - b.cigarOff);
                 }
+                sd_agg::HitKey hk;
+                hk.cell = qs * a->nTSets + ts; hk.q = q; hk.idx = (uint32_t) myBest.size();
+                myKey.push_back(hk);
                 myBest.push_back(b);
             }
         }
         myBest.swap(a->tBest[th]);
         myCigar.swap(a->tCigar[th]);
+        myKey.swap(a->tKey[th]);
     }
     a->nAligned += nPairs;
     a->nAccepted += accepted;
@@ -246,27 +255,34 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
 int sd_agg_finish(sd_agg *a, uint64_t *nEntries, uint64_t *nHits) {
     size_t total = 0;
     for (size_t t = 0; t < a->tBest.size(); t++) total += a->tBest[t].size();
-    a->best.resize(total);
+    a->best.assign(total, (const BestHit *) NULL);
+    // counting sort into (qSet, tSet) entries, then the few hundred hits of an entry by query key; (qSet, tSet, q)
+    // is unique per hit, so the order does not depend on how the hits were spread over threads
+    const size_t nCells = (size_t) a->nQSets * a->nTSets;
+    std::vector<uint64_t> cellStart(nCells + 1, 0);
+    for (size_t t = 0; t < a->tKey.size(); t++)
+        for (const sd_agg::HitKey &k : a->tKey[t]) cellStart[(size_t) k.cell + 1]++;
+    for (size_t c = 0; c < nCells; c++) cellStart[c + 1] += cellStart[c];
+    std::vector<std::pair<uint32_t, const BestHit *> > byCell(total);   // (query key, hit)
     {
-        size_t pos = 0;
-        for (size_t t = 0; t < a->tBest.size(); t++)
-            for (size_t x = 0; x < a->tBest[t].size(); x++) a->best[pos++] = &a->tBest[t][x];
+        std::vector<uint64_t> cursor(cellStart.begin(), cellStart.end() - 1);
+        for (size_t t = 0; t < a->tKey.size(); t++)
+            for (const sd_agg::HitKey &k : a->tKey[t]) byCell[cursor[k.cell]++] = std::make_pair(k.q, &a->tBest[t][k.idx]);
     }
-    // (qSet, tSet, q) is unique per hit, so the order does not depend on how the hits were spread over threads
-    __gnu_parallel::sort(a->best.begin(), a->best.end(), [](const BestHit *x, const BestHit *y) {
-        if (x->qSet != y->qSet) return x->qSet < y->qSet;
-        if (x->tSet != y->tSet) return x->tSet < y->tSet;
-        return x->q < y->q;
-    });
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t c = 0; c < nCells; c++) {
+        std::sort(byCell.begin() + cellStart[c], byCell.begin() + cellStart[c + 1],
+                  [](const std::pair<uint32_t, const BestHit *> &x, const std::pair<uint32_t, const BestHit *> &y) { return x.first < y.first; });
+        for (uint64_t x = cellStart[c]; x < cellStart[c + 1]; x++) a->best[x] = byCell[x].second;
+    }
     a->entryOff.clear();
     a->entryQSet.clear();
     a->entryTSet.clear();
-    for (size_t i = 0; i < a->best.size(); i++) {
-        if (i == 0 || a->best[i]->qSet != a->best[i - 1]->qSet || a->best[i]->tSet != a->best[i - 1]->tSet) {
-            a->entryOff.push_back(i);
-            a->entryQSet.push_back(a->best[i]->qSet);
-            a->entryTSet.push_back(a->best[i]->tSet);
-        }
+    for (size_t c = 0; c < nCells; c++) {
+        if (cellStart[c + 1] == cellStart[c]) continue;
+        a->entryOff.push_back(cellStart[c]);
+        a->entryQSet.push_back((uint32_t) (c / a->nTSets));
+        a->entryTSet.push_back((uint32_t) (c % a->nTSets));
     }
     a->entryOff.push_back(a->best.size());
     if (nEntries) *nEntries = a->entryQSet.size();

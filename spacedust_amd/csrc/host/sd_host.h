@@ -41,7 +41,9 @@ void calcLocalAaBiasCorrection(const SubMat &m, const uint8_t *seq, int N, float
 void swCompBias8(const SubMat &blosum2, const uint8_t *seq, int N, int8_t *out);              // StripedSmithWaterman.cpp:1231-1235
 void diagCompBias8(const SubMat &seed8, const uint8_t *seq, int N, int8_t *out);              // UngappedAlignment.cpp:392-396
 void kmerThrBias16(const SubMat &seed8, const uint8_t *seq, int N, const uint8_t *seedPos, int k,
-                   int span, int16_t *out /* N-span+1 */);                                    // QueryMatcher.cpp:230-240
+                   int span, int16_t *out /* N-span+1 */);
+void diagCompBias8From(const float *cb, int N, int8_t *out);
+void kmerThrBias16From(const float *cb, int N, const uint8_t *seedPos, int k, int span, int16_t *out);                                    // QueryMatcher.cpp:230-240
 
 // ---------------------------------------------------------------------------
 // Extended (2-mer / 3-mer) substitution tables (M/src/prefiltering/ExtendedSubstitutionMatrix.cpp:20-69)

@@ -120,6 +120,10 @@ void swCompBias8(const SubMat &blosum2, const uint8_t *seq, int N, int8_t *out) 
 void diagCompBias8(const SubMat &seed8, const uint8_t *seq, int N, int8_t *out) {
     std::vector<float> cb(N > 0 ? N : 1);
     calcLocalAaBiasCorrection(seed8, seq, N, cb.data(), 1.0f);
+    diagCompBias8From(cb.data(), N, out);
+}
+
+void diagCompBias8From(const float *cb, int N, int8_t *out) {
     for (int i = 0; i < N; i++) {
         float a = cb[i];
         // float aaCorrBias = (a < 0.0) ? a/4 - 0.5 : a/4 + 0.5;  (double expression stored to float)
@@ -132,6 +136,10 @@ void kmerThrBias16(const SubMat &seed8, const uint8_t *seq, int N, const uint8_t
                    int16_t *out) {
     std::vector<float> cb(N > 0 ? N : 1);
     calcLocalAaBiasCorrection(seed8, seq, N, cb.data(), 1.0f);
+    kmerThrBias16From(cb.data(), N, seedPos, k, span, out);
+}
+
+void kmerThrBias16From(const float *cb, int N, const uint8_t *seedPos, int k, int span, int16_t *out) {
     for (int i = 0; i + span <= N; i++) {
         float b = 0;
         for (int p = 0; p < k; p++) b += cb[i + seedPos[p]];
