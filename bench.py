@@ -21,7 +21,9 @@ import time
 
 import numpy as np
 
-os.environ.setdefault('OMP_NUM_THREADS', str(max(1, min(64, (os.cpu_count() or 2) // 2))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from spacedust_amd.cpus import configure_openmp, effective_cpus  # noqa: E402
+configure_openmp()
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -85,7 +87,7 @@ def main():
 
     P, B = args.proteomes, args.batch
     # host stages: a bounded share of the cores (never saturate the box)
-    n_threads = max(1, min(64, (os.cpu_count() or 1) // 2) // max(1, world))
+    n_threads = max(1, effective_cpus() // max(1, world))
     host = Host(n_threads)
     gpu = Context(local_rank if world > 1 else 0)
     t0 = time.time()
@@ -221,6 +223,7 @@ def main():
         'setup_s': {'generate': t_gen, 'index_build_host': cs.timing['index_build_s'], 'upload': cs.timing['upload_s']},
         'device': gpu.device_name(),
         'host_cores': os.cpu_count(),
+        'host_cpu_quota': effective_cpus(),
     }
     if not args.no_cpu:
         import tempfile
@@ -230,7 +233,7 @@ def main():
                      nq=cs.last_entries[5])
         del cs, gpu
         res['cpu_baseline'] = cpu_baseline_subprocess(args, max_seqs, kmer_thr_used, bin_size_used, ent, args.cpu_seconds,
-                                                      args.cpu_threads or max(1, min(32, (os.cpu_count() or 4) // 4)))
+                                                      args.cpu_threads or effective_cpus())
     print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

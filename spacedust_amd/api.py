@@ -6,6 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from .cpus import effective_cpus
 from ._lib import SdError, ptr
 
 
@@ -23,7 +24,7 @@ class Host:
     def __init__(self, threads=0):
         import os
         self.L = _lib.load()
-        self.threads = threads or (os.cpu_count() or 1)
+        self.threads = threads or effective_cpus()
         h = C.c_void_p()
         _check(None, self.L.sd_host_create(self.threads, C.byref(h)), 'sd_host_create')
         self.h = h

@@ -16,6 +16,7 @@
 // is the K*(4+4+1) input bytes plus K*4 output bytes per pair (algorithmic), the scratch stays in L2.
 // The double-precision P-values of the emitted clusters (exp/pow/log) are evaluated on the host with the
 // reference's own expressions (sd_clusterhits_batch below) so their text form matches digit for digit.
+#include <memory>
 #include "sd_common.h"
 
 #include <algorithm>
@@ -318,6 +319,7 @@ extern "C" int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32
     (void) hipSetDevice(ctx->device);
     const uint64_t total = hitOff[nPairs];
     if (total == 0 || nPairs == 0) return SD_OK;
+    std::unique_ptr<HostScope> hs(new HostScope(ctx, "ch.setup"));
     std::vector<ChPair> hp(nPairs);
     uint32_t maxK = 0;
     for (uint32_t p = 0; p < nPairs; p++) {
@@ -331,6 +333,7 @@ extern "C" int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32
     for (uint64_t x = 0; x < total; x++) maxPos = std::max(maxPos, std::max(qPos[x], tPos[x]));
     if ((uint64_t) maxPos + 3 > lGammaLen || (uint64_t) maxK + 2 > lGammaLen || par->maxGeneGap + 3 > lGammaLen)
         return sdFail(ctx, SD_EINVAL, "logGamma table too short: %u entries, need %llu", lGammaLen, (unsigned long long) std::max<uint64_t>(maxPos + 3, maxK + 2));
+    hs.reset(new HostScope(ctx, "ch.device"));
     struct { ChPair *p; } dPairs;
     struct { uint32_t *p; } dQ, dT, dScratchU, dNode, dMerges;
     struct { uint8_t *p; } dS;
@@ -344,22 +347,50 @@ extern "C" int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32
     SD_HIP(ctx, wsGet(ctx, "ch.scratchD", total, &dScratchD.p));
     SD_HIP(ctx, wsGet(ctx, "ch.node", total, &dNode.p));
     SD_HIP(ctx, wsGet(ctx, "ch.merges", nPairs, &dMerges.p));
-    SD_HIP(ctx, hipMemcpyAsync(dPairs.p, hp.data(), nPairs * sizeof(ChPair), hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(dQ.p, qPos, total * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(dT.p, tPos, total * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(dS.p, strands, total, hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(dLg.p, lGamma, lGammaLen * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(ctx, hipMemsetAsync(dNode.p, 0xFF, total * sizeof(uint32_t), ctx->stream));
+    hs.reset(new HostScope(ctx, "ch.h2d"));
     {
-        ProfScope ps(ctx, "clusterhits");
-        hipLaunchKernelGGL(clusterhits_kernel, dim3(nPairs), dim3(256), 0, ctx->stream, dPairs.p, nPairs, dQ.p, dT.p, dS.p, dLg.p,
-                           log(0.001), log(2.0), par->maxGeneGap, dScratchU.p, dScratchD.p, dNode.p, dMerges.p);
+        // one pinned staging block for all inputs (pageable sources make every copy a slow synchronous path)
+        const size_t bPairs = nPairs * sizeof(ChPair), bPos = total * sizeof(uint32_t), bLg = lGammaLen * sizeof(double);
+        auto up = [](size_t v) { return (v + 255) & ~(size_t) 255; };
+        const size_t oQ = up(bPairs), oT = oQ + up(bPos), oS = oT + up(bPos), oL = oS + up(total), all = oL + up(bLg);
+        uint8_t *stage = nullptr;
+        SD_HIP(ctx, pinGet(ctx, "ch.stage", all, &stage));
+        memcpy(stage, hp.data(), bPairs);
+        memcpy(stage + oQ, qPos, bPos);
+        memcpy(stage + oT, tPos, bPos);
+        memcpy(stage + oS, strands, total);
+        memcpy(stage + oL, lGamma, bLg);
+        SD_HIP(ctx, hipMemcpyAsync(dPairs.p, stage, bPairs, hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(dQ.p, stage + oQ, bPos, hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(dT.p, stage + oT, bPos, hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(dS.p, stage + oS, total, hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(dLg.p, stage + oL, bLg, hipMemcpyHostToDevice, ctx->stream));
     }
-    SD_HIP(ctx, hipGetLastError());
+    SD_HIP(ctx, hipMemsetAsync(dNode.p, 0xFF, total * sizeof(uint32_t), ctx->stream));
+    hs.reset(new HostScope(ctx, "ch.kernel"));
+    {
+        const bool dbg = getenv("SD_DEBUG_TIMING") != nullptr;
+        auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double a0 = now();
+        if (dbg) (void) hipStreamSynchronize(ctx->stream);
+        const double a1 = now();
+        {
+            ProfScope ps(ctx, "clusterhits");
+            hipLaunchKernelGGL(clusterhits_kernel, dim3(nPairs), dim3(256), 0, ctx->stream, dPairs.p, nPairs, dQ.p, dT.p, dS.p, dLg.p,
+                               log(0.001), log(2.0), par->maxGeneGap, dScratchU.p, dScratchD.p, dNode.p, dMerges.p);
+            if (dbg) fprintf(stderr, "[clusterhits] sync-before %.1f ms, launch call %.1f ms\n", a1 - a0, now() - a1);
+        }
+        const double a2 = now();
+        SD_HIP(ctx, hipGetLastError());
+        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (dbg) fprintf(stderr, "[clusterhits] profscope %.1f ms, sync-after %.1f ms\n", a2 - a1, now() - a2);
+    }
+    hs.reset(new HostScope(ctx, "ch.d2h"));
     uint32_t *node = nullptr;
     SD_HIP(ctx, pinGet(ctx, "ch.hnode", total, &node));
     SD_HIP(ctx, hipMemcpyAsync(node, dNode.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hs.reset(new HostScope(ctx, "ch.finalise"));
     // ---- emission (:456-485): nodes in index order, size >= cls, pCO / pMH thresholds
 #pragma omp parallel
     {

@@ -1,5 +1,8 @@
 // C-ABI wrappers of the host-side stages (sd_host_* in include/spacedust_gpu.h).
 #include "sd_host.h"
+#include <omp.h>
+#include <cstdio>
+#include <cstdlib>
 #include "spacedust_gpu.h"
 
 #include <cmath>
@@ -54,6 +57,7 @@ int sd_host_comp_bias(sd_host *h, const uint8_t *residues, const uint64_t *offse
                       int8_t *swBias, int8_t *diagBias, int16_t *kmerBias) {
     uint8_t seedPos[8];
     const int span = sd::spacedPattern(kmerSize, seedPos);
+    const double tDbg = omp_get_wtime();
 #pragma omp parallel num_threads(h->threads)
     {
         std::vector<float> cbSeed;
@@ -74,6 +78,7 @@ int sd_host_comp_bias(sd_host *h, const uint8_t *residues, const uint64_t *offse
             }
         }
     }
+    if (getenv("SD_DEBUG_TIMING")) fprintf(stderr, "[sd_host_comp_bias] %u seqs, %d threads: %.1f ms\n", n, h->threads, (omp_get_wtime() - tDbg) * 1e3);
     return SD_OK;
 }
 
