@@ -208,7 +208,9 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
                     const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
                     int go, int ge, int ldsStride /* ints per array */, int8_t *__restrict__ dirs, char *__restrict__ bt,
                     int32_t *__restrict__ res /* per task: btLen (-2 = band too small, -1 = traceback error), identical */,
-                    const uint32_t *__restrict__ order /* nullable */) {
+                    const uint32_t *__restrict__ order /* nullable */,
+                    int maxWidthLoop /* 0: one attempt; else keep doubling the band inside the kernel while
+                                        2*band+3 <= maxWidthLoop (scratch must be sized for that width) */) {
     extern __shared__ int32_t lds[];
     __shared__ int8_t smat[441];
     for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
@@ -220,18 +222,22 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
     TbTask tk;
     if (have) tk = tasks[id];
     else { tk.qLen = 0; tk.tLen = 0; tk.band = 1; tk.score = 0; tk.maxv = 0; tk.qAbs = 0; tk.tAbs = 0; tk.slot = 0; tk.dirOff = 0; tk.btOff = 0; }
-    const int band = tk.band, qLen = tk.qLen, tLen = tk.tLen;
-    const int width = band * 2 + 3, width_d = band * 2 + 1;
+    const int qLen = tk.qLen, tLen = tk.tLen;
+    int band = tk.band;
     int32_t *h_b = lds + (size_t) grp * 3 * ldsStride;
     int32_t *e_b = h_b + ldsStride;
     int32_t *h_c = e_b + ldsStride;
-    for (int x = l; x <= width && x < ldsStride; x += 32) { h_b[x] = 0; e_b[x] = 0; h_c[x] = 0; }
-    __builtin_amdgcn_wave_barrier();
     const uint8_t *q = qRes + tk.qAbs;
     const int8_t *cb = qBias + tk.qAbs;
     const uint8_t *t = tRes + tk.tAbs;
     int8_t *direction = dirs + tk.dirOff;
     int maxv = tk.maxv;
+    int width, width_d;
+  for (;;) {
+    width = band * 2 + 3;
+    width_d = band * 2 + 1;
+    for (int x = l; x <= width && x < ldsStride; x += 32) { h_b[x] = 0; e_b[x] = 0; h_c[x] = 0; }
+    __builtin_amdgcn_wave_barrier();
     for (int i = 0; i < qLen; i++) {
         int beg = 0, end = tLen - 1;
         int jj = i - band; beg = beg > jj ? beg : jj;
@@ -308,16 +314,26 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
         int o = __shfl_xor(maxv, off, 32);
         maxv = o > maxv ? o : maxv;
     }
-    if (!have || l != 0) return;
-    tasks[id].maxv = maxv;
-    if (maxv < tk.score) {
-        res[2 * id] = -2;
+    if (maxv >= tk.score) break;
+    band *= 2;   // the reference's do/while doubles the band (:1492-1493)
+    if (band * 2 + 3 > maxWidthLoop) {
+        if (have && l == 0) {
+            tasks[id].maxv = maxv;
+            tasks[id].band = band;
+            res[2 * id] = -2;
+        }
         return;
     }
+  }
+    if (!have || l != 0) return;
+    tasks[id].maxv = maxv;
+    tasks[id].band = band;
     // traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581)
     __threadfence();
+    // the path is walked from its end, so the characters are written from the end of the task's region backwards:
+    // the finished backtrace is the last `len` bytes of [btOff, btOff + qLen + tLen + 2)
     int i = qLen - 1, j = tLen - 1, state = 2;
-    char *o = bt + tk.btOff;
+    char *o = bt + tk.btOff + (qLen + tLen + 2);
     int len = 0, ids = 0;
     bool bad = false;
     while (i > 0 || j > 0) {
@@ -333,11 +349,11 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
         else if (state == 1) dcode = dF;
         else dcode = (code & 4) ? dE : ((code & 8) ? dF : 1);
         switch (dcode) {
-            case 1: ids += (q[i] == t[j]); --i; --j; state = 2; o[len++] = 'M'; break;
-            case 2: --i; state = 0; o[len++] = 'I'; break;
-            case 3: --i; state = 2; o[len++] = 'I'; break;
-            case 4: --j; state = 1; o[len++] = 'D'; break;
-            default: --j; state = 2; o[len++] = 'D'; break;
+            case 1: ids += (q[i] == t[j]); --i; --j; state = 2; *--o = 'M'; len++; break;
+            case 2: --i; state = 0; *--o = 'I'; len++; break;
+            case 3: --i; state = 2; *--o = 'I'; len++; break;
+            case 4: --j; state = 1; *--o = 'D'; len++; break;
+            default: --j; state = 2; *--o = 'D'; len++; break;
         }
     }
     if (bad || i != 0 || j != 0) {
@@ -345,12 +361,195 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
         return;
     }
     ids += (q[0] == t[0]);
-    o[len++] = 'M';
-    for (int a = 0, z = len - 1; a < z; a++, z--) {
-        char tmp = o[a];
-        o[a] = o[z];
-        o[z] = tmp;
+    *--o = 'M';
+    len++;
+    res[2 * id] = len;
+    res[2 * id + 1] = ids;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Narrow bands (2*band+3 <= 32, i.e. almost every alignment): the same banded_sw arithmetic with the three band
+// arrays held in registers -- lane p of a 32-lane half wavefront owns array index p -- so a row costs a few DPP
+// moves instead of LDS round trips: h_b[e], e_b[e] and h_b[d] are the lane itself or a neighbour depending on
+// whether the band window moved (xi != xim), the horizontal-gap prefix maximum is a DPP scan, and the band is
+// doubled inside the kernel while it still fits.  The query slice, its bias, the target slice and the 4-bit
+// direction codes (16 bytes per row) live in LDS; lane 0 walks the path out of LDS.
+// qCap / tCap: LDS capacity per task (rows, columns) of this launch class.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dppI(int oldv, int src, int ctrl, int rowMask) {
+    switch (ctrl) {   // the control word must be a compile-time constant
+        case 0x138: return __builtin_amdgcn_update_dpp(oldv, src, 0x138, 0xf, 0xf, false);   // wave_shr:1
+        case 0x130: return __builtin_amdgcn_update_dpp(oldv, src, 0x130, 0xf, 0xf, false);   // wave_shl:1
+        case 0x111: return __builtin_amdgcn_update_dpp(oldv, src, 0x111, 0xf, 0xf, false);   // row_shr:1
+        case 0x112: return __builtin_amdgcn_update_dpp(oldv, src, 0x112, 0xf, 0xf, false);
+        case 0x114: return __builtin_amdgcn_update_dpp(oldv, src, 0x114, 0xf, 0xf, false);
+        case 0x118: return __builtin_amdgcn_update_dpp(oldv, src, 0x118, 0xf, 0xf, false);
+        default: return __builtin_amdgcn_update_dpp(oldv, src, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
     }
+    (void) rowMask;
+}
+
+__global__ void __launch_bounds__(64)
+sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
+                           const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
+                           int go, int ge, int qCap, int tCap, char *__restrict__ bt, int32_t *__restrict__ res,
+                           const uint32_t *__restrict__ order) {
+    extern __shared__ uint8_t ldsRaw[];
+    __shared__ int8_t smat[441];
+    for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
+    const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const uint32_t lid = blockIdx.x * 2 + grp;
+    const bool have = lid < nTasks;
+    const uint32_t id = have ? (order ? order[lid] : lid) : 0;
+    TbTask tk;
+    if (have) tk = tasks[id];
+    else { tk.qLen = 0; tk.tLen = 0; tk.band = 1; tk.score = 0; tk.maxv = 0; tk.qAbs = 0; tk.tAbs = 0; tk.slot = 0; tk.dirOff = 0; tk.btOff = 0; }
+    const int qLen = tk.qLen, tLen = tk.tLen;
+    const size_t perTask = (size_t) 16 * qCap + 2 * (size_t) qCap + tCap;
+    uint8_t *dirs = ldsRaw + grp * perTask;           // 16 bytes (32 nibbles) per row
+    uint8_t *sq = dirs + (size_t) 16 * qCap;          // query residues
+    int8_t *scb = (int8_t *) (sq + qCap);             // query bias
+    uint8_t *st = (uint8_t *) (scb + qCap);           // target residues
+    for (int x = l; x < qLen; x += 32) {
+        sq[x] = qRes[tk.qAbs + x];
+        scb[x] = qBias[tk.qAbs + x];
+    }
+    for (int x = l; x < tLen; x += 32) st[x] = tRes[tk.tAbs + x];
+    __syncthreads();
+
+    const int NEG = -(1 << 28);
+    int band = tk.band, maxv = tk.maxv;
+    bool reached = false;
+    // both half wavefronts run the same number of attempts / rows (uniform control flow for the DPP moves)
+    for (;;) {
+        const int width = band * 2 + 3;
+        const bool fits = width <= 32;
+        int hb = 0, eb = 0;
+        const int rows = (fits && !reached) ? qLen : 0;
+        const int rowsOther = __shfl_xor(rows, 32, 64);
+        const int nRows = max(rows, rowsOther);
+        // substitution score of this lane's cell, fetched one row ahead (two dependent LDS reads off the critical path)
+        auto cellScore = [&](int row) -> int {
+            if (rows == 0) return 0;
+            const int r = row < qLen ? row : qLen - 1;
+            const int x0 = (r - band) > 0 ? (r - band) : 0;
+            int jn = x0 + l - 1;
+            jn = jn < 0 ? 0 : (jn >= tLen ? tLen - 1 : jn);
+            return (int) smat[21 * sq[r] + st[jn]] + (int) scb[r];
+        };
+        int sNext = cellScore(0);
+        for (int i = 0; i < nRows; i++) {
+            const bool live = i < rows;
+            const int sCur = sNext;
+            sNext = cellScore(i + 1);
+            const int xi = (i - band) > 0 ? (i - band) : 0;
+            const int delta = (i - band) >= 1 ? 1 : 0;     // xi - xim
+            int end = tLen - 1;
+            end = end < i + band ? end : i + band;
+            const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+            const int W = end - xi + 1;
+            if (live && (l == 0 || l == edge)) { hb = 0; eb = 0; }
+            // previous-row values at index e = u + delta and d = e - 1
+            const int hbUp = dppI(0, hb, 0x130, 0xf), ebUp = dppI(0, eb, 0x130, 0xf), hbDn = dppI(0, hb, 0x138, 0xf);
+            const int hE = delta ? hbUp : hb, eE = delta ? ebUp : eb, hD = delta ? hb : hbDn;
+            const int u = l;
+            const bool valid = live && u >= 1 && u <= W;
+            int T = 0, S = NEG, eNew = 0, e1 = 0, diag = 0;
+            bool dirE = false;
+            if (valid) {
+                const int t1 = i == 0 ? -go : hE - go;
+                const int t2 = i == 0 ? -ge : eE - ge;
+                eNew = t1 > t2 ? t1 : t2;
+                dirE = t1 > t2;
+                e1 = eNew > 0 ? eNew : 0;
+                diag = hD + sCur;
+                T = e1 > diag ? e1 : diag;
+                S = T - go + ge * u;
+            }
+            // inclusive prefix maximum of S over the 32 lanes of the half wavefront
+            int incl = S, o;
+            o = dppI(NEG, incl, 0x111, 0xf); incl = incl > o ? incl : o;
+            o = dppI(NEG, incl, 0x112, 0xf); incl = incl > o ? incl : o;
+            o = dppI(NEG, incl, 0x114, 0xf); incl = incl > o ? incl : o;
+            o = dppI(NEG, incl, 0x118, 0xf); incl = incl > o ? incl : o;
+            o = dppI(NEG, incl, 0x142, 0xa); incl = incl > o ? incl : o;
+            int excl = dppI(NEG, incl, 0x138, 0xf);
+            if (l == 0) excl = NEG;
+            const int g = (-ge) > excl ? (-ge) : excl;
+            const int f = g - ge * (u - 1);
+            const int hcv = T > f ? T : f;
+            int hcP = dppI(0, hcv, 0x138, 0xf), fP = dppI(0, f, 0x138, 0xf);
+            if (u <= 1) { hcP = 0; fP = 0; }
+            int code = 0;
+            if (valid) {
+                const bool dirF = (hcP - go) > (fP - ge);
+                const int f1 = f > 0 ? f : 0;
+                const int tmp1 = e1 > f1 ? e1 : f1;
+                code = (dirE ? 1 : 0) | (dirF ? 2 : 0);
+                if (!(tmp1 <= diag)) code |= (e1 > f1) ? 4 : 8;
+                eb = eNew;
+                hb = hcv;
+                maxv = hcv > maxv ? hcv : maxv;
+            }
+            // two cells per byte: cell x = u - 1; odd u carries the low nibble and fetches its right neighbour's
+            const int codeUp = dppI(0, code, 0x130, 0xf);
+            if (valid && (u & 1)) dirs[(size_t) 16 * i + ((u - 1) >> 1)] = (uint8_t) (code | (codeUp << 4));
+        }
+        if (!reached && fits) {
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                const int o2 = __shfl_xor(maxv, off, 32);
+                maxv = o2 > maxv ? o2 : maxv;
+            }
+            if (maxv >= tk.score) reached = true;
+            else band *= 2;
+        }
+        const bool done = reached || band * 2 + 3 > 32 || !have;
+        const bool doneOther = __shfl_xor(done ? 1 : 0, 32, 64) != 0;
+        if (done && doneOther) break;
+    }
+    __syncthreads();
+    if (!have || l != 0) return;
+    tasks[id].maxv = maxv;
+    tasks[id].band = band;
+    if (!reached) {
+        res[2 * id] = -2;
+        return;
+    }
+    // traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581), written backwards
+    const int width_d = band * 2 + 1;
+    int i = qLen - 1, j = tLen - 1, state = 2;
+    char *o = bt + tk.btOff + (qLen + tLen + 2);
+    int len = 0, ids = 0;
+    bool bad = false;
+    while (i > 0 || j > 0) {
+        if (i < 0 || j < 0) { bad = true; break; }
+        int x = i - band;
+        x = x > 0 ? x : 0;
+        x = j - x;
+        if (x < 0 || x >= width_d) { bad = true; break; }
+        const int byte = dirs[(size_t) 16 * i + (x >> 1)];
+        const int code = (x & 1) ? (byte >> 4) : (byte & 15);
+        int dcode;
+        const int dE = (code & 1) ? 3 : 2, dF = (code & 2) ? 5 : 4;
+        if (state == 0) dcode = dE;
+        else if (state == 1) dcode = dF;
+        else dcode = (code & 4) ? dE : ((code & 8) ? dF : 1);
+        switch (dcode) {
+            case 1: ids += (sq[i] == st[j]); --i; --j; state = 2; *--o = 'M'; len++; break;
+            case 2: --i; state = 0; *--o = 'I'; len++; break;
+            case 3: --i; state = 2; *--o = 'I'; len++; break;
+            case 4: --j; state = 1; *--o = 'D'; len++; break;
+            default: --j; state = 2; *--o = 'D'; len++; break;
+        }
+    }
+    if (bad || i != 0 || j != 0) {
+        res[2 * id] = -1;
+        return;
+    }
+    ids += (sq[0] == st[0]);
+    *--o = 'M';
+    len++;
     res[2 * id] = len;
     res[2 * id + 1] = ids;
 }
@@ -659,13 +858,28 @@ k_gate_rev(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ
     keys[i] = scoreKey(tk.n, tk.tL, !usePk ? SCORE_INT32 : (word[i] ? SCORE_PK_WIDE : SCORE_PK));
 }
 
-__device__ __forceinline__ uint32_t tbKey(int band, int qLen) {
+// traceback task classes: 0-2 register-band kernel (LDS capacity 320x640 / 512x1024 / 1024x2048 rows x columns),
+// 3-5 LDS-band kernel by band width (<=127, <=511, <=2047)
+static const int TB_NARROW_Q[3] = {320, 512, 1024}, TB_NARROW_T[3] = {640, 1024, 2048};
+__device__ __forceinline__ bool tbNarrow(int band, int qLen, int tLen) { return band * 2 + 3 <= 32 && qLen <= 1024 && tLen <= 2048; }
+__device__ __forceinline__ uint32_t tbKey(int band, int qLen, int tLen) {
     const int w = band * 2 + 3;
-    const int ci = w <= 127 ? 0 : (w <= 511 ? 1 : 2);
+    int ci;
+    if (tbNarrow(band, qLen, tLen)) ci = (qLen <= 320 && tLen <= 640) ? 0 : ((qLen <= 512 && tLen <= 1024) ? 1 : 2);
+    else ci = w <= 127 ? 3 : (w <= 511 ? 4 : 5);
     const unsigned long long work = (unsigned long long) ((2 * band + 1 + 31) / 32) * (unsigned long long) qLen;
     return (uint32_t) ci * 4096u + (uint32_t) (4095 - (int) min(work >> 3, 4095ull));
 }
-constexpr uint32_t TBKEY_INVALID = 3u * 4096u;
+constexpr uint32_t N_TB_CLASSES = 6;
+constexpr uint32_t TBKEY_INVALID = N_TB_CLASSES * 4096u;
+// global direction scratch (LDS-band kernel only), sized for the widest band of the task's class because the
+// kernel keeps doubling the band inside its class
+__device__ __forceinline__ uint64_t tbDirBytes(int band, int qLen, int tLen) {
+    if (tbNarrow(band, qLen, tLen)) return 0ull;
+    const int w = band * 2 + 3;
+    const int wMax = w <= 127 ? 127 : (w <= 511 ? 511 : 2047);
+    return (uint64_t) (wMax - 2) * (uint64_t) qLen + 16;
+}
 
 // start positions (:475-476), second coverage gate (:483-489) and traceback tasks
 __global__ void __launch_bounds__(256)
@@ -703,8 +917,8 @@ k_gate_tb(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ,
     t.band = abs(t.tLen - t.qLen) + 1;
     t.maxv = 0; t.slot = i; t.intOff = 0; t.dirOff = 0; t.btOff = 0;
     tb[i] = t;
-    keys[i] = tbKey(t.band, t.qLen);
-    dirBytes[i] = (uint64_t) (2 * t.band + 1) * (uint64_t) t.qLen + 16;
+    keys[i] = tbKey(t.band, t.qLen, t.tLen);
+    dirBytes[i] = tbDirBytes(t.band, t.qLen, t.tLen);
     btBytes[i] = (uint64_t) t.qLen + t.tLen + 2;
 }
 
@@ -728,11 +942,10 @@ k_tb_collect(uint32_t nPairs, uint32_t *__restrict__ keys, uint32_t *__restrict_
     if (keys[i] == TBKEY_INVALID) { dirBytes[i] = 0; return; }
     const int len = tbRes[2 * i];
     if (len == -2) {
-        const int band = tb[i].band * 2;
-        tb[i].band = band;
+        const int band = tb[i].band;   // already doubled by the kernel that gave up
         if (band * 2 + 3 > maxBand) { atomicExch(errFlag, 3); keys[i] = TBKEY_INVALID; dirBytes[i] = 0; return; }
-        keys[i] = tbKey(band, tb[i].qLen);
-        dirBytes[i] = (uint64_t) (2 * band + 1) * (uint64_t) tb[i].qLen + 16;
+        keys[i] = tbKey(band, tb[i].qLen, tb[i].tLen);
+        dirBytes[i] = tbDirBytes(band, tb[i].qLen, tb[i].tLen);
     } else if (len < 0) {
         atomicExch(errFlag, 2);
         keys[i] = TBKEY_INVALID;
@@ -756,7 +969,7 @@ k_bt_pack(uint32_t nPairs, const uint64_t *__restrict__ btLen, const uint64_t *_
     if (i >= nPairs) return;
     const uint64_t len = btLen[i];
     if (len == 0) return;
-    const char *src = bt + tb[i].btOff;
+    const char *src = bt + tb[i].btOff + ((uint64_t) (tb[i].qLen + tb[i].tLen + 2) - len);   // written backwards from the end
     char *dst = pool + dense[i];
     for (uint64_t x = lane; x < len; x += 64) dst[x] = src[x];
     if (lane == 0) res[i].btOffset = poolBase + dense[i];
@@ -1180,27 +1393,38 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
         rc = devExclusiveScan(ctx, dDirBytes, dDirOff, N + 1);
         if (rc != SD_OK) return rc;
         hipLaunchKernelGGL(k_tb_offsets, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dDirOff, dBtOff, dTb);
-        rc = devSortPairs(ctx, dKeys, dKeysS, dVals, dOrder, nPairs, 14);
+        rc = devSortPairs(ctx, dKeys, dKeysS, dVals, dOrder, nPairs, 15);
         if (rc != SD_OK) return rc;
-        hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysS, nPairs, 4096u, dBounds, 4);
-        uint32_t hb[4];
+        hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysS, nPairs, 4096u, dBounds, (int) N_TB_CLASSES + 1);
+        uint32_t hb[N_TB_CLASSES + 1];
         uint64_t dirTotal = 0;
         SD_HIP(ctx, hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(&dirTotal, dDirOff + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (hb[3] == 0) break;   // nothing left
+        if (hb[N_TB_CLASSES] == 0) break;   // nothing left
         if (dirTotal > SCRATCH_BUDGET) return sdFail(ctx, SD_ENOMEM, "traceback direction scratch of %llu bytes exceeds the budget; use smaller batches", (unsigned long long) dirTotal);
         int8_t *dDir = nullptr;
         SD_HIP(ctx, wsGet(ctx, "tb.dir", dirTotal + 64, &dDir));
-        static const int ldsClass[3] = {128, 512, 2048};
         for (int ci = 0; ci < 3; ci++) {
             const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
             if (cnt == 0) continue;
-            ProfScope ps(ctx, "sw_traceback");
+            static const char *const tbNames[3] = {"sw_traceback.narrow320", "sw_traceback.narrow512", "sw_traceback.narrow1024"};
+            ProfScope ps(ctx, tbNames[ci]);
+            const int qCap = TB_NARROW_Q[ci], tCap = TB_NARROW_T[ci];
+            const size_t ldsBytes = 2 * ((size_t) 16 * qCap + 2 * (size_t) qCap + tCap);
+            hipLaunchKernelGGL(sw_traceback_narrow_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
+                               queries->dBias, targets->dRes, dMat, go, ge, qCap, tCap, dBt, dTbRes, dOrder + begin);
+        }
+        static const int ldsClass[3] = {128, 512, 2048};
+        for (int ci = 0; ci < 3; ci++) {
+            const uint32_t begin = hb[3 + ci], cnt = hb[4 + ci] - hb[3 + ci];
+            if (cnt == 0) continue;
+            ProfScope ps(ctx, "sw_traceback.lds");
             const int ldsStride = ldsClass[ci] + 1;
             const size_t ldsBytes = (size_t) 2 * 3 * ldsStride * sizeof(int32_t);
             hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
-                               queries->dBias, targets->dRes, dMat, go, ge, ldsStride, dDir, dBt, dTbRes, dOrder + begin);
+                               queries->dBias, targets->dRes, dMat, go, ge, ldsStride, dDir, dBt, dTbRes, dOrder + begin,
+                               ldsClass[ci] - 1);
         }
         SD_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_tb_collect, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dVals, dTb, dTbRes, dDirBytes, dBtLen,
@@ -1510,7 +1734,7 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
                 const size_t ldsBytes = (size_t) 2 * 3 * ldsStride * sizeof(int32_t);
                 hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dT.p, cnt,
                                    queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, ldsStride, dDir.p, dBt.p, dRes.p,
-                                   (const uint32_t *) nullptr);
+                                   (const uint32_t *) nullptr, 0);
             }
             SD_HIP(ctx, hipGetLastError());
             TbTask *back = nullptr;
@@ -1530,7 +1754,7 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
                 const int len = hres[2 * x];
                 if (len == -2) {
                     TbTask nt = t;
-                    nt.band = t.band * 2;
+                    nt.band = t.band;   // doubled by the kernel
                     next.push_back(nt);
                 } else if (len < 0) {
                     return sdFail(ctx, SD_EHIP, "Trace back error for pair %u", t.slot);
@@ -1546,7 +1770,7 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
                 if (len < 0) continue;
                 const TbTask &t = back[x];
                 sd_sw_result &r = out[t.slot];
-                memcpy(btPool + dst[x], hbt + t.btOff, len);
+                memcpy(btPool + dst[x], hbt + t.btOff + ((size_t) (t.qLen + t.tLen + 2) - (size_t) len), len);
                 r.btOffset = dst[x];
                 r.btLen = len;
                 r.identical = hres[2 * x + 1];
