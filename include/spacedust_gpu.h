@@ -76,7 +76,8 @@ typedef struct {
     int32_t identical;     /* identicalAACnt (0 when no backtrace) */
     int32_t btLen;         /* backtrace length (alnLength) */
     int32_t flags;         /* bit0: word (int16) kernel semantics used; bit1: fwd/bwd mismatch */
-    double evalue;
+    double evalue;         /* bit-exact EvalueComputation value when <= 2*evalThr (everything the reference can report);
+                            * above that the device-evaluated value (same formula, relative error < 1e-12) */
     uint64_t btOffset;     /* offset of the expanded backtrace (chars M/I/D) in the pool */
 } sd_sw_result;
 
@@ -191,6 +192,10 @@ void sd_host_index_destroy(sd_host_index *ix);
 int sd_host_ext_matrix(sd_host *h, int wordLen, const int16_t **score, const uint16_t **index, uint32_t *size);
 int sd_host_kmer_threshold(float sensitivity, int kmerSize);
 unsigned sd_host_bin_size(uint64_t dbSize, uint64_t l2CacheSize); /* l2CacheSize 0 = sysconf of this host */
+/* the (query, target) pair list Alignment::run walks (Alignment.cpp:346-379), from sd_prefilter_batch's row-per-query
+ * output; returns the number of pairs (pairQ / pairT NULL: count only) */
+uint64_t sd_host_pair_list(const sd_hit *hits, const uint32_t *counts, uint32_t nQ, uint32_t rowWidth, uint32_t *pairQ,
+                           uint32_t *pairT);
 int sd_host_lgamma_table(double *out, uint32_t n);
 double sd_host_evalue(uint64_t dbResidues, double score, double qLen);
 double sd_host_bitscore(double score);

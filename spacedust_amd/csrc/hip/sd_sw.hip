@@ -1484,7 +1484,10 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
         if (!(isIdentity && isIdentity[i])) {
             const int qL = (int) (queries->hOff[pairQ[i] + 1] - queries->hOff[pairQ[i]]);
             if (r.tEnd != -1 && qL > 0) {
-                r.evalue = sd::computeEvalue(ev, r.score, qL);
+                // the device's value (same formula, device libm: relative error ~1e-15) stands for pairs far above the
+                // threshold -- the reference computes but never reports those; everything that can be reported gets
+                // the host's bit-exact value
+                if (!(r.evalue > 2.0 * par->evalThr)) r.evalue = sd::computeEvalue(ev, r.score, qL);
                 if (r.evalue > par->evalThr && r.qStart != -1) {   // decided by the host's exact value
                     r.qStart = -1; r.tStart = -1; r.identical = 0; r.btLen = 0; r.btOffset = 0; r.flags &= 1;
                 }

@@ -1,5 +1,6 @@
 // C-ABI wrappers of the host-side stages (sd_host_* in include/spacedust_gpu.h).
 #include "sd_host.h"
+#include <vector>
 #include <omp.h>
 #include <cstdio>
 #include <cstdlib>
@@ -141,6 +142,26 @@ unsigned sd_host_bin_size(uint64_t dbSize, uint64_t l2CacheSize) {
         l2CacheSize = v > 0 ? (uint64_t) v : 262144;
     }
     return sd::diagonalBinSize(dbSize, l2CacheSize);
+}
+
+// (query, target) pairs in prefilter order from the row-per-query hit table (Alignment.cpp:346-379 reads them in
+// this order); returns the number of pairs, pairQ/pairT may be NULL to only count
+uint64_t sd_host_pair_list(const sd_hit *hits, const uint32_t *counts, uint32_t nQ, uint32_t rowWidth, uint32_t *pairQ,
+                           uint32_t *pairT) {
+    std::vector<uint64_t> start((size_t) nQ + 1, 0);
+    for (uint32_t q = 0; q < nQ; q++) start[q + 1] = start[q] + counts[q];
+    if (pairQ && pairT) {
+#pragma omp parallel for schedule(static)
+        for (uint32_t q = 0; q < nQ; q++) {
+            const sd_hit *row = hits + (size_t) q * rowWidth;
+            uint64_t w = start[q];
+            for (uint32_t x = 0; x < counts[q]; x++, w++) {
+                pairQ[w] = q;
+                pairT[w] = row[x].seqId;
+            }
+        }
+    }
+    return start[nQ];
 }
 
 static double chLogGamma(double x) {

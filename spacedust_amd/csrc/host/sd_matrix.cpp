@@ -1,6 +1,9 @@
 // Substitution matrices, composition bias, extended 2-/3-mer tables, similar-k-mer
 // enumeration (host side).  See sd_host.h for the reference citations.
 #include "sd_host.h"
+#include <vector>
+#include <memory>
+#include <mutex>
 #include "sd_matrix_data.inc"
 
 #include <algorithm>
@@ -87,8 +90,57 @@ void mapSequence(const SubMat &m, const char *seq, size_t len, uint8_t *out) {
     for (size_t i = 0; i < len; i++) out[i] = m.aa2num[(unsigned char) seq[i]];
 }
 
+// The correction of a residue depends only on (residue type, window length, integer window sum): the 21-step
+// float/double accumulation over the background that follows the sum is memoised per matrix (same operations, same
+// rounding, evaluated once per distinct triple).
+namespace {
+struct BiasMemo {
+    short sub[ALPH][ALPH];
+    double pBack[ALPH];
+    int alphabetSize = 0;
+    int lo = 0, span = 0;
+    std::vector<uint32_t> tab;   // float bit patterns; EMPTY = not computed yet
+};
+constexpr uint32_t BIAS_EMPTY = 0x7FC0DEADu;   // a NaN payload the computation cannot produce from finite inputs
+std::mutex biasMemoLock;
+std::vector<std::unique_ptr<BiasMemo> > biasMemos;
+
+BiasMemo *biasMemoFor(const SubMat &m) {
+    std::lock_guard<std::mutex> g(biasMemoLock);
+    for (auto &p : biasMemos)
+        if (p->alphabetSize == m.alphabetSize && memcmp(p->sub, m.sub, sizeof(m.sub)) == 0 && memcmp(p->pBack, m.pBack, sizeof(m.pBack)) == 0)
+            return p.get();
+    std::unique_ptr<BiasMemo> b(new BiasMemo());
+    memcpy(b->sub, m.sub, sizeof(m.sub));
+    memcpy(b->pBack, m.pBack, sizeof(m.pBack));
+    b->alphabetSize = m.alphabetSize;
+    int mn = 0, mx = 0;
+    for (int a = 0; a < ALPH; a++)
+        for (int c = 0; c < ALPH; c++) {
+            mn = std::min(mn, (int) m.sub[a][c]);
+            mx = std::max(mx, (int) m.sub[a][c]);
+        }
+    b->lo = 40 * mn - mx;
+    b->span = (40 * mx - mn) - b->lo + 1;
+    b->tab.assign((size_t) ALPH * 41 * b->span, BIAS_EMPTY);
+    biasMemos.push_back(std::move(b));
+    return biasMemos.back().get();
+}
+
+inline float biasTail(const SubMat &m, const short *row, int sum, int windowLength) {
+    float d = (float) sum;
+    // "deltaS_i /= -1.0 * float(W)": the double literal promotes the division
+    d = (float) ((double) d / (-1.0 * (double) (float) windowLength));
+    for (int a = 0; a < m.alphabetSize; a++) {
+        d = (float) ((double) d + m.pBack[a] * (double) (float) row[a]);
+    }
+    return d;
+}
+}  // namespace
+
 void calcLocalAaBiasCorrection(const SubMat &m, const uint8_t *seq, int N, float *out, float scale) {
     const int windowSize = 40;
+    BiasMemo *memo = biasMemoFor(m);
     for (int i = 0; i < N; i++) {
         const int minPos = std::max(0, (i - windowSize / 2));
         const int maxPos = std::min(N, (i + windowSize / 2));
@@ -97,11 +149,20 @@ void calcLocalAaBiasCorrection(const SubMat &m, const uint8_t *seq, int N, float
         const short *row = m.sub[seq[i]];
         for (int j = minPos; j < maxPos; j++) sum += row[seq[j]];
         sum -= row[seq[i]];
-        float d = (float) sum;
-        // "deltaS_i /= -1.0 * float(W)": the double literal promotes the division
-        d = (float) ((double) d / (-1.0 * (double) (float) windowLength));
-        for (int a = 0; a < m.alphabetSize; a++) {
-            d = (float) ((double) d + m.pBack[a] * (double) (float) row[a]);
+        float d;
+        const int rel = sum - memo->lo;
+        if (rel >= 0 && rel < memo->span && windowLength <= 40) {
+            uint32_t &slot = memo->tab[((size_t) seq[i] * 41 + windowLength) * memo->span + rel];
+            uint32_t bits = __atomic_load_n(&slot, __ATOMIC_RELAXED);
+            if (bits == BIAS_EMPTY) {
+                d = biasTail(m, row, sum, windowLength);
+                memcpy(&bits, &d, 4);
+                __atomic_store_n(&slot, bits, __ATOMIC_RELAXED);
+            } else {
+                memcpy(&d, &bits, 4);
+            }
+        } else {
+            d = biasTail(m, row, sum, windowLength);
         }
         out[i] = scale * d;
     }

@@ -134,9 +134,10 @@ class ClusterSearch:
                 continue
             # pair list in prefilter order (Alignment.cpp:346-379)
             t0 = time.time()
-            mask = np.arange(hits.shape[1])[None, :] < cnt[:, None]
-            pair_q_local = np.repeat(np.arange(c1 - c0, dtype=np.uint32), cnt)
-            pair_t = hits['seqId'][mask].astype(np.uint32)
+            cnt = np.ascontiguousarray(cnt, np.uint32)
+            pair_q_local = np.empty(n_pairs, np.uint32)
+            pair_t = np.empty(n_pairs, np.uint32)
+            L.sd_host_pair_list(ptr(hits), ptr(cnt), c1 - c0, hits.shape[1], ptr(pair_q_local), ptr(pair_t))
             ql = (off[1:] - off[:-1]).astype(np.int32)
             # Alignment::run coverage pre-check (Alignment.cpp:370-373) is the same test the prefilter applied
             tm['pairs'] = tm.get('pairs', 0.0) + time.time() - t0
