@@ -11,6 +11,9 @@ LIB_PATH = os.path.join(HERE, 'libsdgpu.so')
 _vp = C.c_void_p
 
 
+SD_OK, SD_ENODEVICE, SD_EHIP, SD_EINVAL, SD_ENOMEM, SD_EUNSUPPORTED, SD_EMISMATCH = 0, -1, -2, -3, -4, -5, -6
+
+
 class SdError(RuntimeError):
     pass
 

@@ -173,22 +173,41 @@ class Context:
                'sd_sw_score_batch')
         return out
 
-    def sw_align(self, par, queries, targets, pair_q, pair_t, identity=None, bt_cap=None, hostpath=False):
+    def sw_align(self, par, queries, targets, pair_q, pair_t, identity=None, bt_cap=None, hostpath=False, reuse=False):
+        """sd_sw_align_batch.  bt_cap: capacity of the backtrace pool (default: a generous guess, grown to the exact
+        bound sum(qLen + tLen) if the library reports SD_ENOMEM).  reuse=True hands out views of two alternating
+        context-owned buffers instead of fresh arrays (valid until the next-but-one call)."""
         pq = np.ascontiguousarray(pair_q, np.uint32)
         pt = np.ascontiguousarray(pair_t, np.uint32)
         n = len(pq)
         idt = np.ascontiguousarray(identity, np.uint8) if identity is not None else np.zeros(n, np.uint8)
-        res = np.zeros(n, _lib.SW_RESULT_DTYPE)
-        if bt_cap is None:
-            ql = (queries.offsets[pq + 1] - queries.offsets[pq]).astype(np.int64)
-            tl = (targets.offsets[pt + 1] - targets.offsets[pt]).astype(np.int64)
-            bt_cap = int((ql + tl).sum()) + 64
-        pool = np.zeros(bt_cap, np.uint8)
-        used = C.c_uint64()
         fn = self.L.sd_sw_align_batch_hostpath if hostpath else self.L.sd_sw_align_batch
-        _check(self.h, fn(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt), ptr(idt), ptr(res), ptr(pool),
-                          bt_cap, C.byref(used)), 'sd_sw_align_batch')
-        return res, pool[:used.value]
+        exact_cap = None
+        if bt_cap is None:
+            bt_cap = max(1 << 20, 96 * n)
+        while True:
+            if reuse:
+                self._flip = 1 - getattr(self, '_flip', 0)
+                bufs = self.__dict__.setdefault('_align_bufs', [None, None])
+                b = bufs[self._flip]
+                if b is None or len(b[0]) < n or len(b[1]) < bt_cap:
+                    b = (np.empty(max(n, int(1.25 * (len(b[0]) if b else 0))), _lib.SW_RESULT_DTYPE),
+                         np.empty(max(bt_cap, int(1.25 * (len(b[1]) if b else 0))), np.uint8))
+                    bufs[self._flip] = b
+                res, pool = b[0][:n], b[1]
+            else:
+                res = np.zeros(n, _lib.SW_RESULT_DTYPE)
+                pool = np.zeros(bt_cap, np.uint8)
+            used = C.c_uint64()
+            rc = fn(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt), ptr(idt), ptr(res), ptr(pool),
+                    len(pool), C.byref(used))
+            if rc == _lib.SD_ENOMEM and exact_cap is None:
+                ql = (queries.offsets[pq + 1] - queries.offsets[pq]).astype(np.int64)
+                tl = (targets.offsets[pt + 1] - targets.offsets[pt]).astype(np.int64)
+                exact_cap = bt_cap = int((ql + tl).sum()) + 64
+                continue
+            _check(self.h, rc, 'sd_sw_align_batch')
+            return res, pool[:used.value]
 
     def sw_cells(self):
         f, r, t = C.c_uint64(), C.c_uint64(), C.c_uint64()

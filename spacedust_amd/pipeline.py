@@ -146,7 +146,7 @@ class ClusterSearch:
             tm['seqset'] = tm.get('seqset', 0.0) + time.time() - t0
             t0 = time.time()
             identity = (pair_q_local + np.uint32(c0) == pair_t) if same_db else np.zeros(n_pairs, bool)
-            r, pool = self.ctx.sw_align(self.sw_par, qset, self.t_seqs, pair_q_local, pair_t, identity=identity)
+            r, pool = self.ctx.sw_align(self.sw_par, qset, self.t_seqs, pair_q_local, pair_t, identity=identity, reuse=True)
             tm['align'] += time.time() - t0
             f, rv, tb = self.ctx.sw_cells()
             self.stats['cells_fwd'] += f
