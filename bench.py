@@ -115,6 +115,7 @@ def main():
     for w in range(args.warmup):
         run_step(w)
     gpu.profile(True)
+    cs.ctx_al.profile(True)
     for k in cs.stats:
         cs.stats[k] = 0
     if dist is not None:
@@ -139,6 +140,7 @@ def main():
         gathered = [torch.zeros_like(tsum) for _ in range(world)]
         dist.all_gather(gathered, tsum)
     gpu.synchronize()
+    cs.ctx_al.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -157,7 +159,10 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    prof = gpu.profile_report()
+    prof = dict(gpu.profile_report())
+    for k_, v_ in cs.ctx_al.profile_report().items():   # the align stage runs on its own context / stream
+        a_ = prof.get(k_, (0.0, 0))
+        prof[k_] = (a_[0] + v_[0], a_[1] + v_[1])
     kernels = {k: dict(ms=v[0], launches=int(v[1])) for k, v in prof.items()}
     # variants of one kernel template ("name.variant") are one kernel for the roofline
     grouped = {}

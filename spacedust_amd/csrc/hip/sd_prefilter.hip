@@ -651,6 +651,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
 
     uint32_t qBeg = 0;
     uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 4096);   // ~0.6 G hits per sub-batch on a proteome-scale target DB: larger sorts were measured 4x slower per item
+    if (const char *e = getenv("SD_PF_BATCH")) batchQ = std::max<uint32_t>(1, std::min<uint32_t>(maxBatchQ, (uint32_t) atoi(e)));
     while (qBeg < nQ) {
         uint32_t bq = std::min<uint32_t>(batchQ, nQ - qBeg);
         std::unique_ptr<HostScope> hs(new HostScope(ctx, "pf.upload_count"));

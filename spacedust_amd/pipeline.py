@@ -59,8 +59,13 @@ class ClusterSearch:
 
     def __init__(self, ctx, host, target_db, sensitivity=5.7, max_seqs=300, eval_thr=10.0, cov_mode=2, cov_thr=0.8,
                  aln_len_thr=30, max_gene_gap=3, cluster_size=2, alpha=1.0, p_clu_thr=0.01, p_mh_thr=0.01,
-                 filter_self_match=True, bin_size=None, verbose=False):
+                 filter_self_match=True, bin_size=None, verbose=False, align_ctx=None):
+        """ctx runs the prefilter (and clusterhits); align_ctx -- a second context (own HIP stream and workspace)
+        on the same device, created here if not given -- runs the alignments, so that the prefilter of the next
+        chunk (HBM random-access bound) and the Smith-Waterman of the current one (integer-VALU bound) share the
+        GPU instead of taking turns."""
         self.ctx, self.host, self.T = ctx, host, target_db
+        self.ctx_al = align_ctx if align_ctx is not None else api.Context(ctx.device_index)
         self.verbose = verbose
         self.k = 6
         self.kmer_thr = host.kmer_threshold(sensitivity, self.k)
@@ -76,12 +81,12 @@ class ClusterSearch:
         self.timing['index_build_s'] = time.time() - t0
         t0 = time.time()
         self.target = api.Target(ctx, host, self.index)
-        self.t_seqs = ctx.seqset(target_db.residues, target_db.offsets, self.t_sw_bias)
+        self.t_seqs = self.ctx_al.seqset(target_db.residues, target_db.offsets, self.t_sw_bias)
         self.timing['upload_s'] = time.time() - t0
         self.pf_par = api.prefilter_params(host, target_db.n, kmer_thr=self.kmer_thr, max_hits=max_seqs, bin_size=bin_size,
                                            cov_mode=cov_mode, cov_thr=cov_thr, k=self.k)
         mat, _, _ = host.matrix(0)
-        self.sw_par = ctx.sw_params(mat, int(target_db.offsets[-1]), sw_mode=2, eval_thr=eval_thr, cov_mode=cov_mode,
+        self.sw_par = self.ctx_al.sw_params(mat, int(target_db.offsets[-1]), sw_mode=2, eval_thr=eval_thr, cov_mode=cov_mode,
                                     cov_thr=cov_thr)
         self.stats = dict(prefilter_hits=0, pairs=0, cells_fwd=0, cells_rev=0, cells_tb=0, kmers=0, index_hits=0,
                           diagonals=0, diag_len=0)
@@ -112,43 +117,59 @@ class ClusterSearch:
                        'sd_agg_add')
             return time.time() - t1
 
-        for c0 in range(a0, b0, chunk_queries):
-            c1 = min(b0, c0 + chunk_queries)
+        def prefilter_job(c0, c1):
+            """bias + prefilter + pair list of one chunk (runs on its own thread and HIP stream)"""
+            t = {}
             r0, r1 = int(Q.offsets[c0]), int(Q.offsets[c1])
             res = Q.residues[r0:r1]
             off = (Q.offsets[c0:c1 + 1] - Q.offsets[c0]).astype(np.uint64)
             t0 = time.time()
             sw_b, dg_b, km_b = self.host.comp_bias(res, off, self.k)
-            tm['bias'] += time.time() - t0
+            t['bias'] = time.time() - t0
             ident = (np.arange(c0, c1, dtype=np.uint32) if same_db else np.full(c1 - c0, 0xFFFFFFFF, np.uint32))
             t0 = time.time()
             hits, cnt, st = api.prefilter(self.ctx, self.target, self.pf_par, res, off, km_b, dg_b, ident, want_stats=True)
-            tm['prefilter'] += time.time() - t0
+            t['prefilter'] = time.time() - t0
+            # pair list in prefilter order (Alignment.cpp:346-379); Alignment::run's coverage pre-check (:370-373) is
+            # the same test the prefilter applied
+            t0 = time.time()
+            n_pairs = int(cnt.sum())
+            cnt = np.ascontiguousarray(cnt, np.uint32)
+            pair_q_local = np.empty(n_pairs, np.uint32)
+            pair_t = np.empty(n_pairs, np.uint32)
+            if n_pairs:
+                L.sd_host_pair_list(ptr(hits), ptr(cnt), c1 - c0, hits.shape[1], ptr(pair_q_local), ptr(pair_t))
+            t['pairs'] = time.time() - t0
+            return dict(c0=c0, c1=c1, res=res, off=off, sw_b=sw_b, st=st, n_pairs=n_pairs, pair_q_local=pair_q_local,
+                        pair_t=pair_t, t=t)
+
+        chunks = [(c0, min(b0, c0 + chunk_queries)) for c0 in range(a0, b0, chunk_queries)]
+        pf_exec = ThreadPoolExecutor(max_workers=1)
+        pf_next = pf_exec.submit(prefilter_job, *chunks[0]) if chunks else None
+        for ci in range(len(chunks)):
+            t0 = time.time()
+            d = pf_next.result()
+            tm['prefilter_wait'] = tm.get('prefilter_wait', 0.0) + time.time() - t0
+            pf_next = pf_exec.submit(prefilter_job, *chunks[ci + 1]) if ci + 1 < len(chunks) else None
+            for k_, v_ in d['t'].items():
+                tm[k_] = tm.get(k_, 0.0) + v_
+            st, n_pairs, c0, c1 = d['st'], d['n_pairs'], d['c0'], d['c1']
             self.stats['kmers'] += int(st[:, 0].sum())
             self.stats['index_hits'] += int(st[:, 1].sum())
             self.stats['diagonals'] += int(st[:, 2].sum())
             self.stats['diag_len'] += int(st[:, 3].sum())
-            n_pairs = int(cnt.sum())
             self.stats['prefilter_hits'] += n_pairs
             if n_pairs == 0:
                 continue
-            # pair list in prefilter order (Alignment.cpp:346-379)
+            pair_q_local, pair_t = d['pair_q_local'], d['pair_t']
             t0 = time.time()
-            cnt = np.ascontiguousarray(cnt, np.uint32)
-            pair_q_local = np.empty(n_pairs, np.uint32)
-            pair_t = np.empty(n_pairs, np.uint32)
-            L.sd_host_pair_list(ptr(hits), ptr(cnt), c1 - c0, hits.shape[1], ptr(pair_q_local), ptr(pair_t))
-            ql = (off[1:] - off[:-1]).astype(np.int32)
-            # Alignment::run coverage pre-check (Alignment.cpp:370-373) is the same test the prefilter applied
-            tm['pairs'] = tm.get('pairs', 0.0) + time.time() - t0
-            t0 = time.time()
-            qset = self.ctx.seqset(res, off, sw_b)
+            qset = self.ctx_al.seqset(d['res'], d['off'], d['sw_b'])
             tm['seqset'] = tm.get('seqset', 0.0) + time.time() - t0
             t0 = time.time()
             identity = (pair_q_local + np.uint32(c0) == pair_t) if same_db else np.zeros(n_pairs, bool)
-            r, pool = self.ctx.sw_align(self.sw_par, qset, self.t_seqs, pair_q_local, pair_t, identity=identity, reuse=True)
+            r, pool = self.ctx_al.sw_align(self.sw_par, qset, self.t_seqs, pair_q_local, pair_t, identity=identity, reuse=True)
             tm['align'] += time.time() - t0
-            f, rv, tb = self.ctx.sw_cells()
+            f, rv, tb = self.ctx_al.sw_cells()
             self.stats['cells_fwd'] += f
             self.stats['cells_rev'] += rv
             self.stats['cells_tb'] += tb
@@ -159,6 +180,7 @@ class ClusterSearch:
             pending = pool_exec.submit(aggregate_job, n_pairs, pair_q_local, pair_t, r, identity, pool, c0)
             tm['aggregate'] += time.time() - t0
             del qset
+        pf_exec.shutdown()
         t0 = time.time()
         if pending is not None:
             tm['aggregate_busy'] += pending.result()
