@@ -36,6 +36,9 @@ typedef struct sd_target sd_target;
 
 /* ---- context ------------------------------------------------------------------------- */
 int sd_ctx_create(int device, sd_ctx **out);
+/* priority < 0 / 0 / > 0: the context's stream gets the device's highest / middle / lowest stream priority (two
+ * contexts on one device share it: e.g. the memory-bound prefilter ahead of the VALU-bound alignments) */
+int sd_ctx_create_prio(int device, int priority, sd_ctx **out);
 void sd_ctx_destroy(sd_ctx *ctx);
 const char *sd_last_error(sd_ctx *ctx);
 int sd_device_name(sd_ctx *ctx, char *buf, size_t cap);

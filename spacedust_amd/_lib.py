@@ -63,6 +63,7 @@ def load():
     L = C.CDLL(LIB_PATH)
     sig = {
         'sd_ctx_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
+        'sd_ctx_create_prio': (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
         'sd_ctx_destroy': (None, [_vp]),
         'sd_last_error': (C.c_char_p, [_vp]),
         'sd_device_name': (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
@@ -130,7 +131,7 @@ def load():
 
 
 DECLARED_SYMBOLS = [
-    'sd_ctx_create', 'sd_ctx_destroy', 'sd_last_error', 'sd_device_name', 'sd_synchronize', 'sd_profile_enable',
+    'sd_ctx_create', 'sd_ctx_create_prio', 'sd_ctx_destroy', 'sd_last_error', 'sd_device_name', 'sd_synchronize', 'sd_profile_enable',
     'sd_profile_reset', 'sd_profile_get', 'sd_profile_names', 'sd_seqset_create', 'sd_seqset_destroy',
     'sd_sw_align_batch', 'sd_sw_align_batch_hostpath', 'sd_sw_score_batch', 'sd_sw_last_cells', 'sd_target_create', 'sd_target_destroy',
     'sd_prefilter_batch', 'sd_clusterhits_batch', 'sd_host_create', 'sd_host_destroy', 'sd_host_matrix',

@@ -118,10 +118,10 @@ class HostIndex:
 class Context:
     """One GPU (sd_ctx).  Raises SdError when no HIP device is visible -- there is no CPU fallback."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, priority=0):
         self.L = _lib.load()
         h = C.c_void_p()
-        rc = self.L.sd_ctx_create(device, C.byref(h))
+        rc = self.L.sd_ctx_create_prio(device, priority, C.byref(h))
         if rc != 0:
             raise SdError('sd_ctx_create(%d) failed (%d): no usable HIP device; the HIP path has no CPU fallback'
                           % (device, rc))

@@ -1100,7 +1100,9 @@ int sdFail(sd_ctx *ctx, int code, const char *fmt, ...) {
 
 extern "C" {
 
-int sd_ctx_create(int device, sd_ctx **out) {
+int sd_ctx_create(int device, sd_ctx **out) { return sd_ctx_create_prio(device, 0, out); }
+
+int sd_ctx_create_prio(int device, int priority, sd_ctx **out) {
     if (out == nullptr) return SD_EINVAL;
     *out = nullptr;
     int count = 0;
@@ -1114,7 +1116,10 @@ int sd_ctx_create(int device, sd_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return SD_ENODEVICE;
     sd_ctx *c = new sd_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    int least = 0, greatest = 0;   // numerically: least priority >= greatest priority
+    (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const int prio = priority < 0 ? greatest : (priority > 0 ? least : (least + greatest) / 2);
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) != hipSuccess) {
         delete c;
         return SD_EHIP;
     }

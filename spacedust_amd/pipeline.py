@@ -65,7 +65,7 @@ class ClusterSearch:
         chunk (HBM random-access bound) and the Smith-Waterman of the current one (integer-VALU bound) share the
         GPU instead of taking turns."""
         self.ctx, self.host, self.T = ctx, host, target_db
-        self.ctx_al = align_ctx if align_ctx is not None else api.Context(ctx.device_index)
+        self.ctx_al = align_ctx if align_ctx is not None else api.Context(ctx.device_index, priority=int(os.environ.get('SD_ALIGN_PRIO', '1')))
         self.verbose = verbose
         self.k = 6
         self.kmer_thr = host.kmer_threshold(sensitivity, self.k)
