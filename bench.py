@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--proteomes', type=int, default=100)
     ap.add_argument('--genes', type=int, default=3000)
     ap.add_argument('--batch', type=int, default=10, help='query proteomes per step')
-    ap.add_argument('--chunk', type=int, default=30000, help='queries per device chunk')
+    ap.add_argument('--chunk', type=int, default=10000, help='queries per device chunk')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--cpu-threads', type=int, default=0)

@@ -283,6 +283,280 @@ __global__ void query_hit_base_kernel(uint32_t nQ, const uint64_t *__restrict__ 
     if (q <= nQ) qHitBase[q] = hitBase[kmerBase[posBase[q]]];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bucketed double-diagonal match (replaces the global radix sort + match + flag scan + compaction).
+// The hit stream is already grouped by query.  Per query one workgroup splits its segment into `bins` target
+// ranges (a power of two chosen from the segment size so that a range holds ~10^3 hits), reordering every tile in
+// LDS first so that the global writes are runs, not a scatter.  Per (query, range) bucket one workgroup then
+// sorts in LDS -- counting sort on the target offset, ties put back into emission order with the stream position
+// carried in the value -- runs the match on the sorted bucket and writes only the matched hits, compacted, to the
+// front of the bucket's region.  Buckets are ordered (query, target range), so concatenating them gives the
+// candidates in (query, target, emission) order directly.
+// ---------------------------------------------------------------------------------------------
+constexpr int PF_NB_MAX = 2048;        // bucket slots per query
+constexpr int PF_LB_MAX = 11;          // log2(PF_NB_MAX)
+constexpr int PF_BUCKET_CAP = 2048;    // hits an LDS bucket sort can take; larger buckets flag the fallback
+constexpr int PF_TILE = 2048;          // hits reordered in LDS per partition step (256 threads x 8)
+constexpr int PF_CNT_MAX = 4096;       // counting-sort bins (target offsets) per bucket
+
+__device__ __forceinline__ int pfLog2Bins(uint64_t n, int tBits) {
+    const uint64_t want = (n + 767) / 768;
+    int lb = 0;
+    while ((1ull << lb) < want && lb < PF_LB_MAX) lb++;
+    const int minLb = tBits > 12 ? tBits - 12 : 0;   // a bucket's target range must fit PF_CNT_MAX counters
+    lb = lb < minLb ? minLb : lb;
+    lb = lb > tBits ? tBits : lb;
+    return lb;   // > PF_LB_MAX only when tBits > 12 + PF_LB_MAX: the caller falls back
+}
+
+// exclusive scan of arr[0..n) (n <= 4 * 1024, 256 threads), in place; returns the total
+__device__ uint32_t pfBlockScan(uint32_t *arr, int n, uint32_t *part /* 256 */) {
+    const int t = threadIdx.x;
+    const int per = (n + 255) / 256;
+    const int b = t * per, e = min(n, b + per);
+    uint32_t sum = 0;
+    for (int x = b; x < e; x++) sum += arr[x];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const uint32_t total = part[255];
+    uint32_t run = t ? part[t - 1] : 0;
+    for (int x = b; x < e; x++) {
+        const uint32_t v = arr[x];
+        arr[x] = run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
+}
+
+__global__ void __launch_bounds__(256)
+partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tBits, const uint32_t *__restrict__ inKey,
+                      const uint32_t *__restrict__ inVal, uint32_t *__restrict__ outKey, uint32_t *__restrict__ outVal,
+                      uint32_t *__restrict__ qLog2Bins, uint64_t *__restrict__ bktStart, uint32_t *__restrict__ bktCount,
+                      int *__restrict__ flag) {
+    __shared__ uint32_t cursor[PF_NB_MAX], tcount[PF_NB_MAX], tstart[PF_NB_MAX], part[256];
+    __shared__ uint32_t tileK[PF_TILE], tileV[PF_TILE];
+    const uint32_t q = blockIdx.x;
+    const int t = threadIdx.x;
+    const uint64_t s = qHitBase[q], e = qHitBase[q + 1];
+    const uint64_t n = e - s;
+    int lb = pfLog2Bins(n, tBits);
+    if (lb > PF_LB_MAX) {
+        if (t == 0) {
+            qLog2Bins[q] = (uint32_t) lb;
+            if (n > 0) atomicExch(flag, 1);
+        }
+        return;
+    }
+    const uint32_t tMask = (1u << tBits) - 1;
+    int bins, shift;
+    // histogram of the segment; a finer split is taken while some range holds more than an LDS bucket can sort
+    for (;;) {
+        bins = 1 << lb;
+        shift = tBits - lb;
+        for (int b = t; b < bins; b += 256) { cursor[b] = 0; tcount[b] = 0; }
+        if (t == 0) part[0] = 0;
+        __syncthreads();
+        for (uint64_t i = s + t; i < e; i += 256) atomicAdd(&cursor[(inKey[i] & tMask) >> shift], 1u);
+        __syncthreads();
+        uint32_t mx = 0;
+        for (int b = t; b < bins; b += 256) mx = max(mx, cursor[b]);
+        if (mx > (uint32_t) PF_BUCKET_CAP) atomicMax(&part[0], mx);
+        __syncthreads();
+        const bool over = part[0] > (uint32_t) PF_BUCKET_CAP;
+        __syncthreads();
+        if (!over || lb >= PF_LB_MAX || lb >= tBits) break;
+        lb++;
+    }
+    if (t == 0) qLog2Bins[q] = (uint32_t) lb;
+    for (int b = t; b < bins; b += 256) bktCount[(size_t) q * PF_NB_MAX + b] = cursor[b];
+    __syncthreads();
+    pfBlockScan(cursor, bins, part);
+    for (int b = t; b < bins; b += 256) bktStart[(size_t) q * PF_NB_MAX + b] = s + cursor[b];
+    __syncthreads();
+    for (uint64_t base = s; base < e; base += PF_TILE) {
+        const int tn = (int) min((uint64_t) PF_TILE, e - base);
+        uint32_t k[8], v[8], r[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            const int j = x * 256 + t;
+            if (j < tn) {
+                k[x] = inKey[base + j];
+                v[x] = inVal[base + j];
+                r[x] = atomicAdd(&tcount[(k[x] & tMask) >> shift], 1u);
+            }
+        }
+        __syncthreads();
+        for (int b = t; b < bins; b += 256) tstart[b] = tcount[b];
+        __syncthreads();
+        pfBlockScan(tstart, bins, part);
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            const int j = x * 256 + t;
+            if (j < tn) {
+                const uint32_t p = tstart[(k[x] & tMask) >> shift] + r[x];
+                tileK[p] = k[x];
+                tileV[p] = v[x];
+            }
+        }
+        __syncthreads();
+        for (int j = t; j < tn; j += 256) {
+            const uint32_t kk = tileK[j];
+            const uint32_t b = (kk & tMask) >> shift;
+            const uint64_t g = s + cursor[b] + ((uint32_t) j - tstart[b]);
+            outKey[g] = kk;
+            outVal[g] = tileV[j];
+        }
+        __syncthreads();
+        for (int b = t; b < bins; b += 256) { cursor[b] += tcount[b]; tcount[b] = 0; }
+        __syncthreads();
+    }
+}
+
+// workgroup w -> (query, bin): bins of a query are contiguous, binBase[q] = sum of bins of the queries before
+__device__ __forceinline__ bool pfSlotOf(uint32_t w, uint32_t nQ, const uint64_t *__restrict__ binBase, uint32_t &q, uint32_t &b) {
+    if (w >= binBase[nQ]) return false;
+    uint32_t lo = 0, hi = nQ;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (binBase[mid] <= w) lo = mid;
+        else hi = mid;
+    }
+    q = lo;
+    b = w - (uint32_t) binBase[lo];
+    return true;
+}
+
+__global__ void __launch_bounds__(256)
+bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uint32_t *__restrict__ qLog2Bins, int tBits,
+                    const uint64_t *__restrict__ bktStart, const uint32_t *__restrict__ bktCount,
+                    const uint32_t *__restrict__ inKey, const uint32_t *__restrict__ inVal, uint32_t *__restrict__ outKey,
+                    uint32_t *__restrict__ outVal, uint32_t *__restrict__ bktEmit, int *__restrict__ flag) {
+    __shared__ uint32_t aK[PF_BUCKET_CAP], aV[PF_BUCKET_CAP], bK[PF_BUCKET_CAP], bV[PF_BUCKET_CAP];
+    __shared__ uint32_t cnt[PF_CNT_MAX], part[256];
+    uint32_t q, b;
+    if (!pfSlotOf(blockIdx.x, nQ, binBase, q, b)) return;
+    const size_t slot = (size_t) q * PF_NB_MAX + b;
+    const int n = (int) bktCount[slot];
+    if (n == 0) return;
+    const int t = threadIdx.x;
+    if (n > PF_BUCKET_CAP) {
+        if (t == 0) atomicExch(flag, 2);
+        return;
+    }
+    const uint64_t start = bktStart[slot];
+    const int shift = tBits - (int) qLog2Bins[q];
+    const uint32_t offMask = (1u << shift) - 1;   // key & offMask = target offset inside the bucket's range
+    const int nCnt = 1 << shift;
+    for (int x = t; x < nCnt; x += 256) cnt[x] = 0;
+    __syncthreads();
+    for (int x = t; x < n; x += 256) {
+        aK[x] = inKey[start + x];
+        aV[x] = inVal[start + x];
+        atomicAdd(&cnt[aK[x] & offMask], 1u);
+    }
+    __syncthreads();
+    pfBlockScan(cnt, nCnt, part);
+    for (int x = t; x < n; x += 256) {
+        const uint32_t p = atomicAdd(&cnt[aK[x] & offMask], 1u);   // cnt[o] ends as the end of group o
+        bK[p] = aK[x];
+        bV[p] = aV[x];
+    }
+    __syncthreads();
+    // emission order inside every target group: rank by stream position (low 24 bits of the value)
+    for (int p = t; p < n; p += 256) {
+        const uint32_t o = bK[p] & offMask;
+        const uint32_t gs = o ? cnt[o - 1] : 0, ge = cnt[o];
+        uint32_t fin = gs;
+        if (ge - gs > 1) {
+            const uint32_t me = bV[p] & 0xFFFFFFu;
+            for (uint32_t x = gs; x < ge; x++) fin += ((bV[x] & 0xFFFFFFu) < me) ? 1u : 0u;
+        }
+        aK[fin] = bK[p];
+        aV[fin] = bV[p];
+    }
+    __syncthreads();
+    // match (QueryMatcher.cpp double-diagonal logic, as match_diag_kernel) on the sorted bucket
+    const int per = (n + 255) / 256;
+    const int pb = t * per, pe = min(n, pb + per);
+    uint32_t emitMask = 0;   // per <= 8
+    uint32_t mine = 0;
+    for (int p = pb; p < pe; p++) {
+        const uint8_t d8 = (uint8_t) (aV[p] >> 24);
+        auto flagAt = [&](int x) -> bool {
+            const uint8_t dx = (uint8_t) (aV[x] >> 24);
+            const bool first = (x == 0) || (aK[x - 1] != aK[x]);
+            const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) (aV[x - 1] >> 24);
+            return dx == prev;
+        };
+        bool e = false;
+        if (flagAt(p)) {
+            e = true;
+            int x = p;
+            while (x > 0 && aK[x - 1] == aK[p]) {
+                x--;
+                if (flagAt(x)) {
+                    e = ((uint8_t) (aV[x] >> 24)) != d8;
+                    break;
+                }
+            }
+        }
+        if (e) {
+            emitMask |= 1u << (p - pb);
+            mine++;
+        }
+    }
+    part[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t w = t ? part[t - 1] : 0;
+    for (int p = pb; p < pe; p++) {
+        if (emitMask & (1u << (p - pb))) {
+            outKey[start + w] = aK[p];
+            outVal[start + w] = aV[p];
+            w++;
+        }
+    }
+    if (t == 255) bktEmit[slot] = part[255];
+}
+
+// per-query bin counts -> running bin base (so that a flat workgroup index maps to (query, bin))
+__global__ void bin_count_kernel(uint32_t nQ, const uint32_t *__restrict__ qLog2Bins, uint32_t *__restrict__ qBins) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nQ) qBins[q] = qLog2Bins[q] <= (uint32_t) PF_LB_MAX ? (1u << qLog2Bins[q]) : 0u;
+    if (q == nQ) qBins[q] = 0;
+}
+
+// emitted hits of every bucket -> the dense candidate arrays (offsets: exclusive scan of the emit counts in
+// (query, bin) slot order)
+__global__ void __launch_bounds__(64)
+bucket_collect_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uint64_t *__restrict__ bktStart,
+                      const uint32_t *__restrict__ bktEmit, const uint64_t *__restrict__ emitOff,
+                      const uint32_t *__restrict__ inKey, const uint32_t *__restrict__ inVal, uint32_t *__restrict__ cKey,
+                      uint32_t *__restrict__ cVal) {
+    uint32_t q, b;
+    if (!pfSlotOf(blockIdx.x, nQ, binBase, q, b)) return;
+    const size_t slot = (size_t) q * PF_NB_MAX + b;
+    const uint32_t n = bktEmit[slot];
+    if (n == 0) return;
+    const uint64_t src = bktStart[slot], dst = emitOff[slot];
+    for (uint32_t x = threadIdx.x; x < n; x += 64) {
+        cKey[dst + x] = inKey[src + x];
+        cVal[dst + x] = inVal[src + x];
+    }
+}
+
 // K5: ungapped diagonal score (UngappedAlignment.cpp:30-43,416-430); candidates are (key,val) pairs
 __global__ void __launch_bounds__(256)
 score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint32_t *__restrict__ cVal,
@@ -746,6 +1020,8 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
 
         hs.reset(new HostScope(ctx, "pf.gather_sort_match"));
         uint32_t nCand = 0, nKept = 0;
+        bool bucketDone = false;
+        const bool useBuckets = getenv("SD_PF_SORT") == nullptr;
         WsView<uint32_t> dKeyA(ctx, "pf.dKeyA");
         WsView<uint32_t> dKeyB(ctx, "pf.dKeyB");
         WsView<uint32_t> dValA(ctx, "pf.dValA");
@@ -779,6 +1055,74 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                                    dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, T->dEntrySeq, T->dEntryPos, tBits, dQHitBase.p,
                                    dKeyA.p, dValA.p, dDiag.p);
             }
+            // ---- double-diagonal match: bucketed LDS path, or (fallback / SD_PF_SORT=1) global radix sort + match
+            if (useBuckets) {
+                const size_t nSlots = (size_t) bq * PF_NB_MAX;
+                WsView<uint64_t> dBktStart(ctx, "pf.dBktStart");
+                WsView<uint32_t> dBktCount(ctx, "pf.dBktCount");
+                WsView<uint32_t> dBktEmit(ctx, "pf.dBktEmit");
+                WsView<uint64_t> dEmitOff(ctx, "pf.dEmitOff");
+                WsView<uint32_t> dQLog2(ctx, "pf.dQLog2");
+                WsView<uint32_t> dQBins(ctx, "pf.dQBins");
+                WsView<uint64_t> dBinBase(ctx, "pf.dBinBase");
+                WsView<int> dFlag(ctx, "pf.dFlag");
+                SD_HIP(ctx, dBktStart.alloc(nSlots));
+                SD_HIP(ctx, dBktCount.alloc(nSlots));
+                SD_HIP(ctx, dBktEmit.alloc(nSlots + 1));
+                SD_HIP(ctx, dEmitOff.alloc(nSlots + 1));
+                SD_HIP(ctx, dQLog2.alloc(bq));
+                SD_HIP(ctx, dQBins.alloc(bq + 1));
+                SD_HIP(ctx, dBinBase.alloc(bq + 1));
+                SD_HIP(ctx, dFlag.alloc(1));
+                SD_HIP(ctx, hipMemsetAsync(dBktEmit.p, 0, (nSlots + 1) * sizeof(uint32_t), ctx->stream));
+                SD_HIP(ctx, hipMemsetAsync(dFlag.p, 0, sizeof(int), ctx->stream));
+                {
+                    ProfScope ps(ctx, "prefilter_partition_hits");
+                    hipLaunchKernelGGL(partition_hits_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, dQHitBase.p, tBits, dKeyA.p,
+                                       dValA.p, dKeyB.p, dValB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
+                }
+                hipLaunchKernelGGL(bin_count_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, dQLog2.p, dQBins.p);
+                int rc = exclusiveScanWiden(ctx, dQBins.p, dBinBase.p, bq + 1, scanTmp);
+                if (rc != SD_OK) return rc;
+                int hFlag = 0;
+                uint64_t totalBins = 0;
+                SD_HIP(ctx, hipMemcpyAsync(&hFlag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                SD_HIP(ctx, hipMemcpyAsync(&totalBins, dBinBase.p + bq, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (hFlag == 0 && totalBins > 0) {
+                    {
+                        ProfScope ps(ctx, "prefilter_bucket_match");
+                        hipLaunchKernelGGL(bucket_match_kernel, dim3((unsigned) totalBins), dim3(256), 0, ctx->stream, bq, dBinBase.p,
+                                           dQLog2.p, tBits, dBktStart.p, dBktCount.p, dKeyB.p, dValB.p, dKeyA.p, dValA.p, dBktEmit.p,
+                                           dFlag.p);
+                    }
+                    rc = exclusiveScanWiden(ctx, dBktEmit.p, dEmitOff.p, nSlots + 1, scanTmp);
+                    if (rc != SD_OK) return rc;
+                    uint64_t nc64 = 0;
+                    SD_HIP(ctx, hipMemcpyAsync(&hFlag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                    SD_HIP(ctx, hipMemcpyAsync(&nc64, dEmitOff.p + nSlots, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if (hFlag == 0) {
+                        nCand = (uint32_t) nc64;
+                        bucketDone = true;
+                        if (nCand > 0) {
+                            SD_HIP(ctx, dCKey.alloc(nCand));
+                            SD_HIP(ctx, dCVal.alloc(nCand));
+                            hipLaunchKernelGGL(bucket_collect_kernel, dim3((unsigned) totalBins), dim3(64), 0, ctx->stream, bq, dBinBase.p,
+                                               dBktStart.p, dBktEmit.p, dEmitOff.p, dKeyA.p, dValA.p, dCKey.p, dCVal.p);
+                        }
+                    }
+                }
+                if (!bucketDone) {
+                    // a bucket larger than the LDS capacity (or more target bits than the slots cover): redo this
+                    // sub-batch with the global sort; dKeyA / dValA were overwritten by the emitted hits, so gather again
+                    ProfScope ps(ctx, "prefilter_gather_hits");
+                    hipLaunchKernelGGL(gather_hits_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKStart.p,
+                                       dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, T->dEntrySeq, T->dEntryPos, tBits, dQHitBase.p,
+                                       dKeyA.p, dValA.p, dDiag.p);
+                }
+            }
+            if (!bucketDone) {
             {
                 ProfScope ps(ctx, "prefilter_sort_hits");
                 // Hits arrive grouped by query in emission order.  A stable sort on the target bits alone makes every
@@ -804,14 +1148,17 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             SD_HIP(ctx, hipMemcpyAsync(&nc64, dEmitPos.p + nHits, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
             nCand = (uint32_t) nc64;
+            }
         }
         hs.reset(new HostScope(ctx, "pf.score_keep"));
         if (nCand > 0) {
-            SD_HIP(ctx, dCKey.alloc(nCand));
-            SD_HIP(ctx, dCVal.alloc(nCand));
+            if (!bucketDone) {
+                SD_HIP(ctx, dCKey.alloc(nCand));
+                SD_HIP(ctx, dCVal.alloc(nCand));
+            }
             SD_HIP(ctx, dCScore.alloc(nCand));
             SD_HIP(ctx, dCLen.alloc(nCand));
-            {
+            if (!bucketDone) {
                 // compact into scratch, then a stable sort on the query bits restores (query, target, emission) order
                 WsView<uint32_t> dCKey0(ctx, "pf.dCKey0");
                 WsView<uint32_t> dCVal0(ctx, "pf.dCVal0");

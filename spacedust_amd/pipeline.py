@@ -91,7 +91,7 @@ class ClusterSearch:
         self.stats = dict(prefilter_hits=0, pairs=0, cells_fwd=0, cells_rev=0, cells_tb=0, kmers=0, index_hits=0,
                           diagonals=0, diag_len=0)
 
-    def search(self, Q, same_db=False, chunk_queries=20000, tsv_path=None, canonical=True, query_range=None):
+    def search(self, Q, same_db=False, chunk_queries=10000, tsv_path=None, canonical=True, query_range=None):
         """run the workflow for query set DB Q (optionally only proteins [a,b) = a shard of whole query sets)."""
         L = self.ctx.L
         T = self.T
