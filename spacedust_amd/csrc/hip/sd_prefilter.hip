@@ -295,12 +295,13 @@ __global__ void query_hit_base_kernel(uint32_t nQ, const uint64_t *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 constexpr int PF_NB_MAX = 2048;        // bucket slots per query
 constexpr int PF_LB_MAX = 11;          // log2(PF_NB_MAX)
-constexpr int PF_BUCKET_CAP = 2048;    // hits an LDS bucket sort can take; larger buckets flag the fallback
-constexpr int PF_TILE = 2048;          // hits reordered in LDS per partition step (256 threads x 8)
+constexpr int PF_BUCKET_CAP = 1024;    // hits the LDS bucket sort takes; larger buckets go to a second launch with
+constexpr int PF_BUCKET_CAP_BIG = 6144;   // this capacity, and only beyond that the whole sub-batch falls back
+constexpr int PF_TILE = 1024;          // hits reordered in LDS per partition step (256 threads x 4)
 constexpr int PF_CNT_MAX = 4096;       // counting-sort bins (target offsets) per bucket
 
 __device__ __forceinline__ int pfLog2Bins(uint64_t n, int tBits) {
-    const uint64_t want = (n + 767) / 768;
+    const uint64_t want = (n + 255) / 256;
     int lb = 0;
     while ((1ull << lb) < want && lb < PF_LB_MAX) lb++;
     const int minLb = tBits > 12 ? tBits - 12 : 0;   // a bucket's target range must fit PF_CNT_MAX counters
@@ -309,30 +310,65 @@ __device__ __forceinline__ int pfLog2Bins(uint64_t n, int tBits) {
     return lb;   // > PF_LB_MAX only when tBits > 12 + PF_LB_MAX: the caller falls back
 }
 
-// exclusive scan of arr[0..n) (n <= 4 * 1024, 256 threads), in place; returns the total
-__device__ uint32_t pfBlockScan(uint32_t *arr, int n, uint32_t *part /* 256 */) {
+// 16-bit counters packed two per LDS word (every count here is < 65536): add one / read one
+__device__ __forceinline__ uint32_t pk16Add(uint32_t *w, uint32_t idx) {
+    const uint32_t sh = (idx & 1u) * 16u;
+    return (atomicAdd(&w[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t pk16Get(const uint32_t *w, uint32_t idx) { return (w[idx >> 1] >> ((idx & 1u) * 16u)) & 0xFFFFu; }
+
+// exclusive scan of n packed 16-bit counters (n even, n/2 words), in place; NT threads, part[] >= NT/64 + 1 words
+template <int NT>
+__device__ void pk16Scan(uint32_t *w, int n, uint32_t *part) {
+    const int t = threadIdx.x, words = n >> 1;
+    const int per = (words + NT - 1) / NT;
+    const int b = t * per, e = min(words, b + per);
+    uint32_t sum = 0;
+    for (int x = b; x < e; x++) sum += (w[x] & 0xFFFFu) + (w[x] >> 16);
+    // inclusive scan of the per-thread sums across the workgroup
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += o;
+    }
+    if ((t & 63) == 63) part[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int wv = 0; wv < (t >> 6); wv++) base += part[wv];
+    uint32_t run = base + incl - sum;
+    for (int x = b; x < e; x++) {
+        const uint32_t lo = w[x] & 0xFFFFu, hi = w[x] >> 16;
+        w[x] = (run & 0xFFFFu) | (((run + lo) & 0xFFFFu) << 16);
+        run += lo + hi;
+    }
+    __syncthreads();
+}
+
+// exclusive scan of arr[0..n) (32-bit, 256 threads), in place
+__device__ void pfBlockScan(uint32_t *arr, int n, uint32_t *part /* >= 5 */) {
     const int t = threadIdx.x;
     const int per = (n + 255) / 256;
     const int b = t * per, e = min(n, b + per);
     uint32_t sum = 0;
     for (int x = b; x < e; x++) sum += arr[x];
-    part[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += o;
     }
-    const uint32_t total = part[255];
-    uint32_t run = t ? part[t - 1] : 0;
+    if ((t & 63) == 63) part[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int wv = 0; wv < (t >> 6); wv++) base += part[wv];
+    uint32_t run = base + incl - sum;
     for (int x = b; x < e; x++) {
         const uint32_t v = arr[x];
         arr[x] = run;
         run += v;
     }
     __syncthreads();
-    return total;
 }
 
 __global__ void __launch_bounds__(256)
@@ -340,7 +376,10 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
                       const uint32_t *__restrict__ inVal, uint32_t *__restrict__ outKey, uint32_t *__restrict__ outVal,
                       uint32_t *__restrict__ qLog2Bins, uint64_t *__restrict__ bktStart, uint32_t *__restrict__ bktCount,
                       int *__restrict__ flag) {
-    __shared__ uint32_t cursor[PF_NB_MAX], tcount[PF_NB_MAX], tstart[PF_NB_MAX], part[256];
+    __shared__ uint32_t cursor[PF_NB_MAX];          // segment histogram, then the running write position per bin
+    __shared__ uint32_t tcount[PF_NB_MAX / 2];      // per tile: packed 16-bit counts, then exclusive starts
+    __shared__ uint32_t tsize[PF_NB_MAX / 2];       // per tile: packed 16-bit counts (kept for the cursor update)
+    __shared__ uint32_t part[8];
     __shared__ uint32_t tileK[PF_TILE], tileV[PF_TILE];
     const uint32_t q = blockIdx.x;
     const int t = threadIdx.x;
@@ -360,16 +399,16 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
     for (;;) {
         bins = 1 << lb;
         shift = tBits - lb;
-        for (int b = t; b < bins; b += 256) { cursor[b] = 0; tcount[b] = 0; }
-        if (t == 0) part[0] = 0;
+        for (int b = t; b < bins; b += 256) cursor[b] = 0;
+        if (t == 0) part[7] = 0;
         __syncthreads();
         for (uint64_t i = s + t; i < e; i += 256) atomicAdd(&cursor[(inKey[i] & tMask) >> shift], 1u);
         __syncthreads();
         uint32_t mx = 0;
         for (int b = t; b < bins; b += 256) mx = max(mx, cursor[b]);
-        if (mx > (uint32_t) PF_BUCKET_CAP) atomicMax(&part[0], mx);
+        if (mx > (uint32_t) PF_BUCKET_CAP) atomicMax(&part[7], mx);
         __syncthreads();
-        const bool over = part[0] > (uint32_t) PF_BUCKET_CAP;
+        const bool over = part[7] > (uint32_t) PF_BUCKET_CAP;
         __syncthreads();
         if (!over || lb >= PF_LB_MAX || lb >= tBits) break;
         lb++;
@@ -379,28 +418,30 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
     __syncthreads();
     pfBlockScan(cursor, bins, part);
     for (int b = t; b < bins; b += 256) bktStart[(size_t) q * PF_NB_MAX + b] = s + cursor[b];
+    const int binsEven = bins < 2 ? 2 : bins;
+    for (int x = t; x < binsEven / 2; x += 256) tcount[x] = 0;
     __syncthreads();
     for (uint64_t base = s; base < e; base += PF_TILE) {
         const int tn = (int) min((uint64_t) PF_TILE, e - base);
-        uint32_t k[8], v[8], r[8];
+        uint32_t k[4], v[4], r[4];
 #pragma unroll
-        for (int x = 0; x < 8; x++) {
+        for (int x = 0; x < 4; x++) {
             const int j = x * 256 + t;
             if (j < tn) {
                 k[x] = inKey[base + j];
                 v[x] = inVal[base + j];
-                r[x] = atomicAdd(&tcount[(k[x] & tMask) >> shift], 1u);
+                r[x] = pk16Add(tcount, (k[x] & tMask) >> shift);
             }
         }
         __syncthreads();
-        for (int b = t; b < bins; b += 256) tstart[b] = tcount[b];
+        for (int x = t; x < binsEven / 2; x += 256) tsize[x] = tcount[x];
         __syncthreads();
-        pfBlockScan(tstart, bins, part);
+        pk16Scan<256>(tcount, binsEven, part);
 #pragma unroll
-        for (int x = 0; x < 8; x++) {
+        for (int x = 0; x < 4; x++) {
             const int j = x * 256 + t;
             if (j < tn) {
-                const uint32_t p = tstart[(k[x] & tMask) >> shift] + r[x];
+                const uint32_t p = pk16Get(tcount, (k[x] & tMask) >> shift) + r[x];
                 tileK[p] = k[x];
                 tileV[p] = v[x];
             }
@@ -409,12 +450,14 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
         for (int j = t; j < tn; j += 256) {
             const uint32_t kk = tileK[j];
             const uint32_t b = (kk & tMask) >> shift;
-            const uint64_t g = s + cursor[b] + ((uint32_t) j - tstart[b]);
+            const uint64_t g = s + cursor[b] + ((uint32_t) j - pk16Get(tcount, b));
             outKey[g] = kk;
             outVal[g] = tileV[j];
         }
         __syncthreads();
-        for (int b = t; b < bins; b += 256) { cursor[b] += tcount[b]; tcount[b] = 0; }
+        for (int b = t; b < bins; b += 256) cursor[b] += pk16Get(tsize, b);
+        __syncthreads();
+        for (int x = t; x < binsEven / 2; x += 256) tcount[x] = 0;
         __syncthreads();
     }
 }
@@ -433,102 +476,153 @@ __device__ __forceinline__ bool pfSlotOf(uint32_t w, uint32_t nQ, const uint64_t
     return true;
 }
 
-__global__ void __launch_bounds__(256)
+// NT threads sort buckets of up to CAP hits.  slotList == nullptr: workgroup index -> (query, bin) through binBase,
+// buckets above CAP are appended to bigList (or flag the fallback when there is no list to append to);
+// slotList != nullptr: the listed slots only (second launch with a larger CAP for the few oversize buckets).
+template <int NT, int CAP>
+__global__ void __launch_bounds__(NT)
 bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uint32_t *__restrict__ qLog2Bins, int tBits,
                     const uint64_t *__restrict__ bktStart, const uint32_t *__restrict__ bktCount,
                     const uint32_t *__restrict__ inKey, const uint32_t *__restrict__ inVal, uint32_t *__restrict__ outKey,
-                    uint32_t *__restrict__ outVal, uint32_t *__restrict__ bktEmit, int *__restrict__ flag) {
-    __shared__ uint32_t aK[PF_BUCKET_CAP], aV[PF_BUCKET_CAP], bK[PF_BUCKET_CAP], bV[PF_BUCKET_CAP];
-    __shared__ uint32_t cnt[PF_CNT_MAX], part[256];
+                    uint32_t *__restrict__ outVal, uint32_t *__restrict__ bktEmit, int *__restrict__ flag,
+                    const uint32_t *__restrict__ slotList, uint32_t *__restrict__ bigList, uint32_t *__restrict__ bigCount,
+                    uint32_t bigCap) {
+    __shared__ uint32_t eK[CAP], eV[CAP];
+    __shared__ uint32_t cnt[PF_CNT_MAX / 2];   // packed 16-bit: counts -> group starts -> group ends
+    __shared__ uint32_t part[NT / 64 + 1];
+    constexpr int PER = CAP / NT;
+    static_assert(CAP % NT == 0 && PER <= 32 && CAP < 65536, "bucket geometry");
     uint32_t q, b;
-    if (!pfSlotOf(blockIdx.x, nQ, binBase, q, b)) return;
+    if (slotList) {
+        const uint32_t sl = slotList[blockIdx.x];
+        q = sl / PF_NB_MAX;
+        b = sl % PF_NB_MAX;
+    } else if (!pfSlotOf(blockIdx.x, nQ, binBase, q, b)) {
+        return;
+    }
     const size_t slot = (size_t) q * PF_NB_MAX + b;
     const int n = (int) bktCount[slot];
     if (n == 0) return;
     const int t = threadIdx.x;
-    if (n > PF_BUCKET_CAP) {
-        if (t == 0) atomicExch(flag, 2);
+    if (n > CAP) {
+        if (t == 0) {
+            if (bigList) {
+                const uint32_t at = atomicAdd(bigCount, 1u);
+                if (at < bigCap) bigList[at] = (uint32_t) slot;
+                else atomicExch(flag, 2);
+            } else {
+                atomicExch(flag, 2);
+            }
+        }
         return;
     }
     const uint64_t start = bktStart[slot];
     const int shift = tBits - (int) qLog2Bins[q];
     const uint32_t offMask = (1u << shift) - 1;   // key & offMask = target offset inside the bucket's range
-    const int nCnt = 1 << shift;
-    for (int x = t; x < nCnt; x += 256) cnt[x] = 0;
+    const int nCnt = shift == 0 ? 2 : (1 << shift);
+    for (int x = t; x < nCnt / 2; x += NT) cnt[x] = 0;
     __syncthreads();
-    for (int x = t; x < n; x += 256) {
-        aK[x] = inKey[start + x];
-        aV[x] = inVal[start + x];
-        atomicAdd(&cnt[aK[x] & offMask], 1u);
+    uint32_t k[PER], v[PER];
+#pragma unroll
+    for (int x = 0; x < PER; x++) {
+        const int j = x * NT + t;
+        if (j < n) {
+            k[x] = inKey[start + j];
+            v[x] = inVal[start + j];
+            pk16Add(cnt, k[x] & offMask);
+        }
     }
     __syncthreads();
-    pfBlockScan(cnt, nCnt, part);
-    for (int x = t; x < n; x += 256) {
-        const uint32_t p = atomicAdd(&cnt[aK[x] & offMask], 1u);   // cnt[o] ends as the end of group o
-        bK[p] = aK[x];
-        bV[p] = aV[x];
+    pk16Scan<NT>(cnt, nCnt, part);
+#pragma unroll
+    for (int x = 0; x < PER; x++) {
+        const int j = x * NT + t;
+        if (j < n) {
+            const uint32_t p = pk16Add(cnt, k[x] & offMask);   // cnt[o] ends as the end of group o
+            eK[p] = k[x];
+            eV[p] = v[x];
+        }
     }
     __syncthreads();
     // emission order inside every target group: rank by stream position (low 24 bits of the value)
-    for (int p = t; p < n; p += 256) {
-        const uint32_t o = bK[p] & offMask;
-        const uint32_t gs = o ? cnt[o - 1] : 0, ge = cnt[o];
-        uint32_t fin = gs;
-        if (ge - gs > 1) {
-            const uint32_t me = bV[p] & 0xFFFFFFu;
-            for (uint32_t x = gs; x < ge; x++) fin += ((bV[x] & 0xFFFFFFu) < me) ? 1u : 0u;
+    uint32_t fin[PER];
+#pragma unroll
+    for (int x = 0; x < PER; x++) {
+        const int p = x * NT + t;
+        if (p < n) {
+            k[x] = eK[p];
+            v[x] = eV[p];
+            const uint32_t o = k[x] & offMask;
+            const uint32_t gs = o ? pk16Get(cnt, o - 1) : 0, ge = pk16Get(cnt, o);
+            uint32_t f = gs;
+            if (ge - gs > 1) {
+                const uint32_t me = v[x] & 0xFFFFFFu;
+                for (uint32_t y = gs; y < ge; y++) f += ((eV[y] & 0xFFFFFFu) < me) ? 1u : 0u;
+            }
+            fin[x] = f;
         }
-        aK[fin] = bK[p];
-        aV[fin] = bV[p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < PER; x++) {
+        const int p = x * NT + t;
+        if (p < n) {
+            eK[fin[x]] = k[x];
+            eV[fin[x]] = v[x];
+        }
     }
     __syncthreads();
     // match (QueryMatcher.cpp double-diagonal logic, as match_diag_kernel) on the sorted bucket
-    const int per = (n + 255) / 256;
+    const int per = (n + NT - 1) / NT;
     const int pb = t * per, pe = min(n, pb + per);
-    uint32_t emitMask = 0;   // per <= 8
-    uint32_t mine = 0;
+    uint32_t emitMask = 0, mine = 0;
     for (int p = pb; p < pe; p++) {
-        const uint8_t d8 = (uint8_t) (aV[p] >> 24);
+        const uint8_t d8 = (uint8_t) (eV[p] >> 24);
         auto flagAt = [&](int x) -> bool {
-            const uint8_t dx = (uint8_t) (aV[x] >> 24);
-            const bool first = (x == 0) || (aK[x - 1] != aK[x]);
-            const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) (aV[x - 1] >> 24);
+            const uint8_t dx = (uint8_t) (eV[x] >> 24);
+            const bool first = (x == 0) || (eK[x - 1] != eK[x]);
+            const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) (eV[x - 1] >> 24);
             return dx == prev;
         };
-        bool e = false;
+        bool em = false;
         if (flagAt(p)) {
-            e = true;
+            em = true;
             int x = p;
-            while (x > 0 && aK[x - 1] == aK[p]) {
+            while (x > 0 && eK[x - 1] == eK[p]) {
                 x--;
                 if (flagAt(x)) {
-                    e = ((uint8_t) (aV[x] >> 24)) != d8;
+                    em = ((uint8_t) (eV[x] >> 24)) != d8;
                     break;
                 }
             }
         }
-        if (e) {
+        if (em) {
             emitMask |= 1u << (p - pb);
             mine++;
         }
     }
-    part[t] = mine;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += o;
     }
-    uint32_t w = t ? part[t - 1] : 0;
+    if ((t & 63) == 63) part[t >> 6] = incl;
+    __syncthreads();
+    uint32_t w = incl - mine;
+    for (int wv = 0; wv < (t >> 6); wv++) w += part[wv];
     for (int p = pb; p < pe; p++) {
         if (emitMask & (1u << (p - pb))) {
-            outKey[start + w] = aK[p];
-            outVal[start + w] = aV[p];
+            outKey[start + w] = eK[p];
+            outVal[start + w] = eV[p];
             w++;
         }
     }
-    if (t == 255) bktEmit[slot] = part[255];
+    if (t == NT - 1) {
+        uint32_t tot = 0;
+        for (int wv = 0; wv < NT / 64; wv++) tot += part[wv];
+        bktEmit[slot] = tot;
+    }
 }
 
 // per-query bin counts -> running bin base (so that a flat workgroup index maps to (query, bin))
@@ -1090,11 +1184,26 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                 SD_HIP(ctx, hipMemcpyAsync(&totalBins, dBinBase.p + bq, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
                 SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 if (hFlag == 0 && totalBins > 0) {
+                    const uint32_t bigCap = 1u << 16;
+                    WsView<uint32_t> dBigList(ctx, "pf.dBigList");
+                    SD_HIP(ctx, dBigList.alloc(bigCap + 1));
+                    uint32_t *dBigCount = dBigList.p + bigCap;
+                    SD_HIP(ctx, hipMemsetAsync(dBigCount, 0, sizeof(uint32_t), ctx->stream));
                     {
                         ProfScope ps(ctx, "prefilter_bucket_match");
-                        hipLaunchKernelGGL(bucket_match_kernel, dim3((unsigned) totalBins), dim3(256), 0, ctx->stream, bq, dBinBase.p,
-                                           dQLog2.p, tBits, dBktStart.p, dBktCount.p, dKeyB.p, dValB.p, dKeyA.p, dValA.p, dBktEmit.p,
-                                           dFlag.p);
+                        hipLaunchKernelGGL((bucket_match_kernel<128, PF_BUCKET_CAP>), dim3((unsigned) totalBins), dim3(128), 0, ctx->stream,
+                                           bq, dBinBase.p, dQLog2.p, tBits, dBktStart.p, dBktCount.p, dKeyB.p, dValB.p, dKeyA.p, dValA.p,
+                                           dBktEmit.p, dFlag.p, (const uint32_t *) nullptr, dBigList.p, dBigCount, bigCap);
+                    }
+                    uint32_t nBig = 0;
+                    SD_HIP(ctx, hipMemcpyAsync(&nBig, dBigCount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if (nBig > 0 && nBig <= bigCap) {   // the few buckets with one very hit-rich target (e.g. the query itself)
+                        ProfScope ps(ctx, "prefilter_bucket_match_big");
+                        hipLaunchKernelGGL((bucket_match_kernel<256, PF_BUCKET_CAP_BIG>), dim3(nBig), dim3(256), 0, ctx->stream, bq,
+                                           dBinBase.p, dQLog2.p, tBits, dBktStart.p, dBktCount.p, dKeyB.p, dValB.p, dKeyA.p, dValA.p,
+                                           dBktEmit.p, dFlag.p, (const uint32_t *) dBigList.p, (uint32_t *) nullptr,
+                                           (uint32_t *) nullptr, 0u);
                     }
                     rc = exclusiveScanWiden(ctx, dBktEmit.p, dEmitOff.p, nSlots + 1, scanTmp);
                     if (rc != SD_OK) return rc;
@@ -1113,6 +1222,9 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                         }
                     }
                 }
+                if (!bucketDone && getenv("SD_DEBUG_TIMING"))
+                    fprintf(stderr, "[prefilter] bucket path fell back: flag %d, %llu bins, %llu hits, %u queries\n", hFlag,
+                            (unsigned long long) totalBins, (unsigned long long) nHits, bq);
                 if (!bucketDone) {
                     // a bucket larger than the LDS capacity (or more target bits than the slots cover): redo this
                     // sub-batch with the global sort; dKeyA / dValA were overwritten by the emitted hits, so gather again
