@@ -157,6 +157,7 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
     const int cutoff1 = (int) (short) (pi.thr - best1);
     const int n0 = countGE(row0, 8000, cutoff1);
     uint64_t base = kmerBase[p];
+    const uint32_t qi = (pi.q << 16) | (uint32_t) pi.i;   // owning query (< 2^16 per sub-batch) and position (< 2^16)
     for (int a0 = 0; a0 < n0; a0 += 64) {
         const int a = a0 + lane;
         uint32_t c = 0;
@@ -176,12 +177,30 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
         if (a < n0) {
             const uint32_t k0 = ix0[a];
             uint64_t w = base + excl;
-            for (uint32_t b = 0; b < c; b++) {
+            // eight independent index lookups in flight per lane (each is a random 8-byte read)
+            uint32_t b = 0;
+            for (; b + 8 <= c; b += 8) {
+                uint32_t km[8], s4[8], e4[8];
+#pragma unroll
+                for (int x = 0; x < 8; x++) km[x] = k0 + 8000u * (uint32_t) ix1[b + x];
+#pragma unroll
+                for (int x = 0; x < 8; x++) {
+                    s4[x] = idxOffsets[km[x]];
+                    e4[x] = idxOffsets[km[x] + 1];
+                }
+#pragma unroll
+                for (int x = 0; x < 8; x++) {
+                    kStart[w + b + x] = s4[x];
+                    kLen[w + b + x] = e4[x] - s4[x];
+                    kPos[w + b + x] = qi;
+                }
+            }
+            for (; b < c; b++) {
                 const uint32_t kmer = k0 + 8000u * (uint32_t) ix1[b];
                 const uint32_t s = idxOffsets[kmer], e = idxOffsets[kmer + 1];
                 kStart[w + b] = s;
                 kLen[w + b] = e - s;
-                kPos[w + b] = (uint32_t) p;
+                kPos[w + b] = qi;
             }
         }
         base += chunkTotal;
@@ -208,26 +227,33 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
         if (len) {
             start = kStart[kidx];
             base = hitBase[kidx];
-            const uint64_t p = kPos[kidx];
-            uint32_t lo = 0, hi = nQ;
-            while (hi - lo > 1) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (posBase[mid] <= p) lo = mid;
-                else hi = mid;
-            }
-            q = lo;
-            i = (int) (p - posBase[lo]);
+            const uint32_t qi = kPos[kidx];
+            q = qi >> 16;
+            i = (int) (qi & 0xFFFFu);
         }
     }
     // short lists: each lane copies its own; long lists: the wavefront copies them cooperatively
     const bool isLong = len > 8;
     if (len && !isLong) {
-        for (uint32_t x = 0; x < len; x++) {
-            const uint32_t sid = entrySeq[start + x];
-            const uint16_t d = (uint16_t) (i - (int) entryPos[start + x]);
-            hitKey[base + x] = (q << tBits) | sid;
-            hitVal[base + x] = ((uint32_t) (d & 0xFF) << 24) | (uint32_t) (base + x - qHitBase[q]);
-            hitDiag[base + x] = d;
+        // all (at most eight) entry reads are issued before the first is used
+        uint32_t sid[8];
+        uint16_t ep[8];
+        const uint32_t rel = (uint32_t) (base - qHitBase[q]);
+#pragma unroll
+        for (uint32_t x = 0; x < 8; x++) {
+            if (x < len) {
+                sid[x] = entrySeq[start + x];
+                ep[x] = entryPos[start + x];
+            }
+        }
+#pragma unroll
+        for (uint32_t x = 0; x < 8; x++) {
+            if (x < len) {
+                const uint16_t d = (uint16_t) (i - (int) ep[x]);
+                hitKey[base + x] = (q << tBits) | sid[x];
+                hitVal[base + x] = ((uint32_t) (d & 0xFF) << 24) | (rel + x);
+                hitDiag[base + x] = d;
+            }
         }
     }
     unsigned long long longMask = __ballot(isLong);
