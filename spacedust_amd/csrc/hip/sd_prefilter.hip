@@ -399,7 +399,7 @@ __device__ void pfBlockScan(uint32_t *arr, int n, uint32_t *part /* >= 5 */) {
 
 __global__ void __launch_bounds__(256)
 partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tBits, const uint32_t *__restrict__ inKey,
-                      const uint32_t *__restrict__ inVal, uint32_t *__restrict__ outKey, uint32_t *__restrict__ outVal,
+                      const uint32_t *__restrict__ inVal, uint2 *__restrict__ outKV /* (key, value) per hit */,
                       uint32_t *__restrict__ qLog2Bins, uint64_t *__restrict__ bktStart, uint32_t *__restrict__ bktCount,
                       int *__restrict__ flag) {
     __shared__ uint32_t cursor[PF_NB_MAX];          // segment histogram, then the running write position per bin
@@ -477,8 +477,7 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
             const uint32_t kk = tileK[j];
             const uint32_t b = (kk & tMask) >> shift;
             const uint64_t g = s + cursor[b] + ((uint32_t) j - pk16Get(tcount, b));
-            outKey[g] = kk;
-            outVal[g] = tileV[j];
+            outKV[g] = make_uint2(kk, tileV[j]);   // one 8-byte store per hit: the runs per bin are short
         }
         __syncthreads();
         for (int b = t; b < bins; b += 256) cursor[b] += pk16Get(tsize, b);
@@ -509,7 +508,7 @@ template <int NT, int CAP>
 __global__ void __launch_bounds__(NT)
 bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uint32_t *__restrict__ qLog2Bins, int tBits,
                     const uint64_t *__restrict__ bktStart, const uint32_t *__restrict__ bktCount,
-                    const uint32_t *__restrict__ inKey, const uint32_t *__restrict__ inVal, uint32_t *__restrict__ outKey,
+                    const uint2 *__restrict__ inKV, uint32_t *__restrict__ outKey,
                     uint32_t *__restrict__ outVal, uint32_t *__restrict__ bktEmit, int *__restrict__ flag,
                     const uint32_t *__restrict__ slotList, uint32_t *__restrict__ bigList, uint32_t *__restrict__ bigCount,
                     uint32_t bigCap) {
@@ -553,8 +552,9 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
     for (int x = 0; x < PER; x++) {
         const int j = x * NT + t;
         if (j < n) {
-            k[x] = inKey[start + j];
-            v[x] = inVal[start + j];
+            const uint2 kv = inKV[start + j];
+            k[x] = kv.x;
+            v[x] = kv.y;
             pk16Add(cnt, k[x] & offMask);
         }
     }
@@ -1194,12 +1194,14 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                 SD_HIP(ctx, dQBins.alloc(bq + 1));
                 SD_HIP(ctx, dBinBase.alloc(bq + 1));
                 SD_HIP(ctx, dFlag.alloc(1));
+                WsView<uint2> dKVB(ctx, "pf.dKVB");
+                SD_HIP(ctx, dKVB.alloc(nHits));
                 SD_HIP(ctx, hipMemsetAsync(dBktEmit.p, 0, (nSlots + 1) * sizeof(uint32_t), ctx->stream));
                 SD_HIP(ctx, hipMemsetAsync(dFlag.p, 0, sizeof(int), ctx->stream));
                 {
                     ProfScope ps(ctx, "prefilter_partition_hits");
                     hipLaunchKernelGGL(partition_hits_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, dQHitBase.p, tBits, dKeyA.p,
-                                       dValA.p, dKeyB.p, dValB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
+                                       dValA.p, dKVB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
                 }
                 hipLaunchKernelGGL(bin_count_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, dQLog2.p, dQBins.p);
                 int rc = exclusiveScanWiden(ctx, dQBins.p, dBinBase.p, bq + 1, scanTmp);
@@ -1218,8 +1220,8 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                     {
                         ProfScope ps(ctx, "prefilter_bucket_match");
                         hipLaunchKernelGGL((bucket_match_kernel<128, PF_BUCKET_CAP>), dim3((unsigned) totalBins), dim3(128), 0, ctx->stream,
-                                           bq, dBinBase.p, dQLog2.p, tBits, dBktStart.p, dBktCount.p, dKeyB.p, dValB.p, dKeyA.p, dValA.p,
-                                           dBktEmit.p, dFlag.p, (const uint32_t *) nullptr, dBigList.p, dBigCount, bigCap);
+                                           bq, dBinBase.p, dQLog2.p, tBits, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p,
+                                           dValA.p, dBktEmit.p, dFlag.p, (const uint32_t *) nullptr, dBigList.p, dBigCount, bigCap);
                     }
                     uint32_t nBig = 0;
                     SD_HIP(ctx, hipMemcpyAsync(&nBig, dBigCount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1227,7 +1229,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                     if (nBig > 0 && nBig <= bigCap) {   // the few buckets with one very hit-rich target (e.g. the query itself)
                         ProfScope ps(ctx, "prefilter_bucket_match_big");
                         hipLaunchKernelGGL((bucket_match_kernel<256, PF_BUCKET_CAP_BIG>), dim3(nBig), dim3(256), 0, ctx->stream, bq,
-                                           dBinBase.p, dQLog2.p, tBits, dBktStart.p, dBktCount.p, dKeyB.p, dValB.p, dKeyA.p, dValA.p,
+                                           dBinBase.p, dQLog2.p, tBits, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p, dValA.p,
                                            dBktEmit.p, dFlag.p, (const uint32_t *) dBigList.p, (uint32_t *) nullptr,
                                            (uint32_t *) nullptr, 0u);
                     }
