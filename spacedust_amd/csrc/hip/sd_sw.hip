@@ -691,12 +691,13 @@ int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, c
 // the ordering of tasks all happen on the GPU; the host only launches, reads six class boundaries per pass
 // and receives the finished result records + a dense backtrace pool.
 // ---------------------------------------------------------------------------------------------
-// score-pass task classes: 0-7 packed-int16 kernel with the five-bit row code, 8-15 the same with the wide row
-// code (rows: <=128, <=256, <=384, <=512, <=768, then 2 / 3 / more strips of 512 rows), 16-19 int32 kernel
-// (rows: <=128, <=256, <=512, more)
-constexpr uint32_t N_SCORE_CLASSES = 20;
-constexpr uint32_t FIRST_WIDE_CLASS = 8;
-constexpr uint32_t FIRST_INT32_CLASS = 16;
+// score-pass task classes: 0-10 packed-int16 kernel with the five-bit row code, 11-21 the same with the wide row
+// code (rows: <=128, <=192, <=256, <=320, <=384, <=512, <=640, <=768, then 2 / 3 / more strips of 512 rows),
+// 22-25 int32 kernel (rows: <=128, <=256, <=512, more)
+constexpr uint32_t N_PK_CLASSES = 11;
+constexpr uint32_t N_SCORE_CLASSES = 2 * N_PK_CLASSES + 4;
+constexpr uint32_t FIRST_WIDE_CLASS = N_PK_CLASSES;
+constexpr uint32_t FIRST_INT32_CLASS = 2 * N_PK_CLASSES;
 enum ScoreKernel { SCORE_PK = 0, SCORE_PK_WIDE = 1, SCORE_INT32 = 2 };
 constexpr uint32_t KEY_INVALID = N_SCORE_CLASSES * 1024u;   // sorts after every class
 __device__ __forceinline__ uint32_t scoreKey(int n, int tL, int kernel) {
@@ -706,8 +707,9 @@ __device__ __forceinline__ uint32_t scoreKey(int n, int tL, int kernel) {
     if (kernel == SCORE_INT32 || tL > 65535) {
         ci = FIRST_INT32_CLASS + (n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3)));
     } else {
-        if (n <= 768) ci = n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 384 ? 2 : (n <= 512 ? 3 : 4)));
-        else ci = min(5 + (n + 511) / 512 - 2, 7);   // 2 strips -> 5, 3 strips -> 6, more -> 7
+        if (n <= 384) ci = (n + 63) / 64 < 2 ? 0 : (n + 63) / 64 - 2;   // 128, 192, 256, 320, 384 rows -> 0..4
+        else if (n <= 768) ci = n <= 512 ? 5 : (n <= 640 ? 6 : 7);
+        else ci = min(8 + (n + 511) / 512 - 2, 10);   // 2 strips -> 8, 3 strips -> 9, more -> 10
         if (kernel == SCORE_PK_WIDE) ci += FIRST_WIDE_CLASS;
     }
     return (uint32_t) ci * 1024u + (uint32_t) (1023 - min(tL >> 4, 1023));
@@ -1003,7 +1005,7 @@ k_bound_need(uint32_t nPairs, const SwTask *__restrict__ tasks, const uint32_t *
     uint64_t v = 0;
     if (keys[i] != KEY_INVALID) {
         const uint32_t ci = keys[i] >> 10;
-        if (ci < FIRST_INT32_CLASS && (ci & 7) >= 5) v = 2ull * (uint64_t) tasks[i].tL;
+        if (ci < FIRST_INT32_CLASS && (ci % N_PK_CLASSES) >= 8) v = 2ull * (uint64_t) tasks[i].tL;
         else if (ci == N_SCORE_CLASSES - 1 && tasks[i].n > 1024) v = (uint64_t) tasks[i].tL;
     }
     need[i] = v;
@@ -1041,33 +1043,40 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
     for (uint32_t ci = 0; ci < N_SCORE_CLASSES; ci++) {
         const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
         if (cnt == 0) continue;
-        static const char *const names[N_SCORE_CLASSES] = {
-            "sw_score_pk.rt4x32", "sw_score_pk.rt8x32", "sw_score_pk.rt12x32", "sw_score_pk.rt8x64", "sw_score_pk.rt12x64",
-            "sw_score_pk.rt8x64s2", "sw_score_pk.rt8x64s3", "sw_score_pk.rt8x64sN",
-            "sw_score_pk.w_rt4x32", "sw_score_pk.w_rt8x32", "sw_score_pk.w_rt12x32", "sw_score_pk.w_rt8x64", "sw_score_pk.w_rt12x64",
-            "sw_score_pk.w_rt8x64s2", "sw_score_pk.w_rt8x64s3", "sw_score_pk.w_rt8x64sN",
-            "sw_score.rt4", "sw_score.rt8", "sw_score.rt16", "sw_score.rt32"};
-        ProfScope ps(ctx, names[ci]);
+        static const char *const pkNames[N_PK_CLASSES] = {"rt4x32", "rt6x32", "rt8x32", "rt10x32", "rt12x32", "rt8x64", "rt10x64",
+                                                          "rt12x64", "rt8x64s2", "rt8x64s3", "rt8x64sN"};
+        static const char *const i32Names[4] = {"sw_score.rt4", "sw_score.rt8", "sw_score.rt16", "sw_score.rt32"};
+        char name[48];
+        if (ci < FIRST_INT32_CLASS) snprintf(name, sizeof(name), "sw_score_pk.%s%s", ci >= FIRST_WIDE_CLASS ? "w_" : "", pkNames[ci % N_PK_CLASSES]);
+        else snprintf(name, sizeof(name), "%s", i32Names[ci - FIRST_INT32_CLASS]);
+        ProfScope ps(ctx, name);
         const uint32_t *ord = dOrder + begin;
 #define SD_PK(RT, LW, MULTI, WIDE) launchScorePk<RT, LW, MULTI, WIDE>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound)
-        switch (ci) {
-            case 0: SD_PK(4, 32, false, false); break;
-            case 1: SD_PK(8, 32, false, false); break;
-            case 2: SD_PK(12, 32, false, false); break;
-            case 3: SD_PK(8, 64, false, false); break;
-            case 4: SD_PK(12, 64, false, false); break;
-            case 5: case 6: case 7: SD_PK(8, 64, true, false); break;
-            case 8: SD_PK(4, 32, false, true); break;
-            case 9: SD_PK(8, 32, false, true); break;
-            case 10: SD_PK(12, 32, false, true); break;
-            case 11: SD_PK(8, 64, false, true); break;
-            case 12: SD_PK(12, 64, false, true); break;
-            case 13: case 14: case 15: SD_PK(8, 64, true, true); break;
-            case 16: launchScoreIdx<4>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 17: launchScoreIdx<8>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            case 18: launchScoreIdx<16>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
-            default: launchScoreIdx<32>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+#define SD_PK_CLASS(WIDE)                                                     \
+        switch (ci % N_PK_CLASSES) {                                          \
+            case 0: SD_PK(4, 32, false, WIDE); break;                         \
+            case 1: SD_PK(6, 32, false, WIDE); break;                         \
+            case 2: SD_PK(8, 32, false, WIDE); break;                         \
+            case 3: SD_PK(10, 32, false, WIDE); break;                        \
+            case 4: SD_PK(12, 32, false, WIDE); break;                        \
+            case 5: SD_PK(8, 64, false, WIDE); break;                         \
+            case 6: SD_PK(10, 64, false, WIDE); break;                        \
+            case 7: SD_PK(12, 64, false, WIDE); break;                        \
+            default: SD_PK(8, 64, true, WIDE); break;                         \
         }
+        if (ci < FIRST_WIDE_CLASS) {
+            SD_PK_CLASS(false)
+        } else if (ci < FIRST_INT32_CLASS) {
+            SD_PK_CLASS(true)
+        } else {
+            switch (ci - FIRST_INT32_CLASS) {
+                case 0: launchScoreIdx<4>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+                case 1: launchScoreIdx<8>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+                case 2: launchScoreIdx<16>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+                default: launchScoreIdx<32>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
+            }
+        }
+#undef SD_PK_CLASS
 #undef SD_PK
     }
     SD_HIP(ctx, hipGetLastError());

@@ -117,10 +117,12 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                    int go, int ge, int32_t *__restrict__ out, uint2 *__restrict__ boundary,
                    const uint32_t *__restrict__ order) {
     constexpr int ROWS = LW * RT;
-    constexpr int WORDS = RT / 4;
+    constexpr int WORDS = (RT + 3) / 4;    // profile dwords per lane, pair and residue (RT need not be a multiple of 4:
+    constexpr int RTP = 4 * WORDS;         //  the bytes past RT in the last dword are padding)
+    constexpr int PSTRIDE = LW * WORDS;    // dwords per residue row of a profile
     constexpr int NGRP = 64 / LW;
     constexpr int NT = 2 * NGRP;   // tasks per wavefront
-    __shared__ uint32_t prof[NT][22][ROWS / 4];
+    __shared__ uint32_t prof[NT][22][PSTRIDE];
     __shared__ int8_t smat[441];
     for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
     __syncthreads();
@@ -162,7 +164,7 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
     for (int strip = 0; strip < nStrips; strip++) {
         const int q0 = strip * ROWS + l * RT;
         // ---- query profiles of this strip (SmithWaterman::createQueryProfile, :163-187) and the lazy-F reset rows
-        uint32_t mask[RT];
+        uint32_t mask[RTP];
         if (strip > 0) __syncthreads();   // the previous strip's profile reads are done
 #pragma unroll
         for (int x = 0; x < 2; x++) {
@@ -176,7 +178,7 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const int qi = q0 + 4 * w + b;
-                    valid[b] = qi < T.n;
+                    valid[b] = (4 * w + b < RT) && qi < T.n;
                     res[b] = 20;
                     cb[b] = 0;
                     if (valid[b]) {
@@ -197,16 +199,16 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                         const int v = valid[b] ? (int) smat[a * 21 + res[b]] + cb[b] : -64;
                         word |= (uint32_t) (uint8_t) (int8_t) v << (8 * b);
                     }
-                    pw[a * (ROWS / 4) + w] = word;
+                    pw[a * PSTRIDE + w] = word;
                 }
-                pw[PK_NEUTRAL * (ROWS / 4) + w] = 0xC0C0C0C0u;
+                pw[PK_NEUTRAL * PSTRIDE + w] = 0xC0C0C0C0u;
             }
         }
         __syncthreads();
 
-        uint32_t H[RT], E[RT];
+        uint32_t H[RTP], E[RTP];
 #pragma unroll
-        for (int r = 0; r < RT; r++) {
+        for (int r = 0; r < RTP; r++) {
             H[r] = 0;
             E[r] = 0;
         }
@@ -267,9 +269,9 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                     inFl = writeLane<32>(0, inFl);
                 }
                 curT = inT;
-                const uint32_t *pa = profA + (curT & 0xFFu) * (ROWS / 4);
-                const uint32_t *pb = profB + (curT >> 8) * (ROWS / 4);
-                uint32_t h[RT];
+                const uint32_t *pa = profA + (curT & 0xFFu) * PSTRIDE;
+                const uint32_t *pb = profB + (curT >> 8) * PSTRIDE;
+                uint32_t h[RTP];
 #pragma unroll
                 for (int w = 0; w < WORDS; w++) {
                     const uint32_t d0 = (w == 0) ? prevInG : H[4 * w - 1];
