@@ -187,8 +187,17 @@ def main():
     else:
         alg, per = 17 * int(summary[1]) + 4 * int(summary[1]), grouped.get(dom, dict(ms=1, launches=1))
     achieved = (alg / max(per['launches'], 1)) / ((per['ms'] / max(per['launches'], 1)) * 1e-3) / 1e9 if per['ms'] > 0 else 0.0
+    # HBM traffic per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs, tools/pmc_summary.py; chunk size 30000 there, so launches are ~3x larger than here)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        if dom in pmc:
+            traffic = pmc[dom]['bytes_per_launch'] * (pmc[dom]['launches'] / max(per['launches'] / max(args.steps, 1), 1))
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
-                    traffic=None, launches=per['launches'], avg_launch_ms=per['ms'] / max(per['launches'], 1),
+                    traffic=traffic, launches=per['launches'], avg_launch_ms=per['ms'] / max(per['launches'], 1),
                     note=('the score pass is integer-VALU bound (DP state lives in VGPR/LDS): see sw_valu; '
                           'algorithmic bytes = residue streams only') if dom.startswith('sw_score') else 'algorithmic bytes per SURVEY.md 8(d)')
     # VALU view of the score pass: lane-instructions of the inner loop per DP cell (counted in the gfx950 ISA of the
@@ -208,7 +217,7 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'int32',
+        'dtype': 'int16',
         'data': 'synthetic',
         'config': {'workload': '%d synthetic proteomes x %d proteins (len~300) all-vs-all, clustersearch --search-mode 0 '
                                '--filter-self-match --max-seqs %d; step = %d query proteomes vs all %d targets'

@@ -54,3 +54,24 @@ def test_host_stages_match_oracle(host, oracle, small_proteomes):
     assert host.kmer_threshold(5.7, 6) == 112 and host.bin_size(5898, 2 << 20) == 2 and host.bin_size(10 ** 7, 2 << 20) == 8
     lg = host.lgamma_table(10)
     assert abs(lg[5] - np.log(24.0)) < 1e-10 and np.isinf(lg[0])
+
+
+def test_pair_list_and_cpu_quota():
+    import ctypes as C
+    from spacedust_amd import _lib
+    from spacedust_amd._lib import ptr
+    from spacedust_amd.cpus import effective_cpus
+    L = _lib.load()
+    rng = np.random.default_rng(2)
+    nq, w = 37, 11
+    hits = np.zeros((nq, w), _lib.HIT_DTYPE)
+    hits['seqId'] = rng.integers(0, 1000, (nq, w))
+    cnt = rng.integers(0, w + 1, nq).astype(np.uint32)
+    n = int(cnt.sum())
+    assert L.sd_host_pair_list(ptr(hits), ptr(cnt), nq, w, None, None) == n
+    pq, pt = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    assert L.sd_host_pair_list(ptr(hits), ptr(cnt), nq, w, ptr(pq), ptr(pt)) == n
+    exp_q = np.repeat(np.arange(nq, dtype=np.uint32), cnt)
+    exp_t = np.concatenate([hits['seqId'][q, :cnt[q]] for q in range(nq)]).astype(np.uint32)
+    assert np.array_equal(pq, exp_q) and np.array_equal(pt, exp_t)
+    assert 1 <= effective_cpus() <= (os.cpu_count() or 1)

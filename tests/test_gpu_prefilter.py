@@ -71,3 +71,27 @@ def test_prefilter_examples_md5(gpu, host):
     assert len(lines) == 98957
     lines.sort(key=lambda s: s.encode())
     assert hashlib.md5(''.join(lines).encode()).hexdigest() == '8109a70bdea70ee10e0dbd27ba6b7e37'
+
+
+def test_prefilter_bucket_path_equals_sort_path(gpu, host, monkeypatch):
+    """the bucketed LDS match (default) and the global-radix-sort fallback give identical hit tables, at a size
+    where queries span many target-range buckets and long queries overflow the small bucket capacity"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=12, genes_per_proteome=900, n_families=1400, seed=91)
+    ident = np.arange(ps.n, dtype=np.uint32)
+    sw_b, dg_b, km_b = host.comp_bias(ps.residues, ps.offsets)
+    idx = host.build_index(ps.residues, ps.offsets)
+    tgt = api.Target(gpu, host, idx)
+    par = api.prefilter_params(host, idx.n, max_hits=300, cov_thr=0.8, bin_size=None)
+    nq = 3000
+    res = ps.residues[:int(ps.offsets[nq])]
+    off = ps.offsets[:nq + 1]
+    a = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)
+    monkeypatch.setenv('SD_PF_SORT', '1')
+    b = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)
+    assert np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2])
+    for q in range(nq):
+        n = int(a[1][q])
+        assert np.array_equal(a[0][q, :n], b[0][q, :n]), q
+    assert int(a[1].sum()) > 50000

@@ -139,3 +139,25 @@ def test_sw_device_vs_host_orchestration(gpu, host):
             sa = pa[int(a['btOffset'][x]):int(a['btOffset'][x]) + int(a['btLen'][x])]
             sb = pb[int(b['btOffset'][x]):int(b['btOffset'][x]) + int(b['btLen'][x])]
             assert np.array_equal(sa, sb), x
+
+
+def test_sw_packed_kernel_equals_int32_kernel(gpu, host, monkeypatch):
+    """the packed-int16 score kernels (all row classes, 32- and 64-lane variants, wide row code) against the int32
+    kernel on the same pairs, through the full align call"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=5, genes_per_proteome=400, n_families=600, seed=5, mean_len=330)
+    rng = np.random.default_rng(17)
+    pq, pt = _pairs(ps, rng, 6000)
+    sw_bias, _, _ = host.comp_bias(ps.residues, ps.offsets)
+    mat, _, _ = host.matrix(0)
+    db = int(ps.offsets[-1])
+    ss = gpu.seqset(ps.residues, ps.offsets, sw_bias)
+    par = gpu.sw_params(mat, db)
+    ident = (pq == pt)
+    a, pa = gpu.sw_align(par, ss, ss, pq, pt, identity=ident)
+    monkeypatch.setenv('SD_SW_INT32', '1')
+    b, pb = gpu.sw_align(par, ss, ss, pq, pt, identity=ident)
+    for f in ('score', 'qStart', 'qEnd', 'tStart', 'tEnd', 'identical', 'btLen', 'flags', 'evalue'):
+        assert np.array_equal(a[f], b[f]), (f, np.flatnonzero(a[f] != b[f])[:5])
+    lens = (ps.offsets[1:] - ps.offsets[:-1])[pq]
+    assert lens.min() <= 128 and lens.max() > 768   # every row class is exercised
