@@ -101,19 +101,26 @@ def main():
     n_batches = (P + B - 1) // B
     set_start = ps.set_start
 
-    def run_step(step_idx, keep=False):
+    def step_range(step_idx):
         b = (rank * (args.steps + args.warmup) + step_idx) % n_batches
         s0, s1 = b * B, min(P, (b + 1) * B)
-        out = cs.search(db, same_db=True, query_range=(int(set_start[s0]), int(set_start[s1])), chunk_queries=args.chunk)
-        if keep and out['cluster_out'] is not None:
+        return (int(set_start[s0]), int(set_start[s1])), (s1 - s0) * P
+
+    def run_steps(step_ids, keep=False):
+        """the given steps (one batch of query proteomes each) streamed through the pipeline: every step gets its own
+        aggregation / clusterhits / result, and the prefilter of step k+1 overlaps the alignments of step k"""
+        rngs = [step_range(x) for x in step_ids]
+        outs = cs.search_stream(db, [r for r, _ in rngs], same_db=True, chunk_queries=args.chunk)
+        if keep and outs and outs[-1]['cluster_out'] is not None:
+            out = outs[-1]
             hq, ht = out['hit_q'], out['hit_t']
             cs.last_entries = (out['entry_off'], db.pos_in_set[hq], db.pos_in_set[ht],
                                (db.strand[hq] | (db.strand[ht] << 1)).astype(np.uint8),
                                np.zeros(len(hq)) + 1e-30, db.set_size[out['entry_q']])
-        return (s1 - s0) * P, out
+        return sum(n for _, n in rngs), outs
 
-    for w in range(args.warmup):
-        run_step(w)
+    if args.warmup:
+        run_steps(list(range(args.warmup)))
     gpu.profile(True)
     cs.ctx_al.profile(True)
     for k in cs.stats:
@@ -127,9 +134,8 @@ def main():
     q_len_sum = 0
     summary = np.zeros(4, np.int64)
     stage = {}
-    for k in range(args.steps):
-        n, out = run_step(args.warmup + k, keep=(k == args.steps - 1))
-        pairs_done += n
+    pairs_done, outs = run_steps([args.warmup + k for k in range(args.steps)], keep=True)
+    for out in outs:
         summary += np.array([out['entries'], out['matched_hits'], out['clusters'], out['cluster_hits']], np.int64)
         for s, v in out['timing'].items():
             stage[s] = stage.get(s, 0.0) + v

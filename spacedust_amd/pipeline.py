@@ -93,24 +93,36 @@ class ClusterSearch:
 
     def search(self, Q, same_db=False, chunk_queries=10000, tsv_path=None, canonical=True, query_range=None):
         """run the workflow for query set DB Q (optionally only proteins [a,b) = a shard of whole query sets)."""
+        rng = query_range if query_range is not None else (0, Q.n)
+        return self.search_stream(Q, [rng], same_db=same_db, chunk_queries=chunk_queries, tsv_paths=[tsv_path],
+                                  canonical=canonical)[0]
+
+    def search_stream(self, Q, ranges, same_db=False, chunk_queries=10000, tsv_paths=None, canonical=True):
+        """The workflow for several query ranges [a,b) of Q (whole query sets each), streamed through one pipeline:
+        the prefilter of the next chunk -- of the same or of the next range -- overlaps the alignments of the current
+        one.  Every range gets its own aggregation, clusterhits call and result record, exactly as separate search()
+        calls would produce.  Returns the list of result dicts (stage timings, summed over the stream, ride on the last)."""
         L = self.ctx.L
         T = self.T
-        a0, b0 = query_range if query_range is not None else (0, Q.n)
         t_all = time.time()
-        agg = C.c_void_p()
         tl = T.lengths().astype(np.int32)
         qlens = Q.lengths().astype(np.int32)
-        api._check(None, L.sd_agg_create(ptr(Q.set_id), ptr(qlens), Q.n, ptr(T.set_id), ptr(tl), T.n, Q.n_sets, T.n_sets,
-                                         self.eval_thr,
-                                         self.cov_mode, self.cov_thr, self.aln_len_thr, 1 if self.filter_self_match else 0,
-                                         C.byref(agg)), 'sd_agg_create')
+        tsv_paths = tsv_paths if tsv_paths is not None else [None] * len(ranges)
+        aggs = []
+        for _ in ranges:
+            agg = C.c_void_p()
+            api._check(None, L.sd_agg_create(ptr(Q.set_id), ptr(qlens), Q.n, ptr(T.set_id), ptr(tl), T.n, Q.n_sets, T.n_sets,
+                                             self.eval_thr, self.cov_mode, self.cov_thr, self.aln_len_thr,
+                                             1 if self.filter_self_match else 0, C.byref(agg)), 'sd_agg_create')
+            aggs.append(agg)
         tm = dict(prefilter=0.0, align=0.0, aggregate=0.0, clusterhits=0.0, bias=0.0, aggregate_busy=0.0)
-        # the host-side aggregation of chunk i runs on a worker thread while the GPU stages of chunk i+1 run
-        # (ctypes releases the GIL); one job in flight keeps the order of sd_agg_add calls and bounds memory
+        # three threads: bias + prefilter + pair list of chunk i+1 (context A) | alignments of chunk i (context B, this
+        # thread) | host aggregation of chunk i-1.  ctypes releases the GIL; one aggregation job in flight keeps the
+        # order of sd_agg_add calls and bounds memory (the alignment results live in two alternating buffers).
         pool_exec = ThreadPoolExecutor(max_workers=1)
         pending = None
 
-        def aggregate_job(n_pairs, pair_q_local, pair_t, r, identity, pool, c0):
+        def aggregate_job(agg, n_pairs, pair_q_local, pair_t, r, identity, pool, c0):
             t1 = time.time()
             idt = np.ascontiguousarray(identity, np.uint8)
             api._check(None, L.sd_agg_add(agg, n_pairs, c0, ptr(pair_q_local), ptr(pair_t), ptr(r), ptr(idt), ptr(pool)),
@@ -143,14 +155,72 @@ class ClusterSearch:
             return dict(c0=c0, c1=c1, res=res, off=off, sw_b=sw_b, st=st, n_pairs=n_pairs, pair_q_local=pair_q_local,
                         pair_t=pair_t, t=t)
 
-        chunks = [(c0, min(b0, c0 + chunk_queries)) for c0 in range(a0, b0, chunk_queries)]
+        def finalize(ri):
+            """aggregation result of range ri -> clusterhits -> result record (alignment thread, context B)"""
+            agg = aggs[ri]
+            t0 = time.time()
+            ne, nh = C.c_uint64(), C.c_uint64()
+            L.sd_agg_finish(agg, C.byref(ne), C.byref(nh))
+            ne, nh = ne.value, nh.value
+            entry_off = np.zeros(ne + 1, np.uint64)
+            eq = np.zeros(max(ne, 1), np.uint32)
+            et = np.zeros(max(ne, 1), np.uint32)
+            hq = np.zeros(max(nh, 1), np.uint32)
+            ht = np.zeros(max(nh, 1), np.uint32)
+            pv = np.zeros(max(nh, 1), np.float64)
+            L.sd_agg_get(agg, ptr(entry_off), ptr(eq), ptr(et), ptr(hq), ptr(ht), ptr(pv))
+            hq, ht, pv, eq, et = hq[:nh], ht[:nh], pv[:nh], eq[:ne], et[:ne]
+            tm['aggregate'] += time.time() - t0
+            t0 = time.time()
+            out = None
+            n_clusters = n_cluster_hits = 0
+            if nh > 0:
+                qp = Q.pos_in_set[hq]
+                tp = T.pos_in_set[ht]
+                sd = (Q.strand[hq] | (T.strand[ht] << 1)).astype(np.uint8)
+                nq = Q.set_size[eq]
+                lg_n = int(max(int(Q.set_size.max()), int(T.set_size.max()), int(qp.max()), int(tp.max()))) + 8
+                out = api.clusterhits(self.ctx_al, self.host, entry_off, qp, tp, sd, pv, nq, lgamma=self.host.lgamma_table(lg_n),
+                                      **self.ch)
+                n_clusters = int(out['n_clusters'].sum())
+                n_cluster_hits = int((out['cluster_of'] != 0xFFFFFFFF).sum())
+            tm['clusterhits'] += time.time() - t0
+            if tsv_paths[ri] is not None and out is not None:
+                Q.default_names()
+                T.default_names()
+                qn, qno = _pack_strings(Q.names)
+                tn, tno = _pack_strings(T.names)
+                qs, qso = _pack_strings(Q.sources)
+                ts, tso = _pack_strings(T.sources)
+                nc, nhl = C.c_uint64(), C.c_uint64()
+                api._check(None, L.sd_agg_write_tsv(agg, tsv_paths[ri].encode(), ptr(out['cluster_of']), ptr(out['rank']),
+                                                    ptr(out['n_clusters']), ptr(out['pCO']), ptr(out['pMH']), ptr(out['size']),
+                                                    qn, ptr(qno), tn, ptr(tno), qs, ptr(qso), ts, ptr(tso),
+                                                    1 if canonical else 0, C.byref(nc), C.byref(nhl)), 'sd_agg_write_tsv')
+            na, nacc = C.c_uint64(), C.c_uint64()
+            L.sd_agg_stats(agg, C.byref(na), C.byref(nacc))
+            L.sd_agg_destroy(agg)
+            return dict(entries=ne, matched_hits=nh, clusters=n_clusters, cluster_hits=n_cluster_hits, aligned=na.value,
+                        accepted=nacc.value, timing={}, entry_q=eq, entry_t=et, entry_off=entry_off, cluster_out=out,
+                        hit_q=hq, hit_t=ht)
+
+        chunks = []
+        for ri, (a0, b0) in enumerate(ranges):
+            cs_ = [(ri, c0, min(b0, c0 + chunk_queries)) for c0 in range(a0, b0, chunk_queries)]
+            chunks += cs_
+        last_chunk_of = {}
+        for x, (ri, _, _) in enumerate(chunks):
+            last_chunk_of[ri] = x
+        results = [None] * len(ranges)
+        to_finalize = []   # (range, its last aggregation job)
         pf_exec = ThreadPoolExecutor(max_workers=1)
-        pf_next = pf_exec.submit(prefilter_job, *chunks[0]) if chunks else None
+        pf_next = pf_exec.submit(prefilter_job, chunks[0][1], chunks[0][2]) if chunks else None
         for ci in range(len(chunks)):
+            ri = chunks[ci][0]
             t0 = time.time()
             d = pf_next.result()
             tm['prefilter_wait'] = tm.get('prefilter_wait', 0.0) + time.time() - t0
-            pf_next = pf_exec.submit(prefilter_job, *chunks[ci + 1]) if ci + 1 < len(chunks) else None
+            pf_next = pf_exec.submit(prefilter_job, chunks[ci + 1][1], chunks[ci + 1][2]) if ci + 1 < len(chunks) else None
             for k_, v_ in d['t'].items():
                 tm[k_] = tm.get(k_, 0.0) + v_
             st, n_pairs, c0, c1 = d['st'], d['n_pairs'], d['c0'], d['c1']
@@ -159,83 +229,47 @@ class ClusterSearch:
             self.stats['diagonals'] += int(st[:, 2].sum())
             self.stats['diag_len'] += int(st[:, 3].sum())
             self.stats['prefilter_hits'] += n_pairs
-            if n_pairs == 0:
-                continue
-            pair_q_local, pair_t = d['pair_q_local'], d['pair_t']
-            t0 = time.time()
-            qset = self.ctx_al.seqset(d['res'], d['off'], d['sw_b'])
-            tm['seqset'] = tm.get('seqset', 0.0) + time.time() - t0
-            t0 = time.time()
-            identity = (pair_q_local + np.uint32(c0) == pair_t) if same_db else np.zeros(n_pairs, bool)
-            r, pool = self.ctx_al.sw_align(self.sw_par, qset, self.t_seqs, pair_q_local, pair_t, identity=identity, reuse=True)
-            tm['align'] += time.time() - t0
-            f, rv, tb = self.ctx_al.sw_cells()
-            self.stats['cells_fwd'] += f
-            self.stats['cells_rev'] += rv
-            self.stats['cells_tb'] += tb
-            self.stats['pairs'] += n_pairs
-            t0 = time.time()
-            if pending is not None:
-                tm['aggregate_busy'] += pending.result()
-            pending = pool_exec.submit(aggregate_job, n_pairs, pair_q_local, pair_t, r, identity, pool, c0)
-            tm['aggregate'] += time.time() - t0
-            del qset
+            if n_pairs > 0:
+                pair_q_local, pair_t = d['pair_q_local'], d['pair_t']
+                t0 = time.time()
+                qset = self.ctx_al.seqset(d['res'], d['off'], d['sw_b'])
+                tm['seqset'] = tm.get('seqset', 0.0) + time.time() - t0
+                t0 = time.time()
+                identity = (pair_q_local + np.uint32(c0) == pair_t) if same_db else np.zeros(n_pairs, bool)
+                r, pool = self.ctx_al.sw_align(self.sw_par, qset, self.t_seqs, pair_q_local, pair_t, identity=identity, reuse=True)
+                tm['align'] += time.time() - t0
+                f, rv, tb = self.ctx_al.sw_cells()
+                self.stats['cells_fwd'] += f
+                self.stats['cells_rev'] += rv
+                self.stats['cells_tb'] += tb
+                self.stats['pairs'] += n_pairs
+                t0 = time.time()
+                if pending is not None:
+                    tm['aggregate_busy'] += pending.result()
+                pending = pool_exec.submit(aggregate_job, aggs[ri], n_pairs, pair_q_local, pair_t, r, identity, pool, c0)
+                tm['aggregate'] += time.time() - t0
+                del qset
+            if last_chunk_of[ri] == ci:
+                to_finalize.append((ri, pending))
+            # ranges whose last aggregation job has finished meanwhile
+            while to_finalize and (to_finalize[0][1] is None or to_finalize[0][1].done()):
+                fri, _ = to_finalize.pop(0)
+                results[fri] = finalize(fri)
         pf_exec.shutdown()
         t0 = time.time()
         if pending is not None:
             tm['aggregate_busy'] += pending.result()
-        pool_exec.shutdown()
-        ne, nh = C.c_uint64(), C.c_uint64()
-        L.sd_agg_finish(agg, C.byref(ne), C.byref(nh))
-        ne, nh = ne.value, nh.value
-        entry_off = np.zeros(ne + 1, np.uint64)
-        eq = np.zeros(max(ne, 1), np.uint32)
-        et = np.zeros(max(ne, 1), np.uint32)
-        hq = np.zeros(max(nh, 1), np.uint32)
-        ht = np.zeros(max(nh, 1), np.uint32)
-        pv = np.zeros(max(nh, 1), np.float64)
-        L.sd_agg_get(agg, ptr(entry_off), ptr(eq), ptr(et), ptr(hq), ptr(ht), ptr(pv))
-        hq, ht, pv, eq, et = hq[:nh], ht[:nh], pv[:nh], eq[:ne], et[:ne]
         tm['aggregate'] += time.time() - t0
-        t0 = time.time()
-        out = None
-        n_clusters = n_cluster_hits = 0
-        dbg = os.environ.get('SD_DEBUG_TIMING') is not None
-        if nh > 0:
-            qp = Q.pos_in_set[hq]
-            tp = T.pos_in_set[ht]
-            sd = (Q.strand[hq] | (T.strand[ht] << 1)).astype(np.uint8)
-            nq = Q.set_size[eq]
-            lg_n = int(max(int(Q.set_size.max()), int(T.set_size.max()), int(qp.max()), int(tp.max()))) + 8
-            t1 = time.time()
-            lg = self.host.lgamma_table(lg_n)
-            t2 = time.time()
-            out = api.clusterhits(self.ctx, self.host, entry_off, qp, tp, sd, pv, nq, lgamma=lg, **self.ch)
-            if dbg:
-                print('[clusterhits] gather %.1f ms, lgamma(%d) %.1f ms, call %.1f ms' % ((t1 - t0) * 1e3, lg_n, (t2 - t1) * 1e3,
-                                                                                       (time.time() - t2) * 1e3), file=sys.stderr)
-            n_clusters = int(out['n_clusters'].sum())
-            n_cluster_hits = int((out['cluster_of'] != 0xFFFFFFFF).sum())
-        tm['clusterhits'] += time.time() - t0
-        if tsv_path is not None and out is not None:
-            Q.default_names()
-            T.default_names()
-            qn, qno = _pack_strings(Q.names)
-            tn, tno = _pack_strings(T.names)
-            qs, qso = _pack_strings(Q.sources)
-            ts, tso = _pack_strings(T.sources)
-            nc, nhl = C.c_uint64(), C.c_uint64()
-            api._check(None, L.sd_agg_write_tsv(agg, tsv_path.encode(), ptr(out['cluster_of']), ptr(out['rank']),
-                                                ptr(out['n_clusters']), ptr(out['pCO']), ptr(out['pMH']), ptr(out['size']),
-                                                qn, ptr(qno), tn, ptr(tno), qs, ptr(qso), ts, ptr(tso),
-                                                1 if canonical else 0, C.byref(nc), C.byref(nhl)), 'sd_agg_write_tsv')
-        na, nacc = C.c_uint64(), C.c_uint64()
-        L.sd_agg_stats(agg, C.byref(na), C.byref(nacc))
-        L.sd_agg_destroy(agg)
+        pool_exec.shutdown()
+        for fri, _ in to_finalize:
+            results[fri] = finalize(fri)
+        for ri in range(len(ranges)):   # ranges without any chunk
+            if results[ri] is None:
+                results[ri] = finalize(ri)
         tm['total'] = time.time() - t_all
-        return dict(entries=ne, matched_hits=nh, clusters=n_clusters, cluster_hits=n_cluster_hits, aligned=na.value,
-                    accepted=nacc.value, timing=tm, entry_q=eq, entry_t=et, entry_off=entry_off, cluster_out=out,
-                    hit_q=hq, hit_t=ht)
+        if results:
+            results[-1]['timing'] = tm
+        return results
 
 
 def shard_query_sets(set_residues, world, rank):
