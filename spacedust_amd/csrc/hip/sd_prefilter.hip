@@ -764,11 +764,12 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
                    const uint64_t *__restrict__ qHitBase, int tBits,
                    uint32_t binMask, int maxHits, int minDiag, const uint32_t *__restrict__ identityId,
                    const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, int covMode, float covThr,
+                   const uint8_t *__restrict__ qRes, const int8_t *__restrict__ diagBias, const int8_t *__restrict__ mat,
                    sd_hit *__restrict__ outHits, uint32_t *__restrict__ outCount, int *__restrict__ errFlag) {
     __shared__ unsigned long long keys[SEL_CAP];
     __shared__ uint32_t pay[SEL_CAP];
     __shared__ unsigned int hist[256];
-    __shared__ int sThr, sCnt;
+    __shared__ int sThr, sCnt, sMaxSelf;
     const uint32_t q = blockIdx.x;
     if (q >= nQ) return;
     const uint32_t beg = kStartOfQ[q], end = kStartOfQ[q + 1];
@@ -789,7 +790,6 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
         thr = max(minDiag, thr);
         sThr = thr;
         sCnt = 0;
-        if (thr >= 255) atomicExch(errFlag, 1);   // rescoring path (QueryMatcher.cpp:163-170) not on the device
     }
     __syncthreads();
     const int thr = sThr;
@@ -818,6 +818,39 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
     for (int x = n + threadIdx.x; x < np2; x += blockDim.x) { keys[x] = ~0ull; pay[x] = 0xFFFFFFFFu; }
     __syncthreads();
     if (np2 > 1) bitonicSort(keys, pay, np2);
+    // Truncated scores (QueryMatcher.cpp:157-170): when the cut itself is the saturated 8-bit score, the reference
+    // rescales the true diagonal scores of the saturated hits against the query's self score (rescoreHits, :525-544),
+    // re-sorts them by the rescaled byte (stable) and reports 255 + byte * maxSelf / 255.
+    const bool rescored = thr >= 255;
+    auto rescaledByte = [&](uint32_t e) -> uint32_t {
+        unsigned int ns = (unsigned int) kScore[e] - 255u;
+        const float sc = (float) min(ns, 65535u);
+        const double dv = (double) ((sc / (float) sMaxSelf) * 255.0f) + 0.5;
+        return (uint32_t) (uint8_t) (int) dv;
+    };
+    if (rescored) {
+        if (threadIdx.x == 0) {
+            // self score: the query against itself on diagonal 0 (UngappedAlignment::scoreSingleSequence)
+            const uint8_t *qs = qRes + qOff[q];
+            const int8_t *qb = diagBias + qOff[q];
+            const int qL = (int) (qOff[q + 1] - qOff[q]);
+            int score = 0, best = 0;
+            for (int x = 0; x < qL; x++) {
+                score += (int) (int8_t) (mat[qs[x] * 21 + qs[x]] + qb[x]);
+                score = score < 0 ? 0 : score;
+                best = score > best ? score : best;
+            }
+            int ms = best - 255;
+            ms = ms < 1 ? 1 : ms;
+            ms = ms > 65535 ? 65535 : ms;
+            sMaxSelf = ms;
+        }
+        __syncthreads();
+        for (int x = threadIdx.x; x < n; x += blockDim.x)
+            keys[x] = ((unsigned long long) (255u - rescaledByte(pay[x])) << 56) | (unsigned long long) x;
+        __syncthreads();
+        if (np2 > 1) bitonicSort(keys, pay, np2);
+    }
     // take the first (maxHits - hasIdentity) with id != identity (getResult, QueryMatcher.cpp:364-420)
     // done serially by thread 0 into the key array re-used for the final order
     __shared__ int sTake;
@@ -832,7 +865,8 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
                 // final order: |score| desc, seqId asc (QueryMatcher.h:38-48); true score for saturated counts
                 const int sc = kScore[e];
                 const int cnt = min(255, sc);
-                const int prefScore = cnt >= 255 ? sc : cnt;
+                const int prefScore = rescored ? (int) (255u + rescaledByte(e) * (unsigned int) sMaxSelf / 255u)
+                                               : (cnt >= 255 ? sc : cnt);
                 keys[take] = ((unsigned long long) (0x7FFFFFFFu - (uint32_t) prefScore) << 32) | sid;
                 take++;
                 current++;
@@ -871,10 +905,8 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
             const uint32_t e = pay[x];
             const uint32_t sid = kKey[e] & ((1u << tBits) - 1);
             if (!covered(sid)) continue;
-            const int sc = kScore[e];
-            const int cnt = min(255, sc);
             o[w].seqId = sid;
-            o[w].score = cnt >= 255 ? sc : cnt;
+            o[w].score = (int32_t) (0x7FFFFFFFu - (uint32_t) (keys[x] >> 32));   // as ordered
             o[w].diagonal = hitDiag[qHitBase[q] + (kVal[e] & 0xFFFFFFu)];
             o[w].pad = 0;
             w++;
@@ -1362,7 +1394,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             ProfScope ps(ctx, "prefilter_select_hits");
             hipLaunchKernelGGL(select_hits_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
                                dDiag.p, dQHitBase.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
-                               par->covMode, par->covThr, dOut.p, dOutCount.p, dErr.p);
+                               par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p);
         }
         SD_HIP(ctx, hipGetLastError());
         hs.reset(new HostScope(ctx, "pf.download"));
@@ -1373,7 +1405,6 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         SD_HIP(ctx, hipMemcpyAsync(outCount + qBeg, dOutCount.p, bq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         if (stats) SD_HIP(ctx, hipMemcpyAsync(stats + (size_t) qBeg * 4, dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (hErr == 1) return sdFail(ctx, SD_EUNSUPPORTED, "a query reached the rescoring path (diagonal threshold >= 255, QueryMatcher.cpp:163-170), not implemented on the device");
         if (hErr == 2) return sdFail(ctx, SD_EUNSUPPORTED, "more than %d tied candidates at the score cut of one query", SEL_CAP);
         hs.reset(new HostScope(ctx, "pf.scatter"));
         // the caller's rows are par->maxHitsPerQuery wide

@@ -95,3 +95,26 @@ def test_prefilter_bucket_path_equals_sort_path(gpu, host, monkeypatch):
         n = int(a[1][q])
         assert np.array_equal(a[0][q, :n], b[0][q, :n]), q
     assert int(a[1].sum()) > 50000
+
+
+def test_prefilter_rescoring_path_matches_reference(gpu, host, oracle):
+    """the truncated-score path on the device against rows produced by the real reference"""
+    g = np.load(os.path.join(GOLD, 'rescore_vectors.npz'))
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    res = np.concatenate(nums)
+    n = len(nums)
+    ident = np.arange(n, dtype=np.uint32)
+    sw_b, dg_b, km_b = host.comp_bias(res, off)
+    idx = host.build_index(res, off)
+    tgt = api.Target(gpu, host, idx)
+    par = api.prefilter_params(host, idx.n, max_hits=300, cov_thr=0.0, bin_size=2)
+    hits, cnt, _ = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident, want_stats=True)
+    rows = g['pf_rows']
+    for q in g['queries']:
+        exp = rows[rows[:, 0] == q]
+        m = int(cnt[q])
+        assert m == len(exp), (q, m, len(exp))
+        assert (hits[q, :m]['seqId'] == exp[:, 1]).all() and (hits[q, :m]['score'] == exp[:, 2]).all(), q
+        assert (hits[q, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), q

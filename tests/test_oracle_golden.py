@@ -144,3 +144,19 @@ def test_clusterhits_regression_known_answers(oracle):
     lines.sort(key=lambda s: s.encode())
     assert hashlib.md5(''.join(lines).encode()).hexdigest() == 'abb28ee37bc130a5f09a9f767ef00ccf'
     assert ''.join(lines) == open(os.path.join(GOLD, 'config1_canonical.tsv')).read()
+
+
+def test_prefilter_rescoring_path(oracle):
+    """more than maxHits targets saturate the 8-bit diagonal score: rescoreHits / rescaled scores
+    (QueryMatcher.cpp:157-170,525-544); expected rows from the real reference (tools/make_golden_rescore.py)"""
+    g = np.load(os.path.join(GOLD, 'rescore_vectors.npz'))
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    tgt = oracle.target(np.concatenate(nums), off)
+    rows = g['pf_rows']
+    assert ((rows[:, 2] >= 255) & (rows[:, 2] < 65535)).sum() > 1000
+    for q in g['queries']:
+        exp = rows[rows[:, 0] == q]
+        ids, sc, dg, _ = tgt.prefilter(nums[q], identity_id=int(q), max_hits=300)
+        assert len(ids) == len(exp) and (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all() and (dg == exp[:, 3]).all(), q
