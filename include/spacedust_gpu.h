@@ -92,6 +92,15 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
                       uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
                       sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed);
 
+/* sd_sw_align_batch for callers that only consume what Alignment::run can write (swMode 2): returns the records of the
+ * identity pairs and of the pairs that were not stopped at an E-value / coverage gate -- out[x] belongs to pair
+ * outIdx[x], x < *nOut, pair order preserved; every other pair fails checkCriteria (Alignment.cpp:548-567) anyway.
+ * out / outIdx must hold nPairs entries. */
+int sd_sw_align_batch_compact(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                              uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
+                              uint32_t *outIdx, sd_sw_result *out, uint32_t *nOut, char *btPool, uint64_t btCap,
+                              uint64_t *btUsed);
+
 /* Same contract and results as sd_sw_align_batch, with the gating / task building between the passes done on
  * the host (one device round trip per pass).  Kept as the A/B cross-check of the device-resident orchestration
  * (tests/test_gpu_sw.py); btOffset values may differ, the bytes they point to may not. */

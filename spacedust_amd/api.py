@@ -173,10 +173,12 @@ class Context:
                'sd_sw_score_batch')
         return out
 
-    def sw_align(self, par, queries, targets, pair_q, pair_t, identity=None, bt_cap=None, hostpath=False, reuse=False):
+    def sw_align(self, par, queries, targets, pair_q, pair_t, identity=None, bt_cap=None, hostpath=False, reuse=False,
+                 compact=False):
         """sd_sw_align_batch.  bt_cap: capacity of the backtrace pool (default: a generous guess, grown to the exact
         bound sum(qLen + tLen) if the library reports SD_ENOMEM).  reuse=True hands out views of two alternating
-        context-owned buffers instead of fresh arrays (valid until the next-but-one call)."""
+        context-owned buffers instead of fresh arrays (valid until the next-but-one call).  compact=True
+        (sd_sw_align_batch_compact) returns (pair indices, their records, pool) for the reportable pairs only."""
         pq = np.ascontiguousarray(pair_q, np.uint32)
         pt = np.ascontiguousarray(pair_t, np.uint32)
         n = len(pq)
@@ -199,14 +201,24 @@ class Context:
                 res = np.zeros(n, _lib.SW_RESULT_DTYPE)
                 pool = np.zeros(bt_cap, np.uint8)
             used = C.c_uint64()
-            rc = fn(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt), ptr(idt), ptr(res), ptr(pool),
-                    len(pool), C.byref(used))
+            if compact:
+                if not hasattr(self, '_cidx') or len(self._cidx[0]) < n:
+                    self._cidx = [np.empty(int(1.25 * n) + 1, np.uint32), np.empty(int(1.25 * n) + 1, np.uint32)]
+                cidx = self._cidx[getattr(self, '_flip', 0)] if reuse else np.empty(n, np.uint32)
+                n_out = C.c_uint32()
+                rc = self.L.sd_sw_align_batch_compact(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt), ptr(idt),
+                                                      ptr(cidx), ptr(res), C.byref(n_out), ptr(pool), len(pool), C.byref(used))
+            else:
+                rc = fn(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt), ptr(idt), ptr(res), ptr(pool),
+                        len(pool), C.byref(used))
             if rc == _lib.SD_ENOMEM and exact_cap is None:
                 ql = (queries.offsets[pq + 1] - queries.offsets[pq]).astype(np.int64)
                 tl = (targets.offsets[pt + 1] - targets.offsets[pt]).astype(np.int64)
                 exact_cap = bt_cap = int((ql + tl).sum()) + 64
                 continue
             _check(self.h, rc, 'sd_sw_align_batch')
+            if compact:
+                return cidx[:n_out.value], res[:n_out.value], pool[:used.value]
             return res, pool[:used.value]
 
     def sw_cells(self):

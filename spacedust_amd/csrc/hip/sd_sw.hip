@@ -977,6 +977,26 @@ k_bt_pack(uint32_t nPairs, const uint64_t *__restrict__ btLen, const uint64_t *_
     if (lane == 0) res[i].btOffset = poolBase + dense[i];
 }
 
+// compact mode: which records go back to the host
+__global__ void __launch_bounds__(256)
+k_accept(uint32_t nPairs, const sd_sw_result *__restrict__ res, const uint8_t *__restrict__ ident, uint8_t *__restrict__ acc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs) return;
+    const sd_sw_result &r = res[i];
+    acc[i] = (ident[i] || (r.btLen > 0 && r.qStart >= 0 && r.tStart >= 0)) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256)
+k_accept_compact(uint32_t nPairs, const sd_sw_result *__restrict__ res, const uint8_t *__restrict__ acc,
+                 const uint64_t *__restrict__ pos, sd_sw_result *__restrict__ outRes, uint32_t *__restrict__ outIdx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs || !acc[i]) return;
+    outRes[pos[i]] = res[i];
+    outIdx[pos[i]] = i;
+}
+struct WidenU8 {
+    __host__ __device__ __forceinline__ uint64_t operator()(const uint8_t &v) const { return (uint64_t) v; }
+};
+
 template <typename T>
 int devExclusiveScan(sd_ctx *ctx, const T *in, T *out, size_t n) {
     size_t bytes = 0;
@@ -1282,12 +1302,17 @@ int sd_sw_score_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     return SD_OK;
 }
 
-int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
-                      uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
-                      sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed) {
+// compactIdx != nullptr: only the pairs that reached a result worth reporting (identity pairs and pairs that were
+// not stopped at a gate) are returned, out[x] being the record of pair compactIdx[x], x < *nCompact
+static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                          uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
+                          sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed, uint32_t *compactIdx,
+                          uint32_t *nCompact) {
     if (!ctx || !par || !queries || !targets || !out) return SD_EINVAL;
+    if (compactIdx && (!nCompact || par->swMode != 2)) return SD_EINVAL;
     (void) hipSetDevice(ctx->device);
     if (btUsed) *btUsed = 0;
+    if (nCompact) *nCompact = 0;
     if (nPairs == 0) return SD_OK;
     const int go = par->gapOpen, ge = par->gapExtend;
     ctx->cellsFwd = ctx->cellsRev = ctx->cellsTb = 0;
@@ -1472,11 +1497,43 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     if (poolBytes > 0)
         hipLaunchKernelGGL(k_bt_pack, dim3((nPairs + 3) / 4), dim3(256), 0, ctx->stream, nPairs, dBtLen, dDense, dTb, dBt, dPool,
                            (uint64_t) 0, dRes);
+    // records to bring back: all of them, or (compact mode) only identity pairs and pairs that passed every gate
+    uint32_t nRec = nPairs;
+    sd_sw_result *dRecSrc = dRes;
+    uint32_t *hIdx = nullptr;
+    if (compactIdx) {
+        uint8_t *dAcc = nullptr;
+        uint64_t *dAccPos = nullptr;
+        sd_sw_result *dResC = nullptr;
+        uint32_t *dIdxC = nullptr;
+        SD_HIP(ctx, wsGet(ctx, "al.acc", N + 1, &dAcc));
+        SD_HIP(ctx, wsGet(ctx, "al.accpos", N + 1, &dAccPos));
+        SD_HIP(ctx, wsGet(ctx, "al.resc", N, &dResC));
+        SD_HIP(ctx, wsGet(ctx, "al.idxc", N, &dIdxC));
+        hipLaunchKernelGGL(k_accept, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dRes, dIdent, dAcc);
+        SD_HIP(ctx, hipMemsetAsync(dAcc + N, 0, 1, ctx->stream));
+        {
+            size_t bytes = 0;
+            hipcub::TransformInputIterator<uint64_t, WidenU8, const uint8_t *> it(dAcc, WidenU8());
+            SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, dAccPos, (int) (N + 1), ctx->stream));
+            uint8_t *tmp = nullptr;
+            SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
+            SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, dAccPos, (int) (N + 1), ctx->stream));
+        }
+        hipLaunchKernelGGL(k_accept_compact, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dRes, dAcc, dAccPos, dResC, dIdxC);
+        uint64_t nAcc = 0;
+        SD_HIP(ctx, hipMemcpyAsync(&nAcc, dAccPos + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        nRec = (uint32_t) nAcc;
+        dRecSrc = dResC;
+        SD_HIP(ctx, pinGet(ctx, "al.hidx", std::max<uint32_t>(nRec, 1), &hIdx));
+        SD_HIP(ctx, hipMemcpyAsync(hIdx, dIdxC, (size_t) nRec * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
     sd_sw_result *hRes = nullptr;
     char *hPool = nullptr;
-    SD_HIP(ctx, pinGet(ctx, "al.hres", N, &hRes));
+    SD_HIP(ctx, pinGet(ctx, "al.hres", std::max<uint32_t>(nRec, 1), &hRes));
     SD_HIP(ctx, pinGet(ctx, "al.hpool", poolBytes + 64, &hPool));
-    SD_HIP(ctx, hipMemcpyAsync(hRes, dRes, N * sizeof(sd_sw_result), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, hipMemcpyAsync(hRes, dRecSrc, (size_t) nRec * sizeof(sd_sw_result), hipMemcpyDeviceToHost, ctx->stream));
     if (poolBytes > 0) SD_HIP(ctx, hipMemcpyAsync(hPool, dPool, poolBytes, hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hs.reset(new HostScope(ctx, "align.finish"));
@@ -1493,8 +1550,9 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     // exact E-values (the device value only served the gate), identity pairs, and the rare results the device
     // let through because they sat within 1e-9 of the E-value threshold
 #pragma omp parallel for schedule(static)
-    for (uint32_t i = 0; i < nPairs; i++) {
-        sd_sw_result r = hRes[i];
+    for (uint32_t x = 0; x < nRec; x++) {
+        const uint32_t i = hIdx ? hIdx[x] : x;
+        sd_sw_result r = hRes[x];
         if (!(isIdentity && isIdentity[i])) {
             const int qL = (int) (queries->hOff[pairQ[i] + 1] - queries->hOff[pairQ[i]]);
             if (r.tEnd != -1 && qL > 0) {
@@ -1509,10 +1567,13 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
                 r.evalue = 0.0;
             }
         }
-        out[i] = r;
+        out[x] = r;
+        if (compactIdx) compactIdx[x] = i;
     }
+    if (nCompact) *nCompact = nRec;
     if (isIdentity) {
-        for (uint32_t i = 0; i < nPairs; i++) {
+        for (uint32_t x = 0; x < nRec; x++) {
+            const uint32_t i = hIdx ? hIdx[x] : x;
             if (!isIdentity[i]) continue;
             // scoreIdentical (StripedSmithWaterman.cpp:1675-1710), host side, O(L)
             const int L = (int) (targets->hOff[pairT[i] + 1] - targets->hOff[pairT[i]]);
@@ -1523,7 +1584,7 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
             const uint8_t *t = targets->hRes.data() + targets->hOff[pairT[i]];
             short score = 0;
             for (int p = 0; p < L; p++) score += (short) (par->matrix[t[p] * 21 + q[p]] + cb[p]);
-            sd_sw_result &r = out[i];
+            sd_sw_result &r = out[x];
             r.score = (int32_t) (uint32_t) (int) score;
             r.qStart = par->swMode == 0 ? -1 : 0;
             r.tStart = par->swMode == 0 ? -1 : 0;
@@ -1540,6 +1601,20 @@ int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
     if (btUsed) *btUsed = btPos;
     hs.reset();
     return SD_OK;
+}
+
+int sd_sw_align_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                      uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
+                      sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed) {
+    return alignBatchImpl(ctx, par, queries, targets, nPairs, pairQ, pairT, isIdentity, out, btPool, btCap, btUsed, nullptr, nullptr);
+}
+
+int sd_sw_align_batch_compact(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                              uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
+                              uint32_t *outIdx, sd_sw_result *out, uint32_t *nOut, char *btPool, uint64_t btCap,
+                              uint64_t *btUsed) {
+    if (!outIdx || !nOut) return SD_EINVAL;
+    return alignBatchImpl(ctx, par, queries, targets, nPairs, pairQ, pairT, isIdentity, out, btPool, btCap, btUsed, outIdx, nOut);
 }
 
 int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,

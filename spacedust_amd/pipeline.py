@@ -236,13 +236,19 @@ class ClusterSearch:
                 tm['seqset'] = tm.get('seqset', 0.0) + time.time() - t0
                 t0 = time.time()
                 identity = (pair_q_local + np.uint32(c0) == pair_t) if same_db else np.zeros(n_pairs, bool)
-                r, pool = self.ctx_al.sw_align(self.sw_par, qset, self.t_seqs, pair_q_local, pair_t, identity=identity, reuse=True)
+                # only the reportable pairs come back (identity pairs + pairs past every gate, ~10 %): everything else
+                # fails Alignment::checkCriteria and would be skipped by the aggregation anyway
+                cidx, r, pool = self.ctx_al.sw_align(self.sw_par, qset, self.t_seqs, pair_q_local, pair_t, identity=identity,
+                                                     reuse=True, compact=True)
+                n_all = n_pairs
+                pair_q_local, pair_t, identity = pair_q_local[cidx], pair_t[cidx], identity[cidx]
+                n_pairs = len(cidx)
                 tm['align'] += time.time() - t0
                 f, rv, tb = self.ctx_al.sw_cells()
                 self.stats['cells_fwd'] += f
                 self.stats['cells_rev'] += rv
                 self.stats['cells_tb'] += tb
-                self.stats['pairs'] += n_pairs
+                self.stats['pairs'] += n_all
                 t0 = time.time()
                 if pending is not None:
                     tm['aggregate_busy'] += pending.result()

@@ -161,3 +161,27 @@ def test_sw_packed_kernel_equals_int32_kernel(gpu, host, monkeypatch):
         assert np.array_equal(a[f], b[f]), (f, np.flatnonzero(a[f] != b[f])[:5])
     lens = (ps.offsets[1:] - ps.offsets[:-1])[pq]
     assert lens.min() <= 128 and lens.max() > 768   # every row class is exercised
+
+
+def test_sw_align_compact_equals_full(gpu, host):
+    """sd_sw_align_batch_compact returns exactly the reportable records of sd_sw_align_batch, in pair order"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=4, genes_per_proteome=300, n_families=500, seed=8)
+    rng = np.random.default_rng(4)
+    pq, pt = _pairs(ps, rng, 3000)
+    sw_bias, _, _ = host.comp_bias(ps.residues, ps.offsets)
+    mat, _, _ = host.matrix(0)
+    ss = gpu.seqset(ps.residues, ps.offsets, sw_bias)
+    par = gpu.sw_params(mat, int(ps.offsets[-1]))
+    ident = (pq == pt)
+    full, pool_f = gpu.sw_align(par, ss, ss, pq, pt, identity=ident)
+    idx, comp, pool_c = gpu.sw_align(par, ss, ss, pq, pt, identity=ident, compact=True)
+    keep = np.flatnonzero(ident | ((full['btLen'] > 0) & (full['qStart'] >= 0)))
+    assert np.array_equal(idx, keep.astype(np.uint32))
+    for f in ('score', 'qStart', 'qEnd', 'tStart', 'tEnd', 'identical', 'btLen', 'flags', 'evalue'):
+        assert np.array_equal(comp[f], full[f][keep]), f
+    for x in range(0, len(keep), 11):
+        a = pool_c[int(comp['btOffset'][x]):int(comp['btOffset'][x]) + int(comp['btLen'][x])]
+        b = pool_f[int(full['btOffset'][keep[x]]):int(full['btOffset'][keep[x]]) + int(full['btLen'][keep[x]])]
+        assert np.array_equal(a, b), x
+    assert 100 < len(keep) < len(pq)
