@@ -554,13 +554,13 @@ sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const ui
     res[2 * id + 1] = ids;
 }
 
-template <int RT, int LW, bool MULTI, bool WIDE>
+template <int RT, int LW, bool MULTI, bool WIDE, bool SHARED>
 void launchScorePk(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, uint32_t n, const sd_seqset *q,
                    const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut, uint2 *dBound) {
     if (n == 0) return;
     constexpr uint32_t perWave = 2 * (64 / LW);
     dim3 grid((n + perWave - 1) / perWave), block(64);
-    hipLaunchKernelGGL((sdpk::sw_score_pk_kernel<RT, LW, MULTI, WIDE>), grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias,
+    hipLaunchKernelGGL((sdpk::sw_score_pk_kernel<RT, LW, MULTI, WIDE, SHARED>), grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias,
                        t->dRes, dMat, go, ge, dOut, dBound, dOrder);
 }
 
@@ -1037,14 +1037,111 @@ k_bound_apply(uint32_t nPairs, SwTask *__restrict__ tasks, const uint64_t *__res
     tasks[i].boundOff = off[i];
 }
 
+// ---- tasks of one query two by two (shared-profile kernels) --------------------------------------------------------
+// key64 = class | query | target-length bucket: a stable sort puts the tasks of a (class, query) run together, longest
+// target first; inside a run consecutive tasks form pairs, an odd last task stays alone.
+constexpr uint32_t PAIR_NONE = 0xFFFFFFFFu;
+__global__ void __launch_bounds__(256)
+k_pair_keys(uint32_t n, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ pairQ, uint64_t *__restrict__ key64) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    key64[i] = (k == KEY_INVALID || (k >> 10) >= FIRST_INT32_CLASS)
+                   ? ~0ull
+                   : (((uint64_t) (k >> 10)) << 34) | ((uint64_t) pairQ[i] << 10) | (uint64_t) (k & 1023u);
+}
+__global__ void __launch_bounds__(256)
+k_pair_heads(uint32_t n, const uint64_t *__restrict__ key64S, uint32_t *__restrict__ headPos) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const bool head = p == 0 || (key64S[p] >> 10) != (key64S[p - 1] >> 10);
+    headPos[p] = head ? p : 0u;
+}
+__global__ void __launch_bounds__(256)
+k_pair_leaders(uint32_t n, const uint64_t *__restrict__ key64S, const uint32_t *__restrict__ runStart, uint8_t *__restrict__ leader) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n) return;
+    leader[p] = (p < n && key64S[p] != ~0ull && ((p - runStart[p]) & 1u) == 0) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256)
+k_pair_emit(uint32_t n, const uint64_t *__restrict__ key64S, const uint32_t *__restrict__ vals, const uint8_t *__restrict__ leader,
+            const uint64_t *__restrict__ pairIdx, uint32_t *__restrict__ order2) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || !leader[p]) return;
+    const uint64_t w = pairIdx[p];
+    order2[2 * w] = vals[p];
+    const bool mate = p + 1 < n && (key64S[p + 1] >> 10) == (key64S[p] >> 10);
+    order2[2 * w + 1] = mate ? vals[p + 1] : PAIR_NONE;
+}
+// pair-index boundaries of the packed classes: b[c] = number of pairs of classes < c
+__global__ void k_pair_bounds(const uint64_t *__restrict__ key64S, uint32_t n, const uint64_t *__restrict__ pairIdx,
+                              uint32_t *__restrict__ b, int nb) {
+    const int c = threadIdx.x;
+    if (c >= nb) return;
+    const uint64_t want = (uint64_t) c << 34;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (key64S[mid] < want) lo = mid + 1;
+        else hi = mid;
+    }
+    b[c] = (uint32_t) pairIdx[lo];
+}
+struct MaxU32 {
+    __host__ __device__ __forceinline__ uint32_t operator()(const uint32_t &a, const uint32_t &b) const { return a > b ? a : b; }
+};
+
 // sort (keys,vals) -> order, read the class boundaries, launch one score kernel per RT class
 int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint32_t *dVals, uint32_t *dKeysSorted,
                 uint32_t *dOrder, uint32_t *dBounds, SwTask *dTasks, uint64_t *dScanA, uint64_t *dScanB,
                 const sd_seqset *q, const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut,
-                uint32_t *nValid) {
+                uint32_t *nValid, const uint32_t *dPairQ /* non-null: every task scans its whole query, pair them up */) {
     const unsigned grid = (nPairs + 255) / 256;
     int rc = devSortPairs(ctx, dKeys, dKeysSorted, dVals, dOrder, nPairs, 15);
     if (rc != SD_OK) return rc;
+    uint32_t *dOrder2 = nullptr, *dPairBounds = nullptr;
+    if (dPairQ) {
+        uint64_t *dKey64 = nullptr, *dKey64S = nullptr, *dPairIdx = nullptr;
+        uint32_t *dVals2 = nullptr, *dHead = nullptr, *dRunStart = nullptr;
+        uint8_t *dLeader = nullptr;
+        SD_HIP(ctx, wsGet(ctx, "sp.key64", (size_t) nPairs, &dKey64));
+        SD_HIP(ctx, wsGet(ctx, "sp.key64s", (size_t) nPairs, &dKey64S));
+        SD_HIP(ctx, wsGet(ctx, "sp.vals2", (size_t) nPairs, &dVals2));
+        SD_HIP(ctx, wsGet(ctx, "sp.head", (size_t) nPairs, &dHead));
+        SD_HIP(ctx, wsGet(ctx, "sp.runstart", (size_t) nPairs, &dRunStart));
+        SD_HIP(ctx, wsGet(ctx, "sp.leader", (size_t) nPairs + 1, &dLeader));
+        SD_HIP(ctx, wsGet(ctx, "sp.pairidx", (size_t) nPairs + 1, &dPairIdx));
+        SD_HIP(ctx, wsGet(ctx, "sp.order2", (size_t) 2 * nPairs, &dOrder2));
+        SD_HIP(ctx, wsGet(ctx, "sp.bounds", 32, &dPairBounds));
+        hipLaunchKernelGGL(k_pair_keys, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dPairQ, dKey64);
+        {
+            size_t bytes = 0;
+            SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dKey64, dKey64S, dVals, dVals2, (int) nPairs, 0, 40, ctx->stream));
+            uint8_t *tmp = nullptr;
+            SD_HIP(ctx, wsGet(ctx, "al.sorttmp", bytes + 256, &tmp));
+            SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, bytes, dKey64, dKey64S, dVals, dVals2, (int) nPairs, 0, 40, ctx->stream));
+        }
+        hipLaunchKernelGGL(k_pair_heads, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKey64S, dHead);
+        {
+            size_t bytes = 0;
+            SD_HIP(ctx, hipcub::DeviceScan::InclusiveScan(nullptr, bytes, dHead, dRunStart, MaxU32(), (int) nPairs, ctx->stream));
+            uint8_t *tmp = nullptr;
+            SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
+            SD_HIP(ctx, hipcub::DeviceScan::InclusiveScan(tmp, bytes, dHead, dRunStart, MaxU32(), (int) nPairs, ctx->stream));
+        }
+        hipLaunchKernelGGL(k_pair_leaders, dim3((nPairs + 256) / 256), dim3(256), 0, ctx->stream, nPairs, dKey64S, dRunStart, dLeader);
+        {
+            size_t bytes = 0;
+            hipcub::TransformInputIterator<uint64_t, WidenU8, const uint8_t *> it(dLeader, WidenU8());
+            SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, dPairIdx, (int) (nPairs + 1), ctx->stream));
+            uint8_t *tmp = nullptr;
+            SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
+            SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, dPairIdx, (int) (nPairs + 1), ctx->stream));
+        }
+        hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKey64S, dVals2, dLeader, dPairIdx, dOrder2);
+        hipLaunchKernelGGL(k_pair_bounds, dim3(1), dim3(64), 0, ctx->stream, dKey64S, nPairs, dPairIdx, dPairBounds,
+                           (int) FIRST_INT32_CLASS + 1);
+    }
     hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1024u, dBounds, (int) N_SCORE_CLASSES + 1);
     // strip hand-off workspace for queries longer than one 1024-row strip
     hipLaunchKernelGGL(k_bound_need, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dKeys, dScanA);
@@ -1052,8 +1149,9 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
     rc = devExclusiveScan(ctx, dScanA, dScanB, (size_t) nPairs + 1);
     if (rc != SD_OK) return rc;
     hipLaunchKernelGGL(k_bound_apply, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dScanB);
-    uint32_t hb[N_SCORE_CLASSES + 1];
+    uint32_t hb[N_SCORE_CLASSES + 1], hpb[FIRST_INT32_CLASS + 1];
     uint64_t boundTotal = 0;
+    if (dPairQ) SD_HIP(ctx, hipMemcpyAsync(hpb, dPairBounds, sizeof(hpb), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(&boundTotal, dScanB + nPairs, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1071,7 +1169,17 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
         else snprintf(name, sizeof(name), "%s", i32Names[ci - FIRST_INT32_CLASS]);
         ProfScope ps(ctx, name);
         const uint32_t *ord = dOrder + begin;
-#define SD_PK(RT, LW, MULTI, WIDE) launchScorePk<RT, LW, MULTI, WIDE>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound)
+        const bool shared = dPairQ != nullptr && ci < FIRST_INT32_CLASS;
+        uint32_t nOrd = cnt;
+        if (shared) {   // explicit pairs: two entries per pair of the class
+            ord = dOrder2 + 2 * (size_t) hpb[ci];
+            nOrd = 2 * (hpb[ci + 1] - hpb[ci]);
+        }
+#define SD_PK(RT, LW, MULTI, WIDE)                                                                                          \
+    do {                                                                                                                   \
+        if (shared) launchScorePk<RT, LW, MULTI, WIDE, true>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut, dBound);     \
+        else launchScorePk<RT, LW, MULTI, WIDE, false>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut, dBound);           \
+    } while (0)
 #define SD_PK_CLASS(WIDE)                                                     \
         switch (ci % N_PK_CLASSES) {                                          \
             case 0: SD_PK(4, 32, false, WIDE); break;                         \
@@ -1395,8 +1503,9 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     hipLaunchKernelGGL(k_make_fwd, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dPT, dIdent, queries->dOff, targets->dOff,
                        dTasks, dFwdKeys, dVals, dRes, usePk);
     hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dFwdKeys, dCells + 0);
+    const uint32_t *dShare = (getenv("SD_SW_NOSHARE") || queries->n >= (1u << 24)) ? nullptr : dPQ;   // forward passes scan whole queries: pair by query
     int rc = devRunScore(ctx, nPairs, dFwdKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go,
-                         ge, dOut32, &nValid);
+                         ge, dOut32, &nValid, dShare);
     if (rc != SD_OK) return rc;
     // ---- pass 2: saturated pairs again with the word kernel's 16-lane structure
     hs.reset(new HostScope(ctx, "align.fwd16"));
@@ -1404,7 +1513,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
                        dVals, dWord, dFwdKeys, usePk);
     hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dKeys, dCells + 0);
     rc = devRunScore(ctx, nPairs, dKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go, ge,
-                     dOut16, &nValid);
+                     dOut16, &nValid, dShare);
     if (rc != SD_OK) return rc;
     // ---- gates + pass 3: start positions
     hs.reset(new HostScope(ctx, "align.rev"));
@@ -1412,7 +1521,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
                        dOut16, dWord, dFwdKeys, dTasks, dRevKeys, dVals, dRes, usePk);
     hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dRevKeys, dCells + 1);
     rc = devRunScore(ctx, nPairs, dRevKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go, ge,
-                     dOutRev, &nValid);
+                     dOutRev, &nValid, nullptr);   // start-position tasks scan per-pair prefixes: no shared profile
     if (rc != SD_OK) return rc;
     // ---- pass 4: banded traceback, band doubling on the device
     hs.reset(new HostScope(ctx, "align.traceback"));

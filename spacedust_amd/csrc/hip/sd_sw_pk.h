@@ -110,7 +110,10 @@ constexpr int PK_NEUTRAL = 21;   // profile row of -64s: columns outside the tar
 // LW = 64 one pair.  ROWS = LW*RT query rows per strip.  MULTI: queries longer than one strip.
 // WIDE: the column maximum is tracked per task in a 32-bit (value << 16 | 31-r) code instead of the packed
 // five-bit one, which lifts the g < 1024 limit to the int16 range (scores of the reference's word kernel).
-template <int RT, int LW, bool MULTI, bool WIDE>
+// SHARED: the two tasks of a pair have the same query (same rows, same profile): one profile per pair in LDS
+// instead of two, which doubles the wavefronts a CU can hold; `order` then lists pairs explicitly, 0xFFFFFFFF
+// standing for "no second task".
+template <int RT, int LW, bool MULTI, bool WIDE, bool SHARED>
 __global__ void __launch_bounds__(64)
 sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                    const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
@@ -122,7 +125,7 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
     constexpr int PSTRIDE = LW * WORDS;    // dwords per residue row of a profile
     constexpr int NGRP = 64 / LW;
     constexpr int NT = 2 * NGRP;   // tasks per wavefront
-    __shared__ uint32_t prof[NT][22][PSTRIDE];
+    __shared__ uint32_t prof[SHARED ? NGRP : NT][22][PSTRIDE];
     __shared__ int8_t smat[441];
     for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
     __syncthreads();
@@ -134,16 +137,21 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
 #pragma unroll
     for (int x = 0; x < NT; x++) {
         const uint32_t id = blockIdx.x * NT + x;
-        if (id < nTasks) {
-            tk[x] = tasks[order ? order[id] : id];
+        const uint32_t tid = id < nTasks ? (order ? order[id] : id) : 0xFFFFFFFFu;
+        if (tid != 0xFFFFFFFFu) {
+            tk[x] = tasks[tid];
         } else {
             tk[x].n = 0; tk[x].tL = 0; tk[x].qOff = 0; tk[x].tOff = 0; tk[x].qStep = 1; tk[x].tStep = 1; tk[x].segLen = 1;
             tk[x].slot = 0; tk[x].boundOff = 0;
         }
     }
     const SwTask A = (NGRP == 2 && grp) ? tk[NT - 2] : tk[0];
-    const SwTask B = (NGRP == 2 && grp) ? tk[NT - 1] : tk[1];
-    const bool haveA = blockIdx.x * NT + 2 * grp < nTasks, haveB = blockIdx.x * NT + 2 * grp + 1 < nTasks;
+    SwTask B = (NGRP == 2 && grp) ? tk[NT - 1] : tk[1];
+    const bool haveA = A.n > 0, haveB = B.n > 0;
+    if (SHARED && !haveB) {   // lone task of its query: the second half idles on the same rows
+        B = A;
+        B.tL = 0;
+    }
     int maxN = 0, maxTL = 0;
 #pragma unroll
     for (int x = 0; x < NT; x++) {
@@ -158,8 +166,8 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
 
     const uint32_t goP = (uint32_t) go | ((uint32_t) go << 16), geP = (uint32_t) ge | ((uint32_t) ge << 16);
     unsigned long long keyA = 0, keyB = 0;   // (value, 0xFFFFF - column, 0xFFFFF - row), best over strips
-    const uint32_t *profA = &prof[2 * grp][0][0] + l * WORDS;
-    const uint32_t *profB = &prof[2 * grp + 1][0][0] + l * WORDS;
+    const uint32_t *profA = &prof[SHARED ? grp : 2 * grp][0][0] + l * WORDS;
+    const uint32_t *profB = SHARED ? profA : &prof[2 * grp + 1][0][0] + l * WORDS;
 
     for (int strip = 0; strip < nStrips; strip++) {
         const int q0 = strip * ROWS + l * RT;
@@ -167,9 +175,9 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
         uint32_t mask[RTP];
         if (strip > 0) __syncthreads();   // the previous strip's profile reads are done
 #pragma unroll
-        for (int x = 0; x < 2; x++) {
+        for (int x = 0; x < (SHARED ? 1 : 2); x++) {
             const SwTask &T = x ? B : A;
-            uint32_t *pw = &prof[2 * grp + x][0][0] + l * WORDS;
+            uint32_t *pw = &prof[SHARED ? grp : 2 * grp + x][0][0] + l * WORDS;
             int seg = T.segLen > 0 ? q0 % T.segLen : 0;
 #pragma unroll
             for (int w = 0; w < WORDS; w++) {
@@ -189,7 +197,8 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                     const bool reset = valid[b] && seg == 0;
                     seg = (seg + 1 == T.segLen) ? 0 : seg + 1;
                     const uint32_t m = reset ? 0u : 0xFFFFu;
-                    if (x == 0) mask[4 * w + b] = m;
+                    if (SHARED) mask[4 * w + b] = m | (m << 16);
+                    else if (x == 0) mask[4 * w + b] = m;
                     else mask[4 * w + b] |= m << 16;
                 }
                 for (int a = 0; a < 21; a++) {
