@@ -389,6 +389,17 @@ __device__ __forceinline__ int dppI(int oldv, int src, int ctrl, int rowMask) {
     (void) rowMask;
 }
 
+__device__ __forceinline__ int dppZ(int src, int ctrl) {   // lanes without a source read 0
+    switch (ctrl) {
+        case 0x138: return __builtin_amdgcn_update_dpp(0, src, 0x138, 0xf, 0xf, true);
+        case 0x130: return __builtin_amdgcn_update_dpp(0, src, 0x130, 0xf, 0xf, true);
+        case 0x111: return __builtin_amdgcn_update_dpp(0, src, 0x111, 0xf, 0xf, true);
+        case 0x112: return __builtin_amdgcn_update_dpp(0, src, 0x112, 0xf, 0xf, true);
+        case 0x114: return __builtin_amdgcn_update_dpp(0, src, 0x114, 0xf, 0xf, true);
+        default: return __builtin_amdgcn_update_dpp(0, src, 0x118, 0xf, 0xf, true);
+    }
+}
+
 __global__ void __launch_bounds__(64)
 sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                            const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
@@ -448,51 +459,49 @@ sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const ui
             end = end < i + band ? end : i + band;
             const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
             const int W = end - xi + 1;
-            if (live && (l == 0 || l == edge)) { hb = 0; eb = 0; }
-            // previous-row values at index e = u + delta and d = e - 1
-            const int hbUp = dppI(0, hb, 0x130, 0xf), ebUp = dppI(0, eb, 0x130, 0xf), hbDn = dppI(0, hb, 0x138, 0xf);
+            const bool zeroed = live && (l == 0 || l == edge);
+            hb = zeroed ? 0 : hb;
+            eb = zeroed ? 0 : eb;
+            // previous-row values at index e = u + delta and d = e - 1 (zero-filled DPP moves, no exec masking: every
+            // lane computes, `valid` selects what is kept)
+            const int hbUp = dppZ(hb, 0x130), ebUp = dppZ(eb, 0x130), hbDn = dppZ(hb, 0x138);
             const int hE = delta ? hbUp : hb, eE = delta ? ebUp : eb, hD = delta ? hb : hbDn;
             const int u = l;
             const bool valid = live && u >= 1 && u <= W;
-            int T = 0, S = NEG, eNew = 0, e1 = 0, diag = 0;
-            bool dirE = false;
-            if (valid) {
-                const int t1 = i == 0 ? -go : hE - go;
-                const int t2 = i == 0 ? -ge : eE - ge;
-                eNew = t1 > t2 ? t1 : t2;
-                dirE = t1 > t2;
-                e1 = eNew > 0 ? eNew : 0;
-                diag = hD + sCur;
-                T = e1 > diag ? e1 : diag;
-                S = T - go + ge * u;
-            }
-            // inclusive prefix maximum of S over the 32 lanes of the half wavefront
-            int incl = S, o;
-            o = dppI(NEG, incl, 0x111, 0xf); incl = incl > o ? incl : o;
-            o = dppI(NEG, incl, 0x112, 0xf); incl = incl > o ? incl : o;
-            o = dppI(NEG, incl, 0x114, 0xf); incl = incl > o ? incl : o;
-            o = dppI(NEG, incl, 0x118, 0xf); incl = incl > o ? incl : o;
-            o = dppI(NEG, incl, 0x142, 0xa); incl = incl > o ? incl : o;
-            int excl = dppI(NEG, incl, 0x138, 0xf);
-            if (l == 0) excl = NEG;
-            const int g = (-ge) > excl ? (-ge) : excl;
+            const int t1 = i == 0 ? -go : hE - go;
+            const int t2 = i == 0 ? -ge : eE - ge;
+            const int eNew = t1 > t2 ? t1 : t2;
+            const bool dirE = t1 > t2;
+            const int e1 = eNew > 0 ? eNew : 0;
+            const int diag = hD + sCur;
+            const int T = e1 > diag ? e1 : diag;
+            // prefix maximum of S = T - go + ge*u, carried as S + go + 1 >= 1 so that 0 (what a zero-filled DPP move
+            // delivers where there is no source lane) is the identity
+            int incl = valid ? T + ge * u + 1 : 0, o;
+            o = dppZ(incl, 0x111); incl = incl > o ? incl : o;
+            o = dppZ(incl, 0x112); incl = incl > o ? incl : o;
+            o = dppZ(incl, 0x114); incl = incl > o ? incl : o;
+            o = dppZ(incl, 0x118); incl = incl > o ? incl : o;
+            o = dppI(0, incl, 0x142, 0xa); incl = incl > o ? incl : o;
+            int excl = dppZ(incl, 0x138);
+            excl = l == 0 ? 0 : excl;
+            const int gx = excl - go - 1;
+            const int g = (-ge) > gx ? (-ge) : gx;
             const int f = g - ge * (u - 1);
             const int hcv = T > f ? T : f;
-            int hcP = dppI(0, hcv, 0x138, 0xf), fP = dppI(0, f, 0x138, 0xf);
-            if (u <= 1) { hcP = 0; fP = 0; }
-            int code = 0;
-            if (valid) {
-                const bool dirF = (hcP - go) > (fP - ge);
-                const int f1 = f > 0 ? f : 0;
-                const int tmp1 = e1 > f1 ? e1 : f1;
-                code = (dirE ? 1 : 0) | (dirF ? 2 : 0);
-                if (!(tmp1 <= diag)) code |= (e1 > f1) ? 4 : 8;
-                eb = eNew;
-                hb = hcv;
-                maxv = hcv > maxv ? hcv : maxv;
-            }
+            int hcP = dppZ(hcv, 0x138), fP = dppZ(f, 0x138);
+            hcP = u <= 1 ? 0 : hcP;
+            fP = u <= 1 ? 0 : fP;
+            const bool dirF = (hcP - go) > (fP - ge);
+            const int f1 = f > 0 ? f : 0;
+            const int tmp1 = e1 > f1 ? e1 : f1;
+            int code = (dirE ? 1 : 0) | (dirF ? 2 : 0) | ((tmp1 > diag) ? ((e1 > f1) ? 4 : 8) : 0);
+            code = valid ? code : 0;
+            eb = valid ? eNew : eb;
+            hb = valid ? hcv : hb;
+            maxv = (valid && hcv > maxv) ? hcv : maxv;
             // two cells per byte: cell x = u - 1; odd u carries the low nibble and fetches its right neighbour's
-            const int codeUp = dppI(0, code, 0x130, 0xf);
+            const int codeUp = dppZ(code, 0x130);
             if (valid && (u & 1)) dirs[(size_t) 16 * i + ((u - 1) >> 1)] = (uint8_t) (code | (codeUp << 4));
         }
         if (!reached && fits) {
