@@ -23,7 +23,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from spacedust_amd.cpus import configure_openmp, effective_cpus  # noqa: E402
-configure_openmp()
+# one process per GPU shares the node's CPU quota: size every OpenMP team for this rank's share
+configure_openmp(max(1, effective_cpus() // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))))))
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
