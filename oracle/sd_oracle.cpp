@@ -205,6 +205,11 @@ int64_t or_prefilter_query(void *vt, const unsigned char *q, int qL, uint32_t id
     std::vector<uint32_t> kmers;
     uint64_t nKmers = 0;
     uint8_t window[8];
+    // the hit buffer holds maxDbMatches entries; a list that would fill it closes the current chunk first
+    // (QueryMatcher.cpp:281-316): chunkStart[] = stream positions where a new chunk begins
+    const uint64_t maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;
+    std::vector<size_t> chunkStart(1, 0);
+    uint64_t inBuffer = 0;
     for (int i = 0; i + span <= qL; i++) {
         bool hasX = false;
         float bias = 0;
@@ -220,43 +225,69 @@ int64_t or_prefilter_query(void *vt, const unsigned char *q, int qL, uint32_t id
         nKmers += kmers.size();
         for (size_t z = 0; z < kmers.size(); z++) {
             uint32_t a = ix.offsets[kmers[z]], e = ix.offsets[kmers[z] + 1];
+            if (inBuffer + (e - a) >= maxDbMatches) {
+                chunkStart.push_back(hitSeq.size());
+                inBuffer = 0;
+            }
+            inBuffer += e - a;
             for (uint32_t x = a; x < e; x++) {
                 hitSeq.push_back(ix.entrySeq[x]);
                 hitDiag.push_back((uint16_t) (i - ix.entryPos[x]));
             }
         }
     }
-    const uint64_t maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;
-    if (hitSeq.size() >= maxDbMatches) return -2;   // overflow path (QueryMatcher.cpp:281-316) not restated
+    // two overflows in a row take the merge + score + keep-max route of :289-303, which is not restated
+    if (chunkStart.size() > 2) return -2;
+    chunkStart.push_back(hitSeq.size());
 
-    // step 6: double-diagonal detection, bins ascending, stream order inside a bin
+    // step 6: double-diagonal detection per chunk, bins ascending, stream order inside a bin
     // (CacheFriendlyOperations.cpp:38-48,185-272,337-347)
     const uint32_t mask = binSize - 1;
-    std::vector<std::vector<uint32_t> > binIdx(binSize);
-    for (uint32_t h = 0; h < hitSeq.size(); h++) binIdx[hitSeq[h] & mask].push_back(h);
     std::vector<uint8_t> prev8(dbSize, 0), mark(dbSize, 0);
     std::vector<Cand> cands;
     std::vector<Cand> tmp;
-    for (uint32_t b = 0; b < binSize; b++) {
-        tmp.clear();
-        const std::vector<uint32_t> &v = binIdx[b];
-        for (size_t n = 0; n < v.size(); n++) {
-            const uint32_t id = hitSeq[v[n]];
-            const uint8_t cur = (uint8_t) hitDiag[v[n]];
-            if (cur == prev8[id]) {
-                Cand cd;
-                cd.id = id;
-                cd.diag = hitDiag[v[n]];
-                cd.count = 0;
-                tmp.push_back(cd);
+    for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
+        std::vector<std::vector<uint32_t> > binIdx(binSize);
+        for (size_t h = chunkStart[ch]; h < chunkStart[ch + 1]; h++) binIdx[hitSeq[h] & mask].push_back((uint32_t) h);
+        std::fill(prev8.begin(), prev8.end(), 0);
+        for (uint32_t b = 0; b < binSize; b++) {
+            tmp.clear();
+            const std::vector<uint32_t> &v = binIdx[b];
+            for (size_t n = 0; n < v.size(); n++) {
+                const uint32_t id = hitSeq[v[n]];
+                const uint8_t cur = (uint8_t) hitDiag[v[n]];
+                if (cur == prev8[id]) {
+                    Cand cd;
+                    cd.id = id;
+                    cd.diag = hitDiag[v[n]];
+                    cd.count = 0;
+                    tmp.push_back(cd);
+                }
+                prev8[id] = cur;
             }
-            prev8[id] = cur;
+            for (size_t n = tmp.size(); n-- > 0;) mark[tmp[n].id] = (uint8_t) ((uint8_t) tmp[n].diag + 1);
+            for (size_t n = 0; n < tmp.size(); n++) {
+                if (mark[tmp[n].id] != (uint8_t) tmp[n].diag) cands.push_back(tmp[n]);
+                mark[tmp[n].id] = (uint8_t) tmp[n].diag;
+            }
         }
-        for (size_t n = tmp.size(); n-- > 0;) mark[tmp[n].id] = (uint8_t) ((uint8_t) tmp[n].diag + 1);
-        for (size_t n = 0; n < tmp.size(); n++) {
-            if (mark[tmp[n].id] != (uint8_t) tmp[n].diag) cands.push_back(tmp[n]);
-            mark[tmp[n].id] = (uint8_t) tmp[n].diag;
+    }
+    if (chunkStart.size() > 2) {
+        // one overflow: the two result lists are merged with mergeElementsByDiagonal (:323-326 ->
+        // CacheFriendlyOperations.cpp:84-115): re-binned in arrival order, consecutive equal 8-bit diagonals of a
+        // target collapse to the first
+        std::vector<Cand> merged;
+        for (uint32_t b = 0; b < binSize; b++) {
+            tmp.clear();
+            for (size_t n = 0; n < cands.size(); n++)
+                if ((cands[n].id & mask) == b) tmp.push_back(cands[n]);
+            for (size_t n = tmp.size(); n-- > 0;) mark[tmp[n].id] = (uint8_t) ((uint8_t) tmp[n].diag + 1);
+            for (size_t n = 0; n < tmp.size(); n++) {
+                if (mark[tmp[n].id] != (uint8_t) tmp[n].diag) merged.push_back(tmp[n]);
+                mark[tmp[n].id] = (uint8_t) tmp[n].diag;
+            }
         }
+        cands.swap(merged);
     }
     const uint64_t foundDiagonalsSize = std::max<uint64_t>(1000000, dbSize);
     if (cands.size() >= foundDiagonalsSize / 2) return -3;   // unsorted branch not restated

@@ -274,26 +274,33 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
 }
 
 // K4: double-diagonal match on the (query,target)-sorted stream
-__device__ __forceinline__ bool flagA(uint64_t s, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val) {
+// A query whose hits overflow the reference's hit buffer is matched in two independent parts (QueryMatcher.cpp:281-316):
+// split = stream position (inside the query) where the second part starts, 0xFFFFFFFF = no overflow.  The previous-hit
+// state of a target does not carry over the split; the merge of the two result lists (:323-326) collapses equal
+// consecutive diagonals across it like inside a part.
+__device__ __forceinline__ bool flagA(uint64_t s, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val,
+                                      uint32_t split) {
     const uint8_t d8 = (uint8_t) (val[s] >> 24);
-    const bool first = (s == 0) || (key[s - 1] != key[s]);
+    bool first = (s == 0) || (key[s - 1] != key[s]);
+    if (!first) first = ((val[s - 1] & 0xFFFFFFu) < split) != ((val[s] & 0xFFFFFFu) < split);
     const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) (val[s - 1] >> 24);
     return d8 == prev;
 }
 
 __global__ void __launch_bounds__(256)
 match_diag_kernel(uint64_t nHits, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val,
-                  uint8_t *__restrict__ emit) {
+                  const uint32_t *__restrict__ qSplit, int tBits, uint8_t *__restrict__ emit) {
     const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nHits) return;
+    const uint32_t split = qSplit[key[s] >> tBits];
     bool e = false;
-    if (flagA(s, key, val)) {
+    if (flagA(s, key, val, split)) {
         e = true;
         const uint8_t d8 = (uint8_t) (val[s] >> 24);
         uint64_t x = s;
         while (x > 0 && key[x - 1] == key[s]) {
             x--;
-            if (flagA(x, key, val)) {
+            if (flagA(x, key, val, split)) {
                 e = ((uint8_t) (val[x] >> 24)) != d8;
                 break;
             }
@@ -307,6 +314,31 @@ __global__ void query_hit_base_kernel(uint32_t nQ, const uint64_t *__restrict__ 
                                       const uint64_t *__restrict__ hitBase, uint64_t *__restrict__ qHitBase) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q <= nQ) qHitBase[q] = hitBase[kmerBase[posBase[q]]];
+}
+
+// where the reference's hit buffer (cap entries) overflows inside query q: the k-mer list that would fill it
+// (inBuffer + listSize >= cap) starts the second part; a second overflow is flagged (not implemented)
+__global__ void query_split_kernel(uint32_t nQ, const uint64_t *__restrict__ posBase, const uint64_t *__restrict__ kmerBase,
+                                   const uint64_t *__restrict__ hitBase, uint64_t cap, uint32_t *__restrict__ qSplit,
+                                   int *__restrict__ flag) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nQ) return;
+    const uint64_t k0 = kmerBase[posBase[q]], k1 = kmerBase[posBase[q + 1]];
+    const uint64_t h0 = hitBase[k0], total = hitBase[k1] - h0;
+    uint32_t split = 0xFFFFFFFFu;
+    if (total >= (1ull << 24)) atomicExch(flag, 1);   // stream positions are carried in 24 bits
+    if (total >= cap) {
+        // first k in [k0, k1) with hitBase[k + 1] - h0 >= cap
+        uint64_t lo = k0, hi = k1;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (hitBase[mid + 1] - h0 >= cap) hi = mid;
+            else lo = mid + 1;
+        }
+        split = (uint32_t) (hitBase[lo] - h0);
+        if (total - split >= cap) atomicExch(flag, 1);
+    }
+    qSplit[q] = split;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -511,7 +543,7 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
                     const uint2 *__restrict__ inKV, uint32_t *__restrict__ outKey,
                     uint32_t *__restrict__ outVal, uint32_t *__restrict__ bktEmit, int *__restrict__ flag,
                     const uint32_t *__restrict__ slotList, uint32_t *__restrict__ bigList, uint32_t *__restrict__ bigCount,
-                    uint32_t bigCap) {
+                    uint32_t bigCap, const uint32_t *__restrict__ qSplit) {
     __shared__ uint32_t eK[CAP], eV[CAP];
     __shared__ uint32_t cnt[PF_CNT_MAX / 2];   // packed 16-bit: counts -> group starts -> group ends
     __shared__ uint32_t part[NT / 64 + 1];
@@ -543,6 +575,7 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
     }
     const uint64_t start = bktStart[slot];
     const int shift = tBits - (int) qLog2Bins[q];
+    const uint32_t split = qSplit[q];
     const uint32_t offMask = (1u << shift) - 1;   // key & offMask = target offset inside the bucket's range
     const int nCnt = shift == 0 ? 2 : (1 << shift);
     for (int x = t; x < nCnt / 2; x += NT) cnt[x] = 0;
@@ -606,7 +639,8 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
         const uint8_t d8 = (uint8_t) (eV[p] >> 24);
         auto flagAt = [&](int x) -> bool {
             const uint8_t dx = (uint8_t) (eV[x] >> 24);
-            const bool first = (x == 0) || (eK[x - 1] != eK[x]);
+            bool first = (x == 0) || (eK[x - 1] != eK[x]);
+            if (!first) first = ((eV[x - 1] & 0xFFFFFFu) < split) != ((eV[x] & 0xFFFFFFu) < split);   // overflow split
             const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) (eV[x - 1] >> 24);
             return dx == prev;
         };
@@ -769,7 +803,7 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
     __shared__ unsigned long long keys[SEL_CAP];
     __shared__ uint32_t pay[SEL_CAP];
     __shared__ unsigned int hist[256];
-    __shared__ int sThr, sCnt, sMaxSelf;
+    __shared__ int sThr, sCnt, sMaxSelf, sQual;
     const uint32_t q = blockIdx.x;
     if (q >= nQ) return;
     const uint32_t beg = kStartOfQ[q], end = kStartOfQ[q + 1];
@@ -789,48 +823,15 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
         }
         thr = max(minDiag, thr);
         sThr = thr;
-        sCnt = 0;
-    }
-    __syncthreads();
-    const int thr = sThr;
-    // collect elements >= thr
-    for (uint32_t x = beg + threadIdx.x; x < end; x += blockDim.x) {
-        const int cnt = min(255, kScore[x]);
-        if (cnt >= thr) {
-            const int slot = atomicAdd(&sCnt, 1);
-            if (slot < SEL_CAP) {
-                const uint32_t sid = kKey[x] & ((1u << tBits) - 1);
-                // order of the cut: count desc, bin asc, stream position asc
-                keys[slot] = ((unsigned long long) (255 - cnt) << 56) | ((unsigned long long) (sid & binMask) << 40) |
-                             (unsigned long long) (kVal[x] & 0xFFFFFFu);
-                pay[slot] = x;
-            }
-        }
-    }
-    __syncthreads();
-    int n = sCnt;
-    if (n > SEL_CAP) {
-        if (threadIdx.x == 0) atomicExch(errFlag, 2);
-        n = SEL_CAP;
-    }
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int x = n + threadIdx.x; x < np2; x += blockDim.x) { keys[x] = ~0ull; pay[x] = 0xFFFFFFFFu; }
-    __syncthreads();
-    if (np2 > 1) bitonicSort(keys, pay, np2);
-    // Truncated scores (QueryMatcher.cpp:157-170): when the cut itself is the saturated 8-bit score, the reference
-    // rescales the true diagonal scores of the saturated hits against the query's self score (rescoreHits, :525-544),
-    // re-sorts them by the rescaled byte (stable) and reports 255 + byte * maxSelf / 255.
-    const bool rescored = thr >= 255;
-    auto rescaledByte = [&](uint32_t e) -> uint32_t {
-        unsigned int ns = (unsigned int) kScore[e] - 255u;
-        const float sc = (float) min(ns, 65535u);
-        const double dv = (double) ((sc / (float) sMaxSelf) * 255.0f) + 0.5;
-        return (uint32_t) (uint8_t) (int) dv;
-    };
-    if (rescored) {
-        if (threadIdx.x == 0) {
-            // self score: the query against itself on diagonal 0 (UngappedAlignment::scoreSingleSequence)
+        int qual = 0;
+        for (int c = thr; c < 256; c++) qual += (int) hist[c];
+        sQual = qual;
+        sMaxSelf = 1;
+        if (thr >= 255) {
+            // Truncated scores (QueryMatcher.cpp:157-170): the cut itself is the saturated 8-bit score, so the reference
+            // rescales the true diagonal scores of the saturated hits against the query's self score (rescoreHits,
+            // :525-544), re-sorts them by the rescaled byte (stable) and reports 255 + byte * maxSelf / 255.
+            // Self score: the query against itself on diagonal 0 (UngappedAlignment::scoreSingleSequence).
             const uint8_t *qs = qRes + qOff[q];
             const int8_t *qb = diagBias + qOff[q];
             const int qL = (int) (qOff[q + 1] - qOff[q]);
@@ -845,12 +846,80 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
             ms = ms > 65535 ? 65535 : ms;
             sMaxSelf = ms;
         }
+    }
+    __syncthreads();
+    const int thr = sThr;
+    const bool rescored = thr >= 255;
+    auto rescaledByte = [&](uint32_t e) -> uint32_t {
+        unsigned int ns = (unsigned int) kScore[e] - 255u;
+        const float sc = (float) min(ns, 65535u);
+        const double dv = (double) ((sc / (float) sMaxSelf) * 255.0f) + 0.5;
+        return (uint32_t) (uint8_t) (int) dv;
+    };
+    // order of the cut: (rescaled) count desc, then the order the reference's counting sort keeps: bin asc, stream
+    // position asc
+    auto keyOf = [&](uint32_t x) -> unsigned long long {
+        const uint32_t sid = kKey[x] & ((1u << tBits) - 1);
+        const uint32_t top = rescored ? 255u - rescaledByte(x) : 255u - (uint32_t) min(255, kScore[x]);
+        return ((unsigned long long) top << 56) | ((unsigned long long) (sid & binMask) << 40) |
+               (unsigned long long) (kVal[x] & 0xFFFFFFu);
+    };
+    // Only the first maxHits + 1 elements of that order are ever read (at most one of them is the identity target).
+    // Usually everything at or above the cut fits the LDS arrays; otherwise (very many tied candidates) the candidate
+    // list is swept in windows that cannot overflow them, keeping the best maxHits + 1 between windows.
+    const int K = min(maxHits + 1, SEL_CAP / 2);
+    if (sQual > SEL_CAP && maxHits + 1 > SEL_CAP / 2 && threadIdx.x == 0) atomicExch(errFlag, 2);
+    int n = 0;
+    if (sQual <= SEL_CAP) {
+        if (threadIdx.x == 0) sCnt = 0;
         __syncthreads();
-        for (int x = threadIdx.x; x < n; x += blockDim.x)
-            keys[x] = ((unsigned long long) (255u - rescaledByte(pay[x])) << 56) | (unsigned long long) x;
+        for (uint32_t x = beg + threadIdx.x; x < end; x += blockDim.x) {
+            if (min(255, kScore[x]) >= thr) {
+                const int slot = atomicAdd(&sCnt, 1);
+                keys[slot] = keyOf(x);
+                pay[slot] = x;
+            }
+        }
+        __syncthreads();
+        n = sCnt;
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        for (int x = n + threadIdx.x; x < np2; x += blockDim.x) { keys[x] = ~0ull; pay[x] = 0xFFFFFFFFu; }
         __syncthreads();
         if (np2 > 1) bitonicSort(keys, pay, np2);
+    } else {
+        const uint32_t W = (uint32_t) (SEL_CAP - K);
+        int have = 0;
+        for (uint32_t base = beg; base < end; base += W) {
+            __syncthreads();
+            if (threadIdx.x == 0) sCnt = have;
+            __syncthreads();
+            const unsigned long long bound = have >= K ? keys[K - 1] : ~0ull;
+            __syncthreads();
+            const uint32_t stop = min(end, base + W);
+            for (uint32_t x = base + threadIdx.x; x < stop; x += blockDim.x) {
+                if (min(255, kScore[x]) >= thr) {
+                    const unsigned long long kk = keyOf(x);
+                    if (kk < bound) {
+                        const int slot = atomicAdd(&sCnt, 1);
+                        keys[slot] = kk;
+                        pay[slot] = x;
+                    }
+                }
+            }
+            __syncthreads();
+            const int m = sCnt;
+            int np2 = 1;
+            while (np2 < m) np2 <<= 1;
+            for (int x = m + threadIdx.x; x < np2; x += blockDim.x) { keys[x] = ~0ull; pay[x] = 0xFFFFFFFFu; }
+            __syncthreads();
+            if (np2 > 1) bitonicSort(keys, pay, np2);
+            __syncthreads();
+            have = min(m, K);
+        }
+        n = have;
     }
+    __syncthreads();
     // take the first (maxHits - hasIdentity) with id != identity (getResult, QueryMatcher.cpp:364-420)
     // done serially by thread 0 into the key array re-used for the final order
     __shared__ int sTake;
@@ -876,7 +945,7 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
     }
     __syncthreads();
     const int take = sTake;
-    np2 = 1;
+    int np2 = 1;
     while (np2 < take) np2 <<= 1;
     for (int x = take + threadIdx.x; x < np2; x += blockDim.x) { keys[x] = ~0ull; pay[x] = 0xFFFFFFFFu; }
     __syncthreads();
@@ -1162,13 +1231,22 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         SD_HIP(ctx, hipMemsetAsync(dStats.p, 0, (size_t) bq * 4 * sizeof(uint64_t), ctx->stream));
         hipLaunchKernelGGL(stats_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
                            dHitBase.p, nKmers, nHits, dStats.p);
-        // reference overflow path check (per query hits >= maxDbMatches)
+        // the reference's hit buffer holds maxDbMatches entries per query; where a query overflows it once, the match runs
+        // on the two parts separately (query_split_kernel); two overflows are not implemented
+        WsView<uint32_t> dQSplit(ctx, "pf.dQSplit");
+        WsView<int> dSplitFlag(ctx, "pf.dSplitFlag");
+        SD_HIP(ctx, dQSplit.alloc(bq));
+        SD_HIP(ctx, dSplitFlag.alloc(1));
+        SD_HIP(ctx, hipMemsetAsync(dSplitFlag.p, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(query_split_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
+                           dHitBase.p, maxDbMatches, dQSplit.p, dSplitFlag.p);
+        int hSplitFlag = 0;
+        SD_HIP(ctx, hipMemcpyAsync(&hSplitFlag, dSplitFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(hStats.data(), dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t x = 0; x < bq; x++)
-            if (hStats[4 * x + 1] >= maxDbMatches)
-                return sdFail(ctx, SD_EUNSUPPORTED, "query %u: %llu index hits reach the reference's overflow path (QueryMatcher.cpp:281-316), not implemented",
-                              qBeg + x, (unsigned long long) hStats[4 * x + 1]);
+        if (hSplitFlag)
+            return sdFail(ctx, SD_EUNSUPPORTED, "a query of the batch [%u, %u) overflows the reference's hit buffer twice (or has >= 2^24 index hits): "
+                          "the double-overflow route of QueryMatcher.cpp:289-303 is not implemented", qBeg, qBeg + bq);
 
         hs.reset(new HostScope(ctx, "pf.gather_sort_match"));
         uint32_t nCand = 0, nKept = 0;
@@ -1253,7 +1331,8 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                         ProfScope ps(ctx, "prefilter_bucket_match");
                         hipLaunchKernelGGL((bucket_match_kernel<128, PF_BUCKET_CAP>), dim3((unsigned) totalBins), dim3(128), 0, ctx->stream,
                                            bq, dBinBase.p, dQLog2.p, tBits, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p,
-                                           dValA.p, dBktEmit.p, dFlag.p, (const uint32_t *) nullptr, dBigList.p, dBigCount, bigCap);
+                                           dValA.p, dBktEmit.p, dFlag.p, (const uint32_t *) nullptr, dBigList.p, dBigCount, bigCap,
+                                           dQSplit.p);
                     }
                     uint32_t nBig = 0;
                     SD_HIP(ctx, hipMemcpyAsync(&nBig, dBigCount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1263,7 +1342,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                         hipLaunchKernelGGL((bucket_match_kernel<256, PF_BUCKET_CAP_BIG>), dim3(nBig), dim3(256), 0, ctx->stream, bq,
                                            dBinBase.p, dQLog2.p, tBits, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p, dValA.p,
                                            dBktEmit.p, dFlag.p, (const uint32_t *) dBigList.p, (uint32_t *) nullptr,
-                                           (uint32_t *) nullptr, 0u);
+                                           (uint32_t *) nullptr, 0u, dQSplit.p);
                     }
                     rc = exclusiveScanWiden(ctx, dBktEmit.p, dEmitOff.p, nSlots + 1, scanTmp);
                     if (rc != SD_OK) return rc;
@@ -1311,7 +1390,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             {
                 ProfScope ps(ctx, "prefilter_match_diag");
                 hipLaunchKernelGGL(match_diag_kernel, dim3(gridFor(nHits, 256)), dim3(256), 0, ctx->stream, nHits, dKeyB.p, dValB.p,
-                                   dEmit.p);
+                                   dQSplit.p, tBits, dEmit.p);
             }
             SD_HIP(ctx, hipMemsetAsync(dEmit.p + nHits, 0, 1, ctx->stream));
             int rc = exclusiveScanWiden(ctx, dEmit.p, dEmitPos.p, nHits + 1, scanTmp);
@@ -1405,7 +1484,9 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         SD_HIP(ctx, hipMemcpyAsync(outCount + qBeg, dOutCount.p, bq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         if (stats) SD_HIP(ctx, hipMemcpyAsync(stats + (size_t) qBeg * 4, dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (hErr == 2) return sdFail(ctx, SD_EUNSUPPORTED, "more than %d tied candidates at the score cut of one query", SEL_CAP);
+        if (hErr == 2)
+            return sdFail(ctx, SD_EUNSUPPORTED, "more than %d candidates at the score cut of one query together with maxHitsPerQuery > %d",
+                          SEL_CAP, SEL_CAP / 2 - 1);
         hs.reset(new HostScope(ctx, "pf.scatter"));
         // the caller's rows are par->maxHitsPerQuery wide
         for (uint32_t x = 0; x < bq; x++)

@@ -118,3 +118,34 @@ def test_prefilter_rescoring_path_matches_reference(gpu, host, oracle):
         assert m == len(exp), (q, m, len(exp))
         assert (hits[q, :m]['seqId'] == exp[:, 1]).all() and (hits[q, :m]['score'] == exp[:, 2]).all(), q
         assert (hits[q, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), q
+
+
+def test_prefilter_hit_buffer_overflow_matches_reference(gpu, host, oracle, monkeypatch):
+    """the one-overflow path on the device (bucket path and sort fallback) against rows from the real reference"""
+    g = np.load(os.path.join(GOLD, 'overflow_vectors.npz'))
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    res = np.concatenate(nums)
+    sw_b, dg_b, km_b = host.comp_bias(res, off)
+    idx = host.build_index(res, off)
+    tgt = api.Target(gpu, host, idx)
+    par = api.prefilter_params(host, idx.n, max_hits=300, cov_thr=0.0, bin_size=2)
+    qs = [int(q) for q in g['queries']]
+    qoff = np.zeros(len(qs) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(nums[q]) for q in qs])
+    qres = np.concatenate([nums[q] for q in qs])
+    qkm = np.concatenate([km_b[int(off[q]):int(off[q + 1])] for q in qs])
+    qdg = np.concatenate([dg_b[int(off[q]):int(off[q + 1])] for q in qs])
+    rows = g['pf_rows']
+    for mode in ('bucket', 'sort'):
+        if mode == 'sort':
+            monkeypatch.setenv('SD_PF_SORT', '1')
+        hits, cnt, st = api.prefilter(gpu, tgt, par, qres, qoff, qkm, qdg, np.array(qs, np.uint32), want_stats=True)
+        assert int(st[0, 1]) == int(g['index_hits_q0'][0])
+        for x, q in enumerate(qs):
+            exp = rows[rows[:, 0] == q]
+            m = int(cnt[x])
+            assert m == len(exp), (mode, q, m, len(exp))
+            assert (hits[x, :m]['seqId'] == exp[:, 1]).all() and (hits[x, :m]['score'] == exp[:, 2]).all(), (mode, q)
+            assert (hits[x, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (mode, q)

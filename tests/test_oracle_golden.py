@@ -160,3 +160,19 @@ def test_prefilter_rescoring_path(oracle):
         exp = rows[rows[:, 0] == q]
         ids, sc, dg, _ = tgt.prefilter(nums[q], identity_id=int(q), max_hits=300)
         assert len(ids) == len(exp) and (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all() and (dg == exp[:, 3]).all(), q
+
+
+def test_prefilter_hit_buffer_overflow(oracle):
+    """a query with more index hits than the reference's hit buffer (2*max(1e6, #targets)): one overflow, two match
+    parts, merged result lists (QueryMatcher.cpp:281-326); rows from the real reference (tools/make_golden_overflow.py)"""
+    g = np.load(os.path.join(GOLD, 'overflow_vectors.npz'))
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    tgt = oracle.target(np.concatenate(nums), off)
+    rows = g['pf_rows']
+    assert int(g['index_hits_q0'][0]) >= 2000000
+    for q in g['queries']:
+        exp = rows[rows[:, 0] == q]
+        ids, sc, dg, st = tgt.prefilter(nums[q], identity_id=int(q), max_hits=300)
+        assert len(ids) == len(exp) and (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all() and (dg == (exp[:, 3] & 0xFFFF)).all(), q
