@@ -1322,7 +1322,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                 SD_HIP(ctx, hipMemcpyAsync(&totalBins, dBinBase.p + bq, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
                 SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 if (hFlag == 0 && totalBins > 0) {
-                    const uint32_t bigCap = 1u << 16;
+                    const uint32_t bigCap = (uint32_t) std::min<size_t>(nSlots, 1u << 26);   // every bucket may be oversize on very large target sets
                     WsView<uint32_t> dBigList(ctx, "pf.dBigList");
                     SD_HIP(ctx, dBigList.alloc(bigCap + 1));
                     uint32_t *dBigCount = dBigList.p + bigCap;
