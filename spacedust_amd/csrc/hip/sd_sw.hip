@@ -1047,51 +1047,51 @@ k_bound_apply(uint32_t nPairs, SwTask *__restrict__ tasks, const uint64_t *__res
 }
 
 // ---- tasks of one query two by two (shared-profile kernels) --------------------------------------------------------
-// key64 = class | query | target-length bucket: a stable sort puts the tasks of a (class, query) run together, longest
-// target first; inside a run consecutive tasks form pairs, an odd last task stays alone.
+// key = class (5 bits) | query (17 bits) | target-length bucket (10 bits): one stable sort puts the tasks of a
+// (class, query) run together, longest target first; inside a run of a packed class consecutive tasks form pairs, an
+// odd last task stays alone.  Invalid tasks sort last (all ones).
 constexpr uint32_t PAIR_NONE = 0xFFFFFFFFu;
+constexpr int PAIR_QUERY_BITS = 17;
 __global__ void __launch_bounds__(256)
-k_pair_keys(uint32_t n, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ pairQ, uint64_t *__restrict__ key64) {
+k_pair_keys(uint32_t n, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ pairQ, uint32_t *__restrict__ key2) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = keys[i];
-    key64[i] = (k == KEY_INVALID || (k >> 10) >= FIRST_INT32_CLASS)
-                   ? ~0ull
-                   : (((uint64_t) (k >> 10)) << 34) | ((uint64_t) pairQ[i] << 10) | (uint64_t) (k & 1023u);
+    key2[i] = k == KEY_INVALID ? 0xFFFFFFFFu : ((k >> 10) << 27) | (pairQ[i] << 10) | (k & 1023u);
 }
 __global__ void __launch_bounds__(256)
-k_pair_heads(uint32_t n, const uint64_t *__restrict__ key64S, uint32_t *__restrict__ headPos) {
+k_pair_heads(uint32_t n, const uint32_t *__restrict__ keyS, uint32_t *__restrict__ headPos) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const bool head = p == 0 || (key64S[p] >> 10) != (key64S[p - 1] >> 10);
+    const bool head = p == 0 || (keyS[p] >> 10) != (keyS[p - 1] >> 10);
     headPos[p] = head ? p : 0u;
 }
 __global__ void __launch_bounds__(256)
-k_pair_leaders(uint32_t n, const uint64_t *__restrict__ key64S, const uint32_t *__restrict__ runStart, uint8_t *__restrict__ leader) {
+k_pair_leaders(uint32_t n, const uint32_t *__restrict__ keyS, const uint32_t *__restrict__ runStart, uint8_t *__restrict__ leader) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n) return;
-    leader[p] = (p < n && key64S[p] != ~0ull && ((p - runStart[p]) & 1u) == 0) ? 1 : 0;
+    leader[p] = (p < n && (keyS[p] >> 27) < FIRST_INT32_CLASS && ((p - runStart[p]) & 1u) == 0) ? 1 : 0;
 }
 __global__ void __launch_bounds__(256)
-k_pair_emit(uint32_t n, const uint64_t *__restrict__ key64S, const uint32_t *__restrict__ vals, const uint8_t *__restrict__ leader,
+k_pair_emit(uint32_t n, const uint32_t *__restrict__ keyS, const uint32_t *__restrict__ vals, const uint8_t *__restrict__ leader,
             const uint64_t *__restrict__ pairIdx, uint32_t *__restrict__ order2) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n || !leader[p]) return;
     const uint64_t w = pairIdx[p];
     order2[2 * w] = vals[p];
-    const bool mate = p + 1 < n && (key64S[p + 1] >> 10) == (key64S[p] >> 10);
+    const bool mate = p + 1 < n && (keyS[p + 1] >> 10) == (keyS[p] >> 10);
     order2[2 * w + 1] = mate ? vals[p + 1] : PAIR_NONE;
 }
 // pair-index boundaries of the packed classes: b[c] = number of pairs of classes < c
-__global__ void k_pair_bounds(const uint64_t *__restrict__ key64S, uint32_t n, const uint64_t *__restrict__ pairIdx,
+__global__ void k_pair_bounds(const uint32_t *__restrict__ keyS, uint32_t n, const uint64_t *__restrict__ pairIdx,
                               uint32_t *__restrict__ b, int nb) {
     const int c = threadIdx.x;
     if (c >= nb) return;
-    const uint64_t want = (uint64_t) c << 34;
+    const uint32_t want = (uint32_t) c << 27;
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (key64S[mid] < want) lo = mid + 1;
+        if (keyS[mid] < want) lo = mid + 1;
         else hi = mid;
     }
     b[c] = (uint32_t) pairIdx[lo];
@@ -1106,15 +1106,14 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
                 const sd_seqset *q, const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut,
                 uint32_t *nValid, const uint32_t *dPairQ /* non-null: every task scans its whole query, pair them up */) {
     const unsigned grid = (nPairs + 255) / 256;
-    int rc = devSortPairs(ctx, dKeys, dKeysSorted, dVals, dOrder, nPairs, 15);
-    if (rc != SD_OK) return rc;
+    int rc = SD_OK;
     uint32_t *dOrder2 = nullptr, *dPairBounds = nullptr;
     if (dPairQ) {
-        uint64_t *dKey64 = nullptr, *dKey64S = nullptr, *dPairIdx = nullptr;
-        uint32_t *dVals2 = nullptr, *dHead = nullptr, *dRunStart = nullptr;
+        // one sort serves both the pairing of the packed classes and the plain order of the int32 classes
+        uint32_t *dKey2 = nullptr, *dVals2 = nullptr, *dHead = nullptr, *dRunStart = nullptr;
+        uint64_t *dPairIdx = nullptr;
         uint8_t *dLeader = nullptr;
-        SD_HIP(ctx, wsGet(ctx, "sp.key64", (size_t) nPairs, &dKey64));
-        SD_HIP(ctx, wsGet(ctx, "sp.key64s", (size_t) nPairs, &dKey64S));
+        SD_HIP(ctx, wsGet(ctx, "sp.key2", (size_t) nPairs, &dKey2));
         SD_HIP(ctx, wsGet(ctx, "sp.vals2", (size_t) nPairs, &dVals2));
         SD_HIP(ctx, wsGet(ctx, "sp.head", (size_t) nPairs, &dHead));
         SD_HIP(ctx, wsGet(ctx, "sp.runstart", (size_t) nPairs, &dRunStart));
@@ -1122,15 +1121,11 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
         SD_HIP(ctx, wsGet(ctx, "sp.pairidx", (size_t) nPairs + 1, &dPairIdx));
         SD_HIP(ctx, wsGet(ctx, "sp.order2", (size_t) 2 * nPairs, &dOrder2));
         SD_HIP(ctx, wsGet(ctx, "sp.bounds", 32, &dPairBounds));
-        hipLaunchKernelGGL(k_pair_keys, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dPairQ, dKey64);
-        {
-            size_t bytes = 0;
-            SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dKey64, dKey64S, dVals, dVals2, (int) nPairs, 0, 40, ctx->stream));
-            uint8_t *tmp = nullptr;
-            SD_HIP(ctx, wsGet(ctx, "al.sorttmp", bytes + 256, &tmp));
-            SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, bytes, dKey64, dKey64S, dVals, dVals2, (int) nPairs, 0, 40, ctx->stream));
-        }
-        hipLaunchKernelGGL(k_pair_heads, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKey64S, dHead);
+        hipLaunchKernelGGL(k_pair_keys, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dPairQ, dKey2);
+        rc = devSortPairs(ctx, dKey2, dKeysSorted, dVals, dVals2, nPairs, 32);
+        if (rc != SD_OK) return rc;
+        dOrder = dVals2;
+        hipLaunchKernelGGL(k_pair_heads, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dHead);
         {
             size_t bytes = 0;
             SD_HIP(ctx, hipcub::DeviceScan::InclusiveScan(nullptr, bytes, dHead, dRunStart, MaxU32(), (int) nPairs, ctx->stream));
@@ -1138,7 +1133,7 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
             SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
             SD_HIP(ctx, hipcub::DeviceScan::InclusiveScan(tmp, bytes, dHead, dRunStart, MaxU32(), (int) nPairs, ctx->stream));
         }
-        hipLaunchKernelGGL(k_pair_leaders, dim3((nPairs + 256) / 256), dim3(256), 0, ctx->stream, nPairs, dKey64S, dRunStart, dLeader);
+        hipLaunchKernelGGL(k_pair_leaders, dim3((nPairs + 256) / 256), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dRunStart, dLeader);
         {
             size_t bytes = 0;
             hipcub::TransformInputIterator<uint64_t, WidenU8, const uint8_t *> it(dLeader, WidenU8());
@@ -1147,11 +1142,15 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
             SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
             SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, dPairIdx, (int) (nPairs + 1), ctx->stream));
         }
-        hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKey64S, dVals2, dLeader, dPairIdx, dOrder2);
-        hipLaunchKernelGGL(k_pair_bounds, dim3(1), dim3(64), 0, ctx->stream, dKey64S, nPairs, dPairIdx, dPairBounds,
+        hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dVals2, dLeader, dPairIdx, dOrder2);
+        hipLaunchKernelGGL(k_pair_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, dPairIdx, dPairBounds,
                            (int) FIRST_INT32_CLASS + 1);
+        hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1u << 27, dBounds, (int) N_SCORE_CLASSES + 1);
+    } else {
+        rc = devSortPairs(ctx, dKeys, dKeysSorted, dVals, dOrder, nPairs, 15);
+        if (rc != SD_OK) return rc;
+        hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1024u, dBounds, (int) N_SCORE_CLASSES + 1);
     }
-    hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1024u, dBounds, (int) N_SCORE_CLASSES + 1);
     // strip hand-off workspace for queries longer than one 1024-row strip
     hipLaunchKernelGGL(k_bound_need, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dKeys, dScanA);
     SD_HIP(ctx, hipMemsetAsync(dScanA + nPairs, 0, sizeof(uint64_t), ctx->stream));
@@ -1512,7 +1511,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     hipLaunchKernelGGL(k_make_fwd, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dPT, dIdent, queries->dOff, targets->dOff,
                        dTasks, dFwdKeys, dVals, dRes, usePk);
     hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dFwdKeys, dCells + 0);
-    const uint32_t *dShare = (getenv("SD_SW_NOSHARE") || queries->n >= (1u << 24)) ? nullptr : dPQ;   // forward passes scan whole queries: pair by query
+    const uint32_t *dShare = (getenv("SD_SW_NOSHARE") || queries->n >= (1u << PAIR_QUERY_BITS)) ? nullptr : dPQ;   // forward passes scan whole queries: pair by query
     int rc = devRunScore(ctx, nPairs, dFwdKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go,
                          ge, dOut32, &nValid, dShare);
     if (rc != SD_OK) return rc;
