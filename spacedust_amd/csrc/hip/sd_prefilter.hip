@@ -32,8 +32,9 @@ struct sd_target {
     uint64_t nEntries = 0;
     uint64_t tableSize = 0;
     uint32_t *dOffsets = nullptr;
-    uint32_t *dEntrySeq = nullptr;
+    uint32_t *dEntrySeq = nullptr;   // upload staging only (freed after the interleaved copy is built)
     uint16_t *dEntryPos = nullptr;
+    uint2 *dEntries = nullptr;       // (seqId, position) per index entry, 8 B: one sector per short list instead of two
     uint8_t *dMasked = nullptr;
     uint64_t *dSeqOff = nullptr;
     int16_t *dExt3Score = nullptr;
@@ -137,6 +138,12 @@ count_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t
     if (lane == 0) kmerCount[p] = total;
 }
 
+__global__ void interleave_entries_kernel(uint64_t n, const uint32_t *__restrict__ seq, const uint16_t *__restrict__ pos,
+                                          uint2 *__restrict__ out) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_uint2(seq[i], (uint32_t) pos[i]);
+}
+
 // K2: emit k-mers (+ index list start/len, + owning position) in the reference's enumeration order
 __global__ void __launch_bounds__(256)
 emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
@@ -214,8 +221,8 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
 __global__ void __launch_bounds__(256)
 gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const uint32_t *__restrict__ kLen,
                    const uint32_t *__restrict__ kPos, const uint64_t *__restrict__ hitBase,
-                   const uint64_t *__restrict__ posBase, uint32_t nQ, const uint32_t *__restrict__ entrySeq,
-                   const uint16_t *__restrict__ entryPos, int tBits, const uint64_t *__restrict__ qHitBase,
+                   const uint64_t *__restrict__ posBase, uint32_t nQ, const uint2 *__restrict__ entries, int tBits,
+                   const uint64_t *__restrict__ qHitBase,
                    uint32_t *__restrict__ hitKey, uint32_t *__restrict__ hitVal, uint16_t *__restrict__ hitDiag) {
     const uint64_t kidx = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -242,8 +249,9 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
 #pragma unroll
         for (uint32_t x = 0; x < 8; x++) {
             if (x < len) {
-                sid[x] = entrySeq[start + x];
-                ep[x] = entryPos[start + x];
+                const uint2 en = entries[start + x];
+                sid[x] = en.x;
+                ep[x] = (uint16_t) en.y;
             }
         }
 #pragma unroll
@@ -264,8 +272,9 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
         const int i2 = __shfl(i, src, 64);
         const uint64_t b2 = ((uint64_t) __shfl((uint32_t) (base >> 32), src, 64) << 32) | __shfl((uint32_t) base, src, 64);
         for (uint32_t x = lane; x < l2; x += 64) {
-            const uint32_t sid = entrySeq[s2 + x];
-            const uint16_t d = (uint16_t) (i2 - (int) entryPos[s2 + x]);
+            const uint2 en = entries[s2 + x];
+            const uint32_t sid = en.x;
+            const uint16_t d = (uint16_t) (i2 - (int) en.y);
             hitKey[b2 + x] = (q2 << tBits) | sid;
             hitVal[b2 + x] = ((uint32_t) (d & 0xFF) << 24) | (uint32_t) (b2 + x - qHitBase[q2]);
             hitDiag[b2 + x] = d;
@@ -1103,10 +1112,23 @@ int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, con
         ok = ok && up((void **) &t->dExt2Score, ext2Score, (size_t) 400 * 400 * sizeof(int16_t));
         ok = ok && up((void **) &t->dExt2Index, ext2Index, (size_t) 400 * 400 * sizeof(uint16_t));
     }
+    ok = ok && hipMalloc((void **) &t->dEntries, (std::max<uint64_t>(nEntries, 1) + 8) * sizeof(uint2)) == hipSuccess;
     if (!ok) {
         sd_target_destroy(t);
         return sdFail(ctx, SD_ENOMEM, "sd_target_create: device allocation/upload failed");
     }
+    if (nEntries > 0) {
+        hipLaunchKernelGGL(interleave_entries_kernel, dim3((unsigned) ((nEntries + 255) / 256)), dim3(256), 0, ctx->stream, nEntries,
+                           t->dEntrySeq, t->dEntryPos, t->dEntries);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            sd_target_destroy(t);
+            return sdFail(ctx, SD_EHIP, "sd_target_create: interleaving the index entries failed");
+        }
+    }
+    (void) hipFree(t->dEntrySeq);
+    (void) hipFree(t->dEntryPos);
+    t->dEntrySeq = nullptr;
+    t->dEntryPos = nullptr;
     *out = t;
     return SD_OK;
 }
@@ -1114,7 +1136,7 @@ int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, con
 void sd_target_destroy(sd_target *t) {
     if (!t) return;
     void *ptrs[] = {t->dOffsets, t->dEntrySeq, t->dEntryPos, t->dMasked, t->dSeqOff, t->dExt3Score, t->dExt3Index,
-                    t->dExt2Score, t->dExt2Index};
+                    t->dExt2Score, t->dExt2Index, t->dEntries};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     delete t;
@@ -1282,7 +1304,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             {
                 ProfScope ps(ctx, "prefilter_gather_hits");
                 hipLaunchKernelGGL(gather_hits_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKStart.p,
-                                   dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, T->dEntrySeq, T->dEntryPos, tBits, dQHitBase.p,
+                                   dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, (const uint2 *) T->dEntries, tBits, dQHitBase.p,
                                    dKeyA.p, dValA.p, dDiag.p);
             }
             // ---- double-diagonal match: bucketed LDS path, or (fallback / SD_PF_SORT=1) global radix sort + match
@@ -1369,7 +1391,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                     // sub-batch with the global sort; dKeyA / dValA were overwritten by the emitted hits, so gather again
                     ProfScope ps(ctx, "prefilter_gather_hits");
                     hipLaunchKernelGGL(gather_hits_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKStart.p,
-                                       dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, T->dEntrySeq, T->dEntryPos, tBits, dQHitBase.p,
+                                       dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, (const uint2 *) T->dEntries, tBits, dQHitBase.p,
                                        dKeyA.p, dValA.p, dDiag.p);
                 }
             }
