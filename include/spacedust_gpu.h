@@ -203,6 +203,8 @@ int sd_host_index_arrays(sd_host_index *ix, const uint32_t **kmerOffsets, const 
 void sd_host_index_destroy(sd_host_index *ix);
 int sd_host_ext_matrix(sd_host *h, int wordLen, const int16_t **score, const uint16_t **index, uint32_t *size);
 int sd_host_kmer_threshold(float sensitivity, int kmerSize);
+/* IndexTable::computeKmerSize (M/src/prefiltering/IndexTable.h:439-449): 6 below 3.35e9 target residues, else 7 */
+int sd_host_auto_kmer_size(uint64_t targetResidues);
 unsigned sd_host_bin_size(uint64_t dbSize, uint64_t l2CacheSize); /* l2CacheSize 0 = sysconf of this host */
 /* the (query, target) pair list Alignment::run walks (Alignment.cpp:346-379), from sd_prefilter_batch's row-per-query
  * output; returns the number of pairs (pairQ / pairT NULL: count only) */

@@ -95,6 +95,7 @@ def load():
         'sd_host_index_destroy': (None, [_vp]),
         'sd_host_ext_matrix': (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint32)]),
         'sd_host_kmer_threshold': (C.c_int, [C.c_float, C.c_int]),
+        'sd_host_auto_kmer_size': (C.c_int, [C.c_uint64]),
         'sd_host_bin_size': (C.c_uint, [C.c_uint64, C.c_uint64]),
         'sd_host_pair_list': (C.c_uint64, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
         'sd_host_lgamma_table': (C.c_int, [_vp, C.c_uint32]),
@@ -138,7 +139,7 @@ DECLARED_SYMBOLS = [
     'sd_sw_align_batch', 'sd_sw_align_batch_compact', 'sd_sw_align_batch_hostpath', 'sd_sw_score_batch', 'sd_sw_last_cells', 'sd_target_create', 'sd_target_destroy',
     'sd_prefilter_batch', 'sd_clusterhits_batch', 'sd_host_create', 'sd_host_destroy', 'sd_host_matrix',
     'sd_host_map_sequence', 'sd_host_comp_bias', 'sd_host_index_build', 'sd_host_index_info', 'sd_host_index_arrays',
-    'sd_host_index_destroy', 'sd_host_ext_matrix', 'sd_host_kmer_threshold', 'sd_host_bin_size', 'sd_host_pair_list',
+    'sd_host_index_destroy', 'sd_host_ext_matrix', 'sd_host_kmer_threshold', 'sd_host_auto_kmer_size', 'sd_host_bin_size', 'sd_host_pair_list',
     'sd_host_lgamma_table', 'sd_host_evalue', 'sd_host_bitscore', 'sd_agg_create', 'sd_agg_destroy', 'sd_agg_add',
     'sd_agg_finish', 'sd_agg_stats', 'sd_agg_get', 'sd_agg_write_tsv',
 ]

@@ -70,6 +70,9 @@ class Host:
     def kmer_threshold(self, sensitivity, k):
         return self.L.sd_host_kmer_threshold(sensitivity, k)
 
+    def auto_kmer_size(self, target_residues):
+        return self.L.sd_host_auto_kmer_size(int(target_residues))
+
     def bin_size(self, db_size, l2=0):
         return self.L.sd_host_bin_size(db_size, l2)
 

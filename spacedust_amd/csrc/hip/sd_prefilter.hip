@@ -144,6 +144,158 @@ __global__ void interleave_entries_kernel(uint64_t n, const uint32_t *__restrict
     if (i < n) out[i] = make_uint2(seq[i], (uint32_t) pos[i]);
 }
 
+// ---- k = 7 (targets >= 3.35e9 residues, IndexTable.h:439-449): spaced seed 11010110011 (span 11, Sequence.h:24), divide
+// strategy [2,2,3] after the reversal at KmerGenerator.cpp:84-85.  generateKmerList's two array products
+// (KmerGenerator.cpp:107-216) nest as  for a in list0: for b in list1(a): for c in list2(a,b)  with the `short` cutoffs
+//   a: s0[a] >= thr - best1 - best2;  b: s1[b] >= thr - s0[a] - best2;  c: s2[c] >= thr - (s0[a] + s1[b])
+// and k-mer index i0[a] + 400 i1[b] + 160000 i2[c]; that loop order is the order of the hit stream.
+constexpr int SPAN7 = 11;
+__constant__ uint8_t c_seed7[7] = {0, 1, 3, 5, 6, 9, 10};
+
+struct PosInfo7 {
+    uint32_t q;
+    int i;
+    bool ok;
+    uint32_t idx0, idx1, idx2;
+    int thr;
+};
+
+__device__ __forceinline__ PosInfo7 decodePos7(uint64_t p, const uint64_t *__restrict__ posBase, uint32_t nQ,
+                                               const uint8_t *__restrict__ qRes, const uint64_t *__restrict__ qOff,
+                                               const int16_t *__restrict__ kmerBias, int kmerThr) {
+    PosInfo7 r;
+    uint32_t lo = 0, hi = nQ;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (posBase[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    r.q = lo;
+    r.i = (int) (p - posBase[lo]);
+    const uint8_t *s = qRes + qOff[lo] + r.i;
+    uint8_t w[7];
+    bool hasX = false;
+#pragma unroll
+    for (int x = 0; x < 7; x++) {
+        w[x] = s[c_seed7[x]];
+        hasX |= (w[x] >= 20);
+    }
+    r.ok = !hasX;
+    r.idx0 = w[0] + 20u * w[1];
+    r.idx1 = w[2] + 20u * w[3];
+    r.idx2 = w[4] + 20u * w[5] + 400u * w[6];
+    int b = kmerBias[qOff[lo] + r.i];
+    int t = kmerThr - b;
+    r.thr = t > 0 ? t : 0;
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+count_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
+                    const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
+                    const int16_t *__restrict__ ext2Score, const int16_t *__restrict__ ext3Score,
+                    uint32_t *__restrict__ kmerCount) {
+    const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= nPos) return;
+    PosInfo7 pi = decodePos7(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr);
+    uint32_t total = 0;
+    if (pi.ok) {
+        const int16_t *row0 = ext2Score + (size_t) pi.idx0 * 400;
+        const int16_t *row1 = ext2Score + (size_t) pi.idx1 * 400;
+        const int16_t *row2 = ext3Score + (size_t) pi.idx2 * 8000;
+        const int best2 = row2[0];
+        const int rest0 = (int) (short) ((int) row1[0] + best2);
+        const int n0 = countGE(row0, 400, (int) (short) (pi.thr - rest0));
+        for (int a = 0; a < n0; a++) {
+            const int sa = row0[a];
+            const int nb = countGE(row1, 400, (int) (short) (pi.thr - sa - best2));
+            for (int b = lane; b < nb; b += 64) {
+                const int sab = (int) (short) (sa + (int) row1[b]);
+                total += (uint32_t) countGE(row2, 8000, (int) (short) (pi.thr - sab));
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0) kmerCount[p] = total;
+}
+
+__global__ void __launch_bounds__(256)
+emit_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
+                   const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
+                   const int16_t *__restrict__ ext2Score, const uint16_t *__restrict__ ext2Index,
+                   const int16_t *__restrict__ ext3Score, const uint16_t *__restrict__ ext3Index,
+                   const uint32_t *__restrict__ idxOffsets, const uint64_t *__restrict__ kmerBase,
+                   uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen, uint32_t *__restrict__ kPos) {
+    const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= nPos) return;
+    PosInfo7 pi = decodePos7(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr);
+    if (!pi.ok) return;
+    const int16_t *row0 = ext2Score + (size_t) pi.idx0 * 400;
+    const int16_t *row1 = ext2Score + (size_t) pi.idx1 * 400;
+    const int16_t *row2 = ext3Score + (size_t) pi.idx2 * 8000;
+    const uint16_t *ix0 = ext2Index + (size_t) pi.idx0 * 400;
+    const uint16_t *ix1 = ext2Index + (size_t) pi.idx1 * 400;
+    const uint16_t *ix2 = ext3Index + (size_t) pi.idx2 * 8000;
+    const int best2 = row2[0];
+    const int rest0 = (int) (short) ((int) row1[0] + best2);
+    const int n0 = countGE(row0, 400, (int) (short) (pi.thr - rest0));
+    uint64_t base = kmerBase[p];
+    const uint32_t qi = (pi.q << 16) | (uint32_t) pi.i;
+    for (int a = 0; a < n0; a++) {
+        const int sa = row0[a];
+        const uint32_t ka = ix0[a];
+        const int nb = countGE(row1, 400, (int) (short) (pi.thr - sa - best2));
+        for (int b0 = 0; b0 < nb; b0 += 64) {
+            const int b = b0 + lane;
+            uint32_t c = 0;
+            if (b < nb) {
+                const int sab = (int) (short) (sa + (int) row1[b]);
+                c = (uint32_t) countGE(row2, 8000, (int) (short) (pi.thr - sab));
+            }
+            uint32_t incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            const uint32_t excl = incl - c;
+            const uint32_t chunkTotal = __shfl(incl, 63, 64);
+            if (b < nb) {
+                const uint32_t kab = ka + 400u * (uint32_t) ix1[b];
+                const uint64_t w = base + excl;
+                uint32_t x = 0;
+                for (; x + 4 <= c; x += 4) {
+                    uint32_t km[4], s4[4], e4[4];
+#pragma unroll
+                    for (int y = 0; y < 4; y++) km[y] = kab + 160000u * (uint32_t) ix2[x + y];
+#pragma unroll
+                    for (int y = 0; y < 4; y++) {
+                        s4[y] = idxOffsets[km[y]];
+                        e4[y] = idxOffsets[km[y] + 1];
+                    }
+#pragma unroll
+                    for (int y = 0; y < 4; y++) {
+                        kStart[w + x + y] = s4[y];
+                        kLen[w + x + y] = e4[y] - s4[y];
+                        kPos[w + x + y] = qi;
+                    }
+                }
+                for (; x < c; x++) {
+                    const uint32_t kmer = kab + 160000u * (uint32_t) ix2[x];
+                    const uint32_t st = idxOffsets[kmer], en = idxOffsets[kmer + 1];
+                    kStart[w + x] = st;
+                    kLen[w + x] = en - st;
+                    kPos[w + x] = qi;
+                }
+            }
+            base += chunkTotal;
+        }
+    }
+}
+
 // K2: emit k-mers (+ index list start/len, + owning position) in the reference's enumeration order
 __global__ void __launch_bounds__(256)
 emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
@@ -1087,14 +1239,15 @@ int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, con
                      const uint64_t *seqOffsets, uint32_t nSeq, const int16_t *ext2Score, const uint16_t *ext2Index,
                      const int16_t *ext3Score, const uint16_t *ext3Index, sd_target **out) {
     if (!ctx || !out || !kmerOffsets || !maskedResidues || !seqOffsets || !ext3Score || !ext3Index) return SD_EINVAL;
-    if (kmerSize != 6) return sdFail(ctx, SD_EUNSUPPORTED, "k=%d: only k=6 (targets < 3.35e9 residues) is implemented on the device", kmerSize);
+    if (kmerSize != 6 && kmerSize != 7) return sdFail(ctx, SD_EUNSUPPORTED, "k=%d: the device implements k=6 and k=7", kmerSize);
+    if (kmerSize == 7 && (!ext2Score || !ext2Index)) return sdFail(ctx, SD_EINVAL, "k=7 needs the 2-mer score matrix");
     (void) hipSetDevice(ctx->device);
     sd_target *t = new sd_target();
     t->ctx = ctx;
     t->k = kmerSize;
     t->nSeq = nSeq;
     t->nEntries = nEntries;
-    t->tableSize = 64000000ull;
+    t->tableSize = kmerSize == 6 ? 64000000ull : 1280000000ull;   // 20^k
     t->hSeqOff.assign(seqOffsets, seqOffsets + nSeq + 1);
     const uint64_t total = seqOffsets[nSeq];
     auto up = [&](void **d, const void *h, size_t bytes) -> bool {
@@ -1179,7 +1332,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         for (uint32_t x = 0; x <= bq; x++) hOff[x] = qOffsets[qBeg + x] - r0;
         for (uint32_t x = 0; x < bq; x++) {
             const int64_t L = (int64_t) (hOff[x + 1] - hOff[x]);
-            hPos[x + 1] = hPos[x] + (uint64_t) std::max<int64_t>(0, L - SPAN6 + 1);
+            hPos[x + 1] = hPos[x] + (uint64_t) std::max<int64_t>(0, L - (T->k == 6 ? SPAN6 : SPAN7) + 1);
         }
         const uint64_t nPos = hPos[bq];
         WsView<uint8_t> dQ(ctx, "pf.dQ");
@@ -1211,14 +1364,23 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         if (nPos > 0) {
             {
                 ProfScope ps(ctx, "prefilter_count_kmers");
-                hipLaunchKernelGGL(count_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
-                                   dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p);
+                if (T->k == 6)
+                    hipLaunchKernelGGL(count_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p);
+                else
+                    hipLaunchKernelGGL(count_kmers7_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt3Score, dKmerCount.p);
             }
             int rc = exclusiveScanWiden(ctx, dKmerCount.p, dKmerBase.p, nPos + 1, scanTmp);
             if (rc != SD_OK) return rc;
             SD_HIP(ctx, hipMemcpyAsync(&nKmers, dKmerBase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
+        if (nKmers > HIT_BUDGET && bq > 1) {   // permissive thresholds: the k-mer list itself outgrows 32-bit device scans
+            batchQ = std::max<uint32_t>(1, bq / 2);
+            continue;
+        }
+        if (nKmers >= 0x7FFFFFFFull) return sdFail(ctx, SD_EUNSUPPORTED, "more than 2^31 similar k-mers for one query");
         hs.reset(new HostScope(ctx, "pf.emit"));
         WsView<uint32_t> dKStart(ctx, "pf.dKStart");
         WsView<uint32_t> dKLen(ctx, "pf.dKLen");
@@ -1232,9 +1394,14 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         if (nKmers > 0) {
             {
                 ProfScope ps(ctx, "prefilter_emit_kmers");
-                hipLaunchKernelGGL(emit_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
-                                   dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
-                                   dKmerBase.p, dKStart.p, dKLen.p, dKPos.p);
+                if (T->k == 6)
+                    hipLaunchKernelGGL(emit_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
+                                       dKmerBase.p, dKStart.p, dKLen.p, dKPos.p);
+                else
+                    hipLaunchKernelGGL(emit_kmers7_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt2Index, T->dExt3Score,
+                                       T->dExt3Index, T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p);
             }
             int rc = exclusiveScanWiden(ctx, dKLen.p, dHitBase.p, nKmers + 1, scanTmp);
             if (rc != SD_OK) return rc;

@@ -1558,6 +1558,9 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         SD_HIP(ctx, hipMemcpyAsync(&dirTotal, dDirOff + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (hb[N_TB_CLASSES] == 0) break;   // nothing left
+        if (getenv("SD_DEBUG_TB"))
+            fprintf(stderr, "[tb] round %d: narrow %u %u %u lds %u %u %u dir %.1f MB\n", round, hb[1] - hb[0], hb[2] - hb[1], hb[3] - hb[2],
+                    hb[4] - hb[3], hb[5] - hb[4], hb[6] - hb[5], dirTotal / 1e6);
         if (dirTotal > SCRATCH_BUDGET) return sdFail(ctx, SD_ENOMEM, "traceback direction scratch of %llu bytes exceeds the budget; use smaller batches", (unsigned long long) dirTotal);
         int8_t *dDir = nullptr;
         SD_HIP(ctx, wsGet(ctx, "tb.dir", dirTotal + 64, &dDir));

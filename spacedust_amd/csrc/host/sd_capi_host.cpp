@@ -88,9 +88,15 @@ int sd_host_index_build(sd_host *h, const uint8_t *residues, const uint64_t *off
     if (!out || (kmerSize != 6 && kmerSize != 7)) return SD_EINVAL;
     sd_host_index *ix = new sd_host_index();
     sd::buildTargetIndex(h->seed8, residues, offsets, n, kmerSize, kmerThr, mask != 0, maskProb, h->threads, ix->idx);
+    if (ix->idx.tableSize == 0) {   // more than 2^32 index entries (targets beyond ~4.4e9 residues): 32-bit list offsets in this ABI
+        delete ix;
+        return SD_EUNSUPPORTED;
+    }
     *out = ix;
     return SD_OK;
 }
+
+int sd_host_auto_kmer_size(uint64_t targetResidues) { return sd::autoKmerSize(targetResidues); }
 
 int sd_host_index_info(sd_host_index *ix, uint64_t *tableSize, uint64_t *nEntries, uint64_t *maskedResidues) {
     if (tableSize) *tableSize = ix->idx.tableSize;

@@ -10,6 +10,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 namespace sd {
@@ -77,11 +78,34 @@ int tantanMask(const MaskCtx &ctx, uint8_t *seq, int L, double minMaskProb);
 // Target k-mer index (M/src/prefiltering/IndexTable.h, IndexBuilder.cpp:55-239)
 // Layout is ours (HBM-friendly): u32 offsets (nEntries < 2^32), SoA entries.
 // ---------------------------------------------------------------------------
+// calloc-backed uint32 array: a fresh 20^k table (k = 7: 5 GB) comes as untouched zero pages instead of being
+// written once by a constructor; pages are first touched by the parallel passes that fill it
+struct ZeroedU32 {
+    uint32_t *p = nullptr;
+    size_t n = 0;
+    ZeroedU32() {}
+    ZeroedU32(const ZeroedU32 &) = delete;
+    ZeroedU32 &operator=(const ZeroedU32 &) = delete;
+    ~ZeroedU32() { free(p); }
+    bool reset(size_t count) {
+        free(p);
+        p = count ? (uint32_t *) calloc(count, sizeof(uint32_t)) : nullptr;
+        n = p ? count : 0;
+        return count == 0 || p != nullptr;
+    }
+    void shrink(size_t count) { n = count; }
+    uint32_t *data() { return p; }
+    const uint32_t *data() const { return p; }
+    size_t size() const { return n; }
+    uint32_t &operator[](size_t i) { return p[i]; }
+    const uint32_t &operator[](size_t i) const { return p[i]; }
+};
+
 struct TargetIndex {
     int k, span;
     uint8_t seedPos[8];
     uint64_t tableSize;                 // 20^k
-    std::vector<uint32_t> offsets;      // tableSize+1
+    ZeroedU32 offsets;                  // tableSize+1
     std::vector<uint32_t> entrySeq;     // nEntries
     std::vector<uint16_t> entryPos;     // nEntries
     std::vector<uint8_t> masked;        // concatenated masked numeric residues

@@ -72,7 +72,14 @@ void buildTargetIndex(const SubMat &seed8, const uint8_t *seqs, const uint64_t *
     MaskCtx mctx;
     initMaskCtx(seed8, mctx);
     uint64_t maskedResidues = 0;
-    std::vector<uint32_t> counts(tableSize + 1, 0);
+    // one table of 20^k + 2 counters serves as histogram, cursor array and final offsets (k = 7: 5 GB, so no copies):
+    // list sizes are counted into A[kmer + 2]; after the inclusive prefix sum A[kmer + 1] is the start of the list, and it
+    // is that slot the fill advances, which leaves A[kmer] = start of list kmer for every kmer when the fill is done.
+    ZeroedU32 &A = out.offsets;
+    if (!A.reset(tableSize + 2)) {
+        out.tableSize = 0;
+        return;
+    }
 #pragma omp parallel num_threads(threads)
     {
         std::vector<Tmp> buf;
@@ -86,25 +93,48 @@ void buildTargetIndex(const SubMat &seed8, const uint8_t *seqs, const uint64_t *
             for (size_t i = 0; i < buf.size(); i++) {
                 if (buf[i].kmer != prev) {
 #pragma omp atomic
-                    counts[buf[i].kmer]++;
+                    A[(size_t) buf[i].kmer + 2]++;
                 }
                 prev = buf[i].kmer;
             }
         }
     }
     out.maskedResidues = maskedResidues;
-    out.offsets.assign(tableSize + 1, 0);
     uint64_t run = 0;
-    for (uint64_t i = 0; i < tableSize; i++) {
-        out.offsets[i] = (uint32_t) run;
-        run += counts[i];
+    {
+        // two-pass parallel inclusive prefix sum
+        const int nb = std::max(1, threads);
+        const uint64_t n = tableSize + 2, blk = (n + nb - 1) / nb;
+        std::vector<uint64_t> part(nb + 1, 0);
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+        for (int b = 0; b < nb; b++) {
+            uint64_t sum = 0;
+            for (uint64_t i = std::min(n, b * blk), e = std::min(n, (b + 1) * blk); i < e; i++) sum += A[i];
+            part[b + 1] = sum;
+        }
+        for (int b = 0; b < nb; b++) part[b + 1] += part[b];
+        run = part[nb];
+        if (run > 0xFFFFFFFFull) {   // the ABI carries 32-bit list offsets
+            out.offsets.reset(0);
+            out.entrySeq.clear();
+            out.entryPos.clear();
+            out.tableSize = 0;
+            return;
+        }
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+        for (int b = 0; b < nb; b++) {
+            uint64_t sum = part[b];
+            for (uint64_t i = std::min(n, b * blk), e = std::min(n, (b + 1) * blk); i < e; i++) {
+                sum += A[i];
+                A[i] = (uint32_t) sum;
+            }
+        }
     }
-    out.offsets[tableSize] = (uint32_t) run;
     out.entrySeq.assign(run, 0);
     out.entryPos.assign(run, 0);
     // fill in target order so every list comes out sorted by (seqId,pos) without a second sort:
     // targets are processed in blocks; a serial pass over per-block results keeps seqId ascending.
-    std::vector<uint32_t> cursor(out.offsets.begin(), out.offsets.end() - 1);
+    uint32_t *cursor = A.data() + 1;
     const uint32_t BLOCK = 4096;
     for (uint32_t b0 = 0; b0 < nSeq; b0 += BLOCK) {
         uint32_t b1 = std::min(nSeq, b0 + BLOCK);
@@ -134,6 +164,7 @@ void buildTargetIndex(const SubMat &seed8, const uint8_t *seqs, const uint64_t *
             }
         }
     }
+    A.shrink(tableSize + 1);   // A[kmer] = list start, A[tableSize] = number of entries
 }
 
 }  // namespace sd

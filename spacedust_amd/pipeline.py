@@ -59,7 +59,7 @@ class ClusterSearch:
 
     def __init__(self, ctx, host, target_db, sensitivity=5.7, max_seqs=300, eval_thr=10.0, cov_mode=2, cov_thr=0.8,
                  aln_len_thr=30, max_gene_gap=3, cluster_size=2, alpha=1.0, p_clu_thr=0.01, p_mh_thr=0.01,
-                 filter_self_match=True, bin_size=None, verbose=False, align_ctx=None):
+                 filter_self_match=True, bin_size=None, verbose=False, align_ctx=None, k=None):
         """ctx runs the prefilter (and clusterhits); align_ctx -- a second context (own HIP stream and workspace)
         on the same device, created here if not given -- runs the alignments, so that the prefilter of the next
         chunk (HBM random-access bound) and the Smith-Waterman of the current one (integer-VALU bound) share the
@@ -67,7 +67,8 @@ class ClusterSearch:
         self.ctx, self.host, self.T = ctx, host, target_db
         self.ctx_al = align_ctx if align_ctx is not None else api.Context(ctx.device_index, priority=int(os.environ.get('SD_ALIGN_PRIO', '1')))
         self.verbose = verbose
-        self.k = 6
+        # -k 0 semantics (IndexTable::computeKmerSize, IndexTable.h:439-441): 6 below 3.35e9 target residues, 7 from there on
+        self.k = int(k) if k else host.auto_kmer_size(int(target_db.offsets[-1]))
         self.kmer_thr = host.kmer_threshold(sensitivity, self.k)
         self.max_seqs = max_seqs
         self.eval_thr, self.cov_mode, self.cov_thr, self.aln_len_thr = eval_thr, cov_mode, cov_thr, aln_len_thr

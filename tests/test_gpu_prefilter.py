@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
 
-def _run(gpu, host, res, off, identity, max_hits=300, cov_thr=0.8):
-    sw_b, dg_b, km_b = host.comp_bias(res, off)
-    idx = host.build_index(res, off)
+def _run(gpu, host, res, off, identity, max_hits=300, cov_thr=0.8, k=6, kmer_thr=112):
+    sw_b, dg_b, km_b = host.comp_bias(res, off, k)
+    idx = host.build_index(res, off, k, kmer_thr)
     tgt = api.Target(gpu, host, idx)
-    par = api.prefilter_params(host, idx.n, max_hits=max_hits, cov_thr=cov_thr, bin_size=2)
+    par = api.prefilter_params(host, idx.n, kmer_thr=kmer_thr, max_hits=max_hits, cov_thr=cov_thr, bin_size=2, k=k)
     hits, cnt, st = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, identity, want_stats=True)
     return idx, hits, cnt, st
 
@@ -36,6 +36,32 @@ def test_prefilter_synthetic_matches_oracle(gpu, host, oracle, small_proteomes):
         assert (hits[q, :n]['score'] == sc).all(), q
         assert (hits[q, :n]['diagonal'] == dg).all(), q
         assert tuple(int(x) for x in st[q]) == tuple(int(x) for x in ost), (q, st[q], ost)
+
+
+@pytest.mark.parametrize('kmer_thr', [122, 100])
+def test_prefilter_k7_matches_oracle(gpu, host, oracle, small_proteomes, kmer_thr):
+    """k = 7 (the automatic choice from 3.35e9 target residues, IndexTable.h:439-449): spaced seed of span 11 and the
+    2+2+3 k-mer generator (KmerGenerator.cpp:41-86).  122 = kmerThreshold(5.7, 7); 100 is a far more permissive list."""
+    ps = small_proteomes
+    assert host.kmer_threshold(5.7, 7) == 122
+    ident = np.arange(ps.n, dtype=np.uint32)
+    idx, hits, cnt, st = _run(gpu, host, ps.residues, ps.offsets, ident, max_hits=50, cov_thr=0.0, k=7, kmer_thr=kmer_thr)
+    ot = oracle.target(ps.residues, ps.offsets, k=7, kmer_thr=kmer_thr)
+    assert ot.n_entries == idx.n_entries
+    total = 0
+    # all queries go through the device (at 100 the k-mer lists of the batch exceed the 2^30 budget and the batch is
+    # split); the single-core oracle checks every query at 122 and every 6th at 100
+    for q in range(0, ps.n, 1 if kmer_thr == 122 else 6):
+        seq = ps.residues[int(ps.offsets[q]):int(ps.offsets[q + 1])]
+        ids, sc, dg, ost = ot.prefilter(seq, identity_id=q, kmer_thr=kmer_thr, max_hits=50, bin_size=2)
+        n = int(cnt[q])
+        total += n
+        assert n == len(ids), (q, n, len(ids))
+        assert (hits[q, :n]['seqId'] == ids).all(), q
+        assert (hits[q, :n]['score'] == sc).all(), q
+        assert (hits[q, :n]['diagonal'] == dg).all(), q
+        assert tuple(int(x) for x in st[q]) == tuple(int(x) for x in ost), (q, st[q], ost)
+    assert total > ps.n // 6
 
 
 def _read_fasta_gz(path):
@@ -112,6 +138,25 @@ def test_prefilter_rescoring_path_matches_reference(gpu, host, oracle):
     par = api.prefilter_params(host, idx.n, max_hits=300, cov_thr=0.0, bin_size=2)
     hits, cnt, _ = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident, want_stats=True)
     rows = g['pf_rows']
+    for q in g['queries']:
+        exp = rows[rows[:, 0] == q]
+        m = int(cnt[q])
+        assert m == len(exp), (q, m, len(exp))
+        assert (hits[q, :m]['seqId'] == exp[:, 1]).all() and (hits[q, :m]['score'] == exp[:, 2]).all(), q
+        assert (hits[q, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), q
+
+
+@pytest.mark.parametrize('kmer_thr', [122, 100])
+def test_prefilter_k7_matches_reference(gpu, host, oracle, kmer_thr):
+    """k = 7 on the device against rows produced by the real reference (tools/make_golden_k7.py)"""
+    g = np.load(os.path.join(GOLD, 'k7_vectors.npz'))
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    res = np.concatenate(nums)
+    ident = np.arange(len(nums), dtype=np.uint32)
+    idx, hits, cnt, _ = _run(gpu, host, res, off, ident, max_hits=300, cov_thr=0.0, k=7, kmer_thr=kmer_thr)
+    rows = g['pf_rows_%d' % kmer_thr]
     for q in g['queries']:
         exp = rows[rows[:, 0] == q]
         m = int(cnt[q])

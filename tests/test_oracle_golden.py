@@ -162,6 +162,29 @@ def test_prefilter_rescoring_path(oracle):
         assert len(ids) == len(exp) and (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all() and (dg == exp[:, 3]).all(), q
 
 
+def test_k7_kmer_lists_and_prefilter(oracle):
+    """k = 7: similar k-mer lists (order included) for 12 windows and prefilter rows at two thresholds, all from the
+    real reference classes (tools/make_golden_k7.py)"""
+    g = np.load(os.path.join(GOLD, 'k7_vectors.npz'))
+    lo = g['list_off']
+    for i, (w, t) in enumerate(zip(g['windows'], g['window_thr'])):
+        exp = g['lists'][int(lo[i]):int(lo[i + 1])]
+        got = np.asarray(oracle.kmer_list(w, int(t), k=7), np.uint32)
+        assert len(got) == len(exp) and (got == exp).all(), i
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    for thr in (122, 100):
+        tgt = oracle.target(np.concatenate(nums), off, k=7, kmer_thr=thr)
+        rows = g['pf_rows_%d' % thr]
+        assert len(rows) > 2 * len(g['queries'])
+        for q in (g['queries'] if thr == 122 else g['queries'][:3]):   # the permissive lists are slow on one core
+            exp = rows[rows[:, 0] == q]
+            ids, sc, dg, _ = tgt.prefilter(nums[q], identity_id=int(q), kmer_thr=thr, max_hits=300)
+            assert len(ids) == len(exp) and (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all(), (thr, q)
+            assert (dg.astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (thr, q)
+
+
 def test_prefilter_hit_buffer_overflow(oracle):
     """a query with more index hits than the reference's hit buffer (2*max(1e6, #targets)): one overflow, two match
     parts, merged result lists (QueryMatcher.cpp:281-326); rows from the real reference (tools/make_golden_overflow.py)"""
