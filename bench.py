@@ -17,6 +17,7 @@ import argparse
 import json
 import os
 import sys
+import resource
 import time
 
 import numpy as np
@@ -35,7 +36,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--proteomes', type=int, default=100)
     ap.add_argument('--genes', type=int, default=3000)
@@ -131,6 +132,7 @@ def main():
     torch.cuda.synchronize()
     gpu.synchronize()
     t0 = time.time()
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     pairs_done = 0
     q_len_sum = 0
     summary = np.zeros(4, np.int64)
@@ -152,6 +154,19 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.time() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    if os.environ.get('SD_BENCH_THREADS'):   # per-thread CPU seconds since process start (debugging aid)
+        rows = []
+        for tid in os.listdir('/proc/self/task'):
+            try:
+                w = open('/proc/self/task/%s/stat' % tid).read().rsplit(')', 1)
+                f = w[1].split()
+                rows.append(((int(f[11]) + int(f[12])) / os.sysconf('SC_CLK_TCK'), w[0].split('(', 1)[1], tid))
+            except OSError:
+                pass
+        rows.sort(reverse=True)
+        sys.stderr.write('threads: ' + ' | '.join('%s %.1fs' % (n, c) for c, n, _ in rows[:24]) + '\n')
+    host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64).cuda()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -239,6 +254,7 @@ def main():
                       'kmers': st['kmers'], 'hits': st['prefilter_hits']},
         'kernels': kernels,
         'stage_wall_s': stage,
+        'host_cpu_s_per_step': round(host_cpu_s / max(1, args.steps), 3),
         'results': {'entries': int(summary[0]), 'matched_hits': int(summary[1]), 'clusters': int(summary[2]),
                     'cluster_hits': int(summary[3])},
         'setup_s': {'generate': t_gen, 'index_build_host': cs.timing['index_build_s'], 'upload': cs.timing['upload_s']},

@@ -24,6 +24,8 @@ def effective_cpus():
             n = min(n, max(1, q // p))
     except (OSError, ValueError):
         pass
+    if os.environ.get('SD_CPUS'):   # explicit cap (e.g. to rehearse a rank's share of a multi-GPU node on one GPU)
+        n = min(n, max(1, int(os.environ['SD_CPUS'])))
     return max(1, n)
 
 

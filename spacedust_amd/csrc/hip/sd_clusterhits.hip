@@ -372,7 +372,7 @@ extern "C" int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32
         const bool dbg = getenv("SD_DEBUG_TIMING") != nullptr;
         auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double a0 = now();
-        if (dbg) (void) hipStreamSynchronize(ctx->stream);
+        if (dbg) (void) sdStreamSync(ctx);
         const double a1 = now();
         {
             ProfScope ps(ctx, "clusterhits");
@@ -382,14 +382,14 @@ extern "C" int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32
         }
         const double a2 = now();
         SD_HIP(ctx, hipGetLastError());
-        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SD_HIP(ctx, sdStreamSync(ctx));
         if (dbg) fprintf(stderr, "[clusterhits] profscope %.1f ms, sync-after %.1f ms\n", a2 - a1, now() - a2);
     }
     hs.reset(new HostScope(ctx, "ch.d2h"));
     uint32_t *node = nullptr;
     SD_HIP(ctx, pinGet(ctx, "ch.hnode", total, &node));
     SD_HIP(ctx, hipMemcpyAsync(node, dNode.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SD_HIP(ctx, sdStreamSync(ctx));
     hs.reset(new HostScope(ctx, "ch.finalise"));
     // ---- emission (:456-485): nodes in index order, size >= cls, pCO / pMH thresholds
 #pragma omp parallel

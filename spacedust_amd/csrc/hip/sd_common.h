@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <algorithm>
+#include <ctime>
+#include <sys/prctl.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -26,6 +28,7 @@ struct sd_ctx {
     bool profiling = false;
     std::map<std::string, sd_profile_entry> profile;
     hipEvent_t evStart = nullptr, evStop = nullptr;
+    hipEvent_t evSync = nullptr;   // blocking-sync event: host threads sleep while they wait for the stream (sdStreamSync)
     uint64_t cellsFwd = 0, cellsRev = 0, cellsTb = 0;
     hipDeviceProp_t prop;
     // grow-only device workspace: hipMalloc/hipFree per call cost far more than the kernels they serve
@@ -33,6 +36,34 @@ struct sd_ctx {
     std::map<std::string, WsEntry> ws;
     std::map<std::string, WsEntry> pinned;
 };
+
+// Wait for the context's stream without burning a core.  hipStreamSynchronize -- and hipEventSynchronize even on a
+// hipEventBlockingSync event (measured, ROCm 7.2: thread CPU time = wall time) -- busy-wait; a pipeline keeps two such
+// threads per GPU waiting most of the time, and on a box whose CPU quota is a couple of cores per GPU that starves the
+// host stages (OpenMP teams).  So: record an event, poll it, and sleep ~20 us between polls after a short spin.
+inline hipError_t sdEventWait(hipEvent_t ev) {
+    for (int i = 0; i < 64; i++) {   // a few microseconds: results that are (almost) ready
+        hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+    }
+    static thread_local bool slackSet = false;
+    if (!slackSet) {   // 1 us of timer slack instead of the default 50 us for this thread's short sleeps
+        prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+        slackSet = true;
+    }
+    for (;;) {
+        timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+        hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+    }
+}
+inline hipError_t sdStreamSync(sd_ctx *ctx) {
+    if (ctx->evSync == nullptr) return hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipEventRecord(ctx->evSync, ctx->stream);
+    if (e != hipSuccess) return e;
+    return sdEventWait(ctx->evSync);
+}
 
 // persistent device buffer `key` of at least count elements (contents undefined after growth)
 template <typename T>
@@ -121,7 +152,7 @@ struct ProfScope {
     ~ProfScope() {
         if (ctx->profiling) {
             (void) hipEventRecord(ctx->evStop, ctx->stream);
-            (void) hipEventSynchronize(ctx->evStop);
+            (void) (ctx->evSync ? sdEventWait(ctx->evStop) : hipEventSynchronize(ctx->evStop));
             float ms = 0;
             (void) hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop);
             sd_profile_entry &e = ctx->profile[name];

@@ -1273,7 +1273,7 @@ int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, con
     if (nEntries > 0) {
         hipLaunchKernelGGL(interleave_entries_kernel, dim3((unsigned) ((nEntries + 255) / 256)), dim3(256), 0, ctx->stream, nEntries,
                            t->dEntrySeq, t->dEntryPos, t->dEntries);
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        if (sdStreamSync(ctx) != hipSuccess) {
             sd_target_destroy(t);
             return sdFail(ctx, SD_EHIP, "sd_target_create: interleaving the index entries failed");
         }
@@ -1374,7 +1374,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             int rc = exclusiveScanWiden(ctx, dKmerCount.p, dKmerBase.p, nPos + 1, scanTmp);
             if (rc != SD_OK) return rc;
             SD_HIP(ctx, hipMemcpyAsync(&nKmers, dKmerBase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-            SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SD_HIP(ctx, sdStreamSync(ctx));
         }
         if (nKmers > HIT_BUDGET && bq > 1) {   // permissive thresholds: the k-mer list itself outgrows 32-bit device scans
             batchQ = std::max<uint32_t>(1, bq / 2);
@@ -1406,7 +1406,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             int rc = exclusiveScanWiden(ctx, dKLen.p, dHitBase.p, nKmers + 1, scanTmp);
             if (rc != SD_OK) return rc;
             SD_HIP(ctx, hipMemcpyAsync(&nHits, dHitBase.p + nKmers, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-            SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SD_HIP(ctx, sdStreamSync(ctx));
         }
         hs.reset(new HostScope(ctx, "pf.stats"));
         if (nHits > HIT_BUDGET && bq > 1) {   // too many hits for one sort: halve the sub-batch and retry
@@ -1432,7 +1432,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         int hSplitFlag = 0;
         SD_HIP(ctx, hipMemcpyAsync(&hSplitFlag, dSplitFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(hStats.data(), dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SD_HIP(ctx, sdStreamSync(ctx));
         if (hSplitFlag)
             return sdFail(ctx, SD_EUNSUPPORTED, "a query of the batch [%u, %u) overflows the reference's hit buffer twice (or has >= 2^24 index hits): "
                           "the double-overflow route of QueryMatcher.cpp:289-303 is not implemented", qBeg, qBeg + bq);
@@ -1509,7 +1509,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                 uint64_t totalBins = 0;
                 SD_HIP(ctx, hipMemcpyAsync(&hFlag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 SD_HIP(ctx, hipMemcpyAsync(&totalBins, dBinBase.p + bq, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-                SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                SD_HIP(ctx, sdStreamSync(ctx));
                 if (hFlag == 0 && totalBins > 0) {
                     const uint32_t bigCap = (uint32_t) std::min<size_t>(nSlots, 1u << 26);   // every bucket may be oversize on very large target sets
                     WsView<uint32_t> dBigList(ctx, "pf.dBigList");
@@ -1525,7 +1525,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                     }
                     uint32_t nBig = 0;
                     SD_HIP(ctx, hipMemcpyAsync(&nBig, dBigCount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-                    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    SD_HIP(ctx, sdStreamSync(ctx));
                     if (nBig > 0 && nBig <= bigCap) {   // the few buckets with one very hit-rich target (e.g. the query itself)
                         ProfScope ps(ctx, "prefilter_bucket_match_big");
                         hipLaunchKernelGGL((bucket_match_kernel<256, PF_BUCKET_CAP_BIG>), dim3(nBig), dim3(256), 0, ctx->stream, bq,
@@ -1538,7 +1538,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
                     uint64_t nc64 = 0;
                     SD_HIP(ctx, hipMemcpyAsync(&hFlag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                     SD_HIP(ctx, hipMemcpyAsync(&nc64, dEmitOff.p + nSlots, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-                    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    SD_HIP(ctx, sdStreamSync(ctx));
                     if (hFlag == 0) {
                         nCand = (uint32_t) nc64;
                         bucketDone = true;
@@ -1586,7 +1586,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             if (rc != SD_OK) return rc;
             uint64_t nc64 = 0;
             SD_HIP(ctx, hipMemcpyAsync(&nc64, dEmitPos.p + nHits, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-            SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SD_HIP(ctx, sdStreamSync(ctx));
             nCand = (uint32_t) nc64;
             }
         }
@@ -1637,7 +1637,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             if (rc != SD_OK) return rc;
             uint64_t nk64 = 0;
             SD_HIP(ctx, hipMemcpyAsync(&nk64, dKPos64.p + nCand, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-            SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SD_HIP(ctx, sdStreamSync(ctx));
             nKept = (uint32_t) nk64;
             SD_HIP(ctx, dKKey.alloc(nKept + 1));
             SD_HIP(ctx, dKVal.alloc(nKept + 1));
@@ -1672,7 +1672,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         SD_HIP(ctx, hipMemcpyAsync(hOut.data(), dOut.p, hOut.size() * sizeof(sd_hit), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(outCount + qBeg, dOutCount.p, bq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         if (stats) SD_HIP(ctx, hipMemcpyAsync(stats + (size_t) qBeg * 4, dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SD_HIP(ctx, sdStreamSync(ctx));
         if (hErr == 2)
             return sdFail(ctx, SD_EUNSUPPORTED, "more than %d candidates at the score cut of one query together with maxHitsPerQuery > %d",
                           SEL_CAP, SEL_CAP / 2 - 1);

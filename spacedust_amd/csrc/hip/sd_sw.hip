@@ -689,7 +689,7 @@ int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, c
         SD_HIP(ctx, hipGetLastError());
     }
     SD_HIP(ctx, hipMemcpyAsync(hPin, dOut, (size_t) nSlots * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SD_HIP(ctx, sdStreamSync(ctx));
     memcpy(hOut.data(), hPin, (size_t) nSlots * 3 * sizeof(int32_t));
     return SD_OK;
 }
@@ -1162,7 +1162,7 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
     if (dPairQ) SD_HIP(ctx, hipMemcpyAsync(hpb, dPairBounds, sizeof(hpb), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(&boundTotal, dScanB + nPairs, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SD_HIP(ctx, sdStreamSync(ctx));
     *nValid = hb[N_SCORE_CLASSES];
     uint2 *dBound = nullptr;
     SD_HIP(ctx, wsGet(ctx, "sw.bound", std::max<uint64_t>(boundTotal, 1), &dBound));
@@ -1268,8 +1268,12 @@ int sd_ctx_create_prio(int device, int priority, sd_ctx **out) {
         delete c;
         return SD_EHIP;
     }
+    // SD_SYNC=spin keeps hipStreamSynchronize's busy wait (lowest wake-up latency, one core per waiting thread)
+    const char *syncMode = getenv("SD_SYNC");
+    const bool spin = syncMode && strcmp(syncMode, "spin") == 0;
     (void) hipEventCreate(&c->evStart);
     (void) hipEventCreate(&c->evStop);
+    if (!spin) (void) hipEventCreateWithFlags(&c->evSync, hipEventDisableTiming);
     (void) hipGetDeviceProperties(&c->prop, device);
     *out = c;
     return SD_OK;
@@ -1280,6 +1284,7 @@ void sd_ctx_destroy(sd_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     if (ctx->evStart) (void) hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void) hipEventDestroy(ctx->evStop);
+    if (ctx->evSync) (void) hipEventDestroy(ctx->evSync);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     for (auto &kv : ctx->ws) if (kv.second.p) (void) hipFree(kv.second.p);
     for (auto &kv : ctx->pinned) if (kv.second.p) (void) hipHostFree(kv.second.p);
@@ -1295,7 +1300,7 @@ int sd_device_name(sd_ctx *ctx, char *buf, size_t cap) {
 }
 
 int sd_synchronize(sd_ctx *ctx) {
-    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SD_HIP(ctx, sdStreamSync(ctx));
     return SD_OK;
 }
 
@@ -1540,7 +1545,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     if (rc != SD_OK) return rc;
     uint64_t btScratch = 0;
     SD_HIP(ctx, hipMemcpyAsync(&btScratch, dBtOff + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SD_HIP(ctx, sdStreamSync(ctx));
     char *dBt = nullptr;
     SD_HIP(ctx, wsGet(ctx, "tb.bt", btScratch + 64, &dBt));
     const uint64_t SCRATCH_BUDGET = 16ull << 30;
@@ -1556,7 +1561,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         uint64_t dirTotal = 0;
         SD_HIP(ctx, hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(&dirTotal, dDirOff + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SD_HIP(ctx, sdStreamSync(ctx));
         if (hb[N_TB_CLASSES] == 0) break;   // nothing left
         if (getenv("SD_DEBUG_TB"))
             fprintf(stderr, "[tb] round %d: narrow %u %u %u lds %u %u %u dir %.1f MB\n", round, hb[1] - hb[0], hb[2] - hb[1], hb[3] - hb[2],
@@ -1599,7 +1604,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     SD_HIP(ctx, hipMemcpyAsync(&poolBytes, dDense + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(hErr, dErr, sizeof(hErr), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(hCells, dCells, sizeof(hCells), hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SD_HIP(ctx, sdStreamSync(ctx));
     if (hErr[0] == 1) return sdFail(ctx, SD_EMISMATCH, "Score of forward/backward SW differ (fatal in the reference, StripedSmithWaterman.cpp:466-473)");
     if (hErr[0] == 2) return sdFail(ctx, SD_EHIP, "Trace back error");
     if (hErr[0] == 3) return sdFail(ctx, SD_EUNSUPPORTED, "traceback band exceeds the LDS-resident limit");
@@ -1643,7 +1648,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         hipLaunchKernelGGL(k_accept_compact, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dRes, dAcc, dAccPos, dResC, dIdxC);
         uint64_t nAcc = 0;
         SD_HIP(ctx, hipMemcpyAsync(&nAcc, dAccPos + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SD_HIP(ctx, sdStreamSync(ctx));
         nRec = (uint32_t) nAcc;
         dRecSrc = dResC;
         SD_HIP(ctx, pinGet(ctx, "al.hidx", std::max<uint32_t>(nRec, 1), &hIdx));
@@ -1655,7 +1660,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     SD_HIP(ctx, pinGet(ctx, "al.hpool", poolBytes + 64, &hPool));
     SD_HIP(ctx, hipMemcpyAsync(hRes, dRecSrc, (size_t) nRec * sizeof(sd_sw_result), hipMemcpyDeviceToHost, ctx->stream));
     if (poolBytes > 0) SD_HIP(ctx, hipMemcpyAsync(hPool, dPool, poolBytes, hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SD_HIP(ctx, sdStreamSync(ctx));
     hs.reset(new HostScope(ctx, "align.finish"));
     {
         const int nth = std::max(1, std::min(omp_get_max_threads(), 64));
@@ -1958,7 +1963,7 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
             SD_HIP(ctx, hipMemcpyAsync(back, dT.p, cnt * sizeof(TbTask), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipMemcpyAsync(hbt, dBt.p, nBt, hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipMemcpyAsync(hres, dRes.p, (size_t) cnt * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-            SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SD_HIP(ctx, sdStreamSync(ctx));
             // pool offsets serially (cheap), payload copies in parallel
             std::vector<uint64_t> dst(cnt, 0);
             for (uint32_t x = 0; x < cnt; x++) {

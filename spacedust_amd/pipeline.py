@@ -130,15 +130,20 @@ class ClusterSearch:
                        'sd_agg_add')
             return time.time() - t1
 
-        def prefilter_job(c0, c1):
-            """bias + prefilter + pair list of one chunk (runs on its own thread and HIP stream)"""
-            t = {}
+        def bias_job(c0, c1):
+            """composition bias of one chunk's queries (host, float: SubstitutionMatrix.cpp:79-109); its own thread, so
+            that on a box with few cores per GPU it is not serialised with the prefilter calls of the same chunk"""
             r0, r1 = int(Q.offsets[c0]), int(Q.offsets[c1])
             res = Q.residues[r0:r1]
             off = (Q.offsets[c0:c1 + 1] - Q.offsets[c0]).astype(np.uint64)
             t0 = time.time()
             sw_b, dg_b, km_b = self.host.comp_bias(res, off, self.k)
-            t['bias'] = time.time() - t0
+            return res, off, sw_b, dg_b, km_b, time.time() - t0
+
+        def prefilter_job(c0, c1, bias_future):
+            """prefilter + pair list of one chunk (runs on its own thread and HIP stream)"""
+            t = {}
+            res, off, sw_b, dg_b, km_b, t['bias'] = bias_future.result()
             ident = (np.arange(c0, c1, dtype=np.uint32) if same_db else np.full(c1 - c0, 0xFFFFFFFF, np.uint32))
             t0 = time.time()
             hits, cnt, st = api.prefilter(self.ctx, self.target, self.pf_par, res, off, km_b, dg_b, ident, want_stats=True)
@@ -214,14 +219,28 @@ class ClusterSearch:
             last_chunk_of[ri] = x
         results = [None] * len(ranges)
         to_finalize = []   # (range, its last aggregation job)
+        # stage threads: bias (chunk i+2) | prefilter (chunk i+1) | alignments (chunk i, this thread) | aggregation (chunk i-1)
         pf_exec = ThreadPoolExecutor(max_workers=1)
-        pf_next = pf_exec.submit(prefilter_job, chunks[0][1], chunks[0][2]) if chunks else None
+        bias_exec = ThreadPoolExecutor(max_workers=1)
+        bias_fut = {}
+
+        def submit_bias(x):
+            if x < len(chunks) and x not in bias_fut:
+                bias_fut[x] = bias_exec.submit(bias_job, chunks[x][1], chunks[x][2])
+
+        def submit_prefilter(x):
+            submit_bias(x)
+            f = pf_exec.submit(prefilter_job, chunks[x][1], chunks[x][2], bias_fut.pop(x))
+            submit_bias(x + 1)
+            return f
+
+        pf_next = submit_prefilter(0) if chunks else None
         for ci in range(len(chunks)):
             ri = chunks[ci][0]
             t0 = time.time()
             d = pf_next.result()
             tm['prefilter_wait'] = tm.get('prefilter_wait', 0.0) + time.time() - t0
-            pf_next = pf_exec.submit(prefilter_job, chunks[ci + 1][1], chunks[ci + 1][2]) if ci + 1 < len(chunks) else None
+            pf_next = submit_prefilter(ci + 1) if ci + 1 < len(chunks) else None
             for k_, v_ in d['t'].items():
                 tm[k_] = tm.get(k_, 0.0) + v_
             st, n_pairs, c0, c1 = d['st'], d['n_pairs'], d['c0'], d['c1']
@@ -263,6 +282,7 @@ class ClusterSearch:
                 fri, _ = to_finalize.pop(0)
                 results[fri] = finalize(fri)
         pf_exec.shutdown()
+        bias_exec.shutdown()
         t0 = time.time()
         if pending is not None:
             tm['aggregate_busy'] += pending.result()
