@@ -59,6 +59,12 @@ int sd_profile_names(sd_ctx *ctx, char *buf, size_t cap); /* comma separated */
  * SmithWaterman::ssw_init (M/src/alignment/StripedSmithWaterman.cpp:1230-1235); NULL = all zero. */
 int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offsets, uint32_t n,
                      const int8_t *swCompBias, sd_seqset **out);
+/* Profile queries for sd_sw_align_batch*: the set a Matcher::initQuery with a profile Sequence stands for
+ * (ssw_init's PROFILE branch, StripedSmithWaterman.cpp:1238-1301).  queryLetters take the residues' place (identity
+ * counting, :558), alnProfile (total x 21 int8) replaces "matrix row + composition bias" in the score, start-position
+ * and traceback kernels; pass the returned set as `queries`.  Identity pairs do not exist for profile queries. */
+int sd_profileset_create(sd_ctx *ctx, const uint8_t *queryLetters, const uint64_t *offsets, uint32_t n,
+                         const int8_t *alnProfile, sd_seqset **out);
 void sd_seqset_destroy(sd_seqset *s);
 
 /* ---- Smith-Waterman (align module) ---------------------------------------------------- */
@@ -161,6 +167,27 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *target, const sd_prefilter_
                        const uint8_t *qResidues, const uint64_t *qOffsets, const int16_t *qKmerBias,
                        const int8_t *qDiagBias, const uint32_t *identityId, sd_hit *outHits, uint32_t *outCount,
                        uint64_t *stats);
+
+/* ---- Profile queries (`--num-iterations` > 1 feeds profile DBs to prefilter and align) ----
+ * sd_host_map_profiles restates Sequence::mapProfile (M/src/commons/Sequence.cpp:241-292) for n profile DB entries
+ * (25 bytes per position, Sequence.h:458-471; byteOffsets[n+1] into profileData): per position the query letter,
+ * the consensus letter (nullable output), the int8 alignment profile [21] = score / 4 with the X column 0, and the
+ * k-mer generator's row: the 20 scores sorted descending by Util::rankedDescSort20's network and the amino acids
+ * in that order.  posOffsets[n+1] receives the position offsets (= byteOffsets / 25). */
+int sd_host_map_profiles(const char *profileData, const uint64_t *byteOffsets, uint32_t n, uint8_t *queryLetters,
+                         uint8_t *consensus, int8_t *alnProfile /* total x 21 */, int16_t *sortedScore /* total x 20 */,
+                         uint8_t *sortedIndex /* total x 20 */, uint64_t *posOffsets);
+/* Prefiltering::getKmerThreshold for profile searches without context pseudo counts (Prefiltering.cpp:1031-1043) */
+int sd_host_profile_kmer_threshold(float sensitivity, int kmerSize);
+/* sd_prefilter_batch for profile queries: QueryMatcher::matchQuery with a DBTYPE_HMM_PROFILE Sequence --
+ * k-mers from the per-position rows (Sequence::nextProfileKmer :294-305, KmerGenerator::setDivideStrategy(ScoreMatrix**)
+ * KmerGenerator.cpp:30-39), windows whose query letter is X skipped, no composition bias (QueryMatcher.cpp:93-99),
+ * diagonal scores from the alignment profile (UngappedAlignment::createProfile's profile branch, :398-405).
+ * The target index must have been built with k-mer threshold 0 (Prefiltering.cpp:525-527). */
+int sd_prefilter_profile_batch(sd_ctx *ctx, const sd_target *target, const sd_prefilter_params *par, uint32_t nQ,
+                               const uint8_t *queryLetters, const uint64_t *qOffsets, const int16_t *sortedScore,
+                               const uint8_t *sortedIndex, const int8_t *alnProfile, sd_hit *outHits, uint32_t *outCount,
+                               uint64_t *stats);
 
 /* ---- clusterhits ---------------------------------------------------------------------- */
 typedef struct {

@@ -60,6 +60,15 @@ class Oracle:
         L.or_sw_align.restype = C.c_double
         L.or_sw_align.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int,
                                   C.c_float, C.c_int, C.c_int, _vp, _vp, C.c_int]
+        L.or_sw_align_profile.restype = C.c_double
+        L.or_sw_align_profile.argtypes = [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int,
+                                          C.c_float, _vp, _vp, C.c_int]
+        L.or_prefilter_query_profile.restype = C.c_int64
+        L.or_prefilter_query_profile.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32,
+                                                 _vp, _vp, _vp, _vp]
+        L.or_map_profile.argtypes = [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]
+        L.or_profile_kmer_list.restype = C.c_size_t
+        L.or_profile_kmer_list.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t]
         L.or_banded_traceback.argtypes = [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int]
         L.or_diag_score.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_uint16]
         L.or_evalue.restype = C.c_double
@@ -100,6 +109,36 @@ class Oracle:
         w = np.ascontiguousarray(window, np.uint8)
         n = self.lib.or_kmer_list(self.ctx, k, _ptr(w), thr, _ptr(out), cap)
         return out[:n].copy()
+
+    def map_profile(self, data):
+        """Sequence::mapProfile: 25-byte records -> (letters, consensus, aln [L][21], sorted scores [L][20], order [L][20])"""
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+        L = len(data) // 25
+        letters, cons = np.zeros(L, np.uint8), np.zeros(L, np.uint8)
+        aln = np.zeros((L, 21), np.int8)
+        sc = np.zeros((L, 20), np.int16)
+        ix = np.zeros((L, 20), np.uint8)
+        self.lib.or_map_profile(_ptr(data), L, _ptr(letters), _ptr(cons), _ptr(aln), _ptr(sc), _ptr(ix))
+        return letters, cons, aln, sc, ix
+
+    def profile_kmer_list(self, sorted_score, sorted_index, thr, cap=1 << 22):
+        sc = np.ascontiguousarray(sorted_score, np.int16)
+        ix = np.ascontiguousarray(sorted_index, np.uint8)
+        out = np.zeros(cap, np.uint32)
+        n = self.lib.or_profile_kmer_list(_ptr(sc), _ptr(ix), sc.shape[0], thr, _ptr(out), cap)
+        return out[:n].copy()
+
+    def sw_align_profile(self, letters, aln, t, db_residues, sw_mode=2, eval_thr=10.0, cov_mode=2, cov_thr=0.8):
+        letters = np.ascontiguousarray(letters, np.uint8)
+        aln = np.ascontiguousarray(aln, np.int8)
+        t = np.ascontiguousarray(t, np.uint8)
+        out = np.zeros(8, np.int32)
+        cap = len(letters) + len(t) + 8
+        bt = C.create_string_buffer(cap)
+        ev = self.lib.or_sw_align_profile(self.ctx, _ptr(letters), _ptr(aln), len(letters), _ptr(t), len(t), db_residues,
+                                          sw_mode, eval_thr, cov_mode, cov_thr, _ptr(out), bt, cap)
+        return dict(score=int(out[0]), qStart=int(out[1]), qEnd=int(out[2]), tStart=int(out[3]), tEnd=int(out[4]),
+                    identical=int(out[5]), btLen=int(out[6]), flags=int(out[7]), evalue=ev, backtrace=bt.value.decode())
 
     def mask(self, num, prob=0.9):
         a = np.array(num, np.uint8, copy=True)
@@ -174,6 +213,23 @@ class OracleTarget:
             raise RuntimeError('oracle prefilter path not restated: code %d' % n)
         return ids[:n].copy(), sc[:n].copy(), dg[:n].copy(), st
 
+    def prefilter_profile(self, letters, aln, sorted_score, sorted_index, kmer_thr, max_hits=300, min_diag=15, bin_size=2):
+        letters = np.ascontiguousarray(letters, np.uint8)
+        aln = np.ascontiguousarray(aln, np.int8)
+        ssc = np.ascontiguousarray(sorted_score, np.int16)
+        six = np.ascontiguousarray(sorted_index, np.uint8)
+        cap = max(max_hits, 1) + 1
+        ids = np.zeros(cap, np.uint32)
+        sc = np.zeros(cap, np.int32)
+        dg = np.zeros(cap, np.uint16)
+        st = np.zeros(4, np.uint64)
+        n = self.orc.lib.or_prefilter_query_profile(self.h, _ptr(letters), _ptr(aln), _ptr(ssc), _ptr(six), len(letters),
+                                                    kmer_thr, max_hits, min_diag, bin_size, _ptr(ids), _ptr(sc), _ptr(dg),
+                                                    _ptr(st))
+        if n < 0:
+            raise RuntimeError('oracle prefilter path not restated: code %d' % n)
+        return ids[:n].copy(), sc[:n].copy(), dg[:n].copy(), st
+
     def __del__(self):
         try:
             self.orc.lib.or_target_destroy(self.h)
@@ -220,6 +276,11 @@ class Ref:
         L.ref_sw_align.argtypes = [_vp, C.c_char_p, C.c_uint, C.c_int, C.c_double, C.c_int, C.c_float, _vp,
                                    C.c_char_p, C.c_size_t, C.c_int]
         L.ref_sw_destroy.argtypes = [_vp]
+        L.ref_sw_set_query_profile.argtypes = [_vp, C.c_char_p, C.c_uint]
+        L.ref_prefilter_create_profile.restype = _vp
+        L.ref_prefilter_create_profile.argtypes = [_vp, C.c_int, C.c_size_t, C.c_size_t, C.c_int]
+        L.ref_profile_kmer_list.restype = C.c_size_t
+        L.ref_profile_kmer_list.argtypes = [_vp, C.c_char_p, C.c_uint, C.c_uint, C.c_int, _vp, C.c_size_t]
         L.ref_evalue.restype = C.c_double
         L.ref_evalue.argtypes = [_vp, C.c_double, C.c_double]
         L.ref_bitscore.restype = C.c_double
@@ -268,6 +329,12 @@ class Ref:
         n = self.lib.ref_kmer_list(self.ctx, _ptr(w), thr, _ptr(out), cap)
         return out[:n].astype(np.uint32)
 
+    def profile_kmer_list(self, data, pos, thr, cap=1 << 22):
+        data = bytes(data)
+        out = np.zeros(cap, np.uint64)
+        n = self.lib.ref_profile_kmer_list(self.ctx, data, len(data) // 25, pos, thr, _ptr(out), cap)
+        return out[:n].copy()
+
     def mask(self, num, prob=0.9):
         a = np.array(num, np.uint8, copy=True)
         n = self.lib.ref_mask(self.ctx, _ptr(a), len(a), prob)
@@ -308,6 +375,15 @@ class RefIndex:
     def prefilter(self, max_query_len, max_hits=300, min_diag=15, comp_bias=True):
         return RefPrefilter(self, max_query_len, max_hits, min_diag, comp_bias)
 
+    def prefilter_profile(self, max_query_len, kmer_thr, max_hits=300, min_diag=15):
+        """profile queries against this index (build it with kmer_thr=0, Prefiltering.cpp:525-527); query() then takes
+        the raw 25-byte-per-position profile entry"""
+        p = RefPrefilter.__new__(RefPrefilter)
+        p.idx, p.lib, p.max_hits = self, self.ref.lib, max_hits
+        p.h = self.ref.lib.ref_prefilter_create_profile(self.h, kmer_thr, max_query_len, max_hits, min_diag)
+        p.profile = True
+        return p
+
 
 class RefPrefilter:
     def __init__(self, idx, max_query_len, max_hits, min_diag, comp_bias):
@@ -323,8 +399,9 @@ class RefPrefilter:
         sc = np.zeros(cap, np.int32)
         dg = np.zeros(cap, np.uint16)
         st = np.zeros(2, np.float64)
-        b = ascii_seq.encode() if isinstance(ascii_seq, str) else ascii_seq
-        n = self.lib.ref_prefilter_query(self.h, b, len(b), identity_id, _ptr(ids), _ptr(sc), _ptr(dg), _ptr(st))
+        b = ascii_seq.encode() if isinstance(ascii_seq, str) else bytes(ascii_seq)
+        L = len(b) // 25 if getattr(self, 'profile', False) else len(b)
+        n = self.lib.ref_prefilter_query(self.h, b, L, identity_id, _ptr(ids), _ptr(sc), _ptr(dg), _ptr(st))
         return ids[:n].copy(), sc[:n].copy(), dg[:n].copy(), st
 
 
@@ -337,6 +414,11 @@ class RefSW:
         b = ascii_seq.encode() if isinstance(ascii_seq, str) else ascii_seq
         self.qlen = len(b)
         self.lib.ref_sw_set_query(self.h, b, len(b))
+
+    def set_query_profile(self, data):
+        b = bytes(data)
+        self.qlen = len(b) // 25
+        self.lib.ref_sw_set_query_profile(self.h, b, self.qlen)
 
     def align(self, ascii_t, sw_mode=2, eval_thr=10.0, cov_mode=2, cov_thr=0.8, identity=False):
         b = ascii_t.encode() if isinstance(ascii_t, str) else ascii_t

@@ -66,9 +66,11 @@ struct RefSW {
     SmithWaterman *sw;
     EvalueComputation *evaluer;
     Sequence *q;
+    Sequence *qp = NULL;   // profile query (DBTYPE_HMM_PROFILE), created on first use
     Sequence *t;
     int8_t *tiny;
     size_t maxLen;
+    int curQL = 0;
 };
 }
 
@@ -266,6 +268,36 @@ size_t ref_prefilter_query(void *vp, const char *seq, unsigned int L, unsigned i
     return r.second;
 }
 
+// profile queries: the matcher takes its k-mer generator rows from the Sequence (Prefiltering.cpp:790-795:
+// matcher.setProfileMatrix(seq.profile_matrix)); the index must have been built with threshold 0 (:525-527)
+void *ref_prefilter_create_profile(void *vi, int kmerThr, size_t maxQueryLen, size_t maxHits, int minDiagScore) {
+    RefIndex *ix = (RefIndex *) vi;
+    RefCtx *c = ix->ctx;
+    RefPref *p = new RefPref();
+    p->idx = ix;
+    size_t maxLen = std::max(ix->maxLen, maxQueryLen) + 2;
+    p->matcher = new QueryMatcher(ix->table, ix->lookup, c->seed8, c->ungapped2, (short) kmerThr, c->kmerSize,
+                                  ix->nSeq, (unsigned int) maxLen, maxHits, true, 1.0f, true,
+                                  (unsigned int) minDiagScore, false, false);
+    p->seq = new Sequence(maxLen, Parameters::DBTYPE_HMM_PROFILE, c->seed8, c->kmerSize, true, true);
+    p->matcher->setProfileMatrix(p->seq->profile_matrix);
+    return p;
+}
+
+// similar k-mers of the window starting at position `pos` of a profile (KmerGenerator over the Sequence's rows)
+size_t ref_profile_kmer_list(void *vc, const char *data, unsigned int L, unsigned int pos, int thr, size_t *out, size_t cap) {
+    RefCtx *c = (RefCtx *) vc;
+    Sequence s(L + 2, Parameters::DBTYPE_HMM_PROFILE, c->seed8, c->kmerSize, true, false);
+    s.mapSequence(0, 0, data, L);
+    KmerGenerator gen(c->kmerSize, c->seed8->alphabetSize - 1, (short) thr);
+    gen.setDivideStrategy(s.profile_matrix);
+    const unsigned char *kmer = NULL;
+    for (unsigned int i = 0; i <= pos && s.hasNextKmer(); i++) kmer = s.nextKmer();
+    std::pair<size_t *, size_t> r = gen.generateKmerList(kmer);
+    for (size_t i = 0; i < r.second && i < cap; i++) out[i] = r.first[i];
+    return r.second;
+}
+
 void ref_prefilter_destroy(void *vp) {
     RefPref *p = (RefPref *) vp;
     delete p->matcher;
@@ -300,6 +332,18 @@ void ref_sw_set_query(void *vs, const char *seq, unsigned int L) {
     RefSW *s = (RefSW *) vs;
     s->q->mapSequence(0, 0, seq, L);
     s->sw->ssw_init(s->q, s->tiny, s->ctx->blosum2);
+    s->curQL = s->q->L;
+}
+
+// profile query: data = L records of Sequence::PROFILE_READIN_SIZE bytes (Matcher::initQuery's profile branch:
+// ssw_init(query, query->getAlignmentProfile(), m))
+void ref_sw_set_query_profile(void *vs, const char *data, unsigned int L) {
+    RefSW *s = (RefSW *) vs;
+    BaseMatrix *m = s->ctx->blosum2;
+    if (s->qp == NULL) s->qp = new Sequence(s->maxLen, Parameters::DBTYPE_HMM_PROFILE, m, 0, false, false);
+    s->qp->mapSequence(0, 0, data, L);
+    s->sw->ssw_init(s->qp, s->qp->getAlignmentProfile(), m);
+    s->curQL = s->qp->L;
 }
 
 // out[0..7] = score, qStart, qEnd, tStart, tEnd, identical, cigarLen(backtrace length), 0 ; returns evalue.
@@ -314,7 +358,7 @@ double ref_sw_align(void *vs, const char *tseq, unsigned int tL, int swMode, dou
         a = s->sw->scoreIdentical(s->t->numSequence, s->t->L, s->evaluer, swMode, bt);
     } else {
         a = s->sw->ssw_align(s->t->numSequence, s->t->numConsensusSequence, s->t->getAlignmentProfile(), s->t->L, bt,
-                             11, 1, (uint8_t) swMode, evalThr, s->evaluer, covMode, covThr, 0.0f, s->q->L / 2, 1);
+                             11, 1, (uint8_t) swMode, evalThr, s->evaluer, covMode, covThr, 0.0f, s->curQL / 2, 1);
     }
     out[0] = (int) a.score1;
     out[1] = a.qStartPos1;
@@ -345,6 +389,7 @@ void ref_sw_destroy(void *vs) {
     delete s->sw;
     delete s->evaluer;
     delete s->q;
+    delete s->qp;
     delete s->t;
     delete[] s->tiny;
     delete s;

@@ -176,9 +176,16 @@ void or_target_dump(void *vt, uint32_t *offsets, uint32_t *entrySeq, uint16_t *e
 // Returns the number of result hits; outputs are in the reference's final order.
 // stats: [0] #similar k-mers, [1] #index entries matched, [2] #candidates scored, [3] sum of diagonal lengths
 // ------------------------------------------------------------------------------------------
-int64_t or_prefilter_query(void *vt, const unsigned char *q, int qL, uint32_t identityId, int kmerThr,
-                           uint32_t maxHits, int minDiagScore, uint32_t binSize, int compBias,
-                           uint32_t *outId, int32_t *outScore, uint16_t *outDiag, uint64_t *stats) {
+struct ProfileQuery {            // Sequence::mapProfile output for one profile query
+    const int8_t *aln;           // [qL][21]
+    const int16_t *sortedScore;  // [qL][20]
+    const uint8_t *sortedIndex;  // [qL][20]
+};
+
+static int64_t prefilterQueryImpl(void *vt, const unsigned char *q, int qL, uint32_t identityId, int kmerThr,
+                                  uint32_t maxHits, int minDiagScore, uint32_t binSize, int compBias,
+                                  uint32_t *outId, int32_t *outScore, uint16_t *outDiag, uint64_t *stats,
+                                  const ProfileQuery *pq) {
     OracleTarget *T = (OracleTarget *) vt;
     OracleCtx *c = T->ctx;
     ensureExt(c);
@@ -189,9 +196,10 @@ int64_t or_prefilter_query(void *vt, const unsigned char *q, int qL, uint32_t id
 
     // steps 1-2: composition bias (seed matrix) and diagonal profile
     std::vector<float> cb(qL > 0 ? qL : 1, 0.0f);
-    if (compBias) calcLocalAaBiasCorrection(c->seed8, q, qL, cb.data(), 1.0f);
+    if (compBias && !pq) calcLocalAaBiasCorrection(c->seed8, q, qL, cb.data(), 1.0f);   // profiles: no correction (QueryMatcher.cpp:93-99)
     std::vector<int8_t> prof((size_t) (qL > 0 ? qL : 1) * ALPH);
-    for (int pos = 0; pos < qL; pos++) {
+    if (pq) memcpy(prof.data(), pq->aln, (size_t) qL * ALPH);   // UngappedAlignment::createProfile, profile branch (:398-405)
+    for (int pos = 0; pos < qL && !pq; pos++) {
         float a = cb[pos];
         float r = (float) ((a < 0.0) ? (double) (a / 4) - 0.5 : (double) (a / 4) + 0.5);
         int8_t corr = (int8_t) (char) r;
@@ -221,7 +229,17 @@ int64_t or_prefilter_query(void *vt, const unsigned char *q, int qL, uint32_t id
         if (hasX) continue;
         short b = (short) ((bias < 0.0) ? (double) bias - 0.5 : (double) bias + 0.5);
         short thr = (short) std::max(kmerThr - b, 0);
-        generateKmerList(c->three, c->two, k, window, thr, kmers);
+        if (pq) {
+            const int16_t *rowScore[8];
+            const uint8_t *rowIndex[8];
+            for (int p = 0; p < k; p++) {   // Sequence::nextProfileKmer (:294-305)
+                rowScore[p] = pq->sortedScore + (size_t) (i + ix.seedPos[p]) * 20;
+                rowIndex[p] = pq->sortedIndex + (size_t) (i + ix.seedPos[p]) * 20;
+            }
+            generateProfileKmerList(rowScore, rowIndex, k, thr, kmers);
+        } else {
+            generateKmerList(c->three, c->two, k, window, thr, kmers);
+        }
         nKmers += kmers.size();
         for (size_t z = 0; z < kmers.size(); z++) {
             uint32_t a = ix.offsets[kmers[z]], e = ix.offsets[kmers[z] + 1];
@@ -423,6 +441,42 @@ int64_t or_prefilter_query(void *vt, const unsigned char *q, int qL, uint32_t id
     return (int64_t) res.size();
 }
 
+int64_t or_prefilter_query(void *vt, const unsigned char *q, int qL, uint32_t identityId, int kmerThr,
+                           uint32_t maxHits, int minDiagScore, uint32_t binSize, int compBias,
+                           uint32_t *outId, int32_t *outScore, uint16_t *outDiag, uint64_t *stats) {
+    return prefilterQueryImpl(vt, q, qL, identityId, kmerThr, maxHits, minDiagScore, binSize, compBias, outId, outScore,
+                              outDiag, stats, nullptr);
+}
+
+// profile query (a22): letters / alignment profile / sorted k-mer generator rows as sd::mapProfile produces them
+int64_t or_prefilter_query_profile(void *vt, const unsigned char *letters, const signed char *aln,
+                                   const int16_t *sortedScore, const unsigned char *sortedIndex, int qL, int kmerThr,
+                                   uint32_t maxHits, int minDiagScore, uint32_t binSize, uint32_t *outId,
+                                   int32_t *outScore, uint16_t *outDiag, uint64_t *stats) {
+    ProfileQuery pq = {(const int8_t *) aln, sortedScore, sortedIndex};
+    return prefilterQueryImpl(vt, letters, qL, 0xFFFFFFFFu, kmerThr, maxHits, minDiagScore, binSize, 0, outId, outScore,
+                              outDiag, stats, &pq);
+}
+
+// Sequence::mapProfile restated in the product's host code (sd::mapProfile); exposed for the golden tests
+void or_map_profile(const char *data, uint32_t L, unsigned char *letters, unsigned char *consensus, signed char *aln,
+                    int16_t *sortedScore, unsigned char *sortedIndex) {
+    mapProfile(data, L, letters, consensus, (int8_t *) aln, sortedScore, sortedIndex);
+}
+size_t or_profile_kmer_list(const int16_t *sortedScore /* [k][20] */, const unsigned char *sortedIndex, int k, int thr,
+                            unsigned int *out, size_t cap) {
+    const int16_t *sc[8];
+    const uint8_t *ix[8];
+    for (int p = 0; p < k; p++) {
+        sc[p] = sortedScore + (size_t) p * 20;
+        ix[p] = sortedIndex + (size_t) p * 20;
+    }
+    std::vector<uint32_t> v;
+    generateProfileKmerList(sc, ix, k, thr, v);
+    for (size_t i = 0; i < v.size() && i < cap; i++) out[i] = v[i];
+    return v.size();
+}
+
 // single diagonal score, for kernel unit tests
 int or_diag_score(const int8_t *prof, int qL, const unsigned char *t, int tL, uint16_t diag) {
     return diagScore(prof, qL, t, tL, diag);
@@ -508,7 +562,7 @@ int or_sw_pass(const int16_t *prof, int n, const unsigned char *t, int tL, int l
 // including what stale band-edge cells hold.
 // ------------------------------------------------------------------------------------------
 static int bandedTraceback(const SubMat &m, const uint8_t *q, const int8_t *cb, int qLen, const uint8_t *t, int tLen,
-                           int score, int go, int ge, std::string &bt) {
+                           int score, int go, int ge, std::string &bt, const int8_t *aln = nullptr /* profile query: [qLen][21] */) {
     int band = abs(tLen - qLen) + 1;
     std::vector<int> h_b, e_b, h_c;
     std::vector<int8_t> direction;
@@ -552,7 +606,7 @@ static int bandedTraceback(const SubMat &m, const uint8_t *q, const int8_t *cb, 
                 int f1 = f > 0 ? f : 0;
                 int e1 = e_b[u] > 0 ? e_b[u] : 0;
                 temp1 = e1 > f1 ? e1 : f1;
-                temp2 = h_b[d] + m.sub[q[i]][t[j]] + cb[i];
+                temp2 = h_b[d] + (aln ? (int) aln[(size_t) i * ALPH + t[j]] : m.sub[q[i]][t[j]] + cb[i]);   // banded_sw's profile branch (:1472-1474)
                 h_c[u] = temp1 > temp2 ? temp1 : temp2;
                 if (h_c[u] > maxv) maxv = h_c[u];
                 if (temp1 <= temp2) dl[dh] = 1;
@@ -608,9 +662,9 @@ int or_banded_traceback(void *vc, const unsigned char *q, const int8_t *cb, int 
 // out[0] score [1] qStart [2] qEnd [3] tStart [4] tEnd [5] identical [6] backtrace length [7] word-mode flag
 // returns evalue.  swMode as in the reference (0 score, 1 +coverage/start, 2 +backtrace).
 // ------------------------------------------------------------------------------------------
-double or_sw_align(void *vc, const unsigned char *q, int qL, const unsigned char *t, int tL, uint64_t dbResidues,
-                   int swMode, double evalThr, int covMode, float covThr, int compBias, int isIdentity, int *out,
-                   char *backtrace, int btCap) {
+static double swAlignImpl(void *vc, const unsigned char *q, int qL, const unsigned char *t, int tL, uint64_t dbResidues,
+                          int swMode, double evalThr, int covMode, float covThr, int compBias, int isIdentity, int *out,
+                          char *backtrace, int btCap, const int8_t *aln /* profile query: [qL][21], else NULL */) {
     OracleCtx *c = (OracleCtx *) vc;
     const SubMat &m = c->blosum2;
     const int go = 11, ge = 1;
@@ -623,7 +677,13 @@ double or_sw_align(void *vc, const unsigned char *q, int qL, const unsigned char
     int matMin = 0;
     for (int i = 0; i < ALPH; i++)
         for (int j = 0; j < ALPH; j++) matMin = std::min(matMin, (int) m.sub[i][j]);
-    const int bias = abs(matMin) + abs(minCb);
+    int bias = abs(matMin) + abs(minCb);
+    if (aln) {   // ssw_init's PROFILE branch (:1271-1281): min over the L x 20 profile scores
+        int pm = 0;
+        for (int i = 0; i < qL; i++)
+            for (int a = 0; a < 20; a++) pm = std::min(pm, (int) aln[(size_t) i * ALPH + a]);
+        bias = abs(pm);
+    }
     for (int i = 0; i < 8; i++) out[i] = 0;
     out[1] = -1;
     out[3] = -1;
@@ -652,7 +712,8 @@ double or_sw_align(void *vc, const unsigned char *q, int qL, const unsigned char
     // forward profile
     std::vector<int16_t> prof((size_t) ALPH * qL);
     for (int a = 0; a < ALPH; a++)
-        for (int j = 0; j < qL; j++) prof[(size_t) a * qL + j] = (int16_t) (m.sub[a][q[j]] + cb8[j]);
+        for (int j = 0; j < qL; j++)
+            prof[(size_t) a * qL + j] = aln ? (int16_t) aln[(size_t) j * ALPH + a] : (int16_t) (m.sub[a][q[j]] + cb8[j]);
     int r[3];
     int word = 0;
     swPass(prof.data(), qL, t, tL, 32, 0, go, ge, 255, bias, true, r);
@@ -676,7 +737,8 @@ double or_sw_align(void *vc, const unsigned char *q, int qL, const unsigned char
     const int n = qEnd + 1;
     std::vector<int16_t> rprof((size_t) ALPH * n);
     for (int a = 0; a < ALPH; a++)
-        for (int j = 0; j < n; j++) rprof[(size_t) a * n + j] = (int16_t) (m.sub[a][q[qEnd - j]] + cb8[qEnd - j]);
+        for (int j = 0; j < n; j++)
+            rprof[(size_t) a * n + j] = aln ? (int16_t) aln[(size_t) (qEnd - j) * ALPH + a] : (int16_t) (m.sub[a][q[qEnd - j]] + cb8[qEnd - j]);
     int rr[3];
     if (word == 0) swPass(rprof.data(), n, t, dbEnd + 1, 32, 1, go, ge, score1, bias, true, rr);
     else swPass(rprof.data(), n, t, dbEnd + 1, 16, 1, go, ge, score1, 0, false, rr);
@@ -693,7 +755,7 @@ double or_sw_align(void *vc, const unsigned char *q, int qL, const unsigned char
     if (swMode == 1 || hasLowerCoverage) return evalue;
 
     int len = bandedTraceback(m, q + qStart, cb8.data() + qStart, qEnd - qStart + 1, t + dbStart,
-                              dbEnd - dbStart + 1, score1, go, ge, bt);
+                              dbEnd - dbStart + 1, score1, go, ge, bt, aln ? aln + (size_t) qStart * ALPH : nullptr);
     if (len < 0) {
         out[7] |= 4;
         return evalue;
@@ -715,6 +777,22 @@ double or_sw_align(void *vc, const unsigned char *q, int qL, const unsigned char
         backtrace[cc] = 0;
     }
     return evalue;
+}
+
+double or_sw_align(void *vc, const unsigned char *q, int qL, const unsigned char *t, int tL, uint64_t dbResidues,
+                   int swMode, double evalThr, int covMode, float covThr, int compBias, int isIdentity, int *out,
+                   char *backtrace, int btCap) {
+    return swAlignImpl(vc, q, qL, t, tL, dbResidues, swMode, evalThr, covMode, covThr, compBias, isIdentity, out, backtrace,
+                       btCap, nullptr);
+}
+
+// profile query (ssw_align_private<PROFILE_SEQ>): letters = the profile's query letters (identity counting only),
+// aln = alignment profile int8 [qL][21]
+double or_sw_align_profile(void *vc, const unsigned char *letters, const signed char *aln, int qL, const unsigned char *t,
+                           int tL, uint64_t dbResidues, int swMode, double evalThr, int covMode, float covThr, int *out,
+                           char *backtrace, int btCap) {
+    return swAlignImpl(vc, letters, qL, t, tL, dbResidues, swMode, evalThr, covMode, covThr, 0, 0, out, backtrace, btCap,
+                       (const int8_t *) aln);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -70,6 +70,24 @@ class Host:
     def kmer_threshold(self, sensitivity, k):
         return self.L.sd_host_kmer_threshold(sensitivity, k)
 
+    def map_profiles(self, data, byte_offsets):
+        """sd_host_map_profiles: profile DB entries (25 bytes per position) -> dict(letters, consensus, aln [P,21],
+        sorted_score [P,20], sorted_index [P,20], offsets [n+1] in positions)"""
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+        bo = np.ascontiguousarray(byte_offsets, np.uint64)
+        n = len(bo) - 1
+        total = int(bo[-1]) // 25
+        out = dict(letters=np.zeros(total, np.uint8), consensus=np.zeros(total, np.uint8), aln=np.zeros((total, 21), np.int8),
+                   sorted_score=np.zeros((total, 20), np.int16), sorted_index=np.zeros((total, 20), np.uint8),
+                   offsets=np.zeros(n + 1, np.uint64))
+        _check(None, self.L.sd_host_map_profiles(ptr(data), ptr(bo), n, ptr(out['letters']), ptr(out['consensus']),
+                                                 ptr(out['aln']), ptr(out['sorted_score']), ptr(out['sorted_index']),
+                                                 ptr(out['offsets'])), 'sd_host_map_profiles')
+        return out
+
+    def profile_kmer_threshold(self, sensitivity, k):
+        return self.L.sd_host_profile_kmer_threshold(sensitivity, k)
+
     def auto_kmer_size(self, target_residues):
         return self.L.sd_host_auto_kmer_size(int(target_residues))
 
@@ -156,6 +174,10 @@ class Context:
     def seqset(self, residues, offsets, sw_bias=None):
         return SeqSet(self, residues, offsets, sw_bias)
 
+    def profileset(self, letters, offsets, aln):
+        """profile queries for sw_align (sd_profileset_create): query letters + int8 alignment profile [P, 21]"""
+        return SeqSet(self, letters, offsets, None, aln=aln)
+
     def sw_params(self, matrix, db_residues, sw_mode=2, eval_thr=10.0, cov_mode=2, cov_thr=0.8, gap_open=11,
                   gap_extend=1):
         p = _lib.SwParams()
@@ -237,15 +259,21 @@ class Context:
 
 
 class SeqSet:
-    def __init__(self, ctx, residues, offsets, sw_bias):
+    def __init__(self, ctx, residues, offsets, sw_bias, aln=None):
         self.ctx = ctx
         self.residues = np.ascontiguousarray(residues, np.uint8)
         self.offsets = np.ascontiguousarray(offsets, np.uint64)
         self.n = len(self.offsets) - 1
         b = np.ascontiguousarray(sw_bias, np.int8) if sw_bias is not None else None
         h = C.c_void_p()
-        _check(ctx.h, ctx.L.sd_seqset_create(ctx.h, ptr(self.residues), ptr(self.offsets), self.n, ptr(b), C.byref(h)),
-               'sd_seqset_create')
+        if aln is not None:
+            a = np.ascontiguousarray(aln, np.int8)
+            assert a.size == len(self.residues) * 21
+            _check(ctx.h, ctx.L.sd_profileset_create(ctx.h, ptr(self.residues), ptr(self.offsets), self.n, ptr(a), C.byref(h)),
+                   'sd_profileset_create')
+        else:
+            _check(ctx.h, ctx.L.sd_seqset_create(ctx.h, ptr(self.residues), ptr(self.offsets), self.n, ptr(b), C.byref(h)),
+                   'sd_seqset_create')
         self.h = h
 
     def __del__(self):
@@ -303,6 +331,18 @@ def prefilter(ctx, target, par, residues, offsets, kmer_bias, diag_bias, identit
     _check(ctx.h, ctx.L.sd_prefilter_batch(ctx.h, target.h, C.byref(par), nq, ptr(residues), ptr(offsets), ptr(kb),
                                            ptr(db), ptr(ident), ptr(hits), ptr(counts), ptr(stats)),
            'sd_prefilter_batch')
+    return hits, counts, stats
+
+
+def prefilter_profile(ctx, target, par, prof, want_stats=False):
+    """sd_prefilter_profile_batch for the profiles of Host.map_profiles (the target index built with kmer_thr=0)"""
+    nq = len(prof['offsets']) - 1
+    hits = np.zeros((nq, par.maxHitsPerQuery), _lib.HIT_DTYPE)
+    counts = np.zeros(nq, np.uint32)
+    stats = np.zeros((nq, 4), np.uint64) if want_stats else None
+    _check(ctx.h, ctx.L.sd_prefilter_profile_batch(ctx.h, target.h, C.byref(par), nq, ptr(prof['letters']), ptr(prof['offsets']),
+                                                   ptr(prof['sorted_score']), ptr(prof['sorted_index']), ptr(prof['aln']),
+                                                   ptr(hits), ptr(counts), ptr(stats)), 'sd_prefilter_profile_batch')
     return hits, counts, stats
 
 

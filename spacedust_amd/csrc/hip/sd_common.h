@@ -107,6 +107,8 @@ struct sd_seqset {
     uint64_t total = 0;
     uint8_t *dRes = nullptr;      // residues
     int8_t *dBias = nullptr;      // SW composition bias (int8 per residue)
+    int8_t *dProf = nullptr;      // profile sets only: int8 [position][21] alignment profile (replaces matrix row + bias)
+    std::vector<int32_t> hProfBias;   // profile sets only: per profile |min(0, min score)| (ssw_init, StripedSmithWaterman.cpp:1276-1287)
     uint64_t *dOff = nullptr;     // offsets n+1
     std::vector<uint64_t> hOff;   // host copy of the offsets
     std::vector<int32_t> hMinBias;// per sequence min(0, min cb8)

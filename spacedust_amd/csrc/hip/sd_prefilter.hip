@@ -296,6 +296,138 @@ emit_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t
     }
 }
 
+// ---- profile queries (Sequence::nextProfileKmer, Sequence.cpp:294-305; KmerGenerator::setDivideStrategy(ScoreMatrix**),
+// KmerGenerator.cpp:30-39): every seed position contributes its own list of 20 (score, amino acid) pairs sorted by
+// descending score, divide strategy 1+1+...+1.  generateKmerList's k-1 array products (:143-165) are run stage by
+// stage like the reference does, a wavefront per query position: the partial list lives in a per-wavefront scratch
+// buffer (L2 resident), lanes take parents, each appends its run of children after an exclusive scan of the run
+// lengths -- parent-major, child-minor, which is the reference's order.  The last product writes the k-mer stream
+// (EMIT) or only counts it.  Cutoffs are the reference's `short` expressions.
+// Two tiers of scratch: every position first runs with PROFILE_PARTIAL_CAP partial k-mers per stage on a wide grid; the
+// few positions that outgrow it (a partial list is never longer than the final one, and the reference's own buffer
+// holds 2^23 k-mers, KmerGenerator.h:45) are flagged and redone by a narrow grid with PROFILE_PARTIAL_CAP_BIG.
+constexpr uint32_t PROFILE_PARTIAL_CAP = 1u << 16;
+constexpr uint32_t PROFILE_PARTIAL_CAP_BIG = 1u << 23;
+constexpr uint32_t PROFILE_GRID = 2048, PROFILE_GRID_BIG = 16;
+
+template <bool EMIT>
+__global__ void __launch_bounds__(64)
+profile_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qLetters,
+                     const uint64_t *__restrict__ qOff, const int16_t *__restrict__ sortedScore,
+                     const uint8_t *__restrict__ sortedIndex, int kmerThr, int k, uint2 *__restrict__ scratch,
+                     uint32_t *__restrict__ kmerCount, const uint32_t *__restrict__ idxOffsets,
+                     const uint64_t *__restrict__ kmerBase, uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen,
+                     uint32_t *__restrict__ kPos, int *__restrict__ errFlag, uint32_t cap /* scratch entries per list */,
+                     uint8_t *__restrict__ big /* per position: 1 = outgrew the small tier */, int bigTier) {
+    __shared__ int16_t rowS[7][20];
+    __shared__ uint8_t rowI[7][20];
+    const int lane = threadIdx.x;
+    uint2 *listA = scratch + (size_t) blockIdx.x * 2 * cap;
+    uint2 *listB = listA + cap;
+    const uint8_t *seed = k == 6 ? c_seed6 : c_seed7;
+    const int thr = kmerThr > 0 ? kmerThr : 0;   // no composition bias for profiles (QueryMatcher.cpp:93-99,237-238)
+    for (uint64_t p = blockIdx.x; p < nPos; p += gridDim.x) {
+        if ((big[p] != 0) != (bigTier != 0)) continue;   // block-uniform
+        uint32_t lo = 0, hi = nQ;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (posBase[mid] <= p) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t q = lo;
+        const int i = (int) (p - posBase[lo]);
+        const uint64_t r0 = qOff[q] + (uint64_t) i;
+        bool hasX = false;
+        for (int x = 0; x < k; x++) hasX |= qLetters[r0 + seed[x]] >= 20;   // kmerContainsX on the query letters (Sequence.h:397-403)
+        __syncthreads();   // the previous position's rows are no longer read
+        for (int x = lane; x < k * 20; x += 64) {
+            const int sIdx = x / 20, e = x % 20;
+            rowS[sIdx][e] = sortedScore[(r0 + seed[sIdx]) * 20 + e];
+            rowI[sIdx][e] = sortedIndex[(r0 + seed[sIdx]) * 20 + e];
+        }
+        __syncthreads();
+        uint32_t totalOut = 0;
+        if (!hasX) {
+            int rest[7];
+            rest[k - 1] = 0;
+            for (int x = k - 1; x >= 1; x--) rest[x - 1] = (int) (short) ((int) rowS[x][0] + rest[x]);
+            const int cutoff1 = (int) (short) (thr - rest[0]);
+            uint32_t nA = 0;
+            while (nA < 20 && (int) rowS[0][nA] >= cutoff1) nA++;
+            if ((uint32_t) lane < nA) listA[lane] = make_uint2((uint32_t) (int) rowS[0][lane], (uint32_t) rowI[0][lane]);
+            uint32_t mult = 1;
+            uint64_t base = EMIT ? kmerBase[p] : 0;
+            const uint32_t qi = (q << 16) | (uint32_t) i;
+            bool overflow = false;
+            for (int st = 0; st + 1 < k && !overflow; st++) {
+                mult *= 20u;
+                const bool last = st + 2 == k;
+                const int16_t *rs = rowS[st + 1];
+                const uint8_t *ri = rowI[st + 1];
+                const int restNext = rest[st + 1];
+                uint32_t nB = 0;
+                __threadfence_block();
+                for (uint32_t c0 = 0; c0 < nA; c0 += 64) {
+                    const uint32_t e = c0 + lane;
+                    int si = 0;
+                    uint32_t ki = 0, c = 0;
+                    if (e < nA) {
+                        // agent-scope loads: the entry was written by another lane of this wavefront a stage ago and the
+                        // vector L1 may still hold the line from the buffer's previous use
+                        const uint32_t px = __hip_atomic_load(&listA[e].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ki = __hip_atomic_load(&listA[e].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        si = (int) (short) px;
+                        const int cutoff2 = (int) (short) (thr - si - restNext);
+                        while (c < 20 && (int) rs[c] >= cutoff2) c++;
+                    }
+                    uint32_t incl = c;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        uint32_t o = __shfl_up(incl, off, 64);
+                        if (lane >= off) incl += o;
+                    }
+                    const uint32_t excl = incl - c;
+                    const uint32_t chunkTotal = __shfl(incl, 63, 64);
+                    if (!last) {
+                        if (nB + chunkTotal > cap) {
+                            overflow = true;
+                            break;
+                        }
+                        for (uint32_t j = 0; j < c; j++)
+                            listB[nB + excl + j] = make_uint2((uint32_t) (int) (short) (si + (int) rs[j]), ki + (uint32_t) ri[j] * mult);
+                    } else if (EMIT) {
+                        const uint64_t w = base + nB + excl;
+                        for (uint32_t j = 0; j < c; j++) {
+                            const uint32_t kmer = ki + (uint32_t) ri[j] * mult;
+                            const uint32_t s0 = idxOffsets[kmer], e0 = idxOffsets[kmer + 1];
+                            kStart[w + j] = s0;
+                            kLen[w + j] = e0 - s0;
+                            kPos[w + j] = qi;
+                        }
+                    }
+                    nB += chunkTotal;
+                }
+                if (last) {
+                    totalOut = nB;
+                } else {
+                    uint2 *t = listA;
+                    listA = listB;
+                    listB = t;
+                    nA = nB;
+                }
+            }
+            if (overflow) {   // only possible while counting: the emit pass runs a position in the tier that counted it
+                if (lane == 0) {
+                    if (!bigTier) big[p] = 1;
+                    atomicMax(errFlag, bigTier ? 8 : 7);
+                }
+                totalOut = 0;
+            }
+        }
+        if (!EMIT && lane == 0) kmerCount[p] = totalOut;
+    }
+}
+
 // K2: emit k-mers (+ index list start/len, + owning position) in the reference's enumeration order
 __global__ void __launch_bounds__(256)
 emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
@@ -878,7 +1010,8 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
                   const uint16_t *__restrict__ hitDiag, const uint64_t *__restrict__ qHitBase, int tBits,
                   const uint8_t *__restrict__ qRes, const uint64_t *__restrict__ qOff, const int8_t *__restrict__ diagBias,
                   const uint8_t *__restrict__ tMasked, const uint64_t *__restrict__ tOff, const int8_t *__restrict__ mat,
-                  int32_t *__restrict__ cScore, uint32_t *__restrict__ cLen) {
+                  int32_t *__restrict__ cScore, uint32_t *__restrict__ cLen,
+                  const int8_t *__restrict__ qProf /* profile queries: [position][21] replaces matrix row + bias */) {
     __shared__ int8_t smat[441];
     for (int x = threadIdx.x; x < 441; x += blockDim.x) smat[x] = mat[x];
     __syncthreads();
@@ -903,9 +1036,10 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
         t0 = minDist;
     }
     int score = 0, best = 0;
+    const int8_t *qp = qProf ? qProf + (qOff[q] + (uint64_t) q0) * 21 : nullptr;
     for (int x = 0; x < n; x++) {
         const int qr = qs[q0 + x];
-        score += (int) (int8_t) (smat[qr * 21 + ts[t0 + x]] + qb[q0 + x]);
+        score += qp ? (int) qp[(size_t) x * 21 + ts[t0 + x]] : (int) (int8_t) (smat[qr * 21 + ts[t0 + x]] + qb[q0 + x]);
         score = score < 0 ? 0 : score;
         best = score > best ? score : best;
     }
@@ -960,7 +1094,8 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
                    uint32_t binMask, int maxHits, int minDiag, const uint32_t *__restrict__ identityId,
                    const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, int covMode, float covThr,
                    const uint8_t *__restrict__ qRes, const int8_t *__restrict__ diagBias, const int8_t *__restrict__ mat,
-                   sd_hit *__restrict__ outHits, uint32_t *__restrict__ outCount, int *__restrict__ errFlag) {
+                   sd_hit *__restrict__ outHits, uint32_t *__restrict__ outCount, int *__restrict__ errFlag,
+                   const int8_t *__restrict__ qProf /* nullable: profile queries */) {
     __shared__ unsigned long long keys[SEL_CAP];
     __shared__ uint32_t pay[SEL_CAP];
     __shared__ unsigned int hist[256];
@@ -998,7 +1133,7 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
             const int qL = (int) (qOff[q + 1] - qOff[q]);
             int score = 0, best = 0;
             for (int x = 0; x < qL; x++) {
-                score += (int) (int8_t) (mat[qs[x] * 21 + qs[x]] + qb[x]);
+                score += qProf ? (int) qProf[(qOff[q] + (uint64_t) x) * 21 + qs[x]] : (int) (int8_t) (mat[qs[x] * 21 + qs[x]] + qb[x]);
                 score = score < 0 ? 0 : score;
                 best = score > best ? score : best;
             }
@@ -1295,12 +1430,20 @@ void sd_target_destroy(sd_target *t) {
     delete t;
 }
 
-int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_params *par, uint32_t nQ,
-                       const uint8_t *qResidues, const uint64_t *qOffsets, const int16_t *qKmerBias,
-                       const int8_t *qDiagBias, const uint32_t *identityId, sd_hit *outHits, uint32_t *outCount,
-                       uint64_t *stats) {
-    if (!ctx || !T || !par || !qResidues || !qOffsets || !qKmerBias || !qDiagBias || !identityId || !outHits || !outCount)
-        return SD_EINVAL;
+namespace {
+struct ProfileQueries {          // profile queries: Sequence::mapProfile's outputs, concatenated like the letters
+    const int16_t *sortedScore;  // [position][20] descending
+    const uint8_t *sortedIndex;  // [position][20] amino acids in that order
+    const int8_t *aln;           // [position][21] alignment profile
+};
+}  // namespace
+
+static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilter_params *par, uint32_t nQ,
+                              const uint8_t *qResidues, const uint64_t *qOffsets, const int16_t *qKmerBias,
+                              const int8_t *qDiagBias, const uint32_t *identityId, sd_hit *outHits, uint32_t *outCount,
+                              uint64_t *stats, const ProfileQueries *prof) {
+    if (!ctx || !T || !par || !qResidues || !qOffsets || !identityId || !outHits || !outCount) return SD_EINVAL;
+    if (!prof && (!qKmerBias || !qDiagBias)) return SD_EINVAL;
     if (par->kmerSize != T->k) return sdFail(ctx, SD_EINVAL, "k-mer size mismatch");
     if (par->minDiagScore < 1) return sdFail(ctx, SD_EUNSUPPORTED, "minDiagScore must be >= 1");
     if (par->binSize == 0 || (par->binSize & (par->binSize - 1))) return sdFail(ctx, SD_EINVAL, "binSize must be a power of two");
@@ -1348,14 +1491,32 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         SD_HIP(ctx, dPosBase.alloc(bq + 1));
         SD_HIP(ctx, dIdent.alloc(bq));
         SD_HIP(ctx, hipMemcpyAsync(dQ.p, qResidues + r0, r1 - r0, hipMemcpyHostToDevice, ctx->stream));
-        SD_HIP(ctx, hipMemcpyAsync(dKB.p, qKmerBias + r0, (r1 - r0) * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
-        SD_HIP(ctx, hipMemcpyAsync(dDB.p, qDiagBias + r0, r1 - r0, hipMemcpyHostToDevice, ctx->stream));
+        WsView<int16_t> dPS(ctx, "pf.dProfScore");
+        WsView<uint8_t> dPI(ctx, "pf.dProfIndex");
+        WsView<int8_t> dPA(ctx, "pf.dProfAln");
+        const int8_t *dProfAln = nullptr;
+        if (prof) {
+            SD_HIP(ctx, dPS.alloc((r1 - r0) * 20 + 64));
+            SD_HIP(ctx, dPI.alloc((r1 - r0) * 20 + 64));
+            SD_HIP(ctx, dPA.alloc((r1 - r0) * 21 + 64));
+            SD_HIP(ctx, hipMemcpyAsync(dPS.p, prof->sortedScore + r0 * 20, (r1 - r0) * 20 * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
+            SD_HIP(ctx, hipMemcpyAsync(dPI.p, prof->sortedIndex + r0 * 20, (r1 - r0) * 20, hipMemcpyHostToDevice, ctx->stream));
+            SD_HIP(ctx, hipMemcpyAsync(dPA.p, prof->aln + r0 * 21, (r1 - r0) * 21, hipMemcpyHostToDevice, ctx->stream));
+            dProfAln = dPA.p;
+        } else {
+            SD_HIP(ctx, hipMemcpyAsync(dKB.p, qKmerBias + r0, (r1 - r0) * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
+            SD_HIP(ctx, hipMemcpyAsync(dDB.p, qDiagBias + r0, r1 - r0, hipMemcpyHostToDevice, ctx->stream));
+        }
         SD_HIP(ctx, hipMemcpyAsync(dQOff.p, hOff.data(), (bq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(dPosBase.p, hPos.data(), (bq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(dIdent.p, identityId + qBeg, bq * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         SD_HIP(ctx, hipMemsetAsync(dErr.p, 0, sizeof(int), ctx->stream));
 
         uint64_t nKmers = 0, nHits = 0;
+        uint32_t profGrid = 0;
+        bool profAnyBig = false;
+        WsView<uint2> dProfScratch(ctx, "pf.dProfScratch");
+        WsView<uint8_t> dProfBig(ctx, "pf.dProfBig");
         WsView<uint32_t> dKmerCount(ctx, "pf.dKmerCount");
         WsView<uint64_t> dKmerBase(ctx, "pf.dKmerBase");
         SD_HIP(ctx, dKmerCount.alloc(nPos + 1));
@@ -1364,7 +1525,28 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         if (nPos > 0) {
             {
                 ProfScope ps(ctx, "prefilter_count_kmers");
-                if (T->k == 6)
+                if (prof) {
+                    profGrid = (uint32_t) std::min<uint64_t>(nPos, PROFILE_GRID);
+                    SD_HIP(ctx, dProfScratch.alloc(std::max((size_t) PROFILE_GRID * 2 * PROFILE_PARTIAL_CAP,
+                                                            (size_t) PROFILE_GRID_BIG * 2 * PROFILE_PARTIAL_CAP_BIG)));
+                    SD_HIP(ctx, dProfBig.alloc(nPos + 1));
+                    SD_HIP(ctx, hipMemsetAsync(dProfBig.p, 0, nPos + 1, ctx->stream));
+                    hipLaunchKernelGGL(profile_kmers_kernel<false>, dim3(profGrid), dim3(64), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                       dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, dKmerCount.p,
+                                       (const uint32_t *) nullptr, (const uint64_t *) nullptr, (uint32_t *) nullptr,
+                                       (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p, PROFILE_PARTIAL_CAP, dProfBig.p, 0);
+                    int hTier = 0;
+                    SD_HIP(ctx, hipMemcpyAsync(&hTier, dErr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                    SD_HIP(ctx, sdStreamSync(ctx));
+                    profAnyBig = hTier == 7;
+                    if (profAnyBig) {
+                        SD_HIP(ctx, hipMemsetAsync(dErr.p, 0, sizeof(int), ctx->stream));
+                        hipLaunchKernelGGL(profile_kmers_kernel<false>, dim3(PROFILE_GRID_BIG), dim3(64), 0, ctx->stream, nPos, dPosBase.p,
+                                           bq, dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, dKmerCount.p,
+                                           (const uint32_t *) nullptr, (const uint64_t *) nullptr, (uint32_t *) nullptr,
+                                           (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p, PROFILE_PARTIAL_CAP_BIG, dProfBig.p, 1);
+                    }
+                } else if (T->k == 6)
                     hipLaunchKernelGGL(count_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                        dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p);
                 else
@@ -1373,8 +1555,13 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             }
             int rc = exclusiveScanWiden(ctx, dKmerCount.p, dKmerBase.p, nPos + 1, scanTmp);
             if (rc != SD_OK) return rc;
+            int hErrCount = 0;
             SD_HIP(ctx, hipMemcpyAsync(&nKmers, dKmerBase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            if (prof) SD_HIP(ctx, hipMemcpyAsync(&hErrCount, dErr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, sdStreamSync(ctx));
+            if (hErrCount == 8)
+                return sdFail(ctx, SD_EUNSUPPORTED, "more than %u similar k-mers at one profile position (the reference truncates there, KmerGenerator.cpp:202-210)",
+                              PROFILE_PARTIAL_CAP_BIG);
         }
         if (nKmers > HIT_BUDGET && bq > 1) {   // permissive thresholds: the k-mer list itself outgrows 32-bit device scans
             batchQ = std::max<uint32_t>(1, bq / 2);
@@ -1394,7 +1581,16 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
         if (nKmers > 0) {
             {
                 ProfScope ps(ctx, "prefilter_emit_kmers");
-                if (T->k == 6)
+                if (prof) {
+                    hipLaunchKernelGGL(profile_kmers_kernel<true>, dim3(profGrid), dim3(64), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                       dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, (uint32_t *) nullptr,
+                                       T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, dErr.p, PROFILE_PARTIAL_CAP, dProfBig.p, 0);
+                    if (profAnyBig)
+                        hipLaunchKernelGGL(profile_kmers_kernel<true>, dim3(PROFILE_GRID_BIG), dim3(64), 0, ctx->stream, nPos, dPosBase.p,
+                                           bq, dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, (uint32_t *) nullptr,
+                                           T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, dErr.p, PROFILE_PARTIAL_CAP_BIG,
+                                           dProfBig.p, 1);
+                } else if (T->k == 6)
                     hipLaunchKernelGGL(emit_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                        dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
                                        dKmerBase.p, dKStart.p, dKLen.p, dKPos.p);
@@ -1618,7 +1814,8 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             {
                 ProfScope ps(ctx, "prefilter_score_diag");
                 hipLaunchKernelGGL(score_diag_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p,
-                                   dDiag.p, dQHitBase.p, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p);
+                                   dDiag.p, dQHitBase.p, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p,
+                                   dProfAln);
             }
             hipLaunchKernelGGL(cand_stats_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCLen.p, tBits,
                                (unsigned long long *) dStats.p);
@@ -1662,7 +1859,7 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
             ProfScope ps(ctx, "prefilter_select_hits");
             hipLaunchKernelGGL(select_hits_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
                                dDiag.p, dQHitBase.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
-                               par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p);
+                               par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln);
         }
         SD_HIP(ctx, hipGetLastError());
         hs.reset(new HostScope(ctx, "pf.download"));
@@ -1688,3 +1885,22 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
 }
 
 }  // extern "C"
+
+int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_params *par, uint32_t nQ,
+                       const uint8_t *qResidues, const uint64_t *qOffsets, const int16_t *qKmerBias,
+                       const int8_t *qDiagBias, const uint32_t *identityId, sd_hit *outHits, uint32_t *outCount,
+                       uint64_t *stats) {
+    return prefilterBatchImpl(ctx, T, par, nQ, qResidues, qOffsets, qKmerBias, qDiagBias, identityId, outHits, outCount, stats,
+                              nullptr);
+}
+
+int sd_prefilter_profile_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_params *par, uint32_t nQ,
+                               const uint8_t *qLetters, const uint64_t *qOffsets, const int16_t *sortedScore,
+                               const uint8_t *sortedIndex, const int8_t *alnProfile, sd_hit *outHits, uint32_t *outCount,
+                               uint64_t *stats) {
+    if (!sortedScore || !sortedIndex || !alnProfile) return SD_EINVAL;
+    ProfileQueries pq = {sortedScore, sortedIndex, alnProfile};
+    std::vector<uint32_t> noIdentity(nQ, 0xFFFFFFFFu);   // a profile is never its own target
+    return prefilterBatchImpl(ctx, T, par, nQ, qLetters, qOffsets, nullptr, nullptr, noIdentity.data(), outHits, outCount, stats,
+                              &pq);
+}

@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(64)
 sw_score_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                 const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
                 int go, int ge, int32_t *__restrict__ out, uint2 *__restrict__ boundary,
-                const uint32_t *__restrict__ order /* nullable: task = tasks[order[x]] */) {
+                const uint32_t *__restrict__ order /* nullable: task = tasks[order[x]] */,
+                const int8_t *__restrict__ qProf /* nullable: profile queries, int8 [position][21] */) {
     constexpr int ROWS = 32 * RT;          // rows per strip
     constexpr int WORDS = RT / 4;          // profile dwords per lane per residue
     __shared__ uint32_t prof[2][21][ROWS / 4];
@@ -71,15 +72,17 @@ sw_score_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t
                 const int qi = q0 + r;
                 const bool valid = qi < n;
                 int res = 20, cb = 0;
+                int64_t pidx = 0;
                 if (valid) {
                     const int64_t idx = (int64_t) tk.qOff + (int64_t) qi * tk.qStep;
                     res = qRes[idx];
                     cb = qBias[idx];
+                    pidx = idx * 21;
                 }
                 if (valid && (qi % tk.segLen) == 0) segMask |= (1u << r);
 #pragma unroll
                 for (int a = 0; a < 21; a++) {
-                    int v = valid ? (int) smat[a * 21 + res] + cb : -64;
+                    int v = valid ? (qProf ? (int) qProf[pidx + a] : (int) smat[a * 21 + res] + cb) : -64;
                     pb[a * ROWS + l * RT + r] = (int8_t) v;
                 }
             }
@@ -210,7 +213,8 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
                     int32_t *__restrict__ res /* per task: btLen (-2 = band too small, -1 = traceback error), identical */,
                     const uint32_t *__restrict__ order /* nullable */,
                     int maxWidthLoop /* 0: one attempt; else keep doubling the band inside the kernel while
-                                        2*band+3 <= maxWidthLoop (scratch must be sized for that width) */) {
+                                        2*band+3 <= maxWidthLoop (scratch must be sized for that width) */,
+                    const int8_t *__restrict__ qProf /* nullable: profile queries, int8 [position][21] */) {
     extern __shared__ int32_t lds[];
     __shared__ int8_t smat[441];
     for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
@@ -248,8 +252,8 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
         const int xi = (i - band) > 0 ? (i - band) : 0;
         const int xim = (i - 1 - band) > 0 ? (i - 1 - band) : 0;
         const int W = end - beg + 1;
-        const int8_t *mrow = smat + 21 * q[i];
-        const int cbi = cb[i];
+        const int8_t *mrow = qProf ? qProf + (tk.qAbs + (uint64_t) i) * 21 : smat + 21 * q[i];
+        const int cbi = qProf ? 0 : cb[i];
         int8_t *dl = direction + (long long) width_d * i;
         int carry = -ge, prevHc = 0, prevF = 0, uLast = 0;
         for (int p0 = 0; p0 < W; p0 += 32) {
@@ -404,7 +408,7 @@ __global__ void __launch_bounds__(64)
 sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                            const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
                            int go, int ge, int qCap, int tCap, char *__restrict__ bt, int32_t *__restrict__ res,
-                           const uint32_t *__restrict__ order) {
+                           const uint32_t *__restrict__ order, const int8_t *__restrict__ qProf /* nullable: profile queries */) {
     extern __shared__ uint8_t ldsRaw[];
     __shared__ int8_t smat[441];
     for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
@@ -446,6 +450,7 @@ sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const ui
             const int x0 = (r - band) > 0 ? (r - band) : 0;
             int jn = x0 + l - 1;
             jn = jn < 0 ? 0 : (jn >= tLen ? tLen - 1 : jn);
+            if (qProf) return (int) qProf[(tk.qAbs + (uint64_t) r) * 21 + st[jn]];
             return (int) smat[21 * sq[r] + st[jn]] + (int) scb[r];
         };
         int sNext = cellScore(0);
@@ -570,7 +575,7 @@ void launchScorePk(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, ui
     constexpr uint32_t perWave = 2 * (64 / LW);
     dim3 grid((n + perWave - 1) / perWave), block(64);
     hipLaunchKernelGGL((sdpk::sw_score_pk_kernel<RT, LW, MULTI, WIDE, SHARED>), grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias,
-                       t->dRes, dMat, go, ge, dOut, dBound, dOrder);
+                       t->dRes, dMat, go, ge, dOut, dBound, dOrder, (const int8_t *) q->dProf);
 }
 
 int rtClass(int n) {
@@ -586,7 +591,7 @@ void launchScore(sd_ctx *ctx, const SwTask *dTasks, uint32_t n, const sd_seqset 
     if (n == 0) return;
     dim3 grid((n + 1) / 2), block(64);
     hipLaunchKernelGGL(sw_score_kernel<RT>, grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes, dMat,
-                       go, ge, dOut, dBound, (const uint32_t *) nullptr);
+                       go, ge, dOut, dBound, (const uint32_t *) nullptr, (const int8_t *) q->dProf);
 }
 
 template <int RT>
@@ -595,7 +600,7 @@ void launchScoreIdx(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, u
     if (n == 0) return;
     dim3 grid((n + 1) / 2), block(64);
     hipLaunchKernelGGL(sw_score_kernel<RT>, grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes, dMat,
-                       go, ge, dOut, dBound, dOrder);
+                       go, ge, dOut, dBound, dOrder, (const int8_t *) q->dProf);
 }
 
 // run a list of score tasks (any mix of sizes); results land in hOut[3*slot..]
@@ -1364,9 +1369,36 @@ int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offse
     return SD_OK;
 }
 
+// Profile queries (Sequence::mapProfile output, Sequence.cpp:241-292; ssw_init's PROFILE branch, StripedSmithWaterman.cpp:1238-1301):
+// the query letters stand in for the residues (identity counting, computerBacktrace :558) and the int8 alignment
+// profile [position][21] (profile score / 4, X column 0) replaces "matrix row + composition bias" in every kernel.
+int sd_profileset_create(sd_ctx *ctx, const uint8_t *queryLetters, const uint64_t *offsets, uint32_t n,
+                         const int8_t *alnProfile, sd_seqset **out) {
+    if (!alnProfile) return SD_EINVAL;
+    int rc = sd_seqset_create(ctx, queryLetters, offsets, n, nullptr, out);
+    if (rc != SD_OK) return rc;
+    sd_seqset *s = *out;
+    const size_t bytes = (size_t) s->total * 21;
+    if (hipMalloc((void **) &s->dProf, bytes + 64) != hipSuccess) {
+        sd_seqset_destroy(s);
+        *out = nullptr;
+        return sdFail(ctx, SD_ENOMEM, "sd_profileset_create: device allocation of %llu bytes failed", (unsigned long long) bytes);
+    }
+    SD_HIP(ctx, hipMemcpy(s->dProf, alnProfile, bytes, hipMemcpyHostToDevice));
+    s->hProfBias.assign(n, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        int m = 0;   // min over the 20 amino-acid columns (matSize = L * PROFILE_AA_SIZE, :1277-1279)
+        for (uint64_t x = offsets[i]; x < offsets[i + 1]; x++)
+            for (int a = 0; a < 20; a++) m = std::min(m, (int) alnProfile[x * 21 + a]);
+        s->hProfBias[i] = -m;
+    }
+    return SD_OK;
+}
+
 void sd_seqset_destroy(sd_seqset *s) {
     if (!s) return;
     if (s->dRes) (void) hipFree(s->dRes);
+    if (s->dProf) (void) hipFree(s->dProf);
     if (s->dBias) (void) hipFree(s->dBias);
     if (s->dOff) (void) hipFree(s->dOff);
     delete s;
@@ -1443,6 +1475,10 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     for (int i = 0; i < 441; i++) matMin = std::min(matMin, (int) par->matrix[i]);
     for (uint32_t i = 0; i < nPairs; i++)
         if (pairQ[i] >= queries->n || pairT[i] >= targets->n) return sdFail(ctx, SD_EINVAL, "pair %u out of range", i);
+    if (targets->dProf) return sdFail(ctx, SD_EUNSUPPORTED, "profile targets are not implemented (profile queries are)");
+    if (queries->dProf && isIdentity)
+        for (uint32_t i = 0; i < nPairs; i++)
+            if (isIdentity[i]) return sdFail(ctx, SD_EINVAL, "identity pairs (scoreIdentical) do not exist for profile queries");
     std::unique_ptr<HostScope> hs(new HostScope(ctx, "align.upload"));
     DevGateParams gp;
     gp.go = go; gp.ge = ge; gp.matMin = matMin; gp.swMode = par->swMode; gp.covMode = par->covMode; gp.covThr = par->covThr;
@@ -1500,7 +1536,9 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     SD_HIP(ctx, hipMemcpyAsync(dPT, pairT, N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     if (isIdentity) SD_HIP(ctx, hipMemcpyAsync(dIdent, isIdentity, N, hipMemcpyHostToDevice, ctx->stream));
     else SD_HIP(ctx, hipMemsetAsync(dIdent, 0, N, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(dMinBias, queries->hMinBias.data(), queries->n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    // byte-kernel bias (ssw_init, :1276-1287): |min(matrix)| + |min(0, composition bias)| for sequences, |min(0, profile)| for profiles
+    SD_HIP(ctx, hipMemcpyAsync(dMinBias, queries->dProf ? queries->hProfBias.data() : queries->hMinBias.data(),
+                               queries->n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(ctx, hipMemsetAsync(dErr, 0, 4 * sizeof(int), ctx->stream));
     SD_HIP(ctx, hipMemsetAsync(dCells, 0, 4 * sizeof(unsigned long long), ctx->stream));
     SD_HIP(ctx, hipMemsetAsync(dOut32, 0, N * 3 * sizeof(int32_t), ctx->stream));
@@ -1522,7 +1560,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     if (rc != SD_OK) return rc;
     // ---- pass 2: saturated pairs again with the word kernel's 16-lane structure
     hs.reset(new HostScope(ctx, "align.fwd16"));
-    hipLaunchKernelGGL(k_gate_word, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dOut32, dMinBias, matMin, dTasks, dKeys,
+    hipLaunchKernelGGL(k_gate_word, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dOut32, dMinBias, queries->dProf ? 0 : matMin, dTasks, dKeys,
                        dVals, dWord, dFwdKeys, usePk);
     hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dKeys, dCells + 0);
     rc = devRunScore(ctx, nPairs, dKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go, ge,
@@ -1577,7 +1615,8 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
             const int qCap = TB_NARROW_Q[ci], tCap = TB_NARROW_T[ci];
             const size_t ldsBytes = 2 * ((size_t) 16 * qCap + 2 * (size_t) qCap + tCap);
             hipLaunchKernelGGL(sw_traceback_narrow_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
-                               queries->dBias, targets->dRes, dMat, go, ge, qCap, tCap, dBt, dTbRes, dOrder + begin);
+                               queries->dBias, targets->dRes, dMat, go, ge, qCap, tCap, dBt, dTbRes, dOrder + begin,
+                               (const int8_t *) queries->dProf);
         }
         static const int ldsClass[3] = {128, 512, 2048};
         for (int ci = 0; ci < 3; ci++) {
@@ -1588,7 +1627,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
             const size_t ldsBytes = (size_t) 2 * 3 * ldsStride * sizeof(int32_t);
             hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
                                queries->dBias, targets->dRes, dMat, go, ge, ldsStride, dDir, dBt, dTbRes, dOrder + begin,
-                               ldsClass[ci] - 1);
+                               ldsClass[ci] - 1, (const int8_t *) queries->dProf);
         }
         SD_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_tb_collect, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dVals, dTb, dTbRes, dDirBytes, dBtLen,
@@ -1746,6 +1785,7 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
                       uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
                       sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed) {
     if (!ctx || !par || !queries || !targets || !out) return SD_EINVAL;
+    if (queries->dProf || targets->dProf) return sdFail(ctx, SD_EUNSUPPORTED, "the host-orchestrated A/B path takes sequence sets only");
     (void) hipSetDevice(ctx->device);
     const int go = par->gapOpen, ge = par->gapExtend;
     ctx->cellsFwd = ctx->cellsRev = ctx->cellsTb = 0;
@@ -1951,7 +1991,7 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
                 const size_t ldsBytes = (size_t) 2 * 3 * ldsStride * sizeof(int32_t);
                 hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dT.p, cnt,
                                    queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, ldsStride, dDir.p, dBt.p, dRes.p,
-                                   (const uint32_t *) nullptr, 0);
+                                   (const uint32_t *) nullptr, 0, (const int8_t *) queries->dProf);
             }
             SD_HIP(ctx, hipGetLastError());
             TbTask *back = nullptr;

@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(64)
 sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                    const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
                    int go, int ge, int32_t *__restrict__ out, uint2 *__restrict__ boundary,
-                   const uint32_t *__restrict__ order) {
+                   const uint32_t *__restrict__ order,
+                   const int8_t *__restrict__ qProf /* profile queries: int8 [position][21] rows replace mat[q][.] + bias */) {
     constexpr int ROWS = LW * RT;
     constexpr int WORDS = (RT + 3) / 4;    // profile dwords per lane, pair and residue (RT need not be a multiple of 4:
     constexpr int RTP = 4 * WORDS;         //  the bytes past RT in the last dword are padding)
@@ -182,6 +183,7 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
 #pragma unroll
             for (int w = 0; w < WORDS; w++) {
                 int res[4], cb[4];
+                int64_t pidx[4];
                 bool valid[4];
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
@@ -189,10 +191,12 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                     valid[b] = (4 * w + b < RT) && qi < T.n;
                     res[b] = 20;
                     cb[b] = 0;
+                    pidx[b] = 0;
                     if (valid[b]) {
                         const int64_t idx = (int64_t) T.qOff + (int64_t) qi * T.qStep;
                         res[b] = qRes[idx];
                         cb[b] = qBias[idx];
+                        pidx[b] = idx * 21;
                     }
                     const bool reset = valid[b] && seg == 0;
                     seg = (seg + 1 == T.segLen) ? 0 : seg + 1;
@@ -205,7 +209,7 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                     uint32_t word = 0;
 #pragma unroll
                     for (int b = 0; b < 4; b++) {
-                        const int v = valid[b] ? (int) smat[a * 21 + res[b]] + cb[b] : -64;
+                        const int v = valid[b] ? (qProf ? (int) qProf[pidx[b] + a] : (int) smat[a * 21 + res[b]] + cb[b]) : -64;
                         word |= (uint32_t) (uint8_t) (int8_t) v << (8 * b);
                     }
                     pw[a * PSTRIDE + w] = word;

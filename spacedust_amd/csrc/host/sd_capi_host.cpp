@@ -98,6 +98,25 @@ int sd_host_index_build(sd_host *h, const uint8_t *residues, const uint64_t *off
 
 int sd_host_auto_kmer_size(uint64_t targetResidues) { return sd::autoKmerSize(targetResidues); }
 
+int sd_host_map_profiles(const char *profileData, const uint64_t *byteOffsets, uint32_t n, uint8_t *queryLetters,
+                         uint8_t *consensus, int8_t *alnProfile, int16_t *sortedScore, uint8_t *sortedIndex,
+                         uint64_t *posOffsets) {
+    if (!profileData || !byteOffsets || !queryLetters || !alnProfile || !sortedScore || !sortedIndex || !posOffsets) return SD_EINVAL;
+    for (uint32_t i = 0; i <= n; i++) {
+        if (byteOffsets[i] % sd::PROFILE_RECORD) return SD_EINVAL;
+        posOffsets[i] = byteOffsets[i] / sd::PROFILE_RECORD;
+    }
+#pragma omp parallel for schedule(dynamic, 64)
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t p0 = posOffsets[i];
+        sd::mapProfile(profileData + byteOffsets[i], (uint32_t) (posOffsets[i + 1] - p0), queryLetters + p0,
+                       consensus ? consensus + p0 : nullptr, alnProfile + p0 * 21, sortedScore + p0 * 20, sortedIndex + p0 * 20);
+    }
+    return SD_OK;
+}
+
+int sd_host_profile_kmer_threshold(float sensitivity, int kmerSize) { return sd::profileKmerThreshold(sensitivity, kmerSize); }
+
 int sd_host_index_info(sd_host_index *ix, uint64_t *tableSize, uint64_t *nEntries, uint64_t *maskedResidues) {
     if (tableSize) *tableSize = ix->idx.tableSize;
     if (nEntries) *nEntries = ix->idx.entrySeq.size();

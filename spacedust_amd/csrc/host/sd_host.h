@@ -66,6 +66,20 @@ size_t generateKmerList(const ExtMatrix &three, const ExtMatrix &two, int k, con
                         std::vector<uint32_t> &out);
 
 // ---------------------------------------------------------------------------
+// Profile queries (M/src/commons/Sequence.cpp:241-305, Sequence.h:458-471)
+// ---------------------------------------------------------------------------
+constexpr int PROFILE_RECORD = 25;   // bytes per position: 20 scores, query letter, consensus letter, neff, 2 reserved
+// one profile of L positions -> query letters, consensus letters (nullable), alignment profile int8 [L][21]
+// (score / 4, X column 0), k-mer generator rows: scores sorted descending by the reference's sorting network and
+// the amino acids in that order, [L][20] each
+void mapProfile(const char *data, uint32_t L, uint8_t *letters, uint8_t *consensus, int8_t *aln, int16_t *sortedScore,
+                uint8_t *sortedIndex);
+// similar k-mers of one window: score[s] / index[s] = sorted row of seed position s (s < k)
+size_t generateProfileKmerList(const int16_t *const *score, const uint8_t *const *index, int k, int thr,
+                               std::vector<uint32_t> &out);
+int profileKmerThreshold(float sensitivity, int k);   // Prefiltering.cpp:1031-1043 (no context pseudo counts)
+
+// ---------------------------------------------------------------------------
 // tantan repeat masking (M/lib/tantan/tantan.cpp, M/src/commons/Masker.cpp:15-55)
 // ---------------------------------------------------------------------------
 struct MaskCtx {

@@ -1,0 +1,164 @@
+"""GPU parity for profile queries through the C ABI: sd_host_map_profiles + sd_prefilter_profile_batch
+and sd_profileset_create + sd_sw_align_batch against rows / alignments produced by the REAL reference classes
+(tools/make_golden_profile.py) and, on larger random cases, against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from spacedust_amd import api
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _golden(host):
+    g = np.load(os.path.join(GOLD, 'profile_vectors.npz'))
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    n = len(off) - 1
+    res, off2 = host.map_sequences([blob[int(off[i]):int(off[i + 1])] for i in range(n)])
+    assert (off2 == off).all()
+    prof = host.map_profiles(g['profiles'].tobytes(), g['poff'])
+    return g, res, off, prof
+
+
+def test_profile_prefilter_matches_reference(gpu, host):
+    g, res, off, prof = _golden(host)
+    assert host.profile_kmer_threshold(5.7, 6) == 99
+    idx = host.build_index(res, off, 6, 0)   # profile searches index every non-X target k-mer (Prefiltering.cpp:525-527)
+    tgt = api.Target(gpu, host, idx)
+    for thr in (99, 80):
+        par = api.prefilter_params(host, idx.n, kmer_thr=thr, max_hits=300, cov_thr=0.0, bin_size=2, k=6)
+        hits, cnt, st = api.prefilter_profile(gpu, tgt, par, prof, want_stats=True)
+        rows = g['pf_rows_%d' % thr]
+        for q in range(len(cnt)):
+            exp = rows[rows[:, 0] == q]
+            m = int(cnt[q])
+            assert m == len(exp), (thr, q, m, len(exp))
+            assert (hits[q, :m]['seqId'] == exp[:, 1]).all() and (hits[q, :m]['score'] == exp[:, 2]).all(), (thr, q)
+            assert (hits[q, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (thr, q)
+
+
+def test_profile_prefilter_matches_oracle_stats(gpu, host, oracle):
+    """k-mer / index-hit / diagonal counts per query as well (the oracle is pinned to the reference for these inputs)"""
+    g, res, off, prof = _golden(host)
+    idx = host.build_index(res, off, 6, 0)
+    tgt = api.Target(gpu, host, idx)
+    par = api.prefilter_params(host, idx.n, kmer_thr=70, max_hits=50, cov_thr=0.0, bin_size=2, k=6)
+    hits, cnt, st = api.prefilter_profile(gpu, tgt, par, prof, want_stats=True)
+    ot = oracle.target(res, off, k=6, kmer_thr=0)
+    po = prof['offsets']
+    total = 0
+    for q in range(len(cnt)):
+        a, b = int(po[q]), int(po[q + 1])
+        ids, sc, dg, ost = ot.prefilter_profile(prof['letters'][a:b], prof['aln'][a:b], prof['sorted_score'][a:b],
+                                                prof['sorted_index'][a:b], 70, max_hits=50)
+        m = int(cnt[q])
+        total += m
+        assert m == len(ids) and (hits[q, :m]['seqId'] == ids).all() and (hits[q, :m]['score'] == sc).all(), q
+        assert (hits[q, :m]['diagonal'] == dg).all(), q
+        assert tuple(int(x) for x in st[q]) == tuple(int(x) for x in ost), (q, st[q], ost)
+    assert total > 100
+
+
+def test_profile_alignments_match_reference(gpu, host):
+    g, res, off, prof = _golden(host)
+    mat, _, _ = host.matrix(0)
+    db = int(off[-1])
+    qs = gpu.profileset(prof['letters'], prof['offsets'], prof['aln'])
+    ts = gpu.seqset(res, off, None)
+    par = gpu.sw_params(mat, db)
+    pq, pt = g['sw_pairs'][:, 0].astype(np.uint32), g['sw_pairs'][:, 1].astype(np.uint32)
+    out, pool = gpu.sw_align(par, qs, ts, pq, pt)
+    bts = g['sw_bt'].tobytes().decode().split('\n')
+    n_bt = 0
+    for x in range(len(pq)):
+        r, e = out[x], g['sw_res'][x]
+        assert (int(r['score']), int(r['qEnd']), int(r['tEnd'])) == (e[0], e[2], e[4]), (x, r, e)
+        assert (int(r['qStart']), int(r['tStart']), int(r['btLen'])) == (e[1], e[3], e[6]), (x, r, e)
+        ev = g['evalue'][x]
+        if ev <= 20.0:
+            assert float(r['evalue']) == ev, (x, r['evalue'], ev)
+        else:
+            assert abs(float(r['evalue']) - ev) <= 1e-9 * ev, (x, r['evalue'], ev)
+        if e[6] > 0:
+            n_bt += 1
+            bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
+            assert bt == bts[x], (x, bt, bts[x])
+            assert int(r['identical']) == e[5], x
+    assert n_bt > 50
+
+
+def test_profile_alignments_match_oracle_many(gpu, host, oracle, small_proteomes):
+    """a larger batch: profiles derived from proteome sequences against many targets (all kernel classes, word reruns,
+    band-doubling tracebacks), checked against the oracle"""
+    ps = small_proteomes
+    rng = np.random.default_rng(31)
+    mat, _, _ = host.matrix(0)
+    m = np.array([mat[i] for i in range(441)], np.int32).reshape(21, 21)
+    qids = rng.choice(ps.n, 40, replace=False)
+    recs, boff = [], [0]
+    for q in qids:
+        s = ps.residues[int(ps.offsets[q]):int(ps.offsets[q + 1])]
+        rec = np.zeros((len(s), 25), np.uint8)
+        scale = int(rng.integers(2, 6))
+        for i, a in enumerate(s):
+            row = m[min(int(a), 19), :20] * scale + rng.integers(-5, 6, 20)
+            rec[i, :20] = np.clip(row, -128, 127).astype(np.int8).view(np.uint8)
+            rec[i, 20] = a
+            rec[i, 21] = int(np.argmax(row))
+        recs.append(rec.tobytes())
+        boff.append(boff[-1] + len(recs[-1]))
+    prof = host.map_profiles(b''.join(recs), np.array(boff, np.uint64))
+    db = int(ps.offsets[-1])
+    qs = gpu.profileset(prof['letters'], prof['offsets'], prof['aln'])
+    ts = gpu.seqset(ps.residues, ps.offsets, None)
+    par = gpu.sw_params(mat, db)
+    pq, pt = [], []
+    for x, q in enumerate(qids):
+        pq += [x] * 12
+        pt += [int(q)] + [int(t) for t in rng.integers(0, ps.n, 11)]   # the source sequence itself scores high (word kernel)
+    pq, pt = np.array(pq, np.uint32), np.array(pt, np.uint32)
+    out, pool = gpu.sw_align(par, qs, ts, pq, pt)
+    po = prof['offsets']
+    n_bt = n_word = 0
+    for x in range(len(pq)):
+        a, b = int(po[pq[x]]), int(po[pq[x] + 1])
+        t = ps.residues[int(ps.offsets[pt[x]]):int(ps.offsets[pt[x] + 1])]
+        o = oracle.sw_align_profile(prof['letters'][a:b], prof['aln'][a:b], t, db)
+        r = out[x]
+        n_word += o['flags'] & 1
+        assert int(r['score']) == o['score'], (x, r, o)
+        assert (int(r['qStart']), int(r['qEnd']), int(r['tStart']), int(r['tEnd'])) == \
+               (o['qStart'], o['qEnd'], o['tStart'], o['tEnd']), (x, r, o)
+        assert int(r['btLen']) == o['btLen'], (x, r, o)
+        if o['btLen'] > 0:
+            n_bt += 1
+            bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
+            assert bt == o['backtrace'], (x, bt, o['backtrace'])
+            assert int(r['identical']) == o['identical']
+    assert n_bt >= 40 and n_word >= 10, (n_bt, n_word)
+
+
+def test_profile_prefilter_large_kmer_lists(gpu, host, oracle):
+    """permissive threshold: > 10^5 similar k-mers per position on average, so positions leave the 65 536-entry scratch
+    tier and are redone by the large tier; counts and hits against the oracle"""
+    g, res, off, _ = _golden(host)
+    poff = g['poff'][:4]
+    prof = host.map_profiles(g['profiles'][:int(poff[-1])].tobytes(), poff)
+    idx = host.build_index(res, off, 6, 0)
+    tgt = api.Target(gpu, host, idx)
+    par = api.prefilter_params(host, idx.n, kmer_thr=45, max_hits=50, cov_thr=0.0, bin_size=2, k=6)
+    hits, cnt, st = api.prefilter_profile(gpu, tgt, par, prof, want_stats=True)
+    ot = oracle.target(res, off, k=6, kmer_thr=0)
+    po = prof['offsets']
+    for q in range(len(cnt)):
+        a, b = int(po[q]), int(po[q + 1])
+        ids, sc, dg, ost = ot.prefilter_profile(prof['letters'][a:b], prof['aln'][a:b], prof['sorted_score'][a:b],
+                                                prof['sorted_index'][a:b], 45, max_hits=50)
+        m = int(cnt[q])
+        assert int(st[q][0]) > 100000 * (b - a)
+        assert m == len(ids) and (hits[q, :m]['seqId'] == ids).all() and (hits[q, :m]['score'] == sc).all(), q
+        assert (hits[q, :m]['diagonal'] == dg).all(), q
+        assert tuple(int(x) for x in st[q]) == tuple(int(x) for x in ost), (q, st[q], ost)

@@ -185,6 +185,53 @@ def test_k7_kmer_lists_and_prefilter(oracle):
             assert (dg.astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (thr, q)
 
 
+def _load_profiles(oracle):
+    g = np.load(os.path.join(GOLD, 'profile_vectors.npz'))
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    poff = g['poff']
+    profs = [oracle.map_profile(g['profiles'][int(poff[i]):int(poff[i + 1])].tobytes()) for i in range(len(poff) - 1)]
+    return g, nums, profs
+
+
+def test_profile_queries(oracle):
+    """profile queries (a22): per-position k-mer lists, prefilter rows at two thresholds and full alignments, all from
+    the real reference classes (tools/make_golden_profile.py)"""
+    g, nums, profs = _load_profiles(oracle)
+    seed = [0, 1, 3, 5, 8, 9]
+    lo = g['list_off']
+    for i, (pi, pos, thr) in enumerate(g['windows']):
+        letters, cons, aln, ssc, six = profs[pi]
+        rows = [pos + s for s in seed]
+        got = oracle.profile_kmer_list(ssc[rows], six[rows], int(thr))
+        exp = g['lists'][int(lo[i]):int(lo[i + 1])]
+        assert len(got) == len(exp) and (got == exp).all(), i
+    tgt = oracle.target(np.concatenate(nums), g['off'], k=6, kmer_thr=0)
+    for thr in (99, 80):
+        rows = g['pf_rows_%d' % thr]
+        assert len(rows) > 3 * len(profs)
+        for qi, (letters, cons, aln, ssc, six) in enumerate(profs):
+            exp = rows[rows[:, 0] == qi]
+            ids, sc, dg, _ = tgt.prefilter_profile(letters, aln, ssc, six, thr)
+            assert len(ids) == len(exp) and (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all(), (thr, qi)
+            assert (dg.astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (thr, qi)
+    bts = g['sw_bt'].tobytes().decode().split('\n')
+    db_res = int(g['off'][-1])
+    n_bt = 0
+    for x, (qi, t) in enumerate(g['sw_pairs']):
+        letters, cons, aln, ssc, six = profs[qi]
+        r = oracle.sw_align_profile(letters, aln, nums[t], db_res)
+        e = g['sw_res'][x]
+        assert (r['score'], r['qEnd'], r['tEnd']) == (e[0], e[2], e[4]), x
+        assert r['evalue'] == g['evalue'][x], x
+        assert (r['qStart'], r['tStart'], r['btLen']) == (e[1], e[3], e[6]), x
+        if e[6] > 0:
+            assert r['identical'] == e[5] and r['backtrace'] == bts[x], x
+            n_bt += 1
+    assert n_bt > 50
+
+
 def test_prefilter_hit_buffer_overflow(oracle):
     """a query with more index hits than the reference's hit buffer (2*max(1e6, #targets)): one overflow, two match
     parts, merged result lists (QueryMatcher.cpp:281-326); rows from the real reference (tools/make_golden_overflow.py)"""
