@@ -1036,12 +1036,20 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
         t0 = minDist;
     }
     int score = 0, best = 0;
-    const int8_t *qp = qProf ? qProf + (qOff[q] + (uint64_t) q0) * 21 : nullptr;
-    for (int x = 0; x < n; x++) {
-        const int qr = qs[q0 + x];
-        score += qp ? (int) qp[(size_t) x * 21 + ts[t0 + x]] : (int) (int8_t) (smat[qr * 21 + ts[t0 + x]] + qb[q0 + x]);
-        score = score < 0 ? 0 : score;
-        best = score > best ? score : best;
+    if (qProf) {   // profile query: the row of the position replaces matrix row + bias
+        const int8_t *qp = qProf + (qOff[q] + (uint64_t) q0) * 21;
+        for (int x = 0; x < n; x++) {
+            score += (int) qp[(size_t) x * 21 + ts[t0 + x]];
+            score = score < 0 ? 0 : score;
+            best = score > best ? score : best;
+        }
+    } else {
+        for (int x = 0; x < n; x++) {
+            const int qr = qs[q0 + x];
+            score += (int) (int8_t) (smat[qr * 21 + ts[t0 + x]] + qb[q0 + x]);
+            score = score < 0 ? 0 : score;
+            best = score > best ? score : best;
+        }
     }
     cScore[c] = best;
     cLen[c] = (uint32_t) n;

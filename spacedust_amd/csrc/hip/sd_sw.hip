@@ -80,10 +80,15 @@ sw_score_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t
                     pidx = idx * 21;
                 }
                 if (valid && (qi % tk.segLen) == 0) segMask |= (1u << r);
+                if (qProf) {
 #pragma unroll
-                for (int a = 0; a < 21; a++) {
-                    int v = valid ? (qProf ? (int) qProf[pidx + a] : (int) smat[a * 21 + res] + cb) : -64;
-                    pb[a * ROWS + l * RT + r] = (int8_t) v;
+                    for (int a = 0; a < 21; a++) pb[a * ROWS + l * RT + r] = (int8_t) (valid ? (int) qProf[pidx + a] : -64);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 21; a++) {
+                        int v = valid ? (int) smat[a * 21 + res] + cb : -64;
+                        pb[a * ROWS + l * RT + r] = (int8_t) v;
+                    }
                 }
             }
         }
@@ -206,6 +211,7 @@ struct TbTask {
 // exclusive prefix maximum across lanes (cross-lane scan, carried between 32-cell chunks).  Directions are
 // packed to one byte per cell (bit0 dirE==3, bit1 dirF==5, bits2-3: 0 diag / 1 take dirE / 2 take dirF) and
 // written row-major (coalesced); lane 0 then walks the path.
+template <bool PROF>
 __global__ void __launch_bounds__(64)
 sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                     const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
@@ -252,8 +258,8 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
         const int xi = (i - band) > 0 ? (i - band) : 0;
         const int xim = (i - 1 - band) > 0 ? (i - 1 - band) : 0;
         const int W = end - beg + 1;
-        const int8_t *mrow = qProf ? qProf + (tk.qAbs + (uint64_t) i) * 21 : smat + 21 * q[i];
-        const int cbi = qProf ? 0 : cb[i];
+        const int8_t *mrow = PROF ? qProf + (tk.qAbs + (uint64_t) i) * 21 : smat + 21 * q[i];   // never a mixed (flat) pointer
+        const int cbi = PROF ? 0 : cb[i];
         int8_t *dl = direction + (long long) width_d * i;
         int carry = -ge, prevHc = 0, prevF = 0, uLast = 0;
         for (int p0 = 0; p0 < W; p0 += 32) {
@@ -404,6 +410,7 @@ __device__ __forceinline__ int dppZ(int src, int ctrl) {   // lanes without a so
     }
 }
 
+template <bool PROF>
 __global__ void __launch_bounds__(64)
 sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                            const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
@@ -450,7 +457,7 @@ sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const ui
             const int x0 = (r - band) > 0 ? (r - band) : 0;
             int jn = x0 + l - 1;
             jn = jn < 0 ? 0 : (jn >= tLen ? tLen - 1 : jn);
-            if (qProf) return (int) qProf[(tk.qAbs + (uint64_t) r) * 21 + st[jn]];
+            if (PROF) return (int) qProf[(tk.qAbs + (uint64_t) r) * 21 + st[jn]];
             return (int) smat[21 * sq[r] + st[jn]] + (int) scb[r];
         };
         int sNext = cellScore(0);
@@ -1614,9 +1621,14 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
             ProfScope ps(ctx, tbNames[ci]);
             const int qCap = TB_NARROW_Q[ci], tCap = TB_NARROW_T[ci];
             const size_t ldsBytes = 2 * ((size_t) 16 * qCap + 2 * (size_t) qCap + tCap);
-            hipLaunchKernelGGL(sw_traceback_narrow_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
-                               queries->dBias, targets->dRes, dMat, go, ge, qCap, tCap, dBt, dTbRes, dOrder + begin,
-                               (const int8_t *) queries->dProf);
+            if (queries->dProf)
+                hipLaunchKernelGGL(sw_traceback_narrow_kernel<true>, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt,
+                                   queries->dRes, queries->dBias, targets->dRes, dMat, go, ge, qCap, tCap, dBt, dTbRes, dOrder + begin,
+                                   (const int8_t *) queries->dProf);
+            else
+                hipLaunchKernelGGL(sw_traceback_narrow_kernel<false>, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt,
+                                   queries->dRes, queries->dBias, targets->dRes, dMat, go, ge, qCap, tCap, dBt, dTbRes, dOrder + begin,
+                                   (const int8_t *) nullptr);
         }
         static const int ldsClass[3] = {128, 512, 2048};
         for (int ci = 0; ci < 3; ci++) {
@@ -1625,9 +1637,14 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
             ProfScope ps(ctx, "sw_traceback.lds");
             const int ldsStride = ldsClass[ci] + 1;
             const size_t ldsBytes = (size_t) 2 * 3 * ldsStride * sizeof(int32_t);
-            hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
-                               queries->dBias, targets->dRes, dMat, go, ge, ldsStride, dDir, dBt, dTbRes, dOrder + begin,
-                               ldsClass[ci] - 1, (const int8_t *) queries->dProf);
+            if (queries->dProf)
+                hipLaunchKernelGGL(sw_traceback_kernel<true>, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
+                                   queries->dBias, targets->dRes, dMat, go, ge, ldsStride, dDir, dBt, dTbRes, dOrder + begin,
+                                   ldsClass[ci] - 1, (const int8_t *) queries->dProf);
+            else
+                hipLaunchKernelGGL(sw_traceback_kernel<false>, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
+                                   queries->dBias, targets->dRes, dMat, go, ge, ldsStride, dDir, dBt, dTbRes, dOrder + begin,
+                                   ldsClass[ci] - 1, (const int8_t *) nullptr);
         }
         SD_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_tb_collect, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dVals, dTb, dTbRes, dDirBytes, dBtLen,
@@ -1989,9 +2006,9 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
                 ProfScope ps(ctx, "sw_traceback");
                 const int ldsStride = cls + 1;
                 const size_t ldsBytes = (size_t) 2 * 3 * ldsStride * sizeof(int32_t);
-                hipLaunchKernelGGL(sw_traceback_kernel, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dT.p, cnt,
+                hipLaunchKernelGGL(sw_traceback_kernel<false>, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dT.p, cnt,
                                    queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, ldsStride, dDir.p, dBt.p, dRes.p,
-                                   (const uint32_t *) nullptr, 0, (const int8_t *) queries->dProf);
+                                   (const uint32_t *) nullptr, 0, (const int8_t *) nullptr);
             }
             SD_HIP(ctx, hipGetLastError());
             TbTask *back = nullptr;

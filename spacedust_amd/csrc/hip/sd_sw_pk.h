@@ -205,14 +205,26 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
                     else if (x == 0) mask[4 * w + b] = m;
                     else mask[4 * w + b] |= m << 16;
                 }
-                for (int a = 0; a < 21; a++) {
-                    uint32_t word = 0;
+                if (qProf) {   // profile query: the position's own row
+                    for (int a = 0; a < 21; a++) {
+                        uint32_t word = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const int v = valid[b] ? (qProf ? (int) qProf[pidx[b] + a] : (int) smat[a * 21 + res[b]] + cb[b]) : -64;
-                        word |= (uint32_t) (uint8_t) (int8_t) v << (8 * b);
+                        for (int b = 0; b < 4; b++) {
+                            const int v = valid[b] ? (int) qProf[pidx[b] + a] : -64;
+                            word |= (uint32_t) (uint8_t) (int8_t) v << (8 * b);
+                        }
+                        pw[a * PSTRIDE + w] = word;
                     }
-                    pw[a * PSTRIDE + w] = word;
+                } else {
+                    for (int a = 0; a < 21; a++) {
+                        uint32_t word = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int v = valid[b] ? (int) smat[a * 21 + res[b]] + cb[b] : -64;
+                            word |= (uint32_t) (uint8_t) (int8_t) v << (8 * b);
+                        }
+                        pw[a * PSTRIDE + w] = word;
+                    }
                 }
                 pw[PK_NEUTRAL * PSTRIDE + w] = 0xC0C0C0C0u;
             }
