@@ -62,7 +62,8 @@ int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offse
 /* Profile queries for sd_sw_align_batch*: the set a Matcher::initQuery with a profile Sequence stands for
  * (ssw_init's PROFILE branch, StripedSmithWaterman.cpp:1238-1301).  queryLetters take the residues' place (identity
  * counting, :558), alnProfile (total x 21 int8) replaces "matrix row + composition bias" in the score, start-position
- * and traceback kernels; pass the returned set as `queries`.  Identity pairs do not exist for profile queries. */
+ * and traceback kernels; pass the returned set as `queries`.  Identity pairs (scoreIdentical, :1675-1710) sum the
+ * profile along the main diagonal. */
 int sd_profileset_create(sd_ctx *ctx, const uint8_t *queryLetters, const uint64_t *offsets, uint32_t n,
                          const int8_t *alnProfile, sd_seqset **out);
 void sd_seqset_destroy(sd_seqset *s);
@@ -186,8 +187,9 @@ int sd_host_profile_kmer_threshold(float sensitivity, int kmerSize);
  * The target index must have been built with k-mer threshold 0 (Prefiltering.cpp:525-527). */
 int sd_prefilter_profile_batch(sd_ctx *ctx, const sd_target *target, const sd_prefilter_params *par, uint32_t nQ,
                                const uint8_t *queryLetters, const uint64_t *qOffsets, const int16_t *sortedScore,
-                               const uint8_t *sortedIndex, const int8_t *alnProfile, sd_hit *outHits, uint32_t *outCount,
-                               uint64_t *stats);
+                               const uint8_t *sortedIndex, const int8_t *alnProfile,
+                               const uint32_t *identityId /* as in sd_prefilter_batch; NULL = none */, sd_hit *outHits,
+                               uint32_t *outCount, uint64_t *stats);
 
 /* ---- clusterhits ---------------------------------------------------------------------- */
 typedef struct {

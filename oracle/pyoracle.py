@@ -62,10 +62,10 @@ class Oracle:
                                   C.c_float, C.c_int, C.c_int, _vp, _vp, C.c_int]
         L.or_sw_align_profile.restype = C.c_double
         L.or_sw_align_profile.argtypes = [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int,
-                                          C.c_float, _vp, _vp, C.c_int]
+                                          C.c_float, C.c_int, _vp, _vp, C.c_int]
         L.or_prefilter_query_profile.restype = C.c_int64
-        L.or_prefilter_query_profile.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32,
-                                                 _vp, _vp, _vp, _vp]
+        L.or_prefilter_query_profile.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
+                                                 C.c_uint32, _vp, _vp, _vp, _vp]
         L.or_map_profile.argtypes = [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]
         L.or_profile_kmer_list.restype = C.c_size_t
         L.or_profile_kmer_list.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t]
@@ -128,7 +128,7 @@ class Oracle:
         n = self.lib.or_profile_kmer_list(_ptr(sc), _ptr(ix), sc.shape[0], thr, _ptr(out), cap)
         return out[:n].copy()
 
-    def sw_align_profile(self, letters, aln, t, db_residues, sw_mode=2, eval_thr=10.0, cov_mode=2, cov_thr=0.8):
+    def sw_align_profile(self, letters, aln, t, db_residues, sw_mode=2, eval_thr=10.0, cov_mode=2, cov_thr=0.8, identity=False):
         letters = np.ascontiguousarray(letters, np.uint8)
         aln = np.ascontiguousarray(aln, np.int8)
         t = np.ascontiguousarray(t, np.uint8)
@@ -136,7 +136,7 @@ class Oracle:
         cap = len(letters) + len(t) + 8
         bt = C.create_string_buffer(cap)
         ev = self.lib.or_sw_align_profile(self.ctx, _ptr(letters), _ptr(aln), len(letters), _ptr(t), len(t), db_residues,
-                                          sw_mode, eval_thr, cov_mode, cov_thr, _ptr(out), bt, cap)
+                                          sw_mode, eval_thr, cov_mode, cov_thr, 1 if identity else 0, _ptr(out), bt, cap)
         return dict(score=int(out[0]), qStart=int(out[1]), qEnd=int(out[2]), tStart=int(out[3]), tEnd=int(out[4]),
                     identical=int(out[5]), btLen=int(out[6]), flags=int(out[7]), evalue=ev, backtrace=bt.value.decode())
 
@@ -213,7 +213,8 @@ class OracleTarget:
             raise RuntimeError('oracle prefilter path not restated: code %d' % n)
         return ids[:n].copy(), sc[:n].copy(), dg[:n].copy(), st
 
-    def prefilter_profile(self, letters, aln, sorted_score, sorted_index, kmer_thr, max_hits=300, min_diag=15, bin_size=2):
+    def prefilter_profile(self, letters, aln, sorted_score, sorted_index, kmer_thr, max_hits=300, min_diag=15, bin_size=2,
+                          identity_id=0xFFFFFFFF):
         letters = np.ascontiguousarray(letters, np.uint8)
         aln = np.ascontiguousarray(aln, np.int8)
         ssc = np.ascontiguousarray(sorted_score, np.int16)
@@ -224,7 +225,7 @@ class OracleTarget:
         dg = np.zeros(cap, np.uint16)
         st = np.zeros(4, np.uint64)
         n = self.orc.lib.or_prefilter_query_profile(self.h, _ptr(letters), _ptr(aln), _ptr(ssc), _ptr(six), len(letters),
-                                                    kmer_thr, max_hits, min_diag, bin_size, _ptr(ids), _ptr(sc), _ptr(dg),
+                                                    identity_id, kmer_thr, max_hits, min_diag, bin_size, _ptr(ids), _ptr(sc), _ptr(dg),
                                                     _ptr(st))
         if n < 0:
             raise RuntimeError('oracle prefilter path not restated: code %d' % n)

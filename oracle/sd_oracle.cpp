@@ -450,11 +450,11 @@ int64_t or_prefilter_query(void *vt, const unsigned char *q, int qL, uint32_t id
 
 // profile query (a22): letters / alignment profile / sorted k-mer generator rows as sd::mapProfile produces them
 int64_t or_prefilter_query_profile(void *vt, const unsigned char *letters, const signed char *aln,
-                                   const int16_t *sortedScore, const unsigned char *sortedIndex, int qL, int kmerThr,
-                                   uint32_t maxHits, int minDiagScore, uint32_t binSize, uint32_t *outId,
+                                   const int16_t *sortedScore, const unsigned char *sortedIndex, int qL, uint32_t identityId,
+                                   int kmerThr, uint32_t maxHits, int minDiagScore, uint32_t binSize, uint32_t *outId,
                                    int32_t *outScore, uint16_t *outDiag, uint64_t *stats) {
     ProfileQuery pq = {(const int8_t *) aln, sortedScore, sortedIndex};
-    return prefilterQueryImpl(vt, letters, qL, 0xFFFFFFFFu, kmerThr, maxHits, minDiagScore, binSize, 0, outId, outScore,
+    return prefilterQueryImpl(vt, letters, qL, identityId, kmerThr, maxHits, minDiagScore, binSize, 0, outId, outScore,
                               outDiag, stats, &pq);
 }
 
@@ -693,7 +693,8 @@ static double swAlignImpl(void *vc, const unsigned char *q, int qL, const unsign
     if (isIdentity) {
         // scoreIdentical (:1675-1710)
         short score = 0;
-        for (int pos = 0; pos < tL; pos++) score += (short) (m.sub[t[pos]][q[pos]] + cb8[pos]);
+        for (int pos = 0; pos < tL; pos++)
+            score += aln ? (short) aln[(size_t) pos * ALPH + t[pos]] : (short) (m.sub[t[pos]][q[pos]] + cb8[pos]);
         out[0] = (uint32_t) (int) score;
         out[1] = swMode == 0 ? -1 : 0;
         out[3] = swMode == 0 ? -1 : 0;
@@ -789,10 +790,10 @@ double or_sw_align(void *vc, const unsigned char *q, int qL, const unsigned char
 // profile query (ssw_align_private<PROFILE_SEQ>): letters = the profile's query letters (identity counting only),
 // aln = alignment profile int8 [qL][21]
 double or_sw_align_profile(void *vc, const unsigned char *letters, const signed char *aln, int qL, const unsigned char *t,
-                           int tL, uint64_t dbResidues, int swMode, double evalThr, int covMode, float covThr, int *out,
-                           char *backtrace, int btCap) {
-    return swAlignImpl(vc, letters, qL, t, tL, dbResidues, swMode, evalThr, covMode, covThr, 0, 0, out, backtrace, btCap,
-                       (const int8_t *) aln);
+                           int tL, uint64_t dbResidues, int swMode, double evalThr, int covMode, float covThr, int isIdentity,
+                           int *out, char *backtrace, int btCap) {
+    return swAlignImpl(vc, letters, qL, t, tL, dbResidues, swMode, evalThr, covMode, covThr, 0, isIdentity, out, backtrace,
+                       btCap, (const int8_t *) aln);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -107,7 +107,7 @@ def load():
         'sd_prefilter_batch': (C.c_int, [_vp, _vp, C.POINTER(PrefilterParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _vp]),
         'sd_prefilter_profile_batch': (C.c_int, [_vp, _vp, C.POINTER(PrefilterParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp,
-                                                 _vp, _vp, _vp]),
+                                                 _vp, _vp, _vp, _vp]),
         'sd_profileset_create': (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
         'sd_host_map_profiles': (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
         'sd_host_profile_kmer_threshold': (C.c_int, [C.c_float, C.c_int]),

@@ -334,15 +334,16 @@ def prefilter(ctx, target, par, residues, offsets, kmer_bias, diag_bias, identit
     return hits, counts, stats
 
 
-def prefilter_profile(ctx, target, par, prof, want_stats=False):
+def prefilter_profile(ctx, target, par, prof, identity_id=None, want_stats=False):
     """sd_prefilter_profile_batch for the profiles of Host.map_profiles (the target index built with kmer_thr=0)"""
     nq = len(prof['offsets']) - 1
+    ident = np.ascontiguousarray(identity_id, np.uint32) if identity_id is not None else None
     hits = np.zeros((nq, par.maxHitsPerQuery), _lib.HIT_DTYPE)
     counts = np.zeros(nq, np.uint32)
     stats = np.zeros((nq, 4), np.uint64) if want_stats else None
     _check(ctx.h, ctx.L.sd_prefilter_profile_batch(ctx.h, target.h, C.byref(par), nq, ptr(prof['letters']), ptr(prof['offsets']),
                                                    ptr(prof['sorted_score']), ptr(prof['sorted_index']), ptr(prof['aln']),
-                                                   ptr(hits), ptr(counts), ptr(stats)), 'sd_prefilter_profile_batch')
+                                                   ptr(ident), ptr(hits), ptr(counts), ptr(stats)), 'sd_prefilter_profile_batch')
     return hits, counts, stats
 
 

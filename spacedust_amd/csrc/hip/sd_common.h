@@ -108,6 +108,7 @@ struct sd_seqset {
     uint8_t *dRes = nullptr;      // residues
     int8_t *dBias = nullptr;      // SW composition bias (int8 per residue)
     int8_t *dProf = nullptr;      // profile sets only: int8 [position][21] alignment profile (replaces matrix row + bias)
+    std::vector<int8_t> hProf;        // profile sets only: host copy of the alignment profile (scoreIdentical)
     std::vector<int32_t> hProfBias;   // profile sets only: per profile |min(0, min score)| (ssw_init, StripedSmithWaterman.cpp:1276-1287)
     uint64_t *dOff = nullptr;     // offsets n+1
     std::vector<uint64_t> hOff;   // host copy of the offsets

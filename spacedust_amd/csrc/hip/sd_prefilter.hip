@@ -1904,11 +1904,14 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_param
 
 int sd_prefilter_profile_batch(sd_ctx *ctx, const sd_target *T, const sd_prefilter_params *par, uint32_t nQ,
                                const uint8_t *qLetters, const uint64_t *qOffsets, const int16_t *sortedScore,
-                               const uint8_t *sortedIndex, const int8_t *alnProfile, sd_hit *outHits, uint32_t *outCount,
-                               uint64_t *stats) {
+                               const uint8_t *sortedIndex, const int8_t *alnProfile, const uint32_t *identityId,
+                               sd_hit *outHits, uint32_t *outCount, uint64_t *stats) {
     if (!sortedScore || !sortedIndex || !alnProfile) return SD_EINVAL;
     ProfileQueries pq = {sortedScore, sortedIndex, alnProfile};
-    std::vector<uint32_t> noIdentity(nQ, 0xFFFFFFFFu);   // a profile is never its own target
-    return prefilterBatchImpl(ctx, T, par, nQ, qLetters, qOffsets, nullptr, nullptr, noIdentity.data(), outHits, outCount, stats,
-                              &pq);
+    std::vector<uint32_t> noIdentity;
+    if (!identityId) {   // NULL: no query is in the target DB
+        noIdentity.assign(nQ, 0xFFFFFFFFu);
+        identityId = noIdentity.data();
+    }
+    return prefilterBatchImpl(ctx, T, par, nQ, qLetters, qOffsets, nullptr, nullptr, identityId, outHits, outCount, stats, &pq);
 }

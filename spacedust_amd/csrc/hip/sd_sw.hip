@@ -1392,6 +1392,7 @@ int sd_profileset_create(sd_ctx *ctx, const uint8_t *queryLetters, const uint64_
         return sdFail(ctx, SD_ENOMEM, "sd_profileset_create: device allocation of %llu bytes failed", (unsigned long long) bytes);
     }
     SD_HIP(ctx, hipMemcpy(s->dProf, alnProfile, bytes, hipMemcpyHostToDevice));
+    s->hProf.assign(alnProfile, alnProfile + bytes);
     s->hProfBias.assign(n, 0);
     for (uint32_t i = 0; i < n; i++) {
         int m = 0;   // min over the 20 amino-acid columns (matSize = L * PROFILE_AA_SIZE, :1277-1279)
@@ -1483,9 +1484,6 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     for (uint32_t i = 0; i < nPairs; i++)
         if (pairQ[i] >= queries->n || pairT[i] >= targets->n) return sdFail(ctx, SD_EINVAL, "pair %u out of range", i);
     if (targets->dProf) return sdFail(ctx, SD_EUNSUPPORTED, "profile targets are not implemented (profile queries are)");
-    if (queries->dProf && isIdentity)
-        for (uint32_t i = 0; i < nPairs; i++)
-            if (isIdentity[i]) return sdFail(ctx, SD_EINVAL, "identity pairs (scoreIdentical) do not exist for profile queries");
     std::unique_ptr<HostScope> hs(new HostScope(ctx, "align.upload"));
     DevGateParams gp;
     gp.go = go; gp.ge = ge; gp.matMin = matMin; gp.swMode = par->swMode; gp.covMode = par->covMode; gp.covThr = par->covThr;
@@ -1764,7 +1762,12 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
             const int8_t *cb = queries->hBias.data() + queries->hOff[pairQ[i]];
             const uint8_t *t = targets->hRes.data() + targets->hOff[pairT[i]];
             short score = 0;
-            for (int p = 0; p < L; p++) score += (short) (par->matrix[t[p] * 21 + q[p]] + cb[p]);
+            if (queries->dProf) {   // profile_word_linear[target letter][position] (:1700-1703, :1293-1298)
+                const int8_t *pr = queries->hProf.data() + queries->hOff[pairQ[i]] * 21;
+                for (int p = 0; p < L; p++) score += (short) pr[(size_t) p * 21 + t[p]];
+            } else {
+                for (int p = 0; p < L; p++) score += (short) (par->matrix[t[p] * 21 + q[p]] + cb[p]);
+            }
             sd_sw_result &r = out[x];
             r.score = (int32_t) (uint32_t) (int) score;
             r.qStart = par->swMode == 0 ? -1 : 0;

@@ -30,6 +30,15 @@ class SetDB:
         self.set_size = np.bincount(self.set_id, minlength=self.n_sets).astype(np.uint32)
         self.names = names
         self.sources = sources
+        self.profile = None   # profile DB side (iterations >= 1 of --num-iterations): see with_profiles
+
+    def with_profiles(self, prof):
+        """attach Host.map_profiles output (letters / aln / sorted rows, one profile per protein, same order): the
+        set then searches as a DBTYPE_HMM_PROFILE query DB; `residues` become the profiles' query letters"""
+        assert len(prof['offsets']) == self.n + 1
+        q = SetDB(prof['letters'], prof['offsets'], self.set_id, self.pos_in_set, self.strand, self.n_sets, self.names, self.sources)
+        q.profile = prof
+        return q
 
     @staticmethod
     def from_proteomes(ps, prefix='SYN'):
@@ -59,7 +68,7 @@ class ClusterSearch:
 
     def __init__(self, ctx, host, target_db, sensitivity=5.7, max_seqs=300, eval_thr=10.0, cov_mode=2, cov_thr=0.8,
                  aln_len_thr=30, max_gene_gap=3, cluster_size=2, alpha=1.0, p_clu_thr=0.01, p_mh_thr=0.01,
-                 filter_self_match=True, bin_size=None, verbose=False, align_ctx=None, k=None):
+                 filter_self_match=True, bin_size=None, verbose=False, align_ctx=None, k=None, profile_queries=False):
         """ctx runs the prefilter (and clusterhits); align_ctx -- a second context (own HIP stream and workspace)
         on the same device, created here if not given -- runs the alignments, so that the prefilter of the next
         chunk (HBM random-access bound) and the Smith-Waterman of the current one (integer-VALU bound) share the
@@ -69,7 +78,10 @@ class ClusterSearch:
         self.verbose = verbose
         # -k 0 semantics (IndexTable::computeKmerSize, IndexTable.h:439-441): 6 below 3.35e9 target residues, 7 from there on
         self.k = int(k) if k else host.auto_kmer_size(int(target_db.offsets[-1]))
-        self.kmer_thr = host.kmer_threshold(sensitivity, self.k)
+        # profile searches: own threshold table, and the target index keeps every non-X k-mer (Prefiltering.cpp:525-527,1019-1043)
+        self.profile_queries = bool(profile_queries)
+        self.kmer_thr = (host.profile_kmer_threshold(sensitivity, self.k) if self.profile_queries
+                         else host.kmer_threshold(sensitivity, self.k))
         self.max_seqs = max_seqs
         self.eval_thr, self.cov_mode, self.cov_thr, self.aln_len_thr = eval_thr, cov_mode, cov_thr, aln_len_thr
         self.ch = dict(max_gene_gap=max_gene_gap, cluster_size=cluster_size, alpha=alpha, p_clu_thr=p_clu_thr,
@@ -78,7 +90,7 @@ class ClusterSearch:
         self.timing = {}
         t0 = time.time()
         self.t_sw_bias, _, _ = host.comp_bias(target_db.residues, target_db.offsets, self.k)
-        self.index = host.build_index(target_db.residues, target_db.offsets, self.k, self.kmer_thr)
+        self.index = host.build_index(target_db.residues, target_db.offsets, self.k, 0 if self.profile_queries else self.kmer_thr)
         self.timing['index_build_s'] = time.time() - t0
         t0 = time.time()
         self.target = api.Target(ctx, host, self.index)
@@ -137,6 +149,8 @@ class ClusterSearch:
             res = Q.residues[r0:r1]
             off = (Q.offsets[c0:c1 + 1] - Q.offsets[c0]).astype(np.uint64)
             t0 = time.time()
+            if Q.profile is not None:   # no composition bias for profile queries (QueryMatcher.cpp:93-99, ssw_init :1229-1240)
+                return res, off, None, None, None, 0.0
             sw_b, dg_b, km_b = self.host.comp_bias(res, off, self.k)
             return res, off, sw_b, dg_b, km_b, time.time() - t0
 
@@ -146,7 +160,14 @@ class ClusterSearch:
             res, off, sw_b, dg_b, km_b, t['bias'] = bias_future.result()
             ident = (np.arange(c0, c1, dtype=np.uint32) if same_db else np.full(c1 - c0, 0xFFFFFFFF, np.uint32))
             t0 = time.time()
-            hits, cnt, st = api.prefilter(self.ctx, self.target, self.pf_par, res, off, km_b, dg_b, ident, want_stats=True)
+            if Q.profile is not None:
+                r0 = int(Q.offsets[c0])
+                r1 = int(Q.offsets[c1])
+                pslice = dict(letters=res, offsets=off, aln=Q.profile['aln'][r0:r1], sorted_score=Q.profile['sorted_score'][r0:r1],
+                              sorted_index=Q.profile['sorted_index'][r0:r1])
+                hits, cnt, st = api.prefilter_profile(self.ctx, self.target, self.pf_par, pslice, identity_id=ident, want_stats=True)
+            else:
+                hits, cnt, st = api.prefilter(self.ctx, self.target, self.pf_par, res, off, km_b, dg_b, ident, want_stats=True)
             t['prefilter'] = time.time() - t0
             # pair list in prefilter order (Alignment.cpp:346-379); Alignment::run's coverage pre-check (:370-373) is
             # the same test the prefilter applied
@@ -252,7 +273,11 @@ class ClusterSearch:
             if n_pairs > 0:
                 pair_q_local, pair_t = d['pair_q_local'], d['pair_t']
                 t0 = time.time()
-                qset = self.ctx_al.seqset(d['res'], d['off'], d['sw_b'])
+                if Q.profile is not None:
+                    r0 = int(Q.offsets[c0])
+                    qset = self.ctx_al.profileset(d['res'], d['off'], Q.profile['aln'][r0:r0 + len(d['res'])])
+                else:
+                    qset = self.ctx_al.seqset(d['res'], d['off'], d['sw_b'])
                 tm['seqset'] = tm.get('seqset', 0.0) + time.time() - t0
                 t0 = time.time()
                 identity = (pair_q_local + np.uint32(c0) == pair_t) if same_db else np.zeros(n_pairs, bool)

@@ -30,7 +30,8 @@ def test_profile_prefilter_matches_reference(gpu, host):
     tgt = api.Target(gpu, host, idx)
     for thr in (99, 80):
         par = api.prefilter_params(host, idx.n, kmer_thr=thr, max_hits=300, cov_thr=0.0, bin_size=2, k=6)
-        hits, cnt, st = api.prefilter_profile(gpu, tgt, par, prof, want_stats=True)
+        ident = np.array([4 * q if q % 2 == 0 else 0xFFFFFFFF for q in range(len(prof['offsets']) - 1)], np.uint32)
+        hits, cnt, st = api.prefilter_profile(gpu, tgt, par, prof, identity_id=ident, want_stats=True)
         rows = g['pf_rows_%d' % thr]
         for q in range(len(cnt)):
             exp = rows[rows[:, 0] == q]
@@ -70,7 +71,8 @@ def test_profile_alignments_match_reference(gpu, host):
     ts = gpu.seqset(res, off, None)
     par = gpu.sw_params(mat, db)
     pq, pt = g['sw_pairs'][:, 0].astype(np.uint32), g['sw_pairs'][:, 1].astype(np.uint32)
-    out, pool = gpu.sw_align(par, qs, ts, pq, pt)
+    out, pool = gpu.sw_align(par, qs, ts, pq, pt, identity=g['sw_pairs'][:, 2].astype(np.uint8))
+    assert g['sw_pairs'][:, 2].sum() >= 5   # scoreIdentical pairs (the profile's own sequence in a same-DB search)
     bts = g['sw_bt'].tobytes().decode().split('\n')
     n_bt = 0
     for x in range(len(pq)):
@@ -162,3 +164,57 @@ def test_profile_prefilter_large_kmer_lists(gpu, host, oracle):
         assert m == len(ids) and (hits[q, :m]['seqId'] == ids).all() and (hits[q, :m]['score'] == sc).all(), q
         assert (hits[q, :m]['diagonal'] == dg).all(), q
         assert tuple(int(x) for x in st[q]) == tuple(int(x) for x in ost), (q, st[q], ost)
+
+
+def test_pipeline_with_profile_queries(gpu, host, oracle, small_proteomes):
+    """one search iteration with a profile query DB through the pipeline (prefilter_profile -> profile SW -> aggregation
+    -> clusterhits): prefilter hit count and accepted alignment count against the oracle run stage by stage"""
+    from spacedust_amd.pipeline import SetDB, ClusterSearch
+    ps = small_proteomes
+    rng = np.random.default_rng(17)
+    mat, _, _ = host.matrix(0)
+    m = np.array([mat[i] for i in range(441)], np.int32).reshape(21, 21)
+    recs, boff = [], [0]
+    for q in range(ps.n):
+        s = ps.residues[int(ps.offsets[q]):int(ps.offsets[q + 1])]
+        rec = np.zeros((len(s), 25), np.uint8)
+        for i, a in enumerate(s):
+            row = m[min(int(a), 19), :20] * 3 + rng.integers(-4, 5, 20)
+            rec[i, :20] = np.clip(row, -128, 127).astype(np.int8).view(np.uint8)
+            rec[i, 20] = a
+            rec[i, 21] = int(np.argmax(row))
+        recs.append(rec.tobytes())
+        boff.append(boff[-1] + len(recs[-1]))
+    prof = host.map_profiles(b''.join(recs), np.array(boff, np.uint64))
+    db = SetDB.from_proteomes(ps)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, profile_queries=True)
+    assert cs.kmer_thr == 99
+    out = cs.search(db.with_profiles(prof), same_db=True, chunk_queries=100)
+    # the same, stage by stage, on the oracle
+    ot = oracle.target(ps.residues, ps.offsets, k=6, kmer_thr=0)
+    po = prof['offsets']
+    dbres = int(ps.offsets[-1])
+    n_hits = n_acc = 0
+    for q in range(ps.n):
+        a, b = int(po[q]), int(po[q + 1])
+        ids, sc, dg, _ = ot.prefilter_profile(prof['letters'][a:b], prof['aln'][a:b], prof['sorted_score'][a:b],
+                                              prof['sorted_index'][a:b], 99, max_hits=300, identity_id=q)
+        assert len(ids) >= 1 and ids[0] == q
+        # Util::canBeCovered, COV_MODE_QUERY (Prefiltering.cpp:856-863): float32 ratio of the lengths
+        tl = (ps.offsets[ids.astype(np.int64) + 1] - ps.offsets[ids.astype(np.int64)]).astype(np.float32)
+        ids = ids[(tl / np.float32(b - a)) >= np.float32(0.8)]
+        n_hits += len(ids)
+        for t in ids:
+            ts = ps.residues[int(ps.offsets[t]):int(ps.offsets[t + 1])]
+            r = oracle.sw_align_profile(prof['letters'][a:b], prof['aln'][a:b], ts, dbres, identity=bool(t == q))
+            if t == q:
+                n_acc += 1
+                continue
+            if r['btLen'] <= 0 or r['qStart'] < 0:
+                continue
+            qcov = (r['qEnd'] - r['qStart'] + 1) / float(b - a)
+            if r['evalue'] <= 10.0 and qcov >= 0.8 and r['btLen'] >= 30:
+                n_acc += 1
+    assert cs.stats['prefilter_hits'] == n_hits, (cs.stats['prefilter_hits'], n_hits)
+    assert out['accepted'] == n_acc, (out['accepted'], n_acc)
+    assert n_acc > ps.n

@@ -213,15 +213,15 @@ def test_profile_queries(oracle):
         assert len(rows) > 3 * len(profs)
         for qi, (letters, cons, aln, ssc, six) in enumerate(profs):
             exp = rows[rows[:, 0] == qi]
-            ids, sc, dg, _ = tgt.prefilter_profile(letters, aln, ssc, six, thr)
+            ids, sc, dg, _ = tgt.prefilter_profile(letters, aln, ssc, six, thr, identity_id=4 * qi if qi % 2 == 0 else 0xFFFFFFFF)
             assert len(ids) == len(exp) and (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all(), (thr, qi)
             assert (dg.astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (thr, qi)
     bts = g['sw_bt'].tobytes().decode().split('\n')
     db_res = int(g['off'][-1])
     n_bt = 0
-    for x, (qi, t) in enumerate(g['sw_pairs']):
+    for x, (qi, t, ident) in enumerate(g['sw_pairs']):
         letters, cons, aln, ssc, six = profs[qi]
-        r = oracle.sw_align_profile(letters, aln, nums[t], db_res)
+        r = oracle.sw_align_profile(letters, aln, nums[t], db_res, identity=bool(ident))
         e = g['sw_res'][x]
         assert (r['score'], r['qEnd'], r['tEnd']) == (e[0], e[2], e[4]), x
         assert r['evalue'] == g['evalue'][x], x

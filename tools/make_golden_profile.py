@@ -49,7 +49,9 @@ def main():
     ref = Ref(6)
     m, _, _ = ref.matrix(0)
     base = [''.join(rng.choice(list(AA), int(rng.integers(90, 420)))) for _ in range(36)]
-    seqs = [mutate(b, rng) for b in base for _ in range(4)]
+    # sequence 4*b is the base itself (the profile's own sequence in a same-DB iterative search: identity id of the
+    # prefilter, scoreIdentical pair of the aligner), 4*b+1..3 are mutated descendants
+    seqs = [s for b in base for s in [b] + [mutate(b, rng) for _ in range(3)]]
     lens = np.array([len(s) for s in seqs])
     off = np.zeros(len(seqs) + 1, np.uint64)
     off[1:] = np.cumsum(lens)
@@ -74,7 +76,7 @@ def main():
         rpf = rix.prefilter_profile(int(max(lens.max(), 450)) + 10, thr, max_hits=300)
         rows = []
         for qi, pd in enumerate(profiles):
-            ids, sc, dg, _ = rpf.query(pd)
+            ids, sc, dg, _ = rpf.query(pd, identity_id=4 * qi if qi % 2 == 0 else 0xFFFFFFFF)   # every other query is "in the DB"
             rows += [(qi, int(t), int(s), int(d)) for t, s, d in zip(ids, sc, dg)]
         out['pf_rows_%d' % thr] = np.array(rows, np.int64)
         print('thr', thr, 'rows', len(rows))
@@ -83,10 +85,11 @@ def main():
     pairs, res, bts = [], [], []
     for qi, pd in enumerate(profiles):
         sw.set_query_profile(pd)
-        for t in list(range(4 * qi, 4 * qi + 4)) + [int(rng.integers(len(seqs))) for _ in range(2)]:
-            r = sw.align(seqs[t])
+        for t, ident in [(4 * qi, qi % 2 == 0)] + [(x, False) for x in range(4 * qi + 1, 4 * qi + 4)] + \
+                [(int(rng.integers(len(seqs))), False) for _ in range(2)]:
+            r = sw.align(seqs[t], identity=ident)
             has_bt = r['btLen'] > 0
-            pairs.append((qi, t))
+            pairs.append((qi, t, int(ident)))
             res.append((r['score'], r['qStart'], r['qEnd'], r['tStart'], r['tEnd'], r['identical'] if has_bt else 0, r['btLen']))
             bts.append(r['backtrace'])
             out.setdefault('evalue', []).append(r['evalue'])
