@@ -1361,13 +1361,117 @@ template <typename T>
 struct WidenOp {
     __host__ __device__ __forceinline__ uint64_t operator()(const T &v) const { return (uint64_t) v; }
 };
+// Exclusive prefix sums of small unsigned counts into 64-bit offsets, reduce-then-scan in three launches (tile sums,
+// one-block scan of the tile sums, per-tile scan).  The library's decoupled look-back scan spins on predecessor tiles,
+// and with a second stream's kernels holding most CUs that spinning made the 5*10^8-element k-mer scan the slowest
+// "kernel" of the prefilter (33 ms); this form has no inter-block waiting and runs at HBM speed.
+constexpr int SCAN_ITEMS = 16, SCAN_BLOCK = 256, SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
+
+template <typename T>
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_tile_sums_kernel(const T *__restrict__ in, uint64_t n, uint64_t *__restrict__ tileSum) {
+    __shared__ uint64_t part[SCAN_BLOCK / 64];
+    const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
+    uint64_t sum = 0;
+    if (base + SCAN_ITEMS <= n) {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) sum += (uint64_t) in[base + j];
+    } else {
+        for (int j = 0; j < SCAN_ITEMS; j++)
+            if (base + j < n) sum += (uint64_t) in[base + j];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; w++) t += part[w];
+        tileSum[blockIdx.x] = t;
+    }
+}
+
+// in place: tileSum[i] <- sum of tileSum[0..i); one workgroup, eight consecutive tiles per thread and round
+__global__ void __launch_bounds__(1024)
+scan_tile_bases_kernel(uint64_t *__restrict__ tileSum, uint32_t nTiles) {
+    constexpr int PER = 8;
+    __shared__ uint64_t part[16];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t c0 = 0; c0 < nTiles; c0 += 1024 * PER) {
+        const uint32_t i0 = c0 + threadIdx.x * PER;
+        uint64_t v[PER];
+        uint64_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            v[j] = (i0 + j < nTiles) ? tileSum[i0 + j] : 0;
+            sum += v[j];
+        }
+        uint64_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) part[wave] = incl;
+        __syncthreads();
+        uint64_t run = carry + incl - sum;
+        for (int w = 0; w < wave; w++) run += part[w];
+        const uint64_t endOfThread = run + sum;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            if (i0 + j < nTiles) tileSum[i0 + j] = run;
+            run += v[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = endOfThread;
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_apply_kernel(const T *__restrict__ in, uint64_t n, const uint64_t *__restrict__ tileBase, uint64_t *__restrict__ out) {
+    __shared__ uint64_t part[SCAN_BLOCK / 64];
+    const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        v[j] = (base + j < n) ? (uint64_t) in[base + j] : 0;
+        sum += v[j];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    uint64_t run = tileBase[blockIdx.x] + incl - sum;
+    for (int w = 0; w < wave; w++) run += part[w];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        if (base + j < n) out[base + j] = run;
+        run += v[j];
+    }
+}
+
 template <typename T>
 int exclusiveScanWiden(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, DevBuf<uint8_t> &tmp) {
-    hipcub::TransformInputIterator<uint64_t, WidenOp<T>, const T *> it(in, WidenOp<T>());
-    size_t bytes = 0;
-    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, (int) n, ctx->stream));
-    if (tmp.n < bytes) SD_HIP(ctx, tmp.alloc(bytes + 256));
-    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, it, out, (int) n, ctx->stream));
+    if (n == 0) return SD_OK;
+    const uint64_t nTiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (tmp.n < nTiles * sizeof(uint64_t)) SD_HIP(ctx, tmp.alloc(nTiles * sizeof(uint64_t) + 256));
+    uint64_t *tileSum = (uint64_t *) tmp.p;
+    hipLaunchKernelGGL(scan_tile_sums_kernel<T>, dim3((unsigned) nTiles), dim3(SCAN_BLOCK), 0, ctx->stream, in, n, tileSum);
+    hipLaunchKernelGGL(scan_tile_bases_kernel, dim3(1), dim3(1024), 0, ctx->stream, tileSum, (uint32_t) nTiles);
+    hipLaunchKernelGGL(scan_apply_kernel<T>, dim3((unsigned) nTiles), dim3(SCAN_BLOCK), 0, ctx->stream, in, n,
+                       (const uint64_t *) tileSum, out);
+    SD_HIP(ctx, hipGetLastError());
     return SD_OK;
 }
 
