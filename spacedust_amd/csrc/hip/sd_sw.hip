@@ -881,19 +881,28 @@ k_gate_rev(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ
     keys[i] = scoreKey(tk.n, tk.tL, !usePk ? SCORE_INT32 : (word[i] ? SCORE_PK_WIDE : SCORE_PK));
 }
 
-// traceback task classes: 0-2 register-band kernel (LDS capacity 320x640 / 512x1024 / 1024x2048 rows x columns),
-// 3-5 LDS-band kernel by band width (<=127, <=511, <=2047)
-static const int TB_NARROW_Q[3] = {320, 512, 1024}, TB_NARROW_T[3] = {640, 1024, 2048};
-__device__ __forceinline__ bool tbNarrow(int band, int qLen, int tLen) { return band * 2 + 3 <= 32 && qLen <= 1024 && tLen <= 2048; }
+// traceback task classes: N_TB_NARROW register-band classes by query rows, then three LDS-band classes by band width
+// (<=127, <=511, <=2047)
+// The register-band kernel keeps a task's direction codes (16 B per row), query / bias / target slices in LDS, and
+// it is latency bound, so its throughput is its occupancy: classes by query rows keep the LDS request close to what
+// the tasks need (a band <= 14 means |tLen - qLen| <= 13, so qCap + 16 target columns always suffice).
+constexpr int N_TB_NARROW = 9;
+__constant__ int c_tbNarrowQ[N_TB_NARROW] = {128, 192, 256, 320, 384, 512, 640, 768, 1024};
+static const int TB_NARROW_Q[N_TB_NARROW] = {128, 192, 256, 320, 384, 512, 640, 768, 1024};
+__device__ __forceinline__ bool tbNarrow(int band, int qLen, int tLen) { return band * 2 + 3 <= 32 && qLen <= 1024 && tLen <= 1024 + 13; }
 __device__ __forceinline__ uint32_t tbKey(int band, int qLen, int tLen) {
     const int w = band * 2 + 3;
     int ci;
-    if (tbNarrow(band, qLen, tLen)) ci = (qLen <= 320 && tLen <= 640) ? 0 : ((qLen <= 512 && tLen <= 1024) ? 1 : 2);
-    else ci = w <= 127 ? 3 : (w <= 511 ? 4 : 5);
+    if (tbNarrow(band, qLen, tLen)) {
+        ci = 0;
+        while (qLen > c_tbNarrowQ[ci]) ci++;
+    } else {
+        ci = N_TB_NARROW + (w <= 127 ? 0 : (w <= 511 ? 1 : 2));
+    }
     const unsigned long long work = (unsigned long long) ((2 * band + 1 + 31) / 32) * (unsigned long long) qLen;
     return (uint32_t) ci * 4096u + (uint32_t) (4095 - (int) min(work >> 3, 4095ull));
 }
-constexpr uint32_t N_TB_CLASSES = 6;
+constexpr uint32_t N_TB_CLASSES = N_TB_NARROW + 3;
 constexpr uint32_t TBKEY_INVALID = N_TB_CLASSES * 4096u;
 // global direction scratch (LDS-band kernel only), sized for the widest band of the task's class because the
 // kernel keeps doubling the band inside its class
@@ -1597,7 +1606,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         rc = devExclusiveScan(ctx, dDirBytes, dDirOff, N + 1);
         if (rc != SD_OK) return rc;
         hipLaunchKernelGGL(k_tb_offsets, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dDirOff, dBtOff, dTb);
-        rc = devSortPairs(ctx, dKeys, dKeysS, dVals, dOrder, nPairs, 15);
+        rc = devSortPairs(ctx, dKeys, dKeysS, dVals, dOrder, nPairs, 16);
         if (rc != SD_OK) return rc;
         hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysS, nPairs, 4096u, dBounds, (int) N_TB_CLASSES + 1);
         uint32_t hb[N_TB_CLASSES + 1];
@@ -1606,18 +1615,23 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         SD_HIP(ctx, hipMemcpyAsync(&dirTotal, dDirOff + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, sdStreamSync(ctx));
         if (hb[N_TB_CLASSES] == 0) break;   // nothing left
-        if (getenv("SD_DEBUG_TB"))
-            fprintf(stderr, "[tb] round %d: narrow %u %u %u lds %u %u %u dir %.1f MB\n", round, hb[1] - hb[0], hb[2] - hb[1], hb[3] - hb[2],
-                    hb[4] - hb[3], hb[5] - hb[4], hb[6] - hb[5], dirTotal / 1e6);
+        if (getenv("SD_DEBUG_TB")) {
+            fprintf(stderr, "[tb] round %d: narrow", round);
+            for (int ci = 0; ci < N_TB_NARROW; ci++) fprintf(stderr, " %u", hb[ci + 1] - hb[ci]);
+            fprintf(stderr, " lds %u %u %u dir %.1f MB\n", hb[N_TB_NARROW + 1] - hb[N_TB_NARROW], hb[N_TB_NARROW + 2] - hb[N_TB_NARROW + 1],
+                    hb[N_TB_NARROW + 3] - hb[N_TB_NARROW + 2], dirTotal / 1e6);
+        }
         if (dirTotal > SCRATCH_BUDGET) return sdFail(ctx, SD_ENOMEM, "traceback direction scratch of %llu bytes exceeds the budget; use smaller batches", (unsigned long long) dirTotal);
         int8_t *dDir = nullptr;
         SD_HIP(ctx, wsGet(ctx, "tb.dir", dirTotal + 64, &dDir));
-        for (int ci = 0; ci < 3; ci++) {
+        for (int ci = 0; ci < N_TB_NARROW; ci++) {
             const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
             if (cnt == 0) continue;
-            static const char *const tbNames[3] = {"sw_traceback.narrow320", "sw_traceback.narrow512", "sw_traceback.narrow1024"};
+            static const char *const tbNames[N_TB_NARROW] = {"sw_traceback.narrow128", "sw_traceback.narrow192", "sw_traceback.narrow256",
+                                                             "sw_traceback.narrow320", "sw_traceback.narrow384", "sw_traceback.narrow512",
+                                                             "sw_traceback.narrow640", "sw_traceback.narrow768", "sw_traceback.narrow1024"};
             ProfScope ps(ctx, tbNames[ci]);
-            const int qCap = TB_NARROW_Q[ci], tCap = TB_NARROW_T[ci];
+            const int qCap = TB_NARROW_Q[ci], tCap = qCap + 16;
             const size_t ldsBytes = 2 * ((size_t) 16 * qCap + 2 * (size_t) qCap + tCap);
             if (queries->dProf)
                 hipLaunchKernelGGL(sw_traceback_narrow_kernel<true>, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt,
@@ -1630,7 +1644,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         }
         static const int ldsClass[3] = {128, 512, 2048};
         for (int ci = 0; ci < 3; ci++) {
-            const uint32_t begin = hb[3 + ci], cnt = hb[4 + ci] - hb[3 + ci];
+            const uint32_t begin = hb[N_TB_NARROW + ci], cnt = hb[N_TB_NARROW + 1 + ci] - hb[N_TB_NARROW + ci];
             if (cnt == 0) continue;
             ProfScope ps(ctx, "sw_traceback.lds");
             const int ldsStride = ldsClass[ci] + 1;
