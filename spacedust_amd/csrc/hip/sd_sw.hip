@@ -1600,7 +1600,13 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     SD_HIP(ctx, sdStreamSync(ctx));
     char *dBt = nullptr;
     SD_HIP(ctx, wsGet(ctx, "tb.bt", btScratch + 64, &dBt));
-    const uint64_t SCRATCH_BUDGET = 16ull << 30;
+    // direction scratch of the LDS-band kernel (1 B per band cell, sized for the widest band of the task's class): a
+    // quarter of the device memory at most (288 GB HBM: 72 GB), the rest belongs to the index and the prefilter workspace
+    uint64_t SCRATCH_BUDGET = 16ull << 30;
+    {
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) SCRATCH_BUDGET = std::max<uint64_t>(SCRATCH_BUDGET, totalB / 4);
+    }
     for (int round = 0; round < 24; round++) {
         SD_HIP(ctx, hipMemsetAsync(dDirBytes + N, 0, sizeof(uint64_t), ctx->stream));
         rc = devExclusiveScan(ctx, dDirBytes, dDirOff, N + 1);
@@ -1661,6 +1667,23 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         SD_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_tb_collect, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dVals, dTb, dTbRes, dDirBytes, dBtLen,
                            dRes, dErr, 2047);
+    }
+    if (getenv("SD_DEBUG_TB")) {   // band statistics of the finished tasks
+        std::vector<TbTask> hT(nPairs);
+        std::vector<uint64_t> hL(nPairs);
+        SD_HIP(ctx, hipMemcpy(hT.data(), dTb, (size_t) nPairs * sizeof(TbTask), hipMemcpyDeviceToHost));
+        SD_HIP(ctx, hipMemcpy(hL.data(), dBtLen, (size_t) nPairs * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        uint64_t nDone = 0, init6 = 0, init6final6 = 0, init6final14 = 0, final14 = 0;
+        for (uint32_t i = 0; i < nPairs; i++) {
+            if (hL[i] == 0) continue;
+            nDone++;
+            const int ib = abs(hT[i].tLen - hT[i].qLen) + 1, fb = hT[i].band;
+            if (ib <= 6) { init6++; if (fb <= 6) init6final6++; else if (fb <= 14) init6final14++; }
+            if (fb <= 14) final14++;
+        }
+        fprintf(stderr, "[tb] done %llu: final band<=14 %llu; initial<=6 %llu of which final<=6 %llu, final 7..14 %llu\n",
+                (unsigned long long) nDone, (unsigned long long) final14, (unsigned long long) init6, (unsigned long long) init6final6,
+                (unsigned long long) init6final14);
     }
     // ---- dense backtrace pool + results back to the host
     hs.reset(new HostScope(ctx, "align.download"));
