@@ -812,6 +812,104 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
     }
 }
 
+// ---- coarse split for very hit-rich queries (large target sets: ~1.5*10^6 index hits per query at 3*10^6 targets).
+// The per-query partition above has 2^11 bucket slots; beyond ~5*10^5 hits its buckets outgrow the LDS sort and one
+// workgroup per query is too little parallelism.  So the query's segment is first split into C = 2^cBits target
+// ranges by the top target bits -- many workgroups per query (segments of CP_SEG hits): count, offsets, scatter --
+// and every (query, range) then goes through the partition / bucket machinery as a "virtual query" whose keys have
+// cBits fewer target bits.  Order inside a range is not kept (the bucket sort restores emission order from the
+// stream position in the value); (query, range, bucket) order is (query, target) order, as before.
+constexpr uint32_t CP_SEG = 16384;
+constexpr int CP_MAX_BITS = 6;
+
+__device__ __forceinline__ uint32_t cpQueryOfSeg(uint32_t seg, uint32_t nQ, const uint32_t *__restrict__ segBase) {
+    uint32_t lo = 0, hi = nQ;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (segBase[mid] <= seg) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256)
+coarse_count_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const uint32_t *__restrict__ segBase, int tBits, int cBits,
+                    const uint32_t *__restrict__ inKey, uint32_t *__restrict__ segCount /* [segment][C] */) {
+    __shared__ uint32_t hist[1 << CP_MAX_BITS];
+    const uint32_t seg = blockIdx.x;
+    const uint32_t q = cpQueryOfSeg(seg, nQ, segBase);
+    const uint64_t s = qHitBase[q] + (uint64_t) (seg - segBase[q]) * CP_SEG;
+    const uint64_t e = min(qHitBase[q + 1], s + CP_SEG);
+    const int C = 1 << cBits;
+    if (threadIdx.x < C) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tMask = (1u << tBits) - 1;
+    const int shift = tBits - cBits;
+    for (uint64_t i = s + threadIdx.x; i < e; i += 256) atomicAdd(&hist[(inKey[i] & tMask) >> shift], 1u);
+    __syncthreads();
+    if (threadIdx.x < C) segCount[(size_t) seg * C + threadIdx.x] = hist[threadIdx.x];
+}
+
+// per query: counts [segment][range] -> start of that segment's share inside the query's hit segment, range-major;
+// vqHitBase[q*C + c] = start of range c (absolute)
+__global__ void __launch_bounds__(256)
+coarse_offsets_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const uint32_t *__restrict__ segBase, int cBits,
+                      uint32_t *__restrict__ segCount, uint64_t *__restrict__ vqHitBase) {
+    __shared__ uint32_t part[5];
+    __shared__ uint32_t carry;
+    const uint32_t q = blockIdx.x;
+    const int C = 1 << cBits;
+    const uint32_t s0 = segBase[q], nSeg = segBase[q + 1] - s0;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int c = 0; c < C; c++) {
+        if (t == 0) vqHitBase[(size_t) q * C + c] = qHitBase[q] + carry;
+        for (uint32_t x0 = 0; x0 < nSeg; x0 += 256) {
+            const uint32_t x = x0 + t;
+            const uint32_t v = x < nSeg ? segCount[(size_t) (s0 + x) * C + c] : 0;
+            uint32_t incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, 64);
+                if ((t & 63) >= off) incl += o;
+            }
+            if ((t & 63) == 63) part[t >> 6] = incl;
+            __syncthreads();
+            uint32_t base = carry;
+            for (int w = 0; w < (t >> 6); w++) base += part[w];
+            if (x < nSeg) segCount[(size_t) (s0 + x) * C + c] = base + incl - v;
+            __syncthreads();
+            if (t == 255) carry = base + incl;
+            __syncthreads();
+        }
+    }
+    if (q == nQ - 1 && t == 0) vqHitBase[(size_t) nQ * C] = qHitBase[nQ];
+}
+
+__global__ void __launch_bounds__(256)
+coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const uint32_t *__restrict__ segBase, int tBits, int cBits,
+                      const uint32_t *__restrict__ segOffset, const uint32_t *__restrict__ inKey,
+                      const uint32_t *__restrict__ inVal, uint32_t *__restrict__ outKey, uint32_t *__restrict__ outVal) {
+    __shared__ uint32_t cursor[1 << CP_MAX_BITS];
+    const uint32_t seg = blockIdx.x;
+    const uint32_t q = cpQueryOfSeg(seg, nQ, segBase);
+    const uint64_t qs = qHitBase[q];
+    const uint64_t s = qs + (uint64_t) (seg - segBase[q]) * CP_SEG;
+    const uint64_t e = min(qHitBase[q + 1], s + CP_SEG);
+    const int C = 1 << cBits;
+    if (threadIdx.x < C) cursor[threadIdx.x] = segOffset[(size_t) seg * C + threadIdx.x];
+    __syncthreads();
+    const uint32_t tMask = (1u << tBits) - 1;
+    const int shift = tBits - cBits;
+    for (uint64_t i = s + threadIdx.x; i < e; i += 256) {
+        const uint32_t k = inKey[i];
+        const uint32_t p = atomicAdd(&cursor[(k & tMask) >> shift], 1u);
+        outKey[qs + p] = k;
+        outVal[qs + p] = inVal[i];
+    }
+}
+
 // workgroup w -> (query, bin): bins of a query are contiguous, binBase[q] = sum of bins of the queries before
 __device__ __forceinline__ bool pfSlotOf(uint32_t w, uint32_t nQ, const uint64_t *__restrict__ binBase, uint32_t &q, uint32_t &b) {
     if (w >= binBase[nQ]) return false;
@@ -836,7 +934,7 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
                     const uint2 *__restrict__ inKV, uint32_t *__restrict__ outKey,
                     uint32_t *__restrict__ outVal, uint32_t *__restrict__ bktEmit, int *__restrict__ flag,
                     const uint32_t *__restrict__ slotList, uint32_t *__restrict__ bigList, uint32_t *__restrict__ bigCount,
-                    uint32_t bigCap, const uint32_t *__restrict__ qSplit) {
+                    uint32_t bigCap, const uint32_t *__restrict__ qSplit, int vqShift /* query = virtual query >> vqShift */) {
     __shared__ uint32_t eK[CAP], eV[CAP];
     __shared__ uint32_t cnt[PF_CNT_MAX / 2];   // packed 16-bit: counts -> group starts -> group ends
     __shared__ uint32_t part[NT / 64 + 1];
@@ -868,7 +966,7 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
     }
     const uint64_t start = bktStart[slot];
     const int shift = tBits - (int) qLog2Bins[q];
-    const uint32_t split = qSplit[q];
+    const uint32_t split = qSplit[q >> vqShift];
     const uint32_t offMask = (1u << shift) - 1;   // key & offMask = target offset inside the bucket's range
     const int nCnt = shift == 0 ? 2 : (1 << shift);
     for (int x = t; x < nCnt / 2; x += NT) cnt[x] = 0;
@@ -1784,7 +1882,54 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             }
             // ---- double-diagonal match: bucketed LDS path, or (fallback / SD_PF_SORT=1) global radix sort + match
             if (useBuckets) {
-                const size_t nSlots = (size_t) bq * PF_NB_MAX;
+                // very hit-rich queries (large target sets): coarse split into virtual queries first (see coarse_*_kernel)
+                uint32_t nVQ = bq;
+                int cBits = 0, tBitsV = tBits;
+                const uint64_t *pHitBase = dQHitBase.p;
+                const uint32_t *pKey = dKeyA.p, *pVal = dValA.p;
+                WsView<uint64_t> dVQHitBase(ctx, "pf.dVQHitBase");
+                WsView<uint32_t> dSegBase(ctx, "pf.dSegBase");
+                WsView<uint32_t> dSegCount(ctx, "pf.dSegCount");
+                WsView<uint32_t> dKeyC(ctx, "pf.dKeyC");
+                WsView<uint32_t> dValC(ctx, "pf.dValC");
+                {
+                    std::vector<uint64_t> hQHB(bq + 1);
+                    SD_HIP(ctx, hipMemcpyAsync(hQHB.data(), dQHitBase.p, (bq + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                    SD_HIP(ctx, sdStreamSync(ctx));
+                    uint64_t maxQ = 0;
+                    for (uint32_t x = 0; x < bq; x++) maxQ = std::max(maxQ, hQHB[x + 1] - hQHB[x]);
+                    const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 400000;   // ~200 hits per bucket at 2^11 buckets
+                    while (cBits < CP_MAX_BITS && tBits - (cBits + 1) >= 8 && (maxQ >> cBits) > perVQ) cBits++;
+                    if (cBits > 0) {
+                        ProfScope ps(ctx, "prefilter_coarse_split");
+                        const uint32_t C = 1u << cBits;
+                        std::vector<uint32_t> hSegBase(bq + 1, 0);
+                        for (uint32_t x = 0; x < bq; x++)
+                            hSegBase[x + 1] = hSegBase[x] + (uint32_t) ((hQHB[x + 1] - hQHB[x] + CP_SEG - 1) / CP_SEG);
+                        const uint32_t nSeg = hSegBase[bq];
+                        nVQ = bq * C;
+                        tBitsV = tBits - cBits;
+                        SD_HIP(ctx, dVQHitBase.alloc((size_t) nVQ + 1));
+                        SD_HIP(ctx, dSegBase.alloc(bq + 1));
+                        SD_HIP(ctx, dSegCount.alloc((size_t) std::max<uint32_t>(nSeg, 1) * C));
+                        SD_HIP(ctx, dKeyC.alloc(nHits));
+                        SD_HIP(ctx, dValC.alloc(nHits));
+                        SD_HIP(ctx, hipMemcpyAsync(dSegBase.p, hSegBase.data(), (bq + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                        if (nSeg > 0)
+                            hipLaunchKernelGGL(coarse_count_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, bq, dQHitBase.p, dSegBase.p, tBits,
+                                               cBits, dKeyA.p, dSegCount.p);
+                        hipLaunchKernelGGL(coarse_offsets_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, dQHitBase.p, dSegBase.p, cBits,
+                                           dSegCount.p, dVQHitBase.p);
+                        if (nSeg > 0)
+                            hipLaunchKernelGGL(coarse_scatter_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, bq, dQHitBase.p, dSegBase.p, tBits,
+                                               cBits, dSegCount.p, dKeyA.p, dValA.p, dKeyC.p, dValC.p);
+                        SD_HIP(ctx, sdStreamSync(ctx));   // hSegBase is read by the upload until here
+                        pHitBase = dVQHitBase.p;
+                        pKey = dKeyC.p;
+                        pVal = dValC.p;
+                    }
+                }
+                const size_t nSlots = (size_t) nVQ * PF_NB_MAX;
                 WsView<uint64_t> dBktStart(ctx, "pf.dBktStart");
                 WsView<uint32_t> dBktCount(ctx, "pf.dBktCount");
                 WsView<uint32_t> dBktEmit(ctx, "pf.dBktEmit");
@@ -1797,9 +1942,9 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 SD_HIP(ctx, dBktCount.alloc(nSlots));
                 SD_HIP(ctx, dBktEmit.alloc(nSlots + 1));
                 SD_HIP(ctx, dEmitOff.alloc(nSlots + 1));
-                SD_HIP(ctx, dQLog2.alloc(bq));
-                SD_HIP(ctx, dQBins.alloc(bq + 1));
-                SD_HIP(ctx, dBinBase.alloc(bq + 1));
+                SD_HIP(ctx, dQLog2.alloc(nVQ));
+                SD_HIP(ctx, dQBins.alloc(nVQ + 1));
+                SD_HIP(ctx, dBinBase.alloc(nVQ + 1));
                 SD_HIP(ctx, dFlag.alloc(1));
                 WsView<uint2> dKVB(ctx, "pf.dKVB");
                 SD_HIP(ctx, dKVB.alloc(nHits));
@@ -1807,16 +1952,16 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 SD_HIP(ctx, hipMemsetAsync(dFlag.p, 0, sizeof(int), ctx->stream));
                 {
                     ProfScope ps(ctx, "prefilter_partition_hits");
-                    hipLaunchKernelGGL(partition_hits_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, dQHitBase.p, tBits, dKeyA.p,
-                                       dValA.p, dKVB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
+                    hipLaunchKernelGGL(partition_hits_kernel, dim3(nVQ), dim3(256), 0, ctx->stream, nVQ, pHitBase, tBitsV, pKey,
+                                       pVal, dKVB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
                 }
-                hipLaunchKernelGGL(bin_count_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, dQLog2.p, dQBins.p);
-                int rc = exclusiveScanWiden(ctx, dQBins.p, dBinBase.p, bq + 1, scanTmp);
+                hipLaunchKernelGGL(bin_count_kernel, dim3(gridFor(nVQ + 1, 256)), dim3(256), 0, ctx->stream, nVQ, dQLog2.p, dQBins.p);
+                int rc = exclusiveScanWiden(ctx, dQBins.p, dBinBase.p, nVQ + 1, scanTmp);
                 if (rc != SD_OK) return rc;
                 int hFlag = 0;
                 uint64_t totalBins = 0;
                 SD_HIP(ctx, hipMemcpyAsync(&hFlag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-                SD_HIP(ctx, hipMemcpyAsync(&totalBins, dBinBase.p + bq, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                SD_HIP(ctx, hipMemcpyAsync(&totalBins, dBinBase.p + nVQ, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
                 SD_HIP(ctx, sdStreamSync(ctx));
                 if (hFlag == 0 && totalBins > 0) {
                     const uint32_t bigCap = (uint32_t) std::min<size_t>(nSlots, 1u << 26);   // every bucket may be oversize on very large target sets
@@ -1827,19 +1972,19 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     {
                         ProfScope ps(ctx, "prefilter_bucket_match");
                         hipLaunchKernelGGL((bucket_match_kernel<128, PF_BUCKET_CAP>), dim3((unsigned) totalBins), dim3(128), 0, ctx->stream,
-                                           bq, dBinBase.p, dQLog2.p, tBits, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p,
+                                           nVQ, dBinBase.p, dQLog2.p, tBitsV, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p,
                                            dValA.p, dBktEmit.p, dFlag.p, (const uint32_t *) nullptr, dBigList.p, dBigCount, bigCap,
-                                           dQSplit.p);
+                                           dQSplit.p, cBits);
                     }
                     uint32_t nBig = 0;
                     SD_HIP(ctx, hipMemcpyAsync(&nBig, dBigCount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
                     SD_HIP(ctx, sdStreamSync(ctx));
                     if (nBig > 0 && nBig <= bigCap) {   // the few buckets with one very hit-rich target (e.g. the query itself)
                         ProfScope ps(ctx, "prefilter_bucket_match_big");
-                        hipLaunchKernelGGL((bucket_match_kernel<256, PF_BUCKET_CAP_BIG>), dim3(nBig), dim3(256), 0, ctx->stream, bq,
-                                           dBinBase.p, dQLog2.p, tBits, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p, dValA.p,
+                        hipLaunchKernelGGL((bucket_match_kernel<256, PF_BUCKET_CAP_BIG>), dim3(nBig), dim3(256), 0, ctx->stream, nVQ,
+                                           dBinBase.p, dQLog2.p, tBitsV, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p, dValA.p,
                                            dBktEmit.p, dFlag.p, (const uint32_t *) dBigList.p, (uint32_t *) nullptr,
-                                           (uint32_t *) nullptr, 0u, dQSplit.p);
+                                           (uint32_t *) nullptr, 0u, dQSplit.p, cBits);
                     }
                     rc = exclusiveScanWiden(ctx, dBktEmit.p, dEmitOff.p, nSlots + 1, scanTmp);
                     if (rc != SD_OK) return rc;
@@ -1853,7 +1998,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         if (nCand > 0) {
                             SD_HIP(ctx, dCKey.alloc(nCand));
                             SD_HIP(ctx, dCVal.alloc(nCand));
-                            hipLaunchKernelGGL(bucket_collect_kernel, dim3((unsigned) totalBins), dim3(64), 0, ctx->stream, bq, dBinBase.p,
+                            hipLaunchKernelGGL(bucket_collect_kernel, dim3((unsigned) totalBins), dim3(64), 0, ctx->stream, nVQ, dBinBase.p,
                                                dBktStart.p, dBktEmit.p, dEmitOff.p, dKeyA.p, dValA.p, dCKey.p, dCVal.p);
                         }
                     }

@@ -121,6 +121,16 @@ def test_prefilter_bucket_path_equals_sort_path(gpu, host, monkeypatch):
         n = int(a[1][q])
         assert np.array_equal(a[0][q, :n], b[0][q, :n]), q
     assert int(a[1].sum()) > 50000
+    # the coarse split for very hit-rich queries (large target sets), forced here by a tiny per-range budget: every
+    # query is cut into 2, 4, ... target ranges that go through the bucket machinery as virtual queries
+    monkeypatch.delenv('SD_PF_SORT')
+    for budget in ('6000', '500'):
+        monkeypatch.setenv('SD_PF_COARSE', budget)
+        c = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)
+        assert np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2]), budget
+        for q in range(nq):
+            n = int(a[1][q])
+            assert np.array_equal(a[0][q, :n], c[0][q, :n]), (budget, q)
 
 
 def test_prefilter_rescoring_path_matches_reference(gpu, host, oracle):
@@ -183,8 +193,11 @@ def test_prefilter_hit_buffer_overflow_matches_reference(gpu, host, oracle, monk
     qkm = np.concatenate([km_b[int(off[q]):int(off[q + 1])] for q in qs])
     qdg = np.concatenate([dg_b[int(off[q]):int(off[q + 1])] for q in qs])
     rows = g['pf_rows']
-    for mode in ('bucket', 'sort'):
+    for mode in ('bucket', 'coarse', 'sort'):
+        if mode == 'coarse':   # the overflowing query (2*10^6 hits) is split into target ranges first; the split position
+            monkeypatch.setenv('SD_PF_COARSE', '300000')   # of the overflow is looked up through the virtual query
         if mode == 'sort':
+            monkeypatch.delenv('SD_PF_COARSE')
             monkeypatch.setenv('SD_PF_SORT', '1')
         hits, cnt, st = api.prefilter(gpu, tgt, par, qres, qoff, qkm, qdg, np.array(qs, np.uint32), want_stats=True)
         assert int(st[0, 1]) == int(g['index_hits_q0'][0])
