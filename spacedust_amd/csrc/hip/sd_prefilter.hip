@@ -1893,14 +1893,15 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 WsView<uint32_t> dKeyC(ctx, "pf.dKeyC");
                 WsView<uint32_t> dValC(ctx, "pf.dValC");
                 {
-                    std::vector<uint64_t> hQHB(bq + 1);
-                    SD_HIP(ctx, hipMemcpyAsync(hQHB.data(), dQHitBase.p, (bq + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-                    SD_HIP(ctx, sdStreamSync(ctx));
-                    uint64_t maxQ = 0;
-                    for (uint32_t x = 0; x < bq; x++) maxQ = std::max(maxQ, hQHB[x + 1] - hQHB[x]);
-                    const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 400000;   // ~200 hits per bucket at 2^11 buckets
-                    while (cBits < CP_MAX_BITS && tBits - (cBits + 1) >= 8 && (maxQ >> cBits) > perVQ) cBits++;
+                    // decided by the average query of the sub-batch (a few long queries are what the adaptive bucket count and
+                    // the oversize-bucket launch are for): ~100 hits per bucket at 2^11 buckets
+                    const uint64_t avgQ = nHits / std::max<uint32_t>(bq, 1);
+                    const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 200000;
+                    while (cBits < CP_MAX_BITS && tBits - (cBits + 1) >= 8 && (avgQ >> cBits) > perVQ) cBits++;
                     if (cBits > 0) {
+                        std::vector<uint64_t> hQHB(bq + 1);
+                        SD_HIP(ctx, hipMemcpyAsync(hQHB.data(), dQHitBase.p, (bq + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                        SD_HIP(ctx, sdStreamSync(ctx));
                         ProfScope ps(ctx, "prefilter_coarse_split");
                         const uint32_t C = 1u << cBits;
                         std::vector<uint32_t> hSegBase(bq + 1, 0);
