@@ -1290,26 +1290,12 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
         __syncthreads();
         if (np2 > 1) bitonicSort(keys, pay, np2);
     } else {
-        const uint32_t W = (uint32_t) (SEL_CAP - K);
-        int have = 0;
-        for (uint32_t base = beg; base < end; base += W) {
-            __syncthreads();
-            if (threadIdx.x == 0) sCnt = have;
-            __syncthreads();
-            const unsigned long long bound = have >= K ? keys[K - 1] : ~0ull;
-            __syncthreads();
-            const uint32_t stop = min(end, base + W);
-            for (uint32_t x = base + threadIdx.x; x < stop; x += blockDim.x) {
-                if (min(255, kScore[x]) >= thr) {
-                    const unsigned long long kk = keyOf(x);
-                    if (kk < bound) {
-                        const int slot = atomicAdd(&sCnt, 1);
-                        keys[slot] = kk;
-                        pay[slot] = x;
-                    }
-                }
-            }
-            __syncthreads();
+        // very many candidates at or above the cut (large target sets, or a cut at the minimum score): stream through
+        // the list, buffer what still beats the K-th best key seen so far, sort + truncate whenever the buffer could overflow
+        if (threadIdx.x == 0) sCnt = 0;
+        __syncthreads();
+        unsigned long long bound = ~0ull;
+        auto sortAndTruncate = [&]() {
             const int m = sCnt;
             int np2 = 1;
             while (np2 < m) np2 <<= 1;
@@ -1317,33 +1303,70 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
             __syncthreads();
             if (np2 > 1) bitonicSort(keys, pay, np2);
             __syncthreads();
-            have = min(m, K);
+            const int have = min(m, K);
+            bound = have >= K ? keys[K - 1] : ~0ull;
+            __syncthreads();
+            if (threadIdx.x == 0) sCnt = have;
+            __syncthreads();
+        };
+        for (uint32_t base = beg; base < end; base += blockDim.x) {
+            if (sCnt + (int) blockDim.x > SEL_CAP) sortAndTruncate();   // uniform: sCnt is read after a barrier
+            const uint32_t x = base + threadIdx.x;
+            if (x < end && min(255, kScore[x]) >= thr) {
+                const unsigned long long kk = keyOf(x);
+                if (kk < bound) {
+                    const int slot = atomicAdd(&sCnt, 1);
+                    keys[slot] = kk;
+                    pay[slot] = x;
+                }
+            }
+            __syncthreads();
         }
-        n = have;
+        sortAndTruncate();
+        n = sCnt;
     }
     __syncthreads();
-    // take the first (maxHits - hasIdentity) with id != identity (getResult, QueryMatcher.cpp:364-420)
-    // done serially by thread 0 into the key array re-used for the final order
-    __shared__ int sTake;
-    if (threadIdx.x == 0) {
-        int current = (ident != 0xFFFFFFFFu) ? 1 : 0;
-        int take = 0;
-        for (int x = 0; x < n && current < maxHits; x++) {
-            const uint32_t e = pay[x];
-            const uint32_t sid = kKey[e] & ((1u << tBits) - 1);
-            if (sid != ident) {
-                pay[take] = e;
+    // take the first (maxHits - hasIdentity) with id != identity (getResult, QueryMatcher.cpp:364-420); the identity target
+    // occurs at most once in the list (one entry per target), so this is a shift by one behind its position
+    __shared__ int sTake, sIdentPos;
+    if (threadIdx.x == 0) sIdentPos = n;
+    __syncthreads();
+    for (int x = threadIdx.x; x < n; x += blockDim.x)
+        if ((kKey[pay[x]] & ((1u << tBits) - 1)) == ident) sIdentPos = x;
+    __syncthreads();
+    {
+        const int identPos = sIdentPos;
+        const int current0 = (ident != 0xFFFFFFFFu) ? 1 : 0;
+        const int avail = n - (identPos < n ? 1 : 0);
+        const int take = max(0, min(avail, maxHits - current0));
+        constexpr int PERT = (SEL_CAP / 2 + 255) / 256;
+        uint32_t eReg[PERT];
+        unsigned long long kReg[PERT];
+#pragma unroll
+        for (int y = 0; y < PERT; y++) {
+            const int j = y * 256 + (int) threadIdx.x;
+            if (j < take) {
+                const uint32_t e = pay[j + (j >= identPos ? 1 : 0)];
+                const uint32_t sid = kKey[e] & ((1u << tBits) - 1);
                 // final order: |score| desc, seqId asc (QueryMatcher.h:38-48); true score for saturated counts
                 const int sc = kScore[e];
                 const int cnt = min(255, sc);
                 const int prefScore = rescored ? (int) (255u + rescaledByte(e) * (unsigned int) sMaxSelf / 255u)
                                                : (cnt >= 255 ? sc : cnt);
-                keys[take] = ((unsigned long long) (0x7FFFFFFFu - (uint32_t) prefScore) << 32) | sid;
-                take++;
-                current++;
+                eReg[y] = e;
+                kReg[y] = ((unsigned long long) (0x7FFFFFFFu - (uint32_t) prefScore) << 32) | sid;
             }
         }
-        sTake = take;
+        __syncthreads();
+#pragma unroll
+        for (int y = 0; y < PERT; y++) {
+            const int j = y * 256 + (int) threadIdx.x;
+            if (j < take) {
+                pay[j] = eReg[y];
+                keys[j] = kReg[y];
+            }
+        }
+        if (threadIdx.x == 0) sTake = take;
     }
     __syncthreads();
     const int take = sTake;
@@ -1352,37 +1375,59 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
     for (int x = take + threadIdx.x; x < np2; x += blockDim.x) { keys[x] = ~0ull; pay[x] = 0xFFFFFFFFu; }
     __syncthreads();
     if (np2 > 1) bitonicSort(keys, pay, np2);
-    if (threadIdx.x == 0) {
+    __syncthreads();
+    {
+        // coverage pre-filter (Util::canBeCovered, Util.cpp:477-494; only the modes runSplit applies) and the rows,
+        // compacted in order: every thread owns a run of consecutive entries
         sd_hit *o = outHits + (size_t) q * maxHits;
-        uint32_t w = 0;
         const float qLen = (float) (qOff[q + 1] - qOff[q]);
         auto covered = [&](uint32_t sid) {
             if (!(covThr > 0.0f)) return true;
             const float tLen = (float) (tOff[sid + 1] - tOff[sid]);
-            switch (covMode) {   // Util::canBeCovered (Util.cpp:477-494), only the modes runSplit applies
+            switch (covMode) {
                 case 0: return (qLen / tLen >= covThr) && (tLen / qLen >= covThr);
                 case 2: return (tLen / qLen) >= covThr;
                 case 5: return (fminf(tLen, qLen) / fmaxf(tLen, qLen)) >= covThr;
                 default: return true;
             }
         };
-        if (ident != 0xFFFFFFFFu) {
-            if (covered(ident)) {
-                o[w].seqId = ident; o[w].score = 65535; o[w].diagonal = 0; o[w].pad = 0;
+        const uint32_t w0 = (ident != 0xFFFFFFFFu && covered(ident)) ? 1u : 0u;
+        if (threadIdx.x == 0 && w0) { o[0].seqId = ident; o[0].score = 65535; o[0].diagonal = 0; o[0].pad = 0; }
+        constexpr int PERO = (SEL_CAP / 2 + 255) / 256;
+        __shared__ uint32_t oPart[5];
+        const int b0 = (int) threadIdx.x * PERO;
+        uint32_t sidReg[PERO], mask = 0, cnt = 0;
+#pragma unroll
+        for (int y = 0; y < PERO; y++) {
+            const int x = b0 + y;
+            if (x < take) {
+                sidReg[y] = kKey[pay[x]] & ((1u << tBits) - 1);
+                if (covered(sidReg[y])) { mask |= 1u << y; cnt++; }
+            }
+        }
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o2 = __shfl_up(incl, off, 64);
+            if ((threadIdx.x & 63) >= off) incl += o2;
+        }
+        if ((threadIdx.x & 63) == 63) oPart[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t w = w0 + incl - cnt;
+        for (int wv = 0; wv < (int) (threadIdx.x >> 6); wv++) w += oPart[wv];
+#pragma unroll
+        for (int y = 0; y < PERO; y++) {
+            if (mask & (1u << y)) {
+                const int x = b0 + y;
+                const uint32_t e = pay[x];
+                o[w].seqId = sidReg[y];
+                o[w].score = (int32_t) (0x7FFFFFFFu - (uint32_t) (keys[x] >> 32));   // as ordered
+                o[w].diagonal = hitDiag[qHitBase[q] + (kVal[e] & 0xFFFFFFu)];
+                o[w].pad = 0;
                 w++;
             }
         }
-        for (int x = 0; x < take; x++) {
-            const uint32_t e = pay[x];
-            const uint32_t sid = kKey[e] & ((1u << tBits) - 1);
-            if (!covered(sid)) continue;
-            o[w].seqId = sid;
-            o[w].score = (int32_t) (0x7FFFFFFFu - (uint32_t) (keys[x] >> 32));   // as ordered
-            o[w].diagonal = hitDiag[qHitBase[q] + (kVal[e] & 0xFFFFFFu)];
-            o[w].pad = 0;
-            w++;
-        }
-        outCount[q] = w;
+        if (threadIdx.x == 255) outCount[q] = w;   // the last thread's end = total
     }
 }
 
