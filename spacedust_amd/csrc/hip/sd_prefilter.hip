@@ -648,11 +648,12 @@ constexpr int PF_NB_MAX = 2048;        // bucket slots per query
 constexpr int PF_LB_MAX = 11;          // log2(PF_NB_MAX)
 constexpr int PF_BUCKET_CAP = 1024;    // hits the LDS bucket sort takes; larger buckets go to a second launch with
 constexpr int PF_BUCKET_CAP_BIG = 6144;   // this capacity, and only beyond that the whole sub-batch falls back
+constexpr int PF_FILL = 512;           // aimed hits per bucket: the bucket count is the next power of two of hits / PF_FILL
 constexpr int PF_TILE = 1024;          // hits reordered in LDS per partition step (256 threads x 4)
 constexpr int PF_CNT_MAX = 4096;       // counting-sort bins (target offsets) per bucket
 
 __device__ __forceinline__ int pfLog2Bins(uint64_t n, int tBits) {
-    const uint64_t want = (n + 255) / 256;
+    const uint64_t want = (n + PF_FILL - 1) / PF_FILL;
     int lb = 0;
     while ((1ull << lb) < want && lb < PF_LB_MAX) lb++;
     const int minLb = tBits > 12 ? tBits - 12 : 0;   // a bucket's target range must fit PF_CNT_MAX counters
