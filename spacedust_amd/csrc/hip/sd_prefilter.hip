@@ -649,7 +649,8 @@ constexpr int PF_LB_MAX = 11;          // log2(PF_NB_MAX)
 constexpr int PF_BUCKET_CAP = 1024;    // hits the LDS bucket sort takes; larger buckets go to a second launch with
 constexpr int PF_BUCKET_CAP_BIG = 6144;   // this capacity, and only beyond that the whole sub-batch falls back
 constexpr int PF_FILL = 512;           // aimed hits per bucket: the bucket count is the next power of two of hits / PF_FILL
-constexpr int PF_TILE = 1024;          // hits reordered in LDS per partition step (256 threads x 4)
+constexpr int PF_TILE = 2048;          // hits reordered in LDS per partition step (256 threads x PF_PER)
+constexpr int PF_PER = PF_TILE / 256;
 constexpr int PF_CNT_MAX = 4096;       // counting-sort bins (target offsets) per bucket
 
 __device__ __forceinline__ int pfLog2Bins(uint64_t n, int tBits) {
@@ -775,9 +776,9 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
     __syncthreads();
     for (uint64_t base = s; base < e; base += PF_TILE) {
         const int tn = (int) min((uint64_t) PF_TILE, e - base);
-        uint32_t k[4], v[4], r[4];
+        uint32_t k[PF_PER], v[PF_PER], r[PF_PER];
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
+        for (int x = 0; x < PF_PER; x++) {
             const int j = x * 256 + t;
             if (j < tn) {
                 k[x] = inKey[base + j];
@@ -790,7 +791,7 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
         __syncthreads();
         pk16Scan<256>(tcount, binsEven, part);
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
+        for (int x = 0; x < PF_PER; x++) {
             const int j = x * 256 + t;
             if (j < tn) {
                 const uint32_t p = pk16Get(tcount, (k[x] & tMask) >> shift) + r[x];
@@ -1484,11 +1485,28 @@ __global__ void stats_kernel(uint32_t nQ, const uint64_t *__restrict__ posBase, 
 
 __global__ void cand_stats_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint32_t *__restrict__ cLen,
                                   int tBits, unsigned long long *__restrict__ stats) {
+    // candidates are ordered by query: a wavefront nearly always holds one query, so it adds its sums with one pair of
+    // atomics (64 contended 64-bit atomics per wavefront made this diagnostic kernel cost as much as score_diag)
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nCand) return;
-    const uint32_t q = cKey[c] >> tBits;
-    atomicAdd(&stats[4 * q + 2], 1ull);
-    atomicAdd(&stats[4 * q + 3], (unsigned long long) cLen[c]);
+    const bool live = c < nCand;
+    const uint32_t q = live ? cKey[c] >> tBits : 0xFFFFFFFFu;
+    const unsigned long long len = live ? (unsigned long long) cLen[c] : 0ull;
+    const uint32_t q0 = __shfl(q, 0, 64);
+    if (__all(q == q0 || !live)) {
+        unsigned long long cnt = live ? 1ull : 0ull, sum = len;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            cnt += __shfl_xor(cnt, off, 64);
+            sum += __shfl_xor(sum, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && q0 != 0xFFFFFFFFu) {
+            atomicAdd(&stats[4 * (size_t) q0 + 2], cnt);
+            atomicAdd(&stats[4 * (size_t) q0 + 3], sum);
+        }
+    } else if (live) {
+        atomicAdd(&stats[4 * (size_t) q + 2], 1ull);
+        atomicAdd(&stats[4 * (size_t) q + 3], len);
+    }
 }
 
 template <typename T>
