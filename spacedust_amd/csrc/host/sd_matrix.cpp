@@ -1,6 +1,8 @@
 // Substitution matrices, composition bias, extended 2-/3-mer tables, similar-k-mer
 // enumeration (host side).  See sd_host.h for the reference citations.
 #include "sd_host.h"
+
+#include <immintrin.h>
 #include <vector>
 #include <memory>
 #include <mutex>
@@ -141,14 +143,38 @@ inline float biasTail(const SubMat &m, const short *row, int sum, int windowLeng
 void calcLocalAaBiasCorrection(const SubMat &m, const uint8_t *seq, int N, float *out, float scale) {
     const int windowSize = 40;
     BiasMemo *memo = biasMemoFor(m);
+    // the window sums are integer: eight interior positions at a time with AVX2 gathers from an int32 copy of the matrix
+    // (the float tail below keeps the reference's expression order per position)
+    alignas(32) int32_t tab[ALPH * ALPH + 7];
+    for (int a = 0; a < ALPH; a++)
+        for (int b = 0; b < ALPH; b++) tab[a * ALPH + b] = m.sub[a][b];
+    alignas(32) int32_t vsum[8];
+    int vecFrom = -1;   // first position of the block whose sums are in vsum
     for (int i = 0; i < N; i++) {
         const int minPos = std::max(0, (i - windowSize / 2));
         const int maxPos = std::min(N, (i + windowSize / 2));
         const int windowLength = maxPos - minPos;
         int sum = 0;
         const short *row = m.sub[seq[i]];
-        for (int j = minPos; j < maxPos; j++) sum += row[seq[j]];
-        sum -= row[seq[i]];
+        if (i >= vecFrom && i < vecFrom + 8 && vecFrom >= 0) {
+            sum = vsum[i - vecFrom];
+        } else if (i >= windowSize / 2 && i + 7 + windowSize / 2 <= N) {
+            const __m256i rowBase = _mm256_mullo_epi32(_mm256_cvtepu8_epi32(_mm_loadl_epi64((const __m128i *) (seq + i))),
+                                                       _mm256_set1_epi32(ALPH));
+            __m256i acc = _mm256_setzero_si256();
+            for (int off = -windowSize / 2; off < windowSize / 2; off++) {
+                const __m256i sj = _mm256_cvtepu8_epi32(_mm_loadl_epi64((const __m128i *) (seq + i + off)));
+                acc = _mm256_add_epi32(acc, _mm256_i32gather_epi32(tab, _mm256_add_epi32(rowBase, sj), 4));
+            }
+            const __m256i si = _mm256_cvtepu8_epi32(_mm_loadl_epi64((const __m128i *) (seq + i)));
+            acc = _mm256_sub_epi32(acc, _mm256_i32gather_epi32(tab, _mm256_add_epi32(rowBase, si), 4));
+            _mm256_store_si256((__m256i *) vsum, acc);
+            vecFrom = i;
+            sum = vsum[0];
+        } else {
+            for (int j = minPos; j < maxPos; j++) sum += row[seq[j]];
+            sum -= row[seq[i]];
+        }
         float d;
         const int rel = sum - memo->lo;
         if (rel >= 0 && rel < memo->span && windowLength <= 40) {
