@@ -860,6 +860,7 @@ k_gate_rev(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ
     r.qEnd = src[2];
     r.flags = word[i] ? 1 : 0;
     if (word[i] && r.tEnd == -1) r.tEnd = 0;   // the word kernel initialises end_ref to 0 (:962)
+    if (r.score == 0) r.qEnd = 0;   // no cell scored: the saved column is all zero and the first row matches it (:903-913)
     if (r.tEnd == -1) { res[i] = r; return; }
     const uint64_t qo = qOff[pairQ[i]], to = tOff[pairT[i]];
     const int qL = (int) (qOff[pairQ[i] + 1] - qo), tL = (int) (tOff[pairT[i] + 1] - to);
@@ -1945,6 +1946,7 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
         r.qEnd = src[2];
         r.flags = word[i] ? 1 : 0;
         if (word[i] && r.tEnd == -1) r.tEnd = 0;   // the word kernel initialises end_ref to 0 (:962)
+        if (r.score == 0) r.qEnd = 0;
         if (r.tEnd == -1) { r.evalue = 0.0; continue; }
         r.evalue = sd::computeEvalue(ev, r.score, qLv[i]);
         const bool lowE = r.evalue > par->evalThr;

@@ -1,0 +1,75 @@
+"""Edge cases through the C ABI against the oracle (itself equal to the real reference classes on these inputs):
+queries shorter than the seed span, of exactly the span, all-X sequences, one- and two-residue sequences, a query
+without any hit, an X run inside a sequence; empty batches."""
+import numpy as np
+import pytest
+
+from spacedust_amd import api
+
+pytestmark = pytest.mark.gpu
+AA = 'ACDEFGHIKLMNPQRSTVWY'
+
+
+def _db(oracle):
+    rng = np.random.default_rng(3)
+    base = ''.join(rng.choice(list(AA), 200))
+    seqs = [base, base[:5], base[:10], 'X' * 40, base[20:31], 'A', 'AC', base[::-1], base[:100] + 'X' * 30 + base[130:], base,
+            base[:9], 'X' + base[1:60], base[:60] + 'X']
+    nums = [oracle.map_sequence(s) for s in seqs]
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    return seqs, nums, np.concatenate(nums), off
+
+
+def test_prefilter_edge_cases(gpu, host, oracle):
+    seqs, nums, res, off = _db(oracle)
+    n = len(seqs)
+    sw_b, dg_b, km_b = host.comp_bias(res, off)
+    idx = host.build_index(res, off)
+    tgt = api.Target(gpu, host, idx)
+    par = api.prefilter_params(host, idx.n, max_hits=300, cov_thr=0.0, bin_size=2)
+    hits, cnt, st = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, np.arange(n, dtype=np.uint32), want_stats=True)
+    ot = oracle.target(res, off)
+    assert ot.n_entries == idx.n_entries
+    for q in range(n):
+        ids, sc, dg, ost = ot.prefilter(nums[q], identity_id=q, max_hits=300)
+        m = int(cnt[q])
+        assert m == len(ids), (q, m, len(ids))
+        assert (hits[q, :m]['seqId'] == ids).all() and (hits[q, :m]['score'] == sc).all() and (hits[q, :m]['diagonal'] == dg).all(), q
+        assert tuple(int(x) for x in st[q]) == tuple(int(x) for x in ost), q
+    # the same queries without an identity target: the short / all-X ones have no hit at all
+    hits2, cnt2, _ = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, np.full(n, 0xFFFFFFFF, np.uint32))
+    for q in range(n):
+        ids, sc, dg, _ = ot.prefilter(nums[q], max_hits=300)
+        assert int(cnt2[q]) == len(ids) and (hits2[q, :len(ids)]['seqId'] == ids).all(), q
+    assert int(cnt2[1]) == 0 and int(cnt2[3]) == 0 and int(cnt2[5]) == 0
+    # empty batch
+    e = api.prefilter(gpu, tgt, par, res[:0], off[:1], km_b[:0], dg_b[:0], np.zeros(0, np.uint32))
+    assert e[0].shape[0] == 0 and len(e[1]) == 0
+
+
+def test_alignment_edge_cases(gpu, host, oracle):
+    seqs, nums, res, off = _db(oracle)
+    sw_b, _, _ = host.comp_bias(res, off)
+    mat, _, _ = host.matrix(0)
+    db = int(off[-1])
+    ss = gpu.seqset(res, off, sw_b)
+    par = gpu.sw_params(mat, db)
+    pairs = [(5, 6), (5, 0), (0, 5), (6, 6), (1, 0), (3, 0), (0, 3), (8, 0), (0, 9), (2, 4), (4, 2), (10, 0), (11, 12), (12, 11),
+             (3, 3), (5, 5), (0, 0), (7, 0)]
+    pq = np.array([a for a, _ in pairs], np.uint32)
+    pt = np.array([b for _, b in pairs], np.uint32)
+    ident = np.array([1 if (a == b and a in (0, 5)) else 0 for a, b in pairs], np.uint8)   # scoreIdentical on a 200-mer and a 1-mer
+    out, pool = gpu.sw_align(par, ss, ss, pq, pt, identity=ident)
+    for x, (a, b) in enumerate(pairs):
+        o = oracle.sw_align(nums[a], nums[b], db, identity=bool(ident[x]))
+        r = out[x]
+        assert int(r['score']) == o['score'], (x, r, o)
+        assert (int(r['qEnd']), int(r['tEnd'])) == (o['qEnd'], o['tEnd']), (x, r, o)
+        assert (int(r['qStart']), int(r['tStart']), int(r['btLen'])) == (o['qStart'], o['tStart'], o['btLen']), (x, r, o)
+        if o['btLen'] > 0:
+            bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
+            assert bt == o['backtrace'] and int(r['identical']) == o['identical'], (x, bt, o)
+    # no pairs at all
+    out0, pool0 = gpu.sw_align(par, ss, ss, np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+    assert len(out0) == 0
