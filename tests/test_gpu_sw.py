@@ -185,3 +185,40 @@ def test_sw_align_compact_equals_full(gpu, host):
         b = pool_f[int(full['btOffset'][keep[x]]):int(full['btOffset'][keep[x]]) + int(full['btLen'][keep[x]])]
         assert np.array_equal(a, b), x
     assert 100 < len(keep) < len(pq)
+
+
+@pytest.mark.parametrize('sw_mode,cov_mode,cov_thr,eval_thr', [(0, 2, 0.8, 10.0), (1, 2, 0.8, 10.0), (2, 0, 0.5, 10.0),
+                                                               (2, 1, 0.7, 1e-3), (1, 0, 0.9, 1e-5), (2, 2, 0.0, 1e-10)])
+def test_sw_modes_and_gates(gpu, host, oracle, small_proteomes, sw_mode, cov_mode, cov_thr, eval_thr):
+    """alignment modes (score only / + start positions / + backtrace), coverage modes 0-2 and E-value thresholds: which
+    gate stops a pair decides which fields are filled (StripedSmithWaterman.cpp:389-398,483-489)"""
+    ps = small_proteomes
+    rng = np.random.default_rng(101 + sw_mode * 7 + cov_mode)
+    pq, pt = _pairs(ps, rng, n_random=60)
+    pq, pt = pq[::3], pt[::3]
+    sw_bias, _, _ = host.comp_bias(ps.residues, ps.offsets)
+    mat, _, _ = host.matrix(0)
+    db = int(ps.offsets[-1])
+    ss = gpu.seqset(ps.residues, ps.offsets, sw_bias)
+    par = gpu.sw_params(mat, db, sw_mode=sw_mode, eval_thr=eval_thr, cov_mode=cov_mode, cov_thr=cov_thr)
+    res, pool = gpu.sw_align(par, ss, ss, pq, pt, identity=(pq == pt))
+    n_start = n_bt = 0
+    for x in range(len(pq)):
+        o = oracle.sw_align(_seq(ps, pq[x]), _seq(ps, pt[x]), db, sw_mode=sw_mode, eval_thr=eval_thr, cov_mode=cov_mode,
+                            cov_thr=cov_thr, identity=bool(pq[x] == pt[x]))
+        r = res[x]
+        assert int(r['score']) == o['score'], (x, r, o)
+        assert (int(r['qStart']), int(r['qEnd']), int(r['tStart']), int(r['tEnd'])) == \
+               (o['qStart'], o['qEnd'], o['tStart'], o['tEnd']), (x, r, o)
+        assert int(r['btLen']) == o['btLen'], (x, r, o)
+        if o['evalue'] <= 2.0 * eval_thr:
+            assert float(r['evalue']) == o['evalue'], (x, r['evalue'], o['evalue'])
+        n_start += o['qStart'] >= 0
+        if o['btLen'] > 0 and sw_mode == 2:
+            n_bt += 1
+            bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
+            assert bt == o['backtrace'] and int(r['identical']) == o['identical'], x
+    if sw_mode >= 1:
+        assert n_start > 10
+    if sw_mode == 2:
+        assert n_bt > 10

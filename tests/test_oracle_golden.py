@@ -185,6 +185,26 @@ def test_k7_kmer_lists_and_prefilter(oracle):
             assert (dg.astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (thr, q)
 
 
+def test_sw_modes_and_gates(oracle):
+    """alignment modes 0-2, coverage modes 0-2, E-value thresholds: rows from the real reference (tools/make_golden_modes.py)"""
+    g = np.load(os.path.join(GOLD, 'sw_modes_vectors.npz'))
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    db = int(off[-1])
+    for mi, (sw_mode, cov_mode, cov_thr, eval_thr) in enumerate(g['modes']):
+        rows, evs = g['res_%d' % mi], g['ev_%d' % mi]
+        bts = g['bt_%d' % mi].tobytes().decode().split('\n')
+        for x, (a, b) in enumerate(g['pairs']):
+            r = oracle.sw_align(nums[a], nums[b], db, sw_mode=int(sw_mode), eval_thr=float(eval_thr), cov_mode=int(cov_mode),
+                                cov_thr=float(cov_thr))
+            e = rows[x]
+            assert (r['score'], r['qStart'], r['qEnd'], r['tStart'], r['tEnd'], r['btLen']) == (e[0], e[1], e[2], e[3], e[4], e[6]), (mi, x)
+            assert r['evalue'] == evs[x], (mi, x)
+            if e[6] > 0:
+                assert r['identical'] == e[5] and r['backtrace'] == bts[x], (mi, x)
+
+
 def _load_profiles(oracle):
     g = np.load(os.path.join(GOLD, 'profile_vectors.npz'))
     off = g['off']
