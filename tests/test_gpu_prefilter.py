@@ -207,3 +207,26 @@ def test_prefilter_hit_buffer_overflow_matches_reference(gpu, host, oracle, monk
             assert m == len(exp), (mode, q, m, len(exp))
             assert (hits[x, :m]['seqId'] == exp[:, 1]).all() and (hits[x, :m]['score'] == exp[:, 2]).all(), (mode, q)
             assert (hits[x, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (mode, q)
+
+
+@pytest.mark.parametrize('bin_size,max_hits,min_diag', [(4, 300, 15), (64, 7, 15), (2048, 300, 40), (2, 1, 15)])
+def test_prefilter_parameters_match_oracle(gpu, host, oracle, small_proteomes, bin_size, max_hits, min_diag):
+    """BINSIZE (the order ties are cut in: bin-major, QueryMatcher.cpp:422-450), result list length and the minimum
+    diagonal score"""
+    ps = small_proteomes
+    ident = np.arange(ps.n, dtype=np.uint32)
+    sw_b, dg_b, km_b = host.comp_bias(ps.residues, ps.offsets)
+    idx = host.build_index(ps.residues, ps.offsets)
+    tgt = api.Target(gpu, host, idx)
+    par = api.prefilter_params(host, idx.n, max_hits=max_hits, min_diag=min_diag, cov_thr=0.0, bin_size=bin_size)
+    hits, cnt, _ = api.prefilter(gpu, tgt, par, ps.residues, ps.offsets, km_b, dg_b, ident)
+    ot = oracle.target(ps.residues, ps.offsets)
+    total = 0
+    for q in range(0, ps.n, 2):
+        seq = ps.residues[int(ps.offsets[q]):int(ps.offsets[q + 1])]
+        ids, sc, dg, _ = ot.prefilter(seq, identity_id=q, max_hits=max_hits, min_diag=min_diag, bin_size=bin_size)
+        n = int(cnt[q])
+        total += n
+        assert n == len(ids), (q, n, len(ids))
+        assert (hits[q, :n]['seqId'] == ids).all() and (hits[q, :n]['score'] == sc).all() and (hits[q, :n]['diagonal'] == dg).all(), q
+    assert total >= ps.n // 2
