@@ -79,10 +79,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     import torch
     dist = None
+    # SD_BENCH_REHEARSAL=1: rehearse the N > 1 path on a box with one GPU -- every rank on cuda:0, gloo instead of RCCL
+    rehearsal = os.environ.get('SD_BENCH_REHEARSAL') == '1'
+    dev_index = 0 if rehearsal else local_rank
+    to_dev = (lambda t: t) if rehearsal else (lambda t: t.cuda())
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        torch.cuda.set_device(dev_index)
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     from spacedust_amd.api import Host, Context
     from spacedust_amd.pipeline import SetDB, ClusterSearch
     from spacedust_amd.synth import make_proteomes
@@ -91,7 +98,7 @@ def main():
     # host stages: a bounded share of the cores (never saturate the box)
     n_threads = max(1, effective_cpus() // max(1, world))
     host = Host(n_threads)
-    gpu = Context(local_rank if world > 1 else 0)
+    gpu = Context(dev_index if world > 1 else 0)
     t0 = time.time()
     ps = make_proteomes(P, genes_per_proteome=args.genes, seed=0x5ED0 + 2)
     t_gen = time.time() - t0
@@ -145,7 +152,7 @@ def main():
     gathered = None
     if dist is not None:
         # final result gather over RCCL (xGMI): per-rank result summary
-        tsum = torch.from_numpy(summary).cuda()
+        tsum = to_dev(torch.from_numpy(summary))
         gathered = [torch.zeros_like(tsum) for _ in range(world)]
         dist.all_gather(gathered, tsum)
     gpu.synchronize()
@@ -168,10 +175,10 @@ def main():
         sys.stderr.write('threads: ' + ' | '.join('%s %.1fs' % (n, c) for c, n, _ in rows[:24]) + '\n')
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64).cuda()
+        tmax = to_dev(torch.tensor([dt], dtype=torch.float64))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_max = float(tmax.item())
-        tot = torch.tensor([pairs_done], dtype=torch.float64).cuda()
+        tot = to_dev(torch.tensor([pairs_done], dtype=torch.float64))
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         pairs_total = float(tot.item())
     else:
@@ -262,7 +269,7 @@ def main():
         'host_cores': os.cpu_count(),
         'host_cpu_quota': effective_cpus(),
     }
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:   # the CPU leg belongs to the single-GPU run only
         import tempfile
         ent = os.path.join(tempfile.gettempdir(), 'sd_bench_entries_%d.npz' % os.getpid())
         if cs.last_entries is not None:
