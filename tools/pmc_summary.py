@@ -37,5 +37,32 @@ def main(fetch_csv, write_csv):
         print('%-72s %7d %14.3f %14.3f %16.0f' % (k, n, fb / 1e9, wb / 1e9, tot / max(n, 1)))
 
 
+GROUPS = [('sdpk::sw_score_pk_kernel', 'sw_score_pk'), ('sw_score_kernel', 'sw_score'), ('sw_traceback', 'sw_traceback'),
+          ('emit_kmers', 'prefilter_emit_kmers'), ('count_kmers', 'prefilter_count_kmers'), ('gather_hits', 'prefilter_gather_hits'),
+          ('partition_hits', 'prefilter_partition_hits'), ('bucket_match', 'prefilter_bucket_match'),
+          ('score_diag', 'prefilter_score_diag'), ('select_hits', 'prefilter_select_hits'), ('clusterhits', 'clusterhits')]
+
+
+def to_json(fetch_csv, write_csv, out_path):
+    """the same numbers grouped the way bench.py names its kernel groups (variants of one template summed)"""
+    import json
+    f, w = load(fetch_csv), load(write_csv)
+    out = {}
+    for k in set(f) | set(w):
+        g = next((name for key, name in GROUPS if key in k), None)
+        if g is None:
+            continue
+        o = out.setdefault(g, dict(launches=0, fetch=0.0, write=0.0))
+        o['launches'] += max(f.get(k, [0, 0])[0], w.get(k, [0, 0])[0])
+        o['fetch'] += 2.0 * f.get(k, [0, 0.0])[1] * 1024
+        o['write'] += w.get(k, [0, 0.0])[1] * 1024
+    res = {g: dict(launches=o['launches'], fetch_bytes_per_launch=o['fetch'] / max(o['launches'], 1),
+                   write_bytes_per_launch=o['write'] / max(o['launches'], 1),
+                   bytes_per_launch=(o['fetch'] + o['write']) / max(o['launches'], 1)) for g, o in out.items()}
+    json.dump(res, open(out_path, 'w'), indent=1)
+
+
 if __name__ == '__main__':
     main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 3:
+        to_json(sys.argv[1], sys.argv[2], sys.argv[3])
