@@ -1173,8 +1173,7 @@ keep_max_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const int32_t
     keep[c] = ok ? 1 : 0;
 }
 
-// K7: one workgroup per query
-constexpr int SEL_CAP = 4096;
+// K7: one workgroup per query; SEL_CAP = LDS sorter capacity (48 KB at 4 096; 8 192 for result lists beyond 2 047 hits)
 __device__ __forceinline__ void bitonicSort(unsigned long long *keys, uint32_t *pay, int n /* power of two */) {
     for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -1194,6 +1193,7 @@ __device__ __forceinline__ void bitonicSort(unsigned long long *keys, uint32_t *
     __syncthreads();
 }
 
+template <int SEL_CAP>
 __global__ void __launch_bounds__(256)
 select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, into kept arrays */,
                    const uint32_t *__restrict__ kKey, const uint32_t *__restrict__ kVal,
@@ -2179,9 +2179,14 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, dOutCount.alloc(bq));
         {
             ProfScope ps(ctx, "prefilter_select_hits");
-            hipLaunchKernelGGL(select_hits_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
-                               dDiag.p, dQHitBase.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
-                               par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln);
+            if (maxHits + 1 <= 2048)
+                hipLaunchKernelGGL(select_hits_kernel<4096>, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
+                                   dDiag.p, dQHitBase.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
+                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln);
+            else   // up to 4 095 hits per query (--max-seqs 2N beyond ~1 000 proteomes)
+                hipLaunchKernelGGL(select_hits_kernel<8192>, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
+                                   dDiag.p, dQHitBase.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
+                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln);
         }
         SD_HIP(ctx, hipGetLastError());
         hs.reset(new HostScope(ctx, "pf.download"));
@@ -2193,8 +2198,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         if (stats) SD_HIP(ctx, hipMemcpyAsync(stats + (size_t) qBeg * 4, dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, sdStreamSync(ctx));
         if (hErr == 2)
-            return sdFail(ctx, SD_EUNSUPPORTED, "more than %d candidates at the score cut of one query together with maxHitsPerQuery > %d",
-                          SEL_CAP, SEL_CAP / 2 - 1);
+            return sdFail(ctx, SD_EUNSUPPORTED, "maxHitsPerQuery > 4095 together with more than 8192 candidates at the score cut of one query");
         hs.reset(new HostScope(ctx, "pf.scatter"));
         // the caller's rows are par->maxHitsPerQuery wide
         for (uint32_t x = 0; x < bq; x++)

@@ -230,3 +230,44 @@ def test_prefilter_parameters_match_oracle(gpu, host, oracle, small_proteomes, b
         assert n == len(ids), (q, n, len(ids))
         assert (hits[q, :n]['seqId'] == ids).all() and (hits[q, :n]['score'] == sc).all() and (hits[q, :n]['diagonal'] == dg).all(), q
     assert total >= ps.n // 2
+
+
+def test_prefilter_long_result_lists(gpu, host, oracle):
+    """result lists beyond 2 047 hits (--max-seqs 2N past ~1 000 proteomes) use the 8 192-entry selection: one family of
+    3 600 near-identical sequences, so thousands of targets pass every cut (and saturate the 8-bit score: the list is
+    cut inside the rescaled tie classes)"""
+    rng = np.random.default_rng(404)
+    aa = 'ACDEFGHIKLMNPQRSTVWY'
+    base = ''.join(rng.choice(list(aa), 220))
+    seqs = [base]
+    for _ in range(3600):
+        sq = list(base)
+        for p in np.nonzero(rng.random(len(sq)) < rng.uniform(0.02, 0.35))[0]:
+            sq[p] = aa[rng.integers(20)]
+        seqs.append(''.join(sq))
+    seqs += [''.join(rng.choice(list(aa), int(rng.integers(100, 300)))) for _ in range(400)]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    res, off = host.map_sequences(seqs)
+    sw_b, dg_b, km_b = host.comp_bias(res, off)
+    idx = host.build_index(res, off)
+    tgt = api.Target(gpu, host, idx)
+    ot = oracle.target(res, off)
+    queries = [int(np.nonzero(order == 0)[0][0]), 5, 17, 123]
+    qoff = np.zeros(len(queries) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(seqs[q]) for q in queries])
+    qres = np.concatenate([res[int(off[q]):int(off[q + 1])] for q in queries])
+    qkm = np.concatenate([km_b[int(off[q]):int(off[q + 1])] for q in queries])
+    qdg = np.concatenate([dg_b[int(off[q]):int(off[q + 1])] for q in queries])
+    for max_hits, min_diag in ((3000, 15), (2500, 1), (4000, 15)):
+        par = api.prefilter_params(host, idx.n, max_hits=max_hits, min_diag=min_diag, cov_thr=0.0, bin_size=4)
+        hits, cnt, _ = api.prefilter(gpu, tgt, par, qres, qoff, qkm, qdg, np.array(queries, np.uint32))
+        longest = 0
+        for x, q in enumerate(queries):
+            ids, sc, dg, _ = ot.prefilter(res[int(off[q]):int(off[q + 1])], identity_id=q, max_hits=max_hits, min_diag=min_diag,
+                                          bin_size=4)
+            n = int(cnt[x])
+            longest = max(longest, n)
+            assert n == len(ids), (max_hits, q, n, len(ids))
+            assert (hits[x, :n]['seqId'] == ids).all() and (hits[x, :n]['score'] == sc).all() and (hits[x, :n]['diagonal'] == dg).all(), q
+        assert longest > 2048, (max_hits, longest)
