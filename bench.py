@@ -258,7 +258,8 @@ def main():
         'sw_cells': {'forward': st['cells_fwd'], 'reverse': st['cells_rev'], 'traceback': st['cells_tb']},
         'prefilter': {'queries': args.steps * B * args.genes, 'kernel_ms': pf_ms, 'algorithmic_bytes': b_pref,
                       'achieved_GBs': b_pref / pf_ms / 1e6 if pf_ms > 0 else 0.0, 'index_hits': st['index_hits'],
-                      'kmers': st['kmers'], 'hits': st['prefilter_hits']},
+                      'kmers': st['kmers'], 'hits': st['prefilter_hits'],
+                      'queries_per_s': args.steps * B * args.genes / dt if dt > 0 else 0.0},
         'kernels': kernels,
         'stage_wall_s': stage,
         'host_cpu_s_per_step': round(host_cpu_s / max(1, args.steps), 3),
