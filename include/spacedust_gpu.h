@@ -222,6 +222,12 @@ int sd_host_map_sequence(sd_host *h, const char *ascii, uint64_t len, uint8_t *o
 /* SubstitutionMatrix::calcLocalAaBiasCorrection + the three integer roundings, for n sequences */
 int sd_host_comp_bias(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
                       int8_t *swBias, int8_t *diagBias, int16_t *kmerBias);
+/* The three integer composition-bias arrays of sd_host_comp_bias, computed on the device (same values, bit for bit:
+ * the kernel forms calcLocalAaBiasCorrection's integer window sums, SubstitutionMatrix.cpp:79-109, and reads the float
+ * tail from a table the host evaluated with the reference's expression order).  For callers short of host cores. */
+int sd_comp_bias_batch(sd_ctx *ctx, sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
+                       int8_t *swBias, int8_t *diagBias, int16_t *kmerBias);
+
 /* IndexBuilder::fillDatabase (mask + count + fill), returns an index handle to read back */
 typedef struct sd_host_index sd_host_index;
 int sd_host_index_build(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,

@@ -106,6 +106,7 @@ def load():
         'sd_target_destroy': (None, [_vp]),
         'sd_prefilter_batch': (C.c_int, [_vp, _vp, C.POINTER(PrefilterParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _vp]),
+        'sd_comp_bias_batch': (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_int, _vp, _vp, _vp]),
         'sd_prefilter_profile_batch': (C.c_int, [_vp, _vp, C.POINTER(PrefilterParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp,
                                                  _vp, _vp, _vp, _vp]),
         'sd_profileset_create': (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
@@ -142,7 +143,7 @@ DECLARED_SYMBOLS = [
     'sd_ctx_create', 'sd_ctx_create_prio', 'sd_ctx_destroy', 'sd_last_error', 'sd_device_name', 'sd_synchronize', 'sd_profile_enable',
     'sd_profile_reset', 'sd_profile_get', 'sd_profile_names', 'sd_seqset_create', 'sd_seqset_destroy',
     'sd_sw_align_batch', 'sd_sw_align_batch_compact', 'sd_sw_align_batch_hostpath', 'sd_sw_score_batch', 'sd_sw_last_cells', 'sd_target_create', 'sd_target_destroy',
-    'sd_prefilter_batch', 'sd_prefilter_profile_batch', 'sd_profileset_create', 'sd_host_map_profiles',
+    'sd_prefilter_batch', 'sd_comp_bias_batch', 'sd_prefilter_profile_batch', 'sd_profileset_create', 'sd_host_map_profiles',
     'sd_host_profile_kmer_threshold', 'sd_clusterhits_batch', 'sd_host_create', 'sd_host_destroy', 'sd_host_matrix',
     'sd_host_map_sequence', 'sd_host_comp_bias', 'sd_host_index_build', 'sd_host_index_info', 'sd_host_index_arrays',
     'sd_host_index_destroy', 'sd_host_ext_matrix', 'sd_host_kmer_threshold', 'sd_host_auto_kmer_size', 'sd_host_bin_size', 'sd_host_pair_list',

@@ -174,6 +174,17 @@ class Context:
     def seqset(self, residues, offsets, sw_bias=None):
         return SeqSet(self, residues, offsets, sw_bias)
 
+    def comp_bias(self, host, residues, offsets, k=6):
+        """sd_comp_bias_batch: the (sw int8, diag int8, kmer int16) bias arrays of Host.comp_bias, formed on the device"""
+        residues = np.ascontiguousarray(residues, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        sw = np.zeros(len(residues), np.int8)
+        dg = np.zeros(len(residues), np.int8)
+        km = np.zeros(len(residues), np.int16)
+        _check(self.h, self.L.sd_comp_bias_batch(self.h, host.h, ptr(residues), ptr(offsets), len(offsets) - 1, k, ptr(sw), ptr(dg),
+                                                 ptr(km)), 'sd_comp_bias_batch')
+        return sw, dg, km
+
     def profileset(self, letters, offsets, aln):
         """profile queries for sw_align (sd_profileset_create): query letters + int8 alignment profile [P, 21]"""
         return SeqSet(self, letters, offsets, None, aln=aln)

@@ -28,6 +28,7 @@ struct sd_ctx {
     bool profiling = false;
     std::map<std::string, sd_profile_entry> profile;
     hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool biasTablesUploaded = false;   // sd_comp_bias_batch: correction tables resident in this context's workspace
     hipEvent_t evSync = nullptr;   // blocking-sync event: host threads sleep while they wait for the stream (sdStreamSync)
     uint64_t cellsFwd = 0, cellsRev = 0, cellsTb = 0;
     hipDeviceProp_t prop;

@@ -10,13 +10,6 @@
 #include <cstring>
 #include <unistd.h>
 
-struct sd_host {
-    sd::SubMat blosum2, ungapped2, seed8;
-    sd::ExtMatrix two, three;
-    bool haveTwo = false, haveThree = false;
-    int threads = 1;
-};
-
 struct sd_host_index {
     sd::TargetIndex idx;
 };

@@ -58,6 +58,11 @@ struct ExtMatrix {
 };
 void buildExtMatrix(const SubMat &seed8, int wordLen, ExtMatrix &out, int threads);
 
+// the complete (residue, window length, window sum) -> correction table of calcLocalAaBiasCorrection's float tail
+// (every entry evaluated with the reference's expression order): tab[(residue * 41 + windowLength) * span + (sum - lo)];
+// the device-side composition bias forms the integer sums and reads the corrections from here
+void biasTableFull(const SubMat &m, std::vector<float> &tab, int &lo, int &span);
+
 // spaced seed patterns (M/src/commons/Sequence.h:22-25)
 int spacedPattern(int k, uint8_t *pos /* k entries */);   // returns span
 
@@ -161,4 +166,15 @@ std::string compressBacktrace(const char *bt, size_t n);
 void compressBacktraceAppend(const char *bt, size_t n, std::string &out);
 
 }  // namespace sd
+
+// the host-side handle behind sd_host_* (include/spacedust_gpu.h); the device code reads the matrices from it
+struct sd_host {
+    sd::SubMat blosum2, ungapped2, seed8;
+    sd::ExtMatrix two, three;
+    bool haveTwo = false, haveThree = false;
+    int threads = 1;
+    // composition-bias tables for the device path (built on first use)
+    std::vector<float> biasTabSeed, biasTabBlosum;
+    int biasLoSeed = 0, biasSpanSeed = 0, biasLoBlosum = 0, biasSpanBlosum = 0;
+};
 #endif

@@ -194,6 +194,22 @@ void calcLocalAaBiasCorrection(const SubMat &m, const uint8_t *seq, int N, float
     }
 }
 
+void biasTableFull(const SubMat &m, std::vector<float> &tab, int &lo, int &span) {
+    int mn = 0, mx = 0;
+    for (int a = 0; a < ALPH; a++)
+        for (int c = 0; c < ALPH; c++) {
+            mn = std::min(mn, (int) m.sub[a][c]);
+            mx = std::max(mx, (int) m.sub[a][c]);
+        }
+    lo = 40 * mn - mx;
+    span = (40 * mx - mn) - lo + 1;
+    tab.assign((size_t) ALPH * 41 * span, 0.0f);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int r = 0; r < ALPH; r++)
+        for (int w = 1; w <= 40; w++)
+            for (int x = 0; x < span; x++) tab[((size_t) r * 41 + w) * span + x] = biasTail(m, m.sub[r], lo + x, w);
+}
+
 void swCompBias8(const SubMat &blosum2, const uint8_t *seq, int N, int8_t *out) {
     std::vector<float> cb(N > 0 ? N : 1);
     calcLocalAaBiasCorrection(blosum2, seq, N, cb.data(), 1.0f);

@@ -68,7 +68,8 @@ class ClusterSearch:
 
     def __init__(self, ctx, host, target_db, sensitivity=5.7, max_seqs=300, eval_thr=10.0, cov_mode=2, cov_thr=0.8,
                  aln_len_thr=30, max_gene_gap=3, cluster_size=2, alpha=1.0, p_clu_thr=0.01, p_mh_thr=0.01,
-                 filter_self_match=True, bin_size=None, verbose=False, align_ctx=None, k=None, profile_queries=False):
+                 filter_self_match=True, bin_size=None, verbose=False, align_ctx=None, k=None, profile_queries=False,
+                 device_bias=None):
         """ctx runs the prefilter (and clusterhits); align_ctx -- a second context (own HIP stream and workspace)
         on the same device, created here if not given -- runs the alignments, so that the prefilter of the next
         chunk (HBM random-access bound) and the Smith-Waterman of the current one (integer-VALU bound) share the
@@ -76,6 +77,12 @@ class ClusterSearch:
         self.ctx, self.host, self.T = ctx, host, target_db
         self.ctx_al = align_ctx if align_ctx is not None else api.Context(ctx.device_index, priority=int(os.environ.get('SD_ALIGN_PRIO', '1')))
         self.verbose = verbose
+        # composition bias of the queries on the device (own context and stream) when host cores are scarce (a rank's share
+        # of a multi-GPU node): same values bit for bit (sd_comp_bias_batch), ~0.5 core-seconds per 30 000 queries saved
+        if device_bias is None:
+            from .cpus import effective_cpus
+            device_bias = effective_cpus() // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1'))) < 8
+        self.ctx_bias = api.Context(ctx.device_index) if device_bias else None
         # -k 0 semantics (IndexTable::computeKmerSize, IndexTable.h:439-441): 6 below 3.35e9 target residues, 7 from there on
         self.k = int(k) if k else host.auto_kmer_size(int(target_db.offsets[-1]))
         # profile searches: own threshold table, and the target index keeps every non-X k-mer (Prefiltering.cpp:525-527,1019-1043)
@@ -151,7 +158,10 @@ class ClusterSearch:
             t0 = time.time()
             if Q.profile is not None:   # no composition bias for profile queries (QueryMatcher.cpp:93-99, ssw_init :1229-1240)
                 return res, off, None, None, None, 0.0
-            sw_b, dg_b, km_b = self.host.comp_bias(res, off, self.k)
+            if self.ctx_bias is not None:
+                sw_b, dg_b, km_b = self.ctx_bias.comp_bias(self.host, res, off, self.k)
+            else:
+                sw_b, dg_b, km_b = self.host.comp_bias(res, off, self.k)
             return res, off, sw_b, dg_b, km_b, time.time() - t0
 
         def prefilter_job(c0, c1, bias_future):

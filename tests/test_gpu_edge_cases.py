@@ -73,3 +73,25 @@ def test_alignment_edge_cases(gpu, host, oracle):
     # no pairs at all
     out0, pool0 = gpu.sw_align(par, ss, ss, np.zeros(0, np.uint32), np.zeros(0, np.uint32))
     assert len(out0) == 0
+
+
+def test_device_composition_bias_equals_host(gpu, host, oracle, small_proteomes):
+    """sd_comp_bias_batch (integer window sums on the device + the host's correction table) against sd_host_comp_bias,
+    which is pinned bitwise to the reference's calcLocalAaBiasCorrection: all three arrays, every residue, including
+    sequences shorter than the window, of exactly the window, X runs, and both seed patterns"""
+    seqs, nums, res, off = _db(oracle)
+    rng = np.random.default_rng(12)
+    extra = [''.join(rng.choice(list(AA), L)) for L in (19, 20, 21, 39, 40, 41, 42, 400)]
+    nums2 = nums + [oracle.map_sequence(s) for s in extra]
+    off2 = np.zeros(len(nums2) + 1, np.uint64)
+    off2[1:] = np.cumsum([len(x) for x in nums2])
+    res2 = np.concatenate(nums2)
+    ps = small_proteomes
+    for r, o in ((res2, off2), (ps.residues, ps.offsets)):
+        for k in (6, 7):
+            hs, hd, hk = host.comp_bias(r, o, k)
+            ds, dd, dk = gpu.comp_bias(host, r, o, k)
+            assert np.array_equal(hs, ds), k
+            assert np.array_equal(hd, dd), k
+            assert np.array_equal(hk, dk), k
+    assert np.abs(hs).max() > 0 and np.abs(hk).max() > 0
