@@ -58,3 +58,63 @@ def test_examples_regression_known_answers(gpu, host, tmp_path):
     assert (n_hit, sig, n_clu) == (308, 2, 108)
     lines.sort(key=lambda s: s.encode())
     assert hashlib.md5(''.join(lines).encode()).hexdigest() == 'abb28ee37bc130a5f09a9f767ef00ccf'
+
+
+def test_synthetic_proteomes_match_real_reference(gpu, host):
+    """BASELINE configs[1]-like data (synthetic proteomes, --max-seqs 300) at a size the suite can afford (40 proteomes,
+    1.2e5 targets): device prefilter rows and alignments against the REAL reference classes run beside it
+    (oracle/_ref/libsdref.so travels with the snapshot).  tools/scale_parity.py is the same check at 1 000 proteomes."""
+    from oracle.pyoracle import Ref, RefSW, ref_available
+    if not ref_available():
+        pytest.skip('oracle/_ref/libsdref.so not present on this box')
+    from spacedust_amd import api
+    from spacedust_amd.synth import make_proteomes, ALPHABET
+    ps = make_proteomes(40, genes_per_proteome=3000, seed=0x5ED0 + 2)
+    lens = ps.lengths()
+    rng = np.random.default_rng(9)
+    queries = np.concatenate([np.argsort(-lens)[:6], rng.choice(ps.n, 60, replace=False)]).astype(np.int64)
+    qoff = np.zeros(len(queries) + 1, np.uint64)
+    qoff[1:] = np.cumsum(lens[queries])
+    qres = np.concatenate([ps.residues[int(ps.offsets[q]):int(ps.offsets[q + 1])] for q in queries])
+    sw_b, dg_b, km_b = host.comp_bias(qres, qoff)
+    idx = host.build_index(ps.residues, ps.offsets)
+    tgt = api.Target(gpu, host, idx)
+    par = api.prefilter_params(host, idx.n, max_hits=300, cov_thr=0.0, bin_size=None)
+    hits, cnt, _ = api.prefilter(gpu, tgt, par, qres, qoff, km_b, dg_b, queries.astype(np.uint32))
+    blob = np.frombuffer(ALPHABET.encode(), np.uint8)[ps.residues].tobytes()
+    ref = Ref(6)
+    rix = ref.index(blob, ps.offsets, threads=8)
+    assert rix.n_entries == idx.n_entries
+    rpf = rix.prefilter(int(lens.max()) + 2, max_hits=300)
+    for x, q in enumerate(queries):
+        ids, sc, dg, _ = rpf.query(blob[int(ps.offsets[q]):int(ps.offsets[q + 1])], int(q))
+        n = int(cnt[x])
+        assert n == len(ids), (q, n, len(ids))
+        assert (hits[x, :n]['seqId'] == ids).all() and (hits[x, :n]['score'] == sc).all() and (hits[x, :n]['diagonal'] == dg).all(), q
+    assert int(cnt.sum()) > 3000
+    mat, _, _ = host.matrix(0)
+    db = int(ps.offsets[-1])
+    ts = gpu.seqset(ps.residues, ps.offsets, None)
+    qs = gpu.seqset(qres, qoff, sw_b)
+    spar = gpu.sw_params(mat, db)
+    pq = np.array([x for x in range(6, 26) for _ in range(min(25, int(cnt[x])))], np.uint32)
+    pt = np.array([int(hits[x, h]['seqId']) for x in range(6, 26) for h in range(min(25, int(cnt[x])))], np.uint32)
+    ident = queries[pq] == pt
+    out, pool = gpu.sw_align(spar, qs, ts, pq, pt, identity=ident)
+    sw = RefSW(ref, int(lens.max()) + 2, db)
+    last, n_bt = -1, 0
+    for i in range(len(pq)):
+        if pq[i] != last:
+            q = queries[pq[i]]
+            sw.set_query(blob[int(ps.offsets[q]):int(ps.offsets[q + 1])])
+            last = pq[i]
+        t = pt[i]
+        r = sw.align(blob[int(ps.offsets[t]):int(ps.offsets[t + 1])], identity=bool(ident[i]))
+        o = out[i]
+        assert (int(o['score']), int(o['qEnd']), int(o['tEnd']), int(o['btLen'])) == (r['score'], r['qEnd'], r['tEnd'], r['btLen']), i
+        if r['btLen'] > 0:
+            n_bt += 1
+            bt = pool[int(o['btOffset']):int(o['btOffset']) + int(o['btLen'])].tobytes().decode()
+            assert bt == r['backtrace'] and (int(o['qStart']), int(o['tStart'])) == (r['qStart'], r['tStart']), i
+            assert float(o['evalue']) == r['evalue'], i
+    assert n_bt > 100
