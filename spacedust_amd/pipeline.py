@@ -239,7 +239,7 @@ class ClusterSearch:
             L.sd_agg_destroy(agg)
             return dict(entries=ne, matched_hits=nh, clusters=n_clusters, cluster_hits=n_cluster_hits, aligned=na.value,
                         accepted=nacc.value, timing={}, entry_q=eq, entry_t=et, entry_off=entry_off, cluster_out=out,
-                        hit_q=hq, hit_t=ht)
+                        hit_q=hq, hit_t=ht, hit_pval=pv)
 
         chunks = []
         for ri, (a0, b0) in enumerate(ranges):

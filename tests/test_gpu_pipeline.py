@@ -118,3 +118,27 @@ def test_synthetic_proteomes_match_real_reference(gpu, host):
             assert bt == r['backtrace'] and (int(o['qStart']), int(o['tStart'])) == (r['qStart'], r['tStart']), i
             assert float(o['evalue']) == r['evalue'], i
     assert n_bt > 100
+
+
+def test_clusterhits_on_pipeline_entries_matches_oracle(gpu, host, oracle):
+    """the (query set, target set) entries a real search produces on whole synthetic proteomes (K of a few thousand hits,
+    long syntenic blocks, inversions): device clusterhits against the oracle's dense restatement, entry by entry"""
+    from oracle.pyoracle import oracle_clusterhits
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(3, genes_per_proteome=3000, seed=0x5ED0 + 2)
+    db = SetDB.from_proteomes(ps)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300)
+    out = cs.search(db, same_db=True, chunk_queries=4000)
+    co, off = out['cluster_out'], out['entry_off']
+    assert len(out['entry_q']) == 6 and int(co['n_clusters'].sum()) > 50
+    for e in range(len(out['entry_q'])):
+        a, b = int(off[e]), int(off[e + 1])
+        assert b - a > 100
+        hq, ht = out['hit_q'][a:b], out['hit_t'][a:b]
+        sd = (db.strand[hq] | (db.strand[ht] << 1)).astype(np.uint8)
+        cof, mo, csz, pco, pmh, nm = oracle_clusterhits(oracle, db.pos_in_set[hq], db.pos_in_set[ht], sd, out['hit_pval'][a:b],
+                                                        int(db.set_size[out['entry_q'][e]]))
+        n = len(csz)
+        assert int(co['n_clusters'][e]) == n, (e, co['n_clusters'][e], n)
+        assert (co['cluster_of'][a:b] == cof).all(), e
+        assert (co['size'][a:a + n] == csz).all() and (co['pCO'][a:a + n] == pco).all() and (co['pMH'][a:a + n] == pmh).all(), e
