@@ -142,3 +142,66 @@ def test_clusterhits_on_pipeline_entries_matches_oracle(gpu, host, oracle):
         assert int(co['n_clusters'][e]) == n, (e, co['n_clusters'][e], n)
         assert (co['cluster_of'][a:b] == cof).all(), e
         assert (co['size'][a:a + n] == csz).all() and (co['pCO'][a:a + n] == pco).all() and (co['pMH'][a:a + n] == pmh).all(), e
+
+
+def test_multi_set_aggregation_matches_restatement(gpu, host, oracle, small_proteomes):
+    """three query / target sets with --filter-self-match: the fused aggregation (prefixid -> besthitbyset ->
+    mergeresultsbyset -> combinehits incl. the two %.3E text round trips, clustersearch.sh:121-151) against a plain Python
+    restatement fed with the oracle's prefilter hits and alignments: same (query set, target set) entries, same hits in
+    the same order, bit-identical P-values"""
+    import math
+    import sys
+    ps = small_proteomes
+    db = SetDB.from_proteomes(ps)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2)
+    out = cs.search(db, same_db=True, chunk_queries=100)
+    ot = oracle.target(ps.residues, ps.offsets)
+    db_res = int(ps.offsets[-1])
+    lens = ps.lengths()
+    dbl_min = sys.float_info.min
+
+    def logpval(ev):   # besthitbyset.cpp:49-63,129
+        if ev == 0:
+            return math.log(dbl_min)
+        if 0 < ev < 10e-4:
+            return math.log(ev)
+        return math.log(1 - math.exp(-ev))
+
+    best = {}   # (query, target set) -> (sort key, target)
+    for q in range(ps.n):
+        seq = ps.residues[int(ps.offsets[q]):int(ps.offsets[q + 1])]
+        ids, _, _, _ = ot.prefilter(seq, identity_id=q, max_hits=300, bin_size=2)
+        for t in ids:
+            t = int(t)
+            if not (np.float32(lens[t]) / np.float32(lens[q]) >= np.float32(0.8)):   # Util::canBeCovered, COV_MODE_QUERY
+                continue
+            r = oracle.sw_align(seq, ps.residues[int(ps.offsets[t]):int(ps.offsets[t + 1])], db_res, identity=(t == q))
+            if t != q:
+                if r['btLen'] <= 0 or r['qStart'] < 0:
+                    continue
+                qcov = np.float32(r['qEnd'] - r['qStart'] + 1) / np.float32(lens[q])
+                if not (r['evalue'] <= 10.0 and qcov >= np.float32(0.8) and r['btLen'] >= 30):
+                    continue
+            key = (r['evalue'], -int(oracle.bitscore(r['score']) + 0.5), int(lens[t]), t)   # Matcher::compareHits
+            ts = int(ps.set_id[t])
+            if (q, ts) not in best or key < best[(q, ts)][0]:
+                best[(q, ts)] = (key, t)
+    expected = {}
+    thr = math.log(10e-7)   # combinehits.cpp:101-103
+    for (q, ts), (key, t) in sorted(best.items()):
+        qs = int(ps.set_id[q])
+        if qs == ts:
+            continue   # --filter-self-match (combinehits.cpp:83)
+        lp = float('%.3E' % logpval(float('%.3E' % key[0])))   # the alignment DB carries the E-value as %.3E text (Matcher.cpp:288)
+        if lp < thr:
+            expected.setdefault((qs, ts), []).append((q, t, float('%.3E' % math.exp(lp))))
+    got = {}
+    off = out['entry_off']
+    for e in range(len(out['entry_q'])):
+        a, b = int(off[e]), int(off[e + 1])
+        got[(int(out['entry_q'][e]), int(out['entry_t'][e]))] = [(int(out['hit_q'][x]), int(out['hit_t'][x]), float(out['hit_pval'][x]))
+                                                                  for x in range(a, b)]
+    assert sorted(got) == sorted(expected)
+    assert len(expected) == 6 and sum(len(v) for v in expected.values()) > 100
+    for k_ in expected:
+        assert got[k_] == expected[k_], k_
