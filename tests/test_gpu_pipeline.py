@@ -205,3 +205,34 @@ def test_multi_set_aggregation_matches_restatement(gpu, host, oracle, small_prot
     assert len(expected) == 6 and sum(len(v) for v in expected.values()) > 100
     for k_ in expected:
         assert got[k_] == expected[k_], k_
+
+
+def test_pipeline_with_k7(gpu, host, oracle, small_proteomes):
+    """the search with k = 7 forced (what -k 0 selects from 3.35e9 target residues): hit and accepted-alignment counts
+    against the oracle run stage by stage (the oracle's k = 7 prefilter is pinned to the real reference, k7_vectors.npz)"""
+    ps = small_proteomes
+    db = SetDB.from_proteomes(ps)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, k=7)
+    assert cs.k == 7 and cs.kmer_thr == 122
+    out = cs.search(db, same_db=True, chunk_queries=150)
+    ot = oracle.target(ps.residues, ps.offsets, k=7, kmer_thr=122)
+    lens = ps.lengths()
+    db_res = int(ps.offsets[-1])
+    n_hits = n_acc = 0
+    for q in range(ps.n):
+        seq = ps.residues[int(ps.offsets[q]):int(ps.offsets[q + 1])]
+        ids, _, _, _ = ot.prefilter(seq, identity_id=q, kmer_thr=122, max_hits=300, bin_size=2)
+        ids = ids[(lens[ids.astype(np.int64)].astype(np.float32) / np.float32(lens[q])) >= np.float32(0.8)]
+        n_hits += len(ids)
+        for t in ids:
+            t = int(t)
+            if t == q:
+                n_acc += 1
+                continue
+            r = oracle.sw_align(seq, ps.residues[int(ps.offsets[t]):int(ps.offsets[t + 1])], db_res)
+            if r['btLen'] > 0 and r['qStart'] >= 0 and r['evalue'] <= 10.0 and r['btLen'] >= 30 and \
+                    np.float32(r['qEnd'] - r['qStart'] + 1) / np.float32(lens[q]) >= np.float32(0.8):
+                n_acc += 1
+    assert cs.stats['prefilter_hits'] == n_hits, (cs.stats['prefilter_hits'], n_hits)
+    assert out['accepted'] == n_acc, (out['accepted'], n_acc)
+    assert n_acc > ps.n
