@@ -2191,9 +2191,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, hipGetLastError());
         hs.reset(new HostScope(ctx, "pf.download"));
         int hErr = 0;
-        std::vector<sd_hit> hOut((size_t) bq * maxHits);
+        sd_hit *hOutP = nullptr;   // pinned, persistent: a pageable destination makes this copy a staged, synchronous one
+        SD_HIP(ctx, pinGet(ctx, "pf.hOut", (size_t) bq * maxHits + 1, &hOutP));
         SD_HIP(ctx, hipMemcpyAsync(&hErr, dErr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SD_HIP(ctx, hipMemcpyAsync(hOut.data(), dOut.p, hOut.size() * sizeof(sd_hit), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, hipMemcpyAsync(hOutP, dOut.p, (size_t) bq * maxHits * sizeof(sd_hit), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(outCount + qBeg, dOutCount.p, bq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         if (stats) SD_HIP(ctx, hipMemcpyAsync(stats + (size_t) qBeg * 4, dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, sdStreamSync(ctx));
@@ -2202,7 +2203,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         hs.reset(new HostScope(ctx, "pf.scatter"));
         // the caller's rows are par->maxHitsPerQuery wide
         for (uint32_t x = 0; x < bq; x++)
-            memcpy(outHits + (size_t) (qBeg + x) * par->maxHitsPerQuery, hOut.data() + (size_t) x * maxHits,
+            memcpy(outHits + (size_t) (qBeg + x) * par->maxHitsPerQuery, hOutP + (size_t) x * maxHits,
                    (size_t) std::min<uint32_t>(outCount[qBeg + x], maxHits) * sizeof(sd_hit));
         hs.reset();
         qBeg += bq;
