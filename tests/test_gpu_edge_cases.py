@@ -95,3 +95,48 @@ def test_device_composition_bias_equals_host(gpu, host, oracle, small_proteomes)
             assert np.array_equal(hd, dd), k
             assert np.array_equal(hk, dk), k
     assert np.abs(hs).max() > 0 and np.abs(hk).max() > 0
+
+
+def test_stress_db_matches_reference(gpu, host, oracle):
+    """the stress DB (ties from exact duplicates, masked repeats, X-rich, 1 to 3 000 residues) through the C ABI against
+    rows and alignments produced by the real reference (tools/make_golden_stress.py)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from stress_db import stress_db
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'stress_vectors.npz'))
+    seqs = stress_db()
+    res, off = host.map_sequences(seqs)
+    n = len(seqs)
+    sw_b, dg_b, km_b = host.comp_bias(res, off)
+    idx = host.build_index(res, off)
+    assert idx.n_entries == int(g['n_entries'][0]) and idx.masked_residues == int(g['masked'][0])
+    tgt = api.Target(gpu, host, idx)
+    for mh in (300, 7):
+        par = api.prefilter_params(host, idx.n, max_hits=mh, cov_thr=0.0, bin_size=2)
+        hits, cnt, _ = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, np.arange(n, dtype=np.uint32))
+        rows = g['pf_rows_%d' % mh]
+        for q in range(n):
+            exp = rows[rows[:, 0] == q]
+            m = int(cnt[q])
+            assert m == len(exp), (mh, q, m, len(exp))
+            assert (hits[q, :m]['seqId'] == exp[:, 1]).all() and (hits[q, :m]['score'] == exp[:, 2]).all(), (mh, q)
+            assert (hits[q, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (mh, q)
+    mat, _, _ = host.matrix(0)
+    db = int(off[-1])
+    ss = gpu.seqset(res, off, sw_b)
+    spar = gpu.sw_params(mat, db)
+    pq = g['sw_pairs'][:, 0].astype(np.uint32)
+    pt = g['sw_pairs'][:, 1].astype(np.uint32)
+    out, pool = gpu.sw_align(spar, ss, ss, pq, pt, identity=(pq == pt))
+    bts = g['sw_bt'].tobytes().decode().split('\n')
+    for x in range(len(pq)):
+        r, e = out[x], g['sw_res'][x]
+        assert (int(r['score']), int(r['qEnd']), int(r['tEnd']), int(r['btLen'])) == (e[0], e[2], e[4], e[6]), (x, r, e)
+        assert (int(r['qStart']), int(r['tStart'])) == (e[1], e[3]), (x, r, e)
+        ev = g['sw_ev'][x]
+        if ev <= 20.0:
+            assert float(r['evalue']) == ev, (x, r['evalue'], ev)
+        if e[6] > 0:
+            bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
+            assert bt == bts[x] and int(r['identical']) == e[5], x

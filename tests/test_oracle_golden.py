@@ -205,6 +205,38 @@ def test_sw_modes_and_gates(oracle):
                 assert r['identical'] == e[5] and r['backtrace'] == bts[x], (mi, x)
 
 
+def test_stress_db(oracle):
+    """exact duplicates (ties at every cut), tandem repeats / low complexity (tantan), X-rich, 1 to 3 000 residues: index
+    size and masking, prefilter rows at list lengths 300 and 7, 1 219 alignments -- rows from the real reference
+    (tools/make_golden_stress.py)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from stress_db import stress_db
+    g = np.load(os.path.join(GOLD, 'stress_vectors.npz'))
+    seqs = stress_db()
+    nums = [oracle.map_sequence(s) for s in seqs]
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    tgt = oracle.target(np.concatenate(nums), off)
+    assert tgt.n_entries == int(g['n_entries'][0]) and tgt.masked_residues == int(g['masked'][0])
+    for mh in (300, 7):
+        rows = g['pf_rows_%d' % mh]
+        for q in range(len(seqs)):
+            exp = rows[rows[:, 0] == q]
+            ids, sc, dg, _ = tgt.prefilter(nums[q], identity_id=q, max_hits=mh)
+            assert len(ids) == len(exp) and (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all(), (mh, q)
+            assert (dg.astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (mh, q)
+    bts = g['sw_bt'].tobytes().decode().split('\n')
+    db = int(off[-1])
+    for x, (a, b) in enumerate(g['sw_pairs']):
+        r = oracle.sw_align(nums[a], nums[b], db, identity=bool(a == b))
+        e = g['sw_res'][x]
+        assert (r['score'], r['qStart'], r['qEnd'], r['tStart'], r['tEnd'], r['btLen']) == (e[0], e[1], e[2], e[3], e[4], e[6]), x
+        assert r['evalue'] == g['sw_ev'][x], x
+        if e[6] > 0:
+            assert r['identical'] == e[5] and r['backtrace'] == bts[x], x
+
+
 def _load_profiles(oracle):
     g = np.load(os.path.join(GOLD, 'profile_vectors.npz'))
     off = g['off']
