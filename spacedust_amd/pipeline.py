@@ -243,8 +243,13 @@ class ClusterSearch:
 
         chunks = []
         for ri, (a0, b0) in enumerate(ranges):
-            cs_ = [(ri, c0, min(b0, c0 + chunk_queries)) for c0 in range(a0, b0, chunk_queries)]
-            chunks += cs_
+            c0 = a0
+            while c0 < b0:
+                # the very first chunk of a stream is a quarter of the others: its prefilter is the one stage nothing
+                # overlaps with, so the alignment thread starts that much earlier
+                step = chunk_queries if chunks else max(1, min(chunk_queries, max(1000, chunk_queries // 4)))
+                chunks.append((ri, c0, min(b0, c0 + step)))
+                c0 += step
         last_chunk_of = {}
         for x, (ri, _, _) in enumerate(chunks):
             last_chunk_of[ri] = x
