@@ -223,9 +223,13 @@ class Context:
         exact_cap = None
         if bt_cap is None:
             bt_cap = max(1 << 20, 96 * n)
+        if reuse:
+            # one flip per call: a retry after SD_ENOMEM must stay on this call's slot -- the other one still holds the
+            # previous call's records and backtraces, which the caller may be reading (pipeline.py aggregates them
+            # asynchronously)
+            self._flip = 1 - getattr(self, '_flip', 0)
         while True:
             if reuse:
-                self._flip = 1 - getattr(self, '_flip', 0)
                 bufs = self.__dict__.setdefault('_align_bufs', [None, None])
                 b = bufs[self._flip]
                 if b is None or len(b[0]) < n or len(b[1]) < bt_cap:

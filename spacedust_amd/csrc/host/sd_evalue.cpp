@@ -129,10 +129,14 @@ char *i32toa(int32_t v, char *buf) {
 }
 
 char *seqIdToBuffer(float seqId, char *buffer) {
-    // Util::fastSeqIdToBuffer (M/src/commons/Util.cpp:222-251): truncation, not rounding
+    // Util::fastSeqIdToBuffer (M/src/commons/Util.cpp:222-251): truncation, not rounding.  For seqId == 1.0 the
+    // reference writes "1.000" but returns the position OF the terminator, not one past it as its integer branch does,
+    // so the separator every caller stores at ret[-1] (Matcher.cpp:286-287) lands on the last zero: the text every
+    // alignment DB carries for an identity of one is "1.00" (the reference binary's `result` DB: 6 229 such lines on
+    // config 1).
     if (seqId == 1.0) {
-        memcpy(buffer, "1.000", 5);
-        return buffer + 5;
+        memcpy(buffer, "1.00", 4);
+        return buffer + 4;
     }
     *buffer++ = '0';
     *buffer++ = '.';

@@ -68,7 +68,7 @@ class ClusterSearch:
 
     def __init__(self, ctx, host, target_db, sensitivity=5.7, max_seqs=300, eval_thr=10.0, cov_mode=2, cov_thr=0.8,
                  aln_len_thr=30, max_gene_gap=3, cluster_size=2, alpha=1.0, p_clu_thr=0.01, p_mh_thr=0.01,
-                 filter_self_match=True, bin_size=None, verbose=False, align_ctx=None, k=None, profile_queries=False,
+                 filter_self_match=False, bin_size=None, verbose=False, align_ctx=None, k=None, profile_queries=False,
                  device_bias=None):
         """ctx runs the prefilter (and clusterhits); align_ctx -- a second context (own HIP stream and workspace)
         on the same device, created here if not given -- runs the alignments, so that the prefilter of the next

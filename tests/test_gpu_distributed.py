@@ -37,7 +37,7 @@ def _search(sets):
     ps = make_proteomes(6, genes_per_proteome=150, n_families=220, seed=23)
     db = SetDB.from_proteomes(ps)
     host, gpu = Host(4), Context(0)
-    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
     recs = []
     for s in sets:
         out = cs.search(db, same_db=True, query_range=(int(ps.set_start[s]), int(ps.set_start[s + 1])), chunk_queries=64)

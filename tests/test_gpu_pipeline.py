@@ -45,7 +45,7 @@ def load_examples(host):
 
 def test_examples_regression_known_answers(gpu, host, tmp_path):
     db = load_examples(host)
-    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
     out = cs.search(db, same_db=True, tsv_path=str(tmp_path / 'result.tsv'), canonical=True, chunk_queries=3000)
     assert cs.index.n_entries == 1784989 and cs.index.masked_residues == 11546
     assert cs.stats['prefilter_hits'] == 98957
@@ -127,7 +127,7 @@ def test_clusterhits_on_pipeline_entries_matches_oracle(gpu, host, oracle):
     from spacedust_amd.synth import make_proteomes
     ps = make_proteomes(3, genes_per_proteome=3000, seed=0x5ED0 + 2)
     db = SetDB.from_proteomes(ps)
-    cs = ClusterSearch(gpu, host, db, max_seqs=300)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, filter_self_match=True)
     out = cs.search(db, same_db=True, chunk_queries=4000)
     co, off = out['cluster_out'], out['entry_off']
     assert len(out['entry_q']) == 6 and int(co['n_clusters'].sum()) > 50
@@ -153,7 +153,7 @@ def test_multi_set_aggregation_matches_restatement(gpu, host, oracle, small_prot
     import sys
     ps = small_proteomes
     db = SetDB.from_proteomes(ps)
-    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
     out = cs.search(db, same_db=True, chunk_queries=100)
     ot = oracle.target(ps.residues, ps.offsets)
     db_res = int(ps.offsets[-1])
@@ -212,7 +212,7 @@ def test_pipeline_with_k7(gpu, host, oracle, small_proteomes):
     against the oracle run stage by stage (the oracle's k = 7 prefilter is pinned to the real reference, k7_vectors.npz)"""
     ps = small_proteomes
     db = SetDB.from_proteomes(ps)
-    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, k=7)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, k=7, filter_self_match=True)
     assert cs.k == 7 and cs.kmer_thr == 122
     out = cs.search(db, same_db=True, chunk_queries=150)
     ot = oracle.target(ps.residues, ps.offsets, k=7, kmer_thr=122)

@@ -187,7 +187,7 @@ def test_pipeline_with_profile_queries(gpu, host, oracle, small_proteomes):
         boff.append(boff[-1] + len(recs[-1]))
     prof = host.map_profiles(b''.join(recs), np.array(boff, np.uint64))
     db = SetDB.from_proteomes(ps)
-    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, profile_queries=True)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, profile_queries=True, filter_self_match=True)
     assert cs.kmer_thr == 99
     out = cs.search(db.with_profiles(prof), same_db=True, chunk_queries=100)
     # the same, stage by stage, on the oracle
