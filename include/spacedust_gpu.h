@@ -248,6 +248,8 @@ uint64_t sd_host_pair_list(const sd_hit *hits, const uint32_t *counts, uint32_t 
 int sd_host_lgamma_table(double *out, uint32_t n);
 double sd_host_evalue(uint64_t dbResidues, double score, double qLen);
 double sd_host_bitscore(double score);
+/* Util::canBeCovered (M/src/commons/Util.cpp:477-494): the length pre-check of Prefiltering.cpp:856-863 / Alignment.cpp:370 */
+int sd_host_can_be_covered(float covThr, int covMode, float queryLength, float targetLength);
 
 /* ---- in-process aggregation between align and clusterhits (host) ---------
  * Replaces prefixid -> besthitbyset -> mergeresultsbyset -> combinehits (R/data/clustersearch.sh:121-140) and
@@ -271,6 +273,54 @@ int sd_agg_write_tsv(sd_agg *a, const char *path, const uint32_t *clusterOfHit, 
                      const char *qNames, const uint64_t *qNameOff, const char *tNames, const uint64_t *tNameOff,
                      const char *qSources, const uint64_t *qSourceOff, const char *tSources, const uint64_t *tSourceOff,
                      int canonical, uint64_t *nClusterLines, uint64_t *nHitLines);
+
+
+/* ---- the tail of Alignment::run for a batch: criteria, order, --realign, text (host) --------
+ * What `align` does with the records of one query after the Smith-Waterman calls: Alignment::checkCriteria
+ * (M/src/alignment/Alignment.cpp:389-399,548-567, with the derived fields of Matcher::getSWResult, Matcher.cpp:88-137),
+ * the compareHits sort (Alignment.cpp:403-405, Matcher.h:157-168), the --realign second pass (:408-440) and
+ * Matcher::resultToBuffer (Matcher.cpp:280-327) -- batched over the queries of a chunk. */
+typedef struct {
+    double evalThr;        /* -e */
+    float seqIdThr;        /* --min-seq-id */
+    int32_t alnLenThr;     /* --min-aln-len */
+    int32_t covMode;       /* --cov-mode */
+    float covThr;          /* -c (the realign pass's coverage when realign != 0, Alignment.cpp:49-51) */
+    int32_t seqIdMode;     /* --seq-id-mode: 0 alignment length, 1 shorter, 2 longer sequence */
+    int32_t swMode;        /* Matcher::SCORE_ONLY 0 / SCORE_COV 1 / SCORE_COV_SEQID 2 the records were computed with */
+    int32_t addBacktrace;  /* -a */
+    int32_t realign;       /* --realign: the first pass is SCORE_ONLY without a coverage threshold (Alignment.cpp:45-57) */
+    int32_t realignSwMode; /* mode of the realignment records: max(alignment mode, SCORE_COV) (Alignment.cpp:46) */
+    int32_t realignMaxSeqs;/* --realign-max-seqs */
+    uint32_t maxAccept;    /* --max-accept */
+    uint32_t maxRejected;  /* --max-rejected */
+} sd_aln_criteria;
+
+/* Records res[i] of local query resQ[i] (non-decreasing) against target id resT[i], in prefilter order.  order[] receives the
+ * indices of the records that pass checkCriteria, grouped by query in compareHits order; countPerQuery[nQ] how many each
+ * query has.  qLen[nQ], tLen / tKey by target id (tKey NULL: the id is the DB key). */
+int sd_host_accept_sort(const sd_aln_criteria *crit, uint32_t nQ, uint32_t nRes, const uint32_t *resQ, const uint32_t *resT,
+                        const sd_sw_result *res, const uint8_t *isIdentity, const int32_t *qLen, const int32_t *tLen,
+                        const uint32_t *tKey, uint32_t *order, uint32_t *countPerQuery);
+/* --realign (Alignment.cpp:408-440): second[s] is the realignment (score-biased matrix, E-value gate off) of the s-th accepted
+ * first-pass record first[order[s]]; isIdentity is indexed like `second`.  merged[s] = second[s] carrying the first pass's
+ * score and E-value; outOrder / outCount: the realigned records with coverage (or identity), at most realignMaxSeqs per
+ * query, in compareHits order -- indices into merged. */
+int sd_host_realign_select(const sd_aln_criteria *crit, uint32_t nQ, const uint32_t *countPerQuery, const uint32_t *order,
+                           const uint32_t *resT, const sd_sw_result *first, const sd_sw_result *second,
+                           const uint8_t *isIdentity, const int32_t *qLen, const int32_t *tLen, const uint32_t *tKey,
+                           sd_sw_result *merged, uint32_t *outOrder, uint32_t *outCount);
+typedef struct sd_alntext sd_alntext;
+int sd_alntext_create(sd_alntext **out);
+void sd_alntext_destroy(sd_alntext *t);
+/* alignment DB entries of nQ queries: entry q = the lines of records rec[order[x]] (x in query q's slice, countPerQuery as
+ * above), each `tKey bits seqId eval qStart qEnd qLen tStart tEnd tLen [cigar]` exactly as Matcher::resultToBuffer prints
+ * them.  recT[i]: target id of record i; isIdentity indexed like rec. */
+int sd_alntext_format(sd_alntext *t, const sd_aln_criteria *crit, uint32_t nQ, const uint32_t *countPerQuery,
+                      const uint32_t *order, const uint32_t *recT, const sd_sw_result *rec, const uint8_t *isIdentity,
+                      const char *btPool, const int32_t *qLen, const int32_t *tLen, const uint32_t *tKey);
+/* text / entryOff[nQ+1] of the last sd_alntext_format; valid until the next call on t */
+int sd_alntext_get(sd_alntext *t, const char **text, const uint64_t **entryOff);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libsdgpu.so')
+CLI = os.path.join(HERE, 'sdgpu')   # the multi-call host driver (csrc/cli), linked against libsdgpu.so
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HOST_FLAGS = ['-std=c++17', '-O3', '-mavx2', '-mfma', '-ffp-contract=fast', '-fopenmp', '-fPIC']
 HIP_FLAGS = ['--offload-arch=gfx950', '-std=c++17', '-O3', '-fPIC', '-fopenmp', '-Wno-unused-result']
@@ -54,7 +55,35 @@ def build(force=False, verbose=False):
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
+    build_cli(force=force or bool(jobs), verbose=verbose)
     return OUT
+
+
+def build_cli(force=False, verbose=False):
+    """spacedust_amd/sdgpu: the C++ host driver speaking the reference's module command lines and DB files; it reaches the
+    kernels only through the C ABI of libsdgpu.so (found next to the binary via $ORIGIN)."""
+    cli = os.path.join(CSRC, 'cli')
+    srcs = sorted(os.path.join(cli, f) for f in os.listdir(cli) if f.endswith('.cpp'))
+    deps = srcs + [os.path.join(cli, f) for f in os.listdir(cli) if f.endswith('.h')] + [os.path.join(ROOT, 'include', 'spacedust_gpu.h')]
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(d) <= os.path.getmtime(CLI) for d in deps):
+        return CLI
+    objdir = os.path.join(HERE, 'build')
+    objs, procs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, 'cli_' + os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        cmd = ['g++', '-std=c++17', '-O2', '-fopenmp', '-I' + os.path.join(ROOT, 'include'), '-I' + cli, '-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('compile failed: ' + ' '.join(cmd))
+    cmd = ['g++', '-fopenmp'] + objs + ['-L' + HERE, '-lsdgpu', '-Wl,-rpath,$ORIGIN', '-Wl,-rpath,/opt/rocm/lib', '-lpthread', '-o', CLI]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
 
 
 if __name__ == '__main__':

@@ -1,0 +1,56 @@
+// sdgpu -- multi-call host driver of the MI355X-native clustersearch hot path.  `sdgpu <module> <args>` accepts the
+// command lines the reference's workflow scripts issue as `$MMSEQS <module> <args>` (R/src/spacedust.cpp:26-114 is
+// the reference's command table; R/data/clustersearch.sh and M/data/workflow/blastp.sh / blastpgp.sh are the callers), so a
+// wrapper that forwards the hot modules here and everything else to the reference binary runs those scripts unchanged.
+#include "sd_cli.h"
+
+#include <cstdio>
+#include <cstring>
+
+using namespace sdcli;
+
+namespace {
+struct Module {
+    const char *name;
+    int (*fn)(const Args &);
+    const char *what;
+};
+const Module kModules[] = {
+    {"prefilter", prefilterModule, "k-mer prefilter on the GPU: <queryDB> <targetDB> <prefilterDB>"},
+    {"align", alignModule, "Smith-Waterman alignments on the GPU: <queryDB> <targetDB> <prefilterDB> <alignmentDB>"},
+    {"clusterhits", clusterhitsModule, "agglomerative hit clustering on the GPU: <querySetDB> <targetSetDB> <matchesDB> <clustersDB>"},
+    {"search", searchModule, "prefilter + align (and the --num-iterations profile loop): <queryDB> <targetDB> <alignmentDB> <tmpDir>"},
+    {"clustersearch", clustersearchModule, "the whole --search-mode 0 workflow in one process: <querySetDB> <targetSetDB> <out.tsv> <tmpDir>"},
+    {"prefixid", prefixidModule, "host glue: prefix every line of a result DB with its entry key"},
+    {"besthitbyset", besthitbysetModule, "host glue: best hit per (query protein, target set)"},
+    {"mergeresultsbyset", mergeresultsbysetModule, "host glue: concatenate the entries of a set's members"},
+    {"combinehits", combinehitsModule, "host glue: per (query set, target set) hit lists + multihit E-value"},
+    {"summarizeresults", summarizeresultsModule, "host glue: clusters DB -> final TSV"},
+    {"result2profile", result2profileModule, "host: alignment DB -> profile DB (between search iterations)"},
+    {"subtractdbs", subtractdbsModule, "host glue: remove from result DB A the targets listed in result DB B"},
+    {"mergedbs", mergedbsModule, "host glue: merge the entries of several DBs by key"},
+    {"createsetdb", createsetdbModule, "FASTA files (Prodigal headers) -> setDB in the createsetdb layout"},
+};
+}  // namespace
+
+int main(int argc, const char **argv) {
+    if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
+        printf("sdgpu: MI355X-native hot path of spacedust clustersearch --search-mode 0\n\nusage: sdgpu <module> <args>\n\n");
+        for (const Module &m : kModules) printf("  %-18s %s\n", m.name, m.what);
+        return argc < 2 ? 1 : 0;
+    }
+    for (const Module &m : kModules) {
+        if (strcmp(argv[1], m.name) != 0) continue;
+        Args a;
+        a.module = m.name;
+        std::string err;
+        if (!a.parse(argc - 2, argv + 2, &err)) {
+            fprintf(stderr, "sdgpu %s: %s\n", m.name, err.c_str());
+            return 1;
+        }
+        info(a, "");
+        return m.fn(a);
+    }
+    fprintf(stderr, "sdgpu: unknown module \"%s\" (sdgpu --help lists the modules)\n", argv[1]);
+    return 1;
+}

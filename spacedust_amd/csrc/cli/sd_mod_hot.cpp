@@ -1,0 +1,695 @@
+// The three hot modules behind the reference's command lines and DB files:
+//   prefilter   <queryDB> <targetDB> <resultDB>             (M/src/prefiltering/Main.cpp:13, Prefiltering.cpp:570-951)
+//   align       <queryDB> <targetDB> <prefDB> <alnDB>        (M/src/alignment/Main.cpp:12, Alignment.cpp:244-542)
+//   clusterhits <querySetDB> <targetSetDB> <matches> <out>   (R/src/util/ClusterHits.cpp:215-511)
+// DB in, C ABI of libsdgpu.so (HIP kernels) in the middle, DB out.  No compute here, no CPU fallback: without a GPU
+// sd_ctx_create fails and the module exits non-zero.
+#include "sd_cli.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+namespace sdcli {
+
+namespace {
+
+struct HostH {
+    sd_host *h = nullptr;
+    ~HostH() { if (h) sd_host_destroy(h); }
+};
+struct CtxH {
+    sd_ctx *c = nullptr;
+    ~CtxH() { if (c) sd_ctx_destroy(c); }
+};
+struct SeqSetH {
+    sd_seqset *s = nullptr;
+    ~SeqSetH() { if (s) sd_seqset_destroy(s); }
+    void reset() { if (s) sd_seqset_destroy(s); s = nullptr; }
+};
+struct TargetH {
+    sd_target *t = nullptr;
+    ~TargetH() { if (t) sd_target_destroy(t); }
+};
+struct IndexH {
+    sd_host_index *ix = nullptr;
+    ~IndexH() { if (ix) sd_host_index_destroy(ix); }
+};
+
+// what the modules refuse (the reference has these paths; this build does not)
+int checkCommon(const Args &a) {
+    if (a.integer("--compressed", 0) != 0) return fail("--compressed 1 is not supported");
+    const std::string sm = a.multi("--sub-mat", "aa", "blosum62.out");
+    if (sm != "blosum62.out") return fail("--sub-mat " + sm + ": only blosum62.out is built into this path");
+    if (a.integer("--gpu", 0) != 0) return fail("--gpu 1 selects the reference's CUDA ungapped prefilter (a different algorithm); run without it");
+    return 0;
+}
+
+int deviceOf(const Args &a) {
+    if (a.has("--device")) return (int) a.integer("--device", 0);
+    const char *lr = getenv("LOCAL_RANK");
+    return lr ? atoi(lr) : 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+int prefilterModule(const Args &a) {
+    if (a.pos.size() != 3) return fail("usage: prefilter <queryDB> <targetDB> <resultDB> [options]");
+    if (int rc = checkCommon(a)) return rc;
+    const std::string ssm = a.multi("--seed-sub-mat", "aa", "VTML80.out");
+    if (ssm != "VTML80.out") return fail("--seed-sub-mat " + ssm + ": only VTML80.out is built into this path");
+    if (a.integer("--spaced-kmer-mode", 1) != 1 || a.has("--spaced-kmer-pattern"))
+        return fail("only the default spaced k-mer patterns are supported (--spaced-kmer-mode 1)");
+    if (a.integer("--exact-kmer-matching", 0) != 0) return fail("--exact-kmer-matching 1 is not supported");
+    if (!a.flag("--diag-score", true)) return fail("--diag-score 0 is not supported");
+    if (a.integer("--target-search-mode", 0) != 0) return fail("--target-search-mode 1 is not supported");
+    if (a.integer("--mask-lower-case", 0) != 0 || a.integer("--mask-n-repeat", 0) != 0)
+        return fail("--mask-lower-case / --mask-n-repeat are not supported");
+    if (a.integer("--split", 0) > 1) return fail("--split > 1: the whole target index is resident in HBM here; run with --split 0 or 1");
+    if (a.multi("--alph-size", "aa", "21") != "21") return fail("--alph-size aa:21 only");
+    if (a.real("--comp-bias-corr-scale", 1.0) != 1.0) return fail("--comp-bias-corr-scale 1 only");
+    if (a.has("--taxon-list") && !a.str("--taxon-list", "").empty()) return fail("--taxon-list is not supported");
+    const bool compBias = a.integer("--comp-bias-corr", 1) != 0;
+    const int threads = threadsOf(a);
+
+    HostH host;
+    if (sd_host_create(threads, &host.h) != SD_OK) return fail("sd_host_create failed");
+    std::string err;
+    const bool sameDb = a.pos[0] == a.pos[1];
+    std::unique_ptr<SeqDb> tdb(new SeqDb()), qdbOwn;
+    if (!tdb->load(a.pos[1], host.h, &err)) return fail(err);
+    if (tdb->profile) return fail("profile target databases are not supported on this path");
+    SeqDb *qdb = tdb.get();
+    if (!sameDb) {
+        qdbOwn.reset(new SeqDb());
+        if (!qdbOwn->load(a.pos[0], host.h, &err)) return fail(err);
+        qdb = qdbOwn.get();
+    }
+    info(a, "Query database size: %u type: %s\nTarget database size: %u type: Aminoacid\n", qdb->n,
+         qdb->profile ? "Profile" : "Aminoacid", tdb->n);
+
+    // parameters the way Prefiltering's constructor derives them (Prefiltering.cpp:180-215,1005-1065)
+    int k = (int) a.integer("-k", 0);
+    if (k == 0) k = sd_host_auto_kmer_size(tdb->totalResidues());
+    if (k != 6 && k != 7) return fail("-k " + std::to_string(k) + ": k-mer sizes 6 and 7 are implemented");
+    const float sens = (float) a.real("-s", 4.0);
+    const long long kScore = strtoll(a.multi("--k-score", qdb->profile ? "prof" : "seq", "2147483647").c_str(), nullptr, 10);
+    int kmerThr = kScore != INT_MAX ? (int) kScore
+                                    : (qdb->profile ? sd_host_profile_kmer_threshold(sens, k) : sd_host_kmer_threshold(sens, k));
+    const bool mask = a.integer("--mask", 1) != 0;
+    const double maskProb = a.real("--mask-prob", 0.9);
+    const bool includeIdentity = a.flag("--add-self-matches", false);
+
+    CtxH ctx;
+    int rc = sd_ctx_create(deviceOf(a), &ctx.c);
+    if (rc != SD_OK) return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rc) + "); this path has no CPU fallback");
+
+    // target side: IndexBuilder::fillDatabase on the host (mask + count + fill), resident in HBM afterwards.  Profile
+    // searches index every k-mer (Prefiltering.cpp:525-527)
+    IndexH index;
+    rc = sd_host_index_build(host.h, tdb->residues.data(), tdb->offsets.data(), tdb->n, k, qdb->profile ? 0 : kmerThr, mask ? 1 : 0,
+                             maskProb, &index.ix);
+    if (rc != SD_OK) return fail("sd_host_index_build failed (" + std::to_string(rc) + ")");
+    uint64_t tableSize = 0, nEntries = 0, maskedRes = 0;
+    sd_host_index_info(index.ix, &tableSize, &nEntries, &maskedRes);
+    info(a, "Index table k-mer threshold: %d at k-mer size %d\nIndex statistics\nEntries:          %llu\nMasked residues: %llu\n",
+         kmerThr, k, (unsigned long long) nEntries, (unsigned long long) maskedRes);
+    const uint32_t *kOff, *eSeq;
+    const uint16_t *ePos;
+    const uint8_t *masked;
+    sd_host_index_arrays(index.ix, &kOff, &eSeq, &ePos, &masked);
+    const int16_t *s2, *s3;
+    const uint16_t *i2, *i3;
+    uint32_t sz2, sz3;
+    sd_host_ext_matrix(host.h, 2, &s2, &i2, &sz2);
+    sd_host_ext_matrix(host.h, 3, &s3, &i3, &sz3);
+    TargetH target;
+    rc = sd_target_create(ctx.c, k, kOff, eSeq, ePos, nEntries, masked, tdb->offsets.data(), tdb->n, s2, i2, s3, i3, &target.t);
+    if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_target_create");
+
+    sd_prefilter_params par;
+    memset(&par, 0, sizeof(par));
+    par.kmerSize = k;
+    par.kmerThr = kmerThr;
+    par.maxHitsPerQuery = (int32_t) std::min<long long>(a.integer("--max-seqs", 300), tdb->n);   // Prefiltering.cpp:184
+    par.minDiagScore = (int32_t) a.integer("--min-ungapped-score", 15);
+    par.binSize = a.has("--bin-size") ? (uint32_t) a.integer("--bin-size", 0)
+                                      : sd_host_bin_size(tdb->n, (uint64_t) a.integer("--l2-cache-size", 0));
+    par.covMode = (int32_t) a.integer("--cov-mode", 0);
+    par.covThr = (float) a.real("-c", 0.0);
+    // the writer's coverage pre-filter only exists for these modes (Prefiltering.cpp:856-858)
+    if (!(par.covMode == 0 || par.covMode == 2 || par.covMode == 5)) par.covThr = 0.0f;
+    sd_host_matrix(host.h, 2, par.ungappedMatrix, nullptr, nullptr);
+    if (par.maxHitsPerQuery < 1) par.maxHitsPerQuery = 1;
+
+    sddb::Writer out;
+    if (!out.open(a.pos[2], sddb::DBTYPE_PREFILTER_RES, &err)) return fail(err);
+
+    const uint32_t chunk = (uint32_t) std::max<long long>(1, a.integer("--chunk-queries", 16384));
+    std::vector<sd_hit> hits;
+    std::vector<uint32_t> counts, ident;
+    std::vector<int8_t> diagBias;
+    std::vector<int16_t> kmerBias;
+    std::vector<uint64_t> off;
+    std::string text;
+    uint64_t totalHits = 0;
+    for (uint32_t c0 = 0; c0 < qdb->n; c0 += chunk) {
+        const uint32_t c1 = std::min(qdb->n, c0 + chunk), nq = c1 - c0;
+        const uint64_t r0 = qdb->offsets[c0], r1 = qdb->offsets[c1];
+        off.resize((size_t) nq + 1);
+        for (uint32_t i = 0; i <= nq; i++) off[i] = qdb->offsets[c0 + i] - r0;
+        ident.resize(nq);
+        for (uint32_t i = 0; i < nq; i++) {
+            uint32_t id = UINT32_MAX;
+            if (sameDb) id = c0 + i;
+            else if (includeIdentity) {
+                const size_t t = tdb->rd.idOfKey(qdb->keys[c0 + i]);
+                if (t != SIZE_MAX) id = (uint32_t) t;
+            }
+            ident[i] = id;
+        }
+        hits.resize((size_t) nq * par.maxHitsPerQuery);
+        counts.assign(nq, 0);
+        if (qdb->profile) {
+            rc = sd_prefilter_profile_batch(ctx.c, target.t, &par, nq, qdb->residues.data() + r0, off.data(),
+                                            qdb->sortedScore.data() + r0 * 20, qdb->sortedIndex.data() + r0 * 20,
+                                            qdb->alnProfile.data() + r0 * 21, ident.data(), hits.data(), counts.data(), nullptr);
+        } else {
+            diagBias.assign(r1 - r0 + 1, 0);
+            kmerBias.assign(r1 - r0 + 1, 0);
+            if (compBias)
+                sd_host_comp_bias(host.h, qdb->residues.data() + r0, off.data(), nq, k, nullptr, diagBias.data(), kmerBias.data());
+            rc = sd_prefilter_batch(ctx.c, target.t, &par, nq, qdb->residues.data() + r0, off.data(), kmerBias.data(),
+                                    diagBias.data(), ident.data(), hits.data(), counts.data(), nullptr);
+        }
+        if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_prefilter_batch");
+        // QueryMatcher::prefilterHitToBuffer (QueryMatcher.h:118-130): targetKey \t score \t (int16) diagonal
+        char line[64];
+        for (uint32_t i = 0; i < nq; i++) {
+            text.clear();
+            const sd_hit *row = hits.data() + (size_t) i * par.maxHitsPerQuery;
+            for (uint32_t x = 0; x < counts[i]; x++) {
+                const int len = snprintf(line, sizeof(line), "%u\t%d\t%d\n", tdb->keys[row[x].seqId], row[x].score,
+                                         (int) (int16_t) row[x].diagonal);
+                text.append(line, (size_t) len);
+            }
+            totalHits += counts[i];
+            if (!out.write(qdb->keys[c0 + i], text.data(), text.size())) return fail("cannot write " + a.pos[2]);
+        }
+    }
+    if (!out.close(&err)) return fail(err);
+    info(a, "%llu prefilter hits written for %u queries\n", (unsigned long long) totalHits, qdb->n);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+// one chunk of prefilter entries turned into device work
+struct AlnChunk {
+    std::vector<uint32_t> entryFirst;   // per local query: first record
+    std::vector<uint32_t> qIds;         // query id (in qdb) per local query
+    std::vector<uint32_t> entryOfLocal; // prefilter entry id per local query
+    std::vector<uint32_t> pairQ, pairT;
+    std::vector<uint8_t> ident;
+};
+
+int alignPairs(sd_ctx *ctx, const sd_sw_params &par, sd_seqset *qs, sd_seqset *ts, const SeqDb &qdb, const SeqDb &tdb,
+               const std::vector<uint32_t> &qIdOfLocal, const std::vector<uint32_t> &pq, const std::vector<uint32_t> &pt,
+               const std::vector<uint8_t> &ident, bool compact, std::vector<uint32_t> &outIdx, std::vector<sd_sw_result> &res,
+               std::vector<char> &pool) {
+    const uint32_t n = (uint32_t) pq.size();
+    res.resize(std::max<uint32_t>(n, 1));
+    outIdx.resize(std::max<uint32_t>(n, 1));
+    uint64_t cap = std::max<uint64_t>(1u << 20, 96ull * n);
+    bool exact = false;
+    for (;;) {
+        if (pool.size() < cap) pool.resize(cap);
+        uint64_t used = 0;
+        int rc;
+        uint32_t nOut = n;
+        if (compact)
+            rc = sd_sw_align_batch_compact(ctx, &par, qs, ts, n, pq.data(), pt.data(), ident.data(), outIdx.data(), res.data(),
+                                           &nOut, pool.data(), pool.size(), &used);
+        else
+            rc = sd_sw_align_batch(ctx, &par, qs, ts, n, pq.data(), pt.data(), ident.data(), res.data(), pool.data(), pool.size(),
+                                   &used);
+        if (rc == SD_ENOMEM && !exact) {   // pool too small: the exact bound is sum(qLen + tLen)
+            uint64_t need = 64;
+            for (uint32_t i = 0; i < n; i++) need += (uint64_t) qdb.lens[qIdOfLocal[pq[i]]] + (uint64_t) tdb.lens[pt[i]];
+            cap = need;
+            exact = true;
+            continue;
+        }
+        if (rc != SD_OK) return rc;
+        if (compact) {
+            res.resize(nOut);
+            outIdx.resize(nOut);
+        } else {
+            for (uint32_t i = 0; i < n; i++) outIdx[i] = i;
+        }
+        return SD_OK;
+    }
+}
+
+}  // namespace
+
+int alignModule(const Args &a) {
+    if (a.pos.size() != 4) return fail("usage: align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [options]");
+    if (int rc = checkCommon(a)) return rc;
+    if (a.flag("--wrapped-scoring", false)) return fail("--wrapped-scoring is a nucleotide mode");
+    if (a.integer("--alt-ali", 0) != 0) return fail("--alt-ali > 0 is not supported");
+    if (a.integer("--alignment-output-mode", 0) != 0) return fail("--alignment-output-mode 0 only");
+    if (a.real("--score-bias", 0.0) != 0.0) return fail("--score-bias 0 only");
+    if (a.real("--corr-score-weight", 0.0) != 0.0) return fail("--corr-score-weight 0 only");
+    if (a.multi("--gap-open", "aa", "11") != "11" || a.multi("--gap-extend", "aa", "1") != "1")
+        return fail("gap costs other than --gap-open 11 --gap-extend 1 need other E-value parameters than the built-in preset");
+    if (a.real("--comp-bias-corr-scale", 1.0) != 1.0) return fail("--comp-bias-corr-scale 1 only");
+    const bool compBias = a.integer("--comp-bias-corr", 1) != 0;
+    const int threads = threadsOf(a);
+    int alignmentMode = (int) a.integer("--alignment-mode", 0);
+    if (alignmentMode == 4) return fail("Use rescorediagonal for ungapped alignment mode.");
+    bool addBacktrace = a.flag("-a", false);
+    bool realign = a.flag("--realign", false);
+    const float realignScoreBias = (float) a.real("--realign-score-bias", -0.2);
+    if (realign && !(realignScoreBias == -0.2f || realignScoreBias == 0.0f))
+        return fail("--realign-score-bias: -0.2 (default) and 0 are built in");
+    float covThr = (float) a.real("-c", 0.0);
+    const float canCovThr = covThr;
+    const int covMode = (int) a.integer("--cov-mode", 0);
+    const float seqIdThr = (float) a.real("--min-seq-id", 0.0);
+    // Alignment::Alignment (Alignment.cpp:31-57)
+    if (addBacktrace) alignmentMode = 3;
+    int realignSwMode = 0;
+    auto initSWMode = [](int mode, float cov, float sid) {   // Alignment::initSWMode (:170-192)
+        switch (mode) {
+            case 0: return (cov > 0.0f && sid == 0.0f) ? 1 : ((cov > 0.0f && sid > 0.0f) ? 2 : 0);
+            case 2: return 1;
+            case 3: return 2;
+            default: return 0;
+        }
+    };
+    float realignCov = 0.0f;
+    if (realign) {
+        realignSwMode = initSWMode(std::max(alignmentMode, 2), 0.0f, 0.0f);
+        alignmentMode = 1;
+        realignCov = covThr;
+        covThr = 0.0f;
+        addBacktrace = true;
+    }
+    const int swMode = initSWMode(alignmentMode, (float) a.real("-c", 0.0), seqIdThr);
+
+    HostH host;
+    if (sd_host_create(threads, &host.h) != SD_OK) return fail("sd_host_create failed");
+    std::string err;
+    const bool sameDb = a.pos[0] == a.pos[1];
+    std::unique_ptr<SeqDb> tdb(new SeqDb()), qdbOwn;
+    if (!tdb->load(a.pos[1], host.h, &err)) return fail(err);
+    if (tdb->profile) return fail("profile target databases are not supported on this path");
+    SeqDb *qdb = tdb.get();
+    if (!sameDb) {
+        qdbOwn.reset(new SeqDb());
+        if (!qdbOwn->load(a.pos[0], host.h, &err)) return fail(err);
+        qdb = qdbOwn.get();
+    }
+    sddb::Reader pref;
+    if (!pref.open(a.pos[2], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
+    info(a, "%s\nQuery database size: %u type: %s\nTarget database size: %u type: Aminoacid\n",
+         swMode == 0 ? "Compute score only" : (swMode == 1 ? "Compute score and coverage" : "Compute score, coverage and sequence identity"),
+         qdb->n, qdb->profile ? "Profile" : "Aminoacid", tdb->n);
+
+    CtxH ctx;
+    int rc = sd_ctx_create(deviceOf(a), &ctx.c);
+    if (rc != SD_OK) return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rc) + "); this path has no CPU fallback");
+
+    sd_sw_params par;
+    memset(&par, 0, sizeof(par));
+    par.gapOpen = 11;
+    par.gapExtend = 1;
+    sd_host_matrix(host.h, 0, par.matrix, nullptr, nullptr);
+    par.covMode = covMode;
+    par.covThr = covThr;
+    par.evalThr = a.real("-e", 0.001);
+    par.swMode = swMode;
+    par.dbResidues = tdb->totalResidues();
+    sd_sw_params rpar = par;   // the realigner (Alignment.cpp:296-303,419): score-biased matrix, E-value gate off
+    if (realign) {
+        sd_host_matrix(host.h, realignScoreBias == 0.0f ? 0 : 2, rpar.matrix, nullptr, nullptr);
+        rpar.covThr = realignCov;
+        rpar.evalThr = FLT_MAX;
+        rpar.swMode = realignSwMode;
+    }
+
+    sd_aln_criteria crit;
+    memset(&crit, 0, sizeof(crit));
+    crit.evalThr = par.evalThr;
+    crit.seqIdThr = seqIdThr;
+    crit.alnLenThr = (int32_t) a.integer("--min-aln-len", 0);
+    crit.covMode = covMode;
+    crit.covThr = realign ? realignCov : covThr;
+    crit.seqIdMode = (int32_t) a.integer("--seq-id-mode", 0);
+    crit.swMode = swMode;
+    crit.addBacktrace = addBacktrace ? 1 : 0;
+    crit.realign = realign ? 1 : 0;
+    crit.realignSwMode = realignSwMode;
+    crit.realignMaxSeqs = (int32_t) std::min<long long>(a.integer("--realign-max-seqs", INT_MAX), INT_MAX);
+    crit.maxAccept = (uint32_t) std::min<long long>(a.integer("--max-accept", INT_MAX), INT_MAX);
+    crit.maxRejected = (uint32_t) std::min<long long>(a.integer("--max-rejected", INT_MAX), INT_MAX);
+    const bool stopRules = crit.maxAccept != (uint32_t) INT_MAX || crit.maxRejected != (uint32_t) INT_MAX;
+    const bool includeIdentity = a.flag("--add-self-matches", false);
+
+    SeqSetH tset;
+    rc = sd_seqset_create(ctx.c, tdb->residues.data(), tdb->offsets.data(), tdb->n, nullptr, &tset.s);
+    if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_seqset_create(targets)");
+
+    sddb::Writer out;
+    int outType = sddb::withExtended(sddb::DBTYPE_ALIGNMENT_RES, sddb::extendedType(pref.dbtype()));
+    if (!out.open(a.pos[3], outType, &err)) return fail(err);
+    sd_alntext *text = nullptr;
+    sd_alntext_create(&text);
+    std::unique_ptr<sd_alntext, void (*)(sd_alntext *)> textGuard(text, sd_alntext_destroy);
+
+    const uint64_t maxPairs = 4000000;
+    const size_t nEntries = pref.size();
+    uint64_t alignmentsNum = 0, passedNum = 0;
+    std::vector<uint32_t> localQ, pq, pt, idxOut, order, counts, order2, counts2, accT;
+    std::vector<uint8_t> ident, ident2;
+    std::vector<uint8_t> qres;
+    std::vector<uint64_t> qoff;
+    std::vector<int8_t> qbias, qaln;
+    std::vector<int32_t> qlen;
+    std::vector<sd_sw_result> res, res2, merged;
+    std::vector<char> pool, pool2;
+    std::vector<uint32_t> recQ, recT, pq2, pt2;
+    std::vector<uint8_t> recIdent;
+    for (size_t e0 = 0; e0 < nEntries;) {
+        // chunk of entries bounded by pairs
+        localQ.clear();
+        pq.clear();
+        pt.clear();
+        ident.clear();
+        size_t e1 = e0;
+        std::vector<uint32_t> entryLocal;   // local query index of entry (UINT32_MAX: empty entry)
+        while (e1 < nEntries && (pq.size() < maxPairs || e1 == e0) && localQ.size() < 20000) {
+            const char *d = pref.data(e1);
+            const uint32_t qKey = pref.key(e1);
+            if (*d == '\0') {
+                entryLocal.push_back(UINT32_MAX);
+                e1++;
+                continue;
+            }
+            const size_t qId = qdb->rd.idOfKey(qKey);
+            if (qId == SIZE_MAX)
+                return fail("Query sequence " + std::to_string(qKey) + " is required in the prefiltering, but is not contained in the query sequence database.");
+            const uint32_t lq = (uint32_t) localQ.size();
+            localQ.push_back((uint32_t) qId);
+            entryLocal.push_back(lq);
+            const float qL = (float) qdb->lens[qId];
+            while (*d != '\0') {
+                const uint32_t tKey = (uint32_t) strtoul(d, nullptr, 10);
+                while (*d != '\n' && *d != '\0') d++;
+                if (*d == '\n') d++;
+                const size_t tId = tdb->rd.idOfKey(tKey);
+                if (tId == SIZE_MAX)
+                    return fail("Sequence " + std::to_string(tKey) + " is required in the prefiltering, but is not contained in the target sequence database!");
+                // Util::canBeCovered pre-check (Alignment.cpp:370-373): a rejected pair, never aligned
+                const bool can = sd_host_can_be_covered(canCovThr, covMode, qL, (float) tdb->lens[tId]) != 0;
+                pq.push_back(lq);
+                pt.push_back((uint32_t) tId);
+                // 2 marks the pre-rejected pair: kept only so that --max-rejected counts it
+                ident.push_back(!can ? 2 : ((qKey == tKey && (includeIdentity || sameDb)) ? 1 : 0));
+            }
+            e1++;
+        }
+        const uint32_t nq = (uint32_t) localQ.size();
+        // queries of the chunk as one sequence set on the device
+        qoff.assign((size_t) nq + 1, 0);
+        qlen.resize(nq);
+        for (uint32_t i = 0; i < nq; i++) {
+            qlen[i] = qdb->lens[localQ[i]];
+            qoff[i + 1] = qoff[i] + (uint64_t) qlen[i];
+        }
+        qres.resize(qoff[nq] + 1);
+        for (uint32_t i = 0; i < nq; i++) memcpy(qres.data() + qoff[i], qdb->residues.data() + qdb->offsets[localQ[i]], (size_t) qlen[i]);
+        SeqSetH qset;
+        if (nq) {
+            if (qdb->profile) {
+                qaln.resize((qoff[nq] + 1) * 21);
+                for (uint32_t i = 0; i < nq; i++)
+                    memcpy(qaln.data() + qoff[i] * 21, qdb->alnProfile.data() + qdb->offsets[localQ[i]] * 21, (size_t) qlen[i] * 21);
+                rc = sd_profileset_create(ctx.c, qres.data(), qoff.data(), nq, qaln.data(), &qset.s);
+            } else {
+                qbias.assign(qoff[nq] + 1, 0);
+                if (compBias) sd_host_comp_bias(host.h, qres.data(), qoff.data(), nq, 6, qbias.data(), nullptr, nullptr);
+                rc = sd_seqset_create(ctx.c, qres.data(), qoff.data(), nq, qbias.data(), &qset.s);
+            }
+            if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_seqset_create(queries)");
+        }
+        // the pairs that are aligned (pre-rejected ones are not)
+        std::vector<uint32_t> apq, apt, aIdx;
+        std::vector<uint8_t> aid;
+        apq.reserve(pq.size());
+        for (size_t i = 0; i < pq.size(); i++)
+            if (ident[i] != 2) {
+                apq.push_back(pq[i]);
+                apt.push_back(pt[i]);
+                aid.push_back(ident[i]);
+                aIdx.push_back((uint32_t) i);
+            }
+        alignmentsNum += apq.size();
+        const bool compact = swMode == 2 && !stopRules;
+        if (!apq.empty()) {
+            rc = alignPairs(ctx.c, par, qset.s, tset.s, *qdb, *tdb, localQ, apq, apt, aid, compact, idxOut, res, pool);
+            if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_sw_align_batch");
+        } else {
+            res.clear();
+            idxOut.clear();
+        }
+        // record list handed to the criteria: compact -> only the reportable records; otherwise every pair in prefilter
+        // order, pre-rejected ones as records that fail every criterion (E-value NaN)
+        recQ.clear();
+        recT.clear();
+        recIdent.clear();
+        std::vector<sd_sw_result> *recs = &res;
+        std::vector<sd_sw_result> full;
+        if (compact) {
+            recQ.resize(res.size());
+            recT.resize(res.size());
+            recIdent.resize(res.size());
+            for (size_t x = 0; x < res.size(); x++) {
+                recQ[x] = apq[idxOut[x]];
+                recT[x] = apt[idxOut[x]];
+                recIdent[x] = aid[idxOut[x]];
+            }
+        } else {
+            full.resize(pq.size());
+            sd_sw_result dummy;
+            memset(&dummy, 0, sizeof(dummy));
+            dummy.qStart = dummy.tStart = dummy.qEnd = dummy.tEnd = -1;
+            dummy.evalue = NAN;
+            for (size_t i = 0; i < pq.size(); i++) full[i] = dummy;
+            for (size_t x = 0; x < aIdx.size(); x++) full[aIdx[x]] = res[x];
+            recQ = pq;
+            recT = pt;
+            recIdent.resize(pq.size());
+            for (size_t i = 0; i < pq.size(); i++) recIdent[i] = ident[i] == 1 ? 1 : 0;
+            recs = &full;
+        }
+        order.resize(std::max<size_t>(recs->size(), 1));
+        counts.assign(std::max<uint32_t>(nq, 1), 0);
+        rc = sd_host_accept_sort(&crit, nq, (uint32_t) recs->size(), recQ.data(), recT.data(), recs->data(), recIdent.data(),
+                                 qlen.data(), tdb->lens.data(), tdb->keys.data(), order.data(), counts.data());
+        if (rc != SD_OK) return fail("sd_host_accept_sort failed (" + std::to_string(rc) + ")");
+        uint64_t nAcc = 0;
+        for (uint32_t i = 0; i < nq; i++) nAcc += counts[i];
+        passedNum += nAcc;
+        const std::vector<sd_sw_result> *outRecs = recs;
+        const std::vector<uint32_t> *outOrder = &order, *outCounts = &counts, *outT = &recT;
+        const std::vector<uint8_t> *outIdent = &recIdent;
+        const std::vector<char> *outPool = &pool;
+        if (realign && nAcc > 0) {
+            // second pass over the accepted records, in their order (Alignment.cpp:408-440)
+            pq2.resize(nAcc);
+            pt2.resize(nAcc);
+            ident2.resize(nAcc);
+            uint64_t w = 0;
+            for (uint32_t q = 0; q < nq; q++)
+                for (uint32_t x = 0; x < counts[q]; x++, w++) {
+                    const uint32_t i = order[w];
+                    pq2[w] = q;
+                    pt2[w] = recT[i];
+                    ident2[w] = recIdent[i];
+                }
+            std::vector<uint32_t> idx2;
+            rc = alignPairs(ctx.c, rpar, qset.s, tset.s, *qdb, *tdb, localQ, pq2, pt2, ident2, false, idx2, res2, pool2);
+            if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_sw_align_batch(realign)");
+            merged.resize(nAcc);
+            order2.resize(nAcc);
+            counts2.assign(nq, 0);
+            rc = sd_host_realign_select(&crit, nq, counts.data(), order.data(), recT.data(), recs->data(), res2.data(),
+                                        ident2.data(), qlen.data(), tdb->lens.data(), tdb->keys.data(), merged.data(),
+                                        order2.data(), counts2.data());
+            if (rc != SD_OK) return fail("sd_host_realign_select failed");
+            outRecs = &merged;
+            outOrder = &order2;
+            outCounts = &counts2;
+            accT = pt2;
+            outT = &accT;
+            outIdent = &ident2;
+            outPool = &pool2;
+        } else if (realign) {
+            counts2.assign(std::max<uint32_t>(nq, 1), 0);
+            outCounts = &counts2;
+        }
+        rc = sd_alntext_format(text, &crit, nq, outCounts->data(), outOrder->data(), outT->data(), outRecs->data(), outIdent->data(),
+                               outPool->data(), qlen.data(), tdb->lens.data(), tdb->keys.data());
+        if (rc != SD_OK) return fail("sd_alntext_format failed (" + std::to_string(rc) + ")");
+        const char *txt;
+        const uint64_t *eoff;
+        sd_alntext_get(text, &txt, &eoff);
+        for (size_t e = e0; e < e1; e++) {
+            const uint32_t lq = entryLocal[e - e0];
+            if (lq == UINT32_MAX) {
+                if (!out.write(pref.key(e), "", 0)) return fail("cannot write " + a.pos[3]);
+            } else if (!out.write(pref.key(e), txt + eoff[lq], (size_t) (eoff[lq + 1] - eoff[lq]))) {
+                return fail("cannot write " + a.pos[3]);
+            }
+        }
+        e0 = e1;
+    }
+    if (!out.close(&err)) return fail(err);
+    info(a, "%llu alignments calculated\n%llu sequence pairs passed the thresholds\n", (unsigned long long) alignmentsNum,
+         (unsigned long long) passedNum);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int clusterhitsModule(const Args &a) {
+    if (a.pos.size() != 4) return fail("usage: clusterhits <querySetDB> <targetSetDB> <matchesDB> <clustersDB> [options]");
+    if (a.integer("--compressed", 0) != 0) return fail("--compressed 1 is not supported");
+    if (a.flag("--cluster-use-weight", false)) return fail("--cluster-use-weight 1 is not supported");
+    std::string err;
+    SetInfo qs, tsOwn;
+    if (!qs.load(a.pos[0], false, &err)) return fail(err);
+    const bool sameDb = a.pos[0] == a.pos[1];
+    if (!sameDb && !tsOwn.load(a.pos[1], false, &err)) return fail(err);
+    const SetInfo &ts = sameDb ? qs : tsOwn;
+    sddb::Reader res, hdr;
+    if (!res.open(a.pos[2], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
+    if (!hdr.open(a.pos[2] + "_h", sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
+    if (hdr.size() != res.size()) return fail("matches and matches_h differ in size");
+    const bool dbOut = a.flag("--db-output", false);
+
+    sd_ch_params par;
+    par.maxGeneGap = (uint32_t) a.integer("--max-gene-gap", 3);
+    par.clusterSize = (uint32_t) a.integer("--cluster-size", 2);
+    par.alpha = a.real("--alpha", 1.0);
+    par.pCluThr = (float) a.real("--cluster-pval", 0.01);
+    par.pMHThr = (float) a.real("--multihit-pval", 0.01);
+
+    // entries -> flat arrays (R/src/util/ClusterHits.cpp:300-353)
+    std::vector<uint64_t> hitOff(1, 0);
+    std::vector<uint32_t> qPos, tPos, Nq, entryQSet, entryTSet;
+    std::vector<uint8_t> strands;
+    std::vector<double> pval;
+    std::vector<std::pair<const char *, uint32_t> > lines;   // hit line (with its '\n')
+    uint32_t maxOrf = 0;
+    for (uint32_t s : qs.setSize) maxOrf = std::max(maxOrf, s);
+    for (uint32_t s : ts.setSize) maxOrf = std::max(maxOrf, s);
+    uint32_t maxPos = 0;
+    for (size_t i = 0; i < res.size(); i++) {
+        const char *h = hdr.data(i);
+        char *end;
+        const unsigned long qSet = strtoul(h, &end, 10);
+        const unsigned long tSet = strtoul(end, &end, 10);
+        const unsigned long nq = strtoul(end, &end, 10);
+        // six tab separated columns are required (ClusterHits.cpp:303-307)
+        int cols = 0;
+        for (const char *c = h; *c && *c != '\n'; c++) cols += (*c == '\t');
+        if (cols < 5) return fail("Invalid header record");
+        const size_t first = lines.size();
+        const char *d = res.data(i);
+        while (*d != '\0') {
+            const char *ls = d;
+            char *e2;
+            const unsigned long qid = strtoul(d, &e2, 10);
+            const unsigned long tid = strtoul(e2, &e2, 10);
+            const double p = strtod(e2, nullptr);
+            while (*d != '\n' && *d != '\0') d++;
+            if (*d == '\n') d++;
+            if (qid >= qs.nameOfKey.size() || qs.nameOfKey[qid].empty()) return fail("Invalid query lookup record");
+            if (tid >= ts.nameOfKey.size() || ts.nameOfKey[tid].empty()) return fail("Invalid target lookup record");
+            lines.push_back(std::make_pair(ls, (uint32_t) (d - ls)));
+            qPos.push_back(qs.posOfKey[qid]);
+            tPos.push_back(ts.posOfKey[tid]);
+            maxPos = std::max(maxPos, std::max(qs.posOfKey[qid], ts.posOfKey[tid]));
+            strands.push_back((uint8_t) (qs.strandOfKey[qid] | (ts.strandOfKey[tid] << 1)));
+            pval.push_back(p);
+        }
+        const size_t K = lines.size() - first;
+        if (K == 1) {   // ClusterHits.cpp:359-361
+            lines.pop_back();
+            qPos.pop_back();
+            tPos.pop_back();
+            strands.pop_back();
+            pval.pop_back();
+            continue;
+        }
+        if (K == 0) continue;
+        hitOff.push_back(lines.size());
+        Nq.push_back((uint32_t) nq);
+        entryQSet.push_back((uint32_t) qSet);
+        entryTSet.push_back((uint32_t) tSet);
+    }
+    const uint32_t nPairs = (uint32_t) Nq.size();
+    const uint64_t total = hitOff.back();
+    std::vector<uint32_t> clusterOf(std::max<uint64_t>(total, 1), UINT32_MAX), rank(std::max<uint64_t>(total, 1), 0),
+        nClusters(std::max<uint32_t>(nPairs, 1), 0), cSize(std::max<uint64_t>(total, 1), 0);
+    std::vector<double> pCO(std::max<uint64_t>(total, 1), 0.0), pMH(std::max<uint64_t>(total, 1), 0.0);
+    if (nPairs > 0) {
+        CtxH ctx;
+        int rc = sd_ctx_create(deviceOf(a), &ctx.c);
+        if (rc != SD_OK) return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rc) + "); this path has no CPU fallback");
+        const uint32_t lgN = std::max(maxOrf, maxPos) + 8;
+        std::vector<double> lg(lgN);
+        sd_host_lgamma_table(lg.data(), lgN);
+        rc = sd_clusterhits_batch(ctx.c, &par, nPairs, hitOff.data(), qPos.data(), tPos.data(), strands.data(), pval.data(), Nq.data(),
+                                  lg.data(), lgN, clusterOf.data(), rank.data(), nClusters.data(), pCO.data(), pMH.data(), cSize.data());
+        if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_clusterhits_batch");
+    }
+    sddb::Writer out, outH;
+    if (!out.open(a.pos[3], dbOut ? res.dbtype() : (int) sddb::DBTYPE_OMIT_FILE, &err)) return fail(err);
+    if (!outH.open(a.pos[3] + "_h", sddb::DBTYPE_GENERIC_DB, &err)) return fail(err);
+    uint32_t key = 0;
+    std::string buf, hbuf;
+    std::vector<uint32_t> member;
+    char co[32], mh[32];
+    for (uint32_t e = 0; e < nPairs; e++) {
+        const uint64_t off = hitOff[e], end = hitOff[e + 1];
+        for (uint32_t c = 0; c < nClusters[e]; c++) {
+            member.assign(cSize[off + c], 0);
+            for (uint64_t h = off; h < end; h++)
+                if (clusterOf[h] == c) member[rank[h]] = (uint32_t) (h - off);
+            buf.clear();
+            for (uint32_t m : member) buf.append(lines[off + m].first, lines[off + m].second);
+            snprintf(co, sizeof(co), "%.3E", pCO[off + c]);
+            snprintf(mh, sizeof(mh), "%.3E", pMH[off + c]);
+            hbuf = std::to_string(entryQSet[e]) + "\t" + std::to_string(entryTSet[e]) + "\t" + co + "\t" + mh + "\t" +
+                   std::to_string(cSize[off + c]) + "\n";
+            if (!out.write(key, buf.data(), buf.size()) || !outH.write(key, hbuf.data(), hbuf.size())) return fail("cannot write " + a.pos[3]);
+            key++;
+        }
+    }
+    if (!out.close(&err) || !outH.close(&err)) return fail(err);
+    if (!dbOut) ::remove((a.pos[3] + ".index").c_str());
+    info(a, "%u clusters from %u set pairs\n", key, nPairs);
+    return 0;
+}
+
+}  // namespace sdcli

@@ -217,6 +217,10 @@ double sd_host_evalue(uint64_t dbResidues, double score, double qLen) {
     return sd::computeEvalue(e, score, qLen);
 }
 
+int sd_host_can_be_covered(float covThr, int covMode, float queryLength, float targetLength) {
+    return sd::canBeCovered(covThr, covMode, queryLength, targetLength) ? 1 : 0;
+}
+
 double sd_host_bitscore(double score) {
     sd::Evaluer e;
     sd::initEvaluer(e, 1);
