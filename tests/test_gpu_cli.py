@@ -1,0 +1,88 @@
+"""The drop-in boundary on the GPU: the reference's own module command lines (copied from the log of
+`spacedust clustersearch genome genome result.tsv tmp --filter-self-match`, i.e. what R/data/clustersearch.sh:110-152 and
+M/data/workflow/blastp.sh:70,85 pass to `$MMSEQS prefilter|align|...`) run through the `sdgpu` binary on DB files, and every
+DB must hash to what the reference binary's DB hashes to:
+    pref_0 8109a70b... (98 957 lines), result 2e917f0e... (15 065 lines), final TSV (cut -f2-) abb28ee3... (416 lines),
+    R/util/run_regression.sh:20-23: 308 hit lines, 2 clusters with P < 1E-20."""
+import os
+
+import pytest
+
+from dbutil import write_db, flat_lines_from_gz, entries_by_first_column, sorted_md5, sdgpu, example_fasta
+
+pytestmark = pytest.mark.gpu
+
+PREFILTER_PAR = ("--sub-mat aa:blosum62.out,nucl:nucleotide.out --seed-sub-mat aa:VTML80.out,nucl:nucleotide.out -k 0 "
+                 "--target-search-mode 0 --k-score seq:2147483647,prof:2147483647 --alph-size aa:21,nucl:5 --max-seq-len 65535 "
+                 "--max-seqs 300 --split 0 --split-mode 2 --split-memory-limit 0 -c 0.8 --cov-mode 2 --comp-bias-corr 1 "
+                 "--comp-bias-corr-scale 1 --diag-score 1 --exact-kmer-matching 0 --mask 1 --mask-prob 0.9 --mask-lower-case 0 "
+                 "--mask-n-repeat 0 --min-ungapped-score 15 --add-self-matches 0 --spaced-kmer-mode 1 --db-load-mode 0 "
+                 "--pca substitution:1.100,context:1.400 --pcb substitution:4.100,context:5.800 --threads 8 --compressed 0 -v 3 "
+                 "-s 5.7").split()
+ALIGN_PAR = ("--sub-mat aa:blosum62.out,nucl:nucleotide.out -a 1 --alignment-mode 2 --alignment-output-mode 0 --wrapped-scoring 0 "
+             "-e 10 --min-seq-id 0 --min-aln-len 30 --seq-id-mode 0 --alt-ali 0 -c 0.8 --cov-mode 2 --max-seq-len 65535 "
+             "--comp-bias-corr 1 --comp-bias-corr-scale 1 --max-rejected 2147483647 --max-accept 2147483647 --add-self-matches 0 "
+             "--db-load-mode 0 --pca substitution:1.100,context:1.400 --pcb substitution:4.100,context:5.800 --score-bias 0 "
+             "--realign 0 --realign-score-bias -0.2 --realign-max-seqs 2147483647 --corr-score-weight 0 --gap-open aa:11,nucl:5 "
+             "--gap-extend aa:1,nucl:2 --zdrop 40 --threads 8 --compressed 0 -v 3").split()
+CLUSTERHITS_PAR = ("--multihit-pval 0.01 --cluster-pval 0.01 --max-gene-gap 3 --cluster-size 2 --cluster-use-weight 0 --db-output 1 "
+                   "--alpha 1 --threads 8 --compressed 0 -v 3").split()
+
+
+@pytest.fixture(scope='module')
+def work(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp('dropin')
+    fa = example_fasta(tmp)
+    sdgpu('createsetdb', fa[0], fa[1], tmp / 'genome', tmp / 'tmp', '-v', '0')
+    return tmp
+
+
+def flat(work, db):
+    sdgpu('prefixid', work / db, work / (db + '.flat'), '--tsv', '--threads', '1')
+    return open(work / (db + '.flat')).readlines()
+
+
+def test_module_by_module_reproduces_reference_dbs(work):
+    g = work / 'genome'
+    sdgpu('prefilter', g, g, work / 'pref_0', *PREFILTER_PAR)
+    lines = flat(work, 'pref_0')
+    assert (len(lines), sorted_md5(lines)) == (98957, '8109a70bdea70ee10e0dbd27ba6b7e37')
+    sdgpu('align', g, g, work / 'pref_0', work / 'result', *ALIGN_PAR)
+    lines = flat(work, 'result')
+    assert (len(lines), sorted_md5(lines)) == (15065, '2e917f0e9782e8a7412c7360aa7bf1b4')
+    # the written entries equal the fixture from the real reference classes in DB order too (entry order, line order)
+    assert lines == flat_lines_from_gz('config1_aln.tsv.gz')
+    sdgpu('prefixid', work / 'result', work / 'result_prefixed', '--threads', '8', '-v', '3')
+    sdgpu('besthitbyset', g, g, work / 'result_prefixed', work / 'aggregate', '--simple-best-hit', '1', '--suboptimal-hits', '0',
+          '--threads', '8', '--compressed', '0', '-v', '3')
+    sdgpu('mergeresultsbyset', str(g) + '_set_to_member', work / 'aggregate', work / 'aggregate_merged', '--threads', '8', '-v', '3')
+    sdgpu('combinehits', g, g, work / 'aggregate_merged', work / 'matches', work / 'tmp', '--alpha', '1', '--aggregation-mode', '0',
+          '--filter-self-match', '1', '--threads', '8', '--compressed', '0', '-v', '3')
+    sdgpu('clusterhits', g, g, work / 'matches', work / 'clusters', *CLUSTERHITS_PAR)
+    sdgpu('summarizeresults', g, g, work / 'clusters', work / 'result.tsv', '--threads', '8', '-v', '3')
+    tsv = open(work / 'result.tsv').readlines()
+    n_hit = sum(1 for l in tsv if l.startswith('>'))
+    clu = [l for l in tsv if l.startswith('#')]
+    assert (n_hit, len(clu), sum(1 for l in clu if float(l.split('\t')[3]) < 1e-20)) == (308, 108, 2)   # run_regression.sh:20-23
+    assert sorted_md5(tsv, drop_first_column=True) == 'abb28ee37bc130a5f09a9f767ef00ccf'
+
+
+def test_align_on_the_reference_prefilter_db(work):
+    """`align` alone on the prefilter DB of the real reference classes (fixture), read from split data files"""
+    pref = flat_lines_from_gz('config1_pref.tsv.gz')
+    write_db(str(work / 'pref_ref'), entries_by_first_column(pref, 5898), 7, splits=8)
+    g = work / 'genome'
+    sdgpu('align', g, g, work / 'pref_ref', work / 'result_ref', *ALIGN_PAR)
+    lines = flat(work, 'result_ref')
+    assert (len(lines), sorted_md5(lines)) == (15065, '2e917f0e9782e8a7412c7360aa7bf1b4')
+
+
+def test_no_device_no_result(work):
+    """without a visible GPU the hot modules exit non-zero: there is no CPU path behind them"""
+    import subprocess
+    from dbutil import SDGPU
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='-1', ROCR_VISIBLE_DEVICES='-1')
+    g = str(work / 'genome')
+    p = subprocess.run([SDGPU, 'prefilter', g, g, str(work / 'pref_none')] + PREFILTER_PAR, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and 'no usable HIP device' in p.stderr

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Golden fixtures for the aggregation + clusterhits half of the path: the two (query set, target set) match
 entries of the reference's regression input (K = 732 and 551) with the canonical result TSV whose md5
-(abb28ee3...) equals the reference binary's.  Needs scratch/aln_orc.tsv (scratch/t_sw.py orc)."""
-import hashlib, math, os, sys
+(abb28ee3...) equals the reference binary's.  Input: tests/golden/config1_aln.tsv.gz, the flattened
+alignment DB written by tools/make_golden_alndb.py from the real reference classes (md5 2e917f0e...)."""
+import gzip, hashlib, math, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,7 +21,7 @@ for si, f in enumerate(files):
 setof = np.array(setof)
 setsize = [int((setof == s).sum()) for s in range(2)]
 aln = {}
-for l in open(os.path.join(ROOT, 'scratch', 'aln_orc.tsv')):
+for l in gzip.open(os.path.join(GOLD, 'config1_aln.tsv.gz'), 'rt'):
     w = l.rstrip('\n').split('\t'); aln.setdefault(int(w[0]), []).append(w)
 DBL_MIN = sys.float_info.min
 def logpval(ev):
