@@ -106,7 +106,7 @@ def main():
     max_seqs = max(300, 2 * P)
     cs = ClusterSearch(gpu, host, db, max_seqs=max_seqs, filter_self_match=True)
     cs.last_entries = None
-    kmer_thr_used, bin_size_used = cs.kmer_thr, int(cs.pf_par.binSize)
+    kmer_thr_used, bin_size_used = cs.kmer_thr, int(cs.bin_size)
     n_batches = (P + B - 1) // B
     set_start = ps.set_start
 

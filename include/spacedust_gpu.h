@@ -264,6 +264,9 @@ void sd_agg_destroy(sd_agg *a);
  * checkCriteria, compareHits order, best hit per (query protein, target set), log P threshold of combinehits */
 int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ, const uint32_t *pairT,
                const sd_sw_result *res, const uint8_t *isIdentity, const char *btPool);
+/* optional: DB keys of the query / target proteins (default: key = index) -- the order of the hits inside an entry
+ * (mergeresultsbyset walks the set's members by key) and Matcher::compareHits' last criterion use keys */
+int sd_agg_set_keys(sd_agg *a, const uint32_t *qKeys, const uint32_t *tKeys);
 int sd_agg_finish(sd_agg *a, uint64_t *nEntries, uint64_t *nHits);
 int sd_agg_stats(sd_agg *a, uint64_t *nAligned, uint64_t *nAccepted);
 int sd_agg_get(sd_agg *a, uint64_t *entryOff, uint32_t *entryQSet, uint32_t *entryTSet, uint32_t *hitQ, uint32_t *hitT,
@@ -273,6 +276,12 @@ int sd_agg_write_tsv(sd_agg *a, const char *path, const uint32_t *clusterOfHit, 
                      const char *qNames, const uint64_t *qNameOff, const char *tNames, const uint64_t *tNameOff,
                      const char *qSources, const uint64_t *qSourceOff, const char *tSources, const uint64_t *tSourceOff,
                      int canonical, uint64_t *nClusterLines, uint64_t *nHitLines);
+/* the same, appending to `path` when append != 0 and numbering the clusters from firstClusterKey (several results, one file) */
+int sd_agg_write_tsv_from(sd_agg *a, const char *path, int append, uint64_t firstClusterKey, const uint32_t *clusterOfHit,
+                          const uint32_t *rankInCluster, const uint32_t *nClusters, const double *pCO, const double *pMH,
+                          const uint32_t *clusterSize, const char *qNames, const uint64_t *qNameOff, const char *tNames,
+                          const uint64_t *tNameOff, const char *qSources, const uint64_t *qSourceOff, const char *tSources,
+                          const uint64_t *tSourceOff, int canonical, uint64_t *nClusterLines, uint64_t *nHitLines);
 
 
 /* ---- the tail of Alignment::run for a batch: criteria, order, --realign, text (host) --------
@@ -321,6 +330,95 @@ int sd_alntext_format(sd_alntext *t, const sd_aln_criteria *crit, uint32_t nQ, c
                       const char *btPool, const int32_t *qLen, const int32_t *tLen, const uint32_t *tKey);
 /* text / entryOff[nQ+1] of the last sd_alntext_format; valid until the next call on t */
 int sd_alntext_get(sd_alntext *t, const char **text, const uint64_t **entryOff);
+
+
+/* ---- the whole search in one object: host driver of the streaming pipeline (C++; replaces what the reference runs as
+ * `search` + prefixid/besthitbyset/mergeresultsbyset/combinehits + `clusterhits`, R/data/clustersearch.sh:110-146) ------
+ * sd_search owns two device contexts on one GPU (prefilter | alignments on separate HIP streams), the resident target
+ * (index + sequences) and the stage threads: composition bias of chunk i+2 | prefilter + pair list of chunk i+1 |
+ * alignments of chunk i | aggregation of chunk i-1.  Query ranges are streamed back to back; every range gets its own
+ * aggregation, clusterhits call and result.  Nothing here computes: every stage is one of the calls above. */
+typedef struct {
+    const uint8_t *residues;     /* numeric residues (profile queries: the query letters), concatenated */
+    const uint64_t *offsets;     /* n + 1 */
+    uint32_t n;
+    const uint32_t *setId;       /* genome set of every protein (createsetdb's lookup column 3) */
+    const uint32_t *posInSet;    /* gene index inside the set (lookup name, third field from the end) */
+    const uint8_t *strand;       /* start < end */
+    uint32_t nSets;
+    const uint32_t *keys;        /* DB keys (NULL: key = index); ordering inside result entries and compareHits tie-break */
+    /* profile queries (iterations >= 1 of --num-iterations): sd_host_map_profiles' arrays, NULL for sequence DBs */
+    const int8_t *alnProfile;    /* total x 21 */
+    const int16_t *sortedScore;  /* total x 20 */
+    const uint8_t *sortedIndex;  /* total x 20 */
+} sd_setdb;
+
+typedef struct {
+    float sensitivity;       /* -s (clustersearch: 5.7) */
+    int32_t kmerSize;        /* -k, 0 = automatic (IndexTable.h:439-449) */
+    int32_t maxSeqs;         /* --max-seqs */
+    int32_t minDiagScore;    /* --min-ungapped-score (15) */
+    uint32_t binSize;        /* 0 = from the DB size and this host's L2 (QueryMatcher.cpp:422-450) */
+    int32_t mask;            /* --mask (1) */
+    double maskProb;         /* --mask-prob (0.9) */
+    int32_t compBiasCorr;    /* --comp-bias-corr (1) */
+    double evalThr;          /* -e */
+    int32_t covMode;         /* --cov-mode */
+    float covThr;            /* -c */
+    int32_t alnLenThr;       /* --min-aln-len */
+    uint32_t maxGeneGap, clusterSize;   /* clusterhits */
+    double alpha;
+    float pCluThr, pMHThr;
+    int32_t filterSelfMatch; /* --filter-self-match (reference default 0) */
+    int32_t profileQueries;  /* the query side is a profile DB: own k-mer threshold table, index with threshold 0 */
+    int32_t chunkQueries;    /* queries per device chunk (0 = 10000) */
+    int32_t deviceBias;      /* composition bias on the device: 1 yes, 0 host, -1 by the number of host cores */
+    int32_t threads;         /* host threads of this rank (0 = all of the cgroup quota) */
+    int32_t alignPriority;   /* stream priority of the alignment context (sd_ctx_create_prio) */
+} sd_search_params;
+void sd_search_default_params(sd_search_params *p);   /* the clustersearch workflow defaults (R/src/workflow/clustersearch.cpp:9-37) */
+
+typedef struct sd_search sd_search;
+typedef struct sd_search_result sd_search_result;
+/* builds the index of `target` on the host (tantan masking + IndexBuilder::fillDatabase), uploads it and the target
+ * sequences; the arrays behind `target` must stay valid until sd_search_destroy */
+int sd_search_create(int device, const sd_search_params *par, const sd_setdb *target, sd_search **out);
+void sd_search_destroy(sd_search *s);
+const char *sd_search_last_error(sd_search *s);
+/* the two device contexts (0: prefilter + clusterhits, 1: alignments), e.g. for sd_profile_* */
+sd_ctx *sd_search_ctx(sd_search *s, int which);
+/* optional sinks, called from the pipeline's threads in chunk order: the prefilter rows of a chunk (after the coverage
+ * pre-filter; what `prefilter` writes) and its reportable alignment records (what `align` writes after checkCriteria) */
+typedef void (*sd_pref_sink)(void *user, uint32_t firstQuery, uint32_t nQ, const sd_hit *rows, const uint32_t *counts,
+                             uint32_t rowWidth);
+typedef void (*sd_aln_sink)(void *user, uint32_t firstQuery, uint32_t nQ, uint32_t nRes, const uint32_t *resQ /* chunk-local */,
+                            const uint32_t *resT, const sd_sw_result *res, const uint8_t *isIdentity, const char *btPool);
+int sd_search_set_sinks(sd_search *s, sd_pref_sink pref, sd_aln_sink aln, void *user);
+/* queries per device chunk for the following sd_search_stream calls (results do not depend on it) */
+int sd_search_set_chunk_queries(sd_search *s, int32_t chunkQueries);
+/* query ranges [rangeBegin[i], rangeEnd[i]) of `query` (whole query sets each), streamed through one pipeline;
+ * sameDb != 0: query protein i is target protein i (identity pairs, self hit first).  results[nRanges] receives one
+ * handle per range (destroy each). */
+int sd_search_stream(sd_search *s, const sd_setdb *query, int sameDb, uint32_t nRanges, const uint32_t *rangeBegin,
+                     const uint32_t *rangeEnd, sd_search_result **results);
+/* counts[8]: entries, matched hits, clusters, hits in clusters, pairs aligned, alignments accepted, prefilter hits, 0 */
+int sd_search_result_counts(sd_search_result *r, uint64_t *counts);
+/* copies (any pointer may be NULL): entryOff[entries+1], entryQSet/entryTSet[entries], hitQ/hitT/pval[hits],
+ * clusterOfHit/rankInCluster[hits], nClusters[entries], pCO/pMH/clusterSize[hits] (slot entryOff[e]+ordinal) */
+int sd_search_result_arrays(sd_search_result *r, uint64_t *entryOff, uint32_t *entryQSet, uint32_t *entryTSet, uint32_t *hitQ,
+                            uint32_t *hitT, double *pval, uint32_t *clusterOfHit, uint32_t *rankInCluster, uint32_t *nClusters,
+                            double *pCO, double *pMH, uint32_t *clusterSize);
+/* summarizeresults (R/src/util/SummarizeResults.cpp:77-112) of this result; names / sources as in sd_agg_write_tsv */
+int sd_search_result_write_tsv(sd_search_result *r, const char *path, const char *qNames, const uint64_t *qNameOff,
+                               const char *tNames, const uint64_t *tNameOff, const char *qSources, const uint64_t *qSourceOff,
+                               const char *tSources, const uint64_t *tSourceOff, int canonical, int append,
+                               uint64_t firstClusterKey, uint64_t *nClusterLines, uint64_t *nHitLines);
+void sd_search_result_destroy(sd_search_result *r);
+/* accumulated since create: stats[16] = similar k-mers, index hits, diagonals, diagonal length, prefilter hits, pairs,
+ * forward / reverse / traceback cells, index entries, masked residues, k, k-mer threshold, bin size, 0, 0;
+ * seconds[16] = index build, upload, bias, prefilter, pair list, seqset, align, aggregate (waiting), aggregate (busy),
+ * clusterhits, waiting for the prefilter, total of the last stream, 0... */
+int sd_search_stats(sd_search *s, uint64_t *stats, double *seconds);
 
 #ifdef __cplusplus
 }

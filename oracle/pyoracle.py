@@ -479,3 +479,43 @@ def oracle_clusterhits(orc, q_pos, t_pos, strands, pval, nq, d=3, cls=2, alpha=1
     n = L.or_clusterhits(K, _ptr(q_pos), _ptr(t_pos), _ptr(strands), _ptr(pval), nq, d, cls, alpha, p_clu, p_mh,
                          _ptr(lg), _ptr(cof), _ptr(mo), _ptr(cs), _ptr(pco), _ptr(pmh), None, C.byref(nm))
     return cof[:K], mo, cs[:n], pco[:n], pmh[:n], nm.value
+
+
+def ref_ch_available():
+    return os.path.exists(os.path.join(HERE, '_ref', 'libsdref_ch.so'))
+
+
+class RefClusterHits:
+    """The reference's own clusterhits arithmetic (R/src/util/ClusterHits.cpp compiled where it lies: groupNodes,
+    clusterMatchScore, isCompatibleCluster, multihitPval, logGamma ...) behind oracle/ref_clusterhits.cpp."""
+
+    def __init__(self):
+        self.lib = C.CDLL(os.path.join(HERE, '_ref', 'libsdref_ch.so'))
+        self.lib.ref_ch_loggamma.restype = C.c_double
+        self.lib.ref_ch_loggamma.argtypes = [C.c_double]
+        self.lib.ref_clusterhits_entry.restype = C.c_int
+        self.lib.ref_clusterhits_entry.argtypes = [C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
+                                                                                 C.c_float, C.c_float] + [C.c_void_p] * 7
+
+    def lgamma_table(self, n):
+        return np.array([self.lib.ref_ch_loggamma(float(i)) for i in range(n)])
+
+    def entry(self, q_pos, t_pos, strands, pval, nq, d=3, cls=2, alpha=1.0, p_clu=0.01, p_mh=0.01, lg=None):
+        """-> (cluster_of[K], rank[K], sizes[n], pCO[n], pMH[n])"""
+        q_pos = np.ascontiguousarray(q_pos, np.uint32)
+        t_pos = np.ascontiguousarray(t_pos, np.uint32)
+        strands = np.ascontiguousarray(strands, np.uint8)
+        pval = np.ascontiguousarray(pval, np.float64)
+        K = len(q_pos)
+        if lg is None:
+            lg = self.lgamma_table(int(max(q_pos.max(initial=0), t_pos.max(initial=0), nq, K)) + 8)
+        lg = np.ascontiguousarray(lg, np.float64)
+        cof = np.zeros(max(K, 1), np.uint32)
+        rk = np.zeros(max(K, 1), np.uint32)
+        cs = np.zeros(max(K, 1), np.uint32)
+        pco = np.zeros(max(K, 1))
+        pmh = np.zeros(max(K, 1))
+        n = C.c_uint32()
+        self.lib.ref_clusterhits_entry(K, _ptr(q_pos), _ptr(t_pos), _ptr(strands), _ptr(pval), nq, d, cls, alpha, p_clu, p_mh,
+                                       _ptr(lg), _ptr(cof), _ptr(rk), _ptr(pco), _ptr(pmh), _ptr(cs), C.byref(n))
+        return cof[:K], rk[:K], cs[:n.value], pco[:n.value], pmh[:n.value]

@@ -49,6 +49,27 @@ class ChParams(C.Structure):
                 ('pCluThr', C.c_float), ('pMHThr', C.c_float)]
 
 
+class SetDbView(C.Structure):   # sd_setdb
+    _fields_ = [('residues', _vp), ('offsets', _vp), ('n', C.c_uint32), ('setId', _vp), ('posInSet', _vp), ('strand', _vp),
+                ('nSets', C.c_uint32), ('keys', _vp), ('alnProfile', _vp), ('sortedScore', _vp), ('sortedIndex', _vp)]
+
+
+class SearchParams(C.Structure):   # sd_search_params
+    _fields_ = [('sensitivity', C.c_float), ('kmerSize', C.c_int32), ('maxSeqs', C.c_int32), ('minDiagScore', C.c_int32),
+                ('binSize', C.c_uint32), ('mask', C.c_int32), ('maskProb', C.c_double), ('compBiasCorr', C.c_int32),
+                ('evalThr', C.c_double), ('covMode', C.c_int32), ('covThr', C.c_float), ('alnLenThr', C.c_int32),
+                ('maxGeneGap', C.c_uint32), ('clusterSize', C.c_uint32), ('alpha', C.c_double), ('pCluThr', C.c_float),
+                ('pMHThr', C.c_float), ('filterSelfMatch', C.c_int32), ('profileQueries', C.c_int32), ('chunkQueries', C.c_int32),
+                ('deviceBias', C.c_int32), ('threads', C.c_int32), ('alignPriority', C.c_int32)]
+
+
+class AlnCriteria(C.Structure):   # sd_aln_criteria
+    _fields_ = [('evalThr', C.c_double), ('seqIdThr', C.c_float), ('alnLenThr', C.c_int32), ('covMode', C.c_int32),
+                ('covThr', C.c_float), ('seqIdMode', C.c_int32), ('swMode', C.c_int32), ('addBacktrace', C.c_int32),
+                ('realign', C.c_int32), ('realignSwMode', C.c_int32), ('realignMaxSeqs', C.c_int32), ('maxAccept', C.c_uint32),
+                ('maxRejected', C.c_uint32)]
+
+
 _lib = None
 
 
@@ -124,6 +145,32 @@ def load():
         'sd_agg_write_tsv': (C.c_int, [_vp, C.c_char_p, _vp, _vp, _vp, _vp, _vp, _vp, C.c_char_p, _vp, C.c_char_p, _vp,
                                        C.c_char_p, _vp, C.c_char_p, _vp, C.c_int, C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint64)]),
+        'sd_agg_write_tsv_from': (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_char_p, _vp,
+                                            C.c_char_p, _vp, C.c_char_p, _vp, C.c_char_p, _vp, C.c_int, C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64)]),
+        'sd_agg_set_keys': (C.c_int, [_vp, _vp, _vp]),
+        'sd_host_can_be_covered': (C.c_int, [C.c_float, C.c_int, C.c_float, C.c_float]),
+        'sd_host_accept_sort': (C.c_int, [C.POINTER(AlnCriteria), C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+        'sd_host_realign_select': (C.c_int, [C.POINTER(AlnCriteria), C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                             _vp, _vp]),
+        'sd_alntext_create': (C.c_int, [C.POINTER(_vp)]),
+        'sd_alntext_destroy': (None, [_vp]),
+        'sd_alntext_format': (C.c_int, [_vp, C.POINTER(AlnCriteria), C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+        'sd_alntext_get': (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(_vp)]),
+        'sd_search_default_params': (None, [C.POINTER(SearchParams)]),
+        'sd_search_create': (C.c_int, [C.c_int, C.POINTER(SearchParams), C.POINTER(SetDbView), C.POINTER(_vp)]),
+        'sd_search_destroy': (None, [_vp]),
+        'sd_search_last_error': (C.c_char_p, [_vp]),
+        'sd_search_ctx': (_vp, [_vp, C.c_int]),
+        'sd_search_set_sinks': (C.c_int, [_vp, _vp, _vp, _vp]),
+        'sd_search_set_chunk_queries': (C.c_int, [_vp, C.c_int32]),
+        'sd_search_stream': (C.c_int, [_vp, C.POINTER(SetDbView), C.c_int, C.c_uint32, _vp, _vp, _vp]),
+        'sd_search_result_counts': (C.c_int, [_vp, _vp]),
+        'sd_search_result_arrays': (C.c_int, [_vp] + [_vp] * 12),
+        'sd_search_result_write_tsv': (C.c_int, [_vp, C.c_char_p, C.c_char_p, _vp, C.c_char_p, _vp, C.c_char_p, _vp, C.c_char_p, _vp,
+                                                 C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        'sd_search_result_destroy': (None, [_vp]),
+        'sd_search_stats': (C.c_int, [_vp, _vp, _vp]),
     }
     missing = []
     for name, (res, args) in sig.items():
@@ -139,17 +186,19 @@ def load():
     return L
 
 
-DECLARED_SYMBOLS = [
-    'sd_ctx_create', 'sd_ctx_create_prio', 'sd_ctx_destroy', 'sd_last_error', 'sd_device_name', 'sd_synchronize', 'sd_profile_enable',
-    'sd_profile_reset', 'sd_profile_get', 'sd_profile_names', 'sd_seqset_create', 'sd_seqset_destroy',
-    'sd_sw_align_batch', 'sd_sw_align_batch_compact', 'sd_sw_align_batch_hostpath', 'sd_sw_score_batch', 'sd_sw_last_cells', 'sd_target_create', 'sd_target_destroy',
-    'sd_prefilter_batch', 'sd_comp_bias_batch', 'sd_prefilter_profile_batch', 'sd_profileset_create', 'sd_host_map_profiles',
-    'sd_host_profile_kmer_threshold', 'sd_clusterhits_batch', 'sd_host_create', 'sd_host_destroy', 'sd_host_matrix',
-    'sd_host_map_sequence', 'sd_host_comp_bias', 'sd_host_index_build', 'sd_host_index_info', 'sd_host_index_arrays',
-    'sd_host_index_destroy', 'sd_host_ext_matrix', 'sd_host_kmer_threshold', 'sd_host_auto_kmer_size', 'sd_host_bin_size', 'sd_host_pair_list',
-    'sd_host_lgamma_table', 'sd_host_evalue', 'sd_host_bitscore', 'sd_agg_create', 'sd_agg_destroy', 'sd_agg_add',
-    'sd_agg_finish', 'sd_agg_stats', 'sd_agg_get', 'sd_agg_write_tsv',
-]
+def _declared_symbols():
+    """every function include/spacedust_gpu.h declares (tests/test_capi.py checks the library exports each of them)"""
+    import re
+    text = open(os.path.join(os.path.dirname(HERE), 'include', 'spacedust_gpu.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    names = []
+    for m in re.finditer(r'\b(sd_[a-z0-9_]+)\s*\(', text):
+        if not re.search(r'typedef[^;]*\(\s*\*\s*%s' % m.group(1), text) and m.group(1) not in names:
+            names.append(m.group(1))
+    return names
+
+
+DECLARED_SYMBOLS = _declared_symbols()
 
 
 def ptr(a):

@@ -68,7 +68,8 @@ struct sd_agg {
     float seqIdThr = 0.0f;
     bool filterSelfMatch = true;
     // after besthitbyset + combinehits filter: per worker thread, any order until finish()
-    struct HitKey { uint32_t cell, q, idx; };           // cell = qSet * nTSets + tSet
+    struct HitKey { uint64_t cell; uint32_t q, idx; };  // cell = qSet * nTSets + tSet (64 bit: 30 000 x 30 000 sets and more)
+    std::vector<uint32_t> qDbKey, tDbKey;               // optional DB keys (sd_agg_set_keys): order inside entries, compareHits tie-break
     std::vector<std::vector<BestHit> > tBest;
     std::vector<std::vector<HitKey> > tKey;
     std::vector<std::string> tCigar;
@@ -136,7 +137,8 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
         double eval;
         int bits;
         int dbLen;
-        uint32_t key;
+        uint32_t key;   // DB key of the target (Matcher::compareHits' last criterion)
+        uint32_t t;     // target index
         float seqId;
     };
 #pragma omp parallel num_threads(T) reduction(+ : accepted)
@@ -177,7 +179,8 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                 c.i = i;
                 c.eval = r.evalue;
                 c.dbLen = a->tLen[pairT[i]];
-                c.key = pairT[i];
+                c.key = a->tDbKey.empty() ? pairT[i] : a->tDbKey[pairT[i]];
+                c.t = pairT[i];
                 if (ident) {
                     c.seqId = 1.0f;   // Alignment.cpp:382-387
                 } else {
@@ -191,7 +194,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                 }
                 c.bits = static_cast<int>(sd_host_bitscore((double) (uint32_t) r.score) + 0.5);   // Matcher.cpp:130
                 accepted++;
-                const uint32_t ts = a->tSetOf[c.key];
+                const uint32_t ts = a->tSetOf[c.t];
                 if (stamp[ts] != gen) {
                     stamp[ts] = gen;
                     slotOf[ts] = (uint32_t) slotBest.size();
@@ -224,7 +227,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                 b.pvalText[sizeof(b.pvalText) - 1] = '\0';
                 char *e = sd::seqIdToBuffer(c->seqId, b.seqIdText);
                 *e = '\0';
-                b.q = q; b.t = c->key; b.qSet = qs; b.tSet = ts;
+                b.q = q; b.t = c->t; b.qSet = qs; b.tSet = ts;
                 b.qStart = r.qStart; b.qEnd = r.qEnd; b.qLen = qL;
                 b.tStart = r.tStart; b.tEnd = r.tEnd; b.tLen = c->dbLen;
                 b.arena = (uint32_t) th;
@@ -235,7 +238,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                     b.cigarLen = (uint32_t) (myCigar.size() - b.cigarOff);
                 }
                 sd_agg::HitKey hk;
-                hk.cell = qs * a->nTSets + ts; hk.q = q; hk.idx = (uint32_t) myBest.size();
+                hk.cell = (uint64_t) qs * a->nTSets + ts; hk.q = a->qDbKey.empty() ? q : a->qDbKey[q]; hk.idx = (uint32_t) myBest.size();
                 myKey.push_back(hk);
                 myBest.push_back(b);
             }
@@ -253,40 +256,48 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
 
 // sort into (qSet, tSet) entries; hits inside an entry by query key (mergeresultsbyset order)
 int sd_agg_finish(sd_agg *a, uint64_t *nEntries, uint64_t *nHits) {
+    if (!a) return SD_EINVAL;
     size_t total = 0;
     for (size_t t = 0; t < a->tBest.size(); t++) total += a->tBest[t].size();
-    a->best.assign(total, (const BestHit *) NULL);
-    // counting sort into (qSet, tSet) entries, then the few hundred hits of an entry by query key; (qSet, tSet, q)
-    // is unique per hit, so the order does not depend on how the hits were spread over threads
-    const size_t nCells = (size_t) a->nQSets * a->nTSets;
-    std::vector<uint64_t> cellStart(nCells + 1, 0);
+    // (cell, query key) is unique per hit, so the sorted order does not depend on how the hits were spread over threads;
+    // sorting the hits themselves (not a dense table over all nQSets x nTSets cells) keeps this linear in the output
+    struct Ref {
+        uint64_t cell;
+        uint32_t q;
+        const BestHit *hit;
+    };
+    std::vector<Ref> refs(total);
+    size_t w = 0;
     for (size_t t = 0; t < a->tKey.size(); t++)
-        for (const sd_agg::HitKey &k : a->tKey[t]) cellStart[(size_t) k.cell + 1]++;
-    for (size_t c = 0; c < nCells; c++) cellStart[c + 1] += cellStart[c];
-    std::vector<std::pair<uint32_t, const BestHit *> > byCell(total);   // (query key, hit)
-    {
-        std::vector<uint64_t> cursor(cellStart.begin(), cellStart.end() - 1);
-        for (size_t t = 0; t < a->tKey.size(); t++)
-            for (const sd_agg::HitKey &k : a->tKey[t]) byCell[cursor[k.cell]++] = std::make_pair(k.q, &a->tBest[t][k.idx]);
-    }
-#pragma omp parallel for schedule(dynamic, 16)
-    for (size_t c = 0; c < nCells; c++) {
-        std::sort(byCell.begin() + cellStart[c], byCell.begin() + cellStart[c + 1],
-                  [](const std::pair<uint32_t, const BestHit *> &x, const std::pair<uint32_t, const BestHit *> &y) { return x.first < y.first; });
-        for (uint64_t x = cellStart[c]; x < cellStart[c + 1]; x++) a->best[x] = byCell[x].second;
-    }
+        for (const sd_agg::HitKey &k : a->tKey[t]) {
+            refs[w].cell = k.cell;
+            refs[w].q = k.q;
+            refs[w].hit = &a->tBest[t][k.idx];
+            w++;
+        }
+    __gnu_parallel::sort(refs.begin(), refs.end(), [](const Ref &x, const Ref &y) { return x.cell != y.cell ? x.cell < y.cell : x.q < y.q; });
+    a->best.resize(total);
     a->entryOff.clear();
     a->entryQSet.clear();
     a->entryTSet.clear();
-    for (size_t c = 0; c < nCells; c++) {
-        if (cellStart[c + 1] == cellStart[c]) continue;
-        a->entryOff.push_back(cellStart[c]);
-        a->entryQSet.push_back((uint32_t) (c / a->nTSets));
-        a->entryTSet.push_back((uint32_t) (c % a->nTSets));
+    for (size_t i = 0; i < total; i++) {
+        a->best[i] = refs[i].hit;
+        if (i == 0 || refs[i].cell != refs[i - 1].cell) {
+            a->entryOff.push_back(i);
+            a->entryQSet.push_back((uint32_t) (refs[i].cell / a->nTSets));
+            a->entryTSet.push_back((uint32_t) (refs[i].cell % a->nTSets));
+        }
     }
-    a->entryOff.push_back(a->best.size());
+    a->entryOff.push_back(total);
     if (nEntries) *nEntries = a->entryQSet.size();
     if (nHits) *nHits = a->best.size();
+    return SD_OK;
+}
+
+int sd_agg_set_keys(sd_agg *a, const uint32_t *qKeys, const uint32_t *tKeys) {
+    if (!a) return SD_EINVAL;
+    if (qKeys) a->qDbKey.assign(qKeys, qKeys + a->qSetOf.size());
+    if (tKeys) a->tDbKey.assign(tKeys, tKeys + a->tSetOf.size());
     return SD_OK;
 }
 
@@ -313,14 +324,15 @@ int sd_agg_get(sd_agg *a, uint64_t *entryOff, uint32_t *entryQSet, uint32_t *ent
 // summarizeresults: one "#..." line per emitted cluster followed by its member lines (ascending query position).
 // names: concatenated lookup names + offsets; sources: per set.  clusterKeyBase numbers the clusters.
 // canonical != 0 drops the cluster key and the leading ">qname" field (the `cut -f2-` form used for comparisons).
-int sd_agg_write_tsv(sd_agg *a, const char *path, const uint32_t *clusterOfHit, const uint32_t *rankInCluster,
-                     const uint32_t *nClusters, const double *pCO, const double *pMH, const uint32_t *clusterSize,
-                     const char *qNames, const uint64_t *qNameOff, const char *tNames, const uint64_t *tNameOff,
-                     const char *qSources, const uint64_t *qSourceOff, const char *tSources, const uint64_t *tSourceOff,
-                     int canonical, uint64_t *nClusterLines, uint64_t *nHitLines) {
-    FILE *f = fopen(path, "w");
+int sd_agg_write_tsv_from(sd_agg *a, const char *path, int append, uint64_t firstClusterKey, const uint32_t *clusterOfHit,
+                          const uint32_t *rankInCluster, const uint32_t *nClusters, const double *pCO, const double *pMH,
+                          const uint32_t *clusterSize, const char *qNames, const uint64_t *qNameOff, const char *tNames,
+                          const uint64_t *tNameOff, const char *qSources, const uint64_t *qSourceOff, const char *tSources,
+                          const uint64_t *tSourceOff, int canonical, uint64_t *nClusterLines, uint64_t *nHitLines) {
+    if (!a || !path) return SD_EINVAL;
+    FILE *f = fopen(path, append ? "a" : "w");
     if (!f) return SD_EINVAL;
-    uint64_t key = 0, nc = 0, nh = 0;
+    uint64_t key = firstClusterKey, nc = 0, nh = 0;
     std::vector<uint32_t> order;
     for (size_t e = 0; e + 1 < a->entryOff.size(); e++) {
         const uint64_t off = a->entryOff[e], end = a->entryOff[e + 1];
@@ -352,6 +364,15 @@ int sd_agg_write_tsv(sd_agg *a, const char *path, const uint32_t *clusterOfHit, 
     if (nClusterLines) *nClusterLines = nc;
     if (nHitLines) *nHitLines = nh;
     return SD_OK;
+}
+
+int sd_agg_write_tsv(sd_agg *a, const char *path, const uint32_t *clusterOfHit, const uint32_t *rankInCluster,
+                     const uint32_t *nClusters, const double *pCO, const double *pMH, const uint32_t *clusterSize,
+                     const char *qNames, const uint64_t *qNameOff, const char *tNames, const uint64_t *tNameOff,
+                     const char *qSources, const uint64_t *qSourceOff, const char *tSources, const uint64_t *tSourceOff,
+                     int canonical, uint64_t *nClusterLines, uint64_t *nHitLines) {
+    return sd_agg_write_tsv_from(a, path, 0, 0, clusterOfHit, rankInCluster, nClusters, pCO, pMH, clusterSize, qNames, qNameOff,
+                                 tNames, tNameOff, qSources, qSourceOff, tSources, tSourceOff, canonical, nClusterLines, nHitLines);
 }
 
 }  // extern "C"

@@ -1,0 +1,722 @@
+// sd_search: the C++ host driver of the streaming clustersearch pipeline (include/spacedust_gpu.h, "the whole search in
+// one object").  The reference runs the same work as separate processes with DBs in between
+// (R/data/clustersearch.sh:110-146: search = prefilter + align, prefixid, besthitbyset, mergeresultsbyset, combinehits,
+// clusterhits); here the stages of consecutive query chunks overlap on stage threads and two HIP streams:
+//     bias(i+2)  |  prefilter + pair list (i+1)  |  alignments (i)  |  aggregation (i-1)
+// Every stage is a call of the C ABI (sd_prefilter_batch, sd_sw_align_batch_compact, sd_agg_*, sd_clusterhits_batch);
+// nothing is computed here.
+#include "sd_host.h"
+#include "spacedust_gpu.h"
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <functional>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+double nowSec() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// one thread executing submitted jobs in order (a stage of the pipeline)
+class StageThread {
+public:
+    StageThread() : stop_(false), th_([this] { run(); }) {}
+    ~StageThread() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    template <class F>
+    auto submit(F f) -> std::future<decltype(f())> {
+        typedef decltype(f()) R;
+        std::shared_ptr<std::packaged_task<R()> > task(new std::packaged_task<R()>(std::move(f)));
+        std::future<R> fut = task->get_future();
+        {
+            std::lock_guard<std::mutex> l(m_);
+            q_.push_back([task] { (*task)(); });
+        }
+        cv_.notify_one();
+        return fut;
+    }
+
+private:
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                job = std::move(q_.front());
+                q_.pop_front();
+            }
+            job();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()> > q_;
+    bool stop_;
+    std::thread th_;
+};
+
+int hostCpus() {
+    long t = 0;
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string q, p;
+    if (f >> q >> p && q != "max") {
+        const double quota = strtod(q.c_str(), nullptr), period = strtod(p.c_str(), nullptr);
+        if (quota > 0 && period > 0) t = (long) (quota / period + 0.5);
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (t <= 0 || (hw > 0 && t > (long) hw)) t = hw > 0 ? (long) hw : 1;
+    if (const char *e = getenv("SD_CPUS")) t = std::max(1, atoi(e));
+    return (int) std::max(1L, t);
+}
+
+struct BiasOut {
+    uint32_t c0 = 0, c1 = 0;
+    std::vector<uint64_t> off;
+    std::vector<int8_t> sw, dg;
+    std::vector<int16_t> km;
+    double seconds = 0;
+    int rc = SD_OK;
+};
+
+struct PfOut {
+    std::unique_ptr<BiasOut> bias;
+    std::vector<sd_hit> hits;
+    std::vector<uint32_t> counts;
+    std::vector<uint64_t> stats;   // 4 per query
+    std::vector<uint32_t> pairQ, pairT;
+    uint64_t nPairs = 0;
+    double tPrefilter = 0, tPairs = 0;
+    int rc = SD_OK;
+    std::string err;
+};
+
+enum { T_INDEX, T_UPLOAD, T_BIAS, T_PREFILTER, T_PAIRS, T_SEQSET, T_ALIGN, T_AGG_WAIT, T_AGG_BUSY, T_CLUSTERHITS, T_PF_WAIT, T_TOTAL, T_N = 16 };
+enum { S_KMERS, S_INDEX_HITS, S_DIAGONALS, S_DIAG_LEN, S_PREF_HITS, S_PAIRS, S_CELLS_FWD, S_CELLS_REV, S_CELLS_TB, S_ENTRIES, S_MASKED, S_K,
+       S_KMER_THR, S_BIN, S_N = 16 };
+
+}  // namespace
+
+struct sd_search_result {
+    sd_agg *agg = nullptr;
+    uint64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint64_t> entryOff;
+    std::vector<uint32_t> entryQ, entryT, hitQ, hitT, clusterOf, rank, nClusters, cSize;
+    std::vector<double> pval, pCO, pMH;
+    ~sd_search_result() {
+        if (agg) sd_agg_destroy(agg);
+    }
+};
+
+struct sd_search {
+    sd_search_params par;
+    sd_setdb T;
+    int device = 0;
+    sd_host *host = nullptr;
+    sd_ctx *ctxPf = nullptr, *ctxAl = nullptr, *ctxBias = nullptr;
+    sd_host_index *index = nullptr;
+    sd_target *target = nullptr;
+    sd_seqset *tSeqs = nullptr;
+    int k = 6, kmerThr = 0;
+    sd_prefilter_params pfPar;
+    sd_sw_params swPar;
+    sd_ch_params chPar;
+    std::vector<int32_t> tLen;
+    std::vector<uint32_t> tSetSize;
+    std::vector<double> lgamma;
+    uint64_t stats[S_N];
+    double seconds[T_N];
+    std::string err;
+    sd_pref_sink prefSink = nullptr;
+    sd_aln_sink alnSink = nullptr;
+    void *sinkUser = nullptr;
+    // alignment result buffers, alternating between consecutive chunks (the aggregation of chunk i-1 reads one while the
+    // alignments of chunk i fill the other)
+    struct AlnBuf {
+        std::vector<sd_sw_result> res;
+        std::vector<uint32_t> idx, pq, pt;
+        std::vector<uint8_t> ident;
+        std::vector<char> pool;
+    } buf[2];
+    int flip = 0;
+
+    ~sd_search() {
+        if (tSeqs) sd_seqset_destroy(tSeqs);
+        if (target) sd_target_destroy(target);
+        if (index) sd_host_index_destroy(index);
+        if (ctxBias) sd_ctx_destroy(ctxBias);
+        if (ctxAl) sd_ctx_destroy(ctxAl);
+        if (ctxPf) sd_ctx_destroy(ctxPf);
+        if (host) sd_host_destroy(host);
+    }
+    int fail(int rc, const std::string &what, sd_ctx *ctx = nullptr) {
+        err = what + " failed (" + std::to_string(rc) + ")";
+        if (ctx) err += std::string(": ") + sd_last_error(ctx);
+        return rc;
+    }
+};
+
+extern "C" {
+
+void sd_search_default_params(sd_search_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->sensitivity = 5.7f;   // R/src/workflow/clustersearch.cpp:9-37
+    p->kmerSize = 0;
+    p->maxSeqs = 300;
+    p->minDiagScore = 15;
+    p->binSize = 0;
+    p->mask = 1;
+    p->maskProb = 0.9;
+    p->compBiasCorr = 1;
+    p->evalThr = 10.0;
+    p->covMode = 2;
+    p->covThr = 0.8f;
+    p->alnLenThr = 30;
+    p->maxGeneGap = 3;
+    p->clusterSize = 2;
+    p->alpha = 1.0;
+    p->pCluThr = 0.01f;
+    p->pMHThr = 0.01f;
+    p->filterSelfMatch = 0;
+    p->profileQueries = 0;
+    p->chunkQueries = 10000;
+    p->deviceBias = -1;
+    p->threads = 0;
+    p->alignPriority = 1;
+}
+
+int sd_search_create(int device, const sd_search_params *par, const sd_setdb *target, sd_search **out) {
+    if (!par || !target || !out || !target->residues || !target->offsets || !target->setId || !target->posInSet || !target->strand)
+        return SD_EINVAL;
+    std::unique_ptr<sd_search> s(new sd_search());
+    s->par = *par;
+    s->T = *target;
+    s->device = device;
+    memset(s->stats, 0, sizeof(s->stats));
+    memset(s->seconds, 0, sizeof(s->seconds));
+    const int cpus = hostCpus();
+    const int threads = par->threads > 0 ? par->threads : cpus;
+    int rc = sd_host_create(threads, &s->host);
+    if (rc != SD_OK) return rc;
+    rc = sd_ctx_create(device, &s->ctxPf);
+    if (rc != SD_OK) return rc;
+    rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAl);
+    if (rc != SD_OK) return rc;
+    bool devBias = par->deviceBias > 0;
+    if (par->deviceBias < 0) {
+        int local = 1;
+        if (const char *e = getenv("LOCAL_WORLD_SIZE")) local = std::max(1, atoi(e));
+        devBias = cpus / local < 8;
+    }
+    if (devBias && par->compBiasCorr && !par->profileQueries) {
+        rc = sd_ctx_create(device, &s->ctxBias);
+        if (rc != SD_OK) return rc;
+    }
+    const uint64_t tRes = target->offsets[target->n];
+    s->k = par->kmerSize ? par->kmerSize : sd_host_auto_kmer_size(tRes);
+    if (s->k != 6 && s->k != 7) return SD_EUNSUPPORTED;
+    s->kmerThr = par->profileQueries ? sd_host_profile_kmer_threshold(par->sensitivity, s->k) : sd_host_kmer_threshold(par->sensitivity, s->k);
+    double t0 = nowSec();
+    rc = sd_host_index_build(s->host, target->residues, target->offsets, target->n, s->k, par->profileQueries ? 0 : s->kmerThr,
+                             par->mask ? 1 : 0, par->maskProb, &s->index);
+    if (rc != SD_OK) return rc;
+    s->seconds[T_INDEX] = nowSec() - t0;
+    uint64_t tableSize = 0, nEntries = 0, masked = 0;
+    sd_host_index_info(s->index, &tableSize, &nEntries, &masked);
+    s->stats[S_ENTRIES] = nEntries;
+    s->stats[S_MASKED] = masked;
+    s->stats[S_K] = (uint64_t) s->k;
+    s->stats[S_KMER_THR] = (uint64_t) s->kmerThr;
+    t0 = nowSec();
+    {
+        const uint32_t *kOff, *eSeq;
+        const uint16_t *ePos;
+        const uint8_t *mres;
+        sd_host_index_arrays(s->index, &kOff, &eSeq, &ePos, &mres);
+        const int16_t *s2, *s3;
+        const uint16_t *i2, *i3;
+        uint32_t z2, z3;
+        sd_host_ext_matrix(s->host, 2, &s2, &i2, &z2);
+        sd_host_ext_matrix(s->host, 3, &s3, &i3, &z3);
+        rc = sd_target_create(s->ctxPf, s->k, kOff, eSeq, ePos, nEntries, mres, target->offsets, target->n, s2, i2, s3, i3, &s->target);
+        if (rc != SD_OK) return rc;
+    }
+    rc = sd_seqset_create(s->ctxAl, target->residues, target->offsets, target->n, nullptr, &s->tSeqs);
+    if (rc != SD_OK) return rc;
+    s->seconds[T_UPLOAD] = nowSec() - t0;
+    memset(&s->pfPar, 0, sizeof(s->pfPar));
+    s->pfPar.kmerSize = s->k;
+    s->pfPar.kmerThr = s->kmerThr;
+    s->pfPar.maxHitsPerQuery = (int32_t) std::max<int64_t>(1, std::min<int64_t>(par->maxSeqs, target->n));
+    s->pfPar.minDiagScore = par->minDiagScore;
+    s->pfPar.binSize = par->binSize ? par->binSize : sd_host_bin_size(target->n, 0);
+    s->pfPar.covMode = par->covMode;
+    s->pfPar.covThr = (par->covMode == 0 || par->covMode == 2 || par->covMode == 5) ? par->covThr : 0.0f;
+    sd_host_matrix(s->host, 2, s->pfPar.ungappedMatrix, nullptr, nullptr);
+    s->stats[S_BIN] = s->pfPar.binSize;
+    memset(&s->swPar, 0, sizeof(s->swPar));
+    s->swPar.gapOpen = 11;
+    s->swPar.gapExtend = 1;
+    sd_host_matrix(s->host, 0, s->swPar.matrix, nullptr, nullptr);
+    s->swPar.covMode = par->covMode;
+    s->swPar.covThr = par->covThr;
+    s->swPar.evalThr = par->evalThr;
+    s->swPar.swMode = 2;
+    s->swPar.dbResidues = tRes;
+    s->chPar.maxGeneGap = par->maxGeneGap;
+    s->chPar.clusterSize = par->clusterSize;
+    s->chPar.alpha = par->alpha;
+    s->chPar.pCluThr = par->pCluThr;
+    s->chPar.pMHThr = par->pMHThr;
+    s->tLen.resize(target->n);
+    for (uint32_t i = 0; i < target->n; i++) s->tLen[i] = (int32_t) (target->offsets[i + 1] - target->offsets[i]);
+    s->tSetSize.assign(target->nSets, 0);
+    for (uint32_t i = 0; i < target->n; i++)
+        if (target->setId[i] < target->nSets) s->tSetSize[target->setId[i]]++;
+    *out = s.release();
+    return SD_OK;
+}
+
+void sd_search_destroy(sd_search *s) { delete s; }
+const char *sd_search_last_error(sd_search *s) { return s ? s->err.c_str() : ""; }
+sd_ctx *sd_search_ctx(sd_search *s, int which) { return !s ? nullptr : (which == 0 ? s->ctxPf : (which == 1 ? s->ctxAl : s->ctxBias)); }
+
+int sd_search_set_sinks(sd_search *s, sd_pref_sink pref, sd_aln_sink aln, void *user) {
+    if (!s) return SD_EINVAL;
+    s->prefSink = pref;
+    s->alnSink = aln;
+    s->sinkUser = user;
+    return SD_OK;
+}
+
+int sd_search_set_chunk_queries(sd_search *s, int32_t chunkQueries) {
+    if (!s || chunkQueries < 1) return SD_EINVAL;
+    s->par.chunkQueries = chunkQueries;
+    return SD_OK;
+}
+
+int sd_search_stats(sd_search *s, uint64_t *stats, double *seconds) {
+    if (!s) return SD_EINVAL;
+    if (stats) memcpy(stats, s->stats, sizeof(s->stats));
+    if (seconds) memcpy(seconds, s->seconds, sizeof(s->seconds));
+    return SD_OK;
+}
+
+int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRanges, const uint32_t *rangeBegin,
+                     const uint32_t *rangeEnd, sd_search_result **results) {
+    if (!s || !Q || !results || (nRanges && (!rangeBegin || !rangeEnd))) return SD_EINVAL;
+    const bool profile = Q->alnProfile != nullptr;
+    if (profile != (s->par.profileQueries != 0)) return s->fail(SD_EINVAL, "sd_search_stream: query DB type does not match profileQueries");
+    if (profile && (!Q->sortedScore || !Q->sortedIndex)) return SD_EINVAL;
+    const double tAll = nowSec();
+    const sd_setdb &T = s->T;
+    std::vector<int32_t> qLen(Q->n);
+    for (uint32_t i = 0; i < Q->n; i++) qLen[i] = (int32_t) (Q->offsets[i + 1] - Q->offsets[i]);
+    std::vector<uint32_t> qSetSize(Q->nSets, 0);
+    for (uint32_t i = 0; i < Q->n; i++)
+        if (Q->setId[i] < Q->nSets) qSetSize[Q->setId[i]]++;
+    // lgamma table for clusterhits: set sizes and gene positions bound the indices (ClusterHits.cpp:259-271)
+    {
+        uint32_t m = 0;
+        for (uint32_t v : qSetSize) m = std::max(m, v);
+        for (uint32_t v : s->tSetSize) m = std::max(m, v);
+        for (uint32_t i = 0; i < Q->n; i++) m = std::max(m, Q->posInSet[i]);
+        for (uint32_t i = 0; i < T.n; i++) m = std::max(m, T.posInSet[i]);
+        if (s->lgamma.size() < (size_t) m + 8) {
+            s->lgamma.resize((size_t) m + 8);
+            sd_host_lgamma_table(s->lgamma.data(), (uint32_t) s->lgamma.size());
+        }
+    }
+    std::vector<std::unique_ptr<sd_search_result> > res(nRanges);
+    for (uint32_t r = 0; r < nRanges; r++) {
+        res[r].reset(new sd_search_result());
+        int rc = sd_agg_create(Q->setId, qLen.data(), Q->n, T.setId, s->tLen.data(), T.n, Q->nSets, T.nSets, s->par.evalThr, s->par.covMode,
+                               s->par.covThr, s->par.alnLenThr, s->par.filterSelfMatch, &res[r]->agg);
+        if (rc != SD_OK) return s->fail(rc, "sd_agg_create");
+        if (Q->keys || T.keys) sd_agg_set_keys(res[r]->agg, Q->keys, T.keys);
+    }
+    // chunks: whole query proteins; the very first chunk of a stream is a quarter of the others (its prefilter is the one
+    // stage nothing overlaps with, so the alignment thread starts that much earlier)
+    struct Chunk {
+        uint32_t range, c0, c1;
+    };
+    std::vector<Chunk> chunks;
+    const uint32_t chunkQ = (uint32_t) (s->par.chunkQueries > 0 ? s->par.chunkQueries : 10000);
+    for (uint32_t r = 0; r < nRanges; r++) {
+        if (rangeEnd[r] > Q->n || rangeBegin[r] > rangeEnd[r]) return s->fail(SD_EINVAL, "sd_search_stream: bad range");
+        for (uint32_t c0 = rangeBegin[r]; c0 < rangeEnd[r];) {
+            const uint32_t step = chunks.empty() ? std::max<uint32_t>(1, std::min(chunkQ, std::max<uint32_t>(1000, chunkQ / 4))) : chunkQ;
+            Chunk c;
+            c.range = r;
+            c.c0 = c0;
+            c.c1 = (uint32_t) std::min<uint64_t>(rangeEnd[r], (uint64_t) c0 + step);
+            chunks.push_back(c);
+            c0 = c.c1;
+        }
+    }
+    std::vector<int64_t> lastChunkOf(nRanges, -1);
+    for (size_t x = 0; x < chunks.size(); x++) lastChunkOf[chunks[x].range] = (int64_t) x;
+
+    StageThread biasStage, pfStage, aggStage;
+    double *tm = s->seconds;
+
+    auto biasJob = [s, Q, profile](uint32_t c0, uint32_t c1) {
+        std::unique_ptr<BiasOut> o(new BiasOut());
+        o->c0 = c0;
+        o->c1 = c1;
+        const uint32_t nq = c1 - c0;
+        const uint64_t r0 = Q->offsets[c0], r1 = Q->offsets[c1];
+        o->off.resize((size_t) nq + 1);
+        for (uint32_t i = 0; i <= nq; i++) o->off[i] = Q->offsets[c0 + i] - r0;
+        if (profile) return o;   // no composition bias for profile queries (QueryMatcher.cpp:93-99, ssw_init :1229-1240)
+        const double t0 = nowSec();
+        o->sw.assign(r1 - r0 + 1, 0);
+        o->dg.assign(r1 - r0 + 1, 0);
+        o->km.assign(r1 - r0 + 1, 0);
+        if (s->par.compBiasCorr) {
+            if (s->ctxBias)
+                o->rc = sd_comp_bias_batch(s->ctxBias, s->host, Q->residues + r0, o->off.data(), nq, s->k, o->sw.data(), o->dg.data(), o->km.data());
+            else
+                o->rc = sd_host_comp_bias(s->host, Q->residues + r0, o->off.data(), nq, s->k, o->sw.data(), o->dg.data(), o->km.data());
+        }
+        o->seconds = nowSec() - t0;
+        return o;
+    };
+    typedef std::future<std::unique_ptr<BiasOut> > BiasFut;
+    auto pfJob = [s, Q, profile, sameDb](std::shared_ptr<BiasFut> bf) {
+        std::unique_ptr<PfOut> o(new PfOut());
+        o->bias = bf->get();
+        BiasOut &b = *o->bias;
+        if (b.rc != SD_OK) {
+            o->rc = b.rc;
+            o->err = "composition bias";
+            return o;
+        }
+        const uint32_t nq = b.c1 - b.c0;
+        const uint64_t r0 = Q->offsets[b.c0];
+        std::vector<uint32_t> ident(nq);
+        for (uint32_t i = 0; i < nq; i++) ident[i] = sameDb ? b.c0 + i : UINT32_MAX;
+        const uint32_t W = (uint32_t) s->pfPar.maxHitsPerQuery;
+        o->hits.resize((size_t) nq * W);
+        o->counts.assign(nq, 0);
+        o->stats.assign((size_t) nq * 4, 0);
+        double t0 = nowSec();
+        if (profile)
+            o->rc = sd_prefilter_profile_batch(s->ctxPf, s->target, &s->pfPar, nq, Q->residues + r0, b.off.data(), Q->sortedScore + r0 * 20,
+                                               Q->sortedIndex + r0 * 20, Q->alnProfile + r0 * 21, ident.data(), o->hits.data(),
+                                               o->counts.data(), o->stats.data());
+        else
+            o->rc = sd_prefilter_batch(s->ctxPf, s->target, &s->pfPar, nq, Q->residues + r0, b.off.data(), b.km.data(), b.dg.data(),
+                                       ident.data(), o->hits.data(), o->counts.data(), o->stats.data());
+        o->tPrefilter = nowSec() - t0;
+        if (o->rc != SD_OK) {
+            o->err = std::string("sd_prefilter_batch: ") + sd_last_error(s->ctxPf);
+            return o;
+        }
+        if (s->prefSink) s->prefSink(s->sinkUser, b.c0, nq, o->hits.data(), o->counts.data(), W);
+        // pair list in prefilter order (Alignment.cpp:346-379); Alignment::run's coverage pre-check (:370-373) is the test
+        // the prefilter already applied
+        t0 = nowSec();
+        o->nPairs = sd_host_pair_list(o->hits.data(), o->counts.data(), nq, W, nullptr, nullptr);
+        o->pairQ.resize(std::max<uint64_t>(o->nPairs, 1));
+        o->pairT.resize(std::max<uint64_t>(o->nPairs, 1));
+        if (o->nPairs) sd_host_pair_list(o->hits.data(), o->counts.data(), nq, W, o->pairQ.data(), o->pairT.data());
+        o->tPairs = nowSec() - t0;
+        return o;
+    };
+    typedef std::future<std::unique_ptr<PfOut> > PfFut;
+    std::vector<std::shared_ptr<BiasFut> > biasFut(chunks.size());
+    auto submitBias = [&](size_t x) {
+        if (x < chunks.size() && !biasFut[x]) {
+            const uint32_t c0 = chunks[x].c0, c1 = chunks[x].c1;
+            biasFut[x].reset(new BiasFut(biasStage.submit([biasJob, c0, c1] { return biasJob(c0, c1); })));
+        }
+    };
+    auto submitPf = [&](size_t x) {
+        submitBias(x);
+        std::shared_ptr<BiasFut> bf = biasFut[x];
+        PfFut f = pfStage.submit([pfJob, bf] { return pfJob(bf); });
+        submitBias(x + 1);
+        return f;
+    };
+
+    int status = SD_OK;
+    std::future<std::pair<int, double> > pending;
+    bool havePending = false;
+    auto waitPending = [&]() {
+        if (!havePending) return;
+        const double t0 = nowSec();
+        const std::pair<int, double> r = pending.get();
+        tm[T_AGG_WAIT] += nowSec() - t0;
+        tm[T_AGG_BUSY] += r.second;
+        havePending = false;
+        if (r.first != SD_OK && status == SD_OK) status = s->fail(r.first, "sd_agg_add");
+    };
+
+    auto finalize = [&](uint32_t r) -> int {
+        sd_search_result &R = *res[r];
+        double t0 = nowSec();
+        uint64_t ne = 0, nh = 0;
+        int rc = sd_agg_finish(R.agg, &ne, &nh);
+        if (rc != SD_OK) return s->fail(rc, "sd_agg_finish");
+        R.entryOff.assign(ne + 1, 0);
+        R.entryQ.assign(std::max<uint64_t>(ne, 1), 0);
+        R.entryT.assign(std::max<uint64_t>(ne, 1), 0);
+        R.hitQ.assign(std::max<uint64_t>(nh, 1), 0);
+        R.hitT.assign(std::max<uint64_t>(nh, 1), 0);
+        R.pval.assign(std::max<uint64_t>(nh, 1), 0.0);
+        rc = sd_agg_get(R.agg, R.entryOff.data(), R.entryQ.data(), R.entryT.data(), R.hitQ.data(), R.hitT.data(), R.pval.data());
+        if (rc != SD_OK) return s->fail(rc, "sd_agg_get");
+        R.entryQ.resize(ne);
+        R.entryT.resize(ne);
+        R.hitQ.resize(nh);
+        R.hitT.resize(nh);
+        R.pval.resize(nh);
+        tm[T_AGG_WAIT] += nowSec() - t0;
+        t0 = nowSec();
+        R.clusterOf.assign(nh, UINT32_MAX);
+        R.rank.assign(nh, 0);
+        R.nClusters.assign(ne, 0);
+        R.cSize.assign(nh, 0);
+        R.pCO.assign(nh, 0.0);
+        R.pMH.assign(nh, 0.0);
+        uint64_t nClu = 0, nCluHits = 0;
+        if (nh > 0) {
+            std::vector<uint32_t> qp(nh), tp(nh), nq(ne);
+            std::vector<uint8_t> sd(nh);
+            for (uint64_t h = 0; h < nh; h++) {
+                qp[h] = Q->posInSet[R.hitQ[h]];
+                tp[h] = T.posInSet[R.hitT[h]];
+                sd[h] = (uint8_t) (Q->strand[R.hitQ[h]] | (T.strand[R.hitT[h]] << 1));
+            }
+            for (uint64_t e = 0; e < ne; e++) nq[e] = qSetSize[R.entryQ[e]];
+            rc = sd_clusterhits_batch(s->ctxAl, &s->chPar, (uint32_t) ne, R.entryOff.data(), qp.data(), tp.data(), sd.data(), R.pval.data(),
+                                      nq.data(), s->lgamma.data(), (uint32_t) s->lgamma.size(), R.clusterOf.data(), R.rank.data(),
+                                      R.nClusters.data(), R.pCO.data(), R.pMH.data(), R.cSize.data());
+            if (rc != SD_OK) return s->fail(rc, "sd_clusterhits_batch", s->ctxAl);
+            for (uint64_t e = 0; e < ne; e++) nClu += R.nClusters[e];
+            for (uint64_t h = 0; h < nh; h++) nCluHits += R.clusterOf[h] != UINT32_MAX;
+        }
+        tm[T_CLUSTERHITS] += nowSec() - t0;
+        uint64_t na = 0, nacc = 0;
+        sd_agg_stats(R.agg, &na, &nacc);
+        R.counts[0] = ne;
+        R.counts[1] = nh;
+        R.counts[2] = nClu;
+        R.counts[3] = nCluHits;
+        R.counts[4] = na;
+        R.counts[5] = nacc;
+        return SD_OK;
+    };
+
+    std::vector<std::pair<uint32_t, size_t> > toFinalize;   // (range, chunk whose aggregation must have finished)
+    std::vector<char> finalized(nRanges, 0);
+    std::vector<uint64_t> prefHitsOfRange(nRanges, 0), pairsOfRange(nRanges, 0);
+    PfFut pfNext;
+    if (!chunks.empty()) pfNext = submitPf(0);
+    for (size_t ci = 0; ci < chunks.size() && status == SD_OK; ci++) {
+        const uint32_t r = chunks[ci].range;
+        double t0 = nowSec();
+        std::unique_ptr<PfOut> d = pfNext.get();
+        tm[T_PF_WAIT] += nowSec() - t0;
+        if (ci + 1 < chunks.size()) pfNext = submitPf(ci + 1);
+        if (d->rc != SD_OK) {
+            status = s->fail(d->rc, d->err);
+            break;
+        }
+        tm[T_BIAS] += d->bias->seconds;
+        tm[T_PREFILTER] += d->tPrefilter;
+        tm[T_PAIRS] += d->tPairs;
+        const uint32_t c0 = d->bias->c0, c1 = d->bias->c1, nq = c1 - c0;
+        for (uint32_t i = 0; i < nq; i++) {
+            s->stats[S_KMERS] += d->stats[(size_t) i * 4];
+            s->stats[S_INDEX_HITS] += d->stats[(size_t) i * 4 + 1];
+            s->stats[S_DIAGONALS] += d->stats[(size_t) i * 4 + 2];
+            s->stats[S_DIAG_LEN] += d->stats[(size_t) i * 4 + 3];
+        }
+        s->stats[S_PREF_HITS] += d->nPairs;
+        prefHitsOfRange[r] += d->nPairs;
+        if (d->nPairs > 0) {
+            const uint64_t r0 = Q->offsets[c0];
+            t0 = nowSec();
+            sd_seqset *qset = nullptr;
+            int rc;
+            if (profile)
+                rc = sd_profileset_create(s->ctxAl, Q->residues + r0, d->bias->off.data(), nq, Q->alnProfile + r0 * 21, &qset);
+            else
+                rc = sd_seqset_create(s->ctxAl, Q->residues + r0, d->bias->off.data(), nq, d->bias->sw.data(), &qset);
+            if (rc != SD_OK) {
+                status = s->fail(rc, "sd_seqset_create", s->ctxAl);
+                break;
+            }
+            tm[T_SEQSET] += nowSec() - t0;
+            t0 = nowSec();
+            const uint32_t n = (uint32_t) d->nPairs;
+            std::vector<uint8_t> identAll(n, 0);
+            if (sameDb)
+                for (uint32_t i = 0; i < n; i++) identAll[i] = (d->pairQ[i] + c0 == d->pairT[i]) ? 1 : 0;
+            // the other buffer still feeds the aggregation of the previous chunk: only this call's slot is touched, also
+            // when the backtrace pool has to grow and the call is repeated
+            s->flip = 1 - s->flip;
+            sd_search::AlnBuf &B = s->buf[s->flip];
+            if (B.res.size() < n) {
+                B.res.resize((size_t) (1.25 * n) + 16);
+                B.idx.resize(B.res.size());
+            }
+            uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(1u << 20, 96ull * n), B.pool.size());
+            bool exact = false;
+            uint32_t nOut = 0;
+            for (;;) {
+                if (B.pool.size() < cap) B.pool.resize(cap);
+                uint64_t used = 0;
+                // only the reportable pairs come back (identity pairs + pairs past every gate, ~10 %): everything else
+                // fails Alignment::checkCriteria and would be skipped by the aggregation anyway
+                rc = sd_sw_align_batch_compact(s->ctxAl, &s->swPar, qset, s->tSeqs, n, d->pairQ.data(), d->pairT.data(), identAll.data(),
+                                               B.idx.data(), B.res.data(), &nOut, B.pool.data(), B.pool.size(), &used);
+                if (rc == SD_ENOMEM && !exact) {
+                    uint64_t need = 64;
+                    for (uint32_t i = 0; i < n; i++) need += (uint64_t) qLen[c0 + d->pairQ[i]] + (uint64_t) s->tLen[d->pairT[i]];
+                    cap = need;
+                    exact = true;
+                    continue;
+                }
+                break;
+            }
+            sd_seqset_destroy(qset);
+            if (rc != SD_OK) {
+                status = s->fail(rc, "sd_sw_align_batch_compact", s->ctxAl);
+                break;
+            }
+            B.pq.resize(std::max<uint32_t>(nOut, 1));
+            B.pt.resize(std::max<uint32_t>(nOut, 1));
+            B.ident.resize(std::max<uint32_t>(nOut, 1));
+            for (uint32_t x = 0; x < nOut; x++) {
+                B.pq[x] = d->pairQ[B.idx[x]];
+                B.pt[x] = d->pairT[B.idx[x]];
+                B.ident[x] = identAll[B.idx[x]];
+            }
+            tm[T_ALIGN] += nowSec() - t0;
+            uint64_t f = 0, rv = 0, tb = 0;
+            sd_sw_last_cells(s->ctxAl, &f, &rv, &tb);
+            s->stats[S_CELLS_FWD] += f;
+            s->stats[S_CELLS_REV] += rv;
+            s->stats[S_CELLS_TB] += tb;
+            s->stats[S_PAIRS] += n;
+            pairsOfRange[r] += n;
+            waitPending();
+            if (status != SD_OK) break;
+            sd_agg *agg = res[r]->agg;
+            sd_search::AlnBuf *bp = &B;
+            sd_search *sp = s;
+            pending = aggStage.submit([agg, bp, nOut, c0, nq, sp]() {
+                const double t1 = nowSec();
+                if (sp->alnSink)
+                    sp->alnSink(sp->sinkUser, c0, nq, nOut, bp->pq.data(), bp->pt.data(), bp->res.data(), bp->ident.data(), bp->pool.data());
+                const int rc2 = sd_agg_add(agg, nOut, c0, bp->pq.data(), bp->pt.data(), bp->res.data(), bp->ident.data(), bp->pool.data());
+                return std::make_pair(rc2, nowSec() - t1);
+            });
+            havePending = true;
+        } else if (s->alnSink) {
+            waitPending();
+            s->alnSink(s->sinkUser, c0, nq, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+        }
+        if (lastChunkOf[r] == (int64_t) ci) toFinalize.push_back(std::make_pair(r, ci));
+        // ranges whose last aggregation job has finished meanwhile
+        while (!toFinalize.empty() && status == SD_OK) {
+            const bool ready = !havePending || toFinalize.front().second < ci ||
+                               pending.wait_for(std::chrono::seconds(0)) == std::future_status::ready;
+            if (!ready) break;
+            if (toFinalize.front().second == ci) waitPending();
+            if (status != SD_OK) break;
+            const uint32_t fr = toFinalize.front().first;
+            toFinalize.erase(toFinalize.begin());
+            const int rc = finalize(fr);
+            finalized[fr] = 1;
+            if (rc != SD_OK) status = rc;
+        }
+    }
+    // drain: the stage threads may still hold jobs that reference this frame
+    if (pfNext.valid()) pfNext.wait();
+    for (size_t x = 0; x < biasFut.size(); x++)
+        if (biasFut[x] && biasFut[x]->valid()) biasFut[x]->wait();
+    waitPending();
+    if (status == SD_OK)
+        for (uint32_t r = 0; r < nRanges && status == SD_OK; r++)
+            if (!finalized[r]) status = finalize(r);
+    tm[T_TOTAL] = nowSec() - tAll;
+    if (status != SD_OK) return status;
+    for (uint32_t r = 0; r < nRanges; r++) {
+        res[r]->counts[6] = prefHitsOfRange[r];
+        res[r]->counts[4] = pairsOfRange[r];
+        results[r] = res[r].release();
+    }
+    return SD_OK;
+}
+
+int sd_search_result_counts(sd_search_result *r, uint64_t *counts) {
+    if (!r || !counts) return SD_EINVAL;
+    memcpy(counts, r->counts, sizeof(r->counts));
+    return SD_OK;
+}
+
+int sd_search_result_arrays(sd_search_result *r, uint64_t *entryOff, uint32_t *entryQSet, uint32_t *entryTSet, uint32_t *hitQ,
+                            uint32_t *hitT, double *pval, uint32_t *clusterOfHit, uint32_t *rankInCluster, uint32_t *nClusters,
+                            double *pCO, double *pMH, uint32_t *clusterSize) {
+    if (!r) return SD_EINVAL;
+#define SD_COPY(dst, v) \
+    if (dst && !(v).empty()) memcpy(dst, (v).data(), (v).size() * sizeof((v)[0]))
+    SD_COPY(entryOff, r->entryOff);
+    SD_COPY(entryQSet, r->entryQ);
+    SD_COPY(entryTSet, r->entryT);
+    SD_COPY(hitQ, r->hitQ);
+    SD_COPY(hitT, r->hitT);
+    SD_COPY(pval, r->pval);
+    SD_COPY(clusterOfHit, r->clusterOf);
+    SD_COPY(rankInCluster, r->rank);
+    SD_COPY(nClusters, r->nClusters);
+    SD_COPY(pCO, r->pCO);
+    SD_COPY(pMH, r->pMH);
+    SD_COPY(clusterSize, r->cSize);
+#undef SD_COPY
+    return SD_OK;
+}
+
+int sd_search_result_write_tsv(sd_search_result *r, const char *path, const char *qNames, const uint64_t *qNameOff,
+                               const char *tNames, const uint64_t *tNameOff, const char *qSources, const uint64_t *qSourceOff,
+                               const char *tSources, const uint64_t *tSourceOff, int canonical, int append,
+                               uint64_t firstClusterKey, uint64_t *nClusterLines, uint64_t *nHitLines) {
+    if (!r || !path) return SD_EINVAL;
+    static const uint32_t zero32 = 0;
+    static const double zeroD = 0.0;
+    const bool empty = r->hitQ.empty();
+    return sd_agg_write_tsv_from(r->agg, path, append, firstClusterKey, empty ? &zero32 : r->clusterOf.data(),
+                                 empty ? &zero32 : r->rank.data(), r->nClusters.empty() ? &zero32 : r->nClusters.data(),
+                                 empty ? &zeroD : r->pCO.data(), empty ? &zeroD : r->pMH.data(), empty ? &zero32 : r->cSize.data(), qNames,
+                                 qNameOff, tNames, tNameOff, qSources, qSourceOff, tSources, tSourceOff, canonical, nClusterLines,
+                                 nHitLines);
+}
+
+void sd_search_result_destroy(sd_search_result *r) { delete r; }
+
+}  // extern "C"

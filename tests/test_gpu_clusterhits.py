@@ -8,25 +8,7 @@ from oracle.pyoracle import oracle_clusterhits
 pytestmark = pytest.mark.gpu
 
 
-def _entry(rng, K, genome=600, chain_frac=0.6):
-    """hits with unique query positions: syntenic chains (both orientations), jitter and noise"""
-    q = np.sort(rng.choice(genome, size=K, replace=False)).astype(np.uint32)
-    t = np.zeros(K, np.uint32)
-    i = 0
-    while i < K:
-        run = int(rng.integers(1, 12))
-        if rng.random() < chain_frac:
-            start = int(rng.integers(0, genome))
-            sign = 1 if rng.random() < 0.5 else -1
-            for r in range(min(run, K - i)):
-                t[i + r] = (start + sign * int(q[i + r] - q[i]) + int(rng.integers(-1, 2))) % genome
-        else:
-            t[i:i + run] = rng.integers(0, genome, size=min(run, K - i))
-        i += run
-    strands = rng.integers(0, 4, size=K).astype(np.uint8)
-    pval = 10.0 ** rng.uniform(-60, -6.5, size=K)
-    perm = rng.permutation(K)
-    return q[perm], t[perm], strands[perm], pval[perm]
+from chgen import entry as _entry, many_entries
 
 
 def test_clusterhits_matches_oracle(gpu, host, oracle):
@@ -58,3 +40,32 @@ def test_clusterhits_matches_oracle(gpu, host, oracle):
             w += cs[c]
         total_clusters += n
     assert total_clusters > 20
+
+
+def test_clusterhits_matches_reference_functions_on_1500_entries(gpu, host):
+    """the batched kernel against the reference's own clusterhits code (oracle/_ref/libsdref_ch.so: R/src/util/ClusterHits.cpp
+    compiled where it lies, its merge loop re-driven over flat arrays; travels with the snapshot): partition, printed member
+    order, P-value bit patterns of 1 500 synthetic (query set, target set) entries in one sd_clusterhits_batch call"""
+    from oracle.pyoracle import ref_ch_available, RefClusterHits
+    if not ref_ch_available():
+        pytest.skip('oracle/_ref/libsdref_ch.so not present on this box')
+    ref = RefClusterHits()
+    entries = many_entries(2024, 1500)
+    off = np.zeros(len(entries) + 1, np.uint64)
+    off[1:] = np.cumsum([len(e[0]) for e in entries])
+    nq = np.array([e[4] for e in entries], np.uint32)
+    out = api.clusterhits(gpu, host, off, np.concatenate([e[0] for e in entries]), np.concatenate([e[1] for e in entries]),
+                          np.concatenate([e[2] for e in entries]), np.concatenate([e[3] for e in entries]), nq)
+    total = 0
+    for p, e in enumerate(entries):
+        rcof, rrank, rcs, rpco, rpmh = ref.entry(e[0], e[1], e[2], e[3], e[4])
+        a, b = int(off[p]), int(off[p + 1])
+        n = len(rcs)
+        assert int(out['n_clusters'][p]) == n, p
+        assert (out['cluster_of'][a:b] == rcof).all(), p
+        assert (out['size'][a:a + n] == rcs).all()
+        assert out['pCO'][a:a + n].tobytes() == rpco.tobytes() and out['pMH'][a:a + n].tobytes() == rpmh.tobytes(), p
+        clustered = rcof != 0xFFFFFFFF
+        assert (out['rank'][a:b][clustered] == rrank[clustered]).all(), p
+        total += n
+    assert total > 1000

@@ -47,7 +47,7 @@ def test_examples_regression_known_answers(gpu, host, tmp_path):
     db = load_examples(host)
     cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
     out = cs.search(db, same_db=True, tsv_path=str(tmp_path / 'result.tsv'), canonical=True, chunk_queries=3000)
-    assert cs.index.n_entries == 1784989 and cs.index.masked_residues == 11546
+    assert cs.index_entries == 1784989 and cs.masked_residues == 11546
     assert cs.stats['prefilter_hits'] == 98957
     assert out['accepted'] == 15065
     lines = open(tmp_path / 'result.tsv').readlines()
