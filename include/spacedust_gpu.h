@@ -420,6 +420,26 @@ void sd_search_result_destroy(sd_search_result *r);
  * clusterhits, waiting for the prefilter, total of the last stream, 0... */
 int sd_search_stats(sd_search *s, uint64_t *stats, double *seconds);
 
+
+/* ---- multi-GPU seam: query sets sharded over the ranks, one RCCL gather at the end --------
+ * One process per GPU.  The path has no data-path collective: every rank searches its own query sets against its own
+ * replica of the target.  The reference's counterpart is the MPI master merging per-rank result files
+ * (M/src/prefiltering/Prefiltering.cpp:630-658). */
+/* the ranks' share of the query sets: greedy by residue count, deterministic, mine[] ascending (must hold nSets entries) */
+int sd_shard_query_sets(const uint64_t *setResidues, uint32_t nSets, uint32_t world, uint32_t rank, uint32_t *mine,
+                        uint32_t *nMine);
+typedef struct sd_comm sd_comm;
+/* ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to every rank (torch.distributed broadcast, a file, MPI ...) */
+int sd_comm_unique_id(char *out128);
+int sd_comm_init(int device, int nRanks, int rank, const char *uniqueId128, sd_comm **out);
+void sd_comm_destroy(sd_comm *c);
+const char *sd_comm_last_error(sd_comm *c);
+/* gatherv of byte records over RCCL: sizes[nRanks] receives every rank's byte count (on all ranks); on `root`, outOnRoot
+ * (capacity outCap) receives the records concatenated in rank order and *outBytes their total.  SD_ENOMEM on the root when
+ * outCap is too small (*outBytes still holds the size needed; the exchange itself completes on every rank). */
+int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, uint64_t *sizes, void *outOnRoot, uint64_t outCap,
+                      uint64_t *outBytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,6 +171,12 @@ def load():
                                                  C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_search_result_destroy': (None, [_vp]),
         'sd_search_stats': (C.c_int, [_vp, _vp, _vp]),
+        'sd_shard_query_sets': (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.POINTER(C.c_uint32)]),
+        'sd_comm_unique_id': (C.c_int, [C.c_char_p]),
+        'sd_comm_init': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)]),
+        'sd_comm_destroy': (None, [_vp]),
+        'sd_comm_last_error': (C.c_char_p, [_vp]),
+        'sd_gather_results': (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     }
     missing = []
     for name, (res, args) in sig.items():

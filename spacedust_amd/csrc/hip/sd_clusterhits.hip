@@ -18,6 +18,7 @@
 // reference's own expressions (sd_clusterhits_batch below) so their text form matches digit for digit.
 #include <memory>
 #include "sd_common.h"
+#include "sd_host.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -247,67 +248,10 @@ clusterhits_kernel(const ChPair *__restrict__ pairs, uint32_t nPairs, const uint
     if (t == 0) mergesOut[p] = merges;
 }
 
-// ---- host side: P-values of the final nodes with the reference's own expressions --------------
-struct HHit {
-    double pval;
-    uint32_t qPos, tPos;
-    bool qS, tS;
-    uint32_t idx;
-};
-
-double hLogClusterPval(const double *lookup, int k, int m, double q0 = 0.001) {
-    return 2 * lookup[m + 1] - 2 * lookup[m - k + 1] - lookup[k + 1] + k * log(q0);
-}
-double hLogOrderingPval(const double *lookup, int k, int m) { return log(1 - 1.0 * m / k) - m * log(2) - lookup[m + 1]; }
-
-double hClusterMatchScore(const double *lookup, std::vector<HHit> &c) {
-    if (c.size() == 0) return 0.0;
-    unsigned int iMax = 0, iMin = INT_MAX, jMax = 0, jMin = INT_MAX;
-    for (size_t l = 0; l < c.size(); l++) {
-        iMax = (c[l].qPos > iMax) ? c[l].qPos : iMax;
-        iMin = (c[l].qPos < iMin) ? c[l].qPos : iMin;
-        jMax = (c[l].tPos > jMax) ? c[l].tPos : jMax;
-        jMin = (c[l].tPos < jMin) ? c[l].tPos : jMin;
-    }
-    int spanI = iMax - iMin + 1, spanJ = jMax - jMin + 1;
-    int span = (spanI > spanJ) ? spanI : spanJ;
-    int k = (int) c.size();
-    std::sort(c.begin(), c.end(), [](const HHit &a, const HHit &b) {
-        if (a.qPos != b.qPos) return a.qPos < b.qPos;
-        return a.idx < b.idx;
-    });
-    int m = 0;
-    for (size_t l = 0; l + 1 < c.size(); l++) {
-        bool isSameOrder = (c[l + 1].tPos > c[l].tPos);
-        bool s1 = (c[l].qS == c[l].tS), s2 = (c[l + 1].qS == c[l + 1].tS);
-        if ((s1 == isSameOrder) && (s2 == isSameOrder)) m++;
-    }
-    double logpClu = hLogClusterPval(lookup, k, span);
-    double logpOrd = hLogOrderingPval(lookup, k, m);
-    return -0.5 * logpClu - 0.5 * logpOrd;
-}
-
-double hMultihitPval(const double *lookup, const std::vector<HHit> &cluster, int Nq, double alpha) {
-    size_t k = 0;
-    double r = 0;
-    double pvalThreshold = alpha / (Nq + 1);
-    double logPvalThr = log(pvalThreshold);
-    for (size_t i = 0; i < cluster.size(); ++i) {
-        double logPvalue = log(cluster[i].pval);
-        if (logPvalue < logPvalThr) {
-            k++;
-            r -= logPvalue - logPvalThr;
-        }
-    }
-    if (r == 0) return 1.0;
-    if (std::isinf(r)) return 0.0;
-    double expMinusR = exp(-r);
-    if (expMinusR == 0) return 0.0;
-    double sum = 0;
-    for (size_t i = 0; i < k - 1; ++i) sum += pow(r, i) / exp(lookup[i + 1]);
-    return expMinusR * sum;
-}
-
+// ---- host side: the P-values of the final nodes are evaluated in csrc/host/sd_chpval.cpp, which g++ compiles with the
+// reference's floating-point flags (-mfma, GCC's -ffp-contract=fast): `-0.5 * a - 0.5 * b` and `... + k * log(q0)` contract
+// into different FMAs under clang, and the reference prints these doubles with four significant digits
+using sd::ClusterHit;
 }  // namespace
 
 extern "C" int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32_t nPairs, const uint64_t *hitOff,
@@ -395,7 +339,7 @@ extern "C" int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32
 #pragma omp parallel
     {
         std::vector<uint32_t> start, items;
-        std::vector<HHit> cluster;
+        std::vector<ClusterHit> cluster;
 #pragma omp for schedule(dynamic, 1)
         for (uint32_t p = 0; p < nPairs; p++) {
             const uint64_t off = hitOff[p];
@@ -430,13 +374,13 @@ extern "C" int sd_clusterhits_batch(sd_ctx *ctx, const sd_ch_params *par, uint32
                 cluster.clear();
                 for (uint32_t x = start[n]; x < start[n + 1]; x++) {
                     const uint32_t h = items[x];
-                    HHit hh;
+                    ClusterHit hh;
                     hh.pval = pval[off + h]; hh.qPos = qPos[off + h]; hh.tPos = tPos[off + h];
                     hh.qS = strands[off + h] & 1; hh.tS = (strands[off + h] >> 1) & 1; hh.idx = h;
                     cluster.push_back(hh);
                 }
-                const double co = exp(-hClusterMatchScore(lGamma, cluster));   // sorts `cluster` by qPos, as the reference does
-                const double mh = hMultihitPval(lGamma, cluster, (int) Nq[p], par->alpha);
+                const double co = sd::chClusterPval(lGamma, cluster);   // sorts `cluster` by qPos, as the reference does
+                const double mh = sd::chMultihitPval(lGamma, cluster, (int) Nq[p], par->alpha);
                 if (co <= par->pCluThr && mh <= par->pMHThr) {
                     pCO[off + nClu] = co;
                     pMH[off + nClu] = mh;

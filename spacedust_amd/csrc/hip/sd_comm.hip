@@ -1,0 +1,212 @@
+// Multi-GPU seam of the C ABI: one process per GPU, query genome sets dealt to the ranks, the target
+// index replicated, no collective on the data path; the only exchange is the final gather of the per-rank result
+// records to rank `root` over RCCL (xGMI).  The reference's counterpart is the MPI master merging per-rank result files
+// through the shared file system (M/src/prefiltering/Prefiltering.cpp:630-658).
+//
+// RCCL is opened with dlopen on the first sd_comm_* call (librccl.so.1; a process that already carries an RCCL -- e.g.
+// PyTorch's -- gets that one), so a single-GPU run never loads it.
+#include "sd_common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+// the few RCCL entry points used (signatures of rccl.h; ncclComm_t / ncclUniqueId are opaque here)
+typedef struct { char internal[128]; } RcclUniqueId;
+typedef void *RcclComm;
+typedef int (*FnGetUniqueId)(RcclUniqueId *);
+typedef int (*FnCommInitRank)(RcclComm *, int, RcclUniqueId, int);
+typedef int (*FnCommDestroy)(RcclComm);
+typedef int (*FnAllGather)(const void *, void *, size_t, int /*ncclDataType_t*/, RcclComm, hipStream_t);
+typedef int (*FnSend)(const void *, size_t, int, int, RcclComm, hipStream_t);
+typedef int (*FnRecv)(void *, size_t, int, int, RcclComm, hipStream_t);
+typedef int (*FnGroup)(void);
+typedef const char *(*FnErr)(int);
+enum { RCCL_CHAR = 0, RCCL_UINT64 = 5 };   // ncclInt8 = 0, ncclUint64 = 5
+
+struct Rccl {
+    void *lib = nullptr;
+    FnGetUniqueId getUniqueId = nullptr;
+    FnCommInitRank commInitRank = nullptr;
+    FnCommDestroy commDestroy = nullptr;
+    FnAllGather allGather = nullptr;
+    FnSend send = nullptr;
+    FnRecv recv = nullptr;
+    FnGroup groupStart = nullptr, groupEnd = nullptr;
+    FnErr errString = nullptr;
+    std::string err;
+};
+
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) {
+            r.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "");
+            return;
+        }
+        r.getUniqueId = (FnGetUniqueId) dlsym(r.lib, "ncclGetUniqueId");
+        r.commInitRank = (FnCommInitRank) dlsym(r.lib, "ncclCommInitRank");
+        r.commDestroy = (FnCommDestroy) dlsym(r.lib, "ncclCommDestroy");
+        r.allGather = (FnAllGather) dlsym(r.lib, "ncclAllGather");
+        r.send = (FnSend) dlsym(r.lib, "ncclSend");
+        r.recv = (FnRecv) dlsym(r.lib, "ncclRecv");
+        r.groupStart = (FnGroup) dlsym(r.lib, "ncclGroupStart");
+        r.groupEnd = (FnGroup) dlsym(r.lib, "ncclGroupEnd");
+        r.errString = (FnErr) dlsym(r.lib, "ncclGetErrorString");
+        if (!r.getUniqueId || !r.commInitRank || !r.commDestroy || !r.allGather || !r.send || !r.recv || !r.groupStart || !r.groupEnd)
+            r.err = "librccl lacks an expected entry point";
+    });
+    return &r;
+}
+
+}  // namespace
+
+struct sd_comm {
+    RcclComm comm = nullptr;
+    int nRanks = 1, rank = 0, device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+};
+
+extern "C" {
+
+int sd_comm_unique_id(char *out128) {
+    if (!out128) return SD_EINVAL;
+    Rccl *R = rccl();
+    if (!R->err.empty()) return SD_EUNSUPPORTED;
+    RcclUniqueId id;
+    if (R->getUniqueId(&id) != 0) return SD_EHIP;
+    memcpy(out128, id.internal, 128);
+    return SD_OK;
+}
+
+int sd_comm_init(int device, int nRanks, int rank, const char *uniqueId128, sd_comm **out) {
+    if (!out || !uniqueId128 || nRanks < 1 || rank < 0 || rank >= nRanks) return SD_EINVAL;
+    Rccl *R = rccl();
+    if (!R->err.empty()) {
+        fprintf(stderr, "sd_comm_init: %s\n", R->err.c_str());
+        return SD_EUNSUPPORTED;
+    }
+    if (hipSetDevice(device) != hipSuccess) return SD_ENODEVICE;
+    sd_comm *c = new sd_comm();
+    c->nRanks = nRanks;
+    c->rank = rank;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SD_EHIP;
+    }
+    RcclUniqueId id;
+    memcpy(id.internal, uniqueId128, 128);
+    const int rc = R->commInitRank(&c->comm, nRanks, id, rank);
+    if (rc != 0) {
+        fprintf(stderr, "sd_comm_init: ncclCommInitRank failed: %s\n", R->errString ? R->errString(rc) : "?");
+        hipStreamDestroy(c->stream);
+        delete c;
+        return SD_EHIP;
+    }
+    *out = c;
+    return SD_OK;
+}
+
+void sd_comm_destroy(sd_comm *c) {
+    if (!c) return;
+    if (c->comm) rccl()->commDestroy(c->comm);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *sd_comm_last_error(sd_comm *c) { return c ? c->err.c_str() : ""; }
+
+// gatherv of byte records to `root`: all_gather of the sizes, then grouped send / recv of the payloads
+int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, uint64_t *sizes, void *outOnRoot, uint64_t outCap,
+                      uint64_t *outBytes) {
+    if (!c || (nBytes && !local) || !sizes || root < 0 || root >= c->nRanks) return SD_EINVAL;
+    Rccl *R = rccl();
+    auto fail = [&](const char *what, int rc) {
+        c->err = std::string(what) + ": " + (R->errString ? R->errString(rc) : "RCCL error");
+        return SD_EHIP;
+    };
+    if (hipSetDevice(c->device) != hipSuccess) return SD_ENODEVICE;
+    uint64_t *dSizes = nullptr;
+    char *dLocal = nullptr, *dAll = nullptr;
+    int status = SD_OK;
+    do {
+        if (hipMalloc((void **) &dSizes, sizeof(uint64_t) * ((size_t) c->nRanks + 1)) != hipSuccess) { status = SD_ENOMEM; break; }
+        if (hipMemcpyAsync(dSizes + c->nRanks, &nBytes, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        int rc = R->allGather(dSizes + c->nRanks, dSizes, 1, RCCL_UINT64, c->comm, c->stream);
+        if (rc != 0) { status = fail("ncclAllGather", rc); break; }
+        if (hipMemcpyAsync(sizes, dSizes, sizeof(uint64_t) * c->nRanks, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        uint64_t total = 0;
+        for (int r = 0; r < c->nRanks; r++) total += sizes[r];
+        if (outBytes) *outBytes = total;
+        if (c->rank == root && total > outCap) { status = SD_ENOMEM; }
+        if (nBytes) {
+            if (hipMalloc((void **) &dLocal, nBytes) != hipSuccess) { status = SD_ENOMEM; break; }
+            if (hipMemcpyAsync(dLocal, local, nBytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        }
+        if (c->rank == root && total && hipMalloc((void **) &dAll, total) != hipSuccess) { status = SD_ENOMEM; break; }
+        // every rank takes part in the exchange even when the root's buffer is too small (no rank may be left waiting)
+        rc = R->groupStart();
+        if (rc != 0) { status = fail("ncclGroupStart", rc); break; }
+        if (c->rank == root) {
+            uint64_t off = 0;
+            for (int r = 0; r < c->nRanks; r++) {
+                if (sizes[r] && r != root) R->recv(dAll + off, sizes[r], RCCL_CHAR, r, c->comm, c->stream);
+                off += sizes[r];
+            }
+        } else if (nBytes) {
+            R->send(dLocal, nBytes, RCCL_CHAR, root, c->comm, c->stream);
+        }
+        rc = R->groupEnd();
+        if (rc != 0) { status = fail("ncclGroupEnd", rc); break; }
+        if (c->rank == root && dAll) {
+            uint64_t off = 0;
+            for (int r = 0; r < root; r++) off += sizes[r];
+            if (nBytes) hipMemcpyAsync(dAll + off, dLocal, nBytes, hipMemcpyDeviceToDevice, c->stream);
+            if (status == SD_OK && outOnRoot) hipMemcpyAsync(outOnRoot, dAll, total, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess && status == SD_OK) status = SD_EHIP;
+    } while (false);
+    if (dSizes) hipFree(dSizes);
+    if (dLocal) hipFree(dLocal);
+    if (dAll) hipFree(dAll);
+    return status;
+}
+
+// Whole query genome sets -> ranks, greedy by residue count (largest first; ties: lower set index, lower rank), so that a
+// set's hits stay on one rank through besthitbyset -> combinehits -> clusterhits, which group by query set.
+// Deterministic: every rank computes the same assignment and keeps its own part (ascending set index).
+int sd_shard_query_sets(const uint64_t *setResidues, uint32_t nSets, uint32_t world, uint32_t rank, uint32_t *mine, uint32_t *nMine) {
+    if ((nSets && !setResidues) || !mine || !nMine || world == 0 || rank >= world) return SD_EINVAL;
+    std::vector<uint32_t> order(nSets);
+    for (uint32_t i = 0; i < nSets; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return setResidues[a] > setResidues[b]; });
+    std::vector<uint64_t> load(world, 0);
+    uint32_t n = 0;
+    for (uint32_t x = 0; x < nSets; x++) {
+        uint32_t best = 0;
+        for (uint32_t r = 1; r < world; r++)
+            if (load[r] < load[best]) best = r;
+        load[best] += setResidues[order[x]];
+        if (best == rank) mine[n++] = order[x];
+    }
+    std::sort(mine, mine + n);
+    *nMine = n;
+    return SD_OK;
+}
+
+}  // extern "C"

@@ -165,6 +165,19 @@ char *seqIdToBuffer(float seqId, char *buf);
 std::string compressBacktrace(const char *bt, size_t n);
 void compressBacktraceAppend(const char *bt, size_t n, std::string &out);
 
+// ---------------------------------------------------------------------------
+// clusterhits: P-values of an emitted cluster (R/src/util/ClusterHits.cpp:120-134,184-213,462-464), sd_chpval.cpp
+// ---------------------------------------------------------------------------
+struct ClusterHit {
+    double pval;
+    uint32_t qPos, tPos;
+    bool qS, tS;
+    uint32_t idx;
+};
+// exp(-clusterMatchScore): sorts `cluster` by query position like the reference's findConservedPairs does
+double chClusterPval(const double *lgammaTable, std::vector<ClusterHit> &cluster);
+double chMultihitPval(const double *lgammaTable, const std::vector<ClusterHit> &cluster, int Nq, double alpha);
+
 }  // namespace sd
 
 // the host-side handle behind sd_host_* (include/spacedust_gpu.h); the device code reads the matrices from it

@@ -207,8 +207,7 @@ void sd_search_default_params(sd_search_params *p) {
 }
 
 int sd_search_create(int device, const sd_search_params *par, const sd_setdb *target, sd_search **out) {
-    if (!par || !target || !out || !target->residues || !target->offsets || !target->setId || !target->posInSet || !target->strand)
-        return SD_EINVAL;
+    if (!par || !target || !out || !target->residues || !target->offsets) return SD_EINVAL;
     std::unique_ptr<sd_search> s(new sd_search());
     s->par = *par;
     s->T = *target;
@@ -292,8 +291,9 @@ int sd_search_create(int device, const sd_search_params *par, const sd_setdb *ta
     s->tLen.resize(target->n);
     for (uint32_t i = 0; i < target->n; i++) s->tLen[i] = (int32_t) (target->offsets[i + 1] - target->offsets[i]);
     s->tSetSize.assign(target->nSets, 0);
-    for (uint32_t i = 0; i < target->n; i++)
-        if (target->setId[i] < target->nSets) s->tSetSize[target->setId[i]]++;
+    if (target->setId)
+        for (uint32_t i = 0; i < target->n; i++)
+            if (target->setId[i] < target->nSets) s->tSetSize[target->setId[i]]++;
     *out = s.release();
     return SD_OK;
 }
@@ -333,11 +333,15 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     const sd_setdb &T = s->T;
     std::vector<int32_t> qLen(Q->n);
     for (uint32_t i = 0; i < Q->n; i++) qLen[i] = (int32_t) (Q->offsets[i + 1] - Q->offsets[i]);
+    // without set membership on both sides (a plain `search`) the stream stops after the alignments: the sinks get the
+    // prefilter rows and alignment records, nothing is aggregated or clustered
+    const bool aggregate = Q->setId && Q->posInSet && Q->strand && T.setId && T.posInSet && T.strand;
     std::vector<uint32_t> qSetSize(Q->nSets, 0);
-    for (uint32_t i = 0; i < Q->n; i++)
-        if (Q->setId[i] < Q->nSets) qSetSize[Q->setId[i]]++;
+    if (aggregate)
+        for (uint32_t i = 0; i < Q->n; i++)
+            if (Q->setId[i] < Q->nSets) qSetSize[Q->setId[i]]++;
     // lgamma table for clusterhits: set sizes and gene positions bound the indices (ClusterHits.cpp:259-271)
-    {
+    if (aggregate) {
         uint32_t m = 0;
         for (uint32_t v : qSetSize) m = std::max(m, v);
         for (uint32_t v : s->tSetSize) m = std::max(m, v);
@@ -351,6 +355,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     std::vector<std::unique_ptr<sd_search_result> > res(nRanges);
     for (uint32_t r = 0; r < nRanges; r++) {
         res[r].reset(new sd_search_result());
+        if (!aggregate) continue;
         int rc = sd_agg_create(Q->setId, qLen.data(), Q->n, T.setId, s->tLen.data(), T.n, Q->nSets, T.nSets, s->par.evalThr, s->par.covMode,
                                s->par.covThr, s->par.alnLenThr, s->par.filterSelfMatch, &res[r]->agg);
         if (rc != SD_OK) return s->fail(rc, "sd_agg_create");
@@ -476,6 +481,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
 
     auto finalize = [&](uint32_t r) -> int {
         sd_search_result &R = *res[r];
+        if (!aggregate) return SD_OK;
         double t0 = nowSec();
         uint64_t ne = 0, nh = 0;
         int rc = sd_agg_finish(R.agg, &ne, &nh);
@@ -633,7 +639,8 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
                 const double t1 = nowSec();
                 if (sp->alnSink)
                     sp->alnSink(sp->sinkUser, c0, nq, nOut, bp->pq.data(), bp->pt.data(), bp->res.data(), bp->ident.data(), bp->pool.data());
-                const int rc2 = sd_agg_add(agg, nOut, c0, bp->pq.data(), bp->pt.data(), bp->res.data(), bp->ident.data(), bp->pool.data());
+                const int rc2 = agg ? sd_agg_add(agg, nOut, c0, bp->pq.data(), bp->pt.data(), bp->res.data(), bp->ident.data(), bp->pool.data())
+                                    : SD_OK;
                 return std::make_pair(rc2, nowSec() - t1);
             });
             havePending = true;
@@ -706,7 +713,7 @@ int sd_search_result_write_tsv(sd_search_result *r, const char *path, const char
                                const char *tNames, const uint64_t *tNameOff, const char *qSources, const uint64_t *qSourceOff,
                                const char *tSources, const uint64_t *tSourceOff, int canonical, int append,
                                uint64_t firstClusterKey, uint64_t *nClusterLines, uint64_t *nHitLines) {
-    if (!r || !path) return SD_EINVAL;
+    if (!r || !path || !r->agg) return SD_EINVAL;
     static const uint32_t zero32 = 0;
     static const double zeroD = 0.0;
     const bool empty = r->hitQ.empty();

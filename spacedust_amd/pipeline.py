@@ -255,16 +255,61 @@ class _Stats(dict):
 def shard_query_sets(set_residues, world, rank):
     """Whole query genome sets -> ranks, greedy by residue count (largest first), so a set's hits stay on one rank
     through besthitbyset -> combinehits -> clusterhits (they group by query set).  Deterministic:
-    every rank computes the same assignment and keeps its own part (sorted)."""
-    order = sorted(range(len(set_residues)), key=lambda s: (-int(set_residues[s]), s))
-    load = [0] * world
-    mine = []
-    for s in order:
-        r = min(range(world), key=lambda x: (load[x], x))
-        load[r] += int(set_residues[s])
-        if r == rank:
-            mine.append(s)
-    return sorted(mine)
+    every rank computes the same assignment and keeps its own part (sorted).  sd_shard_query_sets of the C ABI."""
+    L = _lib.load()
+    res = np.ascontiguousarray(set_residues, np.uint64)
+    mine = np.zeros(max(len(res), 1), np.uint32)
+    n = C.c_uint32()
+    api._check(None, L.sd_shard_query_sets(ptr(res), len(res), world, rank, ptr(mine), C.byref(n)), 'sd_shard_query_sets')
+    return [int(x) for x in mine[:n.value]]
+
+
+class RcclGather:
+    """The C ABI's multi-GPU seam (sd_comm_*): one RCCL communicator per rank, used for the one exchange of the path, the
+    final gather of the per-rank result records to rank 0.  unique_id: the 128 bytes of sd_comm_unique_id from rank 0
+    (callers broadcast them, e.g. over torch.distributed or a file)."""
+
+    @staticmethod
+    def unique_id():
+        L = _lib.load()
+        b = C.create_string_buffer(128)
+        api._check(None, L.sd_comm_unique_id(b), 'sd_comm_unique_id')
+        return b.raw
+
+    def __init__(self, device, world, rank, unique_id):
+        self.L = _lib.load()
+        self.world, self.rank = world, rank
+        h = C.c_void_p()
+        api._check(None, self.L.sd_comm_init(device, world, rank, unique_id, C.byref(h)), 'sd_comm_init')
+        self.h = h
+
+    def gather(self, local_records, root=0):
+        """variable-length int64 record arrays -> list of per-rank arrays on `root` (None elsewhere)"""
+        rec = np.ascontiguousarray(local_records, np.int64).reshape(-1)
+        sizes = np.zeros(self.world, np.uint64)
+        total = C.c_uint64()
+        out = np.zeros(0, np.uint8)
+        rc = self.L.sd_gather_results(self.h, ptr(rec) if rec.size else None, rec.nbytes, root, ptr(sizes), None, 0, C.byref(total))
+        if self.rank == root and rc == _lib.SD_ENOMEM:
+            pass   # size probe: the first call tells the root how much room the records need
+        elif rc != 0:
+            raise _lib.SdError('sd_gather_results failed (%d): %s' % (rc, self.L.sd_comm_last_error(self.h).decode(errors='replace')))
+        if total.value:
+            out = np.zeros(int(total.value), np.uint8)
+            rc = self.L.sd_gather_results(self.h, ptr(rec) if rec.size else None, rec.nbytes, root, ptr(sizes), ptr(out), out.nbytes,
+                                          C.byref(total))
+            if rc != 0:
+                raise _lib.SdError('sd_gather_results failed (%d): %s' % (rc, self.L.sd_comm_last_error(self.h).decode(errors='replace')))
+        if self.rank != root:
+            return None
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        return [out[offs[r]:offs[r + 1]].view(np.int64) for r in range(self.world)]
+
+    def __del__(self):
+        try:
+            self.L.sd_comm_destroy(self.h)
+        except Exception:
+            pass
 
 
 def gather_results(local_records, dist, device=None):

@@ -86,3 +86,28 @@ def test_no_device_no_result(work):
     p = subprocess.run([SDGPU, 'prefilter', g, g, str(work / 'pref_none')] + PREFILTER_PAR, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True)
     assert p.returncode != 0 and 'no usable HIP device' in p.stderr
+
+
+def test_fused_clustersearch_and_search_modules(work):
+    """`sdgpu clustersearch` (the whole workflow in one process around the C++ pipeline object) writes the reference's TSV,
+    and with --keep-dbs 1 the prefilter / alignment DBs its sinks write hash like the reference binary's; `sdgpu search`
+    (prefilter + align, blastp.sh) writes the same alignment DB"""
+    g = work / 'genome'
+    sdgpu('clustersearch', g, g, work / 'fused.tsv', work / 'tmpf', '--filter-self-match', '--keep-dbs', '1', '--threads', '8')
+    tsv = open(work / 'fused.tsv').readlines()
+    clu = [l for l in tsv if l.startswith('#')]
+    assert (sum(1 for l in tsv if l.startswith('>')), len(clu), sum(1 for l in clu if float(l.split('\t')[3]) < 1e-20)) == (308, 108, 2)
+    assert sorted_md5(tsv, drop_first_column=True) == 'abb28ee37bc130a5f09a9f767ef00ccf'
+    assert [int(l.split('\t')[0][1:]) for l in clu] == list(range(108))
+    for db, n, md5 in (('tmpf/pref_0', 98957, '8109a70bdea70ee10e0dbd27ba6b7e37'), ('tmpf/result', 15065, '2e917f0e9782e8a7412c7360aa7bf1b4')):
+        sdgpu('prefixid', work / db, work / 'x.flat', '--tsv')
+        lines = open(work / 'x.flat').readlines()
+        assert (len(lines), sorted_md5(lines)) == (n, md5), db
+    sdgpu('search', g, g, work / 'res_search', work / 'tmps', '-a', '1', '--alignment-mode', '2', '-e', '10', '--min-aln-len', '30',
+          '-c', '0.8', '--cov-mode', '2', '-s', '5.7', '--max-seqs', '300', '--threads', '8')
+    sdgpu('prefixid', work / 'res_search', work / 'y.flat', '--tsv')
+    lines = open(work / 'y.flat').readlines()
+    assert (len(lines), sorted_md5(lines)) == (15065, '2e917f0e9782e8a7412c7360aa7bf1b4')
+    # without --filter-self-match (the reference's default) the self pairs of the two genomes stay in
+    sdgpu('clustersearch', g, g, work / 'noself.tsv', work / 'tmpn')
+    assert sum(1 for l in open(work / 'noself.tsv') if l.startswith('#')) > 108

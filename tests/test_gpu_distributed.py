@@ -82,3 +82,46 @@ def test_two_ranks_on_one_gpu_equal_one_rank(gpu):
     whole = np.array(sorted(whole.tolist()), np.int64)
     assert len(whole) > 10 and whole[:, 3].sum() > 0
     assert sharded.shape == whole.shape and (sharded == whole).all()
+
+
+def test_rccl_gather_seam_single_rank(gpu):
+    """sd_comm_init / sd_gather_results of the C ABI over RCCL with the one rank a one-GPU box allows: communicator from a
+    fresh unique id, a variable-length record array goes through the size all_gather and comes back on the root
+    (N > 1 runs the same code with grouped ncclSend / ncclRecv; the driver's multi-GPU bench exercises it)"""
+    from spacedust_amd.pipeline import RcclGather
+    uid = RcclGather.unique_id()
+    assert len(uid) == 128 and any(uid)
+    g = RcclGather(0, 1, 0, uid)
+    recs = np.arange(21, dtype=np.int64).reshape(3, 7) * 1234567
+    out = g.gather(recs)
+    assert len(out) == 1 and (out[0].reshape(-1, 7) == recs).all()
+    out = g.gather(np.zeros((0, 7), np.int64))
+    assert len(out) == 1 and out[0].size == 0
+
+
+def test_sdgpu_clustersearch_two_ranks_equal_one(gpu, tmp_path):
+    """the binary's own multi-rank mode (RANK / WORLD_SIZE, whole query sets per rank, parts merged by rank 0): two ranks
+    sharing cuda:0 must write the same clusters as one rank"""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from dbutil import SDGPU, sdgpu, example_fasta, sorted_md5
+    fa = example_fasta(tmp_path)
+    q, t = tmp_path / 'q', tmp_path / 't'
+    # query DB with two sets (so that two ranks have something each), target DB with both genomes
+    sdgpu('createsetdb', fa[0], fa[1], t, tmp_path / 'tmp', '-v', '0')
+    sdgpu('createsetdb', fa[1], fa[0], q, tmp_path / 'tmp', '-v', '0')
+    sdgpu('clustersearch', q, t, tmp_path / 'one.tsv', tmp_path / 'tmp1', '-v', '0')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0')
+        procs.append(subprocess.Popen([SDGPU, 'clustersearch', str(q), str(t), str(tmp_path / 'two.tsv'), str(tmp_path / 'tmp2'), '-v', '0'],
+                                      env=env))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    one = open(tmp_path / 'one.tsv').readlines()
+    two = open(tmp_path / 'two.tsv').readlines()
+    assert len(one) > 100 and sum(1 for l in one if l.startswith('#')) > 20
+    assert sorted_md5(one, drop_first_column=True) == sorted_md5(two, drop_first_column=True)
+    # cluster keys are consecutive in the merged file
+    keys = [int(l.split('\t')[0][1:]) for l in two if l.startswith('#')]
+    assert keys == list(range(len(keys)))
