@@ -440,6 +440,38 @@ const char *sd_comm_last_error(sd_comm *c);
 int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, uint64_t *sizes, void *outOnRoot, uint64_t outCap,
                       uint64_t *outBytes);
 
+
+/* ---- result2profile: alignment DB -> profile DB between the iterations of `search --num-iterations` (SURVEY.md 8(f).3;
+ * host, float).  M/src/util/result2profile.cpp:239-282: MSA from the backtraces (MultipleAlignment::computeMSA, no query
+ * gaps), MsaFilter::filter, PSSMCalculator::computePSSMFromMSA, calcGlobalAaBiasCorrection, Masker::maskPssm,
+ * Profile::toBuffer.  The records are what sd_host_map_profiles reads (25 bytes per position). */
+typedef struct {
+    int32_t filterMsa;        /* --filter-msa (1) */
+    int32_t filterMinEnable;  /* --filter-min-enable (0) */
+    float filterMaxSeqId;     /* --max-seq-id (0.9) */
+    const char *qid;          /* --qid ("0.0"; comma separated list) */
+    float qsc;                /* --qsc (-20) */
+    float covMSAThr;          /* --cov (0) */
+    int32_t Ndiff;            /* --diff (1000) */
+    int32_t pcMode;           /* --pseudo-cnt-mode: 0 substitution score (the context specific library is not built in) */
+    float pca, pcb;           /* --pca / --pcb substitution values (1.1 / 4.1) */
+    int32_t wg;               /* --wg (0): global instead of position specific sequence weights */
+    int32_t compBiasCorr;     /* --comp-bias-corr (1) */
+    int32_t maskProfile;      /* --mask-profile (1) */
+    double maskProb;          /* --mask-prob (0.9) */
+} sd_r2p_params;
+typedef struct sd_r2p sd_r2p;
+int sd_r2p_create(sd_r2p **out);
+void sd_r2p_destroy(sd_r2p *r);
+/* nQ centre sequences (numeric residues; profile centres: their query letters) with, per centre, the alignments that
+ * enter the profile (the caller has applied the E-value cut and dropped the self hit, result2profile.cpp:184-203):
+ * edges [edgeOff[q], edgeOff[q+1]) -> target id, qStart, tStart and the expanded backtrace btPool[btOff[e] .. btOff[e+1]).
+ * outProfiles: 25 bytes per centre position at qOff[q] * 25; outConsensus (nullable): the consensus residues. */
+int sd_r2p_batch(sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t *qLetters, const uint64_t *qOff,
+                 const uint64_t *edgeOff, const uint32_t *edgeT, const int32_t *edgeQStart, const int32_t *edgeTStart,
+                 const char *btPool, const uint64_t *btOff, const uint8_t *tResidues, const uint64_t *tOff, char *outProfiles,
+                 uint8_t *outConsensus);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,12 @@ class SearchParams(C.Structure):   # sd_search_params
                 ('deviceBias', C.c_int32), ('threads', C.c_int32), ('alignPriority', C.c_int32)]
 
 
+class R2pParams(C.Structure):   # sd_r2p_params
+    _fields_ = [('filterMsa', C.c_int32), ('filterMinEnable', C.c_int32), ('filterMaxSeqId', C.c_float), ('qid', C.c_char_p),
+                ('qsc', C.c_float), ('covMSAThr', C.c_float), ('Ndiff', C.c_int32), ('pcMode', C.c_int32), ('pca', C.c_float),
+                ('pcb', C.c_float), ('wg', C.c_int32), ('compBiasCorr', C.c_int32), ('maskProfile', C.c_int32), ('maskProb', C.c_double)]
+
+
 class AlnCriteria(C.Structure):   # sd_aln_criteria
     _fields_ = [('evalThr', C.c_double), ('seqIdThr', C.c_float), ('alnLenThr', C.c_int32), ('covMode', C.c_int32),
                 ('covThr', C.c_float), ('seqIdMode', C.c_int32), ('swMode', C.c_int32), ('addBacktrace', C.c_int32),
@@ -171,6 +177,9 @@ def load():
                                                  C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_search_result_destroy': (None, [_vp]),
         'sd_search_stats': (C.c_int, [_vp, _vp, _vp]),
+        'sd_r2p_create': (C.c_int, [C.POINTER(_vp)]),
+        'sd_r2p_destroy': (None, [_vp]),
+        'sd_r2p_batch': (C.c_int, [_vp, C.POINTER(R2pParams), C.c_uint32] + [_vp] * 12),
         'sd_shard_query_sets': (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.POINTER(C.c_uint32)]),
         'sd_comm_unique_id': (C.c_int, [C.c_char_p]),
         'sd_comm_init': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)]),

@@ -111,3 +111,19 @@ def test_fused_clustersearch_and_search_modules(work):
     # without --filter-self-match (the reference's default) the self pairs of the two genomes stay in
     sdgpu('clustersearch', g, g, work / 'noself.tsv', work / 'tmpn')
     assert sum(1 for l in open(work / 'noself.tsv') if l.startswith('#')) > 108
+
+
+def test_align_realign_reproduces_reference_db(work):
+    """`align --realign 1 -e 0.001` (iteration 0 of `search --num-iterations`, M/src/workflow/Search.cpp:484-486): score-only
+    first pass without coverage, second pass with the score-biased matrix, scores / E-values of the first pass kept
+    (Alignment.cpp:45-57,408-440).  md5 of the reference binary's own aln_0 on the regression input (12 919 lines)."""
+    pref = flat_lines_from_gz('config1_pref.tsv.gz')
+    if not os.path.exists(work / 'pref_ref.index'):
+        write_db(str(work / 'pref_ref'), entries_by_first_column(pref, 5898), 7, splits=8)
+    g = work / 'genome'
+    par = [x for x in ALIGN_PAR]
+    par[par.index('-e') + 1] = '0.001'
+    par[par.index('--realign') + 1] = '1'
+    sdgpu('align', g, g, work / 'pref_ref', work / 'aln_0', *par)
+    lines = flat(work, 'aln_0')
+    assert (len(lines), sorted_md5(lines)) == (12919, '5d4e3228b0afb4378a0364a0291627f4')
