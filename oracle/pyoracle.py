@@ -519,3 +519,49 @@ class RefClusterHits:
         self.lib.ref_clusterhits_entry(K, _ptr(q_pos), _ptr(t_pos), _ptr(strands), _ptr(pval), nq, d, cls, alpha, p_clu, p_mh,
                                        _ptr(lg), _ptr(cof), _ptr(rk), _ptr(pco), _ptr(pmh), _ptr(cs), C.byref(n))
         return cof[:K], rk[:K], cs[:n.value], pco[:n.value], pmh[:n.value]
+
+
+def matrix_spec(which=0):
+    """what the reference's SubstitutionMatrix constructor takes: the .out path under /root/reference, or -- on a box without
+    the tree -- the matrix contents in its own "NAME.out:DATA" form (BaseMatrix.cpp:189-214)"""
+    name = 'blosum62.out' if which == 0 else 'VTML80.out'
+    if os.path.exists(REF_DATA + name):
+        return REF_DATA + name
+    H = C.CDLL(os.path.join(os.path.dirname(HERE), 'spacedust_amd', 'libsdgpu.so'))
+    buf = C.create_string_buffer(1 << 16)
+    H.sd_host_matrix_text.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    H.sd_host_matrix_text(which, buf, 1 << 16)
+    return name + ':' + buf.value.decode()
+
+
+def ref_r2p_available():
+    return os.path.exists(os.path.join(HERE, '_ref', 'libsdref_r2p.so'))
+
+
+class RefResult2Profile:
+    """The reference's own MultipleAlignment / MsaFilter / PSSMCalculator / Masker classes driven for one centre sequence
+    (oracle/ref_result2profile.cpp): alignment records in, 25-byte profile records out."""
+
+    def __init__(self, blosum_spec=None):
+        self.lib = C.CDLL(os.path.join(HERE, '_ref', 'libsdref_r2p.so'), mode=os.RTLD_LAZY)
+        self.lib.ref_result2profile.restype = C.c_int
+        self.blosum = (blosum_spec or matrix_spec(0)).encode()
+
+    def profile(self, centre, edges, q_start, t_start, backtraces, centre_profile=None, pca=1.1, pcb=4.1, wg=0, filter_msa=1,
+                cov=0.0, qid='0.0', qsc=-20.0, max_seq_id=0.9, ndiff=1000, filter_min_enable=0, comp_bias=1, mask_profile=1,
+                mask_prob=0.9):
+        """centre: ASCII sequence (or None with centre_profile = L*25 bytes); edges: list of ASCII target sequences"""
+        n = len(edges)
+        L = len(centre) if centre_profile is None else len(centre_profile) // 25
+        eseq = (C.c_char_p * max(n, 1))(*[e.encode() for e in edges])
+        elen = (C.c_uint * max(n, 1))(*[len(e) for e in edges])
+        qs = (C.c_int * max(n, 1))(*[int(x) for x in q_start])
+        ts = (C.c_int * max(n, 1))(*[int(x) for x in t_start])
+        bts = (C.c_char_p * max(n, 1))(*[b.encode() for b in backtraces])
+        out = C.create_string_buffer(L * 25 + 64)
+        fl = C.c_float
+        got = self.lib.ref_result2profile(self.blosum, centre.encode() if centre_profile is None else None,
+                                          centre_profile if centre_profile is not None else None, C.c_uint(L), C.c_uint(n), eseq, elen,
+                                          qs, ts, bts, fl(pca), fl(pcb), wg, filter_msa, fl(cov), qid.encode(), fl(qsc), fl(max_seq_id),
+                                          ndiff, filter_min_enable, comp_bias, mask_profile, fl(mask_prob), out)
+        return out.raw[:got]

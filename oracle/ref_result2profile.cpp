@@ -76,3 +76,13 @@ int ref_result2profile(const char *blosumOut, const char *centreSeq, const char 
 }
 
 }  // extern "C"
+
+// the reference's pseudo count matrix P(a|b) and background (for pinning the product's tables)
+extern "C" void ref_r2p_tables(const char *blosumOut, float *R441, double *pBack21) {
+    Debug::setDebugLevel(1);
+    SubstitutionMatrix subMat(blosumOut, 2.0f, -0.2f);
+    for (int i = 0; i < 21; i++) {
+        pBack21[i] = subMat.pBack[i];
+        for (int j = 0; j < 21; j++) R441[i * 21 + j] = subMat.subMatrixPseudoCounts[i][j];
+    }
+}

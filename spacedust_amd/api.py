@@ -106,6 +106,47 @@ class Host:
         return self.L.sd_host_bitscore(float(score))
 
 
+def uncompress_cigar(c):
+    """Matcher::uncompressAlignment (Matcher.cpp:187-201)"""
+    out, n = [], 0
+    for ch in c:
+        if '0' <= ch <= '9':
+            n = n * 10 + ord(ch) - 48
+        else:
+            out.append(ch * (n if n else 1))
+            n = 0
+    return ''.join(out)
+
+
+def result2profile(q_letters, q_off, edge_off, edge_t, edge_qstart, edge_tstart, backtraces, t_residues, t_off, **kw):
+    """sd_r2p_batch: profiles (25 bytes per position, bytes object) of nQ centre sequences from their alignments"""
+    L = _lib.load()
+    h = C.c_void_p()
+    _check(None, L.sd_r2p_create(C.byref(h)), 'sd_r2p_create')
+    p = _lib.R2pParams()
+    p.filterMsa, p.filterMinEnable, p.filterMaxSeqId = kw.get('filter_msa', 1), kw.get('filter_min_enable', 0), kw.get('max_seq_id', 0.9)
+    p.qid, p.qsc, p.covMSAThr, p.Ndiff = kw.get('qid', '0.0').encode(), kw.get('qsc', -20.0), kw.get('cov', 0.0), kw.get('ndiff', 1000)
+    p.pcMode, p.pca, p.pcb, p.wg = 0, kw.get('pca', 1.1), kw.get('pcb', 4.1), kw.get('wg', 0)
+    p.compBiasCorr, p.maskProfile, p.maskProb = kw.get('comp_bias', 1), kw.get('mask_profile', 1), kw.get('mask_prob', 0.9)
+    q_letters = np.ascontiguousarray(q_letters, np.uint8)
+    q_off = np.ascontiguousarray(q_off, np.uint64)
+    edge_off = np.ascontiguousarray(edge_off, np.uint64)
+    edge_t = np.ascontiguousarray(edge_t, np.uint32)
+    qs = np.ascontiguousarray(edge_qstart, np.int32)
+    ts = np.ascontiguousarray(edge_tstart, np.int32)
+    bt_off = np.zeros(len(backtraces) + 1, np.uint64)
+    np.cumsum([len(b) for b in backtraces], out=bt_off[1:])
+    pool = np.frombuffer((''.join(backtraces) + ' ').encode(), np.uint8).copy()
+    t_residues = np.ascontiguousarray(t_residues, np.uint8)
+    t_off = np.ascontiguousarray(t_off, np.uint64)
+    out = np.zeros(int(q_off[-1]) * 25 + 1, np.uint8)
+    rc = L.sd_r2p_batch(h, C.byref(p), len(q_off) - 1, ptr(q_letters), ptr(q_off), ptr(edge_off), ptr(edge_t), ptr(qs), ptr(ts), ptr(pool),
+                        ptr(bt_off), ptr(t_residues), ptr(t_off), ptr(out), None)
+    L.sd_r2p_destroy(h)
+    _check(None, rc, 'sd_r2p_batch')
+    return out[:-1].tobytes()
+
+
 class HostIndex:
     def __init__(self, host, residues, offsets, k, kmer_thr, mask, mask_prob):
         self.host = host

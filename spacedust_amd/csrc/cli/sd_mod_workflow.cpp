@@ -17,8 +17,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <thread>
 
 namespace sdcli {
@@ -399,11 +401,359 @@ int runSearch(const Args &a, bool withClusters) {
 
 }  // namespace
 
-int searchModule(const Args &a) { return runSearch(a, false); }
-int clustersearchModule(const Args &a) { return runSearch(a, true); }
+// ---------------------------------------------------------------------------------------------------------------
+// result2profile <queryDB> <targetDB> <alignmentDB> <profileDB>   (M/src/util/result2profile.cpp:16-322): the host step
+// between search iterations.  The arithmetic is sd_r2p_batch of the C ABI; this is the DB side.
+int result2profileModule(const Args &a) {
+    if (a.pos.size() != 4) return fail("usage: result2profile <queryDB> <targetDB> <alignmentDB> <profileDB> [options]");
+    if (a.integer("--compressed", 0) != 0) return fail("--compressed 1 is not supported");
+    if (a.integer("--profile-output-mode", 0) != 0) return fail("--profile-output-mode 0 only");
+    if (a.integer("--pseudo-cnt-mode", 0) != 0) return fail("--pseudo-cnt-mode 1 needs the context library (not built in)");
+    if (a.flag("--allow-deletion", false)) return fail("--allow-deletion 1 is not supported");
+    if (a.multi("--sub-mat", "aa", "blosum62.out") != "blosum62.out") return fail("--sub-mat: only blosum62.out is built into this path");
+    const std::string qidStr = a.str("--qid", "0.0");
+    sd_r2p_params p;
+    memset(&p, 0, sizeof(p));
+    p.filterMsa = (int32_t) a.integer("--filter-msa", 1);
+    p.filterMinEnable = (int32_t) a.integer("--filter-min-enable", 0);
+    p.filterMaxSeqId = (float) a.real("--max-seq-id", 0.9);
+    p.qid = qidStr.c_str();
+    p.qsc = (float) a.real("--qsc", -20.0);
+    p.covMSAThr = (float) a.real("--cov", 0.0);
+    p.Ndiff = (int32_t) a.integer("--diff", 1000);
+    p.pcMode = 0;
+    p.pca = (float) strtod(a.multi("--pca", "substitution", "1.1").c_str(), nullptr);
+    p.pcb = (float) strtod(a.multi("--pcb", "substitution", "4.1").c_str(), nullptr);
+    p.wg = a.flag("--wg", false) ? 1 : 0;
+    p.compBiasCorr = (int32_t) a.integer("--comp-bias-corr", 1);
+    p.maskProfile = (int32_t) a.integer("--mask-profile", 1);
+    p.maskProb = a.real("--mask-prob", 0.9);
+    double evalThr = a.real("-e", 0.001), evalProfile = a.real("--e-profile", 0.001);
+    evalProfile = (evalThr < evalProfile) ? evalThr : evalProfile;   // result2profile.cpp:33
+    const int threads = threadsOf(a);
+    HostH host;
+    if (sd_host_create(threads, &host.h) != SD_OK) return fail("sd_host_create failed");
+    std::string err;
+    const bool sameDb = a.pos[0] == a.pos[1];
+    std::unique_ptr<SeqDb> tdb(new SeqDb()), qdbOwn;
+    if (!tdb->load(a.pos[1], host.h, &err)) return fail(err);
+    if (tdb->profile) return fail("Only the query OR the target database can be a profile database");
+    SeqDb *qdb = tdb.get();
+    if (!sameDb) {
+        qdbOwn.reset(new SeqDb());
+        if (!qdbOwn->load(a.pos[0], host.h, &err)) return fail(err);
+        qdb = qdbOwn.get();
+    }
+    sddb::Reader aln;
+    if (!aln.open(a.pos[2], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
+    sd_r2p *r2p = nullptr;
+    if (sd_r2p_create(&r2p) != SD_OK) return fail("sd_r2p_create failed");
+    std::unique_ptr<sd_r2p, void (*)(sd_r2p *)> guard(r2p, sd_r2p_destroy);
+    sddb::Writer out;
+    if (!out.open(a.pos[3], sddb::DBTYPE_HMM_PROFILE, &err)) return fail(err);
+    const size_t n = aln.size();
+    const size_t chunk = 4096;
+    std::vector<uint8_t> qLetters;
+    std::vector<uint64_t> qOff, edgeOff, btOff;
+    std::vector<uint32_t> edgeT, keys;
+    std::vector<int32_t> eQ, eT;
+    std::string pool;
+    std::vector<char> profiles;
+    for (size_t c0 = 0; c0 < n; c0 += chunk) {
+        const size_t c1 = std::min(n, c0 + chunk);
+        qLetters.clear();
+        qOff.assign(1, 0);
+        edgeOff.assign(1, 0);
+        btOff.assign(1, 0);
+        edgeT.clear();
+        eQ.clear();
+        eT.clear();
+        keys.clear();
+        pool.clear();
+        for (size_t id = c0; id < c1; id++) {
+            const uint32_t qKey = aln.key(id);
+            const size_t qId = qdb->rd.idOfKey(qKey);
+            if (qId == SIZE_MAX) continue;   // "Invalid query sequence": skipped (result2profile.cpp:173-176)
+            keys.push_back(qKey);
+            qLetters.insert(qLetters.end(), qdb->residues.begin() + qdb->offsets[qId], qdb->residues.begin() + qdb->offsets[qId + 1]);
+            qOff.push_back(qLetters.size());
+            const char *d = aln.data(id);
+            while (*d != '\0') {
+                const char *ls = d;
+                while (*d != '\n' && *d != '\0') d++;
+                const char *le = d;
+                if (*d == '\n') d++;
+                // columns: tKey bits seqId eval qStart qEnd qLen tStart tEnd tLen [cigar]
+                const char *col[12];
+                int nc = 0;
+                col[nc++] = ls;
+                for (const char *c = ls; c < le && nc < 12; c++)
+                    if (*c == '\t') col[nc++] = c + 1;
+                const uint32_t tKey = (uint32_t) strtoul(ls, nullptr, 10);
+                if (tKey == qKey && sameDb) continue;   // the query repeated in the same database case (:186-195)
+                double evalue = 0.0;
+                if (nc >= 4) evalue = strtod(col[3], nullptr);
+                if (!(evalue < evalProfile)) continue;
+                if (nc < 11) return fail("alignment DB without backtraces (run align with -a); recomputing them is the align module's job");
+                const size_t tId = tdb->rd.idOfKey(tKey);
+                if (tId == SIZE_MAX) return fail("Sequence " + std::to_string(tKey) + " does not exist in target sequence database");
+                edgeT.push_back((uint32_t) tId);
+                eQ.push_back((int32_t) strtol(col[4], nullptr, 10));
+                eT.push_back((int32_t) strtol(col[7], nullptr, 10));
+                // Matcher::uncompressAlignment (Matcher.cpp:187-201)
+                size_t count = 0;
+                for (const char *c = col[10]; c < le; c++) {
+                    if (*c >= '0' && *c <= '9') count = count * 10 + (size_t) (*c - '0');
+                    else {
+                        pool.append(count == 0 ? 1 : count, *c);
+                        count = 0;
+                    }
+                }
+                btOff.push_back(pool.size());
+            }
+            edgeOff.push_back(edgeT.size());
+        }
+        const uint32_t nQ = (uint32_t) keys.size();
+        profiles.assign(qOff.back() * 25 + 1, 0);
+        pool.push_back(' ');
+        qLetters.push_back(0);
+        edgeT.push_back(0);
+        eQ.push_back(0);
+        eT.push_back(0);
+        const int rc = sd_r2p_batch(r2p, &p, nQ, qLetters.data(), qOff.data(), edgeOff.data(), edgeT.data(), eQ.data(), eT.data(), pool.data(),
+                                    btOff.data(), tdb->residues.data(), tdb->offsets.data(), profiles.data(), nullptr);
+        if (rc != SD_OK) return fail("sd_r2p_batch failed (" + std::to_string(rc) + ")");
+        for (uint32_t q = 0; q < nQ; q++)
+            if (!out.write(keys[q], profiles.data() + qOff[q] * 25, (size_t) (qOff[q + 1] - qOff[q]) * 25)) return fail("cannot write " + a.pos[3]);
+    }
+    if (!out.close(&err)) return fail(err);
+    // the profile DB shares the query DB's ancillary files (DBReader::softlinkDb(..., SEQUENCE_ANCILLARY), :318-320)
+    for (const char *suffix : {"_h", "_h.index", "_h.dbtype", ".lookup", ".source"}) {
+        const std::string src = a.pos[0] + suffix, dst = a.pos[3] + suffix;
+        ::remove(dst.c_str());
+        if (sddb::fileExists(src)) {
+            char *real = realpath(src.c_str(), nullptr);
+            if (real) {
+                if (symlink(real, dst.c_str()) != 0) { /* best effort, as the reference */ }
+                free(real);
+            }
+        }
+    }
+    info(a, "%zu profiles written\n", n);
+    return 0;
+}
 
-int result2profileModule(const Args &) { return fail("not built yet"); }
-int subtractdbsModule(const Args &) { return fail("not built yet"); }
-int mergedbsModule(const Args &) { return fail("not built yet"); }
+// subtractdbs <resultDB A> <resultDB B> <outDB>  (M/src/util/subtractdbs.cpp:13-118): lines of A whose target is not listed
+// (with E <= threshold) in B
+int subtractdbsModule(const Args &a) {
+    if (a.pos.size() != 3) return fail("usage: subtractdbs <resultDB> <resultDB> <outDB>");
+    double evalThr = a.real("-e", 0.001), evalProfile = a.real("--e-profile", 0.001);
+    evalProfile = (evalThr < evalProfile) ? evalThr : evalProfile;
+    std::string err;
+    sddb::Reader left, right;
+    if (!left.open(a.pos[0], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
+    if (!right.open(a.pos[1], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::NOSORT, &err)) return fail(err);
+    sddb::Writer out;
+    if (!out.open(a.pos[2], left.dbtype(), &err)) return fail(err);
+    auto evalOf = [](const char *ls, const char *le) {
+        int tabs = 0;
+        const char *c3 = nullptr;
+        for (const char *c = ls; c < le; c++)
+            if (*c == '\t' && ++tabs == 3) c3 = c + 1;
+        // an alignment record has at least ten columns; anything shorter (prefilter lines) counts as E = 0
+        int cols = 1;
+        for (const char *c = ls; c < le; c++) cols += (*c == '\t');
+        return (cols >= 10 && c3) ? strtod(c3, nullptr) : 0.0;
+    };
+    std::string result;
+    std::map<unsigned, bool> lookup;
+    for (size_t id = 0; id < left.size(); id++) {
+        lookup.clear();
+        const char *leftData = left.data(id);
+        for (const char *d = leftData; *d != '\0';) {
+            const char *ls = d;
+            while (*d != '\n' && *d != '\0') d++;
+            if (evalOf(ls, d) <= evalProfile) lookup[(unsigned) strtoul(ls, nullptr, 10)] = true;
+            if (*d == '\n') d++;
+        }
+        const size_t rid = right.idOfKey(left.key(id));
+        if (rid != SIZE_MAX) {
+            for (const char *d = right.data(rid); *d != '\0';) {
+                const char *ls = d;
+                while (*d != '\n' && *d != '\0') d++;
+                if (evalOf(ls, d) <= evalProfile) lookup[(unsigned) strtoul(ls, nullptr, 10)] = false;
+                if (*d == '\n') d++;
+            }
+        }
+        result.clear();
+        for (const char *d = leftData; *d != '\0';) {
+            const char *ls = d;
+            while (*d != '\n' && *d != '\0') d++;
+            if (*d == '\n') d++;
+            if (lookup[(unsigned) strtoul(ls, nullptr, 10)]) result.append(ls, d - ls);
+        }
+        if (!out.write(left.key(id), result.data(), result.size())) return fail("cannot write " + a.pos[2]);
+    }
+    if (!out.close(&err)) return fail(err);
+    return 0;
+}
+
+// mergedbs <keyDB> <outDB> <DB1> <DB2> ...  (M/src/util/mergedbs.cpp:8-78): per key of keyDB the concatenation of its entries
+int mergedbsModule(const Args &a) {
+    if (a.pos.size() < 4) return fail("usage: mergedbs <sequenceDB> <outDB> <resultDB1> <resultDB2> [...]");
+    if (a.has("--prefixes") && !a.str("--prefixes", "").empty()) return fail("--prefixes is not supported");
+    std::string err;
+    sddb::Reader keysDb;
+    if (!keysDb.open(a.pos[0], sddb::Reader::USE_INDEX, sddb::Reader::NOSORT, &err)) return fail(err);
+    std::vector<std::unique_ptr<sddb::Reader> > in;
+    for (size_t i = 2; i < a.pos.size(); i++) {
+        in.emplace_back(new sddb::Reader());
+        if (!in.back()->open(a.pos[i], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::NOSORT, &err)) return fail(err);
+    }
+    sddb::Writer out;
+    if (!out.open(a.pos[1], in[0]->dbtype(), &err)) return fail(err);
+    std::string buf;
+    for (size_t id = 0; id < keysDb.size(); id++) {
+        const uint32_t key = keysDb.key(id);
+        buf.clear();
+        for (size_t i = 0; i < in.size(); i++) {
+            const size_t e = in[i]->idOfKey(key);
+            if (e == SIZE_MAX) continue;
+            buf.append(in[i]->data(e), in[i]->entryLength(e) - 1);
+        }
+        if (!out.write(key, buf.data(), buf.size())) return fail("cannot write " + a.pos[1]);
+    }
+    if (!out.close(&err)) return fail(err);
+    return 0;
+}
+
+namespace {
+
+int runModule(int (*fn)(const Args &), const char *name, const std::vector<std::string> &pos, const std::vector<std::string> &flags) {
+    std::vector<const char *> argv;
+    for (const std::string &s : pos) argv.push_back(s.c_str());
+    for (const std::string &s : flags) argv.push_back(s.c_str());
+    Args sub;
+    sub.module = name;
+    std::string err;
+    if (!sub.parse((int) argv.size(), argv.data(), &err)) return fail(std::string(name) + ": " + err);
+    info(sub, "");
+    return fn(sub);
+}
+
+std::vector<std::string> with(std::vector<std::string> v, std::initializer_list<std::string> more) {
+    v.insert(v.end(), more.begin(), more.end());
+    return v;
+}
+
+// `search --num-iterations N` (M/src/workflow/Search.cpp:476-518 builds the per-step parameter strings,
+// M/data/workflow/blastpgp.sh:52-140 runs them): iteration 0 with --realign and the profile E-value, prefilter results of
+// later iterations minus what is aligned already, the last alignment with the user's -e, merged into the result DB
+int iterativeSearch(const Args &a, const std::string &Q, const std::string &T, const std::string &result, const std::string &tmp) {
+    const int numIt = (int) a.integer("--num-iterations", 1);
+    mkdir(tmp.c_str(), 0777);
+    const std::string eUser = a.str("-e", "0.001"), eProfile = a.str("--e-profile", "0.001");
+    const std::vector<std::string> common = {"--threads", std::to_string(threadsOf(a)), "-v", a.str("-v", "3")};
+    std::vector<std::string> pref = with(common, {"-s", a.str("-s", "5.7"), "-k", a.str("-k", "0"), "--max-seqs", a.str("--max-seqs", "300"), "-c",
+                                                  a.str("-c", "0"), "--cov-mode", a.str("--cov-mode", "0"), "--min-ungapped-score",
+                                                  a.str("--min-ungapped-score", "15"), "--mask", a.str("--mask", "1"), "--mask-prob",
+                                                  a.str("--mask-prob", "0.9"), "--comp-bias-corr", a.str("--comp-bias-corr", "1")});
+    for (const char *f : {"--device", "--bin-size", "--l2-cache-size", "--chunk-queries"})
+        if (a.has(f)) pref = with(pref, {f, a.str(f, "")});
+    std::vector<std::string> aln = with(common, {"-a", "1", "--alignment-mode", a.str("--alignment-mode", "2"), "--min-aln-len", a.str("--min-aln-len", "0"),
+                                                 "-c", a.str("-c", "0"), "--cov-mode", a.str("--cov-mode", "0"), "--min-seq-id",
+                                                 a.str("--min-seq-id", "0"), "--comp-bias-corr", a.str("--comp-bias-corr", "1"),
+                                                 "--realign-score-bias", a.str("--realign-score-bias", "-0.2")});
+    if (a.has("--device")) aln = with(aln, {"--device", a.str("--device", "0")});
+    const std::vector<std::string> prof = with(common, {"-e", eProfile, "--e-profile", eProfile, "--mask-profile", a.str("--mask-profile", "1"),
+                                                        "--comp-bias-corr", a.str("--comp-bias-corr", "1"), "--filter-msa", a.str("--filter-msa", "1"),
+                                                        "--filter-min-enable", a.str("--filter-min-enable", "0"), "--max-seq-id",
+                                                        a.str("--max-seq-id", "0.9"), "--qid", a.str("--qid", "0.0"), "--qsc", a.str("--qsc", "-20"),
+                                                        "--cov", a.str("--cov", "0"), "--diff", a.str("--diff", "1000"), "--pca",
+                                                        a.str("--pca", "substitution:1.100,context:1.400"), "--pcb",
+                                                        a.str("--pcb", "substitution:4.100,context:5.800")});
+    std::string query = Q;
+    for (int step = 0; step < numIt; step++) {
+        const std::string s = std::to_string(step), s1 = std::to_string(step - 1);
+        const bool last = step == numIt - 1;
+        const std::string prefDb = tmp + (step == 0 ? "/pref_0" : "/pref_tmp_" + s);
+        if (int rc = runModule(prefilterModule, "prefilter", {query, T, prefDb}, pref)) return rc;
+        std::string prefForAln = prefDb;
+        if (step >= 1) {
+            prefForAln = tmp + "/pref_" + s;
+            if (int rc = runModule(subtractdbsModule, "subtractdbs", {prefDb, tmp + "/aln_" + s1, prefForAln},
+                                   with(common, {"--e-profile", eProfile, "-e", eUser})))
+                return rc;
+            sddb::removeDb(prefDb);
+        }
+        // the realign pass belongs to iteration 0 only; every iteration but the last aligns with the profile E-value
+        // (Search.cpp:484-486,497-505)
+        std::vector<std::string> alnPar = with(aln, {"-e", last ? eUser : eProfile, "--realign", step == 0 ? "1" : "0"});
+        const std::string alnDb = tmp + (step == 0 ? "/aln_0" : "/aln_tmp_" + s);
+        if (int rc = runModule(alignModule, "align", {query, T, prefForAln, alnDb}, alnPar)) return rc;
+        std::string merged = alnDb;
+        if (step > 0) {
+            merged = last ? result : tmp + "/aln_" + s;
+            if (int rc = runModule(mergedbsModule, "mergedbs", {query, merged, tmp + "/aln_" + s1, alnDb}, {})) return rc;
+            sddb::removeDb(tmp + "/aln_" + s1);
+            sddb::removeDb(alnDb);
+        }
+        if (!last) {
+            const std::string profDb = tmp + "/profile_" + s;
+            if (int rc = runModule(result2profileModule, "result2profile", {query, T, merged, profDb}, prof)) return rc;
+            query = profDb;
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+int searchModule(const Args &a) {
+    if (a.integer("--num-iterations", 1) > 1) {
+        if (a.pos.size() != 4) return fail("usage: search <queryDB> <targetDB> <alignmentDB> <tmpDir> [options]");
+        if (int rc = checkWorkflowFlags(a)) return rc;
+        return iterativeSearch(a, a.pos[0], a.pos[1], a.pos[2], a.pos[3]);
+    }
+    return runSearch(a, false);
+}
+
+int clustersearchModule(const Args &a) {
+    if (a.integer("--num-iterations", 1) <= 1) return runSearch(a, true);
+    // iterative profile search (BASELINE config 4): the iterations through the modules, then the module chain of
+    // R/data/clustersearch.sh:121-151 on the merged alignment DB
+    if (a.pos.size() != 4) return fail("usage: clustersearch <querySetDB> <targetSetDB> <out.tsv> <tmpDir> [options]");
+    if (int rc = checkWorkflowFlags(a)) return rc;
+    const std::string Q = a.pos[0], T = a.pos[1], tmp = a.pos[3];
+    mkdir(tmp.c_str(), 0777);
+    Args s = a;   // the search step runs with the clustersearch workflow's defaults (R/src/workflow/clustersearch.cpp:9-37)
+    auto def = [&](const char *f, const char *v) { if (!s.has(f)) s.opt[f] = v; };
+    def("-s", "5.7");
+    def("--cov-mode", "2");
+    def("-c", "0.8");
+    def("-e", "10");
+    def("--min-aln-len", "30");
+    def("--alignment-mode", "2");
+    for (const char *db : {"/result", "/result_prefixed", "/aggregate", "/aggregate_merged", "/matches", "/matches_h", "/clusters", "/clusters_h"})
+        sddb::removeDb(tmp + db);
+    if (int rc = iterativeSearch(s, Q, T, tmp + "/result", tmp + "/search")) return rc;
+    const std::vector<std::string> common = {"--threads", std::to_string(threadsOf(a)), "-v", a.str("-v", "3")};
+    if (int rc = runModule(prefixidModule, "prefixid", {tmp + "/result", tmp + "/result_prefixed"}, common)) return rc;
+    if (int rc = runModule(besthitbysetModule, "besthitbyset", {Q, T, tmp + "/result_prefixed", tmp + "/aggregate"},
+                           with(common, {"--simple-best-hit", "1", "--suboptimal-hits", "0"})))
+        return rc;
+    if (int rc = runModule(mergeresultsbysetModule, "mergeresultsbyset", {Q + "_set_to_member", tmp + "/aggregate", tmp + "/aggregate_merged"}, common))
+        return rc;
+    if (int rc = runModule(combinehitsModule, "combinehits", {Q, T, tmp + "/aggregate_merged", tmp + "/matches", tmp},
+                           with(common, {"--alpha", a.str("--alpha", "1"), "--aggregation-mode", "0", "--filter-self-match",
+                                         a.flag("--filter-self-match", false) ? "1" : "0"})))
+        return rc;
+    std::vector<std::string> ch = with(common, {"--multihit-pval", a.str("--multihit-pval", "0.01"), "--cluster-pval", a.str("--cluster-pval", "0.01"),
+                                                "--max-gene-gap", a.str("--max-gene-gap", "3"), "--cluster-size", a.str("--cluster-size", "2"),
+                                                "--db-output", "1", "--alpha", a.str("--alpha", "1")});
+    if (a.has("--device")) ch = with(ch, {"--device", a.str("--device", "0")});
+    if (int rc = runModule(clusterhitsModule, "clusterhits", {Q, T, tmp + "/matches", tmp + "/clusters"}, ch)) return rc;
+    return runModule(summarizeresultsModule, "summarizeresults", {Q, T, tmp + "/clusters", a.pos[2]}, common);
+}
 
 }  // namespace sdcli

@@ -622,9 +622,17 @@ int sd_r2p_create(sd_r2p **out) {
     r->Rbacking.assign(21 * 24 + 8, 0.0f);
     float *base = r->Rbacking.data();
     while (((uintptr_t) base) % 32) base++;
+    // P(a|b) is taken against the background generateSubMatrix derives from the joint matrix itself (row sums, X fixed at
+    // ANY_BACK = 1e-5; BaseMatrix.cpp:97-123), not against the member pBack the log-odds use
+    double rowBack[21];
+    for (int i = 0; i < 21; i++) {
+        rowBack[i] = 0;
+        for (int j = 0; j < 21; j++) rowBack[i] += r->m.probMatrix[i][j];
+    }
+    rowBack[20] = 1E-5;
     for (int i = 0; i < 21; i++) {
         r->R[i] = base + i * 24;
-        for (int j = 0; j < 21; j++) r->R[i][j] = (float) (r->m.probMatrix[i][j] / (r->m.pBack[j]));
+        for (int j = 0; j < 21; j++) r->R[i][j] = r->m.probMatrix[i][j] / (rowBack[j]);
     }
     for (int i = 0; i < 21; i++)
         for (int j = 0; j < 21; j++) r->sub[i * 21 + j] = (int8_t) r->m.sub[i][j];

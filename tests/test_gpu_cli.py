@@ -127,3 +127,30 @@ def test_align_realign_reproduces_reference_db(work):
     sdgpu('align', g, g, work / 'pref_ref', work / 'aln_0', *par)
     lines = flat(work, 'aln_0')
     assert (len(lines), sorted_md5(lines)) == (12919, '5d4e3228b0afb4378a0364a0291627f4')
+
+
+def _key_ordered_md5(path):
+    import hashlib
+    from dbutil import read_db
+    d = read_db(str(path))
+    h = hashlib.md5()
+    for k in sorted(d):
+        h.update(d[k])
+    return len(d), h.hexdigest()
+
+
+def test_iterative_profile_search_config4(work):
+    """BASELINE config 4 on the regression input: `clustersearch --num-iterations 3` = sequence search with --realign,
+    result2profile, two profile searches (profile k-mer prefilter, profile Smith-Waterman) with subtractdbs / mergedbs
+    between them (M/src/workflow/Search.cpp:476-518, M/data/workflow/blastpgp.sh:52-140).  Pins: md5 of the reference
+    binary's profile DBs, merged alignment DB and final TSV for the same command (331 hits / 119 clusters)."""
+    g = work / 'genome'
+    sdgpu('clustersearch', g, g, work / 'iter.tsv', work / 'tmpi', '--filter-self-match', '--num-iterations', '3', '--threads', '8', '-v', '1')
+    assert _key_ordered_md5(work / 'tmpi' / 'search' / 'profile_0') == (5898, '169a337cab4e438fdcb75be742eef3d2')
+    assert _key_ordered_md5(work / 'tmpi' / 'search' / 'profile_1') == (5898, '0841b3aae841b086fa8850c8086c20af')
+    sdgpu('prefixid', work / 'tmpi' / 'result', work / 'iter_result.flat', '--tsv')
+    lines = open(work / 'iter_result.flat').readlines()
+    assert (len(lines), sorted_md5(lines)) == (18698, 'deee49195d78013868efd140ad77b913')
+    tsv = open(work / 'iter.tsv').readlines()
+    assert (sum(1 for l in tsv if l.startswith('>')), sum(1 for l in tsv if l.startswith('#'))) == (331, 119)
+    assert sorted_md5(tsv, drop_first_column=True) == 'ca3dd1ba9c0f89b9a7cf0726a1bab2ce'
