@@ -222,6 +222,10 @@ int sd_host_map_sequence(sd_host *h, const char *ascii, uint64_t len, uint8_t *o
 /* SubstitutionMatrix::calcLocalAaBiasCorrection + the three integer roundings, for n sequences */
 int sd_host_comp_bias(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
                       int8_t *swBias, int8_t *diagBias, int16_t *kmerBias);
+/* the Smith-Waterman composition bias alone, against matrix `which` (sd_host_matrix numbering): the --realign pass builds its
+ * query profile from the score-biased matrix, and calcLocalAaBiasCorrection reads the matrix it is given
+ * (Alignment.cpp:296-303 -> Matcher::initQuery -> StripedSmithWaterman.cpp:1230-1235) */
+int sd_host_sw_comp_bias(sd_host *h, int which, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int8_t *swBias);
 /* The three integer composition-bias arrays of sd_host_comp_bias, computed on the device (same values, bit for bit:
  * the kernel forms calcLocalAaBiasCorrection's integer window sums, SubstitutionMatrix.cpp:79-109, and reads the float
  * tail from a table the host evaluated with the reference's expression order).  For callers short of host cores. */

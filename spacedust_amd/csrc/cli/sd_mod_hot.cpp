@@ -527,7 +527,18 @@ int alignModule(const Args &a) {
                     ident2[w] = recIdent[i];
                 }
             std::vector<uint32_t> idx2;
-            rc = alignPairs(ctx.c, rpar, qset.s, tset.s, *qdb, *tdb, localQ, pq2, pt2, ident2, false, idx2, res2, pool2);
+            // the realigner's query profile: composition bias against the score-biased matrix (a profile query carries its
+            // scores itself and is reused)
+            SeqSetH qset2;
+            sd_seqset *rq = qset.s;
+            if (!qdb->profile && compBias && realignScoreBias != 0.0f) {
+                std::vector<int8_t> qbias2(qoff[nq] + 1, 0);
+                sd_host_sw_comp_bias(host.h, 2, qres.data(), qoff.data(), nq, qbias2.data());
+                rc = sd_seqset_create(ctx.c, qres.data(), qoff.data(), nq, qbias2.data(), &qset2.s);
+                if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_seqset_create(realign queries)");
+                rq = qset2.s;
+            }
+            rc = alignPairs(ctx.c, rpar, rq, tset.s, *qdb, *tdb, localQ, pq2, pt2, ident2, false, idx2, res2, pool2);
             if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_sw_align_batch(realign)");
             merged.resize(nAcc);
             order2.resize(nAcc);

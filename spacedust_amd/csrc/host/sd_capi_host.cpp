@@ -76,6 +76,15 @@ int sd_host_comp_bias(sd_host *h, const uint8_t *residues, const uint64_t *offse
     return SD_OK;
 }
 
+int sd_host_sw_comp_bias(sd_host *h, int which, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int8_t *swBias) {
+    if (!h || !residues || !offsets || !swBias || which < 0 || which > 2) return SD_EINVAL;
+    const sd::SubMat &m = pick(h, which);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(h->threads)
+    for (uint32_t i = 0; i < n; i++)
+        sd::swCompBias8(m, residues + offsets[i], (int) (offsets[i + 1] - offsets[i]), swBias + offsets[i]);
+    return SD_OK;
+}
+
 int sd_host_index_build(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
                         int kmerThr, int mask, double maskProb, sd_host_index **out) {
     if (!out || (kmerSize != 6 && kmerSize != 7)) return SD_EINVAL;
