@@ -218,6 +218,9 @@ int sd_host_create(int threads, sd_host **out);
 void sd_host_destroy(sd_host *h);
 /* which: 0 blosum62@2 (SW), 1 VTML80@8 bias -0.2 (seeds), 2 blosum62@2 bias -0.2 (diagonal scoring) */
 int sd_host_matrix(sd_host *h, int which, int8_t *out21x21, double *pBack21, uint8_t *aa2num256);
+/* the matrix file text (.out layout: background, lambda, half-bit scores) of blosum62 (0) / VTML80 (1): what an index file's
+ * SCOREMATRIXNAME entry and the reference's "NAME.out:DATA" matrix argument carry (BaseMatrix.cpp:176-214); returns the length */
+int sd_host_matrix_text(int which, char *buf, size_t cap);
 int sd_host_map_sequence(sd_host *h, const char *ascii, uint64_t len, uint8_t *out);
 /* SubstitutionMatrix::calcLocalAaBiasCorrection + the three integer roundings, for n sequences */
 int sd_host_comp_bias(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
@@ -387,6 +390,19 @@ typedef struct sd_search_result sd_search_result;
 /* builds the index of `target` on the host (tantan masking + IndexBuilder::fillDatabase), uploads it and the target
  * sequences; the arrays behind `target` must stay valid until sd_search_destroy */
 int sd_search_create(int device, const sd_search_params *par, const sd_setdb *target, sd_search **out);
+/* the same with a target index that exists already (read from a createindex file, or built once and handed to every rank):
+ * arrays as sd_host_index_arrays returns them; they may be released after the call */
+typedef struct {
+    int32_t kmerSize, kmerThr;
+    const uint32_t *kmerOffsets;     /* 20^k + 1 */
+    const uint32_t *entrySeq;
+    const uint16_t *entryPos;
+    uint64_t nEntries;
+    const uint8_t *maskedResidues;   /* the masked target residues the diagonal scoring reads (SequenceLookup) */
+    uint64_t nMaskedResidues;        /* how many residues tantan masked (statistics only) */
+} sd_index_view;
+int sd_search_create_indexed(int device, const sd_search_params *par, const sd_setdb *target, const sd_index_view *index,
+                             sd_search **out);
 void sd_search_destroy(sd_search *s);
 const char *sd_search_last_error(sd_search *s);
 /* the two device contexts (0: prefilter + clusterhits, 1: alignments), e.g. for sd_profile_* */

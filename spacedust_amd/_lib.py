@@ -155,6 +155,7 @@ def load():
                                             C.c_char_p, _vp, C.c_char_p, _vp, C.c_char_p, _vp, C.c_int, C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]),
         'sd_agg_set_keys': (C.c_int, [_vp, _vp, _vp]),
+        'sd_host_matrix_text': (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
         'sd_host_sw_comp_bias': (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp]),
         'sd_host_can_be_covered': (C.c_int, [C.c_float, C.c_int, C.c_float, C.c_float]),
         'sd_host_accept_sort': (C.c_int, [C.POINTER(AlnCriteria), C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -166,6 +167,7 @@ def load():
         'sd_alntext_get': (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(_vp)]),
         'sd_search_default_params': (None, [C.POINTER(SearchParams)]),
         'sd_search_create': (C.c_int, [C.c_int, C.POINTER(SearchParams), C.POINTER(SetDbView), C.POINTER(_vp)]),
+        'sd_search_create_indexed': (C.c_int, [C.c_int, C.POINTER(SearchParams), C.POINTER(SetDbView), _vp, C.POINTER(_vp)]),
         'sd_search_destroy': (None, [_vp]),
         'sd_search_last_error': (C.c_char_p, [_vp]),
         'sd_search_ctx': (_vp, [_vp, C.c_int]),

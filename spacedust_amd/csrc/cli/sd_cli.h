@@ -54,7 +54,19 @@ struct SetInfo {
     bool load(const std::string &dbPath, bool needSources, std::string *err);
 };
 
+// a target index read from TARGET.idx (sd_mod_index.cpp), in the array form sd_target_create / sd_search_create take
+struct LoadedIndex {
+    int k = 0, kmerThr = 0;
+    uint64_t nEntries = 0;
+    std::vector<uint32_t> offsets, entrySeq;
+    std::vector<uint16_t> entryPos;
+    std::vector<uint8_t> masked;
+};
+int loadTargetIndex(const std::string &targetDb, int wantK, int wantKmerThr, int wantMask, uint64_t nSeq, uint64_t residues,
+                    LoadedIndex &out, std::string *why);
+
 // modules (each: argv after the module name -> exit code)
+int createindexModule(const Args &a);
 int prefilterModule(const Args &a);
 int alignModule(const Args &a);
 int clusterhitsModule(const Args &a);

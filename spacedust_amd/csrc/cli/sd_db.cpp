@@ -235,6 +235,10 @@ const char *Reader::data(size_t id) const {
     return maps_[f].p + (off - maps_[f].start);
 }
 
+void Reader::copyData(char *dst) const {
+    for (const Map &m : maps_) memcpy(dst + m.start, m.p, m.n);
+}
+
 size_t Reader::idOfKey(uint32_t key) const {
     const std::vector<uint32_t>::const_iterator it = std::lower_bound(sortedKey_.begin(), sortedKey_.end(), key);
     if (it == sortedKey_.end() || *it != key) return SIZE_MAX;

@@ -59,6 +59,8 @@ public:
     // payload of entry id ('\0'-terminated inside the mapping); entryLength counts the terminator
     const char *data(size_t id) const;
     size_t entryLength(size_t id) const { return length_[id]; }
+    uint64_t entryOffset(size_t id) const { return offset_[id]; }
+    void copyData(char *dst) const;   // the data file(s) back to back (totalDataSize bytes)
     // DBReader::getSeqLen: sequence entries end in "\n\0" (M/src/commons/DBReader.h:225-231)
     size_t seqLen(size_t id) const { return length_[id] >= 2 ? length_[id] - 2 : 0; }
     size_t idOfKey(uint32_t key) const;                     // SIZE_MAX when absent (DBReader::getId -> UINT_MAX)

@@ -29,6 +29,7 @@ const Module kModules[] = {
     {"result2profile", result2profileModule, "host: alignment DB -> profile DB (between search iterations)"},
     {"subtractdbs", subtractdbsModule, "host glue: remove from result DB A the targets listed in result DB B"},
     {"mergedbs", mergedbsModule, "host glue: merge the entries of several DBs by key"},
+    {"createindex", createindexModule, "target k-mer index built once, in the reference's createindex file layout: <sequenceDB> <tmpDir>"},
     {"createsetdb", createsetdbModule, "FASTA files (Prodigal headers) -> setDB in the createsetdb layout"},
 };
 }  // namespace

@@ -110,20 +110,36 @@ int prefilterModule(const Args &a) {
     int rc = sd_ctx_create(deviceOf(a), &ctx.c);
     if (rc != SD_OK) return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rc) + "); this path has no CPU fallback");
 
-    // target side: IndexBuilder::fillDatabase on the host (mask + count + fill), resident in HBM afterwards.  Profile
-    // searches index every k-mer (Prefiltering.cpp:525-527)
+    // target side: TARGET.idx when a createindex file with matching parameters lies next to the DB (PrefilteringIndexReader
+    // layout, sd_mod_index.cpp), else IndexBuilder::fillDatabase on the host (mask + count + fill); resident in HBM afterwards.
+    // Profile searches index every k-mer (Prefiltering.cpp:525-527)
+    const int indexThr = qdb->profile ? 0 : kmerThr;
     IndexH index;
-    rc = sd_host_index_build(host.h, tdb->residues.data(), tdb->offsets.data(), tdb->n, k, qdb->profile ? 0 : kmerThr, mask ? 1 : 0,
-                             maskProb, &index.ix);
-    if (rc != SD_OK) return fail("sd_host_index_build failed (" + std::to_string(rc) + ")");
-    uint64_t tableSize = 0, nEntries = 0, maskedRes = 0;
-    sd_host_index_info(index.ix, &tableSize, &nEntries, &maskedRes);
-    info(a, "Index table k-mer threshold: %d at k-mer size %d\nIndex statistics\nEntries:          %llu\nMasked residues: %llu\n",
-         kmerThr, k, (unsigned long long) nEntries, (unsigned long long) maskedRes);
+    LoadedIndex loaded;
+    std::string why;
+    uint64_t nEntries = 0, maskedRes = 0;
     const uint32_t *kOff, *eSeq;
     const uint16_t *ePos;
     const uint8_t *masked;
-    sd_host_index_arrays(index.ix, &kOff, &eSeq, &ePos, &masked);
+    const int got = loadTargetIndex(a.pos[1], k, indexThr, mask ? 1 : 0, tdb->n, tdb->totalResidues(), loaded, &why);
+    if (got < 0) return fail(why);
+    if (got == 0) {
+        kOff = loaded.offsets.data();
+        eSeq = loaded.entrySeq.data();
+        ePos = loaded.entryPos.data();
+        masked = loaded.masked.data();
+        nEntries = loaded.nEntries;
+        info(a, "Use index %s.idx\n", a.pos[1].c_str());
+    } else {
+        if (sddb::fileExists(a.pos[1] + ".idx.index")) info(a, "Index file not used: %s\n", why.c_str());
+        rc = sd_host_index_build(host.h, tdb->residues.data(), tdb->offsets.data(), tdb->n, k, indexThr, mask ? 1 : 0, maskProb, &index.ix);
+        if (rc != SD_OK) return fail("sd_host_index_build failed (" + std::to_string(rc) + ")");
+        uint64_t tableSize = 0;
+        sd_host_index_info(index.ix, &tableSize, &nEntries, &maskedRes);
+        sd_host_index_arrays(index.ix, &kOff, &eSeq, &ePos, &masked);
+    }
+    info(a, "Index table k-mer threshold: %d at k-mer size %d\nIndex statistics\nEntries:          %llu\n", kmerThr, k,
+         (unsigned long long) nEntries);
     const int16_t *s2, *s3;
     const uint16_t *i2, *i3;
     uint32_t sz2, sz3;

@@ -232,7 +232,32 @@ int runSearch(const Args &a, bool withClusters) {
     info(a, "Query database size: %u type: %s\nTarget database size: %u type: Aminoacid\n", qdb->n, qdb->profile ? "Profile" : "Aminoacid", tdb->n);
 
     SearchH S;
-    int rc = sd_search_create(device, &par, &tv.view, &S.s);
+    int rc;
+    {
+        // TARGET.idx (createindex layout) instead of a rebuild when its parameters match this run
+        const int k = par.kmerSize ? par.kmerSize : sd_host_auto_kmer_size(tdb->totalResidues());
+        const int thr = par.profileQueries ? 0 : sd_host_kmer_threshold(par.sensitivity, k);
+        LoadedIndex loaded;
+        std::string why;
+        const int got = loadTargetIndex(a.pos[1], k, thr, par.mask ? 1 : 0, tdb->n, tdb->totalResidues(), loaded, &why);
+        if (got < 0) return fail(why);
+        if (got == 0) {
+            sd_index_view v;
+            v.kmerSize = k;
+            v.kmerThr = thr;
+            v.kmerOffsets = loaded.offsets.data();
+            v.entrySeq = loaded.entrySeq.data();
+            v.entryPos = loaded.entryPos.data();
+            v.nEntries = loaded.nEntries;
+            v.maskedResidues = loaded.masked.data();
+            v.nMaskedResidues = 0;
+            info(a, "Use index %s.idx\n", a.pos[1].c_str());
+            rc = sd_search_create_indexed(device, &par, &tv.view, &v, &S.s);
+        } else {
+            if (sddb::fileExists(a.pos[1] + ".idx.index")) info(a, "Index file not used: %s\n", why.c_str());
+            rc = sd_search_create(device, &par, &tv.view, &S.s);
+        }
+    }
     if (rc == SD_ENODEVICE) return fail("no usable HIP device (sd_search_create returned -1); this path has no CPU fallback");
     if (rc != SD_OK) return fail("sd_search_create failed (" + std::to_string(rc) + ")");
     uint64_t st[16];

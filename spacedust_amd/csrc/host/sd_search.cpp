@@ -207,7 +207,12 @@ void sd_search_default_params(sd_search_params *p) {
 }
 
 int sd_search_create(int device, const sd_search_params *par, const sd_setdb *target, sd_search **out) {
+    return sd_search_create_indexed(device, par, target, nullptr, out);
+}
+
+int sd_search_create_indexed(int device, const sd_search_params *par, const sd_setdb *target, const sd_index_view *view, sd_search **out) {
     if (!par || !target || !out || !target->residues || !target->offsets) return SD_EINVAL;
+    if (view && (!view->kmerOffsets || !view->entrySeq || !view->entryPos || !view->maskedResidues)) return SD_EINVAL;
     std::unique_ptr<sd_search> s(new sd_search());
     s->par = *par;
     s->T = *target;
@@ -236,23 +241,35 @@ int sd_search_create(int device, const sd_search_params *par, const sd_setdb *ta
     s->k = par->kmerSize ? par->kmerSize : sd_host_auto_kmer_size(tRes);
     if (s->k != 6 && s->k != 7) return SD_EUNSUPPORTED;
     s->kmerThr = par->profileQueries ? sd_host_profile_kmer_threshold(par->sensitivity, s->k) : sd_host_kmer_threshold(par->sensitivity, s->k);
+    const int indexThr = par->profileQueries ? 0 : s->kmerThr;   // profile searches index every k-mer (Prefiltering.cpp:525-527)
+    if (view && (view->kmerSize != s->k || view->kmerThr != indexThr)) return SD_EINVAL;
     double t0 = nowSec();
-    rc = sd_host_index_build(s->host, target->residues, target->offsets, target->n, s->k, par->profileQueries ? 0 : s->kmerThr,
-                             par->mask ? 1 : 0, par->maskProb, &s->index);
-    if (rc != SD_OK) return rc;
+    uint64_t nEntries = 0, masked = 0;
+    const uint32_t *kOff, *eSeq;
+    const uint16_t *ePos;
+    const uint8_t *mres;
+    if (view) {
+        kOff = view->kmerOffsets;
+        eSeq = view->entrySeq;
+        ePos = view->entryPos;
+        mres = view->maskedResidues;
+        nEntries = view->nEntries;
+        masked = view->nMaskedResidues;
+    } else {
+        rc = sd_host_index_build(s->host, target->residues, target->offsets, target->n, s->k, indexThr, par->mask ? 1 : 0, par->maskProb,
+                                 &s->index);
+        if (rc != SD_OK) return rc;
+        uint64_t tableSize = 0;
+        sd_host_index_info(s->index, &tableSize, &nEntries, &masked);
+        sd_host_index_arrays(s->index, &kOff, &eSeq, &ePos, &mres);
+    }
     s->seconds[T_INDEX] = nowSec() - t0;
-    uint64_t tableSize = 0, nEntries = 0, masked = 0;
-    sd_host_index_info(s->index, &tableSize, &nEntries, &masked);
     s->stats[S_ENTRIES] = nEntries;
     s->stats[S_MASKED] = masked;
     s->stats[S_K] = (uint64_t) s->k;
     s->stats[S_KMER_THR] = (uint64_t) s->kmerThr;
     t0 = nowSec();
     {
-        const uint32_t *kOff, *eSeq;
-        const uint16_t *ePos;
-        const uint8_t *mres;
-        sd_host_index_arrays(s->index, &kOff, &eSeq, &ePos, &mres);
         const int16_t *s2, *s3;
         const uint16_t *i2, *i3;
         uint32_t z2, z3;
@@ -260,6 +277,10 @@ int sd_search_create(int device, const sd_search_params *par, const sd_setdb *ta
         sd_host_ext_matrix(s->host, 3, &s3, &i3, &z3);
         rc = sd_target_create(s->ctxPf, s->k, kOff, eSeq, ePos, nEntries, mres, target->offsets, target->n, s2, i2, s3, i3, &s->target);
         if (rc != SD_OK) return rc;
+    }
+    if (s->index) {   // the host copy is not needed once the target is resident
+        sd_host_index_destroy(s->index);
+        s->index = nullptr;
     }
     rc = sd_seqset_create(s->ctxAl, target->residues, target->offsets, target->n, nullptr, &s->tSeqs);
     if (rc != SD_OK) return rc;

@@ -84,3 +84,34 @@ def test_glue_chain_on_reference_alignment_db(setdb):
     assert hdr[0] == b'0\t1\t4319\t1579\t732\t0.000E+00\n' and hdr[1] == b'1\t0\t1579\t4319\t551\t0.000E+00\n'
     assert open(t / 'matches.dbtype', 'rb').read() == b'\x05\x00\x00\x00'
     assert open(t / 'aggregate_merged.dbtype', 'rb').read() == b'\x05\x00\x02\x00'   # DBTYPE_EXTENDED_INDEX_NEED_SRC
+
+
+def test_createindex_file_equals_the_reference_index_file(setdb):
+    """`sdgpu createindex` writes NAME.idx in PrefilteringIndexReader's layout.  The per-key md5s below are
+    those of the file `spacedust createindex genome tmp -s 5.7` (reference binary) wrote for the same DB: ENTRIES (packed
+    6-byte records), ENTRIESOFFSETS (size_t), the masked SEQINDEXDATA, both extended score matrices, the serialized sequence
+    and header DBs, META -- everything except the matrix file text (regenerated, same numbers) and the GENERATOR string."""
+    sdgpu('createindex', setdb / 'genome', setdb / 'tmp', '-s', '5.7', '--threads', '8', '-v', '0')
+    want = {0: 'a31d4efb05ad73d6ea3c0dfc5b323b99', 1: 'e0640873b3744141c00e26025c036a19', 3: '9b3162d5c618b8a0b552b4fdaf529545',
+            4: 'a63cdf5a33acc9817ce5edb755308e85', 5: 'e0bffb64aa6c5bb8c83611edbc4a1c21', 6: '3e003421cf8e31998ae50da9281c557d',
+            7: 'e0bffb64aa6c5bb8c83611edbc4a1c21', 8: '3e003421cf8e31998ae50da9281c557d', 9: 'ba9915b344ea01bf28dc7f74749c57f8',
+            10: '7c312c4256dbf5975f5aa75a2cdd2f45', 12: 'c3ce4b0559fd1f02e33d286c6880d80b', 13: 'ea7cd3d6ff584b2a33d084abf0de4f77',
+            14: 'd8c7fe7653246e0baca25d0f256b5163', 15: 'ba6e3f11d5bf4173d0092293448bdd7f', 16: '71fd9c58f287a33ce1cd79b9f7925cd4',
+            18: 'fbffa5c8b9ebb68700fe24a41863491e', 19: '94eda297ed394d8fcec45e491dd88f7d', 20: 'fbffa5c8b9ebb68700fe24a41863491e',
+            21: '94eda297ed394d8fcec45e491dd88f7d', 23: '93b885adfe0da089cdf634904fd59f71'}
+    idx = {int(l.split()[0]): (int(l.split()[1]), int(l.split()[2])) for l in open(str(setdb / 'genome.idx') + '.index')}
+    assert sorted(idx) == sorted(list(want) + [2, 22])
+    assert open(str(setdb / 'genome.idx') + '.dbtype', 'rb').read() == b'\x09\x00\x00\x00'
+    with open(setdb / 'genome.idx', 'rb') as f:
+        for k, (off, length) in sorted(idx.items()):
+            assert off % 4096 == 0 or k in (7, 8, 20, 21)          # DBWriter::alignToPageSize
+            if k not in want:
+                continue
+            f.seek(off)
+            h, left = hashlib.md5(), length
+            while left > 0:
+                b = f.read(min(left, 1 << 24))
+                h.update(b)
+                left -= len(b)
+            assert h.hexdigest() == want[k], k
+    os.remove(setdb / 'genome.idx')

@@ -154,3 +154,21 @@ def test_iterative_profile_search_config4(work):
     tsv = open(work / 'iter.tsv').readlines()
     assert (sum(1 for l in tsv if l.startswith('>')), sum(1 for l in tsv if l.startswith('#'))) == (331, 119)
     assert sorted_md5(tsv, drop_first_column=True) == 'ca3dd1ba9c0f89b9a7cf0726a1bab2ce'
+
+
+def test_prefilter_and_clustersearch_use_the_index_file(work):
+    """TARGET.idx (createindex layout) replaces the host index build when its META matches the run; results unchanged"""
+    g = work / 'genome'
+    sdgpu('createindex', g, work / 'tmpx', '-s', '5.7', '--threads', '8', '-v', '0')
+    p = sdgpu('prefilter', g, g, work / 'pref_idx', *PREFILTER_PAR)
+    assert 'Use index' in p.stdout
+    lines = flat(work, 'pref_idx')
+    assert (len(lines), sorted_md5(lines)) == (98957, '8109a70bdea70ee10e0dbd27ba6b7e37')
+    p = sdgpu('clustersearch', g, g, work / 'fused_idx.tsv', work / 'tmpfx', '--filter-self-match', '--threads', '8')
+    assert 'Use index' in p.stdout
+    assert sorted_md5(open(work / 'fused_idx.tsv').readlines(), drop_first_column=True) == 'abb28ee37bc130a5f09a9f767ef00ccf'
+    # an index built for other parameters is reported and not used
+    p = sdgpu('prefilter', g, g, work / 'pref_idx2', *(PREFILTER_PAR[:-1] + ['4']))
+    assert 'Index file not used' in p.stdout
+    for f in ('genome.idx', 'genome.idx.index', 'genome.idx.dbtype'):
+        os.remove(work / f)
