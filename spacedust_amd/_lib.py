@@ -54,6 +54,11 @@ class SetDbView(C.Structure):   # sd_setdb
                 ('nSets', C.c_uint32), ('keys', _vp), ('alnProfile', _vp), ('sortedScore', _vp), ('sortedIndex', _vp)]
 
 
+class IndexView(C.Structure):   # sd_index_view
+    _fields_ = [('kmerSize', C.c_int32), ('kmerThr', C.c_int32), ('kmerOffsets', _vp), ('entrySeq', _vp), ('entryPos', _vp),
+                ('nEntries', C.c_uint64), ('maskedResidues', _vp), ('nMaskedResidues', C.c_uint64)]
+
+
 class SearchParams(C.Structure):   # sd_search_params
     _fields_ = [('sensitivity', C.c_float), ('kmerSize', C.c_int32), ('maxSeqs', C.c_int32), ('minDiagScore', C.c_int32),
                 ('binSize', C.c_uint32), ('mask', C.c_int32), ('maskProb', C.c_double), ('compBiasCorr', C.c_int32),
@@ -167,7 +172,7 @@ def load():
         'sd_alntext_get': (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(_vp)]),
         'sd_search_default_params': (None, [C.POINTER(SearchParams)]),
         'sd_search_create': (C.c_int, [C.c_int, C.POINTER(SearchParams), C.POINTER(SetDbView), C.POINTER(_vp)]),
-        'sd_search_create_indexed': (C.c_int, [C.c_int, C.POINTER(SearchParams), C.POINTER(SetDbView), _vp, C.POINTER(_vp)]),
+        'sd_search_create_indexed': (C.c_int, [C.c_int, C.POINTER(SearchParams), C.POINTER(SetDbView), C.POINTER(IndexView), C.POINTER(_vp)]),
         'sd_search_destroy': (None, [_vp]),
         'sd_search_last_error': (C.c_char_p, [_vp]),
         'sd_search_ctx': (_vp, [_vp, C.c_int]),

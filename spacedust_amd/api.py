@@ -151,6 +151,7 @@ class HostIndex:
     def __init__(self, host, residues, offsets, k, kmer_thr, mask, mask_prob):
         self.host = host
         self.k = k
+        self.kmer_thr = kmer_thr
         self.n = len(offsets) - 1
         self.offsets = np.ascontiguousarray(offsets, np.uint64)
         residues = np.ascontiguousarray(residues, np.uint8)
@@ -175,6 +176,21 @@ class HostIndex:
             self.host.L.sd_host_index_destroy(self.h)
         except Exception:
             pass
+
+
+class IndexArrays:
+    """A target index that exists already as arrays (received from another rank, read from an index file): the attributes
+    of HostIndex that Target and ClusterSearch(index=...) read"""
+
+    def __init__(self, k, kmer_thr, seq_offsets, kmer_offsets, entry_seq, entry_pos, masked, masked_residues=0):
+        self.k, self.kmer_thr = int(k), int(kmer_thr)
+        self.offsets = np.ascontiguousarray(seq_offsets, np.uint64)
+        self.n = len(self.offsets) - 1
+        self.kmer_offsets = np.ascontiguousarray(kmer_offsets, np.uint32)
+        self.entry_seq = np.ascontiguousarray(entry_seq, np.uint32)
+        self.entry_pos = np.ascontiguousarray(entry_pos, np.uint16)
+        self.masked = np.ascontiguousarray(masked, np.uint8)
+        self.table_size, self.n_entries, self.masked_residues = len(self.kmer_offsets) - 1, len(self.entry_seq), int(masked_residues)
 
 
 class Context:

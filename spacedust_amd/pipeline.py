@@ -106,7 +106,7 @@ class ClusterSearch:
     def __init__(self, ctx, host, target_db, sensitivity=5.7, max_seqs=300, eval_thr=10.0, cov_mode=2, cov_thr=0.8,
                  aln_len_thr=30, max_gene_gap=3, cluster_size=2, alpha=1.0, p_clu_thr=0.01, p_mh_thr=0.01,
                  filter_self_match=False, bin_size=None, verbose=False, align_ctx=None, k=None, profile_queries=False,
-                 device_bias=None, chunk_queries=10000):
+                 device_bias=None, chunk_queries=10000, index=None):
         """ctx / host: the caller's context and host handle (used for the device index and for helper calls such as
         Host.map_profiles); the pipeline object creates its own two contexts on that device -- prefilter and alignments
         run on separate HIP streams so that the prefilter of the next chunk (HBM random-access bound) and the
@@ -130,7 +130,16 @@ class ClusterSearch:
         self._keep = []
         tv = _setdb_struct(target_db, self._keep)
         h = C.c_void_p()
-        rc = self.L.sd_search_create(ctx.device_index, C.byref(p), C.byref(tv), C.byref(h))
+        if index is not None:
+            # a target index that exists already (api.HostIndex / api.IndexArrays: built once and shared, or read from a file)
+            iv = _lib.IndexView()
+            iv.kmerSize, iv.kmerThr = index.k, index.kmer_thr
+            iv.kmerOffsets, iv.entrySeq, iv.entryPos = ptr(index.kmer_offsets), ptr(index.entry_seq), ptr(index.entry_pos)
+            iv.nEntries, iv.maskedResidues, iv.nMaskedResidues = index.n_entries, ptr(index.masked), index.masked_residues
+            p.kmerSize = index.k
+            rc = self.L.sd_search_create_indexed(ctx.device_index, C.byref(p), C.byref(tv), C.byref(iv), C.byref(h))
+        else:
+            rc = self.L.sd_search_create(ctx.device_index, C.byref(p), C.byref(tv), C.byref(h))
         if rc != 0:
             raise _lib.SdError('sd_search_create failed (%d)' % rc)
         self.h = h

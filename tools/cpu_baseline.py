@@ -26,6 +26,8 @@ def main():
     ap.add_argument('--seconds', type=float, default=15.0)
     ap.add_argument('--threads', type=int, default=16)
     ap.add_argument('--entries', default='')
+    ap.add_argument('--check', type=int, default=0, help='also return the reference rows / alignments of this many sample queries')
+    ap.add_argument('--check-out', default='')
     a = ap.parse_args()
     os.environ['OMP_NUM_THREADS'] = str(a.threads)
     from oracle import pyoracle
@@ -100,20 +102,44 @@ def main():
     if a.entries and os.path.exists(a.entries):
         g = np.load(a.entries)
         orc2 = pyoracle.Oracle(1)
+        refch = pyoracle.RefClusterHits() if pyoracle.ref_ch_available() else None
         t1 = time.time()
         for e in range(min(len(g['eo']) - 1, 6)):
             x0, x1 = int(g['eo'][e]), int(g['eo'][e + 1])
-            pyoracle.oracle_clusterhits(orc2, g['qp'][x0:x1], g['tp'][x0:x1], g['sd'][x0:x1], np.full(x1 - x0, 1e-30), int(g['nq'][e]))
+            if refch is not None:   # the reference's own clusterhits functions (oracle/_ref/libsdref_ch.so)
+                refch.entry(g['qp'][x0:x1], g['tp'][x0:x1], g['sd'][x0:x1], np.full(x1 - x0, 1e-30), int(g['nq'][e]))
+            else:
+                pyoracle.oracle_clusterhits(orc2, g['qp'][x0:x1], g['tp'][x0:x1], g['sd'][x0:x1], np.full(x1 - x0, 1e-30), int(g['nq'][e]))
             ch_n += 1
         ch_per_entry = (time.time() - t1) / max(ch_n, 1)
     sec_per_pair = (queries_per_pair / q_per_s if q_per_s > 0 else float('inf')) + ch_per_entry / n_threads
+    # parity sample for bench.py's post-check: the reference's prefilter rows and alignments of a few sample queries
+    if a.check > 0 and a.check_out and kind == 'reference':
+        rpf = rix.prefilter(max_len + 2, max_hits=a.max_seqs)
+        sw = pyoracle.RefSW(ref, max_len + 2, db_res)
+        qs, rows, alns = [], [], []
+        for qi in sample[:a.check]:
+            qi = int(qi)
+            seq = blob[int(ps.offsets[qi]):int(ps.offsets[qi + 1])]
+            ids, sc, dg, _ = rpf.query(seq, qi)
+            keep = (lens[ids].astype(np.float32) / np.float32(lens[qi])) >= np.float32(0.8)   # the writer's coverage pre-filter
+            ids, sc, dg = ids[keep], sc[keep], dg[keep]
+            qs.append(qi)
+            rows.append(np.stack([ids.astype(np.int64), sc.astype(np.int64), dg.astype(np.int64)], 1))
+            sw.set_query(seq)
+            for t in ids[:12]:
+                t = int(t)
+                r = sw.align(blob[int(ps.offsets[t]):int(ps.offsets[t + 1])], identity=(t == qi))
+                alns.append([qi, t, r['score'], r['qStart'], r['qEnd'], r['tStart'], r['tEnd'], r['btLen'], r['identical'] if r['btLen'] > 0 else 0])
+        np.savez(a.check_out, queries=np.array(qs, np.int64), row_off=np.cumsum([0] + [len(r) for r in rows]),
+                 rows=np.concatenate(rows) if rows else np.zeros((0, 3), np.int64), alns=np.array(alns, np.int64).reshape(-1, 9))
     print(json.dumps(dict(
         value=1.0 / sec_per_pair if sec_per_pair > 0 else 0.0, unit='genome-pairs/s', cores=n_threads, kind=kind,
         sample='%d query proteins: prefilter + SW against the full %d-proteome target with %d threads in %.1f s, plus %d '
                'clusterhits entries (oracle restatement, 1 core each); reference index build %.1f s not included'
                % (nq, P, n_threads, dt, ch_n, t_index),
         queries_per_s=q_per_s, sw_gcups=ncells / dt / 1e9 if dt > 0 else 0.0, sw_pairs=npairs,
-        clusterhits_s_per_entry_core=ch_per_entry)))
+        clusterhits_s_per_entry_core=ch_per_entry, clusterhits_kind='reference' if (a.entries and pyoracle.ref_ch_available()) else 'port')))
 
 
 if __name__ == '__main__':
