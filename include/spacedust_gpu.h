@@ -163,6 +163,9 @@ void sd_target_destroy(sd_target *t);
  *   qDiagBias: per residue int8 of UngappedAlignment.cpp:392-396
  *   identityId[q]: index of the query in the target DB or UINT32_MAX
  * outHits: nQ * maxHitsPerQuery slots (row q at q*maxHitsPerQuery), outCount[nQ].
+ * outCount[q] == UINT32_MAX marks a query that was NOT computed: it needs a reference route the device lacks (a second
+ * overflow of the hit buffer, QueryMatcher.cpp:289-303, or >= 2^24 index hits); its row is empty, the other queries of the
+ * call are computed normally and sd_last_error() names the count.  Callers must treat such rows as errors, not as "no hits".
  * stats (nullable, 4*nQ u64): #similar k-mers, #index entries, #diagonals scored, sum of diagonal lengths. */
 int sd_prefilter_batch(sd_ctx *ctx, const sd_target *target, const sd_prefilter_params *par, uint32_t nQ,
                        const uint8_t *qResidues, const uint64_t *qOffsets, const int16_t *qKmerBias,
@@ -435,7 +438,8 @@ int sd_search_result_write_tsv(sd_search_result *r, const char *path, const char
                                uint64_t firstClusterKey, uint64_t *nClusterLines, uint64_t *nHitLines);
 void sd_search_result_destroy(sd_search_result *r);
 /* accumulated since create: stats[16] = similar k-mers, index hits, diagonals, diagonal length, prefilter hits, pairs,
- * forward / reverse / traceback cells, index entries, masked residues, k, k-mer threshold, bin size, 0, 0;
+ * forward / reverse / traceback cells, index entries, masked residues, k, k-mer threshold, bin size, queries not computed
+ * (per-query error slots of sd_prefilter_batch; sd_search_last_error says why -- a caller must not take their empty rows for results), 0;
  * seconds[16] = index build, upload, bias, prefilter, pair list, seqset, align, aggregate (waiting), aggregate (busy),
  * clusterhits, waiting for the prefilter, total of the last stream, 0... */
 int sd_search_stats(sd_search *s, uint64_t *stats, double *seconds);

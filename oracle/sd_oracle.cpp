@@ -45,11 +45,10 @@ struct OracleTarget {
 // ungapped diagonal score (M/src/prefiltering/UngappedAlignment.cpp:30-43,416-430)
 // prof: int8 [L][21]
 // ------------------------------------------------------------------------------------------
-int diagScore(const int8_t *prof, int qL, const uint8_t *t, int tL, uint16_t diag16) {
-    const int d = (int16_t) diag16;
-    const unsigned short minDist = (unsigned short) std::min((unsigned short) (0 - diag16), (unsigned short) (diag16 - 0));
+// one real diagonal (computeSingelSequenceScores, UngappedAlignment.cpp:416-430)
+int diagScoreReal(const int8_t *prof, int qL, const uint8_t *t, int tL, int diagonal, unsigned int minDist) {
     int maxv = 0, score = 0;
-    if (d >= 0 && (int) minDist < qL) {
+    if (diagonal >= 0 && minDist < (unsigned int) qL) {
         int n = std::min(tL, qL - (int) minDist);
         const int8_t *p = prof + (size_t) minDist * ALPH;
         for (int pos = 0; pos < n; pos++) {
@@ -57,7 +56,7 @@ int diagScore(const int8_t *prof, int qL, const uint8_t *t, int tL, uint16_t dia
             score = score < 0 ? 0 : score;
             maxv = score > maxv ? score : maxv;
         }
-    } else if (d < 0 && (int) minDist < tL) {
+    } else if (diagonal < 0 && minDist < (unsigned int) tL) {
         int n = std::min(tL - (int) minDist, qL);
         const uint8_t *tt = t + minDist;
         for (int pos = 0; pos < n; pos++) {
@@ -67,6 +66,30 @@ int diagScore(const int8_t *prof, int qL, const uint8_t *t, int tL, uint16_t dia
         }
     }
     return maxv;
+}
+
+// scoreSingleSequence (UngappedAlignment.cpp:437-447): with 32 768 residues or more on either side the 16-bit diagonal
+// is ambiguous and computeLongScore (:312-329) takes the best of every real diagonal it can stand for.
+// NOT restated: the reference's batched route for DIAGONALBINSIZE hits on one diagonal (:235-300) looks up
+// hits[hitIdx] where it means hits[seqs[hitIdx].id] (:290), so a target of >= 32 768 residues that falls into a full
+// batch of eight is scored as another sequence of the batch (0 when that one is short).  Oracle and device score the
+// sequence itself; tests/golden/long_vectors.npz keeps no diagonal with eight hits.
+int diagScore(const int8_t *prof, int qL, const uint8_t *t, int tL, uint16_t diag16) {
+    if (qL >= 32768 || tL >= 32768) {
+        int total = 0;
+        for (unsigned int div = 1; div <= 1 + (unsigned int) tL / 32768; div++) {
+            const int real = (int) diag16 - (int) div * 65536;
+            total = std::max(total, diagScoreReal(prof, qL, t, tL, real, (unsigned int) std::abs(real)));
+        }
+        for (unsigned int div = 0; div <= (unsigned int) qL / 65536; div++) {
+            const int real = (int) diag16 + (int) div * 65536;
+            total = std::max(total, diagScoreReal(prof, qL, t, tL, real, (unsigned int) std::abs(real)));
+        }
+        return total;
+    }
+    const int d = (int16_t) diag16;
+    const unsigned short minDist = (unsigned short) std::min((unsigned short) (0 - diag16), (unsigned short) (diag16 - 0));
+    return diagScoreReal(prof, qL, t, tL, d, minDist);
 }
 
 struct Cand {

@@ -214,6 +214,9 @@ class Context:
     def synchronize(self):
         _check(self.h, self.L.sd_synchronize(self.h), 'sd_synchronize')
 
+    def last_error(self):
+        return self.L.sd_last_error(self.h).decode(errors='replace')
+
     def profile(self, on=True):
         self.L.sd_profile_enable(self.h, 1 if on else 0)
         self.L.sd_profile_reset(self.h)

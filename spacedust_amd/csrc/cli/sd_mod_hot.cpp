@@ -174,7 +174,7 @@ int prefilterModule(const Args &a) {
     std::vector<int16_t> kmerBias;
     std::vector<uint64_t> off;
     std::string text;
-    uint64_t totalHits = 0;
+    uint64_t totalHits = 0, notComputed = 0;
     for (uint32_t c0 = 0; c0 < qdb->n; c0 += chunk) {
         const uint32_t c1 = std::min(qdb->n, c0 + chunk), nq = c1 - c0;
         const uint64_t r0 = qdb->offsets[c0], r1 = qdb->offsets[c1];
@@ -209,6 +209,11 @@ int prefilterModule(const Args &a) {
         char line[64];
         for (uint32_t i = 0; i < nq; i++) {
             text.clear();
+            if (counts[i] == UINT32_MAX) {   // per-query error slot of sd_prefilter_batch: not computed
+                if (notComputed < 5) fprintf(stderr, "sdgpu prefilter: query %u was not computed: %s\n", qdb->keys[c0 + i], sd_last_error(ctx.c));
+                notComputed++;
+                counts[i] = 0;
+            }
             const sd_hit *row = hits.data() + (size_t) i * par.maxHitsPerQuery;
             for (uint32_t x = 0; x < counts[i]; x++) {
                 const int len = snprintf(line, sizeof(line), "%u\t%d\t%d\n", tdb->keys[row[x].seqId], row[x].score,
@@ -221,6 +226,9 @@ int prefilterModule(const Args &a) {
     }
     if (!out.close(&err)) return fail(err);
     info(a, "%llu prefilter hits written for %u queries\n", (unsigned long long) totalHits, qdb->n);
+    if (notComputed)
+        return fail(std::to_string(notComputed) + " queries need the reference's double-overflow route (or have >= 2^24 index hits) and were "
+                    "written as empty entries; every other entry is complete");
     return 0;
 }
 

@@ -345,7 +345,9 @@ int runSearch(const Args &a, bool withClusters) {
     sd_search_stats(S.s, st, tm);
     info(a, "%llu prefilter hits, %llu pairs aligned; prefilter %.2f s | align %.2f s | aggregate %.2f s | clusterhits %.2f s | total %.2f s\n",
          (unsigned long long) st[4], (unsigned long long) st[5], tm[3], tm[6], tm[8], tm[9], tm[11]);
-    if (!withClusters) return 0;
+    const uint64_t notComputed = st[14];
+    if (notComputed) fprintf(stderr, "sdgpu %s: %s\n", a.module.c_str(), sd_search_last_error(S.s));
+    if (!withClusters) return notComputed ? 1 : 0;
 
     // summarizeresults: this rank's part, then rank 0 concatenates in rank order
     std::string qn, tn, qsrc, tsrc;
@@ -421,7 +423,7 @@ int runSearch(const Args &a, bool withClusters) {
             }
         }
     }
-    return 0;
+    return notComputed ? 1 : 0;
 }
 
 }  // namespace

@@ -609,6 +609,8 @@ __global__ void query_hit_base_kernel(uint32_t nQ, const uint64_t *__restrict__ 
     if (q <= nQ) qHitBase[q] = hitBase[kmerBase[posBase[q]]];
 }
 
+constexpr uint32_t QUERY_UNSUPPORTED = 0xFFFFFFFEu;   // qSplit marker: the query needs a reference path the device lacks
+
 // where the reference's hit buffer (cap entries) overflows inside query q: the k-mer list that would fill it
 // (inBuffer + listSize >= cap) starts the second part; a second overflow is flagged (not implemented)
 __global__ void query_split_kernel(uint32_t nQ, const uint64_t *__restrict__ posBase, const uint64_t *__restrict__ kmerBase,
@@ -619,8 +621,8 @@ __global__ void query_split_kernel(uint32_t nQ, const uint64_t *__restrict__ pos
     const uint64_t k0 = kmerBase[posBase[q]], k1 = kmerBase[posBase[q + 1]];
     const uint64_t h0 = hitBase[k0], total = hitBase[k1] - h0;
     uint32_t split = 0xFFFFFFFFu;
-    if (total >= (1ull << 24)) atomicExch(flag, 1);   // stream positions are carried in 24 bits
-    if (total >= cap) {
+    bool unsupported = total >= (1ull << 24);   // stream positions are carried in 24 bits
+    if (!unsupported && total >= cap) {
         // first k in [k0, k1) with hitBase[k + 1] - h0 >= cap
         uint64_t lo = k0, hi = k1;
         while (lo < hi) {
@@ -629,9 +631,22 @@ __global__ void query_split_kernel(uint32_t nQ, const uint64_t *__restrict__ pos
             else lo = mid + 1;
         }
         split = (uint32_t) (hitBase[lo] - h0);
-        if (total - split >= cap) atomicExch(flag, 1);
+        if (total - split >= cap) unsupported = true;   // a second overflow of the hit buffer (QueryMatcher.cpp:289-303)
+    }
+    if (unsupported) {
+        atomicExch(flag, 1);
+        split = QUERY_UNSUPPORTED;
     }
     qSplit[q] = split;
+}
+
+// queries marked QUERY_UNSUPPORTED take no part in the rest of the batch: their index lists are emptied
+__global__ void __launch_bounds__(256)
+drop_query_kmers_kernel(uint64_t nKmers, const uint32_t *__restrict__ kPos, const uint32_t *__restrict__ qSplit,
+                        uint32_t *__restrict__ kLen) {
+    const uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nKmers) return;
+    if (kLen[k] && qSplit[kPos[k] >> 16] == QUERY_UNSUPPORTED) kLen[k] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1123,33 +1138,61 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
     const int d = (int) (int16_t) d16;
     const int qL = (int) (qOff[q + 1] - qOff[q]);
     const int tL = (int) (tOff[sid + 1] - tOff[sid]);
-    const uint16_t minDist = (uint16_t) min((int) (uint16_t) (0 - d16), (int) (uint16_t) d16);
     const uint8_t *qs = qRes + qOff[q];
     const int8_t *qb = diagBias + qOff[q];
     const uint8_t *ts = tMasked + tOff[sid];
-    int n = 0, q0 = 0, t0 = 0;
-    if (d >= 0 && (int) minDist < qL) {
-        n = min(tL, qL - (int) minDist);
-        q0 = minDist;
-    } else if (d < 0 && (int) minDist < tL) {
-        n = min(tL - (int) minDist, qL);
-        t0 = minDist;
-    }
-    int score = 0, best = 0;
-    if (qProf) {   // profile query: the row of the position replaces matrix row + bias
-        const int8_t *qp = qProf + (qOff[q] + (uint64_t) q0) * 21;
-        for (int x = 0; x < n; x++) {
-            score += (int) qp[(size_t) x * 21 + ts[t0 + x]];
-            score = score < 0 ? 0 : score;
-            best = score > best ? score : best;
+    const int8_t *qpBase = qProf ? qProf + qOff[q] * 21 : nullptr;
+    // computeSingelSequenceScores (UngappedAlignment.cpp:416-430) on one real diagonal
+    auto scoreOn = [&](int diagonal, unsigned dist, int &nOut) {
+        int n = 0, q0 = 0, t0 = 0;
+        if (diagonal >= 0 && dist < (unsigned) qL) {
+            n = min(tL, qL - (int) dist);
+            q0 = (int) dist;
+        } else if (diagonal < 0 && dist < (unsigned) tL) {
+            n = min(tL - (int) dist, qL);
+            t0 = (int) dist;
+        }
+        int score = 0, best = 0;
+        if (qpBase) {   // profile query: the row of the position replaces matrix row + bias
+            const int8_t *qp = qpBase + (size_t) q0 * 21;
+            for (int x = 0; x < n; x++) {
+                score += (int) qp[(size_t) x * 21 + ts[t0 + x]];
+                score = score < 0 ? 0 : score;
+                best = score > best ? score : best;
+            }
+        } else {
+            for (int x = 0; x < n; x++) {
+                const int qr = qs[q0 + x];
+                score += (int) (int8_t) (smat[qr * 21 + ts[t0 + x]] + qb[q0 + x]);
+                score = score < 0 ? 0 : score;
+                best = score > best ? score : best;
+            }
+        }
+        nOut = n;
+        return best;
+    };
+    int n = 0, best = 0;
+    if (qL >= 32768 || tL >= 32768) {
+        // computeLongScore (UngappedAlignment.cpp:312-329): the 16-bit diagonal of a sequence this long is ambiguous, so
+        // every real diagonal it can stand for is scored (d16 - 65536 * {1 .. 1 + tL / 32768}, d16 + 65536 * {0 .. qL /
+        // 65536}) and the best one kept (cLen, a work statistic, counts all of them)
+        for (int dv = 1; dv <= 1 + tL / 32768; dv++) {
+            const int real = (int) d16 - dv * 65536;
+            int nn;
+            const int sc = scoreOn(real, (unsigned) abs(real), nn);
+            best = sc > best ? sc : best;
+            n += nn;
+        }
+        for (int dv = 0; dv <= qL / 65536; dv++) {
+            const int real = (int) d16 + dv * 65536;
+            int nn;
+            const int sc = scoreOn(real, (unsigned) abs(real), nn);
+            best = sc > best ? sc : best;
+            n += nn;
         }
     } else {
-        for (int x = 0; x < n; x++) {
-            const int qr = qs[q0 + x];
-            score += (int) (int8_t) (smat[qr * 21 + ts[t0 + x]] + qb[q0 + x]);
-            score = score < 0 ? 0 : score;
-            best = score > best ? score : best;
-        }
+        const uint16_t minDist = (uint16_t) min((int) (uint16_t) (0 - d16), (int) (uint16_t) d16);
+        best = scoreOn(d, minDist, n);
     }
     cScore[c] = best;
     cLen[c] = (uint32_t) n;
@@ -1650,6 +1693,10 @@ int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, con
     if (!ctx || !out || !kmerOffsets || !maskedResidues || !seqOffsets || !ext3Score || !ext3Index) return SD_EINVAL;
     if (kmerSize != 6 && kmerSize != 7) return sdFail(ctx, SD_EUNSUPPORTED, "k=%d: the device implements k=6 and k=7", kmerSize);
     if (kmerSize == 7 && (!ext2Score || !ext2Index)) return sdFail(ctx, SD_EINVAL, "k=7 needs the 2-mer score matrix");
+    for (uint32_t i = 0; i < nSeq; i++)
+        if (seqOffsets[i + 1] - seqOffsets[i] > 65535)
+            return sdFail(ctx, SD_EINVAL, "target %u has %llu residues; index positions are 16 bit (limit 65535, --max-seq-len)", i,
+                          (unsigned long long) (seqOffsets[i + 1] - seqOffsets[i]));
     (void) hipSetDevice(ctx->device);
     sd_target *t = new sd_target();
     t->ctx = ctx;
@@ -1736,6 +1783,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
     SD_HIP(ctx, dErr.alloc(1));
     DevBuf<uint8_t> scanTmp, sortTmp;
 
+    for (uint32_t x = 0; x < nQ; x++)
+        if (qOffsets[x + 1] - qOffsets[x] > 65535)
+            return sdFail(ctx, SD_EINVAL, "query %u has %llu residues; k-mer positions are 16 bit (limit 65535, --max-seq-len)", x,
+                          (unsigned long long) (qOffsets[x + 1] - qOffsets[x]));
     uint32_t qBeg = 0;
     uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 4096);   // ~0.6 G hits per sub-batch on a proteome-scale target DB: larger sorts were measured 4x slower per item
     if (const char *e = getenv("SD_PF_BATCH")) batchQ = std::max<uint32_t>(1, std::min<uint32_t>(maxBatchQ, (uint32_t) atoi(e)));
@@ -1903,9 +1954,33 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, hipMemcpyAsync(&hSplitFlag, dSplitFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(hStats.data(), dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, sdStreamSync(ctx));
-        if (hSplitFlag)
-            return sdFail(ctx, SD_EUNSUPPORTED, "a query of the batch [%u, %u) overflows the reference's hit buffer twice (or has >= 2^24 index hits): "
-                          "the double-overflow route of QueryMatcher.cpp:289-303 is not implemented", qBeg, qBeg + bq);
+        std::vector<uint8_t> hUnsupported;
+        if (hSplitFlag) {
+            // Queries that overflow the reference's hit buffer twice (the double-overflow route of QueryMatcher.cpp:289-303) or
+            // have >= 2^24 index hits cannot be computed here.  They are taken out of the batch -- their index lists emptied,
+            // offsets re-scanned -- and reported per query (outCount = UINT32_MAX); every other query is computed as usual.
+            std::vector<uint32_t> hSplit(bq);
+            SD_HIP(ctx, hipMemcpy(hSplit.data(), dQSplit.p, (size_t) bq * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            hUnsupported.assign(bq, 0);
+            uint32_t nBad = 0, firstBad = 0;
+            for (uint32_t x = 0; x < bq; x++)
+                if (hSplit[x] == QUERY_UNSUPPORTED) {
+                    hUnsupported[x] = 1;
+                    if (!nBad) firstBad = qBeg + x;
+                    nBad++;
+                }
+            sdFail(ctx, SD_EUNSUPPORTED, "%u quer%s of the batch [%u, %u) (first: %u) overflow the reference's hit buffer twice or have >= 2^24 index "
+                   "hits (double-overflow route of QueryMatcher.cpp:289-303): reported with outCount = UINT32_MAX, the rest of the batch is computed",
+                   nBad, nBad == 1 ? "y" : "ies", qBeg, qBeg + bq, firstBad);
+            hipLaunchKernelGGL(drop_query_kmers_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKPos.p, dQSplit.p, dKLen.p);
+            int rc2 = exclusiveScanWiden(ctx, dKLen.p, dHitBase.p, nKmers + 1, scanTmp);
+            if (rc2 != SD_OK) return rc2;
+            SD_HIP(ctx, hipMemcpyAsync(&nHits, dHitBase.p + nKmers, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipMemsetAsync(dSplitFlag.p, 0, sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(query_split_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
+                               dHitBase.p, maxDbMatches, dQSplit.p, dSplitFlag.p);
+            SD_HIP(ctx, sdStreamSync(ctx));
+        }
 
         hs.reset(new HostScope(ctx, "pf.gather_sort_match"));
         uint32_t nCand = 0, nKept = 0;
@@ -2205,6 +2280,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         for (uint32_t x = 0; x < bq; x++)
             memcpy(outHits + (size_t) (qBeg + x) * par->maxHitsPerQuery, hOutP + (size_t) x * maxHits,
                    (size_t) std::min<uint32_t>(outCount[qBeg + x], maxHits) * sizeof(sd_hit));
+        for (uint32_t x = 0; x < (uint32_t) hUnsupported.size(); x++)
+            if (hUnsupported[x]) outCount[qBeg + x] = UINT32_MAX;   // per-query error slot: not computed (see above)
         hs.reset();
         qBeg += bq;
     }

@@ -211,7 +211,25 @@ struct TbTask {
 // exclusive prefix maximum across lanes (cross-lane scan, carried between 32-cell chunks).  Directions are
 // packed to one byte per cell (bit0 dirE==3, bit1 dirF==5, bits2-3: 0 diag / 1 take dirE / 2 take dirF) and
 // written row-major (coalesced); lane 0 then walks the path.
-template <bool PROF>
+// GLOBAL: bands beyond the LDS classes (2*band+3 > 2047: a gap of > 1 000 residues inside the alignment) keep the three
+// band arrays in global scratch in front of the task's direction bytes; the lanes of the half wavefront exchange them
+// through agent-scope accesses with a fence where the LDS version has a wave barrier.  Rare and slow by design --
+// what matters is that the reference's do/while (band doubling, :1492-1493) has no width the device refuses.
+template <bool GLOBAL> __device__ __forceinline__ int bandLd(const int32_t *p) {
+    if constexpr (GLOBAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool GLOBAL> __device__ __forceinline__ void bandSt(int32_t *p, int v) {
+    if constexpr (GLOBAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool GLOBAL> __device__ __forceinline__ void bandSync() {
+    if constexpr (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __builtin_amdgcn_wave_barrier();
+}
+__host__ __device__ __forceinline__ uint64_t tbGlobalIntBytes(int band) { return ((uint64_t) 3 * (2 * (uint64_t) band + 4) * 4 + 15) & ~15ull; }
+
+template <bool PROF, bool GLOBAL = false>
 __global__ void __launch_bounds__(64)
 sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                     const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
@@ -234,27 +252,40 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
     else { tk.qLen = 0; tk.tLen = 0; tk.band = 1; tk.score = 0; tk.maxv = 0; tk.qAbs = 0; tk.tAbs = 0; tk.slot = 0; tk.dirOff = 0; tk.btOff = 0; }
     const int qLen = tk.qLen, tLen = tk.tLen;
     int band = tk.band;
-    int32_t *h_b = lds + (size_t) grp * 3 * ldsStride;
-    int32_t *e_b = h_b + ldsStride;
-    int32_t *h_c = e_b + ldsStride;
+    int32_t *h_b, *e_b, *h_c;
+    int8_t *direction;
+    if constexpr (GLOBAL) {   // one attempt at the task's band per launch: [3 x (width + 1) ints][direction bytes]
+        const int stride = band * 2 + 4;
+        h_b = reinterpret_cast<int32_t *>(dirs + tk.dirOff);
+        e_b = h_b + stride;
+        h_c = e_b + stride;
+        direction = dirs + tk.dirOff + tbGlobalIntBytes(band);
+    } else {
+        h_b = lds + (size_t) grp * 3 * ldsStride;
+        e_b = h_b + ldsStride;
+        h_c = e_b + ldsStride;
+        direction = dirs + tk.dirOff;
+    }
     const uint8_t *q = qRes + tk.qAbs;
     const int8_t *cb = qBias + tk.qAbs;
     const uint8_t *t = tRes + tk.tAbs;
-    int8_t *direction = dirs + tk.dirOff;
     int maxv = tk.maxv;
     int width, width_d;
   for (;;) {
     width = band * 2 + 3;
     width_d = band * 2 + 1;
-    for (int x = l; x <= width && x < ldsStride; x += 32) { h_b[x] = 0; e_b[x] = 0; h_c[x] = 0; }
-    __builtin_amdgcn_wave_barrier();
+    for (int x = l; x <= width && x < ldsStride; x += 32) { bandSt<GLOBAL>(h_b + x, 0); bandSt<GLOBAL>(e_b + x, 0); bandSt<GLOBAL>(h_c + x, 0); }
+    bandSync<GLOBAL>();
     for (int i = 0; i < qLen; i++) {
         int beg = 0, end = tLen - 1;
         int jj = i - band; beg = beg > jj ? beg : jj;
         jj = i + band; end = end < jj ? end : jj;
         const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
-        if (l == 0) { h_b[0] = 0; e_b[0] = 0; h_b[edge] = 0; e_b[edge] = 0; h_c[0] = 0; }
-        __builtin_amdgcn_wave_barrier();
+        if (l == 0) {
+            bandSt<GLOBAL>(h_b, 0); bandSt<GLOBAL>(e_b, 0); bandSt<GLOBAL>(h_b + edge, 0); bandSt<GLOBAL>(e_b + edge, 0);
+            bandSt<GLOBAL>(h_c, 0);
+        }
+        bandSync<GLOBAL>();
         const int xi = (i - band) > 0 ? (i - band) : 0;
         const int xim = (i - 1 - band) > 0 ? (i - 1 - band) : 0;
         const int W = end - beg + 1;
@@ -271,12 +302,12 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
             bool dirE = false;
             if (valid) {
                 const int e = j - xim + 1, d = (j - 1) - xim + 1;
-                int t1 = i == 0 ? -go : h_b[e] - go;
-                int t2 = i == 0 ? -ge : e_b[e] - ge;
+                int t1 = i == 0 ? -go : bandLd<GLOBAL>(h_b + e) - go;
+                int t2 = i == 0 ? -ge : bandLd<GLOBAL>(e_b + e) - ge;
                 eNew = t1 > t2 ? t1 : t2;
                 dirE = t1 > t2;
                 e1 = eNew > 0 ? eNew : 0;
-                diag = h_b[d] + mrow[t[j]] + cbi;
+                diag = bandLd<GLOBAL>(h_b + d) + mrow[t[j]] + cbi;
                 T = e1 > diag ? e1 : diag;
                 S = T - go + ge * (p + 1);
             }
@@ -301,8 +332,8 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
                 int code = (dirE ? 1 : 0) | (dirF ? 2 : 0);
                 if (!(tmp1 <= diag)) code |= (e1 > f1) ? 4 : 8;
                 dl[j - xi] = (int8_t) code;
-                e_b[u] = eNew;
-                h_c[u] = hcv;
+                bandSt<GLOBAL>(e_b + u, eNew);
+                bandSt<GLOBAL>(h_c + u, hcv);
                 maxv = hcv > maxv ? hcv : maxv;
             }
             // carries to the next chunk
@@ -312,12 +343,13 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
             prevF = __shfl(f, 31, 32);
             const int lastValid = (W - p0) < 32 ? (W - p0 - 1) : 31;
             uLast = (beg + p0 + lastValid) - xi + 1;
-            __builtin_amdgcn_wave_barrier();
+            if constexpr (!GLOBAL) __builtin_amdgcn_wave_barrier();   // (GLOBAL: a lane only re-reads what other lanes wrote after the row's fence)
         }
+        bandSync<GLOBAL>();
         if (W > 0) {
-            for (int x = 1 + l; x <= uLast; x += 32) h_b[x] = h_c[x];
+            for (int x = 1 + l; x <= uLast; x += 32) bandSt<GLOBAL>(h_b + x, bandLd<GLOBAL>(h_c + x));
         }
-        __builtin_amdgcn_wave_barrier();
+        bandSync<GLOBAL>();
     }
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) {
@@ -883,7 +915,7 @@ k_gate_rev(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ
 }
 
 // traceback task classes: N_TB_NARROW register-band classes by query rows, then three LDS-band classes by band width
-// (<=127, <=511, <=2047)
+// (<=127, <=511, <=2047) and the global-band class for everything wider
 // The register-band kernel keeps a task's direction codes (16 B per row), query / bias / target slices in LDS, and
 // it is latency bound, so its throughput is its occupancy: classes by query rows keep the LDS request close to what
 // the tasks need (a band <= 14 means |tLen - qLen| <= 13, so qCap + 16 target columns always suffice).
@@ -898,20 +930,22 @@ __device__ __forceinline__ uint32_t tbKey(int band, int qLen, int tLen) {
         ci = 0;
         while (qLen > c_tbNarrowQ[ci]) ci++;
     } else {
-        ci = N_TB_NARROW + (w <= 127 ? 0 : (w <= 511 ? 1 : 2));
+        ci = N_TB_NARROW + (w <= 127 ? 0 : (w <= 511 ? 1 : (w <= 2047 ? 2 : 3)));
     }
     const unsigned long long work = (unsigned long long) ((2 * band + 1 + 31) / 32) * (unsigned long long) qLen;
     return (uint32_t) ci * 4096u + (uint32_t) (4095 - (int) min(work >> 3, 4095ull));
 }
-constexpr uint32_t N_TB_CLASSES = N_TB_NARROW + 3;
+constexpr uint32_t N_TB_CLASSES = N_TB_NARROW + 4;   // + the global-band class (w > 2047)
 constexpr uint32_t TBKEY_INVALID = N_TB_CLASSES * 4096u;
 // global direction scratch (LDS-band kernel only), sized for the widest band of the task's class because the
 // kernel keeps doubling the band inside its class
 __device__ __forceinline__ uint64_t tbDirBytes(int band, int qLen, int tLen) {
     if (tbNarrow(band, qLen, tLen)) return 0ull;
     const int w = band * 2 + 3;
+    if (w > 2047)   // global-band class: one attempt per round at exactly this band, band arrays in front of the directions
+        return (tbGlobalIntBytes(band) + (uint64_t) (w - 2) * (uint64_t) qLen + 31) & ~15ull;
     const int wMax = w <= 127 ? 127 : (w <= 511 ? 511 : 2047);
-    return (uint64_t) (wMax - 2) * (uint64_t) qLen + 16;
+    return ((uint64_t) (wMax - 2) * (uint64_t) qLen + 31) & ~15ull;   // multiples of 16: every task's region stays aligned
 }
 
 // start positions (:475-476), second coverage gate (:483-489) and traceback tasks
@@ -976,7 +1010,9 @@ k_tb_collect(uint32_t nPairs, uint32_t *__restrict__ keys, uint32_t *__restrict_
     const int len = tbRes[2 * i];
     if (len == -2) {
         const int band = tb[i].band;   // already doubled by the kernel that gave up
-        if (band * 2 + 3 > maxBand) { atomicExch(errFlag, 3); keys[i] = TBKEY_INVALID; dirBytes[i] = 0; return; }
+        // the full rectangle is inside the band once band >= max(qLen, tLen): a task that still misses its score then is
+        // a traceback error, not a reason to double again
+        if (band > maxBand) { atomicExch(errFlag, 2); keys[i] = TBKEY_INVALID; dirBytes[i] = 0; return; }
         keys[i] = tbKey(band, tb[i].qLen, tb[i].tLen);
         dirBytes[i] = tbDirBytes(band, tb[i].qLen, tb[i].tLen);
     } else if (len < 0) {
@@ -1358,6 +1394,10 @@ int sd_profile_names(sd_ctx *ctx, char *buf, size_t cap) {
 int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offsets, uint32_t n, const int8_t *swCompBias,
                      sd_seqset **out) {
     if (!ctx || !residues || !offsets || !out) return SD_EINVAL;
+    for (uint32_t i = 0; i < n; i++)
+        if (offsets[i + 1] - offsets[i] > 65535)
+            return sdFail(ctx, SD_EINVAL, "sequence %u has %llu residues; the limit is 65535 (--max-seq-len)", i,
+                          (unsigned long long) (offsets[i + 1] - offsets[i]));
     (void) hipSetDevice(ctx->device);
     sd_seqset *s = new sd_seqset();
     s->ctx = ctx;
@@ -1625,8 +1665,8 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         if (getenv("SD_DEBUG_TB")) {
             fprintf(stderr, "[tb] round %d: narrow", round);
             for (int ci = 0; ci < N_TB_NARROW; ci++) fprintf(stderr, " %u", hb[ci + 1] - hb[ci]);
-            fprintf(stderr, " lds %u %u %u dir %.1f MB\n", hb[N_TB_NARROW + 1] - hb[N_TB_NARROW], hb[N_TB_NARROW + 2] - hb[N_TB_NARROW + 1],
-                    hb[N_TB_NARROW + 3] - hb[N_TB_NARROW + 2], dirTotal / 1e6);
+            fprintf(stderr, " lds %u %u %u global %u dir %.1f MB\n", hb[N_TB_NARROW + 1] - hb[N_TB_NARROW], hb[N_TB_NARROW + 2] - hb[N_TB_NARROW + 1],
+                    hb[N_TB_NARROW + 3] - hb[N_TB_NARROW + 2], hb[N_TB_NARROW + 4] - hb[N_TB_NARROW + 3], dirTotal / 1e6);
         }
         if (dirTotal > SCRATCH_BUDGET) return sdFail(ctx, SD_ENOMEM, "traceback direction scratch of %llu bytes exceeds the budget; use smaller batches", (unsigned long long) dirTotal);
         int8_t *dDir = nullptr;
@@ -1665,9 +1705,23 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
                                    queries->dBias, targets->dRes, dMat, go, ge, ldsStride, dDir, dBt, dTbRes, dOrder + begin,
                                    ldsClass[ci] - 1, (const int8_t *) nullptr);
         }
+        {   // bands beyond the LDS classes: band arrays in global scratch, one attempt per round
+            const uint32_t begin = hb[N_TB_NARROW + 3], cnt = hb[N_TB_NARROW + 4] - hb[N_TB_NARROW + 3];
+            if (cnt) {
+                ProfScope ps(ctx, "sw_traceback.global");
+                if (queries->dProf)
+                    hipLaunchKernelGGL((sw_traceback_kernel<true, true>), dim3((cnt + 1) / 2), dim3(64), 0, ctx->stream, dTb, cnt, queries->dRes,
+                                       queries->dBias, targets->dRes, dMat, go, ge, INT_MAX, dDir, dBt, dTbRes, dOrder + begin, 0,
+                                       (const int8_t *) queries->dProf);
+                else
+                    hipLaunchKernelGGL((sw_traceback_kernel<false, true>), dim3((cnt + 1) / 2), dim3(64), 0, ctx->stream, dTb, cnt, queries->dRes,
+                                       queries->dBias, targets->dRes, dMat, go, ge, INT_MAX, dDir, dBt, dTbRes, dOrder + begin, 0,
+                                       (const int8_t *) nullptr);
+            }
+        }
         SD_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_tb_collect, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dVals, dTb, dTbRes, dDirBytes, dBtLen,
-                           dRes, dErr, 2047);
+                           dRes, dErr, 4 * 65536);
     }
     if (getenv("SD_DEBUG_TB")) {   // band statistics of the finished tasks
         std::vector<TbTask> hT(nPairs);
@@ -1699,7 +1753,6 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     SD_HIP(ctx, sdStreamSync(ctx));
     if (hErr[0] == 1) return sdFail(ctx, SD_EMISMATCH, "Score of forward/backward SW differ (fatal in the reference, StripedSmithWaterman.cpp:466-473)");
     if (hErr[0] == 2) return sdFail(ctx, SD_EHIP, "Trace back error");
-    if (hErr[0] == 3) return sdFail(ctx, SD_EUNSUPPORTED, "traceback band exceeds the LDS-resident limit");
     ctx->cellsFwd = hCells[0];
     ctx->cellsRev = hCells[1];
     // identity pairs need pool space too (scoreIdentical backtraces are written by the host below)
@@ -1999,20 +2052,19 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
     // ---- pass 4: banded traceback in chunks that fit the scratch budget
     if (!tb.empty() && btPool == nullptr) return sdFail(ctx, SD_EINVAL, "swMode 2 needs a backtrace pool");
     const uint64_t SCRATCH_BUDGET = 8ull << 30;
-    auto widthClass = [](int band) { int w = band * 2 + 3; return w <= 127 ? 128 : (w <= 511 ? 512 : 2048); };
+    auto widthClass = [](int band) { int w = band * 2 + 3; return w <= 127 ? 128 : (w <= 511 ? 512 : (w <= 2047 ? 2048 : 0)); };   // 0: global-band class
     std::vector<TbTask> pending = tb;
     while (!pending.empty()) {
         for (size_t x = 0; x < pending.size(); x++)
-            if (pending[x].band * 2 + 3 > 2047)
-                return sdFail(ctx, SD_EUNSUPPORTED, "traceback band %d exceeds the LDS-resident limit (pair %u)", pending[x].band, pending[x].slot);
+            if (pending[x].band > 4 * 65536) return sdFail(ctx, SD_EHIP, "Trace back error (pair %u)", pending[x].slot);
         {   // order: LDS width class, then work (row chunks x rows) descending -- stable counting sort
             auto keyOf = [&](const TbTask &t) {
                 const int c = widthClass(t.band);
-                const int ci = c == 128 ? 0 : (c == 512 ? 1 : 2);
+                const int ci = c == 128 ? 0 : (c == 512 ? 1 : (c == 2048 ? 2 : 3));
                 const uint64_t work = (uint64_t) ((2 * t.band + 1 + 31) / 32) * (uint64_t) t.qLen;
                 return (uint32_t) ci * 4096u + (uint32_t) (4095 - std::min<uint64_t>(work >> 3, 4095));
             };
-            std::vector<uint32_t> cnt(3 * 4096 + 1, 0);
+            std::vector<uint32_t> cnt(4 * 4096 + 1, 0);
             for (size_t i = 0; i < pending.size(); i++) cnt[keyOf(pending[i]) + 1]++;
             for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
             std::vector<TbTask> sortedTb(pending.size());
@@ -2028,7 +2080,7 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
             while (end < pending.size() && widthClass(pending[end].band) == cls) {
                 TbTask &t = pending[end];
                 const uint64_t width_d = (uint64_t) t.band * 2 + 1;
-                const uint64_t ad = width_d * (uint64_t) t.qLen + 16, ab = (uint64_t) t.qLen + t.tLen + 2;
+                const uint64_t ad = ((cls ? 0 : tbGlobalIntBytes(t.band)) + width_d * (uint64_t) t.qLen + 31) & ~15ull, ab = (uint64_t) t.qLen + t.tLen + 2;
                 if (end > pos && (nDir + ad) > SCRATCH_BUDGET) break;
                 t.intOff = 0; t.dirOff = nDir; t.btOff = nBt;
                 nDir += ad; nBt += ab;
@@ -2048,9 +2100,14 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
                 ProfScope ps(ctx, "sw_traceback");
                 const int ldsStride = cls + 1;
                 const size_t ldsBytes = (size_t) 2 * 3 * ldsStride * sizeof(int32_t);
-                hipLaunchKernelGGL(sw_traceback_kernel<false>, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dT.p, cnt,
-                                   queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, ldsStride, dDir.p, dBt.p, dRes.p,
-                                   (const uint32_t *) nullptr, 0, (const int8_t *) nullptr);
+                if (cls)
+                    hipLaunchKernelGGL(sw_traceback_kernel<false>, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dT.p, cnt,
+                                       queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, ldsStride, dDir.p, dBt.p, dRes.p,
+                                       (const uint32_t *) nullptr, 0, (const int8_t *) nullptr);
+                else
+                    hipLaunchKernelGGL((sw_traceback_kernel<false, true>), dim3((cnt + 1) / 2), dim3(64), 0, ctx->stream, dT.p, cnt,
+                                       queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, INT_MAX, dDir.p, dBt.p, dRes.p,
+                                       (const uint32_t *) nullptr, 0, (const int8_t *) nullptr);
             }
             SD_HIP(ctx, hipGetLastError());
             TbTask *back = nullptr;

@@ -88,6 +88,10 @@ int sd_host_sw_comp_bias(sd_host *h, int which, const uint8_t *residues, const u
 int sd_host_index_build(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
                         int kmerThr, int mask, double maskProb, sd_host_index **out) {
     if (!out || (kmerSize != 6 && kmerSize != 7)) return SD_EINVAL;
+    // positions in the index are 16 bit (IndexEntryLocal::position_j, M/src/prefiltering/IndexTable.h): sequences beyond
+    // 65 535 residues (--max-seq-len) are the caller's to split, not something to wrap silently
+    for (uint32_t i = 0; i < n; i++)
+        if (offsets[i + 1] - offsets[i] > 65535) return SD_EINVAL;
     sd_host_index *ix = new sd_host_index();
     sd::buildTargetIndex(h->seed8, residues, offsets, n, kmerSize, kmerThr, mask != 0, maskProb, h->threads, ix->idx);
     if (ix->idx.tableSize == 0) {   // more than 2^32 index entries (targets beyond ~4.4e9 residues): 32-bit list offsets in this ABI

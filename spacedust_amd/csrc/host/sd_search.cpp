@@ -105,7 +105,7 @@ struct PfOut {
     std::vector<uint32_t> counts;
     std::vector<uint64_t> stats;   // 4 per query
     std::vector<uint32_t> pairQ, pairT;
-    uint64_t nPairs = 0;
+    uint64_t nPairs = 0, notComputed = 0;
     double tPrefilter = 0, tPairs = 0;
     int rc = SD_OK;
     std::string err;
@@ -113,7 +113,7 @@ struct PfOut {
 
 enum { T_INDEX, T_UPLOAD, T_BIAS, T_PREFILTER, T_PAIRS, T_SEQSET, T_ALIGN, T_AGG_WAIT, T_AGG_BUSY, T_CLUSTERHITS, T_PF_WAIT, T_TOTAL, T_N = 16 };
 enum { S_KMERS, S_INDEX_HITS, S_DIAGONALS, S_DIAG_LEN, S_PREF_HITS, S_PAIRS, S_CELLS_FWD, S_CELLS_REV, S_CELLS_TB, S_ENTRIES, S_MASKED, S_K,
-       S_KMER_THR, S_BIN, S_N = 16 };
+       S_KMER_THR, S_BIN, S_NOT_COMPUTED, S_N = 16 };
 
 }  // namespace
 
@@ -460,6 +460,11 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             o->err = std::string("sd_prefilter_batch: ") + sd_last_error(s->ctxPf);
             return o;
         }
+        for (uint32_t i = 0; i < nq; i++)
+            if (o->counts[i] == UINT32_MAX) {   // per-query error slot of sd_prefilter_batch: counted, reported, never silent
+                o->counts[i] = 0;
+                o->notComputed++;
+            }
         if (s->prefSink) s->prefSink(s->sinkUser, b.c0, nq, o->hits.data(), o->counts.data(), W);
         // pair list in prefilter order (Alignment.cpp:346-379); Alignment::run's coverage pre-check (:370-373) is the test
         // the prefilter already applied
@@ -583,6 +588,10 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             s->stats[S_DIAG_LEN] += d->stats[(size_t) i * 4 + 3];
         }
         s->stats[S_PREF_HITS] += d->nPairs;
+        if (d->notComputed) {
+            s->stats[S_NOT_COMPUTED] += d->notComputed;
+            s->err = std::to_string(s->stats[S_NOT_COMPUTED]) + " queries were not computed: " + sd_last_error(s->ctxPf);
+        }
         prefHitsOfRange[r] += d->nPairs;
         if (d->nPairs > 0) {
             const uint64_t r0 = Q->offsets[c0];

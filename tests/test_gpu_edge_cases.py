@@ -140,3 +140,15 @@ def test_stress_db_matches_reference(gpu, host, oracle):
         if e[6] > 0:
             bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
             assert bt == bts[x] and int(r['identical']) == e[5], x
+
+
+def test_sequences_beyond_65535_residues_are_rejected(gpu, host):
+    """index and k-mer positions are 16 bit (IndexEntryLocal::position_j): a longer sequence is SD_EINVAL at every door,
+    never wrapped"""
+    from spacedust_amd._lib import SdError
+    res = np.random.default_rng(1).integers(0, 20, 70000).astype(np.uint8)
+    off = np.array([0, 66000, 70000], np.uint64)
+    with pytest.raises(SdError):
+        host.build_index(res, off)
+    with pytest.raises(SdError, match='65535'):
+        gpu.seqset(res, off, np.zeros(len(res), np.int8))

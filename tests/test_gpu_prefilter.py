@@ -209,6 +209,76 @@ def test_prefilter_hit_buffer_overflow_matches_reference(gpu, host, oracle, monk
             assert (hits[x, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (mode, q)
 
 
+def test_prefilter_sequences_of_32768_residues_and_more(gpu, host, oracle):
+    """with 32 768 residues or more on either side the 16-bit diagonal is ambiguous and the reference scores every real
+    diagonal it can stand for (computeLongScore, UngappedAlignment.cpp:312-329): two targets of 40 000 and 34 000
+    residues, fragments of them from both sides of the wrap, every sequence as a query -- rows from the real reference
+    (tests/golden/long_vectors.npz, tools/make_golden_long.py)"""
+    g = np.load(os.path.join(GOLD, 'long_vectors.npz'))
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    n = len(off) - 1
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(n)]
+    res = np.concatenate(nums)
+    sw_b, dg_b, km_b = host.comp_bias(res, off)
+    idx = host.build_index(res, off)
+    tgt = api.Target(gpu, host, idx)
+    par = api.prefilter_params(host, idx.n, max_hits=300, cov_thr=0.0)
+    hits, cnt, _ = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, np.arange(n, dtype=np.uint32))
+    rows = g['pf_rows']
+    long_rows = 0
+    for q in range(n):
+        exp = rows[rows[:, 0] == q]
+        m = int(cnt[q])
+        assert m == len(exp), (q, m, len(exp))
+        assert (hits[q, :m]['seqId'] == exp[:, 1]).all() and (hits[q, :m]['score'] == exp[:, 2]).all(), q
+        assert (hits[q, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), q
+        long_rows += int(((exp[:, 1] < 2) | (q < 2)).sum())
+    assert long_rows > 40
+
+
+def test_prefilter_double_overflow_is_a_per_query_error_slot(gpu, host, oracle):
+    """a query whose index hits overflow the reference's hit buffer twice (QueryMatcher.cpp:289-303) is not computed on the
+    device: it is reported through its own count slot (UINT32_MAX) and sd_last_error, and the other queries of the same
+    batch come back complete and equal to the oracle -- never a batch-fatal error (the target is the overflow fixture
+    twice over: 4.96 * 10^6 index hits for query 0 against the 2 * 10^6-entry buffer)"""
+    g = np.load(os.path.join(GOLD, 'overflow_vectors.npz'))
+    off1 = g['off']
+    blob = g['blob'].tobytes().decode()
+    nums = [oracle.map_sequence(blob[int(off1[i]):int(off1[i + 1])]) for i in range(len(off1) - 1)]
+    nums = nums + nums
+    off = np.zeros(len(nums) + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in nums])
+    res = np.concatenate(nums)
+    sw_b, dg_b, km_b = host.comp_bias(res, off)
+    idx = host.build_index(res, off)
+    tgt = api.Target(gpu, host, idx)
+    par = api.prefilter_params(host, idx.n, max_hits=300, cov_thr=0.0, bin_size=2)
+    qs = [1, 0, 10005, 5, 10030]
+    qoff = np.zeros(len(qs) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(nums[q]) for q in qs])
+    qres = np.concatenate([nums[q] for q in qs])
+    qkm = np.concatenate([km_b[int(off[q]):int(off[q + 1])] for q in qs])
+    qdg = np.concatenate([dg_b[int(off[q]):int(off[q + 1])] for q in qs])
+    hits, cnt, st = api.prefilter(gpu, tgt, par, qres, qoff, qkm, qdg, np.array(qs, np.uint32), want_stats=True)
+    assert int(st[1, 1]) >= 4000000
+    assert int(cnt[1]) == 0xFFFFFFFF
+    assert 'QueryMatcher.cpp:289-303' in gpu.last_error()
+    ot = oracle.target(res, off)
+    computed = 0
+    for x, q in enumerate(qs):
+        try:
+            ids, sc, dg, _ = ot.prefilter(nums[q], identity_id=q, max_hits=300, bin_size=2)
+        except RuntimeError as e:   # the oracle does not restate the double-overflow route either (code -2)
+            assert 'code -2' in str(e) and int(cnt[x]) == 0xFFFFFFFF, (q, str(e), int(cnt[x]))
+            continue
+        n = int(cnt[x])
+        computed += 1
+        assert n == len(ids) and n > 0, (q, n, len(ids))
+        assert (hits[x, :n]['seqId'] == ids).all() and (hits[x, :n]['score'] == sc).all() and (hits[x, :n]['diagonal'] == dg).all(), q
+    assert computed >= 3
+
+
 @pytest.mark.parametrize('bin_size,max_hits,min_diag', [(4, 300, 15), (64, 7, 15), (2048, 300, 40), (2, 1, 15)])
 def test_prefilter_parameters_match_oracle(gpu, host, oracle, small_proteomes, bin_size, max_hits, min_diag):
     """BINSIZE (the order ties are cut in: bin-major, QueryMatcher.cpp:422-450), result list length and the minimum

@@ -114,6 +114,45 @@ def test_sw_long_query_strips(gpu, host, oracle):
             assert bt == o['backtrace']
 
 
+def test_sw_bands_beyond_the_lds_classes(gpu, host, oracle):
+    """alignments that span one gap of 1 100 .. 2 600 residues: the banded traceback starts at |tLen - qLen| + 1 columns,
+    beyond the widest LDS band class, and runs in the global-band class (device-resident and host-orchestrated task
+    building); records and backtraces against rows from the real reference (tests/golden/long_vectors.npz, made by
+    tools/make_golden_long.py) and against the oracle"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'long_vectors.npz'))
+    seqs = []
+    for q, t in zip(g['gap_q'], g['gap_t']):
+        seqs += [oracle.map_sequence(str(q)), oracle.map_sequence(str(t))]
+    rng = np.random.default_rng(9)
+    seqs.append(rng.integers(0, 20, 700).astype(np.uint8))   # an ordinary pair next to them
+    seqs.append(seqs[-1][40:640].copy())
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    resid = np.concatenate(seqs)
+    sw_bias, _, _ = host.comp_bias(resid, off)
+    mat, _, _ = host.matrix(0)
+    db = 10 ** 7
+    ss = gpu.seqset(resid, off, sw_bias)
+    par = gpu.sw_params(mat, db, cov_thr=0.0)
+    pq = np.array([0, 2, 4, 6, 1, 3, 5], np.uint32)
+    pt = np.array([1, 3, 5, 7, 0, 2, 4], np.uint32)
+    for hostpath in (False, True):
+        res, pool = gpu.sw_align(par, ss, ss, pq, pt, hostpath=hostpath)
+        for x in range(len(pq)):
+            r = res[x]
+            got = (int(r['score']), int(r['qStart']), int(r['qEnd']), int(r['tStart']), int(r['tEnd']), int(r['identical']), int(r['btLen']))
+            bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
+            if x < 3:
+                assert got == tuple(int(v) for v in g['gap_res'][x]), (hostpath, x, got, g['gap_res'][x])
+                assert bt == str(g['gap_bt'][x]), (hostpath, x)
+                assert float(r['evalue']) == float(g['gap_eval'][x])
+                assert abs((got[2] - got[1]) - (got[4] - got[3])) + 1 > 1022
+            o = oracle.sw_align(seqs[pq[x]], seqs[pt[x]], db, cov_thr=0.0)
+            assert got == (o['score'], o['qStart'], o['qEnd'], o['tStart'], o['tEnd'], o['identical'], o['btLen']), (hostpath, x, got, o)
+            assert bt == o['backtrace'], (hostpath, x)
+
+
 def test_sw_device_vs_host_orchestration(gpu, host):
     """the device-resident gating / task building gives the same records as the host-side one, at a size the
     oracle would not finish in seconds (all sw modes, all coverage modes)"""

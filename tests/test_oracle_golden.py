@@ -298,3 +298,27 @@ def test_prefilter_hit_buffer_overflow(oracle):
         exp = rows[rows[:, 0] == q]
         ids, sc, dg, st = tgt.prefilter(nums[q], identity_id=int(q), max_hits=300)
         assert len(ids) == len(exp) and (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all() and (dg == (exp[:, 3] & 0xFFFF)).all(), q
+
+
+def test_long_sequences_and_long_gaps(oracle):
+    """sequences of 32 768 residues and more (computeLongScore, UngappedAlignment.cpp:312-329) and alignments across gaps
+    of > 1 000 residues (band doubling from |tLen - qLen| + 1, StripedSmithWaterman.cpp banded traceback); rows from the
+    real reference (tools/make_golden_long.py)"""
+    g = np.load(os.path.join(GOLD, 'long_vectors.npz'))
+    off = g['off']
+    blob = g['blob'].tobytes().decode()
+    n = len(off) - 1
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(n)]
+    assert max(len(x) for x in nums) >= 32768
+    tgt = oracle.target(np.concatenate(nums), off)
+    rows = g['pf_rows']
+    for q in range(n):
+        exp = rows[rows[:, 0] == q]
+        ids, sc, dg, st = tgt.prefilter(nums[q], identity_id=q, max_hits=300)
+        assert len(ids) == len(exp) and (ids == exp[:, 1]).all() and (sc == exp[:, 2]).all() and (dg == (exp[:, 3] & 0xFFFF)).all(), q
+    for x in range(len(g['gap_q'])):
+        o = oracle.sw_align(oracle.map_sequence(str(g['gap_q'][x])), oracle.map_sequence(str(g['gap_t'][x])), 10 ** 7, cov_thr=0.0)
+        got = (o['score'], o['qStart'], o['qEnd'], o['tStart'], o['tEnd'], o['identical'], o['btLen'])
+        assert got == tuple(int(v) for v in g['gap_res'][x]), (x, got)
+        assert o['backtrace'] == str(g['gap_bt'][x])
+        assert o['evalue'] == float(g['gap_eval'][x])
