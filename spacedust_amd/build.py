@@ -56,7 +56,21 @@ def build(force=False, verbose=False):
             print(' '.join(cmd))
         subprocess.check_call(cmd)
     build_cli(force=force or bool(jobs), verbose=verbose)
+    build_tools(force=force, verbose=verbose)
     return OUT
+
+
+def build_tools(force=False, verbose=False):
+    """tools/libvalupeak.so: the VALU issue micro-benchmark behind bench.py's sw_valu calibration (not part of the product)"""
+    src = os.path.join(ROOT, 'tools', 'csrc', 'valu_peak.hip')
+    out = os.path.join(ROOT, 'tools', 'libvalupeak.so')
+    if not os.path.exists(src) or (not force and not _newer(src, out)):
+        return out
+    cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-w', '-shared', '-fPIC', '-o', out, src]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return out
 
 
 def build_cli(force=False, verbose=False):

@@ -244,6 +244,10 @@ emit_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t
     const int n0 = countGE(row0, 400, (int) (short) (pi.thr - rest0));
     uint64_t base = kmerBase[p];
     const uint32_t qi = (pi.q << 16) | (uint32_t) pi.i;
+    // runs flattened over the wavefront as in emit_kmers_kernel: slot t of a chunk -> owning lane by binary search
+    __shared__ uint32_t sIncl[4][64];
+    __shared__ uint32_t sKab[4][64];
+    uint32_t *myIncl = sIncl[threadIdx.x >> 6], *myKab = sKab[threadIdx.x >> 6];
     for (int a = 0; a < n0; a++) {
         const int sa = row0[a];
         const uint32_t ka = ix0[a];
@@ -261,34 +265,42 @@ emit_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t
                 uint32_t o = __shfl_up(incl, off, 64);
                 if (lane >= off) incl += o;
             }
-            const uint32_t excl = incl - c;
             const uint32_t chunkTotal = __shfl(incl, 63, 64);
-            if (b < nb) {
-                const uint32_t kab = ka + 400u * (uint32_t) ix1[b];
-                const uint64_t w = base + excl;
-                uint32_t x = 0;
-                for (; x + 4 <= c; x += 4) {
-                    uint32_t km[4], s4[4], e4[4];
+            __builtin_amdgcn_wave_barrier();
+            myIncl[lane] = incl;
+            myKab[lane] = b < nb ? ka + 400u * (uint32_t) ix1[b] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t t0 = 0; t0 < chunkTotal; t0 += 256) {
+                uint32_t km[4], s4[4], e4[4];
 #pragma unroll
-                    for (int y = 0; y < 4; y++) km[y] = kab + 160000u * (uint32_t) ix2[x + y];
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t t = t0 + (uint32_t) u * 64 + (uint32_t) lane;
+                    km[u] = 0;
+                    if (t < chunkTotal) {
+                        int lo = 0, hi = 63;
 #pragma unroll
-                    for (int y = 0; y < 4; y++) {
-                        s4[y] = idxOffsets[km[y]];
-                        e4[y] = idxOffsets[km[y] + 1];
-                    }
-#pragma unroll
-                    for (int y = 0; y < 4; y++) {
-                        kStart[w + x + y] = s4[y];
-                        kLen[w + x + y] = e4[y] - s4[y];
-                        kPos[w + x + y] = qi;
+                        for (int st = 0; st < 6; st++) {
+                            const int mid = (lo + hi) >> 1;
+                            if (myIncl[mid] > t) hi = mid;
+                            else lo = mid + 1;
+                        }
+                        const uint32_t before = lo ? myIncl[lo - 1] : 0u;
+                        km[u] = myKab[lo] + 160000u * (uint32_t) ix2[t - before];
                     }
                 }
-                for (; x < c; x++) {
-                    const uint32_t kmer = kab + 160000u * (uint32_t) ix2[x];
-                    const uint32_t st = idxOffsets[kmer], en = idxOffsets[kmer + 1];
-                    kStart[w + x] = st;
-                    kLen[w + x] = en - st;
-                    kPos[w + x] = qi;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    s4[u] = idxOffsets[km[u]];
+                    e4[u] = idxOffsets[km[u] + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t t = t0 + (uint32_t) u * 64 + (uint32_t) lane;
+                    if (t < chunkTotal) {
+                        kStart[base + t] = s4[u];
+                        kLen[base + t] = e4[u] - s4[u];
+                        kPos[base + t] = qi;
+                    }
                 }
             }
             base += chunkTotal;
@@ -449,6 +461,13 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
     const int n0 = countGE(row0, 8000, cutoff1);
     uint64_t base = kmerBase[p];
     const uint32_t qi = (pi.q << 16) | (uint32_t) pi.i;   // owning query (< 2^16 per sub-batch) and position (< 2^16)
+    // The lanes first own prefixes (a) and count their suffix runs; the runs are then flattened: output slot t of the chunk
+    // belongs to the lane o with excl[o] <= t < incl[o] (binary search over the 64 scan values in LDS), so every lane
+    // produces k-mers -- the run lengths differ by orders of magnitude between the best and the last prefix -- and the
+    // three stream writes are contiguous across the wavefront.  Four slots per lane keep eight index lookups in flight.
+    __shared__ uint32_t sIncl[4][64];
+    __shared__ uint32_t sK0[4][64];
+    uint32_t *myIncl = sIncl[threadIdx.x >> 6], *myK0 = sK0[threadIdx.x >> 6];
     for (int a0 = 0; a0 < n0; a0 += 64) {
         const int a = a0 + lane;
         uint32_t c = 0;
@@ -456,42 +475,48 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
             const int cutoff2 = (int) (short) (pi.thr - (int) row0[a]);
             c = (uint32_t) countGE(row1, 8000, cutoff2);
         }
-        // exclusive scan of c over the 64 lanes
         uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             uint32_t o = __shfl_up(incl, off, 64);
             if (lane >= off) incl += o;
         }
-        const uint32_t excl = incl - c;
         const uint32_t chunkTotal = __shfl(incl, 63, 64);
-        if (a < n0) {
-            const uint32_t k0 = ix0[a];
-            uint64_t w = base + excl;
-            // eight independent index lookups in flight per lane (each is a random 8-byte read)
-            uint32_t b = 0;
-            for (; b + 8 <= c; b += 8) {
-                uint32_t km[8], s4[8], e4[8];
+        __builtin_amdgcn_wave_barrier();   // the previous chunk's readers are done
+        myIncl[lane] = incl;
+        myK0[lane] = a < n0 ? (uint32_t) ix0[a] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t t0 = 0; t0 < chunkTotal; t0 += 256) {
+            uint32_t km[4], s4[4], e4[4];
 #pragma unroll
-                for (int x = 0; x < 8; x++) km[x] = k0 + 8000u * (uint32_t) ix1[b + x];
+            for (int u = 0; u < 4; u++) {
+                const uint32_t t = t0 + (uint32_t) u * 64 + (uint32_t) lane;
+                km[u] = 0;
+                if (t < chunkTotal) {
+                    int lo = 0, hi = 63;   // smallest o with incl[o] > t
 #pragma unroll
-                for (int x = 0; x < 8; x++) {
-                    s4[x] = idxOffsets[km[x]];
-                    e4[x] = idxOffsets[km[x] + 1];
-                }
-#pragma unroll
-                for (int x = 0; x < 8; x++) {
-                    kStart[w + b + x] = s4[x];
-                    kLen[w + b + x] = e4[x] - s4[x];
-                    kPos[w + b + x] = qi;
+                    for (int st = 0; st < 6; st++) {
+                        const int mid = (lo + hi) >> 1;
+                        if (myIncl[mid] > t) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    const uint32_t before = lo ? myIncl[lo - 1] : 0u;
+                    km[u] = myK0[lo] + 8000u * (uint32_t) ix1[t - before];
                 }
             }
-            for (; b < c; b++) {
-                const uint32_t kmer = k0 + 8000u * (uint32_t) ix1[b];
-                const uint32_t s = idxOffsets[kmer], e = idxOffsets[kmer + 1];
-                kStart[w + b] = s;
-                kLen[w + b] = e - s;
-                kPos[w + b] = qi;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                s4[u] = idxOffsets[km[u]];
+                e4[u] = idxOffsets[km[u] + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t t = t0 + (uint32_t) u * 64 + (uint32_t) lane;
+                if (t < chunkTotal) {
+                    kStart[base + t] = s4[u];
+                    kLen[base + t] = e4[u] - s4[u];
+                    kPos[base + t] = qi;
+                }
             }
         }
         base += chunkTotal;
