@@ -225,8 +225,8 @@ def measure(args, rank, local_rank, world, dist, torch):
 
     if args.warmup:
         run_steps(list(range(args.warmup)))
-    cs.ctx.profile(True)
-    cs.ctx_al.profile(True)
+    for c_ in cs.contexts:
+        c_.profile(True)
     for name in cs.stats:
         cs.stats[name] = 0
     comm = None
@@ -271,8 +271,8 @@ def measure(args, rank, local_rank, world, dist, torch):
         if comm is None:
             from spacedust_amd.pipeline import gather_results
             gathered = gather_results(recs, dist, device=None if rehearsal else torch.device('cuda', dev_index))
-    cs.ctx.synchronize()
-    cs.ctx_al.synchronize()
+    for c_ in cs.contexts:
+        c_.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -290,10 +290,11 @@ def measure(args, rank, local_rank, world, dist, torch):
         dt_max, pairs_total = dt, float(pairs_done)
     if rank != 0:
         return None
-    prof = dict(cs.ctx.profile_report())
-    for k_, v_ in cs.ctx_al.profile_report().items():   # the align stage runs on its own context / stream
-        a_ = prof.get(k_, (0.0, 0))
-        prof[k_] = (a_[0] + v_[0], a_[1] + v_[1])
+    prof = {}
+    for c_ in cs.contexts:   # every stage runs on its own context / stream (two of them for the alignment lanes)
+        for k_, v_ in c_.profile_report().items():
+            a_ = prof.get(k_, (0.0, 0))
+            prof[k_] = (a_[0] + v_[0], a_[1] + v_[1])
     kernels = {k_: dict(ms=v[0], launches=int(v[1])) for k_, v in prof.items()}
     grouped = {}   # variants of one kernel template ("name.variant") are one kernel for the roofline
     for k_, v in kernels.items():

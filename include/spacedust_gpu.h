@@ -408,7 +408,8 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
                              sd_search **out);
 void sd_search_destroy(sd_search *s);
 const char *sd_search_last_error(sd_search *s);
-/* the two device contexts (0: prefilter + clusterhits, 1: alignments), e.g. for sd_profile_* */
+/* the device contexts of the pipeline, e.g. for sd_profile_*: 0 prefilter, 1 alignment lane 0, 2 composition bias (NULL when
+ * the bias runs on the host), 3 alignment lane 1 (NULL with SD_ALIGN_LANES=1), 4 clusterhits, 5 prefilter lane 1 (NULL with SD_PF_LANES=1); NULL beyond */
 sd_ctx *sd_search_ctx(sd_search *s, int which);
 /* optional sinks, called from the pipeline's threads in chunk order: the prefilter rows of a chunk (after the coverage
  * pre-filter; what `prefilter` writes) and its reportable alignment records (what `align` writes after checkCriteria) */

@@ -134,6 +134,10 @@ struct sd_search {
     int device = 0;
     sd_host *host = nullptr;
     sd_ctx *ctxPf = nullptr, *ctxAl = nullptr, *ctxBias = nullptr;
+    sd_ctx *ctxAl2 = nullptr;   // second alignment lane: consecutive chunks are aligned concurrently, each on its own stream
+    sd_ctx *ctxCh = nullptr;    // clusterhits (the main thread finalises ranges while both lanes may be busy)
+    sd_ctx *ctxPf2 = nullptr;   // second prefilter lane (same target index, its own workspace and stream)
+    int alignLanes = 2, pfLanes = 2;
     sd_host_index *index = nullptr;
     sd_target *target = nullptr;
     sd_seqset *tSeqs = nullptr;
@@ -150,14 +154,14 @@ struct sd_search {
     sd_pref_sink prefSink = nullptr;
     sd_aln_sink alnSink = nullptr;
     void *sinkUser = nullptr;
-    // alignment result buffers, alternating between consecutive chunks (the aggregation of chunk i-1 reads one while the
-    // alignments of chunk i fill the other)
+    // alignment result buffers in a ring: up to two chunks being aligned (one per lane) while the aggregation reads the
+    // chunk before them
     struct AlnBuf {
         std::vector<sd_sw_result> res;
         std::vector<uint32_t> idx, pq, pt;
         std::vector<uint8_t> ident;
         std::vector<char> pool;
-    } buf[2];
+    } buf[4];
     int flip = 0;
 
     ~sd_search() {
@@ -165,6 +169,9 @@ struct sd_search {
         if (target) sd_target_destroy(target);
         if (index) sd_host_index_destroy(index);
         if (ctxBias) sd_ctx_destroy(ctxBias);
+        if (ctxPf2) sd_ctx_destroy(ctxPf2);
+        if (ctxCh) sd_ctx_destroy(ctxCh);
+        if (ctxAl2) sd_ctx_destroy(ctxAl2);
         if (ctxAl) sd_ctx_destroy(ctxAl);
         if (ctxPf) sd_ctx_destroy(ctxPf);
         if (host) sd_host_destroy(host);
@@ -227,6 +234,18 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     if (rc != SD_OK) return rc;
     rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAl);
     if (rc != SD_OK) return rc;
+    if (const char *e = getenv("SD_ALIGN_LANES")) s->alignLanes = std::max(1, std::min(2, atoi(e)));
+    if (s->alignLanes > 1) {
+        rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAl2);
+        if (rc != SD_OK) return rc;
+    }
+    rc = sd_ctx_create(device, &s->ctxCh);
+    if (rc != SD_OK) return rc;
+    if (const char *e = getenv("SD_PF_LANES")) s->pfLanes = std::max(1, std::min(2, atoi(e)));
+    if (s->pfLanes > 1) {
+        rc = sd_ctx_create(device, &s->ctxPf2);
+        if (rc != SD_OK) return rc;
+    }
     bool devBias = par->deviceBias > 0;
     if (par->deviceBias < 0) {
         int local = 1;
@@ -321,7 +340,18 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
 
 void sd_search_destroy(sd_search *s) { delete s; }
 const char *sd_search_last_error(sd_search *s) { return s ? s->err.c_str() : ""; }
-sd_ctx *sd_search_ctx(sd_search *s, int which) { return !s ? nullptr : (which == 0 ? s->ctxPf : (which == 1 ? s->ctxAl : s->ctxBias)); }
+sd_ctx *sd_search_ctx(sd_search *s, int which) {
+    if (!s) return nullptr;
+    switch (which) {
+        case 0: return s->ctxPf;
+        case 1: return s->ctxAl;
+        case 2: return s->ctxBias;
+        case 3: return s->ctxAl2;
+        case 4: return s->ctxCh;
+        case 5: return s->ctxPf2;
+        default: return nullptr;
+    }
+}
 
 int sd_search_set_sinks(sd_search *s, sd_pref_sink pref, sd_aln_sink aln, void *user) {
     if (!s) return SD_EINVAL;
@@ -430,7 +460,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         return o;
     };
     typedef std::future<std::unique_ptr<BiasOut> > BiasFut;
-    auto pfJob = [s, Q, profile, sameDb](std::shared_ptr<BiasFut> bf) {
+    auto pfJob = [s, Q, profile, sameDb](std::shared_ptr<BiasFut> bf, sd_ctx *pfCtx) {
         std::unique_ptr<PfOut> o(new PfOut());
         o->bias = bf->get();
         BiasOut &b = *o->bias;
@@ -449,23 +479,23 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         o->stats.assign((size_t) nq * 4, 0);
         double t0 = nowSec();
         if (profile)
-            o->rc = sd_prefilter_profile_batch(s->ctxPf, s->target, &s->pfPar, nq, Q->residues + r0, b.off.data(), Q->sortedScore + r0 * 20,
+            o->rc = sd_prefilter_profile_batch(pfCtx, s->target, &s->pfPar, nq, Q->residues + r0, b.off.data(), Q->sortedScore + r0 * 20,
                                                Q->sortedIndex + r0 * 20, Q->alnProfile + r0 * 21, ident.data(), o->hits.data(),
                                                o->counts.data(), o->stats.data());
         else
-            o->rc = sd_prefilter_batch(s->ctxPf, s->target, &s->pfPar, nq, Q->residues + r0, b.off.data(), b.km.data(), b.dg.data(),
+            o->rc = sd_prefilter_batch(pfCtx, s->target, &s->pfPar, nq, Q->residues + r0, b.off.data(), b.km.data(), b.dg.data(),
                                        ident.data(), o->hits.data(), o->counts.data(), o->stats.data());
         o->tPrefilter = nowSec() - t0;
         if (o->rc != SD_OK) {
-            o->err = std::string("sd_prefilter_batch: ") + sd_last_error(s->ctxPf);
+            o->err = std::string("sd_prefilter_batch: ") + sd_last_error(pfCtx);
             return o;
         }
         for (uint32_t i = 0; i < nq; i++)
             if (o->counts[i] == UINT32_MAX) {   // per-query error slot of sd_prefilter_batch: counted, reported, never silent
                 o->counts[i] = 0;
+                if (!o->notComputed) o->err = sd_last_error(pfCtx);
                 o->notComputed++;
             }
-        if (s->prefSink) s->prefSink(s->sinkUser, b.c0, nq, o->hits.data(), o->counts.data(), W);
         // pair list in prefilter order (Alignment.cpp:346-379); Alignment::run's coverage pre-check (:370-373) is the test
         // the prefilter already applied
         t0 = nowSec();
@@ -484,11 +514,17 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             biasFut[x].reset(new BiasFut(biasStage.submit([biasJob, c0, c1] { return biasJob(c0, c1); })));
         }
     };
+    // prefilter lanes: chunk x runs on lane x % lanes (its own context, workspace and stream; the target index is shared)
+    const int pfLanes = s->pfLanes;
+    std::unique_ptr<StageThread> pfLane2(pfLanes > 1 ? new StageThread() : nullptr);
+    sd_ctx *pfCtxOf[2] = {s->ctxPf, s->ctxPf2};
     auto submitPf = [&](size_t x) {
         submitBias(x);
         std::shared_ptr<BiasFut> bf = biasFut[x];
-        PfFut f = pfStage.submit([pfJob, bf] { return pfJob(bf); });
-        submitBias(x + 1);
+        sd_ctx *pfCtx = pfCtxOf[x % (size_t) pfLanes];
+        StageThread &st = (x % (size_t) pfLanes) ? *pfLane2 : pfStage;
+        PfFut f = st.submit([pfJob, bf, pfCtx] { return pfJob(bf, pfCtx); });
+        for (int a = 1; a <= pfLanes; a++) submitBias(x + (size_t) a);
         return f;
     };
 
@@ -543,10 +579,10 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
                 sd[h] = (uint8_t) (Q->strand[R.hitQ[h]] | (T.strand[R.hitT[h]] << 1));
             }
             for (uint64_t e = 0; e < ne; e++) nq[e] = qSetSize[R.entryQ[e]];
-            rc = sd_clusterhits_batch(s->ctxAl, &s->chPar, (uint32_t) ne, R.entryOff.data(), qp.data(), tp.data(), sd.data(), R.pval.data(),
+            rc = sd_clusterhits_batch(s->ctxCh, &s->chPar, (uint32_t) ne, R.entryOff.data(), qp.data(), tp.data(), sd.data(), R.pval.data(),
                                       nq.data(), s->lgamma.data(), (uint32_t) s->lgamma.size(), R.clusterOf.data(), R.rank.data(),
                                       R.nClusters.data(), R.pCO.data(), R.pMH.data(), R.cSize.data());
-            if (rc != SD_OK) return s->fail(rc, "sd_clusterhits_batch", s->ctxAl);
+            if (rc != SD_OK) return s->fail(rc, "sd_clusterhits_batch", s->ctxCh);
             for (uint64_t e = 0; e < ne; e++) nClu += R.nClusters[e];
             for (uint64_t h = 0; h < nh; h++) nCluHits += R.clusterOf[h] != UINT32_MAX;
         }
@@ -565,106 +601,122 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     std::vector<std::pair<uint32_t, size_t> > toFinalize;   // (range, chunk whose aggregation must have finished)
     std::vector<char> finalized(nRanges, 0);
     std::vector<uint64_t> prefHitsOfRange(nRanges, 0), pairsOfRange(nRanges, 0);
-    PfFut pfNext;
-    if (!chunks.empty()) pfNext = submitPf(0);
-    for (size_t ci = 0; ci < chunks.size() && status == SD_OK; ci++) {
-        const uint32_t r = chunks[ci].range;
+
+    // ---- alignment lanes: chunk ci is aligned by lane ci % lanes on that lane's context / stream, so that the host-side
+    // gaps of one call (sorts, scans, downloads) are filled by the other call's kernels; results are retired in chunk order
+    struct AlOut {
+        int rc = SD_OK;
+        std::string err;
+        std::unique_ptr<PfOut> d;
+        size_t ci = 0;
+        uint32_t n = 0, nOut = 0;
+        sd_search::AlnBuf *B = nullptr;
+        uint64_t f = 0, rv = 0, tb = 0;
+        double tSeqset = 0, tAlign = 0;
+    };
+    const int lanes = s->alignLanes;
+    std::unique_ptr<StageThread> alStage[2];
+    for (int l = 0; l < lanes; l++) alStage[l].reset(new StageThread());
+    sd_ctx *laneCtx[2] = {s->ctxAl, s->ctxAl2};
+    const std::vector<int32_t> *qLenP = &qLen;
+    auto alignJob = [s, Q, profile, sameDb, qLenP](std::shared_ptr<std::unique_ptr<PfOut> > dp, sd_ctx *ctx, sd_search::AlnBuf *Bp, size_t ci) {
+        std::unique_ptr<AlOut> o(new AlOut());
+        o->d = std::move(*dp);
+        o->ci = ci;
+        o->B = Bp;
+        PfOut *d = o->d.get();
+        if (d->nPairs == 0) return o;
+        const uint32_t c0 = d->bias->c0, nq = d->bias->c1 - c0;
+        const uint64_t r0 = Q->offsets[c0];
         double t0 = nowSec();
-        std::unique_ptr<PfOut> d = pfNext.get();
-        tm[T_PF_WAIT] += nowSec() - t0;
-        if (ci + 1 < chunks.size()) pfNext = submitPf(ci + 1);
-        if (d->rc != SD_OK) {
-            status = s->fail(d->rc, d->err);
+        sd_seqset *qset = nullptr;
+        int rc;
+        if (profile)
+            rc = sd_profileset_create(ctx, Q->residues + r0, d->bias->off.data(), nq, Q->alnProfile + r0 * 21, &qset);
+        else
+            rc = sd_seqset_create(ctx, Q->residues + r0, d->bias->off.data(), nq, d->bias->sw.data(), &qset);
+        if (rc != SD_OK) {
+            o->rc = rc;
+            o->err = std::string("sd_seqset_create: ") + sd_last_error(ctx);
+            return o;
+        }
+        o->tSeqset = nowSec() - t0;
+        t0 = nowSec();
+        const uint32_t n = (uint32_t) d->nPairs;
+        o->n = n;
+        std::vector<uint8_t> identAll(n, 0);
+        if (sameDb)
+            for (uint32_t i = 0; i < n; i++) identAll[i] = (d->pairQ[i] + c0 == d->pairT[i]) ? 1 : 0;
+        sd_search::AlnBuf &B = *Bp;
+        if (B.res.size() < n) {
+            B.res.resize((size_t) (1.25 * n) + 16);
+            B.idx.resize(B.res.size());
+        }
+        uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(1u << 20, 96ull * n), B.pool.size());
+        bool exact = false;
+        uint32_t nOut = 0;
+        for (;;) {
+            if (B.pool.size() < cap) B.pool.resize(cap);
+            uint64_t used = 0;
+            // only the reportable pairs come back (identity pairs + pairs past every gate, ~10 %): everything else
+            // fails Alignment::checkCriteria and would be skipped by the aggregation anyway
+            rc = sd_sw_align_batch_compact(ctx, &s->swPar, qset, s->tSeqs, n, d->pairQ.data(), d->pairT.data(), identAll.data(),
+                                           B.idx.data(), B.res.data(), &nOut, B.pool.data(), B.pool.size(), &used);
+            if (rc == SD_ENOMEM && !exact) {   // the backtrace pool has to grow: repeat with the exact bound
+                uint64_t need = 64;
+                for (uint32_t i = 0; i < n; i++) need += (uint64_t) (*qLenP)[c0 + d->pairQ[i]] + (uint64_t) s->tLen[d->pairT[i]];
+                cap = need;
+                exact = true;
+                continue;
+            }
             break;
         }
-        tm[T_BIAS] += d->bias->seconds;
-        tm[T_PREFILTER] += d->tPrefilter;
-        tm[T_PAIRS] += d->tPairs;
-        const uint32_t c0 = d->bias->c0, c1 = d->bias->c1, nq = c1 - c0;
-        for (uint32_t i = 0; i < nq; i++) {
-            s->stats[S_KMERS] += d->stats[(size_t) i * 4];
-            s->stats[S_INDEX_HITS] += d->stats[(size_t) i * 4 + 1];
-            s->stats[S_DIAGONALS] += d->stats[(size_t) i * 4 + 2];
-            s->stats[S_DIAG_LEN] += d->stats[(size_t) i * 4 + 3];
+        sd_seqset_destroy(qset);
+        if (rc != SD_OK) {
+            o->rc = rc;
+            o->err = std::string("sd_sw_align_batch_compact: ") + sd_last_error(ctx);
+            return o;
         }
-        s->stats[S_PREF_HITS] += d->nPairs;
-        if (d->notComputed) {
-            s->stats[S_NOT_COMPUTED] += d->notComputed;
-            s->err = std::to_string(s->stats[S_NOT_COMPUTED]) + " queries were not computed: " + sd_last_error(s->ctxPf);
+        o->nOut = nOut;
+        B.pq.resize(std::max<uint32_t>(nOut, 1));
+        B.pt.resize(std::max<uint32_t>(nOut, 1));
+        B.ident.resize(std::max<uint32_t>(nOut, 1));
+        for (uint32_t x = 0; x < nOut; x++) {
+            B.pq[x] = d->pairQ[B.idx[x]];
+            B.pt[x] = d->pairT[B.idx[x]];
+            B.ident[x] = identAll[B.idx[x]];
         }
-        prefHitsOfRange[r] += d->nPairs;
-        if (d->nPairs > 0) {
-            const uint64_t r0 = Q->offsets[c0];
-            t0 = nowSec();
-            sd_seqset *qset = nullptr;
-            int rc;
-            if (profile)
-                rc = sd_profileset_create(s->ctxAl, Q->residues + r0, d->bias->off.data(), nq, Q->alnProfile + r0 * 21, &qset);
-            else
-                rc = sd_seqset_create(s->ctxAl, Q->residues + r0, d->bias->off.data(), nq, d->bias->sw.data(), &qset);
-            if (rc != SD_OK) {
-                status = s->fail(rc, "sd_seqset_create", s->ctxAl);
-                break;
-            }
-            tm[T_SEQSET] += nowSec() - t0;
-            t0 = nowSec();
-            const uint32_t n = (uint32_t) d->nPairs;
-            std::vector<uint8_t> identAll(n, 0);
-            if (sameDb)
-                for (uint32_t i = 0; i < n; i++) identAll[i] = (d->pairQ[i] + c0 == d->pairT[i]) ? 1 : 0;
-            // the other buffer still feeds the aggregation of the previous chunk: only this call's slot is touched, also
-            // when the backtrace pool has to grow and the call is repeated
-            s->flip = 1 - s->flip;
-            sd_search::AlnBuf &B = s->buf[s->flip];
-            if (B.res.size() < n) {
-                B.res.resize((size_t) (1.25 * n) + 16);
-                B.idx.resize(B.res.size());
-            }
-            uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(1u << 20, 96ull * n), B.pool.size());
-            bool exact = false;
-            uint32_t nOut = 0;
-            for (;;) {
-                if (B.pool.size() < cap) B.pool.resize(cap);
-                uint64_t used = 0;
-                // only the reportable pairs come back (identity pairs + pairs past every gate, ~10 %): everything else
-                // fails Alignment::checkCriteria and would be skipped by the aggregation anyway
-                rc = sd_sw_align_batch_compact(s->ctxAl, &s->swPar, qset, s->tSeqs, n, d->pairQ.data(), d->pairT.data(), identAll.data(),
-                                               B.idx.data(), B.res.data(), &nOut, B.pool.data(), B.pool.size(), &used);
-                if (rc == SD_ENOMEM && !exact) {
-                    uint64_t need = 64;
-                    for (uint32_t i = 0; i < n; i++) need += (uint64_t) qLen[c0 + d->pairQ[i]] + (uint64_t) s->tLen[d->pairT[i]];
-                    cap = need;
-                    exact = true;
-                    continue;
-                }
-                break;
-            }
-            sd_seqset_destroy(qset);
-            if (rc != SD_OK) {
-                status = s->fail(rc, "sd_sw_align_batch_compact", s->ctxAl);
-                break;
-            }
-            B.pq.resize(std::max<uint32_t>(nOut, 1));
-            B.pt.resize(std::max<uint32_t>(nOut, 1));
-            B.ident.resize(std::max<uint32_t>(nOut, 1));
-            for (uint32_t x = 0; x < nOut; x++) {
-                B.pq[x] = d->pairQ[B.idx[x]];
-                B.pt[x] = d->pairT[B.idx[x]];
-                B.ident[x] = identAll[B.idx[x]];
-            }
-            tm[T_ALIGN] += nowSec() - t0;
-            uint64_t f = 0, rv = 0, tb = 0;
-            sd_sw_last_cells(s->ctxAl, &f, &rv, &tb);
-            s->stats[S_CELLS_FWD] += f;
-            s->stats[S_CELLS_REV] += rv;
-            s->stats[S_CELLS_TB] += tb;
-            s->stats[S_PAIRS] += n;
-            pairsOfRange[r] += n;
+        o->tAlign = nowSec() - t0;
+        sd_sw_last_cells(ctx, &o->f, &o->rv, &o->tb);
+        return o;
+    };
+    typedef std::future<std::unique_ptr<AlOut> > AlFut;
+    std::deque<AlFut> inflight;
+
+    // a finished chunk, in chunk order: counters, then its records go to the aggregation stage
+    auto retire = [&](std::unique_ptr<AlOut> a) {
+        if (a->rc != SD_OK) {
+            if (status == SD_OK) status = s->fail(a->rc, a->err);
+            return;
+        }
+        if (status != SD_OK) return;
+        const size_t ci = a->ci;
+        const uint32_t r = chunks[ci].range;
+        const uint32_t c0 = a->d->bias->c0, nq = a->d->bias->c1 - c0;
+        if (a->n > 0) {
+            tm[T_SEQSET] += a->tSeqset;
+            tm[T_ALIGN] += a->tAlign;
+            s->stats[S_CELLS_FWD] += a->f;
+            s->stats[S_CELLS_REV] += a->rv;
+            s->stats[S_CELLS_TB] += a->tb;
+            s->stats[S_PAIRS] += a->n;
+            pairsOfRange[r] += a->n;
             waitPending();
-            if (status != SD_OK) break;
+            if (status != SD_OK) return;
             sd_agg *agg = res[r]->agg;
-            sd_search::AlnBuf *bp = &B;
+            sd_search::AlnBuf *bp = a->B;
             sd_search *sp = s;
+            const uint32_t nOut = a->nOut;
             pending = aggStage.submit([agg, bp, nOut, c0, nq, sp]() {
                 const double t1 = nowSec();
                 if (sp->alnSink)
@@ -692,9 +744,65 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             finalized[fr] = 1;
             if (rc != SD_OK) status = rc;
         }
+    };
+
+    std::deque<PfFut> pfQueue;   // prefilter jobs in flight, in chunk order (one per lane)
+    size_t pfSubmitted = 0;
+    auto pumpPf = [&]() {
+        while (pfSubmitted < chunks.size() && (int) pfQueue.size() < pfLanes) pfQueue.push_back(submitPf(pfSubmitted++));
+    };
+    pumpPf();
+    for (size_t ci = 0; ci < chunks.size() && status == SD_OK; ci++) {
+        const uint32_t r = chunks[ci].range;
+        double t0 = nowSec();
+        std::unique_ptr<PfOut> d = pfQueue.front().get();
+        pfQueue.pop_front();
+        tm[T_PF_WAIT] += nowSec() - t0;
+        pumpPf();
+        if (d->rc != SD_OK) {
+            status = s->fail(d->rc, d->err);
+            break;
+        }
+        tm[T_BIAS] += d->bias->seconds;
+        tm[T_PREFILTER] += d->tPrefilter;
+        tm[T_PAIRS] += d->tPairs;
+        const uint32_t c0 = d->bias->c0, c1 = d->bias->c1, nq = c1 - c0;
+        for (uint32_t i = 0; i < nq; i++) {
+            s->stats[S_KMERS] += d->stats[(size_t) i * 4];
+            s->stats[S_INDEX_HITS] += d->stats[(size_t) i * 4 + 1];
+            s->stats[S_DIAGONALS] += d->stats[(size_t) i * 4 + 2];
+            s->stats[S_DIAG_LEN] += d->stats[(size_t) i * 4 + 3];
+        }
+        s->stats[S_PREF_HITS] += d->nPairs;
+        if (d->notComputed) {
+            s->stats[S_NOT_COMPUTED] += d->notComputed;
+            s->err = std::to_string(s->stats[S_NOT_COMPUTED]) + " queries were not computed: " + d->err;
+        }
+        prefHitsOfRange[r] += d->nPairs;
+        // the prefilter sink sees the chunks in order (the lanes finish in any order)
+        if (s->prefSink) s->prefSink(s->sinkUser, c0, nq, d->hits.data(), d->counts.data(), (uint32_t) s->pfPar.maxHitsPerQuery);
+        // at most one chunk per lane in flight; the oldest is retired (in chunk order) before its lane takes the next
+        while ((int) inflight.size() >= lanes && status == SD_OK) {
+            std::unique_ptr<AlOut> a = inflight.front().get();
+            inflight.pop_front();
+            retire(std::move(a));
+        }
+        if (status != SD_OK) break;
+        // the buffer of chunk ci - 4 is free: its aggregation finished before the aggregation of chunk ci - 3 was submitted
+        s->flip = (s->flip + 1) & 3;
+        sd_search::AlnBuf *Bp = &s->buf[s->flip];
+        std::shared_ptr<std::unique_ptr<PfOut> > dp(new std::unique_ptr<PfOut>(std::move(d)));
+        sd_ctx *ctx = laneCtx[ci % (size_t) lanes];
+        inflight.push_back(alStage[ci % (size_t) lanes]->submit([alignJob, dp, ctx, Bp, ci] { return alignJob(dp, ctx, Bp, ci); }));
+    }
+    while (!inflight.empty()) {   // also on errors: the lanes still hold jobs that reference this frame
+        std::unique_ptr<AlOut> a = inflight.front().get();
+        inflight.pop_front();
+        retire(std::move(a));
     }
     // drain: the stage threads may still hold jobs that reference this frame
-    if (pfNext.valid()) pfNext.wait();
+    for (size_t x = 0; x < pfQueue.size(); x++)
+        if (pfQueue[x].valid()) pfQueue[x].wait();
     for (size_t x = 0; x < biasFut.size(); x++)
         if (biasFut[x] && biasFut[x]->valid()) biasFut[x]->wait();
     waitPending();

@@ -143,8 +143,14 @@ class ClusterSearch:
         if rc != 0:
             raise _lib.SdError('sd_search_create failed (%d)' % rc)
         self.h = h
-        self.ctx = _BorrowedContext(C.c_void_p(self.L.sd_search_ctx(h, 0)), ctx.device_index)      # prefilter + clusterhits
-        self.ctx_al = _BorrowedContext(C.c_void_p(self.L.sd_search_ctx(h, 1)), ctx.device_index)   # alignments
+        self.ctx = _BorrowedContext(C.c_void_p(self.L.sd_search_ctx(h, 0)), ctx.device_index)      # prefilter
+        self.ctx_al = _BorrowedContext(C.c_void_p(self.L.sd_search_ctx(h, 1)), ctx.device_index)   # alignments (lane 0)
+        # every device context the pipeline runs on (prefilter, alignment lanes, composition bias, clusterhits)
+        self.contexts = []
+        for which in range(6):
+            hp = self.L.sd_search_ctx(h, which)
+            if hp:
+                self.contexts.append(_BorrowedContext(C.c_void_p(hp), ctx.device_index))
         self.profile_queries = bool(profile_queries)
         self.max_seqs = max_seqs
         self.filter_self_match = filter_self_match
