@@ -991,7 +991,7 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
         return;
     }
     const size_t slot = (size_t) q * PF_NB_MAX + b;
-    const int n = (int) bktCount[slot];
+    int n = (int) bktCount[slot];
     if (n == 0) return;
     const int t = threadIdx.x;
     if (n > CAP) {
@@ -1025,11 +1025,47 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
         }
     }
     __syncthreads();
-    pk16Scan<NT>(cnt, nCnt, part);
+    // A target hit once in this bucket cannot be flagged unless the low byte of its diagonal is 0 (the match compares with
+    // the previous hit of the same target, 0 for the first): such hits -- the majority on a proteome-scale target set,
+    // where most k-mer hits are chance hits on unrelated targets -- leave here, before the sort.
+    uint32_t keepMask = 0, mineKept = 0;
 #pragma unroll
     for (int x = 0; x < PER; x++) {
         const int j = x * NT + t;
         if (j < n) {
+            const uint32_t o = k[x] & offMask;
+            if (pk16Get(cnt, o) > 1 || (v[x] >> 24) == 0) {
+                keepMask |= 1u << x;
+                mineKept++;
+            }
+        }
+    }
+    __syncthreads();   // every count read before the singles are taken out
+#pragma unroll
+    for (int x = 0; x < PER; x++) {
+        const int j = x * NT + t;
+        if (j < n && !(keepMask & (1u << x))) {
+            const uint32_t o = k[x] & offMask;
+            atomicSub(&cnt[o >> 1], 1u << ((o & 1u) * 16u));   // the only hit of its counter
+        }
+    }
+    {   // n := hits that stay
+        uint32_t tot = mineKept;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+        __syncthreads();
+        if ((t & 63) == 0) part[t >> 6] = tot;
+        __syncthreads();
+        tot = 0;
+        for (int wv = 0; wv < NT / 64; wv++) tot += part[wv];
+        __syncthreads();
+        if (tot == 0) return;   // bktEmit[slot] stays 0 (cleared by the caller)
+        n = (int) tot;
+    }
+    pk16Scan<NT>(cnt, nCnt, part);
+#pragma unroll
+    for (int x = 0; x < PER; x++) {
+        if (keepMask & (1u << x)) {
             const uint32_t p = pk16Add(cnt, k[x] & offMask);   // cnt[o] ends as the end of group o
             eK[p] = k[x];
             eV[p] = v[x];
