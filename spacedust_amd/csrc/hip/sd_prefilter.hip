@@ -1376,7 +1376,15 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
     // Usually everything at or above the cut fits the LDS arrays; otherwise (very many tied candidates) the candidate
     // list is swept in windows that cannot overflow them, keeping the best maxHits + 1 between windows.
     const int K = min(maxHits + 1, SEL_CAP / 2);
-    if (sQual > SEL_CAP && maxHits + 1 > SEL_CAP / 2 && threadIdx.x == 0) atomicExch(errFlag, 2);
+    if (sQual > SEL_CAP && maxHits + 1 > SEL_CAP / 2) {
+        // a result list longer than the windowed selection can carry (maxHits > 4095) with more candidates at the cut than
+        // the LDS sorter holds: this query is reported through its count slot, the others are unaffected (block-uniform)
+        if (threadIdx.x == 0) {
+            atomicExch(errFlag, 2);
+            outCount[q] = 0xFFFFFFFFu;
+        }
+        return;
+    }
     int n = 0;
     if (sQual <= SEL_CAP) {
         if (threadIdx.x == 0) sCnt = 0;
@@ -2334,13 +2342,15 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, hipMemcpyAsync(outCount + qBeg, dOutCount.p, bq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         if (stats) SD_HIP(ctx, hipMemcpyAsync(stats + (size_t) qBeg * 4, dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, sdStreamSync(ctx));
-        if (hErr == 2)
-            return sdFail(ctx, SD_EUNSUPPORTED, "maxHitsPerQuery > 4095 together with more than 8192 candidates at the score cut of one query");
+        if (hErr == 2)   // per-query error slots (outCount = UINT32_MAX), not a failure of the batch
+            sdFail(ctx, SD_EUNSUPPORTED, "maxHitsPerQuery > 4095 together with more than 8192 candidates at the score cut: such queries of "
+                   "the batch [%u, %u) are reported with outCount = UINT32_MAX, the rest is computed", qBeg, qBeg + bq);
         hs.reset(new HostScope(ctx, "pf.scatter"));
         // the caller's rows are par->maxHitsPerQuery wide
         for (uint32_t x = 0; x < bq; x++)
-            memcpy(outHits + (size_t) (qBeg + x) * par->maxHitsPerQuery, hOutP + (size_t) x * maxHits,
-                   (size_t) std::min<uint32_t>(outCount[qBeg + x], maxHits) * sizeof(sd_hit));
+            if (outCount[qBeg + x] != UINT32_MAX)
+                memcpy(outHits + (size_t) (qBeg + x) * par->maxHitsPerQuery, hOutP + (size_t) x * maxHits,
+                       (size_t) std::min<uint32_t>(outCount[qBeg + x], maxHits) * sizeof(sd_hit));
         for (uint32_t x = 0; x < (uint32_t) hUnsupported.size(); x++)
             if (hUnsupported[x]) outCount[qBeg + x] = UINT32_MAX;   // per-query error slot: not computed (see above)
         hs.reset();

@@ -4,7 +4,8 @@ and alignments against the REAL reference classes on the P-proteome target (defa
 configs[2]'s size) -- BINSIZE as chosen from the DB size, coarse split, oversize buckets, the hit-buffer overflow of
 the longest queries, --max-seqs 2P.
 
-  python tools/scale_parity.py [P]          prints the counts (profiles/r02_scale_parity_p1000.log is such a run)
+  python tools/scale_parity.py [P [k [n_longest [max_hits]]]]   prints the counts (profiles/r02_scale_parity_p1000.log is such a run;
+                                                     P = 3730 crosses the reference's k = 7 threshold of 3.35e9 residues)
   tests/test_gpu_scale.py                   asserts run(1000) has no mismatch (-m gpu)
 """
 import os
@@ -16,9 +17,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=print, gpu=None, host=None):
+def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=print, gpu=None, host=None, k=None, sensitivity=5.7,
+        max_hits=None):
     """returns dict(prefilter_queries, prefilter_rows, prefilter_mismatch, alignments, alignment_mismatch, bin_size,
-    max_index_hits)"""
+    max_index_hits, k, not_computed).  k: None = the reference's rule (7 from 3.35e9 target residues on,
+    M/src/prefiltering/Prefiltering.cpp setKmerSize / IndexTable.h:439-449), else forced."""
     from spacedust_amd import api
     from spacedust_amd.synth import make_proteomes, ALPHABET
     from oracle.pyoracle import Ref, RefSW
@@ -35,25 +38,33 @@ def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=pri
     qoff = np.zeros(len(queries) + 1, np.uint64)
     qoff[1:] = np.cumsum(lens[queries])
     qres = np.concatenate([ps.residues[int(ps.offsets[q]):int(ps.offsets[q + 1])] for q in queries])
-    sw_b, dg_b, km_b = host.comp_bias(qres, qoff)
+    if k is None:
+        k = 7 if int(ps.offsets[-1]) >= 3350000000 else 6
+    kmer_thr = host.kmer_threshold(sensitivity, k)
+    log('k', k, 'k-mer threshold', kmer_thr, 'target residues', int(ps.offsets[-1]))
+    sw_b, dg_b, km_b = host.comp_bias(qres, qoff, k=k)
     t0 = time.time()
-    idx = host.build_index(ps.residues, ps.offsets)
-    log('index', round(time.time() - t0, 1))
+    idx = host.build_index(ps.residues, ps.offsets, k=k, kmer_thr=kmer_thr)
+    log('index', round(time.time() - t0, 1), 'entries', idx.n_entries)
     tgt = api.Target(gpu, host, idx)
-    max_hits = max(300, 2 * P)
-    par = api.prefilter_params(host, idx.n, max_hits=max_hits, cov_thr=0.0, bin_size=None)
+    max_hits = max_hits or max(300, 2 * P)   # default: --max-seqs 2P, every target set can be reached
+    par = api.prefilter_params(host, idx.n, kmer_thr=kmer_thr, max_hits=max_hits, cov_thr=0.0, bin_size=None, k=k)
     log('bin size', par.binSize)
     hits, cnt, st = api.prefilter(gpu, tgt, par, qres, qoff, km_b, dg_b, queries.astype(np.uint32), want_stats=True)
-    log('device prefilter done: hits', int(cnt.sum()), 'max index hits/query', int(st[:, 1].max()))
+    not_computed = cnt == 0xFFFFFFFF   # per-query error slots (double overflow of the reference's hit buffer / >= 2^24 index hits)
+    log('device prefilter done: hits', int(cnt[~not_computed].sum()), 'max index hits/query', int(st[:, 1].max()), 'not computed',
+        int(not_computed.sum()))
     lut = np.frombuffer(ALPHABET.encode(), np.uint8)
     blob = lut[ps.residues].tobytes()
-    ref = Ref(6)
+    ref = Ref(k)
     t0 = time.time()
-    rix = ref.index(blob, ps.offsets, threads=16)
+    rix = ref.index(blob, ps.offsets, kmer_thr=kmer_thr, threads=16)
     log('ref index', round(time.time() - t0, 1))
     rpf = rix.prefilter(int(lens.max()) + 2, max_hits=max_hits)
     bad = 0
     for x, q in enumerate(queries):
+        if not_computed[x]:
+            continue
         seq = blob[int(ps.offsets[q]):int(ps.offsets[q + 1])]
         ids, sc, dg, _ = rpf.query(seq, int(q))
         n = int(cnt[x])
@@ -62,7 +73,8 @@ def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=pri
         if not ok:
             bad += 1
             log('MISMATCH query', q, 'len', lens[q], 'device', n, 'ref', len(ids))
-    log('prefilter queries compared', len(queries), 'mismatching', bad, 'rows', int(cnt.sum()))
+    cnt = np.where(not_computed, 0, cnt)
+    log('prefilter queries compared', int((~not_computed).sum()), 'mismatching', bad, 'rows', int(cnt.sum()))
     # alignments of the first hits of some of the random queries
     mat, _, _ = host.matrix(0)
     db = int(ps.offsets[-1])
@@ -98,10 +110,20 @@ def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=pri
         if not same:
             badsw += 1
     log('alignments compared', len(pq), 'mismatching', badsw)
-    return dict(proteomes=P, targets=int(ps.n), prefilter_queries=len(queries), prefilter_rows=int(cnt.sum()),
+    return dict(proteomes=P, targets=int(ps.n), k=k, kmer_thr=int(kmer_thr), target_residues=int(ps.offsets[-1]), index_entries=int(idx.n_entries),
+                not_computed=int(not_computed.sum()), prefilter_queries=int((~not_computed).sum()), prefilter_rows=int(cnt.sum()),
                 prefilter_mismatch=bad, alignments=len(pq), alignment_mismatch=badsw, bin_size=int(par.binSize),
                 max_index_hits=int(st[:, 1].max()))
 
 
 if __name__ == '__main__':
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 1000, log=lambda *a: print(*a, flush=True))
+    import json
+    P_ = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    kw = {}
+    if len(sys.argv) > 2:
+        kw['k'] = int(sys.argv[2]) or None   # 0 = the reference's rule
+    if len(sys.argv) > 3:
+        kw['n_longest'] = int(sys.argv[3])
+    if len(sys.argv) > 4:
+        kw['max_hits'] = int(sys.argv[4])
+    print(json.dumps(run(P_, log=lambda *a: print(*a, flush=True), **kw)))
