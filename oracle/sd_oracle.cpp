@@ -3,7 +3,8 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
 // the product (spacedust_amd/) never does.
 //
-// Pinning: every function here is checked (tests/test_oracle_vs_ref.py, tests/test_golden.py)
+// Pinning: every function here is checked (tests/test_oracle_golden.py, tests/test_oracle_clusterhits_ref.py; golden vectors
+// made from the real reference by tools/make_golden*.py)
 //   * against the real reference classes compiled into oracle/_ref/libsdref.so, and
 //   * against the reference's own known answers on examples/ (index entries 1 784 989, masked
 //     residues 11 546, prefilter/alignment md5s recorded in SURVEY.md 8(c), run_regression.sh counts).

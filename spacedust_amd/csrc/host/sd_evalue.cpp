@@ -35,45 +35,47 @@ void initEvaluer(Evaluer &e, uint64_t dbResidues) {
 
 static inline double normalProbability(double x) { return 0.5 * erfc(-sqrt(0.5) * x); }   // sls_basic.hpp:195-198
 
-static double area(const Evaluer &e, double y_, double seqlen1, double seqlen2) {
-    // AlignmentEvaluer::area(score, seqlen1, seqlen2) passes m_ = seqlen2_, n_ = seqlen1_.
-    // One statement per reference statement: the reference's AVX2 build lets the compiler contract
-    // a*b+c into FMA, so the grouping of products and sums is kept identical.
-    const double m_ = seqlen2, n_ = seqlen1;
-    static const double pi = 3.1415926535897932384626433832795;
-    static const double const_val = 1 / sqrt(2.0 * pi);
-    double tmp = e.aI * y_ + e.bI;
-    double m_li_y = m_ - tmp;
-    double vi_y = std::max(e.viThr, e.alphaI * y_ + e.betaI);
-    double sqrt_vi_y = sqrt(vi_y);
-    double m_F;
-    if (sqrt_vi_y == 0.0) m_F = 1e100;
-    else m_F = m_li_y / sqrt_vi_y;
-    double P_m_F = normalProbability(m_F);
-    double E_m_F = -const_val * exp(-0.5 * m_F * m_F);
-    double m_li_y_P_m_F = m_li_y * P_m_F;
-    double sqrt_vi_y_E_m_F = sqrt_vi_y * E_m_F;
-    double p1 = m_li_y_P_m_F - sqrt_vi_y_E_m_F;
+// Finite-size corrected search-space area for a score (ALP's Gumbel area approximation as AlignmentEvaluer uses it, with
+// compute_only_area_; the database side is seqlen2).  For each of the two sequences: the length left after the expected
+// edge loss (linear in the score), divided by the standard deviation of that loss (variance linear in the score, floored),
+// gives a normal quantile z; the side contributes  left * Phi(z) + sd * phi(z).  The area is the product of the two
+// contributions plus a covariance term  max(cThr, sigma * score + tau) * Phi(z1) * Phi(z2).
+// The operations keep the reference's association and order (its AVX2 build contracts a*b+c into FMA, and the printed
+// %.3E digits depend on it): one side after the other, products formed before the differences that use them.
+namespace {
+struct AreaSide {
+    double phiCdf;   // Phi(z)
+    double part;     // left * Phi(z) + sd * phi(z)
+};
+inline AreaSide areaSide(double score, double length, double lossSlope, double lossOffset, double varSlope, double varOffset,
+                         double varFloor) {
+    static const double kPi = 3.1415926535897932384626433832795;
+    static const double kInvSqrt2Pi = 1 / sqrt(2.0 * kPi);
+    const double loss = lossSlope * score + lossOffset;
+    const double left = length - loss;
+    const double variance = std::max(varFloor, varSlope * score + varOffset);
+    const double sd = sqrt(variance);
+    double z;
+    if (sd == 0.0) z = 1e100;
+    else z = left / sd;
+    AreaSide r;
+    r.phiCdf = normalProbability(z);
+    const double negDensity = -kInvSqrt2Pi * exp(-0.5 * z * z);
+    const double leftTerm = left * r.phiCdf;
+    const double sdTerm = sd * negDensity;
+    r.part = leftTerm - sdTerm;
+    return r;
+}
+}  // namespace
 
-    tmp = e.aJ * y_ + e.bJ;
-    double n_lj_y = n_ - tmp;
-    double vj_y = std::max(e.vjThr, e.alphaJ * y_ + e.betaJ);
-    double sqrt_vj_y = sqrt(vj_y);
-    double n_F;
-    if (sqrt_vj_y == 0.0) n_F = 1e100;
-    else n_F = n_lj_y / sqrt_vj_y;
-    double P_n_F = normalProbability(n_F);
-    double E_n_F = -const_val * exp(-0.5 * n_F * n_F);
-    double n_lj_y_P_n_F = n_lj_y * P_n_F;
-    double sqrt_vj_y_E_n_F = sqrt_vj_y * E_n_F;
-    double p2 = n_lj_y_P_n_F - sqrt_vj_y_E_n_F;
-
-    double c_y = std::max(e.cThr, e.sigma * y_ + e.tau);
-    double P_m_F_P_n_F = P_m_F * P_n_F;
-    double c_y_P_m_F_P_n_F = c_y * P_m_F_P_n_F;
-    double p1_p2 = p1 * p2;
-    double area = p1_p2 + c_y_P_m_F_P_n_F;
-    return area;
+static double area(const Evaluer &e, double score, double queryLen, double dbLen) {
+    const AreaSide dbSide = areaSide(score, dbLen, e.aI, e.bI, e.alphaI, e.betaI, e.viThr);
+    const AreaSide querySide = areaSide(score, queryLen, e.aJ, e.bJ, e.alphaJ, e.betaJ, e.vjThr);
+    const double covariance = std::max(e.cThr, e.sigma * score + e.tau);
+    const double bothInside = dbSide.phiCdf * querySide.phiCdf;
+    const double covTerm = covariance * bothInside;
+    const double product = dbSide.part * querySide.part;
+    return product + covTerm;
 }
 
 double computeEvalue(const Evaluer &e, double score, double qLen) {
