@@ -154,6 +154,11 @@ int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, con
                      const uint16_t *entryPos, uint64_t nEntries, const uint8_t *maskedResidues,
                      const uint64_t *seqOffsets, uint32_t nSeq, const int16_t *ext2Score, const uint16_t *ext2Index,
                      const int16_t *ext3Score, const uint16_t *ext3Index, sd_target **out);
+/* the same for a wide index (sd_host_index_block_base); kmerBlockBase = NULL is sd_target_create */
+int sd_target_create_wide(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, const uint64_t *kmerBlockBase,
+                          const uint32_t *entrySeq, const uint16_t *entryPos, uint64_t nEntries, const uint8_t *maskedResidues,
+                          const uint64_t *seqOffsets, uint32_t nSeq, const int16_t *ext2Score, const uint16_t *ext2Index,
+                          const int16_t *ext3Score, const uint16_t *ext3Index, sd_target **out);
 void sd_target_destroy(sd_target *t);
 
 /* Replaces the per-query loop body of Prefiltering::runSplit (Prefiltering.cpp:817-886), i.e.
@@ -246,6 +251,10 @@ int sd_host_index_build(sd_host *h, const uint8_t *residues, const uint64_t *off
 int sd_host_index_info(sd_host_index *ix, uint64_t *tableSize, uint64_t *nEntries, uint64_t *maskedResidues);
 int sd_host_index_arrays(sd_host_index *ix, const uint32_t **kmerOffsets, const uint32_t **entrySeq,
                          const uint16_t **entryPos, const uint8_t **maskedResidues);
+/* Indexes of 2^32 entries and more (targets beyond ~4.4e9 residues; the reference's offsets are size_t,
+ * IndexTable.h:486) are WIDE: kmerOffsets[i] is then relative to blockBase[i >> 16] (one 64-bit base per 65 536 k-mers,
+ * nBlocks of them), list i starts at blockBase[i >> 16] + kmerOffsets[i].  *blockBase = NULL for an ordinary index. */
+int sd_host_index_block_base(sd_host_index *ix, const uint64_t **blockBase, uint64_t *nBlocks);
 void sd_host_index_destroy(sd_host_index *ix);
 int sd_host_ext_matrix(sd_host *h, int wordLen, const int16_t **score, const uint16_t **index, uint32_t *size);
 int sd_host_kmer_threshold(float sensitivity, int kmerSize);
@@ -404,6 +413,7 @@ typedef struct {
     uint64_t nEntries;
     const uint8_t *maskedResidues;   /* the masked target residues the diagonal scoring reads (SequenceLookup) */
     uint64_t nMaskedResidues;        /* how many residues tantan masked (statistics only) */
+    const uint64_t *kmerBlockBase;   /* NULL, or the bases of a wide index (sd_host_index_block_base) */
 } sd_index_view;
 int sd_search_create_indexed(int device, const sd_search_params *par, const sd_setdb *target, const sd_index_view *index,
                              sd_search **out);

@@ -56,7 +56,7 @@ class SetDbView(C.Structure):   # sd_setdb
 
 class IndexView(C.Structure):   # sd_index_view
     _fields_ = [('kmerSize', C.c_int32), ('kmerThr', C.c_int32), ('kmerOffsets', _vp), ('entrySeq', _vp), ('entryPos', _vp),
-                ('nEntries', C.c_uint64), ('maskedResidues', _vp), ('nMaskedResidues', C.c_uint64)]
+                ('nEntries', C.c_uint64), ('maskedResidues', _vp), ('nMaskedResidues', C.c_uint64), ('kmerBlockBase', _vp)]
 
 
 class SearchParams(C.Structure):   # sd_search_params
@@ -135,6 +135,9 @@ def load():
         'sd_host_bitscore': (C.c_double, [C.c_double]),
         'sd_target_create': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_uint64, _vp, _vp, C.c_uint32, _vp, _vp, _vp,
                                        _vp, C.POINTER(_vp)]),
+        'sd_target_create_wide': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, C.c_uint32, _vp, _vp, _vp,
+                                            _vp, C.POINTER(_vp)]),
+        'sd_host_index_block_base': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64)]),
         'sd_target_destroy': (None, [_vp]),
         'sd_prefilter_batch': (C.c_int, [_vp, _vp, C.POINTER(PrefilterParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _vp]),

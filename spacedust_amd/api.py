@@ -165,6 +165,10 @@ class HostIndex:
         po, ps, pp, pm = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         host.L.sd_host_index_arrays(h, C.byref(po), C.byref(ps), C.byref(pp), C.byref(pm))
         self.kmer_offsets = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint32)), shape=(self.table_size + 1,))
+        # wide index (>= 2^32 entries): kmer_offsets[i] is relative to block_base[i >> 16]; None otherwise
+        pb, nb = C.c_void_p(), C.c_uint64()
+        host.L.sd_host_index_block_base(h, C.byref(pb), C.byref(nb))
+        self.block_base = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint64)), shape=(nb.value,)) if pb.value else None
         ne1 = max(self.n_entries, 1)
         self.entry_seq = np.ctypeslib.as_array(C.cast(ps, C.POINTER(C.c_uint32)), shape=(ne1,))[:self.n_entries]
         self.entry_pos = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint16)), shape=(ne1,))[:self.n_entries]
@@ -182,8 +186,9 @@ class IndexArrays:
     """A target index that exists already as arrays (received from another rank, read from an index file): the attributes
     of HostIndex that Target and ClusterSearch(index=...) read"""
 
-    def __init__(self, k, kmer_thr, seq_offsets, kmer_offsets, entry_seq, entry_pos, masked, masked_residues=0):
+    def __init__(self, k, kmer_thr, seq_offsets, kmer_offsets, entry_seq, entry_pos, masked, masked_residues=0, block_base=None):
         self.k, self.kmer_thr = int(k), int(kmer_thr)
+        self.block_base = None if block_base is None else np.ascontiguousarray(block_base, np.uint64)
         self.offsets = np.ascontiguousarray(seq_offsets, np.uint64)
         self.n = len(self.offsets) - 1
         self.kmer_offsets = np.ascontiguousarray(kmer_offsets, np.uint32)
@@ -366,10 +371,11 @@ class Target:
         s2, i2, _ = host.ext_matrix(2)
         s3, i3, _ = host.ext_matrix(3)
         h = C.c_void_p()
-        _check(ctx.h, ctx.L.sd_target_create(ctx.h, index.k, ptr(index.kmer_offsets), ptr(index.entry_seq),
-                                             ptr(index.entry_pos), index.n_entries, ptr(index.masked),
-                                             ptr(index.offsets), index.n, ptr(s2), ptr(i2), ptr(s3), ptr(i3),
-                                             C.byref(h)), 'sd_target_create')
+        bb = getattr(index, 'block_base', None)
+        _check(ctx.h, ctx.L.sd_target_create_wide(ctx.h, index.k, ptr(index.kmer_offsets), ptr(bb) if bb is not None else None,
+                                                  ptr(index.entry_seq), ptr(index.entry_pos), index.n_entries, ptr(index.masked),
+                                                  ptr(index.offsets), index.n, ptr(s2), ptr(i2), ptr(s3), ptr(i3),
+                                                  C.byref(h)), 'sd_target_create')
         self.h = h
         self.n = index.n
 

@@ -59,6 +59,7 @@ struct LoadedIndex {
     int k = 0, kmerThr = 0;
     uint64_t nEntries = 0;
     std::vector<uint32_t> offsets, entrySeq;
+    std::vector<uint64_t> blockBase;    // non-empty: a wide index (>= 2^32 entries), offsets relative to blockBase[i >> 16]
     std::vector<uint16_t> entryPos;
     std::vector<uint8_t> masked;
 };

@@ -121,10 +121,12 @@ int prefilterModule(const Args &a) {
     const uint32_t *kOff, *eSeq;
     const uint16_t *ePos;
     const uint8_t *masked;
+    const uint64_t *kBase = nullptr;
     const int got = loadTargetIndex(a.pos[1], k, indexThr, mask ? 1 : 0, tdb->n, tdb->totalResidues(), loaded, &why);
     if (got < 0) return fail(why);
     if (got == 0) {
         kOff = loaded.offsets.data();
+        kBase = loaded.blockBase.empty() ? nullptr : loaded.blockBase.data();
         eSeq = loaded.entrySeq.data();
         ePos = loaded.entryPos.data();
         masked = loaded.masked.data();
@@ -137,6 +139,7 @@ int prefilterModule(const Args &a) {
         uint64_t tableSize = 0;
         sd_host_index_info(index.ix, &tableSize, &nEntries, &maskedRes);
         sd_host_index_arrays(index.ix, &kOff, &eSeq, &ePos, &masked);
+        sd_host_index_block_base(index.ix, &kBase, nullptr);
     }
     info(a, "Index table k-mer threshold: %d at k-mer size %d\nIndex statistics\nEntries:          %llu\n", kmerThr, k,
          (unsigned long long) nEntries);
@@ -146,7 +149,7 @@ int prefilterModule(const Args &a) {
     sd_host_ext_matrix(host.h, 2, &s2, &i2, &sz2);
     sd_host_ext_matrix(host.h, 3, &s3, &i3, &sz3);
     TargetH target;
-    rc = sd_target_create(ctx.c, k, kOff, eSeq, ePos, nEntries, masked, tdb->offsets.data(), tdb->n, s2, i2, s3, i3, &target.t);
+    rc = sd_target_create_wide(ctx.c, k, kOff, kBase, eSeq, ePos, nEntries, masked, tdb->offsets.data(), tdb->n, s2, i2, s3, i3, &target.t);
     if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_target_create");
 
     sd_prefilter_params par;

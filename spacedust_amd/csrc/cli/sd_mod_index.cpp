@@ -151,6 +151,8 @@ int createindexModule(const Args &a) {
     const uint16_t *ePos;
     const uint8_t *masked;
     sd_host_index_arrays(index.ix, &kOff, &eSeq, &ePos, &masked);
+    const uint64_t *kBase = nullptr;   // wide index (>= 2^32 entries): offsets relative to a base per 65 536 k-mers
+    sd_host_index_block_base(index.ix, &kBase, nullptr);
 
     const std::string out = a.pos[0] + ".idx";
     sddb::removeDb(out);
@@ -221,9 +223,9 @@ int createindexModule(const Args &a) {
         ok = ok && w.put(K_ENTRIES, ent.data(), nEntries * 6);
     }
     {
-        std::vector<size_t> off64(tableSize + 1);
+        std::vector<size_t> off64(tableSize + 1);   // the file carries absolute size_t offsets (IndexTable.h:486)
 #pragma omp parallel for schedule(static)
-        for (uint64_t i = 0; i <= tableSize; i++) off64[i] = kOff[i];
+        for (uint64_t i = 0; i <= tableSize; i++) off64[i] = (kBase ? kBase[i >> 16] : 0) + kOff[i];
         ok = ok && w.put(K_ENTRIESOFFSETS, off64.data(), off64.size() * sizeof(size_t));
     }
     ok = ok && w.put(K_ENTRIESNUM, &nEntries, sizeof(uint64_t));
@@ -311,10 +313,6 @@ int loadTargetIndex(const std::string &targetDb, int wantK, int wantKmerThr, int
         if (why) *why = path + " does not belong to this target DB (sequence count / size differ)";
         return 1;
     }
-    if (nEntries >= (1ull << 32)) {
-        if (why) *why = path + ": more than 2^32 index entries";
-        return -1;
-    }
     out.k = wantK;
     out.kmerThr = wantKmerThr;
     out.nEntries = nEntries;
@@ -323,8 +321,14 @@ int loadTargetIndex(const std::string &targetDb, int wantK, int wantKmerThr, int
     out.entryPos.resize(std::max<uint64_t>(nEntries, 1));
     out.masked.resize(std::max<uint64_t>(residues, 1));
     const size_t *o64 = (const size_t *) off;
+    out.blockBase.clear();
+    if (nEntries >= (1ull << 32) || getenv("SD_INDEX_WIDE")) {   // wide: 32-bit slots relative to a base per 65 536 k-mers
+        out.blockBase.assign(((tableSize + 2) >> 16) + 1, 0);
+        for (uint64_t b = 0; (b << 16) <= tableSize; b++) out.blockBase[b] = o64[b << 16];
+    }
+    const uint64_t *bb = out.blockBase.empty() ? nullptr : out.blockBase.data();
 #pragma omp parallel for schedule(static)
-    for (uint64_t i = 0; i <= tableSize; i++) out.offsets[i] = (uint32_t) o64[i];
+    for (uint64_t i = 0; i <= tableSize; i++) out.offsets[i] = (uint32_t) (o64[i] - (bb ? bb[i >> 16] : 0));
 #pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < nEntries; i++) {
         memcpy(&out.entrySeq[i], ent + i * 6, 4);

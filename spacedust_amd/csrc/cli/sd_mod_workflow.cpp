@@ -246,6 +246,7 @@ int runSearch(const Args &a, bool withClusters) {
             v.kmerSize = k;
             v.kmerThr = thr;
             v.kmerOffsets = loaded.offsets.data();
+            v.kmerBlockBase = loaded.blockBase.empty() ? nullptr : loaded.blockBase.data();
             v.entrySeq = loaded.entrySeq.data();
             v.entryPos = loaded.entryPos.data();
             v.nEntries = loaded.nEntries;

@@ -32,6 +32,7 @@ struct sd_target {
     uint64_t nEntries = 0;
     uint64_t tableSize = 0;
     uint32_t *dOffsets = nullptr;
+    uint64_t *dBlockBase = nullptr;  // wide indexes (>= 2^32 entries): list i starts at dBlockBase[i >> 16] + dOffsets[i]
     uint32_t *dEntrySeq = nullptr;   // upload staging only (freed after the interleaved copy is built)
     uint16_t *dEntryPos = nullptr;
     uint2 *dEntries = nullptr;       // (seqId, position) per index entry, 8 B: one sector per short list instead of two
@@ -110,6 +111,24 @@ __device__ __forceinline__ PosInfo decodePos(uint64_t p, const uint64_t *__restr
     int t = kmerThr - b;
     r.thr = t > 0 ? t : 0;
     return r;
+}
+
+// Index list of a k-mer: (start, length).  WIDE (indexes of 2^32 entries and more): the 32-bit slot is relative to a 64-bit
+// base per 65 536 k-mers; the high half of the start goes to a second stream array.
+template <bool WIDE>
+__device__ __forceinline__ void idxList(const uint32_t *__restrict__ off, const uint64_t *__restrict__ base, uint32_t km,
+                                        uint32_t &startLo, uint32_t &startHi, uint32_t &len) {
+    const uint32_t s = off[km], e = off[km + 1];
+    if (WIDE) {
+        const uint64_t S = base[km >> 16] + s, E = base[(km + 1) >> 16] + e;
+        startLo = (uint32_t) S;
+        startHi = (uint32_t) (S >> 32);
+        len = (uint32_t) (E - S);
+    } else {
+        startLo = s;
+        startHi = 0;
+        len = e - s;
+    }
 }
 
 // K1: count similar k-mers per position
@@ -221,13 +240,15 @@ count_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_
     if (lane == 0) kmerCount[p] = total;
 }
 
+template <bool WIDE>
 __global__ void __launch_bounds__(256)
 emit_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
                    const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
                    const int16_t *__restrict__ ext2Score, const uint16_t *__restrict__ ext2Index,
                    const int16_t *__restrict__ ext3Score, const uint16_t *__restrict__ ext3Index,
                    const uint32_t *__restrict__ idxOffsets, const uint64_t *__restrict__ kmerBase,
-                   uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen, uint32_t *__restrict__ kPos) {
+                   uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen, uint32_t *__restrict__ kPos,
+                   const uint64_t *__restrict__ blockBase, uint32_t *__restrict__ kStartHi) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
@@ -288,17 +309,16 @@ emit_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t
                         km[u] = myKab[lo] + 160000u * (uint32_t) ix2[t - before];
                     }
                 }
+                uint32_t h4[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    s4[u] = idxOffsets[km[u]];
-                    e4[u] = idxOffsets[km[u] + 1];
-                }
+                for (int u = 0; u < 4; u++) idxList<WIDE>(idxOffsets, blockBase, km[u], s4[u], h4[u], e4[u]);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const uint32_t t = t0 + (uint32_t) u * 64 + (uint32_t) lane;
                     if (t < chunkTotal) {
                         kStart[base + t] = s4[u];
-                        kLen[base + t] = e4[u] - s4[u];
+                        if (WIDE) kStartHi[base + t] = h4[u];
+                        kLen[base + t] = e4[u];
                         kPos[base + t] = qi;
                     }
                 }
@@ -330,7 +350,8 @@ profile_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32
                      uint32_t *__restrict__ kmerCount, const uint32_t *__restrict__ idxOffsets,
                      const uint64_t *__restrict__ kmerBase, uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen,
                      uint32_t *__restrict__ kPos, int *__restrict__ errFlag, uint32_t cap /* scratch entries per list */,
-                     uint8_t *__restrict__ big /* per position: 1 = outgrew the small tier */, int bigTier) {
+                     uint8_t *__restrict__ big /* per position: 1 = outgrew the small tier */, int bigTier,
+                     const uint64_t *__restrict__ blockBase /* nullable: wide index */, uint32_t *__restrict__ kStartHi) {
     __shared__ int16_t rowS[7][20];
     __shared__ uint8_t rowI[7][20];
     const int lane = threadIdx.x;
@@ -411,9 +432,15 @@ profile_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32
                         const uint64_t w = base + nB + excl;
                         for (uint32_t j = 0; j < c; j++) {
                             const uint32_t kmer = ki + (uint32_t) ri[j] * mult;
-                            const uint32_t s0 = idxOffsets[kmer], e0 = idxOffsets[kmer + 1];
+                            uint32_t s0, h0, l0;
+                            if (blockBase) {
+                                idxList<true>(idxOffsets, blockBase, kmer, s0, h0, l0);
+                                kStartHi[w + j] = h0;
+                            } else {
+                                idxList<false>(idxOffsets, blockBase, kmer, s0, h0, l0);
+                            }
                             kStart[w + j] = s0;
-                            kLen[w + j] = e0 - s0;
+                            kLen[w + j] = l0;
                             kPos[w + j] = qi;
                         }
                     }
@@ -441,12 +468,14 @@ profile_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32
 }
 
 // K2: emit k-mers (+ index list start/len, + owning position) in the reference's enumeration order
+template <bool WIDE>
 __global__ void __launch_bounds__(256)
 emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
                   const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
                   const int16_t *__restrict__ ext3Score, const uint16_t *__restrict__ ext3Index,
                   const uint32_t *__restrict__ idxOffsets, const uint64_t *__restrict__ kmerBase,
-                  uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen, uint32_t *__restrict__ kPos) {
+                  uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen, uint32_t *__restrict__ kPos,
+                  const uint64_t *__restrict__ blockBase, uint32_t *__restrict__ kStartHi) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
@@ -504,17 +533,16 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
                     km[u] = myK0[lo] + 8000u * (uint32_t) ix1[t - before];
                 }
             }
+            uint32_t h4[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                s4[u] = idxOffsets[km[u]];
-                e4[u] = idxOffsets[km[u] + 1];
-            }
+            for (int u = 0; u < 4; u++) idxList<WIDE>(idxOffsets, blockBase, km[u], s4[u], h4[u], e4[u]);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t t = t0 + (uint32_t) u * 64 + (uint32_t) lane;
                 if (t < chunkTotal) {
                     kStart[base + t] = s4[u];
-                    kLen[base + t] = e4[u] - s4[u];
+                    if (WIDE) kStartHi[base + t] = h4[u];
+                    kLen[base + t] = e4[u];
                     kPos[base + t] = qi;
                 }
             }
@@ -532,16 +560,19 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
                    const uint32_t *__restrict__ kPos, const uint64_t *__restrict__ hitBase,
                    const uint64_t *__restrict__ posBase, uint32_t nQ, const uint2 *__restrict__ entries, int tBits,
                    const uint64_t *__restrict__ qHitBase,
-                   uint32_t *__restrict__ hitKey, uint32_t *__restrict__ hitVal, uint16_t *__restrict__ hitDiag) {
+                   uint32_t *__restrict__ hitKey, uint32_t *__restrict__ hitVal, uint16_t *__restrict__ hitDiag,
+                   const uint32_t *__restrict__ kStartHi /* nullable: high half of the list starts of a wide index */) {
     const uint64_t kidx = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    uint32_t len = 0, start = 0, q = 0;
+    uint32_t len = 0, q = 0;
+    uint64_t start = 0;
     int i = 0;
     uint64_t base = 0;
     if (kidx < nKmers) {
         len = kLen[kidx];
         if (len) {
             start = kStart[kidx];
+            if (kStartHi) start |= (uint64_t) kStartHi[kidx] << 32;
             base = hitBase[kidx];
             const uint32_t qi = kPos[kidx];
             q = qi >> 16;
@@ -577,7 +608,8 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
     while (longMask) {
         const int src = __ffsll((long long) longMask) - 1;
         longMask &= longMask - 1;
-        const uint32_t l2 = __shfl(len, src, 64), s2 = __shfl(start, src, 64), q2 = __shfl(q, src, 64);
+        const uint32_t l2 = __shfl(len, src, 64), q2 = __shfl(q, src, 64);
+        const uint64_t s2 = ((uint64_t) __shfl((uint32_t) (start >> 32), src, 64) << 32) | __shfl((uint32_t) start, src, 64);
         const int i2 = __shfl(i, src, 64);
         const uint64_t b2 = ((uint64_t) __shfl((uint32_t) (base >> 32), src, 64) << 32) | __shfl((uint32_t) base, src, 64);
         for (uint32_t x = lane; x < l2; x += 64) {
@@ -1759,9 +1791,20 @@ int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, con
                      const uint16_t *entryPos, uint64_t nEntries, const uint8_t *maskedResidues,
                      const uint64_t *seqOffsets, uint32_t nSeq, const int16_t *ext2Score, const uint16_t *ext2Index,
                      const int16_t *ext3Score, const uint16_t *ext3Index, sd_target **out) {
+    return sd_target_create_wide(ctx, kmerSize, kmerOffsets, nullptr, entrySeq, entryPos, nEntries, maskedResidues, seqOffsets, nSeq,
+                                 ext2Score, ext2Index, ext3Score, ext3Index, out);
+}
+
+int sd_target_create_wide(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, const uint64_t *kmerBlockBase,
+                          const uint32_t *entrySeq, const uint16_t *entryPos, uint64_t nEntries, const uint8_t *maskedResidues,
+                          const uint64_t *seqOffsets, uint32_t nSeq, const int16_t *ext2Score, const uint16_t *ext2Index,
+                          const int16_t *ext3Score, const uint16_t *ext3Index, sd_target **out) {
     if (!ctx || !out || !kmerOffsets || !maskedResidues || !seqOffsets || !ext3Score || !ext3Index) return SD_EINVAL;
     if (kmerSize != 6 && kmerSize != 7) return sdFail(ctx, SD_EUNSUPPORTED, "k=%d: the device implements k=6 and k=7", kmerSize);
     if (kmerSize == 7 && (!ext2Score || !ext2Index)) return sdFail(ctx, SD_EINVAL, "k=7 needs the 2-mer score matrix");
+    if (nEntries > 0xFFFFFFFFull && !kmerBlockBase)
+        return sdFail(ctx, SD_EINVAL, "an index of %llu entries needs the block bases of a wide index (sd_host_index_block_base)",
+                      (unsigned long long) nEntries);
     for (uint32_t i = 0; i < nSeq; i++)
         if (seqOffsets[i + 1] - seqOffsets[i] > 65535)
             return sdFail(ctx, SD_EINVAL, "target %u has %llu residues; index positions are 16 bit (limit 65535, --max-seq-len)", i,
@@ -1780,6 +1823,7 @@ int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, con
         return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
     bool ok = up((void **) &t->dOffsets, kmerOffsets, (t->tableSize + 1) * sizeof(uint32_t));
+    if (kmerBlockBase) ok = ok && up((void **) &t->dBlockBase, kmerBlockBase, (((t->tableSize + 2) >> 16) + 1) * sizeof(uint64_t));
     ok = ok && up((void **) &t->dEntrySeq, entrySeq, std::max<uint64_t>(nEntries, 1) * sizeof(uint32_t));
     ok = ok && up((void **) &t->dEntryPos, entryPos, std::max<uint64_t>(nEntries, 1) * sizeof(uint16_t));
     ok = ok && up((void **) &t->dMasked, maskedResidues, std::max<uint64_t>(total, 1));
@@ -1813,7 +1857,7 @@ int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, con
 
 void sd_target_destroy(sd_target *t) {
     if (!t) return;
-    void *ptrs[] = {t->dOffsets, t->dEntrySeq, t->dEntryPos, t->dMasked, t->dSeqOff, t->dExt3Score, t->dExt3Index,
+    void *ptrs[] = {t->dOffsets, t->dBlockBase, t->dEntrySeq, t->dEntryPos, t->dMasked, t->dSeqOff, t->dExt3Score, t->dExt3Index,
                     t->dExt2Score, t->dExt2Index, t->dEntries};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
@@ -1928,7 +1972,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     hipLaunchKernelGGL(profile_kmers_kernel<false>, dim3(profGrid), dim3(64), 0, ctx->stream, nPos, dPosBase.p, bq,
                                        dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, dKmerCount.p,
                                        (const uint32_t *) nullptr, (const uint64_t *) nullptr, (uint32_t *) nullptr,
-                                       (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p, PROFILE_PARTIAL_CAP, dProfBig.p, 0);
+                                       (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p, PROFILE_PARTIAL_CAP, dProfBig.p, 0,
+                                       (const uint64_t *) nullptr, (uint32_t *) nullptr);
                     int hTier = 0;
                     SD_HIP(ctx, hipMemcpyAsync(&hTier, dErr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                     SD_HIP(ctx, sdStreamSync(ctx));
@@ -1938,7 +1983,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         hipLaunchKernelGGL(profile_kmers_kernel<false>, dim3(PROFILE_GRID_BIG), dim3(64), 0, ctx->stream, nPos, dPosBase.p,
                                            bq, dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, dKmerCount.p,
                                            (const uint32_t *) nullptr, (const uint64_t *) nullptr, (uint32_t *) nullptr,
-                                           (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p, PROFILE_PARTIAL_CAP_BIG, dProfBig.p, 1);
+                                           (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p, PROFILE_PARTIAL_CAP_BIG, dProfBig.p, 1,
+                                           (const uint64_t *) nullptr, (uint32_t *) nullptr);
                     }
                 } else if (T->k == 6)
                     hipLaunchKernelGGL(count_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
@@ -1967,7 +2013,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         WsView<uint32_t> dKLen(ctx, "pf.dKLen");
         WsView<uint32_t> dKPos(ctx, "pf.dKPos");
         WsView<uint64_t> dHitBase(ctx, "pf.dHitBase");
+        WsView<uint32_t> dKStartHi(ctx, "pf.dKStartHi");   // wide indexes only: high half of the list starts
+        const bool wideIdx = T->dBlockBase != nullptr;
         SD_HIP(ctx, dKStart.alloc(nKmers + 1));
+        if (wideIdx) SD_HIP(ctx, dKStartHi.alloc(nKmers + 1));
         SD_HIP(ctx, dKLen.alloc(nKmers + 1));
         SD_HIP(ctx, dKPos.alloc(nKmers + 1));
         SD_HIP(ctx, dHitBase.alloc(nKmers + 1));
@@ -1978,20 +2027,34 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 if (prof) {
                     hipLaunchKernelGGL(profile_kmers_kernel<true>, dim3(profGrid), dim3(64), 0, ctx->stream, nPos, dPosBase.p, bq,
                                        dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, (uint32_t *) nullptr,
-                                       T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, dErr.p, PROFILE_PARTIAL_CAP, dProfBig.p, 0);
+                                       T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, dErr.p, PROFILE_PARTIAL_CAP, dProfBig.p, 0,
+                                       (const uint64_t *) T->dBlockBase, wideIdx ? dKStartHi.p : (uint32_t *) nullptr);
                     if (profAnyBig)
                         hipLaunchKernelGGL(profile_kmers_kernel<true>, dim3(PROFILE_GRID_BIG), dim3(64), 0, ctx->stream, nPos, dPosBase.p,
                                            bq, dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, (uint32_t *) nullptr,
                                            T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, dErr.p, PROFILE_PARTIAL_CAP_BIG,
-                                           dProfBig.p, 1);
-                } else if (T->k == 6)
-                    hipLaunchKernelGGL(emit_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
-                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
-                                       dKmerBase.p, dKStart.p, dKLen.p, dKPos.p);
-                else
-                    hipLaunchKernelGGL(emit_kmers7_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
-                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt2Index, T->dExt3Score,
-                                       T->dExt3Index, T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p);
+                                           dProfBig.p, 1, (const uint64_t *) T->dBlockBase, wideIdx ? dKStartHi.p : (uint32_t *) nullptr);
+                } else if (T->k == 6) {
+                    if (wideIdx)
+                        hipLaunchKernelGGL(emit_kmers_kernel<true>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                           dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
+                                           dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, (const uint64_t *) T->dBlockBase, dKStartHi.p);
+                    else
+                        hipLaunchKernelGGL(emit_kmers_kernel<false>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                           dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
+                                           dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, (const uint64_t *) nullptr, (uint32_t *) nullptr);
+                } else {
+                    if (wideIdx)
+                        hipLaunchKernelGGL(emit_kmers7_kernel<true>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                           dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt2Index, T->dExt3Score,
+                                           T->dExt3Index, T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p,
+                                           (const uint64_t *) T->dBlockBase, dKStartHi.p);
+                    else
+                        hipLaunchKernelGGL(emit_kmers7_kernel<false>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
+                                           dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt2Index, T->dExt3Score,
+                                           T->dExt3Index, T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p,
+                                           (const uint64_t *) nullptr, (uint32_t *) nullptr);
+                }
             }
             int rc = exclusiveScanWiden(ctx, dKLen.p, dHitBase.p, nKmers + 1, scanTmp);
             if (rc != SD_OK) return rc;
@@ -2086,7 +2149,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 ProfScope ps(ctx, "prefilter_gather_hits");
                 hipLaunchKernelGGL(gather_hits_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKStart.p,
                                    dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, (const uint2 *) T->dEntries, tBits, dQHitBase.p,
-                                   dKeyA.p, dValA.p, dDiag.p);
+                                   dKeyA.p, dValA.p, dDiag.p, wideIdx ? (const uint32_t *) dKStartHi.p : (const uint32_t *) nullptr);
             }
             // ---- double-diagonal match: bucketed LDS path, or (fallback / SD_PF_SORT=1) global radix sort + match
             if (useBuckets) {
@@ -2221,7 +2284,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     ProfScope ps(ctx, "prefilter_gather_hits");
                     hipLaunchKernelGGL(gather_hits_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKStart.p,
                                        dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, (const uint2 *) T->dEntries, tBits, dQHitBase.p,
-                                       dKeyA.p, dValA.p, dDiag.p);
+                                       dKeyA.p, dValA.p, dDiag.p, wideIdx ? (const uint32_t *) dKStartHi.p : (const uint32_t *) nullptr);
                 }
             }
             if (!bucketDone) {

@@ -94,9 +94,9 @@ int sd_host_index_build(sd_host *h, const uint8_t *residues, const uint64_t *off
         if (offsets[i + 1] - offsets[i] > 65535) return SD_EINVAL;
     sd_host_index *ix = new sd_host_index();
     sd::buildTargetIndex(h->seed8, residues, offsets, n, kmerSize, kmerThr, mask != 0, maskProb, h->threads, ix->idx);
-    if (ix->idx.tableSize == 0) {   // more than 2^32 index entries (targets beyond ~4.4e9 residues): 32-bit list offsets in this ABI
+    if (ix->idx.tableSize == 0) {   // the offset table could not be allocated
         delete ix;
-        return SD_EUNSUPPORTED;
+        return SD_ENOMEM;
     }
     *out = ix;
     return SD_OK;
@@ -136,6 +136,13 @@ int sd_host_index_arrays(sd_host_index *ix, const uint32_t **kmerOffsets, const 
     if (entrySeq) *entrySeq = ix->idx.entrySeq.data();
     if (entryPos) *entryPos = ix->idx.entryPos.data();
     if (maskedResidues) *maskedResidues = ix->idx.masked.data();
+    return SD_OK;
+}
+
+int sd_host_index_block_base(sd_host_index *ix, const uint64_t **blockBase, uint64_t *nBlocks) {
+    if (!ix) return SD_EINVAL;
+    if (blockBase) *blockBase = ix->idx.blockBase.empty() ? nullptr : ix->idx.blockBase.data();
+    if (nBlocks) *nBlocks = ix->idx.blockBase.size();
     return SD_OK;
 }
 

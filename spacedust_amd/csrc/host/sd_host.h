@@ -124,7 +124,10 @@ struct TargetIndex {
     int k, span;
     uint8_t seedPos[8];
     uint64_t tableSize;                 // 20^k
-    ZeroedU32 offsets;                  // tableSize+1
+    ZeroedU32 offsets;                  // tableSize+1: list starts -- absolute while the index has < 2^32 entries
+                                        // (blockBase empty), else relative to blockBase[kmer >> 16]
+    std::vector<uint64_t> blockBase;    // wide indexes only: one base per 65 536 k-mers (start = base + offset)
+    uint64_t nEntries;
     std::vector<uint32_t> entrySeq;     // nEntries
     std::vector<uint16_t> entryPos;     // nEntries
     std::vector<uint8_t> masked;        // concatenated masked numeric residues

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <omp.h>
 
 namespace sd {
@@ -104,7 +105,8 @@ void buildTargetIndex(const SubMat &seed8, const uint8_t *seqs, const uint64_t *
     {
         // two-pass parallel inclusive prefix sum
         const int nb = std::max(1, threads);
-        const uint64_t n = tableSize + 2, blk = (n + nb - 1) / nb;
+        // ranges are whole 65 536-slot blocks: a block's base is set by the thread that then uses it (wide form below)
+        const uint64_t n = tableSize + 2, blk = (((n + nb - 1) / nb) + 0xFFFFull) & ~0xFFFFull;
         std::vector<uint64_t> part(nb + 1, 0);
 #pragma omp parallel for num_threads(threads) schedule(static, 1)
         for (int b = 0; b < nb; b++) {
@@ -114,27 +116,28 @@ void buildTargetIndex(const SubMat &seed8, const uint8_t *seqs, const uint64_t *
         }
         for (int b = 0; b < nb; b++) part[b + 1] += part[b];
         run = part[nb];
-        if (run > 0xFFFFFFFFull) {   // the ABI carries 32-bit list offsets
-            out.offsets.reset(0);
-            out.entrySeq.clear();
-            out.entryPos.clear();
-            out.tableSize = 0;
-            return;
-        }
+        // 2^32 entries and more (targets beyond ~4.4e9 residues; the reference's offsets are size_t, IndexTable.h:486): the
+        // 32-bit slots then hold starts relative to a 64-bit base per 65 536 slots (a block's lists are far below 2^32)
+        const bool wide = run > 0xFFFFFFFFull || getenv("SD_INDEX_WIDE") != nullptr;
+        out.blockBase.clear();
+        if (wide) out.blockBase.assign(((tableSize + 2) >> 16) + 1, 0);
 #pragma omp parallel for num_threads(threads) schedule(static, 1)
         for (int b = 0; b < nb; b++) {
             uint64_t sum = part[b];
             for (uint64_t i = std::min(n, b * blk), e = std::min(n, (b + 1) * blk); i < e; i++) {
+                if (wide && (i & 0xFFFFu) == 0) out.blockBase[i >> 16] = sum;   // everything before slot i
                 sum += A[i];
-                A[i] = (uint32_t) sum;
+                A[i] = wide ? (uint32_t) (sum - out.blockBase[i >> 16]) : (uint32_t) sum;
             }
         }
     }
+    out.nEntries = run;
     out.entrySeq.assign(run, 0);
     out.entryPos.assign(run, 0);
     // fill in target order so every list comes out sorted by (seqId,pos) without a second sort:
     // targets are processed in blocks; a serial pass over per-block results keeps seqId ascending.
     uint32_t *cursor = A.data() + 1;
+    const uint64_t *base = out.blockBase.empty() ? nullptr : out.blockBase.data();
     const uint32_t BLOCK = 4096;
     for (uint32_t b0 = 0; b0 < nSeq; b0 += BLOCK) {
         uint32_t b1 = std::min(nSeq, b0 + BLOCK);
@@ -158,7 +161,8 @@ void buildTargetIndex(const SubMat &seed8, const uint8_t *seqs, const uint64_t *
         for (uint32_t id = b0; id < b1; id++) {
             const std::vector<Tmp> &r = res[id - b0];
             for (size_t i = 0; i < r.size(); i++) {
-                uint32_t c = cursor[r[i].kmer]++;
+                uint64_t c = cursor[r[i].kmer]++;
+                if (base) c += base[((uint64_t) r[i].kmer + 1) >> 16];   // cursor slot = kmer + 1
                 out.entrySeq[c] = id;
                 out.entryPos[c] = r[i].pos;
             }

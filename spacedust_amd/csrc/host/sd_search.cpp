@@ -267,7 +267,9 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     const uint32_t *kOff, *eSeq;
     const uint16_t *ePos;
     const uint8_t *mres;
+    const uint64_t *kBase = nullptr;   // block bases of a wide index (>= 2^32 entries)
     if (view) {
+        kBase = view->kmerBlockBase;
         kOff = view->kmerOffsets;
         eSeq = view->entrySeq;
         ePos = view->entryPos;
@@ -281,6 +283,7 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
         uint64_t tableSize = 0;
         sd_host_index_info(s->index, &tableSize, &nEntries, &masked);
         sd_host_index_arrays(s->index, &kOff, &eSeq, &ePos, &mres);
+        sd_host_index_block_base(s->index, &kBase, nullptr);
     }
     s->seconds[T_INDEX] = nowSec() - t0;
     s->stats[S_ENTRIES] = nEntries;
@@ -294,7 +297,8 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
         uint32_t z2, z3;
         sd_host_ext_matrix(s->host, 2, &s2, &i2, &z2);
         sd_host_ext_matrix(s->host, 3, &s3, &i3, &z3);
-        rc = sd_target_create(s->ctxPf, s->k, kOff, eSeq, ePos, nEntries, mres, target->offsets, target->n, s2, i2, s3, i3, &s->target);
+        rc = sd_target_create_wide(s->ctxPf, s->k, kOff, kBase, eSeq, ePos, nEntries, mres, target->offsets, target->n, s2, i2, s3, i3,
+                                   &s->target);
         if (rc != SD_OK) return rc;
     }
     if (s->index) {   // the host copy is not needed once the target is resident

@@ -136,6 +136,8 @@ class ClusterSearch:
             iv.kmerSize, iv.kmerThr = index.k, index.kmer_thr
             iv.kmerOffsets, iv.entrySeq, iv.entryPos = ptr(index.kmer_offsets), ptr(index.entry_seq), ptr(index.entry_pos)
             iv.nEntries, iv.maskedResidues, iv.nMaskedResidues = index.n_entries, ptr(index.masked), index.masked_residues
+            bb = getattr(index, 'block_base', None)
+            iv.kmerBlockBase = ptr(bb) if bb is not None else None
             p.kmerSize = index.k
             rc = self.L.sd_search_create_indexed(ctx.device_index, C.byref(p), C.byref(tv), C.byref(iv), C.byref(h))
         else:

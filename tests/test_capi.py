@@ -75,3 +75,26 @@ def test_pair_list_and_cpu_quota():
     exp_t = np.concatenate([hits['seqId'][q, :cnt[q]] for q in range(nq)]).astype(np.uint32)
     assert np.array_equal(pq, exp_q) and np.array_equal(pt, exp_t)
     assert 1 <= effective_cpus() <= (os.cpu_count() or 1)
+
+
+def test_wide_index_is_the_same_index(monkeypatch):
+    """indexes of 2^32 entries and more carry 32-bit list starts relative to a 64-bit base per 65 536 k-mers
+    (sd_host_index_block_base); SD_INDEX_WIDE=1 forces that form at any size: base + offset must be the ordinary
+    index's absolute starts, entries identical"""
+    import numpy as np
+    from spacedust_amd import api
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=3, genes_per_proteome=150, n_families=200, seed=5)
+    host = api.Host(threads=4)
+    for k, thr in ((6, 112), (7, 122)):
+        a = host.build_index(ps.residues, ps.offsets, k=k, kmer_thr=thr)
+        assert a.block_base is None
+        monkeypatch.setenv('SD_INDEX_WIDE', '1')
+        b = host.build_index(ps.residues, ps.offsets, k=k, kmer_thr=thr)
+        monkeypatch.delenv('SD_INDEX_WIDE')
+        assert b.block_base is not None and len(b.block_base) == ((b.table_size + 2) >> 16) + 1
+        idx = np.arange(b.table_size + 1, dtype=np.int64)
+        absolute = b.block_base[idx >> 16] + b.kmer_offsets.astype(np.uint64)
+        assert np.array_equal(absolute, a.kmer_offsets.astype(np.uint64))
+        assert np.array_equal(a.entry_seq, b.entry_seq) and np.array_equal(a.entry_pos, b.entry_pos)
+        assert a.n_entries == b.n_entries == int(absolute[-1])

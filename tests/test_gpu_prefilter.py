@@ -209,6 +209,31 @@ def test_prefilter_hit_buffer_overflow_matches_reference(gpu, host, oracle, monk
             assert (hits[x, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (mode, q)
 
 
+@pytest.mark.parametrize('k', [6, 7])
+def test_prefilter_wide_index_equals_ordinary(gpu, host, small_proteomes, monkeypatch, k):
+    """the wide index form (>= 2^32 entries: 32-bit list starts relative to a 64-bit base per 65 536 k-mers, forced here by
+    SD_INDEX_WIDE) through emit_kmers<WIDE> / gather_hits: same rows, same statistics as the ordinary index"""
+    ps = small_proteomes
+    thr = host.kmer_threshold(5.7, k)
+    ident = np.arange(ps.n, dtype=np.uint32)
+    sw_b, dg_b, km_b = host.comp_bias(ps.residues, ps.offsets, k=k)
+    out = []
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv('SD_INDEX_WIDE', '1')
+        idx = host.build_index(ps.residues, ps.offsets, k=k, kmer_thr=thr)
+        if wide:
+            monkeypatch.delenv('SD_INDEX_WIDE')
+        assert (idx.block_base is not None) == wide
+        tgt = api.Target(gpu, host, idx)
+        par = api.prefilter_params(host, idx.n, kmer_thr=thr, max_hits=300, cov_thr=0.0, k=k)
+        out.append(api.prefilter(gpu, tgt, par, ps.residues, ps.offsets, km_b, dg_b, ident, want_stats=True))
+    (h0, c0, s0), (h1, c1, s1) = out
+    assert np.array_equal(c0, c1) and np.array_equal(s0, s1) and int(c0.sum()) > ps.n
+    for q in range(ps.n):
+        assert np.array_equal(h0[q, :int(c0[q])], h1[q, :int(c1[q])]), q
+
+
 def test_prefilter_sequences_of_32768_residues_and_more(gpu, host, oracle):
     """with 32 768 residues or more on either side the 16-bit diagonal is ambiguous and the reference scores every real
     diagonal it can stand for (computeLongScore, UngappedAlignment.cpp:312-329): two targets of 40 000 and 34 000
