@@ -539,6 +539,7 @@ static void swPass(const int16_t *prof, int n, const uint8_t *t, int tL, int lan
             int diag = q > 0 ? H[q - 1] : 0;
             int h = diag + p[q];
             if (h < 0) h = 0;
+            if (!byteMode && h > 32767) h = 32767;   // simdi16_adds: the word kernel's H saturates (:1069)
             int hpre = std::max(std::max(h, E[q]), Fl);
             int g = std::max(hpre, Ff);
             Hn[q] = g;

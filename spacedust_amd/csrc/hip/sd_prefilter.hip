@@ -157,10 +157,12 @@ count_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t
     if (lane == 0) kmerCount[p] = total;
 }
 
+// grid-stride: a dispatch carries its size in work-items as 32 bits, and an index of 2^32 entries and more has more entries
+// than that
 __global__ void interleave_entries_kernel(uint64_t n, const uint32_t *__restrict__ seq, const uint16_t *__restrict__ pos,
                                           uint2 *__restrict__ out) {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = make_uint2(seq[i], (uint32_t) pos[i]);
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = make_uint2(seq[i], (uint32_t) pos[i]);
 }
 
 // ---- k = 7 (targets >= 3.35e9 residues, IndexTable.h:439-449): spaced seed 11010110011 (span 11, Sequence.h:24), divide
@@ -1834,14 +1836,23 @@ int sd_target_create_wide(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets
         ok = ok && up((void **) &t->dExt2Score, ext2Score, (size_t) 400 * 400 * sizeof(int16_t));
         ok = ok && up((void **) &t->dExt2Index, ext2Index, (size_t) 400 * 400 * sizeof(uint16_t));
     }
-    ok = ok && hipMalloc((void **) &t->dEntries, (std::max<uint64_t>(nEntries, 1) + 8) * sizeof(uint2)) == hipSuccess;
+    // SD_INDEX_TEST_SHIFT (tests only, wide indexes): the entries start that many slots into their buffer and every block
+    // base moves with them, so that list starts beyond 2^32 are exercised without an index of that size
+    uint64_t testShift = 0;
+    if (kmerBlockBase && getenv("SD_INDEX_TEST_SHIFT")) testShift = strtoull(getenv("SD_INDEX_TEST_SHIFT"), nullptr, 10);
+    ok = ok && hipMalloc((void **) &t->dEntries, (std::max<uint64_t>(nEntries, 1) + testShift + 8) * sizeof(uint2)) == hipSuccess;
+    if (ok && testShift) {
+        std::vector<uint64_t> bb(kmerBlockBase, kmerBlockBase + ((t->tableSize + 2) >> 16) + 1);
+        for (uint64_t &v : bb) v += testShift;
+        ok = hipMemcpy(t->dBlockBase, bb.data(), bb.size() * sizeof(uint64_t), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) {
         sd_target_destroy(t);
         return sdFail(ctx, SD_ENOMEM, "sd_target_create: device allocation/upload failed");
     }
     if (nEntries > 0) {
-        hipLaunchKernelGGL(interleave_entries_kernel, dim3((unsigned) ((nEntries + 255) / 256)), dim3(256), 0, ctx->stream, nEntries,
-                           t->dEntrySeq, t->dEntryPos, t->dEntries);
+        hipLaunchKernelGGL(interleave_entries_kernel, dim3((unsigned) std::min<uint64_t>((nEntries + 255) / 256, 1u << 20)), dim3(256), 0, ctx->stream, nEntries,
+                           t->dEntrySeq, t->dEntryPos, t->dEntries + testShift);
         if (sdStreamSync(ctx) != hipSuccess) {
             sd_target_destroy(t);
             return sdFail(ctx, SD_EHIP, "sd_target_create: interleaving the index entries failed");
@@ -1916,6 +1927,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             hPos[x + 1] = hPos[x] + (uint64_t) std::max<int64_t>(0, L - (T->k == 6 ? SPAN6 : SPAN7) + 1);
         }
         const uint64_t nPos = hPos[bq];
+        if (nPos * 64 >= (1ull << 32) && bq > 1) {   // a wavefront per position: a dispatch carries at most 2^32 work-items
+            batchQ = std::max<uint32_t>(1, bq / 2);
+            continue;
+        }
         WsView<uint8_t> dQ(ctx, "pf.dQ");
         WsView<int16_t> dKB(ctx, "pf.dKB");
         WsView<int8_t> dDB(ctx, "pf.dDB");

@@ -138,7 +138,7 @@ sw_score_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t
                     const int s = (int) (int8_t) (pw[r >> 2] >> (8 * (r & 3)));
                     if (segMask & (1u << r)) Fl = 0;
                     const int old = H[r];
-                    const int h = diag + s;
+                    const int h = min(diag + s, 32767);   // simdi16_adds: the word kernel's H saturates (sw_sse2_word, :1069)
                     const int hpre = max(max(h, E[r]), Fl);
                     const int g = max(hpre, Ff);
                     const int open = hpre - go;

@@ -32,3 +32,31 @@ def test_config3_size_prefilter_and_alignments_match_real_reference(gpu, host):
     assert r['max_index_hits'] > 2 * 3000000          # the hit-buffer overflow route ran (QueryMatcher.cpp:281-326)
     assert r['prefilter_mismatch'] == 0, lines
     assert r['alignments'] >= 1000 and r['alignment_mismatch'] == 0, lines
+
+
+def test_index_of_more_than_2_32_entries(gpu, host, monkeypatch):
+    """the wide index with entry arrays of more than 2^32 elements (what 10 000 proteomes produce): a small index whose
+    entries sit behind 2^32 + 5*10^7 padding slots -- every list start has a non-zero high half, the upload and the
+    interleaving kernel handle more elements than a dispatch has work-items -- returns the rows of the ordinary index"""
+    import numpy as np
+    from spacedust_amd import api
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=8, genes_per_proteome=400, n_families=600, seed=12)
+    k, thr = 7, host.kmer_threshold(5.7, 7)
+    sw_b, dg_b, km_b = host.comp_bias(ps.residues, ps.offsets, k=k)
+    ident = np.arange(ps.n, dtype=np.uint32)
+    a = host.build_index(ps.residues, ps.offsets, k=k, kmer_thr=thr)
+    par = api.prefilter_params(host, a.n, kmer_thr=thr, max_hits=300, cov_thr=0.0, k=k)
+    h0, c0, _ = api.prefilter(gpu, api.Target(gpu, host, a), par, ps.residues, ps.offsets, km_b, dg_b, ident)
+    monkeypatch.setenv('SD_INDEX_WIDE', '1')
+    b = host.build_index(ps.residues, ps.offsets, k=k, kmer_thr=thr)
+    monkeypatch.delenv('SD_INDEX_WIDE')
+    pad = (1 << 32) + 50000000
+    wide = api.IndexArrays(k, thr, ps.offsets, b.kmer_offsets.copy(), np.concatenate([np.zeros(pad, np.uint32), b.entry_seq]),
+                           np.concatenate([np.zeros(pad, np.uint16), b.entry_pos]), b.masked.copy(), 0,
+                           block_base=b.block_base + np.uint64(pad))
+    assert wide.n_entries > (1 << 32)
+    h1, c1, _ = api.prefilter(gpu, api.Target(gpu, host, wide), par, ps.residues, ps.offsets, km_b, dg_b, ident)
+    assert np.array_equal(c0, c1) and int(c0.sum()) > 2 * ps.n
+    for q in range(ps.n):
+        assert np.array_equal(h0[q, :int(c0[q])], h1[q, :int(c1[q])]), q

@@ -153,6 +153,35 @@ def test_sw_bands_beyond_the_lds_classes(gpu, host, oracle):
             assert bt == o['backtrace'], (hostpath, x)
 
 
+def test_sw_scores_beyond_int16_saturate_like_the_word_kernel(gpu, host, oracle):
+    """near-identical sequences of 7 000 - 9 000 residues: the exact score is ~45 000, the reference's word kernel saturates
+    at 32 767 (simdi16_adds, StripedSmithWaterman.cpp:1069) and reports the first cell that reaches it -- score,
+    coordinates, backtrace against the real reference (tests/golden/long_vectors.npz)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'long_vectors.npz'))
+    seqs = []
+    for q, t in zip(g['sat_q'], g['sat_t']):
+        seqs += [oracle.map_sequence(str(q)), oracle.map_sequence(str(t))]
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    resid = np.concatenate(seqs)
+    sw_bias, _, _ = host.comp_bias(resid, off)
+    mat, _, _ = host.matrix(0)
+    ss = gpu.seqset(resid, off, sw_bias)
+    par = gpu.sw_params(mat, 10 ** 7, cov_thr=0.0)
+    pq = np.array([0, 2, 4], np.uint32)
+    pt = np.array([1, 3, 5], np.uint32)
+    for hostpath in (False, True):
+        res, pool = gpu.sw_align(par, ss, ss, pq, pt, hostpath=hostpath)
+        for x in range(3):
+            r = res[x]
+            got = (int(r['score']), int(r['qStart']), int(r['qEnd']), int(r['tStart']), int(r['tEnd']), int(r['identical']), int(r['btLen']))
+            assert got == tuple(int(v) for v in g['sat_res'][x]), (hostpath, x, got, g['sat_res'][x])
+            assert got[0] == 32767
+            bt = pool[int(r['btOffset']):int(r['btOffset']) + int(r['btLen'])].tobytes().decode()
+            assert bt == str(g['sat_bt'][x]), (hostpath, x)
+
+
 def test_sw_device_vs_host_orchestration(gpu, host):
     """the device-resident gating / task building gives the same records as the host-side one, at a size the
     oracle would not finish in seconds (all sw modes, all coverage modes)"""

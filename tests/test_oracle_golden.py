@@ -322,3 +322,10 @@ def test_long_sequences_and_long_gaps(oracle):
         assert got == tuple(int(v) for v in g['gap_res'][x]), (x, got)
         assert o['backtrace'] == str(g['gap_bt'][x])
         assert o['evalue'] == float(g['gap_eval'][x])
+    # scores beyond int16: the word kernel saturates at 32 767 (simdi16_adds) and reports the first cell that reaches it
+    assert len(g['sat_q']) == 3 and int(g['sat_res'][:, 0].min()) == 32767
+    for x in range(len(g['sat_q'])):
+        o = oracle.sw_align(oracle.map_sequence(str(g['sat_q'][x])), oracle.map_sequence(str(g['sat_t'][x])), 10 ** 7, cov_thr=0.0)
+        got = (o['score'], o['qStart'], o['qEnd'], o['tStart'], o['tEnd'], o['identical'], o['btLen'])
+        assert got == tuple(int(v) for v in g['sat_res'][x]), (x, got)
+        assert o['backtrace'] == str(g['sat_bt'][x])

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Cheap reproductions of what only the 10 000-proteome target has: (A) more than 2^24 target sequences (25 target bits in
+the hit keys), (B) index list starts beyond 2^32 (SD_INDEX_TEST_SHIFT places the entries 2^32 slots into their buffer).
+  python tools/debug_scale.py A|B"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main(which):
+    from spacedust_amd import api
+    from spacedust_amd.synth import ALPHABET
+    from oracle.pyoracle import Ref
+    rng = np.random.default_rng(3)
+    host, gpu = api.Host(), api.Context(0)
+    copies, max_hits, nq = 300, 1000, 24
+    if which == 'A':
+        n_seq, L = 17500000, 48
+    elif which.startswith('C'):   # more saturated homologs than the result list holds: the rescoring path with a long list
+        n_seq, L, copies, max_hits, nq = 400000, 300, 6000, 4000, 6
+    else:
+        n_seq, L = 400000, 120
+    res = rng.integers(0, 20, n_seq * L).astype(np.uint8)
+    off = (np.arange(n_seq + 1, dtype=np.uint64) * L)
+    # families: query i has 300 mutated copies spread over the DB
+    queries = rng.choice(n_seq, nq, replace=False)
+    for q in queries:
+        src = res[q * L:(q + 1) * L]
+        for t in rng.choice(n_seq, copies, replace=False):
+            c = src.copy()
+            m = rng.random(L) < 0.15
+            c[m] = rng.integers(0, 20, int(m.sum()))
+            res[t * L:(t + 1) * L] = c
+        res[q * L:(q + 1) * L] = src
+    k, thr = (7, 122) if which.endswith('7') else (6, 112)
+    if which.startswith('B') or which.startswith('D'):
+        os.environ['SD_INDEX_WIDE'] = '1'
+    t0 = time.time()
+    idx = host.build_index(res, off, k=k, kmer_thr=thr)
+    print('index', round(time.time() - t0, 1), 'entries', idx.n_entries, 'wide', idx.block_base is not None, flush=True)
+    if which.startswith('D'):   # entry arrays of more than 2^32 elements: the real entries sit behind 2^32 + 5e7 padding slots
+        pad = (1 << 32) + 50000000
+        idx = api.IndexArrays(k, thr, off, idx.kmer_offsets.copy(), np.concatenate([np.zeros(pad, np.uint32), idx.entry_seq]),
+                              np.concatenate([np.zeros(pad, np.uint16), idx.entry_pos]), idx.masked.copy(), 0,
+                              block_base=idx.block_base + np.uint64(pad))
+        print('padded entries', idx.n_entries, flush=True)
+    tgt = api.Target(gpu, host, idx)
+    qoff = np.arange(len(queries) + 1, dtype=np.uint64) * L
+    qres = np.concatenate([res[q * L:(q + 1) * L] for q in queries])
+    sw_b, dg_b, km_b = host.comp_bias(qres, qoff, k=k)
+    par = api.prefilter_params(host, idx.n, kmer_thr=thr, max_hits=max_hits, cov_thr=0.0, k=k)
+    hits, cnt, st = api.prefilter(gpu, tgt, par, qres, qoff, km_b, dg_b, queries.astype(np.uint32), want_stats=True)
+    print('device rows', int(cnt.sum()), 'index hits', int(st[:, 1].sum()), flush=True)
+    lut = np.frombuffer(ALPHABET.encode(), np.uint8)
+    blob = lut[res].tobytes()
+    ref = Ref(k)
+    rix = ref.index(blob, off, kmer_thr=thr, threads=16)
+    rpf = rix.prefilter(L + 2, max_hits=max_hits)
+    bad = 0
+    for x, q in enumerate(queries):
+        ids, sc, dg, _ = rpf.query(blob[int(q) * L:(int(q) + 1) * L], int(q))
+        n = int(cnt[x])
+        ok = n == len(ids) and (hits[x, :n]['seqId'] == ids).all() and (hits[x, :n]['score'] == sc).all()
+        if not ok:
+            bad += 1
+            print('MISMATCH', q, 'device', n, 'ref', len(ids), flush=True)
+    print('queries', len(queries), 'mismatching', bad)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

@@ -52,6 +52,17 @@ def gap_pairs(seed=5):
     return out
 
 
+def saturating_pairs(seed=11):
+    """alignments whose score leaves int16: the reference's word kernel saturates at 32 767 (simdi16_adds), so score and
+    end position are those of the first cell that reaches it"""
+    rng = np.random.default_rng(seed)
+    rnd = lambda n: ''.join(rng.choice(list(AA), n))
+    a = rnd(9000)
+    b = rnd(40) + mutate(rng, a, 0.04) + rnd(25)
+    c = rnd(7000)
+    return [(a, b), (b, a), (c, mutate(rng, c, 0.02)[300:])]
+
+
 def main():
     ref, orc = Ref(6), Oracle(4)
     seqs = crafted()
@@ -88,7 +99,21 @@ def main():
         r = sw.align(t, sw_mode=2, eval_thr=10.0, cov_mode=2, cov_thr=0.0)
         print('gap pair', len(q), len(t), {k: v for k, v in r.items() if k != 'backtrace'}, 'band >=', abs((r['qEnd'] - r['qStart']) - (r['tEnd'] - r['tStart'])) + 1)
         aln.append(r)
-    np.savez_compressed(os.path.join(GOLD, 'long_vectors.npz'), blob=np.frombuffer(blob, np.uint8), off=off, pf_rows=rows,
+    sat = saturating_pairs()
+    sw2 = RefSW(ref, max(max(len(q), len(t)) for q, t in sat), 10 ** 7)
+    sat_res = []
+    for q, t in sat:
+        sw2.set_query(q)
+        r = sw2.align(t, sw_mode=2, eval_thr=10.0, cov_mode=2, cov_thr=0.0)
+        print('saturating pair', len(q), len(t), {k: v for k, v in r.items() if k != 'backtrace'})
+        o = orc.sw_align(orc.map_sequence(q), orc.map_sequence(t), 10 ** 7, cov_thr=0.0)
+        same = all(o[k] == r[k] for k in ('score', 'qStart', 'qEnd', 'tStart', 'tEnd', 'identical', 'btLen', 'backtrace', 'evalue'))
+        print('   oracle == reference:', same)
+        sat_res.append(r)
+    np.savez_compressed(os.path.join(GOLD, 'long_vectors.npz'),
+                        sat_q=np.array([q for q, _ in sat]), sat_t=np.array([t for _, t in sat]),
+                        sat_res=np.array([[r['score'], r['qStart'], r['qEnd'], r['tStart'], r['tEnd'], r['identical'], r['btLen']] for r in sat_res], np.int64),
+                        sat_bt=np.array([r['backtrace'] for r in sat_res]), sat_eval=np.array([r['evalue'] for r in sat_res]), blob=np.frombuffer(blob, np.uint8), off=off, pf_rows=rows,
                         gap_q=np.array([q for q, _ in pairs]), gap_t=np.array([t for _, t in pairs]),
                         gap_res=np.array([[r['score'], r['qStart'], r['qEnd'], r['tStart'], r['tEnd'], r['identical'], r['btLen']] for r in aln], np.int64),
                         gap_bt=np.array([r['backtrace'] for r in aln]), gap_eval=np.array([r['evalue'] for r in aln]))
