@@ -169,7 +169,7 @@ void sd_target_destroy(sd_target *t);
  *   identityId[q]: index of the query in the target DB or UINT32_MAX
  * outHits: nQ * maxHitsPerQuery slots (row q at q*maxHitsPerQuery), outCount[nQ].
  * outCount[q] == UINT32_MAX marks a query that was NOT computed: it needs a reference route the device lacks (a second
- * overflow of the hit buffer, QueryMatcher.cpp:289-303, >= 2^24 index hits, or a result list beyond 4 095 hits with more than
+ * overflow of the hit buffer, QueryMatcher.cpp:289-303, >= 2^32 index hits, or a result list beyond 4 095 hits with more than
  * 8 192 candidates at the score cut); its row is empty, the other queries of the
  * call are computed normally and sd_last_error() names the count.  Callers must treat such rows as errors, not as "no hits".
  * stats (nullable, 4*nQ u64): #similar k-mers, #index entries, #diagonals scored, sum of diagonal lengths. */

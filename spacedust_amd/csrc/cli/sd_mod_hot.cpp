@@ -230,7 +230,7 @@ int prefilterModule(const Args &a) {
     if (!out.close(&err)) return fail(err);
     info(a, "%llu prefilter hits written for %u queries\n", (unsigned long long) totalHits, qdb->n);
     if (notComputed)
-        return fail(std::to_string(notComputed) + " queries need the reference's double-overflow route (or have >= 2^24 index hits) and were "
+        return fail(std::to_string(notComputed) + " queries need the reference's double-overflow route (or have >= 2^32 index hits) and were "
                     "written as empty entries; every other entry is complete");
     return 0;
 }

@@ -563,7 +563,9 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
                    const uint64_t *__restrict__ posBase, uint32_t nQ, const uint2 *__restrict__ entries, int tBits,
                    const uint64_t *__restrict__ qHitBase,
                    uint32_t *__restrict__ hitKey, uint32_t *__restrict__ hitVal, uint16_t *__restrict__ hitDiag,
-                   const uint32_t *__restrict__ kStartHi /* nullable: high half of the list starts of a wide index */) {
+                   const uint32_t *__restrict__ kStartHi /* nullable: high half of the list starts of a wide index */,
+                   int widePos /* the value word is the full stream position (queries with >= 2^24 hits); the diagonal byte is
+                                  taken from hitDiag by coarse_scatter_kernel and moves into the key */) {
     const uint64_t kidx = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t len = 0, q = 0;
@@ -601,7 +603,7 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
             if (x < len) {
                 const uint16_t d = (uint16_t) (i - (int) ep[x]);
                 hitKey[base + x] = (q << tBits) | sid[x];
-                hitVal[base + x] = ((uint32_t) (d & 0xFF) << 24) | (rel + x);
+                hitVal[base + x] = widePos ? rel + x : ((uint32_t) (d & 0xFF) << 24) | (rel + x);
                 hitDiag[base + x] = d;
             }
         }
@@ -619,7 +621,8 @@ gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const u
             const uint32_t sid = en.x;
             const uint16_t d = (uint16_t) (i2 - (int) en.y);
             hitKey[b2 + x] = (q2 << tBits) | sid;
-            hitVal[b2 + x] = ((uint32_t) (d & 0xFF) << 24) | (uint32_t) (b2 + x - qHitBase[q2]);
+            const uint32_t rp = (uint32_t) (b2 + x - qHitBase[q2]);
+            hitVal[b2 + x] = widePos ? rp : ((uint32_t) (d & 0xFF) << 24) | rp;
             hitDiag[b2 + x] = d;
         }
     }
@@ -674,13 +677,13 @@ constexpr uint32_t QUERY_UNSUPPORTED = 0xFFFFFFFEu;   // qSplit marker: the quer
 // (inBuffer + listSize >= cap) starts the second part; a second overflow is flagged (not implemented)
 __global__ void query_split_kernel(uint32_t nQ, const uint64_t *__restrict__ posBase, const uint64_t *__restrict__ kmerBase,
                                    const uint64_t *__restrict__ hitBase, uint64_t cap, uint32_t *__restrict__ qSplit,
-                                   int *__restrict__ flag) {
+                                   int *__restrict__ flag, uint64_t posLimit /* 2^24, or ~2^32 with wide stream positions */) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nQ) return;
     const uint64_t k0 = kmerBase[posBase[q]], k1 = kmerBase[posBase[q + 1]];
     const uint64_t h0 = hitBase[k0], total = hitBase[k1] - h0;
     uint32_t split = 0xFFFFFFFFu;
-    bool unsupported = total >= (1ull << 24);   // stream positions are carried in 24 bits
+    bool unsupported = total >= posLimit;   // stream positions are carried in 24 (wide: 32) bits
     if (!unsupported && total >= cap) {
         // first k in [k0, k1) with hitBase[k + 1] - h0 >= cap
         uint64_t lo = k0, hi = k1;
@@ -966,7 +969,10 @@ coarse_offsets_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
 __global__ void __launch_bounds__(256)
 coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const uint32_t *__restrict__ segBase, int tBits, int cBits,
                       const uint32_t *__restrict__ segOffset, const uint32_t *__restrict__ inKey,
-                      const uint32_t *__restrict__ inVal, uint32_t *__restrict__ outKey, uint32_t *__restrict__ outVal) {
+                      const uint32_t *__restrict__ inVal, uint32_t *__restrict__ outKey, uint32_t *__restrict__ outVal,
+                      const uint16_t *__restrict__ hitDiag /* wide stream positions: the diagonal byte goes into the key bits
+                                                              above the virtual query's target bits (the range is implied
+                                                              by the segment), nullptr otherwise */) {
     __shared__ uint32_t cursor[1 << CP_MAX_BITS];
     const uint32_t seg = blockIdx.x;
     const uint32_t q = cpQueryOfSeg(seg, nQ, segBase);
@@ -981,7 +987,7 @@ coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
     for (uint64_t i = s + threadIdx.x; i < e; i += 256) {
         const uint32_t k = inKey[i];
         const uint32_t p = atomicAdd(&cursor[(k & tMask) >> shift], 1u);
-        outKey[qs + p] = k;
+        outKey[qs + p] = hitDiag ? (((uint32_t) hitDiag[i] & 0xFFu) << shift) | (k & ((1u << shift) - 1)) : k;
         outVal[qs + p] = inVal[i];
     }
 }
@@ -1010,7 +1016,9 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
                     const uint2 *__restrict__ inKV, uint32_t *__restrict__ outKey,
                     uint32_t *__restrict__ outVal, uint32_t *__restrict__ bktEmit, int *__restrict__ flag,
                     const uint32_t *__restrict__ slotList, uint32_t *__restrict__ bigList, uint32_t *__restrict__ bigCount,
-                    uint32_t bigCap, const uint32_t *__restrict__ qSplit, int vqShift /* query = virtual query >> vqShift */) {
+                    uint32_t bigCap, const uint32_t *__restrict__ qSplit, int vqShift /* query = virtual query >> vqShift */,
+                    int wpBits /* 0, or (wide stream positions) the virtual query's target bits: the diagonal byte sits in the
+                                  key above them and the value is the position */) {
     __shared__ uint32_t eK[CAP], eV[CAP];
     __shared__ uint32_t cnt[PF_CNT_MAX / 2];   // packed 16-bit: counts -> group starts -> group ends
     __shared__ uint32_t part[NT / 64 + 1];
@@ -1044,6 +1052,10 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
     const int shift = tBits - (int) qLog2Bins[q];
     const uint32_t split = qSplit[q >> vqShift];
     const uint32_t offMask = (1u << shift) - 1;   // key & offMask = target offset inside the bucket's range
+    const bool WP = wpBits != 0;
+    const uint32_t posMask = WP ? 0xFFFFFFFFu : 0xFFFFFFu;
+    const uint32_t tgtMask = WP ? (1u << wpBits) - 1 : 0xFFFFFFFFu;   // what identifies the target in a key
+    auto d8of = [&](uint32_t key, uint32_t val) -> uint32_t { return WP ? (key >> wpBits) & 0xFFu : val >> 24; };
     const int nCnt = shift == 0 ? 2 : (1 << shift);
     for (int x = t; x < nCnt / 2; x += NT) cnt[x] = 0;
     __syncthreads();
@@ -1068,7 +1080,7 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
         const int j = x * NT + t;
         if (j < n) {
             const uint32_t o = k[x] & offMask;
-            if (pk16Get(cnt, o) > 1 || (v[x] >> 24) == 0) {
+            if (pk16Get(cnt, o) > 1 || d8of(k[x], v[x]) == 0) {
                 keepMask |= 1u << x;
                 mineKept++;
             }
@@ -1118,8 +1130,8 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
             const uint32_t gs = o ? pk16Get(cnt, o - 1) : 0, ge = pk16Get(cnt, o);
             uint32_t f = gs;
             if (ge - gs > 1) {
-                const uint32_t me = v[x] & 0xFFFFFFu;
-                for (uint32_t y = gs; y < ge; y++) f += ((eV[y] & 0xFFFFFFu) < me) ? 1u : 0u;
+                const uint32_t me = v[x] & posMask;
+                for (uint32_t y = gs; y < ge; y++) f += ((eV[y] & posMask) < me) ? 1u : 0u;
             }
             fin[x] = f;
         }
@@ -1139,22 +1151,22 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
     const int pb = t * per, pe = min(n, pb + per);
     uint32_t emitMask = 0, mine = 0;
     for (int p = pb; p < pe; p++) {
-        const uint8_t d8 = (uint8_t) (eV[p] >> 24);
+        const uint8_t d8 = (uint8_t) d8of(eK[p], eV[p]);
         auto flagAt = [&](int x) -> bool {
-            const uint8_t dx = (uint8_t) (eV[x] >> 24);
-            bool first = (x == 0) || (eK[x - 1] != eK[x]);
-            if (!first) first = ((eV[x - 1] & 0xFFFFFFu) < split) != ((eV[x] & 0xFFFFFFu) < split);   // overflow split
-            const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) (eV[x - 1] >> 24);
+            const uint8_t dx = (uint8_t) d8of(eK[x], eV[x]);
+            bool first = (x == 0) || (((eK[x - 1] ^ eK[x]) & tgtMask) != 0);
+            if (!first) first = ((eV[x - 1] & posMask) < split) != ((eV[x] & posMask) < split);   // overflow split
+            const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) d8of(eK[x - 1], eV[x - 1]);
             return dx == prev;
         };
         bool em = false;
         if (flagAt(p)) {
             em = true;
             int x = p;
-            while (x > 0 && eK[x - 1] == eK[p]) {
+            while (x > 0 && ((eK[x - 1] ^ eK[p]) & tgtMask) == 0) {
                 x--;
                 if (flagAt(x)) {
-                    em = ((uint8_t) (eV[x] >> 24)) != d8;
+                    em = ((uint8_t) d8of(eK[x], eV[x])) != d8;
                     break;
                 }
             }
@@ -1176,7 +1188,8 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
     for (int wv = 0; wv < (t >> 6); wv++) w += part[wv];
     for (int p = pb; p < pe; p++) {
         if (emitMask & (1u << (p - pb))) {
-            outKey[start + w] = eK[p];
+            // candidates leave in the standard form (query << tBits | target); q = query << vqShift | range already
+            outKey[start + w] = WP ? (q << wpBits) | (eK[p] & tgtMask) : eK[p];
             outVal[start + w] = eV[p];
             w++;
         }
@@ -1221,7 +1234,8 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
                   const uint8_t *__restrict__ qRes, const uint64_t *__restrict__ qOff, const int8_t *__restrict__ diagBias,
                   const uint8_t *__restrict__ tMasked, const uint64_t *__restrict__ tOff, const int8_t *__restrict__ mat,
                   int32_t *__restrict__ cScore, uint32_t *__restrict__ cLen,
-                  const int8_t *__restrict__ qProf /* profile queries: [position][21] replaces matrix row + bias */) {
+                  const int8_t *__restrict__ qProf /* profile queries: [position][21] replaces matrix row + bias */,
+                  uint32_t posMask /* stream position bits of the value word: 2^24 - 1, all 32 with wide positions */) {
     __shared__ int8_t smat[441];
     for (int x = threadIdx.x; x < 441; x += blockDim.x) smat[x] = mat[x];
     __syncthreads();
@@ -1229,7 +1243,7 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
     if (c >= nCand) return;
     const uint32_t k = cKey[c];
     const uint32_t q = k >> tBits, sid = k & ((1u << tBits) - 1);
-    const uint16_t d16 = hitDiag[qHitBase[q] + (cVal[c] & 0xFFFFFFu)];
+    const uint16_t d16 = hitDiag[qHitBase[q] + (cVal[c] & posMask)];
     const int d = (int) (int16_t) d16;
     const int qL = (int) (qOff[q + 1] - qOff[q]);
     const int tL = (int) (tOff[sid + 1] - tOff[sid]);
@@ -1341,7 +1355,8 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
                    const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, int covMode, float covThr,
                    const uint8_t *__restrict__ qRes, const int8_t *__restrict__ diagBias, const int8_t *__restrict__ mat,
                    sd_hit *__restrict__ outHits, uint32_t *__restrict__ outCount, int *__restrict__ errFlag,
-                   const int8_t *__restrict__ qProf /* nullable: profile queries */) {
+                   const int8_t *__restrict__ qProf /* nullable: profile queries */,
+                   uint32_t posMask /* stream position bits of the value word */) {
     __shared__ unsigned long long keys[SEL_CAP];
     __shared__ uint32_t pay[SEL_CAP];
     __shared__ unsigned int hist[256];
@@ -1404,7 +1419,7 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
         const uint32_t sid = kKey[x] & ((1u << tBits) - 1);
         const uint32_t top = rescored ? 255u - rescaledByte(x) : 255u - (uint32_t) min(255, kScore[x]);
         return ((unsigned long long) top << 56) | ((unsigned long long) (sid & binMask) << 40) |
-               (unsigned long long) (kVal[x] & 0xFFFFFFu);
+               (unsigned long long) (kVal[x] & posMask);
     };
     // Only the first maxHits + 1 elements of that order are ever read (at most one of them is the identity target).
     // Usually everything at or above the cut fits the LDS arrays; otherwise (very many tied candidates) the candidate
@@ -1570,7 +1585,7 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
                 const uint32_t e = pay[x];
                 o[w].seqId = sidReg[y];
                 o[w].score = (int32_t) (0x7FFFFFFFu - (uint32_t) (keys[x] >> 32));   // as ordered
-                o[w].diagonal = hitDiag[qHitBase[q] + (kVal[e] & 0xFFFFFFu)];
+                o[w].diagonal = hitDiag[qHitBase[q] + (kVal[e] & posMask)];
                 o[w].pad = 0;
                 w++;
             }
@@ -2088,6 +2103,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, hipMemsetAsync(dStats.p, 0, (size_t) bq * 4 * sizeof(uint64_t), ctx->stream));
         hipLaunchKernelGGL(stats_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
                            dHitBase.p, nKmers, nHits, dStats.p);
+        // Stream positions: 24 bits of the value word beside the diagonal byte -- or, for sub-batches with a query of 2^24 hits
+        // and more, the whole word, the diagonal byte travelling in the key (bucket path only: it needs the coarse split)
+        const bool useBuckets = getenv("SD_PF_SORT") == nullptr;
+        const uint64_t posLimit = useBuckets ? 0xFFFFFFF0ull : (1ull << 24);
         // the reference's hit buffer holds maxDbMatches entries per query; where a query overflows it once, the match runs
         // on the two parts separately (query_split_kernel); two overflows are not implemented
         WsView<uint32_t> dQSplit(ctx, "pf.dQSplit");
@@ -2096,7 +2115,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, dSplitFlag.alloc(1));
         SD_HIP(ctx, hipMemsetAsync(dSplitFlag.p, 0, sizeof(int), ctx->stream));
         hipLaunchKernelGGL(query_split_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
-                           dHitBase.p, maxDbMatches, dQSplit.p, dSplitFlag.p);
+                           dHitBase.p, maxDbMatches, dQSplit.p, dSplitFlag.p, posLimit);
         int hSplitFlag = 0;
         SD_HIP(ctx, hipMemcpyAsync(&hSplitFlag, dSplitFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(hStats.data(), dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2104,7 +2123,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         std::vector<uint8_t> hUnsupported;
         if (hSplitFlag) {
             // Queries that overflow the reference's hit buffer twice (the double-overflow route of QueryMatcher.cpp:289-303) or
-            // have >= 2^24 index hits cannot be computed here.  They are taken out of the batch -- their index lists emptied,
+            // have >= 2^32 index hits cannot be computed here.  They are taken out of the batch -- their index lists emptied,
             // offsets re-scanned -- and reported per query (outCount = UINT32_MAX); every other query is computed as usual.
             std::vector<uint32_t> hSplit(bq);
             SD_HIP(ctx, hipMemcpy(hSplit.data(), dQSplit.p, (size_t) bq * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -2116,7 +2135,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     if (!nBad) firstBad = qBeg + x;
                     nBad++;
                 }
-            sdFail(ctx, SD_EUNSUPPORTED, "%u quer%s of the batch [%u, %u) (first: %u) overflow the reference's hit buffer twice or have >= 2^24 index "
+            sdFail(ctx, SD_EUNSUPPORTED, "%u quer%s of the batch [%u, %u) (first: %u) overflow the reference's hit buffer twice or have >= 2^32 index "
                    "hits (double-overflow route of QueryMatcher.cpp:289-303): reported with outCount = UINT32_MAX, the rest of the batch is computed",
                    nBad, nBad == 1 ? "y" : "ies", qBeg, qBeg + bq, firstBad);
             hipLaunchKernelGGL(drop_query_kmers_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKPos.p, dQSplit.p, dKLen.p);
@@ -2125,14 +2144,18 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             SD_HIP(ctx, hipMemcpyAsync(&nHits, dHitBase.p + nKmers, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipMemsetAsync(dSplitFlag.p, 0, sizeof(int), ctx->stream));
             hipLaunchKernelGGL(query_split_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
-                               dHitBase.p, maxDbMatches, dQSplit.p, dSplitFlag.p);
+                               dHitBase.p, maxDbMatches, dQSplit.p, dSplitFlag.p, posLimit);
             SD_HIP(ctx, sdStreamSync(ctx));
         }
 
         hs.reset(new HostScope(ctx, "pf.gather_sort_match"));
         uint32_t nCand = 0, nKept = 0;
         bool bucketDone = false;
-        const bool useBuckets = getenv("SD_PF_SORT") == nullptr;
+        bool widePos = false;
+        if (useBuckets)
+            for (uint32_t x = 0; x < bq && !widePos; x++)
+                widePos = hStats[(size_t) x * 4 + 1] >= (1ull << 24) && !(x < hUnsupported.size() && hUnsupported[x]);
+        const uint32_t posMask = widePos ? 0xFFFFFFFFu : 0xFFFFFFu;
         WsView<uint32_t> dKeyA(ctx, "pf.dKeyA");
         WsView<uint32_t> dKeyB(ctx, "pf.dKeyB");
         WsView<uint32_t> dValA(ctx, "pf.dValA");
@@ -2164,7 +2187,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 ProfScope ps(ctx, "prefilter_gather_hits");
                 hipLaunchKernelGGL(gather_hits_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKStart.p,
                                    dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, (const uint2 *) T->dEntries, tBits, dQHitBase.p,
-                                   dKeyA.p, dValA.p, dDiag.p, wideIdx ? (const uint32_t *) dKStartHi.p : (const uint32_t *) nullptr);
+                                   dKeyA.p, dValA.p, dDiag.p, wideIdx ? (const uint32_t *) dKStartHi.p : (const uint32_t *) nullptr, widePos ? 1 : 0);
             }
             // ---- double-diagonal match: bucketed LDS path, or (fallback / SD_PF_SORT=1) global radix sort + match
             if (useBuckets) {
@@ -2184,6 +2207,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     const uint64_t avgQ = nHits / std::max<uint32_t>(bq, 1);
                     const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 200000;
                     while (cBits < CP_MAX_BITS && tBits - (cBits + 1) >= 8 && (avgQ >> cBits) > perVQ) cBits++;
+                    // wide stream positions need the split: it is where the diagonal byte moves into the key (8 free bits)
+                    while (widePos && cBits < CP_MAX_BITS && tBits - (cBits + 1) >= 8 && (cBits < 1 || tBits - cBits > 24)) cBits++;
+                    if (widePos && (cBits < 1 || tBits - cBits > 24))
+                        return sdFail(ctx, SD_EUNSUPPORTED, "a query with >= 2^24 index hits against a target set of %u sequences", T->nSeq);
                     if (cBits > 0) {
                         std::vector<uint64_t> hQHB(bq + 1);
                         SD_HIP(ctx, hipMemcpyAsync(hQHB.data(), dQHitBase.p, (bq + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2209,7 +2236,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                            dSegCount.p, dVQHitBase.p);
                         if (nSeg > 0)
                             hipLaunchKernelGGL(coarse_scatter_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, bq, dQHitBase.p, dSegBase.p, tBits,
-                                               cBits, dSegCount.p, dKeyA.p, dValA.p, dKeyC.p, dValC.p);
+                                               cBits, dSegCount.p, dKeyA.p, dValA.p, dKeyC.p, dValC.p,
+                                               widePos ? (const uint16_t *) dDiag.p : (const uint16_t *) nullptr);
                         SD_HIP(ctx, sdStreamSync(ctx));   // hSegBase is read by the upload until here
                         pHitBase = dVQHitBase.p;
                         pKey = dKeyC.p;
@@ -2261,7 +2289,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         hipLaunchKernelGGL((bucket_match_kernel<128, PF_BUCKET_CAP>), dim3((unsigned) totalBins), dim3(128), 0, ctx->stream,
                                            nVQ, dBinBase.p, dQLog2.p, tBitsV, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p,
                                            dValA.p, dBktEmit.p, dFlag.p, (const uint32_t *) nullptr, dBigList.p, dBigCount, bigCap,
-                                           dQSplit.p, cBits);
+                                           dQSplit.p, cBits, widePos ? tBitsV : 0);
                     }
                     uint32_t nBig = 0;
                     SD_HIP(ctx, hipMemcpyAsync(&nBig, dBigCount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2271,7 +2299,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         hipLaunchKernelGGL((bucket_match_kernel<256, PF_BUCKET_CAP_BIG>), dim3(nBig), dim3(256), 0, ctx->stream, nVQ,
                                            dBinBase.p, dQLog2.p, tBitsV, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p, dValA.p,
                                            dBktEmit.p, dFlag.p, (const uint32_t *) dBigList.p, (uint32_t *) nullptr,
-                                           (uint32_t *) nullptr, 0u, dQSplit.p, cBits);
+                                           (uint32_t *) nullptr, 0u, dQSplit.p, cBits, widePos ? tBitsV : 0);
                     }
                     rc = exclusiveScanWiden(ctx, dBktEmit.p, dEmitOff.p, nSlots + 1, scanTmp);
                     if (rc != SD_OK) return rc;
@@ -2299,7 +2327,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     ProfScope ps(ctx, "prefilter_gather_hits");
                     hipLaunchKernelGGL(gather_hits_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKStart.p,
                                        dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, (const uint2 *) T->dEntries, tBits, dQHitBase.p,
-                                       dKeyA.p, dValA.p, dDiag.p, wideIdx ? (const uint32_t *) dKStartHi.p : (const uint32_t *) nullptr);
+                                       dKeyA.p, dValA.p, dDiag.p, wideIdx ? (const uint32_t *) dKStartHi.p : (const uint32_t *) nullptr, 0);
                 }
             }
             if (!bucketDone) {
@@ -2330,6 +2358,14 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             nCand = (uint32_t) nc64;
             }
         }
+        if (widePos && !bucketDone) {
+            // the global-sort fallback carries 24-bit positions only: the heavy queries of this sub-batch are reported, not guessed
+            if (hUnsupported.empty()) hUnsupported.assign(bq, 0);
+            for (uint32_t x = 0; x < bq; x++)
+                if (hStats[(size_t) x * 4 + 1] >= (1ull << 24)) hUnsupported[x] = 1;
+            sdFail(ctx, SD_EUNSUPPORTED, "queries with >= 2^24 index hits in a sub-batch that fell back to the global sort (batch [%u, %u)): "
+                   "reported with outCount = UINT32_MAX", qBeg, qBeg + bq);
+        }
         hs.reset(new HostScope(ctx, "pf.score_keep"));
         if (nCand > 0) {
             if (!bucketDone) {
@@ -2359,7 +2395,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 ProfScope ps(ctx, "prefilter_score_diag");
                 hipLaunchKernelGGL(score_diag_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p,
                                    dDiag.p, dQHitBase.p, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p,
-                                   dProfAln);
+                                   dProfAln, posMask);
             }
             hipLaunchKernelGGL(cand_stats_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCLen.p, tBits,
                                (unsigned long long *) dStats.p);
@@ -2404,11 +2440,11 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             if (maxHits + 1 <= 2048)
                 hipLaunchKernelGGL(select_hits_kernel<4096>, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
                                    dDiag.p, dQHitBase.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
-                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln);
+                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask);
             else   // up to 4 095 hits per query (--max-seqs 2N beyond ~1 000 proteomes)
                 hipLaunchKernelGGL(select_hits_kernel<8192>, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
                                    dDiag.p, dQHitBase.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
-                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln);
+                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask);
         }
         SD_HIP(ctx, hipGetLastError());
         hs.reset(new HostScope(ctx, "pf.download"));

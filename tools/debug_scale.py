@@ -20,6 +20,8 @@ def main(which):
     copies, max_hits, nq = 300, 1000, 24
     if which == 'A':
         n_seq, L = 17500000, 48
+    elif which.startswith('E'):   # queries with >= 2^24 index hits (wide stream positions) beside ordinary ones, one overflow of the hit buffer
+        n_seq, L, copies, max_hits, nq = 5200000, 48, 300, 1000, 12
     elif which.startswith('C'):   # more saturated homologs than the result list holds: the rescoring path with a long list
         n_seq, L, copies, max_hits, nq = 400000, 300, 6000, 4000, 6
     else:
@@ -28,9 +30,10 @@ def main(which):
     off = (np.arange(n_seq + 1, dtype=np.uint64) * L)
     # families: query i has 300 mutated copies spread over the DB
     queries = rng.choice(n_seq, nq, replace=False)
-    for q in queries:
+    for qi, q in enumerate(queries):
         src = res[q * L:(q + 1) * L]
-        for t in rng.choice(n_seq, copies, replace=False):
+        ncop = 420000 if (which.startswith('E') and qi in (3, 7)) else copies
+        for t in rng.choice(n_seq, ncop, replace=False):
             c = src.copy()
             m = rng.random(L) < 0.15
             c[m] = rng.integers(0, 20, int(m.sum()))
@@ -54,7 +57,7 @@ def main(which):
     sw_b, dg_b, km_b = host.comp_bias(qres, qoff, k=k)
     par = api.prefilter_params(host, idx.n, kmer_thr=thr, max_hits=max_hits, cov_thr=0.0, k=k)
     hits, cnt, st = api.prefilter(gpu, tgt, par, qres, qoff, km_b, dg_b, queries.astype(np.uint32), want_stats=True)
-    print('device rows', int(cnt.sum()), 'index hits', int(st[:, 1].sum()), flush=True)
+    print('device rows', int(cnt[cnt != 0xFFFFFFFF].sum()), 'index hits per query', st[:, 1].tolist(), 'not computed', int((cnt == 0xFFFFFFFF).sum()), flush=True)
     lut = np.frombuffer(ALPHABET.encode(), np.uint8)
     blob = lut[res].tobytes()
     ref = Ref(k)
