@@ -60,3 +60,21 @@ def test_index_of_more_than_2_32_entries(gpu, host, monkeypatch):
     assert np.array_equal(c0, c1) and int(c0.sum()) > 2 * ps.n
     for q in range(ps.n):
         assert np.array_equal(h0[q, :int(c0[q])], h1[q, :int(c1[q])]), q
+
+
+def test_queries_with_2_24_index_hits_and_more():
+    """stream positions beyond 24 bits: in a sub-batch that holds a query with >= 2^24 index hits the value word of a hit is
+    the whole position and the diagonal byte travels in the key from the coarse split on (tools/scale_cases.py E: 5.2*10^6
+    targets, two families of 7.2*10^5 copies).  The query with 1.8*10^7 hits -- one overflow of the reference's hit buffer
+    on the way -- equals the real reference row for row; the one with 2.1*10^7 overflows that buffer twice and is reported
+    through its count slot; the ten ordinary queries of the same batch are unaffected."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import scale_cases
+    r = scale_cases.run('E', log=lambda *a: None)
+    heavy = [x for x, h in enumerate(r['index_hits']) if h >= (1 << 24)]
+    assert len(heavy) == 2 and r['mismatching'] == []
+    twice = [x for x in heavy if r['index_hits'][x] >= 2 * r['max_db_matches']]
+    assert r['refused'] == twice and len(twice) == 1
+    assert r['rows'] == 11 * 1000
