@@ -86,7 +86,7 @@ def test_wide_index_is_the_same_index(monkeypatch):
     from spacedust_amd.synth import make_proteomes
     ps = make_proteomes(n_proteomes=3, genes_per_proteome=150, n_families=200, seed=5)
     host = api.Host(threads=4)
-    for k, thr in ((6, 112), (7, 122)):
+    for k, thr in ((6, 112),):   # k = 7 (a 5-GB offset table per build) is covered on the GPU box: tests/test_gpu_prefilter.py
         a = host.build_index(ps.residues, ps.offsets, k=k, kmer_thr=thr)
         assert a.block_base is None
         monkeypatch.setenv('SD_INDEX_WIDE', '1')
