@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--genes', type=int, default=3000)
     ap.add_argument('--batch', type=int, default=10, help='query proteomes per rank and step')
     ap.add_argument('--chunk', type=int, default=10000, help='queries per device chunk')
+    ap.add_argument('--max-seqs', type=int, default=0, help='result list length (default: max(300, 2 x proteomes), every target set reachable)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg (and the parity check that rides on it)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--cpu-threads', type=int, default=0)
@@ -161,7 +162,7 @@ def measure(args, rank, local_rank, world, dist, torch):
     ps = make_proteomes(P, genes_per_proteome=args.genes, seed=0x5ED0 + 2)
     t_gen = time.time() - t0
     db = SetDB.from_proteomes(ps)
-    max_seqs = max(300, 2 * P)
+    max_seqs = args.max_seqs if args.max_seqs > 0 else max(300, 2 * P)
     # the target index: built once (rank 0, all of the node's cores while the others wait) and broadcast
     t0 = time.time()
     index = None
