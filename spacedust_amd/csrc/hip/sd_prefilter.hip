@@ -554,9 +554,10 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
 }
 
 // K3: gather index lists into the hit stream; key = (qLocal << tBits) | seqId, value = low 8 bits of the diagonal
-// (all the double-diagonal match needs) << 24 | position of the hit in its query's stream (< 2^24: the caller
-// rejects queries with >= maxDbMatches ~ 2^21 hits).  The full 16-bit diagonal stays in hitDiag, in stream order,
-// and is looked up for the few surviving candidates only.
+// (all the double-diagonal match needs) << 24 | position of the hit in its query's stream; sub-batches holding a query with
+// 2^24 hits and more set widePos: the value is then the whole position and the diagonal byte is moved into the key by
+// coarse_scatter_kernel.  The full 16-bit diagonal stays in hitDiag, in stream order, and is looked up for the few
+// surviving candidates only.
 __global__ void __launch_bounds__(256)
 gather_hits_kernel(uint64_t nKmers, const uint32_t *__restrict__ kStart, const uint32_t *__restrict__ kLen,
                    const uint32_t *__restrict__ kPos, const uint64_t *__restrict__ hitBase,

@@ -95,7 +95,7 @@ int tantanMask(const MaskCtx &ctx, uint8_t *seq, int L, double minMaskProb);
 
 // ---------------------------------------------------------------------------
 // Target k-mer index (M/src/prefiltering/IndexTable.h, IndexBuilder.cpp:55-239)
-// Layout is ours (HBM-friendly): u32 offsets (nEntries < 2^32), SoA entries.
+// Layout is ours (HBM-friendly): u32 offsets (relative to a u64 base per 65 536 k-mers once nEntries >= 2^32), SoA entries.
 // ---------------------------------------------------------------------------
 // calloc-backed uint32 array: a fresh 20^k table (k = 7: 5 GB) comes as untouched zero pages instead of being
 // written once by a constructor; pages are first touched by the parallel passes that fill it
