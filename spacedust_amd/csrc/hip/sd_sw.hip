@@ -370,8 +370,27 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
     if (!have || l != 0) return;
     tasks[id].maxv = maxv;
     tasks[id].band = band;
-    // traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581)
-    __threadfence();
+    res[2 * id] = -3;   // band found, directions written: sw_traceback_walk_kernel walks the path
+}
+
+// The walk of the LDS-band / global-band kernel's tasks, one task per lane: inside sw_traceback_kernel it was lane 0 of a
+// half wavefront chasing ~qLen + tLen dependent loads with 31 lanes parked; here every lane chases its own chain.
+// traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581)
+template <bool GLOBAL>
+__global__ void __launch_bounds__(256)
+sw_traceback_walk_kernel(const TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
+                         const uint8_t *__restrict__ tRes, const int8_t *__restrict__ dirs, char *__restrict__ bt,
+                         int32_t *__restrict__ res, const uint32_t *__restrict__ order /* nullable */) {
+    const uint32_t lid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lid >= nTasks) return;
+    const uint32_t id = order ? order[lid] : lid;
+    if (res[2 * id] != -3) return;
+    const TbTask tk = tasks[id];
+    const int qLen = tk.qLen, tLen = tk.tLen, band = tk.band;
+    const int width_d = band * 2 + 1;
+    const uint8_t *q = qRes + tk.qAbs;
+    const uint8_t *t = tRes + tk.tAbs;
+    const int8_t *direction = dirs + tk.dirOff + (GLOBAL ? tbGlobalIntBytes(band) : 0);
     // the path is walked from its end, so the characters are written from the end of the task's region backwards:
     // the finished backtrace is the last `len` bytes of [btOff, btOff + qLen + tLen + 2)
     int i = qLen - 1, j = tLen - 1, state = 2;
@@ -384,7 +403,7 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
         x = x > 0 ? x : 0;
         x = j - x;
         if (x < 0 || x >= width_d) { bad = true; break; }
-        const int code = __hip_atomic_load(&direction[(long long) width_d * i + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int code = direction[(long long) width_d * i + x];
         int dcode;
         const int dE = (code & 1) ? 3 : 2, dF = (code & 2) ? 5 : 4;
         if (state == 0) dcode = dE;
@@ -989,6 +1008,17 @@ k_gate_tb(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ,
     btBytes[i] = (uint64_t) t.qLen + t.tLen + 2;
 }
 
+// this round's tasks: everything whose direction scratch ends inside the budget (prefix of the pending tasks in pair
+// order: the first one starts at 0); the others keep their keys and come again
+__global__ void __launch_bounds__(256)
+k_tb_round(uint32_t nPairs, const uint32_t *__restrict__ keys, const uint64_t *__restrict__ dirOff,
+           const uint64_t *__restrict__ dirBytes, uint64_t budget, uint32_t *__restrict__ keysRound) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs) return;
+    const uint32_t k = keys[i];
+    keysRound[i] = (k != TBKEY_INVALID && dirOff[i] + dirBytes[i] <= budget) ? k : TBKEY_INVALID;
+}
+
 __global__ void __launch_bounds__(256)
 k_tb_offsets(uint32_t nPairs, const uint32_t *__restrict__ keys, const uint64_t *__restrict__ dirOff,
              const uint64_t *__restrict__ btOff, TbTask *__restrict__ tb) {
@@ -1002,11 +1032,13 @@ k_tb_offsets(uint32_t nPairs, const uint32_t *__restrict__ keys, const uint64_t 
 __global__ void __launch_bounds__(256)
 k_tb_collect(uint32_t nPairs, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, TbTask *__restrict__ tb,
              const int32_t *__restrict__ tbRes, uint64_t *__restrict__ dirBytes, uint64_t *__restrict__ btLenOut,
-             sd_sw_result *__restrict__ res, int *__restrict__ errFlag, int maxBand) {
+             sd_sw_result *__restrict__ res, int *__restrict__ errFlag, int maxBand,
+             const uint32_t *__restrict__ keysRound /* what this round ran: deferred tasks keep key and scratch size */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPairs) return;
     vals[i] = i;
     if (keys[i] == TBKEY_INVALID) { dirBytes[i] = 0; return; }
+    if (keysRound[i] == TBKEY_INVALID) return;
     const int len = tbRes[2 * i];
     if (len == -2) {
         const int band = tb[i].band;   // already doubled by the kernel that gave up
@@ -1647,13 +1679,17 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     {
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) SCRATCH_BUDGET = std::max<uint64_t>(SCRATCH_BUDGET, totalB / 4);
+        if (const char *e = getenv("SD_TB_BUDGET")) SCRATCH_BUDGET = std::max<uint64_t>(1u << 20, strtoull(e, nullptr, 10));   // tests: force slices
     }
-    for (int round = 0; round < 24; round++) {
+    uint32_t *dKeysRound = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "tb.keysRound", N + 1, &dKeysRound));
+    for (int round = 0; round < 4096; round++) {   // band doublings, and slices of what the direction scratch holds at a time
         SD_HIP(ctx, hipMemsetAsync(dDirBytes + N, 0, sizeof(uint64_t), ctx->stream));
         rc = devExclusiveScan(ctx, dDirBytes, dDirOff, N + 1);
         if (rc != SD_OK) return rc;
-        hipLaunchKernelGGL(k_tb_offsets, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dDirOff, dBtOff, dTb);
-        rc = devSortPairs(ctx, dKeys, dKeysS, dVals, dOrder, nPairs, 16);
+        hipLaunchKernelGGL(k_tb_round, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dDirOff, dDirBytes, SCRATCH_BUDGET, dKeysRound);
+        hipLaunchKernelGGL(k_tb_offsets, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeysRound, dDirOff, dBtOff, dTb);
+        rc = devSortPairs(ctx, dKeysRound, dKeysS, dVals, dOrder, nPairs, 16);
         if (rc != SD_OK) return rc;
         hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysS, nPairs, 4096u, dBounds, (int) N_TB_CLASSES + 1);
         uint32_t hb[N_TB_CLASSES + 1];
@@ -1668,9 +1704,10 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
             fprintf(stderr, " lds %u %u %u global %u dir %.1f MB\n", hb[N_TB_NARROW + 1] - hb[N_TB_NARROW], hb[N_TB_NARROW + 2] - hb[N_TB_NARROW + 1],
                     hb[N_TB_NARROW + 3] - hb[N_TB_NARROW + 2], hb[N_TB_NARROW + 4] - hb[N_TB_NARROW + 3], dirTotal / 1e6);
         }
-        if (dirTotal > SCRATCH_BUDGET) return sdFail(ctx, SD_ENOMEM, "traceback direction scratch of %llu bytes exceeds the budget; use smaller batches", (unsigned long long) dirTotal);
+        // more direction bytes than the budget (long result lists of homologs, e.g. --max-seqs 4000 on a 10 000-proteome target):
+        // this round runs the prefix that fits (k_tb_round), the rest follows in later rounds
         int8_t *dDir = nullptr;
-        SD_HIP(ctx, wsGet(ctx, "tb.dir", dirTotal + 64, &dDir));
+        SD_HIP(ctx, wsGet(ctx, "tb.dir", std::min<uint64_t>(dirTotal, SCRATCH_BUDGET) + 64, &dDir));
         for (int ci = 0; ci < N_TB_NARROW; ci++) {
             const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
             if (cnt == 0) continue;
@@ -1704,6 +1741,8 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
                 hipLaunchKernelGGL(sw_traceback_kernel<false>, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
                                    queries->dBias, targets->dRes, dMat, go, ge, ldsStride, dDir, dBt, dTbRes, dOrder + begin,
                                    ldsClass[ci] - 1, (const int8_t *) nullptr);
+            hipLaunchKernelGGL(sw_traceback_walk_kernel<false>, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, dTb, cnt, queries->dRes,
+                               targets->dRes, dDir, dBt, dTbRes, dOrder + begin);
         }
         {   // bands beyond the LDS classes: band arrays in global scratch, one attempt per round
             const uint32_t begin = hb[N_TB_NARROW + 3], cnt = hb[N_TB_NARROW + 4] - hb[N_TB_NARROW + 3];
@@ -1717,11 +1756,13 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
                     hipLaunchKernelGGL((sw_traceback_kernel<false, true>), dim3((cnt + 1) / 2), dim3(64), 0, ctx->stream, dTb, cnt, queries->dRes,
                                        queries->dBias, targets->dRes, dMat, go, ge, INT_MAX, dDir, dBt, dTbRes, dOrder + begin, 0,
                                        (const int8_t *) nullptr);
+                hipLaunchKernelGGL(sw_traceback_walk_kernel<true>, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, dTb, cnt, queries->dRes,
+                                   targets->dRes, dDir, dBt, dTbRes, dOrder + begin);
             }
         }
         SD_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_tb_collect, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dVals, dTb, dTbRes, dDirBytes, dBtLen,
-                           dRes, dErr, 4 * 65536);
+                           dRes, dErr, 4 * 65536, dKeysRound);
     }
     if (getenv("SD_DEBUG_TB")) {   // band statistics of the finished tasks
         std::vector<TbTask> hT(nPairs);
@@ -2108,6 +2149,12 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
                     hipLaunchKernelGGL((sw_traceback_kernel<false, true>), dim3((cnt + 1) / 2), dim3(64), 0, ctx->stream, dT.p, cnt,
                                        queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, INT_MAX, dDir.p, dBt.p, dRes.p,
                                        (const uint32_t *) nullptr, 0, (const int8_t *) nullptr);
+                if (cls)
+                    hipLaunchKernelGGL(sw_traceback_walk_kernel<false>, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, dT.p, cnt, queries->dRes,
+                                       targets->dRes, dDir.p, dBt.p, dRes.p, (const uint32_t *) nullptr);
+                else
+                    hipLaunchKernelGGL(sw_traceback_walk_kernel<true>, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, dT.p, cnt, queries->dRes,
+                                       targets->dRes, dDir.p, dBt.p, dRes.p, (const uint32_t *) nullptr);
             }
             SD_HIP(ctx, hipGetLastError());
             TbTask *back = nullptr;

@@ -182,6 +182,31 @@ def test_sw_scores_beyond_int16_saturate_like_the_word_kernel(gpu, host, oracle)
             assert bt == str(g['sat_bt'][x]), (hostpath, x)
 
 
+def test_sw_traceback_scratch_in_slices(gpu, host, monkeypatch):
+    """more traceback direction bytes than the scratch budget (long result lists of homologs on very large targets): the
+    rounds run the prefix of the pending tasks that fits and come back for the rest -- same records, same backtraces as
+    with everything in one round (SD_TB_BUDGET forces a 1-MB budget)"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=6, genes_per_proteome=260, n_families=400, seed=23)
+    rng = np.random.default_rng(11)
+    pq, pt = _pairs(ps, rng, 500)
+    sw_bias, _, _ = host.comp_bias(ps.residues, ps.offsets)
+    mat, _, _ = host.matrix(0)
+    ss = gpu.seqset(ps.residues, ps.offsets, sw_bias)
+    par = gpu.sw_params(mat, int(ps.offsets[-1]), cov_thr=0.0)
+    a, pa = gpu.sw_align(par, ss, ss, pq, pt, identity=(pq == pt))
+    monkeypatch.setenv('SD_TB_BUDGET', '1048576')
+    b, pb = gpu.sw_align(par, ss, ss, pq, pt, identity=(pq == pt))
+    monkeypatch.delenv('SD_TB_BUDGET')
+    assert int((a['btLen'] > 0).sum()) > 1000
+    for f in ('score', 'qStart', 'qEnd', 'tStart', 'tEnd', 'identical', 'btLen', 'flags'):
+        assert np.array_equal(a[f], b[f]), f
+    for x in np.flatnonzero(a['btLen'] > 0):
+        sa = pa[int(a['btOffset'][x]):int(a['btOffset'][x]) + int(a['btLen'][x])]
+        sb = pb[int(b['btOffset'][x]):int(b['btOffset'][x]) + int(b['btLen'][x])]
+        assert np.array_equal(sa, sb), x
+
+
 def test_sw_device_vs_host_orchestration(gpu, host):
     """the device-resident gating / task building gives the same records as the host-side one, at a size the
     oracle would not finish in seconds (all sw modes, all coverage modes)"""
