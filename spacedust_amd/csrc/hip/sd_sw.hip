@@ -1678,7 +1678,10 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     uint64_t SCRATCH_BUDGET = 16ull << 30;
     {
         size_t freeB = 0, totalB = 0;
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) SCRATCH_BUDGET = std::max<uint64_t>(SCRATCH_BUDGET, totalB / 4);
+        // a quarter of the device at most -- and no more than a third of what is free right now (the index, the prefilter
+        // lanes and the other alignment lane hold the rest)
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0)
+            SCRATCH_BUDGET = std::max<uint64_t>(1ull << 30, std::min<uint64_t>(totalB / 4, freeB / 3));
         if (const char *e = getenv("SD_TB_BUDGET")) SCRATCH_BUDGET = std::max<uint64_t>(1u << 20, strtoull(e, nullptr, 10));   // tests: force slices
     }
     uint32_t *dKeysRound = nullptr;
@@ -1707,7 +1710,12 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         // more direction bytes than the budget (long result lists of homologs, e.g. --max-seqs 4000 on a 10 000-proteome target):
         // this round runs the prefix that fits (k_tb_round), the rest follows in later rounds
         int8_t *dDir = nullptr;
-        SD_HIP(ctx, wsGet(ctx, "tb.dir", std::min<uint64_t>(dirTotal, SCRATCH_BUDGET) + 64, &dDir));
+        if (wsGet(ctx, "tb.dir", std::min<uint64_t>(dirTotal, SCRATCH_BUDGET) + 64, &dDir) != hipSuccess) {
+            (void) hipGetLastError();
+            if (SCRATCH_BUDGET <= (256ull << 20)) return sdFail(ctx, SD_ENOMEM, "traceback direction scratch: out of device memory");
+            SCRATCH_BUDGET /= 2;   // another lane took the memory meanwhile: smaller slices
+            continue;
+        }
         for (int ci = 0; ci < N_TB_NARROW; ci++) {
             const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
             if (cnt == 0) continue;
