@@ -42,6 +42,8 @@ int sd_ctx_create_prio(int device, int priority, sd_ctx **out);
 void sd_ctx_destroy(sd_ctx *ctx);
 const char *sd_last_error(sd_ctx *ctx);
 int sd_device_name(sd_ctx *ctx, char *buf, size_t cap);
+/* free / total device memory right now (hipMemGetInfo) */
+int sd_device_memory(sd_ctx *ctx, uint64_t *freeBytes, uint64_t *totalBytes);
 int sd_synchronize(sd_ctx *ctx);
 
 /* Kernel timing with HIP events on the library's own stream (bench.py roofline leg).

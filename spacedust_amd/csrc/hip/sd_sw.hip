@@ -1383,6 +1383,16 @@ void sd_ctx_destroy(sd_ctx *ctx) {
 
 const char *sd_last_error(sd_ctx *ctx) { return ctx ? ctx->lastError.c_str() : "no context"; }
 
+int sd_device_memory(sd_ctx *ctx, uint64_t *freeBytes, uint64_t *totalBytes) {
+    if (!ctx) return SD_EINVAL;
+    (void) hipSetDevice(ctx->device);
+    size_t f = 0, t = 0;
+    SD_HIP(ctx, hipMemGetInfo(&f, &t));
+    if (freeBytes) *freeBytes = f;
+    if (totalBytes) *totalBytes = t;
+    return SD_OK;
+}
+
 int sd_device_name(sd_ctx *ctx, char *buf, size_t cap) {
     if (!ctx || !buf || cap == 0) return SD_EINVAL;
     snprintf(buf, cap, "%s (%s, %d CUs)", ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount);

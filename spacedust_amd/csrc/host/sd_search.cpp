@@ -308,6 +308,11 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     rc = sd_seqset_create(s->ctxAl, target->residues, target->offsets, target->n, nullptr, &s->tSeqs);
     if (rc != SD_OK) return rc;
     s->seconds[T_UPLOAD] = nowSec() - t0;
+    {   // a target that fills most of the device (10 000 proteomes: 84 GB of index + sequences) leaves room for one prefilter
+        // and one alignment workspace, not two of each
+        uint64_t freeB = 0, totalB = 0;
+        if (sd_device_memory(s->ctxPf, &freeB, &totalB) == SD_OK && totalB > 0 && freeB < totalB / 4 * 3) s->pfLanes = s->alignLanes = 1;
+    }
     memset(&s->pfPar, 0, sizeof(s->pfPar));
     s->pfPar.kmerSize = s->k;
     s->pfPar.kmerThr = s->kmerThr;
