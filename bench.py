@@ -192,9 +192,20 @@ def measure(args, rank, local_rank, world, dist, torch):
             arrays.append(t.cpu().numpy().view(dt))
             del t
         index_how += ', broadcast over %s (%.2f GB)' % ('gloo' if rehearsal else 'RCCL', sum(a.nbytes for a in arrays) / 1e9)
+        # a wide index (>= 2^32 entries, 10 000 proteomes) also carries its block bases
+        nbb = torch.tensor([0 if (rank != 0 or index.block_base is None) else len(index.block_base)], dtype=torch.int64)
+        nbb = to_dev(nbb)
+        dist.broadcast(nbb, 0)
+        block_base = None
+        if int(nbb.item()) > 0:
+            t = torch.from_numpy(np.ascontiguousarray(index.block_base).view(np.uint8).copy()) if rank == 0 else \
+                torch.empty(int(nbb.item()) * 8, dtype=torch.uint8)
+            t = to_dev(t)
+            dist.broadcast(t, 0)
+            block_base = t.cpu().numpy().view(np.uint64)
         if rank != 0:
             from spacedust_amd.api import IndexArrays
-            index = IndexArrays(k, kmer_thr, ps.offsets, *arrays)
+            index = IndexArrays(k, kmer_thr, ps.offsets, *arrays, block_base=block_base)
     t_index = time.time() - t0
     cs = ClusterSearch(gpu, host, db, max_seqs=max_seqs, filter_self_match=True, chunk_queries=args.chunk, index=index)
     n_global = world * B

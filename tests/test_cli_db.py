@@ -114,4 +114,16 @@ def test_createindex_file_equals_the_reference_index_file(setdb):
                 h.update(b)
                 left -= len(b)
             assert h.hexdigest() == want[k], k
+    # the wide index form (>= 2^32 entries; forced here) goes to the file as the same absolute size_t offsets: identical bytes
+    import subprocess
+    from dbutil import SDGPU
+    first = open(setdb / 'genome.idx', 'rb').read()
+    os.remove(setdb / 'genome.idx')
+    p = subprocess.run([SDGPU, 'createindex', str(setdb / 'genome'), str(setdb / 'tmp'), '-s', '5.7', '--threads', '8', '-v', '0'],
+                       env=dict(os.environ, SD_INDEX_WIDE='1'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr
+    second = open(setdb / 'genome.idx', 'rb').read()
+    k_off, k_len = idx[1]   # ENTRIESOFFSETS and everything index-related; the GENERATOR / matrix text keys are compared above
+    assert len(first) == len(second) and first[k_off:k_off + k_len] == second[k_off:k_off + k_len]
+    assert hashlib.md5(second[idx[0][0]:idx[0][0] + idx[0][1]]).hexdigest() == want[0]
     os.remove(setdb / 'genome.idx')
