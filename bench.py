@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=10)   # 10 steps x 10 query proteomes = one all-vs-all pass over the 100 proteomes
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--proteomes', type=int, default=100)
     ap.add_argument('--genes', type=int, default=3000)
