@@ -1,0 +1,525 @@
+// k-mer-major join: the front half of the prefilter (similar k-mers -> index hits) without a random table access
+// per k-mer.  Included by sd_prefilter.hip (inside its anonymous namespace).
+//
+// The reference walks a query position by position and copies the index list of every similar k-mer
+// (QueryMatcher.cpp:213-346, IndexTable.h:176-180).  Done literally on the device that is one random 8-byte read into
+// the 256-MB offset table plus one random read of a (mostly one- or two-entry) list per k-mer: 64-128 B fetched per
+// 8 useful.  Here a sub-batch's similar k-mers (~4*10^8 over a table of 6.4*10^7 k-mers) are first partitioned by
+// k-mer into 2 048 ranges, each range is then joined with its slice of the offset table and of the entry array --
+// 128 KB + a few hundred KB, read once and served from the XCD's L2 afterwards -- and the hits leave the join already
+// split into groups of queries, which is the input form of the per-query bucket machinery (partition_hits /
+// bucket_match).  Order: a k-mer carries its ordinal in the query's enumeration (kOrd), and an index list holds a
+// target at most once (IndexTable::addSequence adds a sequence's k-mer only at its first position,
+// IndexTable.h:383-392, lists sorted by sequence id, :182-189), so (kOrd, seqId) orders the hits of a query exactly
+// like the reference's hit buffer; the value word carries kOrd where the lookup path carries the stream position.
+//
+// Both partitions (k-mers by k-mer range, hits by query group) are done by JP_WGS persistent workgroups in two passes
+// with no global atomics: pass one counts per (workgroup, bin), a column prefix turns the counts into private write
+// cursors, pass two reorders tile by tile in LDS and appends runs at those cursors -- a workgroup's writes into a bin
+// are consecutive in memory, so partial lines merge in its XCD's L2.
+
+constexpr int JP_WGS = 256;            // persistent workgroups (one per CU)
+constexpr int JP_NT = 1024;
+constexpr int KP_BINS = 2048;          // k-mer ranges: bin = kmer >> 15 (k = 6: 1 954 of them in use)
+constexpr int KP_SHIFT = 53;           // element >> 53 = kmer >> 15
+constexpr int KP_TILE = 16384;
+constexpr int KP_PER = KP_TILE / JP_NT;
+constexpr int JQ_MAX = 4096;           // queries per sub-batch
+constexpr int JJ_WGS = 768;            // persistent workgroups of the join (three per CU)
+constexpr int JJ_NT = 512;
+constexpr int JC = 1024;               // k-mers per join chunk
+constexpr uint32_t JOIN_ORD_LIMIT = 1u << 24;   // k-mers per query the value word can order
+
+// element of the k-mer stream: kmer << 38 | stream index (< 2^30) << 8 | low byte of the query position
+__device__ __forceinline__ uint64_t jpElem(uint32_t kmer, uint64_t streamIdx, int i) {
+    return ((uint64_t) kmer << 38) | (streamIdx << 8) | (uint64_t) (i & 0xFF);
+}
+
+// K2 (join form): similar k-mers in the reference's enumeration order, no index access
+__global__ void __launch_bounds__(256)
+emit_kmers_join_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
+                       const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
+                       const int16_t *__restrict__ ext3Score, const uint16_t *__restrict__ ext3Index,
+                       const uint64_t *__restrict__ kmerBase, uint64_t *__restrict__ elems) {
+    const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= nPos) return;
+    PosInfo pi = decodePos(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr);
+    if (!pi.ok) return;
+    const int16_t *row0 = ext3Score + (size_t) pi.idx0 * 8000;
+    const int16_t *row1 = ext3Score + (size_t) pi.idx1 * 8000;
+    const uint16_t *ix0 = ext3Index + (size_t) pi.idx0 * 8000;
+    const uint16_t *ix1 = ext3Index + (size_t) pi.idx1 * 8000;
+    const int cutoff1 = (int) (short) (pi.thr - (int) row1[0]);
+    const int n0 = countGE(row0, 8000, cutoff1);
+    uint64_t base = kmerBase[p];
+    __shared__ uint32_t sIncl[4][64];
+    __shared__ uint32_t sK0[4][64];
+    uint32_t *myIncl = sIncl[threadIdx.x >> 6], *myK0 = sK0[threadIdx.x >> 6];
+    for (int a0 = 0; a0 < n0; a0 += 64) {
+        const int a = a0 + lane;
+        uint32_t c = 0;
+        if (a < n0) c = (uint32_t) countGE(row1, 8000, (int) (short) (pi.thr - (int) row0[a]));
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const uint32_t chunkTotal = __shfl(incl, 63, 64);
+        __builtin_amdgcn_wave_barrier();
+        myIncl[lane] = incl;
+        myK0[lane] = a < n0 ? (uint32_t) ix0[a] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t t = lane; t < chunkTotal; t += 64) {
+            int lo = 0, hi = 63;   // smallest o with incl[o] > t
+#pragma unroll
+            for (int st = 0; st < 6; st++) {
+                const int mid = (lo + hi) >> 1;
+                if (myIncl[mid] > t) hi = mid;
+                else lo = mid + 1;
+            }
+            const uint32_t before = lo ? myIncl[lo - 1] : 0u;
+            const uint32_t km = myK0[lo] + 8000u * (uint32_t) ix1[t - before];
+            elems[base + t] = jpElem(km, base + t, pi.i);
+        }
+        base += chunkTotal;
+    }
+}
+
+// first stream index of every query (32 bit: a sub-batch holds at most 2^30 k-mers); flag[0] |= 1 when a query has
+// JOIN_ORD_LIMIT k-mers or more
+__global__ void join_query_base_kernel(uint32_t nQ, const uint64_t *__restrict__ posBase, const uint64_t *__restrict__ kmerBase,
+                                       uint32_t *__restrict__ qKmerBase, int *__restrict__ flag) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nQ) return;
+    const uint64_t b = kmerBase[posBase[q]];
+    qKmerBase[q] = (uint32_t) b;
+    if (q < nQ && kmerBase[posBase[q + 1]] - b >= JOIN_ORD_LIMIT) atomicOr(flag, 1);
+}
+
+// ---- partition of the k-mer stream by k-mer range
+__global__ void __launch_bounds__(JP_NT)
+kp_hist_kernel(const uint64_t *__restrict__ elems, uint64_t n, uint32_t *__restrict__ counts /* [JP_WGS][KP_BINS] */) {
+    __shared__ uint32_t hist[KP_BINS];
+    for (int b = threadIdx.x; b < KP_BINS; b += JP_NT) hist[b] = 0;
+    __syncthreads();
+    const uint64_t nTiles = (n + KP_TILE - 1) / KP_TILE, perWg = (nTiles + gridDim.x - 1) / gridDim.x;
+    for (uint64_t t = blockIdx.x * perWg; t < min(nTiles, (blockIdx.x + 1) * perWg); t++) {
+        const uint64_t base = t * KP_TILE;
+#pragma unroll
+        for (int j = 0; j < KP_PER; j++) {
+            const uint64_t idx = base + (uint64_t) j * JP_NT + threadIdx.x;
+            if (idx < n) atomicAdd(&hist[(uint32_t) (elems[idx] >> KP_SHIFT)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < KP_BINS; b += JP_NT) counts[(size_t) blockIdx.x * KP_BINS + b] = hist[b];
+}
+
+// counts[r][c] -> exclusive prefix down every column, in place; total[c] = column sum
+__global__ void __launch_bounds__(256)
+col_prefix_kernel(uint32_t *__restrict__ m, int rows /* multiple of 4 */, int cols, uint32_t *__restrict__ total) {
+    __shared__ uint32_t part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pt = threadIdx.x >> 6;
+    const int RP = rows / 4;
+    uint32_t sum = 0;
+    if (c < cols)
+        for (int r = pt * RP; r < (pt + 1) * RP; r++) sum += m[(size_t) r * cols + c];
+    part[pt][threadIdx.x & 63] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int x = 0; x < pt; x++) run += part[x][threadIdx.x & 63];
+    if (c < cols) {
+        for (int r = pt * RP; r < (pt + 1) * RP; r++) {
+            const uint32_t v = m[(size_t) r * cols + c];
+            m[(size_t) r * cols + c] = run;
+            run += v;
+        }
+        if (pt == 3) total[c] = run;
+    }
+}
+
+// exclusive scan of n <= 4096 totals into 64-bit bases (n + 1 values), one workgroup
+__global__ void __launch_bounds__(JP_NT)
+small_scan_kernel(const uint32_t *__restrict__ in, int n, uint64_t *__restrict__ out) {
+    __shared__ uint64_t part[JP_NT / 64];
+    const int t = threadIdx.x;
+    uint64_t v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        v[j] = (t * 4 + j < n) ? (uint64_t) in[t * 4 + j] : 0;
+        sum += v[j];
+    }
+    uint64_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t o = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += o;
+    }
+    if ((t & 63) == 63) part[t >> 6] = incl;
+    __syncthreads();
+    uint64_t run = incl - sum;
+    for (int w = 0; w < (t >> 6); w++) run += part[w];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (t * 4 + j <= n) out[t * 4 + j] = run;
+        run += v[j];
+    }
+    if (t * 4 + 4 == n) out[n] = run;   // n = 4 * JP_NT: the total has no thread of its own
+}
+
+// exclusive scan of arr[0..n) in LDS, n <= 2 * NT, all NT threads of the workgroup
+template <int NT>
+__device__ __forceinline__ void jpBlockScan2(uint32_t *arr, int n, uint32_t *part) {
+    const int t = threadIdx.x;
+    const uint32_t a = (2 * t < n) ? arr[2 * t] : 0, b = (2 * t + 1 < n) ? arr[2 * t + 1] : 0;
+    const uint32_t sum = a + b;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += o;
+    }
+    if ((t & 63) == 63) part[t >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < (t >> 6); w++) run += part[w];
+    if (2 * t < n) arr[2 * t] = run;
+    if (2 * t + 1 < n) arr[2 * t + 1] = run + a;
+    if (t == NT - 1) part[NT / 64] = run + sum;   // grand total
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(JP_NT)
+kp_scatter_kernel(const uint64_t *__restrict__ in, uint64_t n, const uint32_t *__restrict__ prefix /* [JP_WGS][KP_BINS] */,
+                  const uint64_t *__restrict__ binBase, uint64_t *__restrict__ out) {
+    __shared__ uint64_t stage[KP_TILE];
+    __shared__ uint32_t cnt[KP_BINS], lstart[KP_BINS], cur[KP_BINS];
+    __shared__ uint32_t part[JP_NT / 64 + 1];
+    const int t = threadIdx.x;
+    for (int b = t; b < KP_BINS; b += JP_NT) {
+        cur[b] = (uint32_t) binBase[b] + prefix[(size_t) blockIdx.x * KP_BINS + b];
+        cnt[b] = 0;
+    }
+    __syncthreads();
+    // a workgroup takes a contiguous range of tiles and its share of a bin lies behind the shares of the workgroups before
+    // it: every bin stays in stream order -- i.e. ordered by query -- down to the tile, which is what lets the join write
+    // a chunk's hits as a few long per-query runs
+    const uint64_t nTiles = (n + KP_TILE - 1) / KP_TILE, perWg = (nTiles + gridDim.x - 1) / gridDim.x;
+    for (uint64_t tile = blockIdx.x * perWg; tile < min(nTiles, (blockIdx.x + 1) * perWg); tile++) {
+        const uint64_t base = tile * KP_TILE;
+        const int tn = (int) min((uint64_t) KP_TILE, n - base);
+        uint64_t e[KP_PER];
+        uint32_t r[KP_PER];
+#pragma unroll
+        for (int j = 0; j < KP_PER; j++) {
+            const int x = j * JP_NT + t;
+            if (x < tn) e[j] = in[base + x];
+        }
+#pragma unroll
+        for (int j = 0; j < KP_PER; j++) {
+            const int x = j * JP_NT + t;
+            if (x < tn) r[j] = atomicAdd(&cnt[(uint32_t) (e[j] >> KP_SHIFT)], 1u);
+        }
+        __syncthreads();
+        for (int b = t; b < KP_BINS; b += JP_NT) lstart[b] = cnt[b];
+        __syncthreads();
+        jpBlockScan2<JP_NT>(lstart, KP_BINS, part);
+#pragma unroll
+        for (int j = 0; j < KP_PER; j++) {
+            const int x = j * JP_NT + t;
+            if (x < tn) stage[lstart[(uint32_t) (e[j] >> KP_SHIFT)] + r[j]] = e[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KP_PER; j++) {
+            const int x = j * JP_NT + t;
+            if (x < tn) {
+                const uint64_t v = stage[x];
+                const uint32_t b = (uint32_t) (v >> KP_SHIFT);
+                out[cur[b] + ((uint32_t) x - lstart[b])] = v;
+            }
+        }
+        __syncthreads();
+        for (int b = t; b < KP_BINS; b += JP_NT) {
+            cur[b] += cnt[b];
+            cnt[b] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- the join.  Work split (identical in the count and the scatter pass): XCD x = workgroup & 7 owns the x-th eighth
+// of the k-mer-sorted stream, its workgroups take that range's chunks round-robin, so the CUs of an XCD work on
+// neighbouring chunks -- the same one or two k-mer ranges -- at any time and the table slices stay in that XCD's L2.
+// A range is in query order (see kp_scatter_kernel), so a chunk of 1 024 k-mers touches a few dozen queries and its
+// hits are a few long runs: they are written straight to the per-query segments, positions handed out by LDS cursors
+// (lanes of a wavefront mostly share the query, the returned positions are consecutive, the stores coalesce).
+struct JoinSpan {
+    uint64_t begin, end;   // this XCD's element range
+    uint32_t slot, nSlots;
+};
+__device__ __forceinline__ JoinSpan joinSpan(uint64_t n) {
+    const uint32_t xcd = blockIdx.x & 7u;
+    uint64_t per = (n + 7) / 8;
+    per = (per + JC - 1) / JC * JC;
+    JoinSpan s;
+    s.begin = min(n, (uint64_t) xcd * per);
+    s.end = min(n, s.begin + per);
+    s.slot = blockIdx.x >> 3;
+    s.nSlots = gridDim.x >> 3;
+    return s;
+}
+
+// last q with base[q] <= sidx (base[0] = 0, base[nQ] = total)
+__device__ __forceinline__ uint32_t joinQueryOf(const uint32_t *base, uint32_t nQ, uint32_t sidx) {
+    uint32_t lo = 0, hi = nQ;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (base[mid] <= sidx) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(JJ_NT)
+join_count_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint32_t *__restrict__ idxOffsets,
+                  const uint32_t *__restrict__ qKmerBase, uint32_t nQ, uint32_t *__restrict__ counts /* [JJ_WGS][cols] */,
+                  int cols, unsigned long long *__restrict__ wgTotal /* [JJ_WGS]: 64-bit, the per-query counts are 32 */) {
+    __shared__ uint32_t sQB[JQ_MAX + 1];
+    __shared__ uint32_t hist[JQ_MAX];
+    __shared__ unsigned long long sTotal;
+    unsigned long long mine = 0;
+    if (threadIdx.x == 0) sTotal = 0;
+    for (uint32_t x = threadIdx.x; x <= nQ; x += JJ_NT) sQB[x] = qKmerBase[x];
+    for (int x = threadIdx.x; x < cols; x += JJ_NT) hist[x] = 0;
+    __syncthreads();
+    const JoinSpan sp = joinSpan(n);
+    for (uint64_t base = sp.begin + (uint64_t) sp.slot * JC; base < sp.end; base += (uint64_t) sp.nSlots * JC) {
+#pragma unroll
+        for (int j = 0; j < JC / JJ_NT; j++) {
+            const uint64_t idx = base + (uint64_t) j * JJ_NT + threadIdx.x;
+            if (idx < sp.end) {
+                const uint64_t e = sorted[idx];
+                const uint32_t km = (uint32_t) (e >> 38);
+                const uint32_t len = idxOffsets[km + 1] - idxOffsets[km];
+                if (len) atomicAdd(&hist[joinQueryOf(sQB, nQ, (uint32_t) (e >> 8) & 0x3FFFFFFFu)], len);
+                mine += len;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sTotal, mine);
+    __syncthreads();
+    for (int x = threadIdx.x; x < cols; x += JJ_NT) counts[(size_t) blockIdx.x * cols + x] = hist[x];
+    if (threadIdx.x == 0) wgTotal[blockIdx.x] = sTotal;
+}
+
+// per-query hit totals that take part (queries taken out of the batch count nothing)
+__global__ void join_effective_totals_kernel(uint32_t nQ, const uint32_t *__restrict__ qHits, const uint32_t *__restrict__ qSplit,
+                                             uint32_t *__restrict__ eff) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nQ) eff[q] = qSplit[q] == QUERY_UNSUPPORTED ? 0u : qHits[q];
+}
+
+__global__ void __launch_bounds__(JJ_NT)
+join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint32_t *__restrict__ idxOffsets,
+                    const uint2 *__restrict__ entries, const uint32_t *__restrict__ qKmerBase, uint32_t nQ,
+                    const uint32_t *__restrict__ prefix /* [JJ_WGS][cols]: hits of the workgroups before this one, per query */,
+                    int cols, const uint64_t *__restrict__ qHitBase, int tBits, const uint32_t *__restrict__ qSplit,
+                    uint2 *__restrict__ outKV) {
+    __shared__ uint32_t sQB[JQ_MAX + 1];
+    __shared__ uint32_t qcur[JQ_MAX];   // this workgroup's write position inside every query's segment (< 2^32 hits per sub-batch)
+    __shared__ uint32_t eOff[JC + 1], eStart[JC], eKey[JC], eVal[JC];
+    __shared__ uint32_t part[JJ_NT / 64 + 1];
+    const int t = threadIdx.x;
+    for (uint32_t x = t; x <= nQ; x += JJ_NT) sQB[x] = qKmerBase[x];
+    for (uint32_t q = t; q < nQ; q += JJ_NT)
+        qcur[q] = qSplit[q] == QUERY_UNSUPPORTED ? 0xFFFFFFFFu : (uint32_t) qHitBase[q] + prefix[(size_t) blockIdx.x * cols + q];
+    __syncthreads();
+    const JoinSpan sp = joinSpan(n);
+    for (uint64_t base = sp.begin + (uint64_t) sp.slot * JC; base < sp.end; base += (uint64_t) sp.nSlots * JC) {
+        // the chunk's k-mers: list start / length, owning query, ordinal; thread t owns elements 2t, 2t + 1
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int x = 2 * t + j;
+            const uint64_t idx = base + x;
+            uint32_t len = 0;
+            if (idx < sp.end) {
+                const uint64_t e = sorted[idx];
+                const uint32_t km = (uint32_t) (e >> 38);
+                const uint32_t s = idxOffsets[km];
+                len = idxOffsets[km + 1] - s;
+                const uint32_t sidx = (uint32_t) (e >> 8) & 0x3FFFFFFFu;
+                const uint32_t q = joinQueryOf(sQB, nQ, sidx);
+                if (len && qcur[q] == 0xFFFFFFFFu) len = 0;   // query taken out of the batch
+                eStart[x] = s;
+                eKey[x] = q << tBits;
+                eVal[x] = ((uint32_t) (e & 0xFF) << 24) | (sidx - sQB[q]);
+            }
+            eOff[x] = len;
+        }
+        __syncthreads();
+        jpBlockScan2<JJ_NT>(eOff, JC, part);
+        const uint32_t total = part[JJ_NT / 64];
+        if (t == 0) eOff[JC] = total;
+        __syncthreads();
+        for (uint32_t f0 = 0; f0 < total; f0 += 4 * JJ_NT) {
+            uint32_t x4[4], a4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t f = f0 + (uint32_t) j * JJ_NT + (uint32_t) t;
+                x4[j] = 0xFFFFFFFFu;
+                if (f < total) {
+                    int lo = 0, hi = JC;   // last x with eOff[x] <= f
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (eOff[mid] <= f) lo = mid;
+                        else hi = mid;
+                    }
+                    x4[j] = (uint32_t) lo;
+                    a4[j] = eStart[lo] + (f - eOff[lo]);
+                }
+            }
+            uint2 en[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x4[j] != 0xFFFFFFFFu) en[j] = entries[a4[j]];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (x4[j] != 0xFFFFFFFFu) {
+                    const uint32_t v = eVal[x4[j]], kq = eKey[x4[j]];
+                    const uint32_t pos = atomicAdd(&qcur[kq >> tBits], 1u);
+                    outKV[pos] = make_uint2(kq | en[j].x, ((((v >> 24) - en[j].y) & 0xFFu) << 24) | (v & 0xFFFFFFu));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Where the reference's hit buffer (cap entries) overflows inside a query, in k-mer ordinals: the k-mer whose list would
+// fill the buffer starts the second part (QueryMatcher.cpp:281-316).  One workgroup per query; only queries with at
+// least cap hits walk their k-mers (in enumeration order, list lengths from the offset table).
+__global__ void __launch_bounds__(256)
+query_split_join_kernel(uint32_t nQ, const uint32_t *__restrict__ qKmerBase, const uint64_t *__restrict__ elems,
+                        const uint32_t *__restrict__ idxOffsets, const uint32_t *__restrict__ qHits, uint64_t cap,
+                        uint32_t *__restrict__ qSplit, int *__restrict__ flag) {
+    __shared__ uint64_t part[4];
+    __shared__ uint64_t carry;
+    __shared__ uint32_t found;
+    const uint32_t q = blockIdx.x;
+    const uint64_t total = qHits[q];
+    if (total < cap) {
+        if (threadIdx.x == 0) qSplit[q] = 0xFFFFFFFFu;
+        return;
+    }
+    const uint32_t k0 = qKmerBase[q], nk = qKmerBase[q + 1] - k0;
+    if (threadIdx.x == 0) {
+        carry = 0;
+        found = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t x0 = 0; x0 < nk; x0 += 256) {
+        const uint32_t x = x0 + threadIdx.x;
+        uint64_t len = 0;
+        if (x < nk) {
+            const uint32_t km = (uint32_t) (elems[k0 + x] >> 38);
+            len = idxOffsets[km + 1] - idxOffsets[km];
+        }
+        uint64_t incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) part[wave] = incl;
+        __syncthreads();
+        uint64_t run = carry + incl;
+        for (int w = 0; w < wave; w++) run += part[w];
+        // first k-mer whose inclusive count reaches cap
+        if (x < nk && run >= cap && run - len < cap) found = x;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = run;
+        __syncthreads();
+        if (found != 0xFFFFFFFFu) break;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t split = found;
+        // hits before the split = carry-in of k-mer `found`; a second overflow of the buffer is not implemented
+        // (QueryMatcher.cpp:289-303): recount from the split
+        qSplit[q] = split;
+    }
+}
+
+// second part of query_split_join: a query whose second part overflows again is taken out of the batch
+__global__ void __launch_bounds__(256)
+query_split_check_kernel(uint32_t nQ, const uint32_t *__restrict__ qKmerBase, const uint64_t *__restrict__ elems,
+                         const uint32_t *__restrict__ idxOffsets, uint64_t cap, uint32_t *__restrict__ qSplit,
+                         int *__restrict__ flag) {
+    __shared__ unsigned long long sum;
+    const uint32_t q = blockIdx.x;
+    const uint32_t split = qSplit[q];
+    if (split == 0xFFFFFFFFu) return;
+    const uint32_t k0 = qKmerBase[q], nk = qKmerBase[q + 1] - k0;
+    if (threadIdx.x == 0) sum = 0;
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (uint32_t x = split + threadIdx.x; x < nk; x += 256) {
+        const uint32_t km = (uint32_t) (elems[k0 + x] >> 38);
+        mine += idxOffsets[km + 1] - idxOffsets[km];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sum, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && sum >= cap) {
+        qSplit[q] = QUERY_UNSUPPORTED;
+        atomicExch(flag, 1);
+    }
+}
+
+// per-query statistics of the join path: k-mers and index hits
+__global__ void join_stats_kernel(uint32_t nQ, const uint32_t *__restrict__ qKmerBase, const uint32_t *__restrict__ qHits,
+                                  uint64_t *__restrict__ stats) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nQ) return;
+    stats[4 * q] = qKmerBase[q + 1] - qKmerBase[q];
+    stats[4 * q + 1] = qHits[q];
+}
+
+// The 16-bit diagonal of a hit for the few that survive the match.  Lookup path: kept per stream position at gather
+// time.  Join path: recomputed -- the query position from the k-mer's ordinal (binary search over the per-position
+// stream bases), the target position from the k-mer's index list (sorted by sequence id, one entry per sequence).
+struct DiagSrc {
+    const uint16_t *hitDiag;     // lookup path (nullptr selects the join path)
+    const uint64_t *qHitBase;
+    const uint64_t *elems;       // join path: the query-major k-mer stream
+    const uint64_t *kmerBase;    // first stream index of every position
+    const uint64_t *posBase;     // first position of every query
+    const uint32_t *idxOffsets;
+    const uint2 *entries;
+};
+
+__device__ __forceinline__ uint16_t diagOf(const DiagSrc &S, uint32_t q, uint32_t ord, uint32_t sid) {
+    if (S.hitDiag) return S.hitDiag[S.qHitBase[q] + ord];
+    uint64_t lo = S.posBase[q], hi = S.posBase[q + 1];
+    const uint64_t p0 = lo, sidx = S.kmerBase[lo] + ord;
+    while (hi - lo > 1) {   // last position whose stream base is <= sidx
+        const uint64_t mid = (lo + hi) >> 1;
+        if (S.kmerBase[mid] <= sidx) lo = mid;
+        else hi = mid;
+    }
+    const int i = (int) (lo - p0);
+    const uint32_t km = (uint32_t) (S.elems[sidx] >> 38);
+    uint32_t a = S.idxOffsets[km], b = S.idxOffsets[km + 1];
+    while (b - a > 1) {   // the list's entry of sequence sid
+        const uint32_t mid = (a + b) >> 1;
+        if (S.entries[mid].x <= sid) a = mid;
+        else b = mid;
+    }
+    return (uint16_t) (i - (int) S.entries[a].y);
+}

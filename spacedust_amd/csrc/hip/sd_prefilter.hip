@@ -712,6 +712,8 @@ drop_query_kmers_kernel(uint64_t nKmers, const uint32_t *__restrict__ kPos, cons
     if (kLen[k] && qSplit[kPos[k] >> 16] == QUERY_UNSUPPORTED) kLen[k] = 0;
 }
 
+#include "sd_pf_join.h"
+
 // ---------------------------------------------------------------------------------------------
 // Bucketed double-diagonal match (replaces the global radix sort + match + flag scan + compaction).
 // The hit stream is already grouped by query.  Per query one workgroup splits its segment into `bins` target
@@ -804,7 +806,8 @@ __device__ void pfBlockScan(uint32_t *arr, int n, uint32_t *part /* >= 5 */) {
 
 __global__ void __launch_bounds__(256)
 partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tBits, const uint32_t *__restrict__ inKey,
-                      const uint32_t *__restrict__ inVal, uint2 *__restrict__ outKV /* (key, value) per hit */,
+                      const uint32_t *__restrict__ inVal, const uint2 *__restrict__ inKV /* join path: interleaved input */,
+                      uint2 *__restrict__ outKV /* (key, value) per hit */,
                       uint32_t *__restrict__ qLog2Bins, uint64_t *__restrict__ bktStart, uint32_t *__restrict__ bktCount,
                       int *__restrict__ flag) {
     __shared__ uint32_t cursor[PF_NB_MAX];          // segment histogram, then the running write position per bin
@@ -833,7 +836,10 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
         for (int b = t; b < bins; b += 256) cursor[b] = 0;
         if (t == 0) part[7] = 0;
         __syncthreads();
-        for (uint64_t i = s + t; i < e; i += 256) atomicAdd(&cursor[(inKey[i] & tMask) >> shift], 1u);
+        if (inKV)
+            for (uint64_t i = s + t; i < e; i += 256) atomicAdd(&cursor[(inKV[i].x & tMask) >> shift], 1u);
+        else
+            for (uint64_t i = s + t; i < e; i += 256) atomicAdd(&cursor[(inKey[i] & tMask) >> shift], 1u);
         __syncthreads();
         uint32_t mx = 0;
         for (int b = t; b < bins; b += 256) mx = max(mx, cursor[b]);
@@ -859,8 +865,14 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
         for (int x = 0; x < PF_PER; x++) {
             const int j = x * 256 + t;
             if (j < tn) {
-                k[x] = inKey[base + j];
-                v[x] = inVal[base + j];
+                if (inKV) {
+                    const uint2 kv = inKV[base + j];
+                    k[x] = kv.x;
+                    v[x] = kv.y;
+                } else {
+                    k[x] = inKey[base + j];
+                    v[x] = inVal[base + j];
+                }
                 r[x] = pk16Add(tcount, (k[x] & tMask) >> shift);
             }
         }
@@ -914,7 +926,7 @@ __device__ __forceinline__ uint32_t cpQueryOfSeg(uint32_t seg, uint32_t nQ, cons
 
 __global__ void __launch_bounds__(256)
 coarse_count_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const uint32_t *__restrict__ segBase, int tBits, int cBits,
-                    const uint32_t *__restrict__ inKey, uint32_t *__restrict__ segCount /* [segment][C] */) {
+                    const uint32_t *__restrict__ inKey, const uint2 *__restrict__ inKV, uint32_t *__restrict__ segCount /* [segment][C] */) {
     __shared__ uint32_t hist[1 << CP_MAX_BITS];
     const uint32_t seg = blockIdx.x;
     const uint32_t q = cpQueryOfSeg(seg, nQ, segBase);
@@ -925,7 +937,7 @@ coarse_count_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const ui
     __syncthreads();
     const uint32_t tMask = (1u << tBits) - 1;
     const int shift = tBits - cBits;
-    for (uint64_t i = s + threadIdx.x; i < e; i += 256) atomicAdd(&hist[(inKey[i] & tMask) >> shift], 1u);
+    for (uint64_t i = s + threadIdx.x; i < e; i += 256) atomicAdd(&hist[((inKV ? inKV[i].x : inKey[i]) & tMask) >> shift], 1u);
     __syncthreads();
     if (threadIdx.x < C) segCount[(size_t) seg * C + threadIdx.x] = hist[threadIdx.x];
 }
@@ -970,7 +982,8 @@ coarse_offsets_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
 __global__ void __launch_bounds__(256)
 coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const uint32_t *__restrict__ segBase, int tBits, int cBits,
                       const uint32_t *__restrict__ segOffset, const uint32_t *__restrict__ inKey,
-                      const uint32_t *__restrict__ inVal, uint32_t *__restrict__ outKey, uint32_t *__restrict__ outVal,
+                      const uint32_t *__restrict__ inVal, const uint2 *__restrict__ inKV, uint32_t *__restrict__ outKey,
+                      uint32_t *__restrict__ outVal,
                       const uint16_t *__restrict__ hitDiag /* wide stream positions: the diagonal byte goes into the key bits
                                                               above the virtual query's target bits (the range is implied
                                                               by the segment), nullptr otherwise */) {
@@ -986,10 +999,18 @@ coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
     const uint32_t tMask = (1u << tBits) - 1;
     const int shift = tBits - cBits;
     for (uint64_t i = s + threadIdx.x; i < e; i += 256) {
-        const uint32_t k = inKey[i];
+        uint32_t k, v;
+        if (inKV) {
+            const uint2 kv = inKV[i];
+            k = kv.x;
+            v = kv.y;
+        } else {
+            k = inKey[i];
+            v = inVal[i];
+        }
         const uint32_t p = atomicAdd(&cursor[(k & tMask) >> shift], 1u);
         outKey[qs + p] = hitDiag ? (((uint32_t) hitDiag[i] & 0xFFu) << shift) | (k & ((1u << shift) - 1)) : k;
-        outVal[qs + p] = inVal[i];
+        outVal[qs + p] = v;
     }
 }
 
@@ -1231,7 +1252,7 @@ bucket_collect_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const u
 // K5: ungapped diagonal score (UngappedAlignment.cpp:30-43,416-430); candidates are (key,val) pairs
 __global__ void __launch_bounds__(256)
 score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint32_t *__restrict__ cVal,
-                  const uint16_t *__restrict__ hitDiag, const uint64_t *__restrict__ qHitBase, int tBits,
+                  const DiagSrc ds, int tBits,
                   const uint8_t *__restrict__ qRes, const uint64_t *__restrict__ qOff, const int8_t *__restrict__ diagBias,
                   const uint8_t *__restrict__ tMasked, const uint64_t *__restrict__ tOff, const int8_t *__restrict__ mat,
                   int32_t *__restrict__ cScore, uint32_t *__restrict__ cLen,
@@ -1244,7 +1265,7 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
     if (c >= nCand) return;
     const uint32_t k = cKey[c];
     const uint32_t q = k >> tBits, sid = k & ((1u << tBits) - 1);
-    const uint16_t d16 = hitDiag[qHitBase[q] + (cVal[c] & posMask)];
+    const uint16_t d16 = diagOf(ds, q, cVal[c] & posMask, sid);
     const int d = (int) (int16_t) d16;
     const int qL = (int) (qOff[q + 1] - qOff[q]);
     const int tL = (int) (tOff[sid + 1] - tOff[sid]);
@@ -1350,14 +1371,15 @@ template <int SEL_CAP>
 __global__ void __launch_bounds__(256)
 select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, into kept arrays */,
                    const uint32_t *__restrict__ kKey, const uint32_t *__restrict__ kVal,
-                   const int32_t *__restrict__ kScore, const uint16_t *__restrict__ hitDiag,
-                   const uint64_t *__restrict__ qHitBase, int tBits,
+                   const int32_t *__restrict__ kScore, const DiagSrc ds, int tBits,
                    uint32_t binMask, int maxHits, int minDiag, const uint32_t *__restrict__ identityId,
                    const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, int covMode, float covThr,
                    const uint8_t *__restrict__ qRes, const int8_t *__restrict__ diagBias, const int8_t *__restrict__ mat,
                    sd_hit *__restrict__ outHits, uint32_t *__restrict__ outCount, int *__restrict__ errFlag,
                    const int8_t *__restrict__ qProf /* nullable: profile queries */,
-                   uint32_t posMask /* stream position bits of the value word */) {
+                   uint32_t posMask /* stream position bits of the value word */,
+                   int joinBinBits /* -1, or (join path) log2(BINSIZE): the value word orders by k-mer ordinal, hits of one
+                                      k-mer's list by sequence id */) {
     __shared__ unsigned long long keys[SEL_CAP];
     __shared__ uint32_t pay[SEL_CAP];
     __shared__ unsigned int hist[256];
@@ -1419,6 +1441,9 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
     auto keyOf = [&](uint32_t x) -> unsigned long long {
         const uint32_t sid = kKey[x] & ((1u << tBits) - 1);
         const uint32_t top = rescored ? 255u - rescaledByte(x) : 255u - (uint32_t) min(255, kScore[x]);
+        if (joinBinBits >= 0)
+            return ((unsigned long long) top << 56) | ((unsigned long long) (sid & binMask) << 44) |
+                   ((unsigned long long) (kVal[x] & posMask) << 20) | (unsigned long long) ((sid >> joinBinBits) & 0xFFFFFu);
         return ((unsigned long long) top << 56) | ((unsigned long long) (sid & binMask) << 40) |
                (unsigned long long) (kVal[x] & posMask);
     };
@@ -1586,7 +1611,7 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
                 const uint32_t e = pay[x];
                 o[w].seqId = sidReg[y];
                 o[w].score = (int32_t) (0x7FFFFFFFu - (uint32_t) (keys[x] >> 32));   // as ordered
-                o[w].diagonal = hitDiag[qHitBase[q] + (kVal[e] & posMask)];
+                o[w].diagonal = diagOf(ds, q, kVal[e] & posMask, sidReg[y]);
                 o[w].pad = 0;
                 w++;
             }
@@ -1928,6 +1953,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             return sdFail(ctx, SD_EINVAL, "query %u has %llu residues; k-mer positions are 16 bit (limit 65535, --max-seq-len)", x,
                           (unsigned long long) (qOffsets[x + 1] - qOffsets[x]));
     uint32_t qBeg = 0;
+    bool forceLookup = false;   // this sub-batch is redone on the lookup path (a regime the join path does not carry)
     uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 4096);   // ~0.6 G hits per sub-batch on a proteome-scale target DB: larger sorts were measured 4x slower per item
     if (const char *e = getenv("SD_PF_BATCH")) batchQ = std::max<uint32_t>(1, std::min<uint32_t>(maxBatchQ, (uint32_t) atoi(e)));
     while (qBeg < nQ) {
@@ -1982,6 +2008,16 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, hipMemsetAsync(dErr.p, 0, sizeof(int), ctx->stream));
 
         uint64_t nKmers = 0, nHits = 0;
+        // k-mer-major join (sd_pf_join.h): k = 6, 32-bit list starts, sequence queries, the bucketed match, and a tie order of
+        // the result cut that fits its key (sequence id bits above the bin: 20)
+        const bool useBuckets = getenv("SD_PF_SORT") == nullptr;
+        int binBits = 0;
+        while ((1u << binBits) < par->binSize) binBits++;
+        const bool joinCandidate = !forceLookup && T->k == 6 && T->dBlockBase == nullptr && !prof && useBuckets && bq <= (uint32_t) JQ_MAX &&
+                                   tBits - binBits <= 20 && binBits <= 12 && !(getenv("SD_PF_JOIN") && atoi(getenv("SD_PF_JOIN")) == 0);
+        WsView<uint32_t> dQKmerBase(ctx, "pf.dQKmerBase");
+        WsView<int> dJoinFlag(ctx, "pf.dJoinFlag");
+        int hJoinFlag = 0;
         uint32_t profGrid = 0;
         bool profAnyBig = false;
         WsView<uint2> dProfScratch(ctx, "pf.dProfScratch");
@@ -2027,6 +2063,14 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             int rc = exclusiveScanWiden(ctx, dKmerCount.p, dKmerBase.p, nPos + 1, scanTmp);
             if (rc != SD_OK) return rc;
             int hErrCount = 0;
+            if (joinCandidate) {
+                SD_HIP(ctx, dQKmerBase.alloc(bq + 1));
+                SD_HIP(ctx, dJoinFlag.alloc(1));
+                SD_HIP(ctx, hipMemsetAsync(dJoinFlag.p, 0, sizeof(int), ctx->stream));
+                hipLaunchKernelGGL(join_query_base_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p,
+                                   dKmerBase.p, dQKmerBase.p, dJoinFlag.p);
+                SD_HIP(ctx, hipMemcpyAsync(&hJoinFlag, dJoinFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            }
             SD_HIP(ctx, hipMemcpyAsync(&nKmers, dKmerBase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             if (prof) SD_HIP(ctx, hipMemcpyAsync(&hErrCount, dErr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, sdStreamSync(ctx));
@@ -2046,13 +2090,16 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         WsView<uint64_t> dHitBase(ctx, "pf.dHitBase");
         WsView<uint32_t> dKStartHi(ctx, "pf.dKStartHi");   // wide indexes only: high half of the list starts
         const bool wideIdx = T->dBlockBase != nullptr;
+        const bool useJoin = joinCandidate && !hJoinFlag && nKmers > 0;
+        if (!useJoin) {
         SD_HIP(ctx, dKStart.alloc(nKmers + 1));
         if (wideIdx) SD_HIP(ctx, dKStartHi.alloc(nKmers + 1));
         SD_HIP(ctx, dKLen.alloc(nKmers + 1));
         SD_HIP(ctx, dKPos.alloc(nKmers + 1));
         SD_HIP(ctx, dHitBase.alloc(nKmers + 1));
         SD_HIP(ctx, hipMemsetAsync(dKLen.p, 0, (nKmers + 1) * sizeof(uint32_t), ctx->stream));
-        if (nKmers > 0) {
+        }
+        if (nKmers > 0 && !useJoin) {
             {
                 ProfScope ps(ctx, "prefilter_emit_kmers");
                 if (prof) {
@@ -2093,35 +2140,136 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             SD_HIP(ctx, sdStreamSync(ctx));
         }
         hs.reset(new HostScope(ctx, "pf.stats"));
-        if (nHits > HIT_BUDGET && bq > 1) {   // too many hits for one sort: halve the sub-batch and retry
-            batchQ = std::max<uint32_t>(1, bq / 2);
-            continue;
-        }
-        if (nHits >= 0xFFFFFFFFull) return sdFail(ctx, SD_EUNSUPPORTED, "more than 2^32 hits in one query batch");
         std::vector<uint64_t> hStats((size_t) bq * 4, 0);
         WsView<uint64_t> dStats(ctx, "pf.dStats");
         SD_HIP(ctx, dStats.alloc((size_t) bq * 4));
         SD_HIP(ctx, hipMemsetAsync(dStats.p, 0, (size_t) bq * 4 * sizeof(uint64_t), ctx->stream));
-        hipLaunchKernelGGL(stats_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
-                           dHitBase.p, nKmers, nHits, dStats.p);
-        // Stream positions: 24 bits of the value word beside the diagonal byte -- or, for sub-batches with a query of 2^24 hits
-        // and more, the whole word, the diagonal byte travelling in the key (bucket path only: it needs the coarse split)
-        const bool useBuckets = getenv("SD_PF_SORT") == nullptr;
-        const uint64_t posLimit = useBuckets ? 0xFFFFFFF0ull : (1ull << 24);
-        // the reference's hit buffer holds maxDbMatches entries per query; where a query overflows it once, the match runs
-        // on the two parts separately (query_split_kernel); two overflows are not implemented
         WsView<uint32_t> dQSplit(ctx, "pf.dQSplit");
         WsView<int> dSplitFlag(ctx, "pf.dSplitFlag");
         SD_HIP(ctx, dQSplit.alloc(bq));
         SD_HIP(ctx, dSplitFlag.alloc(1));
         SD_HIP(ctx, hipMemsetAsync(dSplitFlag.p, 0, sizeof(int), ctx->stream));
+        std::vector<uint8_t> hUnsupported;
+        // join path: the k-mer stream, its k-mer-sorted copy, the hits grouped by query group
+        WsView<uint64_t> dElems(ctx, "pf.dElems");
+        WsView<uint64_t> dSorted(ctx, "pf.dSorted");
+        WsView<uint2> dHitsKV(ctx, "pf.dHitsKV");
+        WsView<uint64_t> dQHitBase(ctx, "pf.dQHitBase");   // hits of query q start at dQHitBase[q] (either path)
+        if (useJoin) {
+            WsView<uint32_t> dKpCounts(ctx, "pf.dKpCounts");
+            WsView<uint32_t> dKpTotal(ctx, "pf.dKpTotal");
+            WsView<uint64_t> dKpBase(ctx, "pf.dKpBase");
+            WsView<uint32_t> dJqCounts(ctx, "pf.dJqCounts");
+            WsView<uint32_t> dQHits(ctx, "pf.dQHits");
+            WsView<unsigned long long> dWgTotal(ctx, "pf.dWgTotal");
+            WsView<uint32_t> dQEff(ctx, "pf.dQEff");
+            SD_HIP(ctx, dElems.alloc(nKmers + 1));
+            SD_HIP(ctx, dSorted.alloc(nKmers + 1));
+            SD_HIP(ctx, dKpCounts.alloc((size_t) JP_WGS * KP_BINS));
+            SD_HIP(ctx, dKpTotal.alloc(KP_BINS));
+            SD_HIP(ctx, dKpBase.alloc(KP_BINS + 1));
+            SD_HIP(ctx, dJqCounts.alloc((size_t) JJ_WGS * bq));
+            SD_HIP(ctx, dQHits.alloc(bq));
+            SD_HIP(ctx, dWgTotal.alloc(JJ_WGS));
+            {
+                ProfScope ps(ctx, "prefilter_emit_kmers");
+                hipLaunchKernelGGL(emit_kmers_join_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq, dQ.p,
+                                   dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, dKmerBase.p, dElems.p);
+            }
+            {
+                ProfScope ps(ctx, "prefilter_kmer_partition");
+                hipLaunchKernelGGL(kp_hist_kernel, dim3(JP_WGS), dim3(JP_NT), 0, ctx->stream, (const uint64_t *) dElems.p, nKmers, dKpCounts.p);
+                hipLaunchKernelGGL(col_prefix_kernel, dim3(KP_BINS / 64), dim3(256), 0, ctx->stream, dKpCounts.p, JP_WGS, KP_BINS, dKpTotal.p);
+                hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(JP_NT), 0, ctx->stream, (const uint32_t *) dKpTotal.p, KP_BINS, dKpBase.p);
+                hipLaunchKernelGGL(kp_scatter_kernel, dim3(JP_WGS), dim3(JP_NT), 0, ctx->stream, (const uint64_t *) dElems.p, nKmers,
+                                   (const uint32_t *) dKpCounts.p, (const uint64_t *) dKpBase.p, dSorted.p);
+            }
+            {
+                ProfScope ps(ctx, "prefilter_join_count");
+                hipLaunchKernelGGL(join_count_kernel, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nKmers,
+                                   (const uint32_t *) T->dOffsets, (const uint32_t *) dQKmerBase.p, bq, dJqCounts.p, (int) bq, dWgTotal.p);
+                hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor(bq, 64)), dim3(256), 0, ctx->stream, dJqCounts.p, JJ_WGS, (int) bq, dQHits.p);
+            }
+            // overflow of the reference's hit buffer, in k-mer ordinals
+            hipLaunchKernelGGL(query_split_join_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQKmerBase.p,
+                               (const uint64_t *) dElems.p, (const uint32_t *) T->dOffsets, (const uint32_t *) dQHits.p, maxDbMatches,
+                               dQSplit.p, dSplitFlag.p);
+            hipLaunchKernelGGL(query_split_check_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQKmerBase.p,
+                               (const uint64_t *) dElems.p, (const uint32_t *) T->dOffsets, maxDbMatches, dQSplit.p, dSplitFlag.p);
+            hipLaunchKernelGGL(join_stats_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQKmerBase.p,
+                               (const uint32_t *) dQHits.p, dStats.p);
+            std::vector<unsigned long long> hWg(JJ_WGS);
+            std::vector<uint32_t> hQHits(bq);
+            int hSplitFlagJ = 0;
+            SD_HIP(ctx, hipMemcpyAsync(hWg.data(), dWgTotal.p, JJ_WGS * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipMemcpyAsync(hQHits.data(), dQHits.p, bq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, hipMemcpyAsync(&hSplitFlagJ, dSplitFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, sdStreamSync(ctx));
+            uint64_t all = 0;
+            for (unsigned long long v : hWg) all += v;
+            if (all > HIT_BUDGET && bq > 1) {   // too many hits for one sub-batch: halve it and retry
+                batchQ = std::max<uint32_t>(1, bq / 2);
+                continue;
+            }
+            if (all >= 0xFFFFFFF0ull) {   // the per-query counters are 32 bit: this query goes the lookup path
+                forceLookup = true;
+                continue;
+            }
+            for (uint32_t x = 0; x < bq; x++) hStats[(size_t) x * 4 + 1] = hQHits[x];
+            nHits = all;
+            if (hSplitFlagJ) {
+                // queries that overflow the reference's hit buffer twice (QueryMatcher.cpp:289-303) are taken out of the batch and
+                // reported per query (outCount = UINT32_MAX); the join leaves their lists out
+                std::vector<uint32_t> hSplit(bq);
+                SD_HIP(ctx, hipMemcpy(hSplit.data(), dQSplit.p, (size_t) bq * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                hUnsupported.assign(bq, 0);
+                uint32_t nBad = 0, firstBad = 0;
+                for (uint32_t x = 0; x < bq; x++)
+                    if (hSplit[x] == QUERY_UNSUPPORTED) {
+                        hUnsupported[x] = 1;
+                        nHits -= hQHits[x];
+                        if (!nBad) firstBad = qBeg + x;
+                        nBad++;
+                    }
+                sdFail(ctx, SD_EUNSUPPORTED, "%u quer%s of the batch [%u, %u) (first: %u) overflow the reference's hit buffer twice "
+                       "(double-overflow route of QueryMatcher.cpp:289-303): reported with outCount = UINT32_MAX, the rest of the batch is computed",
+                       nBad, nBad == 1 ? "y" : "ies", qBeg, qBeg + bq, firstBad);
+            }
+            // per-query segments of the hit array (the layout the bucket machinery takes), then the scatter pass of the join
+            SD_HIP(ctx, dQEff.alloc(bq));
+            SD_HIP(ctx, dQHitBase.alloc(bq + 1));
+            hipLaunchKernelGGL(join_effective_totals_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQHits.p,
+                               (const uint32_t *) dQSplit.p, dQEff.p);
+            hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(JP_NT), 0, ctx->stream, (const uint32_t *) dQEff.p, (int) bq, dQHitBase.p);
+            if (nHits > 0) {
+                SD_HIP(ctx, dHitsKV.alloc(nHits));
+                ProfScope ps(ctx, "prefilter_join_scatter");
+                hipLaunchKernelGGL(join_scatter_kernel, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nKmers,
+                                   (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, (const uint32_t *) dQKmerBase.p, bq,
+                                   (const uint32_t *) dJqCounts.p, (int) bq, (const uint64_t *) dQHitBase.p, tBits,
+                                   (const uint32_t *) dQSplit.p, dHitsKV.p);
+            }
+            SD_HIP(ctx, hipGetLastError());
+        }
+        if (!useJoin) {
+        if (nHits > HIT_BUDGET && bq > 1) {   // too many hits for one sort: halve the sub-batch and retry
+            batchQ = std::max<uint32_t>(1, bq / 2);
+            continue;
+        }
+        if (nHits >= 0xFFFFFFFFull) return sdFail(ctx, SD_EUNSUPPORTED, "more than 2^32 hits in one query batch");
+        hipLaunchKernelGGL(stats_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
+                           dHitBase.p, nKmers, nHits, dStats.p);
+        // Stream positions: 24 bits of the value word beside the diagonal byte -- or, for sub-batches with a query of 2^24 hits
+        // and more, the whole word, the diagonal byte travelling in the key (bucket path only: it needs the coarse split)
+        const uint64_t posLimit = useBuckets ? 0xFFFFFFF0ull : (1ull << 24);
+        // the reference's hit buffer holds maxDbMatches entries per query; where a query overflows it once, the match runs
+        // on the two parts separately (query_split_kernel); two overflows are not implemented
         hipLaunchKernelGGL(query_split_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
                            dHitBase.p, maxDbMatches, dQSplit.p, dSplitFlag.p, posLimit);
         int hSplitFlag = 0;
         SD_HIP(ctx, hipMemcpyAsync(&hSplitFlag, dSplitFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(hStats.data(), dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, sdStreamSync(ctx));
-        std::vector<uint8_t> hUnsupported;
         if (hSplitFlag) {
             // Queries that overflow the reference's hit buffer twice (the double-overflow route of QueryMatcher.cpp:289-303) or
             // have >= 2^32 index hits cannot be computed here.  They are taken out of the batch -- their index lists emptied,
@@ -2148,12 +2296,13 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                dHitBase.p, maxDbMatches, dQSplit.p, dSplitFlag.p, posLimit);
             SD_HIP(ctx, sdStreamSync(ctx));
         }
+        }   // lookup path
 
         hs.reset(new HostScope(ctx, "pf.gather_sort_match"));
         uint32_t nCand = 0, nKept = 0;
         bool bucketDone = false;
         bool widePos = false;
-        if (useBuckets)
+        if (useBuckets && !useJoin)
             for (uint32_t x = 0; x < bq && !widePos; x++)
                 widePos = hStats[(size_t) x * 4 + 1] >= (1ull << 24) && !(x < hUnsupported.size() && hUnsupported[x]);
         const uint32_t posMask = widePos ? 0xFFFFFFFFu : 0xFFFFFFu;
@@ -2162,8 +2311,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         WsView<uint32_t> dValA(ctx, "pf.dValA");
         WsView<uint32_t> dValB(ctx, "pf.dValB");
         WsView<uint16_t> dDiag(ctx, "pf.dDiag");
-        WsView<uint64_t> dQHitBase(ctx, "pf.dQHitBase");
-        SD_HIP(ctx, dQHitBase.alloc(bq + 1));
+        if (!useJoin) SD_HIP(ctx, dQHitBase.alloc(bq + 1));
         WsView<uint8_t> dEmit(ctx, "pf.dEmit");
         WsView<uint64_t> dEmitPos(ctx, "pf.dEmitPos");
         WsView<uint64_t> dEmit64(ctx, "pf.dEmit64");
@@ -2178,13 +2326,15 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         WsView<uint8_t> dKeep(ctx, "pf.dKeep");
         if (nHits > 0) {
             SD_HIP(ctx, dKeyA.alloc(nHits));
-            SD_HIP(ctx, dKeyB.alloc(nHits));
             SD_HIP(ctx, dValA.alloc(nHits));
+            if (!useJoin) {
+            SD_HIP(ctx, dKeyB.alloc(nHits));
             SD_HIP(ctx, dValB.alloc(nHits));
             SD_HIP(ctx, dDiag.alloc(nHits));
             hipLaunchKernelGGL(query_hit_base_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p,
                                dKmerBase.p, dHitBase.p, dQHitBase.p);
-            {
+            }
+            if (!useJoin) {
                 ProfScope ps(ctx, "prefilter_gather_hits");
                 hipLaunchKernelGGL(gather_hits_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKStart.p,
                                    dKLen.p, dKPos.p, dHitBase.p, dPosBase.p, bq, (const uint2 *) T->dEntries, tBits, dQHitBase.p,
@@ -2194,9 +2344,13 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             if (useBuckets) {
                 // very hit-rich queries (large target sets): coarse split into virtual queries first (see coarse_*_kernel)
                 uint32_t nVQ = bq;
-                int cBits = 0, tBitsV = tBits;
+                const uint32_t nVQ0 = nVQ;
+                const int tBits0 = tBits;
+                int cBits = 0, tBitsV = tBits0;
                 const uint64_t *pHitBase = dQHitBase.p;
                 const uint32_t *pKey = dKeyA.p, *pVal = dValA.p;
+                // join path: the hits arrive interleaved (key, value)
+                const uint2 *pKV = useJoin ? (const uint2 *) dHitsKV.p : (const uint2 *) nullptr;
                 WsView<uint64_t> dVQHitBase(ctx, "pf.dVQHitBase");
                 WsView<uint32_t> dSegBase(ctx, "pf.dSegBase");
                 WsView<uint32_t> dSegCount(ctx, "pf.dSegCount");
@@ -2205,44 +2359,45 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 {
                     // decided by the average query of the sub-batch (a few long queries are what the adaptive bucket count and
                     // the oversize-bucket launch are for): ~100 hits per bucket at 2^11 buckets
-                    const uint64_t avgQ = nHits / std::max<uint32_t>(bq, 1);
+                    const uint64_t avgQ = nHits / std::max<uint32_t>(nVQ0, 1);
                     const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 200000;
-                    while (cBits < CP_MAX_BITS && tBits - (cBits + 1) >= 8 && (avgQ >> cBits) > perVQ) cBits++;
+                    while (cBits < CP_MAX_BITS && tBits0 - (cBits + 1) >= 8 && (avgQ >> cBits) > perVQ) cBits++;
                     // wide stream positions need the split: it is where the diagonal byte moves into the key (8 free bits)
                     while (widePos && cBits < CP_MAX_BITS && tBits - (cBits + 1) >= 8 && (cBits < 1 || tBits - cBits > 24)) cBits++;
                     if (widePos && (cBits < 1 || tBits - cBits > 24))
                         return sdFail(ctx, SD_EUNSUPPORTED, "a query with >= 2^24 index hits against a target set of %u sequences", T->nSeq);
                     if (cBits > 0) {
-                        std::vector<uint64_t> hQHB(bq + 1);
-                        SD_HIP(ctx, hipMemcpyAsync(hQHB.data(), dQHitBase.p, (bq + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                        std::vector<uint64_t> hQHB(nVQ0 + 1);
+                        SD_HIP(ctx, hipMemcpyAsync(hQHB.data(), pHitBase, (nVQ0 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
                         SD_HIP(ctx, sdStreamSync(ctx));
                         ProfScope ps(ctx, "prefilter_coarse_split");
                         const uint32_t C = 1u << cBits;
-                        std::vector<uint32_t> hSegBase(bq + 1, 0);
-                        for (uint32_t x = 0; x < bq; x++)
+                        std::vector<uint32_t> hSegBase(nVQ0 + 1, 0);
+                        for (uint32_t x = 0; x < nVQ0; x++)
                             hSegBase[x + 1] = hSegBase[x] + (uint32_t) ((hQHB[x + 1] - hQHB[x] + CP_SEG - 1) / CP_SEG);
-                        const uint32_t nSeg = hSegBase[bq];
-                        nVQ = bq * C;
-                        tBitsV = tBits - cBits;
+                        const uint32_t nSeg = hSegBase[nVQ0];
+                        nVQ = nVQ0 * C;
+                        tBitsV = tBits0 - cBits;
                         SD_HIP(ctx, dVQHitBase.alloc((size_t) nVQ + 1));
-                        SD_HIP(ctx, dSegBase.alloc(bq + 1));
+                        SD_HIP(ctx, dSegBase.alloc(nVQ0 + 1));
                         SD_HIP(ctx, dSegCount.alloc((size_t) std::max<uint32_t>(nSeg, 1) * C));
                         SD_HIP(ctx, dKeyC.alloc(nHits));
                         SD_HIP(ctx, dValC.alloc(nHits));
-                        SD_HIP(ctx, hipMemcpyAsync(dSegBase.p, hSegBase.data(), (bq + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                        SD_HIP(ctx, hipMemcpyAsync(dSegBase.p, hSegBase.data(), (nVQ0 + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
                         if (nSeg > 0)
-                            hipLaunchKernelGGL(coarse_count_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, bq, dQHitBase.p, dSegBase.p, tBits,
-                                               cBits, dKeyA.p, dSegCount.p);
-                        hipLaunchKernelGGL(coarse_offsets_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, dQHitBase.p, dSegBase.p, cBits,
+                            hipLaunchKernelGGL(coarse_count_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, tBits0,
+                                               cBits, dKeyA.p, pKV, dSegCount.p);
+                        hipLaunchKernelGGL(coarse_offsets_kernel, dim3(nVQ0), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, cBits,
                                            dSegCount.p, dVQHitBase.p);
                         if (nSeg > 0)
-                            hipLaunchKernelGGL(coarse_scatter_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, bq, dQHitBase.p, dSegBase.p, tBits,
-                                               cBits, dSegCount.p, dKeyA.p, dValA.p, dKeyC.p, dValC.p,
+                            hipLaunchKernelGGL(coarse_scatter_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, tBits0,
+                                               cBits, dSegCount.p, dKeyA.p, dValA.p, pKV, dKeyC.p, dValC.p,
                                                widePos ? (const uint16_t *) dDiag.p : (const uint16_t *) nullptr);
                         SD_HIP(ctx, sdStreamSync(ctx));   // hSegBase is read by the upload until here
                         pHitBase = dVQHitBase.p;
                         pKey = dKeyC.p;
                         pVal = dValC.p;
+                        pKV = nullptr;
                     }
                 }
                 const size_t nSlots = (size_t) nVQ * PF_NB_MAX;
@@ -2269,7 +2424,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 {
                     ProfScope ps(ctx, "prefilter_partition_hits");
                     hipLaunchKernelGGL(partition_hits_kernel, dim3(nVQ), dim3(256), 0, ctx->stream, nVQ, pHitBase, tBitsV, pKey,
-                                       pVal, dKVB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
+                                       pVal, pKV, dKVB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
                 }
                 hipLaunchKernelGGL(bin_count_kernel, dim3(gridFor(nVQ + 1, 256)), dim3(256), 0, ctx->stream, nVQ, dQLog2.p, dQBins.p);
                 int rc = exclusiveScanWiden(ctx, dQBins.p, dBinBase.p, nVQ + 1, scanTmp);
@@ -2322,6 +2477,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 if (!bucketDone && getenv("SD_DEBUG_TIMING"))
                     fprintf(stderr, "[prefilter] bucket path fell back: flag %d, %llu bins, %llu hits, %u queries\n", hFlag,
                             (unsigned long long) totalBins, (unsigned long long) nHits, bq);
+                if (!bucketDone && useJoin) {   // the global-sort fallback belongs to the lookup path: redo the sub-batch there
+                    forceLookup = true;
+                    continue;
+                }
                 if (!bucketDone) {
                     // a bucket larger than the LDS capacity (or more target bits than the slots cover): redo this
                     // sub-batch with the global sort; dKeyA / dValA were overwritten by the emitted hits, so gather again
@@ -2368,6 +2527,14 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                    "reported with outCount = UINT32_MAX", qBeg, qBeg + bq);
         }
         hs.reset(new HostScope(ctx, "pf.score_keep"));
+        DiagSrc diagSrc;
+        diagSrc.hitDiag = useJoin ? (const uint16_t *) nullptr : (const uint16_t *) dDiag.p;
+        diagSrc.qHitBase = dQHitBase.p;
+        diagSrc.elems = dElems.p;
+        diagSrc.kmerBase = dKmerBase.p;
+        diagSrc.posBase = dPosBase.p;
+        diagSrc.idxOffsets = T->dOffsets;
+        diagSrc.entries = T->dEntries;
         if (nCand > 0) {
             if (!bucketDone) {
                 SD_HIP(ctx, dCKey.alloc(nCand));
@@ -2395,7 +2562,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             {
                 ProfScope ps(ctx, "prefilter_score_diag");
                 hipLaunchKernelGGL(score_diag_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p,
-                                   dDiag.p, dQHitBase.p, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p,
+                                   diagSrc, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p,
                                    dProfAln, posMask);
             }
             hipLaunchKernelGGL(cand_stats_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCLen.p, tBits,
@@ -2440,12 +2607,12 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             ProfScope ps(ctx, "prefilter_select_hits");
             if (maxHits + 1 <= 2048)
                 hipLaunchKernelGGL(select_hits_kernel<4096>, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
-                                   dDiag.p, dQHitBase.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
-                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask);
+                                   diagSrc, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
+                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask, useJoin ? binBits : -1);
             else   // up to 4 095 hits per query (--max-seqs 2N beyond ~1 000 proteomes)
                 hipLaunchKernelGGL(select_hits_kernel<8192>, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
-                                   dDiag.p, dQHitBase.p, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
-                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask);
+                                   diagSrc, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
+                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask, useJoin ? binBits : -1);
         }
         SD_HIP(ctx, hipGetLastError());
         hs.reset(new HostScope(ctx, "pf.download"));
@@ -2469,6 +2636,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         for (uint32_t x = 0; x < (uint32_t) hUnsupported.size(); x++)
             if (hUnsupported[x]) outCount[qBeg + x] = UINT32_MAX;   // per-query error slot: not computed (see above)
         hs.reset();
+        forceLookup = false;
         qBeg += bq;
     }
     return SD_OK;

@@ -366,3 +366,44 @@ def test_prefilter_long_result_lists(gpu, host, oracle):
             assert n == len(ids), (max_hits, q, n, len(ids))
             assert (hits[x, :n]['seqId'] == ids).all() and (hits[x, :n]['score'] == sc).all() and (hits[x, :n]['diagonal'] == dg).all(), q
         assert longest > 2048, (max_hits, longest)
+
+
+def test_prefilter_join_path_equals_lookup_path(gpu, host, monkeypatch):
+    """the k-mer-major join (default for k = 6) and the per-k-mer lookup path (SD_PF_JOIN=0) give identical hit tables
+    and statistics -- plain, with the coarse split forced, and with the reference's hit-buffer overflow forced into
+    the longest queries (the split is a k-mer ordinal on the join path, a stream position on the other)"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=12, genes_per_proteome=900, n_families=1400, seed=91)
+    ident = np.arange(ps.n, dtype=np.uint32)
+    sw_b, dg_b, km_b = host.comp_bias(ps.residues, ps.offsets)
+    idx = host.build_index(ps.residues, ps.offsets)
+    tgt = api.Target(gpu, host, idx)
+    nq = 5000
+    res = ps.residues[:int(ps.offsets[nq])]
+    off = ps.offsets[:nq + 1]
+
+    def same(a, b, what):
+        assert np.array_equal(a[1], b[1]), what
+        assert np.array_equal(a[2], b[2]), what
+        for q in range(nq):
+            n = int(a[1][q])
+            assert np.array_equal(a[0][q, :n], b[0][q, :n]), (what, q)
+
+    for bin_size, max_hits in ((None, 300), (8, 50)):
+        par = api.prefilter_params(host, idx.n, max_hits=max_hits, cov_thr=0.8, bin_size=bin_size)
+        monkeypatch.setenv('SD_PF_JOIN', '0')
+        a = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)
+        monkeypatch.setenv('SD_PF_JOIN', '1')
+        b = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)
+        same(a, b, ('plain', bin_size))
+        assert int(a[1].sum()) > 30000
+        for budget in ('20000', '1500'):
+            monkeypatch.setenv('SD_PF_COARSE', budget)
+            c = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)
+            same(a, c, ('coarse', budget))
+        monkeypatch.delenv('SD_PF_COARSE')
+        # small sub-batches: groups of one query, several sub-batches per call
+        monkeypatch.setenv('SD_PF_BATCH', '700')
+        d = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)
+        same(a, d, ('batch 700', bin_size))
+        monkeypatch.delenv('SD_PF_BATCH')
