@@ -25,10 +25,12 @@ constexpr int KP_SHIFT = 53;           // element >> 53 = kmer >> 15
 constexpr int KP_TILE = 16384;
 constexpr int KP_PER = KP_TILE / JP_NT;
 constexpr int JQ_MAX = 4096;           // queries per sub-batch
-constexpr int JJ_WGS = 768;            // persistent workgroups of the join (three per CU)
-constexpr int JJ_NT = 512;
-constexpr int JC = 1024;               // k-mers per join chunk
+constexpr int JJ_WGS = 512;            // persistent workgroups of the join (two per CU)
+constexpr int JJ_NT = 1024;
+constexpr int JE = 2;                  // k-mers per lane and step of the join (independent load chains in flight)
+constexpr int JC = JJ_NT * JE;         // k-mers per join chunk: 64 * JE per wavefront
 constexpr uint32_t JOIN_ORD_LIMIT = 1u << 24;   // k-mers per query the value word can order
+constexpr uint64_t JP_PAD = ~0ull;     // filler behind a k-mer range (ranges are padded to whole join chunks)
 
 // element of the k-mer stream: kmer << 38 | stream index (< 2^30) << 8 | low byte of the query position
 __device__ __forceinline__ uint64_t jpElem(uint32_t kmer, uint64_t streamIdx, int i) {
@@ -140,15 +142,17 @@ col_prefix_kernel(uint32_t *__restrict__ m, int rows /* multiple of 4 */, int co
     }
 }
 
-// exclusive scan of n <= 4096 totals into 64-bit bases (n + 1 values), one workgroup
+// exclusive scan of n <= 4096 totals into 64-bit bases (n + 1 values), one workgroup; pad > 0: every total is rounded
+// up to a multiple of pad first (k-mer ranges start on join-chunk boundaries)
 __global__ void __launch_bounds__(JP_NT)
-small_scan_kernel(const uint32_t *__restrict__ in, int n, uint64_t *__restrict__ out) {
+small_scan_kernel(const uint32_t *__restrict__ in, int n, uint64_t *__restrict__ out, uint32_t pad) {
     __shared__ uint64_t part[JP_NT / 64];
     const int t = threadIdx.x;
     uint64_t v[4], sum = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         v[j] = (t * 4 + j < n) ? (uint64_t) in[t * 4 + j] : 0;
+        if (pad) v[j] = (v[j] + pad - 1) / pad * pad;
         sum += v[j];
     }
     uint64_t incl = sum;
@@ -191,12 +195,21 @@ __device__ __forceinline__ void jpBlockScan2(uint32_t *arr, int n, uint32_t *par
     __syncthreads();
 }
 
+// Element of the k-mer-sorted stream (written by kp_scatter_kernel): the range is implied by the position, so the word
+// has room for the owning query and the k-mer's ordinal in it -- the join looks neither up:
+//   k-mer & 0x7FFF << 44 | query (< 4096) << 32 | ordinal (< 2^24) << 8 | low byte of the query position
+__device__ __forceinline__ uint64_t jpSortedElem(uint64_t e, uint32_t q, uint32_t ord) {
+    return (((e >> 38) & 0x7FFFull) << 44) | ((uint64_t) q << 32) | ((uint64_t) ord << 8) | (e & 0xFFull);
+}
+
 __global__ void __launch_bounds__(JP_NT)
 kp_scatter_kernel(const uint64_t *__restrict__ in, uint64_t n, const uint32_t *__restrict__ prefix /* [JP_WGS][KP_BINS] */,
-                  const uint64_t *__restrict__ binBase, uint64_t *__restrict__ out) {
+                  const uint64_t *__restrict__ binBase, const uint32_t *__restrict__ qKmerBase, uint32_t nQ,
+                  uint64_t *__restrict__ out) {
     __shared__ uint64_t stage[KP_TILE];
     __shared__ uint32_t cnt[KP_BINS], lstart[KP_BINS], cur[KP_BINS];
     __shared__ uint32_t part[JP_NT / 64 + 1];
+    __shared__ uint32_t sQ0;
     const int t = threadIdx.x;
     for (int b = t; b < KP_BINS; b += JP_NT) {
         cur[b] = (uint32_t) binBase[b] + prefix[(size_t) blockIdx.x * KP_BINS + b];
@@ -210,6 +223,15 @@ kp_scatter_kernel(const uint64_t *__restrict__ in, uint64_t n, const uint32_t *_
     for (uint64_t tile = blockIdx.x * perWg; tile < min(nTiles, (blockIdx.x + 1) * perWg); tile++) {
         const uint64_t base = tile * KP_TILE;
         const int tn = (int) min((uint64_t) KP_TILE, n - base);
+        if (t == 0) {   // query of the tile's first k-mer: the tile's k-mers belong to it or to the next few
+            uint32_t lo = 0, hi = nQ;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (qKmerBase[mid] <= (uint32_t) base) lo = mid;
+                else hi = mid;
+            }
+            sQ0 = lo;
+        }
         uint64_t e[KP_PER];
         uint32_t r[KP_PER];
 #pragma unroll
@@ -232,13 +254,17 @@ kp_scatter_kernel(const uint64_t *__restrict__ in, uint64_t n, const uint32_t *_
             if (x < tn) stage[lstart[(uint32_t) (e[j] >> KP_SHIFT)] + r[j]] = e[j];
         }
         __syncthreads();
+        const uint32_t q0 = sQ0;
 #pragma unroll
         for (int j = 0; j < KP_PER; j++) {
             const int x = j * JP_NT + t;
             if (x < tn) {
                 const uint64_t v = stage[x];
                 const uint32_t b = (uint32_t) (v >> KP_SHIFT);
-                out[cur[b] + ((uint32_t) x - lstart[b])] = v;
+                const uint32_t sidx = (uint32_t) (v >> 8) & 0x3FFFFFFFu;
+                uint32_t q = q0;
+                while (q + 1 < nQ && qKmerBase[q + 1] <= sidx) q++;
+                out[cur[b] + ((uint32_t) x - lstart[b])] = jpSortedElem(v, q, sidx - qKmerBase[q]);
             }
         }
         __syncthreads();
@@ -250,17 +276,27 @@ kp_scatter_kernel(const uint64_t *__restrict__ in, uint64_t n, const uint32_t *_
     }
 }
 
+// behind every k-mer range: fillers up to the next chunk boundary, and the range of every chunk
+__global__ void __launch_bounds__(256)
+kp_finish_kernel(const uint32_t *__restrict__ total, const uint64_t *__restrict__ binBase, uint64_t *__restrict__ sorted,
+                 uint16_t *__restrict__ chunkBin) {
+    const uint32_t b = blockIdx.x;
+    const uint64_t s = binBase[b], e = binBase[b + 1];
+    for (uint64_t x = s + total[b] + threadIdx.x; x < e; x += 256) sorted[x] = JP_PAD;
+    for (uint64_t c = s / JC + threadIdx.x; c < e / JC; c += 256) chunkBin[c] = (uint16_t) b;
+}
+
 // ---- the join.  Work split (identical in the count and the scatter pass): XCD x = workgroup & 7 owns the x-th eighth
 // of the k-mer-sorted stream, its workgroups take that range's chunks round-robin, so the CUs of an XCD work on
 // neighbouring chunks -- the same one or two k-mer ranges -- at any time and the table slices stay in that XCD's L2.
-// A range is in query order (see kp_scatter_kernel), so a chunk of 1 024 k-mers touches a few dozen queries and its
-// hits are a few long runs: they are written straight to the per-query segments, positions handed out by LDS cursors
-// (lanes of a wavefront mostly share the query, the returned positions are consecutive, the stores coalesce).
+// A range is in query order (see kp_scatter_kernel), so a chunk's k-mers touch a few dozen queries and its hits are a
+// few long runs: they are written straight to the per-query segments, positions handed out by LDS cursors (lanes of
+// a wavefront mostly share the query, the returned positions are consecutive, the stores coalesce).
 struct JoinSpan {
-    uint64_t begin, end;   // this XCD's element range
+    uint64_t begin, end;   // this XCD's element range (whole chunks)
     uint32_t slot, nSlots;
 };
-__device__ __forceinline__ JoinSpan joinSpan(uint64_t n) {
+__device__ __forceinline__ JoinSpan joinSpan(uint64_t n /* multiple of JC */) {
     const uint32_t xcd = blockIdx.x & 7u;
     uint64_t per = (n + 7) / 8;
     per = (per + JC - 1) / JC * JC;
@@ -272,40 +308,65 @@ __device__ __forceinline__ JoinSpan joinSpan(uint64_t n) {
     return s;
 }
 
-// last q with base[q] <= sidx (base[0] = 0, base[nQ] = total)
-__device__ __forceinline__ uint32_t joinQueryOf(const uint32_t *base, uint32_t nQ, uint32_t sidx) {
-    uint32_t lo = 0, hi = nQ;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (base[mid] <= sidx) lo = mid;
-        else hi = mid;
-    }
-    return lo;
-}
-
 __global__ void __launch_bounds__(JJ_NT)
-join_count_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint32_t *__restrict__ idxOffsets,
-                  const uint32_t *__restrict__ qKmerBase, uint32_t nQ, uint32_t *__restrict__ counts /* [JJ_WGS][cols] */,
-                  int cols, unsigned long long *__restrict__ wgTotal /* [JJ_WGS]: 64-bit, the per-query counts are 32 */) {
-    __shared__ uint32_t sQB[JQ_MAX + 1];
+join_count_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint16_t *__restrict__ chunkBin,
+                  const uint32_t *__restrict__ idxOffsets, uint32_t *__restrict__ counts /* [JJ_WGS][cols] */, int cols,
+                  unsigned long long *__restrict__ wgTotal /* [JJ_WGS]: 64-bit, the per-query counts are 32 */) {
     __shared__ uint32_t hist[JQ_MAX];
     __shared__ unsigned long long sTotal;
     unsigned long long mine = 0;
     if (threadIdx.x == 0) sTotal = 0;
-    for (uint32_t x = threadIdx.x; x <= nQ; x += JJ_NT) sQB[x] = qKmerBase[x];
     for (int x = threadIdx.x; x < cols; x += JJ_NT) hist[x] = 0;
     __syncthreads();
     const JoinSpan sp = joinSpan(n);
-    for (uint64_t base = sp.begin + (uint64_t) sp.slot * JC; base < sp.end; base += (uint64_t) sp.nSlots * JC) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t step = (uint64_t) sp.nSlots * JC;
+    uint64_t nx[JE];   // the next chunk's k-mers are on their way while this one is worked on
+    uint32_t nxHi = 0;
+    {
+        const uint64_t b0 = sp.begin + (uint64_t) sp.slot * JC;
+        if (b0 < sp.end) {
+            nxHi = (uint32_t) chunkBin[b0 / JC] << 15;
 #pragma unroll
-        for (int j = 0; j < JC / JJ_NT; j++) {
-            const uint64_t idx = base + (uint64_t) j * JJ_NT + threadIdx.x;
-            if (idx < sp.end) {
-                const uint64_t e = sorted[idx];
-                const uint32_t km = (uint32_t) (e >> 38);
-                const uint32_t len = idxOffsets[km + 1] - idxOffsets[km];
-                if (len) atomicAdd(&hist[joinQueryOf(sQB, nQ, (uint32_t) (e >> 8) & 0x3FFFFFFFu)], len);
-                mine += len;
+            for (int j = 0; j < JE; j++) nx[j] = __builtin_nontemporal_load(sorted + b0 + (uint64_t) j * JJ_NT + threadIdx.x);
+        }
+    }
+    for (uint64_t base = sp.begin + (uint64_t) sp.slot * JC; base < sp.end; base += step) {
+        const uint32_t kmHi = nxHi;
+        uint64_t e[JE];
+        uint32_t len[JE];
+#pragma unroll
+        for (int j = 0; j < JE; j++) e[j] = nx[j];
+        if (base + step < sp.end) {
+            nxHi = (uint32_t) chunkBin[(base + step) / JC] << 15;
+#pragma unroll
+            for (int j = 0; j < JE; j++) nx[j] = __builtin_nontemporal_load(sorted + base + step + (uint64_t) j * JJ_NT + threadIdx.x);
+        }
+#pragma unroll
+        for (int j = 0; j < JE; j++) {
+            len[j] = 0;
+            if (e[j] != JP_PAD) {
+                const uint32_t km = kmHi | (uint32_t) (e[j] >> 44);
+                uint32_t se[2];   // list start and end in one (4-byte aligned) 8-byte read
+                __builtin_memcpy(se, idxOffsets + km, 8);
+                len[j] = se[1] - se[0];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JE; j++) {
+            const uint32_t q = (uint32_t) (e[j] >> 32) & 0xFFFu;
+            mine += len[j];
+            // the wavefront's k-mers are in query order: one LDS add per query present, not one per lane
+            unsigned long long todo = __ballot(len[j] != 0);
+            while (todo) {
+                const int leader = __ffsll((long long) todo) - 1;
+                const uint32_t qL = __shfl(q, leader, 64);
+                const bool in = len[j] != 0 && q == qL;
+                uint32_t sum = in ? len[j] : 0u;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                if (lane == leader) atomicAdd(&hist[qL], sum);
+                todo &= ~__ballot(in);
             }
         }
     }
@@ -324,56 +385,90 @@ __global__ void join_effective_totals_kernel(uint32_t nQ, const uint32_t *__rest
     if (q < nQ) eff[q] = qSplit[q] == QUERY_UNSUPPORTED ? 0u : qHits[q];
 }
 
+// Every wavefront works through its 64 * JE k-mers of a chunk on its own (no workgroup barrier inside the loop, so the
+// wavefronts of a CU hide each other's memory latency): list starts and lengths, a wave scan of the lengths, then the
+// lists flattened over the lanes -- hit f of the wavefront belongs to the k-mer x with off[x] <= f < off[x + 1].
 __global__ void __launch_bounds__(JJ_NT)
-join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint32_t *__restrict__ idxOffsets,
-                    const uint2 *__restrict__ entries, const uint32_t *__restrict__ qKmerBase, uint32_t nQ,
+join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint16_t *__restrict__ chunkBin,
+                    const uint32_t *__restrict__ idxOffsets, const uint2 *__restrict__ entries, uint32_t nQ,
                     const uint32_t *__restrict__ prefix /* [JJ_WGS][cols]: hits of the workgroups before this one, per query */,
                     int cols, const uint64_t *__restrict__ qHitBase, int tBits, const uint32_t *__restrict__ qSplit,
                     uint2 *__restrict__ outKV) {
-    __shared__ uint32_t sQB[JQ_MAX + 1];
     __shared__ uint32_t qcur[JQ_MAX];   // this workgroup's write position inside every query's segment (< 2^32 hits per sub-batch)
-    __shared__ uint32_t eOff[JC + 1], eStart[JC], eKey[JC], eVal[JC];
-    __shared__ uint32_t part[JJ_NT / 64 + 1];
-    const int t = threadIdx.x;
-    for (uint32_t x = t; x <= nQ; x += JJ_NT) sQB[x] = qKmerBase[x];
+    constexpr int WE = 64 * JE;   // k-mers per wavefront and step
+    __shared__ uint32_t wOff[JJ_NT / 64][WE + 1], wStart[JJ_NT / 64][WE], wKey[JJ_NT / 64][WE], wVal[JJ_NT / 64][WE];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     for (uint32_t q = t; q < nQ; q += JJ_NT)
         qcur[q] = qSplit[q] == QUERY_UNSUPPORTED ? 0xFFFFFFFFu : (uint32_t) qHitBase[q] + prefix[(size_t) blockIdx.x * cols + q];
     __syncthreads();
+    uint32_t *eOff = wOff[wv], *eStart = wStart[wv], *eKey = wKey[wv], *eVal = wVal[wv];
     const JoinSpan sp = joinSpan(n);
-    for (uint64_t base = sp.begin + (uint64_t) sp.slot * JC; base < sp.end; base += (uint64_t) sp.nSlots * JC) {
-        // the chunk's k-mers: list start / length, owning query, ordinal; thread t owns elements 2t, 2t + 1
+    const uint64_t step = (uint64_t) sp.nSlots * JC;
+    uint64_t nx[JE];   // the next chunk's k-mers are on their way while this one is worked on
+    uint32_t nxHi = 0;
+    {
+        const uint64_t b0 = sp.begin + (uint64_t) sp.slot * JC;
+        if (b0 < sp.end) {
+            nxHi = (uint32_t) chunkBin[b0 / JC] << 15;
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int x = 2 * t + j;
-            const uint64_t idx = base + x;
-            uint32_t len = 0;
-            if (idx < sp.end) {
-                const uint64_t e = sorted[idx];
-                const uint32_t km = (uint32_t) (e >> 38);
-                const uint32_t s = idxOffsets[km];
-                len = idxOffsets[km + 1] - s;
-                const uint32_t sidx = (uint32_t) (e >> 8) & 0x3FFFFFFFu;
-                const uint32_t q = joinQueryOf(sQB, nQ, sidx);
-                if (len && qcur[q] == 0xFFFFFFFFu) len = 0;   // query taken out of the batch
-                eStart[x] = s;
-                eKey[x] = q << tBits;
-                eVal[x] = ((uint32_t) (e & 0xFF) << 24) | (sidx - sQB[q]);
-            }
-            eOff[x] = len;
+            for (int j = 0; j < JE; j++)   // streamed once: not to displace the table slices in L2
+                nx[j] = __builtin_nontemporal_load(sorted + b0 + (uint64_t) wv * WE + (uint64_t) j * 64 + lane);
         }
-        __syncthreads();
-        jpBlockScan2<JJ_NT>(eOff, JC, part);
-        const uint32_t total = part[JJ_NT / 64];
-        if (t == 0) eOff[JC] = total;
-        __syncthreads();
-        for (uint32_t f0 = 0; f0 < total; f0 += 4 * JJ_NT) {
+    }
+    for (uint64_t base = sp.begin + (uint64_t) sp.slot * JC; base < sp.end; base += step) {
+        const uint32_t kmHi = nxHi;
+        // the wavefront's k-mers: JE consecutive runs of 64 (element x = j * 64 + lane of the wavefront's step)
+        uint64_t e[JE];
+        uint32_t len[JE], st[JE];
+#pragma unroll
+        for (int j = 0; j < JE; j++) e[j] = nx[j];
+        if (base + step < sp.end) {
+            nxHi = (uint32_t) chunkBin[(base + step) / JC] << 15;
+#pragma unroll
+            for (int j = 0; j < JE; j++)
+                nx[j] = __builtin_nontemporal_load(sorted + base + step + (uint64_t) wv * WE + (uint64_t) j * 64 + lane);
+        }
+#pragma unroll
+        for (int j = 0; j < JE; j++) {
+            len[j] = 0;
+            st[j] = 0;
+            if (e[j] != JP_PAD) {
+                const uint32_t km = kmHi | (uint32_t) (e[j] >> 44);
+                uint32_t se[2];   // list start and end in one (4-byte aligned) 8-byte read
+                __builtin_memcpy(se, idxOffsets + km, 8);
+                st[j] = se[0];
+                len[j] = se[1] - se[0];
+            }
+        }
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < JE; j++) {
+            const int x = j * 64 + lane;
+            const uint32_t q = (uint32_t) (e[j] >> 32) & 0xFFFu;
+            if (len[j] && qcur[q] == 0xFFFFFFFFu) len[j] = 0;   // query taken out of the batch
+            eStart[x] = st[j];
+            eKey[x] = q << tBits;
+            eVal[x] = (uint32_t) (((e[j] & 0xFF) << 24) | ((e[j] >> 8) & 0xFFFFFF));
+            uint32_t incl = len[j];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            eOff[x] = carry + incl - len[j];
+            carry += __shfl(incl, 63, 64);
+        }
+        const uint32_t total = carry;
+        if (lane == 63) eOff[WE] = total;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t f0 = 0; f0 < total; f0 += 4 * 64) {
             uint32_t x4[4], a4[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t f = f0 + (uint32_t) j * JJ_NT + (uint32_t) t;
+                const uint32_t f = f0 + (uint32_t) j * 64 + (uint32_t) lane;
                 x4[j] = 0xFFFFFFFFu;
                 if (f < total) {
-                    int lo = 0, hi = JC;   // last x with eOff[x] <= f
+                    int lo = 0, hi = WE;   // last x with eOff[x] <= f
                     while (hi - lo > 1) {
                         const int mid = (lo + hi) >> 1;
                         if (eOff[mid] <= f) lo = mid;
@@ -389,14 +484,30 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint3
                 if (x4[j] != 0xFFFFFFFFu) en[j] = entries[a4[j]];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (x4[j] != 0xFFFFFFFFu) {
-                    const uint32_t v = eVal[x4[j]], kq = eKey[x4[j]];
-                    const uint32_t pos = atomicAdd(&qcur[kq >> tBits], 1u);
-                    outKV[pos] = make_uint2(kq | en[j].x, ((((v >> 24) - en[j].y) & 0xFFu) << 24) | (v & 0xFFFFFFu));
+                const bool live = x4[j] != 0xFFFFFFFFu;
+                uint32_t v = 0, kq = 0xFFFFFFFFu, pos = 0;
+                if (live) {
+                    v = eVal[x4[j]];
+                    kq = eKey[x4[j]];
                 }
+                // positions: one LDS add per query present in the wavefront; lanes of a query get consecutive positions
+                unsigned long long todo = __ballot(live);
+                while (todo) {
+                    const int leader = __ffsll((long long) todo) - 1;
+                    const uint32_t kL = __shfl(kq, leader, 64);
+                    const unsigned long long mask = __ballot(live && kq == kL);
+                    uint32_t b0 = 0;
+                    if (lane == leader) b0 = atomicAdd(&qcur[kL >> tBits], (uint32_t) __popcll(mask));
+                    b0 = __shfl(b0, leader, 64);
+                    if (live && kq == kL) pos = b0 + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+                    todo &= ~mask;
+                }
+                if (live)
+                    __builtin_nontemporal_store(((unsigned long long) (((((v >> 24) - en[j].y) & 0xFFu) << 24) | (v & 0xFFFFFFu)) << 32) | (kq | en[j].x),
+                                                (unsigned long long *) outKV + pos);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -2163,8 +2163,11 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             WsView<uint32_t> dQHits(ctx, "pf.dQHits");
             WsView<unsigned long long> dWgTotal(ctx, "pf.dWgTotal");
             WsView<uint32_t> dQEff(ctx, "pf.dQEff");
+            const uint64_t nSortedCap = nKmers + (uint64_t) KP_BINS * JC;   // every k-mer range padded to whole join chunks
+            WsView<uint16_t> dChunkBin(ctx, "pf.dChunkBin");
             SD_HIP(ctx, dElems.alloc(nKmers + 1));
-            SD_HIP(ctx, dSorted.alloc(nKmers + 1));
+            SD_HIP(ctx, dSorted.alloc(nSortedCap));
+            SD_HIP(ctx, dChunkBin.alloc(nSortedCap / JC + 1));
             SD_HIP(ctx, dKpCounts.alloc((size_t) JP_WGS * KP_BINS));
             SD_HIP(ctx, dKpTotal.alloc(KP_BINS));
             SD_HIP(ctx, dKpBase.alloc(KP_BINS + 1));
@@ -2176,18 +2179,23 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 hipLaunchKernelGGL(emit_kmers_join_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq, dQ.p,
                                    dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, dKmerBase.p, dElems.p);
             }
+            uint64_t nSorted = 0;
             {
                 ProfScope ps(ctx, "prefilter_kmer_partition");
                 hipLaunchKernelGGL(kp_hist_kernel, dim3(JP_WGS), dim3(JP_NT), 0, ctx->stream, (const uint64_t *) dElems.p, nKmers, dKpCounts.p);
                 hipLaunchKernelGGL(col_prefix_kernel, dim3(KP_BINS / 64), dim3(256), 0, ctx->stream, dKpCounts.p, JP_WGS, KP_BINS, dKpTotal.p);
-                hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(JP_NT), 0, ctx->stream, (const uint32_t *) dKpTotal.p, KP_BINS, dKpBase.p);
+                hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(JP_NT), 0, ctx->stream, (const uint32_t *) dKpTotal.p, KP_BINS, dKpBase.p, (uint32_t) JC);
                 hipLaunchKernelGGL(kp_scatter_kernel, dim3(JP_WGS), dim3(JP_NT), 0, ctx->stream, (const uint64_t *) dElems.p, nKmers,
-                                   (const uint32_t *) dKpCounts.p, (const uint64_t *) dKpBase.p, dSorted.p);
+                                   (const uint32_t *) dKpCounts.p, (const uint64_t *) dKpBase.p, (const uint32_t *) dQKmerBase.p, bq, dSorted.p);
+                hipLaunchKernelGGL(kp_finish_kernel, dim3(KP_BINS), dim3(256), 0, ctx->stream, (const uint32_t *) dKpTotal.p,
+                                   (const uint64_t *) dKpBase.p, dSorted.p, dChunkBin.p);
+                SD_HIP(ctx, hipMemcpyAsync(&nSorted, dKpBase.p + KP_BINS, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                SD_HIP(ctx, sdStreamSync(ctx));
             }
             {
                 ProfScope ps(ctx, "prefilter_join_count");
-                hipLaunchKernelGGL(join_count_kernel, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nKmers,
-                                   (const uint32_t *) T->dOffsets, (const uint32_t *) dQKmerBase.p, bq, dJqCounts.p, (int) bq, dWgTotal.p);
+                hipLaunchKernelGGL(join_count_kernel, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSorted,
+                                   (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, dJqCounts.p, (int) bq, dWgTotal.p);
                 hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor(bq, 64)), dim3(256), 0, ctx->stream, dJqCounts.p, JJ_WGS, (int) bq, dQHits.p);
             }
             // overflow of the reference's hit buffer, in k-mer ordinals
@@ -2240,12 +2248,12 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             SD_HIP(ctx, dQHitBase.alloc(bq + 1));
             hipLaunchKernelGGL(join_effective_totals_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQHits.p,
                                (const uint32_t *) dQSplit.p, dQEff.p);
-            hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(JP_NT), 0, ctx->stream, (const uint32_t *) dQEff.p, (int) bq, dQHitBase.p);
+            hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(JP_NT), 0, ctx->stream, (const uint32_t *) dQEff.p, (int) bq, dQHitBase.p, 0u);
             if (nHits > 0) {
                 SD_HIP(ctx, dHitsKV.alloc(nHits));
                 ProfScope ps(ctx, "prefilter_join_scatter");
-                hipLaunchKernelGGL(join_scatter_kernel, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nKmers,
-                                   (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, (const uint32_t *) dQKmerBase.p, bq,
+                hipLaunchKernelGGL(join_scatter_kernel, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSorted,
+                                   (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                    (const uint32_t *) dJqCounts.p, (int) bq, (const uint64_t *) dQHitBase.p, tBits,
                                    (const uint32_t *) dQSplit.p, dHitsKV.p);
             }
