@@ -56,7 +56,9 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--no-p1000', action='store_true', help='skip the 1 000-proteome record')
-    ap.add_argument('--p1000-steps', type=int, default=2)
+    ap.add_argument('--p1000-steps', type=int, default=5)
+    ap.add_argument('--strong', action='store_true', help='strong scaling: --batch query proteomes per step in TOTAL, dealt over the ranks '
+                                                          '(BASELINE configs[2] as written: one query set of proteomes split over N GPUs)')
     ap.add_argument('--record', action='store_true', help=argparse.SUPPRESS)   # child mode: one plain measurement, JSON out
     return ap.parse_args()
 
@@ -81,23 +83,6 @@ def cpu_baseline_subprocess(proteomes, genes, max_seqs, kmer_thr, bin_size, entr
         return json.loads(line[-1])
     except Exception as e:
         return dict(value=None, unit='genome-pairs/s', cores=0, kind='failed', sample=repr(e))
-
-
-def records_of(out):
-    """one int64 row per (query set, target set) entry of a result: ids, #hits, #clusters, order-sensitive checksums of the
-    cluster assignment and the P-values' bit patterns -- what the final gather carries"""
-    if out['cluster_out'] is None:
-        return np.zeros((0, 6), np.int64)
-    co, off = out['cluster_out'], out['entry_off']
-    rows = []
-    for e in range(len(out['entry_q'])):
-        a, b = int(off[e]), int(off[e + 1])
-        w = np.arange(1, b - a + 1, dtype=np.int64)
-        nclu = int(co['n_clusters'][e])
-        pbits = np.frombuffer(np.ascontiguousarray(co['pCO'][a:a + nclu]).tobytes(), np.int64)
-        rows.append([int(out['entry_q'][e]), int(out['entry_t'][e]), b - a, nclu,
-                     int(((co['cluster_of'][a:b].astype(np.int64) + 2) * w).sum() % (1 << 40)), int((pbits % (1 << 40)).sum() % (1 << 40))])
-    return np.array(rows, np.int64).reshape(-1, 6)
 
 
 def parity_check(gpu, host, ps, index, max_seqs, bin_size, kmer_thr, check_path):
@@ -174,41 +159,36 @@ def measure(args, rank, local_rank, world, dist, torch):
         index = full.build_index(ps.residues, ps.offsets, k, kmer_thr)
         index_how = 'built once on rank 0 (%d threads)' % full.threads
     if dist is not None:
-        shape = torch.zeros(2, dtype=torch.int64)
+        # device to device: rank 0's arrays go up once, every rank makes its target resident from the device buffers
+        # (sd_target_create takes device pointers) -- no host copy of the index on the receiving ranks
+        from spacedust_amd.api import IndexArrays, DeviceArray
+        meta = torch.zeros(4, dtype=torch.int64)
         if rank == 0:
-            shape[0], shape[1] = index.table_size, index.n_entries
-        shape = to_dev(shape)
-        dist.broadcast(shape, 0)
-        table_size, n_entries = int(shape[0].item()), int(shape[1].item())
-        arrays = []
+            meta[0], meta[1], meta[2] = index.table_size, index.n_entries, index.masked_residues
+            meta[3] = 0 if index.block_base is None else len(index.block_base)
+        meta = to_dev(meta)
+        dist.broadcast(meta, 0)
+        table_size, n_entries, n_masked, n_bb = (int(v) for v in meta.cpu().tolist())
+        arrays, nbytes = [], 0
         for name, dt, n in (('kmer_offsets', np.uint32, table_size + 1), ('entry_seq', np.uint32, n_entries),
-                            ('entry_pos', np.uint16, n_entries), ('masked', np.uint8, int(ps.offsets[-1]))):
+                            ('entry_pos', np.uint16, n_entries), ('masked', np.uint8, int(ps.offsets[-1])), ('block_base', np.uint64, n_bb)):
+            if n == 0:
+                arrays.append(None)
+                continue
             if rank == 0:
-                t = torch.from_numpy(np.ascontiguousarray(getattr(index, name)).view(np.uint8).copy())
+                src = np.ascontiguousarray(getattr(index, name)).view(np.uint8)
+                t = torch.from_numpy(src.copy() if rehearsal else src)   # (the host index object owns its arrays: a view must not outlive it)
             else:
                 t = torch.empty(n * np.dtype(dt).itemsize, dtype=torch.uint8)
             t = to_dev(t)
             dist.broadcast(t, 0)
-            arrays.append(t.cpu().numpy().view(dt))
-            del t
-        index_how += ', broadcast over %s (%.2f GB)' % ('gloo' if rehearsal else 'RCCL', sum(a.nbytes for a in arrays) / 1e9)
-        # a wide index (>= 2^32 entries, 10 000 proteomes) also carries its block bases
-        nbb = torch.tensor([0 if (rank != 0 or index.block_base is None) else len(index.block_base)], dtype=torch.int64)
-        nbb = to_dev(nbb)
-        dist.broadcast(nbb, 0)
-        block_base = None
-        if int(nbb.item()) > 0:
-            t = torch.from_numpy(np.ascontiguousarray(index.block_base).view(np.uint8).copy()) if rank == 0 else \
-                torch.empty(int(nbb.item()) * 8, dtype=torch.uint8)
-            t = to_dev(t)
-            dist.broadcast(t, 0)
-            block_base = t.cpu().numpy().view(np.uint64)
-        if rank != 0:
-            from spacedust_amd.api import IndexArrays
-            index = IndexArrays(k, kmer_thr, ps.offsets, *arrays, block_base=block_base)
+            nbytes += t.numel()
+            arrays.append(t.numpy().view(dt) if rehearsal else DeviceArray(t, n))
+        index_how += ', broadcast %s (%.2f GB), targets created from the device buffers' % ('over gloo' if rehearsal else 'device to device over RCCL', nbytes / 1e9)
+        index = IndexArrays(k, kmer_thr, ps.offsets, arrays[0], arrays[1], arrays[2], arrays[3], masked_residues=n_masked, block_base=arrays[4])
     t_index = time.time() - t0
     cs = ClusterSearch(gpu, host, db, max_seqs=max_seqs, filter_self_match=True, chunk_queries=args.chunk, index=index)
-    n_global = world * B
+    n_global = B if args.strong else world * B
     n_batches = (P + n_global - 1) // n_global
     set_start = ps.set_start
     set_res = [int(ps.offsets[set_start[s + 1]] - ps.offsets[set_start[s]]) for s in range(P)]
@@ -233,7 +213,7 @@ def measure(args, rank, local_rank, world, dist, torch):
             r, n = my_ranges(x)
             rngs += r
             pairs += n
-        return pairs, cs.search_stream(db, rngs, same_db=True)
+        return pairs, cs.search_stream(db, rngs, same_db=True, want_records=dist is not None)
 
     if args.warmup:
         run_steps(list(range(args.warmup)))
@@ -244,19 +224,16 @@ def measure(args, rank, local_rank, world, dist, torch):
     comm = None
     gather_how = 'none (single rank)'
     if dist is not None and not rehearsal:
-        try:   # the C ABI's RCCL seam; the communicator is set up before the timed region
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
-            uid = to_dev(uid)
-            dist.broadcast(uid, 0)
-            comm = RcclGather(dev_index, world, rank, bytes(uid.cpu().numpy().tobytes()))
-            gather_how = 'sd_gather_results (RCCL, C ABI)'
-        except Exception as e:   # never lose the measurement to the seam: torch.distributed carries the gather instead
-            comm = None
-            gather_how = 'torch.distributed all_gather (sd_comm_init failed: %s)' % str(e)[:120]
+        # the C ABI's RCCL seam; the communicator is set up before the timed region.  A failure here is a failed run.
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
+        uid = to_dev(uid)
+        dist.broadcast(uid, 0)
+        comm = RcclGather(dev_index, world, rank, bytes(uid.cpu().numpy().tobytes()))
+        gather_how = 'sd_gather_results (RCCL, C ABI): the cluster records of every rank to rank 0, which writes the TSV from the gathered buffer'
     elif dist is not None:
-        gather_how = 'torch.distributed all_gather over gloo (rehearsal)'
+        gather_how = 'rehearsal on one GPU (RCCL refuses two ranks per device): the same records over torch.distributed / gloo'
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -270,19 +247,18 @@ def measure(args, rank, local_rank, world, dist, torch):
         summary += np.array([out['entries'], out['matched_hits'], out['clusters'], out['cluster_hits']], np.int64)
         for s_, v in out['timing'].items():
             stage[s_] = stage.get(s_, 0.0) + v
-    recs = np.concatenate([records_of(o) for o in outs]) if outs else np.zeros((0, 6), np.int64)
-    gathered = None
+    gathered, gather_sizes, tsv_info = None, None, None
     if dist is not None:
-        # the one exchange of the path: every rank's result records to rank 0
+        # the one exchange of the path: every rank's cluster records to rank 0, which writes the result TSV from the gathered buffer
+        recs = np.concatenate([o['records'] for o in outs]) if outs else np.zeros(0, np.uint8)
         if comm is not None:
-            try:
-                gathered = comm.gather(recs)
-            except Exception as e:
-                gather_how = 'torch.distributed all_gather (sd_gather_results failed: %s)' % str(e)[:120]
-                comm = None
-        if comm is None:
+            gathered, gather_sizes = comm.gather_bytes(recs)
+        else:
             from spacedust_amd.pipeline import gather_results
-            gathered = gather_results(recs, dist, device=None if rehearsal else torch.device('cuda', dev_index))
+            parts = gather_results(np.frombuffer(np.concatenate([recs, np.zeros((-len(recs)) % 8, np.uint8)]).tobytes(), np.int64), dist)
+            lens = gather_results(np.array([len(recs)], np.int64), dist)
+            gather_sizes = np.array([int(l[0]) for l in lens], np.uint64)
+            gathered = np.concatenate([np.asarray(p_, np.int64).view(np.uint8)[:int(n_)] for p_, n_ in zip(parts, gather_sizes)]) if rank == 0 else None
     for c_ in cs.contexts:
         c_.synchronize()
     torch.cuda.synchronize()
@@ -298,10 +274,22 @@ def measure(args, rank, local_rank, world, dist, torch):
         tot = to_dev(torch.tensor([pairs_done], dtype=torch.float64))
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         pairs_total = float(tot.item())
+        sm = to_dev(torch.from_numpy(summary.copy()))   # the job's result counters: all ranks
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        summary = sm.cpu().numpy()
     else:
         dt_max, pairs_total = dt, float(pairs_done)
     if rank != 0:
         return None
+    if gathered is not None:
+        # rank 0 writes the result TSV from the gathered buffer (after the timed region: the single-rank line does not write one either)
+        from spacedust_amd.pipeline import write_records_tsv
+        tsv = os.path.join(tempfile.gettempdir(), 'sd_bench_%d.tsv' % os.getpid())
+        t_tsv = time.time()
+        n_clu, n_hit = write_records_tsv(gathered, tsv, db, db)
+        tsv_info = dict(bytes=int(os.path.getsize(tsv)), clusters=n_clu, hits=n_hit, seconds=time.time() - t_tsv,
+                        clusters_match_results=bool(n_clu == int(summary[2]) and n_hit == int(summary[3])))
+        os.remove(tsv)
     prof = {}
     for c_ in cs.contexts:   # every stage runs on its own context / stream (two of them for the alignment lanes)
         for k_, v_ in c_.profile_report().items():
@@ -321,44 +309,78 @@ def measure(args, rank, local_rank, world, dist, torch):
     sw_ms = sum(v['ms'] for k_, v in grouped.items() if k_.startswith('sw_score'))
     cells_sw = st['cells_fwd'] + st['cells_rev']
     b_sw = st['pairs'] * (int(ps.lengths().mean()) * 23 + 24)
-    dev_kernels = {k_: v for k_, v in grouped.items() if not k_.startswith('host:')}
-    dom = max(dev_kernels.items(), key=lambda kv: kv[1]['ms'])[0] if dev_kernels else 'none'
-    if dom.startswith('sw_score'):
-        alg, per = b_sw * grouped[dom]['ms'] / max(sw_ms, 1e-9), grouped[dom]
-    elif dom.startswith('prefilter_'):
-        share = kernels[dom]['ms'] / pf_ms if pf_ms > 0 else 1.0
-        alg, per = (6 * st['index_hits'] if dom in ('prefilter_gather_hits', 'prefilter_sort_hits') else b_pref * share), grouped[dom]
-    else:
-        alg, per = 17 * int(summary[1]) + 4 * int(summary[1]), grouped.get(dom, dict(ms=1, launches=1))
-    achieved = (alg / max(per['launches'], 1)) / ((per['ms'] / max(per['launches'], 1)) * 1e-3) / 1e9 if per['ms'] > 0 else 0.0
-    # HBM traffic per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs, tools/pmc_summary.py): the newest round's file that has the kernel
-    traffic, traffic_src = None, None
-    for fn in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    # One roofline object per stage.  Prefilter: HBM -- every kernel with its own algorithmic bytes (the bytes the stage's data
+    # structures make it move once: K similar k-mers of 8 B, H index hits of 8 B, the table slices once per sub-batch) over its
+    # event-timed duration; the headline `roofline` is the stage with the largest share of the kernel time and, inside it, the
+    # kernel with the largest.  Alignment: the score pass is integer-VALU bound -- `roofline_sw` prices it against the measured
+    # VALU issue peak (sw_valu).
+    K, H, Cn = st['kmers'], st['index_hits'], st['diagonals']
+    n_sub = max(kernels.get('prefilter_emit_kmers', dict(launches=1))['launches'], 1)
+    tab = 4 * (index.table_size + 1)
+    ent = 8 * index.n_entries
+    join = 'prefilter_join_scatter' in kernels
+    alg_of = {'prefilter_count_kmers': 21 * q_len_sum,
+              'prefilter_emit_kmers': 8 * K if join else 16 * K + 0,
+              'prefilter_kmer_partition': 24 * K,
+              'prefilter_join_count': 8 * K + n_sub * tab,
+              'prefilter_join_scatter': 8 * K + n_sub * (tab + ent) + 8 * H,
+              'prefilter_gather_hits': 12 * K + 6 * H + 10 * H,
+              'prefilter_partition_hits': 24 * H,
+              'prefilter_coarse_split': 24 * H,
+              'prefilter_bucket_match': 8 * H + 8 * Cn,
+              'prefilter_bucket_match_big': 0,
+              'prefilter_score_diag': 15 * Cn + st['diag_len'],
+              'prefilter_keep_max': 8 * Cn,
+              'prefilter_select_hits': 12 * Cn + 10 * st['prefilter_hits']}
+    pmc = {}
+    pmc_src = None
+    for fn in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
-            if dom in pmc:
-                traffic = pmc[dom]['bytes_per_launch'] * (pmc[dom]['launches'] / max(per['launches'] / max(args.steps, 1), 1))
-                traffic_src = 'profiles/' + fn
-                break
-        except (OSError, ValueError, KeyError):
+            pmc_src = 'profiles/' + fn
+            break
+        except (OSError, ValueError):
             pass
-    roofline = dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, traffic_source=traffic_src, launches=per['launches'], avg_launch_ms=per['ms'] / max(per['launches'], 1),
-                    note=('the score pass is integer-VALU bound (DP state lives in VGPR/LDS): see sw_valu; algorithmic bytes = '
-                          'residue streams only') if dom.startswith('sw_score') else 'algorithmic bytes per SURVEY.md 8(d)')
+    per_kernel = {}
+    for k_, v in kernels.items():
+        if not k_.startswith('prefilter_') or v['ms'] <= 0:
+            continue
+        alg = alg_of.get(k_, 0)
+        e_ = dict(ms=v['ms'], launches=v['launches'], avg_launch_ms=v['ms'] / max(v['launches'], 1), algorithmic_bytes=int(alg),
+                  achieved=alg / v['ms'] / 1e6, frac=alg / v['ms'] / 1e6 / HBM_PEAK_GBS)
+        if k_ in pmc:   # bytes per launch at the memory side (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes of the same command)
+            e_['traffic'] = pmc[k_]['bytes_per_launch']
+            e_['traffic_over_algorithmic'] = pmc[k_]['bytes_per_launch'] / max(alg / max(v['launches'], 1), 1)
+        per_kernel[k_] = e_
+    tb_ms = sum(v['ms'] for k_, v in grouped.items() if k_.startswith('sw_traceback'))
+    stage_ms = {'prefilter': pf_ms, 'sw_score': sw_ms, 'sw_traceback': tb_ms}
+    dom_stage = max(stage_ms.items(), key=lambda kv: kv[1])[0]
+    dom = max(per_kernel.items(), key=lambda kv: kv[1]['ms'])[0] if per_kernel else 'none'
+    dk = per_kernel.get(dom, dict(achieved=0.0, launches=0, avg_launch_ms=0.0))
+    roofline = dict(bound='hbm', stage='prefilter', kernel=dom, achieved=dk['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=dk['achieved'] / HBM_PEAK_GBS,
+                    traffic=dk.get('traffic'), traffic_source=pmc_src if dk.get('traffic') is not None else None, launches=dk['launches'],
+                    avg_launch_ms=dk['avg_launch_ms'], stage_achieved=b_pref / pf_ms / 1e6 if pf_ms > 0 else 0.0,
+                    stage_frac=(b_pref / pf_ms / 1e6 / HBM_PEAK_GBS) if pf_ms > 0 else 0.0, stage_kernel_ms=stage_ms,
+                    largest_stage=dom_stage, per_kernel=per_kernel,
+                    note='kernel durations are HIP-event timed inside the running pipeline (four streams share the GPU); algorithmic bytes: '
+                         'K k-mers x 8 B, H hits x 8 B, table slices once per sub-batch (DESIGN.md 4.3); stage_achieved uses SURVEY.md 8(d)')
     # VALU view of the score pass: lane-instructions of the inner loop per DP cell against the VALU issue ceiling.  Both
     # constants come from measurements kept under profiles/ (tools/valu_peak.py: issue micro-benchmark; PMC: SQ_INSTS_VALU per
     # cell); the literals are the fallback when that file is absent
     valu = dict(instr_per_cell=11.1, peak_lane_instr_per_s=256 * 64 * 2.4e9,
                 source='ISA count of sw_score_pk RT=8 (178 per 16 cells); 256 CU x 64 lanes x 2.4 GHz')
     try:
-        v = json.load(open(os.path.join(ROOT, 'profiles', 'r02_valu_calibration.json')))
-        valu = dict(instr_per_cell=v['instr_per_cell'], peak_lane_instr_per_s=v['peak_lane_instr_per_s'], source='profiles/r02_valu_calibration.json')
+        fn = 'r03_valu_calibration.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_valu_calibration.json')) else 'r02_valu_calibration.json'
+        v = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+        valu = dict(instr_per_cell=v['instr_per_cell'], peak_lane_instr_per_s=v['peak_lane_instr_per_s'], source='profiles/' + fn)
     except (OSError, ValueError, KeyError):
         pass
     sw_valu = dict(cells_per_s=cells_sw / (sw_ms * 1e-3) if sw_ms > 0 else 0.0, **valu)
     sw_valu['frac'] = sw_valu['cells_per_s'] * sw_valu['instr_per_cell'] / sw_valu['peak_lane_instr_per_s']
+    roofline_sw = dict(bound='valu', stage='sw_score', kernel='sw_score_pk', achieved=sw_valu['cells_per_s'] * sw_valu['instr_per_cell'] / 1e12,
+                       peak=sw_valu['peak_lane_instr_per_s'] / 1e12, unit='T lane-instr/s', frac=sw_valu['frac'], kernel_ms=sw_ms,
+                       hbm_achieved_GBs=b_sw / sw_ms / 1e6 if sw_ms > 0 else 0.0,
+                       note='integer DP in VGPR/LDS: priced against the measured VALU issue peak (tools/valu_peak.py), not HBM')
     res = {
         'metric': 'clustersearch throughput (genome-pairs/s; SW GCUPS alongside)',
         'value': pairs_total / dt_max,
@@ -368,16 +390,17 @@ def measure(args, rank, local_rank, world, dist, torch):
         'warmup': args.warmup,
         'ms_per_step': dt_max / args.steps * 1e3,
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': 'strong' if args.strong else 'weak',
         'vs_baseline': None,
         'dtype': 'int16',
         'data': 'synthetic',
         'config': {'workload': '%d synthetic proteomes x %d proteins (len~300) all-vs-all, clustersearch --search-mode 0 '
-                               '--filter-self-match --max-seqs %d; step = %d query proteomes per rank vs all %d targets'
-                               % (P, args.genes, max_seqs, B, P),
+                               '--filter-self-match --max-seqs %d; step = %d query proteomes %s vs all %d targets'
+                               % (P, args.genes, max_seqs, B, 'in total (strong scaling)' if args.strong else 'per rank', P),
                    'parallelism': 'whole query sets dealt to %d rank(s) by sd_shard_query_sets, target index replicated (%s), '
                                   'final result gather: %s' % (world, index_how, gather_how)},
         'roofline': roofline,
+        'roofline_sw': roofline_sw,
         'sw_gcups': cells_sw / sw_ms / 1e6 if sw_ms > 0 else 0.0,
         'sw_valu': sw_valu,
         'sw_cells': {'forward': st['cells_fwd'], 'reverse': st['cells_rev'], 'traceback': st['cells_tb']},
@@ -393,13 +416,14 @@ def measure(args, rank, local_rank, world, dist, torch):
         'device': gpu.device_name(),
         'host_cores': os.cpu_count(),
         'host_cpu_quota': effective_cpus(),
+        'cpu_note': 'this box exposes %d logical CPUs but a cgroup quota of %d: cpu_baseline runs on (and is quoted against) %d threads'
+                    % (os.cpu_count(), effective_cpus(), effective_cpus()),
     }
-    if gathered is not None:
-        rows = np.concatenate([np.asarray(g, np.int64).reshape(-1, 6) for g in gathered]) if len(gathered) else np.zeros((0, 6), np.int64)
-        res['gather'] = {'how': gather_how, 'records': int(len(rows)), 'records_per_rank': [int(np.asarray(g).size // 6) for g in gathered],
-                         'clusters_in_records': int(rows[:, 3].sum()) if len(rows) else 0}
-        res['multi_gpu_note'] = ('weak scaling over query sets as in BASELINE configs[2]; an 8-GPU curve exists only where the driver '
-                                 'ran this command with --gpus 8')
+    if gather_sizes is not None:
+        res['gather'] = {'how': gather_how, 'bytes': int(gather_sizes.sum()), 'bytes_per_rank': [int(v) for v in gather_sizes],
+                         'payload': 'cluster records (sd_search_result_records): per cluster sets, P-values, members with alignment fields', 'tsv': tsv_info}
+        res['multi_gpu_note'] = ('%s scaling over query sets; an 8-GPU curve exists only where the driver ran this command with --gpus 8'
+                                 % ('strong (BASELINE configs[2] as written)' if args.strong else 'weak'))
     extras = dict(ps=ps, index=index, max_seqs=max_seqs, kmer_thr=kmer_thr, bin_size=int(cs.bin_size), gpu=gpu, host=host,
                   last=outs[-1] if outs else None, db=db)
     del cs

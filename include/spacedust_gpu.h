@@ -151,7 +151,9 @@ typedef struct {
  * sequence lookup and the sorted 2-mer/3-mer similarity tables are uploaded once and stay resident.
  *   kmerOffsets[20^k+1] (u32), entrySeq/entryPos: lists sorted by (seqId,pos) (IndexTable.h:182-189)
  *   maskedResidues/seqOffsets: SequenceLookup (M/src/prefiltering/SequenceLookup.h)
- *   ext2/ext3: ExtendedSubstitutionMatrix::calcScoreMatrix rows (score int16, index u16), 400x400 and 8000x8000 */
+ *   ext2/ext3: ExtendedSubstitutionMatrix::calcScoreMatrix rows (score int16, index u16), 400x400 and 8000x8000
+ * kmerOffsets, kmerBlockBase, entrySeq, entryPos and maskedResidues may be device pointers (an index that arrived by a
+ * device-to-device broadcast is made resident without a host round trip); seqOffsets is read on the host. */
 int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, const uint32_t *entrySeq,
                      const uint16_t *entryPos, uint64_t nEntries, const uint8_t *maskedResidues,
                      const uint64_t *seqOffsets, uint32_t nSeq, const int16_t *ext2Score, const uint16_t *ext2Index,
@@ -304,6 +306,18 @@ int sd_agg_write_tsv_from(sd_agg *a, const char *path, int append, uint64_t firs
                           const uint32_t *clusterSize, const char *qNames, const uint64_t *qNameOff, const char *tNames,
                           const uint64_t *tNameOff, const char *qSources, const uint64_t *qSourceOff, const char *tSources,
                           const uint64_t *tSourceOff, int canonical, uint64_t *nClusterLines, uint64_t *nHitLines);
+/* The clusters of a finished aggregation as one self-contained byte string ("cluster records"): what a rank hands to
+ * sd_gather_results and what the result TSV is written from (R/src/util/SummarizeResults.cpp:77-112 reads the same fields
+ * from the cluster DB).  Little endian; per cluster: u32 members, u32 qSet, u32 tSet, u32 0, f64 pCO, f64 pMH; then per
+ * member in cluster order: u32 q, u32 t, char pval[16], char seqId[8], char eval[16], i32 qStart, qEnd, qLen, tStart, tEnd,
+ * tLen, u32 cigarLen, the cigar bytes padded to a multiple of 4.  out == NULL: *bytes = size needed. */
+int sd_agg_records(sd_agg *a, const uint32_t *clusterOfHit, const uint32_t *rankInCluster, const uint32_t *nClusters,
+                   const double *pCO, const double *pMH, const uint32_t *clusterSize, void *out, uint64_t cap, uint64_t *bytes);
+/* the TSV of cluster records -- of one result or of several ranks' records concatenated: clusters numbered from firstClusterKey */
+int sd_records_write_tsv(const void *records, uint64_t bytes, const char *path, int append, uint64_t firstClusterKey,
+                         const char *qNames, const uint64_t *qNameOff, const char *tNames, const uint64_t *tNameOff,
+                         const char *qSources, const uint64_t *qSourceOff, const char *tSources, const uint64_t *tSourceOff,
+                         int canonical, uint64_t *nClusterLines, uint64_t *nHitLines);
 
 
 /* ---- the tail of Alignment::run for a batch: criteria, order, --realign, text (host) --------
@@ -450,6 +464,8 @@ int sd_search_result_write_tsv(sd_search_result *r, const char *path, const char
                                const char *tNames, const uint64_t *tNameOff, const char *qSources, const uint64_t *qSourceOff,
                                const char *tSources, const uint64_t *tSourceOff, int canonical, int append,
                                uint64_t firstClusterKey, uint64_t *nClusterLines, uint64_t *nHitLines);
+/* the result's cluster records (sd_agg_records of its aggregation and clusters); out == NULL: *bytes = size needed */
+int sd_search_result_records(sd_search_result *r, void *out, uint64_t cap, uint64_t *bytes);
 void sd_search_result_destroy(sd_search_result *r);
 /* accumulated since create: stats[16] = similar k-mers, index hits, diagonals, diagonal length, prefilter hits, pairs,
  * forward / reverse / traceback cells, index entries, masked residues, k, k-mer threshold, bin size, queries not computed
@@ -473,10 +489,24 @@ int sd_comm_init(int device, int nRanks, int rank, const char *uniqueId128, sd_c
 void sd_comm_destroy(sd_comm *c);
 const char *sd_comm_last_error(sd_comm *c);
 /* gatherv of byte records over RCCL: sizes[nRanks] receives every rank's byte count (on all ranks); on `root`, outOnRoot
- * (capacity outCap) receives the records concatenated in rank order and *outBytes their total.  SD_ENOMEM on the root when
- * outCap is too small (*outBytes still holds the size needed; the exchange itself completes on every rank). */
+ * (capacity outCap) receives the records concatenated in rank order and *outBytes their total.  The ranks agree on the
+ * outcome of their local staging before any payload moves: when outCap is too small on the root, EVERY rank returns
+ * SD_ENOMEM (*outBytes = the size needed; call again with room -- the size probe), when a rank cannot stage its records
+ * every rank returns an error; no rank is left waiting in a send or receive. */
 int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, uint64_t *sizes, void *outOnRoot, uint64_t outCap,
                       uint64_t *outBytes);
+/* Host-side rendezvous of the ranks over TCP (addr / port as a one-process-per-GPU launcher's MASTER_ADDR / MASTER_PORT; every
+ * rank connects to rank 0 once, the calls are matched in program order): sd_tcp_bcast hands rank 0's buffer (the 128-byte
+ * unique id) to every rank; sd_tcp_gather is the gatherv of byte records to rank 0 for ranks that share a device -- RCCL
+ * refuses two ranks on one GPU, so one-GPU test rigs move the records this way.  The reference merges its MPI ranks' files
+ * (M/src/prefiltering/Prefiltering.cpp:630-658). */
+typedef struct sd_tcp sd_tcp;
+int sd_tcp_connect(const char *addr, int port, int nRanks, int rank, sd_tcp **out);
+void sd_tcp_close(sd_tcp *t);
+int sd_tcp_bcast(sd_tcp *t, void *buf, uint64_t bytes);
+/* sizes[nRanks] and the concatenated records on rank 0; outCap too small: SD_ENOMEM there with *outBytes = the size needed
+ * (the records are consumed either way: gather the byte counts first) */
+int sd_tcp_gather(sd_tcp *t, const void *local, uint64_t nBytes, uint64_t *sizes, void *outOnRoot, uint64_t outCap, uint64_t *outBytes);
 
 
 /* ---- result2profile: alignment DB -> profile DB between the iterations of `search --num-iterations` (SURVEY.md 8(f).3;

@@ -187,6 +187,10 @@ def load():
         'sd_search_result_arrays': (C.c_int, [_vp] + [_vp] * 12),
         'sd_search_result_write_tsv': (C.c_int, [_vp, C.c_char_p, C.c_char_p, _vp, C.c_char_p, _vp, C.c_char_p, _vp, C.c_char_p, _vp,
                                                  C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        'sd_search_result_records': (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+        'sd_agg_records': (C.c_int, [_vp] * 7 + [_vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+        'sd_records_write_tsv': (C.c_int, [_vp, C.c_uint64, C.c_char_p, C.c_int, C.c_uint64, C.c_char_p, _vp, C.c_char_p, _vp, C.c_char_p, _vp,
+                                           C.c_char_p, _vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_search_result_destroy': (None, [_vp]),
         'sd_search_stats': (C.c_int, [_vp, _vp, _vp]),
         'sd_r2p_create': (C.c_int, [C.POINTER(_vp)]),
@@ -198,6 +202,10 @@ def load():
         'sd_comm_destroy': (None, [_vp]),
         'sd_comm_last_error': (C.c_char_p, [_vp]),
         'sd_gather_results': (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+        'sd_tcp_connect': (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+        'sd_tcp_close': (None, [_vp]),
+        'sd_tcp_bcast': (C.c_int, [_vp, _vp, C.c_uint64]),
+        'sd_tcp_gather': (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     }
     missing = []
     for name, (res, args) in sig.items():

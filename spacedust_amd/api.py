@@ -182,19 +182,40 @@ class HostIndex:
             pass
 
 
+class DeviceArray:
+    """a device-resident array (a torch tensor) where the C ABI takes a pointer that may live on the device: ptr(x) yields
+    its data pointer, the tensor is kept alive"""
+
+    class _P:
+        def __init__(self, t):
+            self.t = t
+
+        def data_as(self, _):
+            return C.c_void_p(self.t.data_ptr())
+
+    def __init__(self, tensor, n_elements):
+        self.tensor, self.n = tensor, int(n_elements)
+        self.ctypes = DeviceArray._P(tensor)
+        self.nbytes = int(tensor.numel() * tensor.element_size())
+
+    def __len__(self):
+        return self.n
+
+
 class IndexArrays:
     """A target index that exists already as arrays (received from another rank, read from an index file): the attributes
     of HostIndex that Target and ClusterSearch(index=...) read"""
 
     def __init__(self, k, kmer_thr, seq_offsets, kmer_offsets, entry_seq, entry_pos, masked, masked_residues=0, block_base=None):
         self.k, self.kmer_thr = int(k), int(kmer_thr)
-        self.block_base = None if block_base is None else np.ascontiguousarray(block_base, np.uint64)
+        host = lambda a, dt: a if isinstance(a, DeviceArray) else np.ascontiguousarray(a, dt)   # device arrays pass through
+        self.block_base = None if block_base is None else host(block_base, np.uint64)
         self.offsets = np.ascontiguousarray(seq_offsets, np.uint64)
         self.n = len(self.offsets) - 1
-        self.kmer_offsets = np.ascontiguousarray(kmer_offsets, np.uint32)
-        self.entry_seq = np.ascontiguousarray(entry_seq, np.uint32)
-        self.entry_pos = np.ascontiguousarray(entry_pos, np.uint16)
-        self.masked = np.ascontiguousarray(masked, np.uint8)
+        self.kmer_offsets = host(kmer_offsets, np.uint32)
+        self.entry_seq = host(entry_seq, np.uint32)
+        self.entry_pos = host(entry_pos, np.uint16)
+        self.masked = host(masked, np.uint8)
         self.table_size, self.n_entries, self.masked_residues = len(self.kmer_offsets) - 1, len(self.entry_seq), int(masked_residues)
 
 

@@ -6,8 +6,8 @@
 //                                                                   combinehits -> clusterhits -> summarizeresults
 //                                                                   (R/data/clustersearch.sh:110-152), fused in-process
 // Several ranks (RANK / WORLD_SIZE / LOCAL_RANK in the environment, one process per GPU): whole query sets are dealt to
-// the ranks, every rank writes its part of the output, rank 0 concatenates after a marker-file barrier in <tmpDir> (the
-// reference's MPI mode exchanges through the shared file system the same way, M/src/prefiltering/Prefiltering.cpp:619-650).
+// the ranks, every rank's cluster records are gathered on rank 0 (RCCL: sd_gather_results), which writes the TSV (the
+// reference's MPI mode merges per-rank result files on the master instead, M/src/prefiltering/Prefiltering.cpp:619-650).
 #include "sd_cli.h"
 
 #include <algorithm>
@@ -183,14 +183,6 @@ void packNames(const std::vector<std::string> &v, std::string &blob, std::vector
     for (const std::string &s : v) blob += s;
 }
 
-bool waitForFile(const std::string &path, int seconds) {
-    for (int i = 0; i < seconds * 10; i++) {
-        if (sddb::fileExists(path)) return true;
-        std::this_thread::sleep_for(std::chrono::milliseconds(100));
-    }
-    return false;
-}
-
 int runSearch(const Args &a, bool withClusters) {
     if (a.pos.size() != 4)
         return fail(withClusters ? "usage: clustersearch <querySetDB> <targetSetDB> <out.tsv> <tmpDir> [options]"
@@ -363,66 +355,85 @@ int runSearch(const Args &a, bool withClusters) {
         packNames(qs.sourceOfSet, qsrc, qso);
         packNames(tsP->sourceOfSet, tsrc, tso);
     }
-    const std::string part = world > 1 ? tmpDir + "/out.tsv.part" + std::to_string(rank) : a.pos[2];
-    ::remove(part.c_str());
-    {   // an empty result still leaves a file
-        FILE *f = fopen(part.c_str(), "w");
-        if (!f) return fail("cannot create " + part);
-        fclose(f);
-    }
-    uint64_t key = 0, nClu = 0, nHit = 0;
+    // this rank's cluster records (every range's clusters, in range order)
+    std::vector<char> rec;
     for (size_t r = 0; r < rb.size(); r++) {
-        uint64_t nc = 0, nh = 0;
-        rc = sd_search_result_write_tsv(results[r], part.c_str(), qn.data(), qno.data(), tn.data(), tno.data(), qsrc.data(), qso.data(),
-                                        tsrc.data(), tso.data(), 0, 1, key, &nc, &nh);
-        if (rc != SD_OK) return fail("sd_search_result_write_tsv failed (" + std::to_string(rc) + ")");
-        key += nc;
-        nClu += nc;
-        nHit += nh;
+        uint64_t need = 0;
+        rc = sd_search_result_records(results[r], nullptr, 0, &need);
+        if (rc != SD_OK) return fail("sd_search_result_records failed (" + std::to_string(rc) + ")");
+        const size_t at = rec.size();
+        rec.resize(at + need);
+        rc = sd_search_result_records(results[r], rec.data() + at, need, &need);
+        if (rc != SD_OK) return fail("sd_search_result_records failed (" + std::to_string(rc) + ")");
     }
-    info(a, "%llu clusters with %llu hits written%s\n", (unsigned long long) nClu, (unsigned long long) nHit,
-         world > 1 ? (" by rank " + std::to_string(rank)).c_str() : "");
+    std::vector<char> all;
+    const std::vector<char> *toWrite = &rec;
     if (world > 1) {
-        {   // this rank is done
-            FILE *f = fopen((tmpDir + "/out.tsv.done" + std::to_string(rank)).c_str(), "w");
-            if (f) {
-                fprintf(f, "%llu\n", (unsigned long long) nClu);
-                fclose(f);
+        // The one exchange of the path: every rank's records to rank 0 (RCCL: sd_gather_results), which writes the TSV from the
+        // gathered buffer.  The ranks meet over TCP at MASTER_ADDR:MASTER_PORT+1 (the RCCL unique id travels that way); ranks
+        // that share a device -- RCCL refuses that, a one-GPU test rig -- hand their records over the same socket path instead.
+        const char *addrEnv = getenv("MASTER_ADDR");
+        const std::string addr = addrEnv && *addrEnv ? addrEnv : "127.0.0.1";
+        const int port = (int) a.integer("--comm-port", envInt("MASTER_PORT", 29500) + 1);
+        std::vector<uint64_t> sizes((size_t) world, 0);
+        sd_tcp *tcp = nullptr;
+        if (sd_tcp_connect(addr.c_str(), port, world, rank, &tcp) != SD_OK)
+            return fail("rendezvous of the ranks at " + addr + ":" + std::to_string(port) + " failed");
+        struct TcpClose {
+            sd_tcp *t;
+            ~TcpClose() { sd_tcp_close(t); }
+        } tcpClose{tcp};
+        // device of every rank -> does each rank have a GPU of its own?
+        int32_t devs[2] = {device, 0};
+        std::vector<int32_t> allDevs((size_t) world * 2, 0);
+        uint64_t got = 0;
+        if (sd_tcp_gather(tcp, devs, sizeof(devs), nullptr, allDevs.data(), allDevs.size() * sizeof(int32_t), &got) != SD_OK)
+            return fail("rendezvous of the ranks failed (devices)");
+        int32_t shared = 0;
+        if (rank == 0)
+            for (int x = 0; x < world; x++)
+                for (int y = 0; y < x; y++)
+                    if (allDevs[(size_t) x * 2] == allDevs[(size_t) y * 2]) shared = 1;
+        if (sd_tcp_bcast(tcp, &shared, sizeof(shared)) != SD_OK) return fail("rendezvous of the ranks failed");
+        uint64_t total = 0;
+        if (!shared) {
+            char uid[128];
+            if (rank == 0 && sd_comm_unique_id(uid) != SD_OK) return fail("sd_comm_unique_id failed (librccl not loadable?)");
+            if (sd_tcp_bcast(tcp, uid, sizeof(uid)) != SD_OK) return fail("broadcast of the RCCL unique id failed");
+            sd_comm *comm = nullptr;
+            if (sd_comm_init(device, world, rank, uid, &comm) != SD_OK) return fail("sd_comm_init failed");
+            rc = sd_gather_results(comm, rec.data(), rec.size(), 0, sizes.data(), nullptr, 0, &total);   // size probe
+            if (rc == SD_ENOMEM) {
+                if (rank == 0) all.resize(total);
+                rc = sd_gather_results(comm, rec.data(), rec.size(), 0, sizes.data(), all.data(), all.size(), &total);
             }
+            if (rc != SD_OK) {
+                const std::string why = sd_comm_last_error(comm);
+                sd_comm_destroy(comm);
+                return fail("sd_gather_results failed (" + std::to_string(rc) + "): " + why);
+            }
+            sd_comm_destroy(comm);
+            info(a, "records gathered over RCCL: %llu bytes from %d ranks\n", (unsigned long long) total, world);
+        } else {
+            uint64_t mine = rec.size();
+            std::vector<uint64_t> allSizes((size_t) world, 0);
+            if (sd_tcp_gather(tcp, &mine, sizeof(mine), nullptr, allSizes.data(), allSizes.size() * sizeof(uint64_t), &got) != SD_OK)
+                return fail("gather of the record sizes failed");
+            if (rank == 0)
+                for (uint64_t v : allSizes) total += v;
+            if (rank == 0) all.resize(total);
+            if (sd_tcp_gather(tcp, rec.data(), rec.size(), sizes.data(), all.data(), all.size(), &total) != SD_OK)
+                return fail("gather of the records failed");
+            info(a, "ranks share a device: records gathered over TCP (%llu bytes)\n", (unsigned long long) total);
         }
-        if (rank == 0) {
-            FILE *out = fopen(a.pos[2].c_str(), "w");
-            if (!out) return fail("cannot create " + a.pos[2]);
-            uint64_t base = 0;
-            std::vector<char> line;
-            for (int r = 0; r < world; r++) {
-                if (!waitForFile(tmpDir + "/out.tsv.done" + std::to_string(r), 24 * 3600)) return fail("rank " + std::to_string(r) + " did not finish");
-                // cluster keys are renumbered so that the merged file counts them like one run would
-                FILE *in = fopen((tmpDir + "/out.tsv.part" + std::to_string(r)).c_str(), "r");
-                if (!in) return fail("part of rank " + std::to_string(r) + " is missing");
-                char *l = nullptr;
-                size_t cap = 0;
-                ssize_t n;
-                uint64_t seen = 0;
-                while ((n = getline(&l, &cap, in)) > 0) {
-                    if (l[0] == '#') {
-                        const char *tab = strchr(l, '\t');
-                        fprintf(out, "#%llu%s", (unsigned long long) (base + seen), tab ? tab : "\n");
-                        seen++;
-                    } else {
-                        fwrite(l, 1, (size_t) n, out);
-                    }
-                }
-                free(l);
-                fclose(in);
-                base += seen;
-            }
-            fclose(out);
-            for (int r = 0; r < world; r++) {
-                ::remove((tmpDir + "/out.tsv.done" + std::to_string(r)).c_str());
-                ::remove((tmpDir + "/out.tsv.part" + std::to_string(r)).c_str());
-            }
-        }
+        toWrite = &all;
+    }
+    uint64_t nClu = 0, nHit = 0;
+    if (rank == 0) {
+        rc = sd_records_write_tsv(toWrite->data(), toWrite->size(), a.pos[2].c_str(), 0, 0, qn.data(), qno.data(), tn.data(), tno.data(),
+                                  qsrc.data(), qso.data(), tsrc.data(), tso.data(), 0, &nClu, &nHit);
+        if (rc != SD_OK) return fail("sd_records_write_tsv failed (" + std::to_string(rc) + ")");
+        info(a, "%llu clusters with %llu hits written\n", (unsigned long long) nClu, (unsigned long long) nHit);
     }
     return notComputed ? 1 : 0;
 }

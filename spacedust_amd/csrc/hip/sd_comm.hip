@@ -3,8 +3,8 @@
 // records to rank `root` over RCCL (xGMI).  The reference's counterpart is the MPI master merging per-rank result files
 // through the shared file system (M/src/prefiltering/Prefiltering.cpp:630-658).
 //
-// RCCL is opened with dlopen on the first sd_comm_* call (librccl.so.1; a process that already carries an RCCL -- e.g.
-// PyTorch's -- gets that one), so a single-GPU run never loads it.
+// RCCL is opened with dlopen on the first sd_comm_* call (the librccl next to the HIP runtime the process runs on), so a
+// single-GPU run never loads it.
 #include "sd_common.h"
 
 #include <algorithm>
@@ -47,9 +47,26 @@ Rccl *rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        // The RCCL that belongs to the HIP runtime this process runs on: the one next to the loaded libamdhip64 (a process that
+        // imported PyTorch first runs on PyTorch's bundled runtime and RCCL, any other on /opt/rocm's) -- an RCCL built for
+        // another runtime fails in ncclCommInitRank.  By path, so that a differently-placed copy already in the process does
+        // not answer for it.
+        std::vector<std::string> names;
+        Dl_info info;
+        if (dladdr((void *) &hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash);
+                names.push_back(dir + "/librccl.so.1");
+                names.push_back(dir + "/librccl.so");
+            }
+        }
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (const std::string &n : names) {
+            r.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (r.lib) break;
         }
         if (!r.lib) {
@@ -113,7 +130,7 @@ int sd_comm_init(int device, int nRanks, int rank, const char *uniqueId128, sd_c
     const int rc = R->commInitRank(&c->comm, nRanks, id, rank);
     if (rc != 0) {
         fprintf(stderr, "sd_comm_init: ncclCommInitRank failed: %s\n", R->errString ? R->errString(rc) : "?");
-        hipStreamDestroy(c->stream);
+        (void) hipStreamDestroy(c->stream);
         delete c;
         return SD_EHIP;
     }
@@ -124,7 +141,7 @@ int sd_comm_init(int device, int nRanks, int rank, const char *uniqueId128, sd_c
 void sd_comm_destroy(sd_comm *c) {
     if (!c) return;
     if (c->comm) rccl()->commDestroy(c->comm);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -153,13 +170,37 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
         uint64_t total = 0;
         for (int r = 0; r < c->nRanks; r++) total += sizes[r];
         if (outBytes) *outBytes = total;
-        if (c->rank == root && total > outCap) { status = SD_ENOMEM; }
-        if (nBytes) {
-            if (hipMalloc((void **) &dLocal, nBytes) != hipSuccess) { status = SD_ENOMEM; break; }
-            if (hipMemcpyAsync(dLocal, local, nBytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        // local staging; whatever fails here is agreed on by all ranks before anyone enters the payload exchange -- a rank that
+        // left early would leave the others waiting in their send / recv
+        int localStatus = SD_OK;
+        bool capacity = false;   // the root's buffer is too small: every rank returns SD_ENOMEM (a size probe), nothing is exchanged
+        if (c->rank == root && total > outCap) {
+            localStatus = SD_ENOMEM;
+            capacity = true;
         }
-        if (c->rank == root && total && hipMalloc((void **) &dAll, total) != hipSuccess) { status = SD_ENOMEM; break; }
-        // every rank takes part in the exchange even when the root's buffer is too small (no rank may be left waiting)
+        if (localStatus == SD_OK && nBytes) {
+            if (hipMalloc((void **) &dLocal, nBytes) != hipSuccess) localStatus = SD_ENOMEM;
+            else if (hipMemcpyAsync(dLocal, local, nBytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) localStatus = SD_EHIP;
+        }
+        if (localStatus == SD_OK && c->rank == root && total && hipMalloc((void **) &dAll, total) != hipSuccess) localStatus = SD_ENOMEM;
+        (void) hipGetLastError();
+        uint64_t mine = (uint64_t) (localStatus == SD_OK ? 0 : capacity ? 2 : 1);
+        std::vector<uint64_t> all((size_t) c->nRanks, 0);
+        if (hipMemcpyAsync(dSizes + c->nRanks, &mine, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        rc = R->allGather(dSizes + c->nRanks, dSizes, 1, RCCL_UINT64, c->comm, c->stream);
+        if (rc != 0) { status = fail("ncclAllGather (status)", rc); break; }
+        if (hipMemcpyAsync(all.data(), dSizes, sizeof(uint64_t) * c->nRanks, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        int firstBad = -1;
+        for (int r = 0; r < c->nRanks && firstBad < 0; r++)
+            if (all[r]) firstBad = r;
+        if (firstBad >= 0) {   // nobody exchanges anything
+            status = localStatus != SD_OK ? localStatus : (all[firstBad] == 2 ? SD_ENOMEM : SD_EHIP);
+            c->err = "sd_gather_results: rank " + std::to_string(firstBad) +
+                     (firstBad == root ? " (root) could not take the gathered records (output capacity or device memory)"
+                                       : " could not stage its records");
+            break;
+        }
         rc = R->groupStart();
         if (rc != 0) { status = fail("ncclGroupStart", rc); break; }
         if (c->rank == root) {
@@ -176,14 +217,14 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
         if (c->rank == root && dAll) {
             uint64_t off = 0;
             for (int r = 0; r < root; r++) off += sizes[r];
-            if (nBytes) hipMemcpyAsync(dAll + off, dLocal, nBytes, hipMemcpyDeviceToDevice, c->stream);
-            if (status == SD_OK && outOnRoot) hipMemcpyAsync(outOnRoot, dAll, total, hipMemcpyDeviceToHost, c->stream);
+            if (nBytes && hipMemcpyAsync(dAll + off, dLocal, nBytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) status = SD_EHIP;
+            if (status == SD_OK && outOnRoot && hipMemcpyAsync(outOnRoot, dAll, total, hipMemcpyDeviceToHost, c->stream) != hipSuccess) status = SD_EHIP;
         }
         if (hipStreamSynchronize(c->stream) != hipSuccess && status == SD_OK) status = SD_EHIP;
     } while (false);
-    if (dSizes) hipFree(dSizes);
-    if (dLocal) hipFree(dLocal);
-    if (dAll) hipFree(dAll);
+    if (dSizes) (void) hipFree(dSizes);
+    if (dLocal) (void) hipFree(dLocal);
+    if (dAll) (void) hipFree(dAll);
     return status;
 }
 

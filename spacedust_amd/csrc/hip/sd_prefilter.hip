@@ -729,8 +729,6 @@ constexpr int PF_LB_MAX = 11;          // log2(PF_NB_MAX)
 constexpr int PF_BUCKET_CAP = 1024;    // hits the LDS bucket sort takes; larger buckets go to a second launch with
 constexpr int PF_BUCKET_CAP_BIG = 6144;   // this capacity, and only beyond that the whole sub-batch falls back
 constexpr int PF_FILL = 512;           // aimed hits per bucket: the bucket count is the next power of two of hits / PF_FILL
-constexpr int PF_TILE = 2048;          // hits reordered in LDS per partition step (256 threads x PF_PER)
-constexpr int PF_PER = PF_TILE / 256;
 constexpr int PF_CNT_MAX = 4096;       // counting-sort bins (target offsets) per bucket
 
 __device__ __forceinline__ int pfLog2Bins(uint64_t n, int tBits) {
@@ -778,10 +776,11 @@ __device__ void pk16Scan(uint32_t *w, int n, uint32_t *part) {
     __syncthreads();
 }
 
-// exclusive scan of arr[0..n) (32-bit, 256 threads), in place
-__device__ void pfBlockScan(uint32_t *arr, int n, uint32_t *part /* >= 5 */) {
+// exclusive scan of arr[0..n) (32-bit, NT threads), in place
+template <int NT>
+__device__ void pfBlockScan(uint32_t *arr, int n, uint32_t *part /* >= NT / 64 + 1 */) {
     const int t = threadIdx.x;
-    const int per = (n + 255) / 256;
+    const int per = (n + NT - 1) / NT;
     const int b = t * per, e = min(n, b + per);
     uint32_t sum = 0;
     for (int x = b; x < e; x++) sum += arr[x];
@@ -804,17 +803,22 @@ __device__ void pfBlockScan(uint32_t *arr, int n, uint32_t *part /* >= 5 */) {
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(256)
+// NT threads reorder TILE hits per step: the average run a tile writes into a bin is TILE / bins hits, and only runs of
+// a cache line or more keep the stores from being partial-line writes (2 048-hit tiles over 512 bins: 32-byte runs,
+// 1.8x the bytes at the memory side; 8 192: 128-byte runs)
+template <int NT, int TILE>
+__global__ void __launch_bounds__(NT)
 partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tBits, const uint32_t *__restrict__ inKey,
                       const uint32_t *__restrict__ inVal, const uint2 *__restrict__ inKV /* join path: interleaved input */,
                       uint2 *__restrict__ outKV /* (key, value) per hit */,
                       uint32_t *__restrict__ qLog2Bins, uint64_t *__restrict__ bktStart, uint32_t *__restrict__ bktCount,
                       int *__restrict__ flag) {
+    constexpr int PER = TILE / NT;
     __shared__ uint32_t cursor[PF_NB_MAX];          // segment histogram, then the running write position per bin
     __shared__ uint32_t tcount[PF_NB_MAX / 2];      // per tile: packed 16-bit counts, then exclusive starts
     __shared__ uint32_t tsize[PF_NB_MAX / 2];       // per tile: packed 16-bit counts (kept for the cursor update)
-    __shared__ uint32_t part[8];
-    __shared__ uint32_t tileK[PF_TILE], tileV[PF_TILE];
+    __shared__ uint32_t part[NT / 64 + 8];
+    __shared__ uint32_t tileK[TILE], tileV[TILE];
     const uint32_t q = blockIdx.x;
     const int t = threadIdx.x;
     const uint64_t s = qHitBase[q], e = qHitBase[q + 1];
@@ -829,41 +833,42 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
     }
     const uint32_t tMask = (1u << tBits) - 1;
     int bins, shift;
+    uint32_t *over = &part[NT / 64 + 7];
     // histogram of the segment; a finer split is taken while some range holds more than an LDS bucket can sort
     for (;;) {
         bins = 1 << lb;
         shift = tBits - lb;
-        for (int b = t; b < bins; b += 256) cursor[b] = 0;
-        if (t == 0) part[7] = 0;
+        for (int b = t; b < bins; b += NT) cursor[b] = 0;
+        if (t == 0) *over = 0;
         __syncthreads();
         if (inKV)
-            for (uint64_t i = s + t; i < e; i += 256) atomicAdd(&cursor[(inKV[i].x & tMask) >> shift], 1u);
+            for (uint64_t i = s + t; i < e; i += NT) atomicAdd(&cursor[(inKV[i].x & tMask) >> shift], 1u);
         else
-            for (uint64_t i = s + t; i < e; i += 256) atomicAdd(&cursor[(inKey[i] & tMask) >> shift], 1u);
+            for (uint64_t i = s + t; i < e; i += NT) atomicAdd(&cursor[(inKey[i] & tMask) >> shift], 1u);
         __syncthreads();
         uint32_t mx = 0;
-        for (int b = t; b < bins; b += 256) mx = max(mx, cursor[b]);
-        if (mx > (uint32_t) PF_BUCKET_CAP) atomicMax(&part[7], mx);
+        for (int b = t; b < bins; b += NT) mx = max(mx, cursor[b]);
+        if (mx > (uint32_t) PF_BUCKET_CAP) atomicMax(over, mx);
         __syncthreads();
-        const bool over = part[7] > (uint32_t) PF_BUCKET_CAP;
+        const bool isOver = *over > (uint32_t) PF_BUCKET_CAP;
         __syncthreads();
-        if (!over || lb >= PF_LB_MAX || lb >= tBits) break;
+        if (!isOver || lb >= PF_LB_MAX || lb >= tBits) break;
         lb++;
     }
     if (t == 0) qLog2Bins[q] = (uint32_t) lb;
-    for (int b = t; b < bins; b += 256) bktCount[(size_t) q * PF_NB_MAX + b] = cursor[b];
+    for (int b = t; b < bins; b += NT) bktCount[(size_t) q * PF_NB_MAX + b] = cursor[b];
     __syncthreads();
-    pfBlockScan(cursor, bins, part);
-    for (int b = t; b < bins; b += 256) bktStart[(size_t) q * PF_NB_MAX + b] = s + cursor[b];
+    pfBlockScan<NT>(cursor, bins, part);
+    for (int b = t; b < bins; b += NT) bktStart[(size_t) q * PF_NB_MAX + b] = s + cursor[b];
     const int binsEven = bins < 2 ? 2 : bins;
-    for (int x = t; x < binsEven / 2; x += 256) tcount[x] = 0;
+    for (int x = t; x < binsEven / 2; x += NT) tcount[x] = 0;
     __syncthreads();
-    for (uint64_t base = s; base < e; base += PF_TILE) {
-        const int tn = (int) min((uint64_t) PF_TILE, e - base);
-        uint32_t k[PF_PER], v[PF_PER], r[PF_PER];
+    for (uint64_t base = s; base < e; base += TILE) {
+        const int tn = (int) min((uint64_t) TILE, e - base);
+        uint32_t k[PER], v[PER], r[PER];
 #pragma unroll
-        for (int x = 0; x < PF_PER; x++) {
-            const int j = x * 256 + t;
+        for (int x = 0; x < PER; x++) {
+            const int j = x * NT + t;
             if (j < tn) {
                 if (inKV) {
                     const uint2 kv = inKV[base + j];
@@ -877,12 +882,12 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
             }
         }
         __syncthreads();
-        for (int x = t; x < binsEven / 2; x += 256) tsize[x] = tcount[x];
+        for (int x = t; x < binsEven / 2; x += NT) tsize[x] = tcount[x];
         __syncthreads();
-        pk16Scan<256>(tcount, binsEven, part);
+        pk16Scan<NT>(tcount, binsEven, part);
 #pragma unroll
-        for (int x = 0; x < PF_PER; x++) {
-            const int j = x * 256 + t;
+        for (int x = 0; x < PER; x++) {
+            const int j = x * NT + t;
             if (j < tn) {
                 const uint32_t p = pk16Get(tcount, (k[x] & tMask) >> shift) + r[x];
                 tileK[p] = k[x];
@@ -890,16 +895,16 @@ partition_hits_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, int tB
             }
         }
         __syncthreads();
-        for (int j = t; j < tn; j += 256) {
+        for (int j = t; j < tn; j += NT) {
             const uint32_t kk = tileK[j];
             const uint32_t b = (kk & tMask) >> shift;
             const uint64_t g = s + cursor[b] + ((uint32_t) j - pk16Get(tcount, b));
-            outKV[g] = make_uint2(kk, tileV[j]);   // one 8-byte store per hit: the runs per bin are short
+            outKV[g] = make_uint2(kk, tileV[j]);
         }
         __syncthreads();
-        for (int b = t; b < bins; b += 256) cursor[b] += pk16Get(tsize, b);
+        for (int b = t; b < bins; b += NT) cursor[b] += pk16Get(tsize, b);
         __syncthreads();
-        for (int x = t; x < binsEven / 2; x += 256) tcount[x] = 0;
+        for (int x = t; x < binsEven / 2; x += NT) tcount[x] = 0;
         __syncthreads();
     }
 }
@@ -1863,7 +1868,7 @@ int sd_target_create_wide(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets
     const uint64_t total = seqOffsets[nSeq];
     auto up = [&](void **d, const void *h, size_t bytes) -> bool {
         if (hipMalloc(d, bytes + 64) != hipSuccess) return false;
-        return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
+        return hipMemcpy(*d, h, bytes, hipMemcpyDefault) == hipSuccess;   // host or device source (an index received device-to-device)
     };
     bool ok = up((void **) &t->dOffsets, kmerOffsets, (t->tableSize + 1) * sizeof(uint32_t));
     if (kmerBlockBase) ok = ok && up((void **) &t->dBlockBase, kmerBlockBase, (((t->tableSize + 2) >> 16) + 1) * sizeof(uint64_t));
@@ -2431,8 +2436,13 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 SD_HIP(ctx, hipMemsetAsync(dFlag.p, 0, sizeof(int), ctx->stream));
                 {
                     ProfScope ps(ctx, "prefilter_partition_hits");
-                    hipLaunchKernelGGL(partition_hits_kernel, dim3(nVQ), dim3(256), 0, ctx->stream, nVQ, pHitBase, tBitsV, pKey,
-                                       pVal, pKV, dKVB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
+                    // large tiles where the virtual queries are large (proteome-scale target sets), the small form for small inputs
+                    if (nHits / std::max<uint32_t>(nVQ, 1) >= 16384 && !getenv("SD_PF_SMALLTILE"))
+                        hipLaunchKernelGGL((partition_hits_kernel<1024, 8192>), dim3(nVQ), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV, pKey,
+                                           pVal, pKV, dKVB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
+                    else
+                        hipLaunchKernelGGL((partition_hits_kernel<256, 2048>), dim3(nVQ), dim3(256), 0, ctx->stream, nVQ, pHitBase, tBitsV, pKey,
+                                           pVal, pKV, dKVB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
                 }
                 hipLaunchKernelGGL(bin_count_kernel, dim3(gridFor(nVQ + 1, 256)), dim3(256), 0, ctx->stream, nVQ, dQLog2.p, dQBins.p);
                 int rc = exclusiveScanWiden(ctx, dQBins.p, dBinBase.p, nVQ + 1, scanTmp);

@@ -274,7 +274,8 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
   for (;;) {
     width = band * 2 + 3;
     width_d = band * 2 + 1;
-    for (int x = l; x <= width && x < ldsStride; x += 32) { bandSt<GLOBAL>(h_b + x, 0); bandSt<GLOBAL>(e_b + x, 0); bandSt<GLOBAL>(h_c + x, 0); }
+    // (the idle half of an odd last wavefront owns no scratch: in the global class its stores would land in another task's arrays)
+    for (int x = l; (have || !GLOBAL) && x <= width && x < ldsStride; x += 32) { bandSt<GLOBAL>(h_b + x, 0); bandSt<GLOBAL>(e_b + x, 0); bandSt<GLOBAL>(h_c + x, 0); }
     bandSync<GLOBAL>();
     for (int i = 0; i < qLen; i++) {
         int beg = 0, end = tLen - 1;
@@ -1696,7 +1697,9 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     }
     uint32_t *dKeysRound = nullptr;
     SD_HIP(ctx, wsGet(ctx, "tb.keysRound", N + 1, &dKeysRound));
+    bool tbPending = false, budgetRaised = false;
     for (int round = 0; round < 4096; round++) {   // band doublings, and slices of what the direction scratch holds at a time
+        tbPending = true;
         SD_HIP(ctx, hipMemsetAsync(dDirBytes + N, 0, sizeof(uint64_t), ctx->stream));
         rc = devExclusiveScan(ctx, dDirBytes, dDirOff, N + 1);
         if (rc != SD_OK) return rc;
@@ -1710,7 +1713,19 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         SD_HIP(ctx, hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(&dirTotal, dDirOff + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, sdStreamSync(ctx));
-        if (hb[N_TB_CLASSES] == 0) break;   // nothing left
+        if (hb[N_TB_CLASSES] == 0) {
+            if (dirTotal == 0) {   // nothing left
+                tbPending = false;
+                break;
+            }
+            // tasks are pending but not even the first fits the budget (a global-band task of a long protein, or a budget halved
+            // after an allocation failure): the budget grows to what a single task needs -- or the call fails, never a silent exit
+            if (SCRATCH_BUDGET >= dirTotal) return sdFail(ctx, SD_EHIP, "traceback: pending tasks but an empty round (budget %llu, pending %llu bytes)",
+                                                          (unsigned long long) SCRATCH_BUDGET, (unsigned long long) dirTotal);
+            SCRATCH_BUDGET = std::min<uint64_t>(dirTotal, SCRATCH_BUDGET * 2);
+            budgetRaised = true;
+            continue;
+        }
         if (getenv("SD_DEBUG_TB")) {
             fprintf(stderr, "[tb] round %d: narrow", round);
             for (int ci = 0; ci < N_TB_NARROW; ci++) fprintf(stderr, " %u", hb[ci + 1] - hb[ci]);
@@ -1722,7 +1737,9 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         int8_t *dDir = nullptr;
         if (wsGet(ctx, "tb.dir", std::min<uint64_t>(dirTotal, SCRATCH_BUDGET) + 64, &dDir) != hipSuccess) {
             (void) hipGetLastError();
-            if (SCRATCH_BUDGET <= (256ull << 20)) return sdFail(ctx, SD_ENOMEM, "traceback direction scratch: out of device memory");
+            if (SCRATCH_BUDGET <= (256ull << 20) || budgetRaised)   // (a raised budget is what one task needs: halving it would only come back here)
+                return sdFail(ctx, SD_ENOMEM, "traceback direction scratch: out of device memory (%llu bytes for one round)",
+                              (unsigned long long) std::min<uint64_t>(dirTotal, SCRATCH_BUDGET));
             SCRATCH_BUDGET /= 2;   // another lane took the memory meanwhile: smaller slices
             continue;
         }
@@ -1782,6 +1799,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         hipLaunchKernelGGL(k_tb_collect, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dVals, dTb, dTbRes, dDirBytes, dBtLen,
                            dRes, dErr, 4 * 65536, dKeysRound);
     }
+    if (tbPending) return sdFail(ctx, SD_EHIP, "traceback: tasks still pending after 4096 rounds");
     if (getenv("SD_DEBUG_TB")) {   // band statistics of the finished tasks
         std::vector<TbTask> hT(nPairs);
         std::vector<uint64_t> hL(nPairs);

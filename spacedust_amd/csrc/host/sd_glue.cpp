@@ -324,46 +324,130 @@ int sd_agg_get(sd_agg *a, uint64_t *entryOff, uint32_t *entryQSet, uint32_t *ent
 // summarizeresults: one "#..." line per emitted cluster followed by its member lines (ascending query position).
 // names: concatenated lookup names + offsets; sources: per set.  clusterKeyBase numbers the clusters.
 // canonical != 0 drops the cluster key and the leading ">qname" field (the `cut -f2-` form used for comparisons).
+// ---- cluster records: the result of a range as one self-contained byte string -- what a rank hands to sd_gather_results
+// and what the TSV is written from (here, or on the root from the gathered buffer).  Little endian, per cluster:
+//   u32 members, u32 qSet, u32 tSet, u32 0, f64 pCO, f64 pMH, then per member (in cluster order):
+//   u32 q, u32 t, char pval[16], char seqId[8], char eval[16], i32 qStart, qEnd, qLen, tStart, tEnd, tLen, u32 cigarLen,
+//   cigar bytes padded to a multiple of 4
+namespace {
+struct RecCluster {
+    uint32_t members, qSet, tSet, pad;
+    double pCO, pMH;
+};
+struct RecMember {
+    uint32_t q, t;
+    char pval[16], seqId[8], eval[16];
+    int32_t qStart, qEnd, qLen, tStart, tEnd, tLen;
+    uint32_t cigarLen;
+};
+static_assert(sizeof(RecCluster) == 32 && sizeof(RecMember) == 76, "record layout");
+}  // namespace
+
+int sd_agg_records(sd_agg *a, const uint32_t *clusterOfHit, const uint32_t *rankInCluster, const uint32_t *nClusters,
+                   const double *pCO, const double *pMH, const uint32_t *clusterSize, void *out, uint64_t cap, uint64_t *bytes) {
+    if (!a || !bytes) return SD_EINVAL;
+    uint64_t w = 0;
+    char *o = (char *) out;
+    std::vector<uint32_t> order;
+    for (size_t e = 0; e + 1 < a->entryOff.size(); e++) {
+        const uint64_t off = a->entryOff[e], end = a->entryOff[e + 1];
+        for (uint32_t c = 0; c < nClusters[e]; c++) {
+            const uint32_t m = clusterSize[off + c];
+            order.assign(m, 0);
+            for (uint64_t h = off; h < end; h++)
+                if (clusterOfHit[h] == c) order[rankInCluster[h]] = (uint32_t) (h - off);
+            if (o && w + sizeof(RecCluster) <= cap) {
+                RecCluster rc = {m, a->entryQSet[e], a->entryTSet[e], 0, pCO[off + c], pMH[off + c]};
+                memcpy(o + w, &rc, sizeof(rc));
+            }
+            w += sizeof(RecCluster);
+            for (uint32_t x = 0; x < m; x++) {
+                const BestHit &b = *a->best[off + order[x]];
+                const uint64_t need = sizeof(RecMember) + ((b.cigarLen + 3u) & ~3u);
+                if (o && w + need <= cap) {
+                    RecMember rm;
+                    memset(&rm, 0, sizeof(rm));
+                    rm.q = b.q;
+                    rm.t = b.t;
+                    memcpy(rm.pval, b.pvalText, sizeof(rm.pval));
+                    memcpy(rm.seqId, b.seqIdText, sizeof(rm.seqId));
+                    memcpy(rm.eval, b.evalText, sizeof(rm.eval));
+                    rm.qStart = b.qStart; rm.qEnd = b.qEnd; rm.qLen = b.qLen;
+                    rm.tStart = b.tStart; rm.tEnd = b.tEnd; rm.tLen = b.tLen;
+                    rm.cigarLen = b.cigarLen;
+                    memcpy(o + w, &rm, sizeof(rm));
+                    memset(o + w + sizeof(rm), 0, need - sizeof(rm));
+                    memcpy(o + w + sizeof(rm), a->tCigar[b.arena].data() + b.cigarOff, b.cigarLen);
+                }
+                w += need;
+            }
+        }
+    }
+    *bytes = w;
+    return (o && w > cap) ? SD_ENOMEM : SD_OK;
+}
+
+// summarizeresults (R/src/util/SummarizeResults.cpp:77-112) from cluster records: '#key source source pCO pMH size' per
+// cluster, '>query target pval seqId eval coordinates cigar' per member; canonical: without the '#key' / '>query' columns
+int sd_records_write_tsv(const void *records, uint64_t bytes, const char *path, int append, uint64_t firstClusterKey,
+                         const char *qNames, const uint64_t *qNameOff, const char *tNames, const uint64_t *tNameOff,
+                         const char *qSources, const uint64_t *qSourceOff, const char *tSources, const uint64_t *tSourceOff,
+                         int canonical, uint64_t *nClusterLines, uint64_t *nHitLines) {
+    if ((bytes && !records) || !path) return SD_EINVAL;
+    FILE *f = fopen(path, append ? "a" : "w");
+    if (!f) return SD_EINVAL;
+    const char *p = (const char *) records, *endP = p + bytes;
+    uint64_t key = firstClusterKey, nc = 0, nh = 0;
+    int status = SD_OK;
+    while (p < endP) {
+        RecCluster rc;
+        if ((uint64_t) (endP - p) < sizeof(rc)) { status = SD_EINVAL; break; }
+        memcpy(&rc, p, sizeof(rc));
+        p += sizeof(rc);
+        char co[32], mh[32];
+        snprintf(co, sizeof(co), "%.3E", rc.pCO);   // SSTR(double) = "{:.3E}" (M/src/commons/Util.cpp:658-660)
+        snprintf(mh, sizeof(mh), "%.3E", rc.pMH);
+        if (!canonical) fprintf(f, "#%llu\t", (unsigned long long) key);
+        fprintf(f, "%.*s\t%.*s\t%s\t%s\t%u\n", (int) (qSourceOff[rc.qSet + 1] - qSourceOff[rc.qSet]), qSources + qSourceOff[rc.qSet],
+                (int) (tSourceOff[rc.tSet + 1] - tSourceOff[rc.tSet]), tSources + tSourceOff[rc.tSet], co, mh, rc.members);
+        nc++;
+        for (uint32_t m = 0; m < rc.members && status == SD_OK; m++) {
+            RecMember rm;
+            if ((uint64_t) (endP - p) < sizeof(rm)) { status = SD_EINVAL; break; }
+            memcpy(&rm, p, sizeof(rm));
+            p += sizeof(rm);
+            const uint64_t padded = (rm.cigarLen + 3u) & ~3u;
+            if ((uint64_t) (endP - p) < padded) { status = SD_EINVAL; break; }
+            if (!canonical) fprintf(f, ">%.*s\t", (int) (qNameOff[rm.q + 1] - qNameOff[rm.q]), qNames + qNameOff[rm.q]);
+            fprintf(f, "%.*s\t%s\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%.*s\n", (int) (tNameOff[rm.t + 1] - tNameOff[rm.t]), tNames + tNameOff[rm.t],
+                    rm.pval, rm.seqId, rm.eval, rm.qStart, rm.qEnd, rm.qLen, rm.tStart, rm.tEnd, rm.tLen, (int) rm.cigarLen, p);
+            p += padded;
+            nh++;
+        }
+        if (status != SD_OK) break;
+        key++;
+    }
+    fclose(f);
+    if (nClusterLines) *nClusterLines = nc;
+    if (nHitLines) *nHitLines = nh;
+    return status;
+}
+
 int sd_agg_write_tsv_from(sd_agg *a, const char *path, int append, uint64_t firstClusterKey, const uint32_t *clusterOfHit,
                           const uint32_t *rankInCluster, const uint32_t *nClusters, const double *pCO, const double *pMH,
                           const uint32_t *clusterSize, const char *qNames, const uint64_t *qNameOff, const char *tNames,
                           const uint64_t *tNameOff, const char *qSources, const uint64_t *qSourceOff, const char *tSources,
                           const uint64_t *tSourceOff, int canonical, uint64_t *nClusterLines, uint64_t *nHitLines) {
     if (!a || !path) return SD_EINVAL;
-    FILE *f = fopen(path, append ? "a" : "w");
-    if (!f) return SD_EINVAL;
-    uint64_t key = firstClusterKey, nc = 0, nh = 0;
-    std::vector<uint32_t> order;
-    for (size_t e = 0; e + 1 < a->entryOff.size(); e++) {
-        const uint64_t off = a->entryOff[e], end = a->entryOff[e + 1];
-        const uint32_t n = nClusters[e];
-        for (uint32_t c = 0; c < n; c++) {
-            order.assign(clusterSize[off + c], 0);
-            for (uint64_t h = off; h < end; h++)
-                if (clusterOfHit[h] == c) order[rankInCluster[h]] = (uint32_t) (h - off);
-            const uint32_t qs = a->entryQSet[e], ts = a->entryTSet[e];
-            char co[32], mh[32];
-            snprintf(co, sizeof(co), "%.3E", pCO[off + c]);   // SSTR(double) = "{:.3E}" (M/src/commons/Util.cpp:658-660)
-            snprintf(mh, sizeof(mh), "%.3E", pMH[off + c]);
-            if (!canonical) fprintf(f, "#%llu\t", (unsigned long long) key);
-            fprintf(f, "%.*s\t%.*s\t%s\t%s\t%u\n", (int) (qSourceOff[qs + 1] - qSourceOff[qs]), qSources + qSourceOff[qs],
-                    (int) (tSourceOff[ts + 1] - tSourceOff[ts]), tSources + tSourceOff[ts], co, mh, clusterSize[off + c]);
-            nc++;
-            for (uint32_t m = 0; m < clusterSize[off + c]; m++) {
-                const BestHit &b = *a->best[off + order[m]];
-                if (!canonical) fprintf(f, ">%.*s\t", (int) (qNameOff[b.q + 1] - qNameOff[b.q]), qNames + qNameOff[b.q]);
-                fprintf(f, "%.*s\t%s\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%s\n", (int) (tNameOff[b.t + 1] - tNameOff[b.t]),
-                        tNames + tNameOff[b.t], b.pvalText, b.seqIdText, b.evalText, b.qStart, b.qEnd, b.qLen, b.tStart,
-                        b.tEnd, b.tLen, std::string(a->tCigar[b.arena], b.cigarOff, b.cigarLen).c_str());
-                nh++;
-            }
-            key++;
-        }
-    }
-    fclose(f);
-    if (nClusterLines) *nClusterLines = nc;
-    if (nHitLines) *nHitLines = nh;
-    return SD_OK;
+    // one path to the file: the records, then the text
+    uint64_t bytes = 0;
+    int rc = sd_agg_records(a, clusterOfHit, rankInCluster, nClusters, pCO, pMH, clusterSize, nullptr, 0, &bytes);
+    if (rc != SD_OK) return rc;
+    std::vector<char> rec(bytes);
+    rc = sd_agg_records(a, clusterOfHit, rankInCluster, nClusters, pCO, pMH, clusterSize, rec.data(), bytes, &bytes);
+    if (rc != SD_OK) return rc;
+    return sd_records_write_tsv(rec.data(), bytes, path, append, firstClusterKey, qNames, qNameOff, tNames, tNameOff, qSources, qSourceOff,
+                                tSources, tSourceOff, canonical, nClusterLines, nHitLines);
 }
 
 int sd_agg_write_tsv(sd_agg *a, const char *path, const uint32_t *clusterOfHit, const uint32_t *rankInCluster,

@@ -540,6 +540,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     int status = SD_OK;
     std::future<std::pair<int, double> > pending;
     bool havePending = false;
+    size_t pendingChunk = 0;   // chunk whose aggregation job `pending` is
     auto waitPending = [&]() {
         if (!havePending) return;
         const double t0 = nowSec();
@@ -726,6 +727,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             sd_search::AlnBuf *bp = a->B;
             sd_search *sp = s;
             const uint32_t nOut = a->nOut;
+            pendingChunk = ci;
             pending = aggStage.submit([agg, bp, nOut, c0, nq, sp]() {
                 const double t1 = nowSec();
                 if (sp->alnSink)
@@ -742,11 +744,16 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         if (lastChunkOf[r] == (int64_t) ci) toFinalize.push_back(std::make_pair(r, ci));
         // ranges whose last aggregation job has finished meanwhile
         while (!toFinalize.empty() && status == SD_OK) {
-            const bool ready = !havePending || toFinalize.front().second < ci ||
-                               pending.wait_for(std::chrono::seconds(0)) == std::future_status::ready;
-            if (!ready) break;
-            if (toFinalize.front().second == ci) waitPending();
-            if (status != SD_OK) break;
+            // the aggregation job in flight may belong to the range at the front (its last chunk with pairs, when later chunks of
+            // the range had none): the range is finalised only once that job has been collected -- never beside it
+            // (jobs run one at a time, each submitted after the previous was collected: a job of a later chunk in flight means
+            // every job of the front range is done)
+            const bool mine = havePending && pendingChunk <= toFinalize.front().second;
+            if (mine) {
+                if (pending.wait_for(std::chrono::seconds(0)) != std::future_status::ready) break;   // come back for it later
+                waitPending();
+                if (status != SD_OK) break;
+            }
             const uint32_t fr = toFinalize.front().first;
             toFinalize.erase(toFinalize.begin());
             const int rc = finalize(fr);
@@ -854,6 +861,16 @@ int sd_search_result_arrays(sd_search_result *r, uint64_t *entryOff, uint32_t *e
     SD_COPY(clusterSize, r->cSize);
 #undef SD_COPY
     return SD_OK;
+}
+
+int sd_search_result_records(sd_search_result *r, void *out, uint64_t cap, uint64_t *bytes) {
+    if (!r || !r->agg || !bytes) return SD_EINVAL;
+    static const uint32_t zero32 = 0;
+    static const double zeroD = 0.0;
+    const bool empty = r->hitQ.empty();
+    return sd_agg_records(r->agg, empty ? &zero32 : r->clusterOf.data(), empty ? &zero32 : r->rank.data(),
+                          r->nClusters.empty() ? &zero32 : r->nClusters.data(), empty ? &zeroD : r->pCO.data(),
+                          empty ? &zeroD : r->pMH.data(), empty ? &zero32 : r->cSize.data(), out, cap, bytes);
 }
 
 int sd_search_result_write_tsv(sd_search_result *r, const char *path, const char *qNames, const uint64_t *qNameOff,

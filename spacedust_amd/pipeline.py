@@ -181,7 +181,7 @@ class ClusterSearch:
         return self.search_stream(Q, [rng], same_db=same_db, chunk_queries=chunk_queries, tsv_paths=[tsv_path],
                                   canonical=canonical)[0]
 
-    def search_stream(self, Q, ranges, same_db=False, chunk_queries=None, tsv_paths=None, canonical=True):
+    def search_stream(self, Q, ranges, same_db=False, chunk_queries=None, tsv_paths=None, canonical=True, want_records=False):
         """The workflow for several query ranges [a,b) of Q (whole query sets each), streamed through one pipeline
         (sd_search_stream): the prefilter of the next chunk -- of the same or of the next range -- overlaps the alignments
         of the current one.  Every range gets its own aggregation, clusterhits call and result record.  Returns the list
@@ -227,8 +227,15 @@ class ClusterSearch:
                 api._check(None, L.sd_search_result_write_tsv(h, tsv_paths[ri].encode(), qn, ptr(qno), tn, ptr(tno), qs, ptr(qso), ts,
                                                              ptr(tso), 1 if canonical else 0, 0, 0, C.byref(nc), C.byref(nhl)),
                            'sd_search_result_write_tsv')
+            records = None
+            if want_records:   # the cluster records of the range: what a rank sends to the root (sd_search_result_records)
+                need = C.c_uint64()
+                api._check(None, L.sd_search_result_records(h, None, 0, C.byref(need)), 'sd_search_result_records')
+                records = np.zeros(int(need.value), np.uint8)
+                if need.value:
+                    api._check(None, L.sd_search_result_records(h, ptr(records), records.nbytes, C.byref(need)), 'sd_search_result_records')
             L.sd_search_result_destroy(h)
-            results.append(dict(entries=ne, matched_hits=nh, clusters=int(cnt[2]), cluster_hits=int(cnt[3]), aligned=int(cnt[4]),
+            results.append(dict(records=records, entries=ne, matched_hits=nh, clusters=int(cnt[2]), cluster_hits=int(cnt[3]), aligned=int(cnt[4]),
                                 accepted=int(cnt[5]), prefilter_hits=int(cnt[6]), timing={}, entry_q=eq[:ne], entry_t=et[:ne],
                                 entry_off=eo, cluster_out=out if nh > 0 else None, hit_q=hq[:nh], hit_t=ht[:nh], hit_pval=pv[:nh]))
         if results:
@@ -300,6 +307,21 @@ class RcclGather:
         api._check(None, self.L.sd_comm_init(device, world, rank, unique_id, C.byref(h)), 'sd_comm_init')
         self.h = h
 
+    def gather_bytes(self, local, root=0):
+        """byte records of every rank -> (concatenated bytes in rank order, sizes per rank) on `root`, (None, sizes) elsewhere"""
+        rec = np.ascontiguousarray(local, np.uint8).reshape(-1)
+        sizes = np.zeros(self.world, np.uint64)
+        total = C.c_uint64()
+        out = np.zeros(0, np.uint8)
+        rc = self.L.sd_gather_results(self.h, ptr(rec) if rec.size else None, rec.nbytes, root, ptr(sizes), None, 0, C.byref(total))
+        if rc == _lib.SD_ENOMEM:   # size probe: every rank learns that the root needs room (nothing was exchanged)
+            out = np.zeros(int(total.value) if self.rank == root else 0, np.uint8)
+            rc = self.L.sd_gather_results(self.h, ptr(rec) if rec.size else None, rec.nbytes, root, ptr(sizes), ptr(out) if out.size else None,
+                                          out.nbytes, C.byref(total))
+        if rc != 0:
+            raise _lib.SdError('sd_gather_results failed (%d): %s' % (rc, self.L.sd_comm_last_error(self.h).decode(errors='replace')))
+        return (out if self.rank == root else None), sizes
+
     def gather(self, local_records, root=0):
         """variable-length int64 record arrays -> list of per-rank arrays on `root` (None elsewhere)"""
         rec = np.ascontiguousarray(local_records, np.int64).reshape(-1)
@@ -307,8 +329,8 @@ class RcclGather:
         total = C.c_uint64()
         out = np.zeros(0, np.uint8)
         rc = self.L.sd_gather_results(self.h, ptr(rec) if rec.size else None, rec.nbytes, root, ptr(sizes), None, 0, C.byref(total))
-        if self.rank == root and rc == _lib.SD_ENOMEM:
-            pass   # size probe: the first call tells the root how much room the records need
+        if rc == _lib.SD_ENOMEM:
+            pass   # size probe: the first call tells every rank how much room the root needs (nothing was exchanged)
         elif rc != 0:
             raise _lib.SdError('sd_gather_results failed (%d): %s' % (rc, self.L.sd_comm_last_error(self.h).decode(errors='replace')))
         if total.value:
@@ -327,6 +349,23 @@ class RcclGather:
             self.L.sd_comm_destroy(self.h)
         except Exception:
             pass
+
+
+def write_records_tsv(records, path, Q, T, canonical=False, first_cluster_key=0):
+    """the TSV of cluster records (one rank's, or the gathered buffer of all ranks): sd_records_write_tsv; returns (#clusters, #hits)"""
+    L = _lib.load()
+    Q.default_names()
+    T.default_names()
+    qn, qno = _pack_strings(Q.names)
+    tn, tno = _pack_strings(T.names)
+    qs, qso = _pack_strings(Q.sources)
+    ts, tso = _pack_strings(T.sources)
+    rec = np.ascontiguousarray(records, np.uint8).reshape(-1)
+    nc, nh = C.c_uint64(), C.c_uint64()
+    api._check(None, L.sd_records_write_tsv(ptr(rec) if rec.size else None, rec.nbytes, str(path).encode(), 0, first_cluster_key, qn, ptr(qno), tn,
+                                            ptr(tno), qs, ptr(qso), ts, ptr(tso), 1 if canonical else 0, C.byref(nc), C.byref(nh)),
+               'sd_records_write_tsv')
+    return int(nc.value), int(nh.value)
 
 
 def gather_results(local_records, dist, device=None):

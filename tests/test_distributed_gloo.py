@@ -60,3 +60,43 @@ def test_shard_deterministic_and_single_rank():
     a = [shard_query_sets(sizes, 3, r) for r in range(3)]
     assert sorted(sum(a, [])) == list(range(6))
     assert a == [shard_query_sets(sizes, 3, r) for r in range(3)]
+
+
+def _tcp_worker(rank, world, port, q):
+    import ctypes as C
+    from spacedust_amd import _lib
+    L = _lib.load()
+    t = C.c_void_p()
+    assert L.sd_tcp_connect(b'127.0.0.1', port, world, rank, C.byref(t)) == 0
+    # broadcast of rank 0's 128 bytes (the RCCL unique id travels this way in sdgpu)
+    buf = C.create_string_buffer(bytes(range(128)) if rank == 0 else bytes(128), 128)
+    assert L.sd_tcp_bcast(t, buf, 128) == 0
+    # gatherv of variable-length records to rank 0
+    rec = np.arange(5 + 11 * rank, dtype=np.int64) * (rank + 3)
+    sizes = np.zeros(world, np.uint64)
+    total = C.c_uint64()
+    out = np.zeros(int(sum((5 + 11 * r) * 8 for r in range(world))), np.uint8)
+    rc = L.sd_tcp_gather(t, rec.ctypes.data_as(C.c_void_p), rec.nbytes, sizes.ctypes.data_as(C.c_void_p),
+                         out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(total))
+    assert rc == 0
+    L.sd_tcp_close(t)
+    q.put((rank, buf.raw, out.view(np.int64).tolist() if rank == 0 else None, sizes.tolist() if rank == 0 else None))
+
+
+def test_tcp_rendezvous_world3():
+    """sd_tcp_bcast / sd_tcp_gather of the C ABI (the ranks' meeting point in `sdgpu clustersearch`): three processes on 127.0.0.1"""
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_tcp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(o[1] == bytes(range(128)) for o in outs)
+    want = np.concatenate([np.arange(5 + 11 * r, dtype=np.int64) * (r + 3) for r in range(world)])
+    assert outs[0][2] == want.tolist()
+    assert outs[0][3] == [(5 + 11 * r) * 8 for r in range(world)]

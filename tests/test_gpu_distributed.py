@@ -10,27 +10,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _records(out):
-    """one row per (query set, target set) entry: ids, #hits, #clusters, and order-sensitive checksums of the cluster
-    assignment and of the P-values' bit patterns"""
-    rows = []
-    if out['cluster_out'] is None:
-        return np.zeros((0, 7), np.int64)
-    co = out['cluster_out']
-    off = out['entry_off']
-    for e in range(len(out['entry_q'])):
-        a, b = int(off[e]), int(off[e + 1])
-        cl = co['cluster_of'][a:b].astype(np.int64)
-        w = np.arange(1, b - a + 1, dtype=np.int64)
-        nclu = int(co['n_clusters'][e])
-        pbits = np.frombuffer(np.ascontiguousarray(co['pCO'][a:a + nclu]).tobytes(), np.int64)
-        rows.append([int(out['entry_q'][e]), int(out['entry_t'][e]), b - a, nclu,
-                     int(((cl + 2) * w).sum() % (1 << 40)), int((out['hit_t'][a:b].astype(np.int64) * w).sum() % (1 << 40)),
-                     int((pbits % (1 << 40)).sum() % (1 << 40))])
-    return np.array(rows, np.int64).reshape(-1, 7)
-
-
-def _search(sets):
+def _search(sets, tsv=None):
+    """cluster records (sd_search_result_records) of the given query sets, in the given order"""
     from spacedust_amd.api import Host, Context
     from spacedust_amd.pipeline import SetDB, ClusterSearch
     from spacedust_amd.synth import make_proteomes
@@ -38,15 +19,22 @@ def _search(sets):
     db = SetDB.from_proteomes(ps)
     host, gpu = Host(4), Context(0)
     cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
-    recs = []
-    for s in sets:
-        out = cs.search(db, same_db=True, query_range=(int(ps.set_start[s]), int(ps.set_start[s + 1])), chunk_queries=64)
-        recs.append(_records(out))
+    ranges = [(int(ps.set_start[s]), int(ps.set_start[s + 1])) for s in sets]
+    outs = cs.search_stream(db, ranges, same_db=True, chunk_queries=64, want_records=True) if ranges else []
+    recs = np.concatenate([o['records'] for o in outs]) if outs else np.zeros(0, np.uint8)
     sizes = [int(ps.offsets[ps.set_start[s + 1]] - ps.offsets[ps.set_start[s]]) for s in range(6)]
-    return (np.concatenate(recs) if recs else np.zeros((0, 7), np.int64)), sizes
+    return recs, sizes, db
 
 
-def _worker(rank, world, port, q):
+def _tsv_lines(records, db, path):
+    from spacedust_amd.pipeline import write_records_tsv
+    n_clu, n_hit = write_records_tsv(records, path, db, db)
+    lines = open(path).readlines()
+    assert sum(1 for l in lines if l.startswith('#')) == n_clu and len(lines) == n_clu + n_hit
+    return lines
+
+
+def _worker(rank, world, port, q, tmp):
     import torch.distributed as dist
     from spacedust_amd.pipeline import shard_query_sets, gather_results
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -56,32 +44,44 @@ def _worker(rank, world, port, q):
     ps = make_proteomes(6, genes_per_proteome=150, n_families=220, seed=23)
     sizes = [int(ps.offsets[ps.set_start[s + 1]] - ps.offsets[ps.set_start[s]]) for s in range(6)]
     mine = shard_query_sets(sizes, world, rank)
-    recs, _ = _search(mine)
-    got = gather_results(recs, dist)
+    recs, _, db = _search(mine)
+    # the gather of the cluster records (RCCL refuses two ranks on one GPU: the same bytes travel over gloo here), then rank 0
+    # writes the TSV from the gathered buffer
+    pad = np.concatenate([recs, np.zeros((-len(recs)) % 8, np.uint8)])
+    parts = gather_results(np.frombuffer(pad.tobytes(), np.int64), dist)
+    lens = gather_results(np.array([len(recs)], np.int64), dist)
     if rank == 0:
-        q.put((mine, [g.reshape(-1, 7).tolist() for g in got]))
+        allrec = np.concatenate([np.asarray(p, np.int64).view(np.uint8)[:int(n[0])] for p, n in zip(parts, lens)])
+        lines = _tsv_lines(allrec, db, os.path.join(tmp, 'two.tsv'))
+        q.put((mine, lines))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_equal_one_rank(gpu):
+def test_two_ranks_on_one_gpu_equal_one_rank(gpu, tmp_path):
     import torch.multiprocessing as mp
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from dbutil import sorted_md5
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
-    mine0, gathered = q.get(timeout=600)
+    mine0, two = q.get(timeout=600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     assert 0 < len(mine0) < 6
-    sharded = np.array(sorted(r for g in gathered for r in g), np.int64)
-    whole, _ = _search(range(6))
-    whole = np.array(sorted(whole.tolist()), np.int64)
-    assert len(whole) > 10 and whole[:, 3].sum() > 0
-    assert sharded.shape == whole.shape and (sharded == whole).all()
+    recs, _, db = _search(range(6))
+    one = _tsv_lines(recs, db, str(tmp_path / 'one.tsv'))
+    assert len(one) > 100 and sum(1 for l in one if l.startswith('#')) > 10
+    # the TSV written from the gathered records is the one-rank TSV up to the order of the query sets (cluster keys count from 0 in
+    # both, and are consecutive)
+    assert sorted_md5(one, drop_first_column=True) == sorted_md5(two, drop_first_column=True)
+    keys = [int(l.split('\t')[0][1:]) for l in two if l.startswith('#')]
+    assert keys == list(range(len(keys)))
 
 
 def test_rccl_gather_seam_single_rank(gpu):
@@ -97,11 +97,13 @@ def test_rccl_gather_seam_single_rank(gpu):
     assert len(out) == 1 and (out[0].reshape(-1, 7) == recs).all()
     out = g.gather(np.zeros((0, 7), np.int64))
     assert len(out) == 1 and out[0].size == 0
+    raw, sizes = g.gather_bytes(np.arange(1001, dtype=np.uint8))
+    assert raw.tolist() == (np.arange(1001) % 256).tolist() and sizes.tolist() == [1001]
 
 
 def test_sdgpu_clustersearch_two_ranks_equal_one(gpu, tmp_path):
-    """the binary's own multi-rank mode (RANK / WORLD_SIZE, whole query sets per rank, parts merged by rank 0): two ranks
-    sharing cuda:0 must write the same clusters as one rank"""
+    """the binary's own multi-rank mode (RANK / WORLD_SIZE, whole query sets per rank, every rank's cluster records gathered on
+    rank 0, which writes the TSV from the gathered buffer): two ranks sharing cuda:0 must write the same clusters as one rank"""
     import subprocess
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
@@ -114,7 +116,7 @@ def test_sdgpu_clustersearch_two_ranks_equal_one(gpu, tmp_path):
     sdgpu('clustersearch', q, t, tmp_path / 'one.tsv', tmp_path / 'tmp1', '-v', '0')
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0')
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(30500 + os.getpid() % 2000))
         procs.append(subprocess.Popen([SDGPU, 'clustersearch', str(q), str(t), str(tmp_path / 'two.tsv'), str(tmp_path / 'tmp2'), '-v', '0'],
                                       env=env))
     assert [p.wait(timeout=600) for p in procs] == [0, 0]
