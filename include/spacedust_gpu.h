@@ -187,7 +187,8 @@ int sd_prefilter_batch(sd_ctx *ctx, const sd_target *target, const sd_prefilter_
  * (25 bytes per position, Sequence.h:458-471; byteOffsets[n+1] into profileData): per position the query letter,
  * the consensus letter (nullable output), the int8 alignment profile [21] = score / 4 with the X column 0, and the
  * k-mer generator's row: the 20 scores sorted descending by Util::rankedDescSort20's network and the amino acids
- * in that order.  posOffsets[n+1] receives the position offsets (= byteOffsets / 25). */
+ * in that order.  posOffsets[n+1] receives the position offsets: byteOffsets / 25 (when byteOffsets[0] = 0), except that a profile
+ * longer than --max-seq-len (65 535 positions) is cut there as mapProfile does (:247-266) and the later ones move up. */
 int sd_host_map_profiles(const char *profileData, const uint64_t *byteOffsets, uint32_t n, uint8_t *queryLetters,
                          uint8_t *consensus, int8_t *alnProfile /* total x 21 */, int16_t *sortedScore /* total x 20 */,
                          uint8_t *sortedIndex /* total x 20 */, uint64_t *posOffsets);

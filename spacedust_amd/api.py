@@ -83,6 +83,10 @@ class Host:
         _check(None, self.L.sd_host_map_profiles(ptr(data), ptr(bo), n, ptr(out['letters']), ptr(out['consensus']),
                                                  ptr(out['aln']), ptr(out['sorted_score']), ptr(out['sorted_index']),
                                                  ptr(out['offsets'])), 'sd_host_map_profiles')
+        used = int(out['offsets'][-1])   # profiles beyond --max-seq-len positions are cut (Sequence::mapProfile): trim the arrays
+        if used < total:
+            for k_ in ('letters', 'consensus', 'aln', 'sorted_score', 'sorted_index'):
+                out[k_] = np.ascontiguousarray(out[k_][:used])
         return out
 
     def profile_kmer_threshold(self, sensitivity, k):

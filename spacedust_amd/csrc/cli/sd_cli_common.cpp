@@ -96,6 +96,9 @@ bool SeqDb::load(const std::string &path, sd_host *host, std::string *err) {
             if (err) *err = "sd_host_map_profiles failed for " + path;
             return false;
         }
+        // profiles beyond --max-seq-len positions were cut (Sequence::mapProfile): the position offsets are the mapper's
+        for (uint32_t i = 0; i <= n; i++) offsets[i] = posOff[i];
+        for (uint32_t i = 0; i < n; i++) lens[i] = (int32_t) (posOff[i + 1] - posOff[i]);
     }
     return true;
 }

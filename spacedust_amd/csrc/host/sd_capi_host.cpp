@@ -108,10 +108,14 @@ int sd_host_map_profiles(const char *profileData, const uint64_t *byteOffsets, u
                          uint8_t *consensus, int8_t *alnProfile, int16_t *sortedScore, uint8_t *sortedIndex,
                          uint64_t *posOffsets) {
     if (!profileData || !byteOffsets || !queryLetters || !alnProfile || !sortedScore || !sortedIndex || !posOffsets) return SD_EINVAL;
-    for (uint32_t i = 0; i <= n; i++) {
-        if (byteOffsets[i] % sd::PROFILE_RECORD) return SD_EINVAL;
-        posOffsets[i] = byteOffsets[i] / sd::PROFILE_RECORD;
-    }
+    // a profile longer than --max-seq-len (65 535) is cut there: Sequence::mapProfile reads `while (l < maxLen && l < seqLen)`
+    // (M/src/commons/Sequence.cpp:247-266); the positions of the following profiles move up
+    constexpr uint64_t MAX_PROFILE_LEN = 65535;
+    posOffsets[0] = 0;
+    for (uint32_t i = 0; i <= n; i++)
+        if (byteOffsets[i] % sd::PROFILE_RECORD || (i && byteOffsets[i] < byteOffsets[i - 1])) return SD_EINVAL;
+    for (uint32_t i = 0; i < n; i++)
+        posOffsets[i + 1] = posOffsets[i] + std::min<uint64_t>((byteOffsets[i + 1] - byteOffsets[i]) / sd::PROFILE_RECORD, MAX_PROFILE_LEN);
 #pragma omp parallel for schedule(dynamic, 64)
     for (uint32_t i = 0; i < n; i++) {
         const uint64_t p0 = posOffsets[i];

@@ -98,3 +98,25 @@ def test_wide_index_is_the_same_index(monkeypatch):
         assert np.array_equal(absolute, a.kmer_offsets.astype(np.uint64))
         assert np.array_equal(a.entry_seq, b.entry_seq) and np.array_equal(a.entry_pos, b.entry_pos)
         assert a.n_entries == b.n_entries == int(absolute[-1])
+
+
+def test_profiles_beyond_max_seq_len_are_cut():
+    """Sequence::mapProfile stops at maxLen (M/src/commons/Sequence.cpp:247-266, --max-seq-len 65 535): a longer profile entry is
+    cut there, the entries behind it keep their content"""
+    import numpy as np
+    from spacedust_amd.api import Host
+    host = Host(2)
+    rng = np.random.default_rng(5)
+    lens = [30, 70000, 12]
+    recs = [rng.integers(-20, 40, size=(n, 25)).astype(np.int8) for n in lens]
+    for r in recs:
+        r[:, 20] = rng.integers(0, 20, size=len(r))
+    data = b''.join(r.tobytes() for r in recs)
+    bo = np.concatenate([[0], np.cumsum([25 * n for n in lens])]).astype(np.uint64)
+    out = host.map_profiles(data, bo)
+    assert out['offsets'].tolist() == [0, 30, 30 + 65535, 30 + 65535 + 12]
+    assert len(out['letters']) == 30 + 65535 + 12
+    a = int(out['offsets'][2])
+    assert (out['letters'][a:a + 12] == recs[2][:, 20].astype(np.uint8)).all()
+    assert (out['letters'][30:30 + 65535] == recs[1][:65535, 20].astype(np.uint8)).all()
+    assert (out['aln'][a:a + 12, :20] == (recs[2][:, :20].astype(np.int32) / 4).astype(np.int8)).all()

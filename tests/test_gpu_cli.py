@@ -228,3 +228,18 @@ def test_prefilter_and_clustersearch_use_the_index_file(work):
     assert 'Index file not used' in p.stdout
     for f in ('genome.idx', 'genome.idx.index', 'genome.idx.dbtype'):
         os.remove(work / f)
+
+
+def test_literal_config1_two_set_dbs(work):
+    """BASELINE configs[0] as written: NC_000913 as the query set DB, NC_000915 as the target set DB (two createsetdb calls,
+    query != target, no --filter-self-match): 176 hit lines in 61 clusters, one of them with P < 1E-20, and the canonical
+    TSV (without the cluster-key / query columns' first field) hashes like the reference binary's"""
+    fa = example_fasta(work)
+    q, t = work / 'q913', work / 't915'
+    sdgpu('createsetdb', fa[0], q, work / 'tmpq', '-v', '0')
+    sdgpu('createsetdb', fa[1], t, work / 'tmpt', '-v', '0')
+    sdgpu('clustersearch', q, t, work / 'c1.tsv', work / 'tmpc1', '--threads', '8', '-v', '0')
+    tsv = open(work / 'c1.tsv').readlines()
+    clu = [l for l in tsv if l.startswith('#')]
+    assert (sum(1 for l in tsv if l.startswith('>')), len(clu), sum(1 for l in clu if float(l.split('\t')[3]) < 1e-20)) == (176, 61, 1)
+    assert len(tsv) == 237 and sorted_md5(tsv, drop_first_column=True) == '521fe66c5fd4b93b0b3363bd149f9bd7'

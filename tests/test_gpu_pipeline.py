@@ -43,6 +43,34 @@ def load_examples(host):
     return SetDB(res, off, set_id, pos, strand, 2, names=names, sources=sources)
 
 
+def _subset(db, set_index):
+    """one genome of the two-genome example DB as its own set DB (what a createsetdb call on that FASTA alone makes)"""
+    m = np.nonzero(np.asarray(db.set_id) == set_index)[0]
+    a, b = int(m[0]), int(m[-1]) + 1
+    assert (m == np.arange(a, b)).all()
+    off = (db.offsets[a:b + 1] - db.offsets[a]).astype(np.uint64)
+    res = db.residues[int(db.offsets[a]):int(db.offsets[b])]
+    return SetDB(res, off, [0] * (b - a), list(np.asarray(db.pos_in_set)[a:b]), list(np.asarray(db.strand)[a:b]), 1,
+                 names=db.names[a:b], sources=[db.sources[set_index]])
+
+
+def test_query_db_differs_from_target_db(gpu, host, tmp_path):
+    """pipeline.search(same_db=False) -- BASELINE configs[0] as written: NC_000913 (query set DB) against NC_000915 (target
+    set DB), no self-match filter: the reference binary finds 176 hit lines in 61 clusters, one with P < 1E-20, canonical
+    TSV md5 521fe66c..."""
+    both = load_examples(host)
+    q, t = _subset(both, 0), _subset(both, 1)
+    cs = ClusterSearch(gpu, host, t, max_seqs=300, filter_self_match=False)
+    out = cs.search(q, same_db=False, tsv_path=str(tmp_path / 'c1.tsv'), canonical=True)
+    lines = open(tmp_path / 'c1.tsv').readlines()
+    n_clu = sum(1 for l in lines if l.count('\t') == 4)
+    sig = sum(1 for l in lines if l.count('\t') == 4 and float(l.split('\t')[2]) < 1e-20)
+    assert (len(lines) - n_clu, n_clu, sig) == (176, 61, 1)
+    assert out['clusters'] == 61
+    lines.sort(key=lambda s_: s_.encode())
+    assert hashlib.md5(''.join(lines).encode()).hexdigest() == '521fe66c5fd4b93b0b3363bd149f9bd7'
+
+
 def test_examples_regression_known_answers(gpu, host, tmp_path):
     db = load_examples(host)
     cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
