@@ -271,6 +271,12 @@ unsigned sd_host_bin_size(uint64_t dbSize, uint64_t l2CacheSize); /* l2CacheSize
 uint64_t sd_host_pair_list(const sd_hit *hits, const uint32_t *counts, uint32_t nQ, uint32_t rowWidth, uint32_t *pairQ,
                            uint32_t *pairT);
 int sd_host_lgamma_table(double *out, uint32_t n);
+/* The two P-values of one cluster of hits (host; what sd_clusterhits_batch evaluates for every cluster it emits,
+ * R/src/util/ClusterHits.cpp:80-134,184-213): gene positions on both sides, strands (bit 0 query, bit 1 target), per-hit
+ * P-values, the size of the query set.  order[nHits] (nullable): the members by query position, the order they are printed in. */
+int sd_host_cluster_pvalues(uint32_t nHits, const uint32_t *qPos, const uint32_t *tPos, const uint8_t *strands, const double *pval,
+                            uint32_t querySetSize, double alpha, const double *lGamma, uint32_t lGammaLen, double *pCluster,
+                            double *pMultihit, uint32_t *order);
 double sd_host_evalue(uint64_t dbResidues, double score, double qLen);
 double sd_host_bitscore(double score);
 /* Util::canBeCovered (M/src/commons/Util.cpp:477-494): the length pre-check of Prefiltering.cpp:856-863 / Alignment.cpp:370 */

@@ -131,6 +131,8 @@ def load():
         'sd_host_bin_size': (C.c_uint, [C.c_uint64, C.c_uint64]),
         'sd_host_pair_list': (C.c_uint64, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
         'sd_host_lgamma_table': (C.c_int, [_vp, C.c_uint32]),
+        'sd_host_cluster_pvalues': (C.c_int, [C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32, C.c_double, _vp, C.c_uint32, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double), _vp]),
         'sd_host_evalue': (C.c_double, [C.c_uint64, C.c_double, C.c_double]),
         'sd_host_bitscore': (C.c_double, [C.c_double]),
         'sd_target_create': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_uint64, _vp, _vp, C.c_uint32, _vp, _vp, _vp,

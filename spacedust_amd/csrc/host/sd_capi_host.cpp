@@ -1,5 +1,7 @@
 // C-ABI wrappers of the host-side stages (sd_host_* in include/spacedust_gpu.h).
 #include "sd_host.h"
+
+#include <climits>
 #include <vector>
 #include <omp.h>
 #include <cstdio>
@@ -228,6 +230,30 @@ static double chLogGamma(double x) {
     sum += dk[9] / (x + 8);
     sum += dk[10] / (x + 9);
     return log(gc) + (x - 0.5) * log(x + r10 - 0.5) - (x - 0.5) + log(sum);
+}
+
+int sd_host_cluster_pvalues(uint32_t nHits, const uint32_t *qPos, const uint32_t *tPos, const uint8_t *strands, const double *pval,
+                            uint32_t querySetSize, double alpha, const double *lGamma, uint32_t lGammaLen, double *pCluster,
+                            double *pMultihit, uint32_t *order) {
+    if (!nHits || !qPos || !tPos || !strands || !pval || !lGamma || !pCluster || !pMultihit) return SD_EINVAL;
+    std::vector<sd::ClusterHit> c(nHits);
+    uint32_t lo = UINT32_MAX, hi = 0;
+    for (uint32_t x = 0; x < nHits; x++) {
+        c[x].pval = pval[x];
+        c[x].qPos = qPos[x];
+        c[x].tPos = tPos[x];
+        c[x].qS = strands[x] & 1;
+        c[x].tS = (strands[x] >> 1) & 1;
+        c[x].idx = x;
+        lo = std::min(lo, std::min(qPos[x], tPos[x]));
+        hi = std::max(hi, std::max(qPos[x], tPos[x]));
+    }
+    if ((uint64_t) (hi - lo) + 2 >= lGammaLen || (uint64_t) nHits + 1 >= lGammaLen) return SD_EINVAL;   // the table covers span + 1 and hits + 1
+    *pCluster = sd::chClusterPval(lGamma, c);
+    *pMultihit = sd::chMultihitPval(lGamma, c, (int) querySetSize, alpha);
+    if (order)
+        for (uint32_t x = 0; x < nHits; x++) order[x] = c[x].idx;
+    return SD_OK;
 }
 
 int sd_host_lgamma_table(double *out, uint32_t n) {

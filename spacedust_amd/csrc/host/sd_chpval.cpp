@@ -1,78 +1,96 @@
-// P-values of the emitted clusters (R/src/util/ClusterHits.cpp:80-134,184-213,462-464) in double precision with the
-// reference's own expressions.  This file is compiled by g++ with the reference's AVX2 build flags (-mfma and GCC's default
-// -ffp-contract=fast, spacedust_amd/build.py HOST_FLAGS): which products fuse into an FMA decides the last bit of
-// `-0.5 * logpClu - 0.5 * logpOrd` and of `... + k * log(q0)`, and the reference prints these values with %.3E.
-// Pinned against the reference's compiled functions (oracle/_ref/libsdref_ch.so) in tests/test_gpu_clusterhits.py.
+// P-values of an emitted cluster of hits, double precision (the reference evaluates them in clusterhits and prints them
+// with %.3E: R/src/util/ClusterHits.cpp:80-134,184-213,462-464).
+//
+// Two null models, both over lnFact[n] = ln Gamma(n), i.e. lnFact[n + 1] = ln n!:
+//   * clustering x ordering: k hits that span s consecutive genes (the larger of the query-side and the target-side extent)
+//     and of whose k - 1 neighbour pairs (in query order) m keep order and strand,
+//         ln P_clu = 2 ln s! - 2 ln (s - k)! - ln k! + k ln q0          (q0 = 0.001)
+//         ln P_ord = ln(1 - m / k) - m ln 2 - ln m!
+//         P = exp((ln P_clu + ln P_ord) / 2);
+//   * multi-hit: with the per-hit threshold theta = alpha / (Nq + 1), the k' hits below it and their summed log excess
+//     r = sum(ln theta - ln p), P = exp(-r) * sum_{i < k' - 1} r^i / i!.
+// The printed digits depend on the last bit, so the products that the reference's AVX2 build contracts into fused
+// multiply-adds are written as std::fma here (k * ln q0 onto the placement term; m * ln 2 off the tail term) -- the result
+// no longer depends on the compiler's contraction mode -- and r^i / i! keeps the library calls pow and exp.  Pinned bit for
+// bit against the reference's compiled functions (oracle/_ref/libsdref_ch.so): tests/test_oracle_clusterhits_ref.py (host,
+// sd_host_cluster_pvalues) and tests/test_gpu_clusterhits.py (through the device path).
 #include "sd_host.h"
 
 #include <algorithm>
-#include <climits>
 #include <cmath>
 
 namespace sd {
 
 namespace {
 
+constexpr double kSiteProbability = 0.001;   // q0
 
-double hLogClusterPval(const double *lookup, int k, int m, double q0 = 0.001) {
-    return 2 * lookup[m + 1] - 2 * lookup[m - k + 1] - lookup[k + 1] + k * log(q0);
-}
-double hLogOrderingPval(const double *lookup, int k, int m) { return log(1 - 1.0 * m / k) - m * log(2) - lookup[m + 1]; }
+struct ClusterShape {
+    int hits = 0;        // k
+    int span = 0;        // s
+    int conserved = 0;   // m
+};
 
-double hClusterMatchScore(const double *lookup, std::vector<ClusterHit> &c) {
-    if (c.size() == 0) return 0.0;
-    unsigned int iMax = 0, iMin = INT_MAX, jMax = 0, jMin = INT_MAX;
-    for (size_t l = 0; l < c.size(); l++) {
-        iMax = (c[l].qPos > iMax) ? c[l].qPos : iMax;
-        iMin = (c[l].qPos < iMin) ? c[l].qPos : iMin;
-        jMax = (c[l].tPos > jMax) ? c[l].tPos : jMax;
-        jMin = (c[l].tPos < jMin) ? c[l].tPos : jMin;
+// orders the members by gene position on the query side (the order they are printed in) and measures the cluster
+ClusterShape measure(std::vector<ClusterHit> &members) {
+    ClusterShape shape;
+    shape.hits = (int) members.size();
+    uint32_t qLo = members[0].qPos, qHi = members[0].qPos, tLo = members[0].tPos, tHi = members[0].tPos;
+    for (const ClusterHit &h : members) {
+        qLo = std::min(qLo, h.qPos);
+        qHi = std::max(qHi, h.qPos);
+        tLo = std::min(tLo, h.tPos);
+        tHi = std::max(tHi, h.tPos);
     }
-    int spanI = iMax - iMin + 1, spanJ = jMax - jMin + 1;
-    int span = (spanI > spanJ) ? spanI : spanJ;
-    int k = (int) c.size();
-    std::sort(c.begin(), c.end(), [](const ClusterHit &a, const ClusterHit &b) {
-        if (a.qPos != b.qPos) return a.qPos < b.qPos;
-        return a.idx < b.idx;
+    shape.span = (int) std::max(qHi - qLo, tHi - tLo) + 1;
+    std::sort(members.begin(), members.end(), [](const ClusterHit &a, const ClusterHit &b) {
+        return a.qPos != b.qPos ? a.qPos < b.qPos : a.idx < b.idx;
     });
-    int m = 0;
-    for (size_t l = 0; l + 1 < c.size(); l++) {
-        bool isSameOrder = (c[l + 1].tPos > c[l].tPos);
-        bool s1 = (c[l].qS == c[l].tS), s2 = (c[l + 1].qS == c[l + 1].tS);
-        if ((s1 == isSameOrder) && (s2 == isSameOrder)) m++;
+    for (size_t x = 1; x < members.size(); x++) {
+        const ClusterHit &left = members[x - 1], &right = members[x];
+        const bool ascending = right.tPos > left.tPos;
+        // a neighbour pair is conserved when both hits pair equal strands exactly if the target order is ascending
+        if ((left.qS == left.tS) == ascending && (right.qS == right.tS) == ascending) shape.conserved++;
     }
-    double logpClu = hLogClusterPval(lookup, k, span);
-    double logpOrd = hLogOrderingPval(lookup, k, m);
-    return -0.5 * logpClu - 0.5 * logpOrd;
+    return shape;
 }
 
-double hMultihitPval(const double *lookup, const std::vector<ClusterHit> &cluster, int Nq, double alpha) {
-    size_t k = 0;
-    double r = 0;
-    double pvalThreshold = alpha / (Nq + 1);
-    double logPvalThr = log(pvalThreshold);
-    for (size_t i = 0; i < cluster.size(); ++i) {
-        double logPvalue = log(cluster[i].pval);
-        if (logPvalue < logPvalThr) {
-            k++;
-            r -= logPvalue - logPvalThr;
-        }
-    }
-    if (r == 0) return 1.0;
-    if (std::isinf(r)) return 0.0;
-    double expMinusR = exp(-r);
-    if (expMinusR == 0) return 0.0;
-    double sum = 0;
-    for (size_t i = 0; i < k - 1; ++i) sum += pow(r, i) / exp(lookup[i + 1]);
-    return expMinusR * sum;
+double logPlacement(const double *lnFact, const ClusterShape &c) {
+    const double arrangements = 2 * lnFact[c.span + 1] - 2 * lnFact[c.span - c.hits + 1] - lnFact[c.hits + 1];
+    return std::fma((double) c.hits, std::log(kSiteProbability), arrangements);
 }
 
+double logOrdering(const double *lnFact, const ClusterShape &c) {
+    const double tail = std::log(1 - 1.0 * c.conserved / c.hits);
+    return std::fma(-(double) c.conserved, std::log(2.0), tail) - lnFact[c.conserved + 1];
+}
 
 }  // namespace
 
-double chClusterPval(const double *lookup, std::vector<ClusterHit> &cluster) { return exp(-hClusterMatchScore(lookup, cluster)); }
-double chMultihitPval(const double *lookup, const std::vector<ClusterHit> &cluster, int Nq, double alpha) {
-    return hMultihitPval(lookup, cluster, Nq, alpha);
+double chClusterPval(const double *lnFact, std::vector<ClusterHit> &members) {
+    if (members.empty()) return 1.0;
+    const ClusterShape shape = measure(members);
+    return std::exp(0.5 * logPlacement(lnFact, shape) + 0.5 * logOrdering(lnFact, shape));
+}
+
+double chMultihitPval(const double *lnFact, const std::vector<ClusterHit> &members, int nQuerySet, double alpha) {
+    const double logTheta = std::log(alpha / (nQuerySet + 1));
+    size_t strong = 0;
+    double excess = 0;
+    for (const ClusterHit &h : members) {
+        const double lp = std::log(h.pval);
+        if (lp < logTheta) {
+            strong++;
+            excess -= lp - logTheta;
+        }
+    }
+    if (excess == 0) return 1.0;           // no hit below the threshold
+    if (std::isinf(excess)) return 0.0;    // a P-value of zero among them
+    const double decay = std::exp(-excess);
+    if (decay == 0) return 0.0;
+    double series = 0;
+    for (size_t i = 0; i + 1 < strong; i++) series += std::pow(excess, (double) i) / std::exp(lnFact[i + 1]);
+    return decay * series;
 }
 
 }  // namespace sd

@@ -1,16 +1,23 @@
-// result2profile: the host step between the iterations of `search --num-iterations` -- alignment DB ->
-// profile DB.  Restated from the reference's semantics, float operation by float operation, because the next iteration
-// consumes the rounded int8 scores:
-//   MSA from the backtraces, query-gap-free      M/src/alignment/MultipleAlignment.cpp:46-215 (computeMSA, noDeletionMSA)
-//   redundancy filter (HH-suite style)           M/src/alignment/MsaFilter.cpp:85-530
-//   sequence weights, context specific weights,  M/src/alignment/PSSMCalculator.cpp:169-240 (computePSSMFromMSA), :305-372,
-//   Neff, pseudo counts, log-odds PSSM              :374-401, :420-588, :251-265
-//   global composition bias of the PSSM          M/src/commons/SubstitutionMatrix.cpp:205-243
-//   tantan masking of the query positions        M/src/commons/Masker.cpp:57-80
-//   25-byte profile record                       PSSMCalculator.cpp:671-687, M/src/commons/Sequence.h:458-471
-// Compiled by g++ with the reference's AVX2 flags (-mavx2 -mfma, GCC's -ffp-contract=fast): the mixed float/double
-// expressions below keep the reference's literal types and grouping so that they contract the same way, and the one
-// approximate instruction the reference uses (rcpps + one Newton step, PSSMCalculator.cpp:497-504) is used here too.
+// result2profile: the host step between the iterations of `search --num-iterations` -- the alignments of
+// a centre sequence (or profile) become its profile for the next iteration.  What the reference computes
+// (M/src/util/result2profile.cpp:239-282), in the order of this file:
+//   1. a query-anchored multiple alignment from the backtraces, one row per hit, exactly L columns (target residues
+//      opposite a query gap are dropped)                                   M/src/alignment/MultipleAlignment.cpp:46-215
+//   2. a redundancy / diversity filter over the rows (HH-suite's scheme: per-row gates against the centre, then a greedy
+//      selection that raises the allowed pairwise identity only where the alignment is still thin)
+//                                                                          M/src/alignment/MsaFilter.cpp:85-530
+//   3. sequence weights -- per column sub-alignment weights (default) or global position-based weights (--wg) --, the
+//      number of effective sequences per column, substitution-matrix pseudo counts, log-odds scores
+//                                                                          M/src/alignment/PSSMCalculator.cpp:169-588
+//   4. the global composition bias of the scores                          M/src/commons/SubstitutionMatrix.cpp:205-243
+//   5. tantan masking of the centre                                       M/src/commons/Masker.cpp:57-80
+//   6. the 25-byte record per position                                    PSSMCalculator.cpp:671-687, Sequence.h:458-471
+// The next iteration consumes the rounded int8 scores, so every float expression below keeps the reference's operand types
+// and grouping (single precision accumulators, the double literals, the approximate reciprocal with one Newton step); the
+// structure around them -- row spans as one record per row, the gates and the pairwise comparison as functions, the greedy
+// selection over an explicit candidate order -- is this file's own.  Compiled by g++ with the reference's AVX2 flags.
+// Pinned byte for byte against the reference's classes (oracle/_ref/libsdref_r2p.so) on all 5 898 regression queries and on
+// the parameter corners: tests/test_result2profile.py.
 #include "sd_host.h"
 #include "spacedust_gpu.h"
 
@@ -20,18 +27,20 @@
 #include <cstdlib>
 #include <cstring>
 #include <immintrin.h>
+#include <numeric>
 #include <string>
 #include <vector>
 #include <omp.h>
 
 namespace {
 
-enum { AA = 20, ANY = 20, NAA = 20, GAP = 21, ENDGAP = 22 };
-constexpr int BLK = 32;   // VECSIZE_INT * 4 of the AVX2 build: MsaFilter compares rows in 32-byte blocks
+// cell codes of the alignment: residues 0..19, 20 = any residue (X), 21 = gap, 22 = gap before the first / behind the last residue
+enum : int { kResidues = 20, kAny = 20, kGap = 21, kEndGap = 22 };
+constexpr int kBlock = 32;   // rows are compared 32 cells at a time (the reference's AVX2 register width in bytes)
 
 #define SD_MAY_ALIAS(x) x __attribute__((__may_alias__))
 
-// MathUtil::flog2 / fpow2 (M/src/commons/MathUtil.h:121-163): literal types as in the reference
+// MathUtil::flog2 / fpow2 (M/src/commons/MathUtil.h:121-163): polynomial approximations, literal types as in the reference
 inline float flog2(float x) {
     if (x <= 0) return -128;
     SD_MAY_ALIAS(int) *px = (int *) (&x);
@@ -55,561 +64,533 @@ inline double fpow2(float x) {
     return x;
 }
 
-inline float normalizeTo1(float *array, int length, const double *def_array = NULL) {   // MathUtil::NormalizeTo1
-    float sum = 0.0f;
-    for (int k = 0; k < length; k++) sum += array[k];
-    if (sum != 0.0f) {
-        float fac = 1.0 / sum;
-        for (int i = 0; i < length; i++) array[i] *= fac;
-    } else if (def_array) {
-        for (int i = 0; i < length; i++) array[i] = def_array[i];
+// scale to sum 1 in single precision; an all-zero vector takes the fallback distribution (MathUtil::NormalizeTo1)
+inline float scaleToOne(float *v, int n, const double *fallback = nullptr) {
+    float total = 0.0f;
+    for (int x = 0; x < n; x++) total += v[x];
+    if (total != 0.0f) {
+        float factor = 1.0 / total;
+        for (int x = 0; x < n; x++) v[x] *= factor;
+    } else if (fallback) {
+        for (int x = 0; x < n; x++) v[x] = fallback[x];
     }
-    return sum;
+    return total;
 }
 
-inline unsigned char neffToChar(const float neff) {   // MathUtil::convertNeffToChar
-    float retVal = std::min(255.0f, 1.0f + 64.0f * flog2(neff));
-    return std::max(static_cast<unsigned char>(1), static_cast<unsigned char>(retVal + 0.5));
+inline unsigned char effectiveCountByte(const float neff) {   // MathUtil::convertNeffToChar
+    float scaled = std::min(255.0f, 1.0f + 64.0f * flog2(neff));
+    return std::max(static_cast<unsigned char>(1), static_cast<unsigned char>(scaled + 0.5));
 }
 
-// ScalarProd20 (M/lib/simd/simd.h:901-953): five 4-lane products, pairwise adds, two shuffle-add rounds
-inline float scalarProd20(const float *qi, const float *tj) {
-    float __attribute__((aligned(16))) res;
-    __m128 P, R;
-    const __m128 *Qi = (const __m128 *) qi;
-    const __m128 *Tj = (const __m128 *) tj;
-    __m128 P1 = _mm_mul_ps(*(Qi), *(Tj));
-    __m128 P2 = _mm_mul_ps(*(Qi + 1), *(Tj + 1));
-    __m128 R1 = _mm_add_ps(P1, P2);
-    __m128 P3 = _mm_mul_ps(*(Qi + 2), *(Tj + 2));
-    __m128 P4 = _mm_mul_ps(*(Qi + 3), *(Tj + 3));
-    __m128 R2 = _mm_add_ps(P3, P4);
-    __m128 P5 = _mm_mul_ps(*(Qi + 4), *(Tj + 4));
-    R = _mm_add_ps(R1, R2);
-    R = _mm_add_ps(R, P5);
-    P = _mm_shuffle_ps(R, R, _MM_SHUFFLE(2, 0, 2, 0));
-    R = _mm_shuffle_ps(R, R, _MM_SHUFFLE(3, 1, 3, 1));
-    R = _mm_add_ps(R, P);
-    P = _mm_shuffle_ps(R, R, _MM_SHUFFLE(2, 0, 2, 0));
-    R = _mm_shuffle_ps(R, R, _MM_SHUFFLE(3, 1, 3, 1));
-    R = _mm_add_ps(R, P);
-    _mm_store_ss(&res, R);
-    return res;
+// 20-term dot product in the summation order of the reference's SSE helper (M/lib/simd/simd.h:901-953): five 4-lane
+// products, pairwise adds, two shuffle-add rounds
+inline float dot20(const float *a, const float *b) {
+    float __attribute__((aligned(16))) out;
+    const __m128 *A = (const __m128 *) a;
+    const __m128 *B = (const __m128 *) b;
+    const __m128 s01 = _mm_add_ps(_mm_mul_ps(A[0], B[0]), _mm_mul_ps(A[1], B[1]));
+    const __m128 s23 = _mm_add_ps(_mm_mul_ps(A[2], B[2]), _mm_mul_ps(A[3], B[3]));
+    __m128 acc = _mm_add_ps(_mm_add_ps(s01, s23), _mm_mul_ps(A[4], B[4]));
+    for (int round = 0; round < 2; round++) {
+        const __m128 even = _mm_shuffle_ps(acc, acc, _MM_SHUFFLE(2, 0, 2, 0));
+        const __m128 odd = _mm_shuffle_ps(acc, acc, _MM_SHUFFLE(3, 1, 3, 1));
+        acc = _mm_add_ps(odd, even);
+    }
+    _mm_store_ss(&out, acc);
+    return out;
 }
 
-// one worker's scratch space
-struct Work {
-    // MSA rows: stride padded to 32-byte blocks with at least one block of GAP after the last column
-    std::vector<char> msa;
-    std::vector<const char *> rows, X;
+// ---- 1. the alignment -----------------------------------------------------------------------------------------------
+// Rows of `stride` cells, padded with gaps to whole comparison blocks plus one (reads of whole blocks never leave a row).
+struct Alignment {
+    std::vector<char> cells;
+    std::vector<char *> row;
     size_t stride = 0;
-    std::vector<unsigned> queryGaps;
-    // filter
-    std::vector<char> keep, in, inkk, display;
-    std::vector<char *> keepLocal;
-    std::vector<int> seqidPrev, first, last, nres, ksort, N, Nmax, idmaxwin;
-    // PSSM
-    std::vector<float> seqWeight, wi, matchWeight, pseudo, profile, neffM;
-    std::vector<char> pssm;
-    std::vector<unsigned char> consensus, masked;
-    std::vector<int> nseqs, naa;
-    std::vector<float> wContrib;   // [L][24]
-    std::vector<int> n;            // [L + 1][24]
-    std::vector<float> f;          // [L][23]
-    std::vector<float> pNull;
+    int columns = 0;
+
+    void reset(int L, size_t nRows, size_t columnsForStride) {
+        columns = L;
+        stride = (columnsForStride / kBlock + 2) * kBlock;
+        cells.assign(stride * nRows, (char) kGap);
+        row.resize(nRows);
+        for (size_t r = 0; r < nRows; r++) row[r] = cells.data() + r * stride;
+    }
 };
 
-// ---- MultipleAlignment::computeMSA with noDeletionMSA = true: every row has exactly centerL columns -----------------
-void buildMsa(Work &w, const uint8_t *center, int centerL, size_t nEdges, const uint8_t *const *edgeSeq, const int32_t *qStart,
-              const int32_t *tStart, const char *const *bt, const uint32_t *btLen) {
-    const size_t setSize = nEdges + 1;
-    w.stride = ((size_t) (centerL + 1) / BLK + 2) * BLK;   // MultipleAlignment::initX(centerSeq->L + 1, ...)
-    w.msa.assign(w.stride * setSize, (char) GAP);
-    w.rows.resize(setSize);
-    for (size_t k = 0; k < setSize; k++) w.rows[k] = w.msa.data() + k * w.stride;
-    // (computeQueryGaps only matters when deletions are kept; with noDeletionMSA the gap counts are never written out)
-    char *row0 = w.msa.data();
-    for (int p = 0; p < centerL; p++) row0[p] = (char) center[p];
-    for (size_t e = 0; e < nEdges; e++) {
-        char *row = w.msa.data() + (e + 1) * w.stride;
-        const uint8_t *seq = edgeSeq[e];
-        unsigned queryPos = (unsigned) qStart[e], targetPos = (unsigned) tStart[e];
-        size_t bufferPos = 0;
-        if (targetPos == 0xFFFFFFFFu) continue;   // row stays all gaps (MultipleAlignment.cpp:112-119)
-        for (int p = 0; p < qStart[e]; p++) row[bufferPos++] = (char) GAP;
-        const char *b = bt[e];
-        const size_t n = btLen[e];
-        for (size_t a = 0; a < n; a++) {
-            if (b[a] == 'I') {
-                row[bufferPos++] = (char) GAP;
-                queryPos++;
-            } else if (b[a] == 'D') {
-                while (a < n && b[a] == 'D') {   // target residues against a query gap are dropped
-                    targetPos++;
-                    a++;
-                }
-                if (a >= n) break;
-                if (b[a] == 'I') {
-                    row[bufferPos++] = (char) GAP;
-                    queryPos++;
-                } else if (b[a] == 'M') {
-                    row[bufferPos++] = (char) seq[targetPos];
-                    queryPos++;
-                    targetPos++;
-                }
-            } else if (b[a] == 'M') {
-                row[bufferPos++] = (char) seq[targetPos];
-                queryPos++;
-                targetPos++;
+struct Hit {                 // one alignment of the centre
+    const uint8_t *target;   // numeric residues of the target sequence
+    int32_t centreStart, targetStart;
+    const char *path;        // expanded backtrace: M, I (target gap), D (centre gap)
+    uint32_t pathLength;
+};
+
+// row of a hit: gaps up to the alignment start, then one cell per centre position the path covers
+void placeHit(char *cells, const Hit &h) {
+    if ((uint32_t) h.targetStart == 0xFFFFFFFFu) return;   // no coordinates: an all-gap row (MultipleAlignment.cpp:112-119)
+    size_t column = (size_t) std::max(h.centreStart, 0);   // cells before it are gaps already
+    uint32_t t = (uint32_t) h.targetStart;
+    for (uint32_t s = 0; s < h.pathLength; s++) {
+        const char step = h.path[s];
+        if (step == 'M') {
+            cells[column++] = (char) h.target[t++];
+        } else if (step == 'I') {
+            column++;   // a gap cell
+        } else if (step == 'D') {
+            // target residues opposite a centre gap leave no cell; the step that ends the run is consumed with it
+            while (s < h.pathLength && h.path[s] == 'D') {
+                t++;
+                s++;
             }
+            if (s >= h.pathLength) break;
+            if (h.path[s] == 'M') cells[column++] = (char) h.target[t++];
+            else if (h.path[s] == 'I') column++;
         }
-        // the rest of the row is GAP already
     }
-    // numeric residues: the reference maps letters back through aa2num; residues here are numeric from the start and X = 20
 }
 
-// ---- MsaFilter::filter (single qid bucket is the common case; the bucketed variant follows the same code) -----------
-size_t filterMsa(Work &w, const int8_t *subMatrix /* 21x21 of the -0.2 biased blosum62 */, int N_in_total, int L, int coverage,
-                 const std::vector<int> &qid_vec, float qsc, int max_seqid, int Ndiff, int filterMinEnable) {
-    const float PLTY_GAPOPEN = 6.0f, PLTY_GAPEXTD = 1.0f;
-    std::vector<const char *> &X_in = w.rows;
-    w.keep.assign(N_in_total, 0);
-    w.in.assign(N_in_total + 1, 0);
-    w.inkk.assign(N_in_total + 1, 0);
-    w.display.assign(N_in_total + 2, 0);
-    w.seqidPrev.assign(N_in_total + 1, 0);
-    w.first.assign(N_in_total, 0);
-    w.last.assign(N_in_total, 0);
-    w.nres.assign(N_in_total, 0);
-    w.ksort.assign(N_in_total, 0);
-    w.X.assign(N_in_total, nullptr);
-    w.keepLocal.assign(N_in_total, nullptr);
-    w.N.assign(L + 2, 0);
-    w.Nmax.assign(L + 2, 0);
-    w.idmaxwin.assign(L + 2, 0);
-    char *keep = w.keep.data(), *in = w.in.data(), *inkk = w.inkk.data();
-    int *first = w.first.data(), *last = w.last.data(), *nres = w.nres.data(), *ksort = w.ksort.data();
-    int *N = w.N.data(), *Nmax = w.Nmax.data(), *idmaxwin = w.idmaxwin.data(), *seqid_prev = w.seqidPrev.data();
-    const char **X = w.X.data();
-    char **keep_local = w.keepLocal.data();
-    int N_keep_total = 0;
-    for (size_t qid_idx = 0; qid_idx < qid_vec.size(); qid_idx++) {
-        int n = 0;
-        int N_in_bucket = 0;
-        int qid;
-        if (qid_vec.size() == 1) {
-            if (N_in_total < filterMinEnable) {
-                memset(keep, 1, N_in_total * sizeof(char));
-                keep[0] = 2;
-                N_keep_total = N_in_total - 1;
-                break;
+void buildAlignment(Alignment &A, const uint8_t *centre, int L, const std::vector<Hit> &hits) {
+    if (hits.empty()) A.reset(L, 1, (size_t) L);   // a centre without hits: MultipleAlignment::singleSequenceMSA
+    else A.reset(L, hits.size() + 1, (size_t) L + 1);
+    for (int p = 0; p < L; p++) A.row[0][p] = (char) centre[p];
+    for (size_t h = 0; h < hits.size(); h++) placeHit(A.row[h + 1], hits[h]);
+}
+
+// ---- 2. the diversity filter ----------------------------------------------------------------------------------------
+struct FilterSettings {
+    int coveragePercent;        // --cov: residues of a row, in percent of the centre length
+    std::vector<int> identityLadder;   // --qid in percent, ascending; one value: a minimum identity with the centre
+    float scorePerResidue;      // --qsc
+    int maxPairIdentity;        // --max-seq-id in percent
+    int diversity;              // --diff: rows wanted per 50-column window
+    int minRowsToFilter;        // --filter-min-enable
+};
+
+struct RowSpan {
+    int first, last;   // first / last column holding a residue (first = L, last = 0 for a row without residues)
+    int residues;      // residues in between
+};
+
+enum Mark : char { kDropped = 0, kCandidate = 1, kCentre = 2 };
+
+class DiversityFilter {
+public:
+    // marks the rows to keep, moves them to the front of A.row (order preserved) and returns their number
+    size_t run(Alignment &A, size_t nRows, const int8_t *scoreMatrix, const FilterSettings &s);
+
+private:
+    static constexpr int kWindow = 25;   // half width of the window the per-column row count is maximised over
+
+    const int8_t *scores = nullptr;
+    int L = 0;
+    std::vector<RowSpan> span;
+    std::vector<char> mark;          // per alignment row
+    // state of one selection (over the rows of one bucket)
+    std::vector<int> member;         // bucket position -> alignment row
+    std::vector<int> order;          // candidate order: centre first, then by descending residue count
+    std::vector<char> accepted;      // per bucket position, in `order`: 0 no, 1 accepted, 2 the centre
+    std::vector<int> lastTestedAt;   // per bucket position: the identity level the row was last compared at
+    std::vector<int> rowsAt, rowsNear, levelAt;   // per column: accepted rows covering it, their windowed maximum, identity level in force
+    int wanted = 0;                  // rows wanted per window; a bucket without a usable target resets it for the ones after it too
+
+    void measure(const Alignment &A, size_t nRows);
+    bool passesGates(const char *row, const RowSpan &r, const char *centre, const FilterSettings &s, float maxCentreDiffFraction) const;
+    bool tooSimilar(const char *a, const RowSpan &ra, const char *b, const RowSpan &rb, float minDiffFraction) const;
+    int select(const Alignment &A, const FilterSettings &s, int minCentreIdentity);
+};
+
+void DiversityFilter::measure(const Alignment &A, size_t nRows) {
+    span.resize(nRows);
+    for (size_t r = 0; r < nRows; r++) {
+        const char *c = A.row[r];
+        RowSpan &m = span[r];
+        m.first = 0;
+        while (m.first < L && c[m.first] >= kResidues) m.first++;
+        m.last = L - 1;
+        while (m.last > 0 && c[m.last] >= kResidues) m.last--;
+        m.residues = 0;
+        for (int i = m.first; i <= m.last; i++) m.residues += c[i] < kResidues;
+    }
+}
+
+// the three gates a row passes on its own: coverage of the centre, average substitution score against the centre, identity
+// with the centre
+bool DiversityFilter::passesGates(const char *row, const RowSpan &r, const char *centre, const FilterSettings &s,
+                                  float maxCentreDiffFraction) const {
+    if (100 * r.residues < s.coveragePercent * L) return false;
+    if (s.scorePerResidue > -10) {
+        const float gapOpen = 6.0f, gapExtend = 1.0f;
+        const float required = s.scorePerResidue * r.residues;
+        float total = 0.0;
+        int centreGapRun = 0, rowGapRun = 0;   // a run's first gap costs gapOpen, the following ones gapExtend
+        for (int i = r.first; i <= r.last; i++) {
+            const int a = centre[i], b = row[i];
+            if (b < kResidues) {
+                rowGapRun = 0;
+                if (a < kResidues) {
+                    centreGapRun = 0;
+                    total += static_cast<float>(scores[a * 21 + b]);
+                } else if (a != kAny) {
+                    total -= centreGapRun++ ? gapExtend : gapOpen;
+                }
+            } else if (b != kAny && a < kResidues) {
+                centreGapRun = 0;
+                total -= rowGapRun++ ? gapExtend : gapOpen;
             }
-            qid = qid_vec[0];
-            N_in_bucket = N_in_total;
-            for (int k = 0; k < N_in_total; k++) {
-                X[k] = X_in[k];
-                keep_local[k] = &keep[k];
+        }
+        if (total < required) return false;
+    }
+    if (maxCentreDiffFraction < 0.999) {
+        const int limit = int(maxCentreDiffFraction * r.residues + 0.9999);
+        int differing = 0;
+        for (int i = r.first; i <= r.last && differing < limit; i++) differing += row[i] < kResidues && row[i] != centre[i];
+        if (differing >= limit) return false;
+    }
+    return true;
+}
+
+// Are rows a (the candidate) and b (an accepted row) more alike than the identity level allows?  Differences are counted over
+// the overlap of their spans, block by block (the count stops at a block border once it is enough); cells where either row
+// has no residue are taken out of the compared length.
+bool DiversityFilter::tooSimilar(const char *a, const RowSpan &ra, const char *b, const RowSpan &rb, float minDiffFraction) const {
+    const int from = std::max(ra.first, rb.first), to = std::min(ra.last, rb.last);
+    int compared = to - from + 1;
+    const int enough = int(minDiffFraction * std::min(ra.residues, compared) + 0.999);
+    const int blockBegin = from / kBlock, blockEnd = to / kBlock + 1;
+    compared += std::abs(blockBegin * kBlock - from) + std::abs(blockEnd * kBlock - (to + 1));   // whole blocks are walked
+    int differing = 0;
+    for (int blk = blockBegin; blk < blockEnd && differing < enough; blk++) {
+        int unpaired = 0, unequal = 0;
+        for (int i = blk * kBlock; i < (blk + 1) * kBlock; i++) {
+            const bool noPair = a[i] >= kResidues || b[i] >= kResidues;
+            unpaired += noPair;
+            unequal += !noPair && a[i] != b[i];
+        }
+        compared -= unpaired;
+        differing += unequal;
+    }
+    return differing < enough && float(differing) <= minDiffFraction * compared && compared > 0;
+}
+
+// One selection over the rows in `member` (member[0] is the centre).  Returns the number of rows kept besides the centre.
+int DiversityFilter::select(const Alignment &A, const FilterSettings &s, int minCentreIdentity) {
+    const int n = (int) member.size();
+    const char *centre = A.row[member[0]];
+    const RowSpan &centreSpan = span[member[0]];
+    // candidates: everything but rows without residues; the centre is fixed (it is accepted from the start below, whatever
+    // its mark says -- a centre of X only has no residues either)
+    for (int p = 0; p < n; p++) mark[member[p]] = span[member[p]].residues == 0 ? kDropped : (p == 0 ? kCentre : kCandidate);
+    order.resize(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin() + 1, order.end(), [&](int x, int y) { return span[member[x]].residues > span[member[y]].residues; });
+    accepted.assign(n, 0);
+    accepted[0] = 2;   // order[0] is bucket position 0
+    lastTestedAt.assign(n, -1);
+    rowsAt.assign(L, 0);
+    for (int i = centreSpan.first; i <= centreSpan.last; i++) rowsAt[i] = 1;
+    rowsNear.assign(L, 0);
+    levelAt.assign(L, -1);
+    int startLevel = 20;
+    if (wanted <= 0 || wanted >= n) {   // no usable diversity target: a single pass at the maximal identity
+        startLevel = s.maxPairIdentity;
+        wanted = n;   // (stays for the buckets that follow, as in the reference, MsaFilter.cpp:223-227)
+    }
+    const float maxCentreDiffFraction = 0.9999 - 0.01 * minCentreIdentity;
+    int survivors = 0;
+    for (int p = 0; p < n; p++) {
+        const int r = member[p];
+        if (mark[r] == kCandidate && !passesGates(A.row[r], span[r], centre, s, maxCentreDiffFraction)) mark[r] = kDropped;
+        survivors += mark[r] != kDropped;
+    }
+    if (survivors == 0) mark[member[0]] = kCandidate;
+    // an empty ladder (--max-seq-id below 20 %): the gates were the whole filter.  The reference counts the centre twice on
+    // this way out (MsaFilter.cpp:353-355), so does the caller's row count
+    if (startLevel > s.maxPairIdentity) return survivors;
+    int kept = 1;   // the centre
+    int shortfall = wanted, shortfallBefore = 0, step = 0;
+    for (int level = startLevel; level <= s.maxPairIdentity; level += step) {
+        // where is the alignment still thinner than wanted?  Those columns take the current identity level.
+        bool thickEnough = true;
+        shortfallBefore = shortfall;
+        shortfall = 0;
+        for (int i = 0; i < L; i++) {
+            const int lo = std::max(0, std::min(L - 2 * kWindow + 1, i - kWindow)), hi = std::min(L, std::max(2 * kWindow, i + kWindow));
+            int most = 0;
+            for (int j = lo; j < hi; j++) most = std::max(most, rowsAt[j]);
+            rowsNear[i] = std::max(rowsNear[i], most);
+            if (rowsNear[i] < wanted) {
+                thickEnough = false;
+                levelAt[i] = level;
+                shortfall = std::max(shortfall, wanted - rowsNear[i]);
             }
+        }
+        if (thickEnough) break;
+        for (int o = 0; o < n; o++) {
+            if (accepted[o]) continue;
+            const int p = order[o], r = member[p];
+            if (mark[r] == kDropped) continue;
+            if (level >= 100) {   // identical rows allowed: everything left is taken
+                accepted[o] = 1;
+                kept++;
+                continue;
+            }
+            // the level that applies to this row: the highest in force on a column it covers
+            float rowLevel = startLevel;
+            for (int i = span[r].first; i <= span[r].last; i++)
+                if (levelAt[i] > rowLevel) rowLevel = levelAt[i];
+            if (lastTestedAt[p] == level) continue;
+            lastTestedAt[p] = level;
+            const float minDiffFraction = 0.9999 - 0.01 * rowLevel;
+            bool redundant = false;
+            for (int earlier = 0; earlier < o && !redundant; earlier++)
+                if (accepted[earlier])
+                    redundant = tooSimilar(A.row[r], span[r], A.row[member[order[earlier]]], span[member[order[earlier]]], minDiffFraction);
+            if (!redundant) {
+                accepted[o] = 1;
+                kept++;
+                for (int i = span[r].first; i <= span[r].last; i++) rowsAt[i]++;
+            }
+        }
+        // the next level: larger steps while the shortfall shrinks slowly
+        step = std::max(1, std::min(5, shortfall / (shortfallBefore - shortfall + 1) * step / 2));
+    }
+    for (int o = 0; o < n; o++) mark[member[order[o]]] = accepted[o];
+    return kept - 1;
+}
+
+size_t DiversityFilter::run(Alignment &A, size_t nRows, const int8_t *scoreMatrix, const FilterSettings &s) {
+    scores = scoreMatrix;
+    L = A.columns;
+    mark.assign(nRows, kDropped);
+    wanted = s.diversity;
+    measure(A, nRows);
+    size_t keptBesidesCentre = 0;
+    if (s.identityLadder.size() == 1) {
+        if ((int) nRows < s.minRowsToFilter) {
+            std::fill(mark.begin(), mark.end(), (char) kCandidate);
+            mark[0] = kCentre;
+            keptBesidesCentre = nRows - 1;
         } else {
-            if (qid_idx == qid_vec.size() - 1) break;
-            qid = 0;
-            X[0] = X_in[0];
-            keep_local[0] = &keep[0];
-            const char *query = X_in[0];
-            N_in_bucket++;
-            for (int k = 1; k < N_in_total; k++) {
-                int nr = 0, nid = 0;
-                for (int i = 0; i < L; ++i) {
-                    nr += (X_in[k][i] < NAA);
-                    nid += (X_in[k][i] == query[i] && X_in[k][i] < NAA);
-                }
-                int seqid = static_cast<int>(100.0f * (static_cast<float>(nid) / static_cast<float>(nr)));
-                if (seqid > qid_vec[qid_idx] && seqid <= qid_vec[qid_idx + 1]) {
-                    X[N_in_bucket] = X_in[k];
-                    keep_local[N_in_bucket] = &keep[k];
-                    N_in_bucket++;
-                }
-            }
-            if (N_in_bucket < filterMinEnable) {
-                for (int k = 1; k < N_in_bucket; k++) *keep_local[k] = 1;
-                *keep_local[0] = 2;
-                N_keep_total += N_in_bucket - 1;
-                continue;
-            }
+            member.resize(nRows);
+            std::iota(member.begin(), member.end(), 0);
+            keptBesidesCentre = (size_t) select(A, s, s.identityLadder[0]);
         }
-        int N_in = N_in_bucket;
-        int seqid1 = 20;
-        const int WFIL = 25;
-        int diffNmax = Ndiff, diffNmax_prev = 0;
-        int seqid, seqid_step = 0;
-        float diff_min_frac;
-        float qdiff_max_frac = 0.9999 - 0.01 * qid;
-        int diff = 0, diff_suff, qdiff_max, cov_kj, first_kj, last_kj;
-        int kk, jj, k, j, i;
-        int kfirst = 0;
-        for (k = 0; k < N_in; ++k) *keep_local[k] = (k == 0) ? 2 : 1;
-        for (n = k = 0; k < N_in; ++k) {
-            if (*keep_local[k] == 2) {
-                in[k] = 2;
-                n++;
+    } else {
+        // several --qid values: the rows are binned by their identity with the centre, (ladder[b], ladder[b + 1]], and every
+        // bin is thinned on its own (no centre-identity gate inside a bin)
+        const char *centre = A.row[0];
+        std::vector<int> identity(nRows, -1);
+        for (size_t r = 1; r < nRows; r++) {
+            int residues = 0, equal = 0;
+            for (int i = 0; i < L; i++) {
+                residues += A.row[r][i] < kResidues;
+                equal += A.row[r][i] == centre[i] && A.row[r][i] < kResidues;
+            }
+            identity[r] = static_cast<int>(100.0f * (static_cast<float>(equal) / static_cast<float>(residues)));
+        }
+        for (size_t b = 0; b + 1 < s.identityLadder.size(); b++) {
+            member.assign(1, 0);
+            for (size_t r = 1; r < nRows; r++)
+                if (identity[r] > s.identityLadder[b] && identity[r] <= s.identityLadder[b + 1]) member.push_back((int) r);
+            if ((int) member.size() < s.minRowsToFilter) {
+                for (size_t p = 1; p < member.size(); p++) mark[member[p]] = kCandidate;
+                mark[0] = kCentre;
+                keptBesidesCentre += member.size() - 1;
             } else {
-                in[k] = 0;
+                keptBesidesCentre += (size_t) select(A, s, 0);
             }
-        }
-        for (k = 0; k < N_in; ++k) {
-            for (i = 0; i < L; ++i)
-                if (X[k][i] < NAA) break;
-            first[k] = i;
-            for (i = (L - 1); i > 0; i--)
-                if (X[k][i] < NAA) break;
-            last[k] = i;
-        }
-        for (k = 0; k < N_in; ++k) {
-            int nr = 0;
-            for (i = first[k]; i <= last[k]; ++i)
-                if (X[k][i] < NAA) nr++;
-            nres[k] = nr;
-            if (nr == 0) *keep_local[k] = 0;
-        }
-        {
-            std::vector<std::pair<int, int> > tmpSort(N_in);
-            for (k = 0; k < N_in; ++k) {
-                tmpSort[k].first = nres[k];
-                tmpSort[k].second = k;
-            }
-            std::stable_sort(tmpSort.begin() + 1, tmpSort.end(),
-                             [](const std::pair<int, int> &l, const std::pair<int, int> &r) { return l.first > r.first; });
-            for (k = 0; k < N_in; ++k) ksort[k] = tmpSort[k].second;
-        }
-        for (kk = 0; kk < N_in; ++kk) inkk[kk] = in[ksort[kk]];
-        for (i = 0; i < first[kfirst]; ++i) N[i] = 0;
-        for (i = first[kfirst]; i <= last[kfirst]; ++i) N[i] = 1;
-        for (i = last[kfirst] + 1; i < L; ++i) N[i] = 0;
-        for (i = 0; i < L; ++i) {
-            Nmax[i] = 0;
-            idmaxwin[i] = -1;
-        }
-        for (k = 0; k < N_in; ++k) seqid_prev[k] = -1;
-        if (Ndiff <= 0 || Ndiff >= N_in) {
-            seqid1 = max_seqid;
-            Ndiff = N_in;
-            diffNmax = Ndiff;
-        }
-        for (k = 0; k < N_in; ++k) {
-            if (*keep_local[k] == 0 || *keep_local[k] == 2) continue;
-            if (100 * nres[k] < coverage * L) {
-                *keep_local[k] = 0;
-                continue;
-            }
-            float qsc_sum = 0.0;
-            if (qsc > -10) {
-                float qsc_min = qsc * nres[k];
-                int gapq = 0, gapk = 0;
-                for (int i2 = first[k]; i2 <= last[k]; ++i2) {
-                    if (X[k][i2] < 20) {
-                        gapk = 0;
-                        if (X[kfirst][i2] < 20) {
-                            gapq = 0;
-                            qsc_sum += static_cast<float>(subMatrix[(int) X[kfirst][i2] * 21 + (int) X[k][i2]]);
-                        } else if (X[kfirst][i2] == ANY)
-                            continue;
-                        else if (gapq++)
-                            qsc_sum -= PLTY_GAPEXTD;
-                        else
-                            qsc_sum -= PLTY_GAPOPEN;
-                    } else if (X[k][i2] == ANY)
-                        continue;
-                    else if (X[kfirst][i2] < 20) {
-                        gapq = 0;
-                        if (gapk++) qsc_sum -= PLTY_GAPEXTD;
-                        else qsc_sum -= PLTY_GAPOPEN;
-                    }
-                }
-                if (qsc_sum < qsc_min) {
-                    *keep_local[k] = 0;
-                    continue;
-                }
-            }
-            if (qdiff_max_frac < 0.999) {
-                qdiff_max = int(qdiff_max_frac * nres[k] + 0.9999);
-                diff = 0;
-                for (int i2 = first[k]; i2 <= last[k]; ++i2)
-                    if (X[k][i2] < NAA && X[k][i2] != X[kfirst][i2] && ++diff >= qdiff_max) break;
-                if (diff >= qdiff_max) {
-                    *keep_local[k] = 0;
-                    continue;
-                }
-            }
-        }
-        int nn = 0;
-        for (k = 0; k < N_in; ++k)
-            if (*keep_local[k] > 0) nn++;
-        if (nn == 0) {   // unreachable while the query row is marked 2; kept for the reference's control flow
-            for (k = 0; k < N_in; k++) {
-                if (w.display[k] != 2) {
-                    *keep_local[k] = 1;
-                    break;
-                }
-            }
-        }
-        if (seqid1 > max_seqid) {
-            N_keep_total += nn;
-            continue;
-        }
-        seqid = seqid1;
-        while (seqid <= max_seqid) {
-            bool stop = true;
-            diffNmax_prev = diffNmax;
-            diffNmax = 0;
-            for (i = 0; i < L; ++i) {
-                int max = 0;
-                for (j = std::max(0, std::min(L - 2 * WFIL + 1, i - WFIL)); j < std::min(L, std::max(2 * WFIL, i + WFIL)); ++j)
-                    if (N[j] > max) max = N[j];
-                if (Nmax[i] < max) Nmax[i] = max;
-                if (Nmax[i] < Ndiff) {
-                    stop = false;
-                    idmaxwin[i] = seqid;
-                    if (diffNmax < Ndiff - Nmax[i]) diffNmax = Ndiff - Nmax[i];
-                }
-            }
-            if (stop) break;
-            for (kk = 0; kk < N_in; ++kk) {
-                if (inkk[kk]) continue;
-                k = ksort[kk];
-                if (!(*keep_local[k])) continue;
-                if (*keep_local[k] == 2) {
-                    inkk[kk] = 2;
-                    continue;
-                }
-                if (seqid >= 100) {
-                    in[k] = inkk[kk] = 1;
-                    n++;
-                    continue;
-                }
-                float seqidk = seqid1;
-                for (i = first[k]; i <= last[k]; ++i)
-                    if (idmaxwin[i] > seqidk) seqidk = idmaxwin[i];
-                if (seqid == seqid_prev[k]) continue;
-                seqid_prev[k] = seqid;
-                diff_min_frac = 0.9999 - 0.01 * seqidk;
-                for (jj = 0; jj < kk; ++jj) {
-                    if (!inkk[jj]) continue;
-                    j = ksort[jj];
-                    first_kj = std::max(first[k], first[j]);
-                    last_kj = std::min(last[k], last[j]);
-                    cov_kj = last_kj - first_kj + 1;
-                    diff_suff = int(diff_min_frac * std::min(nres[k], cov_kj) + 0.999);
-                    diff = 0;
-                    // the reference walks 32-byte blocks (AVX2): whole blocks count, the loop leaves at block borders
-                    const int first_blk = first_kj / BLK;
-                    const int last_blk = last_kj / BLK + 1;
-                    const int first_diff = std::abs(first_blk * BLK - first_kj);
-                    const int last_diff = std::abs(last_blk * BLK - (last_kj + 1));
-                    cov_kj += (first_diff + last_diff);
-                    const char *xk = X[k], *xj = X[j];
-                    for (int b = first_blk; b < last_blk && diff < diff_suff; ++b) {
-                        int noAa = 0, differ = 0;
-                        for (int u = b * BLK; u < (b + 1) * BLK; u++) {
-                            const bool gapOr = (xk[u] > (NAA - 1)) || (xj[u] > (NAA - 1));
-                            noAa += gapOr;
-                            differ += !(gapOr || xk[u] == xj[u]);
-                        }
-                        cov_kj -= noAa;
-                        diff += differ;
-                    }
-                    if (diff < diff_suff && float(diff) <= diff_min_frac * cov_kj && cov_kj > 0) break;
-                }
-                if (jj >= kk) {
-                    in[k] = inkk[kk] = 1;
-                    n++;
-                    for (i = first[k]; i <= last[k]; ++i) N[i]++;
-                }
-            }
-            seqid_step = std::max(1, std::min(5, diffNmax / (diffNmax_prev - diffNmax + 1) * seqid_step / 2));
-            seqid += seqid_step;
-        }
-        for (k = 0; k < N_in; ++k) *keep_local[k] = in[k];
-        N_keep_total += n - 1;
-    }
-    // shuffleSequences: kept rows move to the front, order preserved
-    for (int i = 0, j = 0; j < N_in_total; j++) {
-        if (keep[j] != 0) {
-            if (i < j) std::swap(X_in[i], X_in[j]);
-            i++;
         }
     }
-    return (size_t) N_keep_total + 1;
+    // kept rows to the front, in their order
+    size_t front = 0;
+    for (size_t r = 0; r < nRows; r++) {
+        if (mark[r] == kDropped) continue;
+        if (front < r) std::swap(A.row[front], A.row[r]);
+        front++;
+    }
+    return keptBesidesCentre + 1;
 }
 
-// ---- PSSMCalculator ---------------------------------------------------------------------------------------------------
-void sequenceWeights(float *seqWeight, size_t L, size_t setSize, const char *const *msa) {
-    std::vector<unsigned> number_res(setSize);
-    std::fill(seqWeight, seqWeight + setSize, 1e-6);
-    for (size_t k = 0; k < setSize; ++k) {
-        unsigned nr = 0;
-        for (size_t pos = 0; pos < L; pos++)
-            if (msa[k][pos] != GAP) nr++;
-        number_res[k] = nr;
+// ---- 3. weights, effective sequence numbers, pseudo counts, scores ---------------------------------------------------
+struct ProfileScratch {
+    std::vector<float> globalWeight, localWeight;   // per row
+    std::vector<float> frequency;                    // [L + 2][20]: weighted residue frequencies per column
+    std::vector<float> pseudo, mixed;                // [L + 1][20]
+    std::vector<float> effective;                    // per column: number of effective sequences
+    std::vector<char> score;                         // [L + 1][20]
+    std::vector<unsigned char> consensus, masked;
+    std::vector<int> counts;                         // [L + 1][24]: rows of the current sub-alignment per column and cell code
+    std::vector<float> share;                        // [L + 1][24]: 1 / (distinct residues x rows with that residue)
+    std::vector<float> subFrequency;                 // [L + 1][23]
+    std::vector<int> distinct;
+    std::vector<float> nullScore;
+};
+
+// Position-based sequence weights over the whole alignment (Henikoff & Henikoff) with a length prior: a residue shared by c
+// of the rows in a column of d distinct residues gives each of them 1 / (c * d * (row residues + 30)).
+void globalWeights(float *weight, int L, size_t nRows, const char *const *row) {
+    std::vector<unsigned> rowCells(nRows);
+    std::fill(weight, weight + nRows, 1e-6);
+    for (size_t r = 0; r < nRows; r++) {
+        unsigned cells = 0;
+        for (int i = 0; i < L; i++) cells += row[r][i] != kGap;
+        rowCells[r] = cells;
     }
-    for (size_t pos = 0; pos < L; pos++) {
-        int nl[AA];
-        std::fill(nl, nl + AA, 0);
-        for (size_t k = 0; k < setSize; ++k) {
-            if (msa[k][pos] != GAP) {
-                const unsigned aa_pos = (unsigned char) msa[k][pos];
-                if (aa_pos < AA) nl[aa_pos]++;
-            }
+    for (int i = 0; i < L; i++) {
+        int seen[kResidues] = {0};
+        for (size_t r = 0; r < nRows; r++) {
+            const unsigned c = (unsigned char) row[r][i];
+            if (c < (unsigned) kResidues) seen[c]++;
         }
         int distinct = 0;
-        for (size_t aa = 0; aa < AA; ++aa)
-            if (nl[aa]) ++distinct;
-        for (size_t k = 0; k < setSize; ++k) {
-            if (msa[k][pos] != GAP && distinct != 0) {
-                const unsigned aa_pos = (unsigned char) msa[k][pos];
-                if (aa_pos < AA) seqWeight[k] += 1.0f / (float(nl[aa_pos]) * float(distinct) * (float(number_res[k]) + 30.0f));
-            }
+        for (int a = 0; a < kResidues; a++) distinct += seen[a] != 0;
+        if (distinct == 0) continue;
+        for (size_t r = 0; r < nRows; r++) {
+            const unsigned c = (unsigned char) row[r][i];
+            if (c < (unsigned) kResidues) weight[r] += 1.0f / (float(seen[c]) * float(distinct) * (float(rowCells[r]) + 30.0f));
         }
     }
 }
 
-void contextSpecificWeights(Work &w, const sd::SubMat &m, float *matchWeight, const float *wg, float *Neff_M, size_t L, size_t setSize,
-                            char *const *X) {
-    const float MAXENDGAPFRAC = 0.1;
-    const int NCOLMIN = 20;
-    constexpr int NW = 24;   // (NAA + 3) rounded up to a multiple of 8 floats
-    int nseqi = 0;
-    w.n.assign((L + 1) * NW, 0);
-    w.wContrib.assign((L + 1) * NW, 0.0f);
-    w.f.assign((L + 1) * (NAA + 3), 0.0f);
-    w.naa.assign(L + 1, 0);
-    w.nseqs.assign(L + 1, 0);
-    float *wi = w.wi.data();
-    int *n = w.n.data();
-    float *wc = w.wContrib.data();
-    float *f = w.f.data();
-    for (size_t k = 0; k < setSize; ++k) {
-        for (size_t i = 0; i < L && X[k][i] == GAP; ++i) X[k][i] = ENDGAP;
-        for (int i = (int) L - 1; i >= 0 && X[k][i] == GAP; i--) X[k][i] = ENDGAP;
+// Weights per column from the sub-alignment of the rows that have a residue there (HH-suite's position-specific weighting):
+// the rows taking part change only where some row starts or ends a residue run, and only then is anything recomputed.  Over
+// the columns jmin..jmax where at most a tenth of those rows have an end gap, a row's weight is the sum of the shares of its
+// cells; the frequencies under those weights give the column's number of effective sequences (2^average entropy).
+void columnWeights(ProfileScratch &w, const double *background, float *frequency, const float *globalWeight, float *effective, int L,
+                   size_t nRows, char *const *row) {
+    constexpr int kCodes = 24;    // cell codes 0..22 padded to eight-float groups
+    constexpr int kFreq = 23;
+    const float maxEndGapFraction = 0.1;
+    const int minColumns = 20;
+    w.counts.assign((size_t) (L + 1) * kCodes, 0);
+    w.share.assign((size_t) (L + 1) * kCodes, 0.0f);
+    w.subFrequency.assign((size_t) (L + 1) * kFreq, 0.0f);
+    w.distinct.assign(L + 1, 0);
+    int *count = w.counts.data();
+    float *share = w.share.data();
+    float *sub = w.subFrequency.data();
+    float *local = w.localWeight.data();
+    // gaps outside a row's first / last residue become end gaps for the duration
+    for (size_t r = 0; r < nRows; r++) {
+        for (int i = 0; i < L && row[r][i] == kGap; i++) row[r][i] = kEndGap;
+        for (int i = L - 1; i >= 0 && row[r][i] == kGap; i--) row[r][i] = kEndGap;
     }
-    for (size_t i = 0; i < L; i++) {
-        bool change = false;
-        for (size_t k = 0; k < setSize; ++k) {
-            if ((i == 0 && X[k][i] < ANY) || (i != 0 && X[k][i - 1] >= ANY && X[k][i] < ANY)) {
-                change = true;
-                nseqi++;
-                for (size_t j = 0; j < L; ++j) n[j * NW + (int) X[k][j]]++;
-            } else if (i != 0 && X[k][i - 1] < ANY && X[k][i] >= ANY) {
-                change = true;
-                nseqi--;
-                for (size_t j = 0; j < L; ++j) n[j * NW + (int) X[k][j]]--;
+    int participating = 0;
+    for (int i = 0; i < L; i++) {
+        bool changed = false;
+        for (size_t r = 0; r < nRows; r++) {
+            const bool here = row[r][i] < kAny, before = i != 0 && row[r][i - 1] < kAny;
+            if (here && !before) {
+                changed = true;
+                participating++;
+                for (int j = 0; j < L; j++) count[j * kCodes + (int) row[r][j]]++;
+            } else if (i != 0 && before && !here) {
+                changed = true;
+                participating--;
+                for (int j = 0; j < L; j++) count[j * kCodes + (int) row[r][j]]--;
             }
         }
-        w.nseqs[i] = nseqi;
-        if (change) {
-            int ncol = 0;
-            for (size_t k = 0; k < setSize; ++k) wi[k] = 1E-8;
-            int jmin, jmax;
-            for (jmin = 0; jmin < static_cast<int>(L) && n[jmin * NW + ENDGAP] > MAXENDGAPFRAC * nseqi; ++jmin) {
-            }
-            for (jmax = (int) L - 1; jmax >= 0 && n[jmax * NW + ENDGAP] > MAXENDGAPFRAC * nseqi; --jmax) {
-            }
-            ncol = jmax - jmin + 1;
-            if (ncol < NCOLMIN) {
-                for (size_t k = 0; k < setSize; ++k) wi[k] = (X[k][i] < ANY) ? wg[k] : 0.0f;
+        if (changed) {
+            for (size_t r = 0; r < nRows; r++) local[r] = 1E-8;
+            int jmin = 0, jmax = L - 1;
+            while (jmin < L && count[jmin * kCodes + kEndGap] > maxEndGapFraction * participating) jmin++;
+            while (jmax >= 0 && count[jmax * kCodes + kEndGap] > maxEndGapFraction * participating) jmax--;
+            const int width = jmax - jmin + 1;
+            if (width < minColumns) {
+                for (size_t r = 0; r < nRows; r++) local[r] = (row[r][i] < kAny) ? globalWeight[r] : 0.0f;
             } else {
-                for (int j = jmin; j <= jmax; ++j) {
-                    w.naa[j] = 0;
-                    for (int a = 0; a < ANY; ++a) w.naa[j] += (n[j * NW + a] ? 1 : 0);
+                for (int j = jmin; j <= jmax; j++) {
+                    int d = 0;
+                    for (int a = 0; a < kAny; a++) d += count[j * kCodes + a] != 0;
+                    w.distinct[j] = d;
                 }
-                for (int j = jmin; j <= jmax; ++j) {
-                    // w_contrib[j][a] = 1 / (naa[j] * n[j][a]) through rcpps and one Newton-Raphson step
-                    // (PSSMCalculator.cpp:494-505): rcp + rcp - x * (rcp * rcp), eight amino acids at a time
-                    const __m256 naa_j = _mm256_cvtepi32_ps(_mm256_set1_epi32(w.naa[j]));
-                    const int aa_size = (ANY + 8 - 1) / 8;
-                    for (int a = 0; a < aa_size; ++a) {
-                        const __m256 nja = _mm256_cvtepi32_ps(_mm256_loadu_si256((const __m256i *) (n + j * NW + a * 8)));
-                        const __m256 res = _mm256_mul_ps(nja, naa_j);
-                        const __m256 rcp = _mm256_rcp_ps(res);
-                        const __m256 mul = _mm256_mul_ps(res, _mm256_mul_ps(rcp, rcp));
-                        _mm256_storeu_ps(wc + j * NW + a * 8, _mm256_sub_ps(_mm256_add_ps(rcp, rcp), mul));
+                for (int j = jmin; j <= jmax; j++) {
+                    // share[j][a] = 1 / (distinct[j] * count[j][a]) as an approximate reciprocal refined once,
+                    // y' = 2y - x y^2 (PSSMCalculator.cpp:494-505), eight residues at a time
+                    const __m256 d = _mm256_cvtepi32_ps(_mm256_set1_epi32(w.distinct[j]));
+                    for (int g = 0; g < (kAny + 7) / 8; g++) {
+                        const __m256 x = _mm256_mul_ps(_mm256_cvtepi32_ps(_mm256_loadu_si256((const __m256i *) (count + j * kCodes + g * 8))), d);
+                        const __m256 y = _mm256_rcp_ps(x);
+                        _mm256_storeu_ps(share + j * kCodes + g * 8, _mm256_sub_ps(_mm256_add_ps(y, y), _mm256_mul_ps(x, _mm256_mul_ps(y, y))));
                     }
-                    for (int a = ANY; a < NAA + 3; ++a) wc[j * NW + a] = 0.0f;
+                    for (int a = kAny; a < kFreq; a++) share[j * kCodes + a] = 0.0f;
                 }
-                for (size_t k = 0; k < setSize; ++k) {
-                    if (X[k][i] >= ANY) continue;
-                    for (int j = jmin; j <= jmax; ++j) wi[k] += wc[j * NW + (int) X[k][j]];
+                for (size_t r = 0; r < nRows; r++) {
+                    if (row[r][i] >= kAny) continue;
+                    for (int j = jmin; j <= jmax; j++) local[r] += share[j * kCodes + (int) row[r][j]];
                 }
             }
-            Neff_M[i] = 0.0;
-            for (int j = jmin; j <= jmax; ++j) memset(f + j * (NAA + 3), 0, ANY * sizeof(float));
-            for (size_t k = 0; k < setSize; ++k) {
-                if (X[k][i] >= ANY) continue;
-                for (int j = jmin; j <= jmax; ++j) f[j * (NAA + 3) + (int) X[k][j]] += wi[k];
+            // effective sequences of the sub-alignment
+            effective[i] = 0.0;
+            for (int j = jmin; j <= jmax; j++) memset(sub + j * kFreq, 0, kAny * sizeof(float));
+            for (size_t r = 0; r < nRows; r++) {
+                if (row[r][i] >= kAny) continue;
+                for (int j = jmin; j <= jmax; j++) sub[j * kFreq + (int) row[r][j]] += local[r];
             }
-            for (int j = jmin; j <= jmax; ++j) {
-                normalizeTo1(f + j * (NAA + 3), NAA);
-                for (int a = 0; a < 20; ++a)
-                    if (f[j * (NAA + 3) + a] > 1E-10) Neff_M[i] -= f[j * (NAA + 3) + a] * flog2(f[j * (NAA + 3) + a]);
+            for (int j = jmin; j <= jmax; j++) {
+                scaleToOne(sub + j * kFreq, kResidues);
+                for (int a = 0; a < kResidues; a++)
+                    if (sub[j * kFreq + a] > 1E-10) effective[i] -= sub[j * kFreq + a] * flog2(sub[j * kFreq + a]);
             }
-            if (ncol > 0) Neff_M[i] = fpow2(Neff_M[i] / ncol);
-            else Neff_M[i] = 1.0;
+            if (width > 0) effective[i] = fpow2(effective[i] / width);
+            else effective[i] = 1.0;
         } else {
-            if (i == 0) Neff_M[i] = 0.0f;
-            else Neff_M[i] = Neff_M[i - 1];
+            effective[i] = i == 0 ? 0.0f : effective[i - 1];
         }
-        for (int a = 0; a < 20; ++a) matchWeight[i * AA + a] = 0.0;
-        // (X[k][i] can be 20..22 here: the reference adds those weights to the slots after the 20 amino acids of this
-        // position, i.e. to the first slots of the next position, which the next iteration zeroes again)
-        for (size_t k = 0; k < setSize; ++k) matchWeight[i * AA + (int) X[k][i]] += wi[k];
-        normalizeTo1(matchWeight + i * AA, NAA, m.pBack);
+        // the column's residue frequencies under the current weights.  Cells 20..22 add their weight to the slots behind the
+        // twenty of this column -- the first of the next column, which are cleared when that column's turn comes (the
+        // reference does the same; `frequency` has a spare column)
+        for (int a = 0; a < kResidues; a++) frequency[i * kResidues + a] = 0.0;
+        for (size_t r = 0; r < nRows; r++) frequency[i * kResidues + (int) row[r][i]] += local[r];
+        scaleToOne(frequency + i * kResidues, kResidues, background);
     }
-    for (size_t k = 0; k < setSize; ++k) {
-        for (size_t i = 0; i < L && X[k][i] == ENDGAP; ++i) X[k][i] = GAP;
-        for (int i = (int) L - 1; i >= 0 && X[k][i] == ENDGAP; i--) X[k][i] = GAP;
+    for (size_t r = 0; r < nRows; r++) {
+        for (int i = 0; i < L && row[r][i] == kEndGap; i++) row[r][i] = kGap;
+        for (int i = L - 1; i >= 0 && row[r][i] == kEndGap; i--) row[r][i] = kGap;
     }
 }
 
-void matchWeights(const sd::SubMat &m, float *matchWeight, const float *seqWeight, size_t setSize, size_t L, const char *const *msa) {
-    for (size_t pos = 0; pos < L; pos++) {
-        memset(matchWeight + pos * AA, 0, AA * sizeof(float));
-        for (size_t k = 0; k < setSize; ++k) {
-            if (msa[k][pos] != GAP) {
-                const unsigned aa_pos = (unsigned char) msa[k][pos];
-                if (aa_pos < AA) matchWeight[pos * AA + aa_pos] += seqWeight[k];
-            }
+// --wg: one weight per row everywhere
+void globalFrequencies(const double *background, float *frequency, const float *weight, size_t nRows, int L, const char *const *row) {
+    for (int i = 0; i < L; i++) {
+        float *f = frequency + (size_t) i * kResidues;
+        memset(f, 0, kResidues * sizeof(float));
+        for (size_t r = 0; r < nRows; r++) {
+            const unsigned c = (unsigned char) row[r][i];
+            if (c < (unsigned) kResidues) f[c] += weight[r];
         }
-        normalizeTo1(&matchWeight[pos * AA], AA, m.pBack);
+        scaleToOne(f, kResidues, background);
     }
 }
 
-void neffM(const float *frequency, const float *seqWeight, float *Neff_M, size_t L, size_t setSize, const char *const *msa) {
-    float Neff_HMM = 0.0f;
-    for (size_t pos = 0; pos < L; pos++) {
-        float sum = 0.0f;
-        for (size_t aa = 0; aa < AA; ++aa) {
-            float freq_pos_aa = frequency[pos * AA + aa];
-            if (freq_pos_aa > 1E-10) sum -= freq_pos_aa * flog2(freq_pos_aa);
+// --wg: effective sequences per column from the profile's average entropy, scaled by the weight present in the column
+void globalEffective(const float *frequency, const float *weight, float *effective, int L, size_t nRows, const char *const *row) {
+    float average = 0.0f;
+    for (int i = 0; i < L; i++) {
+        float entropy = 0.0f;
+        for (int a = 0; a < kResidues; a++) {
+            const float f = frequency[(size_t) i * kResidues + a];
+            if (f > 1E-10) entropy -= f * flog2(f);
         }
-        Neff_HMM += fpow2(sum);
+        average += fpow2(entropy);
     }
-    Neff_HMM /= L;
-    float Nlim = fmax(10.0, Neff_HMM + 1.0);
-    float scale = flog2((Nlim - Neff_HMM) / (Nlim - 1.0));
-    for (size_t pos = 0; pos < L; pos++) {
-        float w_M = -1.0 / setSize;
-        for (size_t k = 0; k < setSize; ++k)
-            if (msa[k][pos] != GAP) w_M += seqWeight[k];
-        Neff_M[pos] = (w_M < 0) ? 1.0 : Nlim - (Nlim - 1.0) * fpow2(scale * w_M);
+    average /= L;
+    float ceiling = fmax(10.0, average + 1.0);
+    float scale = flog2((ceiling - average) / (ceiling - 1.0));
+    for (int i = 0; i < L; i++) {
+        float present = -1.0 / nRows;
+        for (size_t r = 0; r < nRows; r++)
+            if (row[r][i] != kGap) present += weight[r];
+        effective[i] = (present < 0) ? 1.0 : ceiling - (ceiling - 1.0) * fpow2(scale * present);
     }
 }
 
 }  // namespace
 
 struct sd_r2p {
-    sd::SubMat m;             // blosum62 at bit factor 2, score bias -0.2 (result2profile.cpp:126)
-    float *R[21];             // subMatrixPseudoCounts[a][b] = P(a|b) (BaseMatrix.cpp:110-123), rows 16-byte aligned
-    std::vector<float> Rbacking;
-    int8_t sub[21 * 21];
+    sd::SubMat matrix;                // blosum62 at bit factor 2, score bias -0.2 (result2profile.cpp:126)
+    float *conditional[21];           // P(a|b) of the matrix (BaseMatrix.cpp:110-123), rows 16-byte aligned
+    std::vector<float> conditionalStore;
+    int8_t scores[21 * 21];
     sd::MaskCtx mask;
 };
 
@@ -618,25 +599,25 @@ extern "C" {
 int sd_r2p_create(sd_r2p **out) {
     if (!out) return SD_EINVAL;
     sd_r2p *r = new sd_r2p();
-    sd::initSubMat(r->m, sd::MAT_BLOSUM62, 2.0f, -0.2f);
-    r->Rbacking.assign(21 * 24 + 8, 0.0f);
-    float *base = r->Rbacking.data();
+    sd::initSubMat(r->matrix, sd::MAT_BLOSUM62, 2.0f, -0.2f);
+    r->conditionalStore.assign(21 * 24 + 8, 0.0f);
+    float *base = r->conditionalStore.data();
     while (((uintptr_t) base) % 32) base++;
-    // P(a|b) is taken against the background generateSubMatrix derives from the joint matrix itself (row sums, X fixed at
-    // ANY_BACK = 1e-5; BaseMatrix.cpp:97-123), not against the member pBack the log-odds use
-    double rowBack[21];
-    for (int i = 0; i < 21; i++) {
-        rowBack[i] = 0;
-        for (int j = 0; j < 21; j++) rowBack[i] += r->m.probMatrix[i][j];
+    // P(a|b) against the background the joint matrix itself implies (row sums, X fixed at 1e-5; BaseMatrix.cpp:97-123), not
+    // against the member background the log-odds use
+    double implied[21];
+    for (int a = 0; a < 21; a++) {
+        implied[a] = 0;
+        for (int b = 0; b < 21; b++) implied[a] += r->matrix.probMatrix[a][b];
     }
-    rowBack[20] = 1E-5;
-    for (int i = 0; i < 21; i++) {
-        r->R[i] = base + i * 24;
-        for (int j = 0; j < 21; j++) r->R[i][j] = r->m.probMatrix[i][j] / (rowBack[j]);
+    implied[20] = 1E-5;
+    for (int a = 0; a < 21; a++) {
+        r->conditional[a] = base + a * 24;
+        for (int b = 0; b < 21; b++) r->conditional[a][b] = r->matrix.probMatrix[a][b] / (implied[b]);
     }
-    for (int i = 0; i < 21; i++)
-        for (int j = 0; j < 21; j++) r->sub[i * 21 + j] = (int8_t) r->m.sub[i][j];
-    sd::initMaskCtx(r->m, r->mask);
+    for (int a = 0; a < 21; a++)
+        for (int b = 0; b < 21; b++) r->scores[a * 21 + b] = (int8_t) r->matrix.sub[a][b];
+    sd::initMaskCtx(r->matrix, r->mask);
     *out = r;
     return SD_OK;
 }
@@ -649,158 +630,149 @@ int sd_r2p_batch(sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t
                  uint8_t *outConsensus) {
     if (!r || !par || !qLetters || !qOff || !edgeOff || !outProfiles) return SD_EINVAL;
     if (par->pcMode != 0) return SD_EUNSUPPORTED;   // context specific pseudo counts need the K4000 library
-    std::vector<int> qid_vec;
-    {
+    FilterSettings fs;
+    {   // --qid: comma separated fractions -> ascending percentages
         const char *s = par->qid ? par->qid : "0.0";
         while (*s) {
-            char *e;
-            const float v = (float) strtod(s, &e);
-            qid_vec.push_back(static_cast<int>(v * 100));
-            s = (*e == ',') ? e + 1 : e;
-            if (e == s && *e) break;
+            char *end;
+            const float v = (float) strtod(s, &end);
+            if (end == s) break;
+            fs.identityLadder.push_back(static_cast<int>(v * 100));
+            s = (*end == ',') ? end + 1 : end;
         }
-        if (qid_vec.empty()) qid_vec.push_back(0);
-        std::sort(qid_vec.begin(), qid_vec.end());
+        if (fs.identityLadder.empty()) fs.identityLadder.push_back(0);
+        std::sort(fs.identityLadder.begin(), fs.identityLadder.end());
     }
-    int status = SD_OK;
+    fs.coveragePercent = (int) (par->covMSAThr * 100);
+    fs.scorePerResidue = par->qsc;
+    fs.maxPairIdentity = (int) (par->filterMaxSeqId * 100);
+    fs.diversity = par->Ndiff;
+    fs.minRowsToFilter = par->filterMinEnable;
+    const double *background = r->matrix.pBack;
 #pragma omp parallel
     {
-        Work w;
-        std::vector<const uint8_t *> edgeSeq;
-        std::vector<const char *> bt;
-        std::vector<uint32_t> btLen;
+        Alignment A;
+        DiversityFilter filter;
+        ProfileScratch w;
+        std::vector<Hit> hits;
 #pragma omp for schedule(dynamic, 8)
         for (uint32_t q = 0; q < nQ; q++) {
-            const uint8_t *center = qLetters + qOff[q];
+            const uint8_t *centre = qLetters + qOff[q];
             const int L = (int) (qOff[q + 1] - qOff[q]);
-            char *out = outProfiles + qOff[q] * 25;
             if (L == 0) continue;
-            const uint64_t e0 = edgeOff[q], e1 = edgeOff[q + 1];
-            const size_t nE = (size_t) (e1 - e0);
-            edgeSeq.resize(nE);
-            bt.resize(nE);
-            btLen.resize(nE);
-            for (size_t e = 0; e < nE; e++) {
-                edgeSeq[e] = tResidues + tOff[edgeT[e0 + e]];
-                bt[e] = btPool + btOff[e0 + e];
-                btLen[e] = (uint32_t) (btOff[e0 + e + 1] - btOff[e0 + e]);
+            hits.resize((size_t) (edgeOff[q + 1] - edgeOff[q]));
+            for (size_t h = 0; h < hits.size(); h++) {
+                const uint64_t e = edgeOff[q] + h;
+                hits[h].target = tResidues + tOff[edgeT[e]];
+                hits[h].centreStart = edgeQStart[e];
+                hits[h].targetStart = edgeTStart[e];
+                hits[h].path = btPool + btOff[e];
+                hits[h].pathLength = (uint32_t) (btOff[e + 1] - btOff[e]);
             }
-            size_t setSize = nE + 1;
-            if (nE == 0) {   // singleSequenceMSA
-                w.stride = ((size_t) L / BLK + 2) * BLK;
-                w.msa.assign(w.stride, (char) GAP);
-                for (int p = 0; p < L; p++) w.msa[p] = (char) center[p];
-                w.rows.assign(1, w.msa.data());
-            } else {
-                buildMsa(w, center, L, nE, edgeSeq.data(), edgeQStart + e0, edgeTStart + e0, bt.data(), btLen.data());
-            }
-            size_t filtered = setSize;
-            if (par->filterMsa)
-                filtered = filterMsa(w, r->sub, (int) setSize, L, (int) (par->covMSAThr * 100), qid_vec, par->qsc,
-                                     (int) (par->filterMaxSeqId * 100), par->Ndiff, par->filterMinEnable);
-            // computePSSMFromMSA(filteredSetSize, centerLength, msa, wg, 0.0)
-            w.seqWeight.assign(filtered, 0.0f);
-            w.wi.assign(filtered, 0.0f);
-            w.matchWeight.assign((size_t) (L + 2) * AA, 0.0f);
-            w.pseudo.assign((size_t) (L + 1) * AA, 0.0f);
-            w.profile.assign((size_t) (L + 1) * AA, 0.0f);
-            w.neffM.assign(L + 1, 0.0f);
-            w.pssm.assign((size_t) (L + 1) * AA, 0);
+            buildAlignment(A, centre, L, hits);
+            size_t nRows = hits.size() + 1;
+            if (par->filterMsa) nRows = filter.run(A, nRows, r->scores, fs);
+            char *const *row = A.row.data();
+
+            w.globalWeight.assign(nRows, 0.0f);
+            w.localWeight.assign(nRows, 0.0f);
+            w.frequency.assign((size_t) (L + 2) * kResidues, 0.0f);
+            w.pseudo.assign((size_t) (L + 1) * kResidues, 0.0f);
+            w.mixed.assign((size_t) (L + 1) * kResidues, 0.0f);
+            w.effective.assign(L + 1, 0.0f);
+            w.score.assign((size_t) (L + 1) * kResidues, 0);
             w.consensus.assign(L + 1, 0);
-            const char *const *rows = w.rows.data();
-            sequenceWeights(w.seqWeight.data(), L, filtered, rows);
-            normalizeTo1(w.seqWeight.data(), (int) filtered);
+            globalWeights(w.globalWeight.data(), L, nRows, row);
+            scaleToOne(w.globalWeight.data(), (int) nRows);
             if (!par->wg) {
-                contextSpecificWeights(w, r->m, w.matchWeight.data(), w.seqWeight.data(), w.neffM.data(), L, filtered,
-                                       (char *const *) rows);
+                columnWeights(w, background, w.frequency.data(), w.globalWeight.data(), w.effective.data(), L, nRows, row);
             } else {
-                matchWeights(r->m, w.matchWeight.data(), w.seqWeight.data(), filtered, L, rows);
-                neffM(w.matchWeight.data(), w.seqWeight.data(), w.neffM.data(), L, filtered, rows);
+                globalFrequencies(background, w.frequency.data(), w.globalWeight.data(), nRows, L, row);
+                globalEffective(w.frequency.data(), w.globalWeight.data(), w.effective.data(), L, nRows, row);
             }
-            // consensus (PSSMCalculator.cpp:652-667): the letter is mapped back to its number for the record
-            for (int pos = 0; pos < L; pos++) {
-                float maxw = 1E-8;
-                int maxa = ANY;
-                for (int aa = 0; aa < AA; ++aa) {
-                    float prob = w.matchWeight[(size_t) pos * AA + aa];
-                    if (prob - r->m.pBack[aa] > maxw) {
-                        maxw = prob - r->m.pBack[aa];
-                        maxa = aa;
+            // consensus: the residue most enriched over the background (PSSMCalculator.cpp:652-667)
+            for (int i = 0; i < L; i++) {
+                float best = 1E-8;
+                int which = kAny;
+                for (int a = 0; a < kResidues; a++) {
+                    const float f = w.frequency[(size_t) i * kResidues + a];
+                    if (f - background[a] > best) {
+                        best = f - background[a];
+                        which = a;
                     }
                 }
-                w.consensus[pos] = (unsigned char) maxa;
+                w.consensus[i] = (unsigned char) which;
             }
+            // substitution-matrix pseudo counts, mixed in with a weight that falls with the effective sequence number
+            // (PSSMCalculator.cpp:274-282,374-392)
             if (par->pca > 0.0f) {
-                // preparePseudoCounts + computePseudoCounts (PSSMCalculator.cpp:274-282,374-392)
-                float __attribute__((aligned(32))) freq[24];
-                for (int pos = 0; pos < L; pos++) {
-                    memcpy(freq, &w.matchWeight[(size_t) pos * AA], AA * sizeof(float));
-                    for (int aa = 0; aa < AA; aa++) w.pseudo[(size_t) pos * AA + aa] = scalarProd20(r->R[aa], freq);
+                float __attribute__((aligned(32))) column[24];
+                for (int i = 0; i < L; i++) {
+                    memcpy(column, &w.frequency[(size_t) i * kResidues], kResidues * sizeof(float));
+                    for (int a = 0; a < kResidues; a++) w.pseudo[(size_t) i * kResidues + a] = dot20(r->conditional[a], column);
                 }
-                for (int pos = 0; pos < L; pos++) {
-                    float tau = fmin(1.0, par->pca / (1.0 + w.neffM[pos] / par->pcb));
-                    for (int aa = 0; aa < AA; ++aa) {
-                        float pseudoCounts = tau * w.pseudo[(size_t) pos * AA + aa];
-                        float frequencySignal = (1.0 - tau) * w.matchWeight[(size_t) pos * AA + aa];
-                        w.profile[(size_t) pos * AA + aa] = frequencySignal + pseudoCounts;
+                for (int i = 0; i < L; i++) {
+                    float tau = fmin(1.0, par->pca / (1.0 + w.effective[i] / par->pcb));
+                    for (int a = 0; a < kResidues; a++) {
+                        float fromPrior = tau * w.pseudo[(size_t) i * kResidues + a];
+                        float fromData = (1.0 - tau) * w.frequency[(size_t) i * kResidues + a];
+                        w.mixed[(size_t) i * kResidues + a] = fromData + fromPrior;
                     }
                 }
             } else {
-                for (int i = 0; i < L * AA; i++) w.profile[i] = w.matchWeight[i];
+                for (int x = 0; x < L * kResidues; x++) w.mixed[x] = w.frequency[x];
             }
-            // computeLogPSSM(subMat, pssm, profile, 8.0, L, 0.0) (PSSMCalculator.cpp:251-265)
-            for (int pos = 0; pos < L; pos++) {
-                for (int aa = 0; aa < AA; aa++) {
-                    const float aaProb = w.profile[(size_t) pos * AA + aa];
-                    float logProb = flog2(aaProb / r->m.pBack[aa]);
+            // log-odds in eighth bits, rounded half away from zero through a char, clamped (PSSMCalculator.cpp:251-265)
+            for (int i = 0; i < L; i++) {
+                for (int a = 0; a < kResidues; a++) {
+                    const float p = w.mixed[(size_t) i * kResidues + a];
+                    float logOdds = flog2(p / background[a]);
                     const float bitFactor = 8.0, scoreBias = 0.0;
-                    float pssmVal = bitFactor * logProb + bitFactor * scoreBias;
-                    pssmVal = static_cast<char>((pssmVal < 0.0) ? pssmVal - 0.5 : pssmVal + 0.5);
-                    float truncPssmVal = std::min(pssmVal, 127.0f);
-                    truncPssmVal = std::max(-128.0f, truncPssmVal);
-                    w.pssm[(size_t) pos * AA + aa] = truncPssmVal;
+                    float v = bitFactor * logOdds + bitFactor * scoreBias;
+                    v = static_cast<char>((v < 0.0) ? v - 0.5 : v + 0.5);
+                    w.score[(size_t) i * kResidues + a] = std::max(-128.0f, std::min(v, 127.0f));
                 }
             }
-            if (par->compBiasCorr) {   // SubstitutionMatrix::calcGlobalAaBiasCorrection (SubstitutionMatrix.cpp:205-243)
-                w.pNull.assign(L, 0.0f);
-                char *ps = w.pssm.data();
-                const int windowSize = 40;
-                for (int pos = 0; pos < L; pos++)
-                    for (int aa = 0; aa < 20; aa++) w.pNull[pos] += r->m.pBack[aa] * static_cast<float>(ps[pos * AA + aa]);
+            if (par->compBiasCorr) {
+                // every column gives up the average excess (over its background expectation) of its 40-column neighbourhood
+                // (SubstitutionMatrix.cpp:205-243)
+                w.nullScore.assign(L, 0.0f);
+                char *sc = w.score.data();
+                const int window = 40;
+                for (int i = 0; i < L; i++)
+                    for (int a = 0; a < kResidues; a++) w.nullScore[i] += background[a] * static_cast<float>(sc[i * kResidues + a]);
                 for (int i = 0; i < L; i++) {
-                    const int minPos = std::max(0, (i - windowSize / 2));
-                    const int maxPos = std::min(L, (i + windowSize / 2));
-                    const int windowLength = maxPos - minPos;
-                    float aaSum[20];
-                    memset(aaSum, 0, sizeof(float) * 20);
-                    for (int j = minPos; j < maxPos; j++) {
-                        if (i == j) continue;
-                        for (int aa = 0; aa < 20; aa++) aaSum[aa] += ps[j * AA + aa] - w.pNull[j];
+                    const int lo = std::max(0, i - window / 2), hi = std::min(L, i + window / 2);
+                    const int span = hi - lo;
+                    float excess[kResidues];
+                    memset(excess, 0, sizeof(excess));
+                    for (int j = lo; j < hi; j++) {
+                        if (j == i) continue;
+                        for (int a = 0; a < kResidues; a++) excess[a] += sc[j * kResidues + a] - w.nullScore[j];
                     }
-                    for (int aa = 0; aa < 20; aa++) ps[i * AA + aa] = static_cast<int>(ps[i * AA + aa] - aaSum[aa] / windowLength);
+                    for (int a = 0; a < kResidues; a++) sc[i * kResidues + a] = static_cast<int>(sc[i * kResidues + a] - excess[a] / span);
                 }
             }
-            if (par->maskProfile) {   // Masker::maskPssm: tantan on the query letters, masked positions score -1 everywhere
-                w.masked.assign(center, center + L);
+            if (par->maskProfile) {   // tantan on the centre's letters: masked positions score -1 against everything
+                w.masked.assign(centre, centre + L);
                 sd::tantanMask(r->mask, w.masked.data(), L, par->maskProb);
-                for (int pos = 0; pos < L; pos++)
-                    if (w.masked[pos] == sd::X_CODE)
-                        for (int aa = 0; aa < AA; aa++) w.pssm[(size_t) pos * AA + aa] = -1;
+                for (int i = 0; i < L; i++)
+                    if (w.masked[i] == sd::X_CODE) memset(&w.score[(size_t) i * kResidues], -1, kResidues);
             }
-            // Profile::toBuffer (PSSMCalculator.cpp:671-687)
-            for (int pos = 0; pos < L; pos++) {
-                char *rec = out + (size_t) pos * 25;
-                memcpy(rec, &w.pssm[(size_t) pos * AA], AA);
-                rec[20] = (char) center[pos];
-                rec[21] = (char) w.consensus[pos];
-                rec[22] = (char) neffToChar(w.neffM[pos]);
+            char *out = outProfiles + qOff[q] * 25;
+            for (int i = 0; i < L; i++) {
+                char *rec = out + (size_t) i * 25;
+                memcpy(rec, &w.score[(size_t) i * kResidues], kResidues);
+                rec[20] = (char) centre[i];
+                rec[21] = (char) w.consensus[i];
+                rec[22] = (char) effectiveCountByte(w.effective[i]);
                 rec[23] = 0;
                 rec[24] = 0;
-                if (outConsensus) outConsensus[qOff[q] + pos] = w.consensus[pos];
+                if (outConsensus) outConsensus[qOff[q] + i] = w.consensus[i];
             }
         }
     }
-    return status;
+    return SD_OK;
 }
 
 }  // extern "C"

@@ -29,3 +29,32 @@ def test_oracle_clusterhits_equals_reference_functions(oracle):
             n_clusters += len(cs)
         n_entries += 1
     assert n_entries == 1500 and n_clusters > 1000
+
+
+@pytest.mark.skipif(not ref_ch_available(), reason='oracle/_ref/libsdref_ch.so not built (needs /root/reference)')
+def test_host_cluster_pvalues_equal_reference_functions():
+    """sd_host_cluster_pvalues (csrc/host/sd_chpval.cpp: the P-values the device path attaches to every emitted cluster) against
+    the reference's clusterMatchScore / multihitPval on the clusters of 600 synthetic entries: bit patterns and member order"""
+    import ctypes as C
+    from spacedust_amd import _lib
+    from spacedust_amd.api import Host, ptr
+    L = _lib.load()
+    ref = RefClusterHits()
+    lg = Host().lgamma_table(5000)
+    n_clusters = 0
+    for (q, t, s, p, genome) in many_entries(77, 600):
+        for alpha in (1.0, 0.01):
+            rcof, rrank, rcs, rpco, rpmh = ref.entry(q, t, s, p, genome, alpha=alpha, p_clu=1.0, p_mh=1.0)
+            for c in range(len(rcs)):
+                m = np.nonzero(rcof == c)[0]
+                m = m[np.argsort(rrank[m])][::-1].copy()   # any input order
+                co, mh = C.c_double(), C.c_double()
+                order = np.zeros(len(m), np.uint32)
+                qq, tt, ss, pp = (np.ascontiguousarray(a[m]) for a in (q, t, s, p))
+                assert L.sd_host_cluster_pvalues(len(m), ptr(qq), ptr(tt), ptr(ss), ptr(pp), genome, alpha, ptr(lg), len(lg), C.byref(co),
+                                                 C.byref(mh), ptr(order)) == 0
+                assert np.float64(co.value).tobytes() == rpco[c:c + 1].tobytes(), (co.value, rpco[c])
+                assert np.float64(mh.value).tobytes() == rpmh[c:c + 1].tobytes(), (mh.value, rpmh[c])
+                assert (rrank[m[order]] == np.arange(len(m))).all()
+                n_clusters += 1
+    assert n_clusters > 800
