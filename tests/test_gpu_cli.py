@@ -178,38 +178,172 @@ def _reference_profiles_on_this_box(aln_lines):
     return out
 
 
-def test_iterative_profile_search_config4(work):
-    """BASELINE config 4 on the regression input: `clustersearch --num-iterations 3` = sequence search with --realign,
-    result2profile, two profile searches (profile k-mer prefilter, profile Smith-Waterman) with subtractdbs / mergedbs
-    between them (M/src/workflow/Search.cpp:476-518, M/data/workflow/blastpgp.sh:52-140).
-    Iteration 0 is pinned to the reference binary (aln_0 md5, previous test).  The profile DB is compared with what the
-    reference's own classes compute on this machine from that aln_0 (rcpps, see above).  Where the host CPU rounds like the
-    one the reference binary ran on (profile_0 md5 equal), every later DB and the final TSV must equal the reference
-    binary's too: profile_1, the merged alignment DB (18 698 lines) and 331 hits / 119 clusters."""
+def _example_sequences():
+    import gzip
+    from dbutil import GOLD
+    seqs = []
+    for f in ('NC_000913.faa', 'NC_000915.faa'):
+        cur = None
+        for line in gzip.open(os.path.join(GOLD, 'examples', f + '.gz'), 'rt'):
+            line = line.rstrip('\n')
+            if line.startswith('>'):
+                if cur is not None:
+                    seqs.append(''.join(cur))
+                cur = []
+            else:
+                cur.append(line)
+        seqs.append(''.join(cur))
+    return seqs
+
+
+ITER_COMMON = ['--threads', '8', '-v', '0']
+ITER_PREF = ITER_COMMON + ['-s', '5.7', '-k', '0', '--max-seqs', '300', '-c', '0.8', '--cov-mode', '2', '--min-ungapped-score', '15', '--mask', '1',
+                           '--mask-prob', '0.9', '--comp-bias-corr', '1']
+ITER_ALN = ITER_COMMON + ['-a', '1', '--alignment-mode', '2', '--min-aln-len', '30', '-c', '0.8', '--cov-mode', '2', '--min-seq-id', '0',
+                          '--comp-bias-corr', '1', '--realign-score-bias', '-0.2']
+ITER_PROF = ITER_COMMON + ['-e', '0.001', '--e-profile', '0.001', '--mask-profile', '1', '--comp-bias-corr', '1', '--filter-msa', '1',
+                           '--filter-min-enable', '0', '--max-seq-id', '0.9', '--qid', '0.0', '--qsc', '-20', '--cov', '0', '--diff', '1000',
+                           '--pca', 'substitution:1.100,context:1.400', '--pcb', 'substitution:4.100,context:5.800']
+
+
+def _compress(bt):
+    """Matcher::compressAlignment (Matcher.cpp:166-185)"""
+    out, state, count = [], 'M', 0
+    for ch in bt:
+        if ch != state:
+            out.append('%d%s' % (count, state))
+            state, count = ch, 1
+        else:
+            count += 1
+    out.append('%d%s' % (count, state))
+    return ''.join(out)
+
+
+def _lines(db):
+    return {k: [l.split('\t') for l in v.decode().split('\n') if l] for k, v in db.items()}
+
+
+def test_profile_iterations_pinned_to_the_reference_classes_on_this_box(work):
+    """Iterations 1 and 2 of BASELINE config 4 (M/data/workflow/blastpgp.sh:73-133) on all 5 898 queries of the regression input,
+    module by module, every step against the reference's own classes run on THIS machine -- nothing here depends on the CPU model
+    (PSSMCalculator's rcpps makes profile bytes vendor-specific, so recorded checksums cannot serve):
+      prefilter   profile_k vs genome      == QueryMatcher driven with the DBTYPE_HMM_PROFILE Sequence (libsdref), row for row
+      align       profile_k on those rows  == Matcher::getSWResult with the profile query (libsdref): targets, coordinates,
+                                              backtraces, E-values
+      result2profile                       == MultipleAlignment / MsaFilter / PSSMCalculator (libsdref_r2p), byte for byte
+    and the DBs of the fused `clustersearch --num-iterations 3` equal the ones these steps produce."""
+    import numpy as np
     from dbutil import read_db
-    from oracle.pyoracle import ref_r2p_available
+    from oracle.pyoracle import ref_available, ref_r2p_available, Ref, RefSW, RefResult2Profile
+    from spacedust_amd import api
+    if not (ref_available() and ref_r2p_available()):
+        pytest.skip('oracle/_ref/libsdref*.so not built (needs /root/reference at build time)')
+    g = work / 'genome'
+    if not os.path.exists(work / 'aln_0.index'):
+        test_align_realign_reproduces_reference_db(work)
+    seqs = _example_sequences()
+    n = len(seqs)
+    lens = np.array([len(x) for x in seqs])
+    blob = ''.join(seqs).encode()
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum(lens)
+    ref = Ref(6)
+    rix = ref.index(blob, off, kmer_thr=0)                      # profile searches index every target k-mer (Prefiltering.cpp:525-527)
+    host = api.Host()
+    thr = host.profile_kmer_threshold(5.7, 6)
+    rpf = rix.prefilter_profile(int(lens.max()) + 10, thr, max_hits=300)
+    rsw = RefSW(ref, int(lens.max()) + 10, int(off[-1]))
+    r2p = RefResult2Profile()
+    it = work / 'it'
+    os.makedirs(it, exist_ok=True)
+    sdgpu('result2profile', g, g, work / 'aln_0', it / 'profile_0', *ITER_PROF)
+    prev_aln = work / 'aln_0'
+    n_rows = n_aln = 0
+    for step in (1, 2):
+        last = step == 2
+        prof_db = it / ('profile_%d' % (step - 1))
+        prof = read_db(str(prof_db))
+        assert len(prof) == n and all(len(prof[q]) == 25 * lens[q] for q in range(n))
+        # ---- prefilter with the profile
+        sdgpu('prefilter', prof_db, g, it / ('pref_tmp_%d' % step), *ITER_PREF)
+        got = _lines(read_db(str(it / ('pref_tmp_%d' % step))))
+        for q in range(n):
+            ids, sc, dg, _ = rpf.query(prof[q])
+            keep = (lens[ids].astype(np.float32) / np.float32(lens[q])) >= np.float32(0.8)   # Util::canBeCovered, --cov-mode 2
+            want = [(int(t), int(s), int(np.int16(np.uint16(d)))) for t, s, d in zip(ids[keep], sc[keep], dg[keep])]
+            mine = [(int(w[0]), int(w[1]), int(w[2])) for w in got.get(q, [])]
+            assert mine == want, (step, q, mine[:3], want[:3])
+            n_rows += len(want)
+        # ---- minus what is aligned already, then the profile alignments
+        sdgpu('subtractdbs', it / ('pref_tmp_%d' % step), prev_aln, it / ('pref_%d' % step), *ITER_COMMON, '--e-profile', '0.001', '-e', '10')
+        todo = _lines(read_db(str(it / ('pref_%d' % step))))
+        sdgpu('align', prof_db, g, it / ('pref_%d' % step), it / ('aln_tmp_%d' % step), *ITER_ALN, '-e', '10' if last else '0.001', '--realign', '0')
+        aln = _lines(read_db(str(it / ('aln_tmp_%d' % step))))
+        for q in range(n):
+            rows = todo.get(q, [])
+            if not rows:
+                assert not aln.get(q), (step, q)
+                continue
+            rsw.set_query_profile(prof[q])
+            want = {}
+            for w in rows:
+                t = int(w[0])
+                r = rsw.align(seqs[t], sw_mode=2, eval_thr=10.0 if last else 0.001, cov_mode=2, cov_thr=0.8)
+                aln_len = len(r['backtrace'])
+                if r['btLen'] > 0 and r['evalue'] <= (10.0 if last else 0.001) and aln_len >= 30:
+                    want[t] = (r['qStart'], r['qEnd'], r['tStart'], r['tEnd'], _compress(r['backtrace']), '%.3E' % r['evalue'])
+            mine = {int(w[0]): (int(w[4]), int(w[5]), int(w[7]), int(w[8]), w[10], w[3]) for w in aln.get(q, [])}
+            assert mine == want, (step, q, sorted(set(mine) ^ set(want))[:5])
+            n_aln += len(want)
+        # ---- merge, next profile
+        merged = it / ('aln_%d' % step)
+        sdgpu('mergedbs', prof_db, merged, prev_aln, it / ('aln_tmp_%d' % step))
+        prev_aln = merged
+        if not last:
+            sdgpu('result2profile', prof_db, g, merged, it / ('profile_%d' % step), *ITER_PROF)
+            nxt = read_db(str(it / ('profile_%d' % step)))
+            by = _lines(read_db(str(merged)))
+            bad = 0
+            for q in range(n):
+                et, eq, ets, bts = [], [], [], []
+                for w in by.get(q, []):
+                    if not (float(w[3]) < 0.001):
+                        continue   # (the centre is a profile DB entry: not "the same database", its own sequence stays in)
+                    et.append(int(w[0]))
+                    eq.append(int(w[4]))
+                    ets.append(int(w[7]))
+                    bts.append(api.uncompress_cigar(w[10]))
+                bad += r2p.profile(None, [seqs[t] for t in et], eq, ets, bts, centre_profile=prof[q]) != nxt[q]
+            assert bad == 0, (step, bad)
+    assert n_rows > 150000 and n_aln > 1000
+    # the fused workflow went through the same DBs
+    sdgpu('clustersearch', g, g, work / 'iter_pinned.tsv', work / 'tmpip', '--filter-self-match', '--num-iterations', '3', '--threads', '8', '-v', '0')
+    for name in ('profile_0', 'profile_1'):
+        assert _key_ordered_md5(work / 'tmpip' / 'search' / name) == _key_ordered_md5(it / name), name
+    assert _key_ordered_md5(work / 'tmpip' / 'result') == _key_ordered_md5(it / 'aln_2')
+
+
+def test_iterative_profile_search_config4(work):
+    """BASELINE config 4 end to end on the regression input: `clustersearch --num-iterations 3` = sequence search with --realign,
+    result2profile, two profile searches (profile k-mer prefilter, profile Smith-Waterman) with subtractdbs / mergedbs
+    between them (M/src/workflow/Search.cpp:476-518, M/data/workflow/blastpgp.sh:52-140).  Iteration 0 is pinned to the
+    reference binary (aln_0 md5), iterations 1 and 2 to the reference's classes on this box (previous test).  Where the host CPU
+    rounds rcpps like the one the reference binary ran on (profile_0 md5 equal), the recorded checksums of that binary's run
+    hold as well: profile_1, the merged alignment DB (18 698 lines), 331 hits / 119 clusters."""
     g = work / 'genome'
     sdgpu('clustersearch', g, g, work / 'iter.tsv', work / 'tmpi', '--filter-self-match', '--num-iterations', '3', '--threads', '8', '-v', '1')
     n0, md5_0 = _key_ordered_md5(work / 'tmpi' / 'search' / 'profile_0')
     assert n0 == 5898
-    if ref_r2p_available():
-        if not os.path.exists(work / 'aln_0.index'):
-            test_align_realign_reproduces_reference_db(work)
-        want = _reference_profiles_on_this_box(flat(work, 'aln_0'))
-        got = read_db(str(work / 'tmpi' / 'search' / 'profile_0'))
-        assert sum(1 for q in want if want[q] != got[q]) == 0
     tsv = open(work / 'iter.tsv').readlines()
     n_hit, n_clu = sum(1 for l in tsv if l.startswith('>')), sum(1 for l in tsv if l.startswith('#'))
     assert n_hit > 308 and n_clu > 108          # the profile iterations add hits to the single-pass result
-    if md5_0 == '169a337cab4e438fdcb75be742eef3d2':   # this CPU's rcpps rounds like the one the pins were recorded on
+    if md5_0 == '169a337cab4e438fdcb75be742eef3d2':   # this CPU's rcpps rounds like the one the checksums were recorded on
         assert _key_ordered_md5(work / 'tmpi' / 'search' / 'profile_1') == (5898, '0841b3aae841b086fa8850c8086c20af')
         sdgpu('prefixid', work / 'tmpi' / 'result', work / 'iter_result.flat', '--tsv')
         lines = open(work / 'iter_result.flat').readlines()
         assert (len(lines), sorted_md5(lines)) == (18698, 'deee49195d78013868efd140ad77b913')
         assert (n_hit, n_clu) == (331, 119)
         assert sorted_md5(tsv, drop_first_column=True) == 'ca3dd1ba9c0f89b9a7cf0726a1bab2ce'
-    else:
-        print('profile_0 md5 %s differs from the recorded one: rcpps of this CPU differs; compared with libsdref_r2p on this box' % md5_0)
 
 
 def test_prefilter_and_clustersearch_use_the_index_file(work):
