@@ -764,10 +764,12 @@ int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, c
 // the ordering of tasks all happen on the GPU; the host only launches, reads six class boundaries per pass
 // and receives the finished result records + a dense backtrace pool.
 // ---------------------------------------------------------------------------------------------
-// score-pass task classes: 0-10 packed-int16 kernel with the five-bit row code, 11-21 the same with the wide row
-// code (rows: <=128, <=192, <=256, <=320, <=384, <=512, <=640, <=768, then 2 / 3 / more strips of 512 rows),
-// 22-25 int32 kernel (rows: <=128, <=256, <=512, more)
-constexpr uint32_t N_PK_CLASSES = 11;
+// score-pass task classes: 0-13 packed-int16 kernel with the five-bit row code, 14-27 the same with the wide row
+// code (rows: <=128, <=192, <=224, <=256, <=288, <=320, <=352, <=384, <=512, <=640, <=768, then 2 / 3 / more strips of 512
+// rows -- steps of 32 rows where most proteins are: a task pays for the rows of its class, not for its own), 28-31 int32
+// kernel (rows: <=128, <=256, <=512, more).  32 classes: the pair sort carries the class in six bits.
+constexpr uint32_t N_PK_CLASSES = 14;
+constexpr uint32_t FIRST_MULTI_PK = 11;   // classes of more than one strip
 constexpr uint32_t N_SCORE_CLASSES = 2 * N_PK_CLASSES + 4;
 constexpr uint32_t FIRST_WIDE_CLASS = N_PK_CLASSES;
 constexpr uint32_t FIRST_INT32_CLASS = 2 * N_PK_CLASSES;
@@ -780,9 +782,10 @@ __device__ __forceinline__ uint32_t scoreKey(int n, int tL, int kernel) {
     if (kernel == SCORE_INT32 || tL > 65535) {
         ci = FIRST_INT32_CLASS + (n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3)));
     } else {
-        if (n <= 384) ci = (n + 63) / 64 < 2 ? 0 : (n + 63) / 64 - 2;   // 128, 192, 256, 320, 384 rows -> 0..4
-        else if (n <= 768) ci = n <= 512 ? 5 : (n <= 640 ? 6 : 7);
-        else ci = min(8 + (n + 511) / 512 - 2, 10);   // 2 strips -> 8, 3 strips -> 9, more -> 10
+        if (n <= 192) ci = n <= 128 ? 0 : 1;
+        else if (n <= 384) ci = 2 + (n - 193) / 32;                      // 224, 256, 288, 320, 352, 384 rows -> 2..7
+        else if (n <= 768) ci = n <= 512 ? 8 : (n <= 640 ? 9 : 10);
+        else ci = min((int) FIRST_MULTI_PK + (n + 511) / 512 - 2, 13);   // 2 strips -> 11, 3 strips -> 12, more -> 13
         if (kernel == SCORE_PK_WIDE) ci += FIRST_WIDE_CLASS;
     }
     return (uint32_t) ci * 1024u + (uint32_t) (1023 - min(tL >> 4, 1023));
@@ -860,11 +863,11 @@ k_make_fwd(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const uint32_t *
 __global__ void k_bounds(const uint32_t *__restrict__ keys, uint32_t n, uint32_t step, uint32_t *__restrict__ b, int nb) {
     const int c = threadIdx.x;
     if (c >= nb) return;
-    const uint32_t want = (uint32_t) c * step;
+    const uint64_t want = (uint64_t) c * step;   // (32 classes x 2^27: the end bound does not fit 32 bits)
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         uint32_t mid = (lo + hi) >> 1;
-        if (keys[mid] < want) lo = mid + 1;
+        if ((uint64_t) keys[mid] < want) lo = mid + 1;
         else hi = mid;
     }
     b[c] = lo;
@@ -1125,7 +1128,7 @@ k_bound_need(uint32_t nPairs, const SwTask *__restrict__ tasks, const uint32_t *
     uint64_t v = 0;
     if (keys[i] != KEY_INVALID) {
         const uint32_t ci = keys[i] >> 10;
-        if (ci < FIRST_INT32_CLASS && (ci % N_PK_CLASSES) >= 8) v = 2ull * (uint64_t) tasks[i].tL;
+        if (ci < FIRST_INT32_CLASS && (ci % N_PK_CLASSES) >= FIRST_MULTI_PK) v = 2ull * (uint64_t) tasks[i].tL;
         else if (ci == N_SCORE_CLASSES - 1 && tasks[i].n > 1024) v = (uint64_t) tasks[i].tL;
     }
     need[i] = v;
@@ -1148,20 +1151,21 @@ k_pair_keys(uint32_t n, const uint32_t *__restrict__ keys, const uint32_t *__res
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = keys[i];
-    key2[i] = k == KEY_INVALID ? 0xFFFFFFFFu : ((k >> 10) << 27) | (pairQ[i] << 10) | (k & 1023u);
+    // class (6 bits) | query (17 bits) | target length code (9 bits): invalid entries sort behind the last class
+    key2[i] = k == KEY_INVALID ? 0xFFFFFFFFu : ((k >> 10) << 26) | (pairQ[i] << 9) | ((k & 1023u) >> 1);
 }
 __global__ void __launch_bounds__(256)
 k_pair_heads(uint32_t n, const uint32_t *__restrict__ keyS, uint32_t *__restrict__ headPos) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const bool head = p == 0 || (keyS[p] >> 10) != (keyS[p - 1] >> 10);
+    const bool head = p == 0 || (keyS[p] >> 9) != (keyS[p - 1] >> 9);
     headPos[p] = head ? p : 0u;
 }
 __global__ void __launch_bounds__(256)
 k_pair_leaders(uint32_t n, const uint32_t *__restrict__ keyS, const uint32_t *__restrict__ runStart, uint8_t *__restrict__ leader) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n) return;
-    leader[p] = (p < n && (keyS[p] >> 27) < FIRST_INT32_CLASS && ((p - runStart[p]) & 1u) == 0) ? 1 : 0;
+    leader[p] = (p < n && (keyS[p] >> 26) < FIRST_INT32_CLASS && ((p - runStart[p]) & 1u) == 0) ? 1 : 0;
 }
 __global__ void __launch_bounds__(256)
 k_pair_emit(uint32_t n, const uint32_t *__restrict__ keyS, const uint32_t *__restrict__ vals, const uint8_t *__restrict__ leader,
@@ -1170,7 +1174,7 @@ k_pair_emit(uint32_t n, const uint32_t *__restrict__ keyS, const uint32_t *__res
     if (p >= n || !leader[p]) return;
     const uint64_t w = pairIdx[p];
     order2[2 * w] = vals[p];
-    const bool mate = p + 1 < n && (keyS[p + 1] >> 10) == (keyS[p] >> 10);
+    const bool mate = p + 1 < n && (keyS[p + 1] >> 9) == (keyS[p] >> 9);
     order2[2 * w + 1] = mate ? vals[p + 1] : PAIR_NONE;
 }
 // pair-index boundaries of the packed classes: b[c] = number of pairs of classes < c
@@ -1178,7 +1182,7 @@ __global__ void k_pair_bounds(const uint32_t *__restrict__ keyS, uint32_t n, con
                               uint32_t *__restrict__ b, int nb) {
     const int c = threadIdx.x;
     if (c >= nb) return;
-    const uint32_t want = (uint32_t) c << 27;
+    const uint32_t want = (uint32_t) c << 26;
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -1211,7 +1215,7 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
         SD_HIP(ctx, wsGet(ctx, "sp.leader", (size_t) nPairs + 1, &dLeader));
         SD_HIP(ctx, wsGet(ctx, "sp.pairidx", (size_t) nPairs + 1, &dPairIdx));
         SD_HIP(ctx, wsGet(ctx, "sp.order2", (size_t) 2 * nPairs, &dOrder2));
-        SD_HIP(ctx, wsGet(ctx, "sp.bounds", 32, &dPairBounds));
+        SD_HIP(ctx, wsGet(ctx, "sp.bounds", 64, &dPairBounds));
         hipLaunchKernelGGL(k_pair_keys, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dPairQ, dKey2);
         rc = devSortPairs(ctx, dKey2, dKeysSorted, dVals, dVals2, nPairs, 32);
         if (rc != SD_OK) return rc;
@@ -1236,9 +1240,9 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
         hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dVals2, dLeader, dPairIdx, dOrder2);
         hipLaunchKernelGGL(k_pair_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, dPairIdx, dPairBounds,
                            (int) FIRST_INT32_CLASS + 1);
-        hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1u << 27, dBounds, (int) N_SCORE_CLASSES + 1);
+        hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1u << 26, dBounds, (int) N_SCORE_CLASSES + 1);
     } else {
-        rc = devSortPairs(ctx, dKeys, dKeysSorted, dVals, dOrder, nPairs, 15);
+        rc = devSortPairs(ctx, dKeys, dKeysSorted, dVals, dOrder, nPairs, 16);
         if (rc != SD_OK) return rc;
         hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1024u, dBounds, (int) N_SCORE_CLASSES + 1);
     }
@@ -1260,8 +1264,8 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
     for (uint32_t ci = 0; ci < N_SCORE_CLASSES; ci++) {
         const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
         if (cnt == 0) continue;
-        static const char *const pkNames[N_PK_CLASSES] = {"rt4x32", "rt6x32", "rt8x32", "rt10x32", "rt12x32", "rt8x64", "rt10x64",
-                                                          "rt12x64", "rt8x64s2", "rt8x64s3", "rt8x64sN"};
+        static const char *const pkNames[N_PK_CLASSES] = {"rt4x32", "rt6x32", "rt7x32", "rt8x32", "rt9x32", "rt10x32", "rt11x32", "rt12x32",
+                                                          "rt8x64", "rt10x64", "rt12x64", "rt8x64s2", "rt8x64s3", "rt8x64sN"};
         static const char *const i32Names[4] = {"sw_score.rt4", "sw_score.rt8", "sw_score.rt16", "sw_score.rt32"};
         char name[48];
         if (ci < FIRST_INT32_CLASS) snprintf(name, sizeof(name), "sw_score_pk.%s%s", ci >= FIRST_WIDE_CLASS ? "w_" : "", pkNames[ci % N_PK_CLASSES]);
@@ -1283,12 +1287,15 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
         switch (ci % N_PK_CLASSES) {                                          \
             case 0: SD_PK(4, 32, false, WIDE); break;                         \
             case 1: SD_PK(6, 32, false, WIDE); break;                         \
-            case 2: SD_PK(8, 32, false, WIDE); break;                         \
-            case 3: SD_PK(10, 32, false, WIDE); break;                        \
-            case 4: SD_PK(12, 32, false, WIDE); break;                        \
-            case 5: SD_PK(8, 64, false, WIDE); break;                         \
-            case 6: SD_PK(10, 64, false, WIDE); break;                        \
-            case 7: SD_PK(12, 64, false, WIDE); break;                        \
+            case 2: SD_PK(7, 32, false, WIDE); break;                         \
+            case 3: SD_PK(8, 32, false, WIDE); break;                         \
+            case 4: SD_PK(9, 32, false, WIDE); break;                         \
+            case 5: SD_PK(10, 32, false, WIDE); break;                        \
+            case 6: SD_PK(11, 32, false, WIDE); break;                        \
+            case 7: SD_PK(12, 32, false, WIDE); break;                        \
+            case 8: SD_PK(8, 64, false, WIDE); break;                         \
+            case 9: SD_PK(10, 64, false, WIDE); break;                        \
+            case 10: SD_PK(12, 64, false, WIDE); break;                       \
             default: SD_PK(8, 64, true, WIDE); break;                         \
         }
         if (ci < FIRST_WIDE_CLASS) {
@@ -1610,7 +1617,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     SD_HIP(ctx, wsGet(ctx, "al.order", N, &dOrder));
     SD_HIP(ctx, wsGet(ctx, "al.fwdkeys", N, &dFwdKeys));
     SD_HIP(ctx, wsGet(ctx, "al.revkeys", N, &dRevKeys));
-    SD_HIP(ctx, wsGet(ctx, "al.bounds", 32, &dBounds));
+    SD_HIP(ctx, wsGet(ctx, "al.bounds", 64, &dBounds));
     SD_HIP(ctx, wsGet(ctx, "al.minbias", queries->n, &dMinBias));
     SD_HIP(ctx, wsGet(ctx, "al.out32", N * 3, &dOut32));
     SD_HIP(ctx, wsGet(ctx, "al.out16", N * 3, &dOut16));
