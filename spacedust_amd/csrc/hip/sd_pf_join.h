@@ -18,7 +18,10 @@
 // cursors, pass two reorders tile by tile in LDS and appends runs at those cursors -- a workgroup's writes into a bin
 // are consecutive in memory, so partial lines merge in its XCD's L2.
 
-constexpr int JP_WGS = 256;            // persistent workgroups (one per CU)
+// Workgroup shapes.  These kernels run beside the alignment stage's kernels (other streams); half-CU shapes (512 threads / 88 KB
+// for the partition, 256 threads / 33 KB for the join) were measured in the running pipeline and did not pay: +25 % isolated
+// time, end-to-end throughput within noise -- unlike partition_hits, where 512 x 4 096 beats both neighbours.
+constexpr int JP_WGS = 256;            // persistent workgroups of the k-mer partition (one per CU)
 constexpr int JP_NT = 1024;
 constexpr int KP_BINS = 2048;          // k-mer ranges: bin = kmer >> 15 (k = 6: 1 954 of them in use)
 constexpr int KP_SHIFT = 53;           // element >> 53 = kmer >> 15
@@ -144,9 +147,10 @@ col_prefix_kernel(uint32_t *__restrict__ m, int rows /* multiple of 4 */, int co
 
 // exclusive scan of n <= 4096 totals into 64-bit bases (n + 1 values), one workgroup; pad > 0: every total is rounded
 // up to a multiple of pad first (k-mer ranges start on join-chunk boundaries)
-__global__ void __launch_bounds__(JP_NT)
+constexpr int SS_NT = 1024;
+__global__ void __launch_bounds__(SS_NT)
 small_scan_kernel(const uint32_t *__restrict__ in, int n, uint64_t *__restrict__ out, uint32_t pad) {
-    __shared__ uint64_t part[JP_NT / 64];
+    __shared__ uint64_t part[SS_NT / 64];
     const int t = threadIdx.x;
     uint64_t v[4], sum = 0;
 #pragma unroll
@@ -170,15 +174,21 @@ small_scan_kernel(const uint32_t *__restrict__ in, int n, uint64_t *__restrict__
         if (t * 4 + j <= n) out[t * 4 + j] = run;
         run += v[j];
     }
-    if (t * 4 + 4 == n) out[n] = run;   // n = 4 * JP_NT: the total has no thread of its own
+    if (t * 4 + 4 == n) out[n] = run;   // n = 4 * SS_NT: the total has no thread of its own
 }
 
-// exclusive scan of arr[0..n) in LDS, n <= 2 * NT, all NT threads of the workgroup
+// exclusive scan of arr[0..n) in LDS by all NT threads of the workgroup (n <= 8 * NT); part[NT / 64] receives the total
 template <int NT>
 __device__ __forceinline__ void jpBlockScan2(uint32_t *arr, int n, uint32_t *part) {
     const int t = threadIdx.x;
-    const uint32_t a = (2 * t < n) ? arr[2 * t] : 0, b = (2 * t + 1 < n) ? arr[2 * t + 1] : 0;
-    const uint32_t sum = a + b;
+    const int per = (n + NT - 1) / NT;
+    const int lo = t * per, hi = min(n, lo + per);
+    uint32_t v[8];
+    uint32_t sum = 0;
+    for (int x = lo; x < hi; x++) {
+        v[x - lo] = arr[x];
+        sum += v[x - lo];
+    }
     uint32_t incl = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -189,9 +199,12 @@ __device__ __forceinline__ void jpBlockScan2(uint32_t *arr, int n, uint32_t *par
     __syncthreads();
     uint32_t run = incl - sum;
     for (int w = 0; w < (t >> 6); w++) run += part[w];
-    if (2 * t < n) arr[2 * t] = run;
-    if (2 * t + 1 < n) arr[2 * t + 1] = run + a;
-    if (t == NT - 1) part[NT / 64] = run + sum;   // grand total
+    for (int x = lo; x < hi; x++) {
+        arr[x] = run;
+        run += v[x - lo];
+    }
+    __syncthreads();
+    if (t == NT - 1) part[NT / 64] = run;   // grand total
     __syncthreads();
 }
 

@@ -2189,7 +2189,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 ProfScope ps(ctx, "prefilter_kmer_partition");
                 hipLaunchKernelGGL(kp_hist_kernel, dim3(JP_WGS), dim3(JP_NT), 0, ctx->stream, (const uint64_t *) dElems.p, nKmers, dKpCounts.p);
                 hipLaunchKernelGGL(col_prefix_kernel, dim3(KP_BINS / 64), dim3(256), 0, ctx->stream, dKpCounts.p, JP_WGS, KP_BINS, dKpTotal.p);
-                hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(JP_NT), 0, ctx->stream, (const uint32_t *) dKpTotal.p, KP_BINS, dKpBase.p, (uint32_t) JC);
+                hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(SS_NT), 0, ctx->stream, (const uint32_t *) dKpTotal.p, KP_BINS, dKpBase.p, (uint32_t) JC);
                 hipLaunchKernelGGL(kp_scatter_kernel, dim3(JP_WGS), dim3(JP_NT), 0, ctx->stream, (const uint64_t *) dElems.p, nKmers,
                                    (const uint32_t *) dKpCounts.p, (const uint64_t *) dKpBase.p, (const uint32_t *) dQKmerBase.p, bq, dSorted.p);
                 hipLaunchKernelGGL(kp_finish_kernel, dim3(KP_BINS), dim3(256), 0, ctx->stream, (const uint32_t *) dKpTotal.p,
@@ -2253,7 +2253,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             SD_HIP(ctx, dQHitBase.alloc(bq + 1));
             hipLaunchKernelGGL(join_effective_totals_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQHits.p,
                                (const uint32_t *) dQSplit.p, dQEff.p);
-            hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(JP_NT), 0, ctx->stream, (const uint32_t *) dQEff.p, (int) bq, dQHitBase.p, 0u);
+            hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(SS_NT), 0, ctx->stream, (const uint32_t *) dQEff.p, (int) bq, dQHitBase.p, 0u);
             if (nHits > 0) {
                 SD_HIP(ctx, dHitsKV.alloc(nHits));
                 ProfScope ps(ctx, "prefilter_join_scatter");
@@ -2437,8 +2437,12 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 {
                     ProfScope ps(ctx, "prefilter_partition_hits");
                     // large tiles where the virtual queries are large (proteome-scale target sets), the small form for small inputs
-                    if (nHits / std::max<uint32_t>(nVQ, 1) >= 16384 && !getenv("SD_PF_SMALLTILE"))
+                    const int tileMode = getenv("SD_PF_TILE") ? atoi(getenv("SD_PF_TILE")) : 1;
+                    if (nHits / std::max<uint32_t>(nVQ, 1) >= 16384 && tileMode == 2)
                         hipLaunchKernelGGL((partition_hits_kernel<1024, 8192>), dim3(nVQ), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV, pKey,
+                                           pVal, pKV, dKVB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
+                    else if (nHits / std::max<uint32_t>(nVQ, 1) >= 16384 && tileMode == 1)
+                        hipLaunchKernelGGL((partition_hits_kernel<512, 4096>), dim3(nVQ), dim3(512), 0, ctx->stream, nVQ, pHitBase, tBitsV, pKey,
                                            pVal, pKV, dKVB.p, dQLog2.p, dBktStart.p, dBktCount.p, dFlag.p);
                     else
                         hipLaunchKernelGGL((partition_hits_kernel<256, 2048>), dim3(nVQ), dim3(256), 0, ctx->stream, nVQ, pHitBase, tBitsV, pKey,
