@@ -524,85 +524,80 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
     }
 }
 
-// Where the reference's hit buffer (cap entries) overflows inside a query, in k-mer ordinals: the k-mer whose list would
-// fill the buffer starts the second part (QueryMatcher.cpp:281-316).  One workgroup per query; only queries with at
-// least cap hits walk their k-mers (in enumeration order, list lengths from the offset table).
+// Where the reference's hit buffer (cap entries) overflows inside a query, in k-mer ordinals: whenever the next k-mer's list
+// would fill the buffer, the buffered part is matched on its own and the buffer starts again with that list
+// (QueryMatcher.cpp:281-316) -- so a split is the ordinal of the first k-mer of a part.  One workgroup per query; only queries
+// with at least cap hits walk their k-mers (enumeration order, list lengths from the offset table), and only the blocks of
+// 256 k-mers in which the running part can reach cap are walked one k-mer at a time.
 __global__ void __launch_bounds__(256)
-query_split_join_kernel(uint32_t nQ, const uint32_t *__restrict__ qKmerBase, const uint64_t *__restrict__ elems,
-                        const uint32_t *__restrict__ idxOffsets, const uint32_t *__restrict__ qHits, uint64_t cap,
-                        uint32_t *__restrict__ qSplit, int *__restrict__ flag) {
-    __shared__ uint64_t part[4];
-    __shared__ uint64_t carry;
-    __shared__ uint32_t found;
+query_splits_join_kernel(uint32_t nQ, const uint32_t *__restrict__ qKmerBase, const uint64_t *__restrict__ elems,
+                         const uint32_t *__restrict__ idxOffsets, const uint32_t *__restrict__ qHits, uint64_t cap,
+                         uint32_t *__restrict__ qSplit, uint32_t *__restrict__ qParts, uint32_t *__restrict__ qSplits /* [nQ][PF_SPLITS_MAX] */,
+                         int *__restrict__ flag) {
+    __shared__ uint32_t lens[256];
+    __shared__ unsigned long long part[4];
+    __shared__ unsigned long long inPart;
+    __shared__ uint32_t nSplit;
+    __shared__ int stop;
     const uint32_t q = blockIdx.x;
-    const uint64_t total = qHits[q];
-    if (total < cap) {
-        if (threadIdx.x == 0) qSplit[q] = 0xFFFFFFFFu;
+    if ((uint64_t) qHits[q] < cap) {
+        if (threadIdx.x == 0) {
+            qSplit[q] = 0xFFFFFFFFu;
+            qParts[q] = 0;
+        }
         return;
     }
     const uint32_t k0 = qKmerBase[q], nk = qKmerBase[q + 1] - k0;
+    uint32_t *out = qSplits + (size_t) q * PF_SPLITS_MAX;
     if (threadIdx.x == 0) {
-        carry = 0;
-        found = 0xFFFFFFFFu;
+        inPart = 0;
+        nSplit = 0;
+        stop = 0;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t x0 = 0; x0 < nk; x0 += 256) {
+    for (uint32_t x0 = 0; x0 < nk && !stop; x0 += 256) {
         const uint32_t x = x0 + threadIdx.x;
-        uint64_t len = 0;
+        uint32_t len = 0;
         if (x < nk) {
             const uint32_t km = (uint32_t) (elems[k0 + x] >> 38);
             len = idxOffsets[km + 1] - idxOffsets[km];
         }
-        uint64_t incl = len;
+        lens[threadIdx.x] = len;
+        unsigned long long sum = len;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint64_t o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == 0) part[wave] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long total = part[0] + part[1] + part[2] + part[3];
+            if (inPart + total < cap) {
+                inPart += total;   // no list of this block can fill the buffer
+            } else {
+                unsigned long long have = inPart;
+                for (uint32_t j = 0; j < 256 && x0 + j < nk; j++) {
+                    const unsigned long long l = lens[j];
+                    if (have + l >= cap) {
+                        if (nSplit < (uint32_t) PF_SPLITS_MAX) out[nSplit] = x0 + j;
+                        nSplit++;
+                        have = 0;
+                        if (l >= cap) {   // a single list as large as the buffer: the reference stops matching here (:312-314)
+                            stop = 1;
+                            break;
+                        }
+                    }
+                    have += l;
+                }
+                inPart = have;
+            }
         }
-        if (lane == 63) part[wave] = incl;
         __syncthreads();
-        uint64_t run = carry + incl;
-        for (int w = 0; w < wave; w++) run += part[w];
-        // first k-mer whose inclusive count reaches cap
-        if (x < nk && run >= cap && run - len < cap) found = x;
-        __syncthreads();
-        if (threadIdx.x == 255) carry = run;
-        __syncthreads();
-        if (found != 0xFFFFFFFFu) break;
     }
     if (threadIdx.x == 0) {
-        uint32_t split = found;
-        // hits before the split = carry-in of k-mer `found`; a second overflow of the buffer is not implemented
-        // (QueryMatcher.cpp:289-303): recount from the split
-        qSplit[q] = split;
-    }
-}
-
-// second part of query_split_join: a query whose second part overflows again is taken out of the batch
-__global__ void __launch_bounds__(256)
-query_split_check_kernel(uint32_t nQ, const uint32_t *__restrict__ qKmerBase, const uint64_t *__restrict__ elems,
-                         const uint32_t *__restrict__ idxOffsets, uint64_t cap, uint32_t *__restrict__ qSplit,
-                         int *__restrict__ flag) {
-    __shared__ unsigned long long sum;
-    const uint32_t q = blockIdx.x;
-    const uint32_t split = qSplit[q];
-    if (split == 0xFFFFFFFFu) return;
-    const uint32_t k0 = qKmerBase[q], nk = qKmerBase[q + 1] - k0;
-    if (threadIdx.x == 0) sum = 0;
-    __syncthreads();
-    unsigned long long mine = 0;
-    for (uint32_t x = split + threadIdx.x; x < nk; x += 256) {
-        const uint32_t km = (uint32_t) (elems[k0 + x] >> 38);
-        mine += idxOffsets[km + 1] - idxOffsets[km];
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&sum, mine);
-    __syncthreads();
-    if (threadIdx.x == 0 && sum >= cap) {
-        qSplit[q] = QUERY_UNSUPPORTED;
-        atomicExch(flag, 1);
+        const bool unsupported = stop || nSplit > (uint32_t) PF_SPLITS_MAX;
+        qParts[q] = unsupported ? 0u : nSplit;
+        qSplit[q] = unsupported ? QUERY_UNSUPPORTED : (nSplit ? out[0] : 0xFFFFFFFFu);
+        if (unsupported) atomicExch(flag, 1);
     }
 }
 

@@ -673,34 +673,46 @@ __global__ void query_hit_base_kernel(uint32_t nQ, const uint64_t *__restrict__ 
 }
 
 constexpr uint32_t QUERY_UNSUPPORTED = 0xFFFFFFFEu;   // qSplit marker: the query needs a reference path the device lacks
+constexpr int PF_SPLITS_MAX = 32;   // overflows of the reference's hit buffer carried per query (33 parts: 6.6*10^7 hits at the smallest buffer)
 
-// where the reference's hit buffer (cap entries) overflows inside query q: the k-mer list that would fill it
-// (inBuffer + listSize >= cap) starts the second part; a second overflow is flagged (not implemented)
+// where the reference's hit buffer (cap entries) overflows inside query q, as stream positions: every k-mer list that would
+// fill the buffer (inBuffer + listSize >= cap) starts a new part (QueryMatcher.cpp:281-316); qSplit = the first one (the
+// common case of one overflow is read from there), qSplits / qParts all of them
 __global__ void query_split_kernel(uint32_t nQ, const uint64_t *__restrict__ posBase, const uint64_t *__restrict__ kmerBase,
                                    const uint64_t *__restrict__ hitBase, uint64_t cap, uint32_t *__restrict__ qSplit,
+                                   uint32_t *__restrict__ qParts, uint32_t *__restrict__ qSplits /* [nQ][PF_SPLITS_MAX] */,
                                    int *__restrict__ flag, uint64_t posLimit /* 2^24, or ~2^32 with wide stream positions */) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nQ) return;
     const uint64_t k0 = kmerBase[posBase[q]], k1 = kmerBase[posBase[q + 1]];
     const uint64_t h0 = hitBase[k0], total = hitBase[k1] - h0;
-    uint32_t split = 0xFFFFFFFFu;
+    uint32_t first = 0xFFFFFFFFu, n = 0;
     bool unsupported = total >= posLimit;   // stream positions are carried in 24 (wide: 32) bits
-    if (!unsupported && total >= cap) {
-        // first k in [k0, k1) with hitBase[k + 1] - h0 >= cap
-        uint64_t lo = k0, hi = k1;
+    uint64_t cur = k0;   // first k-mer of the current part
+    while (!unsupported && hitBase[k1] - hitBase[cur] >= cap) {
+        // first k in [cur, k1) with hitBase[k + 1] - hitBase[cur] >= cap
+        const uint64_t partBase = hitBase[cur];
+        uint64_t lo = cur, hi = k1;
         while (lo < hi) {
             const uint64_t mid = (lo + hi) >> 1;
-            if (hitBase[mid + 1] - h0 >= cap) hi = mid;
+            if (hitBase[mid + 1] - partBase >= cap) hi = mid;
             else lo = mid + 1;
         }
-        split = (uint32_t) (hitBase[lo] - h0);
-        if (total - split >= cap) unsupported = true;   // a second overflow of the hit buffer (QueryMatcher.cpp:289-303)
+        if (lo >= k1) break;
+        const uint32_t pos = (uint32_t) (hitBase[lo] - h0);
+        if (n < (uint32_t) PF_SPLITS_MAX) qSplits[(size_t) q * PF_SPLITS_MAX + n] = pos;
+        if (n == 0) first = pos;
+        n++;
+        if (hitBase[lo + 1] - hitBase[lo] >= cap || n > (uint32_t) PF_SPLITS_MAX) unsupported = true;   // (a list as large as the buffer, :312-314)
+        cur = lo;
     }
     if (unsupported) {
         atomicExch(flag, 1);
-        split = QUERY_UNSUPPORTED;
+        first = QUERY_UNSUPPORTED;
+        n = 0;
     }
-    qSplit[q] = split;
+    qSplit[q] = first;
+    qParts[q] = n;
 }
 
 // queries marked QUERY_UNSUPPORTED take no part in the rest of the batch: their index lists are emptied
@@ -713,6 +725,63 @@ drop_query_kmers_kernel(uint64_t nKmers, const uint32_t *__restrict__ kPos, cons
 }
 
 #include "sd_pf_join.h"
+
+// part of the reference's hit buffer a stream position (lookup path) / k-mer ordinal (join path) falls into: the number of
+// splits at or before it
+struct SplitView {
+    uint32_t first;            // first split (0xFFFFFFFF: none)
+    uint32_t n;                // number of splits
+    const uint32_t *all;       // the query's splits when n >= 2
+};
+__device__ __forceinline__ SplitView splitView(const uint32_t *qSplit, const uint32_t *qParts, const uint32_t *qSplits, uint32_t q) {
+    SplitView v;
+    v.first = qSplit[q];
+    v.n = qParts ? qParts[q] : 0u;
+    v.all = v.n >= 2 ? qSplits + (size_t) q * PF_SPLITS_MAX : nullptr;
+    return v;
+}
+__device__ __forceinline__ uint32_t partOfPos(const SplitView &v, uint32_t pos) {
+    if (!v.all) return pos >= v.first ? 1u : 0u;
+    uint32_t lo = 0, hi = v.n;   // number of splits <= pos
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (v.all[mid] <= pos) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// Place of a hit in the reference's result list once the buffer has overflowed m >= 2 times (parts 0 .. m of the stream).
+// Every merge of carried results with a new part (QueryMatcher.cpp:289-303) walks the bins backwards
+// (CacheFriendlyOperations.cpp:119-147), so the carried list C_j after the j-th overflow reads
+//     C_1 = part 0 forwards;   C_j = part j-1 backwards, then C_{j-1} backwards;
+// and the final list is C_m followed by part m forwards (the last merge, :316-319, walks forwards).  Elements only ever drop
+// out in between, so a survivor's place is that of its part in this sequence and its stream position inside the part, read
+// in the part's direction; it is returned as a position of the same range (a permutation of the stream positions), with
+// `backwards` telling whether hits of one position (join path: one k-mer's list) are read in reverse too.
+__device__ __forceinline__ uint32_t overflowOrderPos(const SplitView &v, uint32_t pos, bool &backwards) {
+    const uint32_t m = v.n;
+    const uint32_t p = partOfPos(v, pos);
+    backwards = false;
+    if (!v.all || p >= m) return pos;
+    auto place = [&](uint32_t part, bool &back) -> uint32_t {   // rank of a part (< m) in C_m, and its direction
+        uint32_t r = 0;
+        back = part != 0;
+        for (uint32_t j = (part == 0 ? 2u : part + 2u); j <= m; j++) {
+            r = 1 + (j - 2 - r);
+            back = !back;
+        }
+        return r;
+    };
+    const uint32_t mine = place(p, backwards);
+    uint32_t base = 0;
+    for (uint32_t o = 0; o < m; o++) {
+        bool b;
+        if (o != p && place(o, b) < mine) base += v.all[o] - (o ? v.all[o - 1] : 0u);
+    }
+    const uint32_t lo = p ? v.all[p - 1] : 0u, hi = v.all[p];
+    return base + (backwards ? hi - 1 - pos : pos - lo);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Bucketed double-diagonal match (replaces the global radix sort + match + flag scan + compaction).
@@ -1043,7 +1112,8 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
                     const uint2 *__restrict__ inKV, uint32_t *__restrict__ outKey,
                     uint32_t *__restrict__ outVal, uint32_t *__restrict__ bktEmit, int *__restrict__ flag,
                     const uint32_t *__restrict__ slotList, uint32_t *__restrict__ bigList, uint32_t *__restrict__ bigCount,
-                    uint32_t bigCap, const uint32_t *__restrict__ qSplit, int vqShift /* query = virtual query >> vqShift */,
+                    uint32_t bigCap, const uint32_t *__restrict__ qSplit, const uint32_t *__restrict__ qParts,
+                    const uint32_t *__restrict__ qSplits, int vqShift /* query = virtual query >> vqShift */,
                     int wpBits /* 0, or (wide stream positions) the virtual query's target bits: the diagonal byte sits in the
                                   key above them and the value is the position */) {
     __shared__ uint32_t eK[CAP], eV[CAP];
@@ -1077,7 +1147,8 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
     }
     const uint64_t start = bktStart[slot];
     const int shift = tBits - (int) qLog2Bins[q];
-    const uint32_t split = qSplit[q >> vqShift];
+    const SplitView sv = splitView(qSplit, qParts, qSplits, q >> vqShift);
+    const bool manyParts = sv.all != nullptr;     // the buffer overflowed more than once: see keep_max_kernel
     const uint32_t offMask = (1u << shift) - 1;   // key & offMask = target offset inside the bucket's range
     const bool WP = wpBits != 0;
     const uint32_t posMask = WP ? 0xFFFFFFFFu : 0xFFFFFFu;
@@ -1182,7 +1253,7 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
         auto flagAt = [&](int x) -> bool {
             const uint8_t dx = (uint8_t) d8of(eK[x], eV[x]);
             bool first = (x == 0) || (((eK[x - 1] ^ eK[x]) & tgtMask) != 0);
-            if (!first) first = ((eV[x - 1] & posMask) < split) != ((eV[x] & posMask) < split);   // overflow split
+            if (!first) first = partOfPos(sv, eV[x - 1] & posMask) != partOfPos(sv, eV[x] & posMask);   // a new part of the hit buffer
             const uint8_t prev = first ? (uint8_t) 0 : (uint8_t) d8of(eK[x - 1], eV[x - 1]);
             return dx == prev;
         };
@@ -1192,6 +1263,9 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
             int x = p;
             while (x > 0 && ((eK[x - 1] ^ eK[p]) & tgtMask) == 0) {
                 x--;
+                // one overflow: the two result lists are merged, equal consecutive diagonals collapse across the split.  More:
+                // every part keeps its own list here, the merges in between are keep_max_kernel's
+                if (manyParts && partOfPos(sv, eV[x] & posMask) != partOfPos(sv, eV[p] & posMask)) break;
                 if (flagAt(x)) {
                     em = ((uint8_t) d8of(eK[x], eV[x])) != d8;
                     break;
@@ -1334,13 +1408,80 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
     cLen[c] = (uint32_t) n;
 }
 
-// K6: keep the first element holding the per-(query,target) maximum of min(255,score)
+// K6: keep the first element holding the per-(query,target) maximum of min(255,score).
+// Queries whose hit buffer overflowed more than once (m >= 2 splits, parts 0..m): the reference merges the carried result list
+// with the new part's at every overflow from the second on -- back to front, so equal neighbouring diagonal bytes collapse onto
+// the LATER element --, scores the merged list and keeps one element per target, the first with the maximal 8-bit score in that
+// reversed order (QueryMatcher.cpp:289-303, CacheFriendlyOperations.cpp:118-150,350-380); the last part is merged front to back
+// (:84-116) and the final keepMaxScoreElementOnly takes the first maximum.  Per target that is: over parts 0 and 1 the LAST
+// candidate in stream order with the maximal score (the last candidate of part 0 leaves first if its diagonal byte equals the
+// first of part 1's); every middle part takes over with its own last maximum unless the carried element scores strictly
+// higher; in the last part the first candidate leaves if its diagonal byte equals the carried element's, and the carried
+// element wins ties.  The head of a (query, target) group walks the group.
 __global__ void __launch_bounds__(256)
-keep_max_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const int32_t *__restrict__ cScore,
-                uint8_t *__restrict__ keep) {
+keep_max_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint32_t *__restrict__ cVal, const int32_t *__restrict__ cScore,
+                uint8_t *__restrict__ keep, int tBits, uint32_t posMask, const uint32_t *__restrict__ qSplit,
+                const uint32_t *__restrict__ qParts, const uint32_t *__restrict__ qSplits, const DiagSrc ds) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nCand) return;
     const uint32_t k = cKey[c];
+    const uint32_t q = k >> tBits;
+    if (qParts[q] >= 2) {
+        if (c > 0 && cKey[c - 1] == k) return;   // the group's head decides for all
+        const SplitView sv = splitView(qSplit, qParts, qSplits, q);
+        const uint32_t m = sv.n;
+        uint32_t e = c;
+        while (e < nCand && cKey[e] == k) e++;
+        auto partOf = [&](uint32_t i) { return partOfPos(sv, cVal[i] & posMask); };
+        auto cnt = [&](uint32_t i) { return min(255, cScore[i]); };
+        auto d8 = [&](uint32_t i) { return (uint32_t) diagOf(ds, q, cVal[i] & posMask, k & ((1u << tBits) - 1)) & 0xFFu; };
+        auto endOfPart = [&](uint32_t i, uint32_t p) {
+            while (i < e && partOf(i) <= p) i++;
+            return i;
+        };
+        // parts 0 and 1
+        const uint32_t b0 = endOfPart(c, 0), b1 = endOfPart(b0, 1);
+        const bool dropLast0 = b0 > c && b1 > b0 && d8(b0 - 1) == d8(b0);
+        uint32_t best = 0xFFFFFFFFu;
+        int bestCnt = -1;
+        for (uint32_t i = c; i < b1; i++) {
+            if (dropLast0 && i == b0 - 1) continue;
+            if (cnt(i) >= bestCnt) {
+                best = i;
+                bestCnt = cnt(i);
+            }
+        }
+        // middle parts 2 .. m - 1
+        uint32_t cur = b1;
+        for (uint32_t p = 2; p + 1 <= m; p++) {
+            const uint32_t b = endOfPart(cur, p);
+            uint32_t lb = 0xFFFFFFFFu;
+            int lc = -1;
+            for (uint32_t i = cur; i < b; i++)
+                if (cnt(i) >= lc) {
+                    lb = i;
+                    lc = cnt(i);
+                }
+            if (lb != 0xFFFFFFFFu && lc >= bestCnt) {
+                best = lb;
+                bestCnt = lc;
+            }
+            cur = b;
+        }
+        // the last part
+        const bool dropFirst = best != 0xFFFFFFFFu && cur < e && d8(cur) == d8(best);
+        uint32_t winner = best;
+        int wc = bestCnt;
+        for (uint32_t i = cur; i < e; i++) {
+            if (dropFirst && i == cur) continue;
+            if (cnt(i) > wc) {
+                winner = i;
+                wc = cnt(i);
+            }
+        }
+        for (uint32_t i = c; i < e; i++) keep[i] = i == winner ? 1 : 0;
+        return;
+    }
     const int mine = min(255, cScore[c]);
     bool ok = true;
     // no earlier element with count >= mine, no later element with count > mine
@@ -1384,7 +1525,8 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
                    const int8_t *__restrict__ qProf /* nullable: profile queries */,
                    uint32_t posMask /* stream position bits of the value word */,
                    int joinBinBits /* -1, or (join path) log2(BINSIZE): the value word orders by k-mer ordinal, hits of one
-                                      k-mer's list by sequence id */) {
+                                      k-mer's list by sequence id */,
+                   const uint32_t *__restrict__ qSplit, const uint32_t *__restrict__ qParts, const uint32_t *__restrict__ qSplits) {
     __shared__ unsigned long long keys[SEL_CAP];
     __shared__ uint32_t pay[SEL_CAP];
     __shared__ unsigned int hist[256];
@@ -1443,14 +1585,18 @@ select_hits_kernel(uint32_t nQ, const uint32_t *__restrict__ kStartOfQ /* nQ+1, 
     };
     // order of the cut: (rescaled) count desc, then the order the reference's counting sort keeps: bin asc, stream
     // position asc
+    const SplitView sv = splitView(qSplit, qParts, qSplits, q);   // more than one overflow: overflowOrderPos
     auto keyOf = [&](uint32_t x) -> unsigned long long {
         const uint32_t sid = kKey[x] & ((1u << tBits) - 1);
         const uint32_t top = rescored ? 255u - rescaledByte(x) : 255u - (uint32_t) min(255, kScore[x]);
-        if (joinBinBits >= 0)
+        bool backwards = false;
+        const uint32_t pos = sv.all ? overflowOrderPos(sv, kVal[x] & posMask, backwards) : kVal[x] & posMask;
+        if (joinBinBits >= 0) {
+            const uint32_t inList = (sid >> joinBinBits) & 0xFFFFFu;
             return ((unsigned long long) top << 56) | ((unsigned long long) (sid & binMask) << 44) |
-                   ((unsigned long long) (kVal[x] & posMask) << 20) | (unsigned long long) ((sid >> joinBinBits) & 0xFFFFFu);
-        return ((unsigned long long) top << 56) | ((unsigned long long) (sid & binMask) << 40) |
-               (unsigned long long) (kVal[x] & posMask);
+                   ((unsigned long long) pos << 20) | (unsigned long long) (backwards ? 0xFFFFFu - inList : inList);
+        }
+        return ((unsigned long long) top << 56) | ((unsigned long long) (sid & binMask) << 40) | (unsigned long long) pos;
     };
     // Only the first maxHits + 1 elements of that order are ever read (at most one of them is the identity target).
     // Usually everything at or above the cut fits the LDS arrays; otherwise (very many tied candidates) the candidate
@@ -2151,7 +2297,11 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, hipMemsetAsync(dStats.p, 0, (size_t) bq * 4 * sizeof(uint64_t), ctx->stream));
         WsView<uint32_t> dQSplit(ctx, "pf.dQSplit");
         WsView<int> dSplitFlag(ctx, "pf.dSplitFlag");
+        WsView<uint32_t> dQParts(ctx, "pf.dQParts");     // overflows of the reference's hit buffer per query, and where (all of them)
+        WsView<uint32_t> dQSplits(ctx, "pf.dQSplits");
         SD_HIP(ctx, dQSplit.alloc(bq));
+        SD_HIP(ctx, dQParts.alloc(bq));
+        SD_HIP(ctx, dQSplits.alloc((size_t) bq * PF_SPLITS_MAX));
         SD_HIP(ctx, dSplitFlag.alloc(1));
         SD_HIP(ctx, hipMemsetAsync(dSplitFlag.p, 0, sizeof(int), ctx->stream));
         std::vector<uint8_t> hUnsupported;
@@ -2204,11 +2354,9 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor(bq, 64)), dim3(256), 0, ctx->stream, dJqCounts.p, JJ_WGS, (int) bq, dQHits.p);
             }
             // overflow of the reference's hit buffer, in k-mer ordinals
-            hipLaunchKernelGGL(query_split_join_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQKmerBase.p,
+            hipLaunchKernelGGL(query_splits_join_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQKmerBase.p,
                                (const uint64_t *) dElems.p, (const uint32_t *) T->dOffsets, (const uint32_t *) dQHits.p, maxDbMatches,
-                               dQSplit.p, dSplitFlag.p);
-            hipLaunchKernelGGL(query_split_check_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQKmerBase.p,
-                               (const uint64_t *) dElems.p, (const uint32_t *) T->dOffsets, maxDbMatches, dQSplit.p, dSplitFlag.p);
+                               dQSplit.p, dQParts.p, dQSplits.p, dSplitFlag.p);
             hipLaunchKernelGGL(join_stats_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQKmerBase.p,
                                (const uint32_t *) dQHits.p, dStats.p);
             std::vector<unsigned long long> hWg(JJ_WGS);
@@ -2231,8 +2379,9 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             for (uint32_t x = 0; x < bq; x++) hStats[(size_t) x * 4 + 1] = hQHits[x];
             nHits = all;
             if (hSplitFlagJ) {
-                // queries that overflow the reference's hit buffer twice (QueryMatcher.cpp:289-303) are taken out of the batch and
-                // reported per query (outCount = UINT32_MAX); the join leaves their lists out
+                // queries the device does not compute (more than PF_SPLITS_MAX overflows of the reference's hit buffer, or a single
+                // index list as large as that buffer) are taken out of the batch and reported per query (outCount = UINT32_MAX); the
+                // join leaves their lists out
                 std::vector<uint32_t> hSplit(bq);
                 SD_HIP(ctx, hipMemcpy(hSplit.data(), dQSplit.p, (size_t) bq * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 hUnsupported.assign(bq, 0);
@@ -2244,8 +2393,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         if (!nBad) firstBad = qBeg + x;
                         nBad++;
                     }
-                sdFail(ctx, SD_EUNSUPPORTED, "%u quer%s of the batch [%u, %u) (first: %u) overflow the reference's hit buffer twice "
-                       "(double-overflow route of QueryMatcher.cpp:289-303): reported with outCount = UINT32_MAX, the rest of the batch is computed",
+                sdFail(ctx, SD_EUNSUPPORTED, "%u quer%s of the batch [%u, %u) (first: %u) overflow the reference's hit buffer more than 32 times or hold "
+                       "an index list as large as that buffer: reported with outCount = UINT32_MAX, the rest of the batch is computed",
                        nBad, nBad == 1 ? "y" : "ies", qBeg, qBeg + bq, firstBad);
             }
             // per-query segments of the hit array (the layout the bucket machinery takes), then the scatter pass of the join
@@ -2278,14 +2427,14 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         // the reference's hit buffer holds maxDbMatches entries per query; where a query overflows it once, the match runs
         // on the two parts separately (query_split_kernel); two overflows are not implemented
         hipLaunchKernelGGL(query_split_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
-                           dHitBase.p, maxDbMatches, dQSplit.p, dSplitFlag.p, posLimit);
+                           dHitBase.p, maxDbMatches, dQSplit.p, dQParts.p, dQSplits.p, dSplitFlag.p, posLimit);
         int hSplitFlag = 0;
         SD_HIP(ctx, hipMemcpyAsync(&hSplitFlag, dSplitFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, hipMemcpyAsync(hStats.data(), dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(ctx, sdStreamSync(ctx));
         if (hSplitFlag) {
-            // Queries that overflow the reference's hit buffer twice (the double-overflow route of QueryMatcher.cpp:289-303) or
-            // have >= 2^32 index hits cannot be computed here.  They are taken out of the batch -- their index lists emptied,
+            // Queries with >= 2^32 index hits (or more than PF_SPLITS_MAX overflows of the reference's hit buffer, or an index list as
+            // large as that buffer) cannot be computed here.  They are taken out of the batch -- their index lists emptied,
             // offsets re-scanned -- and reported per query (outCount = UINT32_MAX); every other query is computed as usual.
             std::vector<uint32_t> hSplit(bq);
             SD_HIP(ctx, hipMemcpy(hSplit.data(), dQSplit.p, (size_t) bq * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -2297,8 +2446,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     if (!nBad) firstBad = qBeg + x;
                     nBad++;
                 }
-            sdFail(ctx, SD_EUNSUPPORTED, "%u quer%s of the batch [%u, %u) (first: %u) overflow the reference's hit buffer twice or have >= 2^32 index "
-                   "hits (double-overflow route of QueryMatcher.cpp:289-303): reported with outCount = UINT32_MAX, the rest of the batch is computed",
+            sdFail(ctx, SD_EUNSUPPORTED, "%u quer%s of the batch [%u, %u) (first: %u) have >= 2^32 index hits or overflow the reference's hit buffer "
+                   "more than 32 times: reported with outCount = UINT32_MAX, the rest of the batch is computed",
                    nBad, nBad == 1 ? "y" : "ies", qBeg, qBeg + bq, firstBad);
             hipLaunchKernelGGL(drop_query_kmers_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKPos.p, dQSplit.p, dKLen.p);
             int rc2 = exclusiveScanWiden(ctx, dKLen.p, dHitBase.p, nKmers + 1, scanTmp);
@@ -2306,7 +2455,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             SD_HIP(ctx, hipMemcpyAsync(&nHits, dHitBase.p + nKmers, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             SD_HIP(ctx, hipMemsetAsync(dSplitFlag.p, 0, sizeof(int), ctx->stream));
             hipLaunchKernelGGL(query_split_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
-                               dHitBase.p, maxDbMatches, dQSplit.p, dSplitFlag.p, posLimit);
+                               dHitBase.p, maxDbMatches, dQSplit.p, dQParts.p, dQSplits.p, dSplitFlag.p, posLimit);
             SD_HIP(ctx, sdStreamSync(ctx));
         }
         }   // lookup path
@@ -2467,7 +2616,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         hipLaunchKernelGGL((bucket_match_kernel<128, PF_BUCKET_CAP>), dim3((unsigned) totalBins), dim3(128), 0, ctx->stream,
                                            nVQ, dBinBase.p, dQLog2.p, tBitsV, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p,
                                            dValA.p, dBktEmit.p, dFlag.p, (const uint32_t *) nullptr, dBigList.p, dBigCount, bigCap,
-                                           dQSplit.p, cBits, widePos ? tBitsV : 0);
+                                           dQSplit.p, dQParts.p, dQSplits.p, cBits, widePos ? tBitsV : 0);
                     }
                     uint32_t nBig = 0;
                     SD_HIP(ctx, hipMemcpyAsync(&nBig, dBigCount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2477,7 +2626,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         hipLaunchKernelGGL((bucket_match_kernel<256, PF_BUCKET_CAP_BIG>), dim3(nBig), dim3(256), 0, ctx->stream, nVQ,
                                            dBinBase.p, dQLog2.p, tBitsV, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, dKeyA.p, dValA.p,
                                            dBktEmit.p, dFlag.p, (const uint32_t *) dBigList.p, (uint32_t *) nullptr,
-                                           (uint32_t *) nullptr, 0u, dQSplit.p, cBits, widePos ? tBitsV : 0);
+                                           (uint32_t *) nullptr, 0u, dQSplit.p, dQParts.p, dQSplits.p, cBits, widePos ? tBitsV : 0);
                     }
                     rc = exclusiveScanWiden(ctx, dBktEmit.p, dEmitOff.p, nSlots + 1, scanTmp);
                     if (rc != SD_OK) return rc;
@@ -2540,6 +2689,22 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             nCand = (uint32_t) nc64;
             }
         }
+        if (!bucketDone && nHits > 0) {
+            // the global-sort fallback matches across one split only: queries whose hit buffer overflows more than once are
+            // reported there, not guessed
+            std::vector<uint32_t> hParts(bq);
+            SD_HIP(ctx, hipMemcpy(hParts.data(), dQParts.p, (size_t) bq * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            bool any = false;
+            for (uint32_t x = 0; x < bq; x++)
+                if (hParts[x] >= 2) {
+                    if (hUnsupported.empty()) hUnsupported.assign(bq, 0);
+                    hUnsupported[x] = 1;
+                    any = true;
+                }
+            if (any)
+                sdFail(ctx, SD_EUNSUPPORTED, "queries whose hit buffer overflows more than once in a sub-batch that fell back to the global sort "
+                       "(batch [%u, %u)): reported with outCount = UINT32_MAX", qBeg, qBeg + bq);
+        }
         if (widePos && !bucketDone) {
             // the global-sort fallback carries 24-bit positions only: the heavy queries of this sub-batch are reported, not guessed
             if (hUnsupported.empty()) hUnsupported.assign(bq, 0);
@@ -2592,7 +2757,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             SD_HIP(ctx, dKeep.alloc(nCand));
             {
                 ProfScope ps(ctx, "prefilter_keep_max");
-                hipLaunchKernelGGL(keep_max_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCScore.p, dKeep.p);
+                hipLaunchKernelGGL(keep_max_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p, dCScore.p, dKeep.p,
+                                   tBits, posMask, (const uint32_t *) dQSplit.p, (const uint32_t *) dQParts.p, (const uint32_t *) dQSplits.p, diagSrc);
             }
         WsView<uint64_t> dK64(ctx, "pf.dK64");
         WsView<uint64_t> dKPos64(ctx, "pf.dKPos64");
@@ -2630,11 +2796,13 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             if (maxHits + 1 <= 2048)
                 hipLaunchKernelGGL(select_hits_kernel<4096>, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
                                    diagSrc, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
-                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask, useJoin ? binBits : -1);
+                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask, useJoin ? binBits : -1,
+                                   (const uint32_t *) dQSplit.p, (const uint32_t *) dQParts.p, (const uint32_t *) dQSplits.p);
             else   // up to 4 095 hits per query (--max-seqs 2N beyond ~1 000 proteomes)
                 hipLaunchKernelGGL(select_hits_kernel<8192>, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
                                    diagSrc, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
-                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask, useJoin ? binBits : -1);
+                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask, useJoin ? binBits : -1,
+                                   (const uint32_t *) dQSplit.p, (const uint32_t *) dQParts.p, (const uint32_t *) dQSplits.p);
         }
         SD_HIP(ctx, hipGetLastError());
         hs.reset(new HostScope(ctx, "pf.download"));

@@ -262,46 +262,48 @@ def test_prefilter_sequences_of_32768_residues_and_more(gpu, host, oracle):
     assert long_rows > 40
 
 
-def test_prefilter_double_overflow_is_a_per_query_error_slot(gpu, host, oracle):
-    """a query whose index hits overflow the reference's hit buffer twice (QueryMatcher.cpp:289-303) is not computed on the
-    device: it is reported through its own count slot (UINT32_MAX) and sd_last_error, and the other queries of the same
-    batch come back complete and equal to the oracle -- never a batch-fatal error (the target is the overflow fixture
-    twice over: 4.96 * 10^6 index hits for query 0 against the 2 * 10^6-entry buffer)"""
-    g = np.load(os.path.join(GOLD, 'overflow_vectors.npz'))
-    off1 = g['off']
+def test_prefilter_repeated_overflow_matches_reference(gpu, host, oracle, monkeypatch):
+    """a query whose index hits overflow the reference's hit buffer two and three times (QueryMatcher.cpp:281-316 with the
+    merge / score / keep-one-per-target branch :289-303) is computed on the device -- through the k-mer-major join and through
+    the index-lookup path, coarse split included -- and equals rows of the real reference (tests/golden/overflow2_vectors.npz,
+    tools/make_golden_overflow2.py: query 0 has 6.45 * 10^6 index hits against the 2 * 10^6-entry buffer); in the global-sort
+    fallback such a query is reported through its count slot, and the others of the batch are still complete"""
+    g = np.load(os.path.join(GOLD, 'overflow2_vectors.npz'))
+    off = g['off']
     blob = g['blob'].tobytes().decode()
-    nums = [oracle.map_sequence(blob[int(off1[i]):int(off1[i + 1])]) for i in range(len(off1) - 1)]
-    nums = nums + nums
-    off = np.zeros(len(nums) + 1, np.uint64)
-    off[1:] = np.cumsum([len(x) for x in nums])
+    nums = [oracle.map_sequence(blob[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
     res = np.concatenate(nums)
     sw_b, dg_b, km_b = host.comp_bias(res, off)
     idx = host.build_index(res, off)
     tgt = api.Target(gpu, host, idx)
     par = api.prefilter_params(host, idx.n, max_hits=300, cov_thr=0.0, bin_size=2)
-    qs = [1, 0, 10005, 5, 10030]
+    qs = [int(q) for q in g['queries']]
     qoff = np.zeros(len(qs) + 1, np.uint64)
     qoff[1:] = np.cumsum([len(nums[q]) for q in qs])
     qres = np.concatenate([nums[q] for q in qs])
     qkm = np.concatenate([km_b[int(off[q]):int(off[q + 1])] for q in qs])
     qdg = np.concatenate([dg_b[int(off[q]):int(off[q + 1])] for q in qs])
-    hits, cnt, st = api.prefilter(gpu, tgt, par, qres, qoff, qkm, qdg, np.array(qs, np.uint32), want_stats=True)
-    assert int(st[1, 1]) >= 4000000
-    assert int(cnt[1]) == 0xFFFFFFFF
-    assert 'QueryMatcher.cpp:289-303' in gpu.last_error()
-    ot = oracle.target(res, off)
-    computed = 0
-    for x, q in enumerate(qs):
-        try:
-            ids, sc, dg, _ = ot.prefilter(nums[q], identity_id=q, max_hits=300, bin_size=2)
-        except RuntimeError as e:   # the oracle does not restate the double-overflow route either (code -2)
-            assert 'code -2' in str(e) and int(cnt[x]) == 0xFFFFFFFF, (q, str(e), int(cnt[x]))
-            continue
-        n = int(cnt[x])
-        computed += 1
-        assert n == len(ids) and n > 0, (q, n, len(ids))
-        assert (hits[x, :n]['seqId'] == ids).all() and (hits[x, :n]['score'] == sc).all() and (hits[x, :n]['diagonal'] == dg).all(), q
-    assert computed >= 3
+    rows = g['pf_rows']
+    stats = g['stats']
+    for mode in ('join', 'lookup', 'coarse', 'sort'):
+        if mode == 'lookup':
+            monkeypatch.setenv('SD_PF_JOIN', '0')
+        if mode == 'coarse':
+            monkeypatch.setenv('SD_PF_COARSE', '300000')
+        if mode == 'sort':
+            monkeypatch.delenv('SD_PF_COARSE')
+            monkeypatch.setenv('SD_PF_SORT', '1')
+        hits, cnt, st = api.prefilter(gpu, tgt, par, qres, qoff, qkm, qdg, np.array(qs, np.uint32), want_stats=True)
+        for x, q in enumerate(qs):
+            assert int(st[x, 1]) == int(stats[x, 2]), (mode, q, st[x], stats[x])
+            exp = rows[rows[:, 0] == q]
+            m = int(cnt[x])
+            if mode == 'sort' and int(st[x, 1]) > 4000000:
+                assert m == 0xFFFFFFFF and 'more than once' in gpu.last_error(), (mode, q, m)
+                continue
+            assert m == len(exp), (mode, q, m, len(exp))
+            assert (hits[x, :m]['seqId'] == exp[:, 1]).all() and (hits[x, :m]['score'] == exp[:, 2]).all(), (mode, q)
+            assert (hits[x, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (mode, q)
 
 
 @pytest.mark.parametrize('bin_size,max_hits,min_diag', [(4, 300, 15), (64, 7, 15), (2048, 300, 40), (2, 1, 15)])
