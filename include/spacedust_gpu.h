@@ -163,6 +163,21 @@ int sd_target_create_wide(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets
                           const uint32_t *entrySeq, const uint16_t *entryPos, uint64_t nEntries, const uint8_t *maskedResidues,
                           const uint64_t *seqOffsets, uint32_t nSeq, const int16_t *ext2Score, const uint16_t *ext2Index,
                           const int16_t *ext3Score, const uint16_t *ext3Index, sd_target **out);
+/* The same target built ON THE DEVICE from the unmasked residues: tantan masking (M/src/commons/Masker.cpp:15-55,
+ * M/lib/tantan/tantan.cpp:308-460), k-mer collection with the self-score threshold, one entry per (k-mer, target) at the
+ * smallest position, lists in (target, position) order (IndexBuilder::fillDatabase, M/src/prefiltering/IndexBuilder.cpp:55-239,
+ * IndexTable.h:131-189,376-392) -- replaces sd_host_build_index + sd_target_create_wide (minutes of host time for 10^4
+ * proteomes).  residues: host or device pointer.  maskRatios / selfScore: sd_host_index_tables.  The result equals the
+ * host-built index entry for entry (tests/test_gpu_index_build.py); the wide form is chosen from the entry count.
+ * stats (nullable): [0] entries, [1] masked residues, [2] k-mer range passes, [3] k-mer records before the per-target dedupe. */
+int sd_target_build(sd_ctx *ctx, int kmerSize, int kmerThr, int mask, double maskProb, const uint8_t *residues,
+                    const uint64_t *seqOffsets, uint32_t nSeq, const double *maskRatios, const int8_t *selfScore,
+                    const int16_t *ext2Score, const uint16_t *ext2Index, const int16_t *ext3Score, const uint16_t *ext3Index,
+                    sd_target **out, uint64_t *stats);
+/* what a target holds on the device (any pointer may be NULL): masked residues, absolute list starts (tableSize + 1),
+ * entries as (sequence id, position) */
+int sd_target_download(sd_ctx *ctx, const sd_target *t, uint64_t *nEntries, uint64_t *tableSize, uint8_t *masked, uint64_t *starts,
+                       uint32_t *entrySeq, uint16_t *entryPos);
 void sd_target_destroy(sd_target *t);
 
 /* Replaces the per-query loop body of Prefiltering::runSplit (Prefiltering.cpp:817-886), i.e.
@@ -251,6 +266,9 @@ int sd_comp_bias_batch(sd_ctx *ctx, sd_host *h, const uint8_t *residues, const u
 
 /* IndexBuilder::fillDatabase (mask + count + fill), returns an index handle to read back */
 typedef struct sd_host_index sd_host_index;
+/* the two host tables sd_target_build takes: tantan's likelihood ratios of the seed matrix (BaseMatrix.h:85-96) and the
+ * k-mer self scores (IndexBuilder.cpp:10-21) */
+int sd_host_index_tables(sd_host *h, double *maskRatios /* 21 x 21 */, int8_t *selfScore /* 21 */);
 int sd_host_index_build(sd_host *h, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int kmerSize,
                         int kmerThr, int mask, double maskProb, sd_host_index **out);
 int sd_host_index_info(sd_host_index *ix, uint64_t *tableSize, uint64_t *nEntries, uint64_t *maskedResidues);

@@ -141,6 +141,10 @@ def load():
                                             _vp, C.POINTER(_vp)]),
         'sd_host_index_block_base': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64)]),
         'sd_target_destroy': (None, [_vp]),
+        'sd_target_build': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      C.POINTER(_vp), _vp]),
+        'sd_target_download': (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _vp, _vp, _vp, _vp]),
+        'sd_host_index_tables': (C.c_int, [_vp, _vp, _vp]),
         'sd_device_memory': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_prefilter_batch': (C.c_int, [_vp, _vp, C.POINTER(PrefilterParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _vp]),

@@ -404,6 +404,43 @@ class Target:
         self.h = h
         self.n = index.n
 
+    @classmethod
+    def build_on_device(cls, ctx, host, residues, offsets, k=6, kmer_thr=112, mask=True, mask_prob=0.9):
+        """sd_target_build: masking, k-mer collection and list construction on the GPU (no host index)"""
+        self = cls.__new__(cls)
+        self.ctx, self.host, self.index = ctx, host, None
+        residues = np.ascontiguousarray(residues, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        s2, i2, _ = host.ext_matrix(2)
+        s3, i3, _ = host.ext_matrix(3)
+        lr = np.zeros(441, np.float64)
+        self_score = np.zeros(21, np.int8)
+        _check(None, host.L.sd_host_index_tables(host.h, ptr(lr), ptr(self_score)), 'sd_host_index_tables')
+        h = C.c_void_p()
+        stats = np.zeros(4, np.uint64)
+        _check(ctx.h, ctx.L.sd_target_build(ctx.h, k, kmer_thr, 1 if mask else 0, mask_prob, ptr(residues), ptr(offsets), len(offsets) - 1,
+                                            ptr(lr), ptr(self_score), ptr(s2), ptr(i2), ptr(s3), ptr(i3), C.byref(h), ptr(stats)),
+               'sd_target_build')
+        self.h = h
+        self.n = len(offsets) - 1
+        self.k = k
+        self.total = int(offsets[-1])
+        self.build_stats = dict(entries=int(stats[0]), masked_residues=int(stats[1]), passes=int(stats[2]), records=int(stats[3]))
+        return self
+
+    def download(self, entries=True):
+        """the device's copy of the index: dict(n_entries, masked, starts [tableSize + 1], entry_seq, entry_pos)"""
+        ne, ts = C.c_uint64(), C.c_uint64()
+        _check(self.ctx.h, self.ctx.L.sd_target_download(self.ctx.h, self.h, C.byref(ne), C.byref(ts), None, None, None, None), 'sd_target_download')
+        total = self.total if getattr(self, 'total', None) is not None else int(self.index.offsets[-1])
+        out = dict(n_entries=ne.value, masked=np.zeros(total, np.uint8), starts=np.zeros(ts.value + 1, np.uint64))
+        es = np.zeros(ne.value if entries else 0, np.uint32)
+        ep = np.zeros(ne.value if entries else 0, np.uint16)
+        _check(self.ctx.h, self.ctx.L.sd_target_download(self.ctx.h, self.h, None, None, ptr(out['masked']), ptr(out['starts']),
+                                                         ptr(es) if entries else None, ptr(ep) if entries else None), 'sd_target_download')
+        out['entry_seq'], out['entry_pos'] = es, ep
+        return out
+
     def __del__(self):
         try:
             self.ctx.L.sd_target_destroy(self.h)

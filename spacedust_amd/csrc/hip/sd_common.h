@@ -118,6 +118,27 @@ struct sd_seqset {
     std::vector<int8_t> hBias;
 };
 
+// the target side of the prefilter, resident in HBM (built by sd_target_create* from host arrays or by sd_target_build on the device)
+struct sd_target {
+    sd_ctx *ctx = nullptr;
+    int k = 6;
+    uint32_t nSeq = 0;
+    uint64_t nEntries = 0;
+    uint64_t tableSize = 0;
+    uint32_t *dOffsets = nullptr;
+    uint64_t *dBlockBase = nullptr;  // wide indexes (>= 2^32 entries): list i starts at dBlockBase[i >> 16] + dOffsets[i]
+    uint32_t *dEntrySeq = nullptr;   // upload staging only (freed after the interleaved copy is built)
+    uint16_t *dEntryPos = nullptr;
+    uint2 *dEntries = nullptr;       // (seqId, position) per index entry, 8 B: one sector per short list instead of two
+    uint8_t *dMasked = nullptr;
+    uint64_t *dSeqOff = nullptr;
+    int16_t *dExt3Score = nullptr;
+    uint16_t *dExt3Index = nullptr;
+    int16_t *dExt2Score = nullptr;
+    uint16_t *dExt2Index = nullptr;
+    std::vector<uint64_t> hSeqOff;
+};
+
 int sdFail(sd_ctx *ctx, int code, const char *fmt, ...);
 
 #define SD_HIP(ctx, call)                                                                          \

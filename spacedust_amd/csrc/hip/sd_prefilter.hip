@@ -25,25 +25,6 @@
 #include <algorithm>
 #include <cstring>
 
-struct sd_target {
-    sd_ctx *ctx = nullptr;
-    int k = 6;
-    uint32_t nSeq = 0;
-    uint64_t nEntries = 0;
-    uint64_t tableSize = 0;
-    uint32_t *dOffsets = nullptr;
-    uint64_t *dBlockBase = nullptr;  // wide indexes (>= 2^32 entries): list i starts at dBlockBase[i >> 16] + dOffsets[i]
-    uint32_t *dEntrySeq = nullptr;   // upload staging only (freed after the interleaved copy is built)
-    uint16_t *dEntryPos = nullptr;
-    uint2 *dEntries = nullptr;       // (seqId, position) per index entry, 8 B: one sector per short list instead of two
-    uint8_t *dMasked = nullptr;
-    uint64_t *dSeqOff = nullptr;
-    int16_t *dExt3Score = nullptr;
-    uint16_t *dExt3Index = nullptr;
-    int16_t *dExt2Score = nullptr;
-    uint16_t *dExt2Index = nullptr;
-    std::vector<uint64_t> hSeqOff;
-};
 
 namespace {
 

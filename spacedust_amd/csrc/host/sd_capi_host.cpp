@@ -44,6 +44,18 @@ int sd_host_matrix(sd_host *h, int which, int8_t *out, double *pBack, uint8_t *a
     return SD_OK;
 }
 
+// the two host tables sd_target_build needs: tantan's likelihood ratios of the seed matrix (BaseMatrix.h:85-96) and the k-mer
+// self scores of IndexBuilder.cpp:10-21
+int sd_host_index_tables(sd_host *h, double *maskRatios /* 21 x 21 */, int8_t *selfScore /* 21 */) {
+    if (!h || !maskRatios || !selfScore) return SD_EINVAL;
+    sd::MaskCtx mc;
+    sd::initMaskCtx(h->seed8, mc);
+    for (int i = 0; i < 21; i++)
+        for (int j = 0; j < 21; j++) maskRatios[i * 21 + j] = mc.lr[i][j];
+    for (int a = 0; a < 21; a++) selfScore[a] = (int8_t) (char) h->seed8.sub[a][a];
+    return SD_OK;
+}
+
 int sd_host_map_sequence(sd_host *h, const char *ascii, uint64_t len, uint8_t *out) {
     sd::mapSequence(h->blosum2, ascii, len, out);
     return SD_OK;
