@@ -9,7 +9,7 @@ One *step* = clustersearch of one batch of query proteomes against all P target 
 N ranks (one process per GPU, `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) run BASELINE
 configs[2]'s structure: a global step holds N*B query proteomes, dealt to the ranks as whole query sets by
 sd_shard_query_sets (greedy by residues; a set's hits stay on one rank); every rank searches its sets against its own replica
-of the target -- the index is built ONCE on rank 0 and broadcast over RCCL -- and at the end of the timed region the real
+of the target -- every rank builds the index on its own GPU (sd_target_build) -- and at the end of the timed region the real
 per-entry result records are gathered to rank 0 over RCCL (sd_comm_* / sd_gather_results of the C ABI).  No collective on
 the data path.  Per-GPU work is fixed as N grows: "scaling": "weak".
 
@@ -57,6 +57,12 @@ def parse():
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--no-p1000', action='store_true', help='skip the 1 000-proteome record')
     ap.add_argument('--p1000-steps', type=int, default=5)
+    ap.add_argument('--no-p10000', action='store_true', help='skip the 10 000-proteome record')
+    ap.add_argument('--p10000-steps', type=int, default=1)
+    ap.add_argument('--p10000-batch', type=int, default=2, help='query proteomes per step of the 10 000-proteome record')
+    ap.add_argument('--no-iter3', action='store_true', help='skip the --num-iterations 3 record (BASELINE configs[3] at 1 000 target proteomes)')
+    ap.add_argument('--iter3-queries', type=int, default=2, help='query proteomes of the --num-iterations 3 record')
+    ap.add_argument('--no-index-check', action='store_true', help='skip the sampled check of the device-built index against the host builder')
     ap.add_argument('--strong', action='store_true', help='strong scaling: --batch query proteomes per step in TOTAL, dealt over the ranks '
                                                           '(BASELINE configs[2] as written: one query set of proteomes split over N GPUs)')
     ap.add_argument('--record', action='store_true', help=argparse.SUPPRESS)   # child mode: one plain measurement, JSON out
@@ -85,7 +91,7 @@ def cpu_baseline_subprocess(proteomes, genes, max_seqs, kmer_thr, bin_size, entr
         return dict(value=None, unit='genome-pairs/s', cores=0, kind='failed', sample=repr(e))
 
 
-def parity_check(gpu, host, ps, index, max_seqs, bin_size, kmer_thr, check_path):
+def parity_check(gpu, host, ps, k, max_seqs, bin_size, kmer_thr, check_path):
     """untimed post-check: the device's prefilter rows and alignments of the sample queries the cpu_baseline leg ran
     through the reference (libsdref), compared field by field"""
     from spacedust_amd import api
@@ -97,9 +103,9 @@ def parity_check(gpu, host, ps, index, max_seqs, bin_size, kmer_thr, check_path)
     qoff = np.zeros(len(queries) + 1, np.uint64)
     qoff[1:] = np.cumsum(lens[queries])
     qres = np.concatenate([ps.residues[int(ps.offsets[q]):int(ps.offsets[q + 1])] for q in queries])
-    sw_b, dg_b, km_b = host.comp_bias(qres, qoff)
-    tgt = api.Target(gpu, host, index)
-    par = api.prefilter_params(host, ps.n, kmer_thr=kmer_thr, max_hits=max_seqs, bin_size=bin_size)
+    sw_b, dg_b, km_b = host.comp_bias(qres, qoff, k=k)
+    tgt = api.Target.build_on_device(gpu, host, ps.residues, ps.offsets, k=k, kmer_thr=kmer_thr)
+    par = api.prefilter_params(host, ps.n, kmer_thr=kmer_thr, max_hits=max_seqs, bin_size=bin_size, k=k)
     hits, cnt, _ = api.prefilter(gpu, tgt, par, qres, qoff, km_b, dg_b, queries.astype(np.uint32))
     bad_rows = n_rows = 0
     for x in range(len(queries)):
@@ -148,46 +154,22 @@ def measure(args, rank, local_rank, world, dist, torch):
     t_gen = time.time() - t0
     db = SetDB.from_proteomes(ps)
     max_seqs = args.max_seqs if args.max_seqs > 0 else max(300, 2 * P)
-    # the target index: built once (rank 0, all of the node's cores while the others wait) and broadcast
+    # the target index is built on every rank's own GPU from the residues (sd_target_build: masking, k-mer lists, list starts):
+    # no host index, nothing to broadcast
     t0 = time.time()
-    index = None
     k = host.auto_kmer_size(int(ps.offsets[-1]))
     kmer_thr = host.kmer_threshold(5.7, k)
-    index_how = 'built on this rank'
-    if dist is None or rank == 0:
-        full = Host(effective_cpus()) if world > 1 else host
-        index = full.build_index(ps.residues, ps.offsets, k, kmer_thr)
-        index_how = 'built once on rank 0 (%d threads)' % full.threads
-    if dist is not None:
-        # device to device: rank 0's arrays go up once, every rank makes its target resident from the device buffers
-        # (sd_target_create takes device pointers) -- no host copy of the index on the receiving ranks
-        from spacedust_amd.api import IndexArrays, DeviceArray
-        meta = torch.zeros(4, dtype=torch.int64)
-        if rank == 0:
-            meta[0], meta[1], meta[2] = index.table_size, index.n_entries, index.masked_residues
-            meta[3] = 0 if index.block_base is None else len(index.block_base)
-        meta = to_dev(meta)
-        dist.broadcast(meta, 0)
-        table_size, n_entries, n_masked, n_bb = (int(v) for v in meta.cpu().tolist())
-        arrays, nbytes = [], 0
-        for name, dt, n in (('kmer_offsets', np.uint32, table_size + 1), ('entry_seq', np.uint32, n_entries),
-                            ('entry_pos', np.uint16, n_entries), ('masked', np.uint8, int(ps.offsets[-1])), ('block_base', np.uint64, n_bb)):
-            if n == 0:
-                arrays.append(None)
-                continue
-            if rank == 0:
-                src = np.ascontiguousarray(getattr(index, name)).view(np.uint8)
-                t = torch.from_numpy(src.copy() if rehearsal else src)   # (the host index object owns its arrays: a view must not outlive it)
-            else:
-                t = torch.empty(n * np.dtype(dt).itemsize, dtype=torch.uint8)
-            t = to_dev(t)
-            dist.broadcast(t, 0)
-            nbytes += t.numel()
-            arrays.append(t.numpy().view(dt) if rehearsal else DeviceArray(t, n))
-        index_how += ', broadcast %s (%.2f GB), targets created from the device buffers' % ('over gloo' if rehearsal else 'device to device over RCCL', nbytes / 1e9)
-        index = IndexArrays(k, kmer_thr, ps.offsets, arrays[0], arrays[1], arrays[2], arrays[3], masked_residues=n_masked, block_base=arrays[4])
-    t_index = time.time() - t0
-    cs = ClusterSearch(gpu, host, db, max_seqs=max_seqs, filter_self_match=True, chunk_queries=args.chunk, index=index)
+    index_how = 'built on every rank\'s GPU (sd_target_build)'
+    cs = ClusterSearch(gpu, host, db, max_seqs=max_seqs, filter_self_match=True, chunk_queries=args.chunk)
+    t_index = time.time() - t0   # contexts, index build on the device, target sequences
+    index_check = None
+    if rank == 0 and not args.no_index_check:
+        # untimed: the device-built index against the host builder (IndexBuilder restatement) on 9 600 sample sequences --
+        # every host entry present, nothing else for these sequences, masked residues equal
+        t1 = time.time()
+        index_check = cs.target_view().sample_check(host, ps.residues, ps.offsets, kmer_thr)
+        index_check['seconds'] = time.time() - t1
+        index_check['against'] = 'sd_host_index_build (host restatement of IndexBuilder::fillDatabase, pinned on libsdref in tests/)'
     n_global = B if args.strong else world * B
     n_batches = (P + n_global - 1) // n_global
     set_start = ps.set_start
@@ -316,8 +298,8 @@ def measure(args, rank, local_rank, world, dist, torch):
     # VALU issue peak (sw_valu).
     K, H, Cn = st['kmers'], st['index_hits'], st['diagonals']
     n_sub = max(kernels.get('prefilter_emit_kmers', dict(launches=1))['launches'], 1)
-    tab = 4 * (index.table_size + 1)
-    ent = 8 * index.n_entries
+    tab = 4 * ((20 ** k) + 1)
+    ent = 8 * cs.index_entries
     join = 'prefilter_join_scatter' in kernels
     alg_of = {'prefilter_count_kmers': 21 * q_len_sum,
               'prefilter_emit_kmers': 8 * K if join else 16 * K + 0,
@@ -381,6 +363,10 @@ def measure(args, rank, local_rank, world, dist, torch):
                        peak=sw_valu['peak_lane_instr_per_s'] / 1e12, unit='T lane-instr/s', frac=sw_valu['frac'], kernel_ms=sw_ms,
                        hbm_achieved_GBs=b_sw / sw_ms / 1e6 if sw_ms > 0 else 0.0,
                        note='integer DP in VGPR/LDS: priced against the measured VALU issue peak (tools/valu_peak.py), not HBM')
+    not_computed = int(cs._raw_stats()[0][14])   # per-query error slots of the prefilter (sd_search: counted, never silent)
+    if not_computed:
+        raise RuntimeError('%d queries were not computed by the prefilter (e.g. --max-seqs beyond 4 095): this is not a valid record' % not_computed)
+    mem = gpu.device_memory()   # target index + sequences + the pipeline's workspaces, after the timed steps
     res = {
         'metric': 'clustersearch throughput (genome-pairs/s; SW GCUPS alongside)',
         'value': pairs_total / dt_max,
@@ -411,9 +397,11 @@ def measure(args, rank, local_rank, world, dist, torch):
         'stage_wall_s': stage,
         'host_cpu_s_per_step': round(host_cpu_s / max(1, args.steps), 3),
         'results': {'entries': int(summary[0]), 'matched_hits': int(summary[1]), 'clusters': int(summary[2]),
-                    'cluster_hits': int(summary[3])},
-        'setup_s': {'generate': t_gen, 'index': t_index, 'upload': cs.timing['upload_s']},
+                    'cluster_hits': int(summary[3]), 'queries_not_computed': not_computed},
+        'setup_s': {'generate': t_gen, 'index': cs.timing['index_build_s'], 'index_where': 'device (sd_target_build)', 'search_create': t_index,
+                    'upload': cs.timing['upload_s']},
         'device': gpu.device_name(),
+        'device_memory': dict(zip(('resident_GB', 'total_GB'), ((mem[1] - mem[0]) / 1e9, mem[1] / 1e9))),
         'host_cores': os.cpu_count(),
         'host_cpu_quota': effective_cpus(),
         'cpu_note': 'this box exposes %d logical CPUs but a cgroup quota of %d: cpu_baseline runs on (and is quoted against) %d threads'
@@ -424,7 +412,8 @@ def measure(args, rank, local_rank, world, dist, torch):
                          'payload': 'cluster records (sd_search_result_records): per cluster sets, P-values, members with alignment fields', 'tsv': tsv_info}
         res['multi_gpu_note'] = ('%s scaling over query sets; an 8-GPU curve exists only where the driver ran this command with --gpus 8'
                                  % ('strong (BASELINE configs[2] as written)' if args.strong else 'weak'))
-    extras = dict(ps=ps, index=index, max_seqs=max_seqs, kmer_thr=kmer_thr, bin_size=int(cs.bin_size), gpu=gpu, host=host,
+    res['index_check'] = index_check
+    extras = dict(ps=ps, k=k, max_seqs=max_seqs, kmer_thr=kmer_thr, bin_size=int(cs.bin_size), gpu=gpu, host=host,
                   last=outs[-1] if outs else None, db=db)
     del cs
     return res, extras
@@ -464,7 +453,7 @@ def main():
                                                       args.cpu_seconds, args.cpu_threads or effective_cpus(), check=24, check_out=chk)
         try:
             if os.path.exists(chk):
-                res['parity_check'] = parity_check(ex['gpu'], ex['host'], ex['ps'], ex['index'], ex['max_seqs'], ex['bin_size'],
+                res['parity_check'] = parity_check(ex['gpu'], ex['host'], ex['ps'], ex['k'], ex['max_seqs'], ex['bin_size'],
                                                    ex['kmer_thr'], chk)
             else:
                 res['parity_check'] = dict(queries=0, note='the reference library did not travel or the CPU leg failed')
@@ -474,7 +463,7 @@ def main():
             if os.path.exists(f):
                 os.remove(f)
     del ex
-    if args.record:   # child of the p1000 leg
+    if args.record:   # child of the p1000 / p10000 leg
         print(json.dumps(res))
         return
     if world == 1 and not args.no_p1000 and args.proteomes != 1000:
@@ -499,6 +488,40 @@ def main():
                 res['p1000'] = dict(error=(p.stderr or p.stdout)[-300:])
         except Exception as e:
             res['p1000'] = dict(error=repr(e)[:300])
+    if world == 1 and not args.no_p10000 and not args.no_p1000 and args.proteomes not in (1000, 10000):
+        # BASELINE configs[4]: 10 000 proteomes (3 * 10^7 sequences, 9 * 10^9 residues, k = 7) resident on this one GPU -- generated,
+        # indexed on the device, checked on a sample against the host builder, and searched for a short step
+        cmd = [sys.executable, os.path.abspath(__file__), '--record', '--proteomes', '10000', '--steps', str(args.p10000_steps), '--warmup', '1',
+               '--batch', str(args.p10000_batch), '--chunk', str(args.chunk), '--max-seqs', '4000', '--no-p1000', '--no-p10000', '--no-cpu']
+        try:
+            t0 = time.time()
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+            line = [l for l in p.stdout.splitlines() if l.startswith('{')]
+            if p.returncode == 0 and line:
+                r = json.loads(line[-1])
+                res['p10000'] = {k: r.get(k) for k in ('value', 'unit', 'steps', 'ms_per_step', 'config', 'sw_gcups', 'index_check', 'results',
+                                                       'setup_s', 'host_cpu_s_per_step', 'device_memory')}
+                res['p10000']['wall_s'] = time.time() - t0
+            else:
+                res['p10000'] = dict(error=(p.stderr or p.stdout)[-300:])
+        except Exception as e:
+            res['p10000'] = dict(error=repr(e)[:300])
+    if world == 1 and not args.no_iter3 and not args.no_p1000 and args.proteomes not in (1000, 10000):
+        # BASELINE configs[3]: `clustersearch --num-iterations 3` (sequence search, two profile searches) against 1 000 target
+        # proteomes through the sdgpu binary and the reference's DB files, with its own sampled parity check against the
+        # reference classes (tools/iter3_scale.py) -- a child process
+        cmd = [sys.executable, os.path.join(ROOT, 'tools', 'iter3_scale.py'), '1000', str(args.iter3_queries), '32']
+        try:
+            t0 = time.time()
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+            line = [l for l in p.stdout.splitlines() if l.startswith('{')]
+            if p.returncode == 0 and line:
+                res['iter3'] = json.loads(line[-1])
+                res['iter3']['leg_wall_s'] = time.time() - t0
+            else:
+                res['iter3'] = dict(error=(p.stderr or p.stdout)[-300:])
+        except Exception as e:
+            res['iter3'] = dict(error=repr(e)[:300])
     print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -176,6 +176,13 @@ int sd_target_build(sd_ctx *ctx, int kmerSize, int kmerThr, int mask, double mas
                     sd_target **out, uint64_t *stats);
 /* what a target holds on the device (any pointer may be NULL): masked residues, absolute list starts (tableSize + 1),
  * entries as (sequence id, position) */
+/* sampled check of an index too large to download: n (k-mer, sequence, position) triples = all entries of the nSample sequences
+ * `sample` (ascending) as computed elsewhere; *missing = triples that are not entries of the index, *inSample = entries of the
+ * index that belong to the sample sequences (== n exactly when it holds nothing else for them); masked residues
+ * [resBegin, resEnd) to maskedOut (nullable) */
+int sd_target_sample_check(sd_ctx *ctx, const sd_target *t, const uint32_t *kmer, const uint32_t *seq, const uint32_t *pos, uint64_t n,
+                           const uint32_t *sample, uint32_t nSample, uint64_t *missing, uint64_t *inSample, uint64_t resBegin,
+                           uint64_t resEnd, uint8_t *maskedOut);
 int sd_target_download(sd_ctx *ctx, const sd_target *t, uint64_t *nEntries, uint64_t *tableSize, uint8_t *masked, uint64_t *starts,
                        uint32_t *entrySeq, uint16_t *entryPos);
 void sd_target_destroy(sd_target *t);
@@ -463,6 +470,8 @@ const char *sd_search_last_error(sd_search *s);
 /* the device contexts of the pipeline, e.g. for sd_profile_*: 0 prefilter, 1 alignment lane 0, 2 composition bias (NULL when
  * the bias runs on the host), 3 alignment lane 1 (NULL with SD_ALIGN_LANES=1), 4 clusterhits, 5 prefilter lane 1 (NULL with SD_PF_LANES=1); NULL beyond */
 sd_ctx *sd_search_ctx(sd_search *s, int which);
+/* the resident target of the search (borrowed: lives as long as the search object; context = sd_search_ctx(s, 0)) */
+const sd_target *sd_search_target(sd_search *s);
 /* optional sinks, called from the pipeline's threads in chunk order: the prefilter rows of a chunk (after the coverage
  * pre-filter; what `prefilter` writes) and its reportable alignment records (what `align` writes after checkCriteria) */
 typedef void (*sd_pref_sink)(void *user, uint32_t firstQuery, uint32_t nQ, const sd_hit *rows, const uint32_t *counts,

@@ -145,6 +145,8 @@ def load():
                                       C.POINTER(_vp), _vp]),
         'sd_target_download': (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _vp, _vp, _vp, _vp]),
         'sd_host_index_tables': (C.c_int, [_vp, _vp, _vp]),
+        'sd_target_sample_check': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                             C.c_uint64, C.c_uint64, _vp]),
         'sd_device_memory': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_prefilter_batch': (C.c_int, [_vp, _vp, C.POINTER(PrefilterParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _vp]),
@@ -186,6 +188,7 @@ def load():
         'sd_search_destroy': (None, [_vp]),
         'sd_search_last_error': (C.c_char_p, [_vp]),
         'sd_search_ctx': (_vp, [_vp, C.c_int]),
+        'sd_search_target': (_vp, [_vp]),
         'sd_search_set_sinks': (C.c_int, [_vp, _vp, _vp, _vp]),
         'sd_search_set_chunk_queries': (C.c_int, [_vp, C.c_int32]),
         'sd_search_stream': (C.c_int, [_vp, C.POINTER(SetDbView), C.c_int, C.c_uint32, _vp, _vp, _vp]),

@@ -247,6 +247,12 @@ class Context:
     def last_error(self):
         return self.L.sd_last_error(self.h).decode(errors='replace')
 
+    def device_memory(self):
+        """(free, total) bytes of this context's device"""
+        f, t = C.c_uint64(), C.c_uint64()
+        _check(self.h, self.L.sd_device_memory(self.h, C.byref(f), C.byref(t)), 'sd_device_memory')
+        return f.value, t.value
+
     def profile(self, on=True):
         self.L.sd_profile_enable(self.h, 1 if on else 0)
         self.L.sd_profile_reset(self.h)
@@ -427,6 +433,47 @@ class Target:
         self.total = int(offsets[-1])
         self.build_stats = dict(entries=int(stats[0]), masked_residues=int(stats[1]), passes=int(stats[2]), records=int(stats[3]))
         return self
+
+    def sample_check(self, host, residues, offsets, kmer_thr, runs=24, run_len=400, seed=3, mask=True, mask_prob=0.9):
+        """an index too large to download against the host builder on a sample: `runs` runs of `run_len` consecutive sequences are
+        masked and indexed on the host (sd_host_index_build of the sample alone: masking and k-mer collection are per sequence);
+        every host entry must be in the device index, the device index must hold nothing else for these sequences, and their
+        masked residues must agree.  Returns dict(sequences, entries, missing, extra, masked_mismatch)"""
+        n = len(offsets) - 1
+        rng = np.random.default_rng(seed)
+        run_len = min(run_len, n)
+        starts = np.unique(rng.integers(0, max(1, n - run_len + 1), runs))
+        ids = np.unique(np.concatenate([np.arange(s, s + run_len) for s in starts])).astype(np.uint32)
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)[ids]
+        sub_off = np.zeros(len(ids) + 1, np.uint64)
+        np.cumsum(lens, out=sub_off[1:])
+        sub_res = np.concatenate([residues[int(offsets[i]):int(offsets[i + 1])] for i in ids])
+        h = host.build_index(sub_res, sub_off, k=self.k, kmer_thr=kmer_thr, mask=mask, mask_prob=mask_prob)
+        list_start = h.kmer_offsets.astype(np.uint64) if h.block_base is None else None
+        assert list_start is not None
+        ent = np.arange(h.n_entries, dtype=np.uint64)
+        kmer = (np.searchsorted(h.kmer_offsets[:-1], ent, side='right') - 1).astype(np.uint32)
+        # (empty lists share their start with the next one: side='right' lands on the last list starting at or before the entry,
+        #  which is the one that holds it)
+        seq = ids[h.entry_seq].astype(np.uint32)
+        pos = h.entry_pos.astype(np.uint32)
+        missing, in_sample = C.c_uint64(), C.c_uint64()
+        _check(self.ctx.h, self.ctx.L.sd_target_sample_check(self.ctx.h, self.h, ptr(kmer), ptr(seq), ptr(pos), len(kmer), ptr(ids), len(ids),
+                                                             C.byref(missing), C.byref(in_sample), 0, 0, None), 'sd_target_sample_check')
+        bad = 0
+        z = np.zeros(1, np.uint32)
+        for s in starts:   # (runs may overlap: compare run by run against the host's masked bytes of the same sequences)
+            a, b = int(offsets[s]), int(offsets[min(n, s + run_len)])
+            buf = np.zeros(b - a, np.uint8)
+            m2, i2 = C.c_uint64(), C.c_uint64()
+            _check(self.ctx.h, self.ctx.L.sd_target_sample_check(self.ctx.h, self.h, ptr(z), ptr(z), ptr(z), 0, ptr(z), 0, C.byref(m2), C.byref(i2),
+                                                                 a, b, ptr(buf)), 'sd_target_sample_check')
+            first = int(np.searchsorted(ids, s))
+            ha, hb = int(sub_off[first]), int(sub_off[first + min(run_len, n - int(s))])
+            bad += int((buf != h.masked[ha:hb]).sum())
+        return dict(sequences=int(len(ids)), entries=int(h.n_entries), missing=int(missing.value),
+                    extra=int(in_sample.value) - int(h.n_entries) + int(missing.value), masked_mismatch=bad,
+                    masked_residues_in_sample=int(h.masked_residues))
 
     def download(self, entries=True):
         """the device's copy of the index: dict(n_entries, masked, starts [tableSize + 1], entry_seq, entry_pos)"""

@@ -111,17 +111,23 @@ int prefilterModule(const Args &a) {
     if (rc != SD_OK) return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rc) + "); this path has no CPU fallback");
 
     // target side: TARGET.idx when a createindex file with matching parameters lies next to the DB (PrefilteringIndexReader
-    // layout, sd_mod_index.cpp), else IndexBuilder::fillDatabase on the host (mask + count + fill); resident in HBM afterwards.
+    // layout, sd_mod_index.cpp), else IndexBuilder::fillDatabase on the device (sd_target_build: mask + lists); resident in HBM afterwards.
     // Profile searches index every k-mer (Prefiltering.cpp:525-527)
     const int indexThr = qdb->profile ? 0 : kmerThr;
     IndexH index;
     LoadedIndex loaded;
     std::string why;
     uint64_t nEntries = 0, maskedRes = 0;
-    const uint32_t *kOff, *eSeq;
-    const uint16_t *ePos;
-    const uint8_t *masked;
+    const uint32_t *kOff = nullptr, *eSeq = nullptr;
+    const uint16_t *ePos = nullptr;
+    const uint8_t *masked = nullptr;
     const uint64_t *kBase = nullptr;
+    const int16_t *s2, *s3;
+    const uint16_t *i2, *i3;
+    uint32_t sz2, sz3;
+    sd_host_ext_matrix(host.h, 2, &s2, &i2, &sz2);
+    sd_host_ext_matrix(host.h, 3, &s3, &i3, &sz3);
+    TargetH target;
     const int got = loadTargetIndex(a.pos[1], k, indexThr, mask ? 1 : 0, tdb->n, tdb->totalResidues(), loaded, &why);
     if (got < 0) return fail(why);
     if (got == 0) {
@@ -134,6 +140,19 @@ int prefilterModule(const Args &a) {
         info(a, "Use index %s.idx\n", a.pos[1].c_str());
     } else {
         if (sddb::fileExists(a.pos[1] + ".idx.index")) info(a, "Index file not used: %s\n", why.c_str());
+    }
+    if (got != 0 && !getenv("SD_INDEX_HOST")) {
+        // IndexBuilder::fillDatabase on the device (sd_target_build): mask, k-mer lists, list starts
+        double ratios[21 * 21];
+        int8_t self[21];
+        sd_host_index_tables(host.h, ratios, self);
+        uint64_t st[4] = {0, 0, 0, 0};
+        rc = sd_target_build(ctx.c, k, indexThr, mask ? 1 : 0, maskProb, tdb->residues.data(), tdb->offsets.data(), tdb->n, ratios, self, s2, i2,
+                             s3, i3, &target.t, st);
+        if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_target_build");
+        nEntries = st[0];
+        maskedRes = st[1];
+    } else if (got != 0) {
         rc = sd_host_index_build(host.h, tdb->residues.data(), tdb->offsets.data(), tdb->n, k, indexThr, mask ? 1 : 0, maskProb, &index.ix);
         if (rc != SD_OK) return fail("sd_host_index_build failed (" + std::to_string(rc) + ")");
         uint64_t tableSize = 0;
@@ -143,14 +162,10 @@ int prefilterModule(const Args &a) {
     }
     info(a, "Index table k-mer threshold: %d at k-mer size %d\nIndex statistics\nEntries:          %llu\n", kmerThr, k,
          (unsigned long long) nEntries);
-    const int16_t *s2, *s3;
-    const uint16_t *i2, *i3;
-    uint32_t sz2, sz3;
-    sd_host_ext_matrix(host.h, 2, &s2, &i2, &sz2);
-    sd_host_ext_matrix(host.h, 3, &s3, &i3, &sz3);
-    TargetH target;
-    rc = sd_target_create_wide(ctx.c, k, kOff, kBase, eSeq, ePos, nEntries, masked, tdb->offsets.data(), tdb->n, s2, i2, s3, i3, &target.t);
-    if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_target_create");
+    if (!target.t) {
+        rc = sd_target_create_wide(ctx.c, k, kOff, kBase, eSeq, ePos, nEntries, masked, tdb->offsets.data(), tdb->n, s2, i2, s3, i3, &target.t);
+        if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_target_create");
+    }
 
     sd_prefilter_params par;
     memset(&par, 0, sizeof(par));

@@ -711,6 +711,7 @@ int iterativeSearch(const Args &a, const std::string &Q, const std::string &T, c
                                                         "--cov", a.str("--cov", "0"), "--diff", a.str("--diff", "1000"), "--pca",
                                                         a.str("--pca", "substitution:1.100,context:1.400"), "--pcb",
                                                         a.str("--pcb", "substitution:4.100,context:5.800")});
+    const bool keep = a.integer("--keep-tmp", 0) != 0;   // keep the per-iteration DBs (parity checks at size read them)
     std::string query = Q;
     for (int step = 0; step < numIt; step++) {
         const std::string s = std::to_string(step), s1 = std::to_string(step - 1);
@@ -723,7 +724,7 @@ int iterativeSearch(const Args &a, const std::string &Q, const std::string &T, c
             if (int rc = runModule(subtractdbsModule, "subtractdbs", {prefDb, tmp + "/aln_" + s1, prefForAln},
                                    with(common, {"--e-profile", eProfile, "-e", eUser})))
                 return rc;
-            sddb::removeDb(prefDb);
+            if (!keep) sddb::removeDb(prefDb);
         }
         // the realign pass belongs to iteration 0 only; every iteration but the last aligns with the profile E-value
         // (Search.cpp:484-486,497-505)
@@ -734,8 +735,10 @@ int iterativeSearch(const Args &a, const std::string &Q, const std::string &T, c
         if (step > 0) {
             merged = last ? result : tmp + "/aln_" + s;
             if (int rc = runModule(mergedbsModule, "mergedbs", {query, merged, tmp + "/aln_" + s1, alnDb}, {})) return rc;
-            sddb::removeDb(tmp + "/aln_" + s1);
-            sddb::removeDb(alnDb);
+            if (!keep) {
+                sddb::removeDb(tmp + "/aln_" + s1);
+                sddb::removeDb(alnDb);
+            }
         }
         if (!last) {
             const std::string profDb = tmp + "/profile_" + s;

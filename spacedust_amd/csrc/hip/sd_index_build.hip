@@ -813,6 +813,84 @@ extern "C" int sd_target_build(sd_ctx *ctx, int kmerSize, int kmerThr, int mask,
     return SD_OK;
 }
 
+namespace {
+// triple x = (k-mer, sequence, position): is it an entry of the index?  Lists are ordered by sequence.
+__global__ void __launch_bounds__(256) ib_check_triples(const uint32_t *__restrict__ offsets, const uint64_t *__restrict__ blockBase,
+                                                        const uint2 *__restrict__ entries, const uint32_t *__restrict__ kmer,
+                                                        const uint32_t *__restrict__ seq, const uint32_t *__restrict__ pos, uint64_t n,
+                                                        unsigned long long *__restrict__ missing) {
+    const uint64_t x = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (x >= n) return;
+    const uint64_t km = kmer[x];
+    uint64_t lo = (blockBase ? blockBase[km >> 16] : 0) + offsets[km];
+    uint64_t hi = (blockBase ? blockBase[(km + 1) >> 16] : 0) + offsets[km + 1];
+    const uint32_t want = seq[x];
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (entries[mid].x < want) lo = mid + 1;
+        else hi = mid;
+    }
+    const uint64_t end = (blockBase ? blockBase[(km + 1) >> 16] : 0) + offsets[km + 1];
+    if (!(lo < end && entries[lo].x == want && entries[lo].y == pos[x])) atomicAdd(missing, 1ull);
+}
+// number of entries that belong to one of the (ascending) sample sequences
+__global__ void __launch_bounds__(256) ib_count_sample(const uint2 *__restrict__ entries, uint64_t nEntries, const uint32_t *__restrict__ sample,
+                                                       uint32_t nSample, unsigned long long *__restrict__ count) {
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < nEntries; i += (uint64_t) gridDim.x * 256) {
+        const uint32_t s = entries[i].x;
+        uint32_t lo = 0, hi = nSample;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sample[mid] < s) lo = mid + 1;
+            else hi = mid;
+        }
+        mine += (lo < nSample && sample[lo] == s) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+}  // namespace
+
+// Sampled check of an index too large to download (10^4 proteomes: 72 GB of entries): for n (k-mer, sequence, position)
+// triples -- the complete entries of the nSample sequences `sample` (ascending), computed elsewhere -- *missing = how many are
+// not entries of the index, *inSample = how many entries of the index belong to the sample sequences (equal to n exactly when
+// the index holds nothing else for them); the masked residues of [resBegin, resEnd) are copied to maskedOut (nullable).
+extern "C" int sd_target_sample_check(sd_ctx *ctx, const sd_target *t, const uint32_t *kmer, const uint32_t *seq, const uint32_t *pos,
+                                      uint64_t n, const uint32_t *sample, uint32_t nSample, uint64_t *missing, uint64_t *inSample,
+                                      uint64_t resBegin, uint64_t resEnd, uint8_t *maskedOut) {
+    if (!ctx || !t || !missing || !inSample || (n && (!kmer || !seq || !pos)) || (nSample && !sample)) return SD_EINVAL;
+    (void) hipSetDevice(ctx->device);
+    Scoped<uint32_t> dK, dS, dP, dSample;
+    Scoped<unsigned long long> dOut;
+    SD_HIP(ctx, dK.alloc(n));
+    SD_HIP(ctx, dS.alloc(n));
+    SD_HIP(ctx, dP.alloc(n));
+    SD_HIP(ctx, dSample.alloc(nSample));
+    SD_HIP(ctx, dOut.alloc(2));
+    SD_HIP(ctx, hipMemcpy(dK.p, kmer, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SD_HIP(ctx, hipMemcpy(dS.p, seq, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SD_HIP(ctx, hipMemcpy(dP.p, pos, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SD_HIP(ctx, hipMemcpy(dSample.p, sample, (size_t) nSample * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SD_HIP(ctx, hipMemsetAsync(dOut.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    if (n)
+        hipLaunchKernelGGL(ib_check_triples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *) t->dOffsets,
+                           (const uint64_t *) t->dBlockBase, (const uint2 *) t->dEntries, (const uint32_t *) dK.p, (const uint32_t *) dS.p,
+                           (const uint32_t *) dP.p, n, dOut.p);
+    if (t->nEntries)
+        hipLaunchKernelGGL(ib_count_sample, dim3(8192), dim3(256), 0, ctx->stream, (const uint2 *) t->dEntries, t->nEntries,
+                           (const uint32_t *) dSample.p, nSample, dOut.p + 1);
+    SD_HIP(ctx, hipGetLastError());
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long h[2] = {0, 0};
+    SD_HIP(ctx, hipMemcpy(h, dOut.p, sizeof(h), hipMemcpyDeviceToHost));
+    *missing = h[0];
+    *inSample = h[1];
+    if (maskedOut && resEnd > resBegin) SD_HIP(ctx, hipMemcpy(maskedOut, t->dMasked + resBegin, resEnd - resBegin, hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
 // the pieces of a target as the device holds them (tests: device-built index against the host-built one).  Any pointer may
 // be NULL; entries = nEntries x (sequence id, position); starts = absolute list starts, tableSize + 1 of them
 extern "C" int sd_target_download(sd_ctx *ctx, const sd_target *t, uint64_t *nEntries, uint64_t *tableSize, uint8_t *masked,

@@ -234,6 +234,12 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     if (rc != SD_OK) return rc;
     rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAl);
     if (rc != SD_OK) return rc;
+    {   // a second lane per stage costs ~0.7 core-seconds per step: with fewer than 4 cores for this rank (8 ranks sharing a
+        // 16-CPU quota) the host would bound the pipeline, so such ranks run one lane per stage
+        int local = 1;
+        if (const char *e = getenv("LOCAL_WORLD_SIZE")) local = std::max(1, atoi(e));
+        if (cpus / local < 4) s->alignLanes = s->pfLanes = 1;
+    }
     if (const char *e = getenv("SD_ALIGN_LANES")) s->alignLanes = std::max(1, std::min(2, atoi(e)));
     if (s->alignLanes > 1) {
         rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAl2);
@@ -264,9 +270,9 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     if (view && (view->kmerSize != s->k || view->kmerThr != indexThr)) return SD_EINVAL;
     double t0 = nowSec();
     uint64_t nEntries = 0, masked = 0;
-    const uint32_t *kOff, *eSeq;
-    const uint16_t *ePos;
-    const uint8_t *mres;
+    const uint32_t *kOff = nullptr, *eSeq = nullptr;
+    const uint16_t *ePos = nullptr;
+    const uint8_t *mres = nullptr;
     const uint64_t *kBase = nullptr;   // block bases of a wide index (>= 2^32 entries)
     if (view) {
         kBase = view->kmerBlockBase;
@@ -276,6 +282,23 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
         mres = view->maskedResidues;
         nEntries = view->nEntries;
         masked = view->nMaskedResidues;
+    } else if (!getenv("SD_INDEX_HOST")) {
+        // the index is built where it is used: masking, k-mer lists and list starts on the device (sd_target_build)
+        const int16_t *s2, *s3;
+        const uint16_t *i2, *i3;
+        uint32_t z2, z3;
+        sd_host_ext_matrix(s->host, 2, &s2, &i2, &z2);
+        sd_host_ext_matrix(s->host, 3, &s3, &i3, &z3);
+        double ratios[21 * 21];
+        int8_t self[21];
+        sd_host_index_tables(s->host, ratios, self);
+        uint64_t st[4] = {0, 0, 0, 0};
+        rc = sd_target_build(s->ctxPf, s->k, indexThr, par->mask ? 1 : 0, par->maskProb, target->residues, target->offsets, target->n, ratios,
+                             self, s2, i2, s3, i3, &s->target, st);
+        if (rc != SD_OK) return rc;
+        nEntries = st[0];
+        masked = st[1];
+        kOff = nullptr;
     } else {
         rc = sd_host_index_build(s->host, target->residues, target->offsets, target->n, s->k, indexThr, par->mask ? 1 : 0, par->maskProb,
                                  &s->index);
@@ -291,7 +314,7 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     s->stats[S_K] = (uint64_t) s->k;
     s->stats[S_KMER_THR] = (uint64_t) s->kmerThr;
     t0 = nowSec();
-    {
+    if (!s->target) {
         const int16_t *s2, *s3;
         const uint16_t *i2, *i3;
         uint32_t z2, z3;
@@ -349,6 +372,8 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
 
 void sd_search_destroy(sd_search *s) { delete s; }
 const char *sd_search_last_error(sd_search *s) { return s ? s->err.c_str() : ""; }
+const sd_target *sd_search_target(sd_search *s) { return s ? s->target : nullptr; }
+
 sd_ctx *sd_search_ctx(sd_search *s, int which) {
     if (!s) return nullptr;
     switch (which) {

@@ -98,6 +98,16 @@ def _setdb_struct(db, keep):
     return v
 
 
+class _BorrowedTarget:
+    """the sd_target owned by an sd_search object (sd_search_target): never destroyed from here"""
+
+    def __init__(self, ctx, handle, k):
+        self.ctx, self.h, self.k = ctx, handle, k
+
+    def sample_check(self, *a, **kw):
+        return api.Target.sample_check(self, *a, **kw)
+
+
 class ClusterSearch:
     """One GPU's worth of the workflow: a thin view of the C++ pipeline object sd_search (csrc/host/sd_search.cpp), which
     owns the device contexts, the resident target (index + sequences) and the stage threads.  Python only hands over the
@@ -162,6 +172,10 @@ class ClusterSearch:
         self.index_entries, self.masked_residues = int(st[9]), int(st[10])
         self.timing = dict(index_build_s=float(tm[0]), upload_s=float(tm[1]))
         self.stats = _Stats(self)
+
+    def target_view(self):
+        """the search's resident target (borrowed), e.g. for sample_check against the host index builder"""
+        return _BorrowedTarget(self.ctx, C.c_void_p(self.L.sd_search_target(self.h)), self.k)
 
     def _raw_stats(self):
         st = np.zeros(16, np.uint64)

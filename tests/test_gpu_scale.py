@@ -78,3 +78,42 @@ def test_queries_with_2_24_index_hits_and_more():
     twice = [x for x in heavy if r['index_hits'][x] >= 2 * r['max_db_matches']]
     assert len(twice) == 1 and r['refused'] == []
     assert r['rows'] == 12 * 1000
+
+
+@pytest.mark.parametrize('P', [1000, 10000])
+def test_index_built_on_the_device_at_scale(P):
+    """BASELINE configs[2] / configs[4] target sizes: the index of 1 000 (k = 6) and of 10 000 proteomes (3 * 10^7 sequences,
+    9 * 10^9 residues, k = 7, more than 2^32 entries: wide form, nine sort passes) built on the GPU by sd_target_build in
+    seconds, and checked on 9 600 sample sequences against the host builder: every host entry present, no other entry for these
+    sequences, masked residues equal (tools/index_build_scale.py; profiles/r03_index_build_p10000.json is such a run)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import index_build_scale
+    r = index_build_scale.run(P, log=lambda *a: None)
+    assert r['sequences'] == 3000 * P and r['k'] == (7 if P == 10000 else 6)
+    assert r['build']['entries'] > 860000 * P and r['build']['masked_residues'] > 100 * P
+    if P == 10000:
+        assert r['build']['entries'] > (1 << 32) and r['build']['passes'] >= 5
+    chk = r['sample_check']
+    assert chk['sequences'] == 9600 and chk['entries'] > 2000000
+    assert chk['missing'] == 0 and chk['extra'] == 0 and chk['masked_mismatch'] == 0, chk
+    assert r['device_build_s'] < 60
+
+
+def test_iterative_profile_search_on_1000_proteomes():
+    """BASELINE configs[3] at its target size on one GPU: `sdgpu clustersearch Q T --num-iterations 3` with T = 1 000 synthetic
+    proteomes (3 * 10^6 proteins) and Q = the first two of them, through createsetdb DBs; the per-iteration DBs of that run
+    against the reference's classes on this machine for 32 sampled queries: profile prefilter rows, profile alignments
+    (coordinates, backtraces, E-values) of iterations 1 and 2, profile bytes of profile_0 and profile_1 (tools/iter3_scale.py)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import iter3_scale
+    r = iter3_scale.run(1000, 2, 32, log=lambda *a: None)
+    assert r['queries'] == 6000 and r['hit_lines'] > 1000 and r['cluster_lines'] > 100
+    pc = r['parity_check']
+    if pc.get('queries', 0) == 0:
+        pytest.skip('oracle/_ref/libsdref*.so not built (needs /root/reference at build time)')
+    assert pc['queries'] == 32 and pc['prefilter_rows'] > 1000 and pc['alignments'] > 30 and pc['profiles'] == 64
+    assert pc['prefilter_queries_mismatching'] == 0 and pc['alignment_queries_mismatching'] == 0 and pc['profiles_mismatching'] == 0, pc

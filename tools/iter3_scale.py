@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3] at its target size on one GPU: `sdgpu clustersearch Q T out tmp --num-iterations 3` with T = P synthetic
+proteomes (default 1 000: 3 * 10^6 proteins) and Q = the first q of them as their own set DB, through the reference's DB files
+(createsetdb from one FASTA file per proteome), timed; then, untimed, the DBs the run left behind (--keep-tmp 1) are checked on
+a sample of queries against the reference's own classes run on this machine (oracle/_ref/libsdref*.so), iteration by iteration
+(M/data/workflow/blastpgp.sh:73-133):
+    prefilter   profile_{k-1} vs T       == QueryMatcher driven with the DBTYPE_HMM_PROFILE Sequence, row for row
+    align       on the subtracted rows   == Matcher::getSWResult with the profile query: targets, coordinates, backtraces, E-values
+    result2profile                       == MultipleAlignment / MsaFilter / PSSMCalculator, byte for byte (profile_0 from the
+                                            sequence search's alignments, profile_1 from the merged ones)
+
+  python tools/iter3_scale.py [P [q [sample]]]        on the GPU box; prints one JSON line
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+def _write_fasta(ps, s, out_dir, lut):
+    """one proteome = one FASTA file with Prodigal-style headers (accession # start # end # strand)"""
+    a, e = int(ps.set_start[s]), int(ps.set_start[s + 1])
+    text = lut[ps.residues[int(ps.offsets[a]):int(ps.offsets[e])]].tobytes()
+    base = int(ps.offsets[a])
+    parts = []
+    for i in range(a, e):
+        o0, o1 = int(ps.offsets[i]) - base, int(ps.offsets[i + 1]) - base
+        start = 1000 + 2000 * (i - a)
+        parts.append(b'>p%05d_%d # %d # %d # %d\n' % (s, i - a, start, start + 3 * (o1 - o0), 1 if ps.strand[i] else -1))
+        parts.append(text[o0:o1])
+        parts.append(b'\n')
+    path = os.path.join(out_dir, 'p%05d.faa' % s)
+    with open(path, 'wb') as f:
+        f.write(b''.join(parts))
+    return path
+
+
+def _compress(bt):
+    out, state, count = [], 'M', 0
+    for ch in bt:
+        if ch != state:
+            out.append('%d%s' % (count, state))
+            state, count = ch, 1
+        else:
+            count += 1
+    out.append('%d%s' % (count, state))
+    return ''.join(out)
+
+
+def _entries(path, keys):
+    """the DB entries of `keys` only (the data files at this size are large): dict key -> list of tab-split lines"""
+    want = set(int(k) for k in keys)
+    loc = {}
+    for line in open(path + '.index'):
+        k, o, l = line.split()
+        if int(k) in want:
+            loc[int(k)] = (int(o), int(l))
+    out = {}
+    with open(path, 'rb') as f:
+        for k, (o, l) in loc.items():
+            f.seek(o)
+            out[k] = f.read(l - 1)
+    return out
+
+
+def _lines(db):
+    return {k: [l.split('\t') for l in v.decode().split('\n') if l] for k, v in db.items()}
+
+
+def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
+    from dbutil import SDGPU
+    from spacedust_amd import api
+    from spacedust_amd.cpus import effective_cpus
+    from spacedust_amd.synth import make_proteomes, ALPHABET
+    from oracle.pyoracle import Ref, RefSW, RefResult2Profile, ref_available, ref_r2p_available
+    threads = threads or effective_cpus()
+    work = keep_dir or tempfile.mkdtemp(prefix='sd_iter3_')
+    os.makedirs(work, exist_ok=True)
+    out = dict(target_proteomes=P, query_proteomes=q_sets, threads=threads)
+    try:
+        t0 = time.time()
+        ps = make_proteomes(P, genes_per_proteome=3000, seed=0x5ED0 + 2)
+        out['generate_s'] = time.time() - t0
+        fa_dir = os.path.join(work, 'fa')
+        os.makedirs(fa_dir, exist_ok=True)
+        t0 = time.time()
+        lut0 = np.frombuffer(ALPHABET.encode(), np.uint8)
+        files = [_write_fasta(ps, s_, fa_dir, lut0) for s_ in range(P)]   # (no worker processes: the caller may hold a HIP context)
+        out['fasta_s'] = time.time() - t0
+
+        def sdgpu(*a):
+            r = subprocess.run([SDGPU] + [str(x) for x in a], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError('sdgpu %s failed: %s' % (a[0], (r.stderr or r.stdout)[-400:]))
+            return r
+
+        T, Q = os.path.join(work, 'T'), os.path.join(work, 'Q')
+        t0 = time.time()
+        sdgpu('createsetdb', *files, T, os.path.join(work, 'tmpT'), '-v', '0')
+        sdgpu('createsetdb', *files[:q_sets], Q, os.path.join(work, 'tmpQ'), '-v', '0')
+        out['createsetdb_s'] = time.time() - t0
+        shutil.rmtree(fa_dir)
+        tmp = os.path.join(work, 'tmp')
+        t0 = time.time()
+        sdgpu('clustersearch', Q, T, os.path.join(work, 'iter3.tsv'), tmp, '--num-iterations', '3', '--keep-tmp', '1', '--threads', threads, '-v', '0')
+        wall = time.time() - t0
+        nq = int(ps.set_start[q_sets])
+        tsv = open(os.path.join(work, 'iter3.tsv')).readlines()
+        out.update(wall_s=wall, queries=nq, genome_pairs=q_sets * P, genome_pairs_per_s=q_sets * P / wall,
+                   hit_lines=sum(1 for l in tsv if l.startswith('>')), cluster_lines=sum(1 for l in tsv if l.startswith('#')))
+        log('clustersearch --num-iterations 3:', round(wall, 1), 's,', out['hit_lines'], 'hits in', out['cluster_lines'], 'clusters')
+        if not (ref_available() and ref_r2p_available()):
+            out['parity_check'] = dict(queries=0, note='oracle/_ref/libsdref*.so did not travel')
+            return out
+
+        # ---------------- sampled parity against the reference classes
+        t0 = time.time()
+        S = os.path.join(tmp, 'search')
+        rng = np.random.default_rng(17)
+        lens = ps.lengths()
+        # queries that have something to align in the profile iterations are the interesting ones: sample among those
+        idx1 = [int(l.split()[0]) for l in open(os.path.join(S, 'aln_tmp_1.index')) if int(l.split()[2]) > 1]
+        pool_q = np.array(sorted(idx1)) if idx1 else np.arange(nq)
+        qs = np.sort(rng.choice(pool_q, min(sample, len(pool_q)), replace=False)).tolist()
+        lut = np.frombuffer(ALPHABET.encode(), np.uint8)
+        blob = lut[ps.residues].tobytes()
+        seq_of = lambda t: blob[int(ps.offsets[t]):int(ps.offsets[t + 1])].decode()
+        ref = Ref(6)
+        rix = ref.index(blob, ps.offsets, kmer_thr=0, threads=threads)     # profile searches index every k-mer (Prefiltering.cpp:525-527)
+        out['reference_index_s'] = time.time() - t0
+        host = api.Host()
+        thr = host.profile_kmer_threshold(5.7, 6)
+        rpf = rix.prefilter_profile(int(lens.max()) + 10, thr, max_hits=300)
+        rsw = RefSW(ref, int(lens.max()) + 10, int(ps.offsets[-1]))
+        r2p = RefResult2Profile()
+        bad = dict(prefilter=0, align=0, profile=0)
+        n = dict(prefilter_rows=0, alignments=0, profiles=0)
+        # profile_0 from the sequence search's alignments
+        prof0 = _entries(os.path.join(S, 'profile_0'), qs)
+        aln0 = _lines(_entries(os.path.join(S, 'aln_0'), qs))
+
+        for q in qs:
+            rows = aln0.get(q, [])
+            et, eq, ets, bts = [], [], [], []
+            for w in rows:
+                if float(w[3]) < 0.001:
+                    et.append(int(w[0])); eq.append(int(w[4])); ets.append(int(w[7])); bts.append(api.uncompress_cigar(w[10]))
+            got = r2p.profile(seq_of(q), [seq_of(t) for t in et], eq, ets, bts)
+            bad['profile'] += got != prof0[q]
+            n['profiles'] += 1
+        for step in (1, 2):
+            last = step == 2
+            prof = _entries(os.path.join(S, 'profile_%d' % (step - 1)), qs)
+            got_pf = _lines(_entries(os.path.join(S, 'pref_tmp_%d' % step), qs))
+            todo = _lines(_entries(os.path.join(S, 'pref_%d' % step), qs))
+            aln = _lines(_entries(os.path.join(S, 'aln_tmp_%d' % step), qs))
+            for q in qs:
+                ids, sc, dg, _ = rpf.query(prof[q])
+                keep = (lens[ids].astype(np.float32) / np.float32(lens[q])) >= np.float32(0.8)   # Util::canBeCovered, --cov-mode 2
+                want = [(int(t), int(s_), int(np.int16(np.uint16(d)))) for t, s_, d in zip(ids[keep], sc[keep], dg[keep])]
+                mine = [(int(w[0]), int(w[1]), int(w[2])) for w in got_pf.get(q, [])]
+                bad['prefilter'] += mine != want
+                n['prefilter_rows'] += len(want)
+                rows = todo.get(q, [])
+                wantA = {}
+                if rows:
+                    rsw.set_query_profile(prof[q])
+                    for w in rows:
+                        t = int(w[0])
+                        r = rsw.align(seq_of(t), sw_mode=2, eval_thr=10.0 if last else 0.001, cov_mode=2, cov_thr=0.8)
+                        if r['btLen'] > 0 and r['evalue'] <= (10.0 if last else 0.001) and len(r['backtrace']) >= 30:
+                            wantA[t] = (r['qStart'], r['qEnd'], r['tStart'], r['tEnd'], _compress(r['backtrace']), '%.3E' % r['evalue'])
+                mineA = {int(w[0]): (int(w[4]), int(w[5]), int(w[7]), int(w[8]), w[10], w[3]) for w in aln.get(q, [])}
+                bad['align'] += mineA != wantA
+                n['alignments'] += len(wantA)
+            if not last:
+                merged = _lines(_entries(os.path.join(S, 'aln_%d' % step), qs))
+                nxt = _entries(os.path.join(S, 'profile_%d' % step), qs)
+                for q in qs:
+                    et, eq, ets, bts = [], [], [], []
+                    for w in merged.get(q, []):
+                        if float(w[3]) < 0.001:
+                            et.append(int(w[0])); eq.append(int(w[4])); ets.append(int(w[7])); bts.append(api.uncompress_cigar(w[10]))
+                    got = r2p.profile(None, [seq_of(t) for t in et], eq, ets, bts, centre_profile=prof[q])
+                    bad['profile'] += got != nxt[q]
+                    n['profiles'] += 1
+        out['parity_check'] = dict(queries=len(qs), prefilter_rows=n['prefilter_rows'], prefilter_queries_mismatching=bad['prefilter'],
+                                   alignments=n['alignments'], alignment_queries_mismatching=bad['align'], profiles=n['profiles'],
+                                   profiles_mismatching=bad['profile'], seconds=time.time() - t0,
+                                   against='oracle/_ref/libsdref.so + libsdref_r2p.so (the reference classes, this machine)')
+        log('parity', out['parity_check'])
+        return out
+    finally:
+        if keep_dir is None:
+            shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == '__main__':
+    a = [int(x) for x in sys.argv[1:4]]
+    print(json.dumps(run(*(a + [1000, 2, 48][len(a):]))))
