@@ -58,7 +58,7 @@ const char *const kValueFlags[] = {
     "--unpack-name-mode", "--unpack-suffix", "--vote-mode", "--weights", "--write-lookup", "--zdrop", "-c", "-e",
     "-k", "-s", "-v",
     // this binary's own (multi-GPU launch and tuning; not reference flags)
-    "--device", "--rank", "--world-size", "--chunk-queries", "--bin-size", "--l2-cache-size", "--keep-dbs",
+    "--device", "--rank", "--world-size", "--chunk-queries", "--bin-size", "--l2-cache-size", "--keep-dbs", "--keep-tmp", "--comm-port",
 };
 
 const std::set<std::string> &boolFlags() {

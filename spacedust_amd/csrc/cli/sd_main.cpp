@@ -3,6 +3,7 @@
 // the reference's command table; R/data/clustersearch.sh and M/data/workflow/blastp.sh / blastpgp.sh are the callers), so a
 // wrapper that forwards the hot modules here and everything else to the reference binary runs those scripts unchanged.
 #include "sd_cli.h"
+#include <omp.h>
 
 #include <cstdio>
 #include <cstring>
@@ -50,6 +51,9 @@ int main(int argc, const char **argv) {
             return 1;
         }
         info(a, "");
+        // OpenMP teams of the host stages: --threads, else the cgroup CPU quota (a 256-thread default team on a 16-CPU quota
+        // spends its time being descheduled)
+        omp_set_num_threads(threadsOf(a));
         return m.fn(a);
     }
     fprintf(stderr, "sdgpu: unknown module \"%s\" (sdgpu --help lists the modules)\n", argv[1]);

@@ -17,8 +17,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <map>
 #include <memory>
+#include <omp.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <thread>
@@ -183,6 +185,53 @@ void packNames(const std::vector<std::string> &v, std::string &blob, std::vector
     for (const std::string &s : v) blob += s;
 }
 
+// Several ranks leave NAME.<rank> + NAME.<rank>.index each; rank 0 turns them into one DB with split data files -- NAME.0 ..
+// NAME.<world-1> and one NAME.index whose offsets run through their concatenation, the layout the reference's multi-threaded
+// DBWriter leaves and every reader here understands (M/src/commons/DBWriter.cpp:540-600)
+bool mergeRankDbs(const std::string &name, int world, int dbtype, std::string *err) {
+    struct Row {
+        uint32_t key;
+        uint64_t off, len;
+    };
+    std::vector<Row> rows;
+    uint64_t base = 0;
+    for (int r = 0; r < world; r++) {
+        const std::string part = name + "." + std::to_string(r);
+        std::ifstream in(part + ".index");
+        if (!in) {
+            *err = "cannot read " + part + ".index";
+            return false;
+        }
+        unsigned long long k, o, l;
+        while (in >> k >> o >> l) rows.push_back({(uint32_t) k, base + o, l});
+        struct stat st;
+        if (stat(part.c_str(), &st) != 0) {
+            *err = "cannot stat " + part;
+            return false;
+        }
+        base += (uint64_t) st.st_size;
+        remove((part + ".index").c_str());
+        remove((part + ".dbtype").c_str());
+    }
+    std::sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.key < y.key; });
+    FILE *f = fopen((name + ".index").c_str(), "wb");
+    if (!f) {
+        *err = "cannot write " + name + ".index";
+        return false;
+    }
+    for (const Row &w : rows) fprintf(f, "%u\t%llu\t%llu\n", w.key, (unsigned long long) w.off, (unsigned long long) w.len);
+    fclose(f);
+    f = fopen((name + ".dbtype").c_str(), "wb");
+    if (!f) {
+        *err = "cannot write " + name + ".dbtype";
+        return false;
+    }
+    const int32_t t = dbtype;
+    fwrite(&t, sizeof(t), 1, f);
+    fclose(f);
+    return true;
+}
+
 int runSearch(const Args &a, bool withClusters) {
     if (a.pos.size() != 4)
         return fail(withClusters ? "usage: clustersearch <querySetDB> <targetSetDB> <out.tsv> <tmpDir> [options]"
@@ -335,6 +384,30 @@ int runSearch(const Args &a, bool withClusters) {
         if (sinks.failed) return fail("writing the prefilter / alignment DB failed");
         if (!sinks.pref.close(&err) || !sinks.aln.close(&err)) return fail(err);
     }
+    // the ranks meet over TCP at MASTER_ADDR:MASTER_PORT+1: merge of the per-rank DBs, and (clustersearch) the RCCL unique id
+    sd_tcp *tcp = nullptr;
+    struct TcpClose {
+        sd_tcp *&t;
+        ~TcpClose() { if (t) sd_tcp_close(t); }
+    } tcpClose{tcp};
+    if (world > 1) {
+        const char *addrEnv = getenv("MASTER_ADDR");
+        const std::string addr = addrEnv && *addrEnv ? addrEnv : "127.0.0.1";
+        const int port = (int) a.integer("--comm-port", envInt("MASTER_PORT", 29500) + 1);
+        if (sd_tcp_connect(addr.c_str(), port, world, rank, &tcp) != SD_OK)
+            return fail("rendezvous of the ranks at " + addr + ":" + std::to_string(port) + " failed");
+        if (dbs) {   // every rank's DB parts are closed: rank 0 makes them one DB (split data files, one index)
+            uint8_t done = 1;
+            std::vector<uint8_t> allDone((size_t) world, 0);
+            uint64_t got = 0;
+            if (sd_tcp_gather(tcp, &done, 1, nullptr, allDone.data(), allDone.size(), &got) != SD_OK) return fail("rendezvous of the ranks failed (DB parts)");
+            if (rank == 0) {
+                const std::string alnPath = withClusters ? tmpDir + "/result" : a.pos[2];
+                if (!mergeRankDbs(tmpDir + "/pref_0", world, sddb::DBTYPE_PREFILTER_RES, &err)) return fail(err);
+                if (!mergeRankDbs(alnPath, world, sddb::DBTYPE_ALIGNMENT_RES, &err)) return fail(err);
+            }
+        }
+    }
     sd_search_stats(S.s, st, tm);
     info(a, "%llu prefilter hits, %llu pairs aligned; prefilter %.2f s | align %.2f s | aggregate %.2f s | clusterhits %.2f s | total %.2f s\n",
          (unsigned long long) st[4], (unsigned long long) st[5], tm[3], tm[6], tm[8], tm[9], tm[11]);
@@ -372,17 +445,7 @@ int runSearch(const Args &a, bool withClusters) {
         // The one exchange of the path: every rank's records to rank 0 (RCCL: sd_gather_results), which writes the TSV from the
         // gathered buffer.  The ranks meet over TCP at MASTER_ADDR:MASTER_PORT+1 (the RCCL unique id travels that way); ranks
         // that share a device -- RCCL refuses that, a one-GPU test rig -- hand their records over the same socket path instead.
-        const char *addrEnv = getenv("MASTER_ADDR");
-        const std::string addr = addrEnv && *addrEnv ? addrEnv : "127.0.0.1";
-        const int port = (int) a.integer("--comm-port", envInt("MASTER_PORT", 29500) + 1);
         std::vector<uint64_t> sizes((size_t) world, 0);
-        sd_tcp *tcp = nullptr;
-        if (sd_tcp_connect(addr.c_str(), port, world, rank, &tcp) != SD_OK)
-            return fail("rendezvous of the ranks at " + addr + ":" + std::to_string(port) + " failed");
-        struct TcpClose {
-            sd_tcp *t;
-            ~TcpClose() { sd_tcp_close(t); }
-        } tcpClose{tcp};
         // device of every rank -> does each rank have a GPU of its own?
         int32_t devs[2] = {device, 0};
         std::vector<int32_t> allDevs((size_t) world * 2, 0);
@@ -677,7 +740,12 @@ int runModule(int (*fn)(const Args &), const char *name, const std::vector<std::
     std::string err;
     if (!sub.parse((int) argv.size(), argv.data(), &err)) return fail(std::string(name) + ": " + err);
     info(sub, "");
-    return fn(sub);
+    omp_set_num_threads(threadsOf(sub));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = fn(sub);
+    // the reference prints "Time for processing" after every module of a workflow (M/src/commons/CommandCaller / Timer)
+    info(sub, "%s: time for processing %.2f s\n", name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return rc;
 }
 
 std::vector<std::string> with(std::vector<std::string> v, std::initializer_list<std::string> more) {

@@ -259,14 +259,14 @@ bool DiversityFilter::tooSimilar(const char *a, const RowSpan &ra, const char *b
     compared += std::abs(blockBegin * kBlock - from) + std::abs(blockEnd * kBlock - (to + 1));   // whole blocks are walked
     int differing = 0;
     for (int blk = blockBegin; blk < blockEnd && differing < enough; blk++) {
-        int unpaired = 0, unequal = 0;
-        for (int i = blk * kBlock; i < (blk + 1) * kBlock; i++) {
-            const bool noPair = a[i] >= kResidues || b[i] >= kResidues;
-            unpaired += noPair;
-            unequal += !noPair && a[i] != b[i];
-        }
-        compared -= unpaired;
-        differing += unequal;
+        // one block = one 32-byte register: cells where either row has no residue, and paired cells that differ
+        const __m256i va = _mm256_loadu_si256((const __m256i *) (a + blk * kBlock));
+        const __m256i vb = _mm256_loadu_si256((const __m256i *) (b + blk * kBlock));
+        const __m256i lastResidue = _mm256_set1_epi8((char) (kResidues - 1));
+        const __m256i noPair = _mm256_or_si256(_mm256_cmpgt_epi8(va, lastResidue), _mm256_cmpgt_epi8(vb, lastResidue));
+        const __m256i unequal = _mm256_andnot_si256(_mm256_or_si256(noPair, _mm256_cmpeq_epi8(va, vb)), _mm256_set1_epi8((char) 0xFF));
+        compared -= __builtin_popcount((unsigned) _mm256_movemask_epi8(noPair));
+        differing += __builtin_popcount((unsigned) _mm256_movemask_epi8(unequal));
     }
     return differing < enough && float(differing) <= minDiffFraction * compared && compared > 0;
 }

@@ -127,3 +127,31 @@ def test_sdgpu_clustersearch_two_ranks_equal_one(gpu, tmp_path):
     # cluster keys are consecutive in the merged file
     keys = [int(l.split('\t')[0][1:]) for l in two if l.startswith('#')]
     assert keys == list(range(len(keys)))
+
+
+def test_sdgpu_search_two_ranks_leave_one_alignment_db(gpu, tmp_path):
+    """plain `search` under two ranks: the per-rank parts become ONE alignment DB (split data files NAME.0 / NAME.1 under one
+    NAME.index, the layout of the reference's multi-threaded DBWriter) with the entries of the one-rank DB, key for key"""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from dbutil import SDGPU, sdgpu, example_fasta
+    fa = example_fasta(tmp_path)
+    q, t = tmp_path / 'q', tmp_path / 't'
+    sdgpu('createsetdb', fa[0], fa[1], t, tmp_path / 'tmp', '-v', '0')
+    sdgpu('createsetdb', fa[1], fa[0], q, tmp_path / 'tmp', '-v', '0')
+    sdgpu('search', q, t, tmp_path / 'aln1', tmp_path / 'tmp1', '-v', '0')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(32500 + os.getpid() % 2000))
+        procs.append(subprocess.Popen([SDGPU, 'search', str(q), str(t), str(tmp_path / 'aln2'), str(tmp_path / 'tmp2'), '-v', '0'], env=env))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    assert os.path.exists(tmp_path / 'aln2.0') and os.path.exists(tmp_path / 'aln2.1') and not os.path.exists(tmp_path / 'aln2.0.index')
+    # both DBs flattened by the binary's own reader
+    sdgpu('prefixid', tmp_path / 'aln1', tmp_path / 'aln1.flat', '--tsv', '--threads', '1')
+    sdgpu('prefixid', tmp_path / 'aln2', tmp_path / 'aln2.flat', '--tsv', '--threads', '1')
+    one, two = open(tmp_path / 'aln1.flat').readlines(), open(tmp_path / 'aln2.flat').readlines()
+    assert len(one) > 10000 and sorted(one) == sorted(two)
+    n1 = sum(1 for _ in open(str(tmp_path / 'aln1') + '.index'))
+    n2 = sum(1 for _ in open(str(tmp_path / 'aln2') + '.index'))
+    assert n1 == n2

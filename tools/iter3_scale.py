@@ -110,8 +110,12 @@ def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
         shutil.rmtree(fa_dir)
         tmp = os.path.join(work, 'tmp')
         t0 = time.time()
-        sdgpu('clustersearch', Q, T, os.path.join(work, 'iter3.tsv'), tmp, '--num-iterations', '3', '--keep-tmp', '1', '--threads', threads, '-v', '0')
+        verbose = os.environ.get('SD_ITER3_VERBOSE') == '1'
+        r = sdgpu('clustersearch', Q, T, os.path.join(work, 'iter3.tsv'), tmp, '--num-iterations', '3', '--keep-tmp', '1', '--threads', threads,
+                  '-v', '3' if verbose else '0')
         wall = time.time() - t0
+        if verbose:
+            log(r.stdout[-6000:])
         nq = int(ps.set_start[q_sets])
         tsv = open(os.path.join(work, 'iter3.tsv')).readlines()
         out.update(wall_s=wall, queries=nq, genome_pairs=q_sets * P, genome_pairs_per_s=q_sets * P / wall,
