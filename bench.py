@@ -150,7 +150,7 @@ def measure(args, rank, local_rank, world, dist, torch):
     host = Host(n_threads)
     gpu = Context(dev_index)
     t0 = time.time()
-    ps = make_proteomes(P, genes_per_proteome=args.genes, seed=0x5ED0 + 2)
+    ps = make_proteomes(P, genes_per_proteome=args.genes, seed=0x5ED0 + 2, workers=n_threads if P >= 32 else 1)   # this rank's share of the cores
     t_gen = time.time() - t0
     db = SetDB.from_proteomes(ps)
     max_seqs = args.max_seqs if args.max_seqs > 0 else max(300, 2 * P)

@@ -633,7 +633,10 @@ void launchScorePk(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, ui
     if (n == 0) return;
     constexpr uint32_t perWave = 2 * (64 / LW);
     dim3 grid((n + perWave - 1) / perWave), block(64);
-    hipLaunchKernelGGL((sdpk::sw_score_pk_kernel<RT, LW, MULTI, WIDE, SHARED>), grid, block, 0, ctx->stream, dTasks, n, q->dRes, q->dBias,
+    // SD_SW_LDS_PAD: unused dynamic LDS per wavefront, i.e. a cap on how many score wavefronts a CU holds -- what it leaves
+    // free (LDS, wave slots) is what the memory-bound prefilter workgroups of the other streams run in
+    static const unsigned ldsPad = getenv("SD_SW_LDS_PAD") ? (unsigned) atoi(getenv("SD_SW_LDS_PAD")) : 0u;
+    hipLaunchKernelGGL((sdpk::sw_score_pk_kernel<RT, LW, MULTI, WIDE, SHARED>), grid, block, ldsPad, ctx->stream, dTasks, n, q->dRes, q->dBias,
                        t->dRes, dMat, go, ge, dOut, dBound, dOrder, (const int8_t *) q->dProf);
 }
 
