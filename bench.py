@@ -60,6 +60,8 @@ def parse():
     ap.add_argument('--no-p10000', action='store_true', help='skip the 10 000-proteome record')
     ap.add_argument('--p10000-steps', type=int, default=1)
     ap.add_argument('--p10000-batch', type=int, default=2, help='query proteomes per step of the 10 000-proteome record')
+    ap.add_argument('--leg-budget', type=float, default=300.0, help='a child record (p1000, p10000, iter3) is started only while the run is '
+                                                                     'younger than this many seconds; later ones are reported as skipped')
     ap.add_argument('--no-iter3', action='store_true', help='skip the --num-iterations 3 record (BASELINE configs[3] at 1 000 target proteomes)')
     ap.add_argument('--iter3-queries', type=int, default=2, help='query proteomes of the --num-iterations 3 record')
     ap.add_argument('--no-index-check', action='store_true', help='skip the sampled check of the device-built index against the host builder')
@@ -150,7 +152,7 @@ def measure(args, rank, local_rank, world, dist, torch):
     host = Host(n_threads)
     gpu = Context(dev_index)
     t0 = time.time()
-    ps = make_proteomes(P, genes_per_proteome=args.genes, seed=0x5ED0 + 2, workers=n_threads if P >= 32 else 1)   # this rank's share of the cores
+    ps = make_proteomes(P, genes_per_proteome=args.genes, seed=0x5ED0 + 2, workers=n_threads if P >= 128 else 1)   # this rank's share of the cores (small sets: in process)
     t_gen = time.time() - t0
     db = SetDB.from_proteomes(ps)
     max_seqs = args.max_seqs if args.max_seqs > 0 else max(300, 2 * P)
@@ -419,8 +421,18 @@ def measure(args, rank, local_rank, world, dist, torch):
     return res, extras
 
 
+def _leg_allowed(res, name, t_start, args):
+    """child records run in the order of their weight for north_star (p1000, p10000, iter3) while the time budget lasts"""
+    age = time.time() - t_start
+    if age < args.leg_budget:
+        return True
+    res[name] = dict(skipped='the run was %.0f s old when this record was due (--leg-budget %.0f)' % (age, args.leg_budget))
+    return False
+
+
 def main():
     args = parse()
+    t_start = time.time()
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -466,7 +478,7 @@ def main():
     if args.record:   # child of the p1000 / p10000 leg
         print(json.dumps(res))
         return
-    if world == 1 and not args.no_p1000 and args.proteomes != 1000:
+    if world == 1 and not args.no_p1000 and args.proteomes != 1000 and _leg_allowed(res, 'p1000', t_start, args):
         # BASELINE configs[2]'s size on this one GPU, in a child process (fresh device memory): a short run with its own
         # reference CPU sample -- north_star quotes its >= 10x target at this size
         cmd = [sys.executable, os.path.abspath(__file__), '--record', '--proteomes', '1000', '--steps', str(args.p1000_steps), '--warmup', '1',
@@ -488,7 +500,7 @@ def main():
                 res['p1000'] = dict(error=(p.stderr or p.stdout)[-300:])
         except Exception as e:
             res['p1000'] = dict(error=repr(e)[:300])
-    if world == 1 and not args.no_p10000 and not args.no_p1000 and args.proteomes not in (1000, 10000):
+    if world == 1 and not args.no_p10000 and not args.no_p1000 and args.proteomes not in (1000, 10000) and _leg_allowed(res, 'p10000', t_start, args):
         # BASELINE configs[4]: 10 000 proteomes (3 * 10^7 sequences, 9 * 10^9 residues, k = 7) resident on this one GPU -- generated,
         # indexed on the device, checked on a sample against the host builder, and searched for a short step
         cmd = [sys.executable, os.path.abspath(__file__), '--record', '--proteomes', '10000', '--steps', str(args.p10000_steps), '--warmup', '1',
@@ -506,7 +518,7 @@ def main():
                 res['p10000'] = dict(error=(p.stderr or p.stdout)[-300:])
         except Exception as e:
             res['p10000'] = dict(error=repr(e)[:300])
-    if world == 1 and not args.no_iter3 and not args.no_p1000 and args.proteomes not in (1000, 10000):
+    if world == 1 and not args.no_iter3 and not args.no_p1000 and args.proteomes not in (1000, 10000) and _leg_allowed(res, 'iter3', t_start, args):
         # BASELINE configs[3]: `clustersearch --num-iterations 3` (sequence search, two profile searches) against 1 000 target
         # proteomes through the sdgpu binary and the reference's DB files, with its own sampled parity check against the
         # reference classes (tools/iter3_scale.py) -- a child process
