@@ -387,7 +387,7 @@ def gather_results(local_records, dist, device=None):
     to all ranks -- all_gather of the lengths, then of the padded payloads (RCCL on GPUs, gloo in the CPU tests)."""
     import torch
     world = dist.get_world_size()
-    rec = torch.as_tensor(np.ascontiguousarray(local_records, np.int64).reshape(-1))
+    rec = torch.from_numpy(np.array(local_records, np.int64, copy=True).reshape(-1))
     if device is not None:
         rec = rec.to(device)
     n = torch.tensor([rec.numel()], dtype=torch.int64, device=rec.device)
