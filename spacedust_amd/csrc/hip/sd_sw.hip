@@ -1823,6 +1823,27 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
             if (ib <= 6) { init6++; if (fb <= 6) init6final6++; else if (fb <= 14) init6final14++; }
             if (fb <= 14) final14++;
         }
+        {
+            static const int lim[8] = {1, 2, 3, 4, 6, 8, 14, 1 << 30};
+            uint64_t hi[8] = {0}, hf[8] = {0}, rowsF[8] = {0};
+            for (uint32_t i = 0; i < nPairs; i++) {
+                if (hL[i] == 0) continue;
+                const int ib = abs(hT[i].tLen - hT[i].qLen) + 1, fb = hT[i].band;
+                int a = 0, b = 0;
+                while (ib > lim[a]) a++;
+                while (fb > lim[b]) b++;
+                hi[a]++;
+                hf[b]++;
+                rowsF[b] += (uint64_t) hT[i].qLen;
+            }
+            fprintf(stderr, "[tb] band <=1 <=2 <=3 <=4 <=6 <=8 <=14 >14: initial");
+            for (int x = 0; x < 8; x++) fprintf(stderr, " %llu", (unsigned long long) hi[x]);
+            fprintf(stderr, " | final");
+            for (int x = 0; x < 8; x++) fprintf(stderr, " %llu", (unsigned long long) hf[x]);
+            fprintf(stderr, " | rows by final");
+            for (int x = 0; x < 8; x++) fprintf(stderr, " %llu", (unsigned long long) rowsF[x]);
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "[tb] done %llu: final band<=14 %llu; initial<=6 %llu of which final<=6 %llu, final 7..14 %llu\n",
                 (unsigned long long) nDone, (unsigned long long) final14, (unsigned long long) init6, (unsigned long long) init6final6,
                 (unsigned long long) init6final14);
