@@ -114,6 +114,7 @@ struct sd_seqset {
     uint64_t *dOff = nullptr;     // offsets n+1
     std::vector<uint64_t> hOff;   // host copy of the offsets
     std::vector<int32_t> hMinBias;// per sequence min(0, min cb8)
+    int32_t maxEntryAdd = 0;      // largest composition bias of the set (sequences) / largest profile entry (profile sets)
     std::vector<uint8_t> hRes;    // host copy (traceback identity count, scoreIdentical)
     std::vector<int8_t> hBias;
 };

@@ -878,7 +878,7 @@ extern "C" int sd_target_sample_check(sd_ctx *ctx, const sd_target *t, const uin
         hipLaunchKernelGGL(ib_check_triples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *) t->dOffsets,
                            (const uint64_t *) t->dBlockBase, (const uint2 *) t->dEntries, (const uint32_t *) dK.p, (const uint32_t *) dS.p,
                            (const uint32_t *) dP.p, n, dOut.p);
-    if (t->nEntries)
+    if (t->nEntries && nSample)
         hipLaunchKernelGGL(ib_count_sample, dim3(8192), dim3(256), 0, ctx->stream, (const uint2 *) t->dEntries, t->nEntries,
                            (const uint32_t *) dSample.p, nSample, dOut.p + 1);
     SD_HIP(ctx, hipGetLastError());

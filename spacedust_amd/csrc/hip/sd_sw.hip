@@ -778,10 +778,11 @@ constexpr uint32_t FIRST_WIDE_CLASS = N_PK_CLASSES;
 constexpr uint32_t FIRST_INT32_CLASS = 2 * N_PK_CLASSES;
 enum ScoreKernel { SCORE_PK = 0, SCORE_PK_WIDE = 1, SCORE_INT32 = 2 };
 constexpr uint32_t KEY_INVALID = N_SCORE_CLASSES * 1024u;   // sorts after every class
-__device__ __forceinline__ uint32_t scoreKey(int n, int tL, int kernel) {
+// wideRowLimit: int16 cells hold a score for certain while min(n, tL) * (largest entry of this call's query profiles) <= 32 767
+// (no saturation of the reference's word kernel to reproduce, no wrap); longer pairs take the int32 kernel
+__device__ __forceinline__ uint32_t scoreKey(int n, int tL, int kernel, int wideRowLimit = 800) {
     int ci;
-    // int16 cells: a score cannot exceed min(n, tL) * (largest profile entry < 40)
-    if (kernel == SCORE_PK_WIDE && min(n, tL) > 800) kernel = SCORE_INT32;
+    if (kernel == SCORE_PK_WIDE && min(n, tL) > wideRowLimit) kernel = SCORE_INT32;
     if (kernel == SCORE_INT32 || tL > 65535) {
         ci = FIRST_INT32_CLASS + (n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3)));
     } else {
@@ -795,7 +796,7 @@ __device__ __forceinline__ uint32_t scoreKey(int n, int tL, int kernel) {
 }
 
 struct DevGateParams {
-    int go, ge, matMin, swMode, covMode;
+    int go, ge, matMin, swMode, covMode, wideRowLimit;
     float covThr;
     double evalThr;
     // Gumbel parameters (sd::Evaluer) for the device-side E-value gate
@@ -880,7 +881,7 @@ __global__ void k_bounds(const uint32_t *__restrict__ keys, uint32_t n, uint32_t
 __global__ void __launch_bounds__(256)
 k_gate_word(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const int32_t *__restrict__ out32,
             const int32_t *__restrict__ minBias, int matMin, SwTask *__restrict__ tasks, uint32_t *__restrict__ keys,
-            uint32_t *__restrict__ vals, uint8_t *__restrict__ word, const uint32_t *__restrict__ fwdKeys, int usePk) {
+            uint32_t *__restrict__ vals, uint8_t *__restrict__ word, const uint32_t *__restrict__ fwdKeys, int usePk, int wideRowLimit) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPairs) return;
     vals[i] = i;
@@ -893,7 +894,7 @@ k_gate_word(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const int32_t *
     word[i] = w ? 1 : 0;
     if (w) {
         tasks[i].segLen = max(1, (tasks[i].n + 15) / 16);
-        keys[i] = scoreKey(tasks[i].n, tasks[i].tL, usePk ? SCORE_PK_WIDE : SCORE_INT32);
+        keys[i] = scoreKey(tasks[i].n, tasks[i].tL, usePk ? SCORE_PK_WIDE : SCORE_INT32, wideRowLimit);
     } else {
         keys[i] = KEY_INVALID;
     }
@@ -937,7 +938,7 @@ k_gate_rev(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ
     tk.segLen = max(1, (tk.n + lanes - 1) / lanes);
     tk.slot = i; tk.boundOff = 0;
     tasks[i] = tk;
-    keys[i] = scoreKey(tk.n, tk.tL, !usePk ? SCORE_INT32 : (word[i] ? SCORE_PK_WIDE : SCORE_PK));
+    keys[i] = scoreKey(tk.n, tk.tL, !usePk ? SCORE_INT32 : (word[i] ? SCORE_PK_WIDE : SCORE_PK), gp.wideRowLimit);
 }
 
 // traceback task classes: N_TB_NARROW register-band classes by query rows, then three LDS-band classes by band width
@@ -1466,6 +1467,11 @@ int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offse
         for (uint64_t x = offsets[i]; x < offsets[i + 1]; x++) m = std::min(m, (int) s->hBias[x]);
         s->hMinBias[i] = m;
     }
+    {
+        int mx = 0;
+        for (int8_t b : s->hBias) mx = std::max(mx, (int) b);
+        s->maxEntryAdd = mx;
+    }
     const size_t pad = 64;
     if (hipMalloc((void **) &s->dRes, s->total + pad) != hipSuccess || hipMalloc((void **) &s->dBias, s->total + pad) != hipSuccess ||
         hipMalloc((void **) &s->dOff, (n + 1) * sizeof(uint64_t)) != hipSuccess) {
@@ -1502,6 +1508,11 @@ int sd_profileset_create(sd_ctx *ctx, const uint8_t *queryLetters, const uint64_
         for (uint64_t x = offsets[i]; x < offsets[i + 1]; x++)
             for (int a = 0; a < 20; a++) m = std::min(m, (int) alnProfile[x * 21 + a]);
         s->hProfBias[i] = -m;
+    }
+    {
+        int mx = 1;
+        for (size_t x = 0; x < bytes; x++) mx = std::max(mx, (int) alnProfile[x]);
+        s->maxEntryAdd = mx;
     }
     return SD_OK;
 }
@@ -1590,6 +1601,12 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     std::unique_ptr<HostScope> hs(new HostScope(ctx, "align.upload"));
     DevGateParams gp;
     gp.go = go; gp.ge = ge; gp.matMin = matMin; gp.swMode = par->swMode; gp.covMode = par->covMode; gp.covThr = par->covThr;
+    {   // the int16 kernels are exact while no cell can exceed 32 767: rows x the largest entry of a query profile of this call
+        int matMax = 0;
+        for (int x = 0; x < 441; x++) matMax = std::max(matMax, (int) par->matrix[x]);
+        const int maxEntry = std::max(1, queries->dProf ? queries->maxEntryAdd : matMax + queries->maxEntryAdd);
+        gp.wideRowLimit = 32767 / maxEntry;
+    }
     gp.evalThr = par->evalThr;
     gp.lambda = ev.lambda; gp.K = ev.K; gp.aI = ev.aI; gp.bI = ev.bI; gp.alphaI = ev.alphaI; gp.betaI = ev.betaI;
     gp.aJ = ev.aJ; gp.bJ = ev.bJ; gp.alphaJ = ev.alphaJ; gp.betaJ = ev.betaJ; gp.sigma = ev.sigma; gp.tau = ev.tau;
@@ -1669,7 +1686,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     // ---- pass 2: saturated pairs again with the word kernel's 16-lane structure
     hs.reset(new HostScope(ctx, "align.fwd16"));
     hipLaunchKernelGGL(k_gate_word, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dOut32, dMinBias, queries->dProf ? 0 : matMin, dTasks, dKeys,
-                       dVals, dWord, dFwdKeys, usePk);
+                       dVals, dWord, dFwdKeys, usePk, gp.wideRowLimit);
     hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dKeys, dCells + 0);
     rc = devRunScore(ctx, nPairs, dKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go, ge,
                      dOut16, &nValid, dShare);
