@@ -2774,7 +2774,12 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, dOutCount.alloc(bq));
         {
             ProfScope ps(ctx, "prefilter_select_hits");
-            if (maxHits + 1 <= 2048)
+            if (maxHits + 1 <= 512 && !getenv("SD_PF_SEL4096"))   // short result lists: a 12-KB sorter instead of 48 KB (more workgroups per CU)
+                hipLaunchKernelGGL(select_hits_kernel<1024>, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
+                                   diagSrc, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
+                                   par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask, useJoin ? binBits : -1,
+                                   (const uint32_t *) dQSplit.p, (const uint32_t *) dQParts.p, (const uint32_t *) dQSplits.p);
+            else if (maxHits + 1 <= 2048)
                 hipLaunchKernelGGL(select_hits_kernel<4096>, dim3(bq), dim3(256), 0, ctx->stream, bq, dQStart.p, dKKey.p, dKVal.p, dKScore.p,
                                    diagSrc, tBits, par->binSize - 1, maxHits, par->minDiagScore, dIdent.p, dQOff.p, T->dSeqOff,
                                    par->covMode, par->covThr, dQ.p, dDB.p, dMat.p, dOut.p, dOutCount.p, dErr.p, dProfAln, posMask, useJoin ? binBits : -1,
