@@ -627,181 +627,6 @@ sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const ui
     res[2 * id + 1] = ids;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Narrow bands, one LANE per task (sequence queries): the register-band kernel above spends a 32-lane half wavefront on a band
-// of 2 * band + 3 <= 32 cells and walks the rows one after the other, so a task with band 2 keeps 7 of 32 lanes busy.  Here a
-// lane owns the whole band -- h_b / e_b in WMAX registers each, the target window in WMAX more -- and steps through its cells
-// itself; 64 tasks of similar length share a wavefront and the row loop is wave-uniform.  Same arithmetic, same direction
-// codes, same walk as sw_traceback_narrow_kernel; the 4-bit codes of a row (ROWB bytes) go to the task's slice of the global
-// direction scratch.  WMAX = 7 / 11 / 19 / 31 serve bands up to 2 / 4 / 8 / 14; a task doubles its band inside the kernel
-// while it fits WMAX and moves to the next class in the next round.
-// ---------------------------------------------------------------------------------------------
-template <int WMAX>
-__global__ void __launch_bounds__(64)
-sw_traceback_lane_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes, const int8_t *__restrict__ qBias,
-                         const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat, int go, int ge, int8_t *__restrict__ dirScratch,
-                         char *__restrict__ bt, int32_t *__restrict__ res, const uint32_t *__restrict__ order) {
-    constexpr int ROWB = WMAX <= 7 ? 4 : (WMAX <= 11 ? 8 : (WMAX <= 19 ? 12 : 16));
-    constexpr int RD = ROWB / 4;
-    __shared__ int8_t smat[441];
-    for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
-    __syncthreads();
-    const uint32_t lid = blockIdx.x * 64 + threadIdx.x;
-    const bool have = lid < nTasks;
-    const uint32_t id = have ? (order ? order[lid] : lid) : 0;
-    TbTask tk;
-    if (have) tk = tasks[id];
-    else { tk.qLen = 0; tk.tLen = 0; tk.band = 1; tk.score = 0; tk.maxv = 0; tk.qAbs = 0; tk.tAbs = 0; tk.slot = 0; tk.dirOff = 0; tk.btOff = 0; }
-    const int qLen = tk.qLen, tLen = tk.tLen;
-    const uint8_t *sq = qRes + tk.qAbs;
-    const int8_t *scb = qBias + tk.qAbs;
-    const uint8_t *st = tRes + tk.tAbs;
-    uint8_t *dirs = (uint8_t *) dirScratch + tk.dirOff;
-    int band = tk.band, maxv = tk.maxv;
-    bool reached = false;
-    for (;;) {
-        const int width = band * 2 + 3;
-        const bool fits = width <= WMAX;
-        const int rows = (have && fits && !reached) ? qLen : 0;
-        int nRows = rows;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) nRows = max(nRows, __shfl_xor(nRows, off, 64));
-        if (nRows == 0) break;
-        int hb[WMAX + 1], eb[WMAX + 1];
-        uint32_t tw[WMAX];   // tw[p] = 21-row offset-free residue of target column xi + p - 1 (p >= 1)
-#pragma unroll
-        for (int p = 0; p <= WMAX; p++) { hb[p] = 0; eb[p] = 0; }
-        auto tAt = [&](int j) -> uint32_t {
-            j = j < 0 ? 0 : (j >= tLen ? tLen - 1 : j);
-            return rows ? (uint32_t) st[j] : 0u;
-        };
-#pragma unroll
-        for (int p = 1; p < WMAX; p++) tw[p] = tAt(p - 1);
-        for (int i = 0; i < nRows; i++) {
-            const bool live = i < rows;
-            const int r = rows ? (i < qLen ? i : qLen - 1) : 0;
-            const int a21 = rows ? 21 * (int) sq[r] : 0;
-            const int cb = rows ? (int) scb[r] : 0;
-            const int xi = (i - band) > 0 ? (i - band) : 0;
-            const bool delta = (i - band) >= 1;
-            int end = tLen - 1;
-            end = end < i + band ? end : i + band;
-            const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
-            const int W = end - xi + 1;
-            if (delta) {   // the window moved one column to the right
-                const uint32_t fresh = tAt(xi + WMAX - 2);
-#pragma unroll
-                for (int p = 1; p < WMAX - 1; p++) tw[p] = tw[p + 1];
-                tw[WMAX - 1] = fresh;
-            }
-            // the two boundary cells of the band array are cleared before the row is read
-            if (live) {
-                hb[0] = 0;
-                eb[0] = 0;
-#pragma unroll
-                for (int p = 1; p < WMAX; p++) {
-                    const bool z = p == edge;
-                    hb[p] = z ? 0 : hb[p];
-                    eb[p] = z ? 0 : eb[p];
-                }
-            }
-            uint32_t rowDw[RD];
-#pragma unroll
-            for (int x = 0; x < RD; x++) rowDw[x] = 0;
-            int below = hb[0];    // previous-row h_b[p - 1] (before this row overwrites it)
-            int run = 0;          // prefix maximum of T + ge * u + 1 over the valid cells left of this one (0: none)
-            int hcPrev = 0, fPrev = 0;
-#pragma unroll
-            for (int p = 1; p < WMAX; p++) {
-                const int u = p;
-                const int oldH = hb[p], oldE = eb[p];
-                const int upH = hb[p + 1], upE = eb[p + 1];
-                const int hE = delta ? upH : oldH, eE = delta ? upE : oldE, hD = delta ? oldH : below;
-                const bool valid = live && u <= W;
-                const int t1 = i == 0 ? -go : hE - go;
-                const int t2 = i == 0 ? -ge : eE - ge;
-                const int eNew = t1 > t2 ? t1 : t2;
-                const bool dirE = t1 > t2;
-                const int e1 = eNew > 0 ? eNew : 0;
-                const int sCur = (int) smat[a21 + (int) tw[p]] + cb;
-                const int diag = hD + sCur;
-                const int T = e1 > diag ? e1 : diag;
-                const int gx = run - go - 1;
-                const int g = (-ge) > gx ? (-ge) : gx;
-                const int f = g - ge * (u - 1);
-                const int hcv = T > f ? T : f;
-                const int hcP = u <= 1 ? 0 : hcPrev, fP = u <= 1 ? 0 : fPrev;
-                const bool dirF = (hcP - go) > (fP - ge);
-                const int f1 = f > 0 ? f : 0;
-                const int tmp1 = e1 > f1 ? e1 : f1;
-                int code = (dirE ? 1 : 0) | (dirF ? 2 : 0) | ((tmp1 > diag) ? ((e1 > f1) ? 4 : 8) : 0);
-                code = valid ? code : 0;
-                const int inc = valid ? T + ge * u + 1 : 0;
-                run = run > inc ? run : inc;
-                hcPrev = hcv;
-                fPrev = f;
-                below = oldH;
-                eb[p] = valid ? eNew : oldE;
-                hb[p] = valid ? hcv : oldH;
-                maxv = (valid && hcv > maxv) ? hcv : maxv;
-                rowDw[(p - 1) >> 3] |= (uint32_t) code << (4 * ((p - 1) & 7));
-            }
-            if (live) {
-                uint32_t *dst = (uint32_t *) (dirs + (size_t) ROWB * i);
-#pragma unroll
-                for (int x = 0; x < RD; x++) dst[x] = rowDw[x];
-            }
-        }
-        if (have && !reached && fits) {
-            if (maxv >= tk.score) reached = true;
-            else band *= 2;
-        }
-    }
-    if (!have) return;
-    tasks[id].maxv = maxv;
-    tasks[id].band = band;
-    if (!reached) {
-        res[2 * id] = -2;
-        return;
-    }
-    // traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581), written backwards
-    const int width_d = band * 2 + 1;
-    int i = qLen - 1, j = tLen - 1, state = 2;
-    char *o = bt + tk.btOff + (qLen + tLen + 2);
-    int len = 0, ids = 0;
-    bool bad = false;
-    while (i > 0 || j > 0) {
-        if (i < 0 || j < 0) { bad = true; break; }
-        int x = i - band;
-        x = x > 0 ? x : 0;
-        x = j - x;
-        if (x < 0 || x >= width_d) { bad = true; break; }
-        const int byte = dirs[(size_t) ROWB * i + (x >> 1)];
-        const int code = (x & 1) ? (byte >> 4) : (byte & 15);
-        int dcode;
-        const int dE = (code & 1) ? 3 : 2, dF = (code & 2) ? 5 : 4;
-        if (state == 0) dcode = dE;
-        else if (state == 1) dcode = dF;
-        else dcode = (code & 4) ? dE : ((code & 8) ? dF : 1);
-        switch (dcode) {
-            case 1: ids += (sq[i] == st[j]); --i; --j; state = 2; *--o = 'M'; len++; break;
-            case 2: --i; state = 0; *--o = 'I'; len++; break;
-            case 3: --i; state = 2; *--o = 'I'; len++; break;
-            case 4: --j; state = 1; *--o = 'D'; len++; break;
-            default: --j; state = 2; *--o = 'D'; len++; break;
-        }
-    }
-    if (bad || i != 0 || j != 0) {
-        res[2 * id] = -1;
-        return;
-    }
-    ids += (sq[0] == st[0]);
-    *--o = 'M';
-    len++;
-    res[2 * id] = len;
-    res[2 * id + 1] = ids;
-}
-
 template <int RT, int LW, bool MULTI, bool WIDE, bool SHARED>
 void launchScorePk(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, uint32_t n, const sd_seqset *q,
                    const sd_seqset *t, const int8_t *dMat, int go, int ge, int32_t *dOut, uint2 *dBound) {
@@ -971,7 +796,7 @@ __device__ __forceinline__ uint32_t scoreKey(int n, int tL, int kernel, int wide
 }
 
 struct DevGateParams {
-    int go, ge, matMin, swMode, covMode, wideRowLimit, tbLane;
+    int go, ge, matMin, swMode, covMode, wideRowLimit;
     float covThr;
     double evalThr;
     // Gumbel parameters (sd::Evaluer) for the device-side E-value gate
@@ -1125,14 +950,10 @@ constexpr int N_TB_NARROW = 9;
 __constant__ int c_tbNarrowQ[N_TB_NARROW] = {128, 192, 256, 320, 384, 512, 640, 768, 1024};
 static const int TB_NARROW_Q[N_TB_NARROW] = {128, 192, 256, 320, 384, 512, 640, 768, 1024};
 __device__ __forceinline__ bool tbNarrow(int band, int qLen, int tLen) { return band * 2 + 3 <= 32 && qLen <= 1024 && tLen <= 1024 + 13; }
-// lane mode (sequence queries): bands up to 14 go to the lane-per-task kernels, classes 0..3 = WMAX 7 / 11 / 19 / 31
-__device__ __forceinline__ int tbLaneClass(int band) { return band <= 2 ? 0 : (band <= 4 ? 1 : (band <= 8 ? 2 : 3)); }
-__device__ __forceinline__ uint32_t tbKey(int band, int qLen, int tLen, int lane = 0) {
+__device__ __forceinline__ uint32_t tbKey(int band, int qLen, int tLen) {
     const int w = band * 2 + 3;
     int ci;
-    if (lane && w <= 31) {
-        return (uint32_t) tbLaneClass(band) * 4096u + (uint32_t) (4095 - min(qLen >> 3, 4095));
-    } else if (tbNarrow(band, qLen, tLen)) {
+    if (tbNarrow(band, qLen, tLen)) {
         ci = 0;
         while (qLen > c_tbNarrowQ[ci]) ci++;
     } else {
@@ -1145,11 +966,7 @@ constexpr uint32_t N_TB_CLASSES = N_TB_NARROW + 4;   // + the global-band class 
 constexpr uint32_t TBKEY_INVALID = N_TB_CLASSES * 4096u;
 // global direction scratch (LDS-band kernel only), sized for the widest band of the task's class because the
 // kernel keeps doubling the band inside its class
-__device__ __forceinline__ uint64_t tbDirBytes(int band, int qLen, int tLen, int lane = 0) {
-    if (lane && band * 2 + 3 <= 31) {   // 4-bit codes, a row of the class's widest band: 4 / 8 / 12 / 16 bytes
-        const int rowBytes = 4 * (tbLaneClass(band) + 1);
-        return ((uint64_t) rowBytes * (uint64_t) qLen + 31) & ~15ull;
-    }
+__device__ __forceinline__ uint64_t tbDirBytes(int band, int qLen, int tLen) {
     if (tbNarrow(band, qLen, tLen)) return 0ull;
     const int w = band * 2 + 3;
     if (w > 2047)   // global-band class: one attempt per round at exactly this band, band arrays in front of the directions
@@ -1194,8 +1011,8 @@ k_gate_tb(uint32_t nPairs, DevGateParams gp, const uint32_t *__restrict__ pairQ,
     t.band = abs(t.tLen - t.qLen) + 1;
     t.maxv = 0; t.slot = i; t.intOff = 0; t.dirOff = 0; t.btOff = 0;
     tb[i] = t;
-    keys[i] = tbKey(t.band, t.qLen, t.tLen, gp.tbLane);
-    dirBytes[i] = tbDirBytes(t.band, t.qLen, t.tLen, gp.tbLane);
+    keys[i] = tbKey(t.band, t.qLen, t.tLen);
+    dirBytes[i] = tbDirBytes(t.band, t.qLen, t.tLen);
     btBytes[i] = (uint64_t) t.qLen + t.tLen + 2;
 }
 
@@ -1224,7 +1041,7 @@ __global__ void __launch_bounds__(256)
 k_tb_collect(uint32_t nPairs, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, TbTask *__restrict__ tb,
              const int32_t *__restrict__ tbRes, uint64_t *__restrict__ dirBytes, uint64_t *__restrict__ btLenOut,
              sd_sw_result *__restrict__ res, int *__restrict__ errFlag, int maxBand,
-             const uint32_t *__restrict__ keysRound /* what this round ran: deferred tasks keep key and scratch size */, int tbLane) {
+             const uint32_t *__restrict__ keysRound /* what this round ran: deferred tasks keep key and scratch size */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPairs) return;
     vals[i] = i;
@@ -1236,8 +1053,8 @@ k_tb_collect(uint32_t nPairs, uint32_t *__restrict__ keys, uint32_t *__restrict_
         // the full rectangle is inside the band once band >= max(qLen, tLen): a task that still misses its score then is
         // a traceback error, not a reason to double again
         if (band > maxBand) { atomicExch(errFlag, 2); keys[i] = TBKEY_INVALID; dirBytes[i] = 0; return; }
-        keys[i] = tbKey(band, tb[i].qLen, tb[i].tLen, tbLane);
-        dirBytes[i] = tbDirBytes(band, tb[i].qLen, tb[i].tLen, tbLane);
+        keys[i] = tbKey(band, tb[i].qLen, tb[i].tLen);
+        dirBytes[i] = tbDirBytes(band, tb[i].qLen, tb[i].tLen);
     } else if (len < 0) {
         atomicExch(errFlag, 2);
         keys[i] = TBKEY_INVALID;
@@ -1790,8 +1607,6 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         const int maxEntry = std::max(1, queries->dProf ? queries->maxEntryAdd : matMax + queries->maxEntryAdd);
         gp.wideRowLimit = 32767 / maxEntry;
     }
-    // narrow traceback bands one lane per task (sequence queries; SD_TB_LANE=0: the half-wavefront kernels)
-    gp.tbLane = (!queries->dProf && !(getenv("SD_TB_LANE") && atoi(getenv("SD_TB_LANE")) == 0)) ? 1 : 0;
     gp.evalThr = par->evalThr;
     gp.lambda = ev.lambda; gp.K = ev.K; gp.aI = ev.aI; gp.bI = ev.bI; gp.alphaI = ev.alphaI; gp.betaI = ev.betaI;
     gp.aJ = ev.aJ; gp.bJ = ev.bJ; gp.alphaJ = ev.alphaJ; gp.betaJ = ev.betaJ; gp.sigma = ev.sigma; gp.tau = ev.tau;
@@ -1955,22 +1770,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
             SCRATCH_BUDGET /= 2;   // another lane took the memory meanwhile: smaller slices
             continue;
         }
-        for (int ci = 0; ci < 4 && gp.tbLane; ci++) {
-            const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
-            if (cnt == 0) continue;
-            static const char *const laneNames[4] = {"sw_traceback.lane7", "sw_traceback.lane11", "sw_traceback.lane19", "sw_traceback.lane31"};
-            ProfScope ps(ctx, laneNames[ci]);
-            const dim3 g((cnt + 63) / 64), b(64);
-#define SD_TB_LANE(W)                                                                                                                  \
-    hipLaunchKernelGGL(sw_traceback_lane_kernel<W>, g, b, 0, ctx->stream, dTb, cnt, queries->dRes, queries->dBias, targets->dRes, dMat, go, ge, \
-                       dDir, dBt, dTbRes, dOrder + begin)
-            if (ci == 0) SD_TB_LANE(7);
-            else if (ci == 1) SD_TB_LANE(11);
-            else if (ci == 2) SD_TB_LANE(19);
-            else SD_TB_LANE(31);
-#undef SD_TB_LANE
-        }
-        for (int ci = 0; ci < N_TB_NARROW && !gp.tbLane; ci++) {
+        for (int ci = 0; ci < N_TB_NARROW; ci++) {
             const uint32_t begin = hb[ci], cnt = hb[ci + 1] - hb[ci];
             if (cnt == 0) continue;
             static const char *const tbNames[N_TB_NARROW] = {"sw_traceback.narrow128", "sw_traceback.narrow192", "sw_traceback.narrow256",
@@ -2024,7 +1824,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         }
         SD_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_tb_collect, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dVals, dTb, dTbRes, dDirBytes, dBtLen,
-                           dRes, dErr, 4 * 65536, dKeysRound, gp.tbLane);
+                           dRes, dErr, 4 * 65536, dKeysRound);
     }
     if (tbPending) return sdFail(ctx, SD_EHIP, "traceback: tasks still pending after 4096 rounds");
     if (getenv("SD_DEBUG_TB")) {   // band statistics of the finished tasks
