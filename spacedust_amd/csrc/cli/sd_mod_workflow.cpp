@@ -555,6 +555,9 @@ int result2profileModule(const Args &a) {
     if (!out.open(a.pos[3], sddb::DBTYPE_HMM_PROFILE, &err)) return fail(err);
     const size_t n = aln.size();
     const size_t chunk = 4096;
+    double tParse = 0, tCompute = 0, tWrite = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tLoaded = now();
     std::vector<uint8_t> qLetters;
     std::vector<uint64_t> qOff, edgeOff, btOff;
     std::vector<uint32_t> edgeT, keys;
@@ -563,6 +566,7 @@ int result2profileModule(const Args &a) {
     std::vector<char> profiles;
     for (size_t c0 = 0; c0 < n; c0 += chunk) {
         const size_t c1 = std::min(n, c0 + chunk);
+        const double t0 = now();
         qLetters.clear();
         qOff.assign(1, 0);
         edgeOff.assign(1, 0);
@@ -622,12 +626,19 @@ int result2profileModule(const Args &a) {
         edgeT.push_back(0);
         eQ.push_back(0);
         eT.push_back(0);
+        const double t1 = now();
         const int rc = sd_r2p_batch(r2p, &p, nQ, qLetters.data(), qOff.data(), edgeOff.data(), edgeT.data(), eQ.data(), eT.data(), pool.data(),
                                     btOff.data(), tdb->residues.data(), tdb->offsets.data(), profiles.data(), nullptr);
         if (rc != SD_OK) return fail("sd_r2p_batch failed (" + std::to_string(rc) + ")");
+        const double t2 = now();
         for (uint32_t q = 0; q < nQ; q++)
             if (!out.write(keys[q], profiles.data() + qOff[q] * 25, (size_t) (qOff[q + 1] - qOff[q]) * 25)) return fail("cannot write " + a.pos[3]);
+        tParse += t1 - t0;
+        tCompute += t2 - t1;
+        tWrite += now() - t2;
     }
+    info(a, "result2profile: parse %.2f s, profiles %.2f s (%d threads), write %.2f s\n", tParse, tCompute, threads, tWrite);
+    (void) tLoaded;
     if (!out.close(&err)) return fail(err);
     // the profile DB shares the query DB's ancillary files (DBReader::softlinkDb(..., SEQUENCE_ANCILLARY), :318-320)
     for (const char *suffix : {"_h", "_h.index", "_h.dbtype", ".lookup", ".source"}) {
