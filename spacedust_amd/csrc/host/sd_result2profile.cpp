@@ -422,6 +422,7 @@ struct ProfileScratch {
     std::vector<float> share;                        // [L + 1][24]: 1 / (distinct residues x rows with that residue)
     std::vector<float> subFrequency;                 // [L + 1][23]
     std::vector<int> distinct;
+    std::vector<uint32_t> active;                    // rows with a residue in the current column
     std::vector<float> nullScore;
 };
 
@@ -514,8 +515,28 @@ void columnWeights(ProfileScratch &w, const double *background, float *frequency
                     }
                     for (int a = kAny; a < kFreq; a++) share[j * kCodes + a] = 0.0f;
                 }
-                for (size_t r = 0; r < nRows; r++) {
-                    if (row[r][i] >= kAny) continue;
+                // a row's weight = the sum of its cells' shares in column order.  Eight rows at a time: eight independent
+                // chains of additions instead of one (every row still adds its own shares in the same order)
+                w.active.clear();
+                for (size_t r = 0; r < nRows; r++)
+                    if (row[r][i] < kAny) w.active.push_back((uint32_t) r);
+                const size_t nActive = w.active.size();
+                size_t g = 0;
+                for (; g + 8 <= nActive; g += 8) {
+                    const char *c0 = row[w.active[g]], *c1 = row[w.active[g + 1]], *c2 = row[w.active[g + 2]], *c3 = row[w.active[g + 3]];
+                    const char *c4 = row[w.active[g + 4]], *c5 = row[w.active[g + 5]], *c6 = row[w.active[g + 6]], *c7 = row[w.active[g + 7]];
+                    float a0 = local[w.active[g]], a1 = local[w.active[g + 1]], a2 = local[w.active[g + 2]], a3 = local[w.active[g + 3]];
+                    float a4 = local[w.active[g + 4]], a5 = local[w.active[g + 5]], a6 = local[w.active[g + 6]], a7 = local[w.active[g + 7]];
+                    for (int j = jmin; j <= jmax; j++) {
+                        const float *sj = share + j * kCodes;
+                        a0 += sj[(int) c0[j]]; a1 += sj[(int) c1[j]]; a2 += sj[(int) c2[j]]; a3 += sj[(int) c3[j]];
+                        a4 += sj[(int) c4[j]]; a5 += sj[(int) c5[j]]; a6 += sj[(int) c6[j]]; a7 += sj[(int) c7[j]];
+                    }
+                    local[w.active[g]] = a0; local[w.active[g + 1]] = a1; local[w.active[g + 2]] = a2; local[w.active[g + 3]] = a3;
+                    local[w.active[g + 4]] = a4; local[w.active[g + 5]] = a5; local[w.active[g + 6]] = a6; local[w.active[g + 7]] = a7;
+                }
+                for (; g < nActive; g++) {
+                    const size_t r = w.active[g];
                     for (int j = jmin; j <= jmax; j++) local[r] += share[j * kCodes + (int) row[r][j]];
                 }
             }
