@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #pragma clang fp contract(off)   // every fused multiply-add below is written out: the host build's contractions, no others
 
@@ -558,6 +559,9 @@ extern "C" int sd_target_build(sd_ctx *ctx, int kmerSize, int kmerThr, int mask,
         longest = std::max<uint32_t>(longest, (uint32_t) len);
     }
     if ((uint64_t) nSeq >= (1ull << 47)) return SD_EINVAL;
+    // the kernels read their tables (seed positions, powers, tantan constants) from __constant__ memory: one build at a time
+    static std::mutex buildMutex;
+    std::lock_guard<std::mutex> buildLock(buildMutex);
     (void) hipSetDevice(ctx->device);
     sd_target *t = new sd_target();
     struct Guard {
