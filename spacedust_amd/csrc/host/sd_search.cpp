@@ -230,7 +230,8 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     const int threads = par->threads > 0 ? par->threads : cpus;
     int rc = sd_host_create(threads, &s->host);
     if (rc != SD_OK) return rc;
-    rc = sd_ctx_create(device, &s->ctxPf);
+    const int pfPrio = getenv("SD_PF_PRIO") ? atoi(getenv("SD_PF_PRIO")) : 0;   // stream priority of the prefilter lanes (-1 highest; measured: no effect on the throughput)
+    rc = sd_ctx_create_prio(device, pfPrio, &s->ctxPf);
     if (rc != SD_OK) return rc;
     rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAl);
     if (rc != SD_OK) return rc;
@@ -249,7 +250,7 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     if (rc != SD_OK) return rc;
     if (const char *e = getenv("SD_PF_LANES")) s->pfLanes = std::max(1, std::min(2, atoi(e)));
     if (s->pfLanes > 1) {
-        rc = sd_ctx_create(device, &s->ctxPf2);
+        rc = sd_ctx_create_prio(device, pfPrio, &s->ctxPf2);
         if (rc != SD_OK) return rc;
     }
     bool devBias = par->deviceBias > 0;
