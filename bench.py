@@ -77,6 +77,31 @@ def algorithmic_bytes(stats, q_len_sum):
         10 * stats['prefilter_hits']
 
 
+def isolated_prefilter(cs, host, ps, k, kmer_thr, max_seqs, bin_size, n_queries=8192):
+    """untimed: the prefilter of one block of queries ALONE on the device (the pipeline is idle), kernel times by HIP events --
+    what the stage's kernels do when nothing shares the GPU with them, next to the in-pipeline numbers of `roofline`"""
+    from spacedust_amd import api
+    n = min(n_queries, ps.n)
+    qoff = ps.offsets[:n + 1].astype(np.uint64)
+    qres = ps.residues[:int(qoff[-1])]
+    sw_b, dg_b, km_b = host.comp_bias(qres, qoff, k=k)
+    par = api.prefilter_params(host, ps.n, kmer_thr=kmer_thr, max_hits=max_seqs, bin_size=bin_size, k=k)
+    ids = np.arange(n, dtype=np.uint32)
+    tgt = cs.target_view()
+    api.prefilter(cs.ctx, tgt, par, qres, qoff, km_b, dg_b, ids)          # warm: workspaces of this shape
+    cs.ctx.profile(True)
+    hits, cnt, st = api.prefilter(cs.ctx, tgt, par, qres, qoff, km_b, dg_b, ids, want_stats=True)
+    rep = {k_: v[0] for k_, v in cs.ctx.profile_report().items() if k_.startswith('prefilter_')}
+    cs.ctx.profile(True)
+    ms = sum(rep.values())
+    stats = dict(kmers=int(st[:, 0].sum()), index_hits=int(st[:, 1].sum()), diagonals=int(st[:, 2].sum()), diag_len=int(st[:, 3].sum()),
+                 prefilter_hits=int(cnt[cnt != 0xFFFFFFFF].sum()))
+    b = algorithmic_bytes(stats, int(qoff[-1]))
+    return dict(queries=int(n), kernel_ms=ms, algorithmic_bytes=int(b), stage_achieved=b / ms / 1e6 if ms > 0 else 0.0,
+                stage_frac=b / ms / 1e6 / HBM_PEAK_GBS if ms > 0 else 0.0, kernel_ms_by_name={k_: round(v, 3) for k_, v in sorted(rep.items())},
+                note='same kernels, same algorithmic bytes (SURVEY.md 8(d)), nothing else on the device')
+
+
 def cpu_baseline_subprocess(proteomes, genes, max_seqs, kmer_thr, bin_size, entries_path, seconds, n_threads, check=0, check_out=''):
     """The baseline leg runs in a child process (niced, hard timeout, a bounded number of threads) so that it can never
     take the measurement -- or the box -- down with it."""
@@ -415,6 +440,11 @@ def measure(args, rank, local_rank, world, dist, torch):
         res['multi_gpu_note'] = ('%s scaling over query sets; an 8-GPU curve exists only where the driver ran this command with --gpus 8'
                                  % ('strong (BASELINE configs[2] as written)' if args.strong else 'weak'))
     res['index_check'] = index_check
+    if rank == 0 and not args.no_index_check:
+        try:
+            res['roofline']['isolated'] = isolated_prefilter(cs, host, ps, k, kmer_thr, max_seqs, int(cs.bin_size))
+        except Exception as e:   # (an extra, never the record)
+            res['roofline']['isolated'] = dict(error=repr(e)[:200])
     extras = dict(ps=ps, k=k, max_seqs=max_seqs, kmer_thr=kmer_thr, bin_size=int(cs.bin_size), gpu=gpu, host=host,
                   last=outs[-1] if outs else None, db=db)
     del cs
