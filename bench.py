@@ -442,7 +442,8 @@ def measure(args, rank, local_rank, world, dist, torch):
     res['index_check'] = index_check
     if rank == 0 and not args.no_index_check:
         try:
-            res['roofline']['isolated'] = isolated_prefilter(cs, host, ps, k, kmer_thr, max_seqs, int(cs.bin_size))
+            res['roofline']['isolated'] = isolated_prefilter(cs, host, ps, k, kmer_thr, max_seqs, int(cs.bin_size),
+                                                             n_queries=8192 if P < 5000 else 2048)
         except Exception as e:   # (an extra, never the record)
             res['roofline']['isolated'] = dict(error=repr(e)[:200])
     extras = dict(ps=ps, k=k, max_seqs=max_seqs, kmer_thr=kmer_thr, bin_size=int(cs.bin_size), gpu=gpu, host=host,
