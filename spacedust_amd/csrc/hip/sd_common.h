@@ -36,7 +36,43 @@ struct sd_ctx {
     struct WsEntry { void *p = nullptr; size_t bytes = 0; };
     std::map<std::string, WsEntry> ws;
     std::map<std::string, WsEntry> pinned;
+    // kernel timing without stalling the launching thread: event pairs are recorded around a launch and read back later
+    // (sdProfDrain), at a point where the stream is waited for anyway
+    struct ProfPending { std::string name; hipEvent_t a = nullptr, b = nullptr; };
+    std::vector<ProfPending> profPending;
+    std::vector<hipEvent_t> evPool;
 };
+
+inline hipEvent_t sdProfEvent(sd_ctx *ctx) {
+    if (!ctx->evPool.empty()) {
+        hipEvent_t e = ctx->evPool.back();
+        ctx->evPool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void) hipEventCreate(&e);
+    return e;
+}
+
+// Fold the finished event pairs into the profile (a stream completes its events in order: the first unfinished pair ends
+// the walk); wait = true blocks until every pair has finished.
+inline void sdProfDrain(sd_ctx *ctx, bool wait) {
+    size_t done = 0;
+    for (; done < ctx->profPending.size(); done++) {
+        sd_ctx::ProfPending &pp = ctx->profPending[done];
+        if (wait) (void) hipEventSynchronize(pp.b);
+        else if (hipEventQuery(pp.b) != hipSuccess) break;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess) {
+            sd_profile_entry &e = ctx->profile[pp.name];
+            e.ms += ms;
+            e.launches += 1;
+        }
+        ctx->evPool.push_back(pp.a);
+        ctx->evPool.push_back(pp.b);
+    }
+    if (done) ctx->profPending.erase(ctx->profPending.begin(), ctx->profPending.begin() + (long) done);
+}
 
 // Wait for the context's stream without burning a core.  hipStreamSynchronize -- and hipEventSynchronize even on a
 // hipEventBlockingSync event (measured, ROCm 7.2: thread CPU time = wall time) -- busy-wait; a pipeline keeps two such
@@ -59,7 +95,16 @@ inline hipError_t sdEventWait(hipEvent_t ev) {
         if (e != hipErrorNotReady) return e;
     }
 }
+struct sd_ctx;
+inline void sdProfDrain(sd_ctx *ctx, bool wait);
+inline hipError_t sdStreamSyncRaw(sd_ctx *ctx);
 inline hipError_t sdStreamSync(sd_ctx *ctx) {
+    const hipError_t e = sdStreamSyncRaw(ctx);
+    sdProfDrain(ctx, false);   // everything recorded before this point has finished
+    return e;
+}
+
+inline hipError_t sdStreamSyncRaw(sd_ctx *ctx) {
     if (ctx->evSync == nullptr) return hipStreamSynchronize(ctx->stream);
     hipError_t e = hipEventRecord(ctx->evSync, ctx->stream);
     if (e != hipSuccess) return e;
@@ -172,18 +217,21 @@ struct DevBuf {
 struct ProfScope {
     sd_ctx *ctx;
     const char *name;
+    hipEvent_t a = nullptr;
     ProfScope(sd_ctx *c, const char *n) : ctx(c), name(n) {
-        if (ctx->profiling) (void) hipEventRecord(ctx->evStart, ctx->stream);
+        if (ctx->profiling) {
+            a = sdProfEvent(ctx);
+            (void) hipEventRecord(a, ctx->stream);
+        }
     }
     ~ProfScope() {
-        if (ctx->profiling) {
-            (void) hipEventRecord(ctx->evStop, ctx->stream);
-            (void) (ctx->evSync ? sdEventWait(ctx->evStop) : hipEventSynchronize(ctx->evStop));
-            float ms = 0;
-            (void) hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop);
-            sd_profile_entry &e = ctx->profile[name];
-            e.ms += ms;
-            e.launches += 1;
+        if (a) {
+            sd_ctx::ProfPending pp;
+            pp.name = name;
+            pp.a = a;
+            pp.b = sdProfEvent(ctx);
+            (void) hipEventRecord(pp.b, ctx->stream);
+            ctx->profPending.push_back(pp);   // read back by sdProfDrain at the next stream wait: the launching thread does not stall
         }
     }
 };

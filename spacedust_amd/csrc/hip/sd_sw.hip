@@ -1387,6 +1387,11 @@ void sd_ctx_destroy(sd_ctx *ctx) {
     if (ctx->evStart) (void) hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void) hipEventDestroy(ctx->evStop);
     if (ctx->evSync) (void) hipEventDestroy(ctx->evSync);
+    for (auto &pp : ctx->profPending) {
+        (void) hipEventDestroy(pp.a);
+        (void) hipEventDestroy(pp.b);
+    }
+    for (hipEvent_t e : ctx->evPool) (void) hipEventDestroy(e);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     for (auto &kv : ctx->ws) if (kv.second.p) (void) hipFree(kv.second.p);
     for (auto &kv : ctx->pinned) if (kv.second.p) (void) hipHostFree(kv.second.p);
@@ -1421,10 +1426,12 @@ int sd_profile_enable(sd_ctx *ctx, int on) {
     return SD_OK;
 }
 int sd_profile_reset(sd_ctx *ctx) {
+    sdProfDrain(ctx, true);
     ctx->profile.clear();
     return SD_OK;
 }
 int sd_profile_get(sd_ctx *ctx, const char *name, double *totalMs, uint64_t *launches) {
+    sdProfDrain(ctx, true);
     auto it = ctx->profile.find(name);
     if (it == ctx->profile.end()) {
         *totalMs = 0;
@@ -1436,6 +1443,7 @@ int sd_profile_get(sd_ctx *ctx, const char *name, double *totalMs, uint64_t *lau
     return SD_OK;
 }
 int sd_profile_names(sd_ctx *ctx, char *buf, size_t cap) {
+    sdProfDrain(ctx, true);
     std::string s;
     for (auto &kv : ctx->profile) {
         if (!s.empty()) s += ",";

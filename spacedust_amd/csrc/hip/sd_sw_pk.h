@@ -395,5 +395,268 @@ sw_score_pk_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint
     }
 }
 
+// ---- aligned form: the lanes ARE the reference's SIMD segments ---------------------------------------------------------
+// A byte-structure task (segLen = ceil(n / 32), StripedSmithWaterman.cpp:639-915) with n in (32 (RT - 1), 32 RT] has
+// segLen == RT: on a 32-lane group with RT rows per lane the reference's 32 segments are exactly the lanes.  The lazy-F
+// chain of the lane structure, Fl, then restarts at row 0 of every lane in every column: no per-row reset masks, no Fl
+// hand-off, and the first / last row of a lane drop the Fl instructions they do not need.  The class of a task is its RT
+// (5 .. 24: 129 .. 768 rows), so a task pays for at most 31 padding rows and queries beyond 384 rows keep the 32-lane
+// ramp.  Also here, against the per-column overhead of the general kernel (sw_score_pk_kernel):
+//   * the residue stream carries LDS byte offsets of the profile rows (res * row stride, 16 bits per task), so a lane's
+//     profile address is one SDWA add per task;
+//   * the profile words of column k + 1 are requested before the cells of column k are computed (the residue a lane sees
+//     next is the one its upper neighbour holds now), so LDS latency is off the dependency chain and one wavefront per
+//     SIMD suffices where LDS is short;
+//   * best-so-far bookkeeping in five instructions on the row-coded column maximum alone (value << 5 | 31 - row: a
+//     strictly larger VALUE takes over, i.e. code > best | 31), the column as the wave-uniform step counter.
+__device__ __forceinline__ uint32_t pkAshr15(uint32_t a) {
+    uint32_t r;
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t bfiAsm(uint32_t mask, uint32_t a, uint32_t b) {   // (a & mask) | (b & ~mask)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t addWord0(uint32_t base, uint32_t packed) {   // base + (packed & 0xFFFF)
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(base), "v"(packed));
+    return r;
+}
+__device__ __forceinline__ uint32_t addWord1(uint32_t base, uint32_t packed) {   // base + (packed >> 16)
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(base), "v"(packed));
+    return r;
+}
+
+template <int RT, bool SHARED>
+__global__ void __launch_bounds__(64)
+sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
+                           const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
+                           int go, int ge, int32_t *__restrict__ out, const uint32_t *__restrict__ order,
+                           const int8_t *__restrict__ qProf) {
+    constexpr int LW = 32;
+    constexpr int WORDS = (RT + 3) / 4;
+    constexpr int RTP = 4 * WORDS;
+    constexpr int PSTRIDE = LW * WORDS;    // dwords per residue row of a profile
+    constexpr int NT = 4;                  // tasks per wavefront: two 32-lane groups of a task pair each
+    constexpr uint32_t ROWB = PSTRIDE * 4; // bytes per residue row
+    static_assert(22 * ROWB < 65536, "row offsets travel in 16 bits");
+    __shared__ uint32_t prof[SHARED ? 2 : NT][22][PSTRIDE];
+    __shared__ int8_t smat[441];
+    for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const int grp = lane / LW, l = lane % LW;
+    SwTask tk[NT];
+#pragma unroll
+    for (int x = 0; x < NT; x++) {
+        const uint32_t id = blockIdx.x * NT + x;
+        const uint32_t tid = id < nTasks ? (order ? order[id] : id) : 0xFFFFFFFFu;
+        if (tid != 0xFFFFFFFFu) {
+            tk[x] = tasks[tid];
+        } else {
+            tk[x].n = 0; tk[x].tL = 0; tk[x].qOff = 0; tk[x].tOff = 0; tk[x].qStep = 1; tk[x].tStep = 1; tk[x].segLen = 1;
+            tk[x].slot = 0; tk[x].boundOff = 0;
+        }
+    }
+    const SwTask A = grp ? tk[2] : tk[0];
+    SwTask B = grp ? tk[3] : tk[1];
+    const bool haveA = A.n > 0, haveB = B.n > 0;
+    if (SHARED && !haveB) {   // lone task of its query: the second half idles on the same rows
+        B = A;
+        B.tL = 0;
+    }
+    int maxN = 0, maxTL = 0;
+#pragma unroll
+    for (int x = 0; x < NT; x++) {
+        maxN = max(maxN, tk[x].n);
+        maxTL = max(maxTL, tk[x].tL);
+    }
+    const int steps = (maxN > 0 && maxTL > 0) ? maxTL + LW - 1 : 0;
+    const uint32_t goP = (uint32_t) go | ((uint32_t) go << 16), geP = (uint32_t) ge | ((uint32_t) ge << 16);
+    const int q0 = l * RT;
+    // ---- query profiles (SmithWaterman::createQueryProfile, :163-187)
+#pragma unroll
+    for (int x = 0; x < (SHARED ? 1 : 2); x++) {
+        const SwTask &T = x ? B : A;
+        uint32_t *pw = &prof[SHARED ? grp : 2 * grp + x][0][0] + l * WORDS;
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) {
+            int res[4], cb[4];
+            int64_t pidx[4];
+            bool valid[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int qi = q0 + 4 * w + b;
+                valid[b] = (4 * w + b < RT) && qi < T.n;
+                res[b] = 20;
+                cb[b] = 0;
+                pidx[b] = 0;
+                if (valid[b]) {
+                    const int64_t idx = (int64_t) T.qOff + (int64_t) qi * T.qStep;
+                    res[b] = qRes[idx];
+                    cb[b] = qBias[idx];
+                    pidx[b] = idx * 21;
+                }
+            }
+            if (qProf) {   // profile query: the position's own row
+                for (int a = 0; a < 21; a++) {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int v = valid[b] ? (int) qProf[pidx[b] + a] : -64;
+                        word |= (uint32_t) (uint8_t) (int8_t) v << (8 * b);
+                    }
+                    pw[a * PSTRIDE + w] = word;
+                }
+            } else {
+                for (int a = 0; a < 21; a++) {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int v = valid[b] ? (int) smat[a * 21 + res[b]] + cb[b] : -64;
+                        word |= (uint32_t) (uint8_t) (int8_t) v << (8 * b);
+                    }
+                    pw[a * PSTRIDE + w] = word;
+                }
+            }
+            pw[PK_NEUTRAL * PSTRIDE + w] = 0xC0C0C0C0u;
+        }
+    }
+    __syncthreads();
+    // LDS byte addresses of this lane's profile words (row 0); the residue stream adds the row offset
+    const uint32_t baseA = (uint32_t) (uintptr_t) (&prof[SHARED ? grp : 2 * grp][0][0] + l * WORDS);
+    const uint32_t baseB = SHARED ? baseA : (uint32_t) (uintptr_t) (&prof[2 * grp + 1][0][0] + l * WORDS);
+    auto ldsWord = [](uint32_t addr, int w) -> uint32_t {
+        return *(const __attribute__((address_space(3))) uint32_t *) (uintptr_t) (addr + 4u * (uint32_t) w);
+    };
+
+    uint32_t H[RTP], E[RTP];
+#pragma unroll
+    for (int r = 0; r < RTP; r++) {
+        H[r] = 0;
+        E[r] = 0;
+    }
+    uint32_t outG = 0, outFf = 0, prevInG = 0;
+    uint32_t bestcm = 0, bestcol = 0;
+    constexpr uint32_t NEUT = (uint32_t) PK_NEUTRAL * ROWB;
+    auto loadChunk = [&](int c0) -> uint32_t {   // row offsets (bytes) of the residues of column c0 + l, task A | task B << 16
+        const int col = c0 + l;
+        uint32_t a = PK_NEUTRAL, b = PK_NEUTRAL;
+        if (col < A.tL) a = tRes[(int64_t) A.tOff + (int64_t) col * A.tStep];
+        if (col < B.tL) b = tRes[(int64_t) B.tOff + (int64_t) col * B.tStep];
+        return (a * ROWB) | ((b * ROWB) << 16);
+    };
+    uint32_t chunk = loadChunk(0);
+    uint32_t chunkNext = loadChunk(LW);
+    // column 0's residues enter at the first lane of either group; every other lane starts on the neutral row
+    uint32_t T = NEUT | (NEUT << 16);
+    T = writeLane<0>(readLane(chunk, 0), T);
+    T = writeLane<32>(readLane(chunk, 32), T);
+    uint32_t pa[WORDS], pb[WORDS];
+    {
+        const uint32_t aA = addWord0(baseA, T), aB = addWord1(baseB, T);
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) {
+            pa[w] = ldsWord(aA, w);
+            pb[w] = ldsWord(aB, w);
+        }
+    }
+#pragma unroll 1
+    for (int k = 0; k < steps; k++) {
+        // ---- the residues and profile words of column k + 1 (needed one iteration from now)
+        const int i1 = (k + 1) & (LW - 1);
+        if (i1 == 0) {
+            chunk = chunkNext;
+            chunkNext = loadChunk(k + 1 + LW);
+        }
+        uint32_t Tn = dppShr1(T);
+        Tn = writeLane<0>(readLane(chunk, i1), Tn);
+        Tn = writeLane<32>(readLane(chunk, 32 + i1), Tn);
+        uint32_t pan[WORDS], pbn[WORDS];
+        {
+            const uint32_t aA = addWord0(baseA, Tn), aB = addWord1(baseB, Tn);
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) {
+                pan[w] = ldsWord(aA, w);
+                pbn[w] = ldsWord(aB, w);
+            }
+        }
+        // ---- hand-off from lane l - 1 (nothing enters the first lane of a group)
+        uint32_t inG = dppShr1(outG), inFf = dppShr1(outFf);
+        inG = writeLane<32>(0, inG);
+        inFf = writeLane<32>(0, inFf);
+        uint32_t h[RTP];
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) {
+            const uint32_t d0 = (w == 0) ? prevInG : H[4 * w - 1];
+            addProfile4(pa[w], pb[w], d0, H[4 * w], H[4 * w + 1], H[4 * w + 2], h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
+        }
+        prevInG = inG;
+        uint32_t Fl = 0, Ff = inFf, cm = 0;
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            uint32_t hpre = pkMax(h[r], E[r]);
+            if (r > 0) hpre = pkMax(hpre, Fl);   // the lane's segment starts at its row 0
+            const uint32_t g = pkMax(hpre, Ff);
+            const uint32_t open = pkSubSat(hpre, goP);
+            E[r] = pkMax(pkSubSat(E[r], geP), open);
+            if (r == 0) Fl = open;
+            else if (r + 1 < RT) Fl = pkMax(pkSubSat(Fl, geP), open);
+            Ff = pkMax(pkSubSat(Ff, geP), open);
+            H[r] = g;
+            const uint32_t code = pkRowCode(g, 31 - r);
+            cm = r == 0 ? code : pkMax(cm, code);
+        }
+        outG = H[RT - 1];
+        outFf = Ff;
+        // ---- a strictly larger value takes over (first column wins, smallest row inside)
+        {
+            const uint32_t t = bestcm | 0x001F001Fu;
+            const uint32_t m = pkAshr15(pkSub(t, cm));   // all ones where cm > t
+            const uint32_t kk = (uint32_t) k | ((uint32_t) k << 16);
+            bestcm = bfiAsm(m, cm, bestcm);
+            bestcol = bfiAsm(m, kk, bestcol);
+        }
+        T = Tn;
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) {
+            pa[w] = pan[w];
+            pb[w] = pbn[w];
+        }
+    }
+    // ---- candidates of this lane -> reduce over the 32 lanes: max value, then smallest column, then smallest row
+    unsigned long long keyA = 0, keyB = 0;
+    {
+        const uint32_t vA = (bestcm & 0xFFFFu) >> 5, vB = bestcm >> 21;
+        const uint32_t rowA = (uint32_t) (q0 + 31 - (int) (bestcm & 31u)), rowB = (uint32_t) (q0 + 31 - (int) ((bestcm >> 16) & 31u));
+        const uint32_t colA = (bestcol & 0xFFFFu) - (uint32_t) l, colB = (bestcol >> 16) - (uint32_t) l;   // step - lane
+        if (vA > 0) keyA = ((unsigned long long) vA << 40) | ((unsigned long long) (0xFFFFFu - colA) << 20) | (unsigned long long) (0xFFFFFu - rowA);
+        if (vB > 0) keyB = ((unsigned long long) vB << 40) | ((unsigned long long) (0xFFFFFu - colB) << 20) | (unsigned long long) (0xFFFFFu - rowB);
+    }
+#pragma unroll
+    for (int off = LW / 2; off >= 1; off >>= 1) {
+        const unsigned long long oa = __shfl_xor(keyA, off, LW), ob = __shfl_xor(keyB, off, LW);
+        keyA = oa > keyA ? oa : keyA;
+        keyB = ob > keyB ? ob : keyB;
+    }
+    if (l == 0) {
+        if (haveA) {
+            const int v = (int) (keyA >> 40);
+            out[3 * A.slot + 0] = v;
+            out[3 * A.slot + 1] = v == 0 ? -1 : 0xFFFFF - (int) ((keyA >> 20) & 0xFFFFF);
+            out[3 * A.slot + 2] = v == 0 ? A.n - 1 : 0xFFFFF - (int) (keyA & 0xFFFFF);
+        }
+        if (haveB) {
+            const int v = (int) (keyB >> 40);
+            out[3 * B.slot + 0] = v;
+            out[3 * B.slot + 1] = v == 0 ? -1 : 0xFFFFF - (int) ((keyB >> 20) & 0xFFFFF);
+            out[3 * B.slot + 2] = v == 0 ? B.n - 1 : 0xFFFFF - (int) (keyB & 0xFFFFF);
+        }
+    }
+}
+
 }  // namespace sdpk
 #endif

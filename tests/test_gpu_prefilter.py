@@ -370,6 +370,80 @@ def test_prefilter_long_result_lists(gpu, host, oracle):
         assert longest > 2048, (max_hits, longest)
 
 
+def test_prefilter_result_lists_of_any_length(gpu, host, oracle):
+    """the reference caps a result list at min(--max-seqs, dbSize) and nothing else (QueryMatcher.cpp:45-46,386); clustersearch
+    asks for --max-seqs 2N.  Lists beyond 4 095 hits with more candidates at the score cut than the LDS sorter of
+    select_hits holds (8 192) go through select_hits_big_kernel (radix selection + global-scratch sort): one family of 9 600
+    near-identical sequences, cuts inside the saturated tie classes, at the minimum score, and no cut at all"""
+    rng = np.random.default_rng(405)
+    aa = 'ACDEFGHIKLMNPQRSTVWY'
+    base = ''.join(rng.choice(list(aa), 200))
+    seqs = [base]
+    for _ in range(9600):
+        sq = list(base)
+        for p in np.nonzero(rng.random(len(sq)) < rng.uniform(0.02, 0.45))[0]:
+            sq[p] = aa[rng.integers(20)]
+        seqs.append(''.join(sq))
+    seqs += [''.join(rng.choice(list(aa), int(rng.integers(100, 300)))) for _ in range(400)]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    res, off = host.map_sequences(seqs)
+    sw_b, dg_b, km_b = host.comp_bias(res, off)
+    idx = host.build_index(res, off)
+    tgt = api.Target(gpu, host, idx)
+    ot = oracle.target(res, off)
+    queries = [int(np.nonzero(order == 0)[0][0]), 5, 17]
+    qoff = np.zeros(len(queries) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(seqs[q]) for q in queries])
+    qres = np.concatenate([res[int(off[q]):int(off[q + 1])] for q in queries])
+    qkm = np.concatenate([km_b[int(off[q]):int(off[q + 1])] for q in queries])
+    qdg = np.concatenate([dg_b[int(off[q]):int(off[q + 1])] for q in queries])
+    for max_hits, min_diag, bin_size in ((6000, 15, 4), (9000, 1, 8), (4500, 40, 2), (20000, 15, 4)):
+        par = api.prefilter_params(host, idx.n, max_hits=max_hits, min_diag=min_diag, cov_thr=0.0, bin_size=bin_size)
+        for ident in (np.array(queries, np.uint32), np.full(len(queries), 0xFFFFFFFF, np.uint32)):
+            hits, cnt, _ = api.prefilter(gpu, tgt, par, qres, qoff, qkm, qdg, ident)
+            longest = 0
+            for x, q in enumerate(queries):
+                ids, sc, dg, _ = ot.prefilter(res[int(off[q]):int(off[q + 1])], identity_id=int(ident[x]), max_hits=max_hits,
+                                              min_diag=min_diag, bin_size=bin_size)
+                n = int(cnt[x])
+                longest = max(longest, n)
+                assert n == len(ids), (max_hits, q, n, len(ids))
+                assert (hits[x, :n]['seqId'] == ids).all() and (hits[x, :n]['score'] == sc).all() and (hits[x, :n]['diagonal'] == dg).all(), (max_hits, q)
+            assert longest >= min(max_hits, 9000) - 1 or max_hits == 20000 and longest > 9000, (max_hits, longest)
+
+
+def test_prefilter_hot_filter_equals_unfiltered(gpu, host, monkeypatch):
+    """hot_filter_kernel drops, in front of the bucket machinery, the hits of targets that cannot emit a candidate (no two hits
+    with the same diagonal byte, no hit with diagonal byte 0): rows and statistics equal the unfiltered run -- on the join path,
+    the lookup path, with the coarse split, and with every segment length filtered (SD_PF_FILTER_MIN=0)"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=12, genes_per_proteome=900, n_families=1400, seed=92)
+    ident = np.arange(ps.n, dtype=np.uint32)
+    sw_b, dg_b, km_b = host.comp_bias(ps.residues, ps.offsets)
+    idx = host.build_index(ps.residues, ps.offsets)
+    tgt = api.Target(gpu, host, idx)
+    nq = 4000
+    res = ps.residues[:int(ps.offsets[nq])]
+    off = ps.offsets[:nq + 1]
+    par = api.prefilter_params(host, idx.n, max_hits=300, cov_thr=0.8, bin_size=None)
+    monkeypatch.setenv('SD_PF_FILTER', '0')
+    a = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)
+    assert int(a[1].sum()) > 30000
+    monkeypatch.setenv('SD_PF_FILTER', '1')
+    for env in ({}, {'SD_PF_FILTER_MIN': '0'}, {'SD_PF_JOIN': '0'}, {'SD_PF_JOIN': '0', 'SD_PF_FILTER_MIN': '0', 'SD_PF_COARSE': '3000'},
+                {'SD_PF_COARSE': '2000', 'SD_PF_FILTER_MIN': '0'}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        b = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), env
+        for q in range(nq):
+            n = int(a[1][q])
+            assert np.array_equal(a[0][q, :n], b[0][q, :n]), (env, q)
+
+
 def test_prefilter_join_path_equals_lookup_path(gpu, host, monkeypatch):
     """the k-mer-major join (default for k = 6) and the per-k-mer lookup path (SD_PF_JOIN=0) give identical hit tables
     and statistics -- plain, with the coarse split forced, and with the reference's hit-buffer overflow forced into
