@@ -640,6 +640,17 @@ void launchScorePk(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, ui
                        t->dRes, dMat, go, ge, dOut, dBound, dOrder, (const int8_t *) q->dProf);
 }
 
+template <int RT, int LW, bool SHARED>
+void launchScorePkAligned(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, uint32_t n, const sd_seqset *q, const sd_seqset *t,
+                          const int8_t *dMat, int go, int ge, int32_t *dOut) {
+    if (n == 0) return;
+    constexpr uint32_t perWave = 2 * (64 / LW);
+    dim3 grid((n + perWave - 1) / perWave), block(64);
+    static const unsigned ldsPad = getenv("SD_SW_LDS_PAD") ? (unsigned) atoi(getenv("SD_SW_LDS_PAD")) : 0u;
+    hipLaunchKernelGGL((sdpk::sw_score_pk_aligned_kernel<RT, LW, SHARED>), grid, block, ldsPad, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes,
+                       dMat, go, ge, dOut, dOrder, (const int8_t *) q->dProf);
+}
+
 int rtClass(int n) {
     if (n <= 128) return 4;
     if (n <= 256) return 8;
@@ -767,17 +778,27 @@ int runScoreTasks(sd_ctx *ctx, std::vector<SwTask> &tasks, const sd_seqset *q, c
 // the ordering of tasks all happen on the GPU; the host only launches, reads six class boundaries per pass
 // and receives the finished result records + a dense backtrace pool.
 // ---------------------------------------------------------------------------------------------
-// score-pass task classes: 0-13 packed-int16 kernel with the five-bit row code, 14-27 the same with the wide row
-// code (rows: <=128, <=192, <=224, <=256, <=288, <=320, <=352, <=384, <=512, <=640, <=768, then 2 / 3 / more strips of 512
-// rows -- steps of 32 rows where most proteins are: a task pays for the rows of its class, not for its own), 28-31 int32
-// kernel (rows: <=128, <=256, <=512, more).  32 classes: the pair sort carries the class in six bits.
-constexpr uint32_t N_PK_CLASSES = 14;
-constexpr uint32_t FIRST_MULTI_PK = 11;   // classes of more than one strip
-constexpr uint32_t N_SCORE_CLASSES = 2 * N_PK_CLASSES + 4;
-constexpr uint32_t FIRST_WIDE_CLASS = N_PK_CLASSES;
-constexpr uint32_t FIRST_INT32_CLASS = 2 * N_PK_CLASSES;
+// score-pass task classes (the pair sort carries the class in six bits: fewer than 64)
+//   0          packed-int16 kernel, <= 128 rows (general form: per-row segment masks)
+//   1 .. 20    aligned packed kernel (sw_score_pk_aligned_kernel): RT = ceil(n / 32) = 5 .. 24, i.e. 129 .. 768 rows in steps
+//              of 32 -- a task pays for the rows of its class, and the reference's 32 SIMD segments are the 32 lanes
+//   21 .. 23   2 / 3 / more strips of 512 rows (general form)
+//   24 .. 37   the general packed kernel with the wide row code (word-kernel reruns; rows: <=128, <=192, <=224, <=256,
+//              <=288, <=320, <=352, <=384, <=512, <=640, <=768, then 2 / 3 / more strips)
+//   38 .. 41   int32 kernel (rows: <=128, <=256, <=512, more)
+constexpr uint32_t N_NARROW_CLASSES = 24;
+constexpr uint32_t FIRST_NARROW_MULTI = 21;
+constexpr uint32_t N_PK_CLASSES = 14;     // classes of the wide form
+constexpr uint32_t FIRST_MULTI_PK = 11;   // (wide form) classes of more than one strip
+constexpr uint32_t FIRST_WIDE_CLASS = N_NARROW_CLASSES;
+constexpr uint32_t FIRST_INT32_CLASS = FIRST_WIDE_CLASS + N_PK_CLASSES;
+constexpr uint32_t N_SCORE_CLASSES = FIRST_INT32_CLASS + 4;
+static_assert(N_SCORE_CLASSES < 63, "class boundaries are found by one 64-lane wavefront; six class bits in the pair key");
 enum ScoreKernel { SCORE_PK = 0, SCORE_PK_WIDE = 1, SCORE_INT32 = 2 };
 constexpr uint32_t KEY_INVALID = N_SCORE_CLASSES * 1024u;   // sorts after every class
+__host__ __device__ __forceinline__ bool scoreClassIsMulti(uint32_t ci) {   // packed classes of more than one strip
+    return (ci >= FIRST_NARROW_MULTI && ci < FIRST_WIDE_CLASS) || (ci >= FIRST_WIDE_CLASS + FIRST_MULTI_PK && ci < FIRST_INT32_CLASS);
+}
 // wideRowLimit: int16 cells hold a score for certain while min(n, tL) * (largest entry of this call's query profiles) <= 32 767
 // (no saturation of the reference's word kernel to reproduce, no wrap); longer pairs take the int32 kernel
 __device__ __forceinline__ uint32_t scoreKey(int n, int tL, int kernel, int wideRowLimit = 800) {
@@ -785,12 +806,16 @@ __device__ __forceinline__ uint32_t scoreKey(int n, int tL, int kernel, int wide
     if (kernel == SCORE_PK_WIDE && min(n, tL) > wideRowLimit) kernel = SCORE_INT32;
     if (kernel == SCORE_INT32 || tL > 65535) {
         ci = FIRST_INT32_CLASS + (n <= 128 ? 0 : (n <= 256 ? 1 : (n <= 512 ? 2 : 3)));
-    } else {
+    } else if (kernel == SCORE_PK_WIDE) {
         if (n <= 192) ci = n <= 128 ? 0 : 1;
         else if (n <= 384) ci = 2 + (n - 193) / 32;                      // 224, 256, 288, 320, 352, 384 rows -> 2..7
         else if (n <= 768) ci = n <= 512 ? 8 : (n <= 640 ? 9 : 10);
         else ci = min((int) FIRST_MULTI_PK + (n + 511) / 512 - 2, 13);   // 2 strips -> 11, 3 strips -> 12, more -> 13
-        if (kernel == SCORE_PK_WIDE) ci += FIRST_WIDE_CLASS;
+        ci += FIRST_WIDE_CLASS;
+    } else {
+        if (n <= 128) ci = 0;
+        else if (n <= 768) ci = (n + 31) / 32 - 4;                       // RT = 5 .. 24 -> 1 .. 20
+        else ci = min((int) FIRST_NARROW_MULTI + (n + 511) / 512 - 2, (int) FIRST_WIDE_CLASS - 1);
     }
     return (uint32_t) ci * 1024u + (uint32_t) (1023 - min(tL >> 4, 1023));
 }
@@ -1132,7 +1157,7 @@ k_bound_need(uint32_t nPairs, const SwTask *__restrict__ tasks, const uint32_t *
     uint64_t v = 0;
     if (keys[i] != KEY_INVALID) {
         const uint32_t ci = keys[i] >> 10;
-        if (ci < FIRST_INT32_CLASS && (ci % N_PK_CLASSES) >= FIRST_MULTI_PK) v = 2ull * (uint64_t) tasks[i].tL;
+        if (scoreClassIsMulti(ci)) v = 2ull * (uint64_t) tasks[i].tL;
         else if (ci == N_SCORE_CLASSES - 1 && tasks[i].n > 1024) v = (uint64_t) tasks[i].tL;
     }
     need[i] = v;
@@ -1271,12 +1296,24 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
         static const char *const pkNames[N_PK_CLASSES] = {"rt4x32", "rt6x32", "rt7x32", "rt8x32", "rt9x32", "rt10x32", "rt11x32", "rt12x32",
                                                           "rt8x64", "rt10x64", "rt12x64", "rt8x64s2", "rt8x64s3", "rt8x64sN"};
         static const char *const i32Names[4] = {"sw_score.rt4", "sw_score.rt8", "sw_score.rt16", "sw_score.rt32"};
+        // SD_SW_LONG32=0: queries of 385 .. 768 rows keep the 64-lane general kernels (half the LDS per wavefront, twice the ramp)
+        static const bool long32 = !(getenv("SD_SW_LONG32") && atoi(getenv("SD_SW_LONG32")) == 0);
+        static const bool useAligned = !(getenv("SD_SW_ALIGNED") && atoi(getenv("SD_SW_ALIGNED")) == 0);
+        const bool shared = dPairQ != nullptr && ci < FIRST_INT32_CLASS;
+        const int alignedRT = (ci >= 1 && ci < FIRST_NARROW_MULTI) ? (int) ci + 4 : 0;
+        // start-position tasks (two profiles per pair in LDS) beyond 384 rows and the A/B switches use the general kernels
+        const bool aligned = alignedRT > 0 && useAligned && (alignedRT <= 12 || (shared && long32));
+        // the general kernel by rows: class 0, the multi-strip classes, and the aligned classes when they are not taken
+        int generalIdx = 0;
+        if (ci >= FIRST_NARROW_MULTI && ci < FIRST_WIDE_CLASS) generalIdx = (int) FIRST_MULTI_PK + (int) (ci - FIRST_NARROW_MULTI);
+        else if (alignedRT) generalIdx = alignedRT <= 6 ? 1 : (alignedRT <= 12 ? alignedRT - 5 : (alignedRT <= 16 ? 8 : (alignedRT <= 20 ? 9 : 10)));
         char name[48];
-        if (ci < FIRST_INT32_CLASS) snprintf(name, sizeof(name), "sw_score_pk.%s%s", ci >= FIRST_WIDE_CLASS ? "w_" : "", pkNames[ci % N_PK_CLASSES]);
+        if (aligned) snprintf(name, sizeof(name), "sw_score_pk.a_seg%d", alignedRT);
+        else if (ci < FIRST_WIDE_CLASS) snprintf(name, sizeof(name), "sw_score_pk.%s", pkNames[generalIdx]);
+        else if (ci < FIRST_INT32_CLASS) snprintf(name, sizeof(name), "sw_score_pk.w_%s", pkNames[ci - FIRST_WIDE_CLASS]);
         else snprintf(name, sizeof(name), "%s", i32Names[ci - FIRST_INT32_CLASS]);
         ProfScope ps(ctx, name);
         const uint32_t *ord = dOrder + begin;
-        const bool shared = dPairQ != nullptr && ci < FIRST_INT32_CLASS;
         uint32_t nOrd = cnt;
         if (shared) {   // explicit pairs: two entries per pair of the class
             ord = dOrder2 + 2 * (size_t) hpb[ci];
@@ -1287,8 +1324,15 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
         if (shared) launchScorePk<RT, LW, MULTI, WIDE, true>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut, dBound);     \
         else launchScorePk<RT, LW, MULTI, WIDE, false>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut, dBound);           \
     } while (0)
-#define SD_PK_CLASS(WIDE)                                                     \
-        switch (ci % N_PK_CLASSES) {                                          \
+#define SD_PKA(RT)                                                                                               \
+    case RT:                                                                                                     \
+        if (shared) launchScorePkAligned<RT, 32, true>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);        \
+        else launchScorePkAligned<RT, 32, false>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);              \
+        break;
+#define SD_PKA16(SEG)                                                                                            \
+    case SEG: launchScorePkAligned<2 * SEG, 16, true>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut); break;
+#define SD_PK_CLASS(WIDE, IDX)                                                \
+        switch (IDX) {                                                        \
             case 0: SD_PK(4, 32, false, WIDE); break;                         \
             case 1: SD_PK(6, 32, false, WIDE); break;                         \
             case 2: SD_PK(7, 32, false, WIDE); break;                         \
@@ -1302,10 +1346,23 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
             case 10: SD_PK(12, 64, false, WIDE); break;                       \
             default: SD_PK(8, 64, true, WIDE); break;                         \
         }
-        if (ci < FIRST_WIDE_CLASS) {
-            SD_PK_CLASS(false)
+        // SD_SW_LW16: shared-profile tasks of up to this many rows per segment run on 16-lane groups (two segments per lane)
+        static const int lw16Max = getenv("SD_SW_LW16") ? atoi(getenv("SD_SW_LW16")) : 8;   // measured: beyond 8 rows per segment the LDS footprint (two segments per lane, eight tasks per wavefront) costs more occupancy than the shorter ramp returns
+        if (aligned && shared && alignedRT <= lw16Max) {
+            switch (alignedRT) {
+                SD_PKA16(5) SD_PKA16(6) SD_PKA16(7) SD_PKA16(8) SD_PKA16(9) SD_PKA16(10) SD_PKA16(11) SD_PKA16(12)
+                default: break;
+            }
+        } else if (aligned) {
+            switch (alignedRT) {
+                SD_PKA(5) SD_PKA(6) SD_PKA(7) SD_PKA(8) SD_PKA(9) SD_PKA(10) SD_PKA(11) SD_PKA(12) SD_PKA(13) SD_PKA(14)
+                SD_PKA(15) SD_PKA(16) SD_PKA(17) SD_PKA(18) SD_PKA(19) SD_PKA(20) SD_PKA(21) SD_PKA(22) SD_PKA(23) SD_PKA(24)
+                default: break;
+            }
+        } else if (ci < FIRST_WIDE_CLASS) {
+            SD_PK_CLASS(false, generalIdx)
         } else if (ci < FIRST_INT32_CLASS) {
-            SD_PK_CLASS(true)
+            SD_PK_CLASS(true, (int) (ci - FIRST_WIDE_CLASS))
         } else {
             switch (ci - FIRST_INT32_CLASS) {
                 case 0: launchScoreIdx<4>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
@@ -1314,6 +1371,8 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
                 default: launchScoreIdx<32>(ctx, dTasks, ord, cnt, q, t, dMat, go, ge, dOut, dBound); break;
             }
         }
+#undef SD_PKA
+#undef SD_PKA16
 #undef SD_PK_CLASS
 #undef SD_PK
     }

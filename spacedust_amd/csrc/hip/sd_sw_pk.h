@@ -430,20 +430,32 @@ __device__ __forceinline__ uint32_t addWord1(uint32_t base, uint32_t packed) {  
     return r;
 }
 
-template <int RT, bool SHARED>
+// LW = 32: a lane is one segment (RT = segLen).  LW = 16: four 16-lane groups of a task pair each, a lane holds TWO segments
+// (RT = 2 segLen, Fl restarts at rows 0 and RT / 2): half the systolic ramp (15 idle steps per task instead of 31), the
+// per-column overhead spread over twice the rows, and the group boundaries are DPP row boundaries -- row_shr:1 hands G / Ff
+// down with a zero entering every group's first lane, and the residues enter there from a register that row_ror:1 rotates
+// once per column (no v_readlane / v_writelane at all).
+template <int CTRL, bool ZERO_FILL>
+__device__ __forceinline__ uint32_t dppMove(uint32_t old, uint32_t v) {
+    return (uint32_t) __builtin_amdgcn_update_dpp((int) old, (int) v, CTRL, 0xf, 0xf, ZERO_FILL);
+}
+
+template <int RT, int LW, bool SHARED>
 __global__ void __launch_bounds__(64)
 sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                            const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
                            int go, int ge, int32_t *__restrict__ out, const uint32_t *__restrict__ order,
                            const int8_t *__restrict__ qProf) {
-    constexpr int LW = 32;
+    static_assert(LW == 32 || (LW == 16 && RT % 2 == 0), "32 lanes of one segment or 16 lanes of two");
+    constexpr int SEG = RT * LW / 32;      // rows of a reference segment
     constexpr int WORDS = (RT + 3) / 4;
     constexpr int RTP = 4 * WORDS;
     constexpr int PSTRIDE = LW * WORDS;    // dwords per residue row of a profile
-    constexpr int NT = 4;                  // tasks per wavefront: two 32-lane groups of a task pair each
+    constexpr int NGRP = 64 / LW;
+    constexpr int NT = 2 * NGRP;           // tasks per wavefront: a task pair per group of LW lanes
     constexpr uint32_t ROWB = PSTRIDE * 4; // bytes per residue row
     static_assert(22 * ROWB < 65536, "row offsets travel in 16 bits");
-    __shared__ uint32_t prof[SHARED ? 2 : NT][22][PSTRIDE];
+    __shared__ uint32_t prof[SHARED ? NGRP : NT][22][PSTRIDE];
     __shared__ int8_t smat[441];
     for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
     __syncthreads();
@@ -461,8 +473,13 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
             tk[x].slot = 0; tk[x].boundOff = 0;
         }
     }
-    const SwTask A = grp ? tk[2] : tk[0];
-    SwTask B = grp ? tk[3] : tk[1];
+    SwTask A = tk[0], B = tk[1];
+#pragma unroll
+    for (int g = 1; g < NGRP; g++)
+        if (grp == g) {
+            A = tk[2 * g];
+            B = tk[2 * g + 1];
+        }
     const bool haveA = A.n > 0, haveB = B.n > 0;
     if (SHARED && !haveB) {   // lone task of its query: the second half idles on the same rows
         B = A;
@@ -527,11 +544,10 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
     }
     __syncthreads();
     // LDS byte addresses of this lane's profile words (row 0); the residue stream adds the row offset
-    const uint32_t baseA = (uint32_t) (uintptr_t) (&prof[SHARED ? grp : 2 * grp][0][0] + l * WORDS);
-    const uint32_t baseB = SHARED ? baseA : (uint32_t) (uintptr_t) (&prof[2 * grp + 1][0][0] + l * WORDS);
-    auto ldsWord = [](uint32_t addr, int w) -> uint32_t {
-        return *(const __attribute__((address_space(3))) uint32_t *) (uintptr_t) (addr + 4u * (uint32_t) w);
-    };
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t baseA = (uint32_t) (size_t) (lds_u32 *) (&prof[SHARED ? grp : 2 * grp][0][0] + l * WORDS);
+    const uint32_t baseB = SHARED ? baseA : (uint32_t) (size_t) (lds_u32 *) (&prof[2 * grp + 1][0][0] + l * WORDS);
+    auto ldsWord = [](uint32_t addr, int w) -> uint32_t { return *((const lds_u32 *) (size_t) addr + w); };
 
     uint32_t H[RTP], E[RTP];
 #pragma unroll
@@ -542,8 +558,10 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
     uint32_t outG = 0, outFf = 0, prevInG = 0;
     uint32_t bestcm = 0, bestcol = 0;
     constexpr uint32_t NEUT = (uint32_t) PK_NEUTRAL * ROWB;
-    auto loadChunk = [&](int c0) -> uint32_t {   // row offsets (bytes) of the residues of column c0 + l, task A | task B << 16
-        const int col = c0 + l;
+    auto loadChunk = [&](int c0) -> uint32_t {   // row offsets (bytes) of the residues of one column per lane, task A | task B << 16
+        // LW = 32: lane l holds column c0 + l.  LW = 16: lane 0 holds c0, lane 15 c0 + 1, ... lane 1 c0 + 15 -- the order in which
+        // row_ror:1 brings them to lane 0
+        const int col = c0 + (LW == 16 ? (16 - l) & 15 : l);
         uint32_t a = PK_NEUTRAL, b = PK_NEUTRAL;
         if (col < A.tL) a = tRes[(int64_t) A.tOff + (int64_t) col * A.tStep];
         if (col < B.tL) b = tRes[(int64_t) B.tOff + (int64_t) col * B.tStep];
@@ -553,8 +571,12 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
     uint32_t chunkNext = loadChunk(LW);
     // column 0's residues enter at the first lane of either group; every other lane starts on the neutral row
     uint32_t T = NEUT | (NEUT << 16);
-    T = writeLane<0>(readLane(chunk, 0), T);
-    T = writeLane<32>(readLane(chunk, 32), T);
+    if (LW == 16) {
+        T = l == 0 ? chunk : T;
+    } else {
+        T = writeLane<0>(readLane(chunk, 0), T);
+        T = writeLane<32>(readLane(chunk, 32), T);
+    }
     uint32_t pa[WORDS], pb[WORDS];
     {
         const uint32_t aA = addWord0(baseA, T), aB = addWord1(baseB, T);
@@ -564,18 +586,30 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
             pb[w] = ldsWord(aB, w);
         }
     }
-#pragma unroll 1
-    for (int k = 0; k < steps; k++) {
-        // ---- the residues and profile words of column k + 1 (needed one iteration from now)
+    // one column step: consumes (T, pa, pb), produces the next column's (Tn, pan, pbn); two steps per loop iteration with the
+    // roles of the two register sets swapped, so nothing is copied (an odd step count is rounded up: a step past the last
+    // column runs on the neutral row and cannot raise a maximum)
+    auto columnStep = [&](const int k, const uint32_t &Tc, const uint32_t (&pac)[WORDS], const uint32_t (&pbc)[WORDS], uint32_t &Tn,
+                          uint32_t (&pan)[WORDS], uint32_t (&pbn)[WORDS]) {
+        // ---- the residues and profile words of column k + 1 (needed one step from now)
         const int i1 = (k + 1) & (LW - 1);
-        if (i1 == 0) {
-            chunk = chunkNext;
-            chunkNext = loadChunk(k + 1 + LW);
+        if (LW == 16) {
+            if (i1 == 0) {
+                chunk = chunkNext;
+                chunkNext = loadChunk(k + 1 + LW);
+            } else {
+                chunk = dppMove<0x121 /* row_ror:1 */, false>(chunk, chunk);   // the next column's residues into lane 0 of every group
+            }
+            Tn = dppMove<0x111 /* row_shr:1 */, false>(chunk, Tc);   // lane 0 of a group keeps `old` = the fresh residues
+        } else {
+            if (i1 == 0) {
+                chunk = chunkNext;
+                chunkNext = loadChunk(k + 1 + LW);
+            }
+            Tn = dppShr1(Tc);
+            Tn = writeLane<0>(readLane(chunk, i1), Tn);
+            Tn = writeLane<32>(readLane(chunk, 32 + i1), Tn);
         }
-        uint32_t Tn = dppShr1(T);
-        Tn = writeLane<0>(readLane(chunk, i1), Tn);
-        Tn = writeLane<32>(readLane(chunk, 32 + i1), Tn);
-        uint32_t pan[WORDS], pbn[WORDS];
         {
             const uint32_t aA = addWord0(baseA, Tn), aB = addWord1(baseB, Tn);
 #pragma unroll
@@ -585,26 +619,33 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
             }
         }
         // ---- hand-off from lane l - 1 (nothing enters the first lane of a group)
-        uint32_t inG = dppShr1(outG), inFf = dppShr1(outFf);
-        inG = writeLane<32>(0, inG);
-        inFf = writeLane<32>(0, inFf);
+        uint32_t inG, inFf;
+        if (LW == 16) {
+            inG = dppMove<0x111, true>(0, outG);
+            inFf = dppMove<0x111, true>(0, outFf);
+        } else {
+            inG = dppShr1(outG);
+            inFf = dppShr1(outFf);
+            inG = writeLane<32>(0, inG);
+            inFf = writeLane<32>(0, inFf);
+        }
         uint32_t h[RTP];
 #pragma unroll
         for (int w = 0; w < WORDS; w++) {
             const uint32_t d0 = (w == 0) ? prevInG : H[4 * w - 1];
-            addProfile4(pa[w], pb[w], d0, H[4 * w], H[4 * w + 1], H[4 * w + 2], h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
+            addProfile4(pac[w], pbc[w], d0, H[4 * w], H[4 * w + 1], H[4 * w + 2], h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
         }
         prevInG = inG;
         uint32_t Fl = 0, Ff = inFf, cm = 0;
 #pragma unroll
         for (int r = 0; r < RT; r++) {
             uint32_t hpre = pkMax(h[r], E[r]);
-            if (r > 0) hpre = pkMax(hpre, Fl);   // the lane's segment starts at its row 0
+            if (r % SEG != 0) hpre = pkMax(hpre, Fl);   // a segment starts here: no vertical gap of the lane structure enters
             const uint32_t g = pkMax(hpre, Ff);
             const uint32_t open = pkSubSat(hpre, goP);
             E[r] = pkMax(pkSubSat(E[r], geP), open);
-            if (r == 0) Fl = open;
-            else if (r + 1 < RT) Fl = pkMax(pkSubSat(Fl, geP), open);
+            if (r % SEG == 0) Fl = open;
+            else if ((r + 1) % SEG != 0) Fl = pkMax(pkSubSat(Fl, geP), open);
             Ff = pkMax(pkSubSat(Ff, geP), open);
             H[r] = g;
             const uint32_t code = pkRowCode(g, 31 - r);
@@ -613,19 +654,17 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
         outG = H[RT - 1];
         outFf = Ff;
         // ---- a strictly larger value takes over (first column wins, smallest row inside)
-        {
-            const uint32_t t = bestcm | 0x001F001Fu;
-            const uint32_t m = pkAshr15(pkSub(t, cm));   // all ones where cm > t
-            const uint32_t kk = (uint32_t) k | ((uint32_t) k << 16);
-            bestcm = bfiAsm(m, cm, bestcm);
-            bestcol = bfiAsm(m, kk, bestcol);
-        }
-        T = Tn;
-#pragma unroll
-        for (int w = 0; w < WORDS; w++) {
-            pa[w] = pan[w];
-            pb[w] = pbn[w];
-        }
+        const uint32_t t = bestcm | 0x001F001Fu;
+        const uint32_t m = pkAshr15(pkSub(t, cm));   // all ones where cm > t
+        const uint32_t kk = (uint32_t) k | ((uint32_t) k << 16);
+        bestcm = bfiAsm(m, cm, bestcm);
+        bestcol = bfiAsm(m, kk, bestcol);
+    };
+    uint32_t T2, pa2[WORDS], pb2[WORDS];
+#pragma unroll 1
+    for (int k = 0; k < steps; k += 2) {
+        columnStep(k, T, pa, pb, T2, pa2, pb2);
+        columnStep(k + 1, T2, pa2, pb2, T, pa, pb);
     }
     // ---- candidates of this lane -> reduce over the 32 lanes: max value, then smallest column, then smallest row
     unsigned long long keyA = 0, keyB = 0;
