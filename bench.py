@@ -59,7 +59,8 @@ def parse():
     ap.add_argument('--p1000-steps', type=int, default=5)
     ap.add_argument('--no-p10000', action='store_true', help='skip the 10 000-proteome record')
     ap.add_argument('--p10000-steps', type=int, default=1)
-    ap.add_argument('--p10000-batch', type=int, default=2, help='query proteomes per step of the 10 000-proteome record')
+    ap.add_argument('--p10000-batch', type=int, default=1, help='query proteomes per step of the 10 000-proteome record')
+    ap.add_argument('--p10000-chunk', type=int, default=1000, help='queries per device chunk of the 10 000-proteome record (lists of up to 20 000 hits per query)')
     ap.add_argument('--leg-budget', type=float, default=300.0, help='a child record (p1000, p10000, iter3) is started only while the run is '
                                                                      'younger than this many seconds; later ones are reported as skipped')
     ap.add_argument('--no-iter3', action='store_true', help='skip the --num-iterations 3 record (BASELINE configs[3] at 1 000 target proteomes)')
@@ -314,7 +315,7 @@ def measure(args, rank, local_rank, world, dist, torch):
     n_queries = int(sum(b - a for x in range(args.steps) for a, b in my_ranges(args.warmup + x)[0]))
     q_len_sum = int(ps.lengths().mean() * n_queries)
     b_pref = algorithmic_bytes(st, q_len_sum)
-    pf_ms = sum(v['ms'] for k_, v in kernels.items() if k_.startswith('prefilter_'))
+    pf_ms = sum(v['ms'] for k_, v in kernels.items() if k_.startswith('prefilter_'))   # ('stat.*' entries are counters, not times)
     sw_ms = sum(v['ms'] for k_, v in grouped.items() if k_.startswith('sw_score'))
     cells_sw = st['cells_fwd'] + st['cells_rev']
     b_sw = st['pairs'] * (int(ps.lengths().mean()) * 23 + 24)
@@ -328,22 +329,25 @@ def measure(args, rank, local_rank, world, dist, torch):
     tab = 4 * ((20 ** k) + 1)
     ent = 8 * cs.index_entries
     join = 'prefilter_join_scatter' in kernels
+    HL = int(kernels.get('stat.prefilter_hits_left', dict(ms=H))['ms'])   # hits behind the hot-target filter (H without it)
     alg_of = {'prefilter_count_kmers': 21 * q_len_sum,
               'prefilter_emit_kmers': 8 * K if join else 16 * K + 0,
               'prefilter_kmer_partition': 24 * K,
               'prefilter_join_count': 8 * K + n_sub * tab,
               'prefilter_join_scatter': 8 * K + n_sub * (tab + ent) + 8 * H,
               'prefilter_gather_hits': 12 * K + 6 * H + 10 * H,
-              'prefilter_partition_hits': 24 * H,
+              'prefilter_hot_filter': 8 * H + 8 * HL,          # every hit looked at once, the survivors rewritten
+              'prefilter_segment_match': 8 * HL + 8 * Cn,
+              'prefilter_partition_hits': 24 * HL,
               'prefilter_coarse_split': 24 * H,
-              'prefilter_bucket_match': 8 * H + 8 * Cn,
+              'prefilter_bucket_match': 8 * HL + 8 * Cn,
               'prefilter_bucket_match_big': 0,
               'prefilter_score_diag': 15 * Cn + st['diag_len'],
               'prefilter_keep_max': 8 * Cn,
               'prefilter_select_hits': 12 * Cn + 10 * st['prefilter_hits']}
     pmc = {}
     pmc_src = None
-    for fn in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for fn in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
             pmc_src = 'profiles/' + fn
@@ -379,10 +383,10 @@ def measure(args, rank, local_rank, world, dist, torch):
     valu = dict(instr_per_cell=11.1, peak_lane_instr_per_s=256 * 64 * 2.4e9,
                 source='ISA count of sw_score_pk RT=8 (178 per 16 cells); 256 CU x 64 lanes x 2.4 GHz')
     try:
-        fn = 'r03_valu_calibration.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_valu_calibration.json')) else 'r02_valu_calibration.json'
+        fn = next(f for f in ('r04_valu_calibration.json', 'r03_valu_calibration.json', 'r02_valu_calibration.json') if os.path.exists(os.path.join(ROOT, 'profiles', f)))
         v = json.load(open(os.path.join(ROOT, 'profiles', fn)))
         valu = dict(instr_per_cell=v['instr_per_cell'], peak_lane_instr_per_s=v['peak_lane_instr_per_s'], source='profiles/' + fn)
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, StopIteration):
         pass
     sw_valu = dict(cells_per_s=cells_sw / (sw_ms * 1e-3) if sw_ms > 0 else 0.0, **valu)
     sw_valu['frac'] = sw_valu['cells_per_s'] * sw_valu['instr_per_cell'] / sw_valu['peak_lane_instr_per_s']
@@ -392,8 +396,12 @@ def measure(args, rank, local_rank, world, dist, torch):
                        note='integer DP in VGPR/LDS: priced against the measured VALU issue peak (tools/valu_peak.py), not HBM')
     not_computed = int(cs._raw_stats()[0][14])   # per-query error slots of the prefilter (sd_search: counted, never silent)
     if not_computed:
-        raise RuntimeError('%d queries were not computed by the prefilter (e.g. --max-seqs beyond 4 095): this is not a valid record' % not_computed)
+        raise RuntimeError('%d queries were not computed by the prefilter: this is not a valid record' % not_computed)
     mem = gpu.device_memory()   # target index + sequences + the pipeline's workspaces, after the timed steps
+    ws_rep = []   # high-water marks of the persistent workspaces, per pipeline context (the largest keys named)
+    for c_ in cs.contexts:
+        d_, p_, top_ = c_.workspace_report(4)
+        ws_rep.append(dict(device_GB=round(d_ / 1e9, 2), pinned_GB=round(p_ / 1e9, 2), largest={k_: round(v_ / 1e9, 2) for k_, v_ in top_}))
     res = {
         'metric': 'clustersearch throughput (genome-pairs/s; SW GCUPS alongside)',
         'value': pairs_total / dt_max,
@@ -408,7 +416,9 @@ def measure(args, rank, local_rank, world, dist, torch):
         'dtype': 'int16',
         'data': 'synthetic',
         'config': {'workload': '%d synthetic proteomes x %d proteins (len~300) all-vs-all, clustersearch --search-mode 0 '
-                               '--filter-self-match --max-seqs %d; step = %d query proteomes %s vs all %d targets'
+                               '--filter-self-match --max-seqs %d; step = %d query proteomes %s vs all %d targets; timed: search + aggregation + '
+                               'clusterhits (+ the result gather for N > 1), the TSV is written after the timed region, the CPU leg likewise '
+                               'stops at the cluster records'
                                % (P, args.genes, max_seqs, B, 'in total (strong scaling)' if args.strong else 'per rank', P),
                    'parallelism': 'whole query sets dealt to %d rank(s) by sd_shard_query_sets, target index replicated (%s), '
                                   'final result gather: %s' % (world, index_how, gather_how)},
@@ -421,14 +431,18 @@ def measure(args, rank, local_rank, world, dist, torch):
                       'achieved_GBs': b_pref / pf_ms / 1e6 if pf_ms > 0 else 0.0, 'index_hits': st['index_hits'],
                       'kmers': st['kmers'], 'hits': st['prefilter_hits'], 'queries_per_s': n_queries / dt if dt > 0 else 0.0},
         'kernels': kernels,
-        'stage_wall_s': stage,
+        'stage_wall_s': {k_: v_ for k_, v_ in stage.items() if not k_.startswith('cpu_')},
         'host_cpu_s_per_step': round(host_cpu_s / max(1, args.steps), 3),
+        # where the host CPU of a step goes: thread CPU seconds of the pipeline's stage threads (sd_search), the rest of the process's
+        # CPU time (OpenMP workers of the host stages -- composition bias, accept / sort / text, aggregation --, HIP runtime threads)
+        'host_cpu_by_stage': dict({k_[4:]: round(v_ / max(1, args.steps), 3) for k_, v_ in stage.items() if k_.startswith('cpu_')},
+                                  other_threads=round((host_cpu_s - sum(v_ for k_, v_ in stage.items() if k_.startswith('cpu_'))) / max(1, args.steps), 3)),
         'results': {'entries': int(summary[0]), 'matched_hits': int(summary[1]), 'clusters': int(summary[2]),
                     'cluster_hits': int(summary[3]), 'queries_not_computed': not_computed},
         'setup_s': {'generate': t_gen, 'index': cs.timing['index_build_s'], 'index_where': 'device (sd_target_build)', 'search_create': t_index,
                     'upload': cs.timing['upload_s']},
         'device': gpu.device_name(),
-        'device_memory': dict(zip(('resident_GB', 'total_GB'), ((mem[1] - mem[0]) / 1e9, mem[1] / 1e9))),
+        'device_memory': dict(resident_GB=(mem[1] - mem[0]) / 1e9, total_GB=mem[1] / 1e9, free_GB=mem[0] / 1e9, workspaces=ws_rep),
         'host_cores': os.cpu_count(),
         'host_cpu_quota': effective_cpus(),
         'cpu_note': 'this box exposes %d logical CPUs but a cgroup quota of %d: cpu_baseline runs on (and is quoted against) %d threads'
@@ -522,7 +536,7 @@ def main():
             if p.returncode == 0 and line:
                 r = json.loads(line[-1])
                 res['p1000'] = {k: r.get(k) for k in ('value', 'unit', 'steps', 'ms_per_step', 'config', 'sw_gcups', 'cpu_baseline', 'parity_check',
-                                                      'results', 'setup_s', 'host_cpu_s_per_step')}
+                                                      'results', 'setup_s', 'host_cpu_s_per_step', 'host_cpu_by_stage', 'device_memory', 'roofline', 'roofline_sw')}
                 res['p1000']['wall_s'] = time.time() - t0
                 cb = r.get('cpu_baseline') or {}
                 if cb.get('value'):
@@ -535,7 +549,7 @@ def main():
         # BASELINE configs[4]: 10 000 proteomes (3 * 10^7 sequences, 9 * 10^9 residues, k = 7) resident on this one GPU -- generated,
         # indexed on the device, checked on a sample against the host builder, and searched for a short step
         cmd = [sys.executable, os.path.abspath(__file__), '--record', '--proteomes', '10000', '--steps', str(args.p10000_steps), '--warmup', '1',
-               '--batch', str(args.p10000_batch), '--chunk', str(args.chunk), '--max-seqs', '4000', '--no-p1000', '--no-p10000', '--no-cpu']
+               '--batch', str(args.p10000_batch), '--chunk', str(args.p10000_chunk), '--no-p1000', '--no-p10000', '--no-cpu']   # --max-seqs 2N = 20 000
         try:
             t0 = time.time()
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
@@ -543,7 +557,7 @@ def main():
             if p.returncode == 0 and line:
                 r = json.loads(line[-1])
                 res['p10000'] = {k: r.get(k) for k in ('value', 'unit', 'steps', 'ms_per_step', 'config', 'sw_gcups', 'index_check', 'results',
-                                                       'setup_s', 'host_cpu_s_per_step', 'device_memory')}
+                                                       'setup_s', 'host_cpu_s_per_step', 'host_cpu_by_stage', 'device_memory', 'roofline', 'roofline_sw')}
                 res['p10000']['wall_s'] = time.time() - t0
             else:
                 res['p10000'] = dict(error=(p.stderr or p.stdout)[-300:])
@@ -565,6 +579,24 @@ def main():
                 res['iter3'] = dict(error=(p.stderr or p.stdout)[-300:])
         except Exception as e:
             res['iter3'] = dict(error=repr(e)[:300])
+    # the claims north_star makes, compact and LAST on the line (a log tail shows them): throughput at 100 / 1 000 / 10 000
+    # proteomes, the reference on this box's cores beside it, parity of the sampled rows
+    def _brief(r):
+        if not isinstance(r, dict) or 'value' not in r:
+            return r if isinstance(r, dict) and ('skipped' in r or 'error' in r) else None
+        cb, pc = r.get('cpu_baseline') or {}, r.get('parity_check') or {}
+        b = dict(value=round(r['value'], 1), unit=r.get('unit'), cpu_value=cb.get('value'), cpu_cores=cb.get('cores'), cpu_kind=cb.get('kind'),
+                 gpu_over_cpu=round(r['value'] / cb['value'], 1) if cb.get('value') else None,
+                 parity=dict(prefilter_rows=pc.get('prefilter_rows'), prefilter_queries_mismatching=pc.get('prefilter_queries_mismatching'),
+                             alignments=pc.get('alignments'), alignments_mismatching=pc.get('alignments_mismatching')) if pc else None,
+                 queries_not_computed=(r.get('results') or {}).get('queries_not_computed'),
+                 roofline_frac=(r.get('roofline') or {}).get('frac'), sw_gcups=round(r.get('sw_gcups') or 0.0))
+        if r.get('device_memory'):
+            b['resident_GB'] = round(r['device_memory']['resident_GB'], 1)
+        return b
+    res['summary'] = dict(p100=_brief(res), p1000=_brief(res.get('p1000')), p10000_max_seqs_20000=_brief(res.get('p10000')),
+                          iter3=({k: res['iter3'].get(k) for k in ('genome_pairs_per_s', 'wall_s', 'parity_check', 'skipped', 'error') if k in res['iter3']}
+                                 if isinstance(res.get('iter3'), dict) else None))
     print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

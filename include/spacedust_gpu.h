@@ -44,6 +44,11 @@ const char *sd_last_error(sd_ctx *ctx);
 int sd_device_name(sd_ctx *ctx, char *buf, size_t cap);
 /* free / total device memory right now (hipMemGetInfo) */
 int sd_device_memory(sd_ctx *ctx, uint64_t *freeBytes, uint64_t *totalBytes);
+/* The context's persistent workspaces (device buffers that live from call to call, and pinned host staging): their total
+ * sizes and, if buf is not NULL, a text table "key bytes\n" of the device ones, largest first (cut at cap - 1 characters). */
+int sd_workspace_report(sd_ctx *ctx, uint64_t *deviceBytes, uint64_t *pinnedBytes, char *buf, size_t cap);
+/* Frees the context's device workspaces (they grow again on demand): between phases of very different shape. */
+int sd_workspace_release(sd_ctx *ctx);
 int sd_synchronize(sd_ctx *ctx);
 
 /* Kernel timing with HIP events on the library's own stream (bench.py roofline leg).
@@ -573,6 +578,15 @@ int sd_r2p_batch(sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t
                  const uint64_t *edgeOff, const uint32_t *edgeT, const int32_t *edgeQStart, const int32_t *edgeTStart,
                  const char *btPool, const uint64_t *btOff, const uint8_t *tResidues, const uint64_t *tOff, char *outProfiles,
                  uint8_t *outConsensus);
+/* The same with the position-specific sequence weights -- PSSMCalculator::computeSequenceWeights' sub-alignment per column
+ * (M/src/alignment/PSSMCalculator.cpp:394-588), O(columns^2 x rows) and the bulk of the step -- on the GPU (csrc/hip/sd_r2p.hip:
+ * a workgroup per centre, every summation in the reference's order, the CPU-specific approximate reciprocal tabulated by the
+ * host); alignment assembly, the greedy diversity filter, pseudo counts, scores and masking stay host stages.  Same bytes as
+ * sd_r2p_batch.  (--wg: global weights, computed on the host as before.) */
+int sd_r2p_batch_device(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t *qLetters, const uint64_t *qOff,
+                        const uint64_t *edgeOff, const uint32_t *edgeT, const int32_t *edgeQStart, const int32_t *edgeTStart,
+                        const char *btPool, const uint64_t *btOff, const uint8_t *tResidues, const uint64_t *tOff, char *outProfiles,
+                        uint8_t *outConsensus);
 
 #ifdef __cplusplus
 }

@@ -148,6 +148,8 @@ def load():
         'sd_target_sample_check': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                              C.c_uint64, C.c_uint64, _vp]),
         'sd_device_memory': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        'sd_workspace_report': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
+        'sd_workspace_release': (C.c_int, [_vp]),
         'sd_prefilter_batch': (C.c_int, [_vp, _vp, C.POINTER(PrefilterParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _vp]),
         'sd_comp_bias_batch': (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_int, _vp, _vp, _vp]),
@@ -205,6 +207,7 @@ def load():
         'sd_r2p_create': (C.c_int, [C.POINTER(_vp)]),
         'sd_r2p_destroy': (None, [_vp]),
         'sd_r2p_batch': (C.c_int, [_vp, C.POINTER(R2pParams), C.c_uint32] + [_vp] * 12),
+        'sd_r2p_batch_device': (C.c_int, [_vp, _vp, C.POINTER(R2pParams), C.c_uint32] + [_vp] * 12),
         'sd_shard_query_sets': (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.POINTER(C.c_uint32)]),
         'sd_comm_unique_id': (C.c_int, [C.c_char_p]),
         'sd_comm_init': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)]),

@@ -144,10 +144,15 @@ def result2profile(q_letters, q_off, edge_off, edge_t, edge_qstart, edge_tstart,
     t_residues = np.ascontiguousarray(t_residues, np.uint8)
     t_off = np.ascontiguousarray(t_off, np.uint64)
     out = np.zeros(int(q_off[-1]) * 25 + 1, np.uint8)
-    rc = L.sd_r2p_batch(h, C.byref(p), len(q_off) - 1, ptr(q_letters), ptr(q_off), ptr(edge_off), ptr(edge_t), ptr(qs), ptr(ts), ptr(pool),
-                        ptr(bt_off), ptr(t_residues), ptr(t_off), ptr(out), None)
+    ctx = kw.get('ctx')   # a Context: sd_r2p_batch_device (sequence weights on the GPU); None: the host implementation
+    if ctx is not None:
+        rc = L.sd_r2p_batch_device(ctx.h, h, C.byref(p), len(q_off) - 1, ptr(q_letters), ptr(q_off), ptr(edge_off), ptr(edge_t), ptr(qs),
+                                   ptr(ts), ptr(pool), ptr(bt_off), ptr(t_residues), ptr(t_off), ptr(out), None)
+    else:
+        rc = L.sd_r2p_batch(h, C.byref(p), len(q_off) - 1, ptr(q_letters), ptr(q_off), ptr(edge_off), ptr(edge_t), ptr(qs), ptr(ts), ptr(pool),
+                            ptr(bt_off), ptr(t_residues), ptr(t_off), ptr(out), None)
     L.sd_r2p_destroy(h)
-    _check(None, rc, 'sd_r2p_batch')
+    _check(ctx.h if ctx is not None else None, rc, 'sd_r2p_batch')
     return out[:-1].tobytes()
 
 
@@ -252,6 +257,14 @@ class Context:
         f, t = C.c_uint64(), C.c_uint64()
         _check(self.h, self.L.sd_device_memory(self.h, C.byref(f), C.byref(t)), 'sd_device_memory')
         return f.value, t.value
+
+    def workspace_report(self, top=8):
+        """(device bytes, pinned host bytes, [(key, bytes)] of the largest device workspaces) of this context"""
+        d, p = C.c_uint64(), C.c_uint64()
+        buf = C.create_string_buffer(1 << 16)
+        _check(self.h, self.L.sd_workspace_report(self.h, C.byref(d), C.byref(p), buf, len(buf)), 'sd_workspace_report')
+        rows = [ln.rsplit(' ', 1) for ln in buf.value.decode().splitlines() if ln]
+        return d.value, p.value, [(k, int(v)) for k, v in rows[:top]]
 
     def profile(self, on=True):
         self.L.sd_profile_enable(self.h, 1 if on else 0)

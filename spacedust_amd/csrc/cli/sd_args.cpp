@@ -59,6 +59,7 @@ const char *const kValueFlags[] = {
     "-k", "-s", "-v",
     // this binary's own (multi-GPU launch and tuning; not reference flags)
     "--device", "--rank", "--world-size", "--chunk-queries", "--bin-size", "--l2-cache-size", "--keep-dbs", "--keep-tmp", "--comm-port",
+    "--profile-weights-host",
 };
 
 const std::set<std::string> &boolFlags() {

@@ -551,6 +551,18 @@ int result2profileModule(const Args &a) {
     sd_r2p *r2p = nullptr;
     if (sd_r2p_create(&r2p) != SD_OK) return fail("sd_r2p_create failed");
     std::unique_ptr<sd_r2p, void (*)(sd_r2p *)> guard(r2p, sd_r2p_destroy);
+    // the position-specific weights -- the O(columns^2 x rows) part -- run on the GPU (sd_r2p_batch_device); --profile-weights-host 1
+    // asks for the host implementation explicitly (a box without a GPU, the CPU-side tests).  No silent fallback.
+    const bool hostWeights = a.integer("--profile-weights-host", 0) != 0;
+    sd_ctx *r2pCtx = nullptr;
+    if (!hostWeights) {
+        const int device = a.has("--device") ? (int) a.integer("--device", 0) : envInt("LOCAL_RANK", 0);
+        const int rcCtx = sd_ctx_create(device, &r2pCtx);
+        if (rcCtx != SD_OK)
+            return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rcCtx) + "); result2profile computes the sequence weights on "
+                        "the GPU (--profile-weights-host 1 selects the host implementation)");
+    }
+    std::unique_ptr<sd_ctx, void (*)(sd_ctx *)> ctxGuard(r2pCtx, sd_ctx_destroy);
     sddb::Writer out;
     if (!out.open(a.pos[3], sddb::DBTYPE_HMM_PROFILE, &err)) return fail(err);
     const size_t n = aln.size();
@@ -627,9 +639,12 @@ int result2profileModule(const Args &a) {
         eQ.push_back(0);
         eT.push_back(0);
         const double t1 = now();
-        const int rc = sd_r2p_batch(r2p, &p, nQ, qLetters.data(), qOff.data(), edgeOff.data(), edgeT.data(), eQ.data(), eT.data(), pool.data(),
-                                    btOff.data(), tdb->residues.data(), tdb->offsets.data(), profiles.data(), nullptr);
-        if (rc != SD_OK) return fail("sd_r2p_batch failed (" + std::to_string(rc) + ")");
+        const int rc = r2pCtx ? sd_r2p_batch_device(r2pCtx, r2p, &p, nQ, qLetters.data(), qOff.data(), edgeOff.data(), edgeT.data(), eQ.data(),
+                                                    eT.data(), pool.data(), btOff.data(), tdb->residues.data(), tdb->offsets.data(),
+                                                    profiles.data(), nullptr)
+                              : sd_r2p_batch(r2p, &p, nQ, qLetters.data(), qOff.data(), edgeOff.data(), edgeT.data(), eQ.data(), eT.data(),
+                                             pool.data(), btOff.data(), tdb->residues.data(), tdb->offsets.data(), profiles.data(), nullptr);
+        if (rc != SD_OK) return fail("sd_r2p_batch failed (" + std::to_string(rc) + ")" + (r2pCtx ? std::string(": ") + sd_last_error(r2pCtx) : std::string()));
         const double t2 = now();
         for (uint32_t q = 0; q < nQ; q++)
             if (!out.write(keys[q], profiles.data() + qOff[q] * 25, (size_t) (qOff[q + 1] - qOff[q]) * 25)) return fail("cannot write " + a.pos[3]);
@@ -637,7 +652,8 @@ int result2profileModule(const Args &a) {
         tCompute += t2 - t1;
         tWrite += now() - t2;
     }
-    info(a, "result2profile: parse %.2f s, profiles %.2f s (%d threads), write %.2f s\n", tParse, tCompute, threads, tWrite);
+    info(a, "result2profile: parse %.2f s, profiles %.2f s (%d threads, weights on the %s), write %.2f s\n", tParse, tCompute, threads,
+         r2pCtx ? "GPU" : "host", tWrite);
     (void) tLoaded;
     if (!out.close(&err)) return fail(err);
     // the profile DB shares the query DB's ancillary files (DBReader::softlinkDb(..., SEQUENCE_ANCILLARY), :318-320)

@@ -120,7 +120,8 @@ hipError_t wsGet(sd_ctx *ctx, const char *key, size_t count, T **out) {
         if (e.p) (void) hipFree(e.p);
         e.p = nullptr;
         e.bytes = 0;
-        const size_t grow = need + need / 4 + 256;
+        // slack against regrowth (a hipFree waits for the device): a quarter, an eighth for the buffers of a gigabyte and more
+        const size_t grow = need + (need >= (1ull << 30) ? need / 8 : need / 4) + 256;
         hipError_t err = hipMalloc(&e.p, grow);
         if (err != hipSuccess) return err;
         e.bytes = grow;

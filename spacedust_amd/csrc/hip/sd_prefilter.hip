@@ -2663,10 +2663,14 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                           (unsigned long long) (qOffsets[x + 1] - qOffsets[x]));
     uint32_t qBeg = 0;
     bool forceLookup = false;   // this sub-batch is redone on the lookup path (a regime the join path does not carry)
-    uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 4096);   // ~0.6 G hits per sub-batch on a proteome-scale target DB: larger sorts were measured 4x slower per item
+    // queries per sub-batch: the k-mer stream, its sorted copy and the hit stream of a sub-batch are what the prefilter keeps in
+    // HBM (~3.4 MB per query on a proteome-scale target); the tables are walked once per sub-batch (~1 GB at 100 proteomes)
+    uint32_t batchQ = std::min<uint32_t>(maxBatchQ, 2048);
     if (const char *e = getenv("SD_PF_BATCH")) batchQ = std::max<uint32_t>(1, std::min<uint32_t>(maxBatchQ, (uint32_t) atoi(e)));
     while (qBeg < nQ) {
-        uint32_t bq = std::min<uint32_t>(batchQ, nQ - qBeg);
+        // the rest of the call in equal sub-batches of at most batchQ queries
+        const uint32_t left = nQ - qBeg, parts = (left + batchQ - 1) / batchQ;
+        uint32_t bq = (left + parts - 1) / parts;
         std::unique_ptr<HostScope> hs(new HostScope(ctx, "pf.upload_count"));
         // ---- upload the sub-batch
         const uint64_t r0 = qOffsets[qBeg], r1 = qOffsets[qBeg + bq];
@@ -3152,6 +3156,11 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     SD_HIP(ctx, sdStreamSync(ctx));
                     pSegCount = dHotCount.p;
                     pOutBase = dHotBase.p;
+                    if (ctx->profiling) {   // a counter beside the kernel times: hits that passed the filter (bench.py's algorithmic bytes)
+                        sd_profile_entry &pe = ctx->profile["stat.prefilter_hits_left"];
+                        pe.ms += (double) nLeft;
+                        pe.launches += 1;
+                    }
                     if (getenv("SD_DEBUG_TIMING"))
                         fprintf(stderr, "[prefilter] hot filter: %llu of %llu hits left (%.2f %%), %u segments\n", (unsigned long long) nLeft,
                                 (unsigned long long) nHits, 100.0 * (double) nLeft / (double) std::max<uint64_t>(nHits, 1), nVQ);

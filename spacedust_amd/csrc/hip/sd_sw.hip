@@ -640,7 +640,7 @@ void launchScorePk(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, ui
                        t->dRes, dMat, go, ge, dOut, dBound, dOrder, (const int8_t *) q->dProf);
 }
 
-template <int RT, int LW, bool SHARED>
+template <int RT, int LW, int SHARED>
 void launchScorePkAligned(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, uint32_t n, const sd_seqset *q, const sd_seqset *t,
                           const int8_t *dMat, int go, int ge, int32_t *dOut) {
     if (n == 0) return;
@@ -1174,6 +1174,11 @@ k_bound_apply(uint32_t nPairs, SwTask *__restrict__ tasks, const uint64_t *__res
 // (class, query) run together, longest target first; inside a run of a packed class consecutive tasks form pairs, an
 // odd last task stays alone.  Invalid tasks sort last (all ones).
 constexpr uint32_t PAIR_NONE = 0xFFFFFFFFu;
+// SD_SW_QUADS=0: wavefronts of two independent shared-profile pairs (round 3's form) instead of four tasks of one query
+inline bool sdSwQuads() {
+    static const bool on = !(getenv("SD_SW_QUADS") && atoi(getenv("SD_SW_QUADS")) == 0);
+    return on;
+}
 constexpr int PAIR_QUERY_BITS = 17;
 __global__ void __launch_bounds__(256)
 k_pair_keys(uint32_t n, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ pairQ, uint32_t *__restrict__ key2) {
@@ -1190,17 +1195,29 @@ k_pair_heads(uint32_t n, const uint32_t *__restrict__ keyS, uint32_t *__restrict
     const bool head = p == 0 || (keyS[p] >> 9) != (keyS[p - 1] >> 9);
     headPos[p] = head ? p : 0u;
 }
+// leader[p] = pairs that start at sorted position p: 1 for every second task of a (class, query) run; with `quads` the run's
+// last task adds one EMPTY pair when the run holds an odd number of pairs, so that every wavefront of four tasks (two pairs)
+// stays inside one query (sw_score_pk_aligned_kernel<.., SHARE = 2>: one profile per wavefront)
 __global__ void __launch_bounds__(256)
-k_pair_leaders(uint32_t n, const uint32_t *__restrict__ keyS, const uint32_t *__restrict__ runStart, uint8_t *__restrict__ leader) {
+k_pair_leaders(uint32_t n, const uint32_t *__restrict__ keyS, const uint32_t *__restrict__ runStart, uint8_t *__restrict__ leader, int quads) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n) return;
-    leader[p] = (p < n && (keyS[p] >> 26) < FIRST_INT32_CLASS && ((p - runStart[p]) & 1u) == 0) ? 1 : 0;
+    uint8_t v = 0;
+    if (p < n && (keyS[p] >> 26) < FIRST_INT32_CLASS) {
+        const uint32_t o = p - runStart[p];
+        v = (o & 1u) == 0 ? 1 : 0;
+        if (quads) {
+            const bool lastOfRun = p + 1 >= n || (keyS[p + 1] >> 9) != (keyS[p] >> 9);
+            if (lastOfRun && (((o + 1 + 1) / 2) & 1u)) v += 1;   // pairs of the run = ceil((o + 1) / 2): odd -> one empty pair behind it
+        }
+    }
+    leader[p] = v;
 }
 __global__ void __launch_bounds__(256)
-k_pair_emit(uint32_t n, const uint32_t *__restrict__ keyS, const uint32_t *__restrict__ vals, const uint8_t *__restrict__ leader,
+k_pair_emit(uint32_t n, const uint32_t *__restrict__ keyS, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ runStartOf,
             const uint64_t *__restrict__ pairIdx, uint32_t *__restrict__ order2) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n || !leader[p]) return;
+    if (p >= n || (keyS[p] >> 26) >= FIRST_INT32_CLASS || ((p - runStartOf[p]) & 1u)) return;   // the first task of every pair (packed classes) writes it
     const uint64_t w = pairIdx[p];
     order2[2 * w] = vals[p];
     const bool mate = p + 1 < n && (keyS[p + 1] >> 9) == (keyS[p] >> 9);
@@ -1243,7 +1260,8 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
         SD_HIP(ctx, wsGet(ctx, "sp.runstart", (size_t) nPairs, &dRunStart));
         SD_HIP(ctx, wsGet(ctx, "sp.leader", (size_t) nPairs + 1, &dLeader));
         SD_HIP(ctx, wsGet(ctx, "sp.pairidx", (size_t) nPairs + 1, &dPairIdx));
-        SD_HIP(ctx, wsGet(ctx, "sp.order2", (size_t) 2 * nPairs, &dOrder2));
+        SD_HIP(ctx, wsGet(ctx, "sp.order2", (size_t) 4 * nPairs + 8, &dOrder2));
+        SD_HIP(ctx, hipMemsetAsync(dOrder2, 0xFF, ((size_t) 4 * nPairs + 8) * sizeof(uint32_t), ctx->stream));   // empty pairs: PAIR_NONE
         SD_HIP(ctx, wsGet(ctx, "sp.bounds", 64, &dPairBounds));
         hipLaunchKernelGGL(k_pair_keys, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dPairQ, dKey2);
         rc = devSortPairs(ctx, dKey2, dKeysSorted, dVals, dVals2, nPairs, 32);
@@ -1257,7 +1275,8 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
             SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
             SD_HIP(ctx, hipcub::DeviceScan::InclusiveScan(tmp, bytes, dHead, dRunStart, MaxU32(), (int) nPairs, ctx->stream));
         }
-        hipLaunchKernelGGL(k_pair_leaders, dim3((nPairs + 256) / 256), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dRunStart, dLeader);
+        hipLaunchKernelGGL(k_pair_leaders, dim3((nPairs + 256) / 256), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dRunStart, dLeader,
+                           sdSwQuads() ? 1 : 0);
         {
             size_t bytes = 0;
             hipcub::TransformInputIterator<uint64_t, WidenU8, const uint8_t *> it(dLeader, WidenU8());
@@ -1266,7 +1285,7 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
             SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
             SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, dPairIdx, (int) (nPairs + 1), ctx->stream));
         }
-        hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dVals2, dLeader, dPairIdx, dOrder2);
+        hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dVals2, dRunStart, dPairIdx, dOrder2);
         hipLaunchKernelGGL(k_pair_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, dPairIdx, dPairBounds,
                            (int) FIRST_INT32_CLASS + 1);
         hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, 1u << 26, dBounds, (int) N_SCORE_CLASSES + 1);
@@ -1326,11 +1345,12 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
     } while (0)
 #define SD_PKA(RT)                                                                                               \
     case RT:                                                                                                     \
-        if (shared) launchScorePkAligned<RT, 32, true>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);        \
-        else launchScorePkAligned<RT, 32, false>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);              \
+        if (shared && quads) launchScorePkAligned<RT, 32, 2>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);  \
+        else if (shared) launchScorePkAligned<RT, 32, 1>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);      \
+        else launchScorePkAligned<RT, 32, 0>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);                  \
         break;
 #define SD_PKA16(SEG)                                                                                            \
-    case SEG: launchScorePkAligned<2 * SEG, 16, true>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut); break;
+    case SEG: launchScorePkAligned<2 * SEG, 16, 1>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut); break;
 #define SD_PK_CLASS(WIDE, IDX)                                                \
         switch (IDX) {                                                        \
             case 0: SD_PK(4, 32, false, WIDE); break;                         \
@@ -1347,7 +1367,8 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
             default: SD_PK(8, 64, true, WIDE); break;                         \
         }
         // SD_SW_LW16: shared-profile tasks of up to this many rows per segment run on 16-lane groups (two segments per lane)
-        static const int lw16Max = getenv("SD_SW_LW16") ? atoi(getenv("SD_SW_LW16")) : 8;   // measured: beyond 8 rows per segment the LDS footprint (two segments per lane, eight tasks per wavefront) costs more occupancy than the shorter ramp returns
+        static const int lw16Max = getenv("SD_SW_LW16") ? atoi(getenv("SD_SW_LW16")) : (sdSwQuads() ? 0 : 8);
+        const bool quads = sdSwQuads();   // measured: beyond 8 rows per segment the LDS footprint (two segments per lane, eight tasks per wavefront) costs more occupancy than the shorter ramp returns
         if (aligned && shared && alignedRT <= lw16Max) {
             switch (alignedRT) {
                 SD_PKA16(5) SD_PKA16(6) SD_PKA16(7) SD_PKA16(8) SD_PKA16(9) SD_PKA16(10) SD_PKA16(11) SD_PKA16(12)
@@ -1466,6 +1487,37 @@ int sd_device_memory(sd_ctx *ctx, uint64_t *freeBytes, uint64_t *totalBytes) {
     SD_HIP(ctx, hipMemGetInfo(&f, &t));
     if (freeBytes) *freeBytes = f;
     if (totalBytes) *totalBytes = t;
+    return SD_OK;
+}
+
+int sd_workspace_report(sd_ctx *ctx, uint64_t *deviceBytes, uint64_t *pinnedBytes, char *buf, size_t cap) {
+    if (!ctx) return SD_EINVAL;
+    uint64_t dev = 0, pin = 0;
+    std::vector<std::pair<size_t, std::string> > rows;
+    for (auto &kv : ctx->ws) {
+        dev += kv.second.bytes;
+        rows.push_back(std::make_pair(kv.second.bytes, kv.first));
+    }
+    for (auto &kv : ctx->pinned) pin += kv.second.bytes;
+    if (deviceBytes) *deviceBytes = dev;
+    if (pinnedBytes) *pinnedBytes = pin;
+    if (buf && cap) {
+        std::sort(rows.begin(), rows.end(), [](const std::pair<size_t, std::string> &a, const std::pair<size_t, std::string> &b) { return a.first > b.first; });
+        std::string s;
+        for (auto &r : rows) s += r.second + " " + std::to_string(r.first) + "\n";
+        snprintf(buf, cap, "%s", s.c_str());
+    }
+    return SD_OK;
+}
+
+int sd_workspace_release(sd_ctx *ctx) {
+    if (!ctx) return SD_EINVAL;
+    (void) hipSetDevice(ctx->device);
+    SD_HIP(ctx, sdStreamSync(ctx));
+    for (auto &kv : ctx->ws)
+        if (kv.second.p) (void) hipFree(kv.second.p);
+    ctx->ws.clear();
+    ctx->biasTablesUploaded = false;
     return SD_OK;
 }
 

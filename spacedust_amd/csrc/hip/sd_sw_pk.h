@@ -440,7 +440,11 @@ __device__ __forceinline__ uint32_t dppMove(uint32_t old, uint32_t v) {
     return (uint32_t) __builtin_amdgcn_update_dpp((int) old, (int) v, CTRL, 0xf, 0xf, ZERO_FILL);
 }
 
-template <int RT, int LW, bool SHARED>
+// SHARE: 0 = every task has its own profile; 1 = the two tasks of a pair have the same query (one profile per group);
+// 2 = ALL tasks of the wavefront have the same query (the caller pads a query's run of pairs to whole wavefronts): one profile
+// per wavefront -- half (LW = 32) or a quarter (LW = 16) of the LDS, which is what lets the memory-bound prefilter workgroups of
+// the other streams live on the same CUs.
+template <int RT, int LW, int SHARE>
 __global__ void __launch_bounds__(64)
 sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                            const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
@@ -455,7 +459,8 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
     constexpr int NT = 2 * NGRP;           // tasks per wavefront: a task pair per group of LW lanes
     constexpr uint32_t ROWB = PSTRIDE * 4; // bytes per residue row
     static_assert(22 * ROWB < 65536, "row offsets travel in 16 bits");
-    __shared__ uint32_t prof[SHARED ? NGRP : NT][22][PSTRIDE];
+    constexpr bool SHARED = SHARE != 0;
+    __shared__ uint32_t prof[SHARE == 2 ? 1 : (SHARE == 1 ? NGRP : NT)][22][PSTRIDE];
     __shared__ int8_t smat[441];
     for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
     __syncthreads();
@@ -497,8 +502,8 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
     // ---- query profiles (SmithWaterman::createQueryProfile, :163-187)
 #pragma unroll
     for (int x = 0; x < (SHARED ? 1 : 2); x++) {
-        const SwTask &T = x ? B : A;
-        uint32_t *pw = &prof[SHARED ? grp : 2 * grp + x][0][0] + l * WORDS;
+        const SwTask &T = SHARE == 2 ? tk[0] : (x ? B : A);   // (SHARE == 2: every group writes a share of the residue rows of the one profile)
+        uint32_t *pw = &prof[SHARE == 2 ? 0 : (SHARE == 1 ? grp : 2 * grp + x)][0][0] + l * WORDS;
 #pragma unroll
         for (int w = 0; w < WORDS; w++) {
             int res[4], cb[4];
@@ -518,8 +523,9 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
                     pidx[b] = idx * 21;
                 }
             }
+            const int aFirst = SHARE == 2 ? grp : 0, aStep = SHARE == 2 ? NGRP : 1;
             if (qProf) {   // profile query: the position's own row
-                for (int a = 0; a < 21; a++) {
+                for (int a = aFirst; a < 21; a += aStep) {
                     uint32_t word = 0;
 #pragma unroll
                     for (int b = 0; b < 4; b++) {
@@ -529,7 +535,7 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
                     pw[a * PSTRIDE + w] = word;
                 }
             } else {
-                for (int a = 0; a < 21; a++) {
+                for (int a = aFirst; a < 21; a += aStep) {
                     uint32_t word = 0;
 #pragma unroll
                     for (int b = 0; b < 4; b++) {
@@ -545,7 +551,7 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
     __syncthreads();
     // LDS byte addresses of this lane's profile words (row 0); the residue stream adds the row offset
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    const uint32_t baseA = (uint32_t) (size_t) (lds_u32 *) (&prof[SHARED ? grp : 2 * grp][0][0] + l * WORDS);
+    const uint32_t baseA = (uint32_t) (size_t) (lds_u32 *) (&prof[SHARE == 2 ? 0 : (SHARE == 1 ? grp : 2 * grp)][0][0] + l * WORDS);
     const uint32_t baseB = SHARED ? baseA : (uint32_t) (size_t) (lds_u32 *) (&prof[2 * grp + 1][0][0] + l * WORDS);
     auto ldsWord = [](uint32_t addr, int w) -> uint32_t { return *((const lds_u32 *) (size_t) addr + w); };
 

@@ -615,6 +615,93 @@ struct sd_r2p {
     sd::MaskCtx mask;
 };
 
+// steps 3b .. 6 of the header comment: from the weighted frequencies and effective sequence numbers of a centre to its record
+static void finishProfile(const sd_r2p *r, const sd_r2p_params *par, const double *background, const uint8_t *centre, int L, uint64_t qOffQ,
+                          ProfileScratch &w, char *outProfiles, uint8_t *outConsensus) {
+    const uint64_t qOff[1] = {qOffQ};
+    const uint32_t q = 0;
+    // consensus: the residue most enriched over the background (PSSMCalculator.cpp:652-667)
+    for (int i = 0; i < L; i++) {
+        float best = 1E-8;
+        int which = kAny;
+        for (int a = 0; a < kResidues; a++) {
+            const float f = w.frequency[(size_t) i * kResidues + a];
+            if (f - background[a] > best) {
+                best = f - background[a];
+                which = a;
+            }
+        }
+        w.consensus[i] = (unsigned char) which;
+    }
+    // substitution-matrix pseudo counts, mixed in with a weight that falls with the effective sequence number
+    // (PSSMCalculator.cpp:274-282,374-392)
+    if (par->pca > 0.0f) {
+        float __attribute__((aligned(32))) column[24];
+        for (int i = 0; i < L; i++) {
+            memcpy(column, &w.frequency[(size_t) i * kResidues], kResidues * sizeof(float));
+            for (int a = 0; a < kResidues; a++) w.pseudo[(size_t) i * kResidues + a] = dot20(r->conditional[a], column);
+        }
+        for (int i = 0; i < L; i++) {
+            float tau = fmin(1.0, par->pca / (1.0 + w.effective[i] / par->pcb));
+            for (int a = 0; a < kResidues; a++) {
+                float fromPrior = tau * w.pseudo[(size_t) i * kResidues + a];
+                float fromData = (1.0 - tau) * w.frequency[(size_t) i * kResidues + a];
+                w.mixed[(size_t) i * kResidues + a] = fromData + fromPrior;
+            }
+        }
+    } else {
+        for (int x = 0; x < L * kResidues; x++) w.mixed[x] = w.frequency[x];
+    }
+    // log-odds in eighth bits, rounded half away from zero through a char, clamped (PSSMCalculator.cpp:251-265)
+    for (int i = 0; i < L; i++) {
+        for (int a = 0; a < kResidues; a++) {
+            const float p = w.mixed[(size_t) i * kResidues + a];
+            float logOdds = flog2(p / background[a]);
+            const float bitFactor = 8.0, scoreBias = 0.0;
+            float v = bitFactor * logOdds + bitFactor * scoreBias;
+            v = static_cast<char>((v < 0.0) ? v - 0.5 : v + 0.5);
+            w.score[(size_t) i * kResidues + a] = std::max(-128.0f, std::min(v, 127.0f));
+        }
+    }
+    if (par->compBiasCorr) {
+        // every column gives up the average excess (over its background expectation) of its 40-column neighbourhood
+        // (SubstitutionMatrix.cpp:205-243)
+        w.nullScore.assign(L, 0.0f);
+        char *sc = w.score.data();
+        const int window = 40;
+        for (int i = 0; i < L; i++)
+            for (int a = 0; a < kResidues; a++) w.nullScore[i] += background[a] * static_cast<float>(sc[i * kResidues + a]);
+        for (int i = 0; i < L; i++) {
+            const int lo = std::max(0, i - window / 2), hi = std::min(L, i + window / 2);
+            const int span = hi - lo;
+            float excess[kResidues];
+            memset(excess, 0, sizeof(excess));
+            for (int j = lo; j < hi; j++) {
+                if (j == i) continue;
+                for (int a = 0; a < kResidues; a++) excess[a] += sc[j * kResidues + a] - w.nullScore[j];
+            }
+            for (int a = 0; a < kResidues; a++) sc[i * kResidues + a] = static_cast<int>(sc[i * kResidues + a] - excess[a] / span);
+        }
+    }
+    if (par->maskProfile) {   // tantan on the centre's letters: masked positions score -1 against everything
+        w.masked.assign(centre, centre + L);
+        sd::tantanMask(r->mask, w.masked.data(), L, par->maskProb);
+        for (int i = 0; i < L; i++)
+            if (w.masked[i] == sd::X_CODE) memset(&w.score[(size_t) i * kResidues], -1, kResidues);
+    }
+    char *out = outProfiles + qOff[q] * 25;
+    for (int i = 0; i < L; i++) {
+        char *rec = out + (size_t) i * 25;
+        memcpy(rec, &w.score[(size_t) i * kResidues], kResidues);
+        rec[20] = (char) centre[i];
+        rec[21] = (char) w.consensus[i];
+        rec[22] = (char) effectiveCountByte(w.effective[i]);
+        rec[23] = 0;
+        rec[24] = 0;
+        if (outConsensus) outConsensus[qOff[q] + i] = w.consensus[i];
+    }
+}
+
 extern "C" {
 
 int sd_r2p_create(sd_r2p **out) {
@@ -645,10 +732,54 @@ int sd_r2p_create(sd_r2p **out) {
 
 void sd_r2p_destroy(sd_r2p *r) { delete r; }
 
+// the device half (csrc/hip/sd_r2p.hip): position-specific weights, frequencies and effective sequence numbers of a batch of
+// filtered alignments
+struct R2pTaskH {   // = R2pTask of sd_r2p.hip
+    uint64_t cellOff, cmOff, weightOff, colOff, scratchOff;
+    uint32_t nRows, L, stride, rowStride;
+};
+int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, uint32_t nShort, const void *tasksHost, const char *cells, uint64_t cellBytes, uint64_t cmBytes,
+                             const float *globalWeight, uint64_t nWeights, uint64_t nColumns, uint64_t scratchElems, const float *rcpTable,
+                             uint32_t rcpN, const double *background, float *freqOut, float *effOut);
+
+static int r2pBatchImpl(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t *qLetters, const uint64_t *qOff,
+                        const uint64_t *edgeOff, const uint32_t *edgeT, const int32_t *edgeQStart, const int32_t *edgeTStart,
+                        const char *btPool, const uint64_t *btOff, const uint8_t *tResidues, const uint64_t *tOff, char *outProfiles,
+                        uint8_t *outConsensus);
+
 int sd_r2p_batch(sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t *qLetters, const uint64_t *qOff,
                  const uint64_t *edgeOff, const uint32_t *edgeT, const int32_t *edgeQStart, const int32_t *edgeTStart,
                  const char *btPool, const uint64_t *btOff, const uint8_t *tResidues, const uint64_t *tOff, char *outProfiles,
                  uint8_t *outConsensus) {
+    return r2pBatchImpl(nullptr, r, par, nQ, qLetters, qOff, edgeOff, edgeT, edgeQStart, edgeTStart, btPool, btOff, tResidues, tOff,
+                        outProfiles, outConsensus);
+}
+
+int sd_r2p_batch_device(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t *qLetters, const uint64_t *qOff,
+                        const uint64_t *edgeOff, const uint32_t *edgeT, const int32_t *edgeQStart, const int32_t *edgeTStart,
+                        const char *btPool, const uint64_t *btOff, const uint8_t *tResidues, const uint64_t *tOff, char *outProfiles,
+                        uint8_t *outConsensus) {
+    if (!ctx) return SD_EINVAL;
+    return r2pBatchImpl(ctx, r, par, nQ, qLetters, qOff, edgeOff, edgeT, edgeQStart, edgeTStart, btPool, btOff, tResidues, tOff,
+                        outProfiles, outConsensus);
+}
+
+}  // extern "C"
+
+// share = 1 / x for x = 0 .. n - 1 as PSSMCalculator computes it (:494-505): the CPU's approximate reciprocal, one Newton step
+static void reciprocalTable(std::vector<float> &table, uint32_t n) {
+    table.assign(((size_t) n + 7) / 8 * 8, 0.0f);
+    for (uint32_t g = 0; g < n; g += 8) {
+        const __m256 x = _mm256_cvtepi32_ps(_mm256_add_epi32(_mm256_set1_epi32((int) g), _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7)));
+        const __m256 y = _mm256_rcp_ps(x);
+        _mm256_storeu_ps(table.data() + g, _mm256_sub_ps(_mm256_add_ps(y, y), _mm256_mul_ps(x, _mm256_mul_ps(y, y))));
+    }
+}
+
+static int r2pBatchImpl(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t *qLetters, const uint64_t *qOff,
+                        const uint64_t *edgeOff, const uint32_t *edgeT, const int32_t *edgeQStart, const int32_t *edgeTStart,
+                        const char *btPool, const uint64_t *btOff, const uint8_t *tResidues, const uint64_t *tOff, char *outProfiles,
+                        uint8_t *outConsensus) {
     if (!r || !par || !qLetters || !qOff || !edgeOff || !outProfiles) return SD_EINVAL;
     if (par->pcMode != 0) return SD_EUNSUPPORTED;   // context specific pseudo counts need the K4000 library
     FilterSettings fs;
@@ -670,6 +801,143 @@ int sd_r2p_batch(sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t
     fs.diversity = par->Ndiff;
     fs.minRowsToFilter = par->filterMinEnable;
     const double *background = r->matrix.pBack;
+    if (ctx && !par->wg) {
+        // ---- device path: groups of centres whose filtered alignments fit the staging budget
+        //   A (host, a thread per centre)  alignment, diversity filter, global weights
+        //   B (device)                     position-specific weights, frequencies, effective sequence numbers
+        //   C (host, a thread per centre)  pseudo counts, scores, composition bias, masking, record
+        struct Prepared {
+            std::vector<char> cells;   // [nRows][stride], kept rows in order
+            std::vector<float> gw;
+            uint32_t nRows = 0, stride = 0;
+        };
+        const uint64_t budget = 1ull << 30;   // bytes of alignment cells per device call
+        uint32_t g0 = 0;
+        while (g0 < nQ) {
+            // a group: by the UNfiltered size (rows x columns), which bounds the filtered one
+            uint32_t g1 = g0;
+            uint64_t est = 0;
+            while (g1 < nQ) {
+                const uint64_t Lq = qOff[g1 + 1] - qOff[g1];
+                const uint64_t add = (edgeOff[g1 + 1] - edgeOff[g1] + 1) * (Lq + 4);
+                if (g1 > g0 && est + add > budget) break;
+                est += add;
+                g1++;
+            }
+            const uint32_t nG = g1 - g0;
+            std::vector<Prepared> prep(nG);
+#pragma omp parallel
+            {
+                Alignment A;
+                DiversityFilter filter;
+                std::vector<Hit> hits;
+#pragma omp for schedule(dynamic, 8)
+                for (uint32_t x = 0; x < nG; x++) {
+                    const uint32_t q = g0 + x;
+                    const uint8_t *centre = qLetters + qOff[q];
+                    const int L = (int) (qOff[q + 1] - qOff[q]);
+                    if (L == 0) continue;
+                    hits.resize((size_t) (edgeOff[q + 1] - edgeOff[q]));
+                    for (size_t h = 0; h < hits.size(); h++) {
+                        const uint64_t e = edgeOff[q] + h;
+                        hits[h].target = tResidues + tOff[edgeT[e]];
+                        hits[h].centreStart = edgeQStart[e];
+                        hits[h].targetStart = edgeTStart[e];
+                        hits[h].path = btPool + btOff[e];
+                        hits[h].pathLength = (uint32_t) (btOff[e + 1] - btOff[e]);
+                    }
+                    buildAlignment(A, centre, L, hits);
+                    size_t nRows = hits.size() + 1;
+                    if (par->filterMsa) nRows = filter.run(A, nRows, r->scores, fs);
+                    Prepared &P = prep[x];
+                    P.nRows = (uint32_t) nRows;
+                    P.stride = (uint32_t) ((L + 3) / 4 * 4);
+                    P.cells.assign((size_t) nRows * P.stride, (char) kGap);
+                    for (size_t rr = 0; rr < nRows; rr++) memcpy(&P.cells[rr * P.stride], A.row[rr], (size_t) L);
+                    P.gw.assign(nRows, 0.0f);
+                    globalWeights(P.gw.data(), L, nRows, A.row.data());
+                    scaleToOne(P.gw.data(), (int) nRows);
+                }
+            }
+            // staging
+            std::vector<R2pTaskH> tasks;
+            std::vector<uint32_t> taskQ;
+            uint64_t cellBytes = 0, cmBytes = 0, nWeights = 0, nColumns = 0, scratch = 0;
+            uint32_t maxRows = 1;
+            for (uint32_t x = 0; x < nG; x++) {
+                const Prepared &P = prep[x];
+                if (P.nRows == 0) continue;
+                R2pTaskH t;
+                t.nRows = P.nRows;
+                t.L = (uint32_t) (qOff[g0 + x + 1] - qOff[g0 + x]);
+                t.stride = P.stride;
+                t.rowStride = (P.nRows + 63) / 64 * 64;
+                t.cellOff = cellBytes;
+                t.cmOff = cmBytes;
+                t.weightOff = nWeights;
+                t.colOff = nColumns;
+                t.scratchOff = scratch;
+                cellBytes += (uint64_t) P.nRows * P.stride;
+                cmBytes += (uint64_t) t.L * t.rowStride;
+                nWeights += P.nRows;
+                nColumns += t.L;
+                scratch += (uint64_t) (t.L + 1) * 24;
+                maxRows = std::max(maxRows, P.nRows);
+                tasks.push_back(t);
+                taskQ.push_back(g0 + x);
+            }
+            if (!tasks.empty()) {
+                std::vector<char> cells(cellBytes + 64);
+                std::vector<float> gw(nWeights + 1), freq(nColumns * kResidues + 1), eff(nColumns + 1), table;
+#pragma omp parallel for schedule(dynamic, 16)
+                for (size_t k = 0; k < tasks.size(); k++) {
+                    const Prepared &P = prep[taskQ[k] - g0];
+                    memcpy(&cells[tasks[k].cellOff], P.cells.data(), P.cells.size());
+                    memcpy(&gw[tasks[k].weightOff], P.gw.data(), P.gw.size() * sizeof(float));
+                }
+                const uint32_t rcpN = (maxRows + 1) * 20 + 8;
+                reciprocalTable(table, rcpN);
+                // launch order: the short alignments (<= 320 columns: the LDS form with two workgroups per CU) first, the deepest first inside
+                // each class (the offsets into the staging arrays travel with a task)
+                std::vector<uint32_t> ord(tasks.size());
+                for (size_t k = 0; k < ord.size(); k++) ord[k] = (uint32_t) k;
+                std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+                    const bool sx = tasks[x].L <= 320, sy = tasks[y].L <= 320;
+                    if (sx != sy) return sx;
+                    return (uint64_t) tasks[x].nRows * tasks[x].L > (uint64_t) tasks[y].nRows * tasks[y].L;
+                });
+                std::vector<R2pTaskH> launch(tasks.size());
+                uint32_t nShort = 0;
+                for (size_t k = 0; k < ord.size(); k++) {
+                    launch[k] = tasks[ord[k]];
+                    nShort += launch[k].L <= 320;
+                }
+                const int rc = sdR2pColumnWeightsDevice(ctx, (uint32_t) tasks.size(), nShort, launch.data(), cells.data(), cellBytes, cmBytes, gw.data(),
+                                                        nWeights, nColumns, scratch, table.data(), rcpN, background, freq.data(), eff.data());
+                if (rc != SD_OK) return rc;
+#pragma omp parallel
+                {
+                    ProfileScratch w;
+#pragma omp for schedule(dynamic, 8)
+                    for (size_t k = 0; k < tasks.size(); k++) {
+                        const uint32_t q = taskQ[k];
+                        const int L = (int) tasks[k].L;
+                        w.frequency.assign((size_t) (L + 2) * kResidues, 0.0f);
+                        memcpy(w.frequency.data(), &freq[tasks[k].colOff * kResidues], (size_t) L * kResidues * sizeof(float));
+                        w.effective.assign(L + 1, 0.0f);
+                        memcpy(w.effective.data(), &eff[tasks[k].colOff], (size_t) L * sizeof(float));
+                        w.pseudo.assign((size_t) (L + 1) * kResidues, 0.0f);
+                        w.mixed.assign((size_t) (L + 1) * kResidues, 0.0f);
+                        w.score.assign((size_t) (L + 1) * kResidues, 0);
+                        w.consensus.assign(L + 1, 0);
+                        finishProfile(r, par, background, qLetters + qOff[q], L, qOff[q], w, outProfiles, outConsensus);
+                    }
+                }
+            }
+            g0 = g1;
+        }
+        return SD_OK;
+    }
 #pragma omp parallel
     {
         Alignment A;
@@ -711,89 +979,8 @@ int sd_r2p_batch(sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t
                 globalFrequencies(background, w.frequency.data(), w.globalWeight.data(), nRows, L, row);
                 globalEffective(w.frequency.data(), w.globalWeight.data(), w.effective.data(), L, nRows, row);
             }
-            // consensus: the residue most enriched over the background (PSSMCalculator.cpp:652-667)
-            for (int i = 0; i < L; i++) {
-                float best = 1E-8;
-                int which = kAny;
-                for (int a = 0; a < kResidues; a++) {
-                    const float f = w.frequency[(size_t) i * kResidues + a];
-                    if (f - background[a] > best) {
-                        best = f - background[a];
-                        which = a;
-                    }
-                }
-                w.consensus[i] = (unsigned char) which;
-            }
-            // substitution-matrix pseudo counts, mixed in with a weight that falls with the effective sequence number
-            // (PSSMCalculator.cpp:274-282,374-392)
-            if (par->pca > 0.0f) {
-                float __attribute__((aligned(32))) column[24];
-                for (int i = 0; i < L; i++) {
-                    memcpy(column, &w.frequency[(size_t) i * kResidues], kResidues * sizeof(float));
-                    for (int a = 0; a < kResidues; a++) w.pseudo[(size_t) i * kResidues + a] = dot20(r->conditional[a], column);
-                }
-                for (int i = 0; i < L; i++) {
-                    float tau = fmin(1.0, par->pca / (1.0 + w.effective[i] / par->pcb));
-                    for (int a = 0; a < kResidues; a++) {
-                        float fromPrior = tau * w.pseudo[(size_t) i * kResidues + a];
-                        float fromData = (1.0 - tau) * w.frequency[(size_t) i * kResidues + a];
-                        w.mixed[(size_t) i * kResidues + a] = fromData + fromPrior;
-                    }
-                }
-            } else {
-                for (int x = 0; x < L * kResidues; x++) w.mixed[x] = w.frequency[x];
-            }
-            // log-odds in eighth bits, rounded half away from zero through a char, clamped (PSSMCalculator.cpp:251-265)
-            for (int i = 0; i < L; i++) {
-                for (int a = 0; a < kResidues; a++) {
-                    const float p = w.mixed[(size_t) i * kResidues + a];
-                    float logOdds = flog2(p / background[a]);
-                    const float bitFactor = 8.0, scoreBias = 0.0;
-                    float v = bitFactor * logOdds + bitFactor * scoreBias;
-                    v = static_cast<char>((v < 0.0) ? v - 0.5 : v + 0.5);
-                    w.score[(size_t) i * kResidues + a] = std::max(-128.0f, std::min(v, 127.0f));
-                }
-            }
-            if (par->compBiasCorr) {
-                // every column gives up the average excess (over its background expectation) of its 40-column neighbourhood
-                // (SubstitutionMatrix.cpp:205-243)
-                w.nullScore.assign(L, 0.0f);
-                char *sc = w.score.data();
-                const int window = 40;
-                for (int i = 0; i < L; i++)
-                    for (int a = 0; a < kResidues; a++) w.nullScore[i] += background[a] * static_cast<float>(sc[i * kResidues + a]);
-                for (int i = 0; i < L; i++) {
-                    const int lo = std::max(0, i - window / 2), hi = std::min(L, i + window / 2);
-                    const int span = hi - lo;
-                    float excess[kResidues];
-                    memset(excess, 0, sizeof(excess));
-                    for (int j = lo; j < hi; j++) {
-                        if (j == i) continue;
-                        for (int a = 0; a < kResidues; a++) excess[a] += sc[j * kResidues + a] - w.nullScore[j];
-                    }
-                    for (int a = 0; a < kResidues; a++) sc[i * kResidues + a] = static_cast<int>(sc[i * kResidues + a] - excess[a] / span);
-                }
-            }
-            if (par->maskProfile) {   // tantan on the centre's letters: masked positions score -1 against everything
-                w.masked.assign(centre, centre + L);
-                sd::tantanMask(r->mask, w.masked.data(), L, par->maskProb);
-                for (int i = 0; i < L; i++)
-                    if (w.masked[i] == sd::X_CODE) memset(&w.score[(size_t) i * kResidues], -1, kResidues);
-            }
-            char *out = outProfiles + qOff[q] * 25;
-            for (int i = 0; i < L; i++) {
-                char *rec = out + (size_t) i * 25;
-                memcpy(rec, &w.score[(size_t) i * kResidues], kResidues);
-                rec[20] = (char) centre[i];
-                rec[21] = (char) w.consensus[i];
-                rec[22] = (char) effectiveCountByte(w.effective[i]);
-                rec[23] = 0;
-                rec[24] = 0;
-                if (outConsensus) outConsensus[qOff[q] + i] = w.consensus[i];
-            }
+            finishProfile(r, par, background, centre, L, qOff[q], w, outProfiles, outConsensus);
         }
     }
     return SD_OK;
 }
-
-}  // extern "C"

@@ -30,6 +30,14 @@ double nowSec() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// CPU time of the calling thread: what a stage thread itself burns (staging copies, pair lists, record building, launch
+// overhead); OpenMP workers of the host stages it calls are not in it
+double threadCpuSec() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
 // one thread executing submitted jobs in order (a stage of the pipeline)
 class StageThread {
 public:
@@ -95,7 +103,7 @@ struct BiasOut {
     std::vector<uint64_t> off;
     std::vector<int8_t> sw, dg;
     std::vector<int16_t> km;
-    double seconds = 0;
+    double seconds = 0, cpu = 0;
     int rc = SD_OK;
 };
 
@@ -106,12 +114,14 @@ struct PfOut {
     std::vector<uint64_t> stats;   // 4 per query
     std::vector<uint32_t> pairQ, pairT;
     uint64_t nPairs = 0, notComputed = 0;
-    double tPrefilter = 0, tPairs = 0;
+    double tPrefilter = 0, tPairs = 0, cpu = 0;
     int rc = SD_OK;
     std::string err;
 };
 
-enum { T_INDEX, T_UPLOAD, T_BIAS, T_PREFILTER, T_PAIRS, T_SEQSET, T_ALIGN, T_AGG_WAIT, T_AGG_BUSY, T_CLUSTERHITS, T_PF_WAIT, T_TOTAL, T_N = 16 };
+enum { T_INDEX, T_UPLOAD, T_BIAS, T_PREFILTER, T_PAIRS, T_SEQSET, T_ALIGN, T_AGG_WAIT, T_AGG_BUSY, T_CLUSTERHITS, T_PF_WAIT, T_TOTAL,
+       T_CPU_BIAS, T_CPU_PF, T_CPU_ALIGN, T_CPU_AGG_MAIN,   // thread CPU seconds of the stage threads (bias | prefilter lanes | alignment lanes | aggregation + the driving thread)
+       T_N = 16 };
 enum { S_KMERS, S_INDEX_HITS, S_DIAGONALS, S_DIAG_LEN, S_PREF_HITS, S_PAIRS, S_CELLS_FWD, S_CELLS_REV, S_CELLS_TB, S_ENTRIES, S_MASKED, S_K,
        S_KMER_THR, S_BIN, S_NOT_COMPUTED, S_N = 16 };
 
@@ -474,13 +484,17 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
 
     auto biasJob = [s, Q, profile](uint32_t c0, uint32_t c1) {
         std::unique_ptr<BiasOut> o(new BiasOut());
+        const double cpu0 = threadCpuSec();
         o->c0 = c0;
         o->c1 = c1;
         const uint32_t nq = c1 - c0;
         const uint64_t r0 = Q->offsets[c0], r1 = Q->offsets[c1];
         o->off.resize((size_t) nq + 1);
         for (uint32_t i = 0; i <= nq; i++) o->off[i] = Q->offsets[c0 + i] - r0;
-        if (profile) return o;   // no composition bias for profile queries (QueryMatcher.cpp:93-99, ssw_init :1229-1240)
+        if (profile) {   // no composition bias for profile queries (QueryMatcher.cpp:93-99, ssw_init :1229-1240)
+            o->cpu = threadCpuSec() - cpu0;
+            return o;
+        }
         const double t0 = nowSec();
         o->sw.assign(r1 - r0 + 1, 0);
         o->dg.assign(r1 - r0 + 1, 0);
@@ -492,12 +506,14 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
                 o->rc = sd_host_comp_bias(s->host, Q->residues + r0, o->off.data(), nq, s->k, o->sw.data(), o->dg.data(), o->km.data());
         }
         o->seconds = nowSec() - t0;
+        o->cpu = threadCpuSec() - cpu0;
         return o;
     };
     typedef std::future<std::unique_ptr<BiasOut> > BiasFut;
     auto pfJob = [s, Q, profile, sameDb](std::shared_ptr<BiasFut> bf, sd_ctx *pfCtx) {
         std::unique_ptr<PfOut> o(new PfOut());
         o->bias = bf->get();
+        const double cpu0 = threadCpuSec();
         BiasOut &b = *o->bias;
         if (b.rc != SD_OK) {
             o->rc = b.rc;
@@ -539,6 +555,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         o->pairT.resize(std::max<uint64_t>(o->nPairs, 1));
         if (o->nPairs) sd_host_pair_list(o->hits.data(), o->counts.data(), nq, W, o->pairQ.data(), o->pairT.data());
         o->tPairs = nowSec() - t0;
+        o->cpu = threadCpuSec() - cpu0;
         return o;
     };
     typedef std::future<std::unique_ptr<PfOut> > PfFut;
@@ -565,6 +582,9 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
 
     int status = SD_OK;
     std::future<std::pair<int, double> > pending;
+    std::unique_ptr<double> aggCpu(new double(0.0));   // thread CPU seconds of the aggregation jobs
+    double *aggCpuP = aggCpu.get();
+    const double mainCpu0 = threadCpuSec();
     bool havePending = false;
     size_t pendingChunk = 0;   // chunk whose aggregation job `pending` is
     auto waitPending = [&]() {
@@ -648,7 +668,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         uint32_t n = 0, nOut = 0;
         sd_search::AlnBuf *B = nullptr;
         uint64_t f = 0, rv = 0, tb = 0;
-        double tSeqset = 0, tAlign = 0;
+        double tSeqset = 0, tAlign = 0, cpu = 0;
     };
     const int lanes = s->alignLanes;
     std::unique_ptr<StageThread> alStage[2];
@@ -657,6 +677,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     const std::vector<int32_t> *qLenP = &qLen;
     auto alignJob = [s, Q, profile, sameDb, qLenP](std::shared_ptr<std::unique_ptr<PfOut> > dp, sd_ctx *ctx, sd_search::AlnBuf *Bp, size_t ci) {
         std::unique_ptr<AlOut> o(new AlOut());
+        const double cpu0 = threadCpuSec();
         o->d = std::move(*dp);
         o->ci = ci;
         o->B = Bp;
@@ -724,6 +745,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         }
         o->tAlign = nowSec() - t0;
         sd_sw_last_cells(ctx, &o->f, &o->rv, &o->tb);
+        o->cpu = threadCpuSec() - cpu0;
         return o;
     };
     typedef std::future<std::unique_ptr<AlOut> > AlFut;
@@ -739,6 +761,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         const size_t ci = a->ci;
         const uint32_t r = chunks[ci].range;
         const uint32_t c0 = a->d->bias->c0, nq = a->d->bias->c1 - c0;
+        tm[T_CPU_ALIGN] += a->cpu;
         if (a->n > 0) {
             tm[T_SEQSET] += a->tSeqset;
             tm[T_ALIGN] += a->tAlign;
@@ -754,8 +777,13 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             sd_search *sp = s;
             const uint32_t nOut = a->nOut;
             pendingChunk = ci;
-            pending = aggStage.submit([agg, bp, nOut, c0, nq, sp]() {
+            pending = aggStage.submit([agg, bp, nOut, c0, nq, sp, aggCpuP]() {
                 const double t1 = nowSec();
+                const double cpu1 = threadCpuSec();
+                struct AddCpu {   // the aggregation jobs run one at a time: a plain accumulator
+                    double *acc, c0;
+                    ~AddCpu() { *acc += threadCpuSec() - c0; }
+                } addCpu{aggCpuP, cpu1};
                 if (sp->alnSink)
                     sp->alnSink(sp->sinkUser, c0, nq, nOut, bp->pq.data(), bp->pt.data(), bp->res.data(), bp->ident.data(), bp->pool.data());
                 const int rc2 = agg ? sd_agg_add(agg, nOut, c0, bp->pq.data(), bp->pt.data(), bp->res.data(), bp->ident.data(), bp->pool.data())
@@ -806,6 +834,8 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             break;
         }
         tm[T_BIAS] += d->bias->seconds;
+        tm[T_CPU_BIAS] += d->bias->cpu;
+        tm[T_CPU_PF] += d->cpu;
         tm[T_PREFILTER] += d->tPrefilter;
         tm[T_PAIRS] += d->tPairs;
         const uint32_t c0 = d->bias->c0, c1 = d->bias->c1, nq = c1 - c0;
@@ -852,6 +882,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         for (uint32_t r = 0; r < nRanges && status == SD_OK; r++)
             if (!finalized[r]) status = finalize(r);
     tm[T_TOTAL] = nowSec() - tAll;
+    tm[T_CPU_AGG_MAIN] += *aggCpu + (threadCpuSec() - mainCpu0);
     if (status != SD_OK) return status;
     for (uint32_t r = 0; r < nRanges; r++) {
         res[r]->counts[6] = prefHitsOfRange[r];

@@ -77,7 +77,9 @@ class _BorrowedContext(api.Context):
 _STAT_NAMES = ('kmers', 'index_hits', 'diagonals', 'diag_len', 'prefilter_hits', 'pairs', 'cells_fwd', 'cells_rev', 'cells_tb',
                'index_entries', 'masked_residues', 'k', 'kmer_thr', 'bin_size')
 _TIME_NAMES = ('index_build_s', 'upload_s', 'bias', 'prefilter', 'pairs', 'seqset', 'align', 'aggregate', 'aggregate_busy',
-               'clusterhits', 'prefilter_wait', 'total')
+               'clusterhits', 'prefilter_wait', 'total',
+               # thread CPU seconds of the stage threads themselves (OpenMP workers of the host stages are not in them)
+               'cpu_bias_thread', 'cpu_prefilter_lanes', 'cpu_align_lanes', 'cpu_aggregate_and_driver')
 
 
 def _setdb_struct(db, keep):

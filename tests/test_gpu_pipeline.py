@@ -150,8 +150,11 @@ def test_synthetic_proteomes_match_real_reference(gpu, host):
 
 def test_clusterhits_on_pipeline_entries_matches_oracle(gpu, host, oracle):
     """the (query set, target set) entries a real search produces on whole synthetic proteomes (K of a few thousand hits,
-    long syntenic blocks, inversions): device clusterhits against the oracle's dense restatement, entry by entry"""
-    from oracle.pyoracle import oracle_clusterhits
+    long syntenic blocks, inversions): device clusterhits, entry by entry, against the reference's own functions
+    (oracle/_ref/libsdref_ch.so: partition, sizes, P-value bit patterns, member ranks) where that library travelled, and
+    against the oracle's dense restatement"""
+    from oracle.pyoracle import oracle_clusterhits, ref_ch_available, RefClusterHits
+    ref = RefClusterHits() if ref_ch_available() else None
     from spacedust_amd.synth import make_proteomes
     ps = make_proteomes(3, genes_per_proteome=3000, seed=0x5ED0 + 2)
     db = SetDB.from_proteomes(ps)
@@ -170,6 +173,13 @@ def test_clusterhits_on_pipeline_entries_matches_oracle(gpu, host, oracle):
         assert int(co['n_clusters'][e]) == n, (e, co['n_clusters'][e], n)
         assert (co['cluster_of'][a:b] == cof).all(), e
         assert (co['size'][a:a + n] == csz).all() and (co['pCO'][a:a + n] == pco).all() and (co['pMH'][a:a + n] == pmh).all(), e
+        if ref is not None:
+            rcof, rrank, rcs, rpco, rpmh = ref.entry(db.pos_in_set[hq], db.pos_in_set[ht], sd, out['hit_pval'][a:b],
+                                                     int(db.set_size[out['entry_q'][e]]))
+            assert len(rcs) == n and (co['cluster_of'][a:b] == rcof).all() and (co['size'][a:a + n] == rcs).all(), e
+            assert co['pCO'][a:a + n].tobytes() == rpco.tobytes() and co['pMH'][a:a + n].tobytes() == rpmh.tobytes(), e
+            clustered = rcof != 0xFFFFFFFF
+            assert (co['rank'][a:b][clustered] == rrank[clustered]).all(), e
 
 
 def test_multi_set_aggregation_matches_restatement(gpu, host, oracle, small_proteomes):

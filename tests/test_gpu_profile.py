@@ -218,3 +218,67 @@ def test_pipeline_with_profile_queries(gpu, host, oracle, small_proteomes):
     assert cs.stats['prefilter_hits'] == n_hits, (cs.stats['prefilter_hits'], n_hits)
     assert out['accepted'] == n_acc, (out['accepted'], n_acc)
     assert n_acc > ps.n
+
+
+def test_result2profile_sequence_weights_on_the_device(gpu):
+    """sd_r2p_batch_device (csrc/hip/sd_r2p.hip: the position-specific sequence weights of PSSMCalculator on the GPU, everything
+    in the reference's summation order) gives the bytes of the host implementation for all 5 898 regression queries -- and, where
+    the library travelled, of the reference's own MultipleAlignment / MsaFilter / PSSMCalculator classes run on this box
+    (oracle/_ref/libsdref_r2p.so: the approximate reciprocal differs between CPU models, so the comparison is made where the
+    bytes are produced) -- plus the parameter corners and alignments that are deeper than the regression input's"""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_result2profile import _load, _edges
+    from oracle.pyoracle import ref_r2p_available, RefResult2Profile
+    api_, seqs, res, off, aln = _load()
+    queries = list(range(len(seqs)))
+    edge_off, et, eq, ets, bts = _edges(api_, aln, queries)
+    qoff = np.zeros(len(queries) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(seqs[q]) for q in queries])
+    host_bytes = api_.result2profile(res, qoff, edge_off, et, eq, ets, bts, res, off)
+    dev_bytes = api_.result2profile(res, qoff, edge_off, et, eq, ets, bts, res, off, ctx=gpu)
+    bad = [x for x in range(len(queries)) if host_bytes[int(qoff[x]) * 25:int(qoff[x + 1]) * 25] != dev_bytes[int(qoff[x]) * 25:int(qoff[x + 1]) * 25]]
+    assert bad == [], (len(bad), bad[:10])
+    if ref_r2p_available():
+        ref = RefResult2Profile()
+        nbad = 0
+        for x in range(0, len(queries), 7):
+            a, b = edge_off[x], edge_off[x + 1]
+            nbad += ref.profile(seqs[x], [seqs[t] for t in et[a:b]], eq[a:b], ets[a:b], bts[a:b]) != dev_bytes[int(qoff[x]) * 25:int(qoff[x + 1]) * 25]
+        assert nbad == 0
+    sample = [q for q in queries if edge_off[q + 1] - edge_off[q] >= 2][:60]
+    for kw in (dict(filter_msa=0), dict(comp_bias=0, mask_profile=0), dict(max_seq_id=0.5, ndiff=3), dict(qid='0.0,0.3,0.6', cov=0.5), dict(wg=1)):
+        for q in sample:
+            a, b = edge_off[q], edge_off[q + 1]
+            args = (res[int(off[q]):int(off[q + 1])], [0, len(seqs[q])], [0, b - a], et[a:b], eq[a:b], ets[a:b], bts[a:b], res, off)
+            assert api_.result2profile(*args, **kw) == api_.result2profile(*args, ctx=gpu, **kw), (kw, q)
+    # a deep alignment: one centre against 1 500 mutated copies with indels (rows start and end at many different columns)
+    rng = np.random.default_rng(77)
+    aa = 'ACDEFGHIKLMNPQRSTVWY'
+    base = ''.join(rng.choice(list(aa), 700))
+    fam = [base]
+    for _ in range(1500):
+        lo = int(rng.integers(0, 200))
+        hi = int(rng.integers(500, 700))
+        sq = list(base[lo:hi])
+        for p_ in np.nonzero(rng.random(len(sq)) < rng.uniform(0.05, 0.4))[0]:
+            sq[p_] = aa[rng.integers(20)]
+        for _d in range(int(rng.integers(0, 4))):
+            p_ = int(rng.integers(10, len(sq) - 10))
+            del sq[p_:p_ + int(rng.integers(1, 6))]
+        fam.append(''.join(sq))
+    host = api_.Host()
+    fres, foff = host.map_sequences(fam)
+    sw_b, _, _ = host.comp_bias(fres, foff)
+    ss = gpu.seqset(fres, foff, sw_b)
+    par = gpu.sw_params(host.matrix(0)[0], int(foff[-1]))
+    pq = np.zeros(1500, np.uint32)
+    pt = np.arange(1, 1501, dtype=np.uint32)
+    out, pool = gpu.sw_align(par, ss, ss, pq, pt)
+    keep = [i for i in range(1500) if int(out[i]['btLen']) > 0]   # (fragments below the query coverage gate have no backtrace)
+    assert len(keep) > 300
+    bts2 = [pool[int(out[i]['btOffset']):int(out[i]['btOffset']) + int(out[i]['btLen'])].tobytes().decode() for i in keep]
+    args = (fres[:int(foff[1])], [0, int(foff[1])], [0, len(keep)], [int(pt[i]) for i in keep], [int(out[i]['qStart']) for i in keep],
+            [int(out[i]['tStart']) for i in keep], bts2, fres, foff)
+    for kw in (dict(), dict(filter_msa=0)):
+        assert api_.result2profile(*args, **kw) == api_.result2profile(*args, ctx=gpu, **kw), kw

@@ -34,6 +34,53 @@ def test_config3_size_prefilter_and_alignments_match_real_reference(gpu, host):
     assert r['alignments'] >= 1000 and r['alignment_mismatch'] == 0, lines
 
 
+def test_config2_size_prefilter_and_alignments_match_real_reference(gpu, host):
+    """BASELINE configs[1] at its exact size (100 proteomes, 3 * 10^5 targets, --max-seqs 300, the index built on the device): the
+    bench's headline workload, sampled against the real reference classes"""
+    from oracle.pyoracle import ref_available
+    if not ref_available():
+        pytest.skip('oracle/_ref/libsdref.so not present on this box')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import scale_parity
+    lines = []
+    r = scale_parity.run(100, gpu=gpu, host=host, device_index=True, log=lambda *a: lines.append(' '.join(str(x) for x in a)))
+    assert r['targets'] == 300000 and r['max_hits'] == 300 and r['not_computed'] == 0
+    assert r['prefilter_queries'] == 132 and r['prefilter_rows'] > 10000
+    assert r['prefilter_mismatch'] == 0, lines
+    assert r['alignments'] >= 1000 and r['alignment_mismatch'] == 0, lines
+
+
+def test_config5_size_search_with_max_seqs_2N_matches_real_reference(gpu, host):
+    """BASELINE configs[4] as SURVEY 8(d) writes it: the 10 000-proteome target (3 * 10^7 sequences, 9 * 10^9 residues, k = 7, wide
+    index of 8.7 * 10^9 entries built ON THE DEVICE and resident in HBM), --max-seqs 2N = 20 000 -- result lists beyond the LDS
+    sorter (select_hits_big_kernel), wide stream positions, the coarse split, the hit-buffer overflow of the longest queries.
+    Device prefilter rows of the 4 longest + 40 random queries and 300 alignments (coordinates, backtraces, E-values) against the
+    real reference classes run on this box's host cores (its own index of the same target: ~3 min on 16 threads)."""
+    import time
+    from oracle.pyoracle import ref_available
+    if not ref_available():
+        pytest.skip('oracle/_ref/libsdref.so not present on this box')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import scale_parity
+    lines = []
+    t0 = time.time()
+    r = scale_parity.run(10000, n_longest=4, n_random=40, aln_queries=10, aln_hits=30, gpu=gpu, host=host, device_index=True,
+                         log=lambda *a: lines.append(' '.join(str(x) for x in a)))
+    out = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'scale_parity_p10000.json'), 'w') as f:
+            json.dump(dict(r, log=lines, seconds=time.time() - t0), f, indent=1)
+    except OSError:
+        pass
+    assert r['targets'] == 30000000 and r['k'] == 7 and r['max_hits'] == 20000 and r['index'] == 'device'
+    assert r['index_entries'] > (1 << 32)
+    assert r['not_computed'] == 0 and r['prefilter_queries'] == 44
+    assert r['max_index_hits'] >= (1 << 24)           # wide stream positions ran
+    assert r['prefilter_mismatch'] == 0, lines
+    assert r['alignments'] >= 250 and r['alignment_mismatch'] == 0, lines
+
+
 def test_index_of_more_than_2_32_entries(gpu, host, monkeypatch):
     """the wide index with entry arrays of more than 2^32 elements (what 10 000 proteomes produce): a small index whose
     entries sit behind 2^32 + 5*10^7 padding slots -- every list start has a non-zero high half, the upload and the

@@ -90,7 +90,8 @@ def test_modules_result2profile_subtractdbs_mergedbs(tmp_path):
     lines = flat_lines_from_gz('config1_aln.tsv.gz')
     write_db(str(tmp_path / 'aln'), entries_by_first_column(lines, 5898), 5, splits=3)
     sdgpu('result2profile', g, g, tmp_path / 'aln', tmp_path / 'profile_0', '-e', '0.001', '--e-profile', '0.001', '--pca',
-          'substitution:1.100,context:1.400', '--pcb', 'substitution:4.100,context:5.800', '--threads', '4', '-v', '0')
+          'substitution:1.100,context:1.400', '--pcb', 'substitution:4.100,context:5.800', '--threads', '4', '-v', '0',
+          '--profile-weights-host', '1')   # (no GPU on this side of the suite: the host implementation, asked for explicitly)
     prof = read_db(str(tmp_path / 'profile_0'))
     assert open(tmp_path / 'profile_0.dbtype', 'rb').read() == b'\x02\x00\x00\x00' and len(prof) == 5898
     assert os.path.islink(tmp_path / 'profile_0.lookup') and os.path.islink(tmp_path / 'profile_0_h')

@@ -37,12 +37,15 @@ def main(fetch_csv, write_csv):
         print('%-72s %7d %14.3f %14.3f %16.0f' % (k, n, fb / 1e9, wb / 1e9, tot / max(n, 1)))
 
 
-GROUPS = [('sdpk::sw_score_pk_kernel', 'sw_score_pk'), ('sw_score_kernel', 'sw_score'), ('sw_traceback', 'sw_traceback'),
+# first match wins: the oversize-bucket launch of bucket_match is its own group (bench.py times it as prefilter_bucket_match_big)
+GROUPS = [('sdpk::sw_score_pk', 'sw_score_pk'), ('sw_score_kernel', 'sw_score'), ('sw_traceback', 'sw_traceback'),
           ('emit_kmers', 'prefilter_emit_kmers'), ('count_kmers', 'prefilter_count_kmers'), ('gather_hits', 'prefilter_gather_hits'),
           ('kp_hist', 'prefilter_kmer_partition'), ('kp_scatter', 'prefilter_kmer_partition'), ('join_count', 'prefilter_join_count'),
-          ('join_scatter', 'prefilter_join_scatter'),
-          ('partition_hits', 'prefilter_partition_hits'), ('bucket_match', 'prefilter_bucket_match'),
-          ('score_diag', 'prefilter_score_diag'), ('select_hits', 'prefilter_select_hits'), ('clusterhits', 'clusterhits')]
+          ('join_scatter', 'prefilter_join_scatter'), ('hot_filter', 'prefilter_hot_filter'), ('segment_match', 'prefilter_segment_match'),
+          ('partition_hits', 'prefilter_partition_hits'), ('bucket_match_kernel<256', 'prefilter_bucket_match_big'),
+          ('bucket_match', 'prefilter_bucket_match'), ('coarse_', 'prefilter_coarse_split'),
+          ('score_diag', 'prefilter_score_diag'), ('select_hits_big', 'prefilter_select_hits_big'), ('select_hits', 'prefilter_select_hits'),
+          ('clusterhits', 'clusterhits')]
 
 
 def to_json(fetch_csv, write_csv, out_path):
@@ -55,7 +58,7 @@ def to_json(fetch_csv, write_csv, out_path):
         if g is None:
             continue
         o = out.setdefault(g, dict(launches=0, fetch=0.0, write=0.0))
-        if 'kp_hist' not in k:   # bench.py times kp_hist + kp_scatter as one launch of the k-mer partition
+        if not any(x in k for x in ('kp_hist', 'coarse_count', 'coarse_offsets')):   # bench.py times kp_hist + kp_scatter (coarse count + offsets + scatter) as one launch
             o['launches'] += max(f.get(k, [0, 0])[0], w.get(k, [0, 0])[0])
         o['fetch'] += 2.0 * f.get(k, [0, 0.0])[1] * 1024
         o['write'] += w.get(k, [0, 0.0])[1] * 1024

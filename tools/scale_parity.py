@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=print, gpu=None, host=None, k=None, sensitivity=5.7,
-        max_hits=None):
+        max_hits=None, device_index=False):
     """returns dict(prefilter_queries, prefilter_rows, prefilter_mismatch, alignments, alignment_mismatch, bin_size,
     max_index_hits, k, not_computed).  k: None = the reference's rule (7 from 3.35e9 target residues on,
     M/src/prefiltering/Prefiltering.cpp setKmerSize / IndexTable.h:439-449), else forced."""
@@ -44,11 +44,16 @@ def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=pri
     log('k', k, 'k-mer threshold', kmer_thr, 'target residues', int(ps.offsets[-1]))
     sw_b, dg_b, km_b = host.comp_bias(qres, qoff, k=k)
     t0 = time.time()
-    idx = host.build_index(ps.residues, ps.offsets, k=k, kmer_thr=kmer_thr)
-    log('index', round(time.time() - t0, 1), 'entries', idx.n_entries)
-    tgt = api.Target(gpu, host, idx)
+    if device_index:   # the index the searches use: built on the GPU (sd_target_build) -- the host builder needs ten minutes at 10 000 proteomes
+        tgt = api.Target.build_on_device(gpu, host, ps.residues, ps.offsets, k=k, kmer_thr=kmer_thr)
+        n_entries = int(tgt.build_stats['entries'])
+    else:
+        idx = host.build_index(ps.residues, ps.offsets, k=k, kmer_thr=kmer_thr)
+        tgt = api.Target(gpu, host, idx)
+        n_entries = int(idx.n_entries)
+    log('index', 'device' if device_index else 'host', round(time.time() - t0, 1), 'entries', n_entries)
     max_hits = max_hits or max(300, 2 * P)   # default: --max-seqs 2P, every target set can be reached
-    par = api.prefilter_params(host, idx.n, kmer_thr=kmer_thr, max_hits=max_hits, cov_thr=0.0, bin_size=None, k=k)
+    par = api.prefilter_params(host, ps.n, kmer_thr=kmer_thr, max_hits=max_hits, cov_thr=0.0, bin_size=None, k=k)
     log('bin size', par.binSize)
     hits, cnt, st = api.prefilter(gpu, tgt, par, qres, qoff, km_b, dg_b, queries.astype(np.uint32), want_stats=True)
     not_computed = cnt == 0xFFFFFFFF   # per-query error slots (double overflow of the reference's hit buffer / >= 2^24 index hits)
@@ -110,7 +115,7 @@ def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=pri
         if not same:
             badsw += 1
     log('alignments compared', len(pq), 'mismatching', badsw)
-    return dict(proteomes=P, targets=int(ps.n), k=k, kmer_thr=int(kmer_thr), target_residues=int(ps.offsets[-1]), index_entries=int(idx.n_entries),
+    return dict(proteomes=P, targets=int(ps.n), k=k, kmer_thr=int(kmer_thr), target_residues=int(ps.offsets[-1]), index_entries=n_entries, max_hits=int(max_hits), index='device' if device_index else 'host',
                 not_computed=int(not_computed.sum()), prefilter_queries=int((~not_computed).sum()), prefilter_rows=int(cnt.sum()),
                 prefilter_mismatch=bad, alignments=len(pq), alignment_mismatch=badsw, bin_size=int(par.binSize),
                 max_index_hits=int(st[:, 1].max()))

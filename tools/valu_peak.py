@@ -55,7 +55,7 @@ def pmc(csv_path, bench_json, out_path):
     inst = 0.0
     n = 0
     for r in csv.DictReader(open(csv_path)):
-        if r.get('Counter_Name') == 'SQ_INSTS_VALU' and ('sw_score_pk_kernel' in r['Kernel_Name'] or 'sw_score_kernel' in r['Kernel_Name']):
+        if r.get('Counter_Name') == 'SQ_INSTS_VALU' and ('sw_score_pk' in r['Kernel_Name'] or 'sw_score_kernel' in r['Kernel_Name']):
             inst += float(r['Counter_Value'])
             n += 1
     line = [x for x in open(bench_json).read().splitlines() if x.startswith('{')][-1]
