@@ -200,8 +200,8 @@ void sd_target_destroy(sd_target *t);
  *   identityId[q]: index of the query in the target DB or UINT32_MAX
  * outHits: nQ * maxHitsPerQuery slots (row q at q*maxHitsPerQuery), outCount[nQ].
  * outCount[q] == UINT32_MAX marks a query that was NOT computed: it needs a reference route the device lacks (a second
- * overflow of the hit buffer, QueryMatcher.cpp:289-303, >= 2^32 index hits, or a result list beyond 4 095 hits with more than
- * 8 192 candidates at the score cut); its row is empty, the other queries of the
+ * overflow of the hit buffer beyond 32 parts, QueryMatcher.cpp:289-303, or >= 2^32 index hits; result lists have no length
+ * limit); its row is empty, the other queries of the
  * call are computed normally and sd_last_error() names the count.  Callers must treat such rows as errors, not as "no hits".
  * stats (nullable, 4*nQ u64): #similar k-mers, #index entries, #diagonals scored, sum of diagonal lengths. */
 int sd_prefilter_batch(sd_ctx *ctx, const sd_target *target, const sd_prefilter_params *par, uint32_t nQ,

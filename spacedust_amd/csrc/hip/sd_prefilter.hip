@@ -15,8 +15,10 @@
 //   K7 select_hits   (9-11) per query: score histogram, cut at maxHits, order of the cut = (score desc,
 //                           bin = seqId & (BINSIZE-1), stream position), final (score desc, seqId) order,
 //                           coverage pre-filter (Prefiltering.cpp:856-863)
-// The reference's overflow path (> 2*max(1e6,dbSize) hits per query) and the rescoring path
-// (threshold >= 255) are detected and reported as SD_EUNSUPPORTED -- never silently approximated.
+// Between the hit stream and the match sits the hot-target filter (hot_filter_kernel): hits of targets that cannot emit a
+// candidate are dropped after one look.  The reference's overflow path (> 2*max(1e6,dbSize) hits per query), the rescoring
+// path (threshold >= 255) and result lists of any length (select_hits_big_kernel) are computed; what the device does not
+// compute is reported per query (outCount = UINT32_MAX) -- never silently approximated.
 #include <memory>
 #include "sd_common.h"
 
