@@ -44,6 +44,9 @@ const char *sd_last_error(sd_ctx *ctx);
 int sd_device_name(sd_ctx *ctx, char *buf, size_t cap);
 /* free / total device memory right now (hipMemGetInfo) */
 int sd_device_memory(sd_ctx *ctx, uint64_t *freeBytes, uint64_t *totalBytes);
+/* A number that identifies the physical GPU behind a device ordinal across processes and nodes (hash of the host name and the
+ * PCI bus id): ranks compare it to learn whether they share a device (RCCL refuses two ranks per GPU). */
+int sd_device_identity(int device, uint64_t *id);
 /* The context's persistent workspaces (device buffers that live from call to call, and pinned host staging): their total
  * sizes and, if buf is not NULL, a text table "key bytes\n" of the device ones, largest first (cut at cap - 1 characters). */
 int sd_workspace_report(sd_ctx *ctx, uint64_t *deviceBytes, uint64_t *pinnedBytes, char *buf, size_t cap);
@@ -350,6 +353,10 @@ int sd_agg_write_tsv_from(sd_agg *a, const char *path, int append, uint64_t firs
  * tLen, u32 cigarLen, the cigar bytes padded to a multiple of 4.  out == NULL: *bytes = size needed. */
 int sd_agg_records(sd_agg *a, const uint32_t *clusterOfHit, const uint32_t *rankInCluster, const uint32_t *nClusters,
                    const double *pCO, const double *pMH, const uint32_t *clusterSize, void *out, uint64_t cap, uint64_t *bytes);
+/* Validates a record buffer that was gathered from other ranks before it is written: whole records only, every set / sequence
+ * index inside [0, nQSets) / [0, nTSets) / [0, nQ) / [0, nT) -- SD_EINVAL otherwise; counts of clusters and members (nullable). */
+int sd_records_check(const void *records, uint64_t bytes, uint32_t nQSets, uint32_t nTSets, uint32_t nQ, uint32_t nT, uint64_t *nClusters,
+                     uint64_t *nMembers);
 /* the TSV of cluster records -- of one result or of several ranks' records concatenated: clusters numbered from firstClusterKey */
 int sd_records_write_tsv(const void *records, uint64_t bytes, const char *path, int append, uint64_t firstClusterKey,
                          const char *qNames, const uint64_t *qNameOff, const char *tNames, const uint64_t *tNameOff,
@@ -530,8 +537,9 @@ const char *sd_comm_last_error(sd_comm *c);
 /* gatherv of byte records over RCCL: sizes[nRanks] receives every rank's byte count (on all ranks); on `root`, outOnRoot
  * (capacity outCap) receives the records concatenated in rank order and *outBytes their total.  The ranks agree on the
  * outcome of their local staging before any payload moves: when outCap is too small on the root, EVERY rank returns
- * SD_ENOMEM (*outBytes = the size needed; call again with room -- the size probe), when a rank cannot stage its records
- * every rank returns an error; no rank is left waiting in a send or receive. */
+ * SD_ENOMEM (*outBytes = the size needed; call again with room -- the size probe, and the ONLY meaning of SD_ENOMEM here), when a
+ * rank cannot stage its records (device allocation, copy) EVERY rank returns SD_EHIP; no rank is left waiting in a send or
+ * receive, and no rank repeats the collective alone. */
 int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, uint64_t *sizes, void *outOnRoot, uint64_t outCap,
                       uint64_t *outBytes);
 /* Host-side rendezvous of the ranks over TCP (addr / port as a one-process-per-GPU launcher's MASTER_ADDR / MASTER_PORT; every

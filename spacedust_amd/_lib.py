@@ -148,6 +148,7 @@ def load():
         'sd_target_sample_check': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                              C.c_uint64, C.c_uint64, _vp]),
         'sd_device_memory': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        'sd_device_identity': (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
         'sd_workspace_report': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
         'sd_workspace_release': (C.c_int, [_vp]),
         'sd_prefilter_batch': (C.c_int, [_vp, _vp, C.POINTER(PrefilterParams), C.c_uint32, _vp, _vp, _vp, _vp, _vp,
@@ -200,6 +201,7 @@ def load():
                                                  C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_search_result_records': (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
         'sd_agg_records': (C.c_int, [_vp] * 7 + [_vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+        'sd_records_check': (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_records_write_tsv': (C.c_int, [_vp, C.c_uint64, C.c_char_p, C.c_int, C.c_uint64, C.c_char_p, _vp, C.c_char_p, _vp, C.c_char_p, _vp,
                                            C.c_char_p, _vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_search_result_destroy': (None, [_vp]),

@@ -446,8 +446,11 @@ int runSearch(const Args &a, bool withClusters) {
         // gathered buffer.  The ranks meet over TCP at MASTER_ADDR:MASTER_PORT+1 (the RCCL unique id travels that way); ranks
         // that share a device -- RCCL refuses that, a one-GPU test rig -- hand their records over the same socket path instead.
         std::vector<uint64_t> sizes((size_t) world, 0);
-        // device of every rank -> does each rank have a GPU of its own?
-        int32_t devs[2] = {device, 0};
+        // the physical GPU of every rank (host name + PCI bus id, not the local ordinal: ranks on different nodes, or ranks that
+        // each see their GPU as device 0 through HIP_VISIBLE_DEVICES, are not sharing) -> does each rank have a GPU of its own?
+        uint64_t gpuId = 0;
+        if (sd_device_identity(device, &gpuId) != SD_OK) return fail("sd_device_identity failed");
+        int32_t devs[2] = {(int32_t) (uint32_t) gpuId, (int32_t) (uint32_t) (gpuId >> 32)};
         std::vector<int32_t> allDevs((size_t) world * 2, 0);
         uint64_t got = 0;
         if (sd_tcp_gather(tcp, devs, sizeof(devs), nullptr, allDevs.data(), allDevs.size() * sizeof(int32_t), &got) != SD_OK)
@@ -456,7 +459,7 @@ int runSearch(const Args &a, bool withClusters) {
         if (rank == 0)
             for (int x = 0; x < world; x++)
                 for (int y = 0; y < x; y++)
-                    if (allDevs[(size_t) x * 2] == allDevs[(size_t) y * 2]) shared = 1;
+                    if (allDevs[(size_t) x * 2] == allDevs[(size_t) y * 2] && allDevs[(size_t) x * 2 + 1] == allDevs[(size_t) y * 2 + 1]) shared = 1;
         if (sd_tcp_bcast(tcp, &shared, sizeof(shared)) != SD_OK) return fail("rendezvous of the ranks failed");
         uint64_t total = 0;
         if (!shared) {
@@ -493,6 +496,10 @@ int runSearch(const Args &a, bool withClusters) {
     }
     uint64_t nClu = 0, nHit = 0;
     if (rank == 0) {
+        // (gathered records came over the wire: indices are checked against the tables they will index)
+        rc = sd_records_check(toWrite->data(), toWrite->size(), (uint32_t) (qso.size() - 1), (uint32_t) (tso.size() - 1), (uint32_t) (qno.size() - 1),
+                              (uint32_t) (tno.size() - 1), nullptr, nullptr);
+        if (rc != SD_OK) return fail("the gathered cluster records are truncated or index outside the name tables");
         rc = sd_records_write_tsv(toWrite->data(), toWrite->size(), a.pos[2].c_str(), 0, 0, qn.data(), qno.data(), tn.data(), tno.data(),
                                   qsrc.data(), qso.data(), tsrc.data(), tso.data(), 0, &nClu, &nHit);
         if (rc != SD_OK) return fail("sd_records_write_tsv failed (" + std::to_string(rc) + ")");

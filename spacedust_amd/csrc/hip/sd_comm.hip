@@ -192,10 +192,15 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
         if (hipMemcpyAsync(all.data(), dSizes, sizeof(uint64_t) * c->nRanks, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = SD_EHIP; break; }
         if (hipStreamSynchronize(c->stream) != hipSuccess) { status = SD_EHIP; break; }
         int firstBad = -1;
-        for (int r = 0; r < c->nRanks && firstBad < 0; r++)
-            if (all[r]) firstBad = r;
+        bool realFailure = false;   // some rank could not stage its records (as opposed to the root's capacity probe)
+        for (int r = 0; r < c->nRanks; r++) {
+            if (all[r] && firstBad < 0) firstBad = r;
+            if (all[r] == 1) realFailure = true;
+        }
         if (firstBad >= 0) {   // nobody exchanges anything
-            status = localStatus != SD_OK ? localStatus : (all[firstBad] == 2 ? SD_ENOMEM : SD_EHIP);
+            // every rank returns the SAME code: SD_ENOMEM only for the capacity probe (callers repeat the collective with a larger
+            // buffer -- all of them or none), SD_EHIP when a rank's own staging failed
+            status = realFailure ? SD_EHIP : SD_ENOMEM;
             c->err = "sd_gather_results: rank " + std::to_string(firstBad) +
                      (firstBad == root ? " (root) could not take the gathered records (output capacity or device memory)"
                                        : " could not stage its records");

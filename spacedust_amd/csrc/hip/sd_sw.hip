@@ -16,6 +16,7 @@
 // residue.  HBM traffic is the two residue streams (algorithmic bytes qLen + tLen per task), so the
 // kernel is VALU bound; bench.py reports it in GCUPS.
 #include "sd_common.h"
+#include <unistd.h>
 
 #include <hipcub/hipcub.hpp>
 
@@ -1518,6 +1519,20 @@ int sd_workspace_release(sd_ctx *ctx) {
         if (kv.second.p) (void) hipFree(kv.second.p);
     ctx->ws.clear();
     ctx->biasTablesUploaded = false;
+    return SD_OK;
+}
+
+// identity of a physical GPU across processes and nodes: FNV-1a of the host name and the device's PCI bus id
+int sd_device_identity(int device, uint64_t *id) {
+    if (!id) return SD_EINVAL;
+    char host[256] = {0}, bus[64] = {0};
+    (void) gethostname(host, sizeof(host) - 1);
+    if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) return SD_ENODEVICE;
+    uint64_t h = 1469598103934665603ull;
+    for (const char *p = host; *p; p++) h = (h ^ (uint8_t) *p) * 1099511628211ull;
+    h = (h ^ 0xFFu) * 1099511628211ull;
+    for (const char *p = bus; *p; p++) h = (h ^ (uint8_t) *p) * 1099511628211ull;
+    *id = h;
     return SD_OK;
 }
 

@@ -387,6 +387,36 @@ int sd_agg_records(sd_agg *a, const uint32_t *clusterOfHit, const uint32_t *rank
     return (o && w > cap) ? SD_ENOMEM : SD_OK;
 }
 
+// A record buffer that came over the wire (RCCL / TCP gather) is checked before anything indexes with it: whole records, set and
+// sequence indices inside the name / source tables the writer will use.
+int sd_records_check(const void *records, uint64_t bytes, uint32_t nQSets, uint32_t nTSets, uint32_t nQ, uint32_t nT, uint64_t *nClusters,
+                     uint64_t *nMembers) {
+    if (bytes && !records) return SD_EINVAL;
+    const char *p = (const char *) records, *endP = p + bytes;
+    uint64_t nc = 0, nm = 0;
+    while (p < endP) {
+        RecCluster rc;
+        if ((uint64_t) (endP - p) < sizeof(rc)) return SD_EINVAL;
+        memcpy(&rc, p, sizeof(rc));
+        p += sizeof(rc);
+        if (rc.qSet >= nQSets || rc.tSet >= nTSets) return SD_EINVAL;
+        nc++;
+        for (uint32_t m = 0; m < rc.members; m++) {
+            RecMember rm;
+            if ((uint64_t) (endP - p) < sizeof(rm)) return SD_EINVAL;
+            memcpy(&rm, p, sizeof(rm));
+            p += sizeof(rm);
+            const uint64_t padded = ((uint64_t) rm.cigarLen + 3u) & ~3ull;
+            if (rm.q >= nQ || rm.t >= nT || (uint64_t) (endP - p) < padded) return SD_EINVAL;
+            p += padded;
+            nm++;
+        }
+    }
+    if (nClusters) *nClusters = nc;
+    if (nMembers) *nMembers = nm;
+    return SD_OK;
+}
+
 // summarizeresults (R/src/util/SummarizeResults.cpp:77-112) from cluster records: '#key source source pCO pMH size' per
 // cluster, '>query target pval seqId eval coordinates cigar' per member; canonical: without the '#key' / '>query' columns
 int sd_records_write_tsv(const void *records, uint64_t bytes, const char *path, int append, uint64_t firstClusterKey,
@@ -419,7 +449,7 @@ int sd_records_write_tsv(const void *records, uint64_t bytes, const char *path, 
             const uint64_t padded = (rm.cigarLen + 3u) & ~3u;
             if ((uint64_t) (endP - p) < padded) { status = SD_EINVAL; break; }
             if (!canonical) fprintf(f, ">%.*s\t", (int) (qNameOff[rm.q + 1] - qNameOff[rm.q]), qNames + qNameOff[rm.q]);
-            fprintf(f, "%.*s\t%s\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%.*s\n", (int) (tNameOff[rm.t + 1] - tNameOff[rm.t]), tNames + tNameOff[rm.t],
+            fprintf(f, "%.*s\t%.16s\t%.8s\t%.16s\t%d\t%d\t%d\t%d\t%d\t%d\t%.*s\n", (int) (tNameOff[rm.t + 1] - tNameOff[rm.t]), tNames + tNameOff[rm.t],
                     rm.pval, rm.seqId, rm.eval, rm.qStart, rm.qEnd, rm.qLen, rm.tStart, rm.tEnd, rm.tLen, (int) rm.cigarLen, p);
             p += padded;
             nh++;

@@ -11,10 +11,15 @@
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
 #include <cerrno>
+#include <cstdlib>
+#include <ctime>
+#include <new>
+#include <sys/time.h>
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -118,18 +123,43 @@ int sd_tcp_connect(const char *addr, int port, int nRanks, int rank, sd_tcp **ou
             delete t;
             return SD_EHIP;
         }
+        // Every rank must say hello within the deadline (SD_TCP_TIMEOUT seconds, default 600: a peer that died before connecting
+        // must not park rank 0 forever).  A connection that does not introduce itself properly -- a port scanner, another job on
+        // this port -- is closed and ignored; it does not take the job down.
         bool ok = true;
-        for (int x = 1; x < nRanks && ok; x++) {
-            const int fd = ::accept(ls, nullptr, nullptr);
-            Hello h;
-            if (fd < 0 || !recvAll(fd, &h, sizeof(h)) || h.magic != MAGIC || h.rank == 0 || h.rank >= (uint32_t) nRanks || t->peer[h.rank] >= 0) {
-                if (fd >= 0) ::close(fd);
+        const int deadlineS = getenv("SD_TCP_TIMEOUT") ? atoi(getenv("SD_TCP_TIMEOUT")) : 600;
+        const time_t tEnd = time(nullptr) + (deadlineS > 0 ? deadlineS : 600);
+        int have = 1;
+        while (have < nRanks && ok) {
+            const time_t nowT = time(nullptr);
+            if (nowT >= tEnd) {
                 ok = false;
-            } else {
-                int one = 1;
-                ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-                t->peer[h.rank] = fd;
+                break;
             }
+            pollfd pf;
+            pf.fd = ls;
+            pf.events = POLLIN;
+            pf.revents = 0;
+            const int pr = ::poll(&pf, 1, (int) std::min<long>(1000L * (long) (tEnd - nowT), 5000L));
+            if (pr < 0 && errno != EINTR) ok = false;
+            if (pr <= 0) continue;
+            const int fd = ::accept(ls, nullptr, nullptr);
+            if (fd < 0) continue;
+            timeval tv;
+            tv.tv_sec = 10;
+            tv.tv_usec = 0;
+            ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));   // for the hello only
+            Hello h;
+            if (!recvAll(fd, &h, sizeof(h)) || h.magic != MAGIC || h.rank == 0 || h.rank >= (uint32_t) nRanks || t->peer[h.rank] >= 0) {
+                ::close(fd);   // not one of ours (or a duplicate): ignored
+                continue;
+            }
+            tv.tv_sec = 0;
+            ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));   // payload receives block (a rank may compute for a long time)
+            int one = 1;
+            ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            t->peer[h.rank] = fd;
+            have++;
         }
         ::close(ls);
         if (!ok) {
@@ -187,7 +217,12 @@ int sd_tcp_gather(sd_tcp *t, const void *local, uint64_t nBytes, uint64_t *sizes
         uint64_t n = 0;
         const uint32_t ack = MAGIC;
         if (!recvAll(t->peer[(size_t) r], &n, sizeof(n))) return SD_EHIP;
-        parts[(size_t) r].resize(n);
+        if (n > (1ull << 36)) return SD_EINVAL;   // 64 GiB of result records from one rank: a corrupt length, not a result
+        try {
+            parts[(size_t) r].resize(n);
+        } catch (const std::bad_alloc &) {
+            return SD_ENOMEM;
+        }
         if (!recvAll(t->peer[(size_t) r], parts[(size_t) r].data(), n) || !sendAll(t->peer[(size_t) r], &ack, sizeof(ack))) return SD_EHIP;
     }
     uint64_t total = 0;

@@ -378,6 +378,8 @@ def write_records_tsv(records, path, Q, T, canonical=False, first_cluster_key=0)
     ts, tso = _pack_strings(T.sources)
     rec = np.ascontiguousarray(records, np.uint8).reshape(-1)
     nc, nh = C.c_uint64(), C.c_uint64()
+    api._check(None, L.sd_records_check(ptr(rec) if rec.size else None, rec.nbytes, len(qso) - 1, len(tso) - 1, len(qno) - 1, len(tno) - 1, None, None),
+               'sd_records_check (truncated records, or indices outside the name tables)')
     api._check(None, L.sd_records_write_tsv(ptr(rec) if rec.size else None, rec.nbytes, str(path).encode(), 0, first_cluster_key, qn, ptr(qno), tn,
                                             ptr(tno), qs, ptr(qso), ts, ptr(tso), 1 if canonical else 0, C.byref(nc), C.byref(nh)),
                'sd_records_write_tsv')
