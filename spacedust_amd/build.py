@@ -11,7 +11,7 @@ OUT = os.path.join(HERE, 'libsdgpu.so')
 CLI = os.path.join(HERE, 'sdgpu')   # the multi-call host driver (csrc/cli), linked against libsdgpu.so
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HOST_FLAGS = ['-std=c++17', '-O3', '-mavx2', '-mfma', '-ffp-contract=fast', '-fopenmp', '-fPIC']
-HIP_FLAGS = ['--offload-arch=gfx950', '-std=c++17', '-O3', '-fPIC', '-fopenmp', '-Wno-unused-result']
+HIP_FLAGS = ['--offload-arch=gfx950', '-std=c++17', '-O3', '-fPIC', '-fopenmp', '-Wno-unused-result'] + os.environ.get('SD_HIP_EXTRA', '').split()   # (SD_HIP_EXTRA: tuning builds, e.g. -DSD_KP_LOW=17)
 
 
 def _newer(src, dst):

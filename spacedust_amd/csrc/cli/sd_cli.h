@@ -10,6 +10,8 @@
 #include "spacedust_gpu.h"
 
 #include <cstdint>
+#include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -65,6 +67,28 @@ struct LoadedIndex {
 };
 int loadTargetIndex(const std::string &targetDb, int wantK, int wantKmerThr, int wantMask, uint64_t nSeq, uint64_t residues,
                     LoadedIndex &out, std::string *why);
+
+// What a workflow of several modules over ONE target keeps between them (iterativeSearch: prefilter / align / result2profile
+// of three iterations): the loaded target DB, one context per device, the target index built on it and the target sequence
+// set.  The reference's modules are separate processes that reload everything; in this binary the workflow runs them in
+// process, and at 1 000 target proteomes the reloads were ~40 % of `search --num-iterations 3`.  Off unless a workflow
+// switches it on; a module that runs alone behaves as before.
+struct Resident {
+    bool enabled = false;
+    std::map<std::string, std::shared_ptr<SeqDb> > seqDbs;          // DB path -> loaded sequences
+    std::map<int, sd_ctx *> ctxOfDevice;
+    struct TargetEntry {
+        sd_target *t = nullptr;
+        uint64_t nEntries = 0, masked = 0;
+    };
+    std::map<std::string, TargetEntry> targets;                      // "path|k|threshold|mask|prob|device"
+    std::map<std::string, sd_seqset *> seqSets;                      // "path|device"
+    sd_ctx *ctx(int device, int *rc);                                // the device's context (created on first use)
+    void clear();                                                    // destroys everything (sequence sets and targets before their contexts)
+};
+Resident &resident();
+// the target DB of a module: from the resident cache when it is on, else loaded for this call
+std::shared_ptr<SeqDb> loadTargetDb(const std::string &path, sd_host *host, std::string *err);
 
 // modules (each: argv after the module name -> exit code)
 int createindexModule(const Args &a);

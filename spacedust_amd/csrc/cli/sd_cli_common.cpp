@@ -48,6 +48,51 @@ int threadsOf(const Args &a) {
     return (int) std::max<long long>(1, t);
 }
 
+Resident &resident() {
+    static Resident r;
+    return r;
+}
+
+sd_ctx *Resident::ctx(int device, int *rc) {
+    auto it = ctxOfDevice.find(device);
+    if (it != ctxOfDevice.end()) {
+        if (rc) *rc = SD_OK;
+        return it->second;
+    }
+    sd_ctx *c = nullptr;
+    const int r = sd_ctx_create(device, &c);
+    if (rc) *rc = r;
+    if (r != SD_OK) return nullptr;
+    ctxOfDevice[device] = c;
+    return c;
+}
+
+void Resident::clear() {
+    for (auto &kv : seqSets)
+        if (kv.second) sd_seqset_destroy(kv.second);
+    seqSets.clear();
+    for (auto &kv : targets)
+        if (kv.second.t) sd_target_destroy(kv.second.t);
+    targets.clear();
+    for (auto &kv : ctxOfDevice)
+        if (kv.second) sd_ctx_destroy(kv.second);
+    ctxOfDevice.clear();
+    seqDbs.clear();
+    enabled = false;
+}
+
+std::shared_ptr<SeqDb> loadTargetDb(const std::string &path, sd_host *host, std::string *err) {
+    Resident &R = resident();
+    if (R.enabled) {
+        auto it = R.seqDbs.find(path);
+        if (it != R.seqDbs.end()) return it->second;
+    }
+    std::shared_ptr<SeqDb> db(new SeqDb());
+    if (!db->load(path, host, err)) return std::shared_ptr<SeqDb>();
+    if (R.enabled && !db->profile) R.seqDbs[path] = db;
+    return db;
+}
+
 bool SeqDb::load(const std::string &path, sd_host *host, std::string *err) {
     if (!rd.open(path, sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, err)) return false;
     const int bt = sddb::baseType(rd.dbtype());

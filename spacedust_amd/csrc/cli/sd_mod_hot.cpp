@@ -25,16 +25,29 @@ struct HostH {
 };
 struct CtxH {
     sd_ctx *c = nullptr;
-    ~CtxH() { if (c) sd_ctx_destroy(c); }
+    bool own = true;   // false: the resident context of a workflow (sd_cli.h)
+    ~CtxH() { if (c && own) sd_ctx_destroy(c); }
+    // the module's context: the workflow's resident one when that is on, else its own
+    int open(int device) {
+        if (resident().enabled) {
+            int rc = SD_OK;
+            c = resident().ctx(device, &rc);
+            own = false;
+            return rc;
+        }
+        return sd_ctx_create(device, &c);
+    }
 };
 struct SeqSetH {
     sd_seqset *s = nullptr;
-    ~SeqSetH() { if (s) sd_seqset_destroy(s); }
-    void reset() { if (s) sd_seqset_destroy(s); s = nullptr; }
+    ~SeqSetH() { if (s && own) sd_seqset_destroy(s); }
+    void reset() { if (s && own) sd_seqset_destroy(s); s = nullptr; }
+    bool own = true;
 };
 struct TargetH {
     sd_target *t = nullptr;
-    ~TargetH() { if (t) sd_target_destroy(t); }
+    bool own = true;
+    ~TargetH() { if (t && own) sd_target_destroy(t); }
 };
 struct IndexH {
     sd_host_index *ix = nullptr;
@@ -82,8 +95,9 @@ int prefilterModule(const Args &a) {
     if (sd_host_create(threads, &host.h) != SD_OK) return fail("sd_host_create failed");
     std::string err;
     const bool sameDb = a.pos[0] == a.pos[1];
-    std::unique_ptr<SeqDb> tdb(new SeqDb()), qdbOwn;
-    if (!tdb->load(a.pos[1], host.h, &err)) return fail(err);
+    std::shared_ptr<SeqDb> tdb = loadTargetDb(a.pos[1], host.h, &err);
+    std::unique_ptr<SeqDb> qdbOwn;
+    if (!tdb) return fail(err);
     if (tdb->profile) return fail("profile target databases are not supported on this path");
     SeqDb *qdb = tdb.get();
     if (!sameDb) {
@@ -107,7 +121,7 @@ int prefilterModule(const Args &a) {
     const bool includeIdentity = a.flag("--add-self-matches", false);
 
     CtxH ctx;
-    int rc = sd_ctx_create(deviceOf(a), &ctx.c);
+    int rc = ctx.open(deviceOf(a));
     if (rc != SD_OK) return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rc) + "); this path has no CPU fallback");
 
     // target side: TARGET.idx when a createindex file with matching parameters lies next to the DB (PrefilteringIndexReader
@@ -128,7 +142,19 @@ int prefilterModule(const Args &a) {
     sd_host_ext_matrix(host.h, 2, &s2, &i2, &sz2);
     sd_host_ext_matrix(host.h, 3, &s3, &i3, &sz3);
     TargetH target;
-    const int got = loadTargetIndex(a.pos[1], k, indexThr, mask ? 1 : 0, tdb->n, tdb->totalResidues(), loaded, &why);
+    // a workflow's resident target of exactly this index (same DB, k, threshold, masking, device) is taken as it is
+    char tkey[96];
+    snprintf(tkey, sizeof(tkey), "|%d|%d|%d|%.6f|%d", k, indexThr, mask ? 1 : 0, maskProb, deviceOf(a));
+    const std::string targetKey = a.pos[1] + tkey;
+    if (resident().enabled && resident().targets.count(targetKey)) {
+        const Resident::TargetEntry &te = resident().targets[targetKey];
+        target.t = te.t;
+        target.own = false;
+        nEntries = te.nEntries;
+        maskedRes = te.masked;
+        info(a, "Target index resident from the previous module of this workflow\n");
+    }
+    const int got = target.t ? 1 : loadTargetIndex(a.pos[1], k, indexThr, mask ? 1 : 0, tdb->n, tdb->totalResidues(), loaded, &why);
     if (got < 0) return fail(why);
     if (got == 0) {
         kOff = loaded.offsets.data();
@@ -141,7 +167,9 @@ int prefilterModule(const Args &a) {
     } else {
         if (sddb::fileExists(a.pos[1] + ".idx.index")) info(a, "Index file not used: %s\n", why.c_str());
     }
-    if (got != 0 && !getenv("SD_INDEX_HOST")) {
+    if (target.t) {
+        // resident
+    } else if (got != 0 && !getenv("SD_INDEX_HOST")) {
         // IndexBuilder::fillDatabase on the device (sd_target_build): mask, k-mer lists, list starts
         double ratios[21 * 21];
         int8_t self[21];
@@ -165,6 +193,14 @@ int prefilterModule(const Args &a) {
     if (!target.t) {
         rc = sd_target_create_wide(ctx.c, k, kOff, kBase, eSeq, ePos, nEntries, masked, tdb->offsets.data(), tdb->n, s2, i2, s3, i3, &target.t);
         if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_target_create");
+    }
+    if (resident().enabled && target.own) {   // stays for the next module of the workflow
+        Resident::TargetEntry te;
+        te.t = target.t;
+        te.nEntries = nEntries;
+        te.masked = maskedRes;
+        resident().targets[targetKey] = te;
+        target.own = false;
     }
 
     sd_prefilter_params par;
@@ -351,8 +387,9 @@ int alignModule(const Args &a) {
     if (sd_host_create(threads, &host.h) != SD_OK) return fail("sd_host_create failed");
     std::string err;
     const bool sameDb = a.pos[0] == a.pos[1];
-    std::unique_ptr<SeqDb> tdb(new SeqDb()), qdbOwn;
-    if (!tdb->load(a.pos[1], host.h, &err)) return fail(err);
+    std::shared_ptr<SeqDb> tdb = loadTargetDb(a.pos[1], host.h, &err);
+    std::unique_ptr<SeqDb> qdbOwn;
+    if (!tdb) return fail(err);
     if (tdb->profile) return fail("profile target databases are not supported on this path");
     SeqDb *qdb = tdb.get();
     if (!sameDb) {
@@ -367,7 +404,7 @@ int alignModule(const Args &a) {
          qdb->n, qdb->profile ? "Profile" : "Aminoacid", tdb->n);
 
     CtxH ctx;
-    int rc = sd_ctx_create(deviceOf(a), &ctx.c);
+    int rc = ctx.open(deviceOf(a));
     if (rc != SD_OK) return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rc) + "); this path has no CPU fallback");
 
     sd_sw_params par;
@@ -407,8 +444,18 @@ int alignModule(const Args &a) {
     const bool includeIdentity = a.flag("--add-self-matches", false);
 
     SeqSetH tset;
-    rc = sd_seqset_create(ctx.c, tdb->residues.data(), tdb->offsets.data(), tdb->n, nullptr, &tset.s);
-    if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_seqset_create(targets)");
+    const std::string tsetKey = a.pos[1] + "|" + std::to_string(deviceOf(a));
+    if (resident().enabled && resident().seqSets.count(tsetKey)) {
+        tset.s = resident().seqSets[tsetKey];   // the target sequences are on the device already
+        tset.own = false;
+    } else {
+        rc = sd_seqset_create(ctx.c, tdb->residues.data(), tdb->offsets.data(), tdb->n, nullptr, &tset.s);
+        if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_seqset_create(targets)");
+        if (resident().enabled) {
+            resident().seqSets[tsetKey] = tset.s;
+            tset.own = false;
+        }
+    }
 
     sddb::Writer out;
     int outType = sddb::withExtended(sddb::DBTYPE_ALIGNMENT_RES, sddb::extendedType(pref.dbtype()));

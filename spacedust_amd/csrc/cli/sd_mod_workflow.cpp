@@ -544,8 +544,9 @@ int result2profileModule(const Args &a) {
     if (sd_host_create(threads, &host.h) != SD_OK) return fail("sd_host_create failed");
     std::string err;
     const bool sameDb = a.pos[0] == a.pos[1];
-    std::unique_ptr<SeqDb> tdb(new SeqDb()), qdbOwn;
-    if (!tdb->load(a.pos[1], host.h, &err)) return fail(err);
+    std::shared_ptr<SeqDb> tdb = loadTargetDb(a.pos[1], host.h, &err);
+    std::unique_ptr<SeqDb> qdbOwn;
+    if (!tdb) return fail(err);
     if (tdb->profile) return fail("Only the query OR the target database can be a profile database");
     SeqDb *qdb = tdb.get();
     if (!sameDb) {
@@ -562,14 +563,21 @@ int result2profileModule(const Args &a) {
     // asks for the host implementation explicitly (a box without a GPU, the CPU-side tests).  No silent fallback.
     const bool hostWeights = a.integer("--profile-weights-host", 0) != 0;
     sd_ctx *r2pCtx = nullptr;
+    bool ownCtx = true;
     if (!hostWeights) {
         const int device = a.has("--device") ? (int) a.integer("--device", 0) : envInt("LOCAL_RANK", 0);
-        const int rcCtx = sd_ctx_create(device, &r2pCtx);
+        int rcCtx = SD_OK;
+        if (resident().enabled) {
+            r2pCtx = resident().ctx(device, &rcCtx);
+            ownCtx = false;
+        } else {
+            rcCtx = sd_ctx_create(device, &r2pCtx);
+        }
         if (rcCtx != SD_OK)
             return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rcCtx) + "); result2profile computes the sequence weights on "
                         "the GPU (--profile-weights-host 1 selects the host implementation)");
     }
-    std::unique_ptr<sd_ctx, void (*)(sd_ctx *)> ctxGuard(r2pCtx, sd_ctx_destroy);
+    std::unique_ptr<sd_ctx, void (*)(sd_ctx *)> ctxGuard(ownCtx ? r2pCtx : nullptr, sd_ctx_destroy);
     sddb::Writer out;
     if (!out.open(a.pos[3], sddb::DBTYPE_HMM_PROFILE, &err)) return fail(err);
     const size_t n = aln.size();
@@ -814,6 +822,12 @@ int iterativeSearch(const Args &a, const std::string &Q, const std::string &T, c
                                                         a.str("--pca", "substitution:1.100,context:1.400"), "--pcb",
                                                         a.str("--pcb", "substitution:4.100,context:5.800")});
     const bool keep = a.integer("--keep-tmp", 0) != 0;   // keep the per-iteration DBs (parity checks at size read them)
+    // the modules below run in this process: the target DB, its index on the device and its sequence set stay resident between them
+    // (sd_cli.h: Resident) instead of being reloaded / rebuilt by every module
+    struct ResidentScope {
+        ResidentScope() { resident().enabled = !(getenv("SD_RESIDENT") && atoi(getenv("SD_RESIDENT")) == 0); }
+        ~ResidentScope() { resident().clear(); }
+    } residentScope;
     std::string query = Q;
     for (int step = 0; step < numIt; step++) {
         const std::string s = std::to_string(step), s1 = std::to_string(step - 1);

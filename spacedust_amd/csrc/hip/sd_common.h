@@ -88,8 +88,10 @@ inline hipError_t sdEventWait(hipEvent_t ev) {
         prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
         slackSet = true;
     }
-    for (;;) {
-        timespec ts = {0, 20000};
+    // 20 us between polls for short waits, backing off to 100 us: a lane thread spends most of its life here, and every poll is
+    // a system call plus a runtime query (at 20 us throughout, four waiting lanes cost most of a core)
+    for (int n = 0;; n++) {
+        timespec ts = {0, n < 8 ? 20000 : (n < 24 ? 50000 : 100000)};
         nanosleep(&ts, nullptr);
         hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;

@@ -23,8 +23,18 @@
 // time, end-to-end throughput within noise -- unlike partition_hits, where 512 x 4 096 beats both neighbours.
 constexpr int JP_WGS = 256;            // persistent workgroups of the k-mer partition (one per CU)
 constexpr int JP_NT = 1024;
-constexpr int KP_BINS = 2048;          // k-mer ranges: bin = kmer >> 15 (k = 6: 1 954 of them in use)
-constexpr int KP_SHIFT = 53;           // element >> 53 = kmer >> 15
+// k-mer ranges: bin = kmer >> KP_LOW.  A range's slices of the offset table and of the entry array must stay in an XCD's L2
+// while its elements are joined (KP_LOW = 15: 128 KB + ~350 KB at 100 proteomes; 17: 512 KB + ~1.4 MB of 4 MB), and the hits a
+// query has in one range (62 k-mers x ~1.2 at KP_LOW = 15, four times that at 17) are the runs join_scatter writes: longer runs
+// = fewer partial lines, which the memory side turns into read-modify-writes.
+#ifndef SD_KP_LOW
+#define SD_KP_LOW 15
+#endif
+constexpr int KP_LOW = SD_KP_LOW;
+constexpr int KP_BINS = KP_LOW == 15 ? 2048 : (KP_LOW == 16 ? 1024 : 512);   // >= 64 000 000 >> KP_LOW
+constexpr int KP_SHIFT = 38 + KP_LOW;  // element >> KP_SHIFT = kmer >> KP_LOW
+constexpr uint64_t KP_LOW_MASK = (1ull << KP_LOW) - 1;
+static_assert((64000000 >> KP_LOW) < KP_BINS && KP_LOW <= 19, "k-mer ranges");
 constexpr int KP_TILE = 16384;
 constexpr int KP_PER = KP_TILE / JP_NT;
 constexpr int JQ_MAX = 4096;           // queries per sub-batch
@@ -212,7 +222,7 @@ __device__ __forceinline__ void jpBlockScan2(uint32_t *arr, int n, uint32_t *par
 // has room for the owning query and the k-mer's ordinal in it -- the join looks neither up:
 //   k-mer & 0x7FFF << 44 | query (< 4096) << 32 | ordinal (< 2^24) << 8 | low byte of the query position
 __device__ __forceinline__ uint64_t jpSortedElem(uint64_t e, uint32_t q, uint32_t ord) {
-    return (((e >> 38) & 0x7FFFull) << 44) | ((uint64_t) q << 32) | ((uint64_t) ord << 8) | (e & 0xFFull);
+    return (((e >> 38) & KP_LOW_MASK) << 44) | ((uint64_t) q << 32) | ((uint64_t) ord << 8) | (e & 0xFFull);
 }
 
 __global__ void __launch_bounds__(JP_NT)
@@ -339,7 +349,7 @@ join_count_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint16_
     {
         const uint64_t b0 = sp.begin + (uint64_t) sp.slot * JC;
         if (b0 < sp.end) {
-            nxHi = (uint32_t) chunkBin[b0 / JC] << 15;
+            nxHi = (uint32_t) chunkBin[b0 / JC] << KP_LOW;
 #pragma unroll
             for (int j = 0; j < JE; j++) nx[j] = __builtin_nontemporal_load(sorted + b0 + (uint64_t) j * JJ_NT + threadIdx.x);
         }
@@ -351,7 +361,7 @@ join_count_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint16_
 #pragma unroll
         for (int j = 0; j < JE; j++) e[j] = nx[j];
         if (base + step < sp.end) {
-            nxHi = (uint32_t) chunkBin[(base + step) / JC] << 15;
+            nxHi = (uint32_t) chunkBin[(base + step) / JC] << KP_LOW;
 #pragma unroll
             for (int j = 0; j < JE; j++) nx[j] = __builtin_nontemporal_load(sorted + base + step + (uint64_t) j * JJ_NT + threadIdx.x);
         }
@@ -422,7 +432,7 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
     {
         const uint64_t b0 = sp.begin + (uint64_t) sp.slot * JC;
         if (b0 < sp.end) {
-            nxHi = (uint32_t) chunkBin[b0 / JC] << 15;
+            nxHi = (uint32_t) chunkBin[b0 / JC] << KP_LOW;
 #pragma unroll
             for (int j = 0; j < JE; j++)   // streamed once: not to displace the table slices in L2
                 nx[j] = __builtin_nontemporal_load(sorted + b0 + (uint64_t) wv * WE + (uint64_t) j * 64 + lane);
@@ -436,7 +446,7 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
 #pragma unroll
         for (int j = 0; j < JE; j++) e[j] = nx[j];
         if (base + step < sp.end) {
-            nxHi = (uint32_t) chunkBin[(base + step) / JC] << 15;
+            nxHi = (uint32_t) chunkBin[(base + step) / JC] << KP_LOW;
 #pragma unroll
             for (int j = 0; j < JE; j++)
                 nx[j] = __builtin_nontemporal_load(sorted + base + step + (uint64_t) wv * WE + (uint64_t) j * 64 + lane);

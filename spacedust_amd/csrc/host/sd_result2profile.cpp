@@ -826,6 +826,8 @@ static int r2pBatchImpl(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32
             }
             const uint32_t nG = g1 - g0;
             std::vector<Prepared> prep(nG);
+            const bool dbg = getenv("SD_DEBUG_TIMING") != nullptr;
+            const double tA0 = omp_get_wtime();
 #pragma omp parallel
             {
                 Alignment A;
@@ -859,6 +861,7 @@ static int r2pBatchImpl(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32
                     scaleToOne(P.gw.data(), (int) nRows);
                 }
             }
+            const double tA1 = omp_get_wtime();
             // staging
             std::vector<R2pTaskH> tasks;
             std::vector<uint32_t> taskQ;
@@ -912,9 +915,14 @@ static int r2pBatchImpl(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32
                     launch[k] = tasks[ord[k]];
                     nShort += launch[k].L <= 320;
                 }
+                const double tB0 = omp_get_wtime();
                 const int rc = sdR2pColumnWeightsDevice(ctx, (uint32_t) tasks.size(), nShort, launch.data(), cells.data(), cellBytes, cmBytes, gw.data(),
                                                         nWeights, nColumns, scratch, table.data(), rcpN, background, freq.data(), eff.data());
                 if (rc != SD_OK) return rc;
+                const double tB1 = omp_get_wtime();
+                if (dbg)
+                    fprintf(stderr, "[r2p] group of %u centres: %.1f MB cells, %llu rows; build + filter %.2f s, staging %.2f s, device %.2f s\n", nG,
+                            cellBytes / 1e6, (unsigned long long) nWeights, tA1 - tA0, tB0 - tA1, tB1 - tB0);
 #pragma omp parallel
                 {
                     ProfileScratch w;

@@ -147,6 +147,7 @@ struct sd_search {
     sd_ctx *ctxAl2 = nullptr;   // second alignment lane: consecutive chunks are aligned concurrently, each on its own stream
     sd_ctx *ctxCh = nullptr;    // clusterhits (the main thread finalises ranges while both lanes may be busy)
     sd_ctx *ctxPf2 = nullptr;   // second prefilter lane (same target index, its own workspace and stream)
+    sd_ctx *ctxPfMore[2] = {nullptr, nullptr}, *ctxAlMore[2] = {nullptr, nullptr};   // lanes 3 and 4 (SD_PF_LANES / SD_ALIGN_LANES up to 4)
     int alignLanes = 2, pfLanes = 2;
     sd_host_index *index = nullptr;
     sd_target *target = nullptr;
@@ -171,7 +172,7 @@ struct sd_search {
         std::vector<uint32_t> idx, pq, pt;
         std::vector<uint8_t> ident;
         std::vector<char> pool;
-    } buf[4];
+    } buf[8];   // one per alignment lane + the chunks the aggregation may still read
     int flip = 0;
 
     ~sd_search() {
@@ -179,6 +180,10 @@ struct sd_search {
         if (target) sd_target_destroy(target);
         if (index) sd_host_index_destroy(index);
         if (ctxBias) sd_ctx_destroy(ctxBias);
+        for (int x = 0; x < 2; x++) {
+            if (ctxPfMore[x]) sd_ctx_destroy(ctxPfMore[x]);
+            if (ctxAlMore[x]) sd_ctx_destroy(ctxAlMore[x]);
+        }
         if (ctxPf2) sd_ctx_destroy(ctxPf2);
         if (ctxCh) sd_ctx_destroy(ctxCh);
         if (ctxAl2) sd_ctx_destroy(ctxAl2);
@@ -251,16 +256,24 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
         if (const char *e = getenv("LOCAL_WORLD_SIZE")) local = std::max(1, atoi(e));
         if (cpus / local < 4) s->alignLanes = s->pfLanes = 1;
     }
-    if (const char *e = getenv("SD_ALIGN_LANES")) s->alignLanes = std::max(1, std::min(2, atoi(e)));
+    if (const char *e = getenv("SD_ALIGN_LANES")) s->alignLanes = std::max(1, std::min(4, atoi(e)));
     if (s->alignLanes > 1) {
         rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAl2);
         if (rc != SD_OK) return rc;
     }
+    for (int x = 2; x < s->alignLanes; x++) {
+        rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAlMore[x - 2]);
+        if (rc != SD_OK) return rc;
+    }
     rc = sd_ctx_create(device, &s->ctxCh);
     if (rc != SD_OK) return rc;
-    if (const char *e = getenv("SD_PF_LANES")) s->pfLanes = std::max(1, std::min(2, atoi(e)));
+    if (const char *e = getenv("SD_PF_LANES")) s->pfLanes = std::max(1, std::min(4, atoi(e)));
     if (s->pfLanes > 1) {
         rc = sd_ctx_create_prio(device, pfPrio, &s->ctxPf2);
+        if (rc != SD_OK) return rc;
+    }
+    for (int x = 2; x < s->pfLanes; x++) {
+        rc = sd_ctx_create_prio(device, pfPrio, &s->ctxPfMore[x - 2]);
         if (rc != SD_OK) return rc;
     }
     bool devBias = par->deviceBias > 0;
@@ -394,6 +407,10 @@ sd_ctx *sd_search_ctx(sd_search *s, int which) {
         case 3: return s->ctxAl2;
         case 4: return s->ctxCh;
         case 5: return s->ctxPf2;
+        case 6: return s->ctxPfMore[0];
+        case 7: return s->ctxPfMore[1];
+        case 8: return s->ctxAlMore[0];
+        case 9: return s->ctxAlMore[1];
         default: return nullptr;
     }
 }
@@ -568,13 +585,14 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     };
     // prefilter lanes: chunk x runs on lane x % lanes (its own context, workspace and stream; the target index is shared)
     const int pfLanes = s->pfLanes;
-    std::unique_ptr<StageThread> pfLane2(pfLanes > 1 ? new StageThread() : nullptr);
-    sd_ctx *pfCtxOf[2] = {s->ctxPf, s->ctxPf2};
+    std::unique_ptr<StageThread> pfLaneMore[3];
+    for (int l = 1; l < pfLanes; l++) pfLaneMore[l - 1].reset(new StageThread());
+    sd_ctx *pfCtxOf[4] = {s->ctxPf, s->ctxPf2, s->ctxPfMore[0], s->ctxPfMore[1]};
     auto submitPf = [&](size_t x) {
         submitBias(x);
         std::shared_ptr<BiasFut> bf = biasFut[x];
         sd_ctx *pfCtx = pfCtxOf[x % (size_t) pfLanes];
-        StageThread &st = (x % (size_t) pfLanes) ? *pfLane2 : pfStage;
+        StageThread &st = (x % (size_t) pfLanes) ? *pfLaneMore[x % (size_t) pfLanes - 1] : pfStage;
         PfFut f = st.submit([pfJob, bf, pfCtx] { return pfJob(bf, pfCtx); });
         for (int a = 1; a <= pfLanes; a++) submitBias(x + (size_t) a);
         return f;
@@ -671,9 +689,9 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         double tSeqset = 0, tAlign = 0, cpu = 0;
     };
     const int lanes = s->alignLanes;
-    std::unique_ptr<StageThread> alStage[2];
+    std::unique_ptr<StageThread> alStage[4];
     for (int l = 0; l < lanes; l++) alStage[l].reset(new StageThread());
-    sd_ctx *laneCtx[2] = {s->ctxAl, s->ctxAl2};
+    sd_ctx *laneCtx[4] = {s->ctxAl, s->ctxAl2, s->ctxAlMore[0], s->ctxAlMore[1]};
     const std::vector<int32_t> *qLenP = &qLen;
     auto alignJob = [s, Q, profile, sameDb, qLenP](std::shared_ptr<std::unique_ptr<PfOut> > dp, sd_ctx *ctx, sd_search::AlnBuf *Bp, size_t ci) {
         std::unique_ptr<AlOut> o(new AlOut());
@@ -860,8 +878,8 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             retire(std::move(a));
         }
         if (status != SD_OK) break;
-        // the buffer of chunk ci - 4 is free: its aggregation finished before the aggregation of chunk ci - 3 was submitted
-        s->flip = (s->flip + 1) & 3;
+        // the buffer of chunk ci - 8 is free (at most four chunks in the lanes, one in the aggregation)
+        s->flip = (s->flip + 1) & 7;
         sd_search::AlnBuf *Bp = &s->buf[s->flip];
         std::shared_ptr<std::unique_ptr<PfOut> > dp(new std::unique_ptr<PfOut>(std::move(d)));
         sd_ctx *ctx = laneCtx[ci % (size_t) lanes];

@@ -161,7 +161,7 @@ class ClusterSearch:
         self.ctx_al = _BorrowedContext(C.c_void_p(self.L.sd_search_ctx(h, 1)), ctx.device_index)   # alignments (lane 0)
         # every device context the pipeline runs on (prefilter, alignment lanes, composition bias, clusterhits)
         self.contexts = []
-        for which in range(6):
+        for which in range(10):
             hp = self.L.sd_search_ctx(h, which)
             if hp:
                 self.contexts.append(_BorrowedContext(C.c_void_p(hp), ctx.device_index))
