@@ -118,6 +118,16 @@ int sd_sw_align_batch_compact(sd_ctx *ctx, const sd_sw_params *par, const sd_seq
                               uint32_t *outIdx, sd_sw_result *out, uint32_t *nOut, char *btPool, uint64_t btCap,
                               uint64_t *btUsed);
 
+/* sd_sw_align_batch_compact with the prefilter's diagonal of every pair (sd_hit.diagonal; Matcher::getSWResult receives it too,
+ * Alignment.cpp:379).  Same results.  The diagonal lets the library skip work whose outcome is certain: a pair whose ungapped
+ * score along that diagonal -- a lower bound of the byte kernel's maximum -- already saturates the byte kernel goes straight to
+ * the word-kernel pass the reference would rerun it with (StripedSmithWaterman.cpp:360-368).  pairDiag may be NULL; an entry of
+ * 0x8000 (no sequence pair below 32768 residues has that diagonal) means "no hint for this pair". */
+int sd_sw_align_batch_compact_diag(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                                   uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint16_t *pairDiag,
+                                   const uint8_t *isIdentity, uint32_t *outIdx, sd_sw_result *out, uint32_t *nOut, char *btPool,
+                                   uint64_t btCap, uint64_t *btUsed);
+
 /* Same contract and results as sd_sw_align_batch, with the gating / task building between the passes done on
  * the host (one device round trip per pass).  Kept as the A/B cross-check of the device-resident orchestration
  * (tests/test_gpu_sw.py); btOffset values may differ, the bytes they point to may not. */

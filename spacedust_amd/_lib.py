@@ -110,6 +110,8 @@ def load():
                                         C.c_uint64, C.POINTER(C.c_uint64)]),
         'sd_sw_align_batch_compact': (C.c_int, [_vp, C.POINTER(SwParams), _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp,
                                                 C.POINTER(C.c_uint32), _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+        'sd_sw_align_batch_compact_diag': (C.c_int, [_vp, C.POINTER(SwParams), _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                     C.POINTER(C.c_uint32), _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
         'sd_sw_align_batch_hostpath': (C.c_int, [_vp, C.POINTER(SwParams), _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp,
                                                  C.c_uint64, C.POINTER(C.c_uint64)]),
         'sd_sw_score_batch': (C.c_int, [_vp, C.POINTER(SwParams), _vp, _vp, C.c_uint32, _vp, _vp, C.c_int, C.c_int,

@@ -319,7 +319,7 @@ class Context:
         return out
 
     def sw_align(self, par, queries, targets, pair_q, pair_t, identity=None, bt_cap=None, hostpath=False, reuse=False,
-                 compact=False):
+                 compact=False, diag=None):
         """sd_sw_align_batch.  bt_cap: capacity of the backtrace pool (default: a generous guess, grown to the exact
         bound sum(qLen + tLen) if the library reports SD_ENOMEM).  reuse=True hands out views of two alternating
         context-owned buffers instead of fresh arrays (valid until the next-but-one call).  compact=True
@@ -355,8 +355,14 @@ class Context:
                     self._cidx = [np.empty(int(1.25 * n) + 1, np.uint32), np.empty(int(1.25 * n) + 1, np.uint32)]
                 cidx = self._cidx[getattr(self, '_flip', 0)] if reuse else np.empty(n, np.uint32)
                 n_out = C.c_uint32()
-                rc = self.L.sd_sw_align_batch_compact(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt), ptr(idt),
-                                                      ptr(cidx), ptr(res), C.byref(n_out), ptr(pool), len(pool), C.byref(used))
+                if diag is not None:   # the prefilter's diagonals: sd_sw_align_batch_compact_diag (same results)
+                    dg = np.ascontiguousarray(diag, np.uint16)
+                    rc = self.L.sd_sw_align_batch_compact_diag(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt), ptr(dg),
+                                                               ptr(idt), ptr(cidx), ptr(res), C.byref(n_out), ptr(pool), len(pool),
+                                                               C.byref(used))
+                else:
+                    rc = self.L.sd_sw_align_batch_compact(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt), ptr(idt),
+                                                          ptr(cidx), ptr(res), C.byref(n_out), ptr(pool), len(pool), C.byref(used))
             else:
                 rc = fn(self.h, C.byref(par), queries.h, targets.h, n, ptr(pq), ptr(pt), ptr(idt), ptr(res), ptr(pool),
                         len(pool), C.byref(used))

@@ -865,6 +865,47 @@ __device__ __forceinline__ bool devHasCoverage(float covThr, int covMode, float 
     }
 }
 
+// A pair whose byte-kernel score is CERTAIN to saturate needs no byte-structure pass: the reference discards that pass's
+// result and reruns the pair with the word kernel (:360-368), and the score of any ungapped stretch of one diagonal is a lower
+// bound of the byte kernel's maximum (a diagonal-only path never meets the lane structure's vertical-gap quirk).  With the
+// prefilter's diagonal at hand, k_pre_word walks that diagonal with the alignment's own scoring (matrix row + composition bias,
+// or the profile row) and marks the pairs whose bound already reaches 255 - bias; they skip pass 1 and go straight to pass 2.
+// On proteome-scale searches that is most true homologs, i.e. the longest-running tasks of pass 1.
+__global__ void __launch_bounds__(256)
+k_pre_word(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const uint32_t *__restrict__ pairT, const uint16_t *__restrict__ pairDiag,
+           const uint32_t *__restrict__ fwdKeys, const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff,
+           const uint8_t *__restrict__ qRes, const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
+           const int8_t *__restrict__ qProf, const int32_t *__restrict__ minBias, int matMin, uint8_t *__restrict__ preWord,
+           uint32_t *__restrict__ pass1Keys) {
+    __shared__ int8_t smat[441];
+    for (int x = threadIdx.x; x < 441; x += blockDim.x) smat[x] = mat[x];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs) return;
+    uint8_t pw = 0;
+    const uint32_t key = fwdKeys[i];
+    if (key != KEY_INVALID) {
+        const uint64_t qo = qOff[pairQ[i]], to = tOff[pairT[i]];
+        const int qL = (int) (qOff[pairQ[i] + 1] - qo), tL = (int) (tOff[pairT[i] + 1] - to);
+        if (qL < 32768 && tL < 32768 && pairDiag[i] != 0x8000) {   // (longer sequences: the 16-bit diagonal is ambiguous; 0x8000 = caller has no hint)
+            const int d = (int) (int16_t) pairDiag[i];
+            int q0 = d >= 0 ? d : 0, t0 = d >= 0 ? 0 : -d;
+            const int n = min(qL - q0, tL - t0);
+            const int need = 255 - (abs(matMin) + abs(minBias[pairQ[i]]));
+            int run = 0, best = 0;
+            for (int x = 0; x < n && best < need; x++) {
+                const int qr = qRes[qo + q0 + x], tr = tRes[to + t0 + x];
+                run += qProf ? (int) qProf[(qo + q0 + x) * 21 + tr] : (int) smat[tr * 21 + qr] + (int) qBias[qo + q0 + x];
+                run = run < 0 ? 0 : run;
+                best = run > best ? run : best;
+            }
+            pw = best >= need ? 1 : 0;
+        }
+    }
+    preWord[i] = pw;
+    pass1Keys[i] = pw ? KEY_INVALID : key;
+}
+
 // forward tasks (32-lane structure) for every non-identity pair
 __global__ void __launch_bounds__(256)
 k_make_fwd(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const uint32_t *__restrict__ pairT,
@@ -907,7 +948,8 @@ __global__ void k_bounds(const uint32_t *__restrict__ keys, uint32_t n, uint32_t
 __global__ void __launch_bounds__(256)
 k_gate_word(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const int32_t *__restrict__ out32,
             const int32_t *__restrict__ minBias, int matMin, SwTask *__restrict__ tasks, uint32_t *__restrict__ keys,
-            uint32_t *__restrict__ vals, uint8_t *__restrict__ word, const uint32_t *__restrict__ fwdKeys, int usePk, int wideRowLimit) {
+            uint32_t *__restrict__ vals, uint8_t *__restrict__ word, const uint32_t *__restrict__ fwdKeys, int usePk, int wideRowLimit,
+            const uint8_t *__restrict__ preWord /* nullable: pairs that skipped pass 1 because their byte score saturates for certain */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPairs) return;
     vals[i] = i;
@@ -915,7 +957,7 @@ k_gate_word(uint32_t nPairs, const uint32_t *__restrict__ pairQ, const int32_t *
     if (fwdKeys[i] != KEY_INVALID) {
         const int mb = minBias[pairQ[i]];
         const int bias = abs(matMin) + abs(mb);
-        w = out32[3 * i] + bias >= 255;
+        w = (preWord && preWord[i]) || out32[3 * i] + bias >= 255;
     }
     word[i] = w ? 1 : 0;
     if (w) {
@@ -1716,9 +1758,9 @@ int sd_sw_score_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
 static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
                           uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
                           sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed, uint32_t *compactIdx,
-                          uint32_t *nCompact) {
+                          uint32_t *nCompact, const uint16_t *pairDiag = nullptr /* the prefilter's diagonal of every pair (nullable) */) {
     if (!ctx || !par || !queries || !targets || !out) return SD_EINVAL;
-    if (compactIdx && (!nCompact || par->swMode != 2)) return SD_EINVAL;
+    if (compactIdx && (!nCompact || par->swMode != 2)) return sdFail(ctx, SD_EINVAL, "the compact variants need swMode 2 (records with backtraces)");
     (void) hipSetDevice(ctx->device);
     if (btUsed) *btUsed = 0;
     if (nCompact) *nCompact = 0;
@@ -1812,15 +1854,29 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     uint32_t nValid = 0;
     hipLaunchKernelGGL(k_make_fwd, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dPT, dIdent, queries->dOff, targets->dOff,
                        dTasks, dFwdKeys, dVals, dRes, usePk);
-    hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dFwdKeys, dCells + 0);
+    // pairs whose byte score saturates for certain (k_pre_word) skip this pass
+    uint32_t *dPass1Keys = dFwdKeys;
+    uint8_t *dPreWord = nullptr;
+    if (pairDiag && usePk && !getenv("SD_SW_NO_PREWORD")) {
+        uint16_t *dDiag = nullptr;
+        SD_HIP(ctx, wsGet(ctx, "al.diag", N, &dDiag));
+        SD_HIP(ctx, wsGet(ctx, "al.preword", N, &dPreWord));
+        SD_HIP(ctx, wsGet(ctx, "al.pass1keys", N, &dPass1Keys));
+        SD_HIP(ctx, hipMemcpyAsync(dDiag, pairDiag, N * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_pre_word, dim3(grid), dim3(256), 0, ctx->stream, nPairs, (const uint32_t *) dPQ, (const uint32_t *) dPT,
+                           (const uint16_t *) dDiag, (const uint32_t *) dFwdKeys, (const uint64_t *) queries->dOff, (const uint64_t *) targets->dOff,
+                           (const uint8_t *) queries->dRes, (const int8_t *) queries->dBias, (const uint8_t *) targets->dRes, (const int8_t *) dMat,
+                           (const int8_t *) queries->dProf, (const int32_t *) dMinBias, queries->dProf ? 0 : matMin, dPreWord, dPass1Keys);
+    }
+    hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dPass1Keys, dCells + 0);
     const uint32_t *dShare = (getenv("SD_SW_NOSHARE") || queries->n >= (1u << PAIR_QUERY_BITS)) ? nullptr : dPQ;   // forward passes scan whole queries: pair by query
-    int rc = devRunScore(ctx, nPairs, dFwdKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go,
+    int rc = devRunScore(ctx, nPairs, dPass1Keys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go,
                          ge, dOut32, &nValid, dShare);
     if (rc != SD_OK) return rc;
     // ---- pass 2: saturated pairs again with the word kernel's 16-lane structure
     hs.reset(new HostScope(ctx, "align.fwd16"));
     hipLaunchKernelGGL(k_gate_word, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dPQ, dOut32, dMinBias, queries->dProf ? 0 : matMin, dTasks, dKeys,
-                       dVals, dWord, dFwdKeys, usePk, gp.wideRowLimit);
+                       dVals, dWord, dFwdKeys, usePk, gp.wideRowLimit, (const uint8_t *) dPreWord);
     hipLaunchKernelGGL(k_cells, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dKeys, dCells + 0);
     rc = devRunScore(ctx, nPairs, dKeys, dVals, dKeysS, dOrder, dBounds, dTasks, dScanA, dScanB, queries, targets, dMat, go, ge,
                      dOut16, &nValid, dShare);
@@ -2149,6 +2205,14 @@ int sd_sw_align_batch_compact(sd_ctx *ctx, const sd_sw_params *par, const sd_seq
                               uint64_t *btUsed) {
     if (!outIdx || !nOut) return SD_EINVAL;
     return alignBatchImpl(ctx, par, queries, targets, nPairs, pairQ, pairT, isIdentity, out, btPool, btCap, btUsed, outIdx, nOut);
+}
+
+int sd_sw_align_batch_compact_diag(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                                   uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint16_t *pairDiag,
+                                   const uint8_t *isIdentity, uint32_t *outIdx, sd_sw_result *out, uint32_t *nOut, char *btPool,
+                                   uint64_t btCap, uint64_t *btUsed) {
+    if (!outIdx || !nOut) return SD_EINVAL;
+    return alignBatchImpl(ctx, par, queries, targets, nPairs, pairQ, pairT, isIdentity, out, btPool, btCap, btUsed, outIdx, nOut, pairDiag);
 }
 
 int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,

@@ -738,9 +738,18 @@ struct R2pTaskH {   // = R2pTask of sd_r2p.hip
     uint64_t cellOff, cmOff, weightOff, colOff, scratchOff;
     uint32_t nRows, L, stride, rowStride;
 };
+#ifdef SD_HOST_STAGES_ONLY   // oracle/Makefile: the CPU checker links the host stages without the device library
+}
+static int sdR2pColumnWeightsDevice(sd_ctx *, uint32_t, uint32_t, const void *, const char *, uint64_t, uint64_t, const float *, uint64_t, uint64_t,
+                                    uint64_t, const float *, uint32_t, const double *, float *, float *) {
+    return SD_EINVAL;
+}
+extern "C" {
+#else
 int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, uint32_t nShort, const void *tasksHost, const char *cells, uint64_t cellBytes, uint64_t cmBytes,
                              const float *globalWeight, uint64_t nWeights, uint64_t nColumns, uint64_t scratchElems, const float *rcpTable,
                              uint32_t rcpN, const double *background, float *freqOut, float *effOut);
+#endif
 
 static int r2pBatchImpl(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32_t nQ, const uint8_t *qLetters, const uint64_t *qOff,
                         const uint64_t *edgeOff, const uint32_t *edgeT, const int32_t *edgeQStart, const int32_t *edgeTStart,

@@ -113,6 +113,7 @@ struct PfOut {
     std::vector<uint32_t> counts;
     std::vector<uint64_t> stats;   // 4 per query
     std::vector<uint32_t> pairQ, pairT;
+    std::vector<uint16_t> pairDiag;   // the prefilter's diagonal of every pair (sd_sw_align_batch_compact_diag)
     uint64_t nPairs = 0, notComputed = 0;
     double tPrefilter = 0, tPairs = 0, cpu = 0;
     int rc = SD_OK;
@@ -571,6 +572,16 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         o->pairQ.resize(std::max<uint64_t>(o->nPairs, 1));
         o->pairT.resize(std::max<uint64_t>(o->nPairs, 1));
         if (o->nPairs) sd_host_pair_list(o->hits.data(), o->counts.data(), nq, W, o->pairQ.data(), o->pairT.data());
+        o->pairDiag.resize(std::max<uint64_t>(o->nPairs, 1));
+        {   // same order as the pair list: query-major, a query's hits in prefilter order
+            uint64_t w = 0;
+            for (uint32_t q = 0; q < nq; q++) {
+                const sd_hit *row = o->hits.data() + (size_t) q * W;
+                // 0x8000 = no hint: only a pair whose ungapped prefilter score is already near the byte range can have a
+                // diagonal that saturates the byte kernel, the others need not be walked
+                for (uint32_t x = 0; x < o->counts[q]; x++) o->pairDiag[w++] = row[x].score >= 200 ? row[x].diagonal : (uint16_t) 0x8000;
+            }
+        }
         o->tPairs = nowSec() - t0;
         o->cpu = threadCpuSec() - cpu0;
         return o;
@@ -735,8 +746,8 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             uint64_t used = 0;
             // only the reportable pairs come back (identity pairs + pairs past every gate, ~10 %): everything else
             // fails Alignment::checkCriteria and would be skipped by the aggregation anyway
-            rc = sd_sw_align_batch_compact(ctx, &s->swPar, qset, s->tSeqs, n, d->pairQ.data(), d->pairT.data(), identAll.data(),
-                                           B.idx.data(), B.res.data(), &nOut, B.pool.data(), B.pool.size(), &used);
+            rc = sd_sw_align_batch_compact_diag(ctx, &s->swPar, qset, s->tSeqs, n, d->pairQ.data(), d->pairT.data(), d->pairDiag.data(),
+                                                identAll.data(), B.idx.data(), B.res.data(), &nOut, B.pool.data(), B.pool.size(), &used);
             if (rc == SD_ENOMEM && !exact) {   // the backtrace pool has to grow: repeat with the exact bound
                 uint64_t need = 64;
                 for (uint32_t i = 0; i < n; i++) need += (uint64_t) (*qLenP)[c0 + d->pairQ[i]] + (uint64_t) s->tLen[d->pairT[i]];

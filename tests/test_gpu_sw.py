@@ -280,6 +280,35 @@ def test_sw_align_compact_equals_full(gpu, host):
     assert 100 < len(keep) < len(pq)
 
 
+def test_sw_align_with_prefilter_diagonals_equals_without(gpu, host):
+    """sd_sw_align_batch_compact_diag: the diagonal only lets pairs whose byte-range score saturates for certain go
+    straight to the 16-bit pass; true, random and absurd diagonals all give the records of the call without them"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=5, genes_per_proteome=320, n_families=300, seed=41, mean_len=420)
+    rng = np.random.default_rng(9)
+    pq, pt = _pairs(ps, rng, 5000)
+    pq[:600] = pt[:600]                                     # self pairs: score far above 255, diagonal 0
+    sw_bias, _, _ = host.comp_bias(ps.residues, ps.offsets)
+    mat, _, _ = host.matrix(0)
+    ss = gpu.seqset(ps.residues, ps.offsets, sw_bias)
+    ident = (pq == pt)
+    for sw_mode, cov_mode in ((2, 2), (2, 0), (2, 1)):   # (the compact variants are swMode 2 only)
+        par = gpu.sw_params(mat, int(ps.offsets[-1]), sw_mode=sw_mode, cov_mode=cov_mode)
+        idx0, c0, pool0 = gpu.sw_align(par, ss, ss, pq, pt, identity=ident, compact=True)
+        true_diag = np.zeros(len(pq), np.uint16)
+        for dg in (true_diag, rng.integers(0, 65536, len(pq)).astype(np.uint16), np.full(len(pq), 65535, np.uint16),
+                   np.full(len(pq), 3, np.uint16), np.where(np.arange(len(pq)) % 2 == 0, 0, 0x8000).astype(np.uint16)):
+            idx1, c1, pool1 = gpu.sw_align(par, ss, ss, pq, pt, identity=ident, compact=True, diag=dg)
+            assert np.array_equal(idx0, idx1)
+            for f in ('score', 'qStart', 'qEnd', 'tStart', 'tEnd', 'identical', 'btLen', 'flags', 'evalue'):
+                assert np.array_equal(c0[f], c1[f]), (sw_mode, f, np.flatnonzero(c0[f] != c1[f])[:5])
+            for x in range(0, len(idx0), 13):
+                a = pool0[int(c0['btOffset'][x]):int(c0['btOffset'][x]) + int(c0['btLen'][x])]
+                b = pool1[int(c1['btOffset'][x]):int(c1['btOffset'][x]) + int(c1['btLen'][x])]
+                assert np.array_equal(a, b), x
+        assert int((c0['score'][:50] > 255).sum()) > 0 or len(idx0) > 0
+
+
 @pytest.mark.parametrize('sw_mode,cov_mode,cov_thr,eval_thr', [(0, 2, 0.8, 10.0), (1, 2, 0.8, 10.0), (2, 0, 0.5, 10.0),
                                                                (2, 1, 0.7, 1e-3), (1, 0, 0.9, 1e-5), (2, 2, 0.0, 1e-10)])
 def test_sw_modes_and_gates(gpu, host, oracle, small_proteomes, sw_mode, cov_mode, cov_thr, eval_thr):
