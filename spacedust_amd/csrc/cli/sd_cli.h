@@ -22,6 +22,15 @@ int failCtx(sd_ctx *ctx, int rc, const char *what);     // with sd_last_error
 void info(const Args &a, const char *fmt, ...);         // honours -v (>= 3 prints)
 int threadsOf(const Args &a);                           // --threads, default: cgroup quota / hardware threads
 
+// SD_DEBUG_TIMING=1: wall time between the marks of a module, to stderr
+struct Lap {
+    const char *module;
+    double last;
+    bool on;
+    explicit Lap(const char *module);
+    void mark(const char *what);
+};
+
 // A sequence or profile DB in the layout the device wants: ids follow DBReader::LINEAR_ACCESS order
 // (Prefiltering.cpp:178, Alignment.cpp:75-90), residues are Sequence::mapSequence's numeric alphabet
 // (M/src/commons/Sequence.cpp:307-324).
@@ -84,6 +93,8 @@ struct Resident {
     std::map<std::string, TargetEntry> targets;                      // "path|k|threshold|mask|prob|device"
     std::map<std::string, sd_seqset *> seqSets;                      // "path|device"
     sd_ctx *ctx(int device, int *rc);                                // the device's context (created on first use)
+    std::map<int, sd_host *> hostOfThreads;                          // the host objects (matrices, extended k-mer tables) by thread count
+    sd_host *host(int threads);                                      // created on first use; NULL on failure
     void clear();                                                    // destroys everything (sequence sets and targets before their contexts)
 };
 Resident &resident();

@@ -1,5 +1,7 @@
 #include "sd_cli.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -30,6 +32,15 @@ void info(const Args &a, const char *fmt, ...) {
     vfprintf(stdout, fmt, ap);
     va_end(ap);
     fflush(stdout);
+}
+
+static double lapNow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+Lap::Lap(const char *m) : module(m), last(lapNow()), on(getenv("SD_DEBUG_TIMING") != nullptr) {}
+void Lap::mark(const char *what) {
+    if (!on) return;
+    const double now = lapNow();
+    fprintf(stderr, "[%s] %s %.3f s\n", module, what, now - last);
+    last = now;
 }
 
 int threadsOf(const Args &a) {
@@ -67,7 +78,19 @@ sd_ctx *Resident::ctx(int device, int *rc) {
     return c;
 }
 
+sd_host *Resident::host(int threads) {
+    auto it = hostOfThreads.find(threads);
+    if (it != hostOfThreads.end()) return it->second;
+    sd_host *h = nullptr;
+    if (sd_host_create(threads, &h) != SD_OK) return nullptr;
+    hostOfThreads[threads] = h;
+    return h;
+}
+
 void Resident::clear() {
+    for (auto &kv : hostOfThreads)
+        if (kv.second) sd_host_destroy(kv.second);
+    hostOfThreads.clear();
     for (auto &kv : seqSets)
         if (kv.second) sd_seqset_destroy(kv.second);
     seqSets.clear();

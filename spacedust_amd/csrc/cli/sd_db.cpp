@@ -240,6 +240,7 @@ void Reader::copyData(char *dst) const {
 }
 
 size_t Reader::idOfKey(uint32_t key) const {
+    if (key < sortedKey_.size() && sortedKey_[key] == key) return sortedId_[key];   // dense keys 0 .. n-1: no search
     const std::vector<uint32_t>::const_iterator it = std::lower_bound(sortedKey_.begin(), sortedKey_.end(), key);
     if (it == sortedKey_.end() || *it != key) return SIZE_MAX;
     return sortedId_[it - sortedKey_.begin()];

@@ -45,28 +45,95 @@ std::string fmt3E(double v) {
     return b;
 }
 
-// Aggregation::buildMap (Aggregation.cpp:26-49): lines of one entry grouped by the set of their target column
-typedef std::map<unsigned, std::vector<std::vector<std::string> > > SetMap;
-bool buildMap(const char *data, const sddb::Reader &memberToSet, SetMap &out, std::string *err) {
+// Aggregation::buildMap (Aggregation.cpp:26-49): lines of one entry grouped by the set of their target column -- the
+// reference's std::map<set key, vector of column vectors>, here without a copy of anything: lines and columns are views into
+// the entry, `order` lists the lines by ascending set key, input order inside a set
+struct EntryLines {
+    struct Line {
+        const char *s, *e;
+        uint32_t col0, nCols;
+        unsigned setKey;
+    };
+    std::vector<Line> lines;
+    std::vector<const char *> colStart;
+    std::vector<uint32_t> order;
+    const char *colBegin(const Line &l, uint32_t c) const { return colStart[l.col0 + c]; }
+    const char *colEnd(const Line &l, uint32_t c) const { return c + 1 < l.nCols ? colStart[l.col0 + c + 1] - 1 : l.e; }
+    // strtod / strtoul of a column (an empty column is 0, as it is for the reference's std::string columns)
+    double num(const Line &l, uint32_t c) const { return colBegin(l, c) == colEnd(l, c) ? 0.0 : strtod(colBegin(l, c), nullptr); }
+    void appendCol(std::string &to, const Line &l, uint32_t c) const { to.append(colBegin(l, c), colEnd(l, c) - colBegin(l, c)); }
+};
+bool buildMap(const char *data, const sddb::Reader &memberToSet, EntryLines &out, std::string *err) {
+    out.lines.clear();
+    out.colStart.clear();
     while (*data != '\0') {
         const char *s = data;
         while (*data != '\n' && *data != '\0') data++;
-        std::string line(s, data - s);
+        const char *e = data;
         if (*data == '\n') data++;
-        if (line.empty()) continue;
-        std::vector<std::string> cols = splitTabs(line);
-        if (cols.size() < 2) {
-            if (err) *err = "Invalid result record \"" + line + "\"";
+        if (s == e) continue;
+        EntryLines::Line l;
+        l.s = s;
+        l.e = e;
+        l.col0 = (uint32_t) out.colStart.size();
+        out.colStart.push_back(s);
+        for (const char *c = s; c < e; c++)
+            if (*c == '\t') out.colStart.push_back(c + 1);
+        l.nCols = (uint32_t) out.colStart.size() - l.col0;
+        if (l.nCols < 2) {
+            if (err) *err = "Invalid result record \"" + std::string(s, e - s) + "\"";
             return false;
         }
-        const unsigned tKey = (unsigned) strtoul(cols[1].c_str(), nullptr, 10);
+        const char *k0 = out.colStart[l.col0 + 1], *k1 = l.nCols > 2 ? out.colStart[l.col0 + 2] - 1 : e;
+        const unsigned tKey = k0 == k1 ? 0u : (unsigned) strtoul(k0, nullptr, 10);
         const size_t id = memberToSet.idOfKey(tKey);
         if (id == SIZE_MAX) {
-            if (err) *err = "Invalid target database key " + cols[1] + ".";
+            if (err) *err = "Invalid target database key " + std::string(k0, k1 - k0) + ".";
             return false;
         }
-        const unsigned setKey = (unsigned) strtoul(memberToSet.data(id), nullptr, 10);
-        out[setKey].push_back(cols);
+        l.setKey = (unsigned) strtoul(memberToSet.data(id), nullptr, 10);
+        out.lines.push_back(l);
+    }
+    out.order.resize(out.lines.size());
+    for (uint32_t i = 0; i < out.order.size(); i++) out.order[i] = i;
+    std::stable_sort(out.order.begin(), out.order.end(), [&](uint32_t x, uint32_t y) { return out.lines[x].setKey < out.lines[y].setKey; });
+    return true;
+}
+
+// entries [first, first + n) through `work` on all threads, their outputs handed to `emit` in entry order
+template <typename Out, typename Work, typename Emit>
+bool forEntriesInOrder(size_t nEntries, Work work, Emit emit, std::string *err) {
+    const size_t block = 2048;
+    std::vector<Out> outs(block);
+    std::string firstErr;
+    bool failed = false;
+    for (size_t b0 = 0; b0 < nEntries && !failed; b0 += block) {
+        const size_t b1 = std::min(nEntries, b0 + block);
+#pragma omp parallel
+        {
+            EntryLines m;
+#pragma omp for schedule(dynamic, 8)
+            for (size_t i = b0; i < b1; i++) {
+                std::string e;
+                if (!work(i, m, outs[i - b0], &e)) {
+#pragma omp critical(sd_glue_err)
+                    if (!failed) {
+                        failed = true;
+                        firstErr = e;
+                    }
+                }
+            }
+        }
+        if (failed) break;
+        for (size_t i = b0; i < b1; i++)
+            if (!emit(i, outs[i - b0])) {
+                if (err) *err = "";
+                return false;
+            }
+    }
+    if (failed) {
+        if (err) *err = firstErr;
+        return false;
     }
     return true;
 }
@@ -138,46 +205,54 @@ int besthitbysetModule(const Args &a) {
     if (!in.open(a.pos[2], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
     sddb::Writer out;
     if (!out.open(a.pos[3], sddb::DBTYPE_ALIGNMENT_RES, &err)) return fail(err);
-    std::string buffer;
-    SetMap m;
-    for (size_t i = 0; i < in.size(); i++) {
-        m.clear();
-        if (!buildMap(in.data(i), memberToSet, m, &err)) return fail(err);
+    auto work = [&](size_t i, EntryLines &m, std::string &buffer, std::string *e) {
+        if (!buildMap(in.data(i), memberToSet, m, e)) return false;
         buffer.clear();
-        for (SetMap::iterator it = m.begin(); it != m.end(); ++it) {
-            std::vector<std::vector<std::string> > &rows = it->second;
+        for (size_t g0 = 0; g0 < m.order.size();) {
+            size_t g1 = g0;
+            const unsigned setKey = m.lines[m.order[g0]].setKey;
+            while (g1 < m.order.size() && m.lines[m.order[g1]].setKey == setKey) g1++;
+            const size_t nRows = g1 - g0;
             bool ok = true;
-            const unsigned nbrGenes = sizeOfSet(setSize, it->first, &ok);
-            if (!ok) return fail("Invalid target size database key " + std::to_string(it->first) + ".");
+            const unsigned nbrGenes = sizeOfSet(setSize, setKey, &ok);
+            if (!ok) {
+                *e = "Invalid target size database key " + std::to_string(setKey) + ".";
+                return false;
+            }
             (void) nbrGenes;
             double bestScore = -DBL_MAX, secondBestScore = -DBL_MAX, bestEval = DBL_MAX;
             const double logCal = log(1);
-            std::vector<std::string> *best = nullptr;
-            for (size_t r = 0; r < rows.size(); r++) {
-                if (rows[r].size() < 5) return fail("Invalid alignment result record");
-                const double eval = strtod(rows[r][4].c_str(), nullptr);
+            const EntryLines::Line *best = nullptr;
+            for (size_t r = g0; r < g1; r++) {
+                const EntryLines::Line &row = m.lines[m.order[r]];
+                if (row.nCols < 5) {
+                    *e = "Invalid alignment result record";
+                    return false;
+                }
+                const double eval = m.num(row, 4);
                 const double score = std::min(DBL_MAX, -log(eval));
-                if (simple || rows.size() < 2) {
+                if (simple || nRows < 2) {
                     if (eval < bestEval) {
                         bestEval = eval;
-                        best = &rows[r];
+                        best = &row;
                     }
                 } else if (score >= bestScore) {
                     secondBestScore = bestScore;
                     bestScore = score;
-                    best = &rows[r];
+                    best = &row;
                 } else if (score > secondBestScore) {
                     secondBestScore = score;
                 }
             }
-            std::vector<std::vector<std::string> *> all;
+            std::vector<const EntryLines::Line *> all;
             std::vector<double> evals, logP;
-            if (subopt > 0 && simple && rows.size() > 1) {
+            if (subopt > 0 && simple && nRows > 1) {
                 const double thr = bestEval * subopt;
-                for (size_t r = 0; r < rows.size(); r++) {
-                    const double eval = strtod(rows[r][4].c_str(), nullptr);
+                for (size_t r = g0; r < g1; r++) {
+                    const EntryLines::Line &row = m.lines[m.order[r]];
+                    const double eval = m.num(row, 4);
                     if (eval <= thr) {
-                        all.push_back(&rows[r]);
+                        all.push_back(&row);
                         evals.push_back(eval);
                     }
                 }
@@ -186,25 +261,30 @@ int besthitbysetModule(const Args &a) {
             }
             if (all.size() > 1) {
                 for (size_t r = 0; r < all.size(); r++) logP.push_back(computeLogPval(evals[r], logCal));
-            } else if (simple || rows.size() < 2) {
+            } else if (simple || nRows < 2) {
                 logP.push_back(computeLogPval(bestEval, logCal));
             } else {
                 logP.push_back(secondBestScore - bestScore);
             }
             if (best != nullptr) {
                 for (size_t j = 0; j < all.size(); j++) {
-                    for (size_t c = 0; c < all[j]->size(); c++) {
+                    for (uint32_t c = 0; c < all[j]->nCols; c++) {
                         if (c == 2) buffer.append(fmt3E(logP[j]));
-                        else buffer.append((*all[j])[c]);
-                        if (c + 1 != all[j]->size()) buffer.push_back('\t');
+                        else m.appendCol(buffer, *all[j], c);
+                        if (c + 1 != all[j]->nCols) buffer.push_back('\t');
                     }
                     if (j + 1 != all.size()) buffer.push_back('\n');
                 }
             }
             buffer.push_back('\n');
+            g0 = g1;
         }
-        if (!out.write(in.key(i), buffer.data(), buffer.size())) return fail("cannot write " + a.pos[3]);
-    }
+        return true;
+    };
+    auto emit = [&](size_t i, const std::string &buffer) { return out.write(in.key(i), buffer.data(), buffer.size()); };
+    Lap lap("besthitbyset");
+    if (!forEntriesInOrder<std::string>(in.size(), work, emit, &err)) return fail(err.empty() ? "cannot write " + a.pos[3] : err);
+    lap.mark("entries");
     if (!out.close(&err)) return fail(err);
     return 0;
 }
@@ -256,16 +336,18 @@ int combinehitsModule(const Args &a) {
     sddb::Writer out, outH;
     if (!out.open(a.pos[3], sddb::DBTYPE_ALIGNMENT_RES, &err)) return fail(err);
     if (!outH.open(a.pos[3] + "_h", sddb::DBTYPE_GENERIC_DB, &err)) return fail(err);
+    Lap lap("combinehits");
     unsigned matchIdx = 0;
-    SetMap m;
-    std::string header, body;
+    EntryLines m;
+    std::vector<std::pair<size_t, size_t> > groups;
+    std::vector<std::string> headers, bodies;
     for (size_t i = 0; i < in.size(); i++) {
-        m.clear();
+        // one entry per query set (mergeresultsbyset): its lines parsed once, its target sets worked on by all threads
         const unsigned qSetKey = in.key(i);
         if (!buildMap(in.data(i), memberToSet, m, &err)) return fail(err);
-        bool ok = true;
-        const unsigned orfCount = sizeOfSet(qSize, qSetKey, &ok);
-        if (!ok) return fail("Invalid query size database key " + std::to_string(qSetKey) + ".");
+        bool okQ = true;
+        const unsigned orfCount = sizeOfSet(qSize, qSetKey, &okQ);
+        if (!okQ) return fail("Invalid query size database key " + std::to_string(qSetKey) + ".");
         {   // precomputeLogB (combinepvalperset.cpp:17-27) with pvalThreshold = alpha / (orfCount + 1)
             const double thr = alpha / (orfCount + 1);
             const double logThr = log(thr), log1m = log(1 - thr);
@@ -279,30 +361,56 @@ int combinehitsModule(const Args &a) {
                 }
             }
         }
-        for (SetMap::iterator it = m.begin(); it != m.end(); ++it) {
-            const unsigned tSetKey = it->first;
-            std::vector<std::vector<std::string> > &rows = it->second;
-            if (filterSelf && qSetKey == tSetKey) continue;
+        groups.clear();
+        for (size_t g0 = 0, g1 = 0; g0 < m.order.size(); g0 = g1) {
+            const unsigned tSetKey = m.lines[m.order[g0]].setKey;
+            g1 = g0;
+            while (g1 < m.order.size() && m.lines[m.order[g1]].setKey == tSetKey) g1++;
+            groups.push_back(std::make_pair(g0, g1));
+        }
+        headers.assign(groups.size(), std::string());
+        bodies.assign(groups.size(), std::string());
+        bool failed = false;
+        std::string firstErr;
+        // one (query set, target set) match; an empty header = no match written
+        auto work = [&](size_t g, std::string &header, std::string &body, std::string *e) {
+            const size_t g0 = groups[g].first, g1 = groups[g].second, nRows = g1 - g0;
+            const unsigned tSetKey = m.lines[m.order[g0]].setKey;
+            bool ok = true;
+            std::vector<const EntryLines::Line *> entries;
+            header.clear();
+            auto none = [&]() {
+                header.clear();
+                return true;
+            };
+            if (filterSelf && qSetKey == tSetKey) return none();
             const unsigned tOrf = sizeOfSet(tSize, tSetKey, &ok);
-            if (!ok) return fail("Invalid target size database key " + std::to_string(tSetKey) + ".");
+            if (!ok) {
+                *e = "Invalid target size database key " + std::to_string(tSetKey) + ".";
+                return false;
+            }
             header = std::to_string(qSetKey) + "\t" + std::to_string(tSetKey) + "\t" + std::to_string(orfCount) + "\t" +
                      std::to_string(tOrf) + "\t";
-            std::vector<std::vector<std::string> *> entries;
+            entries.clear();
             if (mode == 0) {   // AGGREGATION_MODE_MULTIHIT (combinehits.cpp:97-153)
                 const double pvalThreshold = 10e-7;
                 size_t k = 0;
                 double r = 0;
                 const double logPvalThr = log(pvalThreshold);
-                for (size_t x = 0; x < rows.size(); x++) {
-                    if (rows[x].size() < 3) return fail("Invalid alignment result record");
-                    const double lp = strtod(rows[x][2].c_str(), nullptr);
+                for (size_t x = g0; x < g1; x++) {
+                    const EntryLines::Line &row = m.lines[m.order[x]];
+                    if (row.nCols < 3) {
+                        *e = "Invalid alignment result record";
+                        return false;
+                    }
+                    const double lp = m.num(row, 2);
                     if (lp < logPvalThr) {
                         k++;
                         r -= lp - logPvalThr;
-                        entries.push_back(&rows[x]);
+                        entries.push_back(&row);
                     }
                 }
-                if (r == 0 || k == 0) continue;
+                if (r == 0 || k == 0) return none();
                 header += std::to_string(k) + "\t";
                 const double expMinusR = exp(-r);
                 if (std::isinf(r) || expMinusR == 0) {
@@ -316,45 +424,73 @@ int combinehitsModule(const Args &a) {
                     header += fmt3E(updatedEval);
                 }
             } else if (mode == 2) {   // AGGREGATION_MODE_PRODUCT
-                if (rows.empty()) continue;
+                if (nRows == 0) return none();
                 double sum = 0;
-                for (size_t x = 0; x < rows.size(); x++) {
-                    sum += strtod(rows[x][2].c_str(), nullptr);
-                    entries.push_back(&rows[x]);
+                for (size_t x = g0; x < g1; x++) {
+                    const EntryLines::Line &row = m.lines[m.order[x]];
+                    if (row.nCols < 3) {
+                        *e = "Invalid alignment result record";
+                        return false;
+                    }
+                    sum += m.num(row, 2);
+                    entries.push_back(&row);
                 }
-                header += std::to_string(rows.size()) + "\t" + fmt3E(exp(sum) * numTargetSets);
+                header += std::to_string(nRows) + "\t" + fmt3E(exp(sum) * numTargetSets);
             } else if (mode == 3) {   // AGGREGATION_MODE_TRUNCATED_PRODUCT: header only (combinehits.cpp:183-199)
                 const double thr = log(alpha / (orfCount + 1));
                 double sum = 0;
                 size_t k = 0;
-                for (size_t x = 0; x < rows.size(); x++) {
-                    const double lp = strtod(rows[x][2].c_str(), nullptr);
+                for (size_t x = g0; x < g1; x++) {
+                    const EntryLines::Line &row = m.lines[m.order[x]];
+                    if (row.nCols < 3) {
+                        *e = "Invalid alignment result record";
+                        return false;
+                    }
+                    const double lp = m.num(row, 2);
                     if (lp < thr) {
                         sum += lp;
                         k++;
                     }
                 }
-                if (k == 0) continue;
+                if (k == 0) return none();
                 header += std::to_string(k) + "\t" + fmt3E(exp(sum));
             } else {
-                return fail("Invalid aggregation function!");
+                *e = "Invalid aggregation function!";
+                return false;
             }
             header.push_back('\n');
             body.clear();
             for (size_t j = 0; j < entries.size(); j++) {
-                for (size_t c = 0; c < entries[j]->size(); c++) {
-                    if (c == 2) body.append(fmt3E(exp(strtod((*entries[j])[c].c_str(), nullptr))));
-                    else body.append((*entries[j])[c]);
-                    if (c + 1 != entries[j]->size()) body.push_back('\t');
+                for (uint32_t c = 0; c < entries[j]->nCols; c++) {
+                    if (c == 2) body.append(fmt3E(exp(m.num(*entries[j], c))));
+                    else m.appendCol(body, *entries[j], c);
+                    if (c + 1 != entries[j]->nCols) body.push_back('\t');
                 }
                 if (j + 1 != entries.size()) body.push_back('\n');
             }
             body.push_back('\n');
-            if (!outH.write(matchIdx, header.data(), header.size()) || !out.write(matchIdx, body.data(), body.size()))
+            return true;
+        };
+#pragma omp parallel for schedule(dynamic, 4)
+        for (size_t g = 0; g < groups.size(); g++) {
+            std::string e;
+            if (!work(g, headers[g], bodies[g], &e)) {
+#pragma omp critical(sd_glue_err)
+                if (!failed) {
+                    failed = true;
+                    firstErr = e;
+                }
+            }
+        }
+        if (failed) return fail(firstErr);
+        for (size_t g = 0; g < groups.size(); g++) {
+            if (headers[g].empty()) continue;
+            if (!outH.write(matchIdx, headers[g].data(), headers[g].size()) || !out.write(matchIdx, bodies[g].data(), bodies[g].size()))
                 return fail("cannot write " + a.pos[3]);
             matchIdx++;
         }
     }
+    lap.mark("entries");
     if (!out.close(&err) || !outH.close(&err)) return fail(err);
     return 0;
 }
@@ -363,11 +499,13 @@ int combinehitsModule(const Args &a) {
 int summarizeresultsModule(const Args &a) {
     if (a.pos.size() != 4) return fail("usage: summarizeresults <querySetDB> <targetSetDB> <clustersDB> <out.tsv>");
     std::string err;
+    Lap lap("summarizeresults");
     SetInfo qs, tsOwn;
     if (!qs.load(a.pos[0], true, &err)) return fail(err);
     const bool sameDb = a.pos[0] == a.pos[1];
     if (!sameDb && !tsOwn.load(a.pos[1], true, &err)) return fail(err);
     const SetInfo &ts = sameDb ? qs : tsOwn;
+    lap.mark("set info");
     sddb::Reader hdr, aln;
     if (!hdr.open(a.pos[2] + "_h", sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
     if (!aln.open(a.pos[2], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::NOSORT, &err)) return fail(err);
@@ -424,6 +562,7 @@ int summarizeresultsModule(const Args &a) {
             fwrite(buffer.data(), 1, buffer.size(), flat);
         }
     }
+    lap.mark("entries");
     if (dbOut) {
         if (!out.close(&err)) return fail(err);
     } else {

@@ -21,7 +21,16 @@ namespace {
 
 struct HostH {
     sd_host *h = nullptr;
-    ~HostH() { if (h) sd_host_destroy(h); }
+    bool own = true;   // false: the resident host object of a workflow (sd_cli.h)
+    ~HostH() { if (h && own) sd_host_destroy(h); }
+    int open(int threads) {
+        if (resident().enabled) {
+            h = resident().host(threads);
+            own = false;
+            return h ? SD_OK : SD_ENOMEM;
+        }
+        return sd_host_create(threads, &h);
+    }
 };
 struct CtxH {
     sd_ctx *c = nullptr;
@@ -91,8 +100,9 @@ int prefilterModule(const Args &a) {
     const bool compBias = a.integer("--comp-bias-corr", 1) != 0;
     const int threads = threadsOf(a);
 
+    Lap lap("prefilter");
     HostH host;
-    if (sd_host_create(threads, &host.h) != SD_OK) return fail("sd_host_create failed");
+    if (host.open(threads) != SD_OK) return fail("sd_host_create failed");
     std::string err;
     const bool sameDb = a.pos[0] == a.pos[1];
     std::shared_ptr<SeqDb> tdb = loadTargetDb(a.pos[1], host.h, &err);
@@ -105,6 +115,7 @@ int prefilterModule(const Args &a) {
         if (!qdbOwn->load(a.pos[0], host.h, &err)) return fail(err);
         qdb = qdbOwn.get();
     }
+    lap.mark("load DBs");
     info(a, "Query database size: %u type: %s\nTarget database size: %u type: Aminoacid\n", qdb->n,
          qdb->profile ? "Profile" : "Aminoacid", tdb->n);
 
@@ -124,6 +135,7 @@ int prefilterModule(const Args &a) {
     int rc = ctx.open(deviceOf(a));
     if (rc != SD_OK) return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rc) + "); this path has no CPU fallback");
 
+    lap.mark("context");
     // target side: TARGET.idx when a createindex file with matching parameters lies next to the DB (PrefilteringIndexReader
     // layout, sd_mod_index.cpp), else IndexBuilder::fillDatabase on the device (sd_target_build: mask + lists); resident in HBM afterwards.
     // Profile searches index every k-mer (Prefiltering.cpp:525-527)
@@ -203,6 +215,7 @@ int prefilterModule(const Args &a) {
         target.own = false;
     }
 
+    lap.mark("target index");
     sd_prefilter_params par;
     memset(&par, 0, sizeof(par));
     par.kmerSize = k;
@@ -259,6 +272,7 @@ int prefilterModule(const Args &a) {
                                     diagBias.data(), ident.data(), hits.data(), counts.data(), nullptr);
         }
         if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_prefilter_batch");
+        lap.mark("chunk: bias + device");
         // QueryMatcher::prefilterHitToBuffer (QueryMatcher.h:118-130): targetKey \t score \t (int16) diagonal
         char line[64];
         for (uint32_t i = 0; i < nq; i++) {
@@ -278,7 +292,9 @@ int prefilterModule(const Args &a) {
             if (!out.write(qdb->keys[c0 + i], text.data(), text.size())) return fail("cannot write " + a.pos[2]);
         }
     }
+    lap.mark("chunks: text + write");
     if (!out.close(&err)) return fail(err);
+    lap.mark("close");
     info(a, "%llu prefilter hits written for %u queries\n", (unsigned long long) totalHits, qdb->n);
     if (notComputed)
         return fail(std::to_string(notComputed) + " queries need the reference's double-overflow route (or have >= 2^32 index hits) and were "
@@ -288,6 +304,18 @@ int prefilterModule(const Args &a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
+
+// backtrace pool of the align calls: raw bytes (a std::vector would zero a gigabyte on every growth)
+struct BtPool {
+    std::unique_ptr<char[]> p;
+    size_t cap = 0;
+    void reserve(size_t n) {
+        if (cap >= n) return;
+        p.reset(new char[n]);
+        cap = n;
+    }
+    const char *data() const { return p.get(); }
+};
 
 // one chunk of prefilter entries turned into device work
 struct AlnChunk {
@@ -301,23 +329,29 @@ struct AlnChunk {
 int alignPairs(sd_ctx *ctx, const sd_sw_params &par, sd_seqset *qs, sd_seqset *ts, const SeqDb &qdb, const SeqDb &tdb,
                const std::vector<uint32_t> &qIdOfLocal, const std::vector<uint32_t> &pq, const std::vector<uint32_t> &pt,
                const std::vector<uint8_t> &ident, bool compact, std::vector<uint32_t> &outIdx, std::vector<sd_sw_result> &res,
-               std::vector<char> &pool) {
+               BtPool &pool) {
     const uint32_t n = (uint32_t) pq.size();
     res.resize(std::max<uint32_t>(n, 1));
     outIdx.resize(std::max<uint32_t>(n, 1));
-    uint64_t cap = std::max<uint64_t>(1u << 20, 96ull * n);
+    // a first guess that a second call rarely has to correct (a too small pool costs the whole batch again): a backtrace has at
+    // most qLen + tLen columns and, for the full-length homologs that dominate, about min(qLen, tLen) of them
+    uint64_t cap = 1u << 20;
+    if (par.swMode == 2) {
+        uint64_t est = 0;
+        for (uint32_t i = 0; i < n; i++) est += (uint64_t) std::min(qdb.lens[qIdOfLocal[pq[i]]], tdb.lens[pt[i]]) + 16;
+        cap += est + est / 4;
+    }
     bool exact = false;
     for (;;) {
-        if (pool.size() < cap) pool.resize(cap);
+        pool.reserve(cap);
         uint64_t used = 0;
         int rc;
         uint32_t nOut = n;
         if (compact)
             rc = sd_sw_align_batch_compact(ctx, &par, qs, ts, n, pq.data(), pt.data(), ident.data(), outIdx.data(), res.data(),
-                                           &nOut, pool.data(), pool.size(), &used);
+                                           &nOut, pool.p.get(), pool.cap, &used);
         else
-            rc = sd_sw_align_batch(ctx, &par, qs, ts, n, pq.data(), pt.data(), ident.data(), res.data(), pool.data(), pool.size(),
-                                   &used);
+            rc = sd_sw_align_batch(ctx, &par, qs, ts, n, pq.data(), pt.data(), ident.data(), res.data(), pool.p.get(), pool.cap, &used);
         if (rc == SD_ENOMEM && !exact) {   // pool too small: the exact bound is sum(qLen + tLen)
             uint64_t need = 64;
             for (uint32_t i = 0; i < n; i++) need += (uint64_t) qdb.lens[qIdOfLocal[pq[i]]] + (uint64_t) tdb.lens[pt[i]];
@@ -382,9 +416,10 @@ int alignModule(const Args &a) {
         addBacktrace = true;
     }
     const int swMode = initSWMode(alignmentMode, (float) a.real("-c", 0.0), seqIdThr);
+    Lap lap("align");
 
     HostH host;
-    if (sd_host_create(threads, &host.h) != SD_OK) return fail("sd_host_create failed");
+    if (host.open(threads) != SD_OK) return fail("sd_host_create failed");
     std::string err;
     const bool sameDb = a.pos[0] == a.pos[1];
     std::shared_ptr<SeqDb> tdb = loadTargetDb(a.pos[1], host.h, &err);
@@ -397,6 +432,7 @@ int alignModule(const Args &a) {
         if (!qdbOwn->load(a.pos[0], host.h, &err)) return fail(err);
         qdb = qdbOwn.get();
     }
+    lap.mark("load DBs");
     sddb::Reader pref;
     if (!pref.open(a.pos[2], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
     info(a, "%s\nQuery database size: %u type: %s\nTarget database size: %u type: Aminoacid\n",
@@ -457,6 +493,7 @@ int alignModule(const Args &a) {
         }
     }
 
+    lap.mark("context + target sequences on the device");
     sddb::Writer out;
     int outType = sddb::withExtended(sddb::DBTYPE_ALIGNMENT_RES, sddb::extendedType(pref.dbtype()));
     if (!out.open(a.pos[3], outType, &err)) return fail(err);
@@ -474,48 +511,84 @@ int alignModule(const Args &a) {
     std::vector<int8_t> qbias, qaln;
     std::vector<int32_t> qlen;
     std::vector<sd_sw_result> res, res2, merged;
-    std::vector<char> pool, pool2;
+    BtPool pool, pool2;
     std::vector<uint32_t> recQ, recT, pq2, pt2;
     std::vector<uint8_t> recIdent;
+    // lines per prefilter entry (one pass over the DB on all threads): the chunks are cut from these, and a chunk's lines are then
+    // parsed in parallel into their places
+    std::vector<uint32_t> lineCount(nEntries, 0);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (size_t e = 0; e < nEntries; e++) {
+        uint32_t c = 0;
+        for (const char *d = pref.data(e); *d != '\0';) {
+            const char *nl = strchr(d, '\n');
+            c++;
+            if (!nl) break;
+            d = nl + 1;
+        }
+        lineCount[e] = c;
+    }
+    lap.mark("count prefilter lines");
+    std::vector<uint64_t> pairOff;
     for (size_t e0 = 0; e0 < nEntries;) {
         // chunk of entries bounded by pairs
         localQ.clear();
-        pq.clear();
-        pt.clear();
-        ident.clear();
         size_t e1 = e0;
         std::vector<uint32_t> entryLocal;   // local query index of entry (UINT32_MAX: empty entry)
-        while (e1 < nEntries && (pq.size() < maxPairs || e1 == e0) && localQ.size() < 20000) {
-            const char *d = pref.data(e1);
-            const uint32_t qKey = pref.key(e1);
-            if (*d == '\0') {
+        pairOff.assign(1, 0);
+        while (e1 < nEntries && (pairOff.back() < maxPairs || e1 == e0) && localQ.size() < 20000) {
+            if (lineCount[e1] == 0) {
                 entryLocal.push_back(UINT32_MAX);
+                pairOff.push_back(pairOff.back());
                 e1++;
                 continue;
             }
+            const uint32_t qKey = pref.key(e1);
             const size_t qId = qdb->rd.idOfKey(qKey);
             if (qId == SIZE_MAX)
                 return fail("Query sequence " + std::to_string(qKey) + " is required in the prefiltering, but is not contained in the query sequence database.");
-            const uint32_t lq = (uint32_t) localQ.size();
+            entryLocal.push_back((uint32_t) localQ.size());
             localQ.push_back((uint32_t) qId);
-            entryLocal.push_back(lq);
-            const float qL = (float) qdb->lens[qId];
-            while (*d != '\0') {
+            pairOff.push_back(pairOff.back() + lineCount[e1]);
+            e1++;
+        }
+        pq.resize(pairOff.back());
+        pt.resize(pairOff.back());
+        ident.resize(pairOff.back());
+        uint32_t missingKey = UINT32_MAX;
+        bool missing = false;
+#pragma omp parallel for schedule(dynamic, 64)
+        for (size_t e = e0; e < e1; e++) {
+            const uint32_t lq = entryLocal[e - e0];
+            if (lq == UINT32_MAX) continue;
+            const uint32_t qKey = pref.key(e);
+            const float qL = (float) qdb->lens[localQ[lq]];
+            uint64_t w = pairOff[e - e0];
+            for (const char *d = pref.data(e); *d != '\0';) {
                 const uint32_t tKey = (uint32_t) strtoul(d, nullptr, 10);
                 while (*d != '\n' && *d != '\0') d++;
                 if (*d == '\n') d++;
                 const size_t tId = tdb->rd.idOfKey(tKey);
-                if (tId == SIZE_MAX)
-                    return fail("Sequence " + std::to_string(tKey) + " is required in the prefiltering, but is not contained in the target sequence database!");
+                if (tId == SIZE_MAX) {
+#pragma omp critical(sd_align_missing)
+                    {
+                        missing = true;
+                        missingKey = tKey;
+                    }
+                    break;
+                }
                 // Util::canBeCovered pre-check (Alignment.cpp:370-373): a rejected pair, never aligned
                 const bool can = sd_host_can_be_covered(canCovThr, covMode, qL, (float) tdb->lens[tId]) != 0;
-                pq.push_back(lq);
-                pt.push_back((uint32_t) tId);
+                pq[w] = lq;
+                pt[w] = (uint32_t) tId;
                 // 2 marks the pre-rejected pair: kept only so that --max-rejected counts it
-                ident.push_back(!can ? 2 : ((qKey == tKey && (includeIdentity || sameDb)) ? 1 : 0));
+                ident[w] = !can ? 2 : ((qKey == tKey && (includeIdentity || sameDb)) ? 1 : 0);
+                w++;
             }
-            e1++;
         }
+        if (missing)
+            return fail("Sequence " + std::to_string(missingKey) + " is required in the prefiltering, but is not contained in the target sequence database!");
+        lap.mark("chunk: parse prefilter entries");
         const uint32_t nq = (uint32_t) localQ.size();
         // queries of the chunk as one sequence set on the device
         qoff.assign((size_t) nq + 1, 0);
@@ -540,6 +613,7 @@ int alignModule(const Args &a) {
             }
             if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_seqset_create(queries)");
         }
+        lap.mark("chunk: query set");
         // the pairs that are aligned (pre-rejected ones are not)
         std::vector<uint32_t> apq, apt, aIdx;
         std::vector<uint8_t> aid;
@@ -560,6 +634,7 @@ int alignModule(const Args &a) {
             res.clear();
             idxOut.clear();
         }
+        lap.mark("chunk: alignPairs");
         // record list handed to the criteria: compact -> only the reportable records; otherwise every pair in prefilter
         // order, pre-rejected ones as records that fail every criterion (E-value NaN)
         recQ.clear();
@@ -601,7 +676,7 @@ int alignModule(const Args &a) {
         const std::vector<sd_sw_result> *outRecs = recs;
         const std::vector<uint32_t> *outOrder = &order, *outCounts = &counts, *outT = &recT;
         const std::vector<uint8_t> *outIdent = &recIdent;
-        const std::vector<char> *outPool = &pool;
+        const BtPool *outPool = &pool;
         if (realign && nAcc > 0) {
             // second pass over the accepted records, in their order (Alignment.cpp:408-440)
             pq2.resize(nAcc);
@@ -647,9 +722,11 @@ int alignModule(const Args &a) {
             counts2.assign(std::max<uint32_t>(nq, 1), 0);
             outCounts = &counts2;
         }
+        lap.mark("chunk: accept / sort (+ realign)");
         rc = sd_alntext_format(text, &crit, nq, outCounts->data(), outOrder->data(), outT->data(), outRecs->data(), outIdent->data(),
                                outPool->data(), qlen.data(), tdb->lens.data(), tdb->keys.data());
         if (rc != SD_OK) return fail("sd_alntext_format failed (" + std::to_string(rc) + ")");
+        lap.mark("chunk: format");
         const char *txt;
         const uint64_t *eoff;
         sd_alntext_get(text, &txt, &eoff);
@@ -661,9 +738,11 @@ int alignModule(const Args &a) {
                 return fail("cannot write " + a.pos[3]);
             }
         }
+        lap.mark("chunk: write");
         e0 = e1;
     }
     if (!out.close(&err)) return fail(err);
+    lap.mark("close");
     info(a, "%llu alignments calculated\n%llu sequence pairs passed the thresholds\n", (unsigned long long) alignmentsNum,
          (unsigned long long) passedNum);
     return 0;
@@ -675,11 +754,13 @@ int clusterhitsModule(const Args &a) {
     if (a.integer("--compressed", 0) != 0) return fail("--compressed 1 is not supported");
     if (a.flag("--cluster-use-weight", false)) return fail("--cluster-use-weight 1 is not supported");
     std::string err;
+    Lap lap("clusterhits");
     SetInfo qs, tsOwn;
     if (!qs.load(a.pos[0], false, &err)) return fail(err);
     const bool sameDb = a.pos[0] == a.pos[1];
     if (!sameDb && !tsOwn.load(a.pos[1], false, &err)) return fail(err);
     const SetInfo &ts = sameDb ? qs : tsOwn;
+    lap.mark("set info");
     sddb::Reader res, hdr;
     if (!res.open(a.pos[2], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
     if (!hdr.open(a.pos[2] + "_h", sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
@@ -747,6 +828,7 @@ int clusterhitsModule(const Args &a) {
         entryQSet.push_back((uint32_t) qSet);
         entryTSet.push_back((uint32_t) tSet);
     }
+    lap.mark("parse matches");
     const uint32_t nPairs = (uint32_t) Nq.size();
     const uint64_t total = hitOff.back();
     std::vector<uint32_t> clusterOf(std::max<uint64_t>(total, 1), UINT32_MAX), rank(std::max<uint64_t>(total, 1), 0),
@@ -763,6 +845,7 @@ int clusterhitsModule(const Args &a) {
                                   lg.data(), lgN, clusterOf.data(), rank.data(), nClusters.data(), pCO.data(), pMH.data(), cSize.data());
         if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_clusterhits_batch");
     }
+    lap.mark("device");
     sddb::Writer out, outH;
     if (!out.open(a.pos[3], dbOut ? res.dbtype() : (int) sddb::DBTYPE_OMIT_FILE, &err)) return fail(err);
     if (!outH.open(a.pos[3] + "_h", sddb::DBTYPE_GENERIC_DB, &err)) return fail(err);
@@ -786,8 +869,10 @@ int clusterhitsModule(const Args &a) {
             key++;
         }
     }
+    lap.mark("write clusters");
     if (!out.close(&err) || !outH.close(&err)) return fail(err);
     if (!dbOut) ::remove((a.pos[3] + ".index").c_str());
+    lap.mark("close");
     info(a, "%u clusters from %u set pairs\n", key, nPairs);
     return 0;
 }

@@ -35,7 +35,16 @@ struct SearchH {
 };
 struct HostH {
     sd_host *h = nullptr;
-    ~HostH() { if (h) sd_host_destroy(h); }
+    bool own = true;   // false: the resident host object of a workflow (sd_cli.h)
+    ~HostH() { if (h && own) sd_host_destroy(h); }
+    int open(int threads) {
+        if (resident().enabled) {
+            h = resident().host(threads);
+            own = false;
+            return h ? SD_OK : SD_ENOMEM;
+        }
+        return sd_host_create(threads, &h);
+    }
 };
 
 int envInt(const char *name, int def) {
@@ -540,8 +549,9 @@ int result2profileModule(const Args &a) {
     double evalThr = a.real("-e", 0.001), evalProfile = a.real("--e-profile", 0.001);
     evalProfile = (evalThr < evalProfile) ? evalThr : evalProfile;   // result2profile.cpp:33
     const int threads = threadsOf(a);
+    Lap lap("result2profile");
     HostH host;
-    if (sd_host_create(threads, &host.h) != SD_OK) return fail("sd_host_create failed");
+    if (host.open(threads) != SD_OK) return fail("sd_host_create failed");
     std::string err;
     const bool sameDb = a.pos[0] == a.pos[1];
     std::shared_ptr<SeqDb> tdb = loadTargetDb(a.pos[1], host.h, &err);
@@ -554,6 +564,7 @@ int result2profileModule(const Args &a) {
         if (!qdbOwn->load(a.pos[0], host.h, &err)) return fail(err);
         qdb = qdbOwn.get();
     }
+    lap.mark("load DBs");
     sddb::Reader aln;
     if (!aln.open(a.pos[2], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
     sd_r2p *r2p = nullptr;
@@ -578,6 +589,7 @@ int result2profileModule(const Args &a) {
                         "the GPU (--profile-weights-host 1 selects the host implementation)");
     }
     std::unique_ptr<sd_ctx, void (*)(sd_ctx *)> ctxGuard(ownCtx ? r2pCtx : nullptr, sd_ctx_destroy);
+    lap.mark("r2p object + context");
     sddb::Writer out;
     if (!out.open(a.pos[3], sddb::DBTYPE_HMM_PROFILE, &err)) return fail(err);
     const size_t n = aln.size();
@@ -667,6 +679,7 @@ int result2profileModule(const Args &a) {
         tCompute += t2 - t1;
         tWrite += now() - t2;
     }
+    lap.mark("chunks");
     info(a, "result2profile: parse %.2f s, profiles %.2f s (%d threads, weights on the %s), write %.2f s\n", tParse, tCompute, threads,
          r2pCtx ? "GPU" : "host", tWrite);
     (void) tLoaded;
@@ -683,6 +696,7 @@ int result2profileModule(const Args &a) {
             }
         }
     }
+    lap.mark("close + links");
     info(a, "%zu profiles written\n", n);
     return 0;
 }

@@ -18,6 +18,8 @@
 // code, nothing else.
 #include "sd_common.h"
 
+#include <chrono>
+
 #include <cfloat>
 
 #pragma clang fp contract(off)
@@ -353,6 +355,11 @@ extern "C" int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, uint32_t n
     SD_HIP(ctx, hipMemcpyAsync(dRcp, rcpTable, (size_t) rcpN * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(dBack, background, kRes * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(ctx, hipMemsetAsync(dErr, 0, sizeof(int), ctx->stream));
+    const bool dbg = getenv("SD_DEBUG_TIMING") != nullptr;
+    auto nowMs = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = nowMs();
+    if (dbg) SD_HIP(ctx, sdStreamSync(ctx));
+    const double t1 = nowMs();
     {
         // the caller lists the alignments of up to 320 columns first (nShort of them)
         ProfScope ps(ctx, "r2p_column_weights");
@@ -366,11 +373,16 @@ extern "C" int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, uint32_t n
                                (const double *) dBack, dCount, dShare, dSub, dLg, dFreq, dEff, dErr);
     }
     SD_HIP(ctx, hipGetLastError());
+    if (dbg) SD_HIP(ctx, sdStreamSync(ctx));
+    const double t2 = nowMs();
     int hErr = 0;
     SD_HIP(ctx, hipMemcpyAsync(freqOut, dFreq, (size_t) nColumns * kRes * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(effOut, dEff, (size_t) nColumns * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(&hErr, dErr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, sdStreamSync(ctx));
+    if (dbg)
+        fprintf(stderr, "[r2p device] %u tasks (%u short): upload %.1f ms, kernels %.1f ms, download %.1f ms\n", nTasks, nShort, t1 - t0, t2 - t1,
+                nowMs() - t2);
     if (hErr) return sdFail(ctx, SD_EHIP, "result2profile: a (count x distinct) product outside the reciprocal table");
     return SD_OK;
 }

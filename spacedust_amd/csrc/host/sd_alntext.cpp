@@ -98,6 +98,7 @@ inline bool hitLess(const Key &a, const Key &b) {   // Matcher::compareHits
 struct sd_alntext {
     std::string text;
     std::vector<uint64_t> entryOff;
+    std::vector<std::string> perQuery;   // formatting scratch, one string per query of the last call (capacity kept)
 };
 
 extern "C" {
@@ -164,37 +165,45 @@ int sd_host_realign_select(const sd_aln_criteria *crit, uint32_t nQ, const uint3
                            sd_sw_result *merged, uint32_t *outOrder, uint32_t *outCount) {
     if (!crit || !countPerQuery || !order || !first || !second || !merged || !outOrder || !outCount) return SD_EINVAL;
     // `second` / `merged` / isIdentity are indexed like `order` (one record per accepted first-pass hit, in order)
-    uint64_t base = 0, w = 0;
-    std::vector<Key> keys;
-    for (uint32_t q = 0; q < nQ; q++) {
-        keys.clear();
-        int acceptedN = 0;
-        for (uint32_t x = 0; x < countPerQuery[q] && acceptedN < crit->realignMaxSeqs; x++) {
-            const uint64_t s = base + x;
-            const uint32_t i = order[s];
-            const bool ident = isIdentity && isIdentity[s];
-            const int tl = tLen[resT[i]];
-            const int mode = crit->realignSwMode;
-            Derived d = derive(second[s], mode, crit->seqIdMode, qLen[q], tl, false);
-            const bool covOk = sd::hasCoverage(crit->covThr, crit->covMode, d.qcov, d.dbcov);
-            if (!(covOk || ident)) continue;
-            merged[s] = second[s];
-            merged[s].score = first[i].score;      // res.score / res.eval of the first pass (Alignment.cpp:426-427)
-            merged[s].evalue = first[i].evalue;
-            acceptedN++;
-            Key k;
-            k.eval = first[i].evalue;
-            k.bits = static_cast<int>(sd_host_bitscore((double) (uint32_t) first[i].score) + 0.5);
-            k.dbLen = tl;
-            k.dbKey = tKey ? tKey[resT[i]] : resT[i];
-            k.idx = (uint32_t) s;
-            keys.push_back(k);
+    std::vector<uint64_t> base((size_t) nQ + 1, 0);
+    for (uint32_t q = 0; q < nQ; q++) base[q + 1] = base[q] + countPerQuery[q];
+    std::vector<uint32_t> scratch(std::max<uint64_t>(base[nQ], 1));   // every query's order at the front of its own segment
+#pragma omp parallel
+    {
+        std::vector<Key> keys;
+#pragma omp for schedule(dynamic, 64)
+        for (uint32_t q = 0; q < nQ; q++) {
+            keys.clear();
+            int acceptedN = 0;
+            for (uint32_t x = 0; x < countPerQuery[q] && acceptedN < crit->realignMaxSeqs; x++) {
+                const uint64_t s = base[q] + x;
+                const uint32_t i = order[s];
+                const bool ident = isIdentity && isIdentity[s];
+                const int tl = tLen[resT[i]];
+                const int mode = crit->realignSwMode;
+                Derived d = derive(second[s], mode, crit->seqIdMode, qLen[q], tl, false);
+                const bool covOk = sd::hasCoverage(crit->covThr, crit->covMode, d.qcov, d.dbcov);
+                if (!(covOk || ident)) continue;
+                merged[s] = second[s];
+                merged[s].score = first[i].score;      // res.score / res.eval of the first pass (Alignment.cpp:426-427)
+                merged[s].evalue = first[i].evalue;
+                acceptedN++;
+                Key k;
+                k.eval = first[i].evalue;
+                k.bits = static_cast<int>(sd_host_bitscore((double) (uint32_t) first[i].score) + 0.5);
+                k.dbLen = tl;
+                k.dbKey = tKey ? tKey[resT[i]] : resT[i];
+                k.idx = (uint32_t) s;
+                keys.push_back(k);
+            }
+            if (keys.size() > 1) std::sort(keys.begin(), keys.end(), hitLess);
+            for (size_t x = 0; x < keys.size(); x++) scratch[base[q] + x] = keys[x].idx;
+            outCount[q] = (uint32_t) keys.size();
         }
-        if (keys.size() > 1) std::sort(keys.begin(), keys.end(), hitLess);
-        for (size_t x = 0; x < keys.size(); x++) outOrder[w++] = keys[x].idx;
-        outCount[q] = (uint32_t) keys.size();
-        base += countPerQuery[q];
     }
+    uint64_t w = 0;
+    for (uint32_t q = 0; q < nQ; q++)
+        for (uint32_t x = 0; x < outCount[q]; x++) outOrder[w++] = scratch[base[q] + x];
     return SD_OK;
 }
 
@@ -214,33 +223,26 @@ int sd_alntext_format(sd_alntext *t, const sd_aln_criteria *crit, uint32_t nQ, c
     for (uint32_t q = 0; q < nQ; q++) start[q + 1] = start[q] + countPerQuery[q];
     const uint64_t n = start[nQ];
     if (n && (!order || !recT || !rec || !tLen)) return SD_EINVAL;
-    // line lengths first, then every query formats into its own slice
-    std::vector<uint64_t> lineOff((size_t) n + 1, 0);
+    // every query formats its lines into a string of its own (no worst-case slab: a backtrace of n columns compresses to anything
+    // between 2 and 2 n characters), then the entries are laid out back to back
     const int mode = crit->realign ? crit->realignSwMode : crit->swMode;
-#pragma omp parallel for schedule(static)
-    for (uint64_t x = 0; x < n; x++) {
-        const sd_sw_result &r = rec[order[x]];
-        uint64_t len = 11 * 12 + 24;   // ten integer fields, the E-value, separators
-        if (crit->addBacktrace && r.btLen > 0) len += (uint64_t) r.btLen * 2 + 16;   // worst case: every column its own run
-        lineOff[x + 1] = len;
-    }
-    for (uint64_t x = 0; x < n; x++) lineOff[x + 1] += lineOff[x];
-    std::string scratch;
-    scratch.resize(lineOff[n]);
-    std::vector<uint32_t> used((size_t) n, 0);
+    std::vector<std::string> &perQ = t->perQuery;
+    if (perQ.size() < nQ) perQ.resize(nQ);
 #pragma omp parallel
     {
         std::string cigar;
-#pragma omp for schedule(dynamic, 64)
+        char head[11 * 12 + 64];
+#pragma omp for schedule(dynamic, 16)
         for (uint32_t q = 0; q < nQ; q++) {
+            std::string &out = perQ[q];
+            out.clear();
             for (uint64_t x = start[q]; x < start[q + 1]; x++) {
                 const uint32_t i = order[x];
                 const sd_sw_result &r = rec[i];
                 const bool ident = isIdentity && isIdentity[i];
                 const int tl = tLen[recT[i]];
                 const Derived d = derive(r, mode, crit->seqIdMode, qLen[q], tl, ident);
-                char *b = &scratch[lineOff[x]];
-                char *p = sd::u32toa(tKey ? tKey[recT[i]] : recT[i], b);
+                char *p = sd::u32toa(tKey ? tKey[recT[i]] : recT[i], head);
                 *p++ = '\t';
                 p = sd::i32toa(d.bits, p);
                 *p++ = '\t';
@@ -259,32 +261,23 @@ int sd_alntext_format(sd_alntext *t, const sd_aln_criteria *crit, uint32_t nQ, c
                 p = sd::i32toa(r.tEnd, p);
                 *p++ = '\t';
                 p = sd::i32toa(tl, p);
+                if (crit->addBacktrace) *p++ = '\t';
+                out.append(head, (size_t) (p - head));
                 if (crit->addBacktrace) {
-                    *p++ = '\t';
                     // Matcher::compressAlignment (Matcher.cpp:166-185): an empty backtrace compresses to "0M"
                     const size_t btN = (r.btLen > 0 && btPool) ? (size_t) r.btLen : 0;
-                    cigar.clear();
-                    sd::compressBacktraceAppend(btN ? btPool + r.btOffset : "", btN, cigar);
-                    memcpy(p, cigar.data(), cigar.size());
-                    p += cigar.size();
+                    sd::compressBacktraceAppend(btN ? btPool + r.btOffset : "", btN, out);
                 }
-                *p++ = '\n';
-                used[x] = (uint32_t) (p - b);
+                out.push_back('\n');
             }
         }
     }
     t->entryOff.assign((size_t) nQ + 1, 0);
-    uint64_t total = 0;
-    for (uint32_t q = 0; q < nQ; q++) {
-        for (uint64_t x = start[q]; x < start[q + 1]; x++) total += used[x];
-        t->entryOff[q + 1] = total;
-    }
-    t->text.resize(total);
-    uint64_t w = 0;
-    for (uint64_t x = 0; x < n; x++) {
-        memcpy(&t->text[w], &scratch[lineOff[x]], used[x]);
-        w += used[x];
-    }
+    for (uint32_t q = 0; q < nQ; q++) t->entryOff[q + 1] = t->entryOff[q] + perQ[q].size();
+    t->text.resize(t->entryOff[nQ]);
+#pragma omp parallel for schedule(static)
+    for (uint32_t q = 0; q < nQ; q++)
+        if (!perQ[q].empty()) memcpy(&t->text[t->entryOff[q]], perQ[q].data(), perQ[q].size());
     return SD_OK;
 }
 

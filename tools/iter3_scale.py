@@ -116,6 +116,7 @@ def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
         wall = time.time() - t0
         if verbose:
             log(r.stdout[-6000:])
+            log(r.stderr[-12000:])   # SD_DEBUG_TIMING=1: the modules' lap times
         nq = int(ps.set_start[q_sets])
         tsv = open(os.path.join(work, 'iter3.tsv')).readlines()
         out.update(wall_s=wall, queries=nq, genome_pairs=q_sets * P, genome_pairs_per_s=q_sets * P / wall,
