@@ -603,6 +603,15 @@ int result2profileModule(const Args &a) {
     std::vector<int32_t> eQ, eT;
     std::string pool;
     std::vector<char> profiles;
+    struct ParsedEntry {
+        bool valid = false;
+        size_t qId = 0;
+        std::vector<uint32_t> edgeT;
+        std::vector<int32_t> eQ, eT;
+        std::vector<uint64_t> btEnd;
+        std::string pool, error;
+    };
+    std::vector<ParsedEntry> parsed;
     for (size_t c0 = 0; c0 < n; c0 += chunk) {
         const size_t c1 = std::min(n, c0 + chunk);
         const double t0 = now();
@@ -615,13 +624,22 @@ int result2profileModule(const Args &a) {
         eT.clear();
         keys.clear();
         pool.clear();
+        // the entries of the chunk parsed on all threads, each into lists of its own, then laid out back to back in entry order
+        parsed.resize(c1 - c0);
+#pragma omp parallel for schedule(dynamic, 16)
         for (size_t id = c0; id < c1; id++) {
+            ParsedEntry &pe = parsed[id - c0];
+            pe.valid = false;
+            pe.error.clear();
+            pe.edgeT.clear();
+            pe.eQ.clear();
+            pe.eT.clear();
+            pe.btEnd.clear();
+            pe.pool.clear();
             const uint32_t qKey = aln.key(id);
-            const size_t qId = qdb->rd.idOfKey(qKey);
-            if (qId == SIZE_MAX) continue;   // "Invalid query sequence": skipped (result2profile.cpp:173-176)
-            keys.push_back(qKey);
-            qLetters.insert(qLetters.end(), qdb->residues.begin() + qdb->offsets[qId], qdb->residues.begin() + qdb->offsets[qId + 1]);
-            qOff.push_back(qLetters.size());
+            pe.qId = qdb->rd.idOfKey(qKey);
+            if (pe.qId == SIZE_MAX) continue;   // "Invalid query sequence": skipped (result2profile.cpp:173-176)
+            pe.valid = true;
             const char *d = aln.data(id);
             while (*d != '\0') {
                 const char *ls = d;
@@ -639,23 +657,43 @@ int result2profileModule(const Args &a) {
                 double evalue = 0.0;
                 if (nc >= 4) evalue = strtod(col[3], nullptr);
                 if (!(evalue < evalProfile)) continue;
-                if (nc < 11) return fail("alignment DB without backtraces (run align with -a); recomputing them is the align module's job");
+                if (nc < 11) {
+                    pe.error = "alignment DB without backtraces (run align with -a); recomputing them is the align module's job";
+                    break;
+                }
                 const size_t tId = tdb->rd.idOfKey(tKey);
-                if (tId == SIZE_MAX) return fail("Sequence " + std::to_string(tKey) + " does not exist in target sequence database");
-                edgeT.push_back((uint32_t) tId);
-                eQ.push_back((int32_t) strtol(col[4], nullptr, 10));
-                eT.push_back((int32_t) strtol(col[7], nullptr, 10));
+                if (tId == SIZE_MAX) {
+                    pe.error = "Sequence " + std::to_string(tKey) + " does not exist in target sequence database";
+                    break;
+                }
+                pe.edgeT.push_back((uint32_t) tId);
+                pe.eQ.push_back((int32_t) strtol(col[4], nullptr, 10));
+                pe.eT.push_back((int32_t) strtol(col[7], nullptr, 10));
                 // Matcher::uncompressAlignment (Matcher.cpp:187-201)
                 size_t count = 0;
                 for (const char *c = col[10]; c < le; c++) {
                     if (*c >= '0' && *c <= '9') count = count * 10 + (size_t) (*c - '0');
                     else {
-                        pool.append(count == 0 ? 1 : count, *c);
+                        pe.pool.append(count == 0 ? 1 : count, *c);
                         count = 0;
                     }
                 }
-                btOff.push_back(pool.size());
+                pe.btEnd.push_back(pe.pool.size());
             }
+        }
+        for (size_t id = c0; id < c1; id++) {
+            const ParsedEntry &pe = parsed[id - c0];
+            if (!pe.error.empty()) return fail(pe.error);
+            if (!pe.valid) continue;
+            keys.push_back(aln.key(id));
+            qLetters.insert(qLetters.end(), qdb->residues.begin() + qdb->offsets[pe.qId], qdb->residues.begin() + qdb->offsets[pe.qId + 1]);
+            qOff.push_back(qLetters.size());
+            edgeT.insert(edgeT.end(), pe.edgeT.begin(), pe.edgeT.end());
+            eQ.insert(eQ.end(), pe.eQ.begin(), pe.eQ.end());
+            eT.insert(eT.end(), pe.eT.begin(), pe.eT.end());
+            const uint64_t base = pool.size();
+            pool.append(pe.pool);
+            for (uint64_t e : pe.btEnd) btOff.push_back(base + e);
             edgeOff.push_back(edgeT.size());
         }
         const uint32_t nQ = (uint32_t) keys.size();

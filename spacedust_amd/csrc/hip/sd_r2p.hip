@@ -85,7 +85,10 @@ __device__ __forceinline__ void r2pScale20(float *v, const double *fallback) {
 }
 
 // LDSCOLS: alignments of up to this many columns keep the sub-alignment frequencies and their logarithms in LDS (60 KB at 320:
-// two workgroups per CU; 120 KB at 640); longer ones use the global scratch
+// two workgroups per CU).  Longer ones keep them in the global scratch, but never work on them there: a thread accumulates a
+// column's frequencies in an LDS slice of its own, and the entropy chain -- one thread, 20 dependent FMAs per column -- reads
+// them from LDS again, LDSCOLS columns staged at a time by the whole workgroup (the chain chasing global loads was 0.8 s for
+// one alignment of 1 200 columns, the tail of the whole batch).
 template <int LDSCOLS>
 __global__ void __launch_bounds__(R2P_NT)
 r2p_column_weights_kernel(const R2pTask *__restrict__ tasks, char *cellsRM, char *cellsCM, const float *__restrict__ globalWeight,
@@ -109,8 +112,9 @@ r2p_column_weights_kernel(const R2pTask *__restrict__ tasks, char *cellsRM, char
     uint32_t *active = activeList + T.weightOff;
     int *count = countG + T.scratchOff;
     float *share = shareG + T.scratchOff;
-    float *sub = L <= LDSCOLS ? subL : subG + T.scratchOff;
-    float *lg = L <= LDSCOLS ? lgL : lgG + T.scratchOff;
+    const bool big = L > LDSCOLS;
+    float *sub = big ? subG + T.scratchOff : subL;
+    float *lg = big ? lgG + T.scratchOff : lgL;
     float *fq = freq + T.colOff * kRes;
     float *ef = eff + T.colOff;
     // ---- gaps outside a row's first / last residue become end gaps; column-major copy; counters cleared
@@ -247,7 +251,7 @@ r2p_column_weights_kernel(const R2pTask *__restrict__ tasks, char *cellsRM, char
             __syncthreads();
             // ---- effective sequences of the sub-alignment: frequencies under the weights (rows in order), entropy
             for (int j = jmin + t; j <= jmax; j += R2P_NT) {
-                float *sj = sub + j * kCodes;
+                float *sj = big ? subL + t * kCodes : sub + j * kCodes;
                 for (int a = 0; a < kCodes; a++) sj[a] = 0.0f;
                 uint32_t x = 0;
                 for (; x + 8 <= nActive; x += 8) {   // eight rows' cells and weights in flight; the adds stay in row order
@@ -267,26 +271,44 @@ r2p_column_weights_kernel(const R2pTask *__restrict__ tasks, char *cellsRM, char
                     sj[(int) rm[(size_t) r * T.stride + j]] += local[r];
                 }
                 r2pScale20(sj, nullptr);
-                for (int a = 0; a < kRes; a++) lg[j * kCodes + a] = ((double) sj[a] > 1E-10) ? r2pFlog2(sj[a]) : 0.0f;
+                // what the entropy chain reads: the frequency (0 where the reference skips the term: fma(-0, 0, e) = e) and its logarithm
+                for (int a = 0; a < kRes; a++) {
+                    const bool term = (double) sj[a] > 1E-10;
+                    lg[j * kCodes + a] = term ? r2pFlog2(sj[a]) : 0.0f;
+                    sub[j * kCodes + a] = term ? sj[a] : 0.0f;
+                }
             }
             __syncthreads();
-            if (t == 0) {
-                float e = 0.0f;
-                for (int j = jmin; j <= jmax; j++) {
-                    float sv[kRes], lv[kRes];
-#pragma unroll
-                    for (int a = 0; a < kRes; a++) {
-                        sv[a] = sub[j * kCodes + a];
-                        lv[a] = lg[j * kCodes + a];
+            {
+                float e = 0.0f;   // thread 0's running sum, in column order
+                for (int j0 = jmin; j0 <= jmax; j0 += LDSCOLS) {
+                    const int nj = min(LDSCOLS, jmax + 1 - j0);
+                    const float *cs = sub + j0 * kCodes, *cl = lg + j0 * kCodes;
+                    if (big) {
+                        for (int x = t; x < nj * kRes; x += R2P_NT) {
+                            const int jj = x / kRes, a = x - jj * kRes;
+                            subL[jj * kCodes + a] = sub[(j0 + jj) * kCodes + a];
+                            lgL[jj * kCodes + a] = lg[(j0 + jj) * kCodes + a];
+                        }
+                        __syncthreads();
+                        cs = subL;
+                        cl = lgL;
                     }
+                    if (t == 0) {
+                        for (int j = 0; j < nj; j++) {
+                            float sv[kRes], lv[kRes];
 #pragma unroll
-                    for (int a = 0; a < kRes; a++) {
-                        const float en = fmaf(-sv[a], lv[a], e);
-                        e = ((double) sv[a] > 1E-10) ? en : e;
+                            for (int a = 0; a < kRes; a++) {
+                                sv[a] = cs[j * kCodes + a];
+                                lv[a] = cl[j * kCodes + a];
+                            }
+#pragma unroll
+                            for (int a = 0; a < kRes; a++) e = fmaf(-sv[a], lv[a], e);
+                        }
                     }
+                    if (big) __syncthreads();   // the staged columns are consumed before the next ones arrive
                 }
-                e = width > 0 ? r2pFpow2(e / (float) width) : 1.0f;
-                ef[i] = e;
+                if (t == 0) ef[i] = width > 0 ? r2pFpow2(e / (float) width) : 1.0f;
             }
             __syncthreads();
             prevEff = ef[i];
@@ -322,7 +344,7 @@ r2p_column_weights_kernel(const R2pTask *__restrict__ tasks, char *cellsRM, char
 }  // namespace
 
 // host entry (called by sd_result2profile.cpp): tasks / cells / weights are host arrays of one batch
-extern "C" int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, uint32_t nShort, const void *tasksHost /* R2pTask[nTasks] */, const char *cells, uint64_t cellBytes,
+extern "C" int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, const void *tasksHost /* R2pTask[nTasks] */, const char *cells, uint64_t cellBytes,
                              uint64_t cmBytes, const float *globalWeight, uint64_t nWeights, uint64_t nColumns, uint64_t scratchElems,
                              const float *rcpTable, uint32_t rcpN, const double *background, float *freqOut, float *effOut) {
     if (!ctx) return SD_EINVAL;
@@ -361,16 +383,11 @@ extern "C" int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, uint32_t n
     if (dbg) SD_HIP(ctx, sdStreamSync(ctx));
     const double t1 = nowMs();
     {
-        // the caller lists the alignments of up to 320 columns first (nShort of them)
+        // one launch, the caller's order (longest alignments first: the tail of the batch starts at time 0)
         ProfScope ps(ctx, "r2p_column_weights");
-        if (nShort)
-            hipLaunchKernelGGL(r2p_column_weights_kernel<320>, dim3(nShort), dim3(R2P_NT), 0, ctx->stream, (const R2pTask *) dTasks, dCells, dCm,
-                               (const float *) dGw, dLocal, dActive, (const float *) dRcp, rcpN, (const double *) dBack, dCount, dShare, dSub,
-                               dLg, dFreq, dEff, dErr);
-        if (nTasks > nShort)
-            hipLaunchKernelGGL(r2p_column_weights_kernel<640>, dim3(nTasks - nShort), dim3(R2P_NT), 0, ctx->stream,
-                               (const R2pTask *) dTasks + nShort, dCells, dCm, (const float *) dGw, dLocal, dActive, (const float *) dRcp, rcpN,
-                               (const double *) dBack, dCount, dShare, dSub, dLg, dFreq, dEff, dErr);
+        hipLaunchKernelGGL(r2p_column_weights_kernel<320>, dim3(nTasks), dim3(R2P_NT), 0, ctx->stream, (const R2pTask *) dTasks, dCells, dCm,
+                           (const float *) dGw, dLocal, dActive, (const float *) dRcp, rcpN, (const double *) dBack, dCount, dShare, dSub, dLg,
+                           dFreq, dEff, dErr);
     }
     SD_HIP(ctx, hipGetLastError());
     if (dbg) SD_HIP(ctx, sdStreamSync(ctx));
@@ -381,7 +398,7 @@ extern "C" int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, uint32_t n
     SD_HIP(ctx, hipMemcpyAsync(&hErr, dErr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, sdStreamSync(ctx));
     if (dbg)
-        fprintf(stderr, "[r2p device] %u tasks (%u short): upload %.1f ms, kernels %.1f ms, download %.1f ms\n", nTasks, nShort, t1 - t0, t2 - t1,
+        fprintf(stderr, "[r2p device] %u tasks: upload %.1f ms, kernel %.1f ms, download %.1f ms\n", nTasks, t1 - t0, t2 - t1,
                 nowMs() - t2);
     if (hErr) return sdFail(ctx, SD_EHIP, "result2profile: a (count x distinct) product outside the reciprocal table");
     return SD_OK;

@@ -740,13 +740,13 @@ struct R2pTaskH {   // = R2pTask of sd_r2p.hip
 };
 #ifdef SD_HOST_STAGES_ONLY   // oracle/Makefile: the CPU checker links the host stages without the device library
 }
-static int sdR2pColumnWeightsDevice(sd_ctx *, uint32_t, uint32_t, const void *, const char *, uint64_t, uint64_t, const float *, uint64_t, uint64_t,
+static int sdR2pColumnWeightsDevice(sd_ctx *, uint32_t, const void *, const char *, uint64_t, uint64_t, const float *, uint64_t, uint64_t,
                                     uint64_t, const float *, uint32_t, const double *, float *, float *) {
     return SD_EINVAL;
 }
 extern "C" {
 #else
-int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, uint32_t nShort, const void *tasksHost, const char *cells, uint64_t cellBytes, uint64_t cmBytes,
+int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, const void *tasksHost, const char *cells, uint64_t cellBytes, uint64_t cmBytes,
                              const float *globalWeight, uint64_t nWeights, uint64_t nColumns, uint64_t scratchElems, const float *rcpTable,
                              uint32_t rcpN, const double *background, float *freqOut, float *effOut);
 #endif
@@ -909,23 +909,18 @@ static int r2pBatchImpl(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32
                 }
                 const uint32_t rcpN = (maxRows + 1) * 20 + 8;
                 reciprocalTable(table, rcpN);
-                // launch order: the short alignments (<= 320 columns: the LDS form with two workgroups per CU) first, the deepest first inside
-                // each class (the offsets into the staging arrays travel with a task)
+                // launch order: the longest alignments first -- the work per alignment grows with the square of its columns, and the
+                // batch is as slow as its last workgroup (the offsets into the staging arrays travel with a task)
                 std::vector<uint32_t> ord(tasks.size());
                 for (size_t k = 0; k < ord.size(); k++) ord[k] = (uint32_t) k;
                 std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
-                    const bool sx = tasks[x].L <= 320, sy = tasks[y].L <= 320;
-                    if (sx != sy) return sx;
-                    return (uint64_t) tasks[x].nRows * tasks[x].L > (uint64_t) tasks[y].nRows * tasks[y].L;
+                    if (tasks[x].L != tasks[y].L) return tasks[x].L > tasks[y].L;
+                    return tasks[x].nRows > tasks[y].nRows;
                 });
                 std::vector<R2pTaskH> launch(tasks.size());
-                uint32_t nShort = 0;
-                for (size_t k = 0; k < ord.size(); k++) {
-                    launch[k] = tasks[ord[k]];
-                    nShort += launch[k].L <= 320;
-                }
+                for (size_t k = 0; k < ord.size(); k++) launch[k] = tasks[ord[k]];
                 const double tB0 = omp_get_wtime();
-                const int rc = sdR2pColumnWeightsDevice(ctx, (uint32_t) tasks.size(), nShort, launch.data(), cells.data(), cellBytes, cmBytes, gw.data(),
+                const int rc = sdR2pColumnWeightsDevice(ctx, (uint32_t) tasks.size(), launch.data(), cells.data(), cellBytes, cmBytes, gw.data(),
                                                         nWeights, nColumns, scratch, table.data(), rcpN, background, freq.data(), eff.data());
                 if (rc != SD_OK) return rc;
                 const double tB1 = omp_get_wtime();
