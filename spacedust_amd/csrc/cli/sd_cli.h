@@ -65,6 +65,10 @@ struct SetInfo {
     bool load(const std::string &dbPath, bool needSources, std::string *err);
 };
 
+// SetInfo::load through a cache of this process (a workflow's clusterhits and summarizeresults read the same two set DBs: three
+// million lookup lines each at 1 000 target proteomes); an entry is reused while NAME.lookup keeps its size and modification time
+std::shared_ptr<const SetInfo> loadSetInfo(const std::string &dbPath, bool needSources, std::string *err);
+
 // a target index read from TARGET.idx (sd_mod_index.cpp), in the array form sd_target_create / sd_search_create take
 struct LoadedIndex {
     int k = 0, kmerThr = 0;

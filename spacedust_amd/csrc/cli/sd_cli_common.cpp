@@ -1,6 +1,7 @@
 #include "sd_cli.h"
 
 #include <chrono>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -174,7 +175,7 @@ bool SeqDb::load(const std::string &path, sd_host *host, std::string *err) {
 bool SetInfo::load(const std::string &dbPath, bool needSources, std::string *err) {
     sddb::Reader lk;
     if (!lk.open(dbPath, sddb::Reader::USE_LOOKUP, sddb::Reader::NOSORT, err)) return false;
-    const std::vector<sddb::LookupEntry> &L = lk.lookup();
+    std::vector<sddb::LookupEntry> L = lk.takeLookup();
     uint32_t maxKey = 0, maxSet = 0;
     for (const sddb::LookupEntry &e : L) {
         maxKey = std::max(maxKey, e.key);
@@ -185,7 +186,7 @@ bool SetInfo::load(const std::string &dbPath, bool needSources, std::string *err
     posOfKey.assign(nk, 0);
     strandOfKey.assign(nk, 0);
     nameOfKey.assign(nk, std::string());
-    for (const sddb::LookupEntry &e : L) {
+    for (sddb::LookupEntry &e : L) {
         // name = accession_index_start_end (R/data/createsetdb.sh:128-133); fields from the end
         const std::string &s = e.name;
         size_t p3 = s.rfind('_');
@@ -201,7 +202,7 @@ bool SetInfo::load(const std::string &dbPath, bool needSources, std::string *err
         setOfKey[e.key] = e.fileNumber;
         posOfKey[e.key] = (uint32_t) pos;
         strandOfKey[e.key] = st < en ? 1 : 0;
-        nameOfKey[e.key] = s;
+        nameOfKey[e.key] = std::move(e.name);
     }
     sddb::Reader sz;
     if (!sz.open(dbPath + "_set_size", sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::NOSORT, err)) return false;
@@ -218,6 +219,42 @@ bool SetInfo::load(const std::string &dbPath, bool needSources, std::string *err
             if (src[i].first < nSets) sourceOfSet[src[i].first] = src[i].second;
     }
     return true;
+}
+
+std::shared_ptr<const SetInfo> loadSetInfo(const std::string &dbPath, bool needSources, std::string *err) {
+    struct Entry {
+        std::shared_ptr<SetInfo> info;
+        off_t size = 0;
+        struct timespec mtime = {0, 0};
+        bool sources = false;
+    };
+    static std::map<std::string, Entry> cache;
+    struct stat st;
+    const bool haveStat = ::stat((dbPath + ".lookup").c_str(), &st) == 0;
+    auto it = cache.find(dbPath);
+    if (it != cache.end() && haveStat && it->second.size == st.st_size && it->second.mtime.tv_sec == st.st_mtim.tv_sec &&
+        it->second.mtime.tv_nsec == st.st_mtim.tv_nsec) {
+        if (needSources && !it->second.sources) {
+            SetInfo &si = *it->second.info;
+            std::vector<std::pair<uint32_t, std::string> > src;
+            if (!sddb::readSources(dbPath, src, err)) return std::shared_ptr<const SetInfo>();
+            si.sourceOfSet.assign(si.nSets, std::string());
+            for (size_t i = 0; i < src.size(); i++)
+                if (src[i].first < si.nSets) si.sourceOfSet[src[i].first] = src[i].second;
+            it->second.sources = true;
+        }
+        return it->second.info;
+    }
+    Entry e;
+    e.info.reset(new SetInfo());
+    if (!e.info->load(dbPath, needSources, err)) return std::shared_ptr<const SetInfo>();
+    e.sources = needSources;
+    if (haveStat) {
+        e.size = st.st_size;
+        e.mtime = st.st_mtim;
+        cache[dbPath] = e;
+    }
+    return e.info;
 }
 
 }  // namespace sdcli

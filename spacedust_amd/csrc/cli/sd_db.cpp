@@ -195,7 +195,7 @@ bool Reader::open(const std::string &dataName, int mode, int access, std::string
             c = nextLine(c, end);
             e.key = (uint32_t) key;
             e.fileNumber = (uint32_t) fileNo;
-            lookup_.push_back(e);
+            lookup_.push_back(std::move(e));
         }
         lk.unmap();
         if (!std::is_sorted(lookup_.begin(), lookup_.end(), [](const LookupEntry &a, const LookupEntry &b) { return a.key < b.key; }))

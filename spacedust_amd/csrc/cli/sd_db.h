@@ -68,6 +68,7 @@ public:
     uint64_t aminoAcidDbSize() const;                       // DBReader::getAminoAcidDBSize: sum of seqLen
     size_t maxSeqLen() const;
     const std::vector<LookupEntry> &lookup() const { return lookup_; }   // sorted by key (USE_LOOKUP)
+    std::vector<LookupEntry> takeLookup() { return std::move(lookup_); }   // the same list handed over (the reader keeps none)
     const std::string &name() const { return name_; }
 
 private:

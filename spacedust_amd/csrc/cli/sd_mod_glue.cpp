@@ -50,52 +50,82 @@ std::string fmt3E(double v) {
 // the entry, `order` lists the lines by ascending set key, input order inside a set
 struct EntryLines {
     struct Line {
-        const char *s, *e;
-        uint32_t col0, nCols;
+        const char *s, *e;      // the line without its newline
+        const char *c2b, *c2e;  // column 2 (the P-value column the modules rewrite); NULL when the line has fewer columns
+        const char *c4b;        // start of column 4 (the E-value); NULL when absent
+        uint32_t nCols;
         unsigned setKey;
     };
     std::vector<Line> lines;
-    std::vector<const char *> colStart;
+    std::vector<const char *> lineStart;
     std::vector<uint32_t> order;
-    const char *colBegin(const Line &l, uint32_t c) const { return colStart[l.col0 + c]; }
-    const char *colEnd(const Line &l, uint32_t c) const { return c + 1 < l.nCols ? colStart[l.col0 + c + 1] - 1 : l.e; }
-    // strtod / strtoul of a column (an empty column is 0, as it is for the reference's std::string columns)
-    double num(const Line &l, uint32_t c) const { return colBegin(l, c) == colEnd(l, c) ? 0.0 : strtod(colBegin(l, c), nullptr); }
-    void appendCol(std::string &to, const Line &l, uint32_t c) const { to.append(colBegin(l, c), colEnd(l, c) - colBegin(l, c)); }
+    // strtod of a column (an empty column is 0, as it is for the reference's std::string columns)
+    static double num(const char *b, const char *lineEnd) { return (!b || b == lineEnd || *b == '\t') ? 0.0 : strtod(b, nullptr); }
+    // the line with column 2 replaced (every other column as it is)
+    static void appendWith(std::string &to, const Line &l, const std::string &col2) {
+        if (!l.c2b) {
+            to.append(l.s, l.e - l.s);
+            return;
+        }
+        to.append(l.s, l.c2b - l.s);
+        to.append(col2);
+        to.append(l.c2e, l.e - l.c2e);
+    }
 };
 bool buildMap(const char *data, const sddb::Reader &memberToSet, EntryLines &out, std::string *err) {
-    out.lines.clear();
-    out.colStart.clear();
+    out.lineStart.clear();
     while (*data != '\0') {
         const char *s = data;
-        while (*data != '\n' && *data != '\0') data++;
-        const char *e = data;
-        if (*data == '\n') data++;
-        if (s == e) continue;
-        EntryLines::Line l;
-        l.s = s;
-        l.e = e;
-        l.col0 = (uint32_t) out.colStart.size();
-        out.colStart.push_back(s);
-        for (const char *c = s; c < e; c++)
-            if (*c == '\t') out.colStart.push_back(c + 1);
-        l.nCols = (uint32_t) out.colStart.size() - l.col0;
-        if (l.nCols < 2) {
-            if (err) *err = "Invalid result record \"" + std::string(s, e - s) + "\"";
-            return false;
-        }
-        const char *k0 = out.colStart[l.col0 + 1], *k1 = l.nCols > 2 ? out.colStart[l.col0 + 2] - 1 : e;
-        const unsigned tKey = k0 == k1 ? 0u : (unsigned) strtoul(k0, nullptr, 10);
-        const size_t id = memberToSet.idOfKey(tKey);
-        if (id == SIZE_MAX) {
-            if (err) *err = "Invalid target database key " + std::string(k0, k1 - k0) + ".";
-            return false;
-        }
-        l.setKey = (unsigned) strtoul(memberToSet.data(id), nullptr, 10);
-        out.lines.push_back(l);
+        const char *nl = strchr(data, '\n');
+        data = nl ? nl + 1 : s + strlen(s);
+        if ((nl ? nl : data) != s) out.lineStart.push_back(s);
     }
-    out.order.resize(out.lines.size());
-    for (uint32_t i = 0; i < out.order.size(); i++) out.order[i] = i;
+    const size_t n = out.lineStart.size();
+    out.lines.resize(n);
+    bool failed = false;
+    std::string firstErr;
+#pragma omp parallel for schedule(static) if (n > 20000)
+    for (size_t x = 0; x < n; x++) {
+        EntryLines::Line &l = out.lines[x];
+        l.s = out.lineStart[x];
+        l.c2b = l.c2e = l.c4b = nullptr;
+        const char *c1b = nullptr;
+        uint32_t cols = 1;
+        const char *c = l.s;
+        for (; *c != '\n' && *c != '\0'; c++)
+            if (*c == '\t') {
+                if (cols == 1) c1b = c + 1;
+                else if (cols == 2) l.c2b = c + 1;
+                else if (cols == 3) l.c2e = c;
+                if (cols == 4) l.c4b = c + 1;   // (cols counts the columns seen so far: this tab ends column 3)
+                cols++;
+            }
+        l.e = c;
+        if (l.c2b && !l.c2e) l.c2e = l.e;
+        l.nCols = cols;
+        std::string e;
+        if (cols < 2) e = "Invalid result record \"" + std::string(l.s, l.e - l.s) + "\"";
+        else {
+            const char *k1 = l.c2b ? l.c2b - 1 : l.e;
+            const unsigned tKey = c1b == k1 ? 0u : (unsigned) strtoul(c1b, nullptr, 10);
+            const size_t id = memberToSet.idOfKey(tKey);
+            if (id == SIZE_MAX) e = "Invalid target database key " + std::string(c1b, k1 - c1b) + ".";
+            else l.setKey = (unsigned) strtoul(memberToSet.data(id), nullptr, 10);
+        }
+        if (!e.empty()) {
+#pragma omp critical(sd_glue_map)
+            if (!failed) {
+                failed = true;
+                firstErr = e;
+            }
+        }
+    }
+    if (failed) {
+        if (err) *err = firstErr;
+        return false;
+    }
+    out.order.resize(n);
+    for (uint32_t i = 0; i < n; i++) out.order[i] = i;
     std::stable_sort(out.order.begin(), out.order.end(), [&](uint32_t x, uint32_t y) { return out.lines[x].setKey < out.lines[y].setKey; });
     return true;
 }
@@ -229,7 +259,7 @@ int besthitbysetModule(const Args &a) {
                     *e = "Invalid alignment result record";
                     return false;
                 }
-                const double eval = m.num(row, 4);
+                const double eval = EntryLines::num(row.c4b, row.e);
                 const double score = std::min(DBL_MAX, -log(eval));
                 if (simple || nRows < 2) {
                     if (eval < bestEval) {
@@ -250,7 +280,7 @@ int besthitbysetModule(const Args &a) {
                 const double thr = bestEval * subopt;
                 for (size_t r = g0; r < g1; r++) {
                     const EntryLines::Line &row = m.lines[m.order[r]];
-                    const double eval = m.num(row, 4);
+                    const double eval = EntryLines::num(row.c4b, row.e);
                     if (eval <= thr) {
                         all.push_back(&row);
                         evals.push_back(eval);
@@ -268,11 +298,7 @@ int besthitbysetModule(const Args &a) {
             }
             if (best != nullptr) {
                 for (size_t j = 0; j < all.size(); j++) {
-                    for (uint32_t c = 0; c < all[j]->nCols; c++) {
-                        if (c == 2) buffer.append(fmt3E(logP[j]));
-                        else m.appendCol(buffer, *all[j], c);
-                        if (c + 1 != all[j]->nCols) buffer.push_back('\t');
-                    }
+                    EntryLines::appendWith(buffer, *all[j], fmt3E(logP[j]));
                     if (j + 1 != all.size()) buffer.push_back('\n');
                 }
             }
@@ -403,7 +429,7 @@ int combinehitsModule(const Args &a) {
                         *e = "Invalid alignment result record";
                         return false;
                     }
-                    const double lp = m.num(row, 2);
+                    const double lp = EntryLines::num(row.c2b, row.e);
                     if (lp < logPvalThr) {
                         k++;
                         r -= lp - logPvalThr;
@@ -432,7 +458,7 @@ int combinehitsModule(const Args &a) {
                         *e = "Invalid alignment result record";
                         return false;
                     }
-                    sum += m.num(row, 2);
+                    sum += EntryLines::num(row.c2b, row.e);
                     entries.push_back(&row);
                 }
                 header += std::to_string(nRows) + "\t" + fmt3E(exp(sum) * numTargetSets);
@@ -446,7 +472,7 @@ int combinehitsModule(const Args &a) {
                         *e = "Invalid alignment result record";
                         return false;
                     }
-                    const double lp = m.num(row, 2);
+                    const double lp = EntryLines::num(row.c2b, row.e);
                     if (lp < thr) {
                         sum += lp;
                         k++;
@@ -461,11 +487,7 @@ int combinehitsModule(const Args &a) {
             header.push_back('\n');
             body.clear();
             for (size_t j = 0; j < entries.size(); j++) {
-                for (uint32_t c = 0; c < entries[j]->nCols; c++) {
-                    if (c == 2) body.append(fmt3E(exp(m.num(*entries[j], c))));
-                    else m.appendCol(body, *entries[j], c);
-                    if (c + 1 != entries[j]->nCols) body.push_back('\t');
-                }
+                EntryLines::appendWith(body, *entries[j], fmt3E(exp(EntryLines::num(entries[j]->c2b, entries[j]->e))));
                 if (j + 1 != entries.size()) body.push_back('\n');
             }
             body.push_back('\n');
@@ -500,11 +522,12 @@ int summarizeresultsModule(const Args &a) {
     if (a.pos.size() != 4) return fail("usage: summarizeresults <querySetDB> <targetSetDB> <clustersDB> <out.tsv>");
     std::string err;
     Lap lap("summarizeresults");
-    SetInfo qs, tsOwn;
-    if (!qs.load(a.pos[0], true, &err)) return fail(err);
+    const std::shared_ptr<const SetInfo> qsP = loadSetInfo(a.pos[0], true, &err);
+    if (!qsP) return fail(err);
     const bool sameDb = a.pos[0] == a.pos[1];
-    if (!sameDb && !tsOwn.load(a.pos[1], true, &err)) return fail(err);
-    const SetInfo &ts = sameDb ? qs : tsOwn;
+    const std::shared_ptr<const SetInfo> tsP = sameDb ? qsP : loadSetInfo(a.pos[1], true, &err);
+    if (!tsP) return fail(err);
+    const SetInfo &qs = *qsP, &ts = *tsP;
     lap.mark("set info");
     sddb::Reader hdr, aln;
     if (!hdr.open(a.pos[2] + "_h", sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
@@ -519,47 +542,78 @@ int summarizeresultsModule(const Args &a) {
         flat = fopen(a.pos[3].c_str(), "wb");
         if (!flat) return fail("cannot create " + a.pos[3]);
     }
-    std::string buffer;
-    for (size_t id = 0; id < hdr.size(); id++) {
-        const unsigned matchKey = hdr.key(id);
-        const size_t alnId = aln.idOfKey(matchKey);
-        if (alnId == SIZE_MAX) return fail("cluster " + std::to_string(matchKey) + " has a header but no entry");
-        buffer.clear();
-        const char *h = hdr.data(id);
-        while (*h != '\0') {
-            const char *s = h;
-            while (*h != '\n' && *h != '\0') h++;
-            std::vector<std::string> cols = splitTabs(std::string(s, h - s));
-            if (*h == '\n') h++;
-            if (cols.size() < 5) return fail("Invalid alignment result record");
-            const unsigned qset = (unsigned) strtoul(cols[0].c_str(), nullptr, 10);
-            const unsigned tset = (unsigned) strtoul(cols[1].c_str(), nullptr, 10);
-            buffer.append("#").append(std::to_string(matchKey)).append("\t");
-            buffer.append(qset < qs.sourceOfSet.size() ? qs.sourceOfSet[qset] : std::string()).append("\t");
-            buffer.append(tset < ts.sourceOfSet.size() ? ts.sourceOfSet[tset] : std::string()).append("\t");
-            buffer.append(cols[2]).append("\t").append(cols[3]).append("\t").append(cols[4]).append("\n");
-            const char *d = aln.data(alnId);
-            while (*d != '\0') {
-                const char *ls = d;
-                while (*d != '\n' && *d != '\0') d++;
-                if (*d == '\n') d++;
-                // first two columns are keys -> lookup names; the rest of the line is copied
-                char *e;
-                const unsigned long qid = strtoul(ls, &e, 10);
-                const unsigned long tid = strtoul(e, &e, 10);
-                int tabs = 0;
-                for (const char *c = ls; c < d; c++) tabs += (*c == '\t');
-                if (tabs < 9) return fail("Invalid alignment result record");
-                if (qid >= qs.nameOfKey.size() || tid >= ts.nameOfKey.size()) return fail("alignment key without lookup entry");
-                const char *rest = e;
-                while (rest < d && (*rest == '\t' || *rest == ' ')) rest++;
-                buffer.append(">").append(qs.nameOfKey[qid]).append("\t").append(ts.nameOfKey[tid]).append("\t").append(rest, d - rest);
+    // a block of clusters formatted on all threads, written in order
+    std::vector<std::string> texts;
+    const size_t block = 16384;
+    for (size_t b0 = 0; b0 < hdr.size(); b0 += block) {
+        const size_t b1 = std::min(hdr.size(), b0 + block);
+        texts.resize(b1 - b0);
+        bool failed = false;
+        std::string firstErr;
+#pragma omp parallel for schedule(dynamic, 64)
+        for (size_t id = b0; id < b1; id++) {
+            std::string &buffer = texts[id - b0];
+            buffer.clear();
+            std::string e;
+            const unsigned matchKey = hdr.key(id);
+            const size_t alnId = aln.idOfKey(matchKey);
+            if (alnId == SIZE_MAX) e = "cluster " + std::to_string(matchKey) + " has a header but no entry";
+            const char *h = hdr.data(id);
+            while (e.empty() && *h != '\0') {
+                const char *s = h;
+                while (*h != '\n' && *h != '\0') h++;
+                std::vector<std::string> cols = splitTabs(std::string(s, h - s));
+                if (*h == '\n') h++;
+                if (cols.size() < 5) {
+                    e = "Invalid alignment result record";
+                    break;
+                }
+                const unsigned qset = (unsigned) strtoul(cols[0].c_str(), nullptr, 10);
+                const unsigned tset = (unsigned) strtoul(cols[1].c_str(), nullptr, 10);
+                buffer.append("#").append(std::to_string(matchKey)).append("\t");
+                buffer.append(qset < qs.sourceOfSet.size() ? qs.sourceOfSet[qset] : std::string()).append("\t");
+                buffer.append(tset < ts.sourceOfSet.size() ? ts.sourceOfSet[tset] : std::string()).append("\t");
+                buffer.append(cols[2]).append("\t").append(cols[3]).append("\t").append(cols[4]).append("\n");
+                const char *d = aln.data(alnId);
+                while (*d != '\0') {
+                    const char *ls = d;
+                    while (*d != '\n' && *d != '\0') d++;
+                    if (*d == '\n') d++;
+                    // first two columns are keys -> lookup names; the rest of the line is copied
+                    char *e2;
+                    const unsigned long qid = strtoul(ls, &e2, 10);
+                    const unsigned long tid = strtoul(e2, &e2, 10);
+                    int tabs = 0;
+                    for (const char *c = ls; c < d; c++) tabs += (*c == '\t');
+                    if (tabs < 9) {
+                        e = "Invalid alignment result record";
+                        break;
+                    }
+                    if (qid >= qs.nameOfKey.size() || tid >= ts.nameOfKey.size()) {
+                        e = "alignment key without lookup entry";
+                        break;
+                    }
+                    const char *rest = e2;
+                    while (rest < d && (*rest == '\t' || *rest == ' ')) rest++;
+                    buffer.append(">").append(qs.nameOfKey[qid]).append("\t").append(ts.nameOfKey[tid]).append("\t").append(rest, d - rest);
+                }
+            }
+            if (!e.empty()) {
+#pragma omp critical(sd_glue_err)
+                if (!failed) {
+                    failed = true;
+                    firstErr = e;
+                }
             }
         }
-        if (dbOut) {
-            if (!out.write(matchKey, buffer.data(), buffer.size())) return fail("cannot write " + a.pos[3]);
-        } else {
-            fwrite(buffer.data(), 1, buffer.size(), flat);
+        if (failed) return fail(firstErr);
+        for (size_t id = b0; id < b1; id++) {
+            const std::string &buffer = texts[id - b0];
+            if (dbOut) {
+                if (!out.write(hdr.key(id), buffer.data(), buffer.size())) return fail("cannot write " + a.pos[3]);
+            } else {
+                fwrite(buffer.data(), 1, buffer.size(), flat);
+            }
         }
     }
     lap.mark("entries");

@@ -755,11 +755,12 @@ int clusterhitsModule(const Args &a) {
     if (a.flag("--cluster-use-weight", false)) return fail("--cluster-use-weight 1 is not supported");
     std::string err;
     Lap lap("clusterhits");
-    SetInfo qs, tsOwn;
-    if (!qs.load(a.pos[0], false, &err)) return fail(err);
+    const std::shared_ptr<const SetInfo> qsP = loadSetInfo(a.pos[0], false, &err);
+    if (!qsP) return fail(err);
     const bool sameDb = a.pos[0] == a.pos[1];
-    if (!sameDb && !tsOwn.load(a.pos[1], false, &err)) return fail(err);
-    const SetInfo &ts = sameDb ? qs : tsOwn;
+    const std::shared_ptr<const SetInfo> tsP = sameDb ? qsP : loadSetInfo(a.pos[1], false, &err);
+    if (!tsP) return fail(err);
+    const SetInfo &qs = *qsP, &ts = *tsP;
     lap.mark("set info");
     sddb::Reader res, hdr;
     if (!res.open(a.pos[2], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
@@ -784,50 +785,87 @@ int clusterhitsModule(const Args &a) {
     for (uint32_t s : qs.setSize) maxOrf = std::max(maxOrf, s);
     for (uint32_t s : ts.setSize) maxOrf = std::max(maxOrf, s);
     uint32_t maxPos = 0;
-    for (size_t i = 0; i < res.size(); i++) {
-        const char *h = hdr.data(i);
-        char *end;
-        const unsigned long qSet = strtoul(h, &end, 10);
-        const unsigned long tSet = strtoul(end, &end, 10);
-        const unsigned long nq = strtoul(end, &end, 10);
-        // six tab separated columns are required (ClusterHits.cpp:303-307)
-        int cols = 0;
-        for (const char *c = h; *c && *c != '\n'; c++) cols += (*c == '\t');
-        if (cols < 5) return fail("Invalid header record");
-        const size_t first = lines.size();
-        const char *d = res.data(i);
-        while (*d != '\0') {
-            const char *ls = d;
-            char *e2;
-            const unsigned long qid = strtoul(d, &e2, 10);
-            const unsigned long tid = strtoul(e2, &e2, 10);
-            const double p = strtod(e2, nullptr);
-            while (*d != '\n' && *d != '\0') d++;
-            if (*d == '\n') d++;
-            if (qid >= qs.nameOfKey.size() || qs.nameOfKey[qid].empty()) return fail("Invalid query lookup record");
-            if (tid >= ts.nameOfKey.size() || ts.nameOfKey[tid].empty()) return fail("Invalid target lookup record");
-            lines.push_back(std::make_pair(ls, (uint32_t) (d - ls)));
-            qPos.push_back(qs.posOfKey[qid]);
-            tPos.push_back(ts.posOfKey[tid]);
-            maxPos = std::max(maxPos, std::max(qs.posOfKey[qid], ts.posOfKey[tid]));
-            strands.push_back((uint8_t) (qs.strandOfKey[qid] | (ts.strandOfKey[tid] << 1)));
-            pval.push_back(p);
+    // the matches parsed on all threads, each into lists of its own, then laid out back to back in entry order
+    struct ParsedMatch {
+        std::vector<std::pair<const char *, uint32_t> > lines;
+        std::vector<uint32_t> qPos, tPos;
+        std::vector<uint8_t> strands;
+        std::vector<double> pval;
+        unsigned long qSet = 0, tSet = 0, nq = 0;
+        uint32_t maxPos = 0;
+        std::string error;
+    };
+    std::vector<ParsedMatch> parsed;
+    const size_t parseBlock = 8192;
+    for (size_t b0 = 0; b0 < res.size(); b0 += parseBlock) {
+        const size_t b1 = std::min(res.size(), b0 + parseBlock);
+        parsed.resize(b1 - b0);
+#pragma omp parallel for schedule(dynamic, 8)
+        for (size_t i = b0; i < b1; i++) {
+            ParsedMatch &pm = parsed[i - b0];
+            pm.lines.clear();
+            pm.qPos.clear();
+            pm.tPos.clear();
+            pm.strands.clear();
+            pm.pval.clear();
+            pm.error.clear();
+            pm.maxPos = 0;
+            const char *h = hdr.data(i);
+            char *end;
+            pm.qSet = strtoul(h, &end, 10);
+            pm.tSet = strtoul(end, &end, 10);
+            pm.nq = strtoul(end, &end, 10);
+            // six tab separated columns are required (ClusterHits.cpp:303-307)
+            int cols = 0;
+            for (const char *c = h; *c && *c != '\n'; c++) cols += (*c == '\t');
+            if (cols < 5) {
+                pm.error = "Invalid header record";
+                continue;
+            }
+            const char *d = res.data(i);
+            while (*d != '\0') {
+                const char *ls = d;
+                char *e2;
+                const unsigned long qid = strtoul(d, &e2, 10);
+                const unsigned long tid = strtoul(e2, &e2, 10);
+                const double p = strtod(e2, nullptr);
+                while (*d != '\n' && *d != '\0') d++;
+                if (*d == '\n') d++;
+                if (qid >= qs.nameOfKey.size() || qs.nameOfKey[qid].empty()) {
+                    pm.error = "Invalid query lookup record";
+                    break;
+                }
+                if (tid >= ts.nameOfKey.size() || ts.nameOfKey[tid].empty()) {
+                    pm.error = "Invalid target lookup record";
+                    break;
+                }
+                pm.lines.push_back(std::make_pair(ls, (uint32_t) (d - ls)));
+                pm.qPos.push_back(qs.posOfKey[qid]);
+                pm.tPos.push_back(ts.posOfKey[tid]);
+                pm.maxPos = std::max(pm.maxPos, std::max(qs.posOfKey[qid], ts.posOfKey[tid]));
+                pm.strands.push_back((uint8_t) (qs.strandOfKey[qid] | (ts.strandOfKey[tid] << 1)));
+                pm.pval.push_back(p);
+            }
         }
-        const size_t K = lines.size() - first;
-        if (K == 1) {   // ClusterHits.cpp:359-361
-            lines.pop_back();
-            qPos.pop_back();
-            tPos.pop_back();
-            strands.pop_back();
-            pval.pop_back();
-            continue;
+        for (size_t i = b0; i < b1; i++) {
+            const ParsedMatch &pm = parsed[i - b0];
+            if (!pm.error.empty()) return fail(pm.error);
+            const size_t K = pm.lines.size();
+            if (K <= 1) continue;   // a single hit is no cluster (ClusterHits.cpp:359-361)
+            lines.insert(lines.end(), pm.lines.begin(), pm.lines.end());
+            qPos.insert(qPos.end(), pm.qPos.begin(), pm.qPos.end());
+            tPos.insert(tPos.end(), pm.tPos.begin(), pm.tPos.end());
+            strands.insert(strands.end(), pm.strands.begin(), pm.strands.end());
+            pval.insert(pval.end(), pm.pval.begin(), pm.pval.end());
+            maxPos = std::max(maxPos, pm.maxPos);
+            hitOff.push_back(lines.size());
+            Nq.push_back((uint32_t) pm.nq);
+            entryQSet.push_back((uint32_t) pm.qSet);
+            entryTSet.push_back((uint32_t) pm.tSet);
         }
-        if (K == 0) continue;
-        hitOff.push_back(lines.size());
-        Nq.push_back((uint32_t) nq);
-        entryQSet.push_back((uint32_t) qSet);
-        entryTSet.push_back((uint32_t) tSet);
     }
+    parsed.clear();
+    parsed.shrink_to_fit();
     lap.mark("parse matches");
     const uint32_t nPairs = (uint32_t) Nq.size();
     const uint64_t total = hitOff.back();
@@ -850,23 +888,55 @@ int clusterhitsModule(const Args &a) {
     if (!out.open(a.pos[3], dbOut ? res.dbtype() : (int) sddb::DBTYPE_OMIT_FILE, &err)) return fail(err);
     if (!outH.open(a.pos[3] + "_h", sddb::DBTYPE_GENERIC_DB, &err)) return fail(err);
     uint32_t key = 0;
-    std::string buf, hbuf;
-    std::vector<uint32_t> member;
-    char co[32], mh[32];
-    for (uint32_t e = 0; e < nPairs; e++) {
-        const uint64_t off = hitOff[e], end = hitOff[e + 1];
-        for (uint32_t c = 0; c < nClusters[e]; c++) {
-            member.assign(cSize[off + c], 0);
-            for (uint64_t h = off; h < end; h++)
-                if (clusterOf[h] == c) member[rank[h]] = (uint32_t) (h - off);
-            buf.clear();
-            for (uint32_t m : member) buf.append(lines[off + m].first, lines[off + m].second);
-            snprintf(co, sizeof(co), "%.3E", pCO[off + c]);
-            snprintf(mh, sizeof(mh), "%.3E", pMH[off + c]);
-            hbuf = std::to_string(entryQSet[e]) + "\t" + std::to_string(entryTSet[e]) + "\t" + co + "\t" + mh + "\t" +
-                   std::to_string(cSize[off + c]) + "\n";
-            if (!out.write(key, buf.data(), buf.size()) || !outH.write(key, hbuf.data(), hbuf.size())) return fail("cannot write " + a.pos[3]);
-            key++;
+    // the clusters of a block of set pairs formatted on all threads (members in their rank order), written in order
+    struct PairText {
+        std::string body, head;
+        std::vector<uint32_t> bodyEnd, headEnd;   // per cluster
+    };
+    std::vector<PairText> texts;
+    const uint32_t writeBlock = 4096;
+    for (uint32_t e0 = 0; e0 < nPairs; e0 += writeBlock) {
+        const uint32_t e1 = std::min(nPairs, e0 + writeBlock);
+        texts.resize(e1 - e0);
+#pragma omp parallel
+        {
+            std::vector<uint32_t> member, start;
+            char co[32], mh[32];
+#pragma omp for schedule(dynamic, 8)
+            for (uint32_t e = e0; e < e1; e++) {
+                PairText &pt = texts[e - e0];
+                pt.body.clear();
+                pt.head.clear();
+                pt.bodyEnd.clear();
+                pt.headEnd.clear();
+                const uint64_t off = hitOff[e], end = hitOff[e + 1];
+                const uint32_t nC = nClusters[e];
+                start.assign((size_t) nC + 1, 0);
+                for (uint32_t c = 0; c < nC; c++) start[c + 1] = start[c] + cSize[off + c];
+                member.assign(start[nC], 0);
+                for (uint64_t h = off; h < end; h++)
+                    if (clusterOf[h] < nC) member[start[clusterOf[h]] + rank[h]] = (uint32_t) (h - off);
+                for (uint32_t c = 0; c < nC; c++) {
+                    for (uint32_t x = start[c]; x < start[c + 1]; x++) pt.body.append(lines[off + member[x]].first, lines[off + member[x]].second);
+                    snprintf(co, sizeof(co), "%.3E", pCO[off + c]);
+                    snprintf(mh, sizeof(mh), "%.3E", pMH[off + c]);
+                    pt.head += std::to_string(entryQSet[e]) + "\t" + std::to_string(entryTSet[e]) + "\t" + co + "\t" + mh + "\t" +
+                               std::to_string(cSize[off + c]) + "\n";
+                    pt.bodyEnd.push_back((uint32_t) pt.body.size());
+                    pt.headEnd.push_back((uint32_t) pt.head.size());
+                }
+            }
+        }
+        for (uint32_t e = e0; e < e1; e++) {
+            const PairText &pt = texts[e - e0];
+            uint32_t b0 = 0, h0 = 0;
+            for (size_t c = 0; c < pt.bodyEnd.size(); c++) {
+                if (!out.write(key, pt.body.data() + b0, pt.bodyEnd[c] - b0) || !outH.write(key, pt.head.data() + h0, pt.headEnd[c] - h0))
+                    return fail("cannot write " + a.pos[3]);
+                b0 = pt.bodyEnd[c];
+                h0 = pt.headEnd[c];
+                key++;
+            }
         }
     }
     lap.mark("write clusters");

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <immintrin.h>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -899,8 +900,10 @@ static int r2pBatchImpl(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32
                 taskQ.push_back(g0 + x);
             }
             if (!tasks.empty()) {
-                std::vector<char> cells(cellBytes + 64);
-                std::vector<float> gw(nWeights + 1), freq(nColumns * kResidues + 1), eff(nColumns + 1), table;
+                // (raw arrays: every byte is written before it is read, and zeroing half a gigabyte per group is time)
+                std::unique_ptr<char[]> cells(new char[cellBytes + 64]);
+                std::unique_ptr<float[]> freq(new float[nColumns * kResidues + 1]), eff(new float[nColumns + 1]);
+                std::vector<float> gw(nWeights + 1), table;
 #pragma omp parallel for schedule(dynamic, 16)
                 for (size_t k = 0; k < tasks.size(); k++) {
                     const Prepared &P = prep[taskQ[k] - g0];
@@ -920,8 +923,8 @@ static int r2pBatchImpl(sd_ctx *ctx, sd_r2p *r, const sd_r2p_params *par, uint32
                 std::vector<R2pTaskH> launch(tasks.size());
                 for (size_t k = 0; k < ord.size(); k++) launch[k] = tasks[ord[k]];
                 const double tB0 = omp_get_wtime();
-                const int rc = sdR2pColumnWeightsDevice(ctx, (uint32_t) tasks.size(), launch.data(), cells.data(), cellBytes, cmBytes, gw.data(),
-                                                        nWeights, nColumns, scratch, table.data(), rcpN, background, freq.data(), eff.data());
+                const int rc = sdR2pColumnWeightsDevice(ctx, (uint32_t) tasks.size(), launch.data(), cells.get(), cellBytes, cmBytes, gw.data(),
+                                                        nWeights, nColumns, scratch, table.data(), rcpN, background, freq.get(), eff.get());
                 if (rc != SD_OK) return rc;
                 const double tB1 = omp_get_wtime();
                 if (dbg)
