@@ -761,34 +761,46 @@ int subtractdbsModule(const Args &a) {
         for (const char *c = ls; c < le; c++) cols += (*c == '\t');
         return (cols >= 10 && c3) ? strtod(c3, nullptr) : 0.0;
     };
-    std::string result;
-    std::map<unsigned, bool> lookup;
-    for (size_t id = 0; id < left.size(); id++) {
-        lookup.clear();
-        const char *leftData = left.data(id);
-        for (const char *d = leftData; *d != '\0';) {
-            const char *ls = d;
-            while (*d != '\n' && *d != '\0') d++;
-            if (evalOf(ls, d) <= evalProfile) lookup[(unsigned) strtoul(ls, nullptr, 10)] = true;
-            if (*d == '\n') d++;
-        }
-        const size_t rid = right.idOfKey(left.key(id));
-        if (rid != SIZE_MAX) {
-            for (const char *d = right.data(rid); *d != '\0';) {
-                const char *ls = d;
-                while (*d != '\n' && *d != '\0') d++;
-                if (evalOf(ls, d) <= evalProfile) lookup[(unsigned) strtoul(ls, nullptr, 10)] = false;
-                if (*d == '\n') d++;
+    // a block of entries on all threads (every thread its own lookup), written in order
+    std::vector<std::string> results;
+    const size_t block = 8192;
+    for (size_t b0 = 0; b0 < left.size(); b0 += block) {
+        const size_t b1 = std::min(left.size(), b0 + block);
+        results.resize(b1 - b0);
+#pragma omp parallel
+        {
+            std::map<unsigned, bool> lookup;
+#pragma omp for schedule(dynamic, 16)
+            for (size_t id = b0; id < b1; id++) {
+                lookup.clear();
+                const char *leftData = left.data(id);
+                for (const char *d = leftData; *d != '\0';) {
+                    const char *ls = d;
+                    while (*d != '\n' && *d != '\0') d++;
+                    if (evalOf(ls, d) <= evalProfile) lookup[(unsigned) strtoul(ls, nullptr, 10)] = true;
+                    if (*d == '\n') d++;
+                }
+                const size_t rid = right.idOfKey(left.key(id));
+                if (rid != SIZE_MAX) {
+                    for (const char *d = right.data(rid); *d != '\0';) {
+                        const char *ls = d;
+                        while (*d != '\n' && *d != '\0') d++;
+                        if (evalOf(ls, d) <= evalProfile) lookup[(unsigned) strtoul(ls, nullptr, 10)] = false;
+                        if (*d == '\n') d++;
+                    }
+                }
+                std::string &result = results[id - b0];
+                result.clear();
+                for (const char *d = leftData; *d != '\0';) {
+                    const char *ls = d;
+                    while (*d != '\n' && *d != '\0') d++;
+                    if (*d == '\n') d++;
+                    if (lookup[(unsigned) strtoul(ls, nullptr, 10)]) result.append(ls, d - ls);
+                }
             }
         }
-        result.clear();
-        for (const char *d = leftData; *d != '\0';) {
-            const char *ls = d;
-            while (*d != '\n' && *d != '\0') d++;
-            if (*d == '\n') d++;
-            if (lookup[(unsigned) strtoul(ls, nullptr, 10)]) result.append(ls, d - ls);
-        }
-        if (!out.write(left.key(id), result.data(), result.size())) return fail("cannot write " + a.pos[2]);
+        for (size_t id = b0; id < b1; id++)
+            if (!out.write(left.key(id), results[id - b0].data(), results[id - b0].size())) return fail("cannot write " + a.pos[2]);
     }
     if (!out.close(&err)) return fail(err);
     return 0;

@@ -18,7 +18,9 @@
 // code, nothing else.
 #include "sd_common.h"
 
+#include <algorithm>
 #include <chrono>
+#include <vector>
 
 #include <cfloat>
 
@@ -26,7 +28,8 @@
 
 namespace {
 
-constexpr int R2P_NT = 256;
+constexpr int R2P_NT = 512;      // threads per alignment: one per column in the column-parallel passes, one per row in the row-parallel ones
+constexpr int R2P_ACT = 768;     // active rows whose index and weight are staged in LDS for the frequency pass (deeper alignments read them from memory)
 constexpr int kCodes = 24;   // cell codes 0..22 (0..19 residues, 20 any, 21 gap, 22 end gap), padded
 constexpr int kAnyC = 20, kGapC = 21, kEndGapC = 22, kRes = 20;
 
@@ -90,16 +93,24 @@ __device__ __forceinline__ void r2pScale20(float *v, const double *fallback) {
 // them from LDS again, LDSCOLS columns staged at a time by the whole workgroup (the chain chasing global loads was 0.8 s for
 // one alignment of 1 200 columns, the tail of the whole batch).
 template <int LDSCOLS>
-__global__ void __launch_bounds__(R2P_NT)
+__global__ void __launch_bounds__(R2P_NT, 4)   // two workgroups per CU: four waves per SIMD
 r2p_column_weights_kernel(const R2pTask *__restrict__ tasks, char *cellsRM, char *cellsCM, const float *__restrict__ globalWeight,
                           float *localWeight, uint32_t *activeList, const float *__restrict__ rcpTable, uint32_t rcpN,
                           const double *__restrict__ background, int *countG, float *shareG, float *subG, float *lgG,
-                          float *__restrict__ freq, float *__restrict__ eff, int *__restrict__ errFlag) {
-    __shared__ float subL[LDSCOLS * kCodes];
-    __shared__ float lgL[LDSCOLS * kCodes];
+                          float *__restrict__ freq, float *__restrict__ eff, int *__restrict__ errFlag,
+                          long long *__restrict__ taskTicks /* NULL, or the 100 MHz ticks every task took (SD_DEBUG_TIMING) */) {
+    const long long tick0 = taskTicks ? (long long) wall_clock64() : 0;
+    // one array: a long alignment's per-thread accumulators (R2P_NT x kCodes) span both halves
+    __shared__ float ldsF[2 * LDSCOLS * kCodes];
+    static_assert(R2P_NT * kCodes <= 2 * LDSCOLS * kCodes, "the accumulator slices of a long alignment must fit");
+    float *const subL = ldsF, *const lgL = ldsF + LDSCOLS * kCodes;
     __shared__ int sJmin, sJmax, sChanged, sActive, sPart;
     __shared__ uint32_t wavePart[R2P_NT / 64 + 1];
-    __shared__ uint32_t changeList[256];
+    __shared__ uint32_t changeList[R2P_NT];
+    __shared__ uint32_t actL[R2P_ACT];
+    __shared__ float actW[R2P_ACT];
+    __shared__ int rowCell[R2P_NT];
+    __shared__ float rowWeight[R2P_NT];
     __shared__ uint32_t sNChange;
     const R2pTask T = tasks[blockIdx.x];
     const int t = threadIdx.x, lane = t & 63;
@@ -111,7 +122,8 @@ r2p_column_weights_kernel(const R2pTask *__restrict__ tasks, char *cellsRM, char
     float *local = localWeight + T.weightOff;
     uint32_t *active = activeList + T.weightOff;
     int *count = countG + T.scratchOff;
-    float *share = shareG + T.scratchOff;
+    // the reciprocal table of a sub-alignment is dead before its logarithms are written: in LDS it shares their array
+    float *share = L > LDSCOLS ? shareG + T.scratchOff : lgL;
     const bool big = L > LDSCOLS;
     float *sub = big ? subG + T.scratchOff : subL;
     float *lg = big ? lgG + T.scratchOff : lgL;
@@ -150,11 +162,11 @@ r2p_column_weights_kernel(const R2pTask *__restrict__ tasks, char *cellsRM, char
             }
             if (delta) {
                 const uint32_t at = atomicAdd(&sNChange, 1u);
-                if (at < 256) changeList[at] = (r << 1) | (delta > 0 ? 1u : 0u);
+                if (at < (uint32_t) R2P_NT) changeList[at] = (r << 1) | (delta > 0 ? 1u : 0u);
                 atomicAdd(&sPart, delta);
             }
             __syncthreads();
-            // more than 256 changing rows in one pass of 256 rows cannot happen; drain the list now
+            // (a pass looks at R2P_NT rows, so the list cannot overflow); drain it now
             const uint32_t nC = sNChange;
             for (uint32_t c = 0; c < nC; c++) {
                 const uint32_t rr = changeList[c] >> 1;
@@ -232,28 +244,47 @@ r2p_column_weights_kernel(const R2pTask *__restrict__ tasks, char *cellsRM, char
                 for (uint32_t x = t; x < nActive; x += R2P_NT) {
                     const uint32_t r = active[x];
                     float acc = 1E-8f;
-                    // eight columns' cells and shares are requested before the first is added (the adds stay in column order)
+                    // sixteen columns' cells and shares are requested before the first is added (the adds stay in column order)
                     int j = jmin;
-                    for (; j + 8 <= jmax + 1; j += 8) {
-                        int c[8];
-                        float sv[8];
+                    for (; j + 16 <= jmax + 1; j += 16) {
+                        int c[16];
+                        float sv[16];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) c[u] = (int) cm[(size_t) (j + u) * T.rowStride + r];
+                        for (int u = 0; u < 16; u++) c[u] = (int) cm[(size_t) (j + u) * T.rowStride + r];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) sv[u] = share[(j + u) * kCodes + c[u]];
+                        for (int u = 0; u < 16; u++) sv[u] = share[(j + u) * kCodes + c[u]];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) acc += sv[u];
+                        for (int u = 0; u < 16; u++) acc += sv[u];
                     }
                     for (; j <= jmax; j++) acc += share[j * kCodes + (int) cm[(size_t) j * T.rowStride + r]];
                     local[r] = acc;
                 }
             }
             __syncthreads();
-            // ---- effective sequences of the sub-alignment: frequencies under the weights (rows in order), entropy
+            // ---- effective sequences of the sub-alignment: frequencies under the weights (rows in order), entropy.  This pass reads
+            // every cell of the sub-alignment -- the bulk of the kernel's time -- so the active rows' indices and weights come from LDS
+            const bool staged = nActive <= (uint32_t) R2P_ACT;
+            if (staged)
+                for (uint32_t x = t; x < nActive; x += R2P_NT) {
+                    const uint32_t r = active[x];
+                    actL[x] = r;
+                    actW[x] = local[r];
+                }
+            __syncthreads();
             for (int j = jmin + t; j <= jmax; j += R2P_NT) {
-                float *sj = big ? subL + t * kCodes : sub + j * kCodes;
+                float *sj = big ? ldsF + t * kCodes : sub + j * kCodes;
                 for (int a = 0; a < kCodes; a++) sj[a] = 0.0f;
                 uint32_t x = 0;
+                if (staged) {
+                    for (; x + 16 <= nActive; x += 16) {   // sixteen rows' cells in flight; the adds stay in row order
+                        int c[16];
+#pragma unroll
+                        for (int u = 0; u < 16; u++) c[u] = (int) rm[(size_t) actL[x + u] * T.stride + j];
+#pragma unroll
+                        for (int u = 0; u < 16; u++) sj[c[u]] += actW[x + u];
+                    }
+                    for (; x < nActive; x++) sj[(int) rm[(size_t) actL[x] * T.stride + j]] += actW[x];
+                }
                 for (; x + 8 <= nActive; x += 8) {   // eight rows' cells and weights in flight; the adds stay in row order
                     int c[8];
                     float wv[8];
@@ -316,29 +347,27 @@ r2p_column_weights_kernel(const R2pTask *__restrict__ tasks, char *cellsRM, char
             if (t == 0) ef[i] = i == 0 ? 0.0f : prevEff;
         }
         // ---- the column's residue frequencies under the current weights (rows in order)
-        if (t < kRes) {
+        {   // R2P_NT rows' cells and weights staged by the workgroup, then one thread per residue adds its rows in order
             float acc = 0.0f;
-            uint32_t r = 0;
-            for (; r + 8 <= nRows; r += 8) {
-                int c[8];
-                float wv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    c[u] = (int) colI[r + u];
-                    wv[u] = local[r + u];
+            for (uint32_t r0 = 0; r0 < nRows; r0 += R2P_NT) {
+                const uint32_t n = min((uint32_t) R2P_NT, nRows - r0);
+                if ((uint32_t) t < n) {
+                    rowCell[t] = (int) colI[r0 + t];
+                    rowWeight[t] = local[r0 + t];
                 }
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (c[u] == t) acc += wv[u];
+                __syncthreads();
+                if (t < kRes)
+                    for (uint32_t x = 0; x < n; x++)
+                        if (rowCell[x] == t) acc += rowWeight[x];
+                __syncthreads();
             }
-            for (; r < nRows; r++)
-                if ((int) colI[r] == t) acc += local[r];
-            fq[i * kRes + t] = acc;
+            if (t < kRes) fq[i * kRes + t] = acc;
         }
         __syncthreads();
         if (t == 0) r2pScale20(fq + i * kRes, background);
         __syncthreads();
     }
+    if (taskTicks && t == 0) taskTicks[blockIdx.x] = (long long) wall_clock64() - tick0;
 }
 
 }  // namespace
@@ -382,12 +411,14 @@ extern "C" int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, const void
     const double t0 = nowMs();
     if (dbg) SD_HIP(ctx, sdStreamSync(ctx));
     const double t1 = nowMs();
+    long long *dTicks = nullptr;
+    if (dbg) SD_HIP(ctx, wsGet(ctx, "r2p.ticks", (size_t) nTasks, &dTicks));
     {
         // one launch, the caller's order (longest alignments first: the tail of the batch starts at time 0)
         ProfScope ps(ctx, "r2p_column_weights");
         hipLaunchKernelGGL(r2p_column_weights_kernel<320>, dim3(nTasks), dim3(R2P_NT), 0, ctx->stream, (const R2pTask *) dTasks, dCells, dCm,
                            (const float *) dGw, dLocal, dActive, (const float *) dRcp, rcpN, (const double *) dBack, dCount, dShare, dSub, dLg,
-                           dFreq, dEff, dErr);
+                           dFreq, dEff, dErr, dTicks);
     }
     SD_HIP(ctx, hipGetLastError());
     if (dbg) SD_HIP(ctx, sdStreamSync(ctx));
@@ -397,6 +428,20 @@ extern "C" int sdR2pColumnWeightsDevice(sd_ctx *ctx, uint32_t nTasks, const void
     SD_HIP(ctx, hipMemcpyAsync(effOut, dEff, (size_t) nColumns * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(&hErr, dErr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(ctx, sdStreamSync(ctx));
+    if (dbg) {
+        std::vector<long long> ticks(nTasks);
+        SD_HIP(ctx, hipMemcpy(ticks.data(), dTicks, (size_t) nTasks * sizeof(long long), hipMemcpyDeviceToHost));
+        const R2pTask *th = (const R2pTask *) tasksHost;
+        std::vector<uint32_t> o(nTasks);
+        for (uint32_t k = 0; k < nTasks; k++) o[k] = k;
+        std::sort(o.begin(), o.end(), [&](uint32_t x, uint32_t y) { return ticks[x] > ticks[y]; });
+        double sum = 0;
+        for (uint32_t k = 0; k < nTasks; k++) sum += (double) ticks[k] * 1e-5;
+        fprintf(stderr, "[r2p device] workgroup time: sum %.0f ms; slowest", sum);
+        for (uint32_t k = 0; k < std::min(nTasks, 5u); k++)
+            fprintf(stderr, " %.1f ms (L %u, %u rows, launch slot %u)", (double) ticks[o[k]] * 1e-5, th[o[k]].L, th[o[k]].nRows, o[k]);
+        fprintf(stderr, "\n");
+    }
     if (dbg)
         fprintf(stderr, "[r2p device] %u tasks: upload %.1f ms, kernel %.1f ms, download %.1f ms\n", nTasks, t1 - t0, t2 - t1,
                 nowMs() - t2);
