@@ -76,6 +76,8 @@ int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offse
  * profile along the main diagonal. */
 int sd_profileset_create(sd_ctx *ctx, const uint8_t *queryLetters, const uint64_t *offsets, uint32_t n,
                          const int8_t *alnProfile, sd_seqset **out);
+/* A set is destroyed before the context it was made with: its device buffers return to that context's pool (the next set of a
+ * similar size takes them over; sd_ctx_destroy / sd_workspace_release free them). */
 void sd_seqset_destroy(sd_seqset *s);
 
 /* ---- Smith-Waterman (align module) ---------------------------------------------------- */

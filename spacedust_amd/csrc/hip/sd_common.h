@@ -11,6 +11,7 @@
 #include <ctime>
 #include <sys/prctl.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,7 +42,53 @@ struct sd_ctx {
     struct ProfPending { std::string name; hipEvent_t a = nullptr, b = nullptr; };
     std::vector<ProfPending> profPending;
     std::vector<hipEvent_t> evPool;
+    // device buffers of destroyed sequence sets, kept for the next one (a pipeline makes and drops a query set per chunk; hipFree
+    // waits for every stream of the device, i.e. for the other lanes' queued work)
+    struct PoolBuf { void *p = nullptr; size_t bytes = 0; };
+    std::vector<PoolBuf> pool;
+    std::mutex poolMutex;
 };
+
+// a device buffer of at least `bytes` from the context's pool (best fit), else a fresh one with a quarter of slack
+inline hipError_t poolGet(sd_ctx *ctx, size_t bytes, void **out, size_t *got) {
+    {
+        std::lock_guard<std::mutex> lock(ctx->poolMutex);
+        int best = -1;
+        for (size_t i = 0; i < ctx->pool.size(); i++)
+            if (ctx->pool[i].bytes >= bytes && (best < 0 || ctx->pool[i].bytes < ctx->pool[(size_t) best].bytes)) best = (int) i;
+        if (best >= 0 && ctx->pool[(size_t) best].bytes <= 4 * bytes + (1u << 20)) {
+            *out = ctx->pool[(size_t) best].p;
+            *got = ctx->pool[(size_t) best].bytes;
+            ctx->pool.erase(ctx->pool.begin() + best);
+            return hipSuccess;
+        }
+    }
+    const size_t grow = bytes + bytes / 4 + 256;
+    const hipError_t e = hipMalloc(out, grow);
+    *got = e == hipSuccess ? grow : 0;
+    return e;
+}
+
+// hands a buffer back; the pool keeps at most 24 (the smallest goes when it is full)
+inline void poolPut(sd_ctx *ctx, void *p, size_t bytes) {
+    if (!p) return;
+    void *drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->poolMutex);
+        sd_ctx::PoolBuf b;
+        b.p = p;
+        b.bytes = bytes;
+        ctx->pool.push_back(b);
+        if (ctx->pool.size() > 24) {
+            size_t smallest = 0;
+            for (size_t i = 1; i < ctx->pool.size(); i++)
+                if (ctx->pool[i].bytes < ctx->pool[smallest].bytes) smallest = i;
+            drop = ctx->pool[smallest].p;
+            ctx->pool.erase(ctx->pool.begin() + (long) smallest);
+        }
+    }
+    if (drop) (void) hipFree(drop);
+}
 
 inline hipEvent_t sdProfEvent(sd_ctx *ctx) {
     if (!ctx->evPool.empty()) {
@@ -160,6 +207,7 @@ struct sd_seqset {
     std::vector<int8_t> hProf;        // profile sets only: host copy of the alignment profile (scoreIdentical)
     std::vector<int32_t> hProfBias;   // profile sets only: per profile |min(0, min score)| (ssw_init, StripedSmithWaterman.cpp:1276-1287)
     uint64_t *dOff = nullptr;     // offsets n+1
+    size_t bRes = 0, bBias = 0, bProf = 0, bOff = 0;   // sizes of the device buffers (they come from and return to the context's pool)
     std::vector<uint64_t> hOff;   // host copy of the offsets
     std::vector<int32_t> hMinBias;// per sequence min(0, min cb8)
     int32_t maxEntryAdd = 0;      // largest composition bias of the set (sequences) / largest profile entry (profile sets)

@@ -2407,8 +2407,8 @@ __global__ void cand_stats_kernel(uint32_t nCand, const uint32_t *__restrict__ c
     }
 }
 
-template <typename T>
-int exclusiveScan(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, DevBuf<uint8_t> &tmp) {
+template <typename T, typename Tmp>
+int exclusiveScan(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, Tmp &tmp) {
     size_t bytes = 0;
     SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int) n, ctx->stream));
     if (tmp.n < bytes) SD_HIP(ctx, tmp.alloc(bytes + 256));
@@ -2521,8 +2521,8 @@ scan_apply_kernel(const T *__restrict__ in, uint64_t n, const uint64_t *__restri
     }
 }
 
-template <typename T>
-int exclusiveScanWiden(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, DevBuf<uint8_t> &tmp) {
+template <typename T, typename Tmp>
+int exclusiveScanWiden(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, Tmp &tmp) {
     if (n == 0) return SD_OK;
     const uint64_t nTiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (tmp.n < nTiles * sizeof(uint64_t)) SD_HIP(ctx, tmp.alloc(nTiles * sizeof(uint64_t) + 256));
@@ -2652,12 +2652,14 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
     const uint64_t maxDbMatches = std::max<uint64_t>(1000000, T->nSeq) * 2;   // QueryMatcher.cpp:43-47
     const uint64_t HIT_BUDGET = 1ull << 30;    // hits per sub-batch: rocPRIM's one-sweep radix sort degrades badly beyond 2^30 items (measured)
 
-    DevBuf<int8_t> dMat;
-    SD_HIP(ctx, dMat.alloc(441));
-    SD_HIP(ctx, hipMemcpy(dMat.p, par->ungappedMatrix, 441, hipMemcpyHostToDevice));
-    DevBuf<int> dErr;
+    // (workspace views, not allocations of this call: a hipFree at the end of every call waits for all streams of the device,
+    // i.e. for the other lanes of a pipeline)
+    WsView<int8_t> dMat(ctx, "pf.mat");
+    SD_HIP(ctx, dMat.alloc(448));
+    SD_HIP(ctx, hipMemcpyAsync(dMat.p, par->ungappedMatrix, 441, hipMemcpyHostToDevice, ctx->stream));
+    WsView<int> dErr(ctx, "pf.err");
     SD_HIP(ctx, dErr.alloc(1));
-    DevBuf<uint8_t> scanTmp, sortTmp;
+    WsView<uint8_t> scanTmp(ctx, "pf.scanTmp"), sortTmp(ctx, "pf.sortTmp");
 
     for (uint32_t x = 0; x < nQ; x++)
         if (qOffsets[x + 1] - qOffsets[x] > 65535)

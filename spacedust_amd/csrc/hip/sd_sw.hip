@@ -1517,6 +1517,7 @@ void sd_ctx_destroy(sd_ctx *ctx) {
     for (hipEvent_t e : ctx->evPool) (void) hipEventDestroy(e);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     for (auto &kv : ctx->ws) if (kv.second.p) (void) hipFree(kv.second.p);
+    for (auto &b : ctx->pool) if (b.p) (void) hipFree(b.p);
     for (auto &kv : ctx->pinned) if (kv.second.p) (void) hipHostFree(kv.second.p);
     delete ctx;
 }
@@ -1560,6 +1561,12 @@ int sd_workspace_release(sd_ctx *ctx) {
     for (auto &kv : ctx->ws)
         if (kv.second.p) (void) hipFree(kv.second.p);
     ctx->ws.clear();
+    {
+        std::lock_guard<std::mutex> lock(ctx->poolMutex);
+        for (auto &b : ctx->pool)
+            if (b.p) (void) hipFree(b.p);
+        ctx->pool.clear();
+    }
     ctx->biasTablesUploaded = false;
     return SD_OK;
 }
@@ -1649,14 +1656,18 @@ int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offse
         s->maxEntryAdd = mx;
     }
     const size_t pad = 64;
-    if (hipMalloc((void **) &s->dRes, s->total + pad) != hipSuccess || hipMalloc((void **) &s->dBias, s->total + pad) != hipSuccess ||
-        hipMalloc((void **) &s->dOff, (n + 1) * sizeof(uint64_t)) != hipSuccess) {
+    if (poolGet(ctx, s->total + pad, (void **) &s->dRes, &s->bRes) != hipSuccess ||
+        poolGet(ctx, s->total + pad, (void **) &s->dBias, &s->bBias) != hipSuccess ||
+        poolGet(ctx, (n + 1) * sizeof(uint64_t), (void **) &s->dOff, &s->bOff) != hipSuccess) {
+        (void) hipGetLastError();
         sd_seqset_destroy(s);
         return sdFail(ctx, SD_ENOMEM, "sd_seqset_create: device allocation of %llu bytes failed", (unsigned long long) s->total);
     }
-    SD_HIP(ctx, hipMemcpy(s->dRes, residues, s->total, hipMemcpyHostToDevice));
-    SD_HIP(ctx, hipMemcpy(s->dBias, s->hBias.data(), s->total, hipMemcpyHostToDevice));
-    SD_HIP(ctx, hipMemcpy(s->dOff, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    // on the context's stream (the set is used there), one wait for the three copies
+    SD_HIP(ctx, hipMemcpyAsync(s->dRes, s->hRes.data(), s->total, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(ctx, hipMemcpyAsync(s->dBias, s->hBias.data(), s->total, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(ctx, hipMemcpyAsync(s->dOff, s->hOff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(ctx, sdStreamSync(ctx));
     *out = s;
     return SD_OK;
 }
@@ -1671,13 +1682,15 @@ int sd_profileset_create(sd_ctx *ctx, const uint8_t *queryLetters, const uint64_
     if (rc != SD_OK) return rc;
     sd_seqset *s = *out;
     const size_t bytes = (size_t) s->total * 21;
-    if (hipMalloc((void **) &s->dProf, bytes + 64) != hipSuccess) {
+    if (poolGet(ctx, bytes + 64, (void **) &s->dProf, &s->bProf) != hipSuccess) {
+        (void) hipGetLastError();
         sd_seqset_destroy(s);
         *out = nullptr;
         return sdFail(ctx, SD_ENOMEM, "sd_profileset_create: device allocation of %llu bytes failed", (unsigned long long) bytes);
     }
-    SD_HIP(ctx, hipMemcpy(s->dProf, alnProfile, bytes, hipMemcpyHostToDevice));
     s->hProf.assign(alnProfile, alnProfile + bytes);
+    SD_HIP(ctx, hipMemcpyAsync(s->dProf, s->hProf.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(ctx, sdStreamSync(ctx));
     s->hProfBias.assign(n, 0);
     for (uint32_t i = 0; i < n; i++) {
         int m = 0;   // min over the 20 amino-acid columns (matSize = L * PROFILE_AA_SIZE, :1277-1279)
@@ -1695,10 +1708,11 @@ int sd_profileset_create(sd_ctx *ctx, const uint8_t *queryLetters, const uint64_
 
 void sd_seqset_destroy(sd_seqset *s) {
     if (!s) return;
-    if (s->dRes) (void) hipFree(s->dRes);
-    if (s->dProf) (void) hipFree(s->dProf);
-    if (s->dBias) (void) hipFree(s->dBias);
-    if (s->dOff) (void) hipFree(s->dOff);
+    // (a set is destroyed before its context, include/spacedust_gpu.h: its buffers go back to that context's pool)
+    poolPut(s->ctx, s->dRes, s->bRes);
+    poolPut(s->ctx, s->dProf, s->bProf);
+    poolPut(s->ctx, s->dBias, s->bBias);
+    poolPut(s->ctx, s->dOff, s->bOff);
     delete s;
 }
 
