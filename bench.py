@@ -249,6 +249,8 @@ def measure(args, rank, local_rank, world, dist, torch):
     torch.cuda.synchronize()
     cs.ctx.synchronize()
     t0 = time.time()
+    if os.environ.get('SD_DEBUG_WS'):   # the library's workspace log carries the same clock
+        print('[bench] t=%.3f timed region starts' % time.monotonic(), file=sys.stderr)
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     pairs_done, outs = run_steps([args.warmup + x for x in range(args.steps)])
     summary = np.zeros(4, np.int64)
@@ -275,6 +277,8 @@ def measure(args, rank, local_rank, world, dist, torch):
     if dist is not None:
         dist.barrier()
     dt = time.time() - t0
+    if os.environ.get('SD_DEBUG_WS'):
+        print('[bench] t=%.3f timed region ends' % time.monotonic(), file=sys.stderr)
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     if dist is not None:

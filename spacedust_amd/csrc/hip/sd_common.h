@@ -166,6 +166,8 @@ hipError_t wsGet(sd_ctx *ctx, const char *key, size_t count, T **out) {
     sd_ctx::WsEntry &e = ctx->ws[key];
     const size_t need = std::max<size_t>(count, 1) * sizeof(T);
     if (e.bytes < need) {
+        static const bool dbgWs = getenv("SD_DEBUG_WS") != nullptr;
+        if (dbgWs) fprintf(stderr, "[ws] t=%.3f %s: %zu -> %zu bytes%s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), key, e.bytes, need, e.p ? " (hipFree: waits for the device)" : "");
         if (e.p) (void) hipFree(e.p);
         e.p = nullptr;
         e.bytes = 0;
@@ -185,6 +187,8 @@ hipError_t pinGet(sd_ctx *ctx, const char *key, size_t count, T **out) {
     sd_ctx::WsEntry &e = ctx->pinned[key];
     const size_t need = std::max<size_t>(count, 1) * sizeof(T);
     if (e.bytes < need) {
+        static const bool dbgWs = getenv("SD_DEBUG_WS") != nullptr;
+        if (dbgWs) fprintf(stderr, "[ws] t=%.3f pinned %s: %zu -> %zu bytes%s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), key, e.bytes, need, e.p ? " (hipHostFree)" : "");
         if (e.p) (void) hipHostFree(e.p);
         e.p = nullptr;
         e.bytes = 0;
