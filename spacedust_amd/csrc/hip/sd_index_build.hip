@@ -155,11 +155,12 @@ __device__ __forceinline__ double bwdPart(MaskLane &m, uint32_t row, double toBg
 __global__ void __launch_bounds__(64)
 ib_mask_kernel(const uint8_t *__restrict__ res, const uint64_t *__restrict__ seqOff, const uint32_t *__restrict__ order, uint32_t nSeq,
                const double *__restrict__ lrTable, const uint64_t *__restrict__ waveRow, float *__restrict__ probT,
-               double *__restrict__ scaleT, double minMaskProb, uint8_t *__restrict__ masked, unsigned long long *__restrict__ nMasked) {
+               double *__restrict__ scaleT, double minMaskProb, uint8_t *__restrict__ masked, unsigned long long *__restrict__ nMasked,
+               uint32_t waveBase /* first wavefront of this launch: the scratch holds the rows of [waveBase, waveBase + gridDim.x) */) {
     __shared__ double lr[IB_ALPH * IB_ALPH];
     for (int i = threadIdx.x; i < IB_ALPH * IB_ALPH; i += 64) lr[i] = lrTable[i];
     __syncthreads();
-    const uint32_t wave = blockIdx.x, lane = threadIdx.x;
+    const uint32_t wave = waveBase + blockIdx.x, lane = threadIdx.x;
     const uint32_t slot = wave * 64 + lane;
     const bool have = slot < nSeq;
     const uint32_t seq = have ? order[slot] : 0;
@@ -171,8 +172,9 @@ ib_mask_kernel(const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq
     if (maxLen == 0) return;
     const uint8_t *s = res + base;
     uint8_t *out = masked + base;
-    float *prob = probT + waveRow[wave] * 64 + lane;
-    double *scale = scaleT + waveRow[wave] / TT_SCALE * 64 + lane;
+    const uint64_t row0 = waveRow[wave] - waveRow[waveBase];
+    float *prob = probT + row0 * 64 + lane;
+    double *scale = scaleT + row0 / TT_SCALE * 64 + lane;
     const double b2b = c_tt.b2b, f2b = c_tt.f2b;
     auto at = [&](int i) -> uint32_t {   // residue i as a byte offset into a row of lr (clamped: lanes outside their sequence)
         i = i >= L ? L - 1 : i;
@@ -558,7 +560,6 @@ extern "C" int sd_target_build(sd_ctx *ctx, int kmerSize, int kmerThr, int mask,
                           (unsigned long long) len);
         longest = std::max<uint32_t>(longest, (uint32_t) len);
     }
-    if ((uint64_t) nSeq >= (1ull << 47)) return SD_EINVAL;
     // the kernels read their tables (seed positions, powers, tantan constants) from __constant__ memory: one build at a time
     static std::mutex buildMutex;
     std::lock_guard<std::mutex> buildLock(buildMutex);
@@ -644,21 +645,45 @@ extern "C" int sd_target_build(sd_ctx *ctx, int kmerSize, int kmerThr, int mask,
             Scoped<float> dProb;
             Scoped<double> dScale, dLr;
             Scoped<unsigned long long> dN;
+            // the forward posteriors and rescaling factors between the passes: 64 lanes x (4 + 8 / 16) bytes per row of a wavefront,
+            // four to five times the residue bytes of the whole DB -- so the wavefronts run in slices against a scratch budget (an
+            // eighth of the device memory, SD_INDEX_MASK_BUDGET bytes for the tests; never less than the longest wavefront needs)
+            uint64_t maskBudgetRows;
+            {
+                size_t freeB = 0, totalB = 0;
+                (void) hipMemGetInfo(&freeB, &totalB);
+                uint64_t budget = getenv("SD_INDEX_MASK_BUDGET") ? strtoull(getenv("SD_INDEX_MASK_BUDGET"), nullptr, 10) : (uint64_t) totalB / 8;
+                budget = std::min<uint64_t>(budget, (uint64_t) freeB / 2);
+                maskBudgetRows = std::max<uint64_t>(budget / (64 * (sizeof(float) + sizeof(double) / TT_SCALE + 1)), 1);
+            }
+            uint64_t sliceRows = 0;   // the largest slice
+            {
+                uint32_t w0 = 0;
+                while (w0 < nWaves) {
+                    uint32_t w1 = w0 + 1;
+                    while (w1 < nWaves && waveRow[w1 + 1] - waveRow[w0] <= maskBudgetRows) w1++;
+                    sliceRows = std::max(sliceRows, waveRow[w1] - waveRow[w0]);
+                    w0 = w1;
+                }
+            }
             SD_HIP(ctx, dOrder.alloc(nSeq));
             SD_HIP(ctx, dWaveRow.alloc(nWaves + 1));
-            SD_HIP(ctx, dProb.alloc(waveRow[nWaves] * 64));
-            SD_HIP(ctx, dScale.alloc(waveRow[nWaves] / TT_SCALE * 64));
+            SD_HIP(ctx, dProb.alloc(sliceRows * 64));
+            SD_HIP(ctx, dScale.alloc(sliceRows / TT_SCALE * 64 + 64));
             SD_HIP(ctx, dLr.alloc(IB_ALPH * IB_ALPH));
             SD_HIP(ctx, dN.alloc(1));
             SD_HIP(ctx, hipMemcpy(dOrder.p, order.data(), (size_t) nSeq * sizeof(uint32_t), hipMemcpyHostToDevice));
             SD_HIP(ctx, hipMemcpy(dWaveRow.p, waveRow.data(), ((size_t) nWaves + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
             SD_HIP(ctx, hipMemcpy(dLr.p, maskRatios, IB_ALPH * IB_ALPH * sizeof(double), hipMemcpyHostToDevice));
             SD_HIP(ctx, hipMemsetAsync(dN.p, 0, sizeof(unsigned long long), ctx->stream));
-            {
+            for (uint32_t w0 = 0; w0 < nWaves;) {   // slices of wavefronts, one after the other on the stream (they share the scratch)
+                uint32_t w1 = w0 + 1;
+                while (w1 < nWaves && waveRow[w1 + 1] - waveRow[w0] <= maskBudgetRows) w1++;
                 ProfScope ps(ctx, "index_mask");
-                hipLaunchKernelGGL(ib_mask_kernel, dim3(nWaves), dim3(64), 0, ctx->stream, (const uint8_t *) dRes.p, (const uint64_t *) t->dSeqOff,
+                hipLaunchKernelGGL(ib_mask_kernel, dim3(w1 - w0), dim3(64), 0, ctx->stream, (const uint8_t *) dRes.p, (const uint64_t *) t->dSeqOff,
                                    (const uint32_t *) dOrder.p, nSeq, (const double *) dLr.p, (const uint64_t *) dWaveRow.p, dProb.p, dScale.p,
-                                   maskProb, t->dMasked, dN.p);
+                                   maskProb, t->dMasked, dN.p, w0);
+                w0 = w1;
             }
             SD_HIP(ctx, hipGetLastError());
             SD_HIP(ctx, hipStreamSynchronize(ctx->stream));

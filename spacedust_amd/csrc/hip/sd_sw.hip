@@ -1645,14 +1645,18 @@ int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offse
     if (swCompBias) s->hBias.assign(swCompBias, swCompBias + s->total);
     else s->hBias.assign(s->total, 0);
     s->hMinBias.assign(n, 0);
-    for (uint32_t i = 0; i < n; i++) {
-        int m = 0;
-        for (uint64_t x = offsets[i]; x < offsets[i + 1]; x++) m = std::min(m, (int) s->hBias[x]);
-        s->hMinBias[i] = m;
-    }
-    {
+    s->maxEntryAdd = 0;
+    if (swCompBias) {   // (a set without a bias -- the target side, 9 * 10^8 residues at 1 000 proteomes -- has nothing to scan)
         int mx = 0;
-        for (int8_t b : s->hBias) mx = std::max(mx, (int) b);
+#pragma omp parallel for schedule(static) reduction(max : mx)
+        for (uint32_t i = 0; i < n; i++) {
+            int m = 0;
+            for (uint64_t x = offsets[i]; x < offsets[i + 1]; x++) {
+                m = std::min(m, (int) swCompBias[x]);
+                mx = std::max(mx, (int) swCompBias[x]);
+            }
+            s->hMinBias[i] = m;
+        }
         s->maxEntryAdd = mx;
     }
     const size_t pad = 64;
@@ -1665,7 +1669,8 @@ int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offse
     }
     // on the context's stream (the set is used there), one wait for the three copies
     SD_HIP(ctx, hipMemcpyAsync(s->dRes, s->hRes.data(), s->total, hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(s->dBias, s->hBias.data(), s->total, hipMemcpyHostToDevice, ctx->stream));
+    if (swCompBias) SD_HIP(ctx, hipMemcpyAsync(s->dBias, s->hBias.data(), s->total, hipMemcpyHostToDevice, ctx->stream));
+    else SD_HIP(ctx, hipMemsetAsync(s->dBias, 0, s->total, ctx->stream));
     SD_HIP(ctx, hipMemcpyAsync(s->dOff, s->hOff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(ctx, sdStreamSync(ctx));
     *out = s;

@@ -73,6 +73,19 @@ def test_masking_of_repeats_and_sequence_lengths_around_the_ramp(gpu, host):
     _same(h, t.download())
 
 
+def test_masking_in_slices_against_a_scratch_budget(gpu, host, monkeypatch):
+    """the forward posteriors between tantan's two passes live in a scratch of bounded size: with a budget of 300 KB the 700
+    sequences run as many slices of wavefronts (down to one wavefront per launch) and give the same mask and index"""
+    rng = np.random.default_rng(5)
+    res, off = _repeats(rng, 700)
+    h = host.build_index(res, off, k=6, kmer_thr=0)
+    for budget in ('300000', '1', '40000000'):
+        monkeypatch.setenv('SD_INDEX_MASK_BUDGET', budget)
+        t = api.Target.build_on_device(gpu, host, res, off, k=6, kmer_thr=0)
+        assert t.build_stats['masked_residues'] == h.masked_residues
+        _same(h, t.download())
+
+
 def test_many_passes_and_the_wide_form(gpu, host, small_proteomes, monkeypatch):
     """k-mer ranges of at most 2 000 records per sort pass (dozens of passes), and 32-bit list starts relative to 64-bit block
     bases (what >= 2^32 entries need, forced by SD_INDEX_WIDE): the same index"""
