@@ -77,7 +77,8 @@ int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offse
 int sd_profileset_create(sd_ctx *ctx, const uint8_t *queryLetters, const uint64_t *offsets, uint32_t n,
                          const int8_t *alnProfile, sd_seqset **out);
 /* A set is destroyed before the context it was made with: its device buffers return to that context's pool (the next set of a
- * similar size takes them over; sd_ctx_destroy / sd_workspace_release free them). */
+ * similar size takes them over; sd_ctx_destroy / sd_workspace_release free them).  No call that uses the set may be in flight on any
+ * context when it is destroyed (every sd_* call returns with its work finished, so this only concerns sets shared between threads). */
 void sd_seqset_destroy(sd_seqset *s);
 
 /* ---- Smith-Waterman (align module) ---------------------------------------------------- */
