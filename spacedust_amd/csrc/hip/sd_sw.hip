@@ -230,6 +230,31 @@ template <bool GLOBAL> __device__ __forceinline__ void bandSync() {
 }
 __host__ __device__ __forceinline__ uint64_t tbGlobalIntBytes(int band) { return ((uint64_t) 3 * (2 * (uint64_t) band + 4) * 4 + 15) & ~15ull; }
 
+// DPP moves with compile-time control words (the traceback kernels' cross-lane traffic)
+__device__ __forceinline__ int dppI(int oldv, int src, int ctrl, int rowMask) {
+    switch (ctrl) {   // the control word must be a compile-time constant
+        case 0x138: return __builtin_amdgcn_update_dpp(oldv, src, 0x138, 0xf, 0xf, false);   // wave_shr:1
+        case 0x130: return __builtin_amdgcn_update_dpp(oldv, src, 0x130, 0xf, 0xf, false);   // wave_shl:1
+        case 0x111: return __builtin_amdgcn_update_dpp(oldv, src, 0x111, 0xf, 0xf, false);   // row_shr:1
+        case 0x112: return __builtin_amdgcn_update_dpp(oldv, src, 0x112, 0xf, 0xf, false);
+        case 0x114: return __builtin_amdgcn_update_dpp(oldv, src, 0x114, 0xf, 0xf, false);
+        case 0x118: return __builtin_amdgcn_update_dpp(oldv, src, 0x118, 0xf, 0xf, false);
+        default: return __builtin_amdgcn_update_dpp(oldv, src, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    }
+    (void) rowMask;
+}
+
+__device__ __forceinline__ int dppZ(int src, int ctrl) {   // lanes without a source read 0
+    switch (ctrl) {
+        case 0x138: return __builtin_amdgcn_update_dpp(0, src, 0x138, 0xf, 0xf, true);
+        case 0x130: return __builtin_amdgcn_update_dpp(0, src, 0x130, 0xf, 0xf, true);
+        case 0x111: return __builtin_amdgcn_update_dpp(0, src, 0x111, 0xf, 0xf, true);
+        case 0x112: return __builtin_amdgcn_update_dpp(0, src, 0x112, 0xf, 0xf, true);
+        case 0x114: return __builtin_amdgcn_update_dpp(0, src, 0x114, 0xf, 0xf, true);
+        default: return __builtin_amdgcn_update_dpp(0, src, 0x118, 0xf, 0xf, true);
+    }
+}
+
 template <bool PROF, bool GLOBAL = false>
 __global__ void __launch_bounds__(64)
 sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
@@ -278,6 +303,29 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
     // (the idle half of an odd last wavefront owns no scratch: in the global class its stores would land in another task's arrays)
     for (int x = l; (have || !GLOBAL) && x <= width && x < ldsStride; x += 32) { bandSt<GLOBAL>(h_b + x, 0); bandSt<GLOBAL>(e_b + x, 0); bandSt<GLOBAL>(h_c + x, 0); }
     bandSync<GLOBAL>();
+    // Operands of the substitution score two rows ahead, the score itself one row ahead: neither the global loads (query
+    // letter, bias, target letter of the row's first 32 cells) nor the matrix / profile lookup sit on a row's critical path.
+    auto rowClamp = [&](int r) -> int { return r < qLen ? r : qLen - 1; };
+    auto loadT = [&](int r) -> int {   // target letter of cell l of row r's first chunk
+        int jn = ((r - band) > 0 ? (r - band) : 0) + l;
+        jn = jn >= tLen ? tLen - 1 : jn;
+        jn = jn < 0 ? 0 : jn;
+        return (int) t[jn];
+    };
+    auto scoreOf = [&](int r, int qv, int cbv, int tv) -> int {
+        if (PROF) return (int) qProf[(tk.qAbs + (uint64_t) r) * 21 + tv];
+        return (int) smat[21 * qv + tv] + cbv;
+    };
+    int qa = 0, cba = 0, qb = 0, cbb = 0, tb = 0, sNext = 0;
+    if (have && qLen > 0 && tLen > 0) {
+        qa = q[0];
+        cba = PROF ? 0 : cb[0];
+        sNext = scoreOf(0, qa, cba, loadT(0));
+        const int r1 = rowClamp(1);
+        qb = q[r1];
+        cbb = PROF ? 0 : cb[r1];
+        tb = loadT(r1);
+    }
     for (int i = 0; i < qLen; i++) {
         int beg = 0, end = tLen - 1;
         int jj = i - band; beg = beg > jj ? beg : jj;
@@ -288,11 +336,15 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
             bandSt<GLOBAL>(h_c, 0);
         }
         bandSync<GLOBAL>();
+        const int sCur = sNext;
+        const int r1 = rowClamp(i + 1), r2 = rowClamp(i + 2);
+        sNext = scoreOf(r1, qb, cbb, tb);
+        const int qc = q[r2], cbc = PROF ? 0 : (int) cb[r2], tc = loadT(r2);
         const int xi = (i - band) > 0 ? (i - band) : 0;
         const int xim = (i - 1 - band) > 0 ? (i - 1 - band) : 0;
         const int W = end - beg + 1;
-        const int8_t *mrow = PROF ? qProf + (tk.qAbs + (uint64_t) i) * 21 : smat + 21 * q[i];   // never a mixed (flat) pointer
-        const int cbi = PROF ? 0 : cb[i];
+        const int8_t *mrow = PROF ? qProf + (tk.qAbs + (uint64_t) i) * 21 : smat + 21 * qa;   // never a mixed (flat) pointer
+        const int cbi = cba;
         int8_t *dl = direction + (long long) width_d * i;
         int carry = -ge, prevHc = 0, prevF = 0, uLast = 0;
         for (int p0 = 0; p0 < W; p0 += 32) {
@@ -300,7 +352,7 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
             const bool valid = p < W;
             const int j = beg + p;
             const int u = j - xi + 1;
-            int T = 0, S = -(1 << 28), eNew = 0, e1 = 0, diag = 0;
+            int T = 0, eNew = 0, e1 = 0, diag = 0;
             bool dirE = false;
             if (valid) {
                 const int e = j - xim + 1, d = (j - 1) - xim + 1;
@@ -309,23 +361,25 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
                 eNew = t1 > t2 ? t1 : t2;
                 dirE = t1 > t2;
                 e1 = eNew > 0 ? eNew : 0;
-                diag = bandLd<GLOBAL>(h_b + d) + mrow[t[j]] + cbi;
+                const int sc = p0 == 0 ? sCur : (int) mrow[t[j]] + cbi;
+                diag = bandLd<GLOBAL>(h_b + d) + sc;
                 T = e1 > diag ? e1 : diag;
-                S = T - go + ge * (p + 1);
             }
-            // exclusive prefix max of S over the 32 lanes
-            int incl = S;
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                int o = __shfl_up(incl, off, 32);
-                if (l >= off) incl = incl > o ? incl : o;
-            }
-            int excl = __shfl_up(incl, 1, 32);
-            if (l == 0) excl = -(1 << 28);
-            int g = carry > excl ? carry : excl;
+            // exclusive prefix maximum of S = T - go + ge * (p + 1) over the 32 lanes by DPP moves (the half wavefront is two
+            // rows of 16), carried as S + go + 1 >= 1 so that the 0 a zero-filled move delivers is the identity
+            int incl = valid ? T + ge * (p + 1) + 1 : 0, o;
+            o = dppZ(incl, 0x111); incl = incl > o ? incl : o;
+            o = dppZ(incl, 0x112); incl = incl > o ? incl : o;
+            o = dppZ(incl, 0x114); incl = incl > o ? incl : o;
+            o = dppZ(incl, 0x118); incl = incl > o ? incl : o;
+            o = dppI(0, incl, 0x142, 0xa); incl = incl > o ? incl : o;
+            int excl = dppZ(incl, 0x138);
+            excl = l == 0 ? 0 : excl;
+            const int exclS = excl - go - 1;   // (no predecessor: -go - 1 < -ge <= carry)
+            int g = carry > exclS ? carry : exclS;
             const int f = g - ge * p;
             const int hcv = T > f ? T : f;
-            int hcP = __shfl_up(hcv, 1, 32), fP = __shfl_up(f, 1, 32);
+            int hcP = dppZ(hcv, 0x138), fP = dppZ(f, 0x138);
             if (l == 0) { hcP = prevHc; fP = prevF; }
             if (valid) {
                 const bool dirF = (hcP - go) > (fP - ge);
@@ -338,11 +392,16 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
                 bandSt<GLOBAL>(h_c + u, hcv);
                 maxv = hcv > maxv ? hcv : maxv;
             }
-            // carries to the next chunk
-            const int cm = __shfl(incl, 31, 32);
-            carry = carry > cm ? carry : cm;
-            prevHc = __shfl(hcv, 31, 32);
-            prevF = __shfl(f, 31, 32);
+            // carries to the next chunk: lane 31 of this half (a full chunk whenever there is a next one)
+            if (p0 + 32 < W) {
+                const int cmA = __builtin_amdgcn_readlane(incl, 31), cmB = __builtin_amdgcn_readlane(incl, 63);
+                const int hcA = __builtin_amdgcn_readlane(hcv, 31), hcB = __builtin_amdgcn_readlane(hcv, 63);
+                const int fA = __builtin_amdgcn_readlane(f, 31), fB = __builtin_amdgcn_readlane(f, 63);
+                const int cm = (grp ? cmB : cmA) - go - 1;
+                carry = carry > cm ? carry : cm;
+                prevHc = grp ? hcB : hcA;
+                prevF = grp ? fB : fA;
+            }
             const int lastValid = (W - p0) < 32 ? (W - p0 - 1) : 31;
             uLast = (beg + p0 + lastValid) - xi + 1;
             if constexpr (!GLOBAL) __builtin_amdgcn_wave_barrier();   // (GLOBAL: a lane only re-reads what other lanes wrote after the row's fence)
@@ -352,6 +411,11 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
             for (int x = 1 + l; x <= uLast; x += 32) bandSt<GLOBAL>(h_b + x, bandLd<GLOBAL>(h_c + x));
         }
         bandSync<GLOBAL>();
+        qa = qb;
+        cba = cbb;
+        qb = qc;
+        cbb = cbc;
+        tb = tc;
     }
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) {
@@ -439,30 +503,6 @@ sw_traceback_walk_kernel(const TbTask *__restrict__ tasks, uint32_t nTasks, cons
 // direction codes (16 bytes per row) live in LDS; lane 0 walks the path out of LDS.
 // qCap / tCap: LDS capacity per task (rows, columns) of this launch class.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int dppI(int oldv, int src, int ctrl, int rowMask) {
-    switch (ctrl) {   // the control word must be a compile-time constant
-        case 0x138: return __builtin_amdgcn_update_dpp(oldv, src, 0x138, 0xf, 0xf, false);   // wave_shr:1
-        case 0x130: return __builtin_amdgcn_update_dpp(oldv, src, 0x130, 0xf, 0xf, false);   // wave_shl:1
-        case 0x111: return __builtin_amdgcn_update_dpp(oldv, src, 0x111, 0xf, 0xf, false);   // row_shr:1
-        case 0x112: return __builtin_amdgcn_update_dpp(oldv, src, 0x112, 0xf, 0xf, false);
-        case 0x114: return __builtin_amdgcn_update_dpp(oldv, src, 0x114, 0xf, 0xf, false);
-        case 0x118: return __builtin_amdgcn_update_dpp(oldv, src, 0x118, 0xf, 0xf, false);
-        default: return __builtin_amdgcn_update_dpp(oldv, src, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
-    }
-    (void) rowMask;
-}
-
-__device__ __forceinline__ int dppZ(int src, int ctrl) {   // lanes without a source read 0
-    switch (ctrl) {
-        case 0x138: return __builtin_amdgcn_update_dpp(0, src, 0x138, 0xf, 0xf, true);
-        case 0x130: return __builtin_amdgcn_update_dpp(0, src, 0x130, 0xf, 0xf, true);
-        case 0x111: return __builtin_amdgcn_update_dpp(0, src, 0x111, 0xf, 0xf, true);
-        case 0x112: return __builtin_amdgcn_update_dpp(0, src, 0x112, 0xf, 0xf, true);
-        case 0x114: return __builtin_amdgcn_update_dpp(0, src, 0x114, 0xf, 0xf, true);
-        default: return __builtin_amdgcn_update_dpp(0, src, 0x118, 0xf, 0xf, true);
-    }
-}
-
 template <bool PROF>
 __global__ void __launch_bounds__(64)
 sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
@@ -583,40 +623,79 @@ sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const ui
         if (done && doneOther) break;
     }
     __syncthreads();
-    if (!have || l != 0) return;
-    tasks[id].maxv = maxv;
-    tasks[id].band = band;
-    if (!reached) {
-        res[2 * id] = -2;
-        return;
+    if (have && l == 0) {
+        tasks[id].maxv = maxv;
+        tasks[id].band = band;
+        if (!reached) res[2 * id] = -2;
     }
-    // traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581), written backwards
+    // traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581), written backwards.  The path is mostly
+    // runs of diagonal steps: while the walk is in the match state the 32 lanes of the half wavefront look at the next 32 cells
+    // down the diagonal at once, the leading run of cells whose code says "diagonal" is taken in one step (a coalesced store
+    // of 'M's, identities by popcount), and the first cell that is anything else goes through the one-cell step below, which
+    // every lane of the half executes redundantly (same LDS words: broadcasts) so that the walk state stays lane-uniform.
     const int width_d = band * 2 + 1;
     int i = qLen - 1, j = tLen - 1, state = 2;
     char *o = bt + tk.btOff + (qLen + tLen + 2);
     int len = 0, ids = 0;
     bool bad = false;
-    while (i > 0 || j > 0) {
-        if (i < 0 || j < 0) { bad = true; break; }
-        int x = i - band;
-        x = x > 0 ? x : 0;
-        x = j - x;
-        if (x < 0 || x >= width_d) { bad = true; break; }
-        const int byte = dirs[(size_t) 16 * i + (x >> 1)];
-        const int code = (x & 1) ? (byte >> 4) : (byte & 15);
-        int dcode;
-        const int dE = (code & 1) ? 3 : 2, dF = (code & 2) ? 5 : 4;
-        if (state == 0) dcode = dE;
-        else if (state == 1) dcode = dF;
-        else dcode = (code & 4) ? dE : ((code & 8) ? dF : 1);
-        switch (dcode) {
-            case 1: ids += (sq[i] == st[j]); --i; --j; state = 2; *--o = 'M'; len++; break;
-            case 2: --i; state = 0; *--o = 'I'; len++; break;
-            case 3: --i; state = 2; *--o = 'I'; len++; break;
-            case 4: --j; state = 1; *--o = 'D'; len++; break;
-            default: --j; state = 2; *--o = 'D'; len++; break;
+    bool going = have && reached && (i > 0 || j > 0);
+    const int sh = grp * 32;
+    while (__ballot(going)) {
+        {
+            const int ii = i - l, jj = j - l;
+            bool ok = going && state == 2 && (ii > 0 || jj > 0) && ii >= 0 && jj >= 0;
+            int x = ii - band;
+            x = x > 0 ? x : 0;
+            x = jj - x;
+            ok = ok && x >= 0 && x < width_d;
+            bool same = false;
+            if (ok) {
+                const int byte = dirs[(size_t) 16 * ii + (x >> 1)];
+                const int code = (x & 1) ? (byte >> 4) : (byte & 15);
+                ok = (code & 12) == 0;
+                same = sq[ii] == st[jj];
+            }
+            const uint32_t okMask = (uint32_t) (__ballot(ok) >> sh);
+            const uint32_t sameMask = (uint32_t) (__ballot(same) >> sh);
+            const int run = okMask == 0xFFFFFFFFu ? 32 : __builtin_ctz(~okMask);
+            const uint32_t runMask = run == 32 ? 0xFFFFFFFFu : ((1u << run) - 1u);
+            if (l < run) o[-1 - l] = 'M';
+            ids += __builtin_popcount(sameMask & runMask);
+            i -= run;
+            j -= run;
+            o -= run;
+            len += run;
         }
+        if (going && (i > 0 || j > 0)) {
+            if (i < 0 || j < 0) bad = true;
+            int x = i - band;
+            x = x > 0 ? x : 0;
+            x = j - x;
+            if (x < 0 || x >= width_d) bad = true;
+            if (!bad) {
+                const int byte = dirs[(size_t) 16 * i + (x >> 1)];
+                const int code = (x & 1) ? (byte >> 4) : (byte & 15);
+                int dcode;
+                const int dE = (code & 1) ? 3 : 2, dF = (code & 2) ? 5 : 4;
+                if (state == 0) dcode = dE;
+                else if (state == 1) dcode = dF;
+                else dcode = (code & 4) ? dE : ((code & 8) ? dF : 1);
+                char c;
+                switch (dcode) {
+                    case 1: ids += (sq[i] == st[j]); --i; --j; state = 2; c = 'M'; break;
+                    case 2: --i; state = 0; c = 'I'; break;
+                    case 3: --i; state = 2; c = 'I'; break;
+                    case 4: --j; state = 1; c = 'D'; break;
+                    default: --j; state = 2; c = 'D'; break;
+                }
+                --o;
+                if (l == 0) *o = c;
+                len++;
+            }
+        }
+        going = going && !bad && (i > 0 || j > 0);
     }
+    if (!have || !reached || l != 0) return;
     if (bad || i != 0 || j != 0) {
         res[2 * id] = -1;
         return;
