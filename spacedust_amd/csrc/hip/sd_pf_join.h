@@ -411,6 +411,7 @@ __global__ void join_effective_totals_kernel(uint32_t nQ, const uint32_t *__rest
 // Every wavefront works through its 64 * JE k-mers of a chunk on its own (no workgroup barrier inside the loop, so the
 // wavefronts of a CU hide each other's memory latency): list starts and lengths, a wave scan of the lengths, then the
 // lists flattened over the lanes -- hit f of the wavefront belongs to the k-mer x with off[x] <= f < off[x + 1].
+template <bool NT_STORE>
 __global__ void __launch_bounds__(JJ_NT)
 join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint16_t *__restrict__ chunkBin,
                     const uint32_t *__restrict__ idxOffsets, const uint2 *__restrict__ entries, uint32_t nQ,
@@ -525,9 +526,11 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
                     if (live && kq == kL) pos = b0 + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
                     todo &= ~mask;
                 }
-                if (live)
-                    __builtin_nontemporal_store(((unsigned long long) (((((v >> 24) - en[j].y) & 0xFFu) << 24) | (v & 0xFFFFFFu)) << 32) | (kq | en[j].x),
-                                                (unsigned long long *) outKV + pos);
+                if (live) {
+                    const unsigned long long kv = ((unsigned long long) (((((v >> 24) - en[j].y) & 0xFFu) << 24) | (v & 0xFFFFFFu)) << 32) | (kq | en[j].x);
+                    if (NT_STORE) __builtin_nontemporal_store(kv, (unsigned long long *) outKV + pos);
+                    else ((unsigned long long *) outKV)[pos] = kv;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();

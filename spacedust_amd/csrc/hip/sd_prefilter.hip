@@ -2972,7 +2972,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             if (nHits > 0) {
                 SD_HIP(ctx, dHitsKV.alloc(nHits));
                 ProfScope ps(ctx, "prefilter_join_scatter");
-                hipLaunchKernelGGL(join_scatter_kernel, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSorted,
+                // SD_JOIN_NT=0: plain stores (partial lines of neighbouring runs merge in the XCD's L2 before they are written back)
+                static const bool ntStore = !(getenv("SD_JOIN_NT") && atoi(getenv("SD_JOIN_NT")) == 0);
+                auto kern = ntStore ? join_scatter_kernel<true> : join_scatter_kernel<false>;
+                hipLaunchKernelGGL(kern, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSorted,
                                    (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                    (const uint32_t *) dJqCounts.p, (int) bq, (const uint64_t *) dQHitBase.p, tBits,
                                    (const uint32_t *) dQSplit.p, dHitsKV.p);

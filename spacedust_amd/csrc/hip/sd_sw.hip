@@ -543,21 +543,37 @@ sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const ui
         const int rows = (fits && !reached) ? qLen : 0;
         const int rowsOther = __shfl_xor(rows, 32, 64);
         const int nRows = max(rows, rowsOther);
-        // substitution score of this lane's cell, fetched one row ahead (two dependent LDS reads off the critical path)
-        auto cellScore = [&](int row) -> int {
-            if (rows == 0) return 0;
+        // substitution score of this lane's cell: its operands (query letter, bias, target letter) are read two rows ahead and
+        // the matrix / profile entry one row ahead, so that neither of the two dependent LDS round trips is waited for inside a
+        // row (a wavefront issues in order: a wait in front of the first use stalls the recurrence behind it as well)
+        auto cellOps = [&](int row, int &qv, int &tv, int &cbv) {
+            qv = 0; tv = 0; cbv = 0;
+            if (rows == 0) return;
             const int r = row < qLen ? row : qLen - 1;
             const int x0 = (r - band) > 0 ? (r - band) : 0;
             int jn = x0 + l - 1;
             jn = jn < 0 ? 0 : (jn >= tLen ? tLen - 1 : jn);
-            if (PROF) return (int) qProf[(tk.qAbs + (uint64_t) r) * 21 + st[jn]];
-            return (int) smat[21 * sq[r] + st[jn]] + (int) scb[r];
+            tv = st[jn];
+            if (!PROF) {
+                qv = sq[r];
+                cbv = scb[r];
+            }
         };
-        int sNext = cellScore(0);
+        auto cellLook = [&](int row, int qv, int tv, int cbv) -> int {
+            if (rows == 0) return 0;
+            const int r = row < qLen ? row : qLen - 1;
+            if (PROF) return (int) qProf[(tk.qAbs + (uint64_t) r) * 21 + tv];
+            return (int) smat[21 * qv + tv] + cbv;
+        };
+        int qb, tb, cbb;
+        cellOps(0, qb, tb, cbb);
+        int sNext = cellLook(0, qb, tb, cbb);
+        cellOps(1, qb, tb, cbb);
         for (int i = 0; i < nRows; i++) {
             const bool live = i < rows;
             const int sCur = sNext;
-            sNext = cellScore(i + 1);
+            sNext = cellLook(i + 1, qb, tb, cbb);
+            cellOps(i + 2, qb, tb, cbb);
             const int xi = (i - band) > 0 ? (i - band) : 0;
             const int delta = (i - band) >= 1 ? 1 : 0;     // xi - xim
             int end = tLen - 1;

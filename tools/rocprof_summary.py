@@ -28,5 +28,18 @@ def main(path):
     print('total GPU kernel time: %.3f ms over %d dispatches' % (tot / 1e6, sum(r[1] for r in rows)))
 
 
+def dispatches(path, pattern):
+    """every dispatch of the kernels whose name contains `pattern`: grid, workgroup, LDS, duration"""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute('pragma table_info(kernels)')]
+    grid = 'grid_x' if 'grid_x' in cols else ('grid_size_x' if 'grid_size_x' in cols else 'workgroup_x')
+    for r in db.execute('select name, %s, workgroup_x, lds_size, duration from kernels where name like ? order by start' % grid,
+                        ('%' + pattern + '%',)):
+        print('%-60s grid %9d wg %5d lds %7d  %10.1f us' % (short(r[0])[:60], r[1], r[2], r[3] or 0, r[4] / 1e3))
+
+
 if __name__ == '__main__':
-    main(sys.argv[1])
+    if len(sys.argv) > 3 and sys.argv[2] == '--dispatches':
+        dispatches(sys.argv[1], sys.argv[3])
+    else:
+        main(sys.argv[1])
