@@ -1095,7 +1095,7 @@ coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
 //           tile i in registers (and have the loads of tile i + 1 in flight) before any survivor of tile i is written, and
 //           the survivors of tiles 0 .. i fit in front of tile i + 1, so no unread hit is overwritten.
 // False positives (Bloom collisions, bitmap aliasing) cost bandwidth downstream, never correctness: bucket_match decides.
-constexpr int HF_PER = 4;                  // hits per thread and tile (pass B; the next tile is in flight as well)
+// (HF_PER, template parameter: hits per thread and tile of pass B; the next tile is in flight as well)
 constexpr int HF_PER_A = 8;                // hits per thread and step of pass A
 
 __device__ __forceinline__ uint32_t hfMix(uint32_t tgt, uint32_t d8) {
@@ -1110,7 +1110,7 @@ __device__ __forceinline__ uint32_t hfMix(uint32_t tgt, uint32_t d8) {
 // BW * 64 / 5 keys (a proteome-scale query segment in one round); a longer segment is taken in rounds over classes of targets (a hash of the target picks the round), the
 // Bloom filter cleared in between and the hot bitmap kept: the false-positive rate stays at the design point whatever the
 // segment length, at one more read of the segment per round.
-template <int NT, int BW, int HL>
+template <int NT, int BW, int HL, int HF_PER = 4>
 __global__ void __launch_bounds__(NT)
 hot_filter_kernel(uint32_t nVQ, const uint64_t *__restrict__ segBase, int tBits, uint32_t *key, uint32_t *val, uint2 *kv,
                   int wpBits /* wide stream positions: the diagonal byte sits in the key above the target bits */,
@@ -3154,7 +3154,9 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         else if (geo == 2) SD_HF(512, 8192, 17);    // 48 KB
                         else if (geo == 3) SD_HF(256, 6144, 16);    // 32 KB
                         else if (geo == 4) SD_HF(1024, 16384, 18);  // 96 KB
-                        else SD_HF(1024, 24576, 18);                // 128 KB
+                        else if (geo == 5) SD_HF(1024, 24576, 18);  // 128 KB, pass-B tiles of 4 096 hits
+                        else hipLaunchKernelGGL((hot_filter_kernel<1024, 24576, 18, 8>), dim3(nVQ), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV,
+                                                (uint32_t *) pKey, (uint32_t *) pVal, (uint2 *) pKV, widePos ? tBitsV : 0, minSeg, dHotCount.p);   // 128 KB, tiles of 8 192: half the barriers (isolated 62.9 -> 60.5 ms per step)
 #undef SD_HF
                     }
                     int rcF = exclusiveScanWiden(ctx, dHotCount.p, dHotBase.p, (uint64_t) nVQ + 1, scanTmp);

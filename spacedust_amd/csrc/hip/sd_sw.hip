@@ -439,19 +439,30 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
     res[2 * id] = -3;   // band found, directions written: sw_traceback_walk_kernel walks the path
 }
 
-// The walk of the LDS-band / global-band kernel's tasks, one task per lane: inside sw_traceback_kernel it was lane 0 of a
-// half wavefront chasing ~qLen + tLen dependent loads with 31 lanes parked; here every lane chases its own chain.
+// The walk of the LDS-band / global-band kernel's tasks: inside sw_traceback_kernel it was lane 0 of a half wavefront chasing
+// ~qLen + tLen dependent loads with 31 lanes parked.  Here 16 lanes own a task (four tasks per wavefront): while the walk is in
+// the match state the lanes look at the next 16 cells down the diagonal at once (16 independent loads instead of 16 dependent
+// ones), the leading run of cells whose code says "diagonal" is taken in one step -- a coalesced store of 'M's, identities by
+// popcount -- and the first cell that is anything else goes through the one-cell step, executed by all 16 lanes alike (same
+// address: one request) so that the walk state stays uniform over the group.
 // traceback (:1498-1558) + expansion / identity count (computerBacktrace, :548-581)
+constexpr int TBW_LANES = 16;
 template <bool GLOBAL>
 __global__ void __launch_bounds__(256)
 sw_traceback_walk_kernel(const TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                          const uint8_t *__restrict__ tRes, const int8_t *__restrict__ dirs, char *__restrict__ bt,
                          int32_t *__restrict__ res, const uint32_t *__restrict__ order /* nullable */) {
-    const uint32_t lid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lid >= nTasks) return;
-    const uint32_t id = order ? order[lid] : lid;
-    if (res[2 * id] != -3) return;
-    const TbTask tk = tasks[id];
+    const uint32_t lid = (blockIdx.x * blockDim.x + threadIdx.x) / TBW_LANES;
+    const int l = threadIdx.x & (TBW_LANES - 1), sh = threadIdx.x & 63 & ~(TBW_LANES - 1);
+    uint32_t id = 0;
+    bool have = lid < nTasks;
+    if (have) {
+        id = order ? order[lid] : lid;
+        have = res[2 * id] == -3;
+    }
+    TbTask tk;
+    if (have) tk = tasks[id];
+    else { tk.qLen = 1; tk.tLen = 1; tk.band = 1; tk.qAbs = 0; tk.tAbs = 0; tk.dirOff = 0; tk.btOff = 0; }
     const int qLen = tk.qLen, tLen = tk.tLen, band = tk.band;
     const int width_d = band * 2 + 1;
     const uint8_t *q = qRes + tk.qAbs;
@@ -463,26 +474,61 @@ sw_traceback_walk_kernel(const TbTask *__restrict__ tasks, uint32_t nTasks, cons
     char *o = bt + tk.btOff + (qLen + tLen + 2);
     int len = 0, ids = 0;
     bool bad = false;
-    while (i > 0 || j > 0) {
-        if (i < 0 || j < 0) { bad = true; break; }
-        int x = i - band;
-        x = x > 0 ? x : 0;
-        x = j - x;
-        if (x < 0 || x >= width_d) { bad = true; break; }
-        const int code = direction[(long long) width_d * i + x];
-        int dcode;
-        const int dE = (code & 1) ? 3 : 2, dF = (code & 2) ? 5 : 4;
-        if (state == 0) dcode = dE;
-        else if (state == 1) dcode = dF;
-        else dcode = (code & 4) ? dE : ((code & 8) ? dF : 1);
-        switch (dcode) {
-            case 1: ids += (q[i] == t[j]); --i; --j; state = 2; *--o = 'M'; len++; break;
-            case 2: --i; state = 0; *--o = 'I'; len++; break;
-            case 3: --i; state = 2; *--o = 'I'; len++; break;
-            case 4: --j; state = 1; *--o = 'D'; len++; break;
-            default: --j; state = 2; *--o = 'D'; len++; break;
+    bool going = have && (i > 0 || j > 0);
+    while (__ballot(going)) {
+        {
+            const int ii = i - l, jj = j - l;
+            bool ok = going && state == 2 && (ii > 0 || jj > 0) && ii >= 0 && jj >= 0;
+            int x = ii - band;
+            x = x > 0 ? x : 0;
+            x = jj - x;
+            ok = ok && x >= 0 && x < width_d;
+            bool same = false;
+            if (ok) {
+                const int code = direction[(long long) width_d * ii + x];
+                ok = (code & 12) == 0;
+                same = q[ii] == t[jj];
+            }
+            const uint32_t okMask = (uint32_t) (__ballot(ok) >> sh) & ((1u << TBW_LANES) - 1u);
+            const uint32_t sameMask = (uint32_t) (__ballot(same) >> sh);
+            const int run = __builtin_ctz(~okMask);   // (bit 16 of ~okMask is set: run <= 16)
+            const uint32_t runMask = (1u << run) - 1u;
+            if (l < run) o[-1 - l] = 'M';
+            ids += __builtin_popcount(sameMask & runMask);
+            i -= run;
+            j -= run;
+            o -= run;
+            len += run;
         }
+        if (going && (i > 0 || j > 0)) {
+            if (i < 0 || j < 0) bad = true;
+            int x = i - band;
+            x = x > 0 ? x : 0;
+            x = j - x;
+            if (x < 0 || x >= width_d) bad = true;
+            if (!bad) {
+                const int code = direction[(long long) width_d * i + x];
+                int dcode;
+                const int dE = (code & 1) ? 3 : 2, dF = (code & 2) ? 5 : 4;
+                if (state == 0) dcode = dE;
+                else if (state == 1) dcode = dF;
+                else dcode = (code & 4) ? dE : ((code & 8) ? dF : 1);
+                char c;
+                switch (dcode) {
+                    case 1: ids += (q[i] == t[j]); --i; --j; state = 2; c = 'M'; break;
+                    case 2: --i; state = 0; c = 'I'; break;
+                    case 3: --i; state = 2; c = 'I'; break;
+                    case 4: --j; state = 1; c = 'D'; break;
+                    default: --j; state = 2; c = 'D'; break;
+                }
+                --o;
+                if (l == 0) *o = c;
+                len++;
+            }
+        }
+        going = going && !bad && (i > 0 || j > 0);
     }
+    if (!have || l != 0) return;
     if (bad || i != 0 || j != 0) {
         res[2 * id] = -1;
         return;
@@ -1121,6 +1167,13 @@ __device__ __forceinline__ uint32_t tbKey(int band, int qLen, int tLen) {
         while (qLen > c_tbNarrowQ[ci]) ci++;
     } else {
         ci = N_TB_NARROW + (w <= 127 ? 0 : (w <= 511 ? 1 : (w <= 2047 ? 2 : 3)));
+    }
+    if (ci < N_TB_NARROW) {
+        // register-band kernel: the two tasks of a wavefront run in lock step through max(attempts) x max(rows).  Tasks with the
+        // same number of bands the kernel can try (initial band 1: 1, 2, 4, 8; 2-3: three; 4-7: two; 8-14: one) sit together,
+        // most attempts first, longest query first inside
+        const int tries = band <= 1 ? 4 : (band <= 3 ? 3 : (band <= 7 ? 2 : 1));
+        return (uint32_t) ci * 4096u + (uint32_t) (4 - tries) * 1024u + (uint32_t) (1023 - min(max(qLen - 1, 0), 1023));
     }
     const unsigned long long work = (unsigned long long) ((2 * band + 1 + 31) / 32) * (unsigned long long) qLen;
     return (uint32_t) ci * 4096u + (uint32_t) (4095 - (int) min(work >> 3, 4095ull));
@@ -2107,7 +2160,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
                 hipLaunchKernelGGL(sw_traceback_kernel<false>, dim3((cnt + 1) / 2), dim3(64), ldsBytes, ctx->stream, dTb, cnt, queries->dRes,
                                    queries->dBias, targets->dRes, dMat, go, ge, ldsStride, dDir, dBt, dTbRes, dOrder + begin,
                                    ldsClass[ci] - 1, (const int8_t *) nullptr);
-            hipLaunchKernelGGL(sw_traceback_walk_kernel<false>, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, dTb, cnt, queries->dRes,
+            hipLaunchKernelGGL(sw_traceback_walk_kernel<false>, dim3((cnt + 256 / TBW_LANES - 1) / (256 / TBW_LANES)), dim3(256), 0, ctx->stream, dTb, cnt, queries->dRes,
                                targets->dRes, dDir, dBt, dTbRes, dOrder + begin);
         }
         {   // bands beyond the LDS classes: band arrays in global scratch, one attempt per round
@@ -2122,7 +2175,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
                     hipLaunchKernelGGL((sw_traceback_kernel<false, true>), dim3((cnt + 1) / 2), dim3(64), 0, ctx->stream, dTb, cnt, queries->dRes,
                                        queries->dBias, targets->dRes, dMat, go, ge, INT_MAX, dDir, dBt, dTbRes, dOrder + begin, 0,
                                        (const int8_t *) nullptr);
-                hipLaunchKernelGGL(sw_traceback_walk_kernel<true>, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, dTb, cnt, queries->dRes,
+                hipLaunchKernelGGL(sw_traceback_walk_kernel<true>, dim3((cnt + 256 / TBW_LANES - 1) / (256 / TBW_LANES)), dim3(256), 0, ctx->stream, dTb, cnt, queries->dRes,
                                    targets->dRes, dDir, dBt, dTbRes, dOrder + begin);
             }
         }
@@ -2546,10 +2599,10 @@ int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_se
                                        queries->dRes, queries->dBias, targets->dRes, dMat.p, go, ge, INT_MAX, dDir.p, dBt.p, dRes.p,
                                        (const uint32_t *) nullptr, 0, (const int8_t *) nullptr);
                 if (cls)
-                    hipLaunchKernelGGL(sw_traceback_walk_kernel<false>, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, dT.p, cnt, queries->dRes,
+                    hipLaunchKernelGGL(sw_traceback_walk_kernel<false>, dim3((cnt + 256 / TBW_LANES - 1) / (256 / TBW_LANES)), dim3(256), 0, ctx->stream, dT.p, cnt, queries->dRes,
                                        targets->dRes, dDir.p, dBt.p, dRes.p, (const uint32_t *) nullptr);
                 else
-                    hipLaunchKernelGGL(sw_traceback_walk_kernel<true>, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, dT.p, cnt, queries->dRes,
+                    hipLaunchKernelGGL(sw_traceback_walk_kernel<true>, dim3((cnt + 256 / TBW_LANES - 1) / (256 / TBW_LANES)), dim3(256), 0, ctx->stream, dT.p, cnt, queries->dRes,
                                        targets->dRes, dDir.p, dBt.p, dRes.p, (const uint32_t *) nullptr);
             }
             SD_HIP(ctx, hipGetLastError());
