@@ -252,6 +252,7 @@ def measure(args, rank, local_rank, world, dist, torch):
     if os.environ.get('SD_DEBUG_WS'):   # the library's workspace log carries the same clock
         print('[bench] t=%.3f timed region starts' % time.monotonic(), file=sys.stderr)
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    thr0 = _thread_cpu_snapshot()
     pairs_done, outs = run_steps([args.warmup + x for x in range(args.steps)])
     summary = np.zeros(4, np.int64)
     stage = {}
@@ -279,6 +280,7 @@ def measure(args, rank, local_rank, world, dist, torch):
     dt = time.time() - t0
     if os.environ.get('SD_DEBUG_WS'):
         print('[bench] t=%.3f timed region ends' % time.monotonic(), file=sys.stderr)
+    thr1 = _thread_cpu_snapshot()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     if dist is not None:
@@ -441,6 +443,9 @@ def measure(args, rank, local_rank, world, dist, torch):
         # CPU time (OpenMP workers of the host stages -- composition bias, accept / sort / text, aggregation --, HIP runtime threads)
         'host_cpu_by_stage': dict({k_[4:]: round(v_ / max(1, args.steps), 3) for k_, v_ in stage.items() if k_.startswith('cpu_')},
                                   other_threads=round((host_cpu_s - sum(v_ for k_, v_ in stage.items() if k_.startswith('cpu_'))) / max(1, args.steps), 3)),
+        # the same by thread (per step; threads sorted by CPU, the twelve busiest): name as the kernel knows it, count of threads of that
+        # name folded into one line when they are a team (OpenMP workers, runtime helpers)
+        'host_cpu_threads': _thread_cpu_report(thr0, thr1, max(1, args.steps)),
         'results': {'entries': int(summary[0]), 'matched_hits': int(summary[1]), 'clusters': int(summary[2]),
                     'cluster_hits': int(summary[3]), 'queries_not_computed': not_computed},
         'setup_s': {'generate': t_gen, 'index': cs.timing['index_build_s'], 'index_where': 'device (sd_target_build)', 'search_create': t_index,
@@ -478,6 +483,38 @@ def _leg_allowed(res, name, t_start, args):
     res[name] = dict(skipped='the run was %.0f s old when this record was due (--leg-budget %.0f)' % (age, args.leg_budget))
     return False
 
+
+
+def _thread_cpu_report(a, b, steps):
+    by = {}
+    for tid, (comm, cpu) in b.items():
+        d = cpu - a.get(tid, (comm, 0.0))[1]
+        if d <= 0:
+            continue
+        e = by.setdefault(comm, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += d
+        e[2] = max(e[2], d)
+    rows = sorted(by.items(), key=lambda kv: -kv[1][1])[:12]
+    return [dict(name=k, threads=v[0], cpu_s_per_step=round(v[1] / steps, 3), busiest_thread=round(v[2] / steps, 3)) for k, v in rows]
+
+
+def _thread_cpu_snapshot():
+    """{tid: (comm, CPU seconds)} of this process's threads (/proc/self/task/*/stat)"""
+    snap = {}
+    tck = os.sysconf('SC_CLK_TCK')
+    try:
+        for tid in os.listdir('/proc/self/task'):
+            try:
+                raw = open('/proc/self/task/%s/stat' % tid).read()
+            except OSError:
+                continue
+            comm = raw[raw.index('(') + 1:raw.rindex(')')]
+            f = raw[raw.rindex(')') + 2:].split()
+            snap[int(tid)] = (comm, (int(f[11]) + int(f[12])) / tck)
+    except OSError:
+        pass
+    return snap
 
 def main():
     args = parse()

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <algorithm>
 #include <ctime>
 #include <sys/prctl.h>
@@ -47,6 +48,12 @@ struct sd_ctx {
     struct PoolBuf { void *p = nullptr; size_t bytes = 0; };
     std::vector<PoolBuf> pool;
     std::mutex poolMutex;
+    // pinned bounce area of the small device -> host reads of a call (sdD2H): blocks are kept, a wait delivers and rewinds
+    struct BounceBlock { uint8_t *p = nullptr; size_t cap = 0; };
+    struct BounceItem { void *dst = nullptr; const uint8_t *src = nullptr; size_t bytes = 0; };
+    std::vector<BounceBlock> bounce;
+    std::vector<BounceItem> bounceItems;
+    size_t bounceCur = 0, bounceUsed = 0;
 };
 
 // a device buffer of at least `bytes` from the context's pool (best fit), else a fresh one with a quarter of slack
@@ -153,11 +160,56 @@ inline hipError_t sdStreamSync(sd_ctx *ctx) {
     return e;
 }
 
-inline hipError_t sdStreamSyncRaw(sd_ctx *ctx) {
-    if (ctx->evSync == nullptr) return hipStreamSynchronize(ctx->stream);
-    hipError_t e = hipEventRecord(ctx->evSync, ctx->stream);
+// Device -> host read of a call's control values (counts, flags, totals, per-query tables) on the context's stream.
+// hipMemcpyAsync into pageable memory -- a stack variable, a std::vector, the caller's array -- is not asynchronous: the runtime
+// waits inside the call for everything queued on the stream before it, in a busy loop, so a lane thread spent its kernels' whole
+// run time there at full CPU (measured: 0.5 core-seconds per lane and 0.6-s step, whatever sdEventWait's back-off).  sdD2H copies
+// into a pinned bounce block of the context instead, which returns at once, and notes the destination; the next sdStreamSync --
+// the sleeping wait -- moves the bytes to where they belong.  The destination must stay valid until that wait.
+inline hipError_t sdD2H(sd_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    const size_t need = (bytes + 63) & ~(size_t) 63;
+    for (;;) {
+        if (ctx->bounceCur < ctx->bounce.size()) {
+            if (ctx->bounceUsed + need <= ctx->bounce[ctx->bounceCur].cap) break;
+            ctx->bounceCur++;
+            ctx->bounceUsed = 0;
+            continue;
+        }
+        sd_ctx::BounceBlock b;
+        b.cap = std::max<size_t>(need, (size_t) 1 << 20);
+        const hipError_t e = hipHostMalloc((void **) &b.p, b.cap, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        ctx->bounce.push_back(b);
+    }
+    uint8_t *at = ctx->bounce[ctx->bounceCur].p + ctx->bounceUsed;
+    const hipError_t e = hipMemcpyAsync(at, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e != hipSuccess) return e;
-    return sdEventWait(ctx->evSync);
+    sd_ctx::BounceItem it;
+    it.dst = dst;
+    it.src = at;
+    it.bytes = bytes;
+    ctx->bounceItems.push_back(it);
+    ctx->bounceUsed += need;
+    return hipSuccess;
+}
+
+inline hipError_t sdStreamSyncRaw(sd_ctx *ctx) {
+    hipError_t e;
+    if (ctx->evSync == nullptr) {
+        e = hipStreamSynchronize(ctx->stream);
+    } else {
+        e = hipEventRecord(ctx->evSync, ctx->stream);
+        if (e == hipSuccess) e = sdEventWait(ctx->evSync);
+    }
+    if (!ctx->bounceItems.empty()) {
+        if (e == hipSuccess)
+            for (const sd_ctx::BounceItem &it : ctx->bounceItems) memcpy(it.dst, it.src, it.bytes);
+        ctx->bounceItems.clear();
+        ctx->bounceCur = 0;
+        ctx->bounceUsed = 0;
+    }
+    return e;
 }
 
 // persistent device buffer `key` of at least count elements (contents undefined after growth)

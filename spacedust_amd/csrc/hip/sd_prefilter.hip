@@ -2759,7 +2759,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                        (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p, PROFILE_PARTIAL_CAP, dProfBig.p, 0,
                                        (const uint64_t *) nullptr, (uint32_t *) nullptr);
                     int hTier = 0;
-                    SD_HIP(ctx, hipMemcpyAsync(&hTier, dErr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                    SD_HIP(ctx, sdD2H(ctx, &hTier, dErr.p, sizeof(int)));
                     SD_HIP(ctx, sdStreamSync(ctx));
                     profAnyBig = hTier == 7;
                     if (profAnyBig) {
@@ -2786,10 +2786,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 SD_HIP(ctx, hipMemsetAsync(dJoinFlag.p, 0, sizeof(int), ctx->stream));
                 hipLaunchKernelGGL(join_query_base_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p,
                                    dKmerBase.p, dQKmerBase.p, dJoinFlag.p);
-                SD_HIP(ctx, hipMemcpyAsync(&hJoinFlag, dJoinFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                SD_HIP(ctx, sdD2H(ctx, &hJoinFlag, dJoinFlag.p, sizeof(int)));
             }
-            SD_HIP(ctx, hipMemcpyAsync(&nKmers, dKmerBase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-            if (prof) SD_HIP(ctx, hipMemcpyAsync(&hErrCount, dErr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, sdD2H(ctx, &nKmers, dKmerBase.p + nPos, sizeof(uint64_t)));
+            if (prof) SD_HIP(ctx, sdD2H(ctx, &hErrCount, dErr.p, sizeof(int)));
             SD_HIP(ctx, sdStreamSync(ctx));
             if (hErrCount == 8)
                 return sdFail(ctx, SD_EUNSUPPORTED, "more than %u similar k-mers at one profile position (the reference truncates there, KmerGenerator.cpp:202-210)",
@@ -2853,7 +2853,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             }
             int rc = exclusiveScanWiden(ctx, dKLen.p, dHitBase.p, nKmers + 1, scanTmp);
             if (rc != SD_OK) return rc;
-            SD_HIP(ctx, hipMemcpyAsync(&nHits, dHitBase.p + nKmers, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, sdD2H(ctx, &nHits, dHitBase.p + nKmers, sizeof(uint64_t)));
             SD_HIP(ctx, sdStreamSync(ctx));
         }
         hs.reset(new HostScope(ctx, "pf.stats"));
@@ -2910,7 +2910,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                    (const uint32_t *) dKpCounts.p, (const uint64_t *) dKpBase.p, (const uint32_t *) dQKmerBase.p, bq, dSorted.p);
                 hipLaunchKernelGGL(kp_finish_kernel, dim3(KP_BINS), dim3(256), 0, ctx->stream, (const uint32_t *) dKpTotal.p,
                                    (const uint64_t *) dKpBase.p, dSorted.p, dChunkBin.p);
-                SD_HIP(ctx, hipMemcpyAsync(&nSorted, dKpBase.p + KP_BINS, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                SD_HIP(ctx, sdD2H(ctx, &nSorted, dKpBase.p + KP_BINS, sizeof(uint64_t)));
                 SD_HIP(ctx, sdStreamSync(ctx));
             }
             {
@@ -2928,9 +2928,9 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             std::vector<unsigned long long> hWg(JJ_WGS);
             std::vector<uint32_t> hQHits(bq);
             int hSplitFlagJ = 0;
-            SD_HIP(ctx, hipMemcpyAsync(hWg.data(), dWgTotal.p, JJ_WGS * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-            SD_HIP(ctx, hipMemcpyAsync(hQHits.data(), dQHits.p, bq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            SD_HIP(ctx, hipMemcpyAsync(&hSplitFlagJ, dSplitFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, sdD2H(ctx, hWg.data(), dWgTotal.p, JJ_WGS * sizeof(unsigned long long)));
+            SD_HIP(ctx, sdD2H(ctx, hQHits.data(), dQHits.p, bq * sizeof(uint32_t)));
+            SD_HIP(ctx, sdD2H(ctx, &hSplitFlagJ, dSplitFlag.p, sizeof(int)));
             SD_HIP(ctx, sdStreamSync(ctx));
             uint64_t all = 0;
             for (unsigned long long v : hWg) all += v;
@@ -2949,7 +2949,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 // index list as large as that buffer) are taken out of the batch and reported per query (outCount = UINT32_MAX); the
                 // join leaves their lists out
                 std::vector<uint32_t> hSplit(bq);
-                SD_HIP(ctx, hipMemcpy(hSplit.data(), dQSplit.p, (size_t) bq * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                SD_HIP(ctx, sdD2H(ctx, hSplit.data(), dQSplit.p, (size_t) bq * sizeof(uint32_t)));
+                SD_HIP(ctx, sdStreamSync(ctx));
                 hUnsupported.assign(bq, 0);
                 uint32_t nBad = 0, firstBad = 0;
                 for (uint32_t x = 0; x < bq; x++)
@@ -2998,15 +2999,16 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         hipLaunchKernelGGL(query_split_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
                            dHitBase.p, maxDbMatches, dQSplit.p, dQParts.p, dQSplits.p, dSplitFlag.p, posLimit);
         int hSplitFlag = 0;
-        SD_HIP(ctx, hipMemcpyAsync(&hSplitFlag, dSplitFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SD_HIP(ctx, hipMemcpyAsync(hStats.data(), dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, sdD2H(ctx, &hSplitFlag, dSplitFlag.p, sizeof(int)));
+        SD_HIP(ctx, sdD2H(ctx, hStats.data(), dStats.p, (size_t) bq * 4 * sizeof(uint64_t)));
         SD_HIP(ctx, sdStreamSync(ctx));
         if (hSplitFlag) {
             // Queries with >= 2^32 index hits (or more than PF_SPLITS_MAX overflows of the reference's hit buffer, or an index list as
             // large as that buffer) cannot be computed here.  They are taken out of the batch -- their index lists emptied,
             // offsets re-scanned -- and reported per query (outCount = UINT32_MAX); every other query is computed as usual.
             std::vector<uint32_t> hSplit(bq);
-            SD_HIP(ctx, hipMemcpy(hSplit.data(), dQSplit.p, (size_t) bq * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            SD_HIP(ctx, sdD2H(ctx, hSplit.data(), dQSplit.p, (size_t) bq * sizeof(uint32_t)));
+            SD_HIP(ctx, sdStreamSync(ctx));
             hUnsupported.assign(bq, 0);
             uint32_t nBad = 0, firstBad = 0;
             for (uint32_t x = 0; x < bq; x++)
@@ -3021,7 +3023,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             hipLaunchKernelGGL(drop_query_kmers_kernel, dim3(gridFor(nKmers, 256)), dim3(256), 0, ctx->stream, nKmers, dKPos.p, dQSplit.p, dKLen.p);
             int rc2 = exclusiveScanWiden(ctx, dKLen.p, dHitBase.p, nKmers + 1, scanTmp);
             if (rc2 != SD_OK) return rc2;
-            SD_HIP(ctx, hipMemcpyAsync(&nHits, dHitBase.p + nKmers, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, sdD2H(ctx, &nHits, dHitBase.p + nKmers, sizeof(uint64_t)));
             SD_HIP(ctx, hipMemsetAsync(dSplitFlag.p, 0, sizeof(int), ctx->stream));
             hipLaunchKernelGGL(query_split_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, dPosBase.p, dKmerBase.p,
                                dHitBase.p, maxDbMatches, dQSplit.p, dQParts.p, dQSplits.p, dSplitFlag.p, posLimit);
@@ -3099,7 +3101,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         return sdFail(ctx, SD_EUNSUPPORTED, "a query with >= 2^24 index hits against a target set of %u sequences", T->nSeq);
                     if (cBits > 0) {
                         std::vector<uint64_t> hQHB(nVQ0 + 1);
-                        SD_HIP(ctx, hipMemcpyAsync(hQHB.data(), pHitBase, (nVQ0 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                        SD_HIP(ctx, sdD2H(ctx, hQHB.data(), pHitBase, (nVQ0 + 1) * sizeof(uint64_t)));
                         SD_HIP(ctx, sdStreamSync(ctx));
                         ProfScope ps(ctx, "prefilter_coarse_split");
                         const uint32_t C = 1u << cBits;
@@ -3161,7 +3163,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     }
                     int rcF = exclusiveScanWiden(ctx, dHotCount.p, dHotBase.p, (uint64_t) nVQ + 1, scanTmp);
                     if (rcF != SD_OK) return rcF;
-                    SD_HIP(ctx, hipMemcpyAsync(&nLeft, dHotBase.p + nVQ, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                    SD_HIP(ctx, sdD2H(ctx, &nLeft, dHotBase.p + nVQ, sizeof(uint64_t)));
                     SD_HIP(ctx, sdStreamSync(ctx));
                     pSegCount = dHotCount.p;
                     pOutBase = dHotBase.p;
@@ -3236,8 +3238,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 if (rc != SD_OK) return rc;
                 int hFlag = 0;
                 uint64_t totalBins = 0;
-                SD_HIP(ctx, hipMemcpyAsync(&hFlag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-                SD_HIP(ctx, hipMemcpyAsync(&totalBins, dBinBase.p + nVQ, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                SD_HIP(ctx, sdD2H(ctx, &hFlag, dFlag.p, sizeof(int)));
+                SD_HIP(ctx, sdD2H(ctx, &totalBins, dBinBase.p + nVQ, sizeof(uint64_t)));
                 SD_HIP(ctx, sdStreamSync(ctx));
                 if (hFlag == 0 && totalBins > 0) {
                     const uint32_t bigCap = (uint32_t) std::min<size_t>(nSlots, 1u << 26);   // every bucket may be oversize on very large target sets
@@ -3253,7 +3255,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                            dQSplit.p, dQParts.p, dQSplits.p, cBits, widePos ? tBitsV : 0);
                     }
                     uint32_t nBig = 0;
-                    SD_HIP(ctx, hipMemcpyAsync(&nBig, dBigCount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                    SD_HIP(ctx, sdD2H(ctx, &nBig, dBigCount, sizeof(uint32_t)));
                     SD_HIP(ctx, sdStreamSync(ctx));
                     if (nBig > 0 && nBig <= bigCap) {   // the few buckets with one very hit-rich target (e.g. the query itself)
                         ProfScope ps(ctx, "prefilter_bucket_match_big");
@@ -3265,8 +3267,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     rc = exclusiveScanWiden(ctx, dBktEmit.p, dEmitOff.p, nSlots + 1, scanTmp);
                     if (rc != SD_OK) return rc;
                     uint64_t nc64 = 0;
-                    SD_HIP(ctx, hipMemcpyAsync(&hFlag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-                    SD_HIP(ctx, hipMemcpyAsync(&nc64, dEmitOff.p + nSlots, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                    SD_HIP(ctx, sdD2H(ctx, &hFlag, dFlag.p, sizeof(int)));
+                    SD_HIP(ctx, sdD2H(ctx, &nc64, dEmitOff.p + nSlots, sizeof(uint64_t)));
                     SD_HIP(ctx, sdStreamSync(ctx));
                     if (hFlag == 0) {
                         nCand = (uint32_t) nc64;
@@ -3318,7 +3320,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             int rc = exclusiveScanWiden(ctx, dEmit.p, dEmitPos.p, nHits + 1, scanTmp);
             if (rc != SD_OK) return rc;
             uint64_t nc64 = 0;
-            SD_HIP(ctx, hipMemcpyAsync(&nc64, dEmitPos.p + nHits, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, sdD2H(ctx, &nc64, dEmitPos.p + nHits, sizeof(uint64_t)));
             SD_HIP(ctx, sdStreamSync(ctx));
             nCand = (uint32_t) nc64;
             }
@@ -3327,7 +3329,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             // the global-sort fallback matches across one split only: queries whose hit buffer overflows more than once are
             // reported there, not guessed
             std::vector<uint32_t> hParts(bq);
-            SD_HIP(ctx, hipMemcpy(hParts.data(), dQParts.p, (size_t) bq * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            SD_HIP(ctx, sdD2H(ctx, hParts.data(), dQParts.p, (size_t) bq * sizeof(uint32_t)));
+            SD_HIP(ctx, sdStreamSync(ctx));
             bool any = false;
             for (uint32_t x = 0; x < bq; x++)
                 if (hParts[x] >= 2) {
@@ -3403,7 +3406,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             int rc = exclusiveScan(ctx, dK64.p, dKPos64.p, (uint64_t) nCand + 1, scanTmp);
             if (rc != SD_OK) return rc;
             uint64_t nk64 = 0;
-            SD_HIP(ctx, hipMemcpyAsync(&nk64, dKPos64.p + nCand, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, sdD2H(ctx, &nk64, dKPos64.p + nCand, sizeof(uint64_t)));
             SD_HIP(ctx, sdStreamSync(ctx));
             nKept = (uint32_t) nk64;
             SD_HIP(ctx, dKKey.alloc(nKept + 1));
@@ -3455,7 +3458,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         if (selBig) {
             // queries whose list is longer than the LDS sorter carries, with more candidates at the cut than it holds
             uint32_t nBigSel = 0;
-            SD_HIP(ctx, hipMemcpyAsync(&nBigSel, dSelBig.p + bq, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            SD_HIP(ctx, sdD2H(ctx, &nBigSel, dSelBig.p + bq, sizeof(uint32_t)));
             SD_HIP(ctx, sdStreamSync(ctx));
             if (nBigSel > 0) {
                 uint32_t stride = 1;
@@ -3484,10 +3487,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         int hErr = 0;
         sd_hit *hOutP = nullptr;   // pinned, persistent: a pageable destination makes this copy a staged, synchronous one
         SD_HIP(ctx, pinGet(ctx, "pf.hOut", (size_t) bq * maxHits + 1, &hOutP));
-        SD_HIP(ctx, hipMemcpyAsync(&hErr, dErr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, sdD2H(ctx, &hErr, dErr.p, sizeof(int)));
         SD_HIP(ctx, hipMemcpyAsync(hOutP, dOut.p, (size_t) bq * maxHits * sizeof(sd_hit), hipMemcpyDeviceToHost, ctx->stream));
-        SD_HIP(ctx, hipMemcpyAsync(outCount + qBeg, dOutCount.p, bq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        if (stats) SD_HIP(ctx, hipMemcpyAsync(stats + (size_t) qBeg * 4, dStats.p, (size_t) bq * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, sdD2H(ctx, outCount + qBeg, dOutCount.p, bq * sizeof(uint32_t)));
+        if (stats) SD_HIP(ctx, sdD2H(ctx, stats + (size_t) qBeg * 4, dStats.p, (size_t) bq * 4 * sizeof(uint64_t)));
         SD_HIP(ctx, sdStreamSync(ctx));
         (void) hErr;
         hs.reset(new HostScope(ctx, "pf.scatter"));

@@ -1493,9 +1493,9 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
     hipLaunchKernelGGL(k_bound_apply, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dTasks, dScanB);
     uint32_t hb[N_SCORE_CLASSES + 1], hpb[FIRST_INT32_CLASS + 1];
     uint64_t boundTotal = 0;
-    if (dPairQ) SD_HIP(ctx, hipMemcpyAsync(hpb, dPairBounds, sizeof(hpb), hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(&boundTotal, dScanB + nPairs, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (dPairQ) SD_HIP(ctx, sdD2H(ctx, hpb, dPairBounds, sizeof(hpb)));
+    SD_HIP(ctx, sdD2H(ctx, hb, dBounds, sizeof(hb)));
+    SD_HIP(ctx, sdD2H(ctx, &boundTotal, dScanB + nPairs, sizeof(uint64_t)));
     SD_HIP(ctx, sdStreamSync(ctx));
     *nValid = hb[N_SCORE_CLASSES];
     uint2 *dBound = nullptr;
@@ -1667,6 +1667,7 @@ void sd_ctx_destroy(sd_ctx *ctx) {
     for (auto &kv : ctx->ws) if (kv.second.p) (void) hipFree(kv.second.p);
     for (auto &b : ctx->pool) if (b.p) (void) hipFree(b.p);
     for (auto &kv : ctx->pinned) if (kv.second.p) (void) hipHostFree(kv.second.p);
+    for (auto &b : ctx->bounce) if (b.p) (void) hipHostFree(b.p);
     delete ctx;
 }
 
@@ -2064,7 +2065,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     rc = devExclusiveScan(ctx, dBtBytes, dBtOff, N + 1);
     if (rc != SD_OK) return rc;
     uint64_t btScratch = 0;
-    SD_HIP(ctx, hipMemcpyAsync(&btScratch, dBtOff + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, sdD2H(ctx, &btScratch, dBtOff + N, sizeof(uint64_t)));
     SD_HIP(ctx, sdStreamSync(ctx));
     char *dBt = nullptr;
     SD_HIP(ctx, wsGet(ctx, "tb.bt", btScratch + 64, &dBt));
@@ -2094,8 +2095,8 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysS, nPairs, 4096u, dBounds, (int) N_TB_CLASSES + 1);
         uint32_t hb[N_TB_CLASSES + 1];
         uint64_t dirTotal = 0;
-        SD_HIP(ctx, hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
-        SD_HIP(ctx, hipMemcpyAsync(&dirTotal, dDirOff + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, sdD2H(ctx, hb, dBounds, sizeof(hb)));
+        SD_HIP(ctx, sdD2H(ctx, &dirTotal, dDirOff + N, sizeof(uint64_t)));
         SD_HIP(ctx, sdStreamSync(ctx));
         if (hb[N_TB_CLASSES] == 0) {
             if (dirTotal == 0) {   // nothing left
@@ -2229,9 +2230,9 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     uint64_t poolBytes = 0;
     int hErr[4] = {0, 0, 0, 0};
     unsigned long long hCells[4] = {0, 0, 0, 0};
-    SD_HIP(ctx, hipMemcpyAsync(&poolBytes, dDense + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(hErr, dErr, sizeof(hErr), hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(hCells, dCells, sizeof(hCells), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, sdD2H(ctx, &poolBytes, dDense + N, sizeof(uint64_t)));
+    SD_HIP(ctx, sdD2H(ctx, hErr, dErr, sizeof(hErr)));
+    SD_HIP(ctx, sdD2H(ctx, hCells, dCells, sizeof(hCells)));
     SD_HIP(ctx, sdStreamSync(ctx));
     if (hErr[0] == 1) return sdFail(ctx, SD_EMISMATCH, "Score of forward/backward SW differ (fatal in the reference, StripedSmithWaterman.cpp:466-473)");
     if (hErr[0] == 2) return sdFail(ctx, SD_EHIP, "Trace back error");
@@ -2274,7 +2275,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         }
         hipLaunchKernelGGL(k_accept_compact, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dRes, dAcc, dAccPos, dResC, dIdxC);
         uint64_t nAcc = 0;
-        SD_HIP(ctx, hipMemcpyAsync(&nAcc, dAccPos + N, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(ctx, sdD2H(ctx, &nAcc, dAccPos + N, sizeof(uint64_t)));
         SD_HIP(ctx, sdStreamSync(ctx));
         nRec = (uint32_t) nAcc;
         dRecSrc = dResC;

@@ -22,6 +22,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <pthread.h>
 #include <vector>
 
 namespace {
@@ -41,7 +42,9 @@ double threadCpuSec() {
 // one thread executing submitted jobs in order (a stage of the pipeline)
 class StageThread {
 public:
-    StageThread() : stop_(false), th_([this] { run(); }) {}
+    // name: what /proc/<pid>/task/<tid>/comm shows (at most 15 characters); threads a stage thread creates -- the OpenMP team of the
+    // host stages it calls -- inherit it, so a per-name CPU table (bench.py: host_cpu_threads) is a per-stage table
+    explicit StageThread(const char *name = "sd-stage") : stop_(false), name_(name), th_([this] { run(); }) {}
     ~StageThread() {
         {
             std::lock_guard<std::mutex> l(m_);
@@ -65,6 +68,7 @@ public:
 
 private:
     void run() {
+        pthread_setname_np(pthread_self(), name_.c_str());
         for (;;) {
             std::function<void()> job;
             {
@@ -81,6 +85,7 @@ private:
     std::condition_variable cv_;
     std::deque<std::function<void()> > q_;
     bool stop_;
+    std::string name_;
     std::thread th_;
 };
 
@@ -497,7 +502,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     std::vector<int64_t> lastChunkOf(nRanges, -1);
     for (size_t x = 0; x < chunks.size(); x++) lastChunkOf[chunks[x].range] = (int64_t) x;
 
-    StageThread biasStage, pfStage, aggStage;
+    StageThread biasStage{"sd-bias"}, pfStage{"sd-pf0"}, aggStage{"sd-agg"};
     double *tm = s->seconds;
 
     auto biasJob = [s, Q, profile](uint32_t c0, uint32_t c1) {
@@ -597,7 +602,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     // prefilter lanes: chunk x runs on lane x % lanes (its own context, workspace and stream; the target index is shared)
     const int pfLanes = s->pfLanes;
     std::unique_ptr<StageThread> pfLaneMore[3];
-    for (int l = 1; l < pfLanes; l++) pfLaneMore[l - 1].reset(new StageThread());
+    for (int l = 1; l < pfLanes; l++) pfLaneMore[l - 1].reset(new StageThread(("sd-pf" + std::to_string(l)).c_str()));
     sd_ctx *pfCtxOf[4] = {s->ctxPf, s->ctxPf2, s->ctxPfMore[0], s->ctxPfMore[1]};
     auto submitPf = [&](size_t x) {
         submitBias(x);
@@ -701,7 +706,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     };
     const int lanes = s->alignLanes;
     std::unique_ptr<StageThread> alStage[4];
-    for (int l = 0; l < lanes; l++) alStage[l].reset(new StageThread());
+    for (int l = 0; l < lanes; l++) alStage[l].reset(new StageThread(("sd-al" + std::to_string(l)).c_str()));
     sd_ctx *laneCtx[4] = {s->ctxAl, s->ctxAl2, s->ctxAlMore[0], s->ctxAlMore[1]};
     const std::vector<int32_t> *qLenP = &qLen;
     auto alignJob = [s, Q, profile, sameDb, qLenP](std::shared_ptr<std::unique_ptr<PfOut> > dp, sd_ctx *ctx, sd_search::AlnBuf *Bp, size_t ci) {
