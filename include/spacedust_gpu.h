@@ -465,7 +465,7 @@ typedef struct {
     int32_t filterSelfMatch; /* --filter-self-match (reference default 0) */
     int32_t profileQueries;  /* the query side is a profile DB: own k-mer threshold table, index with threshold 0 */
     int32_t chunkQueries;    /* queries per device chunk (0 = 10000) */
-    int32_t deviceBias;      /* composition bias on the device: 1 yes, 0 host, -1 by the number of host cores */
+    int32_t deviceBias;      /* composition bias: 0 = host stage (OpenMP), anything else (1, -1 = default) = on the device */
     int32_t threads;         /* host threads of this rank (0 = all of the cgroup quota) */
     int32_t alignPriority;   /* stream priority of the alignment context (sd_ctx_create_prio) */
 } sd_search_params;

@@ -142,9 +142,9 @@ extern "C" int sd_comp_bias_batch(sd_ctx *ctx, sd_host *h, const uint8_t *residu
         hipLaunchKernelGGL(bias_round_kernel, dim3(grid), dim3(256), 0, ctx->stream, total, dOff, n, dCbS, dCbB, kmerSize, span, dSw, dDg, dKm);
     }
     SD_HIP(ctx, hipGetLastError());
-    SD_HIP(ctx, hipMemcpyAsync(swBias, dSw, total, hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(diagBias, dDg, total, hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(kmerBias, dKm, total * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(ctx, sdD2H(ctx, swBias, dSw, total));   // (the caller's arrays are pageable: see sdD2H)
+    SD_HIP(ctx, sdD2H(ctx, diagBias, dDg, total));
+    SD_HIP(ctx, sdD2H(ctx, kmerBias, dKm, total * sizeof(int16_t)));
     SD_HIP(ctx, sdStreamSync(ctx));
     return SD_OK;
 }
