@@ -312,15 +312,15 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
         jn = jn < 0 ? 0 : jn;
         return (int) t[jn];
     };
-    auto scoreOf = [&](int r, int qv, int cbv, int tv) -> int {
+    auto scoreOf = [&](int r, int qv, int tv) -> int {   // (without the bias: an add right behind the read would wait for it at the row's top)
         if (PROF) return (int) qProf[(tk.qAbs + (uint64_t) r) * 21 + tv];
-        return (int) smat[21 * qv + tv] + cbv;
+        return (int) smat[21 * qv + tv];
     };
     int qa = 0, cba = 0, qb = 0, cbb = 0, tb = 0, sNext = 0;
     if (have && qLen > 0 && tLen > 0) {
         qa = q[0];
         cba = PROF ? 0 : cb[0];
-        sNext = scoreOf(0, qa, cba, loadT(0));
+        sNext = scoreOf(0, qa, loadT(0));
         const int r1 = rowClamp(1);
         qb = q[r1];
         cbb = PROF ? 0 : cb[r1];
@@ -331,14 +331,14 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
         int jj = i - band; beg = beg > jj ? beg : jj;
         jj = i + band; end = end < jj ? end : jj;
         const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
-        if (l == 0) {
-            bandSt<GLOBAL>(h_b, 0); bandSt<GLOBAL>(e_b, 0); bandSt<GLOBAL>(h_b + edge, 0); bandSt<GLOBAL>(e_b + edge, 0);
-            bandSt<GLOBAL>(h_c, 0);
+        if (l < 5) {   // h_b[0], e_b[0], h_b[edge], e_b[edge], h_c[0] = 0: one store of five lanes
+            int32_t *z = l == 0 ? h_b : (l == 1 ? e_b : (l == 2 ? h_b + edge : (l == 3 ? e_b + edge : h_c)));
+            bandSt<GLOBAL>(z, 0);
         }
         bandSync<GLOBAL>();
         const int sCur = sNext;
         const int r1 = rowClamp(i + 1), r2 = rowClamp(i + 2);
-        sNext = scoreOf(r1, qb, cbb, tb);
+        sNext = scoreOf(r1, qb, tb);
         const int qc = q[r2], cbc = PROF ? 0 : (int) cb[r2], tc = loadT(r2);
         const int xi = (i - band) > 0 ? (i - band) : 0;
         const int xim = (i - 1 - band) > 0 ? (i - 1 - band) : 0;
@@ -361,7 +361,7 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
                 eNew = t1 > t2 ? t1 : t2;
                 dirE = t1 > t2;
                 e1 = eNew > 0 ? eNew : 0;
-                const int sc = p0 == 0 ? sCur : (int) mrow[t[j]] + cbi;
+                const int sc = (p0 == 0 ? sCur : (int) mrow[t[j]]) + cbi;
                 diag = bandLd<GLOBAL>(h_b + d) + sc;
                 T = e1 > diag ? e1 : diag;
             }
@@ -407,10 +407,16 @@ sw_traceback_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *
             if constexpr (!GLOBAL) __builtin_amdgcn_wave_barrier();   // (GLOBAL: a lane only re-reads what other lanes wrote after the row's fence)
         }
         bandSync<GLOBAL>();
+        // the reference copies h_c[1 .. uLast] to h_b here (:1477-1478).  The arrays are exchanged instead: the next row reads h_b at
+        // indices 0 (zeroed above), 1 .. uLast (this row's values in either form) and, where its window grew by a column, uLast + 1 --
+        // which is exactly the `edge` index it has just zeroed (end + 1 while the window still starts at column 0, width - 1
+        // afterwards) -- so what the other entries hold never reaches a cell
         if (W > 0) {
-            for (int x = 1 + l; x <= uLast; x += 32) bandSt<GLOBAL>(h_b + x, bandLd<GLOBAL>(h_c + x));
+            int32_t *sw = h_b;
+            h_b = h_c;
+            h_c = sw;
         }
-        bandSync<GLOBAL>();
+        (void) uLast;
         qa = qb;
         cba = cbb;
         qb = qc;
@@ -592,33 +598,40 @@ sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const ui
         // substitution score of this lane's cell: its operands (query letter, bias, target letter) are read two rows ahead and
         // the matrix / profile entry one row ahead, so that neither of the two dependent LDS round trips is waited for inside a
         // row (a wavefront issues in order: a wait in front of the first use stalls the recurrence behind it as well)
+        // (no branch around the reads -- a half without rows reads its first entries: every address stays inside the task's LDS
+        // slice / the profile -- so that the only waits are in front of the uses)
         auto cellOps = [&](int row, int &qv, int &tv, int &cbv) {
-            qv = 0; tv = 0; cbv = 0;
-            if (rows == 0) return;
-            const int r = row < qLen ? row : qLen - 1;
+            int r = row < qLen ? row : qLen - 1;
+            r = r > 0 ? r : 0;
             const int x0 = (r - band) > 0 ? (r - band) : 0;
             int jn = x0 + l - 1;
-            jn = jn < 0 ? 0 : (jn >= tLen ? tLen - 1 : jn);
+            jn = jn >= tLen ? tLen - 1 : jn;
+            jn = jn > 0 ? jn : 0;
             tv = st[jn];
+            qv = 0;
+            cbv = 0;
             if (!PROF) {
                 qv = sq[r];
                 cbv = scb[r];
             }
         };
-        auto cellLook = [&](int row, int qv, int tv, int cbv) -> int {
-            if (rows == 0) return 0;
-            const int r = row < qLen ? row : qLen - 1;
-            if (PROF) return (int) qProf[(tk.qAbs + (uint64_t) r) * 21 + tv];
-            return (int) smat[21 * qv + tv] + cbv;
+        // (the matrix entry and the bias stay separate until the cell uses them: an add right behind the read would put the wait for
+        // the read at the top of the row)
+        auto cellLook = [&](int row, int qv, int tv) -> int {
+            int r = row < qLen ? row : qLen - 1;
+            r = r > 0 ? r : 0;
+            if (PROF) return (int) qProf[(tk.qAbs + (uint64_t) r) * 21 + (tv < 21 ? tv : 20)];
+            return (int) smat[21 * qv + tv];   // (an idle half may form any index from its unwritten slice: LDS, no cell takes the value)
         };
         int qb, tb, cbb;
         cellOps(0, qb, tb, cbb);
-        int sNext = cellLook(0, qb, tb, cbb);
+        int sNext = cellLook(0, qb, tb), cNext = cbb;
         cellOps(1, qb, tb, cbb);
         for (int i = 0; i < nRows; i++) {
             const bool live = i < rows;
-            const int sCur = sNext;
-            sNext = cellLook(i + 1, qb, tb, cbb);
+            const int sCur = sNext, cCur = cNext;
+            sNext = cellLook(i + 1, qb, tb);
+            cNext = cbb;
             cellOps(i + 2, qb, tb, cbb);
             const int xi = (i - band) > 0 ? (i - band) : 0;
             const int delta = (i - band) >= 1 ? 1 : 0;     // xi - xim
@@ -640,7 +653,7 @@ sw_traceback_narrow_kernel(TbTask *__restrict__ tasks, uint32_t nTasks, const ui
             const int eNew = t1 > t2 ? t1 : t2;
             const bool dirE = t1 > t2;
             const int e1 = eNew > 0 ? eNew : 0;
-            const int diag = hD + sCur;
+            const int diag = hD + sCur + cCur;
             const int T = e1 > diag ? e1 : diag;
             // prefix maximum of S = T - go + ge*u, carried as S + go + 1 >= 1 so that 0 (what a zero-filled DPP move
             // delivers where there is no source lane) is the identity
