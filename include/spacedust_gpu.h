@@ -39,6 +39,11 @@ int sd_ctx_create(int device, sd_ctx **out);
 /* priority < 0 / 0 / > 0: the context's stream gets the device's highest / middle / lowest stream priority (two
  * contexts on one device share it: e.g. the memory-bound prefilter ahead of the VALU-bound alignments) */
 int sd_ctx_create_prio(int device, int priority, sd_ctx **out);
+/* as sd_ctx_create_prio, and the context's stream may not use `reserveCUs` of the device's compute units (a CU mask with that
+ * many bits cleared, spread over the XCDs): kernels of the other contexts of the device find those free.  The pipeline keeps the
+ * long-lived one-wavefront workgroups of the alignment stage off a few CUs so that the prefilter's many short dependent launches
+ * start at once instead of waiting for a generation of alignment wavefronts to retire. */
+int sd_ctx_create_masked(int device, int priority, int reserveCUs, sd_ctx **out);
 void sd_ctx_destroy(sd_ctx *ctx);
 const char *sd_last_error(sd_ctx *ctx);
 int sd_device_name(sd_ctx *ctx, char *buf, size_t cap);

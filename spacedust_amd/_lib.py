@@ -96,6 +96,7 @@ def load():
     sig = {
         'sd_ctx_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
         'sd_ctx_create_prio': (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+        'sd_ctx_create_masked': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
         'sd_ctx_destroy': (None, [_vp]),
         'sd_last_error': (C.c_char_p, [_vp]),
         'sd_device_name': (C.c_int, [_vp, C.c_char_p, C.c_size_t]),

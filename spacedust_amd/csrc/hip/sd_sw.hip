@@ -1633,7 +1633,9 @@ extern "C" {
 
 int sd_ctx_create(int device, sd_ctx **out) { return sd_ctx_create_prio(device, 0, out); }
 
-int sd_ctx_create_prio(int device, int priority, sd_ctx **out) {
+int sd_ctx_create_prio(int device, int priority, sd_ctx **out) { return sd_ctx_create_masked(device, priority, 0, out); }
+
+int sd_ctx_create_masked(int device, int priority, int reserveCUs, sd_ctx **out) {
     if (out == nullptr) return SD_EINVAL;
     *out = nullptr;
     int count = 0;
@@ -1650,7 +1652,19 @@ int sd_ctx_create_prio(int device, int priority, sd_ctx **out) {
     int least = 0, greatest = 0;   // numerically: least priority >= greatest priority
     (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
     const int prio = priority < 0 ? greatest : (priority > 0 ? least : (least + greatest) / 2);
-    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) != hipSuccess) {
+    hipError_t se = hipSuccess;
+    (void) hipGetDeviceProperties(&c->prop, device);
+    const int nCU = c->prop.multiProcessorCount;
+    if (reserveCUs > 0 && nCU > 0 && reserveCUs < nCU) {
+        // the queue's CU mask: the driver deals the bits round the XCDs (bit i -> XCD i mod 8), so clearing the top bits takes the
+        // same number of CUs from every XCD.  (A masked stream has the default priority: the masked-stream call takes none.)
+        std::vector<uint32_t> mask((size_t) (nCU + 31) / 32, 0u);
+        for (int b = 0; b < nCU - reserveCUs; b++) mask[(size_t) b / 32] |= 1u << (b % 32);
+        se = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t) mask.size(), mask.data());
+    } else {
+        se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
+    }
+    if (se != hipSuccess) {
         delete c;
         return SD_EHIP;
     }

@@ -254,7 +254,9 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     const int pfPrio = getenv("SD_PF_PRIO") ? atoi(getenv("SD_PF_PRIO")) : 0;   // stream priority of the prefilter lanes (-1 highest; measured: no effect on the throughput)
     rc = sd_ctx_create_prio(device, pfPrio, &s->ctxPf);
     if (rc != SD_OK) return rc;
-    rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAl);
+    // CUs the alignment streams leave alone (see sd_ctx_create_masked)
+    const int alReserve = getenv("SD_ALIGN_RESERVE_CUS") ? atoi(getenv("SD_ALIGN_RESERVE_CUS")) : 0;
+    rc = sd_ctx_create_masked(device, par->alignPriority, alReserve, &s->ctxAl);
     if (rc != SD_OK) return rc;
     {   // a second lane per stage costs ~0.7 core-seconds per step: with fewer than 4 cores for this rank (8 ranks sharing a
         // 16-CPU quota) the host would bound the pipeline, so such ranks run one lane per stage
@@ -264,11 +266,11 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     }
     if (const char *e = getenv("SD_ALIGN_LANES")) s->alignLanes = std::max(1, std::min(4, atoi(e)));
     if (s->alignLanes > 1) {
-        rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAl2);
+        rc = sd_ctx_create_masked(device, par->alignPriority, alReserve, &s->ctxAl2);
         if (rc != SD_OK) return rc;
     }
     for (int x = 2; x < s->alignLanes; x++) {
-        rc = sd_ctx_create_prio(device, par->alignPriority, &s->ctxAlMore[x - 2]);
+        rc = sd_ctx_create_masked(device, par->alignPriority, alReserve, &s->ctxAlMore[x - 2]);
         if (rc != SD_OK) return rc;
     }
     rc = sd_ctx_create(device, &s->ctxCh);

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Idle gaps per HIP stream from a rocprofv3 --kernel-trace results.db: for every stream (queue) the kernels in start order, the time
+between the end of one and the start of the next, summed by the kernel that follows the gap.  Shows where a lane's stream waits for
+its host thread (sync round trips, uploads) rather than for the device.  usage: stream_gaps.py results.db [min_gap_us]"""
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    m = re.match(r'(?:void )?([A-Za-z0-9_:<>, ]+?)\(', name)
+    return (m.group(1) if m else name)[:48]
+
+
+def main(path, min_gap_us=5.0):
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute('pragma table_info(kernels)')]
+    print('columns:', cols)
+    sid = next((c for c in ('stream_id', 'stream', 'queue_id', 'queue') if c in cols), None)
+    if sid is None:
+        print('no stream / queue column'); return
+    rows = db.execute('select %s, name, start, end from kernels order by start' % sid).fetchall()
+    by = defaultdict(list)
+    for s, n, a, b in rows:
+        by[s].append((a, b, short(n)))
+    t0 = min(r[2] for r in rows); t1 = max(r[3] for r in rows)
+    print('trace span %.1f ms, %d kernels, %d streams' % ((t1 - t0) / 1e6, len(rows), len(by)))
+    for s, ks in sorted(by.items(), key=lambda kv: -len(kv[1])):
+        if len(ks) < 50:
+            continue
+        busy = sum(b - a for a, b, _ in ks)
+        span = ks[-1][1] - ks[0][0]
+        gaps = defaultdict(lambda: [0, 0.0])
+        small = 0.0
+        for (a0, b0, n0), (a1, b1, n1) in zip(ks, ks[1:]):
+            g = (a1 - b0) / 1e3
+            if g >= min_gap_us:
+                e = gaps[(n0, n1)]
+                e[0] += 1; e[1] += g
+            elif g > 0:
+                small += g
+        tot_gap = sum(v[1] for v in gaps.values())
+        print('\nstream %s: %d kernels, span %.1f ms, busy %.1f ms (%.0f %%), gaps >= %.0f us: %.1f ms, smaller: %.1f ms' %
+              (s, len(ks), span / 1e6, busy / 1e6, 100.0 * busy / span, min_gap_us, tot_gap / 1e3, small / 1e3))
+        for (n0, n1), (c, g) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
+            print('   %8.1f ms in %5d gaps (avg %7.0f us)  %s -> %s' % (g / 1e3, c, g / c, n0, n1))
+
+
+def timeline(path, stream, first, count):
+    """kernels first .. first + count of one stream in start order: gap before, duration, name, grid"""
+    db = sqlite3.connect(path)
+    rows = db.execute('select name, start, end, grid_x from kernels where stream_id = ? order by start', (stream,)).fetchall()
+    prev = None
+    for n, a, b, g in rows[first:first + count]:
+        print('%9.3f ms  gap %8.1f us  dur %8.1f us  grid %9d  %s' % ((a - rows[0][1]) / 1e6, (a - prev) / 1e3 if prev else 0.0, (b - a) / 1e3, g, short(n)))
+        prev = b
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 2 and sys.argv[2] == '--timeline':
+        timeline(sys.argv[1], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+    else:
+        main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 5.0)
