@@ -258,12 +258,8 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     const int alReserve = getenv("SD_ALIGN_RESERVE_CUS") ? atoi(getenv("SD_ALIGN_RESERVE_CUS")) : 0;
     rc = sd_ctx_create_masked(device, par->alignPriority, alReserve, &s->ctxAl);
     if (rc != SD_OK) return rc;
-    {   // a second lane per stage costs ~0.7 core-seconds per step: with fewer than 4 cores for this rank (8 ranks sharing a
-        // 16-CPU quota) the host would bound the pipeline, so such ranks run one lane per stage
-        int local = 1;
-        if (const char *e = getenv("LOCAL_WORLD_SIZE")) local = std::max(1, atoi(e));
-        if (cpus / local < 4) s->alignLanes = s->pfLanes = 1;
-    }
+    // (two lanes per stage whatever the CPU quota: a lane thread sleeps while its kernels run -- 0.04 - 0.08 core-seconds per step
+    // since the small reads go through sdD2H; before that a second lane cost 0.7 and ranks with fewer than 4 cores ran one)
     if (const char *e = getenv("SD_ALIGN_LANES")) s->alignLanes = std::max(1, std::min(4, atoi(e)));
     if (s->alignLanes > 1) {
         rc = sd_ctx_create_masked(device, par->alignPriority, alReserve, &s->ctxAl2);
