@@ -96,6 +96,7 @@ extern "C" int sd_comp_bias_batch(sd_ctx *ctx, sd_host *h, const uint8_t *residu
     if (!ctx || !h || !residues || !offsets || !swBias || !diagBias || !kmerBias) return SD_EINVAL;
     if (kmerSize != 6 && kmerSize != 7) return SD_EINVAL;
     (void) hipSetDevice(ctx->device);
+    sdD2HReset(ctx);   // (reads an earlier, failed call left pending)
     const uint64_t total = offsets[n];
     if (total == 0) return SD_OK;
     if (h->biasTabSeed.empty()) {   // once per host handle (a few 10^6 table entries)

@@ -194,6 +194,14 @@ inline hipError_t sdD2H(sd_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return hipSuccess;
 }
 
+// at the entry of a call: reads a failed call left pending point at its dead stack frame -- drop them (their copies into the bounce area
+// are harmless, and the stream keeps later copies into the same bytes behind them)
+inline void sdD2HReset(sd_ctx *ctx) {
+    ctx->bounceItems.clear();
+    ctx->bounceCur = 0;
+    ctx->bounceUsed = 0;
+}
+
 inline hipError_t sdStreamSyncRaw(sd_ctx *ctx) {
     hipError_t e;
     if (ctx->evSync == nullptr) {
@@ -286,6 +294,10 @@ struct sd_target {
     uint8_t *dMasked = nullptr;
     uint64_t *dSeqOff = nullptr;
     int16_t *dExt3Score = nullptr;
+    // countGE(row, cutoff) of a 3-mer row as ONE table read: dExt3Cum[row * 256 + (cutoff - ext3Lo)] = entries of the row with a score >= cutoff
+    // (sdBuildExt3Cum; null when the scores span more than 255 values: the kernels then search the sorted row)
+    uint16_t *dExt3Cum = nullptr;
+    int ext3Lo = 0;
     uint16_t *dExt3Index = nullptr;
     int16_t *dExt2Score = nullptr;
     uint16_t *dExt2Index = nullptr;
@@ -293,6 +305,7 @@ struct sd_target {
 };
 
 int sdFail(sd_ctx *ctx, int code, const char *fmt, ...);
+int sdBuildExt3Cum(sd_ctx *ctx, sd_target *t);   // sd_prefilter.hip; after dExt3Score is resident
 
 #define SD_HIP(ctx, call)                                                                          \
     do {                                                                                           \

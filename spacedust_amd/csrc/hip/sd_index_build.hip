@@ -598,6 +598,10 @@ extern "C" int sd_target_build(sd_ctx *ctx, int kmerSize, int kmerThr, int mask,
     SD_HIP(ctx, up((void **) &t->dSeqOff, seqOffsets, (nSeq + 1) * sizeof(uint64_t)));
     SD_HIP(ctx, up((void **) &t->dExt3Score, ext3Score, (size_t) 8000 * 8000 * sizeof(int16_t)));
     SD_HIP(ctx, up((void **) &t->dExt3Index, ext3Index, (size_t) 8000 * 8000 * sizeof(uint16_t)));
+    {
+        const int rcCum = sdBuildExt3Cum(ctx, t);
+        if (rcCum != SD_OK) return rcCum;
+    }
     if (ext2Score && ext2Index) {
         SD_HIP(ctx, up((void **) &t->dExt2Score, ext2Score, (size_t) 400 * 400 * sizeof(int16_t)));
         SD_HIP(ctx, up((void **) &t->dExt2Index, ext2Index, (size_t) 400 * 400 * sizeof(uint16_t)));

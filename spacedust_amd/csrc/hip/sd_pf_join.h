@@ -55,7 +55,8 @@ __global__ void __launch_bounds__(256)
 emit_kmers_join_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
                        const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
                        const int16_t *__restrict__ ext3Score, const uint16_t *__restrict__ ext3Index,
-                       const uint64_t *__restrict__ kmerBase, uint64_t *__restrict__ elems) {
+                       const uint64_t *__restrict__ kmerBase, uint64_t *__restrict__ elems,
+                       const uint16_t *__restrict__ ext3Cum /* nullable: countGETab */, int ext3Lo) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
@@ -66,7 +67,9 @@ emit_kmers_join_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint
     const uint16_t *ix0 = ext3Index + (size_t) pi.idx0 * 8000;
     const uint16_t *ix1 = ext3Index + (size_t) pi.idx1 * 8000;
     const int cutoff1 = (int) (short) (pi.thr - (int) row1[0]);
-    const int n0 = countGE(row0, 8000, cutoff1);
+    const uint16_t *cum0 = ext3Cum ? ext3Cum + (size_t) pi.idx0 * EXT3_CUM_SPAN : nullptr;
+    const uint16_t *cum1 = ext3Cum ? ext3Cum + (size_t) pi.idx1 * EXT3_CUM_SPAN : nullptr;
+    const int n0 = ext3Cum ? countGETab(cum0, ext3Lo, cutoff1) : countGE(row0, 8000, cutoff1);
     uint64_t base = kmerBase[p];
     __shared__ uint32_t sIncl[4][64];
     __shared__ uint32_t sK0[4][64];
@@ -74,7 +77,10 @@ emit_kmers_join_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint
     for (int a0 = 0; a0 < n0; a0 += 64) {
         const int a = a0 + lane;
         uint32_t c = 0;
-        if (a < n0) c = (uint32_t) countGE(row1, 8000, (int) (short) (pi.thr - (int) row0[a]));
+        if (a < n0) {
+            const int cutoff2 = (int) (short) (pi.thr - (int) row0[a]);
+            c = (uint32_t) (ext3Cum ? countGETab(cum1, ext3Lo, cutoff2) : countGE(row1, 8000, cutoff2));
+        }
         uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {

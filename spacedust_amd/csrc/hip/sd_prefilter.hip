@@ -114,11 +114,53 @@ __device__ __forceinline__ void idxList(const uint32_t *__restrict__ off, const 
     }
 }
 
+// countGE of a whole 3-mer row from the cumulative table (sd_target::dExt3Cum): one read instead of a 13-step search.  Exactly the
+// same number -- the rows are sorted by descending score, so "first index below the cutoff" is "entries at or above it".
+constexpr int EXT3_CUM_SPAN = 256;
+__device__ __forceinline__ int countGETab(const uint16_t *__restrict__ cumRow, int lo, int cutoff) {
+    const int c = cutoff - lo;
+    return c <= 0 ? 8000 : (c >= EXT3_CUM_SPAN ? 0 : (int) cumRow[c]);
+}
+
+__global__ void ext3_minmax_kernel(const int16_t *__restrict__ score, uint64_t n, int *__restrict__ mm /* [min, max] */) {
+    int lo = 32767, hi = -32768;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const int v = score[i];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+
+// one workgroup per row: histogram of the row's scores, then cum[c] = entries with score >= lo + c
+__global__ void __launch_bounds__(256)
+ext3_cum_kernel(const int16_t *__restrict__ score, int lo, uint16_t *__restrict__ cum) {
+    __shared__ uint32_t hist[EXT3_CUM_SPAN];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int16_t *row = score + (size_t) blockIdx.x * 8000;
+    for (int j = threadIdx.x; j < 8000; j += 256) atomicAdd(&hist[(int) row[j] - lo], 1u);
+    __syncthreads();
+    uint32_t sum = 0;
+    for (int v = threadIdx.x; v < EXT3_CUM_SPAN; v++) sum += hist[v];
+    cum[(size_t) blockIdx.x * EXT3_CUM_SPAN + threadIdx.x] = (uint16_t) sum;
+}
+
 // K1: count similar k-mers per position
 __global__ void __launch_bounds__(256)
 count_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
                    const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
-                   const int16_t *__restrict__ ext3Score, uint32_t *__restrict__ kmerCount) {
+                   const int16_t *__restrict__ ext3Score, uint32_t *__restrict__ kmerCount,
+                   const uint16_t *__restrict__ ext3Cum /* nullable */, int ext3Lo) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
@@ -129,10 +171,16 @@ count_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t
         const int16_t *row1 = ext3Score + (size_t) pi.idx1 * 8000;
         const int best1 = row1[0];
         const int cutoff1 = (int) (short) (pi.thr - best1);
-        const int n0 = countGE(row0, 8000, cutoff1);
-        for (int a = lane; a < n0; a += 64) {
-            const int cutoff2 = (int) (short) (pi.thr - (int) row0[a]);
-            total += (uint32_t) countGE(row1, 8000, cutoff2);
+        if (ext3Cum) {
+            const uint16_t *cum0 = ext3Cum + (size_t) pi.idx0 * EXT3_CUM_SPAN, *cum1 = ext3Cum + (size_t) pi.idx1 * EXT3_CUM_SPAN;
+            const int n0 = countGETab(cum0, ext3Lo, cutoff1);
+            for (int a = lane; a < n0; a += 64) total += (uint32_t) countGETab(cum1, ext3Lo, (int) (short) (pi.thr - (int) row0[a]));
+        } else {
+            const int n0 = countGE(row0, 8000, cutoff1);
+            for (int a = lane; a < n0; a += 64) {
+                const int cutoff2 = (int) (short) (pi.thr - (int) row0[a]);
+                total += (uint32_t) countGE(row1, 8000, cutoff2);
+            }
         }
     }
 #pragma unroll
@@ -2539,6 +2587,31 @@ inline unsigned gridFor(uint64_t n, unsigned block) { return (unsigned) ((n + bl
 
 }  // namespace
 
+// The cumulative score table of the 3-mer rows (see countGETab): built once per target, 4 MB.  Scores that span more than 255
+// values leave dExt3Cum null and the kernels keep searching the sorted rows.
+int sdBuildExt3Cum(sd_ctx *ctx, sd_target *t) {
+    if (!t || !t->dExt3Score || t->dExt3Cum) return SD_OK;
+    if (getenv("SD_PF_CUM") && atoi(getenv("SD_PF_CUM")) == 0) return SD_OK;
+    int *dMM = nullptr;
+    SD_HIP(ctx, hipMalloc((void **) &dMM, 2 * sizeof(int)));
+    const int init[2] = {32767, -32768};
+    int mm[2] = {0, 0};
+    hipError_t e = hipMemcpy(dMM, init, sizeof(init), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ext3_minmax_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const int16_t *) t->dExt3Score, (uint64_t) 8000 * 8000, dMM);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(mm, dMM, sizeof(mm), hipMemcpyDeviceToHost);
+    (void) hipFree(dMM);
+    SD_HIP(ctx, e);
+    if (mm[1] - mm[0] + 1 >= EXT3_CUM_SPAN) return SD_OK;   // (c = hi - lo + 1 must read 0: it has to be inside the table)
+    SD_HIP(ctx, hipMalloc((void **) &t->dExt3Cum, (size_t) 8000 * EXT3_CUM_SPAN * sizeof(uint16_t)));
+    t->ext3Lo = mm[0];
+    hipLaunchKernelGGL(ext3_cum_kernel, dim3(8000), dim3(256), 0, ctx->stream, (const int16_t *) t->dExt3Score, mm[0], t->dExt3Cum);
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
 extern "C" {
 
 int sd_target_create(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets, const uint32_t *entrySeq,
@@ -2614,6 +2687,10 @@ int sd_target_create_wide(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets
     (void) hipFree(t->dEntryPos);
     t->dEntrySeq = nullptr;
     t->dEntryPos = nullptr;
+    if (sdBuildExt3Cum(ctx, t) != SD_OK) {
+        sd_target_destroy(t);
+        return SD_EHIP;
+    }
     *out = t;
     return SD_OK;
 }
@@ -2621,7 +2698,7 @@ int sd_target_create_wide(sd_ctx *ctx, int kmerSize, const uint32_t *kmerOffsets
 void sd_target_destroy(sd_target *t) {
     if (!t) return;
     void *ptrs[] = {t->dOffsets, t->dBlockBase, t->dEntrySeq, t->dEntryPos, t->dMasked, t->dSeqOff, t->dExt3Score, t->dExt3Index,
-                    t->dExt2Score, t->dExt2Index, t->dEntries};
+                    t->dExt2Score, t->dExt2Index, t->dEntries, t->dExt3Cum};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     delete t;
@@ -2645,6 +2722,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
     if (par->minDiagScore < 1) return sdFail(ctx, SD_EUNSUPPORTED, "minDiagScore must be >= 1");
     if (par->binSize == 0 || (par->binSize & (par->binSize - 1))) return sdFail(ctx, SD_EINVAL, "binSize must be a power of two");
     (void) hipSetDevice(ctx->device);
+    sdD2HReset(ctx);   // (reads an earlier, failed call left pending)
     const int maxHits = (int) std::min<uint64_t>((uint64_t) par->maxHitsPerQuery, T->nSeq);
     int tBits = 1;
     while ((1ull << tBits) < T->nSeq) tBits++;
@@ -2772,7 +2850,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     }
                 } else if (T->k == 6)
                     hipLaunchKernelGGL(count_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
-                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p);
+                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo);
                 else
                     hipLaunchKernelGGL(count_kmers7_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                        dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt3Score, dKmerCount.p);
@@ -2898,7 +2976,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             {
                 ProfScope ps(ctx, "prefilter_emit_kmers");
                 hipLaunchKernelGGL(emit_kmers_join_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq, dQ.p,
-                                   dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, dKmerBase.p, dElems.p);
+                                   dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, dKmerBase.p, dElems.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo);
             }
             uint64_t nSorted = 0;
             {

@@ -1957,6 +1957,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     if (!ctx || !par || !queries || !targets || !out) return SD_EINVAL;
     if (compactIdx && (!nCompact || par->swMode != 2)) return sdFail(ctx, SD_EINVAL, "the compact variants need swMode 2 (records with backtraces)");
     (void) hipSetDevice(ctx->device);
+    sdD2HReset(ctx);   // (reads an earlier, failed call left pending)
     if (btUsed) *btUsed = 0;
     if (nCompact) *nCompact = 0;
     if (nPairs == 0) return SD_OK;
