@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256)
 count_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
                     const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
                     const int16_t *__restrict__ ext2Score, const int16_t *__restrict__ ext3Score,
-                    uint32_t *__restrict__ kmerCount) {
+                    uint32_t *__restrict__ kmerCount, const uint16_t *__restrict__ ext3Cum /* nullable */, int ext3Lo) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
@@ -264,7 +264,8 @@ count_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_
             const int nb = countGE(row1, 400, (int) (short) (pi.thr - sa - best2));
             for (int b = lane; b < nb; b += 64) {
                 const int sab = (int) (short) (sa + (int) row1[b]);
-                total += (uint32_t) countGE(row2, 8000, (int) (short) (pi.thr - sab));
+                const int cutoff3 = (int) (short) (pi.thr - sab);
+                total += (uint32_t) (ext3Cum ? countGETab(ext3Cum + (size_t) pi.idx2 * EXT3_CUM_SPAN, ext3Lo, cutoff3) : countGE(row2, 8000, cutoff3));
             }
         }
     }
@@ -281,7 +282,8 @@ emit_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t
                    const int16_t *__restrict__ ext3Score, const uint16_t *__restrict__ ext3Index,
                    const uint32_t *__restrict__ idxOffsets, const uint64_t *__restrict__ kmerBase,
                    uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen, uint32_t *__restrict__ kPos,
-                   const uint64_t *__restrict__ blockBase, uint32_t *__restrict__ kStartHi) {
+                   const uint64_t *__restrict__ blockBase, uint32_t *__restrict__ kStartHi,
+                   const uint16_t *__restrict__ ext3Cum /* nullable: countGETab */, int ext3Lo) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
@@ -311,7 +313,8 @@ emit_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t
             uint32_t c = 0;
             if (b < nb) {
                 const int sab = (int) (short) (sa + (int) row1[b]);
-                c = (uint32_t) countGE(row2, 8000, (int) (short) (pi.thr - sab));
+                const int cutoff3 = (int) (short) (pi.thr - sab);
+                c = (uint32_t) (ext3Cum ? countGETab(ext3Cum + (size_t) pi.idx2 * EXT3_CUM_SPAN, ext3Lo, cutoff3) : countGE(row2, 8000, cutoff3));
             }
             uint32_t incl = c;
 #pragma unroll
@@ -508,7 +511,8 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
                   const int16_t *__restrict__ ext3Score, const uint16_t *__restrict__ ext3Index,
                   const uint32_t *__restrict__ idxOffsets, const uint64_t *__restrict__ kmerBase,
                   uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen, uint32_t *__restrict__ kPos,
-                  const uint64_t *__restrict__ blockBase, uint32_t *__restrict__ kStartHi) {
+                  const uint64_t *__restrict__ blockBase, uint32_t *__restrict__ kStartHi,
+                   const uint16_t *__restrict__ ext3Cum /* nullable: countGETab */, int ext3Lo) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
@@ -520,7 +524,7 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
     const uint16_t *ix1 = ext3Index + (size_t) pi.idx1 * 8000;
     const int best1 = row1[0];
     const int cutoff1 = (int) (short) (pi.thr - best1);
-    const int n0 = countGE(row0, 8000, cutoff1);
+    const int n0 = ext3Cum ? countGETab(ext3Cum + (size_t) pi.idx0 * EXT3_CUM_SPAN, ext3Lo, cutoff1) : countGE(row0, 8000, cutoff1);
     uint64_t base = kmerBase[p];
     const uint32_t qi = (pi.q << 16) | (uint32_t) pi.i;   // owning query (< 2^16 per sub-batch) and position (< 2^16)
     // The lanes first own prefixes (a) and count their suffix runs; the runs are then flattened: output slot t of the chunk
@@ -535,7 +539,7 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
         uint32_t c = 0;
         if (a < n0) {
             const int cutoff2 = (int) (short) (pi.thr - (int) row0[a]);
-            c = (uint32_t) countGE(row1, 8000, cutoff2);
+            c = (uint32_t) (ext3Cum ? countGETab(ext3Cum + (size_t) pi.idx1 * EXT3_CUM_SPAN, ext3Lo, cutoff2) : countGE(row1, 8000, cutoff2));
         }
         uint32_t incl = c;
 #pragma unroll
@@ -2853,7 +2857,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                        dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo);
                 else
                     hipLaunchKernelGGL(count_kmers7_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
-                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt3Score, dKmerCount.p);
+                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt3Score, dKmerCount.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo);
             }
             int rc = exclusiveScanWiden(ctx, dKmerCount.p, dKmerBase.p, nPos + 1, scanTmp);
             if (rc != SD_OK) return rc;
@@ -2911,22 +2915,26 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     if (wideIdx)
                         hipLaunchKernelGGL(emit_kmers_kernel<true>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                            dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
-                                           dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, (const uint64_t *) T->dBlockBase, dKStartHi.p);
+                                           dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, (const uint64_t *) T->dBlockBase, dKStartHi.p,
+                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo);
                     else
                         hipLaunchKernelGGL(emit_kmers_kernel<false>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                            dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
-                                           dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, (const uint64_t *) nullptr, (uint32_t *) nullptr);
+                                           dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, (const uint64_t *) nullptr, (uint32_t *) nullptr,
+                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo);
                 } else {
                     if (wideIdx)
                         hipLaunchKernelGGL(emit_kmers7_kernel<true>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                            dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt2Index, T->dExt3Score,
                                            T->dExt3Index, T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p,
-                                           (const uint64_t *) T->dBlockBase, dKStartHi.p);
+                                           (const uint64_t *) T->dBlockBase, dKStartHi.p,
+                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo);
                     else
                         hipLaunchKernelGGL(emit_kmers7_kernel<false>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                            dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt2Index, T->dExt3Score,
                                            T->dExt3Index, T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p,
-                                           (const uint64_t *) nullptr, (uint32_t *) nullptr);
+                                           (const uint64_t *) nullptr, (uint32_t *) nullptr,
+                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo);
                 }
             }
             int rc = exclusiveScanWiden(ctx, dKLen.p, dHitBase.p, nKmers + 1, scanTmp);
