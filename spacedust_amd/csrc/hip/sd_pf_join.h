@@ -56,11 +56,12 @@ emit_kmers_join_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint
                        const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
                        const int16_t *__restrict__ ext3Score, const uint16_t *__restrict__ ext3Index,
                        const uint64_t *__restrict__ kmerBase, uint64_t *__restrict__ elems,
-                       const uint16_t *__restrict__ ext3Cum /* nullable: countGETab */, int ext3Lo) {
+                       const uint16_t *__restrict__ ext3Cum /* nullable: countGETab */, int ext3Lo,
+                       const uint32_t *__restrict__ posQuery /* nullable */) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
-    PosInfo pi = decodePos(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr);
+    PosInfo pi = decodePos(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr, posQuery);
     if (!pi.ok) return;
     const int16_t *row0 = ext3Score + (size_t) pi.idx0 * 8000;
     const int16_t *row1 = ext3Score + (size_t) pi.idx1 * 8000;

@@ -68,14 +68,20 @@ struct PosInfo {
 
 __device__ __forceinline__ PosInfo decodePos(uint64_t p, const uint64_t *__restrict__ posBase, uint32_t nQ,
                                              const uint8_t *__restrict__ qRes, const uint64_t *__restrict__ qOff,
-                                             const int16_t *__restrict__ kmerBias, int kmerThr) {
+                                             const int16_t *__restrict__ kmerBias, int kmerThr,
+                                             const uint32_t *__restrict__ posQuery = nullptr /* pos_query_kernel's answer */) {
     PosInfo r;
-    // binary search: last q with posBase[q] <= p
+    // binary search: last q with posBase[q] <= p -- eleven dependent reads in front of everything else a wavefront does for its
+    // position; the hot kernels take the answer from posQuery (computed once per sub-batch, 64 positions per wavefront)
     uint32_t lo = 0, hi = nQ;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (posBase[mid] <= p) lo = mid;
-        else hi = mid;
+    if (posQuery) {
+        lo = posQuery[p];
+    } else {
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (posBase[mid] <= p) lo = mid;
+            else hi = mid;
+        }
     }
     r.q = lo;
     r.i = (int) (p - posBase[lo]);
@@ -112,6 +118,20 @@ __device__ __forceinline__ void idxList(const uint32_t *__restrict__ off, const 
         startHi = 0;
         len = e - s;
     }
+}
+
+// query of every position of a sub-batch (last q with posBase[q] <= p), a thread per position
+__global__ void __launch_bounds__(256)
+pos_query_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, uint32_t *__restrict__ posQuery) {
+    const uint64_t p = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (p >= nPos) return;
+    uint32_t lo = 0, hi = nQ;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (posBase[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    posQuery[p] = lo;
 }
 
 // countGE of a whole 3-mer row from the cumulative table (sd_target::dExt3Cum): one read instead of a 13-step search.  Exactly the
@@ -160,11 +180,11 @@ __global__ void __launch_bounds__(256)
 count_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
                    const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
                    const int16_t *__restrict__ ext3Score, uint32_t *__restrict__ kmerCount,
-                   const uint16_t *__restrict__ ext3Cum /* nullable */, int ext3Lo) {
+                   const uint16_t *__restrict__ ext3Cum /* nullable */, int ext3Lo, const uint32_t *__restrict__ posQuery /* nullable */) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
-    PosInfo pi = decodePos(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr);
+    PosInfo pi = decodePos(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr, posQuery);
     uint32_t total = 0;
     if (pi.ok) {
         const int16_t *row0 = ext3Score + (size_t) pi.idx0 * 8000;
@@ -2826,6 +2846,11 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, dKmerCount.alloc(nPos + 1));
         SD_HIP(ctx, dKmerBase.alloc(nPos + 1));
         SD_HIP(ctx, hipMemsetAsync(dKmerCount.p, 0, (nPos + 1) * sizeof(uint32_t), ctx->stream));
+        WsView<uint32_t> dPosQuery(ctx, "pf.dPosQuery");   // sequence queries, k = 6: the query of every position, looked up once
+        if (nPos > 0 && !prof && T->k == 6) {
+            SD_HIP(ctx, dPosQuery.alloc(nPos));
+            hipLaunchKernelGGL(pos_query_kernel, dim3(gridFor(nPos, 256)), dim3(256), 0, ctx->stream, nPos, (const uint64_t *) dPosBase.p, bq, dPosQuery.p);
+        }
         if (nPos > 0) {
             {
                 ProfScope ps(ctx, "prefilter_count_kmers");
@@ -2854,7 +2879,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     }
                 } else if (T->k == 6)
                     hipLaunchKernelGGL(count_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
-                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo);
+                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, dKmerCount.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo,
+                                       (const uint32_t *) dPosQuery.p);
                 else
                     hipLaunchKernelGGL(count_kmers7_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                        dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt3Score, dKmerCount.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo);
@@ -2984,7 +3010,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             {
                 ProfScope ps(ctx, "prefilter_emit_kmers");
                 hipLaunchKernelGGL(emit_kmers_join_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq, dQ.p,
-                                   dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, dKmerBase.p, dElems.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo);
+                                   dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, dKmerBase.p, dElems.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo,
+                                   (const uint32_t *) dPosQuery.p);
             }
             uint64_t nSorted = 0;
             {
