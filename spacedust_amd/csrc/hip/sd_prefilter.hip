@@ -1665,6 +1665,16 @@ segment_match_kernel(uint32_t nVQ, const uint64_t *__restrict__ segBase, const u
 }
 
 // per-query bin counts -> running bin base (so that a flat workgroup index maps to (query, bin))
+// the (query, bin) slot of every bucket workgroup, a thread per workgroup: bucket_match / bucket_collect read theirs instead of each
+// searching binBase (eleven dependent reads at the head of a workgroup that lives ten microseconds)
+__global__ void __launch_bounds__(256)
+slot_list_kernel(uint32_t nSlotsTotal, uint32_t nQ, const uint64_t *__restrict__ binBase, uint32_t *__restrict__ slotList) {
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nSlotsTotal) return;
+    uint32_t q = 0, b = 0;
+    slotList[w] = pfSlotOf(w, nQ, binBase, q, b) ? q * (uint32_t) PF_NB_MAX + b : 0u;
+}
+
 __global__ void bin_count_kernel(uint32_t nQ, const uint32_t *__restrict__ qLog2Bins, uint32_t *__restrict__ qBins) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < nQ) qBins[q] = qLog2Bins[q] <= (uint32_t) PF_LB_MAX ? (1u << qLog2Bins[q]) : 0u;
@@ -1677,10 +1687,15 @@ __global__ void __launch_bounds__(64)
 bucket_collect_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uint64_t *__restrict__ bktStart,
                       const uint32_t *__restrict__ bktEmit, const uint64_t *__restrict__ emitOff,
                       const uint32_t *__restrict__ inKey, const uint32_t *__restrict__ inVal, uint32_t *__restrict__ cKey,
-                      uint32_t *__restrict__ cVal) {
+                      uint32_t *__restrict__ cVal, const uint32_t *__restrict__ slotList /* nullable: slot_list_kernel */) {
     uint32_t q, b;
-    if (!pfSlotOf(blockIdx.x, nQ, binBase, q, b)) return;
-    const size_t slot = (size_t) q * PF_NB_MAX + b;
+    size_t slot;
+    if (slotList) {
+        slot = slotList[blockIdx.x];
+    } else {
+        if (!pfSlotOf(blockIdx.x, nQ, binBase, q, b)) return;
+        slot = (size_t) q * PF_NB_MAX + b;
+    }
     const uint32_t n = bktEmit[slot];
     if (n == 0) return;
     const uint64_t src = bktStart[slot], dst = emitOff[slot];
@@ -3294,6 +3309,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     SD_HIP(ctx, dValA.alloc(nLeft));
                 }
                 const size_t nSlots = (size_t) nVQ * PF_NB_MAX;
+                WsView<uint32_t> dSlotList(ctx, "pf.dSlotList");
                 WsView<uint64_t> dBktStart(ctx, "pf.dBktStart");
                 WsView<uint32_t> dBktCount(ctx, "pf.dBktCount");
                 WsView<uint32_t> dBktEmit(ctx, "pf.dBktEmit");
@@ -3362,9 +3378,12 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     SD_HIP(ctx, hipMemsetAsync(dBigCount, 0, sizeof(uint32_t), ctx->stream));
                     {
                         ProfScope ps(ctx, "prefilter_bucket_match");
+                        SD_HIP(ctx, dSlotList.alloc(totalBins));
+                        hipLaunchKernelGGL(slot_list_kernel, dim3(gridFor(totalBins, 256)), dim3(256), 0, ctx->stream, (uint32_t) totalBins, nVQ,
+                                           (const uint64_t *) dBinBase.p, dSlotList.p);
                         hipLaunchKernelGGL((bucket_match_kernel<128, PF_BUCKET_CAP>), dim3((unsigned) totalBins), dim3(128), 0, ctx->stream,
                                            nVQ, dBinBase.p, dQLog2.p, tBitsV, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, outK,
-                                           outV, dBktEmit.p, dFlag.p, (const uint32_t *) nullptr, dBigList.p, dBigCount, bigCap,
+                                           outV, dBktEmit.p, dFlag.p, (const uint32_t *) dSlotList.p, dBigList.p, dBigCount, bigCap,
                                            dQSplit.p, dQParts.p, dQSplits.p, cBits, widePos ? tBitsV : 0);
                     }
                     uint32_t nBig = 0;
@@ -3390,7 +3409,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                             SD_HIP(ctx, dCKey.alloc(nCand));
                             SD_HIP(ctx, dCVal.alloc(nCand));
                             hipLaunchKernelGGL(bucket_collect_kernel, dim3((unsigned) totalBins), dim3(64), 0, ctx->stream, nVQ, dBinBase.p,
-                                               dBktStart.p, dBktEmit.p, dEmitOff.p, outK, outV, dCKey.p, dCVal.p);
+                                               dBktStart.p, dBktEmit.p, dEmitOff.p, outK, outV, dCKey.p, dCVal.p, (const uint32_t *) dSlotList.p);
                         }
                     }
                 }
