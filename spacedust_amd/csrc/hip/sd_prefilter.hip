@@ -1748,7 +1748,25 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
                 best = score > best ? score : best;
             }
         } else {
-            for (int x = 0; x < n; x++) {
+            // eight cells per step: the three byte streams (query letters, their bias, target letters) as one unaligned 8-byte read
+            // each -- a lane walks its own pair of sequences, so every read is a request of its own and their number is what the
+            // kernel costs
+            int x = 0;
+            for (; x + 8 <= n; x += 8) {
+                unsigned long long wq, wb, wt;
+                __builtin_memcpy(&wq, qs + q0 + x, 8);
+                __builtin_memcpy(&wb, qb + q0 + x, 8);
+                __builtin_memcpy(&wt, ts + t0 + x, 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int qr = (int) ((wq >> (8 * j)) & 0xFFull), tr = (int) ((wt >> (8 * j)) & 0xFFull);
+                    const int8_t bj = (int8_t) (uint8_t) ((wb >> (8 * j)) & 0xFFull);
+                    score += (int) (int8_t) (smat[qr * 21 + tr] + bj);
+                    score = score < 0 ? 0 : score;
+                    best = score > best ? score : best;
+                }
+            }
+            for (; x < n; x++) {
                 const int qr = qs[q0 + x];
                 score += (int) (int8_t) (smat[qr * 21 + ts[t0 + x]] + qb[q0 + x]);
                 score = score < 0 ? 0 : score;
