@@ -234,13 +234,18 @@ struct PosInfo7 {
 
 __device__ __forceinline__ PosInfo7 decodePos7(uint64_t p, const uint64_t *__restrict__ posBase, uint32_t nQ,
                                                const uint8_t *__restrict__ qRes, const uint64_t *__restrict__ qOff,
-                                               const int16_t *__restrict__ kmerBias, int kmerThr) {
+                                               const int16_t *__restrict__ kmerBias, int kmerThr,
+                                               const uint32_t *__restrict__ posQuery = nullptr) {
     PosInfo7 r;
     uint32_t lo = 0, hi = nQ;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (posBase[mid] <= p) lo = mid;
-        else hi = mid;
+    if (posQuery) {
+        lo = posQuery[p];
+    } else {
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (posBase[mid] <= p) lo = mid;
+            else hi = mid;
+        }
     }
     r.q = lo;
     r.i = (int) (p - posBase[lo]);
@@ -266,11 +271,12 @@ __global__ void __launch_bounds__(256)
 count_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t nQ, const uint8_t *__restrict__ qRes,
                     const uint64_t *__restrict__ qOff, const int16_t *__restrict__ kmerBias, int kmerThr,
                     const int16_t *__restrict__ ext2Score, const int16_t *__restrict__ ext3Score,
-                    uint32_t *__restrict__ kmerCount, const uint16_t *__restrict__ ext3Cum /* nullable */, int ext3Lo) {
+                    uint32_t *__restrict__ kmerCount, const uint16_t *__restrict__ ext3Cum /* nullable */, int ext3Lo,
+                    const uint32_t *__restrict__ posQuery /* nullable */) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
-    PosInfo7 pi = decodePos7(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr);
+    PosInfo7 pi = decodePos7(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr, posQuery);
     uint32_t total = 0;
     if (pi.ok) {
         const int16_t *row0 = ext2Score + (size_t) pi.idx0 * 400;
@@ -303,11 +309,12 @@ emit_kmers7_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t
                    const uint32_t *__restrict__ idxOffsets, const uint64_t *__restrict__ kmerBase,
                    uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen, uint32_t *__restrict__ kPos,
                    const uint64_t *__restrict__ blockBase, uint32_t *__restrict__ kStartHi,
-                   const uint16_t *__restrict__ ext3Cum /* nullable: countGETab */, int ext3Lo) {
+                   const uint16_t *__restrict__ ext3Cum /* nullable: countGETab */, int ext3Lo,
+                   const uint32_t *__restrict__ posQuery /* nullable */) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
-    PosInfo7 pi = decodePos7(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr);
+    PosInfo7 pi = decodePos7(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr, posQuery);
     if (!pi.ok) return;
     const int16_t *row0 = ext2Score + (size_t) pi.idx0 * 400;
     const int16_t *row1 = ext2Score + (size_t) pi.idx1 * 400;
@@ -532,11 +539,12 @@ emit_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32_t 
                   const uint32_t *__restrict__ idxOffsets, const uint64_t *__restrict__ kmerBase,
                   uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen, uint32_t *__restrict__ kPos,
                   const uint64_t *__restrict__ blockBase, uint32_t *__restrict__ kStartHi,
-                   const uint16_t *__restrict__ ext3Cum /* nullable: countGETab */, int ext3Lo) {
+                   const uint16_t *__restrict__ ext3Cum /* nullable: countGETab */, int ext3Lo,
+                   const uint32_t *__restrict__ posQuery /* nullable */) {
     const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= nPos) return;
-    PosInfo pi = decodePos(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr);
+    PosInfo pi = decodePos(p, posBase, nQ, qRes, qOff, kmerBias, kmerThr, posQuery);
     if (!pi.ok) return;
     const int16_t *row0 = ext3Score + (size_t) pi.idx0 * 8000;
     const int16_t *row1 = ext3Score + (size_t) pi.idx1 * 8000;
@@ -2879,8 +2887,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         SD_HIP(ctx, dKmerCount.alloc(nPos + 1));
         SD_HIP(ctx, dKmerBase.alloc(nPos + 1));
         SD_HIP(ctx, hipMemsetAsync(dKmerCount.p, 0, (nPos + 1) * sizeof(uint32_t), ctx->stream));
-        WsView<uint32_t> dPosQuery(ctx, "pf.dPosQuery");   // sequence queries, k = 6: the query of every position, looked up once
-        if (nPos > 0 && !prof && T->k == 6) {
+        WsView<uint32_t> dPosQuery(ctx, "pf.dPosQuery");   // sequence queries: the query of every position, looked up once
+        if (nPos > 0 && !prof) {
             SD_HIP(ctx, dPosQuery.alloc(nPos));
             hipLaunchKernelGGL(pos_query_kernel, dim3(gridFor(nPos, 256)), dim3(256), 0, ctx->stream, nPos, (const uint64_t *) dPosBase.p, bq, dPosQuery.p);
         }
@@ -2916,7 +2924,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                        (const uint32_t *) dPosQuery.p);
                 else
                     hipLaunchKernelGGL(count_kmers7_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
-                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt3Score, dKmerCount.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo);
+                                       dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt3Score, dKmerCount.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo,
+                                       (const uint32_t *) dPosQuery.p);
             }
             int rc = exclusiveScanWiden(ctx, dKmerCount.p, dKmerBase.p, nPos + 1, scanTmp);
             if (rc != SD_OK) return rc;
@@ -2975,25 +2984,25 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         hipLaunchKernelGGL(emit_kmers_kernel<true>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                            dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
                                            dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, (const uint64_t *) T->dBlockBase, dKStartHi.p,
-                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo);
+                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo, (const uint32_t *) dPosQuery.p);
                     else
                         hipLaunchKernelGGL(emit_kmers_kernel<false>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                            dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, T->dOffsets,
                                            dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, (const uint64_t *) nullptr, (uint32_t *) nullptr,
-                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo);
+                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo, (const uint32_t *) dPosQuery.p);
                 } else {
                     if (wideIdx)
                         hipLaunchKernelGGL(emit_kmers7_kernel<true>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                            dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt2Index, T->dExt3Score,
                                            T->dExt3Index, T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p,
                                            (const uint64_t *) T->dBlockBase, dKStartHi.p,
-                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo);
+                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo, (const uint32_t *) dPosQuery.p);
                     else
                         hipLaunchKernelGGL(emit_kmers7_kernel<false>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
                                            dQ.p, dQOff.p, dKB.p, par->kmerThr, T->dExt2Score, T->dExt2Index, T->dExt3Score,
                                            T->dExt3Index, T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p,
                                            (const uint64_t *) nullptr, (uint32_t *) nullptr,
-                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo);
+                                           (const uint16_t *) T->dExt3Cum, T->ext3Lo, (const uint32_t *) dPosQuery.p);
                 }
             }
             int rc = exclusiveScanWiden(ctx, dKLen.p, dHitBase.p, nKmers + 1, scanTmp);
