@@ -40,7 +40,10 @@ constexpr int KP_PER = KP_TILE / JP_NT;
 constexpr int JQ_MAX = 4096;           // queries per sub-batch
 constexpr int JJ_WGS = 512;            // persistent workgroups of the join (two per CU)
 constexpr int JJ_NT = 1024;
-constexpr int JE = 2;                  // k-mers per lane and step of the join (independent load chains in flight)
+#ifndef SD_JE
+#define SD_JE 2
+#endif
+constexpr int JE = SD_JE;              // k-mers per lane and step of the join (independent load chains in flight)
 constexpr int JC = JJ_NT * JE;         // k-mers per join chunk: 64 * JE per wavefront
 constexpr uint32_t JOIN_ORD_LIMIT = 1u << 24;   // k-mers per query the value word can order
 constexpr uint64_t JP_PAD = ~0ull;     // filler behind a k-mer range (ranges are padded to whole join chunks)
