@@ -483,3 +483,32 @@ def test_prefilter_join_path_equals_lookup_path(gpu, host, monkeypatch):
         d = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)
         same(a, d, ('batch 700', bin_size))
         monkeypatch.delenv('SD_PF_BATCH')
+
+
+@pytest.mark.parametrize('k,kmer_thr', [(6, 112), (6, 95), (7, 122)])
+def test_prefilter_cumulative_score_table_equals_row_search(gpu, host, monkeypatch, k, kmer_thr):
+    """countGE of a sorted 3-mer row as one read of the target's cumulative score table (sdBuildExt3Cum) against the 13-step search of
+    the row it replaces (a target created with SD_PF_CUM=0 has no table): identical rows and statistics (k-mer and hit counts per
+    query) on the join path, the lookup path and the k = 7 generator"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=6, genes_per_proteome=500, n_families=800, seed=93)
+    ident = np.arange(ps.n, dtype=np.uint32)
+    sw_b, dg_b, km_b = host.comp_bias(ps.residues, ps.offsets, k)
+    idx = host.build_index(ps.residues, ps.offsets, k, kmer_thr)
+    par = api.prefilter_params(host, idx.n, kmer_thr=kmer_thr, max_hits=100, cov_thr=0.0, bin_size=2, k=k)
+    monkeypatch.setenv('SD_PF_CUM', '0')
+    plain = api.Target(gpu, host, idx)
+    monkeypatch.delenv('SD_PF_CUM')
+    table = api.Target(gpu, host, idx)
+    for env in ({}, {'SD_PF_JOIN': '0'}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        a = api.prefilter(gpu, plain, par, ps.residues, ps.offsets, km_b, dg_b, ident, want_stats=True)
+        b = api.prefilter(gpu, table, par, ps.residues, ps.offsets, km_b, dg_b, ident, want_stats=True)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert int(a[1].sum()) > 1000
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), env
+        for q in range(ps.n):
+            n = int(a[1][q])
+            assert np.array_equal(a[0][q, :n], b[0][q, :n]), (env, q)
