@@ -1199,13 +1199,16 @@ hot_filter_kernel(uint32_t nVQ, const uint64_t *__restrict__ segBase, int tBits,
     __shared__ uint32_t bloom[BW];
     __shared__ uint32_t hot[1 << (HL - 5)];
     __shared__ uint32_t outCur;
-    const uint32_t q = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63;
+    // a workgroup takes the segments blockIdx.x, blockIdx.x + gridDim.x, ...: with one workgroup per segment that is one round; with
+    // a grid of one workgroup per CU (SD_PF_HF_PERSIST) a workgroup keeps the CU it has waited for
+    for (uint32_t q = blockIdx.x; q < nVQ; q += gridDim.x) {
+    __syncthreads();   // (the previous segment's last reads of hot / outCur)
     const uint64_t s = segBase[q], e = segBase[q + 1];
     const uint64_t n = e - s;
     if (n < (uint64_t) minSeg || n >= 0xFFFFFFF0ull) {
         if (t == 0) segCount[q] = (uint32_t) n;
-        return;
+        continue;
     }
     for (int x = t; x < (1 << (HL - 5)); x += NT) hot[x] = 0;
     if (t == 0) outCur = 0;
@@ -1322,6 +1325,7 @@ hot_filter_kernel(uint32_t nVQ, const uint64_t *__restrict__ segBase, int tBits,
     }
     __syncthreads();
     if (t == 0) segCount[q] = outCur;
+    }
 }
 
 // workgroup w -> (query, bin): bins of a query are contiguous, binBase[q] = sum of bins of the queries before
@@ -3304,15 +3308,18 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     {
                         ProfScope ps(ctx, "prefilter_hot_filter");
                         const int geo = getenv("SD_PF_HF") ? atoi(getenv("SD_PF_HF")) : 0;
+                        // SD_PF_HF_PERSIST=n: n workgroups per CU that loop over the segments instead of one workgroup per segment
+                        const int hfPersist = getenv("SD_PF_HF_PERSIST") ? atoi(getenv("SD_PF_HF_PERSIST")) : 0;
+                        const uint32_t hfGrid = hfPersist > 0 ? std::min<uint32_t>(nVQ, (uint32_t) hfPersist * (uint32_t) ctx->prop.multiProcessorCount) : nVQ;
 #define SD_HF(NT_, BW_, HL_)                                                                                                              \
-    hipLaunchKernelGGL((hot_filter_kernel<NT_, BW_, HL_>), dim3(nVQ), dim3(NT_), 0, ctx->stream, nVQ, pHitBase, tBitsV, (uint32_t *) pKey, \
+    hipLaunchKernelGGL((hot_filter_kernel<NT_, BW_, HL_>), dim3(hfGrid), dim3(NT_), 0, ctx->stream, nVQ, pHitBase, tBitsV, (uint32_t *) pKey, \
                        (uint32_t *) pVal, (uint2 *) pKV, widePos ? tBitsV : 0, minSeg, dHotCount.p)
                         if (geo == 1) SD_HF(512, 12288, 17);        // 64 KB
                         else if (geo == 2) SD_HF(512, 8192, 17);    // 48 KB
                         else if (geo == 3) SD_HF(256, 6144, 16);    // 32 KB
                         else if (geo == 4) SD_HF(1024, 16384, 18);  // 96 KB
                         else if (geo == 5) SD_HF(1024, 24576, 18);  // 128 KB, pass-B tiles of 4 096 hits
-                        else hipLaunchKernelGGL((hot_filter_kernel<1024, 24576, 18, 8>), dim3(nVQ), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV,
+                        else hipLaunchKernelGGL((hot_filter_kernel<1024, 24576, 18, 8>), dim3(hfGrid), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV,
                                                 (uint32_t *) pKey, (uint32_t *) pVal, (uint2 *) pKV, widePos ? tBitsV : 0, minSeg, dHotCount.p);   // 128 KB, tiles of 8 192: half the barriers (isolated 62.9 -> 60.5 ms per step)
 #undef SD_HF
                     }
