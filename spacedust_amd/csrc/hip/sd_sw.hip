@@ -795,14 +795,14 @@ void launchScorePk(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, ui
                        t->dRes, dMat, go, ge, dOut, dBound, dOrder, (const int8_t *) q->dProf);
 }
 
-template <int RT, int LW, int SHARED>
+template <int RT, int LW, int SHARED, int WAVES = 1>
 void launchScorePkAligned(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, uint32_t n, const sd_seqset *q, const sd_seqset *t,
                           const int8_t *dMat, int go, int ge, int32_t *dOut) {
     if (n == 0) return;
-    constexpr uint32_t perWave = 2 * (64 / LW);
-    dim3 grid((n + perWave - 1) / perWave), block(64);
+    constexpr uint32_t perWg = 2 * (64 / LW) * WAVES;
+    dim3 grid((n + perWg - 1) / perWg), block(64 * WAVES);
     static const unsigned ldsPad = getenv("SD_SW_LDS_PAD") ? (unsigned) atoi(getenv("SD_SW_LDS_PAD")) : 0u;
-    hipLaunchKernelGGL((sdpk::sw_score_pk_aligned_kernel<RT, LW, SHARED>), grid, block, ldsPad, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes,
+    hipLaunchKernelGGL((sdpk::sw_score_pk_aligned_kernel<RT, LW, SHARED, WAVES>), grid, block, ldsPad, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes,
                        dMat, go, ge, dOut, dOrder, (const int8_t *) q->dProf);
 }
 
@@ -1383,6 +1383,11 @@ inline bool sdSwQuads() {
     static const bool on = !(getenv("SD_SW_QUADS") && atoi(getenv("SD_SW_QUADS")) == 0);
     return on;
 }
+// SD_SW_WAVES=2: two wavefronts (eight tasks of one query) per workgroup of the aligned kernel share the profile
+inline int sdSwWaves() {
+    static const int w = (sdSwQuads() && getenv("SD_SW_WAVES") && atoi(getenv("SD_SW_WAVES")) == 2) ? 2 : 1;
+    return w;
+}
 constexpr int PAIR_QUERY_BITS = 17;
 __global__ void __launch_bounds__(256)
 k_pair_keys(uint32_t n, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ pairQ, uint32_t *__restrict__ key2) {
@@ -1410,9 +1415,10 @@ k_pair_leaders(uint32_t n, const uint32_t *__restrict__ keyS, const uint32_t *__
     if (p < n && (keyS[p] >> 26) < FIRST_INT32_CLASS) {
         const uint32_t o = p - runStart[p];
         v = (o & 1u) == 0 ? 1 : 0;
-        if (quads) {
+        if (quads) {   // quads = pairs per workgroup (2 per wavefront): the run is padded to a multiple with empty pairs behind it
             const bool lastOfRun = p + 1 >= n || (keyS[p + 1] >> 9) != (keyS[p] >> 9);
-            if (lastOfRun && (((o + 1 + 1) / 2) & 1u)) v += 1;   // pairs of the run = ceil((o + 1) / 2): odd -> one empty pair behind it
+            const uint32_t pairs = (o + 1 + 1) / 2;   // pairs of the run = ceil((o + 1) / 2)
+            if (lastOfRun) v += (uint8_t) (((uint32_t) quads - pairs % (uint32_t) quads) % (uint32_t) quads);
         }
     }
     leader[p] = v;
@@ -1464,8 +1470,10 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
         SD_HIP(ctx, wsGet(ctx, "sp.runstart", (size_t) nPairs, &dRunStart));
         SD_HIP(ctx, wsGet(ctx, "sp.leader", (size_t) nPairs + 1, &dLeader));
         SD_HIP(ctx, wsGet(ctx, "sp.pairidx", (size_t) nPairs + 1, &dPairIdx));
-        SD_HIP(ctx, wsGet(ctx, "sp.order2", (size_t) 4 * nPairs + 8, &dOrder2));
-        SD_HIP(ctx, hipMemsetAsync(dOrder2, 0xFF, ((size_t) 4 * nPairs + 8) * sizeof(uint32_t), ctx->stream));   // empty pairs: PAIR_NONE
+        const int padPairs = sdSwQuads() ? 2 * sdSwWaves() : 0;   // pairs per workgroup of the shared-profile kernels
+        const size_t order2Cap = (size_t) 2 * (size_t) std::max(padPairs, 2) * nPairs + 8;   // worst case: every run one task, padded to a workgroup
+        SD_HIP(ctx, wsGet(ctx, "sp.order2", order2Cap, &dOrder2));
+        SD_HIP(ctx, hipMemsetAsync(dOrder2, 0xFF, order2Cap * sizeof(uint32_t), ctx->stream));   // empty pairs: PAIR_NONE
         SD_HIP(ctx, wsGet(ctx, "sp.bounds", 64, &dPairBounds));
         hipLaunchKernelGGL(k_pair_keys, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeys, dPairQ, dKey2);
         rc = devSortPairs(ctx, dKey2, dKeysSorted, dVals, dVals2, nPairs, 32);
@@ -1480,7 +1488,7 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
             SD_HIP(ctx, hipcub::DeviceScan::InclusiveScan(tmp, bytes, dHead, dRunStart, MaxU32(), (int) nPairs, ctx->stream));
         }
         hipLaunchKernelGGL(k_pair_leaders, dim3((nPairs + 256) / 256), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dRunStart, dLeader,
-                           sdSwQuads() ? 1 : 0);
+                           padPairs);
         {
             size_t bytes = 0;
             hipcub::TransformInputIterator<uint64_t, WidenU8, const uint8_t *> it(dLeader, WidenU8());
@@ -1549,7 +1557,8 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
     } while (0)
 #define SD_PKA(RT)                                                                                               \
     case RT:                                                                                                     \
-        if (shared && quads) launchScorePkAligned<RT, 32, 2>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);  \
+        if (shared && quads && sdSwWaves() == 2) launchScorePkAligned<RT, 32, 2, 2>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);  \
+        else if (shared && quads) launchScorePkAligned<RT, 32, 2>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);  \
         else if (shared) launchScorePkAligned<RT, 32, 1>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);      \
         else launchScorePkAligned<RT, 32, 0>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);                  \
         break;

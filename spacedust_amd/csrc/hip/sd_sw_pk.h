@@ -444,13 +444,17 @@ __device__ __forceinline__ uint32_t dppMove(uint32_t old, uint32_t v) {
 // 2 = ALL tasks of the wavefront have the same query (the caller pads a query's run of pairs to whole wavefronts): one profile
 // per wavefront -- half (LW = 32) or a quarter (LW = 16) of the LDS, which is what lets the memory-bound prefilter workgroups of
 // the other streams live on the same CUs.
-template <int RT, int LW, int SHARE>
-__global__ void __launch_bounds__(64)
+// WAVES (SHARE == 2 only): wavefronts per workgroup that share the one profile -- the caller pads a query's run of pairs to whole
+// workgroups; the LDS a score wavefront holds is what bounds how many of them (and how many of the other streams' workgroups) a CU
+// takes, and half a profile per wavefront lifts that bound to the wave slots
+template <int RT, int LW, int SHARE, int WAVES = 1>
+__global__ void __launch_bounds__(64 * WAVES)
 sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
                            const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
                            int go, int ge, int32_t *__restrict__ out, const uint32_t *__restrict__ order,
                            const int8_t *__restrict__ qProf) {
     static_assert(LW == 32 || (LW == 16 && RT % 2 == 0), "32 lanes of one segment or 16 lanes of two");
+    static_assert(WAVES == 1 || SHARE == 2, "several wavefronts per workgroup share ONE profile");
     constexpr int SEG = RT * LW / 32;      // rows of a reference segment
     constexpr int WORDS = (RT + 3) / 4;
     constexpr int RTP = 4 * WORDS;
@@ -462,14 +466,14 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
     constexpr bool SHARED = SHARE != 0;
     __shared__ uint32_t prof[SHARE == 2 ? 1 : (SHARE == 1 ? NGRP : NT)][22][PSTRIDE];
     __shared__ int8_t smat[441];
-    for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
+    for (int i = threadIdx.x; i < 441; i += 64 * WAVES) smat[i] = mat[i];
     __syncthreads();
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LW, l = lane % LW;
     SwTask tk[NT];
 #pragma unroll
     for (int x = 0; x < NT; x++) {
-        const uint32_t id = blockIdx.x * NT + x;
+        const uint32_t id = (blockIdx.x * WAVES + (uint32_t) wave) * NT + x;
         const uint32_t tid = id < nTasks ? (order ? order[id] : id) : 0xFFFFFFFFu;
         if (tid != 0xFFFFFFFFu) {
             tk[x] = tasks[tid];
@@ -502,7 +506,15 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
     // ---- query profiles (SmithWaterman::createQueryProfile, :163-187)
 #pragma unroll
     for (int x = 0; x < (SHARED ? 1 : 2); x++) {
-        const SwTask &T = SHARE == 2 ? tk[0] : (x ? B : A);   // (SHARE == 2: every group writes a share of the residue rows of the one profile)
+        // (SHARE == 2: every group of every wavefront writes a share of the residue rows of the one profile; the first task of the
+        // workgroup is a real one -- a run is padded at its end -- and names the query for all of them)
+        SwTask T0 = tk[0];
+        if (WAVES > 1) {
+            const uint32_t id0 = blockIdx.x * WAVES * NT;
+            const uint32_t tid0 = id0 < nTasks ? (order ? order[id0] : id0) : 0xFFFFFFFFu;
+            if (tid0 != 0xFFFFFFFFu) T0 = tasks[tid0];
+        }
+        const SwTask &T = SHARE == 2 ? T0 : (x ? B : A);
         uint32_t *pw = &prof[SHARE == 2 ? 0 : (SHARE == 1 ? grp : 2 * grp + x)][0][0] + l * WORDS;
 #pragma unroll
         for (int w = 0; w < WORDS; w++) {
@@ -523,7 +535,7 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
                     pidx[b] = idx * 21;
                 }
             }
-            const int aFirst = SHARE == 2 ? grp : 0, aStep = SHARE == 2 ? NGRP : 1;
+            const int aFirst = SHARE == 2 ? wave * NGRP + grp : 0, aStep = SHARE == 2 ? NGRP * WAVES : 1;
             if (qProf) {   // profile query: the position's own row
                 for (int a = aFirst; a < 21; a += aStep) {
                     uint32_t word = 0;
