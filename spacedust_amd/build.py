@@ -62,6 +62,11 @@ def build(force=False, verbose=False):
 
 def build_tools(force=False, verbose=False):
     """tools/libvalupeak.so: the VALU issue micro-benchmark behind bench.py's sw_valu calibration (not part of the product)"""
+    # tools/launch_latency: dependent launches beside long-lived workgroups (DESIGN 5); a measurement tool, built when its source is newer
+    lsrc = os.path.join(ROOT, 'tools', 'csrc', 'launch_latency.hip')
+    lout = os.path.join(ROOT, 'tools', 'launch_latency')
+    if os.path.exists(lsrc) and (force or _newer(lsrc, lout)):
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O2', '-w', '-o', lout, lsrc])
     src = os.path.join(ROOT, 'tools', 'csrc', 'valu_peak.hip')
     out = os.path.join(ROOT, 'tools', 'libvalupeak.so')
     if not os.path.exists(src) or (not force and not _newer(src, out)):
