@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- clustersearch hot path (prefilter + SW align + clusterhits) on MI355X.
 
-Workload (BASELINE.json configs[1]): P synthetic proteomes (default 100 x 3000 proteins, len ~300) searched all-vs-all,
---max-seqs max(300, 2P), --filter-self-match.  The target side (k-mer index, masked lookup, sequences) is resident in HBM.
-One *step* = clustersearch of one batch of query proteomes against all P target proteomes; K timed steps, W warm-up steps;
-`value` = genome pairs of all ranks / max-over-ranks time.
+Workload (BASELINE.json: the configuration north_star quotes its target on -- 1 000 synthetic proteomes; configs[2] on one GPU):
+P synthetic proteomes (default 1 000 x 3 000 proteins, len ~300) searched all-vs-all, --max-seqs max(300, 2P), --filter-self-match.
+The target side (k-mer index, masked lookup, sequences) is resident in HBM.  One *step* = clustersearch of one batch of query
+proteomes (default 4 per rank) against all P target proteomes; K timed steps, W warm-up steps; `value` = genome pairs of all
+ranks / max-over-ranks time.
 
 N ranks (one process per GPU, `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) run BASELINE
 configs[2]'s structure: a global step holds N*B query proteomes, dealt to the ranks as whole query sets by
@@ -13,14 +14,15 @@ of the target -- every rank builds the index on its own GPU (sd_target_build) --
 per-entry result records are gathered to rank 0 over RCCL (sd_comm_* / sd_gather_results of the C ABI).  No collective on
 the data path.  Per-GPU work is fixed as N grows: "scaling": "weak".
 
-Prints ONE JSON line (rank 0):
-  roofline      the kernel with the largest accumulated time (HIP events recorded by libsdgpu on its own streams)
+Prints ONE compact JSON line (rank 0; a few KB -- everything bulky goes to the side file gpurun_out/bench_detail.json):
+  roofline      the prefilter kernel with the largest accumulated time (HIP events recorded by libsdgpu on its own streams)
   cpu_baseline  the reference's own AVX2 code (oracle/_ref/libsdref.so; kind "port" if it did not travel) on a bounded
                 sample of the same workload on this box's host cores -- N = 1 only
   parity_check  untimed: device prefilter rows and alignments of sample queries against the reference rows the cpu_baseline
-                leg produced for the same queries
-  p1000         N = 1 only (skip with --no-p1000): a short record at BASELINE configs[2]'s size (1 000 proteomes on one
-                GPU) with its own reference CPU sample, so that north_star's ">= 10x at 1 000 proteomes" is driver-timed
+                leg produced for the same queries; the (query set, target set) entries of one whole measured query set against
+                an independent aggregation of the reference's rows and alignments; the cluster records of measured entries
+                against the reference's clusterhits functions
+  p100 / p10000 / iter3   N = 1 only: short child records at BASELINE configs[1] / configs[4] / configs[3]
 """
 import argparse
 import json
@@ -45,23 +47,25 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)   # 10 steps x 10 query proteomes = one all-vs-all pass over the 100 proteomes
+    ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--proteomes', type=int, default=100)
+    ap.add_argument('--proteomes', type=int, default=1000)   # the size north_star quotes its target on (BASELINE configs[2], one GPU)
     ap.add_argument('--genes', type=int, default=3000)
-    ap.add_argument('--batch', type=int, default=10, help='query proteomes per rank and step')
+    ap.add_argument('--batch', type=int, default=0, help='query proteomes per rank and step (default: 4 at 1 000 proteomes and beyond, else 10)')
     ap.add_argument('--chunk', type=int, default=10000, help='queries per device chunk')
     ap.add_argument('--max-seqs', type=int, default=0, help='result list length (default: max(300, 2 x proteomes), every target set reachable)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg (and the parity check that rides on it)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--cpu-threads', type=int, default=0)
-    ap.add_argument('--no-p1000', action='store_true', help='skip the 1 000-proteome record')
-    ap.add_argument('--p1000-steps', type=int, default=5)
+    ap.add_argument('--no-children', '--no-p1000', dest='no_children', action='store_true', help='skip the child records (p100, p10000, iter3)')
+    ap.add_argument('--no-p100', action='store_true', help='skip the 100-proteome record')
+    ap.add_argument('--p100-steps', type=int, default=10)
+    ap.add_argument('--detail-out', default='', help='side file for the bulky parts of the record (default gpurun_out/bench_detail.json)')
     ap.add_argument('--no-p10000', action='store_true', help='skip the 10 000-proteome record')
     ap.add_argument('--p10000-steps', type=int, default=1)
     ap.add_argument('--p10000-batch', type=int, default=1, help='query proteomes per step of the 10 000-proteome record')
     ap.add_argument('--p10000-chunk', type=int, default=1000, help='queries per device chunk of the 10 000-proteome record (lists of up to 20 000 hits per query)')
-    ap.add_argument('--leg-budget', type=float, default=300.0, help='a child record (p1000, p10000, iter3) is started only while the run is '
+    ap.add_argument('--leg-budget', type=float, default=330.0, help='a child record (p100, p10000, iter3) is started only while the run is '
                                                                      'younger than this many seconds; later ones are reported as skipped')
     ap.add_argument('--no-iter3', action='store_true', help='skip the --num-iterations 3 record (BASELINE configs[3] at 1 000 target proteomes)')
     ap.add_argument('--iter3-queries', type=int, default=2, help='query proteomes of the --num-iterations 3 record')
@@ -69,7 +73,10 @@ def parse():
     ap.add_argument('--strong', action='store_true', help='strong scaling: --batch query proteomes per step in TOTAL, dealt over the ranks '
                                                           '(BASELINE configs[2] as written: one query set of proteomes split over N GPUs)')
     ap.add_argument('--record', action='store_true', help=argparse.SUPPRESS)   # child mode: one plain measurement, JSON out
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.batch <= 0:
+        a.batch = 4 if a.proteomes >= 1000 else 10
+    return a
 
 
 def algorithmic_bytes(stats, q_len_sum):
@@ -103,14 +110,16 @@ def isolated_prefilter(cs, host, ps, k, kmer_thr, max_seqs, bin_size, n_queries=
                 note='same kernels, same algorithmic bytes (SURVEY.md 8(d)), nothing else on the device')
 
 
-def cpu_baseline_subprocess(proteomes, genes, max_seqs, kmer_thr, bin_size, entries_path, seconds, n_threads, check=0, check_out=''):
+def cpu_baseline_subprocess(proteomes, genes, max_seqs, kmer_thr, bin_size, entries_path, seconds, n_threads, check=0, check_out='',
+                            check_sets=(), check_entries=32):
     """The baseline leg runs in a child process (niced, hard timeout, a bounded number of threads) so that it can never
     take the measurement -- or the box -- down with it."""
     cmd = [sys.executable, os.path.join(ROOT, 'tools', 'cpu_baseline.py'), '--proteomes', str(proteomes), '--genes', str(genes),
            '--max-seqs', str(max_seqs), '--kmer-thr', str(kmer_thr), '--bin-size', str(bin_size), '--seconds', str(seconds),
-           '--threads', str(n_threads), '--entries', entries_path, '--check', str(check), '--check-out', check_out]
+           '--threads', str(n_threads), '--entries', entries_path, '--check', str(check), '--check-out', check_out,
+           '--check-sets', ','.join(str(int(x)) for x in check_sets), '--check-entries', str(check_entries)]
     try:
-        out = subprocess.run(['nice', '-n', '10'] + cmd, capture_output=True, text=True, timeout=seconds * 6 + 600)
+        out = subprocess.run(['nice', '-n', '10'] + cmd, capture_output=True, text=True, timeout=seconds * 6 + 900)
         line = [l for l in out.stdout.splitlines() if l.startswith('{')]
         if out.returncode != 0 or not line:
             return dict(value=None, unit='genome-pairs/s', cores=0, kind='failed', sample=(out.stderr or out.stdout)[-300:])
@@ -119,9 +128,61 @@ def cpu_baseline_subprocess(proteomes, genes, max_seqs, kmer_thr, bin_size, entr
         return dict(value=None, unit='genome-pairs/s', cores=0, kind='failed', sample=repr(e))
 
 
-def parity_check(gpu, host, ps, k, max_seqs, bin_size, kmer_thr, check_path):
+def back_half_check(g, last, db):
+    """the back half of the measured run against reference-derived results (check file of tools/cpu_baseline.py):
+    (a) the (query set, target set) entries of whole measured query sets -- entry keys, hits in order, P-value bits -- against
+        the reference's rows and alignments of every query of those sets pushed through oracle/agg_restatement.py
+        (besthitbyset.cpp:41-144, combinehits.cpp:74-234);
+    (b) the cluster records of measured entries -- partition, member ranks, sizes, both P-values bit for bit -- against the
+        reference's own clusterhits functions (oracle/_ref/libsdref_ch.so, ClusterHits.cpp:295-492) on the same entries"""
+    res = {}
+    eo = last['entry_off']
+    if 'agg_keys' in g.files:
+        sets = set(int(x) for x in g['agg_sets'])
+        want = {}
+        for i, (qs, ts) in enumerate(g['agg_keys']):
+            x0, x1 = int(g['agg_off'][i]), int(g['agg_off'][i + 1])
+            want[(int(qs), int(ts))] = (g['agg_q'][x0:x1], g['agg_t'][x0:x1], g['agg_p'][x0:x1])
+        got = {}
+        for e in range(len(last['entry_q'])):
+            if int(last['entry_q'][e]) in sets:
+                x0, x1 = int(eo[e]), int(eo[e + 1])
+                got[(int(last['entry_q'][e]), int(last['entry_t'][e]))] = (last['hit_q'][x0:x1], last['hit_t'][x0:x1], last['hit_pval'][x0:x1])
+        bad = len(set(want) ^ set(got))
+        n_hits = 0
+        for k_ in set(want) & set(got):
+            w, h = want[k_], got[k_]
+            n_hits += len(w[0])
+            same = len(w[0]) == len(h[0]) and (w[0] == h[0].astype(np.int64)).all() and (w[1] == h[1].astype(np.int64)).all() and \
+                np.asarray(w[2], np.float64).tobytes() == np.asarray(h[2], np.float64).tobytes()
+            bad += 0 if same else 1
+        res.update(query_sets=sorted(sets), entries=len(want), entries_measured=len(got), entry_hits=int(n_hits), entries_mismatching=int(bad),
+                   reference_alignments=int(g['agg_alignments']), reference_seconds=round(float(g['agg_seconds']), 1))
+    if 'ch_ncl' in g.files and last['cluster_out'] is not None:
+        co = last['cluster_out']
+        n = int(g['ch_entries'])
+        bad = n_clu = 0
+        c0 = 0   # cluster-wise arrays of the reference side are concatenated entry by entry
+        for e in range(n):
+            x0, x1 = int(eo[e]), int(eo[e + 1])
+            nc = int(g['ch_ncl'][e])
+            rcof, rrk = g['ch_cof'][x0:x1], g['ch_rank'][x0:x1]
+            ok = int(co['n_clusters'][e]) == nc and (co['cluster_of'][x0:x1] == rcof).all()
+            if ok:
+                clustered = rcof != 0xFFFFFFFF
+                ok = (co['rank'][x0:x1][clustered] == rrk[clustered]).all() and (co['size'][x0:x0 + nc] == g['ch_size'][c0:c0 + nc]).all() and \
+                    co['pCO'][x0:x0 + nc].tobytes() == g['ch_pco'][c0:c0 + nc].tobytes() and \
+                    co['pMH'][x0:x0 + nc].tobytes() == g['ch_pmh'][c0:c0 + nc].tobytes()
+            bad += 0 if ok else 1
+            n_clu += nc
+            c0 += nc
+        res.update(cluster_entries=n, clusters=int(n_clu), cluster_entries_mismatching=int(bad))
+    return res
+
+
+def parity_check(gpu, host, ps, k, max_seqs, bin_size, kmer_thr, check_path, last=None, db=None):
     """untimed post-check: the device's prefilter rows and alignments of the sample queries the cpu_baseline leg ran
-    through the reference (libsdref), compared field by field"""
+    through the reference (libsdref), compared field by field; then the back half (back_half_check)"""
     from spacedust_amd import api
     g = np.load(check_path)
     queries = g['queries']
@@ -161,8 +222,12 @@ def parity_check(gpu, host, ps, k, max_seqs, bin_size, kmer_thr, check_path):
                 bad_aln += got[0] != int(a[2]) or got[2] != int(a[4]) or got[4] != int(a[6])
             else:
                 bad_aln += got != [int(v) for v in a[2:9]]
-    return dict(queries=int(len(queries)), prefilter_rows=int(n_rows), prefilter_queries_mismatching=int(bad_rows),
-                alignments=int(len(alns)), alignments_mismatching=int(bad_aln), against='oracle/_ref/libsdref.so (the reference classes)')
+    res = dict(queries=int(len(queries)), prefilter_rows=int(n_rows), prefilter_queries_mismatching=int(bad_rows),
+               alignments=int(len(alns)), alignments_mismatching=int(bad_aln))
+    if last is not None:
+        res.update(back_half_check(g, last, db))
+    res['against'] = 'oracle/_ref/libsdref.so + libsdref_ch.so (the reference classes / functions), oracle/agg_restatement.py'
+    return res
 
 
 def measure(args, rank, local_rank, world, dist, torch):
@@ -353,7 +418,7 @@ def measure(args, rank, local_rank, world, dist, torch):
               'prefilter_select_hits': 12 * Cn + 10 * st['prefilter_hits']}
     pmc = {}
     pmc_src = None
-    for fn in ('r04d_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for fn in ('r05_pmc_traffic.json', 'r04d_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
             pmc_src = 'profiles/' + fn
@@ -389,7 +454,7 @@ def measure(args, rank, local_rank, world, dist, torch):
     valu = dict(instr_per_cell=11.1, peak_lane_instr_per_s=256 * 64 * 2.4e9,
                 source='ISA count of sw_score_pk RT=8 (178 per 16 cells); 256 CU x 64 lanes x 2.4 GHz')
     try:
-        fn = next(f for f in ('r04d_valu_calibration.json', 'r04_valu_calibration.json', 'r03_valu_calibration.json', 'r02_valu_calibration.json') if os.path.exists(os.path.join(ROOT, 'profiles', f)))
+        fn = next(f for f in ('r05_valu_calibration.json', 'r04d_valu_calibration.json', 'r04_valu_calibration.json', 'r03_valu_calibration.json', 'r02_valu_calibration.json') if os.path.exists(os.path.join(ROOT, 'profiles', f)))
         v = json.load(open(os.path.join(ROOT, 'profiles', fn)))
         valu = dict(instr_per_cell=v['instr_per_cell'], peak_lane_instr_per_s=v['peak_lane_instr_per_s'], source='profiles/' + fn)
     except (OSError, ValueError, KeyError, StopIteration):
@@ -421,7 +486,8 @@ def measure(args, rank, local_rank, world, dist, torch):
         'vs_baseline': None,
         'dtype': 'int16',
         'data': 'synthetic',
-        'config': {'workload': '%d synthetic proteomes x %d proteins (len~300) all-vs-all, clustersearch --search-mode 0 '
+        'config': {'workload_short': 'p%d: %d query proteomes per step vs %d targets, --max-seqs %d' % (P, B, P, max_seqs),
+                   'workload': '%d synthetic proteomes x %d proteins (len~300) all-vs-all, clustersearch --search-mode 0 '
                                '--filter-self-match --max-seqs %d; step = %d query proteomes %s vs all %d targets; timed: search + aggregation + '
                                'clusterhits (+ the result gather for N > 1), the TSV is written after the timed region, the CPU leg likewise '
                                'stops at the cluster records'
@@ -430,7 +496,9 @@ def measure(args, rank, local_rank, world, dist, torch):
                                   'final result gather: %s' % (world, index_how, gather_how)},
         'roofline': roofline,
         'roofline_sw': roofline_sw,
-        'sw_gcups': cells_sw / sw_ms / 1e6 if sw_ms > 0 else 0.0,
+        # forward cells of the aligned pairs over the score kernels' time (which also holds the reverse pass)
+        'sw_gcups': st['cells_fwd'] / sw_ms / 1e6 if sw_ms > 0 else 0.0,
+        'sw_gcups_fwd_plus_rev': cells_sw / sw_ms / 1e6 if sw_ms > 0 else 0.0,
         'sw_valu': sw_valu,
         'sw_cells': {'forward': st['cells_fwd'], 'reverse': st['cells_rev'], 'traceback': st['cells_tb']},
         'prefilter': {'queries': n_queries, 'kernel_ms': pf_ms, 'algorithmic_bytes': b_pref,
@@ -454,8 +522,6 @@ def measure(args, rank, local_rank, world, dist, torch):
         'device_memory': dict(resident_GB=(mem[1] - mem[0]) / 1e9, total_GB=mem[1] / 1e9, free_GB=mem[0] / 1e9, workspaces=ws_rep),
         'host_cores': os.cpu_count(),
         'host_cpu_quota': effective_cpus(),
-        'cpu_note': 'this box exposes %d logical CPUs but a cgroup quota of %d: cpu_baseline runs on (and is quoted against) %d threads'
-                    % (os.cpu_count(), effective_cpus(), effective_cpus()),
     }
     if gather_sizes is not None:
         res['gather'] = {'how': gather_how, 'bytes': int(gather_sizes.sum()), 'bytes_per_rank': [int(v) for v in gather_sizes],
@@ -469,8 +535,11 @@ def measure(args, rank, local_rank, world, dist, torch):
                                                              n_queries=8192 if P < 5000 else 2048)
         except Exception as e:   # (an extra, never the record)
             res['roofline']['isolated'] = dict(error=repr(e)[:200])
+    last_ranges = my_ranges(args.warmup + args.steps - 1)[0] if args.steps > 0 else []
     extras = dict(ps=ps, k=k, max_seqs=max_seqs, kmer_thr=kmer_thr, bin_size=int(cs.bin_size), gpu=gpu, host=host,
-                  last=outs[-1] if outs else None, db=db)
+                  last=outs[-1] if outs else None, db=db,
+                  # the first query set of the last measured range: its aggregated entries are checked against the reference
+                  last_first_set=int(ps.set_id[last_ranges[-1][0]]) if last_ranges else None)
     del cs
     return res, extras
 
@@ -546,13 +615,14 @@ def main():
         if last is not None and last['cluster_out'] is not None:
             hq, ht = last['hit_q'], last['hit_t']
             np.savez(ent, eo=last['entry_off'], qp=db.pos_in_set[hq], tp=db.pos_in_set[ht],
-                     sd=(db.strand[hq] | (db.strand[ht] << 1)).astype(np.uint8), nq=db.set_size[last['entry_q']])
+                     sd=(db.strand[hq] | (db.strand[ht] << 1)).astype(np.uint8), nq=db.set_size[last['entry_q']], pv=last['hit_pval'])
         res['cpu_baseline'] = cpu_baseline_subprocess(args.proteomes, args.genes, ex['max_seqs'], ex['kmer_thr'], ex['bin_size'], ent,
-                                                      args.cpu_seconds, args.cpu_threads or effective_cpus(), check=24, check_out=chk)
+                                                      args.cpu_seconds, args.cpu_threads or effective_cpus(), check=24, check_out=chk,
+                                                      check_sets=[ex['last_first_set']] if ex['last_first_set'] is not None else [], check_entries=32)
         try:
             if os.path.exists(chk):
                 res['parity_check'] = parity_check(ex['gpu'], ex['host'], ex['ps'], ex['k'], ex['max_seqs'], ex['bin_size'],
-                                                   ex['kmer_thr'], chk)
+                                                   ex['kmer_thr'], chk, last=last, db=db)
             else:
                 res['parity_check'] = dict(queries=0, note='the reference library did not travel or the CPU leg failed')
         except Exception as e:
@@ -561,84 +631,88 @@ def main():
             if os.path.exists(f):
                 os.remove(f)
     del ex
-    if args.record:   # child of the p1000 / p10000 leg
+    if args.record:   # child of a leg: the whole record, the parent keeps what it needs
         print(json.dumps(res))
         return
-    if world == 1 and not args.no_p1000 and args.proteomes != 1000 and _leg_allowed(res, 'p1000', t_start, args):
-        # BASELINE configs[2]'s size on this one GPU, in a child process (fresh device memory): a short run with its own
-        # reference CPU sample -- north_star quotes its >= 10x target at this size
-        cmd = [sys.executable, os.path.abspath(__file__), '--record', '--proteomes', '1000', '--steps', str(args.p1000_steps), '--warmup', '1',
-               '--batch', str(args.batch), '--chunk', str(args.chunk), '--no-p1000'] + (['--no-cpu'] if args.no_cpu else []) + \
-              ['--cpu-seconds', str(min(args.cpu_seconds, 12.0))]
+
+    def child(name, cmd, keep=None):
+        """a child record in its own process (fresh device memory); its full record goes to the side file, a brief into the line"""
         try:
             t0 = time.time()
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
             line = [l for l in p.stdout.splitlines() if l.startswith('{')]
             if p.returncode == 0 and line:
                 r = json.loads(line[-1])
-                res['p1000'] = {k: r.get(k) for k in ('value', 'unit', 'steps', 'ms_per_step', 'config', 'sw_gcups', 'cpu_baseline', 'parity_check',
-                                                      'results', 'setup_s', 'host_cpu_s_per_step', 'host_cpu_by_stage', 'device_memory', 'roofline', 'roofline_sw')}
-                res['p1000']['wall_s'] = time.time() - t0
-                cb = r.get('cpu_baseline') or {}
-                if cb.get('value'):
-                    res['p1000']['gpu_over_cpu'] = r['value'] / cb['value']
-            else:
-                res['p1000'] = dict(error=(p.stderr or p.stdout)[-300:])
+                r['leg_wall_s'] = time.time() - t0
+                return r
+            return dict(error=(p.stderr or p.stdout)[-300:])
         except Exception as e:
-            res['p1000'] = dict(error=repr(e)[:300])
-    if world == 1 and not args.no_p10000 and not args.no_p1000 and args.proteomes not in (1000, 10000) and _leg_allowed(res, 'p10000', t_start, args):
+            return dict(error=repr(e)[:300])
+
+    children = {}
+    kids = world == 1 and not args.no_children
+    if kids and not args.no_p100 and args.proteomes != 100 and _leg_allowed(children, 'p100', t_start, args):
+        # BASELINE configs[1]: 100 proteomes all-vs-all (one pass = 10 steps of 10 query proteomes), its own CPU sample and parity leg
+        children['p100'] = child('p100', [sys.executable, os.path.abspath(__file__), '--record', '--proteomes', '100', '--steps', str(args.p100_steps),
+                                          '--warmup', '1', '--batch', '10', '--chunk', str(args.chunk), '--no-children'] +
+                                 (['--no-cpu'] if args.no_cpu else []) + ['--cpu-seconds', str(min(args.cpu_seconds, 10.0))])
+    if kids and not args.no_p10000 and args.proteomes != 10000 and _leg_allowed(children, 'p10000', t_start, args):
         # BASELINE configs[4]: 10 000 proteomes (3 * 10^7 sequences, 9 * 10^9 residues, k = 7) resident on this one GPU -- generated,
-        # indexed on the device, checked on a sample against the host builder, and searched for a short step
-        cmd = [sys.executable, os.path.abspath(__file__), '--record', '--proteomes', '10000', '--steps', str(args.p10000_steps), '--warmup', '1',
-               '--batch', str(args.p10000_batch), '--chunk', str(args.p10000_chunk), '--no-p1000', '--no-p10000', '--no-cpu']   # --max-seqs 2N = 20 000
-        try:
-            t0 = time.time()
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
-            line = [l for l in p.stdout.splitlines() if l.startswith('{')]
-            if p.returncode == 0 and line:
-                r = json.loads(line[-1])
-                res['p10000'] = {k: r.get(k) for k in ('value', 'unit', 'steps', 'ms_per_step', 'config', 'sw_gcups', 'index_check', 'results',
-                                                       'setup_s', 'host_cpu_s_per_step', 'host_cpu_by_stage', 'device_memory', 'roofline', 'roofline_sw')}
-                res['p10000']['wall_s'] = time.time() - t0
-            else:
-                res['p10000'] = dict(error=(p.stderr or p.stdout)[-300:])
-        except Exception as e:
-            res['p10000'] = dict(error=repr(e)[:300])
-    if world == 1 and not args.no_iter3 and not args.no_p1000 and args.proteomes not in (1000, 10000) and _leg_allowed(res, 'iter3', t_start, args):
+        # indexed on the device, checked on a sample against the host builder, and searched for a short step; --max-seqs 2N = 20 000
+        children['p10000'] = child('p10000', [sys.executable, os.path.abspath(__file__), '--record', '--proteomes', '10000', '--steps', str(args.p10000_steps),
+                                              '--warmup', '1', '--batch', str(args.p10000_batch), '--chunk', str(args.p10000_chunk), '--no-children', '--no-cpu'])
+    if kids and not args.no_iter3 and _leg_allowed(children, 'iter3', t_start, args):
         # BASELINE configs[3]: `clustersearch --num-iterations 3` (sequence search, two profile searches) against 1 000 target
         # proteomes through the sdgpu binary and the reference's DB files, with its own sampled parity check against the
         # reference classes (tools/iter3_scale.py) -- a child process
-        cmd = [sys.executable, os.path.join(ROOT, 'tools', 'iter3_scale.py'), '1000', str(args.iter3_queries), '32']
-        try:
-            t0 = time.time()
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
-            line = [l for l in p.stdout.splitlines() if l.startswith('{')]
-            if p.returncode == 0 and line:
-                res['iter3'] = json.loads(line[-1])
-                res['iter3']['leg_wall_s'] = time.time() - t0
-            else:
-                res['iter3'] = dict(error=(p.stderr or p.stdout)[-300:])
-        except Exception as e:
-            res['iter3'] = dict(error=repr(e)[:300])
-    # the claims north_star makes, compact and LAST on the line (a log tail shows them): throughput at 100 / 1 000 / 10 000
-    # proteomes, the reference on this box's cores beside it, parity of the sampled rows
+        children['iter3'] = child('iter3', [sys.executable, os.path.join(ROOT, 'tools', 'iter3_scale.py'), '1000', str(args.iter3_queries), '32'])
+
+    # ---- the printed line is compact (the driver parses it); everything bulky goes to the side file
     def _brief(r):
         if not isinstance(r, dict) or 'value' not in r:
             return r if isinstance(r, dict) and ('skipped' in r or 'error' in r) else None
-        cb, pc = r.get('cpu_baseline') or {}, r.get('parity_check') or {}
-        b = dict(value=round(r['value'], 1), unit=r.get('unit'), cpu_value=cb.get('value'), cpu_cores=cb.get('cores'), cpu_kind=cb.get('kind'),
-                 gpu_over_cpu=round(r['value'] / cb['value'], 1) if cb.get('value') else None,
-                 parity=dict(prefilter_rows=pc.get('prefilter_rows'), prefilter_queries_mismatching=pc.get('prefilter_queries_mismatching'),
-                             alignments=pc.get('alignments'), alignments_mismatching=pc.get('alignments_mismatching')) if pc else None,
+        cb, pc, rf = r.get('cpu_baseline') or {}, r.get('parity_check') or {}, r.get('roofline') or {}
+        b = dict(value=round(r['value'], 1), unit=r.get('unit'), ms_per_step=round(r.get('ms_per_step') or 0.0, 1), steps=r.get('steps'),
+                 workload=(r.get('config') or {}).get('workload_short'), cpu_value=round(cb['value'], 2) if cb.get('value') else None,
+                 cpu_cores=cb.get('cores'), cpu_kind=cb.get('kind'), gpu_over_cpu=round(r['value'] / cb['value'], 1) if cb.get('value') else None,
+                 parity={k_: v_ for k_, v_ in pc.items() if k_ not in ('against', 'query_sets', 'reference_seconds')} if pc else None,
                  queries_not_computed=(r.get('results') or {}).get('queries_not_computed'),
-                 roofline_frac=(r.get('roofline') or {}).get('frac'), sw_gcups=round(r.get('sw_gcups') or 0.0))
+                 roofline_frac=round(rf.get('frac') or 0.0, 4), roofline_kernel=rf.get('kernel'), stage_frac=round(rf.get('stage_frac') or 0.0, 4),
+                 sw_gcups=round(r.get('sw_gcups') or 0.0), leg_wall_s=round(r.get('leg_wall_s') or 0.0, 1))
         if r.get('device_memory'):
             b['resident_GB'] = round(r['device_memory']['resident_GB'], 1)
         return b
-    res['summary'] = dict(p100=_brief(res), p1000=_brief(res.get('p1000')), p10000_max_seqs_20000=_brief(res.get('p10000')),
-                          iter3=({k: res['iter3'].get(k) for k in ('genome_pairs_per_s', 'wall_s', 'parity_check', 'skipped', 'error') if k in res['iter3']}
-                                 if isinstance(res.get('iter3'), dict) else None))
-    print(json.dumps(res))
+
+    detail = dict(main=res, **children)
+    detail_path = args.detail_out or os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')
+    try:
+        os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+        with open(detail_path, 'w') as f:
+            json.dump(detail, f)
+    except OSError as e:
+        detail_path = 'not written: %r' % (e,)
+    rf = dict(res['roofline'])
+    iso = rf.get('isolated') or {}
+    rf.pop('per_kernel', None)
+    rf['isolated'] = {k_: iso.get(k_) for k_ in ('queries', 'kernel_ms', 'stage_achieved', 'stage_frac', 'error') if k_ in iso}
+    line = {k_: res[k_] for k_ in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                                   'dtype', 'data', 'config')}
+    line['roofline'] = rf
+    line['roofline_sw'] = res['roofline_sw']
+    for k_ in ('sw_gcups', 'sw_gcups_fwd_plus_rev', 'sw_cells', 'prefilter', 'stage_wall_s', 'host_cpu_s_per_step', 'host_cpu_by_stage', 'results',
+               'setup_s', 'device', 'host_cores', 'host_cpu_quota', 'gather', 'multi_gpu_note', 'index_check', 'cpu_baseline', 'parity_check'):
+        if k_ in res:
+            line[k_] = res[k_]
+    line['device_memory'] = {k_: round(v_, 1) for k_, v_ in res['device_memory'].items() if k_ != 'workspaces'}
+    line['detail'] = detail_path if not os.path.isabs(detail_path) else os.path.relpath(detail_path, ROOT)
+    if world == 1:
+        for name in ('p100', 'p10000', 'iter3'):
+            c_ = children.get(name)
+            if name == 'iter3' and isinstance(c_, dict) and 'genome_pairs_per_s' in c_:
+                line[name] = {k_: c_.get(k_) for k_ in ('genome_pairs_per_s', 'wall_s', 'query_proteomes', 'target_proteomes', 'parity_check', 'leg_wall_s') if k_ in c_}
+            else:
+                line[name] = _brief(c_)
+    print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -403,7 +403,8 @@ unsigned long ref_l2_cache_size() { return Util::getL2CacheSize(); }
 // cpu_baseline driver: the reference's per-query loop bodies (Prefiltering::runSplit :817-886 and
 // Alignment::run :312-514) over a sample of queries with OpenMP threads, each thread owning its
 // QueryMatcher / SmithWaterman exactly as the reference's threads do.  Stops at the deadline.
-// out[0] = queries done, out[1] = pairs aligned, out[2] = forward DP cells, out[3] = seconds
+// out[0] = queries done, out[1] = pairs aligned, out[2] = forward DP cells, out[3] = seconds,
+// out[4] = thread-seconds spent inside the Smith-Waterman calls alone (sum over the threads)
 // ------------------------------------------------------------------------------------------------
 #include <chrono>
 extern "C" int ref_run_queries(void *vi, const char *seqs, const size_t *offsets, const unsigned int *sample,
@@ -420,9 +421,10 @@ extern "C" int ref_run_queries(void *vi, const char *seqs, const size_t *offsets
         sw[t] = (RefSW *) ref_sw_create(c, maxLen, dbResidues, 1);
     }
     size_t done = 0, pairs = 0, cells = 0;
+    double swSeconds = 0.0;
     const auto t0 = std::chrono::steady_clock::now();
     bool stop = false;
-#pragma omp parallel num_threads(threads) reduction(+ : done, pairs, cells)
+#pragma omp parallel num_threads(threads) reduction(+ : done, pairs, cells, swSeconds)
     {
         const int t = omp_get_thread_num();
         std::vector<unsigned int> ids(maxHits + 2);
@@ -440,6 +442,7 @@ extern "C" int ref_run_queries(void *vi, const char *seqs, const size_t *offsets
             const char *qs = seqs + offsets[q];
             const unsigned int qL = (unsigned int) (offsets[q + 1] - offsets[q]);
             size_t n = ref_prefilter_query(pf[t], qs, qL, q, ids.data(), sc.data(), dg.data(), NULL);
+            const auto s0 = std::chrono::steady_clock::now();
             ref_sw_set_query(sw[t], qs, qL);
             for (size_t h = 0; h < n; h++) {
                 const unsigned int tid = ids[h];
@@ -449,6 +452,7 @@ extern "C" int ref_run_queries(void *vi, const char *seqs, const size_t *offsets
                 pairs++;
                 cells += (size_t) qL * tL;
             }
+            swSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
             done++;
         }
     }
@@ -456,9 +460,74 @@ extern "C" int ref_run_queries(void *vi, const char *seqs, const size_t *offsets
     out[0] = (double) done;
     out[1] = (double) pairs;
     out[2] = (double) cells;
+    out[4] = swSeconds;
     for (int t = 0; t < threads; t++) {
         ref_prefilter_destroy(pf[t]);
         ref_sw_destroy(sw[t]);
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole query sets through the reference's two loop bodies, every alignment kept: the input of an
+// independent restatement of the aggregation modules (oracle/agg_restatement.py), so that the
+// (query set, target set) entries of a measured run can be compared with something reference-derived
+// at the run's own size.  Per aligned pair one row of 8 doubles:
+//   query, target, score, E-value, bit score, qStart, qEnd, backtrace length (0: stopped at a gate)
+// Returns the number of rows (rows beyond cap are counted, not written).
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t ref_run_query_set(void *vi, const char *seqs, const size_t *offsets, const unsigned int *queries,
+                                    size_t nQueries, int kmerThr, size_t maxHits, int threads, size_t dbResidues,
+                                    double *rows, size_t cap) {
+    RefIndex *ix = (RefIndex *) vi;
+    RefCtx *c = ix->ctx;
+    ensureExt(c);
+    size_t maxLen = ix->maxLen + 2;
+    std::vector<RefPref *> pf(threads);
+    std::vector<RefSW *> sw(threads);
+    for (int t = 0; t < threads; t++) {
+        pf[t] = (RefPref *) ref_prefilter_create(ix, kmerThr, maxLen, maxHits, 15, 1);
+        sw[t] = (RefSW *) ref_sw_create(c, maxLen, dbResidues, 1);
+    }
+    size_t nRows = 0;
+#pragma omp parallel num_threads(threads)
+    {
+        const int t = omp_get_thread_num();
+        std::vector<unsigned int> ids(maxHits + 2);
+        std::vector<int> sc(maxHits + 2);
+        std::vector<unsigned short> dg(maxHits + 2);
+        std::vector<double> mine;
+        int res[8];
+#pragma omp for schedule(dynamic, 1)
+        for (size_t s = 0; s < nQueries; s++) {
+            const unsigned int q = queries[s];
+            const char *qs = seqs + offsets[q];
+            const unsigned int qL = (unsigned int) (offsets[q + 1] - offsets[q]);
+            size_t n = ref_prefilter_query(pf[t], qs, qL, q, ids.data(), sc.data(), dg.data(), NULL);
+            ref_sw_set_query(sw[t], qs, qL);
+            mine.clear();
+            for (size_t h = 0; h < n; h++) {
+                const unsigned int tid = ids[h];
+                const unsigned int tL = (unsigned int) (offsets[tid + 1] - offsets[tid]);
+                if (Util::canBeCovered(0.8f, Parameters::COV_MODE_QUERY, (float) qL, (float) tL) == false) continue;
+                const double ev = ref_sw_align(sw[t], seqs + offsets[tid], tL, 2, 10.0, Parameters::COV_MODE_QUERY, 0.8f, res, NULL, 0, tid == q);
+                const double row[8] = {(double) q, (double) tid, (double) res[0], ev, ref_bitscore(sw[t], (double) res[0]),
+                                       (double) res[1], (double) res[2], (double) res[6]};
+                mine.insert(mine.end(), row, row + 8);
+            }
+            size_t at;
+#pragma omp critical
+            {
+                at = nRows;
+                nRows += mine.size() / 8;
+            }
+            for (size_t r = 0; r < mine.size() / 8; r++)
+                if (at + r < cap) memcpy(rows + (at + r) * 8, mine.data() + r * 8, 8 * sizeof(double));
+        }
+    }
+    for (int t = 0; t < threads; t++) {
+        ref_prefilter_destroy(pf[t]);
+        ref_sw_destroy(sw[t]);
+    }
+    return nRows;
 }

@@ -67,6 +67,11 @@ def build_tools(force=False, verbose=False):
     lout = os.path.join(ROOT, 'tools', 'launch_latency')
     if os.path.exists(lsrc) and (force or _newer(lsrc, lout)):
         subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O2', '-w', '-o', lout, lsrc])
+    # tools/fetch_calib: known byte counts per access pattern for the FETCH_SIZE / WRITE_SIZE calibration (tools/fetch_calib.sh)
+    csrc_ = os.path.join(ROOT, 'tools', 'csrc', 'fetch_calib.hip')
+    cout = os.path.join(ROOT, 'tools', 'fetch_calib')
+    if os.path.exists(csrc_) and (force or _newer(csrc_, cout)):
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O2', '-w', '-o', cout, csrc_])
     src = os.path.join(ROOT, 'tools', 'csrc', 'valu_peak.hip')
     out = os.path.join(ROOT, 'tools', 'libvalupeak.so')
     if not os.path.exists(src) or (not force and not _newer(src, out)):

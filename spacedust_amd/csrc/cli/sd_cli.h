@@ -89,6 +89,7 @@ int loadTargetIndex(const std::string &targetDb, int wantK, int wantKmerThr, int
 struct Resident {
     bool enabled = false;
     std::map<std::string, std::shared_ptr<SeqDb> > seqDbs;          // DB path -> loaded sequences
+    std::map<std::string, std::pair<long long, long long> > seqDbSig; // DB path -> (size, mtime in ns) of its .index when it was loaded
     std::map<int, sd_ctx *> ctxOfDevice;
     struct TargetEntry {
         sd_target *t = nullptr;

@@ -102,18 +102,38 @@ void Resident::clear() {
         if (kv.second) sd_ctx_destroy(kv.second);
     ctxOfDevice.clear();
     seqDbs.clear();
+    seqDbSig.clear();
     enabled = false;
 }
 
 std::shared_ptr<SeqDb> loadTargetDb(const std::string &path, sd_host *host, std::string *err) {
     Resident &R = resident();
+    // a cached DB is only taken while its index file is the one that was read (size and mtime, as loadSetInfo does): a module of the
+    // workflow may rewrite a DB under the same path
+    struct stat st;
+    const bool haveStat = ::stat((path + ".index").c_str(), &st) == 0;
     if (R.enabled) {
         auto it = R.seqDbs.find(path);
-        if (it != R.seqDbs.end()) return it->second;
+        if (it != R.seqDbs.end()) {
+            const std::pair<long long, long long> &sig = R.seqDbSig[path];
+            if (haveStat && sig.first == (long long) st.st_size && sig.second == (long long) st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec)
+                return it->second;
+            R.seqDbs.erase(it);
+            for (auto ss = R.seqSets.begin(); ss != R.seqSets.end();)   // the device copy of the stale DB goes with it
+                if (ss->first.compare(0, path.size() + 1, path + "|") == 0) {
+                    if (ss->second) sd_seqset_destroy(ss->second);
+                    ss = R.seqSets.erase(ss);
+                } else {
+                    ++ss;
+                }
+        }
     }
     std::shared_ptr<SeqDb> db(new SeqDb());
     if (!db->load(path, host, err)) return std::shared_ptr<SeqDb>();
-    if (R.enabled && !db->profile) R.seqDbs[path] = db;
+    if (R.enabled && !db->profile && haveStat) {
+        R.seqDbs[path] = db;
+        R.seqDbSig[path] = std::make_pair((long long) st.st_size, (long long) st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec);
+    }
     return db;
 }
 

@@ -207,6 +207,21 @@ int prefilterModule(const Args &a) {
         if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_target_create");
     }
     if (resident().enabled && target.own) {   // stays for the next module of the workflow
+        // one resident index per (DB, device): an index of the same DB with other parameters -- the sequence-threshold index of
+        // iteration 0 once the profile iterations (threshold 0, a larger index) begin -- would only hold HBM until the workflow ends
+        char dsuf[24];
+        snprintf(dsuf, sizeof(dsuf), "|%d", deviceOf(a));
+        const std::string pfx = a.pos[1] + "|", suf = dsuf;
+        for (auto it = resident().targets.begin(); it != resident().targets.end();) {
+            const std::string &key = it->first;
+            if (key.compare(0, pfx.size(), pfx) == 0 && key.size() >= suf.size() && key.compare(key.size() - suf.size(), suf.size(), suf) == 0) {
+                info(a, "Resident target index %s replaced\n", key.c_str());
+                sd_target_destroy(it->second.t);
+                it = resident().targets.erase(it);
+            } else {
+                ++it;
+            }
+        }
         Resident::TargetEntry te;
         te.t = target.t;
         te.nEntries = nEntries;

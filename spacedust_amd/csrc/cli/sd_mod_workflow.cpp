@@ -878,13 +878,17 @@ int iterativeSearch(const Args &a, const std::string &Q, const std::string &T, c
                                                  a.str("--min-seq-id", "0"), "--comp-bias-corr", a.str("--comp-bias-corr", "1"),
                                                  "--realign-score-bias", a.str("--realign-score-bias", "-0.2")});
     if (a.has("--device")) aln = with(aln, {"--device", a.str("--device", "0")});
-    const std::vector<std::string> prof = with(common, {"-e", eProfile, "--e-profile", eProfile, "--mask-profile", a.str("--mask-profile", "1"),
+    std::vector<std::string> prof = with(common, {"-e", eProfile, "--e-profile", eProfile, "--mask-profile", a.str("--mask-profile", "1"),
                                                         "--comp-bias-corr", a.str("--comp-bias-corr", "1"), "--filter-msa", a.str("--filter-msa", "1"),
                                                         "--filter-min-enable", a.str("--filter-min-enable", "0"), "--max-seq-id",
                                                         a.str("--max-seq-id", "0.9"), "--qid", a.str("--qid", "0.0"), "--qsc", a.str("--qsc", "-20"),
                                                         "--cov", a.str("--cov", "0"), "--diff", a.str("--diff", "1000"), "--pca",
                                                         a.str("--pca", "substitution:1.100,context:1.400"), "--pcb",
                                                         a.str("--pcb", "substitution:4.100,context:5.800")});
+    // result2profile's sequence weights run on the GPU and the module fails without one unless the user asked for the host form:
+    // the workflow hands both choices on (device and --profile-weights-host) instead of deciding for the module
+    if (a.has("--profile-weights-host")) prof = with(prof, {"--profile-weights-host", a.str("--profile-weights-host", "0")});
+    if (a.has("--device")) prof = with(prof, {"--device", a.str("--device", "0")});
     const bool keep = a.integer("--keep-tmp", 0) != 0;   // keep the per-iteration DBs (parity checks at size read them)
     // the modules below run in this process: the target DB, its index on the device and its sequence set stay resident between them
     // (sd_cli.h: Resident) instead of being reloaded / rebuilt by every module

@@ -76,25 +76,39 @@ inline hipError_t poolGet(sd_ctx *ctx, size_t bytes, void **out, size_t *got) {
     return e;
 }
 
-// hands a buffer back; the pool keeps at most 24 (the smallest goes when it is full)
+// hands a buffer back.  The pool keeps at most 24 buffers and at most POOL_BYTES_MAX bytes: beyond either the OLDEST goes (the
+// pool is in hand-back order) -- the buffers a pipeline lane recycles per chunk are handed back and taken again all the time and
+// so stay young, while the target-sized buffers of a destroyed set that nothing asks for again age out instead of holding HBM
+// until the context is destroyed.  A single buffer larger than the budget is freed at once.
+constexpr size_t POOL_BYTES_MAX = (size_t) 2 << 30;
+inline size_t poolBytes(sd_ctx *ctx) {
+    std::lock_guard<std::mutex> lock(ctx->poolMutex);
+    size_t sum = 0;
+    for (const sd_ctx::PoolBuf &b : ctx->pool) sum += b.bytes;
+    return sum;
+}
 inline void poolPut(sd_ctx *ctx, void *p, size_t bytes) {
     if (!p) return;
-    void *drop = nullptr;
+    std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> lock(ctx->poolMutex);
-        sd_ctx::PoolBuf b;
-        b.p = p;
-        b.bytes = bytes;
-        ctx->pool.push_back(b);
-        if (ctx->pool.size() > 24) {
-            size_t smallest = 0;
-            for (size_t i = 1; i < ctx->pool.size(); i++)
-                if (ctx->pool[i].bytes < ctx->pool[smallest].bytes) smallest = i;
-            drop = ctx->pool[smallest].p;
-            ctx->pool.erase(ctx->pool.begin() + (long) smallest);
+        if (bytes > POOL_BYTES_MAX) {
+            drop.push_back(p);
+        } else {
+            sd_ctx::PoolBuf b;
+            b.p = p;
+            b.bytes = bytes;
+            ctx->pool.push_back(b);
+            size_t sum = 0;
+            for (const sd_ctx::PoolBuf &x : ctx->pool) sum += x.bytes;
+            while (ctx->pool.size() > 24 || sum > POOL_BYTES_MAX) {
+                drop.push_back(ctx->pool.front().p);
+                sum -= ctx->pool.front().bytes;
+                ctx->pool.erase(ctx->pool.begin());
+            }
         }
     }
-    if (drop) (void) hipFree(drop);
+    for (void *d : drop) (void) hipFree(d);
 }
 
 inline hipEvent_t sdProfEvent(sd_ctx *ctx) {
@@ -307,11 +321,15 @@ struct sd_target {
 int sdFail(sd_ctx *ctx, int code, const char *fmt, ...);
 int sdBuildExt3Cum(sd_ctx *ctx, sd_target *t);   // sd_prefilter.hip; after dExt3Score is resident
 
+// (a failed call returns from here with reads of sdD2H possibly still queued: their destinations -- stack variables, local
+// vectors of the returning function -- die with this return, so the queue is dropped before any later wait could deliver them)
 #define SD_HIP(ctx, call)                                                                          \
     do {                                                                                           \
         hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
+        if (e_ != hipSuccess) {                                                                    \
+            if ((ctx) != nullptr) sdD2HReset(ctx);                                                 \
             return sdFail((ctx), SD_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                          \
     } while (0)
 
 // RAII device buffer

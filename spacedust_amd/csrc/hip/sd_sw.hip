@@ -1728,6 +1728,11 @@ int sd_workspace_report(sd_ctx *ctx, uint64_t *deviceBytes, uint64_t *pinnedByte
         rows.push_back(std::make_pair(kv.second.bytes, kv.first));
     }
     for (auto &kv : ctx->pinned) pin += kv.second.bytes;
+    const size_t pooled = poolBytes(ctx);   // device buffers of destroyed sequence sets kept for the next one (poolPut)
+    if (pooled) {
+        dev += pooled;
+        rows.push_back(std::make_pair(pooled, std::string("pool(seqset buffers)")));
+    }
     if (deviceBytes) *deviceBytes = dev;
     if (pinnedBytes) *pinnedBytes = pin;
     if (buf && cap) {
@@ -1852,12 +1857,20 @@ int sd_seqset_create(sd_ctx *ctx, const uint8_t *residues, const uint64_t *offse
         sd_seqset_destroy(s);
         return sdFail(ctx, SD_ENOMEM, "sd_seqset_create: device allocation of %llu bytes failed", (unsigned long long) s->total);
     }
-    // on the context's stream (the set is used there), one wait for the three copies
-    SD_HIP(ctx, hipMemcpyAsync(s->dRes, s->hRes.data(), s->total, hipMemcpyHostToDevice, ctx->stream));
-    if (swCompBias) SD_HIP(ctx, hipMemcpyAsync(s->dBias, s->hBias.data(), s->total, hipMemcpyHostToDevice, ctx->stream));
-    else SD_HIP(ctx, hipMemsetAsync(s->dBias, 0, s->total, ctx->stream));
-    SD_HIP(ctx, hipMemcpyAsync(s->dOff, s->hOff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(ctx, sdStreamSync(ctx));
+    // on the context's stream (the set is used there), one wait for the three copies; a failed upload hands the half-built set
+    // back (host copies freed, device buffers to the pool) instead of leaking it
+    hipError_t e = hipMemcpyAsync(s->dRes, s->hRes.data(), s->total, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = swCompBias ? hipMemcpyAsync(s->dBias, s->hBias.data(), s->total, hipMemcpyHostToDevice, ctx->stream)
+                       : hipMemsetAsync(s->dBias, 0, s->total, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->dOff, s->hOff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = sdStreamSync(ctx);
+    if (e != hipSuccess) {
+        (void) sdStreamSyncRaw(ctx);   // nothing may still read the host copies
+        sd_seqset_destroy(s);
+        *out = nullptr;
+        return sdFail(ctx, SD_EHIP, "sd_seqset_create: upload failed: %s", hipGetErrorString(e));
+    }
     *out = s;
     return SD_OK;
 }
@@ -1879,8 +1892,16 @@ int sd_profileset_create(sd_ctx *ctx, const uint8_t *queryLetters, const uint64_
         return sdFail(ctx, SD_ENOMEM, "sd_profileset_create: device allocation of %llu bytes failed", (unsigned long long) bytes);
     }
     s->hProf.assign(alnProfile, alnProfile + bytes);
-    SD_HIP(ctx, hipMemcpyAsync(s->dProf, s->hProf.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(ctx, sdStreamSync(ctx));
+    {
+        hipError_t e = hipMemcpyAsync(s->dProf, s->hProf.data(), bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = sdStreamSync(ctx);
+        if (e != hipSuccess) {
+            (void) sdStreamSyncRaw(ctx);
+            sd_seqset_destroy(s);
+            *out = nullptr;
+            return sdFail(ctx, SD_EHIP, "sd_profileset_create: upload failed: %s", hipGetErrorString(e));
+        }
+    }
     s->hProfBias.assign(n, 0);
     for (uint32_t i = 0; i < n; i++) {
         int m = 0;   // min over the 20 amino-acid columns (matSize = L * PROFILE_AA_SIZE, :1277-1279)

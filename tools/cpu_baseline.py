@@ -1,8 +1,16 @@
 #!/usr/bin/env python3
 """cpu_baseline leg of bench.py (child process): a bounded sample of the same workload on the host cores.
 Prefilter + Smith-Waterman per query protein by the reference's own AVX2 code (oracle/_ref/libsdref.so,
-kind "reference") when that library travelled, else by the oracle port; clusterhits entries by the oracle's
-restatement (the reference's clusterhits() is not linkable).  Prints one JSON object."""
+kind "reference") when that library travelled, else by the oracle port; clusterhits entries by the reference's own
+functions (oracle/_ref/libsdref_ch.so) or, without them, the oracle's restatement.  Prints one JSON object.
+
+Beside the timing it leaves what bench.py's parity leg compares the measured run with (--check-out, an .npz):
+  queries / rows / alns   the reference's prefilter rows and alignments of --check sample queries
+  agg_*                   the (query set, target set) entries of the whole query sets --check-sets, from the reference's rows
+                          and alignments of EVERY query of those sets (ref_run_query_set) pushed through the independent
+                          restatement of besthitbyset / combinehits (oracle/agg_restatement.py)
+  ch_*                    the reference's clusterhits functions on the first --check-entries measured entries handed over in
+                          --entries: partition, member ranks, sizes and the bit patterns of both P-values"""
 import argparse
 import json
 import os
@@ -28,6 +36,8 @@ def main():
     ap.add_argument('--entries', default='')
     ap.add_argument('--check', type=int, default=0, help='also return the reference rows / alignments of this many sample queries')
     ap.add_argument('--check-out', default='')
+    ap.add_argument('--check-sets', default='', help='comma-separated query sets (proteomes) whose aggregated entries the reference side computes')
+    ap.add_argument('--check-entries', type=int, default=32, help='measured entries of --entries the reference clusterhits functions are run on')
     a = ap.parse_args()
     os.environ['OMP_NUM_THREADS'] = str(a.threads)
     from oracle import pyoracle
@@ -56,12 +66,13 @@ def main():
         L = ref.lib
         L.ref_run_queries.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t,
                                       C.c_int, C.c_double, C.c_size_t, C.c_void_p]
-        out = np.zeros(4, np.float64)
+        out = np.zeros(8, np.float64)
         smp = np.ascontiguousarray(sample, np.uint32)
         offs = np.ascontiguousarray(ps.offsets, np.uint64)
         L.ref_run_queries(rix.h, blob, offs.ctypes.data, smp.ctypes.data, len(smp), a.kmer_thr, a.max_seqs, n_threads,
                           a.seconds, db_res, out.ctypes.data)
         nq, npairs, ncells, dt = int(out[0]), int(out[1]), float(out[2]), float(out[3])
+        sw_thread_s = float(out[4])
     else:
         done, pairs, cells = [0] * n_threads, [0] * n_threads, [0] * n_threads
         ready = threading.Barrier(n_threads + 1)
@@ -96,22 +107,36 @@ def main():
             t.join()
         dt = time.time() - t0
         nq, npairs, ncells = sum(done), sum(pairs), float(sum(cells))
+        sw_thread_s = 0.0
     q_per_s = nq / dt if dt > 0 else 0.0
     queries_per_pair = ps.n / float(P * P)   # all-vs-all: P*genes queries serve P*P genome pairs
     ch_per_entry, ch_n = 0.0, 0
+    ch_out = {}
     if a.entries and os.path.exists(a.entries):
         g = np.load(a.entries)
         orc2 = pyoracle.Oracle(1)
         refch = pyoracle.RefClusterHits() if pyoracle.ref_ch_available() else None
+        n_ent = min(len(g['eo']) - 1, max(a.check_entries, 0))
+        pv_all = g['pv'] if 'pv' in g.files else None
+        lg = refch.lgamma_table(int(max(g['qp'].max(initial=0), g['tp'].max(initial=0), g['nq'].max(initial=0))) + 4096) if refch is not None and n_ent else None
+        cof_l, rk_l, sz_l, pco_l, pmh_l, ncl = [], [], [], [], [], []
         t1 = time.time()
-        for e in range(min(len(g['eo']) - 1, 6)):
+        for e in range(n_ent):
             x0, x1 = int(g['eo'][e]), int(g['eo'][e + 1])
+            pv = pv_all[x0:x1] if pv_all is not None else np.full(x1 - x0, 1e-30)
             if refch is not None:   # the reference's own clusterhits functions (oracle/_ref/libsdref_ch.so)
-                refch.entry(g['qp'][x0:x1], g['tp'][x0:x1], g['sd'][x0:x1], np.full(x1 - x0, 1e-30), int(g['nq'][e]))
+                if x1 - x0 + 8 > len(lg):
+                    lg = refch.lgamma_table(x1 - x0 + 4096)
+                cof, rk, cs_, pco, pmh = refch.entry(g['qp'][x0:x1], g['tp'][x0:x1], g['sd'][x0:x1], pv, int(g['nq'][e]), lg=lg)
+                cof_l.append(cof.copy()); rk_l.append(rk.copy()); sz_l.append(cs_.copy()); pco_l.append(pco.copy()); pmh_l.append(pmh.copy())
+                ncl.append(len(cs_))
             else:
-                pyoracle.oracle_clusterhits(orc2, g['qp'][x0:x1], g['tp'][x0:x1], g['sd'][x0:x1], np.full(x1 - x0, 1e-30), int(g['nq'][e]))
+                pyoracle.oracle_clusterhits(orc2, g['qp'][x0:x1], g['tp'][x0:x1], g['sd'][x0:x1], pv, int(g['nq'][e]))
             ch_n += 1
         ch_per_entry = (time.time() - t1) / max(ch_n, 1)
+        if refch is not None and ch_n:
+            ch_out = dict(ch_entries=np.int64(ch_n), ch_ncl=np.array(ncl, np.int64), ch_cof=np.concatenate(cof_l), ch_rank=np.concatenate(rk_l),
+                          ch_size=np.concatenate(sz_l) if sz_l else np.zeros(0, np.uint32), ch_pco=np.concatenate(pco_l), ch_pmh=np.concatenate(pmh_l))
     sec_per_pair = (queries_per_pair / q_per_s if q_per_s > 0 else float('inf')) + ch_per_entry / n_threads
     # parity sample for bench.py's post-check: the reference's prefilter rows and alignments of a few sample queries
     if a.check > 0 and a.check_out and kind == 'reference':
@@ -131,15 +156,48 @@ def main():
                 t = int(t)
                 r = sw.align(blob[int(ps.offsets[t]):int(ps.offsets[t + 1])], identity=(t == qi))
                 alns.append([qi, t, r['score'], r['qStart'], r['qEnd'], r['tStart'], r['tEnd'], r['btLen'], r['identical'] if r['btLen'] > 0 else 0])
+        agg_out = {}
+        if a.check_sets:
+            # whole query sets through the reference, then the independent restatement of the aggregation modules
+            from oracle import agg_restatement
+            import ctypes as C
+            sets = [int(x) for x in a.check_sets.split(',') if x != '']
+            qsel = np.concatenate([np.arange(int(ps.set_start[s_]), int(ps.set_start[s_ + 1])) for s_ in sets]).astype(np.uint32)
+            cap = len(qsel) * (a.max_seqs + 1)
+            rws = np.zeros((cap, 8), np.float64)
+            L = ref.lib
+            L.ref_run_query_set.restype = C.c_size_t
+            L.ref_run_query_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_size_t,
+                                            C.c_void_p, C.c_size_t]
+            offs = np.ascontiguousarray(ps.offsets, np.uint64)
+            t2 = time.time()
+            n_rows = L.ref_run_query_set(rix.h, blob, offs.ctypes.data, qsel.ctypes.data, len(qsel), a.kmer_thr, a.max_seqs, n_threads, db_res,
+                                         rws.ctypes.data, cap)
+            ent = agg_restatement.aggregate(rws[:min(n_rows, cap)], lens, ps.set_id)
+            keys = sorted(ent)
+            agg_out = dict(agg_sets=np.array(sets, np.int64), agg_keys=np.array(keys, np.int64).reshape(-1, 2),
+                           agg_off=np.cumsum([0] + [len(ent[k_]) for k_ in keys]).astype(np.int64),
+                           agg_q=np.array([r[0] for k_ in keys for r in ent[k_]], np.int64),
+                           agg_t=np.array([r[1] for k_ in keys for r in ent[k_]], np.int64),
+                           agg_p=np.array([r[2] for k_ in keys for r in ent[k_]], np.float64),
+                           agg_seconds=np.float64(time.time() - t2), agg_alignments=np.int64(n_rows))
         np.savez(a.check_out, queries=np.array(qs, np.int64), row_off=np.cumsum([0] + [len(r) for r in rows]),
-                 rows=np.concatenate(rows) if rows else np.zeros((0, 3), np.int64), alns=np.array(alns, np.int64).reshape(-1, 9))
+                 rows=np.concatenate(rows) if rows else np.zeros((0, 3), np.int64), alns=np.array(alns, np.int64).reshape(-1, 9),
+                 **agg_out, **ch_out)
+    ch_kind = 'reference' if (a.entries and pyoracle.ref_ch_available()) else 'port'
+    sw_wall = sw_thread_s / n_threads if sw_thread_s > 0 else dt   # the Smith-Waterman part of the wall time (thread-seconds / threads)
     print(json.dumps(dict(
         value=1.0 / sec_per_pair if sec_per_pair > 0 else 0.0, unit='genome-pairs/s', cores=n_threads, kind=kind,
-        sample='%d query proteins: prefilter + SW against the full %d-proteome target with %d threads in %.1f s, plus %d '
-               'clusterhits entries (oracle restatement, 1 core each); reference index build %.1f s not included'
-               % (nq, P, n_threads, dt, ch_n, t_index),
-        queries_per_s=q_per_s, sw_gcups=ncells / dt / 1e9 if dt > 0 else 0.0, sw_pairs=npairs,
-        clusterhits_s_per_entry_core=ch_per_entry, clusterhits_kind='reference' if (a.entries and pyoracle.ref_ch_available()) else 'port')))
+        sample='%d query proteins: prefilter + SW (%s) against the full %d-proteome target on %d threads = %d of the box\'s %d logical CPUs '
+               '(cgroup quota) in %.1f s, plus %d clusterhits entries (%s, 1 core each); the text glue modules between them are not '
+               'run on the CPU side; reference index build %.1f s not included'
+               % (nq, 'the reference classes' if kind == 'reference' else 'oracle port', P, n_threads, n_threads, os.cpu_count() or 0, dt, ch_n,
+                  'the reference functions' if ch_kind == 'reference' else 'oracle restatement', t_index),
+        queries_per_s=q_per_s, sw_gcups=ncells / sw_wall / 1e9 if sw_wall > 0 else 0.0,
+        sw_gcups_per_core=ncells / sw_thread_s / 1e9 if sw_thread_s > 0 else None,
+        sw_gcups_note='forward cells of the aligned pairs / the time inside the Smith-Waterman calls alone (thread-seconds / threads)',
+        sw_share_of_wall=sw_thread_s / (dt * n_threads) if dt > 0 and sw_thread_s > 0 else None, sw_pairs=npairs,
+        clusterhits_s_per_entry_core=ch_per_entry, clusterhits_kind=ch_kind)))
 
 
 if __name__ == '__main__':
