@@ -38,6 +38,7 @@ static_assert((64000000 >> KP_LOW) < KP_BINS && KP_LOW <= 19, "k-mer ranges");
 constexpr int KP_TILE = 16384;
 constexpr int KP_PER = KP_TILE / JP_NT;
 constexpr int JQ_MAX = 4096;           // queries per sub-batch
+constexpr int JX_COLS_MAX = 15360;     // (query, target range) columns of the ranged scatter: 60 KB of LDS cursors
 constexpr int JJ_WGS = 512;            // persistent workgroups of the join (two per CU)
 constexpr int JJ_NT = 1024;
 #ifndef SD_JE
@@ -421,19 +422,38 @@ __global__ void join_effective_totals_kernel(uint32_t nQ, const uint32_t *__rest
 // Every wavefront works through its 64 * JE k-mers of a chunk on its own (no workgroup barrier inside the loop, so the
 // wavefronts of a CU hide each other's memory latency): list starts and lengths, a wave scan of the lengths, then the
 // lists flattened over the lanes -- hit f of the wavefront belongs to the k-mer x with off[x] <= f < off[x + 1].
-template <bool NT_STORE>
+//
+// RANGES (target sets beyond ~150 proteomes, where the average query of a sub-batch has more than 2 * 10^5 index hits): the hits
+// leave the join already split into C = 2^cBits target ranges per query -- the columns are (query, range) pairs, the cursors sit in
+// LDS as before (JX_COLS_MAX of them), every (query, range) sub-segment is the "virtual query" the hot-target filter and the bucket
+// machinery take -- instead of per query, to be split by three more streaming passes over the whole hit stream (coarse_count /
+// coarse_scatter: 24 B per hit).  The keys do not change: key >> (tBits - cBits) IS the virtual query.  The price is the COUNT form
+// of this kernel: the same walk with a histogram of the columns in place of the stores (a hit's range is known only from its entry,
+// so the count pass reads the entries too; join_count_kernel, which reads list lengths only, still sizes the sub-batch).  Inside a
+// sub-segment the hits are in no particular order (the lanes take positions from LDS atomics): the bucket sort restores emission
+// order from the k-mer ordinal in the value, as it does behind coarse_scatter_kernel.
+template <bool NT_STORE, bool RANGES, bool COUNT>
 __global__ void __launch_bounds__(JJ_NT)
 join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint16_t *__restrict__ chunkBin,
                     const uint32_t *__restrict__ idxOffsets, const uint2 *__restrict__ entries, uint32_t nQ,
-                    const uint32_t *__restrict__ prefix /* [JJ_WGS][cols]: hits of the workgroups before this one, per query */,
-                    int cols, const uint64_t *__restrict__ qHitBase, int tBits, const uint32_t *__restrict__ qSplit,
-                    uint2 *__restrict__ outKV) {
-    __shared__ uint32_t qcur[JQ_MAX];   // this workgroup's write position inside every query's segment (< 2^32 hits per sub-batch)
+                    const uint32_t *__restrict__ prefix /* [JJ_WGS][cols]: hits of the workgroups before this one, per column (scatter) */,
+                    int cols, const uint64_t *__restrict__ qHitBase /* per column */, int tBits, const uint32_t *__restrict__ qSplit,
+                    uint2 *__restrict__ outKV, int cBits, uint32_t *__restrict__ counts /* COUNT: [JJ_WGS][cols] */) {
+    __shared__ uint32_t qcur[RANGES ? JX_COLS_MAX : JQ_MAX];   // this workgroup's write position inside every column's segment (< 2^32 hits per sub-batch)
     constexpr int WE = 64 * JE;   // k-mers per wavefront and step
     __shared__ uint32_t wOff[JJ_NT / 64][WE + 1], wStart[JJ_NT / 64][WE], wKey[JJ_NT / 64][WE], wVal[JJ_NT / 64][WE];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    for (uint32_t q = t; q < nQ; q += JJ_NT)
-        qcur[q] = qSplit[q] == QUERY_UNSUPPORTED ? 0xFFFFFFFFu : (uint32_t) qHitBase[q] + prefix[(size_t) blockIdx.x * cols + q];
+    const int rShift = tBits - cBits;
+    const uint32_t rMask = (1u << cBits) - 1u;
+    if (COUNT) {
+        for (int c = t; c < cols; c += JJ_NT) qcur[c] = qSplit[(uint32_t) c >> cBits] == QUERY_UNSUPPORTED ? 0xFFFFFFFFu : 0u;
+    } else if (RANGES) {
+        for (int c = t; c < cols; c += JJ_NT)
+            qcur[c] = qSplit[(uint32_t) c >> cBits] == QUERY_UNSUPPORTED ? 0xFFFFFFFFu : (uint32_t) qHitBase[c] + prefix[(size_t) blockIdx.x * cols + c];
+    } else {
+        for (uint32_t q = t; q < nQ; q += JJ_NT)
+            qcur[q] = qSplit[q] == QUERY_UNSUPPORTED ? 0xFFFFFFFFu : (uint32_t) qHitBase[q] + prefix[(size_t) blockIdx.x * cols + q];
+    }
     __syncthreads();
     uint32_t *eOff = wOff[wv], *eStart = wStart[wv], *eKey = wKey[wv], *eVal = wVal[wv];
     const JoinSpan sp = joinSpan(n);
@@ -479,7 +499,7 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
         for (int j = 0; j < JE; j++) {
             const int x = j * 64 + lane;
             const uint32_t q = (uint32_t) (e[j] >> 32) & 0xFFFu;
-            if (len[j] && qcur[q] == 0xFFFFFFFFu) len[j] = 0;   // query taken out of the batch
+            if (len[j] && qcur[RANGES ? (q << cBits) : q] == 0xFFFFFFFFu) len[j] = 0;   // query taken out of the batch
             eStart[x] = st[j];
             eKey[x] = q << tBits;
             eVal[x] = (uint32_t) (((e[j] & 0xFF) << 24) | ((e[j] >> 8) & 0xFFFFFF));
@@ -524,6 +544,14 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
                     v = eVal[x4[j]];
                     kq = eKey[x4[j]];
                 }
+                if (RANGES) {
+                    // a column per (query, target range): every lane takes its own position (or counts itself)
+                    if (live) {
+                        const uint32_t col = ((kq >> tBits) << cBits) | ((en[j].x >> rShift) & rMask);
+                        if (COUNT) atomicAdd(&qcur[col], 1u);
+                        else pos = atomicAdd(&qcur[col], 1u);
+                    }
+                } else {
                 // positions: one LDS add per query present in the wavefront; lanes of a query get consecutive positions
                 unsigned long long todo = __ballot(live);
                 while (todo) {
@@ -536,7 +564,8 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
                     if (live && kq == kL) pos = b0 + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
                     todo &= ~mask;
                 }
-                if (live) {
+                }
+                if (live && !COUNT) {
                     const unsigned long long kv = ((unsigned long long) (((((v >> 24) - en[j].y) & 0xFFu) << 24) | (v & 0xFFFFFFu)) << 32) | (kq | en[j].x);
                     if (NT_STORE) __builtin_nontemporal_store(kv, (unsigned long long *) outKV + pos);
                     else ((unsigned long long *) outKV)[pos] = kv;
@@ -545,7 +574,14 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (COUNT) {
+        __syncthreads();
+        for (int c = t; c < cols; c += JJ_NT) counts[(size_t) blockIdx.x * cols + c] = qcur[c] == 0xFFFFFFFFu ? 0u : qcur[c];
+    }
 }
+
+// per (query, range) column: the query's first column carries the marker of a query taken out of the batch -- the other columns of
+// such a query must not count either (the COUNT form initialises every column of it to the marker and writes 0)
 
 // Where the reference's hit buffer (cap entries) overflows inside a query, in k-mer ordinals: whenever the next k-mer's list
 // would fill the buffer, the buffered part is matched on its own and the buffer starts again with that list

@@ -22,7 +22,6 @@
 #include <memory>
 #include "sd_common.h"
 
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstring>
@@ -2524,131 +2523,28 @@ __global__ void cand_stats_kernel(uint32_t nCand, const uint32_t *__restrict__ c
     }
 }
 
-template <typename T, typename Tmp>
-int exclusiveScan(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, Tmp &tmp) {
-    size_t bytes = 0;
-    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int) n, ctx->stream));
-    if (tmp.n < bytes) SD_HIP(ctx, tmp.alloc(bytes + 256));
-    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int) n, ctx->stream));
-    return SD_OK;
-}
-
-// exclusive sum of a narrow array straight into 64-bit offsets (no widened copy)
-template <typename T>
-struct WidenOp {
-    __host__ __device__ __forceinline__ uint64_t operator()(const T &v) const { return (uint64_t) v; }
-};
-// Exclusive prefix sums of small unsigned counts into 64-bit offsets, reduce-then-scan in three launches (tile sums,
-// one-block scan of the tile sums, per-tile scan).  The library's decoupled look-back scan spins on predecessor tiles,
-// and with a second stream's kernels holding most CUs that spinning made the 5*10^8-element k-mer scan the slowest
-// "kernel" of the prefilter (33 ms); this form has no inter-block waiting and runs at HBM speed.
-constexpr int SCAN_ITEMS = 16, SCAN_BLOCK = 256, SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
-
-template <typename T>
-__global__ void __launch_bounds__(SCAN_BLOCK)
-scan_tile_sums_kernel(const T *__restrict__ in, uint64_t n, uint64_t *__restrict__ tileSum) {
-    __shared__ uint64_t part[SCAN_BLOCK / 64];
-    const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
-    uint64_t sum = 0;
-    if (base + SCAN_ITEMS <= n) {
-#pragma unroll
-        for (int j = 0; j < SCAN_ITEMS; j++) sum += (uint64_t) in[base + j];
-    } else {
-        for (int j = 0; j < SCAN_ITEMS; j++)
-            if (base + j < n) sum += (uint64_t) in[base + j];
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t t = 0;
-        for (int w = 0; w < SCAN_BLOCK / 64; w++) t += part[w];
-        tileSum[blockIdx.x] = t;
-    }
-}
-
-// in place: tileSum[i] <- sum of tileSum[0..i); one workgroup, eight consecutive tiles per thread and round
-__global__ void __launch_bounds__(1024)
-scan_tile_bases_kernel(uint64_t *__restrict__ tileSum, uint32_t nTiles) {
-    constexpr int PER = 8;
-    __shared__ uint64_t part[16];
-    __shared__ uint64_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t c0 = 0; c0 < nTiles; c0 += 1024 * PER) {
-        const uint32_t i0 = c0 + threadIdx.x * PER;
-        uint64_t v[PER];
-        uint64_t sum = 0;
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            v[j] = (i0 + j < nTiles) ? tileSum[i0 + j] : 0;
-            sum += v[j];
-        }
-        uint64_t incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint64_t o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        if (lane == 63) part[wave] = incl;
-        __syncthreads();
-        uint64_t run = carry + incl - sum;
-        for (int w = 0; w < wave; w++) run += part[w];
-        const uint64_t endOfThread = run + sum;
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            if (i0 + j < nTiles) tileSum[i0 + j] = run;
-            run += v[j];
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = endOfThread;
-        __syncthreads();
-    }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(SCAN_BLOCK)
-scan_apply_kernel(const T *__restrict__ in, uint64_t n, const uint64_t *__restrict__ tileBase, uint64_t *__restrict__ out) {
-    __shared__ uint64_t part[SCAN_BLOCK / 64];
-    const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
-    uint64_t v[SCAN_ITEMS];
-    uint64_t sum = 0;
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-        v[j] = (base + j < n) ? (uint64_t) in[base + j] : 0;
-        sum += v[j];
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint64_t o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-    }
-    if (lane == 63) part[wave] = incl;
-    __syncthreads();
-    uint64_t run = tileBase[blockIdx.x] + incl - sum;
-    for (int w = 0; w < wave; w++) run += part[w];
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-        if (base + j < n) out[base + j] = run;
-        run += v[j];
-    }
-}
-
+// device-wide scans and the radix sort: this library's own kernels (sd_scan_sort.h)
+#include "sd_scan_sort.h"
 template <typename T, typename Tmp>
 int exclusiveScanWiden(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, Tmp &tmp) {
     if (n == 0) return SD_OK;
-    const uint64_t nTiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    if (tmp.n < nTiles * sizeof(uint64_t)) SD_HIP(ctx, tmp.alloc(nTiles * sizeof(uint64_t) + 256));
-    uint64_t *tileSum = (uint64_t *) tmp.p;
-    hipLaunchKernelGGL(scan_tile_sums_kernel<T>, dim3((unsigned) nTiles), dim3(SCAN_BLOCK), 0, ctx->stream, in, n, tileSum);
-    hipLaunchKernelGGL(scan_tile_bases_kernel, dim3(1), dim3(1024), 0, ctx->stream, tileSum, (uint32_t) nTiles);
-    hipLaunchKernelGGL(scan_apply_kernel<T>, dim3((unsigned) nTiles), dim3(SCAN_BLOCK), 0, ctx->stream, in, n,
-                       (const uint64_t *) tileSum, out);
-    SD_HIP(ctx, hipGetLastError());
+    if (tmp.n < sdScanTmpBytes(n)) SD_HIP(ctx, tmp.alloc(sdScanTmpBytes(n) + 256));
+    SD_HIP(ctx, (sdScanLaunch<T, ScanSum64, false, uint64_t>(ctx->stream, in, out, n, (uint64_t *) tmp.p)));
+    return SD_OK;
+}
+template <typename T, typename Tmp>
+int exclusiveScan(sd_ctx *ctx, const T *in, uint64_t *out, uint64_t n, Tmp &tmp) {
+    return exclusiveScanWiden(ctx, in, out, n, tmp);
+}
+// stable sort of (key, value) pairs by the key bits [beginBit, endBit) into (kOut, vOut); scratch in the workspace
+int sortPairs(sd_ctx *ctx, const uint32_t *kIn, uint32_t *kOut, const uint32_t *vIn, uint32_t *vOut, uint64_t n, int beginBit, int endBit) {
+    if (n == 0) return SD_OK;
+    if (n >= 0xFFFFFFFFull) return sdFail(ctx, SD_EUNSUPPORTED, "sort of %llu elements", (unsigned long long) n);
+    WsView<uint32_t> kTmp(ctx, "pf.sortK"), vTmp(ctx, "pf.sortV"), cnt(ctx, "pf.sortCounts");
+    SD_HIP(ctx, kTmp.alloc(n));
+    SD_HIP(ctx, vTmp.alloc(n));
+    SD_HIP(ctx, cnt.alloc(sdRadixSortCountsBytes() / sizeof(uint32_t)));
+    SD_HIP(ctx, sdRadixSortPairs(ctx->stream, kIn, vIn, kOut, vOut, kTmp.p, vTmp.p, (uint32_t) n, beginBit, endBit, cnt.p));
     return SD_OK;
 }
 
@@ -3034,6 +2930,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         WsView<uint64_t> dSorted(ctx, "pf.dSorted");
         WsView<uint2> dHitsKV(ctx, "pf.dHitsKV");
         WsView<uint64_t> dQHitBase(ctx, "pf.dQHitBase");   // hits of query q start at dQHitBase[q] (either path)
+        WsView<uint64_t> dVQHitBase(ctx, "pf.dVQHitBase");  // with a split into target ranges: hits of (query, range) start here
+        int jcBits = 0;   // join path: the scatter wrote (query, target range) sub-segments of 2^jcBits ranges per query
         if (useJoin) {
             WsView<uint32_t> dKpCounts(ctx, "pf.dKpCounts");
             WsView<uint32_t> dKpTotal(ctx, "pf.dKpTotal");
@@ -3129,16 +3027,52 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             hipLaunchKernelGGL(join_effective_totals_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQHits.p,
                                (const uint32_t *) dQSplit.p, dQEff.p);
             hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(SS_NT), 0, ctx->stream, (const uint32_t *) dQEff.p, (int) bq, dQHitBase.p, 0u);
-            if (nHits > 0) {
+            // very hit-rich queries (large target sets): the scatter splits every query's hits into target ranges right away
+            // (join_scatter_kernel<RANGES>) -- the rule of the coarse split below, which this replaces on the join path
+            if (nHits > 0 && !(getenv("SD_JOIN_RANGES") && atoi(getenv("SD_JOIN_RANGES")) == 0)) {
+                const uint64_t avgQ = nHits / std::max<uint32_t>(bq, 1);
+                const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 200000;
+                const uint64_t perVQsplit = getenv("SD_PF_COARSE") ? perVQ : 100000;
+                if (avgQ > perVQ)
+                    while (jcBits < CP_MAX_BITS && tBits - (jcBits + 1) >= 8 && (avgQ >> jcBits) > perVQsplit) jcBits++;
+                while (jcBits > 0 && ((uint64_t) bq << jcBits) > (uint64_t) JX_COLS_MAX) jcBits--;   // the columns' cursors live in LDS
+            }
+            if (nHits > 0 && jcBits > 0) {
+                const int cols = (int) (bq << jcBits);
+                WsView<uint32_t> dJrCounts(ctx, "pf.dJrCounts");
+                WsView<uint32_t> dVQHits(ctx, "pf.dVQHits");
+                SD_HIP(ctx, dJrCounts.alloc((size_t) JJ_WGS * cols));
+                SD_HIP(ctx, dVQHits.alloc((size_t) cols + 1));
+                SD_HIP(ctx, dVQHitBase.alloc((size_t) cols + 1));
+                SD_HIP(ctx, dHitsKV.alloc(nHits));
+                {
+                    ProfScope ps(ctx, "prefilter_join_count");
+                    hipLaunchKernelGGL((join_scatter_kernel<false, true, true>), dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p,
+                                       nSorted, (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
+                                       (const uint32_t *) nullptr, cols, (const uint64_t *) nullptr, tBits, (const uint32_t *) dQSplit.p,
+                                       (uint2 *) nullptr, jcBits, dJrCounts.p);
+                    hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor((uint64_t) cols, 64)), dim3(256), 0, ctx->stream, dJrCounts.p, JJ_WGS, cols, dVQHits.p);
+                    SD_HIP(ctx, hipMemsetAsync(dVQHits.p + cols, 0, sizeof(uint32_t), ctx->stream));
+                    int rcV = exclusiveScanWiden(ctx, dVQHits.p, dVQHitBase.p, (uint64_t) cols + 1, scanTmp);
+                    if (rcV != SD_OK) return rcV;
+                }
+                ProfScope ps(ctx, "prefilter_join_scatter");
+                static const bool ntStore = !(getenv("SD_JOIN_NT") && atoi(getenv("SD_JOIN_NT")) == 0);
+                auto kern = ntStore ? join_scatter_kernel<true, true, false> : join_scatter_kernel<false, true, false>;
+                hipLaunchKernelGGL(kern, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSorted,
+                                   (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
+                                   (const uint32_t *) dJrCounts.p, cols, (const uint64_t *) dVQHitBase.p, tBits,
+                                   (const uint32_t *) dQSplit.p, dHitsKV.p, jcBits, (uint32_t *) nullptr);
+            } else if (nHits > 0) {
                 SD_HIP(ctx, dHitsKV.alloc(nHits));
                 ProfScope ps(ctx, "prefilter_join_scatter");
                 // SD_JOIN_NT=0: plain stores (partial lines of neighbouring runs merge in the XCD's L2 before they are written back)
                 static const bool ntStore = !(getenv("SD_JOIN_NT") && atoi(getenv("SD_JOIN_NT")) == 0);
-                auto kern = ntStore ? join_scatter_kernel<true> : join_scatter_kernel<false>;
+                auto kern = ntStore ? join_scatter_kernel<true, false, false> : join_scatter_kernel<false, false, false>;
                 hipLaunchKernelGGL(kern, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSorted,
                                    (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                    (const uint32_t *) dJqCounts.p, (int) bq, (const uint64_t *) dQHitBase.p, tBits,
-                                   (const uint32_t *) dQSplit.p, dHitsKV.p);
+                                   (const uint32_t *) dQSplit.p, dHitsKV.p, 0, (uint32_t *) nullptr);
             }
             SD_HIP(ctx, hipGetLastError());
         }
@@ -3243,17 +3177,27 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 const uint32_t *pKey = dKeyA.p, *pVal = dValA.p;
                 // join path: the hits arrive interleaved (key, value)
                 const uint2 *pKV = useJoin ? (const uint2 *) dHitsKV.p : (const uint2 *) nullptr;
-                WsView<uint64_t> dVQHitBase(ctx, "pf.dVQHitBase");
                 WsView<uint32_t> dSegBase(ctx, "pf.dSegBase");
                 WsView<uint32_t> dSegCount(ctx, "pf.dSegCount");
                 WsView<uint32_t> dKeyC(ctx, "pf.dKeyC");
                 WsView<uint32_t> dValC(ctx, "pf.dValC");
-                {
+                if (useJoin && jcBits > 0) {   // the join wrote (query, target range) sub-segments: they are the virtual queries
+                    cBits = jcBits;
+                    nVQ = nVQ0 << cBits;
+                    tBitsV = tBits0 - cBits;
+                    pHitBase = dVQHitBase.p;
+                } else {
                     // decided by the average query of the sub-batch (a few long queries are what the adaptive bucket count and
                     // the oversize-bucket launch are for): ~100 hits per bucket at 2^11 buckets
                     const uint64_t avgQ = nHits / std::max<uint32_t>(nVQ0, 1);
+                    // no split up to 2 * 10^5 hits per average query (the filter takes such a segment in one round); beyond that, ranges of
+                    // at most 10^5 hits: the filter's Bloom rounds, the partition and the bucket sort all run on half-size segments for one more
+                    // level of the (cheap, streaming) split -- isolated prefilter at 1 000 proteomes 443 -> 390 ms per 8 192 queries, +4 % end
+                    // to end; at 100 proteomes (1.5 * 10^5 hits per query) a split would only add its 24 B per hit (1 915 -> 1 767)
                     const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 200000;
-                    while (cBits < CP_MAX_BITS && tBits0 - (cBits + 1) >= 8 && (avgQ >> cBits) > perVQ) cBits++;
+                    const uint64_t perVQsplit = getenv("SD_PF_COARSE") ? perVQ : 100000;
+                    if (avgQ > perVQ)
+                        while (cBits < CP_MAX_BITS && tBits0 - (cBits + 1) >= 8 && (avgQ >> cBits) > perVQsplit) cBits++;
                     // wide stream positions need the split: it is where the diagonal byte moves into the key (8 free bits)
                     while (widePos && cBits < CP_MAX_BITS && tBits - (cBits + 1) >= 8 && (cBits < 1 || tBits - cBits > 24)) cBits++;
                     if (widePos && (cBits < 1 || tBits - cBits > 24))
@@ -3470,10 +3414,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 // (target, query) group contiguous with its emission order intact, which is all match_diag needs; the
                 // few surviving candidates are put back into (query, target) order below.  19 target bits = 3 radix
                 // passes instead of the 4 that (query, target) would take.
-                size_t bytes = 0;
-                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, (int) nHits, 0, tBits, ctx->stream));
-                if (sortTmp.n < bytes) SD_HIP(ctx, sortTmp.alloc(bytes + 256));
-                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sortTmp.p, bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, (int) nHits, 0, tBits, ctx->stream));
+                const int rcS = sortPairs(ctx, dKeyA.p, dKeyB.p, dValA.p, dValB.p, nHits, 0, tBits);
+                if (rcS != SD_OK) return rcS;
             }
             SD_HIP(ctx, dEmit.alloc(nHits + 1));
             SD_HIP(ctx, dEmitPos.alloc(nHits + 1));
@@ -3544,10 +3486,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 uint32_t qb = bq - 1;
                 while (qb) { endBit++; qb >>= 1; }
                 endBit = std::min(32, std::max(endBit, tBits + 1));
-                size_t bytes = 0;
-                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dCKey0.p, dCKey.p, dCVal0.p, dCVal.p, (int) nCand, tBits, endBit, ctx->stream));
-                if (sortTmp.n < bytes) SD_HIP(ctx, sortTmp.alloc(bytes + 256));
-                SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sortTmp.p, bytes, dCKey0.p, dCKey.p, dCVal0.p, dCVal.p, (int) nCand, tBits, endBit, ctx->stream));
+                const int rcS = sortPairs(ctx, dCKey0.p, dCKey.p, dCVal0.p, dCVal.p, nCand, tBits, endBit);
+                if (rcS != SD_OK) return rcS;
             }
             {
                 ProfScope ps(ctx, "prefilter_score_diag");

@@ -18,7 +18,6 @@
 #include "sd_common.h"
 #include <unistd.h>
 
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -1329,26 +1328,34 @@ k_accept_compact(uint32_t nPairs, const sd_sw_result *__restrict__ res, const ui
     outRes[pos[i]] = res[i];
     outIdx[pos[i]] = i;
 }
-struct WidenU8 {
-    __host__ __device__ __forceinline__ uint64_t operator()(const uint8_t &v) const { return (uint64_t) v; }
-};
+// device-wide scans and the radix sort of the task keys: this library's own kernels (sd_scan_sort.h), 256-thread workgroups
+// without inter-workgroup waiting -- they run between the score wavefronts of the other lanes
+#include "sd_scan_sort.h"
 
+// exclusive sum of n values (any unsigned width) into 64-bit offsets
 template <typename T>
-int devExclusiveScan(sd_ctx *ctx, const T *in, T *out, size_t n) {
-    size_t bytes = 0;
-    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int) n, ctx->stream));
-    uint8_t *tmp = nullptr;
-    SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
-    SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int) n, ctx->stream));
+int devExclusiveScan(sd_ctx *ctx, const T *in, uint64_t *out, size_t n) {
+    uint64_t *tmp = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "al.scantmp", sdScanTmpBytes(n) / sizeof(uint64_t) + 32, &tmp));
+    SD_HIP(ctx, (sdScanLaunch<T, ScanSum64, false, uint64_t>(ctx->stream, in, out, n, tmp)));
+    return SD_OK;
+}
+// running maximum (inclusive) of n 32-bit values
+int devInclusiveMax(sd_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
+    uint32_t *tmp = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "al.scantmp32", sdScanTmpBytes(n) / sizeof(uint32_t) + 32, &tmp));
+    SD_HIP(ctx, (sdScanLaunch<uint32_t, ScanMax32, true, uint32_t>(ctx->stream, in, out, n, tmp)));
     return SD_OK;
 }
 
+// stable sort of (key, value) pairs by the key bits [0, endBit)
 int devSortPairs(sd_ctx *ctx, const uint32_t *kIn, uint32_t *kOut, const uint32_t *vIn, uint32_t *vOut, size_t n, int endBit) {
-    size_t bytes = 0;
-    SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kIn, kOut, vIn, vOut, (int) n, 0, endBit, ctx->stream));
-    uint8_t *tmp = nullptr;
-    SD_HIP(ctx, wsGet(ctx, "al.sorttmp", bytes + 256, &tmp));
-    SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, bytes, kIn, kOut, vIn, vOut, (int) n, 0, endBit, ctx->stream));
+    if (n == 0) return SD_OK;
+    uint32_t *kTmp = nullptr, *vTmp = nullptr, *cnt = nullptr;
+    SD_HIP(ctx, wsGet(ctx, "al.sortK", n, &kTmp));
+    SD_HIP(ctx, wsGet(ctx, "al.sortV", n, &vTmp));
+    SD_HIP(ctx, wsGet(ctx, "al.sortCounts", sdRadixSortCountsBytes() / sizeof(uint32_t), &cnt));
+    SD_HIP(ctx, sdRadixSortPairs(ctx->stream, kIn, vIn, kOut, vOut, kTmp, vTmp, (uint32_t) n, 0, endBit, cnt));
     return SD_OK;
 }
 
@@ -1447,9 +1454,6 @@ __global__ void k_pair_bounds(const uint32_t *__restrict__ keyS, uint32_t n, con
     }
     b[c] = (uint32_t) pairIdx[lo];
 }
-struct MaxU32 {
-    __host__ __device__ __forceinline__ uint32_t operator()(const uint32_t &a, const uint32_t &b) const { return a > b ? a : b; }
-};
 
 // sort (keys,vals) -> order, read the class boundaries, launch one score kernel per RT class
 int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint32_t *dVals, uint32_t *dKeysSorted,
@@ -1480,23 +1484,12 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
         if (rc != SD_OK) return rc;
         dOrder = dVals2;
         hipLaunchKernelGGL(k_pair_heads, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dHead);
-        {
-            size_t bytes = 0;
-            SD_HIP(ctx, hipcub::DeviceScan::InclusiveScan(nullptr, bytes, dHead, dRunStart, MaxU32(), (int) nPairs, ctx->stream));
-            uint8_t *tmp = nullptr;
-            SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
-            SD_HIP(ctx, hipcub::DeviceScan::InclusiveScan(tmp, bytes, dHead, dRunStart, MaxU32(), (int) nPairs, ctx->stream));
-        }
+        rc = devInclusiveMax(ctx, dHead, dRunStart, nPairs);
+        if (rc != SD_OK) return rc;
         hipLaunchKernelGGL(k_pair_leaders, dim3((nPairs + 256) / 256), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dRunStart, dLeader,
                            padPairs);
-        {
-            size_t bytes = 0;
-            hipcub::TransformInputIterator<uint64_t, WidenU8, const uint8_t *> it(dLeader, WidenU8());
-            SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, dPairIdx, (int) (nPairs + 1), ctx->stream));
-            uint8_t *tmp = nullptr;
-            SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
-            SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, dPairIdx, (int) (nPairs + 1), ctx->stream));
-        }
+        rc = devExclusiveScan(ctx, (const uint8_t *) dLeader, dPairIdx, (size_t) nPairs + 1);
+        if (rc != SD_OK) return rc;
         hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dKeysSorted, dVals2, dRunStart, dPairIdx, dOrder2);
         hipLaunchKernelGGL(k_pair_bounds, dim3(1), dim3(64), 0, ctx->stream, dKeysSorted, nPairs, dPairIdx, dPairBounds,
                            (int) FIRST_INT32_CLASS + 1);
@@ -2324,12 +2317,8 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         hipLaunchKernelGGL(k_accept, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dRes, dIdent, dAcc);
         SD_HIP(ctx, hipMemsetAsync(dAcc + N, 0, 1, ctx->stream));
         {
-            size_t bytes = 0;
-            hipcub::TransformInputIterator<uint64_t, WidenU8, const uint8_t *> it(dAcc, WidenU8());
-            SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, dAccPos, (int) (N + 1), ctx->stream));
-            uint8_t *tmp = nullptr;
-            SD_HIP(ctx, wsGet(ctx, "al.scantmp", bytes + 256, &tmp));
-            SD_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, dAccPos, (int) (N + 1), ctx->stream));
+            const int rcS = devExclusiveScan(ctx, (const uint8_t *) dAcc, dAccPos, N + 1);
+            if (rcS != SD_OK) return rcS;
         }
         hipLaunchKernelGGL(k_accept_compact, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dRes, dAcc, dAccPos, dResC, dIdxC);
         uint64_t nAcc = 0;

@@ -271,7 +271,11 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     }
     rc = sd_ctx_create(device, &s->ctxCh);
     if (rc != SD_OK) return rc;
+    // prefilter lanes: SD_PF_LANES fixes the number; otherwise three contexts are made (a context is a stream and an empty workspace)
+    // and the number in use is decided once the target is resident (below)
+    const bool pfLanesFixed = getenv("SD_PF_LANES") != nullptr;
     if (const char *e = getenv("SD_PF_LANES")) s->pfLanes = std::max(1, std::min(4, atoi(e)));
+    else s->pfLanes = 3;
     if (s->pfLanes > 1) {
         rc = sd_ctx_create_prio(device, pfPrio, &s->ctxPf2);
         if (rc != SD_OK) return rc;
@@ -360,7 +364,13 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     {   // a target that fills most of the device (10 000 proteomes: 84 GB of index + sequences) leaves room for one prefilter
         // and one alignment workspace, not two of each
         uint64_t freeB = 0, totalB = 0;
-        if (sd_device_memory(s->ctxPf, &freeB, &totalB) == SD_OK && totalB > 0 && freeB < totalB / 4 * 3) s->pfLanes = s->alignLanes = 1;
+        const bool tight = sd_device_memory(s->ctxPf, &freeB, &totalB) == SD_OK && totalB > 0 && freeB < totalB / 4 * 3;
+        if (tight) s->pfLanes = s->alignLanes = 1;
+        // Proteome-scale target sets (10^6 sequences and more): a prefilter call is a chain of ~17 sub-batches of ~700 queries with a
+        // dozen host synchronisation points each, and two lanes leave the stage idle 28 % of the time while it is what bounds a step
+        // (measured at 1 000 proteomes, 12 steps: 2 lanes 2 200 - 2 220, 3 lanes 2 308, 4 lanes 2 099 genome-pairs/s).  Smaller targets:
+        // two (100 proteomes: 2 x 2 and 3 x 2 lanes within noise, the third workspace is not worth its 9 GB)
+        else if (!pfLanesFixed) s->pfLanes = target->n >= 1000000u ? 3 : 2;
     }
     memset(&s->pfPar, 0, sizeof(s->pfPar));
     s->pfPar.kmerSize = s->k;

@@ -100,3 +100,66 @@ def test_tcp_rendezvous_world3():
     want = np.concatenate([np.arange(5 + 11 * r, dtype=np.int64) * (r + 3) for r in range(world)])
     assert outs[0][2] == want.tolist()
     assert outs[0][3] == [(5 + 11 * r) * 8 for r in range(world)]
+
+
+def _worker8(rank, world, port, sizes, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    out = []
+    for step_sizes in sizes:   # several global steps, as bench.py deals them: some with fewer sets than ranks
+        mine = shard_query_sets(step_sizes, world, rank)
+        got = gather_results(_records_for(mine), dist)
+        out.append((mine, [g.tolist() for g in got] if rank == 0 else None))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_gather_world8():
+    """the layout the driver's 8-GPU run uses (one rank per GPU): 8 ranks over gloo, a step of 32 query sets (4 per rank, bench.py's
+    weak-scaling step), a ragged step of 13 and one of 5 sets (three ranks with nothing to do: empty shards, empty records);
+    every set lands on exactly one rank, the loads obey the greedy bound, rank 0 receives every rank's records"""
+    rng = np.random.default_rng(8)
+    steps = [rng.integers(800000, 1000000, size=32).tolist(), rng.integers(100000, 2000000, size=13).tolist(), [7, 7, 7, 7, 7]]
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for si, sizes in enumerate(steps):
+        shards = [outs[r][si][0] for r in range(world)]
+        assert sorted(s for sh in shards for s in sh) == list(range(len(sizes)))
+        loads = [sum(sizes[s] for s in sh) for sh in shards]
+        assert max(loads) - min(loads) <= max(sizes)
+        if len(sizes) >= world:
+            assert all(len(sh) > 0 for sh in shards)
+        gathered = outs[0][si][1]
+        assert len(gathered) == world
+        for r in range(world):   # rank order is kept: part r is rank r's records
+            assert np.array(gathered[r], np.int64).reshape(-1, 3).tolist() == _records_for(shards[r]).reshape(-1, 3).tolist()
+
+
+def test_tcp_rendezvous_world8():
+    """the C ABI's TCP rendezvous with eight ranks (what `sdgpu clustersearch` uses under an 8-process launcher)"""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_tcp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(o[1] == bytes(range(128)) for o in outs)
+    want = np.concatenate([np.arange(5 + 11 * r, dtype=np.int64) * (r + 3) for r in range(world)])
+    assert outs[0][2] == want.tolist()
+    assert outs[0][3] == [(5 + 11 * r) * 8 for r in range(world)]

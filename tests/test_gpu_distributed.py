@@ -155,3 +155,39 @@ def test_sdgpu_search_two_ranks_leave_one_alignment_db(gpu, tmp_path):
     n1 = sum(1 for _ in open(str(tmp_path / 'aln1') + '.index'))
     n2 = sum(1 for _ in open(str(tmp_path / 'aln2') + '.index'))
     assert n1 == n2
+
+
+@pytest.mark.gpu
+def test_sdgpu_clustersearch_eight_ranks_equal_one(gpu, tmp_path):
+    """the layout of the driver's 8-GPU run rehearsed on the one GPU a box has: eight `sdgpu clustersearch` ranks share cuda:0, each
+    takes its share of 16 synthetic query proteomes (sd_shard_query_sets), searches them against all 16, and rank 0 writes the TSV
+    from the eight gathered record buffers (ranks that share a device exchange over the TCP rendezvous: RCCL refuses two ranks
+    per device) -- the clusters must be those of the one-rank run, the cluster keys consecutive across the eight parts"""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), 'tools'))
+    from dbutil import SDGPU, sdgpu, sorted_md5
+    from iter3_scale import _write_fasta
+    from spacedust_amd.synth import make_proteomes, ALPHABET
+    ps = make_proteomes(16, genes_per_proteome=150, seed=0x5ED0 + 8)
+    lut = np.frombuffer(ALPHABET.encode(), np.uint8)
+    fa_dir = tmp_path / 'fa'
+    os.makedirs(fa_dir)
+    files = [_write_fasta(ps, s, str(fa_dir), lut) for s in range(16)]
+    t = tmp_path / 't'
+    sdgpu('createsetdb', *files, t, tmp_path / 'tmp', '-v', '0')
+    sdgpu('clustersearch', t, t, tmp_path / 'one.tsv', tmp_path / 'tmp1', '-v', '0', '--filter-self-match', '1')
+    procs = []
+    port = str(34500 + os.getpid() % 2000)
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='8', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=port, SD_CPUS='2')
+        procs.append(subprocess.Popen([SDGPU, 'clustersearch', str(t), str(t), str(tmp_path / 'eight.tsv'), str(tmp_path / 'tmp8'), '-v', '0',
+                                       '--filter-self-match', '1'], env=env))
+    assert [p.wait(timeout=900) for p in procs] == [0] * 8
+    one = open(tmp_path / 'one.tsv').readlines()
+    eight = open(tmp_path / 'eight.tsv').readlines()
+    assert sum(1 for l in one if l.startswith('#')) > 50
+    assert sorted_md5(one, drop_first_column=True) == sorted_md5(eight, drop_first_column=True)
+    keys = [int(l.split('\t')[0][1:]) for l in eight if l.startswith('#')]
+    assert keys == list(range(len(keys)))
