@@ -117,7 +117,8 @@ def cpu_baseline_subprocess(proteomes, genes, max_seqs, kmer_thr, bin_size, entr
     cmd = [sys.executable, os.path.join(ROOT, 'tools', 'cpu_baseline.py'), '--proteomes', str(proteomes), '--genes', str(genes),
            '--max-seqs', str(max_seqs), '--kmer-thr', str(kmer_thr), '--bin-size', str(bin_size), '--seconds', str(seconds),
            '--threads', str(n_threads), '--entries', entries_path, '--check', str(check), '--check-out', check_out,
-           '--check-sets', ','.join(str(int(x)) for x in check_sets), '--check-entries', str(check_entries)]
+           '--check-sets', ','.join(str(int(x)) for x in check_sets), '--check-entries', str(check_entries),
+           '--gate-seconds', str(max(4.0, seconds / 2))]
     try:
         out = subprocess.run(['nice', '-n', '10'] + cmd, capture_output=True, text=True, timeout=seconds * 6 + 900)
         line = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -490,7 +491,8 @@ def measure(args, rank, local_rank, world, dist, torch):
                    'workload': '%d synthetic proteomes x %d proteins (len~300) all-vs-all, clustersearch --search-mode 0 '
                                '--filter-self-match --max-seqs %d; step = %d query proteomes %s vs all %d targets; timed: search + aggregation + '
                                'clusterhits (+ the result gather for N > 1), the TSV is written after the timed region, the CPU leg likewise '
-                               'stops at the cluster records'
+                               'stops at the cluster records; results.evalue_pushdown = 1: alignments gated at combinehits\' E-value bound '
+                               '(1.2e-6) instead of -e 10, identical cluster hits (parity_check.entries_mismatching)'
                                % (P, args.genes, max_seqs, B, 'in total (strong scaling)' if args.strong else 'per rank', P),
                    'parallelism': 'whole query sets dealt to %d rank(s) by sd_shard_query_sets, target index replicated (%s), '
                                   'final result gather: %s' % (world, index_how, gather_how)},
@@ -515,7 +517,10 @@ def measure(args, rank, local_rank, world, dist, torch):
         # name folded into one line when they are a team (OpenMP workers, runtime helpers)
         'host_cpu_threads': _thread_cpu_report(thr0, thr1, max(1, args.steps)),
         'results': {'entries': int(summary[0]), 'matched_hits': int(summary[1]), 'clusters': int(summary[2]),
-                    'cluster_hits': int(summary[3]), 'queries_not_computed': not_computed},
+                    'cluster_hits': int(summary[3]), 'queries_not_computed': not_computed,
+                    # 1: the alignments ran with combinehits' E-value bound (1.2e-6) as their gate instead of -e 10 -- pairs that cannot
+                    # reach the cluster-hit result stop after the score pass (sd_search.cpp; SD_EVAL_PUSHDOWN=0 switches it off)
+                    'evalue_pushdown': int(cs._raw_stats()[0][15])},
         'setup_s': {'generate': t_gen, 'index': cs.timing['index_build_s'], 'index_where': 'device (sd_target_build)', 'search_create': t_index,
                     'upload': cs.timing['upload_s']},
         'device': gpu.device_name(),

@@ -533,7 +533,10 @@ int sd_search_result_records(sd_search_result *r, void *out, uint64_t cap, uint6
 void sd_search_result_destroy(sd_search_result *r);
 /* accumulated since create: stats[16] = similar k-mers, index hits, diagonals, diagonal length, prefilter hits, pairs,
  * forward / reverse / traceback cells, index entries, masked residues, k, k-mer threshold, bin size, queries not computed
- * (per-query error slots of sd_prefilter_batch; sd_search_last_error says why -- a caller must not take their empty rows for results), 0;
+ * (per-query error slots of sd_prefilter_batch; sd_search_last_error says why -- a caller must not take their empty rows for results),
+ * 1 if the last stream ran its alignments with combinehits' E-value bound as their gate (a stream that writes nothing but cluster
+ * records: pairs that cannot reach the cluster-hit result stop after the score pass, as pairs above -e do in the reference; the
+ * `accepted` count of its results then refers to that gate; SD_EVAL_PUSHDOWN=0 switches it off);
  * seconds[16] = index build, upload, bias, prefilter, pair list, seqset, align, aggregate (waiting), aggregate (busy),
  * clusterhits, waiting for the prefilter, total of the last stream, 0... */
 int sd_search_stats(sd_search *s, uint64_t *stats, double *seconds);

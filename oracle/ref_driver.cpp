@@ -407,9 +407,11 @@ unsigned long ref_l2_cache_size() { return Util::getL2CacheSize(); }
 // out[4] = thread-seconds spent inside the Smith-Waterman calls alone (sum over the threads)
 // ------------------------------------------------------------------------------------------------
 #include <chrono>
+// evalThr: the alignment's E-value gate (Alignment.cpp:379 hands par.evalThr to getSWResult): 10 is clustersearch's default; bench.py
+// also times the reference with the bound the device pipeline pushes down from combinehits (same final cluster hits, less work)
 extern "C" int ref_run_queries(void *vi, const char *seqs, const size_t *offsets, const unsigned int *sample,
                                size_t nSample, int kmerThr, size_t maxHits, int threads, double seconds,
-                               size_t dbResidues, double *out) {
+                               size_t dbResidues, double *out, double evalThr) {
     RefIndex *ix = (RefIndex *) vi;
     RefCtx *c = ix->ctx;
     ensureExt(c);
@@ -448,7 +450,7 @@ extern "C" int ref_run_queries(void *vi, const char *seqs, const size_t *offsets
                 const unsigned int tid = ids[h];
                 const unsigned int tL = (unsigned int) (offsets[tid + 1] - offsets[tid]);
                 if (Util::canBeCovered(0.8f, Parameters::COV_MODE_QUERY, (float) qL, (float) tL) == false) continue;
-                ref_sw_align(sw[t], seqs + offsets[tid], tL, 2, 10.0, Parameters::COV_MODE_QUERY, 0.8f, res, NULL, 0, tid == q);
+                ref_sw_align(sw[t], seqs + offsets[tid], tL, 2, evalThr, Parameters::COV_MODE_QUERY, 0.8f, res, NULL, 0, tid == q);
                 pairs++;
                 cells += (size_t) qL * tL;
             }

@@ -343,11 +343,12 @@ __device__ __forceinline__ JoinSpan joinSpan(uint64_t n /* multiple of JC */) {
 }
 
 __global__ void __launch_bounds__(JJ_NT)
-join_count_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint16_t *__restrict__ chunkBin,
+join_count_kernel(const uint64_t *__restrict__ sorted, const uint64_t *__restrict__ nPtr /* elements of the sorted stream: read on the device, no host round trip */, const uint16_t *__restrict__ chunkBin,
                   const uint32_t *__restrict__ idxOffsets, uint32_t *__restrict__ counts /* [JJ_WGS][cols] */, int cols,
                   unsigned long long *__restrict__ wgTotal /* [JJ_WGS]: 64-bit, the per-query counts are 32 */) {
     __shared__ uint32_t hist[JQ_MAX];
     __shared__ unsigned long long sTotal;
+    const uint64_t n = *nPtr;
     unsigned long long mine = 0;
     if (threadIdx.x == 0) sTotal = 0;
     for (int x = threadIdx.x; x < cols; x += JJ_NT) hist[x] = 0;
@@ -434,7 +435,7 @@ __global__ void join_effective_totals_kernel(uint32_t nQ, const uint32_t *__rest
 // order from the k-mer ordinal in the value, as it does behind coarse_scatter_kernel.
 template <bool NT_STORE, bool RANGES, bool COUNT>
 __global__ void __launch_bounds__(JJ_NT)
-join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint16_t *__restrict__ chunkBin,
+join_scatter_kernel(const uint64_t *__restrict__ sorted, const uint64_t *__restrict__ nPtr, const uint16_t *__restrict__ chunkBin,
                     const uint32_t *__restrict__ idxOffsets, const uint2 *__restrict__ entries, uint32_t nQ,
                     const uint32_t *__restrict__ prefix /* [JJ_WGS][cols]: hits of the workgroups before this one, per column (scatter) */,
                     int cols, const uint64_t *__restrict__ qHitBase /* per column */, int tBits, const uint32_t *__restrict__ qSplit,
@@ -442,7 +443,10 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
     __shared__ uint32_t qcur[RANGES ? JX_COLS_MAX : JQ_MAX];   // this workgroup's write position inside every column's segment (< 2^32 hits per sub-batch)
     constexpr int WE = 64 * JE;   // k-mers per wavefront and step
     __shared__ uint32_t wOff[JJ_NT / 64][WE + 1], wStart[JJ_NT / 64][WE], wKey[JJ_NT / 64][WE], wVal[JJ_NT / 64][WE];
+    __shared__ uint8_t wOwn[JJ_NT / 64][256];   // per wavefront: the k-mer whose list starts at a flat slot of the current 256-hit batch
+    static_assert(WE <= 256, "k-mer indices of a wavefront's step are bytes");
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint64_t n = *nPtr;
     const int rShift = tBits - cBits;
     const uint32_t rMask = (1u << cBits) - 1u;
     if (COUNT) {
@@ -495,6 +499,7 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
             }
         }
         uint32_t carry = 0;
+        uint32_t myOff[JE];
 #pragma unroll
         for (int j = 0; j < JE; j++) {
             const int x = j * 64 + lane;
@@ -509,29 +514,45 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, uint64_t n, const uint1
                 const uint32_t o = __shfl_up(incl, off, 64);
                 if (lane >= off) incl += o;
             }
-            eOff[x] = carry + incl - len[j];
+            myOff[j] = carry + incl - len[j];
+            eOff[x] = myOff[j];
             carry += __shfl(incl, 63, 64);
         }
         const uint32_t total = carry;
         if (lane == 63) eOff[WE] = total;
         __builtin_amdgcn_wave_barrier();
+        // Flat slot f of the wavefront's hits belongs to the last k-mer x with eOff[x] <= f.  Per batch of 256 slots every k-mer whose
+        // list STARTS inside the batch writes its index at that slot (a byte in LDS), and a running maximum over the slots hands
+        // every slot its owner (the k-mer indices grow with the slots; a list that began in an earlier batch is the carry) -- two
+        // dozen shuffles per four hits where a binary search of eOff cost seven dependent LDS reads per hit
+        uint8_t *own = wOwn[wv];
+        uint32_t ownCarry = 0;
         for (uint32_t f0 = 0; f0 < total; f0 += 4 * 64) {
             uint32_t x4[4], a4[4];
+            ((uint32_t *) own)[lane] = 0u;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < JE; j++)
+                if (len[j] && myOff[j] >= f0 && myOff[j] < f0 + 256u) own[myOff[j] - f0] = (uint8_t) (j * 64 + lane);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t f = f0 + (uint32_t) j * 64 + (uint32_t) lane;
+                uint32_t v = own[j * 64 + lane];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = __shfl_up(v, off, 64);
+                    if (lane >= off) v = max(v, o);
+                }
+                v = max(v, ownCarry);
+                ownCarry = __shfl(v, 63, 64);
                 x4[j] = 0xFFFFFFFFu;
                 if (f < total) {
-                    int lo = 0, hi = WE;   // last x with eOff[x] <= f
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (eOff[mid] <= f) lo = mid;
-                        else hi = mid;
-                    }
-                    x4[j] = (uint32_t) lo;
-                    a4[j] = eStart[lo] + (f - eOff[lo]);
+                    x4[j] = v;
+                    a4[j] = eStart[v] + (f - eOff[v]);
                 }
             }
+            __builtin_amdgcn_wave_barrier();
             uint2 en[4];
 #pragma unroll
             for (int j = 0; j < 4; j++)

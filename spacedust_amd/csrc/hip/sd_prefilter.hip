@@ -1354,7 +1354,9 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
                     uint32_t bigCap, const uint32_t *__restrict__ qSplit, const uint32_t *__restrict__ qParts,
                     const uint32_t *__restrict__ qSplits, int vqShift /* query = virtual query >> vqShift */,
                     int wpBits /* 0, or (wide stream positions) the virtual query's target bits: the diagonal byte sits in the
-                                  key above them and the value is the position */) {
+                                  key above them and the value is the position */,
+                    const uint32_t *__restrict__ listCount /* with slotList: entries of the list (read on the device), null: the grid */,
+                    uint32_t listFirst /* first list entry this launch takes */) {
     __shared__ uint32_t eK[CAP], eV[CAP];
     __shared__ uint32_t cnt[PF_CNT_MAX / 2];   // packed 16-bit: counts -> group starts -> group ends
     __shared__ uint32_t part[NT / 64 + 1];
@@ -1362,7 +1364,8 @@ bucket_match_kernel(uint32_t nQ, const uint64_t *__restrict__ binBase, const uin
     static_assert(CAP % NT == 0 && PER <= 32 && CAP < 65536, "bucket geometry");
     uint32_t q, b;
     if (slotList) {
-        const uint32_t sl = slotList[blockIdx.x];
+        if (listCount && listFirst + blockIdx.x >= *listCount) return;
+        const uint32_t sl = slotList[listFirst + blockIdx.x];
         q = sl / PF_NB_MAX;
         b = sl % PF_NB_MAX;
     } else if (!pfSlotOf(blockIdx.x, nQ, binBase, q, b)) {
@@ -2470,10 +2473,11 @@ __global__ void widen_kernel(uint64_t n, const uint32_t *__restrict__ in, uint64
 }
 
 // first kept index of every query (keys are sorted): start[q] = lower_bound(q << tBits)
-__global__ void query_bounds_kernel(uint32_t nQ, uint32_t nKept, const uint32_t *__restrict__ kKey, int tBits,
-                                    uint32_t *__restrict__ start) {
+__global__ void query_bounds_kernel(uint32_t nQ, uint32_t nKept, const uint64_t *__restrict__ nKeptPtr /* non-null: the count as the scan left it */,
+                                    const uint32_t *__restrict__ kKey, int tBits, uint32_t *__restrict__ start) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nQ) return;
+    if (nKeptPtr) nKept = (uint32_t) *nKeptPtr;
     if (q == nQ) { start[q] = nKept; return; }
     uint32_t lo = 0, hi = nKept;
     while (lo < hi) {
@@ -2957,7 +2961,6 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                    dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, dKmerBase.p, dElems.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo,
                                    (const uint32_t *) dPosQuery.p);
             }
-            uint64_t nSorted = 0;
             {
                 ProfScope ps(ctx, "prefilter_kmer_partition");
                 hipLaunchKernelGGL(kp_hist_kernel, dim3(JP_WGS), dim3(JP_NT), 0, ctx->stream, (const uint64_t *) dElems.p, nKmers, dKpCounts.p);
@@ -2967,12 +2970,12 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                    (const uint32_t *) dKpCounts.p, (const uint64_t *) dKpBase.p, (const uint32_t *) dQKmerBase.p, bq, dSorted.p);
                 hipLaunchKernelGGL(kp_finish_kernel, dim3(KP_BINS), dim3(256), 0, ctx->stream, (const uint32_t *) dKpTotal.p,
                                    (const uint64_t *) dKpBase.p, dSorted.p, dChunkBin.p);
-                SD_HIP(ctx, sdD2H(ctx, &nSorted, dKpBase.p + KP_BINS, sizeof(uint64_t)));
-                SD_HIP(ctx, sdStreamSync(ctx));
             }
+            // (the join kernels read the padded length of the sorted stream where the partition left it: no round trip to the host)
+            const uint64_t *nSortedPtr = dKpBase.p + KP_BINS;
             {
                 ProfScope ps(ctx, "prefilter_join_count");
-                hipLaunchKernelGGL(join_count_kernel, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSorted,
+                hipLaunchKernelGGL(join_count_kernel, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
                                    (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, dJqCounts.p, (int) bq, dWgTotal.p);
                 hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor(bq, 64)), dim3(256), 0, ctx->stream, dJqCounts.p, JJ_WGS, (int) bq, dQHits.p);
             }
@@ -3027,9 +3030,13 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             hipLaunchKernelGGL(join_effective_totals_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQHits.p,
                                (const uint32_t *) dQSplit.p, dQEff.p);
             hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(SS_NT), 0, ctx->stream, (const uint32_t *) dQEff.p, (int) bq, dQHitBase.p, 0u);
-            // very hit-rich queries (large target sets): the scatter splits every query's hits into target ranges right away
-            // (join_scatter_kernel<RANGES>) -- the rule of the coarse split below, which this replaces on the join path
-            if (nHits > 0 && !(getenv("SD_JOIN_RANGES") && atoi(getenv("SD_JOIN_RANGES")) == 0)) {
+            // SD_JOIN_RANGES=1 (an experiment kept for the A/B, off by default): the scatter splits every query's hits into target
+            // ranges right away (join_scatter_kernel<RANGES>) by the rule of the coarse split below, which it replaces on the join path.
+            // Measured at 1 000 proteomes, isolated, per 8 192 queries: plain scatter 72.8 + coarse split 97.9 = 171 ms against ranged
+            // count 90 + ranged scatter 150 - 197 ms, 2 379 vs 2 235 genome-pairs/s end to end -- a wavefront's 256 hits fall into ~40
+            // (query, range) columns, i.e. 48-byte pieces, where the plain scatter writes 600-byte runs and the coarse split moves
+            // 16 384-hit tiles into at most 64 ranges (2-KB runs): two streaming levels beat one fine-grained scatter.
+            if (nHits > 0 && getenv("SD_JOIN_RANGES") && atoi(getenv("SD_JOIN_RANGES")) == 1) {
                 const uint64_t avgQ = nHits / std::max<uint32_t>(bq, 1);
                 const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 200000;
                 const uint64_t perVQsplit = getenv("SD_PF_COARSE") ? perVQ : 100000;
@@ -3048,7 +3055,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 {
                     ProfScope ps(ctx, "prefilter_join_count");
                     hipLaunchKernelGGL((join_scatter_kernel<false, true, true>), dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p,
-                                       nSorted, (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
+                                       nSortedPtr, (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                        (const uint32_t *) nullptr, cols, (const uint64_t *) nullptr, tBits, (const uint32_t *) dQSplit.p,
                                        (uint2 *) nullptr, jcBits, dJrCounts.p);
                     hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor((uint64_t) cols, 64)), dim3(256), 0, ctx->stream, dJrCounts.p, JJ_WGS, cols, dVQHits.p);
@@ -3059,7 +3066,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 ProfScope ps(ctx, "prefilter_join_scatter");
                 static const bool ntStore = !(getenv("SD_JOIN_NT") && atoi(getenv("SD_JOIN_NT")) == 0);
                 auto kern = ntStore ? join_scatter_kernel<true, true, false> : join_scatter_kernel<false, true, false>;
-                hipLaunchKernelGGL(kern, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSorted,
+                hipLaunchKernelGGL(kern, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
                                    (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                    (const uint32_t *) dJrCounts.p, cols, (const uint64_t *) dVQHitBase.p, tBits,
                                    (const uint32_t *) dQSplit.p, dHitsKV.p, jcBits, (uint32_t *) nullptr);
@@ -3069,7 +3076,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 // SD_JOIN_NT=0: plain stores (partial lines of neighbouring runs merge in the XCD's L2 before they are written back)
                 static const bool ntStore = !(getenv("SD_JOIN_NT") && atoi(getenv("SD_JOIN_NT")) == 0);
                 auto kern = ntStore ? join_scatter_kernel<true, false, false> : join_scatter_kernel<false, false, false>;
-                hipLaunchKernelGGL(kern, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSorted,
+                hipLaunchKernelGGL(kern, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
                                    (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                    (const uint32_t *) dJqCounts.p, (int) bq, (const uint64_t *) dQHitBase.p, tBits,
                                    (const uint32_t *) dQSplit.p, dHitsKV.p, 0, (uint32_t *) nullptr);
@@ -3125,7 +3132,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         }   // lookup path
 
         hs.reset(new HostScope(ctx, "pf.gather_sort_match"));
-        uint32_t nCand = 0, nKept = 0;
+        uint32_t nCand = 0;
+        const uint64_t *nKeptPtr = nullptr;   // kept candidates (device); null: none
         bool bucketDone = false;
         bool widePos = false;
         if (useBuckets && !useJoin)
@@ -3203,12 +3211,22 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     if (widePos && (cBits < 1 || tBits - cBits > 24))
                         return sdFail(ctx, SD_EUNSUPPORTED, "a query with >= 2^24 index hits against a target set of %u sequences", T->nSeq);
                     if (cBits > 0) {
-                        std::vector<uint64_t> hQHB(nVQ0 + 1);
-                        SD_HIP(ctx, sdD2H(ctx, hQHB.data(), pHitBase, (nVQ0 + 1) * sizeof(uint64_t)));
-                        SD_HIP(ctx, sdStreamSync(ctx));
+                        // segments of CP_SEG hits per query.  The join path knows every query's hits on the host already (the read that
+                        // sized the sub-batch), the lookup path reads the segment starts back; the segment table goes up through a pinned
+                        // buffer, so nothing here waits for the stream a second time
+                        std::vector<uint64_t> hQHB(nVQ0 + 1, 0);
+                        if (useJoin) {
+                            for (uint32_t x = 0; x < nVQ0; x++)
+                                hQHB[x + 1] = hQHB[x] + ((x < hUnsupported.size() && hUnsupported[x]) ? 0ull : hStats[(size_t) x * 4 + 1]);
+                        } else {
+                            SD_HIP(ctx, sdD2H(ctx, hQHB.data(), pHitBase, (nVQ0 + 1) * sizeof(uint64_t)));
+                            SD_HIP(ctx, sdStreamSync(ctx));
+                        }
                         ProfScope ps(ctx, "prefilter_coarse_split");
                         const uint32_t C = 1u << cBits;
-                        std::vector<uint32_t> hSegBase(nVQ0 + 1, 0);
+                        uint32_t *hSegBase = nullptr;
+                        SD_HIP(ctx, pinGet(ctx, "pf.hSegBase", (size_t) nVQ0 + 1, &hSegBase));
+                        hSegBase[0] = 0;
                         for (uint32_t x = 0; x < nVQ0; x++)
                             hSegBase[x + 1] = hSegBase[x] + (uint32_t) ((hQHB[x + 1] - hQHB[x] + CP_SEG - 1) / CP_SEG);
                         const uint32_t nSeg = hSegBase[nVQ0];
@@ -3219,7 +3237,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         SD_HIP(ctx, dSegCount.alloc((size_t) std::max<uint32_t>(nSeg, 1) * C));
                         SD_HIP(ctx, dKeyC.alloc(nHits));
                         SD_HIP(ctx, dValC.alloc(nHits));
-                        SD_HIP(ctx, hipMemcpyAsync(dSegBase.p, hSegBase.data(), (nVQ0 + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                        SD_HIP(ctx, hipMemcpyAsync(dSegBase.p, hSegBase, (nVQ0 + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
                         if (nSeg > 0)
                             hipLaunchKernelGGL(coarse_count_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, tBits0,
                                                cBits, dKeyA.p, pKV, dSegCount.p);
@@ -3229,7 +3247,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                             hipLaunchKernelGGL(coarse_scatter_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, tBits0,
                                                cBits, dSegCount.p, dKeyA.p, dValA.p, pKV, dKeyC.p, dValC.p,
                                                widePos ? (const uint16_t *) dDiag.p : (const uint16_t *) nullptr);
-                        SD_HIP(ctx, sdStreamSync(ctx));   // hSegBase is read by the upload until here
+                        // (hSegBase is pinned and persistent: the upload may still be reading it; the next sub-batch writes it only after
+                        // several waits for this stream)
                         pHitBase = dVQHitBase.p;
                         pKey = dKeyC.p;
                         pVal = dValC.p;
@@ -3263,6 +3282,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         else if (geo == 3) SD_HF(256, 6144, 16);    // 32 KB
                         else if (geo == 4) SD_HF(1024, 16384, 18);  // 96 KB
                         else if (geo == 5) SD_HF(1024, 24576, 18);  // 128 KB, pass-B tiles of 4 096 hits
+                        else if (geo == 6) hipLaunchKernelGGL((hot_filter_kernel<1024, 12288, 18, 8>), dim3(hfGrid), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV,
+                                                              (uint32_t *) pKey, (uint32_t *) pVal, (uint2 *) pKV, widePos ? tBitsV : 0, minSeg, dHotCount.p);   // 48 + 32 KB: two workgroups per CU
+                        else if (geo == 7) hipLaunchKernelGGL((hot_filter_kernel<1024, 16384, 17, 8>), dim3(hfGrid), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV,
+                                                              (uint32_t *) pKey, (uint32_t *) pVal, (uint2 *) pKV, widePos ? tBitsV : 0, minSeg, dHotCount.p);   // 64 + 16 KB: two workgroups per CU
                         else hipLaunchKernelGGL((hot_filter_kernel<1024, 24576, 18, 8>), dim3(hfGrid), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV,
                                                 (uint32_t *) pKey, (uint32_t *) pVal, (uint2 *) pKV, widePos ? tBitsV : 0, minSeg, dHotCount.p);   // 128 KB, tiles of 8 192: half the barriers (isolated 62.9 -> 60.5 ms per step)
 #undef SD_HF
@@ -3362,24 +3385,37 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         hipLaunchKernelGGL((bucket_match_kernel<128, PF_BUCKET_CAP>), dim3((unsigned) totalBins), dim3(128), 0, ctx->stream,
                                            nVQ, dBinBase.p, dQLog2.p, tBitsV, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, outK,
                                            outV, dBktEmit.p, dFlag.p, (const uint32_t *) dSlotList.p, dBigList.p, dBigCount, bigCap,
-                                           dQSplit.p, dQParts.p, dQSplits.p, cBits, widePos ? tBitsV : 0);
+                                           dQSplit.p, dQParts.p, dQSplits.p, cBits, widePos ? tBitsV : 0, (const uint32_t *) nullptr, 0u);
                     }
-                    uint32_t nBig = 0;
-                    SD_HIP(ctx, sdD2H(ctx, &nBig, dBigCount, sizeof(uint32_t)));
-                    SD_HIP(ctx, sdStreamSync(ctx));
-                    if (nBig > 0 && nBig <= bigCap) {   // the few buckets with one very hit-rich target (e.g. the query itself)
+                    // the few buckets with one very hit-rich target (e.g. the query itself): their number stays on the device -- a launch of
+                    // BIG_GRID workgroups that compare their index with the list's length takes them without a round trip to the host; a
+                    // list longer than that (every bucket can be oversize on a very large target set) is finished after the next read
+                    constexpr uint32_t BIG_GRID = 2048;
+                    auto launchBig = [&](uint32_t first, uint32_t grid) {
                         ProfScope ps(ctx, "prefilter_bucket_match_big");
-                        hipLaunchKernelGGL((bucket_match_kernel<256, PF_BUCKET_CAP_BIG>), dim3(nBig), dim3(256), 0, ctx->stream, nVQ,
+                        hipLaunchKernelGGL((bucket_match_kernel<256, PF_BUCKET_CAP_BIG>), dim3(grid), dim3(256), 0, ctx->stream, nVQ,
                                            dBinBase.p, dQLog2.p, tBitsV, dBktStart.p, dBktCount.p, (const uint2 *) dKVB.p, outK, outV,
                                            dBktEmit.p, dFlag.p, (const uint32_t *) dBigList.p, (uint32_t *) nullptr,
-                                           (uint32_t *) nullptr, 0u, dQSplit.p, dQParts.p, dQSplits.p, cBits, widePos ? tBitsV : 0);
-                    }
+                                           (uint32_t *) nullptr, 0u, dQSplit.p, dQParts.p, dQSplits.p, cBits, widePos ? tBitsV : 0,
+                                           (const uint32_t *) dBigCount, first);
+                    };
+                    launchBig(0, std::min<uint32_t>(BIG_GRID, bigCap));
                     rc = exclusiveScanWiden(ctx, dBktEmit.p, dEmitOff.p, nSlots + 1, scanTmp);
                     if (rc != SD_OK) return rc;
                     uint64_t nc64 = 0;
+                    uint32_t nBig = 0;
+                    SD_HIP(ctx, sdD2H(ctx, &nBig, dBigCount, sizeof(uint32_t)));
                     SD_HIP(ctx, sdD2H(ctx, &hFlag, dFlag.p, sizeof(int)));
                     SD_HIP(ctx, sdD2H(ctx, &nc64, dEmitOff.p + nSlots, sizeof(uint64_t)));
                     SD_HIP(ctx, sdStreamSync(ctx));
+                    if (hFlag == 0 && nBig > BIG_GRID && nBig <= bigCap) {   // the rest of a long list, then the offsets again
+                        for (uint32_t first = BIG_GRID; first < nBig; first += 1u << 20) launchBig(first, std::min<uint32_t>(nBig - first, 1u << 20));
+                        rc = exclusiveScanWiden(ctx, dBktEmit.p, dEmitOff.p, nSlots + 1, scanTmp);
+                        if (rc != SD_OK) return rc;
+                        SD_HIP(ctx, sdD2H(ctx, &hFlag, dFlag.p, sizeof(int)));
+                        SD_HIP(ctx, sdD2H(ctx, &nc64, dEmitOff.p + nSlots, sizeof(uint64_t)));
+                        SD_HIP(ctx, sdStreamSync(ctx));
+                    }
                     if (hFlag == 0) {
                         nCand = (uint32_t) nc64;
                         bucketDone = true;
@@ -3511,16 +3547,14 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             hipLaunchKernelGGL(flag_to_u64_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, (uint64_t) nCand, dKeep.p, dK64.p);
             int rc = exclusiveScan(ctx, dK64.p, dKPos64.p, (uint64_t) nCand + 1, scanTmp);
             if (rc != SD_OK) return rc;
-            uint64_t nk64 = 0;
-            SD_HIP(ctx, sdD2H(ctx, &nk64, dKPos64.p + nCand, sizeof(uint64_t)));
-            SD_HIP(ctx, sdStreamSync(ctx));
-            nKept = (uint32_t) nk64;
-            SD_HIP(ctx, dKKey.alloc(nKept + 1));
-            SD_HIP(ctx, dKVal.alloc(nKept + 1));
-            SD_HIP(ctx, dKScore.alloc(nKept + 1));
-            if (nKept > 0)
-                hipLaunchKernelGGL(compact_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, (uint64_t) nCand, dKeep.p,
-                                   dKPos64.p, dCKey.p, dCVal.p, dCScore.p, dKKey.p, dKVal.p, dKScore.p);
+            // the number of kept candidates stays on the device (query_bounds_kernel reads it where the scan left it): the kept arrays
+            // are sized by the candidates, no round trip to the host
+            nKeptPtr = dKPos64.p + nCand;
+            SD_HIP(ctx, dKKey.alloc((size_t) nCand + 1));
+            SD_HIP(ctx, dKVal.alloc((size_t) nCand + 1));
+            SD_HIP(ctx, dKScore.alloc((size_t) nCand + 1));
+            hipLaunchKernelGGL(compact_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, (uint64_t) nCand, dKeep.p,
+                               dKPos64.p, dCKey.p, dCVal.p, dCScore.p, dKKey.p, dKVal.p, dKScore.p);
         } else {
             SD_HIP(ctx, dKKey.alloc(1));
             SD_HIP(ctx, dKVal.alloc(1));
@@ -3529,7 +3563,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         }
         hs.reset(new HostScope(ctx, "pf.select"));
         SD_HIP(ctx, dQStart.alloc(bq + 1));
-        hipLaunchKernelGGL(query_bounds_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, nKept, dKKey.p, tBits, dQStart.p);
+        hipLaunchKernelGGL(query_bounds_kernel, dim3(gridFor(bq + 1, 256)), dim3(256), 0, ctx->stream, bq, 0u, nKeptPtr, (const uint32_t *) dKKey.p, tBits, dQStart.p);
         WsView<sd_hit> dOut(ctx, "pf.dOut");
         WsView<uint32_t> dOutCount(ctx, "pf.dOutCount");
         SD_HIP(ctx, dOut.alloc((size_t) bq * maxHits));

@@ -135,7 +135,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
     struct Cand {
         uint32_t i;
         double eval;
-        int bits;
+        int score;   // (the rounded bit score, Matcher::compareHits' second criterion, is derived from it when two E-values tie)
         int dbLen;
         uint32_t key;   // DB key of the target (Matcher::compareHits' last criterion)
         uint32_t t;     // target index
@@ -161,7 +161,11 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
         uint32_t gen = 0;
         auto better = [](const Cand &x, const Cand &y) {
             if (x.eval != y.eval) return x.eval < y.eval;
-            if (x.bits != y.bits) return x.bits > y.bits;
+            if (x.score != y.score) {   // Matcher.cpp:130: static_cast<int>(bit score + 0.5)
+                const int xb = static_cast<int>(sd_host_bitscore((double) (uint32_t) x.score) + 0.5);
+                const int yb = static_cast<int>(sd_host_bitscore((double) (uint32_t) y.score) + 0.5);
+                if (xb != yb) return xb > yb;
+            }
             if (x.dbLen != y.dbLen) return x.dbLen < y.dbLen;
             return x.key < y.key;
         };
@@ -192,7 +196,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                                     sd::hasCoverage(a->covThr, a->covMode, qcov, dbcov) && (r.btLen >= a->alnLenThr);
                     if (!ok) continue;
                 }
-                c.bits = static_cast<int>(sd_host_bitscore((double) (uint32_t) r.score) + 0.5);   // Matcher.cpp:130
+                c.score = r.score;
                 accepted++;
                 const uint32_t ts = a->tSetOf[c.t];
                 if (stamp[ts] != gen) {
@@ -215,6 +219,11 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                 const uint32_t ts = bestOfSet[s].first;
                 if (a->filterSelfMatch && qs == ts) continue;   // combinehits.cpp:83
                 const sd_sw_result &r = res[c->i];
+                // combinehits keeps a hit only if its log P, after two %.3E text round trips, is below log(10e-7) = -13.8155.  An
+                // E-value of 1.1e-6 and more cannot get there: its text form is >= 1.0994e-6, log of that -13.7208 (larger E-values
+                // take the other branch of ComputelogPval, >= -6.9), and the second rounding moves it by at most 5e-4 relative, to
+                // >= -13.7277.  Four in five best hits of a proteome-scale search end here, before any formatting.
+                if (c->eval >= 1.1e-6) continue;
                 BestHit b;
                 char evalText[32], lpText[32], pvalText[32];
                 const double evParsed = quantise3E(c->eval, evalText);

@@ -129,7 +129,7 @@ enum { T_INDEX, T_UPLOAD, T_BIAS, T_PREFILTER, T_PAIRS, T_SEQSET, T_ALIGN, T_AGG
        T_CPU_BIAS, T_CPU_PF, T_CPU_ALIGN, T_CPU_AGG_MAIN,   // thread CPU seconds of the stage threads (bias | prefilter lanes | alignment lanes | aggregation + the driving thread)
        T_N = 16 };
 enum { S_KMERS, S_INDEX_HITS, S_DIAGONALS, S_DIAG_LEN, S_PREF_HITS, S_PAIRS, S_CELLS_FWD, S_CELLS_REV, S_CELLS_TB, S_ENTRIES, S_MASKED, S_K,
-       S_KMER_THR, S_BIN, S_NOT_COMPUTED, S_N = 16 };
+       S_KMER_THR, S_BIN, S_NOT_COMPUTED, S_EVAL_PUSHDOWN /* 1: the alignments ran with combinehits' E-value bound as their gate */, S_N = 16 };
 
 }  // namespace
 
@@ -161,6 +161,7 @@ struct sd_search {
     int k = 6, kmerThr = 0;
     sd_prefilter_params pfPar;
     sd_sw_params swPar;
+    sd_sw_params swParRun;   // swPar with the E-value gate of the running stream (sd_search_stream: predicate pushdown)
     sd_ch_params chPar;
     std::vector<int32_t> tLen;
     std::vector<uint32_t> tSetSize;
@@ -461,6 +462,19 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     // without set membership on both sides (a plain `search`) the stream stops after the alignments: the sinks get the
     // prefilter rows and alignment records, nothing is aggregated or clustered
     const bool aggregate = Q->setId && Q->posInSet && Q->strand && T.setId && T.posInSet && T.strand;
+    // Predicate pushdown of the fused workflow.  combinehits keeps a best hit only if log P(E) < log(10e-7) after its %.3E text round
+    // trips (combinehits.cpp:101-113), which no alignment with E >= 1.1e-6 survives (sd_agg_add has the arithmetic).  When nothing
+    // but the cluster records leaves this call -- no alignment sink, so no alignment DB is written -- the alignments therefore run
+    // with 1.2e-6 as their E-value gate instead of the user's -e (10 for clustersearch): a pair above it stops after the score
+    // pass, exactly as the reference stops a pair above -e (StripedSmithWaterman.cpp:389-398), and the reverse pass, the traceback,
+    // the record and its backtrace are spent on the ~20 % of the pairs that can reach the result.  The cluster-hit TSV is unchanged
+    // (every hit that passes combinehits has its full record; asserted by the md5s of tests/test_gpu_cli.py and, at the measured
+    // size, by bench.py's back-half parity leg against the reference run with -e 10); the `accepted` counter then counts what
+    // passed the tighter gate.  SD_EVAL_PUSHDOWN=0 runs every pair to the user's -e.
+    const bool pushdown = aggregate && !s->alnSink && !(getenv("SD_EVAL_PUSHDOWN") && atoi(getenv("SD_EVAL_PUSHDOWN")) == 0);
+    s->swParRun = s->swPar;
+    if (pushdown) s->swParRun.evalThr = std::min(s->swPar.evalThr, 1.2e-6);
+    s->stats[S_EVAL_PUSHDOWN] = pushdown ? 1 : 0;
     std::vector<uint32_t> qSetSize(Q->nSets, 0);
     if (aggregate)
         for (uint32_t i = 0; i < Q->n; i++)
@@ -757,7 +771,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             uint64_t used = 0;
             // only the reportable pairs come back (identity pairs + pairs past every gate, ~10 %): everything else
             // fails Alignment::checkCriteria and would be skipped by the aggregation anyway
-            rc = sd_sw_align_batch_compact_diag(ctx, &s->swPar, qset, s->tSeqs, n, d->pairQ.data(), d->pairT.data(), d->pairDiag.data(),
+            rc = sd_sw_align_batch_compact_diag(ctx, &s->swParRun, qset, s->tSeqs, n, d->pairQ.data(), d->pairT.data(), d->pairDiag.data(),
                                                 identAll.data(), B.idx.data(), B.res.data(), &nOut, B.pool.data(), B.pool.size(), &used);
             if (rc == SD_ENOMEM && !exact) {   // the backtrace pool has to grow: repeat with the exact bound
                 uint64_t need = 64;

@@ -170,7 +170,7 @@ def test_sdgpu_clustersearch_eight_ranks_equal_one(gpu, tmp_path):
     from dbutil import SDGPU, sdgpu, sorted_md5
     from iter3_scale import _write_fasta
     from spacedust_amd.synth import make_proteomes, ALPHABET
-    ps = make_proteomes(16, genes_per_proteome=150, seed=0x5ED0 + 8)
+    ps = make_proteomes(16, genes_per_proteome=200, n_families=300, seed=0x5ED0 + 8)
     lut = np.frombuffer(ALPHABET.encode(), np.uint8)
     fa_dir = tmp_path / 'fa'
     os.makedirs(fa_dir)
@@ -187,7 +187,7 @@ def test_sdgpu_clustersearch_eight_ranks_equal_one(gpu, tmp_path):
     assert [p.wait(timeout=900) for p in procs] == [0] * 8
     one = open(tmp_path / 'one.tsv').readlines()
     eight = open(tmp_path / 'eight.tsv').readlines()
-    assert sum(1 for l in one if l.startswith('#')) > 50
+    assert sum(1 for l in one if l.startswith('#')) > 10 and len(one) > 100
     assert sorted_md5(one, drop_first_column=True) == sorted_md5(eight, drop_first_column=True)
     keys = [int(l.split('\t')[0][1:]) for l in eight if l.startswith('#')]
     assert keys == list(range(len(keys)))

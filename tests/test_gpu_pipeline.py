@@ -71,13 +71,22 @@ def test_query_db_differs_from_target_db(gpu, host, tmp_path):
     assert hashlib.md5(''.join(lines).encode()).hexdigest() == '521fe66c5fd4b93b0b3363bd149f9bd7'
 
 
-def test_examples_regression_known_answers(gpu, host, tmp_path):
+@pytest.mark.parametrize('pushdown', ['0', '1'])
+def test_examples_regression_known_answers(gpu, host, tmp_path, monkeypatch, pushdown):
+    """the reference's regression run.  pushdown = 0: every pair aligned to -e 10 (15 065 accepted alignments = the lines of the
+    reference's alignment DB); pushdown = 1, the default of a stream that leaves nothing but cluster records: the alignments gated
+    at combinehits' E-value bound -- fewer accepted alignments, the same TSV byte for byte"""
+    monkeypatch.setenv('SD_EVAL_PUSHDOWN', pushdown)
     db = load_examples(host)
     cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
     out = cs.search(db, same_db=True, tsv_path=str(tmp_path / 'result.tsv'), canonical=True, chunk_queries=3000)
     assert cs.index_entries == 1784989 and cs.masked_residues == 11546
     assert cs.stats['prefilter_hits'] == 98957
-    assert out['accepted'] == 15065
+    assert int(cs._raw_stats()[0][15]) == int(pushdown)
+    if pushdown == '0':
+        assert out['accepted'] == 15065
+    else:
+        assert 308 <= out['accepted'] < 15065
     lines = open(tmp_path / 'result.tsv').readlines()
     n_clu = sum(1 for l in lines if l.count('\t') == 4)
     n_hit = len(lines) - n_clu
@@ -245,11 +254,12 @@ def test_multi_set_aggregation_matches_restatement(gpu, host, oracle, small_prot
         assert got[k_] == expected[k_], k_
 
 
-def test_pipeline_with_k7(gpu, host, oracle, small_proteomes):
+def test_pipeline_with_k7(gpu, host, oracle, small_proteomes, monkeypatch):
     """the search with k = 7 forced (what -k 0 selects from 3.35e9 target residues): hit and accepted-alignment counts
     against the oracle run stage by stage (the oracle's k = 7 prefilter is pinned to the real reference, k7_vectors.npz)"""
     ps = small_proteomes
     db = SetDB.from_proteomes(ps)
+    monkeypatch.setenv('SD_EVAL_PUSHDOWN', '0')   # (the count of alignments accepted at -e 10 is what is compared)
     cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, k=7, filter_self_match=True)
     assert cs.k == 7 and cs.kmer_thr == 122
     out = cs.search(db, same_db=True, chunk_queries=150)

@@ -432,7 +432,9 @@ def test_prefilter_hot_filter_equals_unfiltered(gpu, host, monkeypatch):
     assert int(a[1].sum()) > 30000
     monkeypatch.setenv('SD_PF_FILTER', '1')
     for env in ({}, {'SD_PF_FILTER_MIN': '0'}, {'SD_PF_JOIN': '0'}, {'SD_PF_JOIN': '0', 'SD_PF_FILTER_MIN': '0', 'SD_PF_COARSE': '3000'},
-                {'SD_PF_COARSE': '2000', 'SD_PF_FILTER_MIN': '0'}):
+                {'SD_PF_COARSE': '2000', 'SD_PF_FILTER_MIN': '0'},
+                # the join's ranged scatter (SD_JOIN_RANGES=1: an experiment, off by default) instead of the coarse split behind a per-query scatter
+                {'SD_PF_COARSE': '2000', 'SD_JOIN_RANGES': '1'}, {'SD_PF_COARSE': '20000', 'SD_JOIN_RANGES': '1'}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         b = api.prefilter(gpu, tgt, par, res, off, km_b, dg_b, ident[:nq], want_stats=True)

@@ -166,10 +166,11 @@ def test_profile_prefilter_large_kmer_lists(gpu, host, oracle):
         assert tuple(int(x) for x in st[q]) == tuple(int(x) for x in ost), (q, st[q], ost)
 
 
-def test_pipeline_with_profile_queries(gpu, host, oracle, small_proteomes):
+def test_pipeline_with_profile_queries(gpu, host, oracle, small_proteomes, monkeypatch):
     """one search iteration with a profile query DB through the pipeline (prefilter_profile -> profile SW -> aggregation
     -> clusterhits): prefilter hit count and accepted alignment count against the oracle run stage by stage"""
     from spacedust_amd.pipeline import SetDB, ClusterSearch
+    monkeypatch.setenv('SD_EVAL_PUSHDOWN', '0')   # (the count of alignments accepted at -e 10 is what is compared)
     ps = small_proteomes
     rng = np.random.default_rng(17)
     mat, _, _ = host.matrix(0)

@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--entries', default='')
     ap.add_argument('--check', type=int, default=0, help='also return the reference rows / alignments of this many sample queries')
     ap.add_argument('--check-out', default='')
+    ap.add_argument('--gate-seconds', type=float, default=0.0, help='also time the reference with the pushed-down E-value gate (1.2e-6) for this long')
     ap.add_argument('--check-sets', default='', help='comma-separated query sets (proteomes) whose aggregated entries the reference side computes')
     ap.add_argument('--check-entries', type=int, default=32, help='measured entries of --entries the reference clusterhits functions are run on')
     a = ap.parse_args()
@@ -65,14 +66,21 @@ def main():
         import ctypes as C
         L = ref.lib
         L.ref_run_queries.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t,
-                                      C.c_int, C.c_double, C.c_size_t, C.c_void_p]
+                                      C.c_int, C.c_double, C.c_size_t, C.c_void_p, C.c_double]
         out = np.zeros(8, np.float64)
         smp = np.ascontiguousarray(sample, np.uint32)
         offs = np.ascontiguousarray(ps.offsets, np.uint64)
         L.ref_run_queries(rix.h, blob, offs.ctypes.data, smp.ctypes.data, len(smp), a.kmer_thr, a.max_seqs, n_threads,
-                          a.seconds, db_res, out.ctypes.data)
+                          a.seconds, db_res, out.ctypes.data, 10.0)
         nq, npairs, ncells, dt = int(out[0]), int(out[1]), float(out[2]), float(out[3])
         sw_thread_s = float(out[4])
+        if a.gate_seconds > 0:
+            # the same loop with the E-value gate the device pipeline pushes down from combinehits (identical cluster hits): what the
+            # reference would do if it were run with -e 1.2e-6
+            out2 = np.zeros(8, np.float64)
+            L.ref_run_queries(rix.h, blob, offs.ctypes.data, smp.ctypes.data, len(smp), a.kmer_thr, a.max_seqs, n_threads,
+                              a.gate_seconds, db_res, out2.ctypes.data, 1.2e-6)
+            q_per_s_gate = out2[0] / out2[3] if out2[3] > 0 else 0.0
     else:
         done, pairs, cells = [0] * n_threads, [0] * n_threads, [0] * n_threads
         ready = threading.Barrier(n_threads + 1)
@@ -138,6 +146,9 @@ def main():
             ch_out = dict(ch_entries=np.int64(ch_n), ch_ncl=np.array(ncl, np.int64), ch_cof=np.concatenate(cof_l), ch_rank=np.concatenate(rk_l),
                           ch_size=np.concatenate(sz_l) if sz_l else np.zeros(0, np.uint32), ch_pco=np.concatenate(pco_l), ch_pmh=np.concatenate(pmh_l))
     sec_per_pair = (queries_per_pair / q_per_s if q_per_s > 0 else float('inf')) + ch_per_entry / n_threads
+    value_gate = None
+    if kind == 'reference' and a.gate_seconds > 0 and q_per_s_gate > 0:
+        value_gate = 1.0 / (queries_per_pair / q_per_s_gate + ch_per_entry / n_threads)
     # parity sample for bench.py's post-check: the reference's prefilter rows and alignments of a few sample queries
     if a.check > 0 and a.check_out and kind == 'reference':
         rpf = rix.prefilter(max_len + 2, max_hits=a.max_seqs)
@@ -193,6 +204,9 @@ def main():
                'run on the CPU side; reference index build %.1f s not included'
                % (nq, 'the reference classes' if kind == 'reference' else 'oracle port', P, n_threads, n_threads, os.cpu_count() or 0, dt, ch_n,
                   'the reference functions' if ch_kind == 'reference' else 'oracle restatement', t_index),
+        value_with_pushed_down_evalue_gate=value_gate,
+        evalue_gate_note='value: the reference as it runs, every pair aligned to clustersearch\'s -e 10; value_with_pushed_down_evalue_gate: the same '
+                         'loop with -e 1.2e-6, the bound the device pipeline takes from combinehits (same cluster hits, the work the GPU side does)',
         queries_per_s=q_per_s, sw_gcups=ncells / sw_wall / 1e9 if sw_wall > 0 else 0.0,
         sw_gcups_per_core=ncells / sw_thread_s / 1e9 if sw_thread_s > 0 else None,
         sw_gcups_note='forward cells of the aligned pairs / the time inside the Smith-Waterman calls alone (thread-seconds / threads)',

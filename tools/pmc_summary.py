@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as the PMC slot
 budget requires).  Counter values are KiB per dispatch; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for
-gfx950 (128-B requests tallied at 64 B).  Usage: pmc_summary.py <fetch counter_collection.csv> <write ...csv>"""
+gfx950 (128-B requests tallied at 64 B).  That factor is calibrated for this repo's access patterns
+(tools/fetch_calib.sh -> profiles/r05_fetch_calibration.*): on gfx950 EVERY read request of the L2 is a 128-B one -- also for
+one random 8-B read per lane -- so 2 x FETCH_SIZE = 128 x TCC_EA0_RDREQ_128B exactly in all ten patterns, and WRITE_SIZE is
+exact (32-B and 64-B write requests are tallied apart).  With a third CSV (a pass of TCC_EA0_RDREQ_32B_sum / _64B_sum /
+_128B_sum) the exact byte count is printed beside 2 x FETCH_SIZE per kernel.
+Usage: pmc_summary.py <fetch counter_collection.csv> <write ...csv> [out.json [rdreq ...csv]]"""
 import csv
 import re
 import sys
@@ -14,17 +19,29 @@ def short(name):
     return (m.group(1) if m else name)[:70]
 
 
-def load(path):
+def load(path, counter=None, scale=1.0):
     acc = defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
+        if counter is not None and r.get('Counter_Name') != counter:
+            continue
         a = acc[short(r['Kernel_Name'])]
         a[0] += 1
-        a[1] += float(r['Counter_Value'])
+        a[1] += float(r['Counter_Value']) * scale
     return acc
 
 
-def main(fetch_csv, write_csv):
+def load_exact(path):
+    """bytes per kernel from the per-size read request counters"""
+    tot = defaultdict(float)
+    for name, size in (('TCC_EA0_RDREQ_32B_sum', 32), ('TCC_EA0_RDREQ_64B_sum', 64), ('TCC_EA0_RDREQ_128B_sum', 128)):
+        for k, v in load(path, name, size).items():
+            tot[k] += v[1]
+    return tot
+
+
+def main(fetch_csv, write_csv, exact_csv=None):
     f, w = load(fetch_csv), load(write_csv)
+    ex = load_exact(exact_csv) if exact_csv else {}
     rows = []
     for k in set(f) | set(w):
         n = max(f.get(k, [0, 0])[0], w.get(k, [0, 0])[0])
@@ -32,9 +49,9 @@ def main(fetch_csv, write_csv):
         wb = w.get(k, [0, 0.0])[1] * 1024
         rows.append((fb + wb, k, n, fb, wb))
     rows.sort(reverse=True)
-    print('%-72s %7s %14s %14s %16s' % ('kernel', 'calls', 'fetch_GB(x2)', 'write_GB', 'bytes_per_call'))
+    print('%-72s %7s %14s %14s %16s%s' % ('kernel', 'calls', 'fetch_GB(x2)', 'write_GB', 'bytes_per_call', '   fetch_GB(exact: 32/64/128-B requests)' if ex else ''))
     for tot, k, n, fb, wb in rows[:40]:
-        print('%-72s %7d %14.3f %14.3f %16.0f' % (k, n, fb / 1e9, wb / 1e9, tot / max(n, 1)))
+        print('%-72s %7d %14.3f %14.3f %16.0f%s' % (k, n, fb / 1e9, wb / 1e9, tot / max(n, 1), '   %14.3f' % (ex.get(k, 0.0) / 1e9) if ex else ''))
 
 
 # first match wins: the oversize-bucket launch of bucket_match is its own group (bench.py times it as prefilter_bucket_match_big)
@@ -69,6 +86,6 @@ def to_json(fetch_csv, write_csv, out_path):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[4] if len(sys.argv) > 4 else None)
     if len(sys.argv) > 3:
         to_json(sys.argv[1], sys.argv[2], sys.argv[3])

@@ -48,10 +48,44 @@ def main(path, min_gap_us=5.0):
             print('   %8.1f ms in %5d gaps (avg %7.0f us)  %s -> %s' % (g / 1e3, c, g / c, n0, n1))
 
 
+def union_busy(path):
+    """how much of the time between the first and the last kernel of the busiest half of the trace at least one kernel runs, and how
+    many run at once on average -- the device's idle time (no kernel of any stream) is what more overlap could still fill"""
+    db = sqlite3.connect(path)
+    rows = db.execute('select start, end from kernels order by start').fetchall()
+    if not rows:
+        return
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    # the window: the second half of the trace (the timed steps of bench.py; generation and index build come first)
+    w0 = t0 + (t1 - t0) // 2
+    ev = []
+    for a, b in rows:
+        a, b = max(a, w0), min(b, t1)
+        if b > a:
+            ev.append((a, 1))
+            ev.append((b, -1))
+    ev.sort()
+    cur, last, busy, area = 0, w0, 0, 0
+    for t, d in ev:
+        if cur > 0:
+            busy += t - last
+        area += cur * (t - last)
+        last = t
+        cur += d
+    span = t1 - w0
+    print('second half of the trace (%.1f ms): at least one kernel running %.1f %% of the time, %.2f kernels at once on average'
+          % (span / 1e6, 100.0 * busy / span, area / span))
+
+
 def timeline(path, stream, first, count):
     """kernels first .. first + count of one stream in start order: gap before, duration, name, grid"""
     db = sqlite3.connect(path)
-    rows = db.execute('select name, start, end, grid_x from kernels where stream_id = ? order by start', (stream,)).fetchall()
+    cols = [r[1] for r in db.execute('pragma table_info(kernels)')]
+    grid = 'grid_x' if 'grid_x' in cols else ('grid_size_x' if 'grid_size_x' in cols else 'workgroup_x')
+    sid = next((c for c in ('stream_id', 'stream', 'queue_id', 'queue') if c in cols), None)
+    rows = db.execute('select name, start, end, %s from kernels where %s = ? order by start' % (grid, sid), (stream,)).fetchall()
+    if first < 0:   # count kernels from the middle of the stream
+        first = max(0, len(rows) // 2 - count // 2)
     prev = None
     for n, a, b, g in rows[first:first + count]:
         print('%9.3f ms  gap %8.1f us  dur %8.1f us  grid %9d  %s' % ((a - rows[0][1]) / 1e6, (a - prev) / 1e3 if prev else 0.0, (b - a) / 1e3, g, short(n)))
@@ -63,3 +97,4 @@ if __name__ == '__main__':
         timeline(sys.argv[1], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     else:
         main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 5.0)
+        union_busy(sys.argv[1])
