@@ -139,6 +139,22 @@ int sd_sw_align_batch_compact_diag(sd_ctx *ctx, const sd_sw_params *par, const s
 /* Same contract and results as sd_sw_align_batch, with the gating / task building between the passes done on
  * the host (one device round trip per pass).  Kept as the A/B cross-check of the device-resident orchestration
  * (tests/test_gpu_sw.py); btOffset values may differ, the bytes they point to may not. */
+/* ---- besthitbyset on the device (R/src/util/besthitbyset.cpp:41-144 with --simple-best-hit 1) ----------------------
+ * sd_seqset_set_groups: the target set of every sequence of a (target) sequence set (createsetdb's set membership) and,
+ * optionally, its DB key (Matcher::compareHits' last criterion; NULL: the index), resident beside the sequences.
+ * sd_sw_align_batch_best_by_group = sd_sw_align_batch_compact_diag whose returned records are restricted to what besthitbyset
+ * can keep: identity pairs, and per (query, target set) the ONE accepted alignment that Matcher::compareHits (Matcher.h:157-168)
+ * orders first -- smallest E-value, i.e. for one query the largest score, then the shorter target, then the smaller key.
+ * "Accepted" is Alignment::checkCriteria (Alignment.cpp:548-567) with the E-value, coverage mode / threshold of `par` and the
+ * sequence-identity and alignment-length thresholds given here.  Every other pair is computed as before but its record and its
+ * backtrace stay on the device (at proteome scale: a third of the records, more where a target set holds paralogs).  The caller's
+ * own best-hit selection over what comes back gives what it gave over all records. */
+int sd_seqset_set_groups(sd_seqset *s, const uint32_t *groupOf, uint32_t nGroups, const uint32_t *keys);
+int sd_sw_align_batch_best_by_group(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                                    uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint16_t *pairDiag,
+                                    const uint8_t *isIdentity, float seqIdThr, int32_t alnLenThr, uint32_t *outIdx, sd_sw_result *out,
+                                    uint32_t *nOut, char *btPool, uint64_t btCap, uint64_t *btUsed);
+
 int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
                                uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
                                sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed);

@@ -291,6 +291,9 @@ struct sd_seqset {
     int32_t maxEntryAdd = 0;      // largest composition bias of the set (sequences) / largest profile entry (profile sets)
     std::vector<uint8_t> hRes;    // host copy (traceback identity count, scoreIdentical)
     std::vector<int8_t> hBias;
+    uint32_t *dGroupOf = nullptr, *dGroupKey = nullptr;   // sd_seqset_set_groups: target set and DB key of every sequence
+    size_t bGroupOf = 0, bGroupKey = 0;
+    uint32_t nGroups = 0;
 };
 
 // the target side of the prefilter, resident in HBM (built by sd_target_create* from host arrays or by sd_target_build on the device)

@@ -1312,6 +1312,66 @@ k_bt_pack(uint32_t nPairs, const uint64_t *__restrict__ btLen, const uint64_t *_
     if (lane == 0) res[i].btOffset = poolBase + dense[i];
 }
 
+// ---- besthitbyset on the device (sd_sw_align_batch_best_by_group).  Matcher::compareHits orders a query's accepted alignments by
+// E-value, rounded bit score, target length, target key; for one query the E-value is a strictly decreasing function of the score
+// and the bit score a function of it, so the first of a (query, target set) cell is the maximum of
+//   score << 44 | (0xFFFF - target length) << 28 | (0x0FFFFFFF - key)
+// over the cell's accepted pairs: one atomic maximum per pair into a table of queries x target sets, then a second look.
+struct BestByGroup {
+    const uint32_t *groupOf, *groupKey;   // per target sequence (groupKey nullable: the index)
+    uint32_t nGroups;
+    float seqIdThr, covThr;
+    int alnLenThr, covMode;
+    double evalThr;
+};
+__device__ __forceinline__ float bbCov(uint32_t startPos, uint32_t endPos, uint32_t len) {   // sd::computeCov (Util::computeCov)
+    return (float) (min(len, max(startPos, endPos)) - min(startPos, endPos) + 1u) / (float) len;
+}
+__device__ __forceinline__ bool bbAccepted(const sd_sw_result &r, const BestByGroup &B, uint32_t qL, uint32_t tL) {
+    if (r.btLen <= 0 || r.qStart < 0 || r.tStart < 0) return false;   // stopped at a gate
+    const float qcov = bbCov((uint32_t) r.qStart, (uint32_t) r.qEnd, qL), dbcov = bbCov((uint32_t) r.tStart, (uint32_t) r.tEnd, tL);
+    const float seqId = (float) r.identical / (float) r.btLen;
+    bool cov = true;
+    if (B.covMode == 0) cov = qcov >= B.covThr && dbcov >= B.covThr;
+    else if (B.covMode == 2) cov = qcov >= B.covThr;
+    else if (B.covMode == 1) cov = dbcov >= B.covThr;
+    // (the device's E-value stands within 1e-15 of the host's: a pair inside that band of the threshold is the worst of its cell
+    // and can only be the maximum where nothing better exists, so keeping it costs a record and never displaces one)
+    return r.evalue <= B.evalThr * (1.0 + 1e-9) && seqId >= B.seqIdThr && cov && r.btLen >= B.alnLenThr;
+}
+__device__ __forceinline__ unsigned long long bbPack(const sd_sw_result &r, uint32_t tL, uint32_t key) {
+    return ((unsigned long long) min((uint32_t) r.score, 0xFFFFFu) << 44) | ((unsigned long long) (0xFFFFu - min(tL, 0xFFFFu)) << 28) |
+           (unsigned long long) (0x0FFFFFFFu - min(key, 0x0FFFFFFFu));
+}
+__global__ void __launch_bounds__(256)
+k_best_mark(uint32_t nPairs, const sd_sw_result *__restrict__ res, const uint8_t *__restrict__ ident, const uint32_t *__restrict__ pq,
+            const uint32_t *__restrict__ pt, const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, BestByGroup B,
+            unsigned long long *__restrict__ table) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs || ident[i]) return;
+    const uint32_t q = pq[i], t = pt[i];
+    const uint32_t qL = (uint32_t) (qOff[q + 1] - qOff[q]), tL = (uint32_t) (tOff[t + 1] - tOff[t]);
+    const sd_sw_result r = res[i];
+    if (!bbAccepted(r, B, qL, tL)) return;
+    atomicMax(&table[(size_t) q * B.nGroups + B.groupOf[t]], bbPack(r, tL, B.groupKey ? B.groupKey[t] : t));
+}
+// a pair that is neither an identity pair nor the first of its cell leaves no record and no backtrace
+__global__ void __launch_bounds__(256)
+k_best_keep(uint32_t nPairs, sd_sw_result *__restrict__ res, const uint8_t *__restrict__ ident, const uint32_t *__restrict__ pq,
+            const uint32_t *__restrict__ pt, const uint64_t *__restrict__ qOff, const uint64_t *__restrict__ tOff, BestByGroup B,
+            const unsigned long long *__restrict__ table, uint64_t *__restrict__ btLen) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPairs || ident[i]) return;
+    const uint32_t q = pq[i], t = pt[i];
+    const uint32_t qL = (uint32_t) (qOff[q + 1] - qOff[q]), tL = (uint32_t) (tOff[t + 1] - tOff[t]);
+    const sd_sw_result r = res[i];
+    const bool keep = bbAccepted(r, B, qL, tL) && table[(size_t) q * B.nGroups + B.groupOf[t]] == bbPack(r, tL, B.groupKey ? B.groupKey[t] : t);
+    if (!keep) {
+        res[i].btLen = 0;
+        btLen[i] = 0;
+    }
+}
+
 // compact mode: which records go back to the host
 __global__ void __launch_bounds__(256)
 k_accept(uint32_t nPairs, const sd_sw_result *__restrict__ res, const uint8_t *__restrict__ ident, uint8_t *__restrict__ acc) {
@@ -1917,7 +1977,26 @@ void sd_seqset_destroy(sd_seqset *s) {
     poolPut(s->ctx, s->dProf, s->bProf);
     poolPut(s->ctx, s->dBias, s->bBias);
     poolPut(s->ctx, s->dOff, s->bOff);
+    poolPut(s->ctx, s->dGroupOf, s->bGroupOf);
+    poolPut(s->ctx, s->dGroupKey, s->bGroupKey);
     delete s;
+}
+
+int sd_seqset_set_groups(sd_seqset *s, const uint32_t *groupOf, uint32_t nGroups, const uint32_t *keys) {
+    if (!s || !groupOf || nGroups == 0) return SD_EINVAL;
+    sd_ctx *ctx = s->ctx;
+    (void) hipSetDevice(ctx->device);
+    for (uint32_t i = 0; i < s->n; i++)
+        if (groupOf[i] >= nGroups) return sdFail(ctx, SD_EINVAL, "sd_seqset_set_groups: sequence %u is in group %u of %u", i, groupOf[i], nGroups);
+    if (!s->dGroupOf && poolGet(ctx, (size_t) (s->n + 1) * sizeof(uint32_t), (void **) &s->dGroupOf, &s->bGroupOf) != hipSuccess)
+        return sdFail(ctx, SD_ENOMEM, "sd_seqset_set_groups: device allocation failed");
+    if (keys && !s->dGroupKey && poolGet(ctx, (size_t) (s->n + 1) * sizeof(uint32_t), (void **) &s->dGroupKey, &s->bGroupKey) != hipSuccess)
+        return sdFail(ctx, SD_ENOMEM, "sd_seqset_set_groups: device allocation failed");
+    SD_HIP(ctx, hipMemcpyAsync(s->dGroupOf, groupOf, (size_t) s->n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (keys) SD_HIP(ctx, hipMemcpyAsync(s->dGroupKey, keys, (size_t) s->n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(ctx, sdStreamSync(ctx));
+    s->nGroups = nGroups;
+    return SD_OK;
 }
 
 int sd_sw_last_cells(sd_ctx *ctx, uint64_t *f, uint64_t *r, uint64_t *t) {
@@ -1976,7 +2055,8 @@ int sd_sw_score_batch(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *que
 static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
                           uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
                           sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed, uint32_t *compactIdx,
-                          uint32_t *nCompact, const uint16_t *pairDiag = nullptr /* the prefilter's diagonal of every pair (nullable) */) {
+                          uint32_t *nCompact, const uint16_t *pairDiag = nullptr /* the prefilter's diagonal of every pair (nullable) */,
+                          const float *bestBy = nullptr /* non-null: {seqIdThr, alnLenThr}: sd_sw_align_batch_best_by_group */) {
     if (!ctx || !par || !queries || !targets || !out) return SD_EINVAL;
     if (compactIdx && (!nCompact || par->swMode != 2)) return sdFail(ctx, SD_EINVAL, "the compact variants need swMode 2 (records with backtraces)");
     (void) hipSetDevice(ctx->device);
@@ -2274,6 +2354,29 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
                 (unsigned long long) nDone, (unsigned long long) final14, (unsigned long long) init6, (unsigned long long) init6final6,
                 (unsigned long long) init6final14);
     }
+    // ---- besthitbyset on the device: only identity pairs and the first accepted alignment of every (query, target set) cell keep
+    // their record and their backtrace (a table of queries x target sets; beyond 2^27 cells the call returns everything)
+    if (bestBy && compactIdx && targets->dGroupOf && (uint64_t) queries->n * targets->nGroups <= (1ull << 27)) {
+        BestByGroup B;
+        B.groupOf = targets->dGroupOf;
+        B.groupKey = targets->dGroupKey;
+        B.nGroups = targets->nGroups;
+        B.seqIdThr = bestBy[0];
+        B.alnLenThr = (int) bestBy[1];
+        B.covThr = par->covThr;
+        B.covMode = par->covMode;
+        B.evalThr = par->evalThr;
+        unsigned long long *dTable = nullptr;
+        const size_t cellsN = (size_t) queries->n * targets->nGroups;
+        SD_HIP(ctx, wsGet(ctx, "al.besttable", cellsN, &dTable));
+        SD_HIP(ctx, hipMemsetAsync(dTable, 0, cellsN * sizeof(unsigned long long), ctx->stream));
+        ProfScope ps(ctx, "align_best_by_group");
+        hipLaunchKernelGGL(k_best_mark, dim3(grid), dim3(256), 0, ctx->stream, nPairs, (const sd_sw_result *) dRes, (const uint8_t *) dIdent,
+                           (const uint32_t *) dPQ, (const uint32_t *) dPT, (const uint64_t *) queries->dOff, (const uint64_t *) targets->dOff, B, dTable);
+        hipLaunchKernelGGL(k_best_keep, dim3(grid), dim3(256), 0, ctx->stream, nPairs, dRes, (const uint8_t *) dIdent, (const uint32_t *) dPQ,
+                           (const uint32_t *) dPT, (const uint64_t *) queries->dOff, (const uint64_t *) targets->dOff, B,
+                           (const unsigned long long *) dTable, dBtLen);
+    }
     // ---- dense backtrace pool + results back to the host
     hs.reset(new HostScope(ctx, "align.download"));
     rc = devExclusiveScan(ctx, dBtLen, dDense, N + 1);
@@ -2428,6 +2531,16 @@ int sd_sw_align_batch_compact_diag(sd_ctx *ctx, const sd_sw_params *par, const s
                                    uint64_t btCap, uint64_t *btUsed) {
     if (!outIdx || !nOut) return SD_EINVAL;
     return alignBatchImpl(ctx, par, queries, targets, nPairs, pairQ, pairT, isIdentity, out, btPool, btCap, btUsed, outIdx, nOut, pairDiag);
+}
+
+int sd_sw_align_batch_best_by_group(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
+                                    uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint16_t *pairDiag,
+                                    const uint8_t *isIdentity, float seqIdThr, int32_t alnLenThr, uint32_t *outIdx, sd_sw_result *out,
+                                    uint32_t *nOut, char *btPool, uint64_t btCap, uint64_t *btUsed) {
+    if (!outIdx || !nOut || !targets) return SD_EINVAL;
+    if (!targets->dGroupOf) return sdFail(ctx, SD_EINVAL, "sd_sw_align_batch_best_by_group: the target set has no groups (sd_seqset_set_groups)");
+    const float bb[2] = {seqIdThr, (float) alnLenThr};
+    return alignBatchImpl(ctx, par, queries, targets, nPairs, pairQ, pairT, isIdentity, out, btPool, btCap, btUsed, outIdx, nOut, pairDiag, bb);
 }
 
 int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,

@@ -162,6 +162,8 @@ struct sd_search {
     sd_prefilter_params pfPar;
     sd_sw_params swPar;
     sd_sw_params swParRun;   // swPar with the E-value gate of the running stream (sd_search_stream: predicate pushdown)
+    bool targetHasGroups = false;   // sd_seqset_set_groups was applied to tSeqs
+    bool bestOnDevice = false;      // the running stream lets the device keep only besthitbyset's candidates
     sd_ch_params chPar;
     std::vector<int32_t> tLen;
     std::vector<uint32_t> tSetSize;
@@ -361,6 +363,11 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     }
     rc = sd_seqset_create(s->ctxAl, target->residues, target->offsets, target->n, nullptr, &s->tSeqs);
     if (rc != SD_OK) return rc;
+    if (target->setId && target->nSets > 0) {   // besthitbyset on the device needs the set (and DB key) of every target beside the sequences
+        rc = sd_seqset_set_groups(s->tSeqs, target->setId, target->nSets, target->keys);
+        if (rc != SD_OK) return rc;
+        s->targetHasGroups = true;
+    }
     s->seconds[T_UPLOAD] = nowSec() - t0;
     {   // a target that fills most of the device (10 000 proteomes: 84 GB of index + sequences) leaves room for one prefilter
         // and one alignment workspace, not two of each
@@ -475,6 +482,10 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     s->swParRun = s->swPar;
     if (pushdown) s->swParRun.evalThr = std::min(s->swPar.evalThr, 1.2e-6);
     s->stats[S_EVAL_PUSHDOWN] = pushdown ? 1 : 0;
+    // The same streams also leave besthitbyset's choice to the device: of a query's accepted alignments only the first per target
+    // set (Matcher::compareHits order) and the identity pair come back (sd_sw_align_batch_best_by_group); the aggregation's own
+    // selection over those gives what it gave over all records.  SD_BEST_ON_DEVICE=0: every accepted record comes back.
+    s->bestOnDevice = pushdown && s->targetHasGroups && !(getenv("SD_BEST_ON_DEVICE") && atoi(getenv("SD_BEST_ON_DEVICE")) == 0);
     std::vector<uint32_t> qSetSize(Q->nSets, 0);
     if (aggregate)
         for (uint32_t i = 0; i < Q->n; i++)
@@ -771,6 +782,11 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             uint64_t used = 0;
             // only the reportable pairs come back (identity pairs + pairs past every gate, ~10 %): everything else
             // fails Alignment::checkCriteria and would be skipped by the aggregation anyway
+            if (s->bestOnDevice)
+                rc = sd_sw_align_batch_best_by_group(ctx, &s->swParRun, qset, s->tSeqs, n, d->pairQ.data(), d->pairT.data(), d->pairDiag.data(),
+                                                     identAll.data(), 0.0f /* sd_agg: no --min-seq-id on this path */, s->par.alnLenThr, B.idx.data(), B.res.data(), &nOut,
+                                                     B.pool.data(), B.pool.size(), &used);
+            else
             rc = sd_sw_align_batch_compact_diag(ctx, &s->swParRun, qset, s->tSeqs, n, d->pairQ.data(), d->pairT.data(), d->pairDiag.data(),
                                                 identAll.data(), B.idx.data(), B.res.data(), &nOut, B.pool.data(), B.pool.size(), &used);
             if (rc == SD_ENOMEM && !exact) {   // the backtrace pool has to grow: repeat with the exact bound

@@ -284,3 +284,31 @@ def test_pipeline_with_k7(gpu, host, oracle, small_proteomes, monkeypatch):
     assert cs.stats['prefilter_hits'] == n_hits, (cs.stats['prefilter_hits'], n_hits)
     assert out['accepted'] == n_acc, (out['accepted'], n_acc)
     assert n_acc > ps.n
+
+
+def test_best_hit_by_set_on_the_device_equals_host_selection(gpu, host, monkeypatch):
+    """besthitbyset's choice left to the device (sd_sw_align_batch_best_by_group: per (query, target set) only the first accepted
+    alignment in Matcher::compareHits order and the identity pair come back) against the host's selection over all accepted records:
+    proteomes with few families, so that a target set holds several homologs of a query (paralogs: up to a dozen candidates per
+    cell, equal scores included) -- the same entries, hits, P-value bits and clusters; fewer records cross the bus"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(5, genes_per_proteome=400, n_families=60, seed=77)
+    db = SetDB.from_proteomes(ps)
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('SD_BEST_ON_DEVICE', mode)
+        cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
+        outs[mode] = cs.search(db, same_db=True, chunk_queries=500)
+        del cs
+    a, b = outs['0'], outs['1']
+    assert a['matched_hits'] > 1000 and a['clusters'] > 20
+    assert b['accepted'] < a['accepted']   # (what the aggregation saw)
+    for k_ in ('entries', 'matched_hits', 'clusters', 'cluster_hits'):
+        assert a[k_] == b[k_], k_
+    for k_ in ('entry_q', 'entry_t', 'entry_off', 'hit_q', 'hit_t'):
+        assert np.array_equal(a[k_], b[k_]), k_
+    assert a['hit_pval'].tobytes() == b['hit_pval'].tobytes()
+    for k_ in ('cluster_of', 'rank', 'n_clusters', 'size'):
+        assert np.array_equal(a['cluster_out'][k_], b['cluster_out'][k_]), k_
+    assert a['cluster_out']['pCO'].tobytes() == b['cluster_out']['pCO'].tobytes()
+    assert a['cluster_out']['pMH'].tobytes() == b['cluster_out']['pMH'].tobytes()
