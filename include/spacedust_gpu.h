@@ -155,6 +155,14 @@ int sd_sw_align_batch_best_by_group(sd_ctx *ctx, const sd_sw_params *par, const 
                                     const uint8_t *isIdentity, float seqIdThr, int32_t alnLenThr, uint32_t *outIdx, sd_sw_result *out,
                                     uint32_t *nOut, char *btPool, uint64_t btCap, uint64_t *btUsed);
 
+/* ---- self-test entry points of the library's own device primitives (csrc/hip/sd_scan_sort.h), for tests/ ----------------------
+ * sd_selftest_sort_pairs: stable sort of (key, value) pairs by the key bits [beginBit, endBit) -- what the alignment task order and
+ * the prefilter's fall-back paths use.  sd_selftest_scan: exclusive sums of n 32-bit values into 64-bit offsets (n + 1 outputs: the
+ * total last) and, with runningMax != NULL, the inclusive running maximum of the same values. */
+int sd_selftest_sort_pairs(sd_ctx *ctx, const uint32_t *keys, const uint32_t *vals, uint32_t n, int beginBit, int endBit, uint32_t *outKeys,
+                           uint32_t *outVals);
+int sd_selftest_scan(sd_ctx *ctx, const uint32_t *in, uint32_t n, uint64_t *exclusiveSum, uint32_t *runningMax);
+
 int sd_sw_align_batch_hostpath(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
                                uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint8_t *isIdentity,
                                sd_sw_result *out, char *btPool, uint64_t btCap, uint64_t *btUsed);

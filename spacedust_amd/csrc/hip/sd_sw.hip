@@ -2533,6 +2533,50 @@ int sd_sw_align_batch_compact_diag(sd_ctx *ctx, const sd_sw_params *par, const s
     return alignBatchImpl(ctx, par, queries, targets, nPairs, pairQ, pairT, isIdentity, out, btPool, btCap, btUsed, outIdx, nOut, pairDiag);
 }
 
+int sd_selftest_sort_pairs(sd_ctx *ctx, const uint32_t *keys, const uint32_t *vals, uint32_t n, int beginBit, int endBit, uint32_t *outKeys,
+                           uint32_t *outVals) {
+    if (!ctx || (n && (!keys || !vals || !outKeys || !outVals)) || beginBit < 0 || endBit > 32 || beginBit >= endBit) return SD_EINVAL;
+    if (n == 0) return SD_OK;
+    (void) hipSetDevice(ctx->device);
+    DevBuf<uint32_t> kIn, vIn, kOut, vOut, kTmp, vTmp, cnt;
+    SD_HIP(ctx, kIn.alloc(n));
+    SD_HIP(ctx, vIn.alloc(n));
+    SD_HIP(ctx, kOut.alloc(n));
+    SD_HIP(ctx, vOut.alloc(n));
+    SD_HIP(ctx, kTmp.alloc(n));
+    SD_HIP(ctx, vTmp.alloc(n));
+    SD_HIP(ctx, cnt.alloc(sdRadixSortCountsBytes() / sizeof(uint32_t)));
+    SD_HIP(ctx, hipMemcpy(kIn.p, keys, (size_t) n * 4, hipMemcpyHostToDevice));
+    SD_HIP(ctx, hipMemcpy(vIn.p, vals, (size_t) n * 4, hipMemcpyHostToDevice));
+    SD_HIP(ctx, sdRadixSortPairs(ctx->stream, kIn.p, vIn.p, kOut.p, vOut.p, kTmp.p, vTmp.p, n, beginBit, endBit, cnt.p));
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SD_HIP(ctx, hipMemcpy(outKeys, kOut.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    SD_HIP(ctx, hipMemcpy(outVals, vOut.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+int sd_selftest_scan(sd_ctx *ctx, const uint32_t *in, uint32_t n, uint64_t *exclusiveSum, uint32_t *runningMax) {
+    if (!ctx || !in || !exclusiveSum || n == 0) return SD_EINVAL;
+    (void) hipSetDevice(ctx->device);
+    DevBuf<uint32_t> dIn, dMax;
+    DevBuf<uint64_t> dOut;
+    SD_HIP(ctx, dIn.alloc((size_t) n + 1));
+    SD_HIP(ctx, dOut.alloc((size_t) n + 1));
+    SD_HIP(ctx, hipMemset(dIn.p, 0, ((size_t) n + 1) * 4));
+    SD_HIP(ctx, hipMemcpy(dIn.p, in, (size_t) n * 4, hipMemcpyHostToDevice));
+    int rc = devExclusiveScan(ctx, (const uint32_t *) dIn.p, dOut.p, (size_t) n + 1);
+    if (rc != SD_OK) return rc;
+    if (runningMax) {
+        SD_HIP(ctx, dMax.alloc(n));
+        rc = devInclusiveMax(ctx, dIn.p, dMax.p, n);
+        if (rc != SD_OK) return rc;
+    }
+    SD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SD_HIP(ctx, hipMemcpy(exclusiveSum, dOut.p, ((size_t) n + 1) * 8, hipMemcpyDeviceToHost));
+    if (runningMax) SD_HIP(ctx, hipMemcpy(runningMax, dMax.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
 int sd_sw_align_batch_best_by_group(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset *queries, const sd_seqset *targets,
                                     uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint16_t *pairDiag,
                                     const uint8_t *isIdentity, float seqIdThr, int32_t alnLenThr, uint32_t *outIdx, sd_sw_result *out,
