@@ -3271,8 +3271,12 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     {
                         ProfScope ps(ctx, "prefilter_hot_filter");
                         const int geo = getenv("SD_PF_HF") ? atoi(getenv("SD_PF_HF")) : 0;
-                        // SD_PF_HF_PERSIST=n: n workgroups per CU that loop over the segments instead of one workgroup per segment
-                        const int hfPersist = getenv("SD_PF_HF_PERSIST") ? atoi(getenv("SD_PF_HF_PERSIST")) : 0;
+                        // One workgroup per CU that loops over the segments (SD_PF_HF_PERSIST=n: n per CU, 0: one workgroup per segment).  A
+                        // 128-KB workgroup needs a drained CU; beside the score wavefronts of the other streams every new workgroup waited for
+                        // one again, the persistent one keeps the CU it has waited for.  Round 5, interleaved runs on one box: the kernel's
+                        // time inside the pipeline 7 - 11 s -> 2.7 s per 14 steps at 1 000 proteomes, 2 417 -> 2 444 genome-pairs/s (three runs
+                        // each), 1 905 -> 1 929 at 100 proteomes (round 4 had measured the same kernel time and no gain in throughput)
+                        const int hfPersist = getenv("SD_PF_HF_PERSIST") ? atoi(getenv("SD_PF_HF_PERSIST")) : 1;
                         const uint32_t hfGrid = hfPersist > 0 ? std::min<uint32_t>(nVQ, (uint32_t) hfPersist * (uint32_t) ctx->prop.multiProcessorCount) : nVQ;
 #define SD_HF(NT_, BW_, HL_)                                                                                                              \
     hipLaunchKernelGGL((hot_filter_kernel<NT_, BW_, HL_>), dim3(hfGrid), dim3(NT_), 0, ctx->stream, nVQ, pHitBase, tBitsV, (uint32_t *) pKey, \
