@@ -1562,12 +1562,15 @@ segment_match_kernel(uint32_t nVQ, const uint64_t *__restrict__ segBase, const u
                      int vqShift, int wpBits) {
     __shared__ unsigned long long sk[CAP];
     __shared__ uint32_t part[NT / 64 + 1];
-    const uint32_t q = blockIdx.x;
     const int t = threadIdx.x;
+    // a workgroup takes the segments blockIdx.x, blockIdx.x + gridDim.x, ...: the caller launches a few workgroups per CU that keep the
+    // CU they have waited for (64 KB of LDS beside the score wavefronts of the other streams) instead of one per segment
+    for (uint32_t q = blockIdx.x; q < nVQ; q += gridDim.x) {
+    __syncthreads();   // (the previous segment's last reads of sk / part)
     const uint32_t n = segCount[q];
     if (n > (uint32_t) CAP) {
         if (t == 0) segDone[q] = 0;
-        return;
+        continue;
     }
     const size_t slot = (size_t) q * PF_NB_MAX;
     const uint64_t ob = outBase[q];
@@ -1577,7 +1580,7 @@ segment_match_kernel(uint32_t nVQ, const uint64_t *__restrict__ segBase, const u
         bktCount[slot] = 0;
         bktStart[slot] = ob;
     }
-    if (n == 0) return;   // bktEmit[slot] stays 0 (cleared by the caller)
+    if (n == 0) continue;   // bktEmit[slot] stays 0 (cleared by the caller)
     const uint64_t s = segBase[q];
     const uint32_t tMask = (1u << tBits) - 1;
     const bool WP = wpBits != 0;
@@ -1675,6 +1678,7 @@ segment_match_kernel(uint32_t nVQ, const uint64_t *__restrict__ segBase, const u
         uint32_t tot = 0;
         for (int wv = 0; wv < NT / 64; wv++) tot += part[wv];
         bktEmit[slot] = tot;
+    }
     }
 }
 
@@ -3347,7 +3351,12 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     // filtered segments that fit the LDS sorter are matched as a whole; the rest goes through partition / bucket_match
                     SD_HIP(ctx, dSegDone.alloc((size_t) nVQ + 1));
                     ProfScope ps(ctx, "prefilter_segment_match");
-                    hipLaunchKernelGGL((segment_match_kernel<512, 8192>), dim3(nVQ), dim3(512), 0, ctx->stream, nVQ, pHitBase, pSegCount, pOutBase,
+                    // (SD_PF_SM_PERSIST=n: n workgroups per CU looping over the segments; default one workgroup per segment -- measured
+                    // round 5, interleaved: the kernel's in-pipeline time 3.5 - 3.9 s -> 1.5 s per 14 steps with n = 1 or 2, the throughput
+                    // 2 347 / 2 436 (0) vs 2 434 (1) vs 2 225 / 2 330 (2): the waiting moves to the other kernels)
+                    const int smPersist = getenv("SD_PF_SM_PERSIST") ? atoi(getenv("SD_PF_SM_PERSIST")) : 0;
+                    const uint32_t smGrid = smPersist > 0 ? std::min<uint32_t>(nVQ, (uint32_t) smPersist * (uint32_t) ctx->prop.multiProcessorCount) : nVQ;
+                    hipLaunchKernelGGL((segment_match_kernel<512, 8192>), dim3(smGrid), dim3(512), 0, ctx->stream, nVQ, pHitBase, pSegCount, pOutBase,
                                        tBitsV, pKey, pVal, pKV, outK, outV, dQLog2.p, dBktStart.p, dBktCount.p, dBktEmit.p, dSegDone.p,
                                        (const uint32_t *) dQSplit.p, (const uint32_t *) dQParts.p, (const uint32_t *) dQSplits.p, cBits,
                                        widePos ? tBitsV : 0);
