@@ -1988,6 +1988,11 @@ int sd_seqset_set_groups(sd_seqset *s, const uint32_t *groupOf, uint32_t nGroups
     (void) hipSetDevice(ctx->device);
     for (uint32_t i = 0; i < s->n; i++)
         if (groupOf[i] >= nGroups) return sdFail(ctx, SD_EINVAL, "sd_seqset_set_groups: sequence %u is in group %u of %u", i, groupOf[i], nGroups);
+    // the selection key carries 28 bits of the DB key (or of the index): larger keys cannot break ties there, so such a set keeps
+    // every accepted record for the caller's own selection (sd_sw_align_batch_best_by_group then returns what _compact_diag returns)
+    bool keysFit = s->n <= 0x0FFFFFFFu;
+    if (keys)
+        for (uint32_t i = 0; i < s->n && keysFit; i++) keysFit = keys[i] < 0x0FFFFFFFu;
     if (!s->dGroupOf && poolGet(ctx, (size_t) (s->n + 1) * sizeof(uint32_t), (void **) &s->dGroupOf, &s->bGroupOf) != hipSuccess)
         return sdFail(ctx, SD_ENOMEM, "sd_seqset_set_groups: device allocation failed");
     if (keys && !s->dGroupKey && poolGet(ctx, (size_t) (s->n + 1) * sizeof(uint32_t), (void **) &s->dGroupKey, &s->bGroupKey) != hipSuccess)
@@ -1995,7 +2000,7 @@ int sd_seqset_set_groups(sd_seqset *s, const uint32_t *groupOf, uint32_t nGroups
     SD_HIP(ctx, hipMemcpyAsync(s->dGroupOf, groupOf, (size_t) s->n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     if (keys) SD_HIP(ctx, hipMemcpyAsync(s->dGroupKey, keys, (size_t) s->n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(ctx, sdStreamSync(ctx));
-    s->nGroups = nGroups;
+    s->nGroups = keysFit ? nGroups : 0;
     return SD_OK;
 }
 
@@ -2356,7 +2361,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     }
     // ---- besthitbyset on the device: only identity pairs and the first accepted alignment of every (query, target set) cell keep
     // their record and their backtrace (a table of queries x target sets; beyond 2^27 cells the call returns everything)
-    if (bestBy && compactIdx && targets->dGroupOf && (uint64_t) queries->n * targets->nGroups <= (1ull << 27)) {
+    if (bestBy && compactIdx && targets->dGroupOf && targets->nGroups > 0 && (uint64_t) queries->n * targets->nGroups <= (1ull << 27)) {
         BestByGroup B;
         B.groupOf = targets->dGroupOf;
         B.groupKey = targets->dGroupKey;
