@@ -52,7 +52,7 @@ def parse():
     ap.add_argument('--proteomes', type=int, default=1000)   # the size north_star quotes its target on (BASELINE configs[2], one GPU)
     ap.add_argument('--genes', type=int, default=3000)
     ap.add_argument('--batch', type=int, default=0, help='query proteomes per rank and step (default: 4 at 1 000 proteomes and beyond, else 10)')
-    ap.add_argument('--chunk', type=int, default=10000, help='queries per device chunk')
+    ap.add_argument('--chunk', type=int, default=0, help='queries per device chunk at most (0: the library\'s choice by target size: 10 000, or 2 500 against 10^6 target sequences and more)')
     ap.add_argument('--max-seqs', type=int, default=0, help='result list length (default: max(300, 2 x proteomes), every target set reachable)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg (and the parity check that rides on it)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
@@ -495,7 +495,8 @@ def measure(args, rank, local_rank, world, dist, torch):
                                '(1.2e-6) instead of -e 10, identical cluster hits (parity_check.entries_mismatching)'
                                % (P, args.genes, max_seqs, B, 'in total (strong scaling)' if args.strong else 'per rank', P),
                    'parallelism': 'whole query sets dealt to %d rank(s) by sd_shard_query_sets, target index replicated (%s), '
-                                  'final result gather: %s' % (world, index_how, gather_how)},
+                                  'final result gather: %s' % (world, index_how, gather_how),
+                   'chunk_queries': args.chunk if args.chunk else ('auto: %d' % (2500 if ps.n >= 1000000 else 10000))},
         'roofline': roofline,
         'roofline_sw': roofline_sw,
         # forward cells of the aligned pairs over the score kernels' time (which also holds the reverse pass)
@@ -540,6 +541,29 @@ def measure(args, rank, local_rank, world, dist, torch):
                                                              n_queries=8192 if P < 5000 else 2048)
         except Exception as e:   # (an extra, never the record)
             res['roofline']['isolated'] = dict(error=repr(e)[:200])
+        # The dominant kernel.  Inside the pipeline a kernel's event-timed duration is mostly the wait of its workgroups for a CU the score
+        # wavefronts of the other streams hold, so "largest in-pipeline time" names whichever kernel queues worst (segment_match: 0.9 ms
+        # alone, 10 - 18 ms in the pipeline), not the one that does the stage's work.  The kernel named in `roofline` is therefore the
+        # single kernel with the largest time when the stage runs ALONE (the leg above, same run, same device); its achieved / frac stay
+        # what the contract asks for -- algorithmic bytes over the event-timed duration inside the timed region -- and its rate alone
+        # stands beside them.  Scopes that time several kernels together are listed in per_kernel and not eligible.
+        iso_k = (res['roofline'].get('isolated') or {}).get('kernel_ms_by_name') or {}
+        pk = res['roofline'].get('per_kernel') or {}
+        lumped = ('prefilter_coarse_split', 'prefilter_kmer_partition')
+        cand = {k_: v_ for k_, v_ in iso_k.items() if k_ in pk and k_ not in lumped and v_ > 0}
+        if cand:
+            dom = max(cand.items(), key=lambda kv: kv[1])[0]
+            dk = pk[dom]
+            q_total = max(int(res['prefilter']['queries']), 1)
+            alg_iso = dk['algorithmic_bytes'] * res['roofline']['isolated']['queries'] / q_total
+            res['roofline'].update(kernel=dom, achieved=dk['achieved'], frac=dk['achieved'] / HBM_PEAK_GBS, traffic=dk.get('traffic'),
+                                   traffic_source=res['roofline'].get('traffic_source') if dk.get('traffic') is not None else None,
+                                   launches=dk['launches'], avg_launch_ms=dk['avg_launch_ms'],
+                                   kernel_alone=dict(ms=cand[dom], achieved=alg_iso / cand[dom] / 1e6, frac=alg_iso / cand[dom] / 1e6 / HBM_PEAK_GBS,
+                                                     note='the same kernel in roofline.isolated (nothing else on the device): algorithmic bytes '
+                                                          'scaled by queries / its time there'),
+                                   dominant_by='largest single kernel of the prefilter stage running alone (roofline.isolated, this run); '
+                                               'the largest in-pipeline time is %s' % max(pk.items(), key=lambda kv: kv[1]['ms'])[0])
     last_ranges = my_ranges(args.warmup + args.steps - 1)[0] if args.steps > 0 else []
     extras = dict(ps=ps, k=k, max_seqs=max_seqs, kmer_thr=kmer_thr, bin_size=int(cs.bin_size), gpu=gpu, host=host,
                   last=outs[-1] if outs else None, db=db,

@@ -493,7 +493,7 @@ typedef struct {
     float pCluThr, pMHThr;
     int32_t filterSelfMatch; /* --filter-self-match (reference default 0) */
     int32_t profileQueries;  /* the query side is a profile DB: own k-mer threshold table, index with threshold 0 */
-    int32_t chunkQueries;    /* queries per device chunk (0 = 10000) */
+    int32_t chunkQueries;    /* queries per device chunk at most; a range is cut into equal chunks (0 = by the target set: 10000, 2500 against 10^6 sequences and more) */
     int32_t deviceBias;      /* composition bias: 0 = host stage (OpenMP), anything else (1, -1 = default) = on the device */
     int32_t threads;         /* host threads of this rank (0 = all of the cgroup quota) */
     int32_t alignPriority;   /* stream priority of the alignment context (sd_ctx_create_prio) */
@@ -533,7 +533,7 @@ typedef void (*sd_pref_sink)(void *user, uint32_t firstQuery, uint32_t nQ, const
 typedef void (*sd_aln_sink)(void *user, uint32_t firstQuery, uint32_t nQ, uint32_t nRes, const uint32_t *resQ /* chunk-local */,
                             const uint32_t *resT, const sd_sw_result *res, const uint8_t *isIdentity, const char *btPool);
 int sd_search_set_sinks(sd_search *s, sd_pref_sink pref, sd_aln_sink aln, void *user);
-/* queries per device chunk for the following sd_search_stream calls (results do not depend on it) */
+/* queries per device chunk (at most; 0 = the library's choice) for the following sd_search_stream calls (results do not depend on it) */
 int sd_search_set_chunk_queries(sd_search *s, int32_t chunkQueries);
 /* query ranges [rangeBegin[i], rangeEnd[i]) of `query` (whole query sets each), streamed through one pipeline;
  * sameDb != 0: query protein i is target protein i (identity pairs, self hit first).  results[nRanges] receives one

@@ -80,7 +80,7 @@ void fillParams(const Args &a, sd_search_params &p, bool clustersearchDefaults) 
     p.pCluThr = (float) a.real("--cluster-pval", 0.01);
     p.pMHThr = (float) a.real("--multihit-pval", 0.01);
     p.filterSelfMatch = a.flag("--filter-self-match", false) ? 1 : 0;
-    p.chunkQueries = (int32_t) a.integer("--chunk-queries", 10000);
+    p.chunkQueries = (int32_t) a.integer("--chunk-queries", 0);   // 0: sd_search_stream chooses by the size of the target set
     p.threads = threadsOf(a);
 }
 

@@ -805,6 +805,26 @@ void launchScorePkAligned(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOr
                        dMat, go, ge, dOut, dOrder, (const int8_t *) q->dProf);
 }
 
+// SD_SW_CHAIN=M: a wavefront of the aligned shared-profile kernel takes M consecutive quads of the pair list and chains those of one
+// query (sw_score_pk_chain_kernel: one profile, one systolic ramp per chain); 0 / 1: one quad per wavefront
+// (measured at 1 000 proteomes, profiles/r05_experiments.txt item 13: 4.6 % fewer VALU instructions per quad at M = 4 and the same
+// throughput -- a class launch holds about six quads per wave slot, so M-quad workgroups coarsen the grid as much as they save: off.
+// Read at every call: tests switch it inside one process.)
+inline uint32_t sdSwChain() {
+    const char *e = getenv("SD_SW_CHAIN");
+    return e ? (uint32_t) std::min(64, std::max(0, atoi(e))) : 0u;
+}
+template <int RT>
+void launchScorePkChain(sd_ctx *ctx, const SwTask *dTasks, const uint32_t *dOrder, uint32_t n, const sd_seqset *q, const sd_seqset *t,
+                        const int8_t *dMat, int go, int ge, int32_t *dOut) {
+    if (n == 0) return;
+    const uint32_t nQuads = (n + 3) / 4, chainLen = sdSwChain();
+    dim3 grid((nQuads + chainLen - 1) / chainLen), block(64);
+    static const unsigned ldsPad = getenv("SD_SW_LDS_PAD") ? (unsigned) atoi(getenv("SD_SW_LDS_PAD")) : 0u;
+    hipLaunchKernelGGL((sdpk::sw_score_pk_chain_kernel<RT>), grid, block, ldsPad, ctx->stream, dTasks, n, q->dRes, q->dBias, t->dRes, dMat, go, ge,
+                       dOut, dOrder, (const int8_t *) q->dProf, chainLen);
+}
+
 int rtClass(int n) {
     if (n <= 128) return 4;
     if (n <= 256) return 8;
@@ -1611,6 +1631,7 @@ int devRunScore(sd_ctx *ctx, uint32_t nPairs, const uint32_t *dKeys, const uint3
 #define SD_PKA(RT)                                                                                               \
     case RT:                                                                                                     \
         if (shared && quads && sdSwWaves() == 2) launchScorePkAligned<RT, 32, 2, 2>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);  \
+        else if (shared && quads && sdSwChain() > 1) launchScorePkChain<RT>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);  \
         else if (shared && quads) launchScorePkAligned<RT, 32, 2>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);  \
         else if (shared) launchScorePkAligned<RT, 32, 1>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);      \
         else launchScorePkAligned<RT, 32, 0>(ctx, dTasks, ord, nOrd, q, t, dMat, go, ge, dOut);                  \

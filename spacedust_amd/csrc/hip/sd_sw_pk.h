@@ -715,5 +715,311 @@ sw_score_pk_aligned_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, co
     }
 }
 
+
+// ---- chained form of the aligned kernel: the quads of one query flow through the wavefront back to back --------------------
+// sw_score_pk_aligned_kernel<RT, 32, 2> runs one quad (four tasks of one query: two 32-lane groups x two packed tasks) per wavefront
+// and pays the systolic ramp -- 31 steps in which part of the lanes work on nothing -- for every quad of ~330 columns.  Here a
+// wavefront takes up to `chainLen` CONSECUTIVE quads of the pair list and, while the query stays the same, feeds the next quad's
+// first column into lane 0 in the step after the previous quad's last one: the boundary between two targets travels down the
+// lanes one lane per step, so in the first 32 steps of a segment lane i (and only lane i, at step i) snapshots its running best
+// of the quad it has just finished and clears its DP state (H, E, the diagonal hand-off, the best).  After those 32 steps every
+// lane has handed in its snapshot and the finished quad is reduced and stored; the profile is built once per chain and the ramp
+// is paid once (the 32 draining steps behind the last quad).  A segment is the longest of its four targets, rounded up to an even
+// number of steps and to at least 32 (so that at most one boundary is in flight); columns past a target's end run on the neutral
+// profile row and cannot raise a maximum, exactly as in the one-quad kernel.  The column of a best is kept as the chain's step
+// counter (16 bits per task), so a chain ends early where the next segment would take it past 65 535.
+template <int RT>
+__global__ void __launch_bounds__(64)
+sw_score_pk_chain_kernel(const SwTask *__restrict__ tasks, uint32_t nTasks, const uint8_t *__restrict__ qRes,
+                         const int8_t *__restrict__ qBias, const uint8_t *__restrict__ tRes, const int8_t *__restrict__ mat,
+                         int go, int ge, int32_t *__restrict__ out, const uint32_t *__restrict__ order,
+                         const int8_t *__restrict__ qProf, uint32_t chainLen) {
+    constexpr int LW = 32;
+    constexpr int WORDS = (RT + 3) / 4;
+    constexpr int RTP = 4 * WORDS;
+    constexpr int PSTRIDE = LW * WORDS;    // dwords per residue row of the profile
+    constexpr uint32_t ROWB = PSTRIDE * 4; // bytes per residue row
+    static_assert(22 * ROWB < 65536, "row offsets travel in 16 bits");
+    __shared__ uint32_t prof[22][PSTRIDE];
+    __shared__ int8_t smat[441];
+    for (int i = threadIdx.x; i < 441; i += 64) smat[i] = mat[i];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const int grp = lane >> 5, l = lane & 31;
+    const int q0 = l * RT;
+    const uint32_t goP = (uint32_t) go | ((uint32_t) go << 16), geP = (uint32_t) ge | ((uint32_t) ge << 16);
+    constexpr uint32_t NEUT = (uint32_t) PK_NEUTRAL * ROWB;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t base = (uint32_t) (size_t) (lds_u32 *) (&prof[0][0] + l * WORDS);
+    auto ldsWord = [](uint32_t addr, int w) -> uint32_t { return *((const lds_u32 *) (size_t) addr + w); };
+
+    const uint32_t nQuads = (nTasks + 3) / 4;
+    uint32_t qd = blockIdx.x * chainLen;
+    const uint32_t qdEnd = min(qd + chainLen, nQuads);
+    auto loadQuad = [&](uint32_t quad, SwTask (&tk)[4]) {   // uniform loads; entries beyond the list and PAIR_NONE entries are empty tasks
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const uint32_t id = quad * 4 + x;
+            const uint32_t tid = id < nTasks ? (order ? order[id] : id) : 0xFFFFFFFFu;
+            if (tid != 0xFFFFFFFFu) {
+                tk[x] = tasks[tid];
+            } else {
+                tk[x].n = 0; tk[x].tL = 0; tk[x].qOff = 0; tk[x].tOff = 0; tk[x].qStep = 1; tk[x].tStep = 1; tk[x].segLen = 1;
+                tk[x].slot = 0; tk[x].boundOff = 0;
+            }
+        }
+    };
+    bool firstChain = true;
+    while (qd < qdEnd) {
+        SwTask tk[4];
+        loadQuad(qd, tk);
+        if (tk[0].n <= 0) {   // (a quad's first task is a real one: runs are padded at their end)
+            qd++;
+            continue;
+        }
+        // ---- the query's profile (SmithWaterman::createQueryProfile, :163-187): either group writes half of the residue rows
+        if (!firstChain) __syncthreads();
+        firstChain = false;
+        const SwTask Q = tk[0];
+        {
+            uint32_t *pw = &prof[0][0] + l * WORDS;
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) {
+                int res[4], cb[4];
+                int64_t pidx[4];
+                bool valid[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int qi = q0 + 4 * w + b;
+                    valid[b] = (4 * w + b < RT) && qi < Q.n;
+                    res[b] = 20;
+                    cb[b] = 0;
+                    pidx[b] = 0;
+                    if (valid[b]) {
+                        const int64_t idx = (int64_t) Q.qOff + (int64_t) qi * Q.qStep;
+                        res[b] = qRes[idx];
+                        cb[b] = qBias[idx];
+                        pidx[b] = idx * 21;
+                    }
+                }
+                if (qProf) {   // profile query: the position's own row
+                    for (int a = grp; a < 21; a += 2) {
+                        uint32_t word = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int v = valid[b] ? (int) qProf[pidx[b] + a] : -64;
+                            word |= (uint32_t) (uint8_t) (int8_t) v << (8 * b);
+                        }
+                        pw[a * PSTRIDE + w] = word;
+                    }
+                } else {
+                    for (int a = grp; a < 21; a += 2) {
+                        uint32_t word = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int v = valid[b] ? (int) smat[a * 21 + res[b]] + cb[b] : -64;
+                            word |= (uint32_t) (uint8_t) (int8_t) v << (8 * b);
+                        }
+                        pw[a * PSTRIDE + w] = word;
+                    }
+                }
+                pw[PK_NEUTRAL * PSTRIDE + w] = 0xC0C0C0C0u;
+            }
+        }
+        __syncthreads();
+
+        uint32_t H[RTP], E[RTP];
+#pragma unroll
+        for (int r = 0; r < RTP; r++) {
+            H[r] = 0;
+            E[r] = 0;
+        }
+        uint32_t outG = 0, outFf = 0, prevInG = 0;
+        uint32_t bestcm = 0, bestcol = 0, savedcm = 0, savedcol = 0;
+        uint32_t T = NEUT | (NEUT << 16);
+        uint32_t pa[WORDS], pb[WORDS], T2, pa2[WORDS], pb2[WORDS];
+        // the targets of the segment in flight, as this lane's group sees them
+        uint64_t tOffA = 0, tOffB = 0;
+        int32_t tLA = 0, tLB = 0, tStepA = 1, tStepB = 1;
+        uint32_t chunk = 0, chunkNext = 0;
+        auto loadChunk = [&](int c0) -> uint32_t {   // row offsets (bytes) of the residues of column c0 + l, task A | task B << 16
+            const int col = c0 + l;
+            uint32_t a = PK_NEUTRAL, b = PK_NEUTRAL;
+            if (col < tLA) a = tRes[(int64_t) tOffA + (int64_t) col * tStepA];
+            if (col < tLB) b = tRes[(int64_t) tOffB + (int64_t) col * tStepB];
+            return (a * ROWB) | ((b * ROWB) << 16);
+        };
+        uint32_t S = 0;   // the chain's step counter at the start of the segment in flight
+        // one column step (see sw_score_pk_aligned_kernel): consumes (Tc, pac, pbc), produces the next column's (Tn, pan, pbn)
+        auto columnStep = [&](const int i, const uint32_t &Tc, const uint32_t (&pac)[WORDS], const uint32_t (&pbc)[WORDS], uint32_t &Tn,
+                              uint32_t (&pan)[WORDS], uint32_t (&pbn)[WORDS]) {
+            const int i1 = (i + 1) & (LW - 1);
+            if (i1 == 0) {
+                chunk = chunkNext;
+                chunkNext = loadChunk(i + 1 + LW);
+            }
+            Tn = dppShr1(Tc);
+            Tn = writeLane<0>(readLane(chunk, i1), Tn);
+            Tn = writeLane<32>(readLane(chunk, 32 + i1), Tn);
+            {
+                const uint32_t aA = addWord0(base, Tn), aB = addWord1(base, Tn);
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) {
+                    pan[w] = ldsWord(aA, w);
+                    pbn[w] = ldsWord(aB, w);
+                }
+            }
+            uint32_t inG = dppShr1(outG), inFf = dppShr1(outFf);
+            inG = writeLane<32>(0, inG);
+            inFf = writeLane<32>(0, inFf);
+            uint32_t h[RTP];
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) {
+                const uint32_t d0 = (w == 0) ? prevInG : H[4 * w - 1];
+                addProfile4(pac[w], pbc[w], d0, H[4 * w], H[4 * w + 1], H[4 * w + 2], h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
+            }
+            prevInG = inG;
+            uint32_t Fl = 0, Ff = inFf, cm = 0;
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                uint32_t hpre = pkMax(h[r], E[r]);
+                if (r != 0) hpre = pkMax(hpre, Fl);   // a lane is a segment of the reference: no vertical gap of the lane structure enters row 0
+                const uint32_t g = pkMax(hpre, Ff);
+                const uint32_t open = pkSubSat(hpre, goP);
+                E[r] = pkMax(pkSubSat(E[r], geP), open);
+                if (r == 0) Fl = open;
+                else if (r + 1 != RT) Fl = pkMax(pkSubSat(Fl, geP), open);
+                Ff = pkMax(pkSubSat(Ff, geP), open);
+                H[r] = g;
+                const uint32_t code = pkRowCode(g, 31 - r);
+                cm = r == 0 ? code : pkMax(cm, code);
+            }
+            outG = H[RT - 1];
+            outFf = Ff;
+            const uint32_t t = bestcm | 0x001F001Fu;
+            const uint32_t m = pkAshr15(pkSub(t, cm));   // all ones where cm > t
+            const uint32_t k = S + (uint32_t) i;
+            const uint32_t kk = k | (k << 16);
+            bestcm = bfiAsm(m, cm, bestcm);
+            bestcol = bfiAsm(m, kk, bestcol);
+        };
+        // the boundary between two quads reaches lane i of either group at step i of the new segment
+        auto boundary = [&](const int i) {
+            if (l == i) {
+                savedcm = bestcm;
+                savedcol = bestcol;
+                bestcm = 0;
+                bestcol = 0;
+                prevInG = 0;
+#pragma unroll
+                for (int r = 0; r < RTP; r++) {
+                    H[r] = 0;
+                    E[r] = 0;
+                }
+            }
+        };
+        // first residues of a segment into the first lane of either group, and that lane's profile words again
+        auto enterSegment = [&]() {
+            chunk = loadChunk(0);
+            chunkNext = loadChunk(LW);
+            T = writeLane<0>(readLane(chunk, 0), T);
+            T = writeLane<32>(readLane(chunk, 32), T);
+            const uint32_t aA = addWord0(base, T), aB = addWord1(base, T);
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) {
+                pa[w] = ldsWord(aA, w);
+                pb[w] = ldsWord(aB, w);
+            }
+        };
+        // the finished quad: its snapshot -> max value, then smallest column, then smallest row over the 32 lanes of a group
+        uint32_t pSlotA = 0, pSlotB = 0, pN = 0, pS = 0;
+        bool pHaveA = false, pHaveB = false, havePrev = false;
+        auto storePrev = [&]() {
+            unsigned long long keyA = 0, keyB = 0;
+            const uint32_t vA = (savedcm & 0xFFFFu) >> 5, vB = savedcm >> 21;
+            const uint32_t rowA = (uint32_t) (q0 + 31 - (int) (savedcm & 31u)), rowB = (uint32_t) (q0 + 31 - (int) ((savedcm >> 16) & 31u));
+            const uint32_t colA = (savedcol & 0xFFFFu) - (uint32_t) l - pS, colB = (savedcol >> 16) - (uint32_t) l - pS;   // step - lane - segment start
+            if (vA > 0) keyA = ((unsigned long long) vA << 40) | ((unsigned long long) (0xFFFFFu - colA) << 20) | (unsigned long long) (0xFFFFFu - rowA);
+            if (vB > 0) keyB = ((unsigned long long) vB << 40) | ((unsigned long long) (0xFFFFFu - colB) << 20) | (unsigned long long) (0xFFFFFu - rowB);
+#pragma unroll
+            for (int off = LW / 2; off >= 1; off >>= 1) {
+                const unsigned long long oa = __shfl_xor(keyA, off, LW), ob = __shfl_xor(keyB, off, LW);
+                keyA = oa > keyA ? oa : keyA;
+                keyB = ob > keyB ? ob : keyB;
+            }
+            if (l == 0) {
+                if (pHaveA) {
+                    const int v = (int) (keyA >> 40);
+                    out[3 * pSlotA + 0] = v;
+                    out[3 * pSlotA + 1] = v == 0 ? -1 : 0xFFFFF - (int) ((keyA >> 20) & 0xFFFFF);
+                    out[3 * pSlotA + 2] = v == 0 ? (int) pN - 1 : 0xFFFFF - (int) (keyA & 0xFFFFF);
+                }
+                if (pHaveB) {
+                    const int v = (int) (keyB >> 40);
+                    out[3 * pSlotB + 0] = v;
+                    out[3 * pSlotB + 1] = v == 0 ? -1 : 0xFFFFF - (int) ((keyB >> 20) & 0xFFFFF);
+                    out[3 * pSlotB + 2] = v == 0 ? (int) pN - 1 : 0xFFFFF - (int) (keyB & 0xFFFFF);
+                }
+            }
+        };
+
+        bool more = true;
+        while (more) {
+            const SwTask &A = grp ? tk[2] : tk[0];
+            const SwTask &B = grp ? tk[3] : tk[1];
+            tOffA = A.tOff; tLA = A.n > 0 ? A.tL : 0; tStepA = A.tStep;
+            tOffB = B.tOff; tLB = B.n > 0 ? B.tL : 0; tStepB = B.tStep;
+            int maxTL = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) maxTL = max(maxTL, tk[x].n > 0 ? tk[x].tL : 0);
+            const int L = max((maxTL + 1) & ~1, LW);
+            enterSegment();
+#pragma unroll 1
+            for (int i = 0; i < LW; i += 2) {
+                boundary(i);
+                columnStep(i, T, pa, pb, T2, pa2, pb2);
+                boundary(i + 1);
+                columnStep(i + 1, T2, pa2, pb2, T, pa, pb);
+            }
+            if (havePrev) storePrev();
+#pragma unroll 1
+            for (int i = LW; i < L; i += 2) {
+                columnStep(i, T, pa, pb, T2, pa2, pb2);
+                columnStep(i + 1, T2, pa2, pb2, T, pa, pb);
+            }
+            pSlotA = A.slot; pSlotB = B.slot; pN = (uint32_t) Q.n; pS = S;
+            pHaveA = A.n > 0; pHaveB = B.n > 0; havePrev = true;
+            S += (uint32_t) L;
+            // the next quad of the list continues the chain while it belongs to the same query
+            qd++;
+            more = false;
+            if (qd < qdEnd) {
+                SwTask nk[4];
+                loadQuad(qd, nk);
+                int nTL = 0;
+#pragma unroll
+                for (int x = 0; x < 4; x++) nTL = max(nTL, nk[x].n > 0 ? nk[x].tL : 0);
+                if (nk[0].n == Q.n && nk[0].qOff == Q.qOff && nk[0].qStep == Q.qStep && S + (uint32_t) max(nTL + 1, LW) + LW <= 65535u) {
+#pragma unroll
+                    for (int x = 0; x < 4; x++) tk[x] = nk[x];
+                    more = true;
+                }
+            }
+        }
+        // ---- drain: 32 steps on the neutral row carry the boundary behind the last quad down the lanes
+        tLA = 0;
+        tLB = 0;
+        enterSegment();
+#pragma unroll 1
+        for (int i = 0; i < LW; i += 2) {
+            boundary(i);
+            columnStep(i, T, pa, pb, T2, pa2, pb2);
+            boundary(i + 1);
+            columnStep(i + 1, T2, pa2, pb2, T, pa, pb);
+        }
+        storePrev();
+    }
+}
+
 }  // namespace sdpk
 #endif

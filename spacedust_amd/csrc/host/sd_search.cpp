@@ -231,7 +231,7 @@ void sd_search_default_params(sd_search_params *p) {
     p->pMHThr = 0.01f;
     p->filterSelfMatch = 0;
     p->profileQueries = 0;
-    p->chunkQueries = 10000;
+    p->chunkQueries = 0;   // by the size of the target set (sd_search_stream)
     p->deviceBias = -1;
     p->threads = 0;
     p->alignPriority = 1;
@@ -444,7 +444,7 @@ int sd_search_set_sinks(sd_search *s, sd_pref_sink pref, sd_aln_sink aln, void *
 }
 
 int sd_search_set_chunk_queries(sd_search *s, int32_t chunkQueries) {
-    if (!s || chunkQueries < 1) return SD_EINVAL;
+    if (!s || chunkQueries < 0) return SD_EINVAL;   // 0: the library's choice (sd_search_stream)
     s->par.chunkQueries = chunkQueries;
     return SD_OK;
 }
@@ -517,15 +517,31 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         uint32_t range, c0, c1;
     };
     std::vector<Chunk> chunks;
-    const uint32_t chunkQ = (uint32_t) (s->par.chunkQueries > 0 ? s->par.chunkQueries : 10000);
+    // Chunk size.  What a chunk costs follows its index hits, not its queries: against 3e5 target sequences (100 proteomes) a query has
+    // 1.5e5 hits and a prefilter sub-batch is 4 096 queries, against 3e6 sequences it has 1.5e6 and a sub-batch (bounded by 2^30 hits) is
+    // 700 queries -- there chunks of 10 000 queries keep three prefilter lanes and two alignment lanes busy with very uneven pieces
+    // (a 12 000-query range is 10 000 + 2 000).  Measured on one box, 1 000 proteomes: 10 000 -> 2 200 - 2 290, 6 000 -> 2 400 - 2 500,
+    // 4 000 -> 2 530 - 2 550, 2 000 -> 2 570 - 2 590 genome-pairs/s; 100 proteomes: 10 000 -> 1 935, 6 000 -> 1 890, 3 000 -> 1 685
+    // (profiles/r05_experiments.txt item 14).  A range is cut into EQUAL chunks of at most that size.
+    const uint32_t chunkQ = (uint32_t) (s->par.chunkQueries > 0 ? s->par.chunkQueries : (T.n >= 1000000u ? 2500 : 10000));
     for (uint32_t r = 0; r < nRanges; r++) {
         if (rangeEnd[r] > Q->n || rangeBegin[r] > rangeEnd[r]) return s->fail(SD_EINVAL, "sd_search_stream: bad range");
-        for (uint32_t c0 = rangeBegin[r]; c0 < rangeEnd[r];) {
-            const uint32_t step = chunks.empty() ? std::max<uint32_t>(1, std::min(chunkQ, std::max<uint32_t>(1000, chunkQ / 4))) : chunkQ;
+        uint32_t c0 = rangeBegin[r];
+        if (chunks.empty() && c0 < rangeEnd[r]) {   // the stream's first chunk (see above)
             Chunk c;
             c.range = r;
             c.c0 = c0;
-            c.c1 = (uint32_t) std::min<uint64_t>(rangeEnd[r], (uint64_t) c0 + step);
+            c.c1 = (uint32_t) std::min<uint64_t>(rangeEnd[r], (uint64_t) c0 + std::max<uint32_t>(1, std::min(chunkQ, std::max<uint32_t>(1000, chunkQ / 4))));
+            chunks.push_back(c);
+            c0 = c.c1;
+        }
+        const uint32_t left = rangeEnd[r] - c0;
+        const uint32_t parts = (left + chunkQ - 1) / chunkQ;
+        for (uint32_t x = 0; x < parts; x++) {   // equal parts: the first left % parts of them one query longer
+            Chunk c;
+            c.range = r;
+            c.c0 = c0;
+            c.c1 = c0 + left / parts + (x < left % parts ? 1u : 0u);
             chunks.push_back(c);
             c0 = c.c1;
         }

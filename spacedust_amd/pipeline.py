@@ -118,7 +118,7 @@ class ClusterSearch:
     def __init__(self, ctx, host, target_db, sensitivity=5.7, max_seqs=300, eval_thr=10.0, cov_mode=2, cov_thr=0.8,
                  aln_len_thr=30, max_gene_gap=3, cluster_size=2, alpha=1.0, p_clu_thr=0.01, p_mh_thr=0.01,
                  filter_self_match=False, bin_size=None, verbose=False, align_ctx=None, k=None, profile_queries=False,
-                 device_bias=None, chunk_queries=10000, index=None):
+                 device_bias=None, chunk_queries=0, index=None):
         """ctx / host: the caller's context and host handle (used for the device index and for helper calls such as
         Host.map_profiles); the pipeline object creates its own two contexts on that device -- prefilter and alignments
         run on separate HIP streams so that the prefilter of the next chunk (HBM random-access bound) and the

@@ -256,6 +256,52 @@ def test_sw_packed_kernel_equals_int32_kernel(gpu, host, monkeypatch):
     assert lens.min() <= 128 and lens.max() > 768   # every row class is exercised
 
 
+@pytest.mark.parametrize('chain', [2, 5, 64])
+def test_sw_chained_quads_equal_one_quad_per_wavefront(gpu, host, monkeypatch, chain):
+    """sw_score_pk_chain_kernel (SD_SW_CHAIN=M: a wavefront runs up to M consecutive quads of the pair list, those of one query back
+    to back through one systolic pipeline) against the one-quad-per-wavefront kernel: queries with long runs of targets (chains that
+    fill their M quads), runs of one to three tasks (a chain that ends after every quad, empty pairs), targets shorter than the 32
+    lanes, every aligned row class"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=5, genes_per_proteome=400, n_families=600, seed=5, mean_len=330)
+    rng = np.random.default_rng(23)
+    # the proteomes plus 40 fragments of 3 .. 40 residues (targets shorter than the 32 lanes: a segment is padded to 32 steps)
+    frag_len = rng.integers(3, 41, size=40)
+    frag = [ps.residues[int(o):int(o) + int(n)] for o, n in zip(ps.offsets[rng.integers(ps.n, size=40)], frag_len)]
+    residues = np.concatenate([ps.residues] + frag)
+    offsets = np.concatenate([ps.offsets, ps.offsets[-1] + np.cumsum(frag_len)]).astype(ps.offsets.dtype)
+    n_seq = len(offsets) - 1
+    short = np.arange(ps.n, n_seq)
+    lens = offsets[1:] - offsets[:-1]
+    pq, pt = [], []
+    for q in rng.choice(ps.n, 120, replace=False):   # long runs: 5 .. 90 targets of one query, homologs and fragments among them
+        n = int(rng.integers(5, 90))
+        t = rng.integers(ps.n, size=n)
+        t[:4] = rng.choice(short, 4)
+        same = np.flatnonzero(ps.family == ps.family[q]) if ps.family[q] >= 0 else np.zeros(0, np.int64)
+        k = min(len(same), n - 4)
+        t[4:4 + k] = same[:k]
+        pq += [int(q)] * n
+        pt += [int(x) for x in t]
+    q2, t2 = _pairs(ps, rng, 3000)   # short runs
+    pq = np.concatenate([np.array(pq, np.uint32), q2])
+    pt = np.concatenate([np.array(pt, np.uint32), t2])
+    sw_bias, _, _ = host.comp_bias(residues, offsets)
+    mat, _, _ = host.matrix(0)
+    ss = gpu.seqset(residues, offsets, sw_bias)
+    par = gpu.sw_params(mat, int(offsets[-1]))
+    ident = (pq == pt)
+    monkeypatch.delenv('SD_SW_CHAIN', raising=False)
+    a, pa = gpu.sw_align(par, ss, ss, pq, pt, identity=ident)
+    monkeypatch.setenv('SD_SW_CHAIN', str(chain))
+    b, pb = gpu.sw_align(par, ss, ss, pq, pt, identity=ident)
+    for f in ('score', 'qStart', 'qEnd', 'tStart', 'tEnd', 'identical', 'btLen', 'flags', 'evalue'):
+        assert np.array_equal(a[f], b[f]), (f, np.flatnonzero(a[f] != b[f])[:5])
+    assert np.array_equal(pa, pb)
+    assert lens[pq].min() <= 160 and lens[pq].max() > 768 and lens[pt].min() < 32   # the aligned row classes, targets below 32 residues
+    assert int((a['score'] > 0).sum()) > len(pq) // 2
+
+
 def test_sw_align_compact_equals_full(gpu, host):
     """sd_sw_align_batch_compact returns exactly the reportable records of sd_sw_align_batch, in pair order"""
     from spacedust_amd.synth import make_proteomes
