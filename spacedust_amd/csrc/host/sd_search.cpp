@@ -274,11 +274,11 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
     }
     rc = sd_ctx_create(device, &s->ctxCh);
     if (rc != SD_OK) return rc;
-    // prefilter lanes: SD_PF_LANES fixes the number; otherwise three contexts are made (a context is a stream and an empty workspace)
+    // prefilter lanes: SD_PF_LANES fixes the number; otherwise four contexts are made (a context is a stream and an empty workspace)
     // and the number in use is decided once the target is resident (below)
     const bool pfLanesFixed = getenv("SD_PF_LANES") != nullptr;
     if (const char *e = getenv("SD_PF_LANES")) s->pfLanes = std::max(1, std::min(4, atoi(e)));
-    else s->pfLanes = 3;
+    else s->pfLanes = 4;
     if (s->pfLanes > 1) {
         rc = sd_ctx_create_prio(device, pfPrio, &s->ctxPf2);
         if (rc != SD_OK) return rc;
@@ -378,7 +378,7 @@ int sd_search_create_indexed(int device, const sd_search_params *par, const sd_s
         // dozen host synchronisation points each, and two lanes leave the stage idle 28 % of the time while it is what bounds a step
         // (measured at 1 000 proteomes, 12 steps: 2 lanes 2 200 - 2 220, 3 lanes 2 308, 4 lanes 2 099 genome-pairs/s).  Smaller targets:
         // two (100 proteomes: 2 x 2 and 3 x 2 lanes within noise, the third workspace is not worth its 9 GB)
-        else if (!pfLanesFixed) s->pfLanes = target->n >= 1000000u ? 3 : 2;
+        else if (!pfLanesFixed) s->pfLanes = target->n >= 1000000u ? 4 : 2;   // (four lanes with the chunks of 2 500 queries such a target gets: 2 628 vs 2 575 genome-pairs/s with three)
     }
     memset(&s->pfPar, 0, sizeof(s->pfPar));
     s->pfPar.kmerSize = s->k;
@@ -902,10 +902,17 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         }
     };
 
-    std::deque<PfFut> pfQueue;   // prefilter jobs in flight, in chunk order (one per lane)
+    // prefilter jobs submitted and not yet collected, in chunk order.  A lane's thread runs its jobs one after the other; with ONE job
+    // per lane a lane that finishes chunk x + 1 before chunk x is collected (chunks are collected in order, and this thread is also the
+    // one that retires alignments and runs clusterhits) stands idle until then -- and the prefilter is the stage a step waits for.  With
+    // SD_PF_DEPTH jobs per lane it goes on with its next chunk; a finished chunk's rows wait in host memory.  Measured (round 5, 1 000
+    // proteomes, three and four lanes, depth 1 / 2 / 3): this thread's wait for the prefilter 10.4 -> 7 s per 12 steps, the throughput the
+    // same (2 575 / 2 560 / 2 550 and 2 628 / 2 620 / 2 593) -- the device, not the lanes' idle time, bounds a step: one job per lane stays.
+    std::deque<PfFut> pfQueue;
     size_t pfSubmitted = 0;
+    static const int pfDepth = getenv("SD_PF_DEPTH") ? std::max(1, std::min(4, atoi(getenv("SD_PF_DEPTH")))) : 1;
     auto pumpPf = [&]() {
-        while (pfSubmitted < chunks.size() && (int) pfQueue.size() < pfLanes) pfQueue.push_back(submitPf(pfSubmitted++));
+        while (pfSubmitted < chunks.size() && (int) pfQueue.size() < pfLanes * pfDepth) pfQueue.push_back(submitPf(pfSubmitted++));
     };
     pumpPf();
     for (size_t ci = 0; ci < chunks.size() && status == SD_OK; ci++) {
