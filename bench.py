@@ -419,7 +419,7 @@ def measure(args, rank, local_rank, world, dist, torch):
               'prefilter_select_hits': 12 * Cn + 10 * st['prefilter_hits']}
     pmc = {}
     pmc_src = None
-    for fn in ('r05_pmc_traffic.json', 'r04d_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for fn in ('r05i_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04d_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
             pmc_src = 'profiles/' + fn
@@ -455,7 +455,7 @@ def measure(args, rank, local_rank, world, dist, torch):
     valu = dict(instr_per_cell=11.1, peak_lane_instr_per_s=256 * 64 * 2.4e9,
                 source='ISA count of sw_score_pk RT=8 (178 per 16 cells); 256 CU x 64 lanes x 2.4 GHz')
     try:
-        fn = next(f for f in ('r05_valu_calibration.json', 'r04d_valu_calibration.json', 'r04_valu_calibration.json', 'r03_valu_calibration.json', 'r02_valu_calibration.json') if os.path.exists(os.path.join(ROOT, 'profiles', f)))
+        fn = next(f for f in ('r05i_valu_calibration.json', 'r05_valu_calibration.json', 'r04d_valu_calibration.json', 'r04_valu_calibration.json', 'r03_valu_calibration.json', 'r02_valu_calibration.json') if os.path.exists(os.path.join(ROOT, 'profiles', f)))
         v = json.load(open(os.path.join(ROOT, 'profiles', fn)))
         valu = dict(instr_per_cell=v['instr_per_cell'], peak_lane_instr_per_s=v['peak_lane_instr_per_s'], source='profiles/' + fn)
     except (OSError, ValueError, KeyError, StopIteration):
