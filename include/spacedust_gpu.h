@@ -354,6 +354,12 @@ int sd_host_cluster_pvalues(uint32_t nHits, const uint32_t *qPos, const uint32_t
                             double *pMultihit, uint32_t *order);
 double sd_host_evalue(uint64_t dbResidues, double score, double qLen);
 double sd_host_bitscore(double score);
+/* A double after one hand-off between two reference modules: printed as "%.3E" (Matcher.cpp:288, besthitbyset.cpp:129,
+ * combinehits.cpp:218-221) and parsed by strtod.  text: >= 16 bytes, NUL-terminated; *back: the parsed value. */
+int sd_host_quantise_3e(double v, char *text, double *back);
+/* Matcher::compressAlignment (M/src/alignment/Matcher.cpp:166-185): the run-length form of a backtrace of M / I / D letters (an empty
+ * one is "0M").  out == NULL: *len = length needed; SD_ENOMEM when cap is smaller. */
+int sd_host_compress_backtrace(const char *bt, uint64_t n, char *out, uint64_t cap, uint64_t *len);
 /* Util::canBeCovered (M/src/commons/Util.cpp:477-494): the length pre-check of Prefiltering.cpp:856-863 / Alignment.cpp:370 */
 int sd_host_can_be_covered(float covThr, int covMode, float queryLength, float targetLength);
 

@@ -181,6 +181,8 @@ def load():
         'sd_host_matrix_text': (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
         'sd_host_sw_comp_bias': (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp]),
         'sd_host_can_be_covered': (C.c_int, [C.c_float, C.c_int, C.c_float, C.c_float]),
+        'sd_host_quantise_3e': (C.c_int, [C.c_double, C.c_char_p, C.POINTER(C.c_double)]),
+        'sd_host_compress_backtrace': (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
         'sd_host_accept_sort': (C.c_int, [C.POINTER(AlnCriteria), C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
         'sd_host_realign_select': (C.c_int, [C.POINTER(AlnCriteria), C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _vp, _vp]),

@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstring>
 
+#include <immintrin.h>
+
 namespace sd {
 
 void initEvaluer(Evaluer &e, uint64_t dbResidues) {
@@ -153,22 +155,66 @@ std::string compressBacktrace(const char *bt, size_t n) {
     return ret;
 }
 
-void compressBacktraceAppend(const char *bt, size_t n, std::string &ret) {
-    char state = 'M';
-    size_t counter = 0;
-    char num[16];
-    for (size_t i = 0; i < n; ++i) {
-        if (bt[i] != state) {
-            ret.append(num, u32toa((uint32_t) counter, num) - num);
-            ret.push_back(state);
-            state = bt[i];
-            counter = 1;
-        } else {
-            counter++;
+namespace {
+struct Dec3 {
+    struct { char d[4]; } t[1000];   // the decimal digits of 0 .. 999, left-aligned, and their number in d[3]
+    Dec3() {
+        for (int v = 0; v < 1000; v++) {
+            char b[8];
+            const int len = (int) (u32toa((uint32_t) v, b) - b);
+            memset(t[v].d, '0', 3);
+            memcpy(t[v].d, b, (size_t) len);
+            t[v].d[3] = (char) len;
         }
     }
-    ret.append(num, u32toa((uint32_t) counter, num) - num);
-    ret.push_back(state);
+};
+const Dec3 kDec3;
+}  // namespace
+
+// Matcher::compressAlignment (M/src/alignment/Matcher.cpp:166-185): run lengths, starting in state 'M' with a count of 0 (a
+// backtrace that does not begin with a match begins "0M").  Run boundaries are found 32 letters at a time (the letters against their
+// left neighbours, one compare + movemask):
+// a protein alignment is mostly match runs of dozens of letters, and this loop was 60 % of the aggregation stage's CPU time.
+void compressBacktraceAppend(const char *bt, size_t n, std::string &ret) {
+    char state = 'M';
+    size_t runStart = 0, i = 0;
+    char out[256], *o = out;   // runs are written here and appended in pieces (one append per run was the rest of the cost)
+    auto emit = [&](size_t count) {
+        if (o > out + sizeof(out) - 16) {
+            ret.append(out, (size_t) (o - out));
+            o = out;
+        }
+        if (count < 1000) {   // no branch on the number of digits (run lengths are as good as random: every branch here mispredicts)
+            memcpy(o, kDec3.t[count].d, 4);
+            o += kDec3.t[count].d[3];
+        } else {
+            o = u32toa((uint32_t) count, o);
+        }
+        *o++ = state;
+    };
+    if (n && bt[0] != 'M') {
+        emit(0);
+        state = bt[0];
+    }
+    auto boundary = [&](size_t pos) {
+        emit(pos - runStart);
+        state = bt[pos];
+        runStart = pos;
+    };
+    i = 1;
+    for (; i + 32 <= n; i += 32) {   // letters i .. i + 31 against their left neighbours
+        const __m256i cur = _mm256_loadu_si256((const __m256i *) (bt + i));
+        const __m256i left = _mm256_loadu_si256((const __m256i *) (bt + i - 1));
+        uint32_t ne = ~(uint32_t) _mm256_movemask_epi8(_mm256_cmpeq_epi8(cur, left));
+        while (ne) {
+            boundary(i + (size_t) __builtin_ctz(ne));
+            ne &= ne - 1;
+        }
+    }
+    for (; i < n; i++)
+        if (bt[i] != bt[i - 1]) boundary(i);
+    emit(n - runStart);
+    ret.append(out, (size_t) (o - out));
 }
 
 }  // namespace sd

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include <omp.h>
@@ -37,17 +38,124 @@ struct BestHit {
     uint64_t cigarOff;
 };
 
-// snprintf("%.3E") followed by strtod, i.e. what one reference module writes and the next one parses; to_chars /
-// from_chars produce the same digits and the same double (both are exact conversions), several times faster
-double quantise3E(double v, char *text) {
+// snprintf("%.3E") followed by strtod, i.e. what one reference module writes and the next one parses.  to_chars / from_chars produce
+// the same digits and the same double (both are exact conversions).  The four digits are found without the exact conversion whenever
+// that is safe: x * 10^(3 - e) in 80-bit arithmetic is within 1e-15 of the true quotient, so unless it lies within 1e-6 of a rounding
+// boundary (then: to_chars) floor(. + 0.5) is the digit string printf rounds the exact value to.  (to_chars was 65 of the 85 ns of a round trip,
+// and a matched hit makes three of them.)
+struct Pow10L {
+    long double p[700];   // 10^(i - 350), correctly rounded to the 64-bit significand (glibc's strtold)
+    Pow10L() {
+        char t[16];
+        for (int i = 0; i < 700; i++) {
+            snprintf(t, sizeof(t), "1e%d", i - 350);
+            p[i] = strtold(t, nullptr);
+        }
+    }
+};
+const Pow10L kPow10L;
+static_assert(sizeof(long double) == 16 && LDBL_MANT_DIG == 64, "x87 extended precision expected");
+
+double quantise3ESlow(double v, char *text) {
     std::to_chars_result r = std::to_chars(text, text + 24, v, std::chars_format::scientific, 3);
     *r.ptr = '\0';
     for (char *p = text; p < r.ptr; p++)
-        if (*p == 'e') *p = 'E';
+        if (*p >= 'a' && *p <= 'z') *p = (char) (*p - 'a' + 'A');   // 'E'; "INF" / "NAN" as %E writes them
     double back = 0.0;
-    std::from_chars(text, r.ptr, back);
+    if (std::from_chars(text, r.ptr, back).ec != std::errc()) back = strtod(text, nullptr);   // out of range: strtod's +-HUGE_VAL / 0
     return back;
 }
+
+double quantise3E(double x, char *text) {
+    const double v = fabs(x);   // printf rounds the magnitude (to nearest, ties to even digit): the sign is copied
+    if (!(v >= 1e-300 && v <= 1e300)) return quantise3ESlow(x, text);   // zero, subnormal, huge, NaN
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    const int e2 = (int) (bits >> 52) - 1022;   // v = f * 2^e2 with 0.5 <= f < 1 (v is normal here)
+    int e10 = (int) floor((double) (e2 - 1) * 0.30102999566398120);   // <= floor(log10 v) <= this + 1
+    long double scaled = (long double) v * kPow10L.p[3 - e10 + 350];
+    if (scaled >= 10000.0L) {
+        e10++;
+        scaled = (long double) v * kPow10L.p[3 - e10 + 350];
+    }
+    if (!(scaled >= 1000.0L && scaled < 10000.0L)) return quantise3ESlow(x, text);
+    const int fi = (int) scaled;   // truncation = floor (positive)
+    const long double frac = scaled - (long double) fi;
+    if (fabsl(frac - 0.5L) < 1e-6L || frac < 1e-6L || frac > 1.0L - 1e-6L) return quantise3ESlow(x, text);
+    int m = fi + (frac > 0.5L ? 1 : 0);
+    if (m == 10000) {
+        m = 1000;
+        e10++;
+    }
+    char *p = text;
+    if (x < 0) *p++ = '-';
+    *p++ = (char) ('0' + m / 1000);
+    *p++ = '.';
+    *p++ = (char) ('0' + m / 100 % 10);
+    *p++ = (char) ('0' + m / 10 % 10);
+    *p++ = (char) ('0' + m % 10);
+    *p++ = 'E';
+    int ae = e10;
+    if (ae < 0) {
+        *p++ = '-';
+        ae = -ae;
+    } else {
+        *p++ = '+';
+    }
+    if (ae >= 100) *p++ = (char) ('0' + ae / 100);
+    *p++ = (char) ('0' + ae / 10 % 10);
+    *p++ = (char) ('0' + ae % 10);
+    *p = '\0';
+    // strtod of that text = m * 10^(e10 - 3) rounded once.  In 80-bit arithmetic the product is within one unit of its 64-bit significand
+    // of the true value (table entry and product: half a unit each), and rounding it to 53 bits gives the correctly rounded double unless
+    // its eleven extra bits are within a few units of the half-way pattern (1 in 250: from_chars decides)
+    const long double prod = (long double) m * kPow10L.p[e10 - 3 + 350];
+    uint64_t sig;
+    memcpy(&sig, &prod, 8);   // x87 layout: the 64-bit significand, then sign + exponent
+    const int low = (int) (sig & 0x7FFu);
+    double back;
+    if (low >= 0x400 - 4 && low <= 0x400 + 4) {
+        back = 0.0;
+        const char *digits = x < 0 ? text + 1 : text;
+        if (std::from_chars(digits, (const char *) p, back).ec != std::errc()) back = strtod(digits, nullptr);
+    } else {
+        back = (double) prod;
+    }
+    return x < 0 ? -back : back;
+}
+
+// Append-only storage in fixed blocks: what is appended never moves.  The per-thread hit lists of a proteome-scale range grow to
+// hundreds of MB; as std::vectors they were copied at every doubling (the "push_back" share of sd_agg_add: 10 - 40 % of its CPU time).
+template <typename T, unsigned LOG2>
+struct Blocks {
+    std::vector<std::unique_ptr<T[]> > blocks;
+    size_t n = 0;
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return blocks[i >> LOG2][i & ((1u << LOG2) - 1)]; }
+    const T &operator[](size_t i) const { return blocks[i >> LOG2][i & ((1u << LOG2) - 1)]; }
+    void push_back(const T &v) {
+        if ((n >> LOG2) == blocks.size()) blocks.emplace_back(new T[(size_t) 1 << LOG2]);
+        (*this)[n] = v;
+        n++;
+    }
+    // room for `len` contiguous items: the index of the first (the tail of a block that cannot hold them stays unused)
+    size_t appendRun(const T *src, size_t len) {
+        const size_t cap = (size_t) 1 << LOG2;
+        if (len > cap) return SIZE_MAX;
+        if (n == blocks.size() * cap || (n & (cap - 1)) + len > cap) {
+            n = blocks.size() * cap;
+            blocks.emplace_back(new T[cap]);
+        }
+        const size_t at = n;
+        memcpy(&(*this)[at], src, len * sizeof(T));
+        n += len;
+        return at;
+    }
+    void swap(Blocks &o) {
+        blocks.swap(o.blocks);
+        std::swap(n, o.n);
+    }
+};
 
 double computeLogPval(double eval, double logCalibration) {   // besthitbyset.cpp:10-20
     if (eval == 0) return log(DBL_MIN) - logCalibration;
@@ -70,9 +178,9 @@ struct sd_agg {
     // after besthitbyset + combinehits filter: per worker thread, any order until finish()
     struct HitKey { uint64_t cell; uint32_t q, idx; };  // cell = qSet * nTSets + tSet (64 bit: 30 000 x 30 000 sets and more)
     std::vector<uint32_t> qDbKey, tDbKey;               // optional DB keys (sd_agg_set_keys): order inside entries, compareHits tie-break
-    std::vector<std::vector<BestHit> > tBest;
-    std::vector<std::vector<HitKey> > tKey;
-    std::vector<std::string> tCigar;
+    std::vector<Blocks<BestHit, 13> > tBest;
+    std::vector<Blocks<HitKey, 14> > tKey;
+    std::vector<Blocks<char, 20> > tCigar;   // a CIGAR is contiguous inside a 1-MB block
     std::vector<const BestHit *> best;   // finish(): (qSet, tSet, q) order
     uint64_t nAligned = 0, nAccepted = 0;
     // finish(): entries sorted by (qSet, tSet), hits by query key
@@ -103,6 +211,28 @@ int sd_agg_create(const uint32_t *qSetOf, const int32_t *qLen, uint32_t nQ, cons
 }
 
 void sd_agg_destroy(sd_agg *a) { delete a; }
+
+// the two text conversions of this file, callable on their own (tests/test_host_text.py compares them with printf / strtod)
+int sd_host_quantise_3e(double v, char *text, double *back) {
+    if (!text || !back) return SD_EINVAL;
+    char t[32];
+    *back = quantise3E(v, t);
+    memcpy(text, t, 16);
+    text[15] = '\0';
+    return SD_OK;
+}
+
+int sd_host_compress_backtrace(const char *bt, uint64_t n, char *out, uint64_t cap, uint64_t *len) {
+    if ((n && !bt) || !len) return SD_EINVAL;
+    std::string c;
+    sd::compressBacktraceAppend(bt ? bt : "", (size_t) n, c);
+    *len = c.size();
+    if (out) {
+        if (cap < c.size()) return SD_ENOMEM;
+        memcpy(out, c.data(), c.size());
+    }
+    return SD_OK;
+}
 
 // pairs of one query must be contiguous
 int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ, const uint32_t *pairT,
@@ -141,13 +271,15 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
         uint32_t t;     // target index
         float seqId;
     };
-#pragma omp parallel num_threads(T) reduction(+ : accepted)
+    int tooLong = 0;
+#pragma omp parallel num_threads(T) reduction(+ : accepted) reduction(| : tooLong)
     {
         const int th = omp_get_thread_num();
         // thread-private containers (the shared vectors' headers sit on common cache lines), swapped back at the end
-        std::vector<BestHit> myBest;
-        std::string myCigar;
-        std::vector<sd_agg::HitKey> myKey;
+        Blocks<BestHit, 13> myBest;
+        Blocks<char, 20> myCigar;
+        Blocks<sd_agg::HitKey, 14> myKey;
+        std::string cigar;
         myBest.swap(a->tBest[th]);
         myCigar.swap(a->tCigar[th]);
         myKey.swap(a->tKey[th]);
@@ -225,7 +357,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                 // >= -13.7277.  Four in five best hits of a proteome-scale search end here, before any formatting.
                 if (c->eval >= 1.1e-6) continue;
                 BestHit b;
-                char evalText[32], lpText[32], pvalText[32];
+                char evalText[32] = {0}, lpText[32], pvalText[32] = {0};   // (the record fields are zero behind the text: the same bytes every run)
                 const double evParsed = quantise3E(c->eval, evalText);
                 const double logP = quantise3E(computeLogPval(evParsed, log(1)), lpText);       // besthitbyset.cpp:129
                 if (!(logP < logPvalThr)) continue;                                            // combinehits.cpp:107-112
@@ -234,17 +366,25 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                 memcpy(b.pvalText, pvalText, sizeof(b.pvalText));
                 b.evalText[sizeof(b.evalText) - 1] = '\0';
                 b.pvalText[sizeof(b.pvalText) - 1] = '\0';
+                memset(b.seqIdText, 0, sizeof(b.seqIdText));
                 char *e = sd::seqIdToBuffer(c->seqId, b.seqIdText);
                 *e = '\0';
                 b.q = q; b.t = c->t; b.qSet = qs; b.tSet = ts;
                 b.qStart = r.qStart; b.qEnd = r.qEnd; b.qLen = qL;
                 b.tStart = r.tStart; b.tEnd = r.tEnd; b.tLen = c->dbLen;
                 b.arena = (uint32_t) th;
-                b.cigarOff = myCigar.size();
+                b.cigarOff = 0;
                 b.cigarLen = 0;
                 if (btPool && r.btLen > 0) {
-                    sd::compressBacktraceAppend(btPool + r.btOffset, (size_t) r.btLen, myCigar);
-                    b.cigarLen = (uint32_t) (myCigar.size() - b.cigarOff);
+                    cigar.clear();
+                    sd::compressBacktraceAppend(btPool + r.btOffset, (size_t) r.btLen, cigar);
+                    const size_t at = myCigar.appendRun(cigar.data(), cigar.size());
+                    if (at == SIZE_MAX) {   // a CIGAR of more than 2^20 characters: no sequence of <= 65 535 residues has one
+                        tooLong = 1;
+                        continue;
+                    }
+                    b.cigarOff = at;
+                    b.cigarLen = (uint32_t) cigar.size();
                 }
                 sd_agg::HitKey hk;
                 hk.cell = (uint64_t) qs * a->nTSets + ts; hk.q = a->qDbKey.empty() ? q : a->qDbKey[q]; hk.idx = (uint32_t) myBest.size();
@@ -256,6 +396,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
         myCigar.swap(a->tCigar[th]);
         myKey.swap(a->tKey[th]);
     }
+    if (tooLong) return SD_EINVAL;
     a->nAligned += nPairs;
     a->nAccepted += accepted;
     if (dbg) fprintf(stderr, "[sd_agg_add] pairs %u groups %zu threads %d: setup %.1f ms, parallel %.1f ms\n", nPairs, nGroups, T,
@@ -278,7 +419,8 @@ int sd_agg_finish(sd_agg *a, uint64_t *nEntries, uint64_t *nHits) {
     std::vector<Ref> refs(total);
     size_t w = 0;
     for (size_t t = 0; t < a->tKey.size(); t++)
-        for (const sd_agg::HitKey &k : a->tKey[t]) {
+        for (size_t x = 0; x < a->tKey[t].size(); x++) {
+            const sd_agg::HitKey &k = a->tKey[t][x];
             refs[w].cell = k.cell;
             refs[w].q = k.q;
             refs[w].hit = &a->tBest[t][k.idx];
@@ -386,7 +528,7 @@ int sd_agg_records(sd_agg *a, const uint32_t *clusterOfHit, const uint32_t *rank
                     rm.cigarLen = b.cigarLen;
                     memcpy(o + w, &rm, sizeof(rm));
                     memset(o + w + sizeof(rm), 0, need - sizeof(rm));
-                    memcpy(o + w + sizeof(rm), a->tCigar[b.arena].data() + b.cigarOff, b.cigarLen);
+                    if (b.cigarLen) memcpy(o + w + sizeof(rm), &a->tCigar[b.arena][b.cigarOff], b.cigarLen);
                 }
                 w += need;
             }
