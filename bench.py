@@ -329,7 +329,7 @@ def measure(args, rank, local_rank, world, dist, torch):
     gathered, gather_sizes, tsv_info = None, None, None
     if dist is not None:
         # the one exchange of the path: every rank's cluster records to rank 0, which writes the result TSV from the gathered buffer
-        recs = np.concatenate([o['records'] for o in outs]) if outs else np.zeros(0, np.uint8)
+        recs = outs[-1]['records_all'] if outs else np.zeros(0, np.uint8)   # the ranges' records back to back in one buffer
         if comm is not None:
             gathered, gather_sizes = comm.gather_bytes(recs)
         else:

@@ -541,6 +541,10 @@ typedef void (*sd_aln_sink)(void *user, uint32_t firstQuery, uint32_t nQ, uint32
 int sd_search_set_sinks(sd_search *s, sd_pref_sink pref, sd_aln_sink aln, void *user);
 /* queries per device chunk (at most; 0 = the library's choice) for the following sd_search_stream calls (results do not depend on it) */
 int sd_search_set_chunk_queries(sd_search *s, int32_t chunkQueries);
+/* on != 0: the following sd_search_stream calls build every range's cluster records (sd_search_result_records) when the range is
+ * finished, inside the pipeline, instead of on demand afterwards -- what a rank of a multi-GPU run asks for, whose records all go into
+ * the final gather (sd_gather_results) */
+int sd_search_set_want_records(sd_search *s, int on);
 /* query ranges [rangeBegin[i], rangeEnd[i]) of `query` (whole query sets each), streamed through one pipeline;
  * sameDb != 0: query protein i is target protein i (identity pairs, self hit first).  results[nRanges] receives one
  * handle per range (destroy each). */

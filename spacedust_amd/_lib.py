@@ -199,6 +199,7 @@ def load():
         'sd_search_target': (_vp, [_vp]),
         'sd_search_set_sinks': (C.c_int, [_vp, _vp, _vp, _vp]),
         'sd_search_set_chunk_queries': (C.c_int, [_vp, C.c_int32]),
+        'sd_search_set_want_records': (C.c_int, [_vp, C.c_int]),
         'sd_search_stream': (C.c_int, [_vp, C.POINTER(SetDbView), C.c_int, C.c_uint32, _vp, _vp, _vp]),
         'sd_search_result_counts': (C.c_int, [_vp, _vp]),
         'sd_search_result_arrays': (C.c_int, [_vp] + [_vp] * 12),

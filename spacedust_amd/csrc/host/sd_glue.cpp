@@ -497,25 +497,57 @@ static_assert(sizeof(RecCluster) == 32 && sizeof(RecMember) == 76, "record layou
 int sd_agg_records(sd_agg *a, const uint32_t *clusterOfHit, const uint32_t *rankInCluster, const uint32_t *nClusters,
                    const double *pCO, const double *pMH, const uint32_t *clusterSize, void *out, uint64_t cap, uint64_t *bytes) {
     if (!a || !bytes) return SD_EINVAL;
-    uint64_t w = 0;
-    char *o = (char *) out;
-    std::vector<uint32_t> order;
-    for (size_t e = 0; e + 1 < a->entryOff.size(); e++) {
+    // Linear in the hits and parallel over the entries (a 1 000-proteome step holds 3 500 entries with 180 clusters of 750 hits each:
+    // looking for every cluster's members among all hits of its entry was a second per step, paid twice -- size probe and build -- by every
+    // rank of a multi-GPU run behind its last kernel).  Pass 1: bytes per entry; pass 2: every entry written at its offset, the members
+    // of a cluster placed through the clusters' start positions (sizes in clusterSize[off + c], rank inside from rankInCluster).
+    const size_t nE = a->entryOff.empty() ? 0 : a->entryOff.size() - 1;
+    std::vector<uint64_t> at(nE + 1, 0);
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(| : bad)
+    for (size_t e = 0; e < nE; e++) {
         const uint64_t off = a->entryOff[e], end = a->entryOff[e + 1];
-        for (uint32_t c = 0; c < nClusters[e]; c++) {
-            const uint32_t m = clusterSize[off + c];
-            order.assign(m, 0);
+        uint64_t sz = (uint64_t) nClusters[e] * sizeof(RecCluster), members = 0, sizes = 0;
+        if (nClusters[e] > end - off) bad |= 1;
+        else
+            for (uint32_t c = 0; c < nClusters[e]; c++) sizes += clusterSize[off + c];
+        for (uint64_t h = off; h < end; h++)
+            if (clusterOfHit[h] != UINT32_MAX) {
+                if (clusterOfHit[h] >= nClusters[e] || clusterOfHit[h] >= end - off || rankInCluster[h] >= clusterSize[off + clusterOfHit[h]]) bad |= 1;
+                sz += sizeof(RecMember) + ((a->best[h]->cigarLen + 3u) & ~3u);
+                members++;
+            }
+        if (members != sizes) bad |= 1;   // every member slot of every cluster is some hit's (cluster, rank)
+        at[e + 1] = sz;
+    }
+    if (bad) return SD_EINVAL;
+    for (size_t e = 0; e < nE; e++) at[e + 1] += at[e];
+    *bytes = at[nE];
+    char *o = (char *) out;
+    if (!o) return SD_OK;
+    if (at[nE] > cap) return SD_ENOMEM;
+#pragma omp parallel
+    {
+        std::vector<uint32_t> start, order;
+#pragma omp for schedule(dynamic, 16)
+        for (size_t e = 0; e < nE; e++) {
+            const uint64_t off = a->entryOff[e], end = a->entryOff[e + 1];
+            const uint32_t nC = nClusters[e];
+            if (nC == 0) continue;
+            start.assign((size_t) nC + 1, 0);
+            for (uint32_t c = 0; c < nC; c++) start[c + 1] = start[c] + clusterSize[off + c];
+            order.assign(start[nC], 0);
             for (uint64_t h = off; h < end; h++)
-                if (clusterOfHit[h] == c) order[rankInCluster[h]] = (uint32_t) (h - off);
-            if (o && w + sizeof(RecCluster) <= cap) {
+                if (clusterOfHit[h] != UINT32_MAX) order[start[clusterOfHit[h]] + rankInCluster[h]] = (uint32_t) (h - off);
+            uint64_t w = at[e];
+            for (uint32_t c = 0; c < nC; c++) {
+                const uint32_t m = clusterSize[off + c];
                 RecCluster rc = {m, a->entryQSet[e], a->entryTSet[e], 0, pCO[off + c], pMH[off + c]};
                 memcpy(o + w, &rc, sizeof(rc));
-            }
-            w += sizeof(RecCluster);
-            for (uint32_t x = 0; x < m; x++) {
-                const BestHit &b = *a->best[off + order[x]];
-                const uint64_t need = sizeof(RecMember) + ((b.cigarLen + 3u) & ~3u);
-                if (o && w + need <= cap) {
+                w += sizeof(RecCluster);
+                for (uint32_t x = 0; x < m; x++) {
+                    const BestHit &b = *a->best[off + order[start[c] + x]];
+                    const uint64_t need = sizeof(RecMember) + ((b.cigarLen + 3u) & ~3u);
                     RecMember rm;
                     memset(&rm, 0, sizeof(rm));
                     rm.q = b.q;
@@ -529,13 +561,12 @@ int sd_agg_records(sd_agg *a, const uint32_t *clusterOfHit, const uint32_t *rank
                     memcpy(o + w, &rm, sizeof(rm));
                     memset(o + w + sizeof(rm), 0, need - sizeof(rm));
                     if (b.cigarLen) memcpy(o + w + sizeof(rm), &a->tCigar[b.arena][b.cigarOff], b.cigarLen);
+                    w += need;
                 }
-                w += need;
             }
         }
     }
-    *bytes = w;
-    return (o && w > cap) ? SD_ENOMEM : SD_OK;
+    return SD_OK;
 }
 
 // A record buffer that came over the wire (RCCL / TCP gather) is checked before anything indexes with it: whole records, set and

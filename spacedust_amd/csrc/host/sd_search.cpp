@@ -139,6 +139,8 @@ struct sd_search_result {
     std::vector<uint64_t> entryOff;
     std::vector<uint32_t> entryQ, entryT, hitQ, hitT, clusterOf, rank, nClusters, cSize;
     std::vector<double> pval, pCO, pMH;
+    std::vector<char> records;   // the range's cluster records, built inside the stream (sd_search_set_want_records)
+    bool haveRecords = false;
     ~sd_search_result() {
         if (agg) sd_agg_destroy(agg);
     }
@@ -164,6 +166,7 @@ struct sd_search {
     sd_sw_params swParRun;   // swPar with the E-value gate of the running stream (sd_search_stream: predicate pushdown)
     bool targetHasGroups = false;   // sd_seqset_set_groups was applied to tSeqs
     bool bestOnDevice = false;      // the running stream lets the device keep only besthitbyset's candidates
+    bool wantRecords = false;       // sd_search_set_want_records
     sd_ch_params chPar;
     std::vector<int32_t> tLen;
     std::vector<uint32_t> tSetSize;
@@ -449,6 +452,15 @@ int sd_search_set_chunk_queries(sd_search *s, int32_t chunkQueries) {
     return SD_OK;
 }
 
+// on != 0: sd_search_stream builds every range's cluster records when the range is finalised -- inside the pipeline, on the thread that is
+// otherwise waiting for the lanes -- so that sd_search_result_records is a copy.  (A rank of a multi-GPU run needs them all for the
+// final gather; built behind the stream they were seconds of host time after the last kernel.)
+int sd_search_set_want_records(sd_search *s, int on) {
+    if (!s) return SD_EINVAL;
+    s->wantRecords = on != 0;
+    return SD_OK;
+}
+
 int sd_search_stats(sd_search *s, uint64_t *stats, double *seconds) {
     if (!s) return SD_EINVAL;
     if (stats) memcpy(stats, s->stats, sizeof(s->stats));
@@ -726,6 +738,20 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         tm[T_CLUSTERHITS] += nowSec() - t0;
         uint64_t na = 0, nacc = 0;
         sd_agg_stats(R.agg, &na, &nacc);
+        if (s->wantRecords) {
+            static const uint32_t zero32 = 0;
+            static const double zeroD = 0.0;
+            const bool empty = R.hitQ.empty();
+            uint64_t need = 0;
+            for (int pass = 0; pass < 2; pass++) {   // size, then the records
+                rc = sd_agg_records(R.agg, empty ? &zero32 : R.clusterOf.data(), empty ? &zero32 : R.rank.data(),
+                                    R.nClusters.empty() ? &zero32 : R.nClusters.data(), empty ? &zeroD : R.pCO.data(), empty ? &zeroD : R.pMH.data(),
+                                    empty ? &zero32 : R.cSize.data(), pass ? R.records.data() : nullptr, need, &need);
+                if (rc != SD_OK) return s->fail(rc, "sd_agg_records");
+                if (!pass) R.records.resize(need);
+            }
+            R.haveRecords = true;
+        }
         R.counts[0] = ne;
         R.counts[1] = nh;
         R.counts[2] = nClu;
@@ -1015,6 +1041,13 @@ int sd_search_result_arrays(sd_search_result *r, uint64_t *entryOff, uint32_t *e
 
 int sd_search_result_records(sd_search_result *r, void *out, uint64_t cap, uint64_t *bytes) {
     if (!r || !r->agg || !bytes) return SD_EINVAL;
+    if (r->haveRecords) {   // built inside the stream
+        *bytes = r->records.size();
+        if (!out) return SD_OK;
+        if (cap < r->records.size()) return SD_ENOMEM;
+        if (!r->records.empty()) memcpy(out, r->records.data(), r->records.size());
+        return SD_OK;
+    }
     static const uint32_t zero32 = 0;
     static const double zeroD = 0.0;
     const bool empty = r->hitQ.empty();

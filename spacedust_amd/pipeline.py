@@ -212,12 +212,23 @@ class ClusterSearch:
         re = np.array([r[1] for r in ranges], np.uint32)
         handles = (C.c_void_p * max(n, 1))()
         _, tm0 = self._raw_stats()
+        # the ranges' cluster records are built inside the stream, not behind it (a multi-GPU rank's hand-over to the final gather)
+        L.sd_search_set_want_records(self.h, 1 if want_records else 0)
         rc = L.sd_search_stream(self.h, C.byref(qv), 1 if same_db else 0, n, ptr(rb), ptr(re), handles)
         if rc != 0:
             raise _lib.SdError('sd_search_stream failed (%d): %s' % (rc, L.sd_search_last_error(self.h).decode(errors='replace')))
         _, tm1 = self._raw_stats()
         tsv_paths = tsv_paths if tsv_paths is not None else [None] * n
         results = []
+        records_all, rec_at = None, None
+        if want_records:   # one buffer for the records of all ranges, in range order: what sd_gather_results sends, without another copy
+            sizes = []
+            for ri in range(n):
+                need = C.c_uint64()
+                api._check(None, L.sd_search_result_records(C.c_void_p(handles[ri]), None, 0, C.byref(need)), 'sd_search_result_records')
+                sizes.append(int(need.value))
+            rec_at = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            records_all = np.empty(int(rec_at[-1]), np.uint8)
         for ri in range(n):
             h = C.c_void_p(handles[ri])
             cnt = np.zeros(8, np.uint64)
@@ -245,10 +256,9 @@ class ClusterSearch:
                            'sd_search_result_write_tsv')
             records = None
             if want_records:   # the cluster records of the range: what a rank sends to the root (sd_search_result_records)
-                need = C.c_uint64()
-                api._check(None, L.sd_search_result_records(h, None, 0, C.byref(need)), 'sd_search_result_records')
-                records = np.zeros(int(need.value), np.uint8)
-                if need.value:
+                records = records_all[int(rec_at[ri]):int(rec_at[ri + 1])]
+                if records.size:
+                    need = C.c_uint64()
                     api._check(None, L.sd_search_result_records(h, ptr(records), records.nbytes, C.byref(need)), 'sd_search_result_records')
             L.sd_search_result_destroy(h)
             results.append(dict(records=records, entries=ne, matched_hits=nh, clusters=int(cnt[2]), cluster_hits=int(cnt[3]), aligned=int(cnt[4]),
@@ -258,6 +268,7 @@ class ClusterSearch:
             d = tm1 - tm0
             results[-1]['timing'] = {name: float(d[i]) for i, name in enumerate(_TIME_NAMES) if i >= 2 and name != 'total'}
             results[-1]['timing']['total'] = float(tm1[11])
+            results[-1]['records_all'] = records_all   # (want_records) the ranges' records back to back; every result's 'records' is a view of it
         return results
 
 
