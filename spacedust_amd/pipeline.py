@@ -197,11 +197,13 @@ class ClusterSearch:
         return self.search_stream(Q, [rng], same_db=same_db, chunk_queries=chunk_queries, tsv_paths=[tsv_path],
                                   canonical=canonical)[0]
 
-    def search_stream(self, Q, ranges, same_db=False, chunk_queries=None, tsv_paths=None, canonical=True, want_records=False):
+    def search_stream(self, Q, ranges, same_db=False, chunk_queries=None, tsv_paths=None, canonical=True, want_records=False, arrays='all'):
         """The workflow for several query ranges [a,b) of Q (whole query sets each), streamed through one pipeline
         (sd_search_stream): the prefilter of the next chunk -- of the same or of the next range -- overlaps the alignments
         of the current one.  Every range gets its own aggregation, clusterhits call and result record.  Returns the list
-        of result dicts (stage timings, summed over the stream, ride on the last)."""
+        of result dicts (stage timings, summed over the stream, ride on the last).
+        arrays: which ranges' result arrays (entries, hits, P-values, clusters) are copied out of the library's result handles into numpy
+        arrays -- 'all', or 'last' (the other ranges return their counters only: a caller that streams many ranges and reads one)."""
         L = self.L
         if chunk_queries:
             L.sd_search_set_chunk_queries(self.h, int(chunk_queries))
@@ -234,6 +236,17 @@ class ClusterSearch:
             cnt = np.zeros(8, np.uint64)
             L.sd_search_result_counts(h, ptr(cnt))
             ne, nh = int(cnt[0]), int(cnt[1])
+            if arrays == 'last' and ri != n - 1 and tsv_paths[ri] is None:   # counters (and records) only
+                records = None
+                if want_records:
+                    records = records_all[int(rec_at[ri]):int(rec_at[ri + 1])]
+                    if records.size:
+                        need = C.c_uint64()
+                        api._check(None, L.sd_search_result_records(h, ptr(records), records.nbytes, C.byref(need)), 'sd_search_result_records')
+                L.sd_search_result_destroy(h)
+                results.append(dict(records=records, entries=ne, matched_hits=nh, clusters=int(cnt[2]), cluster_hits=int(cnt[3]), aligned=int(cnt[4]),
+                                    accepted=int(cnt[5]), prefilter_hits=int(cnt[6]), timing={}, cluster_out=None))
+                continue
             eo = np.zeros(ne + 1, np.uint64)
             eq, et = np.zeros(max(ne, 1), np.uint32), np.zeros(max(ne, 1), np.uint32)
             hq, ht, pv = np.zeros(max(nh, 1), np.uint32), np.zeros(max(nh, 1), np.uint32), np.zeros(max(nh, 1), np.float64)

@@ -191,3 +191,47 @@ def test_sdgpu_clustersearch_eight_ranks_equal_one(gpu, tmp_path):
     assert sorted_md5(one, drop_first_column=True) == sorted_md5(eight, drop_first_column=True)
     keys = [int(l.split('\t')[0][1:]) for l in eight if l.startswith('#')]
     assert keys == list(range(len(keys)))
+
+
+def test_records_built_inside_the_stream_equal_records_on_demand(gpu):
+    """a rank's hand-over to the final gather: the cluster records built when a range is finalised (sd_search_set_want_records, one buffer for
+    all ranges) are the bytes sd_search_result_records builds on demand from the finished results, and a stream that copies out the last
+    range's arrays only (`arrays='last'`, what bench.py times) reports the same counters and the same records for every range"""
+    import ctypes as C
+    from spacedust_amd import _lib
+    from spacedust_amd.api import Host, Context
+    from spacedust_amd.pipeline import SetDB, ClusterSearch
+    from spacedust_amd.synth import make_proteomes
+    L = _lib.load()
+    ps = make_proteomes(6, genes_per_proteome=150, n_families=220, seed=23)
+    db = SetDB.from_proteomes(ps)
+    host = Host(4)
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
+    ranges = [(int(ps.set_start[s]), int(ps.set_start[s + 1])) for s in range(6)]
+    full = cs.search_stream(db, ranges, same_db=True, chunk_queries=64, want_records=True)
+    lazy = cs.search_stream(db, ranges, same_db=True, chunk_queries=64, want_records=True, arrays='last')
+    assert sum(o['records'].size for o in full) > 10000 and full[-1]['records_all'].size == sum(o['records'].size for o in full)
+    for a, b in zip(full, lazy):
+        for key in ('entries', 'matched_hits', 'clusters', 'cluster_hits', 'aligned', 'accepted', 'prefilter_hits'):
+            assert a[key] == b[key], key
+        assert np.array_equal(a['records'], b['records'])
+    assert 'hit_q' not in lazy[0] and np.array_equal(lazy[-1]['hit_q'], full[-1]['hit_q'])
+    assert np.array_equal(full[-1]['records_all'], np.concatenate([o['records'] for o in full]))
+    # on demand: the flag off, the records asked of the finished result handles
+    L.sd_search_set_want_records(cs.h, 0)
+    keep = []
+    from spacedust_amd.pipeline import _setdb_struct
+    qv = _setdb_struct(db, keep)
+    rb = np.array([r[0] for r in ranges], np.uint32)
+    re_ = np.array([r[1] for r in ranges], np.uint32)
+    handles = (C.c_void_p * len(ranges))()
+    assert L.sd_search_stream(cs.h, C.byref(qv), 1, len(ranges), _lib.ptr(rb), _lib.ptr(re_), handles) == 0
+    for ri in range(len(ranges)):
+        h = C.c_void_p(handles[ri])
+        need = C.c_uint64()
+        assert L.sd_search_result_records(h, None, 0, C.byref(need)) == 0
+        buf = np.zeros(int(need.value), np.uint8)
+        if need.value:
+            assert L.sd_search_result_records(h, _lib.ptr(buf), buf.nbytes, C.byref(need)) == 0
+        L.sd_search_result_destroy(h)
+        assert np.array_equal(buf, full[ri]['records']), ri
