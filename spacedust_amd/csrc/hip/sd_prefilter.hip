@@ -1120,11 +1120,75 @@ coarse_offsets_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
     if (q == nQ - 1 && t == 0) vqHitBase[(size_t) nQ * C] = qHitBase[nQ];
 }
 
+// CS_PER hits per thread and step, all loads issued before the first cursor is taken: with one 8-byte load per thread in flight the
+// kernel moved 2.4 TB/s (32 wavefronts x 512 B per CU: a third of what the memory's latency asks for).  The order inside a range is not
+// kept anyway (see above).  KV / DIAG: the input layout and the wide-position form are compiled apart (one 8-byte load per hit, no
+// branches in the loop).
+template <bool KV, bool DIAG>
+__device__ __forceinline__ void coarseScatterBody(uint64_t s, uint64_t e, uint64_t qs, uint32_t tMask, int shift, int cBits, uint32_t *cursor,
+                                                  const uint32_t *__restrict__ inKey, const uint32_t *__restrict__ inVal,
+                                                  const uint2 *__restrict__ inKV, uint2 *__restrict__ outKV, const uint16_t *__restrict__ hitDiag) {
+    constexpr int CS_PER = 8;
+    const uint32_t lowMask = (1u << shift) - 1;
+    uint64_t i = s + threadIdx.x;
+    for (; i + (uint64_t) (CS_PER - 1) * 256 < e; i += (uint64_t) CS_PER * 256) {
+        uint32_t k[CS_PER], v[CS_PER], d[CS_PER];
+#pragma unroll
+        for (int u = 0; u < CS_PER; u++) {
+            const uint64_t x = i + (uint64_t) u * 256;
+            if (KV) {
+                const uint2 kv = inKV[x];
+                k[u] = kv.x;
+                v[u] = kv.y;
+            } else {
+                k[u] = inKey[x];
+                v[u] = inVal[x];
+            }
+            d[u] = DIAG ? (uint32_t) hitDiag[x] & 0xFFu : 0u;
+        }
+        // one cursor update per range and wavefront: the lanes whose hits fall into the same range find each other with cBits ballots,
+        // the first of them takes room for all (a wavefront's 64 returning atomics on 16 - 64 cursors were served one lane at a time)
+        uint32_t p[CS_PER];
+        const int lane = threadIdx.x & 63;
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int u = 0; u < CS_PER; u++) {
+            const uint32_t r = (k[u] & tMask) >> shift;
+            unsigned long long same = __ballot(1);
+            for (int b = 0; b < cBits; b++) {
+                const bool bit = (r >> b) & 1u;
+                const unsigned long long with = __ballot(bit);
+                same &= bit ? with : ~with;
+            }
+            const int leader = __ffsll((long long) same) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&cursor[r], (uint32_t) __popcll(same));
+            p[u] = (uint32_t) __shfl((int) base, leader, 64) + (uint32_t) __popcll(same & below);
+        }
+#pragma unroll
+        for (int u = 0; u < CS_PER; u++) outKV[qs + p[u]] = make_uint2(DIAG ? (d[u] << shift) | (k[u] & lowMask) : k[u], v[u]);
+    }
+    for (; i < e; i += 256) {
+        uint32_t k, v;
+        if (KV) {
+            const uint2 kv = inKV[i];
+            k = kv.x;
+            v = kv.y;
+        } else {
+            k = inKey[i];
+            v = inVal[i];
+        }
+        const uint32_t p = atomicAdd(&cursor[(k & tMask) >> shift], 1u);
+        outKV[qs + p] = make_uint2(DIAG ? (((uint32_t) hitDiag[i] & 0xFFu) << shift) | (k & lowMask) : k, v);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const uint32_t *__restrict__ segBase, int tBits, int cBits,
                       const uint32_t *__restrict__ segOffset, const uint32_t *__restrict__ inKey,
-                      const uint32_t *__restrict__ inVal, const uint2 *__restrict__ inKV, uint32_t *__restrict__ outKey,
-                      uint32_t *__restrict__ outVal,
+                      const uint32_t *__restrict__ inVal, const uint2 *__restrict__ inKV,
+                      uint2 *__restrict__ outKV /* (key, value) pairs: one 8-byte store per hit -- a wavefront's 64 stores go to as many lines,
+                                                   and the address path takes them one line per clock: two 4-byte arrays were twice that */,
                       const uint16_t *__restrict__ hitDiag /* wide stream positions: the diagonal byte goes into the key bits
                                                               above the virtual query's target bits (the range is implied
                                                               by the segment), nullptr otherwise */) {
@@ -1139,19 +1203,12 @@ coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
     __syncthreads();
     const uint32_t tMask = (1u << tBits) - 1;
     const int shift = tBits - cBits;
-    for (uint64_t i = s + threadIdx.x; i < e; i += 256) {
-        uint32_t k, v;
-        if (inKV) {
-            const uint2 kv = inKV[i];
-            k = kv.x;
-            v = kv.y;
-        } else {
-            k = inKey[i];
-            v = inVal[i];
-        }
-        const uint32_t p = atomicAdd(&cursor[(k & tMask) >> shift], 1u);
-        outKey[qs + p] = hitDiag ? (((uint32_t) hitDiag[i] & 0xFFu) << shift) | (k & ((1u << shift) - 1)) : k;
-        outVal[qs + p] = v;
+    if (inKV) {
+        if (hitDiag) coarseScatterBody<true, true>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag);
+        else coarseScatterBody<true, false>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag);
+    } else {
+        if (hitDiag) coarseScatterBody<false, true>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag);
+        else coarseScatterBody<false, false>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag);
     }
 }
 
@@ -3191,8 +3248,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 const uint2 *pKV = useJoin ? (const uint2 *) dHitsKV.p : (const uint2 *) nullptr;
                 WsView<uint32_t> dSegBase(ctx, "pf.dSegBase");
                 WsView<uint32_t> dSegCount(ctx, "pf.dSegCount");
-                WsView<uint32_t> dKeyC(ctx, "pf.dKeyC");
-                WsView<uint32_t> dValC(ctx, "pf.dValC");
+                WsView<uint2> dKVC(ctx, "pf.dKVC");
                 if (useJoin && jcBits > 0) {   // the join wrote (query, target range) sub-segments: they are the virtual queries
                     cBits = jcBits;
                     nVQ = nVQ0 << cBits;
@@ -3239,8 +3295,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         SD_HIP(ctx, dVQHitBase.alloc((size_t) nVQ + 1));
                         SD_HIP(ctx, dSegBase.alloc(nVQ0 + 1));
                         SD_HIP(ctx, dSegCount.alloc((size_t) std::max<uint32_t>(nSeg, 1) * C));
-                        SD_HIP(ctx, dKeyC.alloc(nHits));
-                        SD_HIP(ctx, dValC.alloc(nHits));
+                        SD_HIP(ctx, dKVC.alloc(nHits));
                         SD_HIP(ctx, hipMemcpyAsync(dSegBase.p, hSegBase, (nVQ0 + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
                         if (nSeg > 0)
                             hipLaunchKernelGGL(coarse_count_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, tBits0,
@@ -3249,14 +3304,14 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                            dSegCount.p, dVQHitBase.p);
                         if (nSeg > 0)
                             hipLaunchKernelGGL(coarse_scatter_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, tBits0,
-                                               cBits, dSegCount.p, dKeyA.p, dValA.p, pKV, dKeyC.p, dValC.p,
+                                               cBits, dSegCount.p, dKeyA.p, dValA.p, pKV, dKVC.p,
                                                widePos ? (const uint16_t *) dDiag.p : (const uint16_t *) nullptr);
                         // (hSegBase is pinned and persistent: the upload may still be reading it; the next sub-batch writes it only after
                         // several waits for this stream)
                         pHitBase = dVQHitBase.p;
-                        pKey = dKeyC.p;
-                        pVal = dValC.p;
-                        pKV = nullptr;
+                        pKey = nullptr;   // the ranges' hits are (key, value) pairs, like the join's stream
+                        pVal = nullptr;
+                        pKV = dKVC.p;
                     }
                 }
                 // hot-target filter (hot_filter_kernel): every (virtual) query's segment is compacted in place to the hits of
