@@ -419,7 +419,7 @@ def measure(args, rank, local_rank, world, dist, torch):
               'prefilter_select_hits': 12 * Cn + 10 * st['prefilter_hits']}
     pmc = {}
     pmc_src = None
-    for fn in ('r05i_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04d_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for fn in ('r05p_pmc_traffic.json', 'r05i_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04d_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
             pmc_src = 'profiles/' + fn
