@@ -674,31 +674,20 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     };
 
     int status = SD_OK;
-    // aggregation jobs submitted and not yet collected, oldest first (the stage thread runs them one at a time, in this order).  This thread
-    // used to collect a chunk's job before it handed over the next chunk's, i.e. it stood still while the stage was busy: 0.24 s per
-    // 1.5-s step when a rank has two CPUs (1 000 proteomes, SD_CPUS=2).  Now up to aggDepth jobs wait in the stage's queue.  A job reads
-    // its chunk's slot of the alignment-buffer ring (eight slots, one per chunk handed to the lanes): the slot of chunk x is taken again by
-    // chunk x + 8, when the chunks up to x + 8 - lanes have been retired -- so lanes + aggDepth <= 8 keeps a queued job's slot untouched.
-    struct AggJob {
-        std::future<std::pair<int, double> > fut;
-        size_t chunk;
-    };
-    std::deque<AggJob> aggQ;
-    const size_t aggDepth = (size_t) std::max(1, std::min(getenv("SD_AGG_DEPTH") ? atoi(getenv("SD_AGG_DEPTH")) : 3, 8 - s->alignLanes));
+    std::future<std::pair<int, double> > pending;
     std::unique_ptr<double> aggCpu(new double(0.0));   // thread CPU seconds of the aggregation jobs
     double *aggCpuP = aggCpu.get();
     const double mainCpu0 = threadCpuSec();
-    auto collectOldest = [&]() {
-        if (aggQ.empty()) return;
+    bool havePending = false;
+    size_t pendingChunk = 0;   // chunk whose aggregation job `pending` is
+    auto waitPending = [&]() {
+        if (!havePending) return;
         const double t0 = nowSec();
-        const std::pair<int, double> r = aggQ.front().fut.get();
-        aggQ.pop_front();
+        const std::pair<int, double> r = pending.get();
         tm[T_AGG_WAIT] += nowSec() - t0;
         tm[T_AGG_BUSY] += r.second;
+        havePending = false;
         if (r.first != SD_OK && status == SD_OK) status = s->fail(r.first, "sd_agg_add");
-    };
-    auto waitPending = [&]() {   // every job submitted so far
-        while (!aggQ.empty()) collectOldest();
     };
 
     auto finalize = [&](uint32_t r) -> int {
@@ -893,16 +882,14 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             s->stats[S_CELLS_TB] += a->tb;
             s->stats[S_PAIRS] += a->n;
             pairsOfRange[r] += a->n;
-            while (aggQ.size() >= aggDepth) collectOldest();
-            while (!aggQ.empty() && aggQ.front().fut.wait_for(std::chrono::seconds(0)) == std::future_status::ready) collectOldest();
+            waitPending();
             if (status != SD_OK) return;
             sd_agg *agg = res[r]->agg;
             sd_search::AlnBuf *bp = a->B;
             sd_search *sp = s;
             const uint32_t nOut = a->nOut;
-            AggJob job;
-            job.chunk = ci;
-            job.fut = aggStage.submit([agg, bp, nOut, c0, nq, sp, aggCpuP]() {
+            pendingChunk = ci;
+            pending = aggStage.submit([agg, bp, nOut, c0, nq, sp, aggCpuP]() {
                 const double t1 = nowSec();
                 const double cpu1 = threadCpuSec();
                 struct AddCpu {   // the aggregation jobs run one at a time: a plain accumulator
@@ -915,7 +902,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
                                     : SD_OK;
                 return std::make_pair(rc2, nowSec() - t1);
             });
-            aggQ.push_back(std::move(job));
+            havePending = true;
         } else if (s->alnSink) {
             waitPending();
             s->alnSink(s->sinkUser, c0, nq, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -923,18 +910,16 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         if (lastChunkOf[r] == (int64_t) ci) toFinalize.push_back(std::make_pair(r, ci));
         // ranges whose last aggregation job has finished meanwhile
         while (!toFinalize.empty() && status == SD_OK) {
-            // jobs still queued may belong to the range at the front (its last chunks with pairs): the range is finalised only once
-            // they have been collected -- never beside them (the queue is in chunk order: a job of a later chunk at its head means every
-            // job of the front range is done)
-            bool later = false;   // a job of the front range has not finished: come back for it later
-            while (!aggQ.empty() && aggQ.front().chunk <= toFinalize.front().second && status == SD_OK) {
-                if (aggQ.front().fut.wait_for(std::chrono::seconds(0)) != std::future_status::ready) {
-                    later = true;
-                    break;
-                }
-                collectOldest();
+            // the aggregation job in flight may belong to the range at the front (its last chunk with pairs, when later chunks of
+            // the range had none): the range is finalised only once that job has been collected -- never beside it
+            // (jobs run one at a time, each submitted after the previous was collected: a job of a later chunk in flight means
+            // every job of the front range is done)
+            const bool mine = havePending && pendingChunk <= toFinalize.front().second;
+            if (mine) {
+                if (pending.wait_for(std::chrono::seconds(0)) != std::future_status::ready) break;   // come back for it later
+                waitPending();
+                if (status != SD_OK) break;
             }
-            if (later || status != SD_OK) break;
             const uint32_t fr = toFinalize.front().first;
             toFinalize.erase(toFinalize.begin());
             const int rc = finalize(fr);
