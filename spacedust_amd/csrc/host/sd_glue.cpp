@@ -212,7 +212,7 @@ int sd_agg_create(const uint32_t *qSetOf, const int32_t *qLen, uint32_t nQ, cons
 
 void sd_agg_destroy(sd_agg *a) { delete a; }
 
-// the two text conversions of this file, callable on their own (tests/test_host_text.py compares them with printf / strtod)
+// the two text conversions of this file, callable on their own (tests/test_host_aggregation.py compares them with printf / strtod and a letter-by-letter loop)
 int sd_host_quantise_3e(double v, char *text, double *back) {
     if (!text || !back) return SD_EINVAL;
     char t[32];
