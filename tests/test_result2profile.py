@@ -114,3 +114,65 @@ def test_modules_result2profile_subtractdbs_mergedbs(tmp_path):
     sdgpu('mergedbs', tmp_path / 'k', tmp_path / 'm', tmp_path / 'a', tmp_path / 's')
     m = read_db(str(tmp_path / 'm'))
     assert m[0] == read_db(str(tmp_path / 'a'))[0] + s[0] and m[1] == s[1] and m[2] == read_db(str(tmp_path / 'a'))[2]
+
+
+def _family(rng, length, rows, div_lo, div_hi):
+    """a centre and `rows` homologs made from it (substitutions at a per-row rate, 1 % target gaps, 1 % centre gaps of one to three
+    letters, ragged ends, flanks), with the alignment each was made by: centre start, target start, backtrace (M, I = target gap,
+    D = centre gap; first and last step a match, as a Smith-Waterman path has them)"""
+    letters = list('ACDEFGHIKLMNPQRSTVWY')
+    centre = ''.join(rng.choice(letters, length))
+    targets, qs, ts, bts = [], [], [], []
+    for _ in range(rows):
+        div = rng.uniform(div_lo, div_hi)
+        a = int(rng.integers(0, max(1, length // 10))) if rng.random() < 0.5 else 0
+        b = length - (int(rng.integers(0, max(1, length // 10))) if rng.random() < 0.5 else 0)
+        head = ''.join(rng.choice(letters, int(rng.integers(0, 6))))
+        t, bt = [head], []
+        p = a
+        while p < b:
+            u = rng.random()
+            inner = p != a and p != b - 1
+            if inner and u < 0.01:
+                n = min(int(rng.integers(1, 4)), b - 1 - p)
+                bt.append('I' * n)
+                p += n
+            elif inner and u < 0.02:
+                n = int(rng.integers(1, 4))
+                t.append(''.join(rng.choice(letters, n)))
+                bt.append('D' * n)
+                t.append(centre[p])
+                bt.append('M')
+                p += 1
+            else:
+                t.append(centre[p] if rng.random() > div else str(rng.choice(letters)))
+                bt.append('M')
+                p += 1
+        t.append(''.join(rng.choice(letters, int(rng.integers(0, 6)))))
+        targets.append(''.join(t))
+        qs.append(a)
+        ts.append(len(head))
+        bts.append(''.join(bt))
+    return centre, targets, qs, ts, bts
+
+
+def test_deep_alignments_equal_reference_classes():
+    """what an iteration of a proteome-scale search hands to result2profile -- alignments of hundreds of rows -- where the regression
+    input has a handful per query: centres of 64 - 900 residues with 40 - 300 synthetic homologs from near-identical (the diversity filter
+    drops almost all of them) to 90 % diverged, through the whole host path (alignment assembly, MsaFilter's identity ladder over
+    25-column windows, position-specific weights, pseudo counts, masking) against the reference's classes: identical profile bytes"""
+    from oracle.pyoracle import ref_r2p_available, RefResult2Profile
+    if not ref_r2p_available():
+        pytest.skip('oracle/_ref/libsdref_r2p.so not built (needs /root/reference)')
+    from spacedust_amd import api
+    host = api.Host(4)
+    ref = RefResult2Profile()
+    rng = np.random.default_rng(31)
+    cases = [(300, 300, 0.1, 0.6), (120, 300, 0.05, 0.3), (600, 250, 0.2, 0.7), (300, 40, 0.1, 0.6), (900, 300, 0.0, 0.2), (64, 300, 0.3, 0.8),
+             (300, 299, 0.0, 0.05), (450, 120, 0.4, 0.9)]
+    for length, rows, d0, d1 in cases:
+        centre, targets, qs, ts, bts = _family(rng, length, rows, d0, d1)
+        res, off = host.map_sequences([centre] + targets)
+        for kw in ({}, dict(wg=1), dict(max_seq_id=0.5, ndiff=3)) if length <= 300 else ({},):
+            mine = api.result2profile(res[:length], [0, length], [0, rows], list(range(1, rows + 1)), qs, ts, bts, res, off, **kw)
+            assert mine == ref.profile(centre, targets, qs, ts, bts, **kw), (length, rows, d0, d1, kw)
