@@ -550,7 +550,12 @@ int sd_search_set_want_records(sd_search *s, int on);
  * handle per range (destroy each). */
 int sd_search_stream(sd_search *s, const sd_setdb *query, int sameDb, uint32_t nRanges, const uint32_t *rangeBegin,
                      const uint32_t *rangeEnd, sd_search_result **results);
-/* counts[8]: entries, matched hits, clusters, hits in clusters, pairs aligned, alignments accepted, prefilter hits, 0 */
+/* counts[8]: entries, matched hits, clusters, hits in clusters, pairs aligned, alignments accepted, prefilter hits, and the gate
+ * "alignments accepted" refers to: 0 = the user's -e, 1 = combinehits' E-value bound (a stream without an alignment sink runs its
+ * alignments with that bound as their gate -- sd_search_stats; entries, hits and clusters do not depend on it).  The fused path is
+ * the clustersearch workflow's aggregation as the reference fixes it (clustersearch.sh:121-151: besthitbyset with
+ * --simple-best-hit 1, combinehits with --aggregation-mode 0, no suboptimal hits); other aggregation settings are not a parameter
+ * of sd_search and go through the glue modules (sd_agg_* / sdgpu besthitbyset ...) with an alignment sink, i.e. without the pushdown */
 int sd_search_result_counts(sd_search_result *r, uint64_t *counts);
 /* copies (any pointer may be NULL): entryOff[entries+1], entryQSet/entryTSet[entries], hitQ/hitT/pval[hits],
  * clusterOfHit/rankInCluster[hits], nClusters[entries], pCO/pMH/clusterSize[hits] (slot entryOff[e]+ordinal) */

@@ -382,6 +382,9 @@ int runSearch(const Args &a, bool withClusters) {
     }
     std::vector<sd_search_result *> results(std::max<size_t>(rb.size(), 1), nullptr);
     if (!rb.empty()) {
+        // the TSV (this rank's, or rank 0's from the gathered buffers) is written from the cluster records: the stream builds them range by
+        // range while its lanes work (sd_search_result_records below is then a copy, not a second pass over every entry's hits)
+        if (withClusters) sd_search_set_want_records(S.s, 1);
         rc = sd_search_stream(S.s, &qv.view, sameDb ? 1 : 0, (uint32_t) rb.size(), rb.data(), re.data(), results.data());
         if (rc != SD_OK) return fail(std::string("sd_search_stream: ") + sd_search_last_error(S.s));
     }

@@ -2758,7 +2758,15 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
     while ((1ull << tBits) < T->nSeq) tBits++;
     const uint32_t maxBatchQ = 1u << std::min(32 - tBits, 16);
     const uint64_t maxDbMatches = std::max<uint64_t>(1000000, T->nSeq) * 2;   // QueryMatcher.cpp:43-47
-    const uint64_t HIT_BUDGET = 1ull << 30;    // hits per sub-batch: rocPRIM's one-sweep radix sort degrades badly beyond 2^30 items (measured)
+    // Hits per sub-batch.  The k-mer stream of a sub-batch carries 30-bit stream indices (jpElem) and the lookup path keeps
+    // 18 - 26 B per hit in its workspace, so those two stay at 2^30; the JOIN path's hit stream is bounded by its 32-bit
+    // write cursors alone (< 0xFFFFFFF0 hits, checked where the sub-batch is sized) -- its tables (offsets + entries: 7.1 GB
+    // at 1 000 proteomes) are walked once per sub-batch by join_count / join_scatter, so the fewer sub-batches the better:
+    // against 3 * 10^6 targets a sub-batch is now maxBatchQ = 1 024 queries (1.5 * 10^9 hits) where the old bound of 2^30
+    // (a limit of the library sort that left the hot path in round 5) cut it into 375-query pieces.  SD_PF_HIT_BUDGET: hits.
+    const uint64_t KMER_BUDGET = 1ull << 30, LOOKUP_HIT_BUDGET = 1ull << 30;
+    uint64_t HIT_BUDGET = 3ull << 30;
+    if (const char *e = getenv("SD_PF_HIT_BUDGET")) HIT_BUDGET = std::max<uint64_t>(1ull << 16, std::min<uint64_t>(0xF0000000ull, (uint64_t) atoll(e)));
 
     // (workspace views, not allocations of this call: a hipFree at the end of every call waits for all streams of the device,
     // i.e. for the other lanes of a pipeline)
@@ -2910,7 +2918,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 return sdFail(ctx, SD_EUNSUPPORTED, "more than %u similar k-mers at one profile position (the reference truncates there, KmerGenerator.cpp:202-210)",
                               PROFILE_PARTIAL_CAP_BIG);
         }
-        if (nKmers > HIT_BUDGET && bq > 1) {   // permissive thresholds: the k-mer list itself outgrows 32-bit device scans
+        if (nKmers > KMER_BUDGET && bq > 1) {   // permissive thresholds: the k-mer list itself outgrows 32-bit device scans
             batchQ = std::max<uint32_t>(1, bq / 2);
             continue;
         }
@@ -3145,7 +3153,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             SD_HIP(ctx, hipGetLastError());
         }
         if (!useJoin) {
-        if (nHits > HIT_BUDGET && bq > 1) {   // too many hits for one sort: halve the sub-batch and retry
+        if (nHits > std::min(HIT_BUDGET, LOOKUP_HIT_BUDGET) && bq > 1) {   // too many hits for one sort: halve the sub-batch and retry
             batchQ = std::max<uint32_t>(1, bq / 2);
             continue;
         }

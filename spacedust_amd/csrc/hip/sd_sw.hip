@@ -1337,12 +1337,21 @@ k_bt_pack(uint32_t nPairs, const uint64_t *__restrict__ btLen, const uint64_t *_
 // and the bit score a function of it, so the first of a (query, target set) cell is the maximum of
 //   score << 44 | (0xFFFF - target length) << 28 | (0x0FFFFFFF - key)
 // over the cell's accepted pairs: one atomic maximum per pair into a table of queries x target sets, then a second look.
+// "Strictly decreasing" ends where the double does: K m n exp(-lambda S) is 0.0 from a raw score of ~2 700 on (about 520
+// identical residues: two near-identical paralogs of a long protein in one target genome) and collides in the last
+// subnormals below that, and compareHits then decides by the ROUNDED bit score (0.39 bit per score unit: neighbouring scores
+// tie), the shorter target, the smaller key -- not by the raw score.  So every accepted pair whose E-value is below
+// BB_EVAL_EXACT (far above the first subnormal, far below anything two different scores can share) is kept whatever the
+// cell's maximum is, and the host's selection -- compareHits itself -- decides among them as it does without the device's
+// help; a pair above the bound can only lose to them (smaller score) and is dropped as before.
+constexpr double BB_EVAL_EXACT = 1e-290;
 struct BestByGroup {
     const uint32_t *groupOf, *groupKey;   // per target sequence (groupKey nullable: the index)
     uint32_t nGroups;
     float seqIdThr, covThr;
     int alnLenThr, covMode;
     double evalThr;
+    double evalExact;   // BB_EVAL_EXACT (SD_BEST_EXACT=0 in the environment: 0.0, the round-5 behaviour, for the A/B of the test)
 };
 __device__ __forceinline__ float bbCov(uint32_t startPos, uint32_t endPos, uint32_t len) {   // sd::computeCov (Util::computeCov)
     return (float) (min(len, max(startPos, endPos)) - min(startPos, endPos) + 1u) / (float) len;
@@ -1385,7 +1394,8 @@ k_best_keep(uint32_t nPairs, sd_sw_result *__restrict__ res, const uint8_t *__re
     const uint32_t q = pq[i], t = pt[i];
     const uint32_t qL = (uint32_t) (qOff[q + 1] - qOff[q]), tL = (uint32_t) (tOff[t + 1] - tOff[t]);
     const sd_sw_result r = res[i];
-    const bool keep = bbAccepted(r, B, qL, tL) && table[(size_t) q * B.nGroups + B.groupOf[t]] == bbPack(r, tL, B.groupKey ? B.groupKey[t] : t);
+    const bool keep = bbAccepted(r, B, qL, tL) &&
+                      (r.evalue < B.evalExact || table[(size_t) q * B.nGroups + B.groupOf[t]] == bbPack(r, tL, B.groupKey ? B.groupKey[t] : t));
     if (!keep) {
         res[i].btLen = 0;
         btLen[i] = 0;
@@ -2392,6 +2402,7 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         B.covThr = par->covThr;
         B.covMode = par->covMode;
         B.evalThr = par->evalThr;
+        B.evalExact = (getenv("SD_BEST_EXACT") && atof(getenv("SD_BEST_EXACT")) == 0.0) ? 0.0 : BB_EVAL_EXACT;
         unsigned long long *dTable = nullptr;
         const size_t cellsN = (size_t) queries->n * targets->nGroups;
         SD_HIP(ctx, wsGet(ctx, "al.besttable", cellsN, &dTable));

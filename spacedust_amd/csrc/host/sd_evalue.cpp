@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstring>
 
+#if defined(__AVX2__)
 #include <immintrin.h>
+#endif
 
 namespace sd {
 
@@ -202,6 +204,7 @@ void compressBacktraceAppend(const char *bt, size_t n, std::string &ret) {
         runStart = pos;
     };
     i = 1;
+#if defined(__AVX2__)   // (the build's flags are the reference's AVX2 flags; a host without AVX2 takes the letter-by-letter loop below)
     for (; i + 32 <= n; i += 32) {   // letters i .. i + 31 against their left neighbours
         const __m256i cur = _mm256_loadu_si256((const __m256i *) (bt + i));
         const __m256i left = _mm256_loadu_si256((const __m256i *) (bt + i - 1));
@@ -211,6 +214,7 @@ void compressBacktraceAppend(const char *bt, size_t n, std::string &ret) {
             ne &= ne - 1;
         }
     }
+#endif
     for (; i < n; i++)
         if (bt[i] != bt[i - 1]) boundary(i);
     emit(n - runStart);

@@ -54,7 +54,8 @@ struct Pow10L {
     }
 };
 const Pow10L kPow10L;
-static_assert(sizeof(long double) == 16 && LDBL_MANT_DIG == 64, "x87 extended precision expected");
+// (the shortcut below reads the 64-bit significand of an x87 long double; any other long double takes the exact conversions)
+constexpr bool kX87LongDouble = sizeof(long double) == 16 && LDBL_MANT_DIG == 64;
 
 double quantise3ESlow(double v, char *text) {
     std::to_chars_result r = std::to_chars(text, text + 24, v, std::chars_format::scientific, 3);
@@ -68,7 +69,7 @@ double quantise3ESlow(double v, char *text) {
 
 double quantise3E(double x, char *text) {
     const double v = fabs(x);   // printf rounds the magnitude (to nearest, ties to even digit): the sign is copied
-    if (!(v >= 1e-300 && v <= 1e300)) return quantise3ESlow(x, text);   // zero, subnormal, huge, NaN
+    if (!kX87LongDouble || !(v >= 1e-300 && v <= 1e300)) return quantise3ESlow(x, text);   // zero, subnormal, huge, NaN
     uint64_t bits;
     memcpy(&bits, &v, 8);
     const int e2 = (int) (bits >> 52) - 1022;   // v = f * 2^e2 with 0.5 <= f < 1 (v is normal here)
@@ -242,8 +243,14 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
         int bad = 0;
 #pragma omp parallel for schedule(static) reduction(| : bad)
         for (uint32_t i = 0; i < nPairs; i++)
-            bad |= ((uint64_t) qBase + pairQ[i] >= a->qSetOf.size() || pairT[i] >= a->tSetOf.size()) ? 1 : 0;
-        if (bad) return SD_EINVAL;
+            bad |= ((uint64_t) qBase + pairQ[i] >= a->qSetOf.size() || pairT[i] >= a->tSetOf.size() ||
+                    // a CIGAR is at most two characters per backtrace letter and must fit one 2^20-byte block of the arena: checked here,
+                    // before anything is appended (sequences are <= 65 535 residues, so a backtrace has < 2^17 letters)
+                    (btPool && res[i].btLen > (1 << 19))) ? 1 : 0;
+        if (bad) {
+            if (getenv("SD_DEBUG_TIMING")) fprintf(stderr, "[sd_agg_add] rejected: a pair index outside the sets, or a backtrace of more than 2^19 letters\n");
+            return SD_EINVAL;   // (nothing was added)
+        }
     }
     const bool dbg = getenv("SD_DEBUG_TIMING") != NULL;
     const double t0 = omp_get_wtime();

@@ -758,6 +758,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         R.counts[3] = nCluHits;
         R.counts[4] = na;
         R.counts[5] = nacc;
+        R.counts[7] = pushdown ? 1 : 0;   // which gate counts[5] refers to: 1 = combinehits' E-value bound (predicate pushdown), 0 = the user's -e
         return SD_OK;
     };
 

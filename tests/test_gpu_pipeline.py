@@ -312,3 +312,67 @@ def test_best_hit_by_set_on_the_device_equals_host_selection(gpu, host, monkeypa
         assert np.array_equal(a['cluster_out'][k_], b['cluster_out'][k_]), k_
     assert a['cluster_out']['pCO'].tobytes() == b['cluster_out']['pCO'].tobytes()
     assert a['cluster_out']['pMH'].tobytes() == b['cluster_out']['pMH'].tobytes()
+
+
+def _paralog_sets(n_sets=3, n_fam=40, seed=5):
+    """sets whose genes come in near-identical paralog pairs of 650 - 1 000 residues: ancestor, and a copy with zero to three
+    substitutions and up to two residues trimmed -- raw scores far beyond the ~2 700 where the E-value of a pair is 0.0"""
+    from spacedust_amd.synth import ProteomeSet, _BG
+    rng = np.random.default_rng(seed)
+    fams = [rng.choice(20, size=int(rng.integers(650, 1001)), p=_BG).astype(np.uint8) for _ in range(n_fam)]
+    seqs, set_id, pos, fam = [], [], [], []
+    for s in range(n_sets):
+        order = rng.permutation(n_fam)
+        p = 0
+        for f in order:
+            copies = int(rng.integers(2, 4))   # two or three paralogs of the family in this set
+            for c in range(copies):
+                a = fams[f].copy()
+                for _ in range(int(rng.integers(0, 4)) if (c or s) else 0):
+                    a[int(rng.integers(0, len(a)))] = rng.integers(0, 20)
+                trim = int(rng.integers(0, 3)) if c else 0
+                a = a[:len(a) - trim]
+                seqs.append(a)
+                set_id.append(s)
+                pos.append(p)
+                fam.append(f)
+                p += 1
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    np.cumsum([len(x) for x in seqs], out=off[1:])
+    return ProteomeSet(np.concatenate(seqs), off, np.array(set_id, np.uint32), np.array(pos, np.uint32),
+                       np.ones(len(seqs), np.uint8), np.array(fam, np.int64), n_sets)
+
+
+def test_best_hit_by_set_on_the_device_with_evalues_of_zero(gpu, host, monkeypatch):
+    """ADVICE r5: K m n exp(-lambda S) is exactly 0.0 beyond a raw score of ~2 700, and Matcher::compareHits (Matcher.h:157-168) then
+    orders a cell's alignments by the ROUNDED bit score, the shorter target and the smaller key -- not by the raw score the device's
+    table maximises.  Sets with two or three near-identical paralogs of 650 - 1 000 residues per family: the device must leave the
+    choice among such pairs to the host's compareHits (every accepted pair with an E-value below BB_EVAL_EXACT comes back), so
+    entries, hits, P-value bits and clusters equal the selection over all accepted records"""
+    ps = _paralog_sets()
+    db = SetDB.from_proteomes(ps)
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('SD_BEST_ON_DEVICE', mode)
+        cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
+        outs[mode] = cs.search(db, same_db=True, chunk_queries=500)
+        del cs
+    # (informational A/B: the round-5 device selection, raw score first -- run with `pytest -s` to see whether this data separates the two)
+    monkeypatch.setenv('SD_BEST_EXACT', '0')
+    cs = ClusterSearch(gpu, host, db, max_seqs=300, bin_size=2, filter_self_match=True)
+    old = cs.search(db, same_db=True, chunk_queries=500)
+    del cs
+    monkeypatch.delenv('SD_BEST_EXACT')
+    print('raw-score selection differs from compareHits on this data: hit_t %s, accepted %d vs %d' %
+          (not np.array_equal(old['hit_t'], outs['0']['hit_t']), old['accepted'], outs['1']['accepted']))
+    a, b = outs['0'], outs['1']
+    assert a['matched_hits'] > 100
+    for k_ in ('entries', 'matched_hits', 'clusters', 'cluster_hits'):
+        assert a[k_] == b[k_], k_
+    for k_ in ('entry_q', 'entry_t', 'entry_off', 'hit_q', 'hit_t'):
+        assert np.array_equal(a[k_], b[k_]), k_
+    assert a['hit_pval'].tobytes() == b['hit_pval'].tobytes()
+    for k_ in ('cluster_of', 'rank', 'n_clusters', 'size'):
+        assert np.array_equal(a['cluster_out'][k_], b['cluster_out'][k_]), k_
+    assert a['cluster_out']['pCO'].tobytes() == b['cluster_out']['pCO'].tobytes()
+    assert a['cluster_out']['pMH'].tobytes() == b['cluster_out']['pMH'].tobytes()
