@@ -68,7 +68,7 @@ def parse():
     ap.add_argument('--leg-budget', type=float, default=330.0, help='a child record (p100, p10000, iter3) is started only while the run is '
                                                                      'younger than this many seconds; later ones are reported as skipped')
     ap.add_argument('--no-iter3', action='store_true', help='skip the --num-iterations 3 record (BASELINE configs[3] at 1 000 target proteomes)')
-    ap.add_argument('--iter3-queries', type=int, default=2, help='query proteomes of the --num-iterations 3 record')
+    ap.add_argument('--iter3-queries', type=int, default=20, help='query proteomes of the --num-iterations 3 record')
     ap.add_argument('--no-index-check', action='store_true', help='skip the sampled check of the device-built index against the host builder')
     ap.add_argument('--strong', action='store_true', help='strong scaling: --batch query proteomes per step in TOTAL, dealt over the ranks '
                                                           '(BASELINE configs[2] as written: one query set of proteomes split over N GPUs)')
@@ -289,7 +289,9 @@ def measure(args, rank, local_rank, world, dist, torch):
             r, n = my_ranges(x)
             rngs += r
             pairs += n
-        return pairs, cs.search_stream(db, rngs, same_db=True, want_records=dist is not None, arrays='last')   # (the parity leg reads the last range's arrays; every range's counters)
+        # every rank builds its ranges' cluster records inside the stream; a rank of an N > 1 run also copies them out for the gather,
+        # a single rank leaves them in the result handles: N = 1 and N > 1 time the same work up to the hand-over
+        return pairs, cs.search_stream(db, rngs, same_db=True, want_records=True if dist is not None else 'build', arrays='last')   # (the parity leg reads the last range's arrays; every range's counters)
 
     if args.warmup:
         run_steps(list(range(args.warmup)))
@@ -419,7 +421,7 @@ def measure(args, rank, local_rank, world, dist, torch):
               'prefilter_select_hits': 12 * Cn + 10 * st['prefilter_hits']}
     pmc = {}
     pmc_src = None
-    for fn in ('r05p_pmc_traffic.json', 'r05i_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04d_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for fn in ('r06_pmc_traffic.json', 'r05p_pmc_traffic.json', 'r05i_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04d_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
             pmc_src = 'profiles/' + fn
@@ -433,17 +435,32 @@ def measure(args, rank, local_rank, world, dist, torch):
         alg = alg_of.get(k_, 0)
         e_ = dict(ms=v['ms'], launches=v['launches'], avg_launch_ms=v['ms'] / max(v['launches'], 1), algorithmic_bytes=int(alg),
                   achieved=alg / v['ms'] / 1e6, frac=alg / v['ms'] / 1e6 / HBM_PEAK_GBS)
-        if k_ in pmc:   # bytes per launch at the memory side (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes of the same command)
+        e_['algorithmic_per_query'] = alg / max(n_queries, 1)
+        if k_ in pmc:   # bytes at the memory side (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes of the same command)
             e_['traffic'] = pmc[k_]['bytes_per_launch']
-            e_['traffic_over_algorithmic'] = pmc[k_]['bytes_per_launch'] / max(alg / max(v['launches'], 1), 1)
+            if pmc[k_].get('bytes_per_query'):
+                # compared PER QUERY: the PMC run's launches and the timed run's launches hold different numbers of queries (the PMC file
+                # carries the queries its process ran through the prefilter: bench.py's prefilter_queries_in_process of that run)
+                e_['traffic_per_query'] = pmc[k_]['bytes_per_query']
+                e_['traffic_over_algorithmic'] = pmc[k_]['bytes_per_query'] / max(e_['algorithmic_per_query'], 1)
+            else:
+                e_['traffic_over_algorithmic'] = None   # a PMC file without its query count: bytes per launch of another launch size
         per_kernel[k_] = e_
     tb_ms = sum(v['ms'] for k_, v in grouped.items() if k_.startswith('sw_traceback'))
     stage_ms = {'prefilter': pf_ms, 'sw_score': sw_ms, 'sw_traceback': tb_ms}
     dom_stage = max(stage_ms.items(), key=lambda kv: kv[1])[0]
     dom = max(per_kernel.items(), key=lambda kv: kv[1]['ms'])[0] if per_kernel else 'none'
     dk = per_kernel.get(dom, dict(achieved=0.0, launches=0, avg_launch_ms=0.0))
+    pmc_tot = pmc.get('_prefilter_total') or {}
     roofline = dict(bound='hbm', stage='prefilter', kernel=dom, achieved=dk['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=dk['achieved'] / HBM_PEAK_GBS,
                     traffic=dk.get('traffic'), traffic_source=pmc_src if dk.get('traffic') is not None else None, launches=dk['launches'],
+                    traffic_per_query=dk.get('traffic_per_query'), algorithmic_per_query=dk.get('algorithmic_per_query'),
+                    # the whole stage, per query: PMC bytes of every prefilter kernel / the queries of the PMC run, against SURVEY.md 8(d)
+                    stage_traffic_per_query=pmc_tot.get('bytes_per_query'), stage_algorithmic_per_query=b_pref / max(n_queries, 1),
+                    stage_traffic_over_algorithmic=(pmc_tot['bytes_per_query'] / (b_pref / max(n_queries, 1))) if pmc_tot.get('bytes_per_query') and b_pref > 0 else None,
+                    # SURVEY.md 8(d) bytes of the timed steps over the WALL time of the timed region (the driver's clock), next to stage_frac,
+                    # which divides by the sum of the prefilter kernels' event times (four lanes overlap: that sum exceeds the wall time)
+                    wall_achieved=b_pref / dt_max / 1e9 if dt_max > 0 else 0.0, wall_frac=(b_pref / dt_max / 1e9 / HBM_PEAK_GBS) if dt_max > 0 else 0.0,
                     avg_launch_ms=dk['avg_launch_ms'], stage_achieved=b_pref / pf_ms / 1e6 if pf_ms > 0 else 0.0,
                     stage_frac=(b_pref / pf_ms / 1e6 / HBM_PEAK_GBS) if pf_ms > 0 else 0.0, stage_kernel_ms=stage_ms,
                     largest_stage=dom_stage, per_kernel=per_kernel,
@@ -537,10 +554,13 @@ def measure(args, rank, local_rank, world, dist, torch):
         res['multi_gpu_note'] = ('%s scaling over query sets; an 8-GPU curve exists only where the driver ran this command with --gpus 8'
                                  % ('strong (BASELINE configs[2] as written)' if args.strong else 'weak'))
     res['index_check'] = index_check
+    q_warm = int(sum(b - a for x in range(args.warmup) for a, b in my_ranges(x)[0]))
+    res['prefilter_queries_in_process'] = n_queries + q_warm   # + the isolated leg's two calls, below
     if rank == 0 and not args.no_index_check:
         try:
             res['roofline']['isolated'] = isolated_prefilter(cs, host, ps, k, kmer_thr, max_seqs, int(cs.bin_size),
                                                              n_queries=8192 if P < 5000 else 2048)
+            res['prefilter_queries_in_process'] += 2 * int(res['roofline']['isolated']['queries'])   # (a warm call and the measured one)
         except Exception as e:   # (an extra, never the record)
             res['roofline']['isolated'] = dict(error=repr(e)[:200])
         # The dominant kernel.  Inside the pipeline a kernel's event-timed duration is mostly the wait of its workgroups for a CU the score
@@ -559,6 +579,8 @@ def measure(args, rank, local_rank, world, dist, torch):
             q_total = max(int(res['prefilter']['queries']), 1)
             alg_iso = dk['algorithmic_bytes'] * res['roofline']['isolated']['queries'] / q_total
             res['roofline'].update(kernel=dom, achieved=dk['achieved'], frac=dk['achieved'] / HBM_PEAK_GBS, traffic=dk.get('traffic'),
+                                   traffic_per_query=dk.get('traffic_per_query'), algorithmic_per_query=dk.get('algorithmic_per_query'),
+                                   traffic_over_algorithmic=dk.get('traffic_over_algorithmic'),
                                    traffic_source=res['roofline'].get('traffic_source') if dk.get('traffic') is not None else None,
                                    launches=dk['launches'], avg_launch_ms=dk['avg_launch_ms'],
                                    kernel_alone=dict(ms=cand[dom], achieved=alg_iso / cand[dom] / 1e6, frac=alg_iso / cand[dom] / 1e6 / HBM_PEAK_GBS,
@@ -694,9 +716,23 @@ def main():
                                               '--warmup', '1', '--batch', str(args.p10000_batch), '--chunk', str(args.p10000_chunk), '--no-children', '--no-cpu'])
     if kids and not args.no_iter3 and _leg_allowed(children, 'iter3', t_start, args):
         # BASELINE configs[3]: `clustersearch --num-iterations 3` (sequence search, two profile searches) against 1 000 target
-        # proteomes through the sdgpu binary and the reference's DB files, with its own sampled parity check against the
-        # reference classes (tools/iter3_scale.py) -- a child process
-        children['iter3'] = child('iter3', [sys.executable, os.path.join(ROOT, 'tools', 'iter3_scale.py'), '1000', str(args.iter3_queries), '32'])
+        # proteomes through the sdgpu binary: the iterations in memory (timed); the module chain over DB files on two query proteomes
+        # gives the same TSV and its DBs are checked on sampled queries against the reference classes (tools/iter3_scale.py) -- a child
+        children['iter3'] = child('iter3', [sys.executable, os.path.join(ROOT, 'tools', 'iter3_scale.py'), '1000', str(args.iter3_queries), '24'])
+        c3, cb = children['iter3'], res.get('cpu_baseline') or {}
+        if isinstance(c3, dict) and c3.get('cpu_profile_iterations') and cb.get('queries_per_s'):
+            # CPU side of this configuration, reference classes throughout: iteration 0 at the main record's measured rate (queries per
+            # second of prefilter + alignment on `cores` threads; its extra --realign pass is not in that figure, so this errs in the
+            # CPU's favour), iterations 1 and 2 and both profile computations from the sampled queries of this leg (one thread, scaled
+            # linearly to the same number of threads)
+            cores = int(cb.get('cores') or 1)
+            s_q = cores / cb['queries_per_s'] + c3['cpu_profile_iterations']['seconds_per_query']   # core-seconds per query
+            q_per_pair = 3000.0 / 1000.0
+            c3['cpu_baseline'] = dict(value=cores / (s_q * q_per_pair), unit='genome-pairs/s', cores=cores, kind='reference',
+                                      sample='iteration 0: the main record\'s reference rate (%d threads); iterations 1-2 + result2profile x 2: %d sampled '
+                                             'queries through the reference classes on one thread (%.3f s per query), scaled to %d threads'
+                                             % (cores, c3['cpu_profile_iterations']['queries'], c3['cpu_profile_iterations']['seconds_per_query'], cores))
+            c3['gpu_over_cpu'] = c3['genome_pairs_per_s'] / c3['cpu_baseline']['value']
 
     # ---- the printed line is compact (the driver parses it); everything bulky goes to the side file
     def _brief(r):
@@ -730,7 +766,7 @@ def main():
                                    'dtype', 'data', 'config')}
     line['roofline'] = rf
     line['roofline_sw'] = res['roofline_sw']
-    for k_ in ('sw_gcups', 'sw_gcups_fwd_plus_rev', 'sw_cells', 'prefilter', 'stage_wall_s', 'host_cpu_s_per_step', 'host_cpu_by_stage', 'results',
+    for k_ in ('sw_gcups', 'sw_gcups_fwd_plus_rev', 'sw_cells', 'prefilter', 'prefilter_queries_in_process', 'stage_wall_s', 'host_cpu_s_per_step', 'host_cpu_by_stage', 'results',
                'setup_s', 'device', 'host_cores', 'host_cpu_quota', 'gather', 'multi_gpu_note', 'index_check', 'cpu_baseline', 'parity_check'):
         if k_ in res:
             line[k_] = res[k_]
@@ -740,7 +776,7 @@ def main():
         for name in ('p100', 'p10000', 'iter3'):
             c_ = children.get(name)
             if name == 'iter3' and isinstance(c_, dict) and 'genome_pairs_per_s' in c_:
-                line[name] = {k_: c_.get(k_) for k_ in ('genome_pairs_per_s', 'wall_s', 'query_proteomes', 'target_proteomes', 'parity_check', 'leg_wall_s') if k_ in c_}
+                line[name] = {k_: c_.get(k_) for k_ in ('genome_pairs_per_s', 'wall_s', 'query_proteomes', 'target_proteomes', 'how', 'stages', 'kernel_ms_total', 'module_chain', 'cpu_baseline', 'gpu_over_cpu', 'parity_check', 'leg_wall_s') if k_ in c_}
             else:
                 line[name] = _brief(c_)
     print(json.dumps(line))

@@ -5,6 +5,7 @@
 // DB in, C ABI of libsdgpu.so (HIP kernels) in the middle, DB out.  No compute here, no CPU fallback: without a GPU
 // sd_ctx_create fails and the module exits non-zero.
 #include "sd_cli.h"
+#include "sd_align_core.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -81,6 +82,37 @@ int deviceOf(const Args &a) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
+int prefilterSetupFromArgs(const Args &a, sd_host *host, const SeqDb &tdb, bool profileQueries, PrefSetup &s) {
+    // parameters the way Prefiltering's constructor derives them (Prefiltering.cpp:180-215,1005-1065)
+    s.k = (int) a.integer("-k", 0);
+    if (s.k == 0) s.k = sd_host_auto_kmer_size(tdb.totalResidues());
+    if (s.k != 6 && s.k != 7) return fail("-k " + std::to_string(s.k) + ": k-mer sizes 6 and 7 are implemented");
+    const float sens = (float) a.real("-s", 4.0);
+    const long long kScore = strtoll(a.multi("--k-score", profileQueries ? "prof" : "seq", "2147483647").c_str(), nullptr, 10);
+    s.kmerThr = kScore != INT_MAX ? (int) kScore
+                                  : (profileQueries ? sd_host_profile_kmer_threshold(sens, s.k) : sd_host_kmer_threshold(sens, s.k));
+    s.indexThr = profileQueries ? 0 : s.kmerThr;   // profile searches index every k-mer (Prefiltering.cpp:525-527)
+    s.mask = a.integer("--mask", 1) != 0;
+    s.maskProb = a.real("--mask-prob", 0.9);
+    s.includeIdentity = a.flag("--add-self-matches", false);
+    s.compBias = a.integer("--comp-bias-corr", 1) != 0;
+    sd_prefilter_params &par = s.par;
+    memset(&par, 0, sizeof(par));
+    par.kmerSize = s.k;
+    par.kmerThr = s.kmerThr;
+    par.maxHitsPerQuery = (int32_t) std::min<long long>(a.integer("--max-seqs", 300), tdb.n);   // Prefiltering.cpp:184
+    par.minDiagScore = (int32_t) a.integer("--min-ungapped-score", 15);
+    par.binSize = a.has("--bin-size") ? (uint32_t) a.integer("--bin-size", 0)
+                                      : sd_host_bin_size(tdb.n, (uint64_t) a.integer("--l2-cache-size", 0));
+    par.covMode = (int32_t) a.integer("--cov-mode", 0);
+    par.covThr = (float) a.real("-c", 0.0);
+    // the writer's coverage pre-filter only exists for these modes (Prefiltering.cpp:856-858)
+    if (!(par.covMode == 0 || par.covMode == 2 || par.covMode == 5)) par.covThr = 0.0f;
+    sd_host_matrix(host, 2, par.ungappedMatrix, nullptr, nullptr);
+    if (par.maxHitsPerQuery < 1) par.maxHitsPerQuery = 1;
+    return 0;
+}
+
 int prefilterModule(const Args &a) {
     if (a.pos.size() != 3) return fail("usage: prefilter <queryDB> <targetDB> <resultDB> [options]");
     if (int rc = checkCommon(a)) return rc;
@@ -119,17 +151,11 @@ int prefilterModule(const Args &a) {
     info(a, "Query database size: %u type: %s\nTarget database size: %u type: Aminoacid\n", qdb->n,
          qdb->profile ? "Profile" : "Aminoacid", tdb->n);
 
-    // parameters the way Prefiltering's constructor derives them (Prefiltering.cpp:180-215,1005-1065)
-    int k = (int) a.integer("-k", 0);
-    if (k == 0) k = sd_host_auto_kmer_size(tdb->totalResidues());
-    if (k != 6 && k != 7) return fail("-k " + std::to_string(k) + ": k-mer sizes 6 and 7 are implemented");
-    const float sens = (float) a.real("-s", 4.0);
-    const long long kScore = strtoll(a.multi("--k-score", qdb->profile ? "prof" : "seq", "2147483647").c_str(), nullptr, 10);
-    int kmerThr = kScore != INT_MAX ? (int) kScore
-                                    : (qdb->profile ? sd_host_profile_kmer_threshold(sens, k) : sd_host_kmer_threshold(sens, k));
-    const bool mask = a.integer("--mask", 1) != 0;
-    const double maskProb = a.real("--mask-prob", 0.9);
-    const bool includeIdentity = a.flag("--add-self-matches", false);
+    PrefSetup PS;
+    if (int rcS = prefilterSetupFromArgs(a, host.h, *tdb, qdb->profile, PS)) return rcS;
+    const int k = PS.k, kmerThr = PS.kmerThr;
+    const bool mask = PS.mask, includeIdentity = PS.includeIdentity;
+    const double maskProb = PS.maskProb;
 
     CtxH ctx;
     int rc = ctx.open(deviceOf(a));
@@ -231,20 +257,7 @@ int prefilterModule(const Args &a) {
     }
 
     lap.mark("target index");
-    sd_prefilter_params par;
-    memset(&par, 0, sizeof(par));
-    par.kmerSize = k;
-    par.kmerThr = kmerThr;
-    par.maxHitsPerQuery = (int32_t) std::min<long long>(a.integer("--max-seqs", 300), tdb->n);   // Prefiltering.cpp:184
-    par.minDiagScore = (int32_t) a.integer("--min-ungapped-score", 15);
-    par.binSize = a.has("--bin-size") ? (uint32_t) a.integer("--bin-size", 0)
-                                      : sd_host_bin_size(tdb->n, (uint64_t) a.integer("--l2-cache-size", 0));
-    par.covMode = (int32_t) a.integer("--cov-mode", 0);
-    par.covThr = (float) a.real("-c", 0.0);
-    // the writer's coverage pre-filter only exists for these modes (Prefiltering.cpp:856-858)
-    if (!(par.covMode == 0 || par.covMode == 2 || par.covMode == 5)) par.covThr = 0.0f;
-    sd_host_matrix(host.h, 2, par.ungappedMatrix, nullptr, nullptr);
-    if (par.maxHitsPerQuery < 1) par.maxHitsPerQuery = 1;
+    const sd_prefilter_params par = PS.par;
 
     sddb::Writer out;
     if (!out.open(a.pos[2], sddb::DBTYPE_PREFILTER_RES, &err)) return fail(err);
@@ -320,27 +333,6 @@ int prefilterModule(const Args &a) {
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
-// backtrace pool of the align calls: raw bytes (a std::vector would zero a gigabyte on every growth)
-struct BtPool {
-    std::unique_ptr<char[]> p;
-    size_t cap = 0;
-    void reserve(size_t n) {
-        if (cap >= n) return;
-        p.reset(new char[n]);
-        cap = n;
-    }
-    const char *data() const { return p.get(); }
-};
-
-// one chunk of prefilter entries turned into device work
-struct AlnChunk {
-    std::vector<uint32_t> entryFirst;   // per local query: first record
-    std::vector<uint32_t> qIds;         // query id (in qdb) per local query
-    std::vector<uint32_t> entryOfLocal; // prefilter entry id per local query
-    std::vector<uint32_t> pairQ, pairT;
-    std::vector<uint8_t> ident;
-};
-
 int alignPairs(sd_ctx *ctx, const sd_sw_params &par, sd_seqset *qs, sd_seqset *ts, const SeqDb &qdb, const SeqDb &tdb,
                const std::vector<uint32_t> &qIdOfLocal, const std::vector<uint32_t> &pq, const std::vector<uint32_t> &pt,
                const std::vector<uint8_t> &ident, bool compact, std::vector<uint32_t> &outIdx, std::vector<sd_sw_result> &res,
@@ -385,11 +377,14 @@ int alignPairs(sd_ctx *ctx, const sd_sw_params &par, sd_seqset *qs, sd_seqset *t
     }
 }
 
+struct SeqSetGuard {
+    sd_seqset *s = nullptr;
+    ~SeqSetGuard() { if (s) sd_seqset_destroy(s); }
+};
+
 }  // namespace
 
-int alignModule(const Args &a) {
-    if (a.pos.size() != 4) return fail("usage: align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [options]");
-    if (int rc = checkCommon(a)) return rc;
+int alignSetupFromArgs(const Args &a, sd_host *host, uint64_t targetResidues, AlignSetup &s) {
     if (a.flag("--wrapped-scoring", false)) return fail("--wrapped-scoring is a nucleotide mode");
     if (a.integer("--alt-ali", 0) != 0) return fail("--alt-ali > 0 is not supported");
     if (a.integer("--alignment-output-mode", 0) != 0) return fail("--alignment-output-mode 0 only");
@@ -398,18 +393,17 @@ int alignModule(const Args &a) {
     if (a.multi("--gap-open", "aa", "11") != "11" || a.multi("--gap-extend", "aa", "1") != "1")
         return fail("gap costs other than --gap-open 11 --gap-extend 1 need other E-value parameters than the built-in preset");
     if (a.real("--comp-bias-corr-scale", 1.0) != 1.0) return fail("--comp-bias-corr-scale 1 only");
-    const bool compBias = a.integer("--comp-bias-corr", 1) != 0;
-    const int threads = threadsOf(a);
+    s.compBias = a.integer("--comp-bias-corr", 1) != 0;
     int alignmentMode = (int) a.integer("--alignment-mode", 0);
     if (alignmentMode == 4) return fail("Use rescorediagonal for ungapped alignment mode.");
     bool addBacktrace = a.flag("-a", false);
-    bool realign = a.flag("--realign", false);
-    const float realignScoreBias = (float) a.real("--realign-score-bias", -0.2);
-    if (realign && !(realignScoreBias == -0.2f || realignScoreBias == 0.0f))
+    s.realign = a.flag("--realign", false);
+    s.realignScoreBias = (float) a.real("--realign-score-bias", -0.2);
+    if (s.realign && !(s.realignScoreBias == -0.2f || s.realignScoreBias == 0.0f))
         return fail("--realign-score-bias: -0.2 (default) and 0 are built in");
     float covThr = (float) a.real("-c", 0.0);
-    const float canCovThr = covThr;
-    const int covMode = (int) a.integer("--cov-mode", 0);
+    s.canCovThr = covThr;
+    s.covMode = (int) a.integer("--cov-mode", 0);
     const float seqIdThr = (float) a.real("--min-seq-id", 0.0);
     // Alignment::Alignment (Alignment.cpp:31-57)
     if (addBacktrace) alignmentMode = 3;
@@ -423,16 +417,220 @@ int alignModule(const Args &a) {
         }
     };
     float realignCov = 0.0f;
-    if (realign) {
+    if (s.realign) {
         realignSwMode = initSWMode(std::max(alignmentMode, 2), 0.0f, 0.0f);
         alignmentMode = 1;
         realignCov = covThr;
         covThr = 0.0f;
         addBacktrace = true;
     }
-    const int swMode = initSWMode(alignmentMode, (float) a.real("-c", 0.0), seqIdThr);
-    Lap lap("align");
+    s.swMode = initSWMode(alignmentMode, (float) a.real("-c", 0.0), seqIdThr);
+    memset(&s.par, 0, sizeof(s.par));
+    s.par.gapOpen = 11;
+    s.par.gapExtend = 1;
+    sd_host_matrix(host, 0, s.par.matrix, nullptr, nullptr);
+    s.par.covMode = s.covMode;
+    s.par.covThr = covThr;
+    s.par.evalThr = a.real("-e", 0.001);
+    s.par.swMode = s.swMode;
+    s.par.dbResidues = targetResidues;
+    s.rpar = s.par;   // the realigner (Alignment.cpp:296-303,419): score-biased matrix, E-value gate off
+    if (s.realign) {
+        sd_host_matrix(host, s.realignScoreBias == 0.0f ? 0 : 2, s.rpar.matrix, nullptr, nullptr);
+        s.rpar.covThr = realignCov;
+        s.rpar.evalThr = FLT_MAX;
+        s.rpar.swMode = realignSwMode;
+    }
+    memset(&s.crit, 0, sizeof(s.crit));
+    s.crit.evalThr = s.par.evalThr;
+    s.crit.seqIdThr = seqIdThr;
+    s.crit.alnLenThr = (int32_t) a.integer("--min-aln-len", 0);
+    s.crit.covMode = s.covMode;
+    s.crit.covThr = s.realign ? realignCov : covThr;
+    s.crit.seqIdMode = (int32_t) a.integer("--seq-id-mode", 0);
+    s.crit.swMode = s.swMode;
+    s.crit.addBacktrace = addBacktrace ? 1 : 0;
+    s.crit.realign = s.realign ? 1 : 0;
+    s.crit.realignSwMode = realignSwMode;
+    s.crit.realignMaxSeqs = (int32_t) std::min<long long>(a.integer("--realign-max-seqs", INT_MAX), INT_MAX);
+    s.crit.maxAccept = (uint32_t) std::min<long long>(a.integer("--max-accept", INT_MAX), INT_MAX);
+    s.crit.maxRejected = (uint32_t) std::min<long long>(a.integer("--max-rejected", INT_MAX), INT_MAX);
+    s.stopRules = s.crit.maxAccept != (uint32_t) INT_MAX || s.crit.maxRejected != (uint32_t) INT_MAX;
+    s.includeIdentity = a.flag("--add-self-matches", false);
+    return 0;
+}
 
+int alignChunkCore(sd_ctx *ctx, sd_host *host, const AlignSetup &s, const SeqDb &qdb, const SeqDb &tdb, sd_seqset *tset, AlignChunk &c, Lap *lap,
+                   const char **what) {
+    static const char *none = "";
+    const char *dummyWhat;
+    if (!what) what = &dummyWhat;
+    *what = none;
+    int rc = SD_OK;
+    const std::vector<uint32_t> &localQ = c.localQ, &pq = c.pq, &pt = c.pt;
+    const std::vector<uint8_t> &ident = c.ident;
+    const uint32_t nq = (uint32_t) localQ.size();
+    // queries of the chunk as one sequence set on the device
+    c.qoff.assign((size_t) nq + 1, 0);
+    c.qlen.resize(nq);
+    for (uint32_t i = 0; i < nq; i++) {
+        c.qlen[i] = qdb.lens[localQ[i]];
+        c.qoff[i + 1] = c.qoff[i] + (uint64_t) c.qlen[i];
+    }
+    c.qres.resize(c.qoff[nq] + 1);
+    for (uint32_t i = 0; i < nq; i++) memcpy(c.qres.data() + c.qoff[i], qdb.residues.data() + qdb.offsets[localQ[i]], (size_t) c.qlen[i]);
+    SeqSetGuard qset;
+    if (nq) {
+        if (qdb.profile) {
+            c.qaln.resize((c.qoff[nq] + 1) * 21);
+            for (uint32_t i = 0; i < nq; i++)
+                memcpy(c.qaln.data() + c.qoff[i] * 21, qdb.alnProfile.data() + qdb.offsets[localQ[i]] * 21, (size_t) c.qlen[i] * 21);
+            rc = sd_profileset_create(ctx, c.qres.data(), c.qoff.data(), nq, c.qaln.data(), &qset.s);
+        } else {
+            c.qbias.assign(c.qoff[nq] + 1, 0);
+            if (s.compBias) sd_host_comp_bias(host, c.qres.data(), c.qoff.data(), nq, 6, c.qbias.data(), nullptr, nullptr);
+            rc = sd_seqset_create(ctx, c.qres.data(), c.qoff.data(), nq, c.qbias.data(), &qset.s);
+        }
+        if (rc != SD_OK) {
+            *what = "sd_seqset_create(queries)";
+            return rc;
+        }
+    }
+    if (lap) lap->mark("chunk: query set");
+    // the pairs that are aligned (pre-rejected ones are not)
+    c.apq.clear();
+    c.apt.clear();
+    c.aid.clear();
+    c.aIdx.clear();
+    c.apq.reserve(pq.size());
+    for (size_t i = 0; i < pq.size(); i++)
+        if (ident[i] != 2) {
+            c.apq.push_back(pq[i]);
+            c.apt.push_back(pt[i]);
+            c.aid.push_back(ident[i]);
+            c.aIdx.push_back((uint32_t) i);
+        }
+    c.aligned = c.apq.size();
+    const bool compact = s.swMode == 2 && !s.stopRules;
+    if (!c.apq.empty()) {
+        rc = alignPairs(ctx, s.par, qset.s, tset, qdb, tdb, localQ, c.apq, c.apt, c.aid, compact, c.idxOut, c.res, c.pool);
+        if (rc != SD_OK) {
+            *what = "sd_sw_align_batch";
+            return rc;
+        }
+    } else {
+        c.res.clear();
+        c.idxOut.clear();
+    }
+    if (lap) lap->mark("chunk: alignPairs");
+    // record list handed to the criteria: compact -> only the reportable records; otherwise every pair in prefilter
+    // order, pre-rejected ones as records that fail every criterion (E-value NaN)
+    c.recQ.clear();
+    c.recT.clear();
+    c.recIdent.clear();
+    std::vector<sd_sw_result> *recs = &c.res;
+    if (compact) {
+        c.recQ.resize(c.res.size());
+        c.recT.resize(c.res.size());
+        c.recIdent.resize(c.res.size());
+        for (size_t x = 0; x < c.res.size(); x++) {
+            c.recQ[x] = c.apq[c.idxOut[x]];
+            c.recT[x] = c.apt[c.idxOut[x]];
+            c.recIdent[x] = c.aid[c.idxOut[x]];
+        }
+    } else {
+        c.full.resize(pq.size());
+        sd_sw_result dummy;
+        memset(&dummy, 0, sizeof(dummy));
+        dummy.qStart = dummy.tStart = dummy.qEnd = dummy.tEnd = -1;
+        dummy.evalue = NAN;
+        for (size_t i = 0; i < pq.size(); i++) c.full[i] = dummy;
+        for (size_t x = 0; x < c.aIdx.size(); x++) c.full[c.aIdx[x]] = c.res[x];
+        c.recQ = pq;
+        c.recT = pt;
+        c.recIdent.resize(pq.size());
+        for (size_t i = 0; i < pq.size(); i++) c.recIdent[i] = ident[i] == 1 ? 1 : 0;
+        recs = &c.full;
+    }
+    c.order.resize(std::max<size_t>(recs->size(), 1));
+    c.counts.assign(std::max<uint32_t>(nq, 1), 0);
+    rc = sd_host_accept_sort(&s.crit, nq, (uint32_t) recs->size(), c.recQ.data(), c.recT.data(), recs->data(), c.recIdent.data(),
+                             c.qlen.data(), tdb.lens.data(), tdb.keys.data(), c.order.data(), c.counts.data());
+    if (rc != SD_OK) {
+        *what = "sd_host_accept_sort";
+        return rc;
+    }
+    uint64_t nAcc = 0;
+    for (uint32_t i = 0; i < nq; i++) nAcc += c.counts[i];
+    c.accepted = nAcc;
+    c.outRecs = recs;
+    c.outOrder = &c.order;
+    c.outCounts = &c.counts;
+    c.outT = &c.recT;
+    c.outIdent = &c.recIdent;
+    c.outPool = &c.pool;
+    if (s.realign && nAcc > 0) {
+        // second pass over the accepted records, in their order (Alignment.cpp:408-440)
+        c.pq2.resize(nAcc);
+        c.pt2.resize(nAcc);
+        c.ident2.resize(nAcc);
+        uint64_t w = 0;
+        for (uint32_t q = 0; q < nq; q++)
+            for (uint32_t x = 0; x < c.counts[q]; x++, w++) {
+                const uint32_t i = c.order[w];
+                c.pq2[w] = q;
+                c.pt2[w] = c.recT[i];
+                c.ident2[w] = c.recIdent[i];
+            }
+        // the realigner's query profile: composition bias against the score-biased matrix (a profile query carries its
+        // scores itself and is reused)
+        SeqSetGuard qset2;
+        sd_seqset *rq = qset.s;
+        if (!qdb.profile && s.compBias && s.realignScoreBias != 0.0f) {
+            c.qbias2.assign(c.qoff[nq] + 1, 0);
+            sd_host_sw_comp_bias(host, 2, c.qres.data(), c.qoff.data(), nq, c.qbias2.data());
+            rc = sd_seqset_create(ctx, c.qres.data(), c.qoff.data(), nq, c.qbias2.data(), &qset2.s);
+            if (rc != SD_OK) {
+                *what = "sd_seqset_create(realign queries)";
+                return rc;
+            }
+            rq = qset2.s;
+        }
+        rc = alignPairs(ctx, s.rpar, rq, tset, qdb, tdb, localQ, c.pq2, c.pt2, c.ident2, false, c.idx2, c.res2, c.pool2);
+        if (rc != SD_OK) {
+            *what = "sd_sw_align_batch(realign)";
+            return rc;
+        }
+        c.merged.resize(nAcc);
+        c.order2.resize(nAcc);
+        c.counts2.assign(nq, 0);
+        rc = sd_host_realign_select(&s.crit, nq, c.counts.data(), c.order.data(), c.recT.data(), recs->data(), c.res2.data(),
+                                    c.ident2.data(), c.qlen.data(), tdb.lens.data(), tdb.keys.data(), c.merged.data(),
+                                    c.order2.data(), c.counts2.data());
+        if (rc != SD_OK) {
+            *what = "sd_host_realign_select";
+            return rc;
+        }
+        c.outRecs = &c.merged;
+        c.outOrder = &c.order2;
+        c.outCounts = &c.counts2;
+        c.accT = c.pt2;
+        c.outT = &c.accT;
+        c.outIdent = &c.ident2;
+        c.outPool = &c.pool2;
+    } else if (s.realign) {
+        c.counts2.assign(std::max<uint32_t>(nq, 1), 0);
+        c.outCounts = &c.counts2;
+    }
+    if (lap) lap->mark("chunk: accept / sort (+ realign)");
+    return SD_OK;
+}
+
+int alignModule(const Args &a) {
+    if (a.pos.size() != 4) return fail("usage: align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [options]");
+    if (int rc = checkCommon(a)) return rc;
+    const int threads = threadsOf(a);
+    Lap lap("align");
     HostH host;
     if (host.open(threads) != SD_OK) return fail("sd_host_create failed");
     std::string err;
@@ -447,6 +645,11 @@ int alignModule(const Args &a) {
         if (!qdbOwn->load(a.pos[0], host.h, &err)) return fail(err);
         qdb = qdbOwn.get();
     }
+    AlignSetup S;
+    if (int rcS = alignSetupFromArgs(a, host.h, tdb->totalResidues(), S)) return rcS;
+    const int swMode = S.swMode, covMode = S.covMode;
+    const float canCovThr = S.canCovThr;
+    const bool includeIdentity = S.includeIdentity;
     lap.mark("load DBs");
     sddb::Reader pref;
     if (!pref.open(a.pos[2], sddb::Reader::USE_INDEX | sddb::Reader::USE_DATA, sddb::Reader::LINEAR_ACCESS, &err)) return fail(err);
@@ -457,42 +660,6 @@ int alignModule(const Args &a) {
     CtxH ctx;
     int rc = ctx.open(deviceOf(a));
     if (rc != SD_OK) return fail("no usable HIP device (sd_ctx_create returned " + std::to_string(rc) + "); this path has no CPU fallback");
-
-    sd_sw_params par;
-    memset(&par, 0, sizeof(par));
-    par.gapOpen = 11;
-    par.gapExtend = 1;
-    sd_host_matrix(host.h, 0, par.matrix, nullptr, nullptr);
-    par.covMode = covMode;
-    par.covThr = covThr;
-    par.evalThr = a.real("-e", 0.001);
-    par.swMode = swMode;
-    par.dbResidues = tdb->totalResidues();
-    sd_sw_params rpar = par;   // the realigner (Alignment.cpp:296-303,419): score-biased matrix, E-value gate off
-    if (realign) {
-        sd_host_matrix(host.h, realignScoreBias == 0.0f ? 0 : 2, rpar.matrix, nullptr, nullptr);
-        rpar.covThr = realignCov;
-        rpar.evalThr = FLT_MAX;
-        rpar.swMode = realignSwMode;
-    }
-
-    sd_aln_criteria crit;
-    memset(&crit, 0, sizeof(crit));
-    crit.evalThr = par.evalThr;
-    crit.seqIdThr = seqIdThr;
-    crit.alnLenThr = (int32_t) a.integer("--min-aln-len", 0);
-    crit.covMode = covMode;
-    crit.covThr = realign ? realignCov : covThr;
-    crit.seqIdMode = (int32_t) a.integer("--seq-id-mode", 0);
-    crit.swMode = swMode;
-    crit.addBacktrace = addBacktrace ? 1 : 0;
-    crit.realign = realign ? 1 : 0;
-    crit.realignSwMode = realignSwMode;
-    crit.realignMaxSeqs = (int32_t) std::min<long long>(a.integer("--realign-max-seqs", INT_MAX), INT_MAX);
-    crit.maxAccept = (uint32_t) std::min<long long>(a.integer("--max-accept", INT_MAX), INT_MAX);
-    crit.maxRejected = (uint32_t) std::min<long long>(a.integer("--max-rejected", INT_MAX), INT_MAX);
-    const bool stopRules = crit.maxAccept != (uint32_t) INT_MAX || crit.maxRejected != (uint32_t) INT_MAX;
-    const bool includeIdentity = a.flag("--add-self-matches", false);
 
     SeqSetH tset;
     const std::string tsetKey = a.pos[1] + "|" + std::to_string(deviceOf(a));
@@ -519,16 +686,9 @@ int alignModule(const Args &a) {
     const uint64_t maxPairs = 4000000;
     const size_t nEntries = pref.size();
     uint64_t alignmentsNum = 0, passedNum = 0;
-    std::vector<uint32_t> localQ, pq, pt, idxOut, order, counts, order2, counts2, accT;
-    std::vector<uint8_t> ident, ident2;
-    std::vector<uint8_t> qres;
-    std::vector<uint64_t> qoff;
-    std::vector<int8_t> qbias, qaln;
-    std::vector<int32_t> qlen;
-    std::vector<sd_sw_result> res, res2, merged;
-    BtPool pool, pool2;
-    std::vector<uint32_t> recQ, recT, pq2, pt2;
-    std::vector<uint8_t> recIdent;
+    AlignChunk C;
+    std::vector<uint32_t> &localQ = C.localQ, &pq = C.pq, &pt = C.pt;
+    std::vector<uint8_t> &ident = C.ident;
     // lines per prefilter entry (one pass over the DB on all threads): the chunks are cut from these, and a chunk's lines are then
     // parsed in parallel into their places
     std::vector<uint32_t> lineCount(nEntries, 0);
@@ -605,141 +765,13 @@ int alignModule(const Args &a) {
             return fail("Sequence " + std::to_string(missingKey) + " is required in the prefiltering, but is not contained in the target sequence database!");
         lap.mark("chunk: parse prefilter entries");
         const uint32_t nq = (uint32_t) localQ.size();
-        // queries of the chunk as one sequence set on the device
-        qoff.assign((size_t) nq + 1, 0);
-        qlen.resize(nq);
-        for (uint32_t i = 0; i < nq; i++) {
-            qlen[i] = qdb->lens[localQ[i]];
-            qoff[i + 1] = qoff[i] + (uint64_t) qlen[i];
-        }
-        qres.resize(qoff[nq] + 1);
-        for (uint32_t i = 0; i < nq; i++) memcpy(qres.data() + qoff[i], qdb->residues.data() + qdb->offsets[localQ[i]], (size_t) qlen[i]);
-        SeqSetH qset;
-        if (nq) {
-            if (qdb->profile) {
-                qaln.resize((qoff[nq] + 1) * 21);
-                for (uint32_t i = 0; i < nq; i++)
-                    memcpy(qaln.data() + qoff[i] * 21, qdb->alnProfile.data() + qdb->offsets[localQ[i]] * 21, (size_t) qlen[i] * 21);
-                rc = sd_profileset_create(ctx.c, qres.data(), qoff.data(), nq, qaln.data(), &qset.s);
-            } else {
-                qbias.assign(qoff[nq] + 1, 0);
-                if (compBias) sd_host_comp_bias(host.h, qres.data(), qoff.data(), nq, 6, qbias.data(), nullptr, nullptr);
-                rc = sd_seqset_create(ctx.c, qres.data(), qoff.data(), nq, qbias.data(), &qset.s);
-            }
-            if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_seqset_create(queries)");
-        }
-        lap.mark("chunk: query set");
-        // the pairs that are aligned (pre-rejected ones are not)
-        std::vector<uint32_t> apq, apt, aIdx;
-        std::vector<uint8_t> aid;
-        apq.reserve(pq.size());
-        for (size_t i = 0; i < pq.size(); i++)
-            if (ident[i] != 2) {
-                apq.push_back(pq[i]);
-                apt.push_back(pt[i]);
-                aid.push_back(ident[i]);
-                aIdx.push_back((uint32_t) i);
-            }
-        alignmentsNum += apq.size();
-        const bool compact = swMode == 2 && !stopRules;
-        if (!apq.empty()) {
-            rc = alignPairs(ctx.c, par, qset.s, tset.s, *qdb, *tdb, localQ, apq, apt, aid, compact, idxOut, res, pool);
-            if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_sw_align_batch");
-        } else {
-            res.clear();
-            idxOut.clear();
-        }
-        lap.mark("chunk: alignPairs");
-        // record list handed to the criteria: compact -> only the reportable records; otherwise every pair in prefilter
-        // order, pre-rejected ones as records that fail every criterion (E-value NaN)
-        recQ.clear();
-        recT.clear();
-        recIdent.clear();
-        std::vector<sd_sw_result> *recs = &res;
-        std::vector<sd_sw_result> full;
-        if (compact) {
-            recQ.resize(res.size());
-            recT.resize(res.size());
-            recIdent.resize(res.size());
-            for (size_t x = 0; x < res.size(); x++) {
-                recQ[x] = apq[idxOut[x]];
-                recT[x] = apt[idxOut[x]];
-                recIdent[x] = aid[idxOut[x]];
-            }
-        } else {
-            full.resize(pq.size());
-            sd_sw_result dummy;
-            memset(&dummy, 0, sizeof(dummy));
-            dummy.qStart = dummy.tStart = dummy.qEnd = dummy.tEnd = -1;
-            dummy.evalue = NAN;
-            for (size_t i = 0; i < pq.size(); i++) full[i] = dummy;
-            for (size_t x = 0; x < aIdx.size(); x++) full[aIdx[x]] = res[x];
-            recQ = pq;
-            recT = pt;
-            recIdent.resize(pq.size());
-            for (size_t i = 0; i < pq.size(); i++) recIdent[i] = ident[i] == 1 ? 1 : 0;
-            recs = &full;
-        }
-        order.resize(std::max<size_t>(recs->size(), 1));
-        counts.assign(std::max<uint32_t>(nq, 1), 0);
-        rc = sd_host_accept_sort(&crit, nq, (uint32_t) recs->size(), recQ.data(), recT.data(), recs->data(), recIdent.data(),
-                                 qlen.data(), tdb->lens.data(), tdb->keys.data(), order.data(), counts.data());
-        if (rc != SD_OK) return fail("sd_host_accept_sort failed (" + std::to_string(rc) + ")");
-        uint64_t nAcc = 0;
-        for (uint32_t i = 0; i < nq; i++) nAcc += counts[i];
-        passedNum += nAcc;
-        const std::vector<sd_sw_result> *outRecs = recs;
-        const std::vector<uint32_t> *outOrder = &order, *outCounts = &counts, *outT = &recT;
-        const std::vector<uint8_t> *outIdent = &recIdent;
-        const BtPool *outPool = &pool;
-        if (realign && nAcc > 0) {
-            // second pass over the accepted records, in their order (Alignment.cpp:408-440)
-            pq2.resize(nAcc);
-            pt2.resize(nAcc);
-            ident2.resize(nAcc);
-            uint64_t w = 0;
-            for (uint32_t q = 0; q < nq; q++)
-                for (uint32_t x = 0; x < counts[q]; x++, w++) {
-                    const uint32_t i = order[w];
-                    pq2[w] = q;
-                    pt2[w] = recT[i];
-                    ident2[w] = recIdent[i];
-                }
-            std::vector<uint32_t> idx2;
-            // the realigner's query profile: composition bias against the score-biased matrix (a profile query carries its
-            // scores itself and is reused)
-            SeqSetH qset2;
-            sd_seqset *rq = qset.s;
-            if (!qdb->profile && compBias && realignScoreBias != 0.0f) {
-                std::vector<int8_t> qbias2(qoff[nq] + 1, 0);
-                sd_host_sw_comp_bias(host.h, 2, qres.data(), qoff.data(), nq, qbias2.data());
-                rc = sd_seqset_create(ctx.c, qres.data(), qoff.data(), nq, qbias2.data(), &qset2.s);
-                if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_seqset_create(realign queries)");
-                rq = qset2.s;
-            }
-            rc = alignPairs(ctx.c, rpar, rq, tset.s, *qdb, *tdb, localQ, pq2, pt2, ident2, false, idx2, res2, pool2);
-            if (rc != SD_OK) return failCtx(ctx.c, rc, "sd_sw_align_batch(realign)");
-            merged.resize(nAcc);
-            order2.resize(nAcc);
-            counts2.assign(nq, 0);
-            rc = sd_host_realign_select(&crit, nq, counts.data(), order.data(), recT.data(), recs->data(), res2.data(),
-                                        ident2.data(), qlen.data(), tdb->lens.data(), tdb->keys.data(), merged.data(),
-                                        order2.data(), counts2.data());
-            if (rc != SD_OK) return fail("sd_host_realign_select failed");
-            outRecs = &merged;
-            outOrder = &order2;
-            outCounts = &counts2;
-            accT = pt2;
-            outT = &accT;
-            outIdent = &ident2;
-            outPool = &pool2;
-        } else if (realign) {
-            counts2.assign(std::max<uint32_t>(nq, 1), 0);
-            outCounts = &counts2;
-        }
-        lap.mark("chunk: accept / sort (+ realign)");
-        rc = sd_alntext_format(text, &crit, nq, outCounts->data(), outOrder->data(), outT->data(), outRecs->data(), outIdent->data(),
-                               outPool->data(), qlen.data(), tdb->lens.data(), tdb->keys.data());
+        const char *what = "";
+        rc = alignChunkCore(ctx.c, host.h, S, *qdb, *tdb, tset.s, C, &lap, &what);
+        if (rc != SD_OK) return failCtx(ctx.c, rc, what);
+        alignmentsNum += C.aligned;
+        passedNum += C.accepted;
+        rc = sd_alntext_format(text, &S.crit, nq, C.outCounts->data(), C.outOrder->data(), C.outT->data(), C.outRecs->data(), C.outIdent->data(),
+                               C.outPool->data(), C.qlen.data(), tdb->lens.data(), tdb->keys.data());
         if (rc != SD_OK) return fail("sd_alntext_format failed (" + std::to_string(rc) + ")");
         lap.mark("chunk: format");
         const char *txt;

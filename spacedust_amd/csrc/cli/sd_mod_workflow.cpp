@@ -9,6 +9,7 @@
 // the ranks, every rank's cluster records are gathered on rank 0 (RCCL: sd_gather_results), which writes the TSV (the
 // reference's MPI mode merges per-rank result files on the master instead, M/src/prefiltering/Prefiltering.cpp:619-650).
 #include "sd_cli.h"
+#include "sd_align_core.h"
 
 #include <algorithm>
 #include <chrono>
@@ -102,40 +103,6 @@ int checkWorkflowFlags(const Args &a) {
     return 0;
 }
 
-// sd_setdb over a loaded DB (+ set membership by id when a lookup exists)
-struct SetDbArrays {
-    std::vector<uint32_t> setId, pos;
-    std::vector<uint8_t> strand;
-    sd_setdb view;
-    void fill(const SeqDb &db, const SetInfo *sets) {
-        memset(&view, 0, sizeof(view));
-        view.residues = db.residues.data();
-        view.offsets = db.offsets.data();
-        view.n = db.n;
-        view.keys = db.keys.data();
-        if (sets) {
-            setId.resize(db.n);
-            pos.resize(db.n);
-            strand.resize(db.n);
-            for (uint32_t i = 0; i < db.n; i++) {
-                const uint32_t k = db.keys[i];
-                setId[i] = k < sets->setOfKey.size() ? sets->setOfKey[k] : 0;
-                pos[i] = k < sets->posOfKey.size() ? sets->posOfKey[k] : 0;
-                strand[i] = k < sets->strandOfKey.size() ? sets->strandOfKey[k] : 0;
-            }
-            view.setId = setId.data();
-            view.posInSet = pos.data();
-            view.strand = strand.data();
-            view.nSets = sets->nSets;
-        }
-        if (db.profile) {
-            view.alnProfile = db.alnProfile.data();
-            view.sortedScore = db.sortedScore.data();
-            view.sortedIndex = db.sortedIndex.data();
-        }
-    }
-};
-
 // DB writers fed by the pipeline's sinks
 struct Sinks {
     const SeqDb *qdb = nullptr, *tdb = nullptr;
@@ -185,14 +152,6 @@ struct Sinks {
             if (!s->aln.write(s->qdb->keys[first + i], txt + eoff[i], (size_t) (eoff[i + 1] - eoff[i]))) s->failed = true;
     }
 };
-
-void packNames(const std::vector<std::string> &v, std::string &blob, std::vector<uint64_t> &off) {
-    off.assign(v.size() + 1, 0);
-    for (size_t i = 0; i < v.size(); i++) off[i + 1] = off[i] + v[i].size();
-    blob.clear();
-    blob.reserve(off.back());
-    for (const std::string &s : v) blob += s;
-}
 
 // Several ranks leave NAME.<rank> + NAME.<rank>.index each; rank 0 turns them into one DB with split data files -- NAME.0 ..
 // NAME.<world-1> and one NAME.index whose offsets run through their concatenation, the layout the reference's multi-threaded
@@ -522,23 +481,19 @@ int runSearch(const Args &a, bool withClusters) {
 
 }  // namespace
 
-// ---------------------------------------------------------------------------------------------------------------
-// result2profile <queryDB> <targetDB> <alignmentDB> <profileDB>   (M/src/util/result2profile.cpp:16-322): the host step
-// between search iterations.  The arithmetic is sd_r2p_batch of the C ABI; this is the DB side.
-int result2profileModule(const Args &a) {
-    if (a.pos.size() != 4) return fail("usage: result2profile <queryDB> <targetDB> <alignmentDB> <profileDB> [options]");
+int r2pSetupFromArgs(const Args &a, R2pSetup &s) {
     if (a.integer("--compressed", 0) != 0) return fail("--compressed 1 is not supported");
     if (a.integer("--profile-output-mode", 0) != 0) return fail("--profile-output-mode 0 only");
     if (a.integer("--pseudo-cnt-mode", 0) != 0) return fail("--pseudo-cnt-mode 1 needs the context library (not built in)");
     if (a.flag("--allow-deletion", false)) return fail("--allow-deletion 1 is not supported");
     if (a.multi("--sub-mat", "aa", "blosum62.out") != "blosum62.out") return fail("--sub-mat: only blosum62.out is built into this path");
-    const std::string qidStr = a.str("--qid", "0.0");
-    sd_r2p_params p;
+    s.qid = a.str("--qid", "0.0");
+    sd_r2p_params &p = s.par;
     memset(&p, 0, sizeof(p));
     p.filterMsa = (int32_t) a.integer("--filter-msa", 1);
     p.filterMinEnable = (int32_t) a.integer("--filter-min-enable", 0);
     p.filterMaxSeqId = (float) a.real("--max-seq-id", 0.9);
-    p.qid = qidStr.c_str();
+    p.qid = s.qid.c_str();
     p.qsc = (float) a.real("--qsc", -20.0);
     p.covMSAThr = (float) a.real("--cov", 0.0);
     p.Ndiff = (int32_t) a.integer("--diff", 1000);
@@ -550,7 +505,19 @@ int result2profileModule(const Args &a) {
     p.maskProfile = (int32_t) a.integer("--mask-profile", 1);
     p.maskProb = a.real("--mask-prob", 0.9);
     double evalThr = a.real("-e", 0.001), evalProfile = a.real("--e-profile", 0.001);
-    evalProfile = (evalThr < evalProfile) ? evalThr : evalProfile;   // result2profile.cpp:33
+    s.evalProfile = (evalThr < evalProfile) ? evalThr : evalProfile;   // result2profile.cpp:33
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// result2profile <queryDB> <targetDB> <alignmentDB> <profileDB>   (M/src/util/result2profile.cpp:16-322): the host step
+// between search iterations.  The arithmetic is sd_r2p_batch of the C ABI; this is the DB side.
+int result2profileModule(const Args &a) {
+    if (a.pos.size() != 4) return fail("usage: result2profile <queryDB> <targetDB> <alignmentDB> <profileDB> [options]");
+    R2pSetup RS;
+    if (int rcS = r2pSetupFromArgs(a, RS)) return rcS;
+    const sd_r2p_params &p = RS.par;
+    const double evalProfile = RS.evalProfile;
     const int threads = threadsOf(a);
     Lap lap("result2profile");
     HostH host;
@@ -865,9 +832,10 @@ std::vector<std::string> with(std::vector<std::string> v, std::initializer_list<
 // `search --num-iterations N` (M/src/workflow/Search.cpp:476-518 builds the per-step parameter strings,
 // M/data/workflow/blastpgp.sh:52-140 runs them): iteration 0 with --realign and the profile E-value, prefilter results of
 // later iterations minus what is aligned already, the last alignment with the user's -e, merged into the result DB
-int iterativeSearch(const Args &a, const std::string &Q, const std::string &T, const std::string &result, const std::string &tmp) {
+int iterativeSearch(const Args &a, const std::string &Q, const std::string &T, const std::string &result, const std::string &tmp,
+                    const std::string *inMemoryTsv = nullptr) {
     const int numIt = (int) a.integer("--num-iterations", 1);
-    mkdir(tmp.c_str(), 0777);
+    if (!inMemoryTsv) mkdir(tmp.c_str(), 0777);
     const std::string eUser = a.str("-e", "0.001"), eProfile = a.str("--e-profile", "0.001");
     const std::vector<std::string> common = {"--threads", std::to_string(threadsOf(a)), "-v", a.str("-v", "3")};
     std::vector<std::string> pref = with(common, {"-s", a.str("-s", "5.7"), "-k", a.str("-k", "0"), "--max-seqs", a.str("--max-seqs", "300"), "-c",
@@ -893,6 +861,11 @@ int iterativeSearch(const Args &a, const std::string &Q, const std::string &T, c
     if (a.has("--profile-weights-host")) prof = with(prof, {"--profile-weights-host", a.str("--profile-weights-host", "0")});
     if (a.has("--device")) prof = with(prof, {"--device", a.str("--device", "0")});
     const bool keep = a.integer("--keep-tmp", 0) != 0;   // keep the per-iteration DBs (parity checks at size read them)
+    if (inMemoryTsv) {
+        // clustersearch without DB files between the modules (sd_mod_iter.cpp): chunks of queries through all iterations in memory,
+        // several at a time, into one aggregation.  --keep-tmp 1 wants the per-iteration DBs: the module chain below writes them
+        return iterativeClusterSearchInMemory(a, Q, T, *inMemoryTsv, pref, aln, prof, eUser, eProfile);
+    }
     // the modules below run in this process: the target DB, its index on the device and its sequence set stay resident between them
     // (sd_cli.h: Resident) instead of being reloaded / rebuilt by every module
     struct ResidentScope {
@@ -965,6 +938,11 @@ int clustersearchModule(const Args &a) {
     def("--alignment-mode", "2");
     for (const char *db : {"/result", "/result_prefixed", "/aggregate", "/aggregate_merged", "/matches", "/matches_h", "/clusters", "/clusters_h"})
         sddb::removeDb(tmp + db);
+    // default: in memory (no DB between the modules of an iteration, no text chain behind them).  The module chain runs when its DBs
+    // are wanted (--keep-tmp 1), with SD_ITER_FILES=1, and for several ranks (they shard whole query sets over the module chain's DBs)
+    const bool files = a.integer("--keep-tmp", 0) != 0 || (getenv("SD_ITER_FILES") && atoi(getenv("SD_ITER_FILES")) != 0) ||
+                       envInt("WORLD_SIZE", 1) > 1 || a.integer("--world-size", 1) > 1;
+    if (!files) return iterativeSearch(s, Q, T, tmp + "/result", tmp + "/search", &a.pos[2]);
     if (int rc = iterativeSearch(s, Q, T, tmp + "/result", tmp + "/search")) return rc;
     const std::vector<std::string> common = {"--threads", std::to_string(threadsOf(a)), "-v", a.str("-v", "3")};
     if (int rc = runModule(prefixidModule, "prefixid", {tmp + "/result", tmp + "/result_prefixed"}, common)) return rc;

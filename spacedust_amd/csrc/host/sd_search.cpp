@@ -674,6 +674,8 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     };
 
     int status = SD_OK;
+    StageThread finStage{"sd-fin"};   // finalises ranges (see `finalize` below)
+    std::mutex finMu;                 // the stage clocks both this thread and the finalising thread add to
     std::future<std::pair<int, double> > pending;
     std::unique_ptr<double> aggCpu(new double(0.0));   // thread CPU seconds of the aggregation jobs
     double *aggCpuP = aggCpu.get();
@@ -684,19 +686,42 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         if (!havePending) return;
         const double t0 = nowSec();
         const std::pair<int, double> r = pending.get();
-        tm[T_AGG_WAIT] += nowSec() - t0;
+        {
+            std::lock_guard<std::mutex> l(finMu);
+            tm[T_AGG_WAIT] += nowSec() - t0;
+        }
         tm[T_AGG_BUSY] += r.second;
         havePending = false;
         if (r.first != SD_OK && status == SD_OK) status = s->fail(r.first, "sd_agg_add");
     };
 
-    auto finalize = [&](uint32_t r) -> int {
+    // A range is finalised -- sd_agg_finish, clusterhits on the device, the cluster records -- on a stage thread of its own: on the driving
+    // thread (where it ran until round 6) the 0.1 - 0.2 s of record building per range were time in which no prefilter result was collected
+    // and no alignment handed over (measured with the records built at N = 1 as well: 1 445 -> 1 526 ms per 1 000-proteome step).  A job
+    // touches its own range's result, the clusterhits context and, under finMu, the stage clocks; errors come back as text.
+    auto finalize = [&](uint32_t r, std::string *errOut) -> int {
+        auto failF = [&](int rc_, const std::string &what, sd_ctx *ctx_ = nullptr) {
+            *errOut = what + " failed (" + std::to_string(rc_) + ")";
+            if (ctx_) *errOut += std::string(": ") + sd_last_error(ctx_);
+            return rc_;
+        };
+        double tAggWait = 0, tCh = 0;
+        struct Clocks {
+            std::mutex &m;
+            double *tm;
+            double &a, &c;
+            ~Clocks() {
+                std::lock_guard<std::mutex> l(m);
+                tm[T_AGG_WAIT] += a;
+                tm[T_CLUSTERHITS] += c;
+            }
+        } clocks{finMu, tm, tAggWait, tCh};
         sd_search_result &R = *res[r];
         if (!aggregate) return SD_OK;
         double t0 = nowSec();
         uint64_t ne = 0, nh = 0;
         int rc = sd_agg_finish(R.agg, &ne, &nh);
-        if (rc != SD_OK) return s->fail(rc, "sd_agg_finish");
+        if (rc != SD_OK) return failF(rc, "sd_agg_finish");
         R.entryOff.assign(ne + 1, 0);
         R.entryQ.assign(std::max<uint64_t>(ne, 1), 0);
         R.entryT.assign(std::max<uint64_t>(ne, 1), 0);
@@ -704,13 +729,13 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         R.hitT.assign(std::max<uint64_t>(nh, 1), 0);
         R.pval.assign(std::max<uint64_t>(nh, 1), 0.0);
         rc = sd_agg_get(R.agg, R.entryOff.data(), R.entryQ.data(), R.entryT.data(), R.hitQ.data(), R.hitT.data(), R.pval.data());
-        if (rc != SD_OK) return s->fail(rc, "sd_agg_get");
+        if (rc != SD_OK) return failF(rc, "sd_agg_get");
         R.entryQ.resize(ne);
         R.entryT.resize(ne);
         R.hitQ.resize(nh);
         R.hitT.resize(nh);
         R.pval.resize(nh);
-        tm[T_AGG_WAIT] += nowSec() - t0;
+        tAggWait += nowSec() - t0;
         t0 = nowSec();
         R.clusterOf.assign(nh, UINT32_MAX);
         R.rank.assign(nh, 0);
@@ -731,11 +756,11 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             rc = sd_clusterhits_batch(s->ctxCh, &s->chPar, (uint32_t) ne, R.entryOff.data(), qp.data(), tp.data(), sd.data(), R.pval.data(),
                                       nq.data(), s->lgamma.data(), (uint32_t) s->lgamma.size(), R.clusterOf.data(), R.rank.data(),
                                       R.nClusters.data(), R.pCO.data(), R.pMH.data(), R.cSize.data());
-            if (rc != SD_OK) return s->fail(rc, "sd_clusterhits_batch", s->ctxCh);
+            if (rc != SD_OK) return failF(rc, "sd_clusterhits_batch", s->ctxCh);
             for (uint64_t e = 0; e < ne; e++) nClu += R.nClusters[e];
             for (uint64_t h = 0; h < nh; h++) nCluHits += R.clusterOf[h] != UINT32_MAX;
         }
-        tm[T_CLUSTERHITS] += nowSec() - t0;
+        tCh += nowSec() - t0;
         uint64_t na = 0, nacc = 0;
         sd_agg_stats(R.agg, &na, &nacc);
         if (s->wantRecords) {
@@ -747,7 +772,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
                 rc = sd_agg_records(R.agg, empty ? &zero32 : R.clusterOf.data(), empty ? &zero32 : R.rank.data(),
                                     R.nClusters.empty() ? &zero32 : R.nClusters.data(), empty ? &zeroD : R.pCO.data(), empty ? &zeroD : R.pMH.data(),
                                     empty ? &zero32 : R.cSize.data(), pass ? R.records.data() : nullptr, need, &need);
-                if (rc != SD_OK) return s->fail(rc, "sd_agg_records");
+                if (rc != SD_OK) return failF(rc, "sd_agg_records");
                 if (!pass) R.records.resize(need);
             }
             R.haveRecords = true;
@@ -762,6 +787,18 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         return SD_OK;
     };
 
+    struct FinJob {
+        std::future<int> fut;
+        std::shared_ptr<std::string> err;
+    };
+    std::vector<FinJob> finJobs;
+    auto submitFinalize = [&](uint32_t r) {
+        FinJob j;
+        j.err.reset(new std::string());
+        std::shared_ptr<std::string> e = j.err;
+        j.fut = finStage.submit([&finalize, r, e] { return finalize(r, e.get()); });
+        finJobs.push_back(std::move(j));
+    };
     std::vector<std::pair<uint32_t, size_t> > toFinalize;   // (range, chunk whose aggregation must have finished)
     std::vector<char> finalized(nRanges, 0);
     std::vector<uint64_t> prefHitsOfRange(nRanges, 0), pairsOfRange(nRanges, 0);
@@ -923,9 +960,8 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             }
             const uint32_t fr = toFinalize.front().first;
             toFinalize.erase(toFinalize.begin());
-            const int rc = finalize(fr);
+            submitFinalize(fr);   // (every aggregation job of the range has been collected: the range's sd_agg is the job's alone now)
             finalized[fr] = 1;
-            if (rc != SD_OK) status = rc;
         }
     };
 
@@ -999,9 +1035,19 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         if (biasFut[x] && biasFut[x]->valid()) biasFut[x]->wait();
     waitPending();
     if (status == SD_OK)
-        for (uint32_t r = 0; r < nRanges && status == SD_OK; r++)
-            if (!finalized[r]) status = finalize(r);
-    tm[T_TOTAL] = nowSec() - tAll;
+        for (uint32_t r = 0; r < nRanges; r++)
+            if (!finalized[r]) submitFinalize(r);
+    for (FinJob &j : finJobs) {   // (also on errors: the jobs reference this frame)
+        const int rcF = j.fut.get();
+        if (rcF != SD_OK && status == SD_OK) {
+            s->err = *j.err;
+            status = rcF;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> l(finMu);
+        tm[T_TOTAL] = nowSec() - tAll;
+    }
     tm[T_CPU_AGG_MAIN] += *aggCpu + (threadCpuSec() - mainCpu0);
     if (status != SD_OK) return status;
     for (uint32_t r = 0; r < nRanges; r++) {

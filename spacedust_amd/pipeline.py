@@ -223,6 +223,10 @@ class ClusterSearch:
         tsv_paths = tsv_paths if tsv_paths is not None else [None] * n
         results = []
         records_all, rec_at = None, None
+        # want_records='build': the records are built inside the stream and stay in the result handles (a single rank has nobody to send
+        # them to: it does the same work as a rank of a multi-GPU run up to the hand-over to the gather)
+        if want_records == 'build':
+            want_records = False
         if want_records:   # one buffer for the records of all ranges, in range order: what sd_gather_results sends, without another copy
             sizes = []
             for ri in range(n):

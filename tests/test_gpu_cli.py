@@ -5,10 +5,11 @@ DB must hash to what the reference binary's DB hashes to:
     pref_0 8109a70b... (98 957 lines), result 2e917f0e... (15 065 lines), final TSV (cut -f2-) abb28ee3... (416 lines),
     R/util/run_regression.sh:20-23: 308 hit lines, 2 clusters with P < 1E-20."""
 import os
+import subprocess
 
 import pytest
 
-from dbutil import write_db, flat_lines_from_gz, entries_by_first_column, sorted_md5, sdgpu, example_fasta
+from dbutil import write_db, flat_lines_from_gz, entries_by_first_column, sorted_md5, sdgpu, example_fasta, SDGPU
 
 pytestmark = pytest.mark.gpu
 
@@ -317,7 +318,9 @@ def test_profile_iterations_pinned_to_the_reference_classes_on_this_box(work):
             assert bad == 0, (step, bad)
     assert n_rows > 150000 and n_aln > 1000
     # the fused workflow went through the same DBs
-    sdgpu('clustersearch', g, g, work / 'iter_pinned.tsv', work / 'tmpip', '--filter-self-match', '--num-iterations', '3', '--threads', '8', '-v', '0')
+    # (--keep-tmp 1: the module chain with its per-iteration DBs; without it the iterations run in memory, next test but one)
+    sdgpu('clustersearch', g, g, work / 'iter_pinned.tsv', work / 'tmpip', '--filter-self-match', '--num-iterations', '3', '--threads', '8', '-v', '0',
+          '--keep-tmp', '1')
     for name in ('profile_0', 'profile_1'):
         assert _key_ordered_md5(work / 'tmpip' / 'search' / name) == _key_ordered_md5(it / name), name
     assert _key_ordered_md5(work / 'tmpip' / 'result') == _key_ordered_md5(it / 'aln_2')
@@ -331,7 +334,8 @@ def test_iterative_profile_search_config4(work):
     rounds rcpps like the one the reference binary ran on (profile_0 and profile_1 md5 equal), the recorded checksums of that binary's run
     hold as well: profile_1, the merged alignment DB (18 698 lines), 331 hits / 119 clusters."""
     g = work / 'genome'
-    sdgpu('clustersearch', g, g, work / 'iter.tsv', work / 'tmpi', '--filter-self-match', '--num-iterations', '3', '--threads', '8', '-v', '1')
+    sdgpu('clustersearch', g, g, work / 'iter.tsv', work / 'tmpi', '--filter-self-match', '--num-iterations', '3', '--threads', '8', '-v', '1',
+          '--keep-tmp', '1')
     n0, md5_0 = _key_ordered_md5(work / 'tmpi' / 'search' / 'profile_0')
     assert n0 == 5898
     tsv = open(work / 'iter.tsv').readlines()
@@ -346,6 +350,33 @@ def test_iterative_profile_search_config4(work):
         assert (len(lines), sorted_md5(lines)) == (18698, 'deee49195d78013868efd140ad77b913')
         assert (n_hit, n_clu) == (331, 119)
         assert sorted_md5(tsv, drop_first_column=True) == 'ca3dd1ba9c0f89b9a7cf0726a1bab2ce'
+
+
+def test_iterative_search_in_memory_equals_the_module_chain(work):
+    """`clustersearch --num-iterations 3` without --keep-tmp runs the iterations in memory (csrc/cli/sd_mod_iter.cpp: chunks of queries
+    through prefilter -> subtract -> align -> merge -> result2profile of all iterations, several chunks at a time, one aggregation): the
+    TSV is the module chain's, byte for byte -- whatever the number of workers and wherever the chunks are cut -- and no DB is left
+    between the modules.  Also with two different set DBs (query != target: no identity pairs, the query's own sequence is an ordinary
+    target of the profile iterations)."""
+    g = work / 'genome'
+    common = ['--filter-self-match', '--num-iterations', '3', '--threads', '8', '-v', '0']
+    sdgpu('clustersearch', g, g, work / 'itf.tsv', work / 'tmpitf', *common, '--keep-tmp', '1')
+    want = open(work / 'itf.tsv').read()
+    assert want.count('\n#') > 100
+    for tag, env in (('a', {}), ('b', {'SD_ITER_WORKERS': '1', 'SD_ITER_CHUNK': '5898'}), ('c', {'SD_ITER_WORKERS': '4', 'SD_ITER_CHUNK': '611'})):
+        p = subprocess.run([SDGPU, 'clustersearch', str(g), str(g), str(work / ('itm_%s.tsv' % tag)), str(work / ('tmpitm_' + tag))] + common,
+                           capture_output=True, text=True, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr[-600:]
+        assert open(work / ('itm_%s.tsv' % tag)).read() == want, tag
+        assert not os.path.exists(work / ('tmpitm_' + tag) / 'search' / 'aln_0') and not os.path.exists(work / ('tmpitm_' + tag) / 'result')
+    fa = example_fasta(work)
+    q, t = work / 'q913i', work / 't915i'
+    sdgpu('createsetdb', fa[0], q, work / 'tmpqi', '-v', '0')
+    sdgpu('createsetdb', fa[1], t, work / 'tmpti', '-v', '0')
+    two = ['--num-iterations', '3', '--threads', '8', '-v', '0']
+    sdgpu('clustersearch', q, t, work / 'itf2.tsv', work / 'tmpitf2', *two, '--keep-tmp', '1')
+    sdgpu('clustersearch', q, t, work / 'itm2.tsv', work / 'tmpitm2', *two)
+    assert open(work / 'itm2.tsv').read() == open(work / 'itf2.tsv').read() and os.path.getsize(work / 'itf2.tsv') > 1000
 
 
 def test_prefilter_and_clustersearch_use_the_index_file(work):

@@ -150,15 +150,18 @@ def test_index_built_on_the_device_at_scale(P):
 
 def test_iterative_profile_search_on_1000_proteomes():
     """BASELINE configs[3] at its target size on one GPU: `sdgpu clustersearch Q T --num-iterations 3` with T = 1 000 synthetic
-    proteomes (3 * 10^6 proteins) and Q = the first two of them, through createsetdb DBs; the per-iteration DBs of that run
+    proteomes (3 * 10^6 proteins) and Q = the first three of them, through createsetdb DBs, in memory; the module chain over DB files
+    on the first two gives the same TSV (the head of the in-memory one), and its per-iteration DBs are checked
     against the reference's classes on this machine for 32 sampled queries: profile prefilter rows, profile alignments
     (coordinates, backtraces, E-values) of iterations 1 and 2, profile bytes of profile_0 and profile_1 (tools/iter3_scale.py)"""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     import iter3_scale
-    r = iter3_scale.run(1000, 2, 32, log=lambda *a: None)
-    assert r['queries'] == 6000 and r['hit_lines'] > 1000 and r['cluster_lines'] > 100
+    r = iter3_scale.run(1000, 3, 32, log=lambda *a: None)
+    assert r['queries'] == 9000 and r['hit_lines'] > 1000 and r['cluster_lines'] > 100
+    assert r['files_between_modules'] == [], r['files_between_modules']   # nothing under the in-memory run's tmp directory
+    assert r['module_chain']['tsv_equals_head_of_in_memory_tsv'], r['module_chain']
     pc = r['parity_check']
     if pc.get('queries', 0) == 0:
         pytest.skip('oracle/_ref/libsdref*.so not built (needs /root/reference at build time)')

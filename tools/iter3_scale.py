@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """BASELINE configs[3] at its target size on one GPU: `sdgpu clustersearch Q T out tmp --num-iterations 3` with T = P synthetic
-proteomes (default 1 000: 3 * 10^6 proteins) and Q = the first q of them as their own set DB, through the reference's DB files
-(createsetdb from one FASTA file per proteome), timed; then, untimed, the DBs the run left behind (--keep-tmp 1) are checked on
-a sample of queries against the reference's own classes run on this machine (oracle/_ref/libsdref*.so), iteration by iteration
-(M/data/workflow/blastpgp.sh:73-133):
+proteomes (default 1 000: 3 * 10^6 proteins) and Q = the first q of them (default 20) as their own set DB (createsetdb from one FASTA
+file per proteome), timed: the iterations run in memory (csrc/cli/sd_mod_iter.cpp, no DB between the modules).  Then, untimed:
+  * the same command with --keep-tmp 1 -- the module chain over DB files -- on the first `parity_sets` query proteomes: its TSV must be
+    the head of the timed run's TSV, byte for byte (entries are ordered by query set, clusters numbered in that order);
+  * the DBs that chain left behind are checked on a sample of queries against the reference's own classes run on this machine
+    (oracle/_ref/libsdref*.so), iteration by iteration (M/data/workflow/blastpgp.sh:73-133):
     prefilter   profile_{k-1} vs T       == QueryMatcher driven with the DBTYPE_HMM_PROFILE Sequence, row for row
     align       on the subtracted rows   == Matcher::getSWResult with the profile query: targets, coordinates, backtraces, E-values
     result2profile                       == MultipleAlignment / MsaFilter / PSSMCalculator, byte for byte (profile_0 from the
@@ -75,7 +77,7 @@ def _lines(db):
     return {k: [l.split('\t') for l in v.decode().split('\n') if l] for k, v in db.items()}
 
 
-def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
+def run(P=1000, q_sets=20, sample=32, threads=None, log=print, keep_dir=None, parity_sets=2):
     from dbutil import SDGPU
     from spacedust_amd import api
     from spacedust_amd.cpus import effective_cpus
@@ -106,22 +108,59 @@ def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
         t0 = time.time()
         sdgpu('createsetdb', *files, T, os.path.join(work, 'tmpT'), '-v', '0')
         sdgpu('createsetdb', *files[:q_sets], Q, os.path.join(work, 'tmpQ'), '-v', '0')
+        parity_sets = min(parity_sets, q_sets)
+        Q2 = os.path.join(work, 'Q2')
+        sdgpu('createsetdb', *files[:parity_sets], Q2, os.path.join(work, 'tmpQ2'), '-v', '0')
         out['createsetdb_s'] = time.time() - t0
         shutil.rmtree(fa_dir)
+        verbose = os.environ.get('SD_ITER3_VERBOSE') == '1'
+        # ---- timed: the iterations in memory
+        t0 = time.time()
+        os.environ['SD_ITER_PROFILE'] = '1'   # per-kernel event times of the workers' contexts, one JSON object on stderr
+        r = sdgpu('clustersearch', Q, T, os.path.join(work, 'iter3.tsv'), os.path.join(work, 'tmpm'), '--num-iterations', '3', '--threads', threads,
+                  '-v', '3')
+        wall = time.time() - t0
+        os.environ.pop('SD_ITER_PROFILE', None)
+        if verbose:
+            log(r.stdout[-6000:])
+            log(r.stderr[-12000:])
+        nq = int(ps.set_start[q_sets])
+        tsv = open(os.path.join(work, 'iter3.tsv')).readlines()
+        out.update(wall_s=wall, queries=nq, genome_pairs=q_sets * P, genome_pairs_per_s=q_sets * P / wall, how='in memory (sd_mod_iter.cpp)',
+                   hit_lines=sum(1 for l in tsv if l.startswith('>')), cluster_lines=sum(1 for l in tsv if l.startswith('#')),
+                   stages=[l.strip() for l in r.stdout.splitlines() if l.startswith('iteration ') or l.startswith('in-memory iterations')],
+                   files_between_modules=sorted(os.listdir(os.path.join(work, 'tmpm'))) if os.path.isdir(os.path.join(work, 'tmpm')) else [])
+        for l in r.stderr.splitlines():
+            if l.startswith('[iter profile] '):
+                try:
+                    kern = json.loads(l[len('[iter profile] '):])
+                    out['kernel_ms'] = {k: round(v[0], 1) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])[:14]}
+                    out['kernel_ms_total'] = round(sum(v[0] for v in kern.values()), 1)
+                except ValueError:
+                    pass
+        log('clustersearch --num-iterations 3 (in memory):', round(wall, 1), 's,', out['hit_lines'], 'hits in', out['cluster_lines'], 'clusters')
+        # ---- untimed: the module chain over DB files on the first query proteomes; same TSV
         tmp = os.path.join(work, 'tmp')
         t0 = time.time()
-        verbose = os.environ.get('SD_ITER3_VERBOSE') == '1'
-        r = sdgpu('clustersearch', Q, T, os.path.join(work, 'iter3.tsv'), tmp, '--num-iterations', '3', '--keep-tmp', '1', '--threads', threads,
+        r = sdgpu('clustersearch', Q2, T, os.path.join(work, 'iter3_chain.tsv'), tmp, '--num-iterations', '3', '--keep-tmp', '1', '--threads', threads,
                   '-v', '3' if verbose else '0')
-        wall = time.time() - t0
+        wall2 = time.time() - t0
         if verbose:
             log(r.stdout[-6000:])
             log(r.stderr[-12000:])   # SD_DEBUG_TIMING=1: the modules' lap times
-        nq = int(ps.set_start[q_sets])
-        tsv = open(os.path.join(work, 'iter3.tsv')).readlines()
-        out.update(wall_s=wall, queries=nq, genome_pairs=q_sets * P, genome_pairs_per_s=q_sets * P / wall,
-                   hit_lines=sum(1 for l in tsv if l.startswith('>')), cluster_lines=sum(1 for l in tsv if l.startswith('#')))
-        log('clustersearch --num-iterations 3:', round(wall, 1), 's,', out['hit_lines'], 'hits in', out['cluster_lines'], 'clusters')
+        chain = open(os.path.join(work, 'iter3_chain.tsv')).readlines()
+        out['module_chain'] = dict(query_proteomes=parity_sets, wall_s=wall2, genome_pairs_per_s=parity_sets * P / wall2, tsv_lines=len(chain),
+                                   tsv_equals_head_of_in_memory_tsv=bool(len(chain) > 0 and tsv[:len(chain)] == chain))
+        log('module chain on', parity_sets, 'query proteomes:', round(wall2, 1), 's; TSV = head of the in-memory TSV:', out['module_chain']['tsv_equals_head_of_in_memory_tsv'])
+        if not out['module_chain']['tsv_equals_head_of_in_memory_tsv']:   # where they part
+            first = next((i for i, (x, y) in enumerate(zip(chain, tsv)) if x != y), min(len(chain), len(tsv)))
+            sc, sm = set(chain), set(tsv[:len(chain)])
+            out['module_chain'].update(first_difference_at_line=first, chain_line=chain[first][:300] if first < len(chain) else None,
+                                       in_memory_line=tsv[first][:300] if first < len(tsv) else None, lines_only_in_chain=len(sc - sm),
+                                       lines_only_in_memory_head=len(sm - sc),
+                                       context_chain=[l[:200] for l in chain[max(0, first - 2):first + 3]], context_in_memory=[l[:200] for l in tsv[max(0, first - 2):first + 3]])
+            log('first difference', json.dumps({k: out['module_chain'][k] for k in ('first_difference_at_line', 'chain_line', 'in_memory_line', 'lines_only_in_chain', 'lines_only_in_memory_head', 'context_chain', 'context_in_memory')}, indent=1))
+        nq = int(ps.set_start[parity_sets])
         if not (ref_available() and ref_r2p_available()):
             out['parity_check'] = dict(queries=0, note='oracle/_ref/libsdref*.so did not travel')
             return out
@@ -148,6 +187,7 @@ def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
         r2p = RefResult2Profile()
         bad = dict(prefilter=0, align=0, profile=0)
         n = dict(prefilter_rows=0, alignments=0, profiles=0)
+        ref_s = dict(prefilter=0.0, align=0.0, profile=0.0)   # seconds inside the reference classes (one thread)
         # profile_0 from the sequence search's alignments
         prof0 = _entries(os.path.join(S, 'profile_0'), qs)
         aln0 = _lines(_entries(os.path.join(S, 'aln_0'), qs))
@@ -158,7 +198,9 @@ def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
             for w in rows:
                 if float(w[3]) < 0.001:
                     et.append(int(w[0])); eq.append(int(w[4])); ets.append(int(w[7])); bts.append(api.uncompress_cigar(w[10]))
+            t1 = time.time()
             got = r2p.profile(seq_of(q), [seq_of(t) for t in et], eq, ets, bts)
+            ref_s['profile'] += time.time() - t1
             bad['profile'] += got != prof0[q]
             n['profiles'] += 1
         for step in (1, 2):
@@ -168,7 +210,9 @@ def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
             todo = _lines(_entries(os.path.join(S, 'pref_%d' % step), qs))
             aln = _lines(_entries(os.path.join(S, 'aln_tmp_%d' % step), qs))
             for q in qs:
+                t1 = time.time()
                 ids, sc, dg, _ = rpf.query(prof[q])
+                ref_s['prefilter'] += time.time() - t1
                 keep = (lens[ids].astype(np.float32) / np.float32(lens[q])) >= np.float32(0.8)   # Util::canBeCovered, --cov-mode 2
                 want = [(int(t), int(s_), int(np.int16(np.uint16(d)))) for t, s_, d in zip(ids[keep], sc[keep], dg[keep])]
                 mine = [(int(w[0]), int(w[1]), int(w[2])) for w in got_pf.get(q, [])]
@@ -177,12 +221,14 @@ def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
                 rows = todo.get(q, [])
                 wantA = {}
                 if rows:
+                    t1 = time.time()
                     rsw.set_query_profile(prof[q])
                     for w in rows:
                         t = int(w[0])
                         r = rsw.align(seq_of(t), sw_mode=2, eval_thr=10.0 if last else 0.001, cov_mode=2, cov_thr=0.8)
                         if r['btLen'] > 0 and r['evalue'] <= (10.0 if last else 0.001) and len(r['backtrace']) >= 30:
                             wantA[t] = (r['qStart'], r['qEnd'], r['tStart'], r['tEnd'], _compress(r['backtrace']), '%.3E' % r['evalue'])
+                    ref_s['align'] += time.time() - t1
                 mineA = {int(w[0]): (int(w[4]), int(w[5]), int(w[7]), int(w[8]), w[10], w[3]) for w in aln.get(q, [])}
                 bad['align'] += mineA != wantA
                 n['alignments'] += len(wantA)
@@ -194,7 +240,9 @@ def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
                     for w in merged.get(q, []):
                         if float(w[3]) < 0.001:
                             et.append(int(w[0])); eq.append(int(w[4])); ets.append(int(w[7])); bts.append(api.uncompress_cigar(w[10]))
+                    t1 = time.time()
                     got = r2p.profile(None, [seq_of(t) for t in et], eq, ets, bts, centre_profile=prof[q])
+                    ref_s['profile'] += time.time() - t1
                     bad['profile'] += got != nxt[q]
                     n['profiles'] += 1
         out['parity_check'] = dict(queries=len(qs), prefilter_rows=n['prefilter_rows'], prefilter_queries_mismatching=bad['prefilter'],
@@ -202,6 +250,15 @@ def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
                                    profiles_mismatching=bad['profile'], seconds=time.time() - t0,
                                    against='oracle/_ref/libsdref.so + libsdref_r2p.so (the reference classes, this machine)')
         log('parity', out['parity_check'])
+        # CPU baseline of the profile part: the reference classes, one thread, on the sampled queries (the two profile prefilters, the
+        # profile alignments of both iterations, both result2profile calls; the sampled queries are those with profile alignments, so
+        # this is the cost of a query that takes part).  Iteration 0 -- an ordinary sequence search with one more alignment pass -- is
+        # what the main record's cpu_baseline measures; bench.py adds it.
+        per_q = sum(ref_s.values()) / max(len(qs), 1)
+        out['cpu_profile_iterations'] = dict(kind='reference', cores=1, queries=len(qs), seconds_per_query=per_q,
+                                             seconds_by_stage={k: round(v / max(len(qs), 1), 4) for k, v in ref_s.items()},
+                                             note='seconds inside QueryMatcher (profile) / Matcher::getSWResult / result2profile classes per sampled query, '
+                                                  'iterations 1 and 2 + both profile computations, one thread; sequence iteration 0 not included')
         return out
     finally:
         if keep_dir is None:
@@ -210,4 +267,4 @@ def run(P=1000, q_sets=2, sample=48, threads=None, log=print, keep_dir=None):
 
 if __name__ == '__main__':
     a = [int(x) for x in sys.argv[1:4]]
-    print(json.dumps(run(*(a + [1000, 2, 48][len(a):]))))
+    print(json.dumps(run(*(a + [1000, 20, 32][len(a):]))))

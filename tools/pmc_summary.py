@@ -6,7 +6,11 @@ gfx950 (128-B requests tallied at 64 B).  That factor is calibrated for this rep
 one random 8-B read per lane -- so 2 x FETCH_SIZE = 128 x TCC_EA0_RDREQ_128B exactly in all ten patterns, and WRITE_SIZE is
 exact (32-B and 64-B write requests are tallied apart).  With a third CSV (a pass of TCC_EA0_RDREQ_32B_sum / _64B_sum /
 _128B_sum) the exact byte count is printed beside 2 x FETCH_SIZE per kernel.
-Usage: pmc_summary.py <fetch counter_collection.csv> <write ...csv> [out.json [rdreq ...csv]]"""
+With the bench line of the PMC run (bench.py prints prefilter_queries_in_process: every query its process ran through the prefilter,
+warm-up, timed steps and both calls of the isolated leg) the JSON also carries bytes PER QUERY for every kernel group and for the
+prefilter stage as a whole (_prefilter_total) -- the figure to hold against SURVEY.md 8(d)'s bytes per query; bytes per launch of a
+PMC run cannot be compared with another run's launches (they hold different numbers of queries).
+Usage: pmc_summary.py <fetch counter_collection.csv> <write ...csv> [out.json [rdreq ...csv | - [bench line .json of the PMC run]]]"""
 import csv
 import re
 import sys
@@ -65,7 +69,7 @@ GROUPS = [('sdpk::sw_score_pk', 'sw_score_pk'), ('sw_score_kernel', 'sw_score'),
           ('clusterhits', 'clusterhits')]
 
 
-def to_json(fetch_csv, write_csv, out_path):
+def to_json(fetch_csv, write_csv, out_path, queries=0):
     """the same numbers grouped the way bench.py names its kernel groups (variants of one template summed)"""
     import json
     f, w = load(fetch_csv), load(write_csv)
@@ -82,10 +86,35 @@ def to_json(fetch_csv, write_csv, out_path):
     res = {g: dict(launches=o['launches'], fetch_bytes_per_launch=o['fetch'] / max(o['launches'], 1),
                    write_bytes_per_launch=o['write'] / max(o['launches'], 1),
                    bytes_per_launch=(o['fetch'] + o['write']) / max(o['launches'], 1)) for g, o in out.items()}
+    if queries > 0:
+        tot = dict(fetch=0.0, write=0.0)
+        for g, o in out.items():
+            res[g].update(queries=queries, fetch_bytes_per_query=o['fetch'] / queries, write_bytes_per_query=o['write'] / queries,
+                          bytes_per_query=(o['fetch'] + o['write']) / queries)
+            if g.startswith('prefilter_'):
+                tot['fetch'] += o['fetch']
+                tot['write'] += o['write']
+        res['_prefilter_total'] = dict(queries=queries, fetch_bytes_per_query=tot['fetch'] / queries, write_bytes_per_query=tot['write'] / queries,
+                                       bytes_per_query=(tot['fetch'] + tot['write']) / queries,
+                                       note='every prefilter_* kernel group of the PMC run: 2 x FETCH_SIZE + WRITE_SIZE over the queries its process ran '
+                                            'through the prefilter (bench.py: prefilter_queries_in_process)')
+        print('prefilter stage: %.1f MB per query at the memory side (%.1f fetched, %.1f written) over %d queries'
+              % (res['_prefilter_total']['bytes_per_query'] / 1e6, tot['fetch'] / queries / 1e6, tot['write'] / queries / 1e6, queries))
+        for g in sorted((g for g in res if g.startswith('prefilter_')), key=lambda g: -res[g]['bytes_per_query']):
+            print('  %-32s %8.2f MB per query (fetch %.2f, write %.2f)' % (g, res[g]['bytes_per_query'] / 1e6, res[g]['fetch_bytes_per_query'] / 1e6,
+                                                                            res[g]['write_bytes_per_query'] / 1e6))
     json.dump(res, open(out_path, 'w'), indent=1)
 
 
+def queries_of(bench_json):
+    import json
+    for line in open(bench_json):
+        if line.startswith('{'):
+            return int(json.loads(line).get('prefilter_queries_in_process') or 0)
+    return 0
+
+
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2], sys.argv[4] if len(sys.argv) > 4 else None)
+    main(sys.argv[1], sys.argv[2], sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != '-' else None)
     if len(sys.argv) > 3:
-        to_json(sys.argv[1], sys.argv[2], sys.argv[3])
+        to_json(sys.argv[1], sys.argv[2], sys.argv[3], queries_of(sys.argv[5]) if len(sys.argv) > 5 else 0)
