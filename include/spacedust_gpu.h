@@ -379,6 +379,12 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
 /* optional: DB keys of the query / target proteins (default: key = index) -- the order of the hits inside an entry
  * (mergeresultsbyset walks the set's members by key) and Matcher::compareHits' last criterion use keys */
 int sd_agg_set_keys(sd_agg *a, const uint32_t *qKeys, const uint32_t *tKeys);
+/* on != 0: a query's records arrive in the line order of its alignment DB entry and that order is not Matcher::compareHits order -- the
+ * merged result of `search --num-iterations` (mergedbs concatenates the iterations' lists, M/data/workflow/blastpgp.sh:106-117).
+ * besthitbyset keeps, per target set, the first line whose %.3E text E-value is strictly smaller than the one it holds
+ * (R/src/util/besthitbyset.cpp:88-101): among equal E-values the line of the earlier iteration.  Default (0): the compareHits minimum,
+ * which is the same line whenever the list is one sorted list (and does not depend on the order the records arrive in). */
+int sd_agg_set_list_order(sd_agg *a, int on);
 int sd_agg_finish(sd_agg *a, uint64_t *nEntries, uint64_t *nHits);
 int sd_agg_stats(sd_agg *a, uint64_t *nAligned, uint64_t *nAccepted);
 int sd_agg_get(sd_agg *a, uint64_t *entryOff, uint32_t *entryQSet, uint32_t *entryTSet, uint32_t *hitQ, uint32_t *hitT,

@@ -178,6 +178,7 @@ def load():
                                             C.c_char_p, _vp, C.c_char_p, _vp, C.c_char_p, _vp, C.c_int, C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]),
         'sd_agg_set_keys': (C.c_int, [_vp, _vp, _vp]),
+        'sd_agg_set_list_order': (C.c_int, [_vp, C.c_int]),
         'sd_host_matrix_text': (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
         'sd_host_sw_comp_bias': (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp]),
         'sd_host_can_be_covered': (C.c_int, [C.c_float, C.c_int, C.c_float, C.c_float]),

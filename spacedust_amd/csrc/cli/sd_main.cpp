@@ -6,7 +6,9 @@
 #include <omp.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 
 using namespace sdcli;
 
@@ -36,6 +38,17 @@ const Module kModules[] = {
 }  // namespace
 
 int main(int argc, const char **argv) {
+    // The host stages' OpenMP teams wait between parallel regions while a kernel runs or another stage has the CPUs; libgomp's default
+    // is to spin there (round 6, `clustersearch --num-iterations 3` on 4 query proteomes: 98 CPU-seconds inside 6.6 s of the alignment
+    // stage, 89 inside 5.8 s of result2profile -- sixteen threads spinning).  The policy is read when libgomp is loaded, i.e. before
+    // main: when the caller has not chosen one, choose the passive one and start over (spacedust_amd/cpus.py does the same for Python).
+    if (!getenv("OMP_WAIT_POLICY") && !getenv("GOMP_SPINCOUNT") && !getenv("SD_NO_REEXEC")) {
+        setenv("OMP_WAIT_POLICY", "passive", 1);
+        setenv("GOMP_SPINCOUNT", "0", 1);
+        setenv("SD_NO_REEXEC", "1", 1);
+        execv("/proc/self/exe", (char *const *) argv);
+        // (exec failed: go on with the default policy)
+    }
     if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
         printf("sdgpu: MI355X-native hot path of spacedust clustersearch --search-mode 0\n\nusage: sdgpu <module> <args>\n\n");
         for (const Module &m : kModules) printf("  %-18s %s\n", m.name, m.what);

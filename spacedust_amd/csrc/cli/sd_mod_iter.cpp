@@ -72,6 +72,7 @@ struct ChunkOut {
     bool done = false;
     double sec[8][IT_N];   // seconds per iteration and stage
     double cpu[8][IT_N];   // process CPU seconds in the same intervals
+    uint64_t cnt[8][4];    // per iteration: prefilter rows, rows left after the subtraction, pairs aligned, pairs accepted
 };
 
 struct Shared {
@@ -125,6 +126,7 @@ int processChunk(const Shared &S, Worker &W, uint32_t g0, uint32_t g1, ChunkOut 
     out.nq = nq;
     memset(out.sec, 0, sizeof(out.sec));
     memset(out.cpu, 0, sizeof(out.cpu));
+    memset(out.cnt, 0, sizeof(out.cnt));
     std::vector<std::vector<Rec> > acc(nq);
     std::string &pool = out.pool;
     pool.clear();
@@ -206,10 +208,12 @@ int processChunk(const Shared &S, Worker &W, uint32_t g0, uint32_t g1, ChunkOut 
             const uint32_t qKey = qdb.keys[g0 + q];
             const float qL = (float) qd.lens[base + q];
             const sd_hit *row = hits.data() + (size_t) q * Wd;
+            out.cnt[std::min(step, 7)][0] += counts[q];
             for (uint32_t x = 0; x < counts[q]; x++) {
                 const uint32_t tId = row[x].seqId;
                 if (prof && W.mark[tId] == W.stamp) continue;
                 out.prefHits++;
+                out.cnt[std::min(step, 7)][1]++;
                 // Util::canBeCovered pre-check (Alignment.cpp:370-373): a rejected pair, never aligned
                 const bool can = sd_host_can_be_covered(AS.canCovThr, AS.covMode, qL, (float) tdb.lens[tId]) != 0;
                 C.pq.push_back(q);
@@ -222,6 +226,8 @@ int processChunk(const Shared &S, Worker &W, uint32_t g0, uint32_t g1, ChunkOut 
         rc = alignChunkCore(W.ctx, W.host, AS, qd, tdb, S.tset, C, nullptr, &what);
         if (rc != SD_OK) return failChunk(out, rc, what, W.ctx);
         out.aligned += C.aligned;
+        out.cnt[std::min(step, 7)][2] += C.aligned;
+        out.cnt[std::min(step, 7)][3] += C.accepted;
         {
             uint64_t w = 0;
             for (uint32_t q = 0; q < nq; q++)
@@ -237,6 +243,21 @@ int processChunk(const Shared &S, Worker &W, uint32_t g0, uint32_t g1, ChunkOut 
                     acc[q].push_back(e);
                     out.accepted++;
                 }
+        }
+        if (const char *dq = getenv("SD_ITER_DEBUG_Q")) {   // the records of one query after this iteration (debugging aid)
+            for (const char *tok = dq; tok && *tok; tok = strchr(tok, ',') ? strchr(tok, ',') + 1 : nullptr) {
+            const long want = atol(tok);
+            if (want >= (long) g0 && want < (long) g1) {
+                const uint32_t q = (uint32_t) (want - g0);
+                FILE *df = getenv("SD_ITER_DEBUG_FILE") ? fopen(getenv("SD_ITER_DEBUG_FILE"), "a") : stderr;
+                if (!df) df = stderr;
+                fprintf(df, "[iter debug] query %ld after iteration %d: %zu records (rows %u)\n", want, step, acc[q].size(), counts[q]);
+                for (const Rec &e : acc[q])
+                    fprintf(df, "[iter debug]   t %u key %u ident %d score %d E %.4g q %d-%d t %d-%d bt %d\n", e.tId, tdb.keys[e.tId], (int) e.ident, e.r.score,
+                            e.r.evalue, e.r.qStart, e.r.qEnd, e.r.tStart, e.r.tEnd, e.r.btLen);
+                if (df != stderr) fclose(df);
+            }
+            }
         }
         out.sec[std::min(step, 7)][IT_ALIGN] += nowS() - t0;
         out.cpu[std::min(step, 7)][IT_ALIGN] += cpuS() - c0;
@@ -397,9 +418,9 @@ int iterativeClusterSearchInMemory(const Args &a, const std::string &Q, const st
     }
 
     // ---- workers: a context, a host object and a result2profile object each
-    int nWorkers = getenv("SD_ITER_WORKERS") ? atoi(getenv("SD_ITER_WORKERS")) : 3;
+    int nWorkers = getenv("SD_ITER_WORKERS") ? atoi(getenv("SD_ITER_WORKERS")) : 4;   // (1 000 target proteomes, 20 query proteomes, one box: 3 workers 491 - 496, 4 workers 501 - 504, 5 workers 454 genome-pairs/s; profiles/r06l_iter3_ab.txt)
     nWorkers = std::max(1, std::min(nWorkers, 8));
-    uint32_t chunkQ = (uint32_t) std::max<long long>(1, a.integer("--iter-chunk-queries", getenv("SD_ITER_CHUNK") ? atoi(getenv("SD_ITER_CHUNK")) : 2048));
+    uint32_t chunkQ = (uint32_t) std::max<long long>(1, a.integer("--iter-chunk-queries", getenv("SD_ITER_CHUNK") ? atoi(getenv("SD_ITER_CHUNK")) : 1500));
     // the host stages of a chunk run on an OpenMP team of its worker; the teams overlap each other's device phases, so together they
     // may ask for more threads than there are CPUs
     const int perWorker = std::max(1, std::min(threads, (threads * 3 / 2 + nWorkers - 1) / nWorkers));
@@ -457,16 +478,48 @@ int iterativeClusterSearchInMemory(const Args &a, const std::string &Q, const st
     S.tset = tg.s;
     const double tResident = nowS();
 
-    // ---- chunks: whole query proteins, a set's members in equal parts of at most chunkQ queries (a chunk never spans two sets'
-    // worth of work unevenly: sets are contiguous in a createsetdb DB)
-    std::vector<std::pair<uint32_t, uint32_t> > chunks;
+    // ---- groups and chunks.  A group is a query set (sets are contiguous id ranges in a createsetdb DB; a DB that is not laid out that
+    // way is one group): it has its own aggregation, finalised -- clusterhits, cluster records, its part of the TSV -- as soon as its
+    // last chunk has been added, on a thread of its own, while the workers are busy with the next sets.  Chunks are equal parts of a
+    // group of at most chunkQ queries.
+    struct Group {
+        uint32_t b = 0, e = 0;
+        size_t firstChunk = 0, nChunks = 0;
+        sd_agg *agg = nullptr;
+    };
+    std::vector<Group> groups;
     {
-        const uint32_t n = qdb->n;
+        bool contiguous = true;
+        for (uint32_t i = 1; i < qdb->n && contiguous; i++) contiguous = qv.setId[i] >= qv.setId[i - 1];
+        if (contiguous && qdb->n) {
+            uint32_t b0 = 0;
+            for (uint32_t i = 1; i <= qdb->n; i++)
+                if (i == qdb->n || qv.setId[i] != qv.setId[b0]) {
+                    Group g;
+                    g.b = b0;
+                    g.e = i;
+                    groups.push_back(g);
+                    b0 = i;
+                }
+        } else if (qdb->n) {
+            Group g;
+            g.e = qdb->n;
+            groups.push_back(g);
+        }
+    }
+    std::vector<std::pair<uint32_t, uint32_t> > chunks;
+    std::vector<size_t> groupOfChunk;
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        Group &g = groups[gi];
+        const uint32_t n = g.e - g.b;
         const uint32_t parts = (n + chunkQ - 1) / chunkQ;
-        uint32_t c0 = 0;
+        g.firstChunk = chunks.size();
+        g.nChunks = parts;
+        uint32_t c0 = g.b;
         for (uint32_t x = 0; x < parts; x++) {
             const uint32_t c1 = c0 + n / parts + (x < n % parts ? 1u : 0u);
             chunks.push_back(std::make_pair(c0, c1));
+            groupOfChunk.push_back(gi);
             c0 = c1;
         }
     }
@@ -512,81 +565,279 @@ int iterativeClusterSearchInMemory(const Args &a, const std::string &Q, const st
         }
     };
 
-    // ---- the aggregation takes the chunks in order while the workers go on
+    // ---- what the finalising thread needs, prepared while the workers run their first chunks: set sizes, the logGamma table of
+    // clusterhits (ClusterHits.cpp:259-271), the name tables of the TSV, a context of its own
     std::vector<int32_t> qLen(qdb->lens.begin(), qdb->lens.end()), tLen(tdb->lens.begin(), tdb->lens.end());
-    sd_agg *agg = nullptr;
     const double evalThr = strtod(eUser.c_str(), nullptr);
     const int covMode = (int) a.integer("--cov-mode", 0);
     const float covThr = (float) a.real("-c", 0.0);
     const int alnLenThr = (int) a.integer("--min-aln-len", 0);
     const int filterSelf = a.flag("--filter-self-match", false) ? 1 : 0;
-    int rc = sd_agg_create(qv.setId.data(), qLen.data(), qdb->n, tv.setId.data(), tLen.data(), tdb->n, qs.nSets, tsP->nSets, evalThr, covMode, covThr,
-                           alnLenThr, filterSelf, &agg);
-    struct AggG {
-        sd_agg *&a;
-        ~AggG() { if (a) sd_agg_destroy(a); }
-    } aggG{agg};
+    sd_ch_params ch;
+    memset(&ch, 0, sizeof(ch));
+    ch.maxGeneGap = (uint32_t) a.integer("--max-gene-gap", 3);
+    ch.clusterSize = (uint32_t) a.integer("--cluster-size", 2);
+    ch.alpha = a.real("--alpha", 1.0);
+    ch.pCluThr = (float) a.real("--cluster-pval", 0.01);
+    ch.pMHThr = (float) a.real("--multihit-pval", 0.01);
     std::string failure;
     uint64_t notComputed = 0, prefHits = 0, aligned = 0, accepted = 0, pfStats[5] = {0, 0, 0, 0, 0};
     double sec[8][IT_N], cpu[8][IT_N];
+    uint64_t cnt[8][4];
+    memset(cnt, 0, sizeof(cnt));
     memset(sec, 0, sizeof(sec));
     memset(cpu, 0, sizeof(cpu));
-    double tAgg = 0;
+    double tAgg = 0, tFinalize = 0;
+    uint64_t nEntriesAll = 0, nCluAll = 0, nCluLines = 0, nHitLines = 0;
+    double tSearched = 0;
+    struct CtxG {
+        sd_ctx *c = nullptr;
+        ~CtxG() { if (c) sd_ctx_destroy(c); }
+    } finCtx;
     {
         Join join{threadsV, failed, cv};
-        if (rc != SD_OK) return fail("sd_agg_create failed (" + std::to_string(rc) + ")");
-        sd_agg_set_keys(agg, qdb->keys.data(), tdb->keys.data());
-        for (size_t x = 0; x < chunks.size(); x++) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return outs[x]->done || failed.load(); });
-                if (!outs[x]->done) break;   // a worker failed on another chunk
+        if (sd_ctx_create(device, &finCtx.c) != SD_OK) return fail("sd_ctx_create failed");
+        std::vector<uint32_t> qSetSize(qs.nSets, 0), tSetSize(tsP->nSets, 0);
+        std::vector<double> lgamma;
+        {
+            for (uint32_t i = 0; i < qdb->n; i++)
+                if (qv.setId[i] < qs.nSets) qSetSize[qv.setId[i]]++;
+            uint32_t m = 0;
+            for (uint32_t i = 0; i < tdb->n; i++) {
+                if (tv.setId[i] < tsP->nSets) tSetSize[tv.setId[i]]++;
+                m = std::max(m, tv.pos[i]);
             }
-            ChunkOut &o = *outs[x];
-            if (o.rc != SD_OK) {
-                failure = o.err;
-                break;
-            }
+            for (uint32_t i = 0; i < qdb->n; i++) m = std::max(m, qv.pos[i]);
+            for (uint32_t v : qSetSize) m = std::max(m, v);
+            for (uint32_t v : tSetSize) m = std::max(m, v);
+            lgamma.resize((size_t) m + 8);
+            sd_host_lgamma_table(lgamma.data(), (uint32_t) lgamma.size());
+        }
+        std::string qn, tn, qsrc, tsrc;
+        std::vector<uint64_t> qno, tno, qso, tso;
+        {
+            std::vector<std::string> names(qdb->n);
+            for (uint32_t i = 0; i < qdb->n; i++) names[i] = qdb->keys[i] < qs.nameOfKey.size() ? qs.nameOfKey[qdb->keys[i]] : std::string();
+            packNames(names, qn, qno);
+            names.assign(tdb->n, std::string());
+            for (uint32_t i = 0; i < tdb->n; i++) names[i] = tdb->keys[i] < tsP->nameOfKey.size() ? tsP->nameOfKey[tdb->keys[i]] : std::string();
+            packNames(names, tn, tno);
+            packNames(qs.sourceOfSet, qsrc, qso);
+            packNames(tsP->sourceOfSet, tsrc, tso);
+        }
+        {   // the TSV exists (and is empty) whatever follows
+            uint64_t z0 = 0, z1 = 0;
+            if (sd_records_write_tsv(nullptr, 0, tsvPath.c_str(), 0, 0, qn.data(), qno.data(), tn.data(), tno.data(), qsrc.data(), qso.data(), tsrc.data(),
+                                     tso.data(), 0, &z0, &z1) != SD_OK)
+                return fail("cannot write " + tsvPath);
+        }
+        // besthitbyset ... combinehits are done when a group's last chunk is in its sd_agg; clusterhits and the group's part of the TSV
+        // (R/data/clustersearch.sh:141-151), groups in order (cluster keys run through the file)
+        std::string finError;
+        auto finalizeGroup = [&](sd_agg *agg) -> int {
             const double t0 = nowS();
-            if (!o.pq.empty()) {
-                rc = sd_agg_add(agg, (uint32_t) o.pq.size(), o.g0, o.pq.data(), o.pt.data(), o.res.data(), o.ident.data(), o.pool.data());
+            uint64_t ne = 0, nh = 0;
+            int rc = sd_agg_finish(agg, &ne, &nh);
+            if (rc != SD_OK) {
+                finError = "sd_agg_finish failed (" + std::to_string(rc) + ")";
+                return rc;
+            }
+            std::vector<uint64_t> entryOff(ne + 1, 0);
+            std::vector<uint32_t> entryQ(std::max<uint64_t>(ne, 1)), entryT(std::max<uint64_t>(ne, 1)), hitQ(std::max<uint64_t>(nh, 1)),
+                hitT(std::max<uint64_t>(nh, 1));
+            std::vector<double> pval(std::max<uint64_t>(nh, 1));
+            rc = sd_agg_get(agg, entryOff.data(), entryQ.data(), entryT.data(), hitQ.data(), hitT.data(), pval.data());
+            if (rc != SD_OK) {
+                finError = "sd_agg_get failed (" + std::to_string(rc) + ")";
+                return rc;
+            }
+            if (const char *dq = getenv("SD_ITER_DEBUG_Q")) {   // (debugging aid: what the aggregation kept of some queries)
+                for (const char *tok = dq; tok && *tok; tok = strchr(tok, ',') ? strchr(tok, ',') + 1 : nullptr) {
+                    const uint32_t want = (uint32_t) atol(tok);
+                    FILE *df = getenv("SD_ITER_DEBUG_FILE") ? fopen(getenv("SD_ITER_DEBUG_FILE"), "a") : stderr;
+                    if (!df) df = stderr;
+                    for (uint64_t e = 0; e < ne; e++)
+                        for (uint64_t h = entryOff[e]; h < entryOff[e + 1]; h++)
+                            if (hitQ[h] == want)
+                                fprintf(df, "[iter debug] aggregated: entry (%u, %u) hit %llu of %llu: q %u t %u (key %u) pval %.4g\n", entryQ[e], entryT[e],
+                                        (unsigned long long) (h - entryOff[e]), (unsigned long long) (entryOff[e + 1] - entryOff[e]), hitQ[h], hitT[h],
+                                        tdb->keys[hitT[h]], pval[h]);
+                    if (df != stderr) fclose(df);
+                }
+            }
+            std::vector<uint32_t> clusterOf(std::max<uint64_t>(nh, 1), UINT32_MAX), rank(std::max<uint64_t>(nh, 1), 0),
+                nClusters(std::max<uint64_t>(ne, 1), 0), cSize(std::max<uint64_t>(nh, 1), 0);
+            std::vector<double> pCO(std::max<uint64_t>(nh, 1), 0.0), pMH(std::max<uint64_t>(nh, 1), 0.0);
+            if (nh > 0) {
+                std::vector<uint32_t> qp(nh), tp(nh), nqOf(ne);
+                std::vector<uint8_t> sd(nh);
+                for (uint64_t h = 0; h < nh; h++) {
+                    qp[h] = qv.pos[hitQ[h]];
+                    tp[h] = tv.pos[hitT[h]];
+                    sd[h] = (uint8_t) (qv.strand[hitQ[h]] | (tv.strand[hitT[h]] << 1));
+                }
+                for (uint64_t e = 0; e < ne; e++) nqOf[e] = qSetSize[entryQ[e]];
+                rc = sd_clusterhits_batch(finCtx.c, &ch, (uint32_t) ne, entryOff.data(), qp.data(), tp.data(), sd.data(), pval.data(), nqOf.data(),
+                                          lgamma.data(), (uint32_t) lgamma.size(), clusterOf.data(), rank.data(), nClusters.data(), pCO.data(),
+                                          pMH.data(), cSize.data());
                 if (rc != SD_OK) {
-                    failure = "sd_agg_add failed (" + std::to_string(rc) + ")";
+                    finError = std::string("sd_clusterhits_batch failed (") + std::to_string(rc) + "): " + sd_last_error(finCtx.c);
+                    return rc;
+                }
+                for (uint64_t e = 0; e < ne; e++) nCluAll += nClusters[e];
+            }
+            nEntriesAll += ne;
+            std::vector<char> rec;
+            uint64_t need = 0;
+            rc = sd_agg_records(agg, clusterOf.data(), rank.data(), nClusters.data(), pCO.data(), pMH.data(), cSize.data(), nullptr, 0, &need);
+            if (rc == SD_OK) {
+                rec.resize(need);
+                rc = sd_agg_records(agg, clusterOf.data(), rank.data(), nClusters.data(), pCO.data(), pMH.data(), cSize.data(), rec.data(), need, &need);
+            }
+            if (rc != SD_OK) {
+                finError = "sd_agg_records failed (" + std::to_string(rc) + ")";
+                return rc;
+            }
+            uint64_t nc = 0, nhl = 0;
+            rc = sd_records_write_tsv(rec.data(), rec.size(), tsvPath.c_str(), 1, nCluLines, qn.data(), qno.data(), tn.data(), tno.data(), qsrc.data(),
+                                      qso.data(), tsrc.data(), tso.data(), 0, &nc, &nhl);
+            if (rc != SD_OK) {
+                finError = "sd_records_write_tsv failed (" + std::to_string(rc) + ")";
+                return rc;
+            }
+            nCluLines += nc;
+            nHitLines += nhl;
+            tFinalize += nowS() - t0;
+            return SD_OK;
+        };
+        // the finalising thread: groups in order
+        std::mutex fmu;
+        std::condition_variable fcv;
+        std::vector<sd_agg *> finQueue;
+        bool finClose = false;
+        int finStatus = SD_OK;
+        std::thread finThread([&] {
+            omp_set_num_threads(std::max(2, threads / 4));
+            size_t at = 0;
+            for (;;) {
+                sd_agg *agg = nullptr;
+                {
+                    std::unique_lock<std::mutex> lk(fmu);
+                    fcv.wait(lk, [&] { return at < finQueue.size() || finClose; });
+                    if (at >= finQueue.size()) return;
+                    agg = finQueue[at++];
+                }
+                if (finStatus == SD_OK) {
+                    const int rcF = finalizeGroup(agg);
+                    if (rcF != SD_OK) {
+                        finStatus = rcF;
+                        failed.store(1);
+                        cv.notify_all();
+                    }
+                }
+                sd_agg_destroy(agg);
+            }
+        });
+        struct FinJoin {
+            std::thread &t;
+            std::mutex &m;
+            std::condition_variable &c;
+            bool &close;
+            ~FinJoin() {
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    close = true;
+                }
+                c.notify_all();
+                if (t.joinable()) t.join();
+            }
+        };
+        {
+            FinJoin finJoin{finThread, fmu, fcv, finClose};
+            // ---- the aggregation takes the chunks in order while the workers go on
+            for (size_t x = 0; x < chunks.size(); x++) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return outs[x]->done || failed.load(); });
+                    if (!outs[x]->done) break;   // a worker (or the finalising thread) failed
+                }
+                ChunkOut &o = *outs[x];
+                if (o.rc != SD_OK) {
+                    failure = o.err;
                     break;
                 }
-            }
-            tAgg += nowS() - t0;
-            notComputed += o.notComputed;
-            if (o.notComputed && failure.empty() && notComputed == o.notComputed) fprintf(stderr, "sdgpu clustersearch: %s\n", o.err.c_str());
-            prefHits += o.prefHits;
-            aligned += o.aligned;
-            accepted += o.accepted;
-            for (int k = 0; k < 5; k++) pfStats[k] += o.pfStats[k];
-            for (int s = 0; s < 8; s++)
-                for (int k = 0; k < IT_N; k++) {
-                    sec[s][k] += o.sec[s][k];
-                    cpu[s][k] += o.cpu[s][k];
+                Group &g = groups[groupOfChunk[x]];
+                const double t0 = nowS();
+                if (!g.agg) {
+                    int rc = sd_agg_create(qv.setId.data(), qLen.data(), qdb->n, tv.setId.data(), tLen.data(), tdb->n, qs.nSets, tsP->nSets, evalThr, covMode,
+                                           covThr, alnLenThr, filterSelf, &g.agg);
+                    if (rc != SD_OK) {
+                        failure = "sd_agg_create failed (" + std::to_string(rc) + ")";
+                        break;
+                    }
+                    sd_agg_set_keys(g.agg, qdb->keys.data(), tdb->keys.data());
+                    sd_agg_set_list_order(g.agg, 1);   // a query's records are the lines of the merged alignment DB: iteration after iteration, each list sorted
                 }
-            outs[x].reset(new ChunkOut());   // the records are in the aggregation now
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                added = x + 1;
+                if (!o.pq.empty()) {
+                    const int rc = sd_agg_add(g.agg, (uint32_t) o.pq.size(), o.g0, o.pq.data(), o.pt.data(), o.res.data(), o.ident.data(), o.pool.data());
+                    if (rc != SD_OK) {
+                        failure = "sd_agg_add failed (" + std::to_string(rc) + ")";
+                        break;
+                    }
+                }
+                tAgg += nowS() - t0;
+                notComputed += o.notComputed;
+                if (o.notComputed && notComputed == o.notComputed) fprintf(stderr, "sdgpu clustersearch: %s\n", o.err.c_str());
+                prefHits += o.prefHits;
+                aligned += o.aligned;
+                accepted += o.accepted;
+                for (int k = 0; k < 5; k++) pfStats[k] += o.pfStats[k];
+                for (int s = 0; s < 8; s++)
+                    for (int k = 0; k < IT_N; k++) {
+                        sec[s][k] += o.sec[s][k];
+                        cpu[s][k] += o.cpu[s][k];
+                    }
+                for (int s = 0; s < 8; s++)
+                    for (int k = 0; k < 4; k++) cnt[s][k] += o.cnt[s][k];
+                outs[x].reset(new ChunkOut());   // the records are in the aggregation now
+                if (x + 1 == g.firstChunk + g.nChunks) {   // the group is complete: over to the finalising thread, which owns its sd_agg from here
+                    {
+                        std::lock_guard<std::mutex> lk(fmu);
+                        finQueue.push_back(g.agg);
+                    }
+                    g.agg = nullptr;
+                    fcv.notify_all();
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    added = x + 1;
+                }
+                cv.notify_all();
             }
-            cv.notify_all();
-        }
+            tSearched = nowS();
+        }   // (the finalising thread has written every complete group)
+        for (Group &g : groups)
+            if (g.agg) {
+                sd_agg_destroy(g.agg);
+                g.agg = nullptr;
+            }
+        if (failure.empty() && finStatus != SD_OK) failure = finError;
         if (failure.empty() && failed.load())
             for (auto &o : outs)
                 if (o && o->rc != SD_OK) {
                     failure = o->err;
                     break;
                 }
+        if (failure.empty() && failed.load()) failure = "a worker failed";
     }   // (workers joined)
     if (!failure.empty()) return fail(failure);
-    const double tSearched = nowS();
     for (int s = 0; s < std::min(numIt, 8); s++)
         info(a, "iteration %d: prefilter %.2f s | align %.2f s | result2profile %.2f s (summed over %d workers)%s\n", s, sec[s][IT_PREF], sec[s][IT_ALIGN],
              sec[s][IT_R2P], nWorkers,
              nWorkers == 1 ? (" | process CPU " + std::to_string(cpu[s][IT_PREF]) + " / " + std::to_string(cpu[s][IT_ALIGN]) + " / " + std::to_string(cpu[s][IT_R2P]) + " s").c_str() : "");
+    for (int s = 0; s < std::min(numIt, 8); s++)
+        info(a, "iteration %d: %llu prefilter rows, %llu after subtracting the aligned targets, %llu alignments calculated, %llu passed the thresholds\n", s,
+             (unsigned long long) cnt[s][0], (unsigned long long) cnt[s][1], (unsigned long long) cnt[s][2], (unsigned long long) cnt[s][3]);
     info(a, "%llu prefilter hits, %llu alignments calculated, %llu sequence pairs passed the thresholds\n", (unsigned long long) prefHits,
          (unsigned long long) aligned, (unsigned long long) accepted);
     info(a, "prefilter stats: kmers %llu index_hits %llu diagonals %llu diag_len %llu query_residues %llu\n", (unsigned long long) pfStats[0],
@@ -621,89 +872,15 @@ int iterativeClusterSearchInMemory(const Args &a, const std::string &Q, const st
         js += "}";
         fprintf(stderr, "[iter profile] %s\n", js.c_str());
     }
-
-    // ---- besthitbyset ... combinehits are done (sd_agg); clusterhits and the TSV (R/data/clustersearch.sh:141-151)
-    uint64_t ne = 0, nh = 0;
-    rc = sd_agg_finish(agg, &ne, &nh);
-    if (rc != SD_OK) return fail("sd_agg_finish failed (" + std::to_string(rc) + ")");
-    std::vector<uint64_t> entryOff(ne + 1, 0);
-    std::vector<uint32_t> entryQ(std::max<uint64_t>(ne, 1)), entryT(std::max<uint64_t>(ne, 1)), hitQ(std::max<uint64_t>(nh, 1)), hitT(std::max<uint64_t>(nh, 1));
-    std::vector<double> pval(std::max<uint64_t>(nh, 1));
-    rc = sd_agg_get(agg, entryOff.data(), entryQ.data(), entryT.data(), hitQ.data(), hitT.data(), pval.data());
-    if (rc != SD_OK) return fail("sd_agg_get failed (" + std::to_string(rc) + ")");
-    std::vector<uint32_t> clusterOf(std::max<uint64_t>(nh, 1), UINT32_MAX), rank(std::max<uint64_t>(nh, 1), 0), nClusters(std::max<uint64_t>(ne, 1), 0),
-        cSize(std::max<uint64_t>(nh, 1), 0);
-    std::vector<double> pCO(std::max<uint64_t>(nh, 1), 0.0), pMH(std::max<uint64_t>(nh, 1), 0.0);
-    uint64_t nClu = 0;
-    if (nh > 0) {
-        std::vector<uint32_t> qSetSize(qs.nSets, 0), tSetSize(tsP->nSets, 0);
-        for (uint32_t i = 0; i < qdb->n; i++)
-            if (qv.setId[i] < qs.nSets) qSetSize[qv.setId[i]]++;
-        uint32_t m = 0;
-        for (uint32_t i = 0; i < tdb->n; i++) {
-            if (tv.setId[i] < tsP->nSets) tSetSize[tv.setId[i]]++;
-            m = std::max(m, tv.pos[i]);
-        }
-        for (uint32_t i = 0; i < qdb->n; i++) m = std::max(m, qv.pos[i]);
-        for (uint32_t v : qSetSize) m = std::max(m, v);
-        for (uint32_t v : tSetSize) m = std::max(m, v);
-        std::vector<double> lgamma((size_t) m + 8);   // ClusterHits.cpp:259-271
-        sd_host_lgamma_table(lgamma.data(), (uint32_t) lgamma.size());
-        std::vector<uint32_t> qp(nh), tp(nh), nqOf(ne);
-        std::vector<uint8_t> sd(nh);
-        for (uint64_t h = 0; h < nh; h++) {
-            qp[h] = qv.pos[hitQ[h]];
-            tp[h] = tv.pos[hitT[h]];
-            sd[h] = (uint8_t) (qv.strand[hitQ[h]] | (tv.strand[hitT[h]] << 1));
-        }
-        for (uint64_t e = 0; e < ne; e++) nqOf[e] = qSetSize[entryQ[e]];
-        sd_ch_params ch;
-        memset(&ch, 0, sizeof(ch));
-        ch.maxGeneGap = (uint32_t) a.integer("--max-gene-gap", 3);
-        ch.clusterSize = (uint32_t) a.integer("--cluster-size", 2);
-        ch.alpha = a.real("--alpha", 1.0);
-        ch.pCluThr = (float) a.real("--cluster-pval", 0.01);
-        ch.pMHThr = (float) a.real("--multihit-pval", 0.01);
-        rc = sd_clusterhits_batch(workers[0]->ctx, &ch, (uint32_t) ne, entryOff.data(), qp.data(), tp.data(), sd.data(), pval.data(), nqOf.data(),
-                                  lgamma.data(), (uint32_t) lgamma.size(), clusterOf.data(), rank.data(), nClusters.data(), pCO.data(), pMH.data(),
-                                  cSize.data());
-        if (rc != SD_OK) return failCtx(workers[0]->ctx, rc, "sd_clusterhits_batch");
-        for (uint64_t e = 0; e < ne; e++) nClu += nClusters[e];
-    }
-    info(a, "%llu clusters from %llu set pairs\n", (unsigned long long) nClu, (unsigned long long) ne);
-    std::vector<char> rec;
-    {
-        uint64_t need = 0;
-        rc = sd_agg_records(agg, clusterOf.data(), rank.data(), nClusters.data(), pCO.data(), pMH.data(), cSize.data(), nullptr, 0, &need);
-        if (rc != SD_OK) return fail("sd_agg_records failed (" + std::to_string(rc) + ")");
-        rec.resize(need);
-        rc = sd_agg_records(agg, clusterOf.data(), rank.data(), nClusters.data(), pCO.data(), pMH.data(), cSize.data(), rec.data(), need, &need);
-        if (rc != SD_OK) return fail("sd_agg_records failed (" + std::to_string(rc) + ")");
-    }
-    std::string qn, tn, qsrc, tsrc;
-    std::vector<uint64_t> qno, tno, qso, tso;
-    {
-        std::vector<std::string> names(qdb->n);
-        for (uint32_t i = 0; i < qdb->n; i++) names[i] = qdb->keys[i] < qs.nameOfKey.size() ? qs.nameOfKey[qdb->keys[i]] : std::string();
-        packNames(names, qn, qno);
-        names.assign(tdb->n, std::string());
-        for (uint32_t i = 0; i < tdb->n; i++) names[i] = tdb->keys[i] < tsP->nameOfKey.size() ? tsP->nameOfKey[tdb->keys[i]] : std::string();
-        packNames(names, tn, tno);
-        packNames(qs.sourceOfSet, qsrc, qso);
-        packNames(tsP->sourceOfSet, tsrc, tso);
-    }
-    uint64_t nCluLines = 0, nHitLines = 0;
-    rc = sd_records_write_tsv(rec.data(), rec.size(), tsvPath.c_str(), 0, 0, qn.data(), qno.data(), tn.data(), tno.data(), qsrc.data(), qso.data(),
-                              tsrc.data(), tso.data(), 0, &nCluLines, &nHitLines);
-    if (rc != SD_OK) return fail("sd_records_write_tsv failed (" + std::to_string(rc) + ")");
     const double tEnd = nowS();
+    info(a, "%llu clusters from %llu set pairs\n", (unsigned long long) nCluAll, (unsigned long long) nEntriesAll);
     info(a, "%llu clusters with %llu hits written\n", (unsigned long long) nCluLines, (unsigned long long) nHitLines);
-    info(a, "in-memory iterations (%d workers, chunks of <= %u queries): load %.2f s | target resident %.2f s | iterations %.2f s (aggregation %.2f s "
-            "inside) | clusterhits + TSV %.2f s | total %.2f s\n",
-         nWorkers, chunkQ, tLoaded - tStart, tResident - tLoaded, tSearched - tResident, tAgg, tEnd - tSearched, tEnd - tStart);
+    info(a, "in-memory iterations (%d workers, chunks of <= %u queries, %zu query sets): load %.2f s | target resident %.2f s | iterations %.2f s (aggregation "
+            "%.2f s inside; clusterhits + TSV of the finished sets %.2f s beside them) | after the last chunk %.2f s | total %.2f s\n",
+         nWorkers, chunkQ, groups.size(), tLoaded - tStart, tResident - tLoaded, tSearched - tResident, tAgg, tFinalize, tEnd - tSearched, tEnd - tStart);
     if (getenv("SD_DEBUG_TIMING"))
-        fprintf(stderr, "[iter] load %.2f s | target resident %.2f s | iterations %.2f s (agg %.2f) | clusterhits + TSV %.2f s | total %.2f s\n",
-                tLoaded - tStart, tResident - tLoaded, tSearched - tResident, tAgg, tEnd - tSearched, tEnd - tStart);
+        fprintf(stderr, "[iter] load %.2f s | target resident %.2f s | iterations %.2f s (agg %.2f, finalise %.2f beside) | tail %.2f s | total %.2f s\n",
+                tLoaded - tStart, tResident - tLoaded, tSearched - tResident, tAgg, tFinalize, tEnd - tSearched, tEnd - tStart);
     if (notComputed)
         return fail(std::to_string(notComputed) + " queries need the reference's double-overflow route (or have >= 2^32 index hits) and were taken as "
                     "queries without rows; every other result is complete");

@@ -26,8 +26,7 @@
 // sort moves 12 B x 2 x 4 passes per record.
 #include "sd_common.h"
 
-#include <hipcub/hipcub.hpp>
-
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +35,9 @@
 #pragma clang fp contract(off)   // every fused multiply-add below is written out: the host build's contractions, no others
 
 namespace {
+
+// the radix sort of the (k-mer, record) pairs: this library's own kernels
+#include "sd_scan_sort.h"
 
 constexpr int TT_OFF = 50;       // maxCycleLength (Masker.cpp:20-32)
 constexpr int TT_SCALE = 16;     // rescaling period (tantan.cpp)
@@ -751,13 +753,7 @@ extern "C" int sd_target_build(sd_ctx *ctx, int kmerSize, int kmerThr, int mask,
         SD_HIP(ctx, dTileCount.alloc((bufN + IK_TILE - 1) / IK_TILE));
         SD_HIP(ctx, dTileBase.alloc((bufN + IK_TILE - 1) / IK_TILE));
         SD_HIP(ctx, dTot.alloc(1));
-        size_t tmpBytes = 0;
-        {
-            hipcub::DoubleBuffer<uint32_t> dk(k0.p, k1.p);
-            hipcub::DoubleBuffer<uint64_t> dv(v0.p, v1.p);
-            SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, dk, dv, (int) bufN, 0, 32, ctx->stream));
-        }
-        SD_HIP(ctx, dTmp.alloc(tmpBytes + 256));
+        SD_HIP(ctx, dTmp.alloc(sdRadixSortCountsBytes()));   // the radix sort's count matrix (sd_scan_sort.h)
         uint32_t bin = 0;
         while (bin < IB_COARSE_BINS) {
             uint32_t e = bin;
@@ -795,12 +791,21 @@ extern "C" int sd_target_build(sd_ctx *ctx, int kmerSize, int kmerThr, int mask,
             SD_HIP(ctx, hipGetLastError());
             int bits = 1;
             while (bits < 32 && (1ull << bits) < (uint64_t) (hi - lo)) bits++;
-            hipcub::DoubleBuffer<uint32_t> dk(k0.p, k1.p);
-            hipcub::DoubleBuffer<uint64_t> dv(v0.p, v1.p);
-            size_t tb = tmpBytes;
-            SD_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(dTmp.p, tb, dk, dv, (int) n, 0, bits, ctx->stream));
-            const uint32_t *sk = dk.Current();
-            const uint64_t *sv = dv.Current();
+            // stable LSD radix sort of (k-mer, record) pairs by the range's k-mer bits (sd_scan_sort.h, 8 bits per pass), ping-pong between
+            // the two buffer pairs: with an odd number of passes the input pair doubles as the scratch pair (it is read by the first pass
+            // only and first written by the second) and the result lands in (k1, v1), with an even number in (k0, v0)
+            const int passes = std::max(1, (bits + 7) / 8);
+            const uint32_t *sk;
+            const uint64_t *sv;
+            if (passes & 1) {
+                SD_HIP(ctx, sdRadixSortPairs<uint64_t>(ctx->stream, k0.p, v0.p, k1.p, v1.p, k0.p, v0.p, (uint32_t) n, 0, bits, (uint32_t *) dTmp.p));
+                sk = k1.p;
+                sv = v1.p;
+            } else {
+                SD_HIP(ctx, sdRadixSortPairs<uint64_t>(ctx->stream, k0.p, v0.p, k0.p, v0.p, k1.p, v1.p, (uint32_t) n, 0, bits, (uint32_t *) dTmp.p));
+                sk = k0.p;
+                sv = v0.p;
+            }
             const unsigned tiles = (unsigned) ((n + IK_TILE - 1) / IK_TILE);
             hipLaunchKernelGGL(ib_keep_count, dim3(tiles), dim3(IK_NT), 0, ctx->stream, sk, sv, n, dTileCount.p);
             SD_HIP(ctx, hipGetLastError());

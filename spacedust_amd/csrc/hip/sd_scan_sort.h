@@ -1,5 +1,5 @@
-// Device-wide prefix scans and a stable LSD radix sort of (uint32 key, uint32 value) pairs -- this library's own (no hipCUB /
-// rocPRIM on the hot path).  Included by sd_prefilter.hip and sd_sw.hip inside their anonymous namespaces.
+// Device-wide prefix scans and a stable LSD radix sort of (uint32 key, 32- or 64-bit value) pairs -- this library's own (no hipCUB /
+// rocPRIM anywhere in the tree).  Included by sd_prefilter.hip, sd_sw.hip and sd_index_build.hip inside their anonymous namespaces.
 //
 // Why not the library forms: the library's scan is a decoupled look-back (tiles spin on their predecessors) and its one-sweep
 // sort runs 1 024-thread workgroups that do the same; both are fine on an idle device and take milliseconds when three other
@@ -208,12 +208,18 @@ rs_prefix_kernel(uint32_t *__restrict__ counts, int rows) {
 // A tile is ranked wave by wave: element j of wavefront w is tile position w * 1024 + j * 64 + lane, so (w, j, lane) is input
 // order.  Inside a step the lanes with equal digits find each other with eight ballots (one per digit bit); the rank of a lane is
 // the wavefront's running count of its digit plus the number of equal lanes below it.
+template <typename V>   // value type: uint32_t (the prefilter's and the alignment stage's sorts) or uint64_t (the index build's records)
+struct RsPair {
+    uint32_t x;
+    V y;
+};
+template <typename V>
 __global__ void __launch_bounds__(RS_NT)
-rs_scatter_kernel(const uint32_t *__restrict__ kIn, const uint32_t *__restrict__ vIn, uint32_t n, int shift, uint32_t mask,
+rs_scatter_kernel(const uint32_t *__restrict__ kIn, const V *__restrict__ vIn, uint32_t n, int shift, uint32_t mask,
                   const uint32_t *__restrict__ starts /* [gridDim.x][RS_BINS] from rs_prefix_kernel */, uint32_t *__restrict__ kOut,
-                  uint32_t *__restrict__ vOut) {
+                  V *__restrict__ vOut) {
     constexpr int NW = RS_NT / 64;
-    __shared__ uint2 stage[RS_TILE];
+    __shared__ RsPair<V> stage[RS_TILE];
     __shared__ uint32_t wcnt[NW][RS_BINS];   // per wavefront: running count, then the wavefront's offset inside the digit
     __shared__ uint32_t binStart[RS_BINS];   // first staging slot of every digit
     __shared__ uint32_t cur[RS_BINS];        // this workgroup's next output position per digit
@@ -227,12 +233,13 @@ rs_scatter_kernel(const uint32_t *__restrict__ kIn, const uint32_t *__restrict__
         const uint32_t base = tile * RS_TILE;
         for (int x = t; x < NW * RS_BINS; x += RS_NT) (&wcnt[0][0])[x] = 0;
         __syncthreads();
-        uint32_t k[RS_PER], v[RS_PER], rank[RS_PER];
+        uint32_t k[RS_PER], rank[RS_PER];
+        V v[RS_PER];
 #pragma unroll
         for (int j = 0; j < RS_PER; j++) {
             const uint32_t i = base + (uint32_t) wv * (64 * RS_PER) + (uint32_t) j * 64 + (uint32_t) lane;
             k[j] = i < n ? kIn[i] : 0xFFFFFFFFu;
-            v[j] = i < n ? vIn[i] : 0u;
+            v[j] = i < n ? vIn[i] : (V) 0;
         }
 #pragma unroll
         for (int j = 0; j < RS_PER; j++) {
@@ -279,7 +286,7 @@ rs_scatter_kernel(const uint32_t *__restrict__ kIn, const uint32_t *__restrict__
             const uint32_t i = base + (uint32_t) wv * (64 * RS_PER) + (uint32_t) j * 64 + (uint32_t) lane;
             if (i < n) {
                 const uint32_t d = rsDigit(k[j], shift, mask);
-                stage[binStart[d] + wcnt[wv][d] + rank[j]] = make_uint2(k[j], v[j]);
+                stage[binStart[d] + wcnt[wv][d] + rank[j]] = RsPair<V>{k[j], v[j]};
             }
         }
         __syncthreads();
@@ -288,7 +295,7 @@ rs_scatter_kernel(const uint32_t *__restrict__ kIn, const uint32_t *__restrict__
         for (int j = 0; j < RS_PER; j++) {
             const uint32_t x = (uint32_t) j * RS_NT + (uint32_t) t;
             if (x < tn) {
-                const uint2 e = stage[x];
+                const RsPair<V> e = stage[x];
                 const uint32_t d = rsDigit(e.x, shift, mask);
                 const uint32_t p = cur[d] + (x - binStart[d]);
                 kOut[p] = e.x;
@@ -307,22 +314,25 @@ inline size_t sdRadixSortCountsBytes() { return (size_t) RS_WGS_MAX * RS_BINS * 
 
 // Sorts (stably) by key bits [beginBit, endBit).  The result lands in (kOut, vOut); (kTmp, vTmp) are scratch of n elements each
 // (distinct from the inputs, which are left untouched).  n < 2^32.
-inline hipError_t sdRadixSortPairs(hipStream_t stream, const uint32_t *kIn, const uint32_t *vIn, uint32_t *kOut, uint32_t *vOut, uint32_t *kTmp,
-                                   uint32_t *vTmp, uint32_t n, int beginBit, int endBit, uint32_t *counts) {
+template <typename V>
+inline hipError_t sdRadixSortPairs(hipStream_t stream, const uint32_t *kIn, const V *vIn, uint32_t *kOut, V *vOut, uint32_t *kTmp,
+                                   V *vTmp, uint32_t n, int beginBit, int endBit, uint32_t *counts) {
     if (n == 0) return hipSuccess;
     const int passes = std::max(1, (endBit - beginBit + 7) / 8);
     const uint32_t nTiles = (n + RS_TILE - 1) / RS_TILE;
     const unsigned wgs = (unsigned) std::min<uint32_t>(nTiles, RS_WGS_MAX);
-    const uint32_t *sk = kIn, *sv = vIn;
+    const uint32_t *sk = kIn;
+    const V *sv = vIn;
     for (int p = 0; p < passes; p++) {
         // the last pass writes (kOut, vOut): the passes before it alternate so that it does
-        uint32_t *dk = ((passes - 1 - p) & 1) ? kTmp : kOut, *dv = ((passes - 1 - p) & 1) ? vTmp : vOut;
+        uint32_t *dk = ((passes - 1 - p) & 1) ? kTmp : kOut;
+        V *dv = ((passes - 1 - p) & 1) ? vTmp : vOut;
         const int shift = beginBit + 8 * p;
         const int bits = std::min(8, endBit - shift);
         const uint32_t mask = bits >= 8 ? 0xFFu : ((1u << std::max(bits, 1)) - 1u);
         hipLaunchKernelGGL(rs_hist_kernel, dim3(wgs), dim3(RS_NT), 0, stream, sk, n, shift, mask, counts);
         hipLaunchKernelGGL(rs_prefix_kernel, dim3(1), dim3(RS_BINS), 0, stream, counts, (int) wgs);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(wgs), dim3(RS_NT), 0, stream, sk, sv, n, shift, mask, (const uint32_t *) counts, dk, dv);
+        hipLaunchKernelGGL(rs_scatter_kernel<V>, dim3(wgs), dim3(RS_NT), 0, stream, sk, sv, n, shift, mask, (const uint32_t *) counts, dk, dv);
         sk = dk;
         sv = dv;
     }

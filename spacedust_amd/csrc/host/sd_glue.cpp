@@ -176,6 +176,7 @@ struct sd_agg {
     int alnLenThr = 30;
     float seqIdThr = 0.0f;
     bool filterSelfMatch = true;
+    bool listOrder = false;   // sd_agg_set_list_order
     // after besthitbyset + combinehits filter: per worker thread, any order until finish()
     struct HitKey { uint64_t cell; uint32_t q, idx; };  // cell = qSet * nTSets + tSet (64 bit: 30 000 x 30 000 sets and more)
     std::vector<uint32_t> qDbKey, tDbKey;               // optional DB keys (sd_agg_set_keys): order inside entries, compareHits tie-break
@@ -277,6 +278,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
         uint32_t key;   // DB key of the target (Matcher::compareHits' last criterion)
         uint32_t t;     // target index
         float seqId;
+        double teval;   // list-order mode: the value the E-value's %.3E text parses to
     };
     int tooLong = 0;
 #pragma omp parallel num_threads(T) reduction(+ : accepted) reduction(| : tooLong)
@@ -338,12 +340,17 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                 c.score = r.score;
                 accepted++;
                 const uint32_t ts = a->tSetOf[c.t];
+                c.teval = 0.0;
+                if (a->listOrder) {
+                    char txt[32];
+                    c.teval = quantise3E(c.eval, txt);
+                }
                 if (stamp[ts] != gen) {
                     stamp[ts] = gen;
                     slotOf[ts] = (uint32_t) slotBest.size();
                     slotBest.push_back(c);
                     slotSet.push_back(ts);
-                } else if (better(c, slotBest[slotOf[ts]])) {
+                } else if (a->listOrder ? c.teval < slotBest[slotOf[ts]].teval : better(c, slotBest[slotOf[ts]])) {
                     slotBest[slotOf[ts]] = c;
                 }
             }
@@ -449,6 +456,17 @@ int sd_agg_finish(sd_agg *a, uint64_t *nEntries, uint64_t *nHits) {
     a->entryOff.push_back(total);
     if (nEntries) *nEntries = a->entryQSet.size();
     if (nHits) *nHits = a->best.size();
+    return SD_OK;
+}
+
+// on != 0: the records of a query arrive in the order of the lines of its alignment DB entry, and that order is NOT Matcher::compareHits
+// order -- the merged result of an iterative search (mergedbs concatenates the iterations' sorted lists).  besthitbyset then keeps, per
+// target set, the first line whose %.3E text E-value is strictly smaller than what it holds (besthitbyset.cpp:88-101): among equal
+// E-values -- equal raw scores of one query -- the line of the EARLIER iteration, not the compareHits minimum.  (For one sorted list
+// the two rules pick the same line; the streaming pipeline hands its records over in device order and needs the default rule.)
+int sd_agg_set_list_order(sd_agg *a, int on) {
+    if (!a) return SD_EINVAL;
+    a->listOrder = on != 0;
     return SD_OK;
 }
 

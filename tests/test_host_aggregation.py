@@ -258,3 +258,43 @@ def test_aggregation_on_synthetic_records_equals_restatement(threads, monkeypatc
             members += 1
     assert p == len(raw) and members == nh
     L.sd_agg_destroy(agg)
+
+
+def test_aggregation_list_order_keeps_the_first_of_equal_evalues():
+    """sd_agg_set_list_order: the records of a query are the lines of a MERGED alignment DB (`search --num-iterations`: mergedbs
+    concatenates the iterations' sorted lists), and besthitbyset keeps the first line with a strictly smaller %.3E text E-value
+    (R/src/util/besthitbyset.cpp:88-101).  Two targets of one set with the same raw score have the same E-value: the default rule
+    (one sorted list, any arrival order) takes the compareHits minimum -- the shorter target --, the list-order rule the earlier line;
+    a strictly smaller E-value later in the list wins under both."""
+    L = _lib.load()
+    host = api.Host(1)
+    lengths = np.array([300, 400, 100, 250, 260], np.int32)   # query 0 is sequence 0; targets 1, 2, 3 in set 1, target 4 in set 2
+    set_of = np.array([0, 1, 1, 1, 2], np.uint32)
+    db_res = 10 ** 9
+
+    def rec(score, off):
+        r = _SwResult()
+        r.score, r.evalue, r.flags = score, host.evalue(db_res, score, 300), 0
+        r.qStart, r.qEnd, r.tStart, r.tEnd, r.btLen, r.identical, r.btOffset = 0, 279, 0, 279, 280, 150, off
+        return r
+
+    pool = b'M' * 280 + b' '
+    for targets, scores, want_default, want_list in (([1, 2], [200, 200], 2, 1),          # equal E-values: shorter target | earlier line
+                                                     ([1, 2, 3], [200, 200, 260], 3, 3),   # a strictly smaller E-value later in the list
+                                                     ([2, 1], [200, 200], 2, 2)):          # the earlier line is also the compareHits minimum
+        for list_order, want in ((0, want_default), (1, want_list)):
+            agg = C.c_void_p()
+            assert L.sd_agg_create(ptr(set_of[:1]), ptr(lengths[:1]), 1, ptr(set_of), ptr(lengths), 5, 1, 3, 10.0, 2, 0.8, 30, 1, C.byref(agg)) == 0
+            assert L.sd_agg_set_list_order(agg, list_order) == 0
+            n = len(targets)
+            recs = (_SwResult * n)(*[rec(s, 0) for s in scores])
+            pq, pt, ident = np.zeros(n, np.uint32), np.array(targets, np.uint32), np.zeros(n, np.uint8)
+            assert L.sd_agg_add(agg, n, 0, ptr(pq), ptr(pt), ptr(np.frombuffer(recs, np.uint8)), ptr(ident), C.c_char_p(pool)) == 0
+            ne, nh = C.c_uint64(), C.c_uint64()
+            assert L.sd_agg_finish(agg, C.byref(ne), C.byref(nh)) == 0
+            assert (ne.value, nh.value) == (1, 1)
+            e_off, e_q, e_t = np.zeros(2, np.uint64), np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+            h_q, h_t, h_p = np.zeros(1, np.uint32), np.zeros(1, np.uint32), np.zeros(1, np.float64)
+            assert L.sd_agg_get(agg, ptr(e_off), ptr(e_q), ptr(e_t), ptr(h_q), ptr(h_t), ptr(h_p)) == 0
+            assert (int(e_q[0]), int(e_t[0]), int(h_t[0])) == (0, 1, want), (targets, scores, list_order)
+            L.sd_agg_destroy(agg)

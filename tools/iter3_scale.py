@@ -159,6 +159,37 @@ def run(P=1000, q_sets=20, sample=32, threads=None, log=print, keep_dir=None, pa
                                        in_memory_line=tsv[first][:300] if first < len(tsv) else None, lines_only_in_chain=len(sc - sm),
                                        lines_only_in_memory_head=len(sm - sc),
                                        context_chain=[l[:200] for l in chain[max(0, first - 2):first + 3]], context_in_memory=[l[:200] for l in tsv[max(0, first - 2):first + 3]])
+            def entry_lines(lines, names):   # every line of the (query set, target set) entry `names`, clusters in file order
+                got, on = [], False
+                for l in lines:
+                    if l.startswith('#'):
+                        on = l.split('\t')[1:3] == names
+                    if on:
+                        got.append(l[:160])
+                return got
+            ref_line = chain[first] if chain[first].startswith('#') else next((chain[i] for i in range(first, -1, -1) if chain[i].startswith('#')), '#')
+            names = ref_line.split('\t')[1:3]
+            ec, em = entry_lines(chain, names), entry_lines(tsv[:len(chain) + 100000], names)
+            log('entry', names, 'chain:', len(ec), 'lines, in memory:', len(em), 'lines; same set of > lines:', sorted(l for l in ec if l[0] == '>') == sorted(l for l in em if l[0] == '>'))
+            hc, hm = set(l for l in ec if l[0] == '>'), set(l for l in em if l[0] == '>')
+            log('ONLY IN CHAIN\n' + ''.join(sorted(hc - hm)[:12]))
+            log('ONLY IN MEMORY\n' + ''.join(sorted(hm - hc)[:12]))
+            genes = set(l.split('\t')[0] for l in (hc ^ hm))
+            log('ALL LINES OF THOSE QUERY GENES, CHAIN\n' + ''.join(l for l in ec if l.split('\t')[0] in genes)[:3000])
+            log('ALL LINES OF THOSE QUERY GENES, IN MEMORY\n' + ''.join(l for l in em if l.split('\t')[0] in genes)[:3000])
+            # the chain's merged alignment DB lines of the first such query gene against that target set
+            try:
+                for g in sorted(genes):
+                    qkey = int(g[1:].split('_')[1]) + int(ps.set_start[int(g[2:7])])
+                    tset = int(names[1][1:6])
+                    for dbn in ('search/aln_0', 'search/aln_tmp_1', 'search/aln_tmp_2', 'result'):
+                        ent = _lines(_entries(os.path.join(tmp, dbn), [qkey])).get(qkey, [])
+                        log('CHAIN %s lines of query key %d against target set %d (%d lines in the entry)' % (dbn, qkey, tset, len(ent)))
+                        for w in ent:
+                            if int(ps.set_start[tset]) <= int(w[0]) < int(ps.set_start[tset + 1]):
+                                log('   ', '\t'.join(w)[:200])
+            except Exception as e_:
+                log('no result DB lines:', repr(e_))
             log('first difference', json.dumps({k: out['module_chain'][k] for k in ('first_difference_at_line', 'chain_line', 'in_memory_line', 'lines_only_in_chain', 'lines_only_in_memory_head', 'context_chain', 'context_in_memory')}, indent=1))
         nq = int(ps.set_start[parity_sets])
         if not (ref_available() and ref_r2p_available()):
