@@ -283,6 +283,8 @@ def measure(args, rank, local_rank, world, dist, torch):
                 ranges.append([a, e])
         return [tuple(r) for r in ranges], len(mine) * P
 
+    rec_buf = [None]   # a rank of an N > 1 run builds its records in the communicator's pinned buffer (set after the warm-up)
+
     def run_steps(step_ids):
         rngs, pairs = [], 0
         for x in step_ids:
@@ -291,15 +293,21 @@ def measure(args, rank, local_rank, world, dist, torch):
             pairs += n
         # every rank builds its ranges' cluster records inside the stream; a rank of an N > 1 run also copies them out for the gather,
         # a single rank leaves them in the result handles: N = 1 and N > 1 time the same work up to the hand-over
-        return pairs, cs.search_stream(db, rngs, same_db=True, want_records=True if dist is not None else 'build', arrays='last')   # (the parity leg reads the last range's arrays; every range's counters)
+        return pairs, cs.search_stream(db, rngs, same_db=True, want_records=True if dist is not None else ('build' if os.environ.get('SD_BENCH_RECORDS', '1') != '0' else False), arrays='last',
+                                       records_buffer=rec_buf[0])   # (the parity leg reads the last range's arrays; every range's counters)
 
+    warm_bytes = 0
     if args.warmup:
-        run_steps(list(range(args.warmup)))
+        _, w_outs = run_steps(list(range(args.warmup)))
+        if dist is not None and w_outs and w_outs[-1].get('records_all') is not None:
+            warm_bytes = int(len(w_outs[-1]['records_all']))
+        del w_outs
     for c_ in cs.contexts:
         c_.profile(True)
     for name in cs.stats:
         cs.stats[name] = 0
     comm = None
+    gather_out = None
     gather_how = 'none (single rank)'
     if dist is not None and not rehearsal:
         # the C ABI's RCCL seam; the communicator is set up before the timed region.  A failure here is a failed run.
@@ -310,6 +318,24 @@ def measure(args, rank, local_rank, world, dist, torch):
         dist.broadcast(uid, 0)
         comm = RcclGather(dev_index, world, rank, bytes(uid.cpu().numpy().tobytes()))
         gather_how = 'sd_gather_results (RCCL, C ABI): the cluster records of every rank to rank 0, which writes the TSV from the gathered buffer'
+        # pinned, pre-sized staging from the warm-up's record size (sd_comm_host_buffer): every rank builds its records in its send buffer,
+        # the root receives into its gather buffer -- no pageable staging, no allocation, no size probe inside the timed region
+        if warm_bytes and args.warmup:
+            est = int(warm_bytes / args.warmup * args.steps * 1.25) + (64 << 20)
+            szs = to_dev(torch.tensor([est], dtype=torch.int64))
+            dist.all_reduce(szs, op=dist.ReduceOp.MAX)   # (every rank the same size: the root's buffer is world x that)
+            est = int(szs.item())
+            try:
+                rec_buf[0] = comm.host_buffer(0, est)
+                gather_out = comm.host_buffer(1, est * world) if rank == 0 else np.zeros(0, np.uint8)
+                gather_how += '; pinned pre-sized staging (%d MB per rank)' % (est >> 20)
+            except Exception as e:   # (not enough pinned memory: the pageable path)
+                rec_buf[0], gather_out = None, None
+                gather_how += '; pageable staging (%r)' % (e,)
+            okf = to_dev(torch.tensor([1 if rec_buf[0] is not None else 0], dtype=torch.int64))
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)   # all ranks or none: the gather's calls are collective
+            if int(okf.item()) == 0:
+                rec_buf[0], gather_out = None, None
     elif dist is not None:
         gather_how = 'rehearsal on one GPU (RCCL refuses two ranks per device): the same records over torch.distributed / gloo'
     if dist is not None:
@@ -332,14 +358,16 @@ def measure(args, rank, local_rank, world, dist, torch):
     if dist is not None:
         # the one exchange of the path: every rank's cluster records to rank 0, which writes the result TSV from the gathered buffer
         recs = outs[-1]['records_all'] if outs else np.zeros(0, np.uint8)   # the ranges' records back to back in one buffer
+        t_g0 = time.time()
         if comm is not None:
-            gathered, gather_sizes = comm.gather_bytes(recs)
+            gathered, gather_sizes = comm.gather_bytes(recs, out=gather_out)
         else:
             from spacedust_amd.pipeline import gather_results
             parts = gather_results(np.frombuffer(np.concatenate([recs, np.zeros((-len(recs)) % 8, np.uint8)]).tobytes(), np.int64), dist)
             lens = gather_results(np.array([len(recs)], np.int64), dist)
             gather_sizes = np.array([int(l[0]) for l in lens], np.uint64)
             gathered = np.concatenate([np.asarray(p_, np.int64).view(np.uint8)[:int(n_)] for p_, n_ in zip(parts, gather_sizes)]) if rank == 0 else None
+        gather_s = time.time() - t_g0
     for c_ in cs.contexts:
         c_.synchronize()
     torch.cuda.synchronize()
@@ -550,6 +578,9 @@ def measure(args, rank, local_rank, world, dist, torch):
     }
     if gather_sizes is not None:
         res['gather'] = {'how': gather_how, 'bytes': int(gather_sizes.sum()), 'bytes_per_rank': [int(v) for v in gather_sizes],
+                         # the tail of the timed region: from the end of this rank's stream (its records are built) to the root holding all bytes
+                         'tail_s': round(gather_s, 3), 'tail_frac_of_timed_region': round(gather_s / dt_max, 4) if dt_max > 0 else None,
+                         'records_copy_s': round(float(outs[-1].get('records_copy_s', 0.0)), 3) if outs else None,
                          'payload': 'cluster records (sd_search_result_records): per cluster sets, P-values, members with alignment fields', 'tsv': tsv_info}
         res['multi_gpu_note'] = ('%s scaling over query sets; an 8-GPU curve exists only where the driver ran this command with --gpus 8'
                                  % ('strong (BASELINE configs[2] as written)' if args.strong else 'weak'))
@@ -714,6 +745,26 @@ def main():
         # indexed on the device, checked on a sample against the host builder, and searched for a short step; --max-seqs 2N = 20 000
         children['p10000'] = child('p10000', [sys.executable, os.path.abspath(__file__), '--record', '--proteomes', '10000', '--steps', str(args.p10000_steps),
                                               '--warmup', '1', '--batch', str(args.p10000_batch), '--chunk', str(args.p10000_chunk), '--no-children', '--no-cpu'])
+        # CPU figure and parity of this configuration: the reference's index of 3 * 10^7 sequences takes minutes to build on the host, so
+        # they are not re-measured inside this run -- they come from the run of tests/test_gpu_scale.py::test_config5_size_search_...
+        # (the same search against the reference classes on the GPU box, 44 queries and 300 alignments, and the seconds those
+        # reference calls took) kept under profiles/
+        c5 = children['p10000']
+        for fn in ('r06_scale_parity_p10000.json', 'r05_scale_parity_p10000.json'):
+            try:
+                sp = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+            except (OSError, ValueError):
+                continue
+            if isinstance(c5, dict) and 'value' in c5:
+                rc_, cores = sp.get('reference_cpu'), effective_cpus()
+                if rc_:
+                    c5['cpu_baseline'] = dict(value=rc_['genome_pairs_per_s_per_core'] * cores, unit='genome-pairs/s', cores=cores, kind='reference',
+                                              sample='profiles/%s: %s; one thread measured, scaled linearly to %d' % (fn, rc_['sample'], cores))
+                c5['parity_check'] = dict(source='profiles/%s (tests/test_gpu_scale.py on the GPU box, reference classes)' % fn,
+                                          queries=sp.get('prefilter_queries'), prefilter_rows=sp.get('prefilter_rows'),
+                                          prefilter_queries_mismatching=sp.get('prefilter_mismatch'), alignments=sp.get('alignments'),
+                                          alignments_mismatching=sp.get('alignment_mismatch'))
+            break
     if kids and not args.no_iter3 and _leg_allowed(children, 'iter3', t_start, args):
         # BASELINE configs[3]: `clustersearch --num-iterations 3` (sequence search, two profile searches) against 1 000 target
         # proteomes through the sdgpu binary: the iterations in memory (timed); the module chain over DB files on two query proteomes

@@ -599,6 +599,11 @@ typedef struct sd_comm sd_comm;
 int sd_comm_unique_id(char *out128);
 int sd_comm_init(int device, int nRanks, int rank, const char *uniqueId128, sd_comm **out);
 void sd_comm_destroy(sd_comm *c);
+/* A pinned host buffer owned by the communicator, with a device buffer of the same size behind it (both grow-only, freed by
+ * sd_comm_destroy; a larger request replaces the buffer: take the pointer again).  which = 0: this rank's records, 1: the gathered
+ * records on the root.  Records built in buffer 0 and gathered into buffer 1 cross the bus at its rate with no staging copy and no
+ * allocation inside sd_gather_results; any other host memory still works (the runtime stages it). */
+int sd_comm_host_buffer(sd_comm *c, int which, uint64_t bytes, void **ptr);
 const char *sd_comm_last_error(sd_comm *c);
 /* gatherv of byte records over RCCL: sizes[nRanks] receives every rank's byte count (on all ranks); on `root`, outOnRoot
  * (capacity outCap) receives the records concatenated in rank order and *outBytes their total.  The ranks agree on the

@@ -221,6 +221,7 @@ def load():
         'sd_comm_unique_id': (C.c_int, [C.c_char_p]),
         'sd_comm_init': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)]),
         'sd_comm_destroy': (None, [_vp]),
+        'sd_comm_host_buffer': (C.c_int, [_vp, C.c_int, C.c_uint64, C.POINTER(_vp)]),
         'sd_comm_last_error': (C.c_char_p, [_vp]),
         'sd_gather_results': (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
         'sd_tcp_connect': (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),

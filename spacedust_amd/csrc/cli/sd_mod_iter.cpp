@@ -438,6 +438,7 @@ int iterativeClusterSearchInMemory(const Args &a, const std::string &Q, const st
     }
     // ---- the target: both indexes (the sequence search's k-mer threshold; every k-mer for the profile searches,
     // Prefiltering.cpp:525-527) and the sequences, resident for the whole run
+    uint64_t indexEntries = 0;
     struct TargetG {
         sd_target *a = nullptr, *b = nullptr;
         sd_seqset *s = nullptr;
@@ -461,12 +462,14 @@ int iterativeClusterSearchInMemory(const Args &a, const std::string &Q, const st
         int rc = sd_target_build(c0, S.pfSeq.k, S.pfSeq.indexThr, S.pfSeq.mask ? 1 : 0, S.pfSeq.maskProb, tdb->residues.data(), tdb->offsets.data(),
                                  tdb->n, ratios, self, s2, i2, s3, i3, &tg.a, st);
         if (rc != SD_OK) return failCtx(c0, rc, "sd_target_build");
+        indexEntries = st[0];
         info(a, "Index table k-mer threshold: %d at k-mer size %d\nIndex statistics\nEntries:          %llu\n", S.pfSeq.kmerThr, S.pfSeq.k,
              (unsigned long long) st[0]);
         if (numIt > 1) {
             rc = sd_target_build(c0, S.pfProf.k, S.pfProf.indexThr, S.pfProf.mask ? 1 : 0, S.pfProf.maskProb, tdb->residues.data(), tdb->offsets.data(),
                                  tdb->n, ratios, self, s2, i2, s3, i3, &tg.b, st);
             if (rc != SD_OK) return failCtx(c0, rc, "sd_target_build (profile searches)");
+            indexEntries = std::max<uint64_t>(indexEntries, st[0]);
             info(a, "Index table k-mer threshold: %d at k-mer size %d (profile iterations: every k-mer indexed)\nEntries:          %llu\n",
                  S.pfProf.kmerThr, S.pfProf.k, (unsigned long long) st[0]);
         }
@@ -477,6 +480,22 @@ int iterativeClusterSearchInMemory(const Args &a, const std::string &Q, const st
     S.profTarget = tg.b;
     S.tset = tg.s;
     const double tResident = nowS();
+    // ---- how many of the workers the device's free memory allows.  A worker's largest workspace is the prefilter's hit stream: the
+    // profile iterations run the lookup path, whose sub-batches hold up to 2^30 hits at ~26 B each (a sub-batch of this chunk size may
+    // hold fewer: similar k-mers per query x the index's mean list length), next to the k-mer streams and the alignment buffers.
+    {
+        uint64_t freeB = 0, totalB = 0;
+        if (sd_device_memory(workers[0]->ctx, &freeB, &totalB) == SD_OK && totalB > 0) {
+            const double meanList = (double) indexEntries / 64000000.0;   // (k = 6: 6.4 * 10^7 k-mers)
+            const double hitsPerSubBatch = std::min((double) (1ull << 30), (double) chunkQ * 1.3e5 * std::max(meanList, 1.0));
+            const double perWorker = 26.0 * hitsPerSubBatch * 1.3 + 6e9;
+            const int fit = (int) std::max(1.0, std::floor(((double) freeB - 4e9) / perWorker));
+            if (fit < nWorkers) {
+                info(a, "%d of %d workers: %.0f GB of device memory free, ~%.0f GB per worker\n", fit, nWorkers, (double) freeB / 1e9, perWorker / 1e9);
+                nWorkers = fit;
+            }
+        }
+    }
 
     // ---- groups and chunks.  A group is a query set (sets are contiguous id ranges in a createsetdb DB; a DB that is not laid out that
     // way is one group): it has its own aggregation, finalised -- clusterhits, cluster records, its part of the TSV -- as soon as its

@@ -95,6 +95,24 @@ struct sd_comm {
     int nRanks = 1, rank = 0, device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    // staging kept between calls (grow-only): [0] this rank's records, [1] the gathered records (root) -- a pinned host buffer a caller
+    // can build its records in / read the gathered ones from (sd_comm_host_buffer), and the device buffer the exchange runs on
+    void *hostBuf[2] = {nullptr, nullptr};
+    uint64_t hostCap[2] = {0, 0};
+    char *devBuf[2] = {nullptr, nullptr};
+    uint64_t devCap[2] = {0, 0};
+    int ensureDev(int which, uint64_t bytes) {
+        if (devCap[which] >= bytes) return SD_OK;
+        if (devBuf[which]) (void) hipFree(devBuf[which]);
+        devBuf[which] = nullptr;
+        devCap[which] = 0;
+        if (hipMalloc((void **) &devBuf[which], bytes) != hipSuccess) {
+            (void) hipGetLastError();
+            return SD_ENOMEM;
+        }
+        devCap[which] = bytes;
+        return SD_OK;
+    }
 };
 
 extern "C" {
@@ -138,8 +156,39 @@ int sd_comm_init(int device, int nRanks, int rank, const char *uniqueId128, sd_c
     return SD_OK;
 }
 
+// A pinned host buffer owned by the communicator (freed by sd_comm_destroy; a larger request replaces it, so take the pointer again
+// after every call): which = 0 for this rank's records, 1 for the gathered records on the root.  A rank that builds its records in
+// buffer 0 and a root that receives into buffer 1 move them between host and device at the bus rate with no staging copy -- pageable
+// memory goes through the runtime's bounce buffers (a 32-GB gather of eight ranks: ~3 s on the root) and a fresh 32-GB array has to be
+// touched first.  The matching device buffer is allocated with it, so a gather inside a timed region allocates nothing.
+int sd_comm_host_buffer(sd_comm *c, int which, uint64_t bytes, void **ptr) {
+    if (!c || which < 0 || which > 1 || !ptr) return SD_EINVAL;
+    if (hipSetDevice(c->device) != hipSuccess) return SD_ENODEVICE;
+    if (c->hostCap[which] < bytes) {
+        if (c->hostBuf[which]) (void) hipHostFree(c->hostBuf[which]);
+        c->hostBuf[which] = nullptr;
+        c->hostCap[which] = 0;
+        if (bytes && hipHostMalloc(&c->hostBuf[which], bytes, hipHostMallocDefault) != hipSuccess) {
+            (void) hipGetLastError();
+            return SD_ENOMEM;
+        }
+        c->hostCap[which] = bytes;
+    }
+    if (bytes) {
+        const int rc = c->ensureDev(which, bytes);
+        if (rc != SD_OK) return rc;
+    }
+    *ptr = c->hostBuf[which];
+    return SD_OK;
+}
+
 void sd_comm_destroy(sd_comm *c) {
     if (!c) return;
+    (void) hipSetDevice(c->device);
+    for (int w = 0; w < 2; w++) {
+        if (c->hostBuf[w]) (void) hipHostFree(c->hostBuf[w]);
+        if (c->devBuf[w]) (void) hipFree(c->devBuf[w]);
+    }
     if (c->comm) rccl()->commDestroy(c->comm);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
@@ -158,7 +207,7 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
     };
     if (hipSetDevice(c->device) != hipSuccess) return SD_ENODEVICE;
     uint64_t *dSizes = nullptr;
-    char *dLocal = nullptr, *dAll = nullptr;
+    char *dLocal = nullptr, *dAll = nullptr;   // (the communicator's grow-only staging buffers: nothing here is freed per call)
     int status = SD_OK;
     do {
         if (hipMalloc((void **) &dSizes, sizeof(uint64_t) * ((size_t) c->nRanks + 1)) != hipSuccess) { status = SD_ENOMEM; break; }
@@ -179,10 +228,16 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
             capacity = true;
         }
         if (localStatus == SD_OK && nBytes) {
-            if (hipMalloc((void **) &dLocal, nBytes) != hipSuccess) localStatus = SD_ENOMEM;
-            else if (hipMemcpyAsync(dLocal, local, nBytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) localStatus = SD_EHIP;
+            if (c->ensureDev(0, nBytes) != SD_OK) localStatus = SD_ENOMEM;
+            else {
+                dLocal = c->devBuf[0];
+                if (hipMemcpyAsync(dLocal, local, nBytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) localStatus = SD_EHIP;
+            }
         }
-        if (localStatus == SD_OK && c->rank == root && total && hipMalloc((void **) &dAll, total) != hipSuccess) localStatus = SD_ENOMEM;
+        if (localStatus == SD_OK && c->rank == root && total) {
+            if (c->ensureDev(1, total) != SD_OK) localStatus = SD_ENOMEM;
+            else dAll = c->devBuf[1];
+        }
         (void) hipGetLastError();
         uint64_t mine = (uint64_t) (localStatus == SD_OK ? 0 : capacity ? 2 : 1);
         std::vector<uint64_t> all((size_t) c->nRanks, 0);
@@ -228,8 +283,6 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
         if (hipStreamSynchronize(c->stream) != hipSuccess && status == SD_OK) status = SD_EHIP;
     } while (false);
     if (dSizes) (void) hipFree(dSizes);
-    if (dLocal) (void) hipFree(dLocal);
-    if (dAll) (void) hipFree(dAll);
     return status;
 }
 

@@ -1878,6 +1878,166 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
     cLen[c] = (uint32_t) n;
 }
 
+// K5, cooperative form (round 6; sequence queries).  The one-thread-per-candidate kernel above walks a diagonal eight cells per step
+// with three 8-byte reads that belong to this lane alone: ~38 dependent steps per candidate, every read a request of its own (PMC:
+// 17.9 MB fetched per query for 4.4 MB of diagonals).  Here a candidate is scored by EIGHT lanes: per step the group reads 64
+// consecutive cells of the three byte streams (one 64-byte run each), every lane folds its eight cells into the summary of a clamped
+// running sum -- r' = max(0, r + s) is max-plus linear in r, so a block of cells is (T, E, P, B): total, the running score it leaves
+// when entered with 0, its maximal prefix sum, the best score inside when entered with 0; entering with r gives r_out = max(r + T, E),
+// best = max(r + P, B) -- and the eight summaries are composed in order by three shuffle steps (exact integer arithmetic: the same
+// score and length as the serial walk, bit for bit).  A candidate costs ceil(n / 64) steps instead of n / 8.  The diagonal itself
+// (binary searches over the k-mer stream and the index list: dependent reads) comes from a pass of its own with a thread per
+// candidate, diag_of_kernel, so that no lane of a group waits for it.  Sequences of 32 768 residues and more (computeLongScore)
+// keep the serial walk, done by the group's first lane.
+struct SdBlk {
+    int T, E, P, B;
+};
+__device__ __forceinline__ SdBlk sdBlkThen(const SdBlk &a, const SdBlk &b) {   // a's cells, then b's
+    SdBlk r;
+    r.T = a.T + b.T;
+    r.E = max(a.E + b.T, b.E);
+    r.P = max(a.P, a.T + b.P);
+    r.B = max(max(a.B, b.B), a.E + b.P);
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+diag_of_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint32_t *__restrict__ cVal, const DiagSrc ds, int tBits, uint32_t posMask,
+               uint16_t *__restrict__ cDiag) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nCand) return;
+    const uint32_t k = cKey[c];
+    cDiag[c] = diagOf(ds, k >> tBits, cVal[c] & posMask, k & ((1u << tBits) - 1));
+}
+
+__global__ void __launch_bounds__(256)
+score_diag_coop_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint16_t *__restrict__ cDiag, int tBits,
+                       const uint8_t *__restrict__ qRes, const uint64_t *__restrict__ qOff, const int8_t *__restrict__ diagBias,
+                       const uint8_t *__restrict__ tMasked, const uint64_t *__restrict__ tOff, const int8_t *__restrict__ mat,
+                       int32_t *__restrict__ cScore, uint32_t *__restrict__ cLen) {
+    __shared__ int8_t smat[441];
+    for (int x = threadIdx.x; x < 441; x += blockDim.x) smat[x] = mat[x];
+    __syncthreads();
+    const uint32_t c = blockIdx.x * 32u + (threadIdx.x >> 3);
+    const int sub = threadIdx.x & 7;
+    if (c >= nCand) return;   // (whole groups leave: the shuffles below stay inside a group)
+    const uint32_t k = cKey[c];
+    const uint32_t q = k >> tBits, sid = k & ((1u << tBits) - 1);
+    const uint16_t d16 = cDiag[c];
+    const int d = (int) (int16_t) d16;
+    const int qL = (int) (qOff[q + 1] - qOff[q]);
+    const int tL = (int) (tOff[sid + 1] - tOff[sid]);
+    const uint8_t *qs = qRes + qOff[q];
+    const int8_t *qb = diagBias + qOff[q];
+    const uint8_t *ts = tMasked + tOff[sid];
+    if (qL >= 32768 || tL >= 32768) {
+        // computeLongScore (UngappedAlignment.cpp:312-329), serial, by the group's first lane: every real diagonal the 16-bit one can stand for
+        if (sub != 0) return;
+        auto scoreOn = [&](int diagonal, unsigned dist, int &nOut) {
+            int n = 0, q0 = 0, t0 = 0;
+            if (diagonal >= 0 && dist < (unsigned) qL) {
+                n = min(tL, qL - (int) dist);
+                q0 = (int) dist;
+            } else if (diagonal < 0 && dist < (unsigned) tL) {
+                n = min(tL - (int) dist, qL);
+                t0 = (int) dist;
+            }
+            int score = 0, best = 0;
+            for (int x = 0; x < n; x++) {
+                score += (int) (int8_t) (smat[(int) qs[q0 + x] * 21 + ts[t0 + x]] + qb[q0 + x]);
+                score = score < 0 ? 0 : score;
+                best = score > best ? score : best;
+            }
+            nOut = n;
+            return best;
+        };
+        int n = 0, best = 0;
+        for (int dv = 1; dv <= 1 + tL / 32768; dv++) {
+            const int real = (int) d16 - dv * 65536;
+            int nn;
+            const int sc = scoreOn(real, (unsigned) abs(real), nn);
+            best = sc > best ? sc : best;
+            n += nn;
+        }
+        for (int dv = 0; dv <= qL / 65536; dv++) {
+            const int real = (int) d16 + dv * 65536;
+            int nn;
+            const int sc = scoreOn(real, (unsigned) abs(real), nn);
+            best = sc > best ? sc : best;
+            n += nn;
+        }
+        cScore[c] = best;
+        cLen[c] = (uint32_t) n;
+        return;
+    }
+    // computeSingelSequenceScores (UngappedAlignment.cpp:416-430) on the one real diagonal
+    const unsigned dist = (unsigned) (uint16_t) min((int) (uint16_t) (0 - d16), (int) (uint16_t) d16);
+    int n = 0, q0 = 0, t0 = 0;
+    if (d >= 0 && dist < (unsigned) qL) {
+        n = min(tL, qL - (int) dist);
+        q0 = (int) dist;
+    } else if (d < 0 && dist < (unsigned) tL) {
+        n = min(tL - (int) dist, qL);
+        t0 = (int) dist;
+    }
+    int run = 0, best = 0;   // the walk's state behind the chunks done so far (identical in the group's lanes)
+    for (int x0 = 0; x0 < n; x0 += 64) {
+        const int x = x0 + 8 * sub;
+        SdBlk b = {0, 0, 0, 0};
+        if (x + 8 <= n) {
+            unsigned long long wq, wb, wt;
+            __builtin_memcpy(&wq, qs + q0 + x, 8);
+            __builtin_memcpy(&wb, qb + q0 + x, 8);
+            __builtin_memcpy(&wt, ts + t0 + x, 8);
+            int sum = 0, r = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int qr = (int) ((wq >> (8 * j)) & 0xFFull), tr = (int) ((wt >> (8 * j)) & 0xFFull);
+                const int8_t bj = (int8_t) (uint8_t) ((wb >> (8 * j)) & 0xFFull);
+                const int sc = (int) (int8_t) (smat[qr * 21 + tr] + bj);
+                sum += sc;
+                r = max(0, r + sc);
+                b.P = j == 0 ? sum : max(b.P, sum);
+                b.B = max(b.B, r);
+            }
+            b.T = sum;
+            b.E = r;
+        } else if (x < n) {
+            int sum = 0, r = 0;
+            for (int j = 0; x + j < n; j++) {
+                const int sc = (int) (int8_t) (smat[(int) qs[q0 + x + j] * 21 + ts[t0 + x + j]] + qb[q0 + x + j]);
+                sum += sc;
+                r = max(0, r + sc);
+                b.P = j == 0 ? sum : max(b.P, sum);
+                b.B = max(b.B, r);
+            }
+            b.T = sum;
+            b.E = r;
+        }
+        // (a lane without cells holds the neutral block: T = E = B = 0, P = 0 -- entering with r >= 0 leaves r and a best of r, which the
+        // walk has already counted)
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            SdBlk o;
+            o.T = __shfl_down(b.T, off, 8);
+            o.E = __shfl_down(b.E, off, 8);
+            o.P = __shfl_down(b.P, off, 8);
+            o.B = __shfl_down(b.B, off, 8);
+            if ((sub & (2 * off - 1)) == 0) b = sdBlkThen(b, o);
+        }
+        b.T = __shfl(b.T, 0, 8);
+        b.E = __shfl(b.E, 0, 8);
+        b.P = __shfl(b.P, 0, 8);
+        b.B = __shfl(b.B, 0, 8);
+        best = max(best, max(run + b.P, b.B));
+        run = max(run + b.T, b.E);
+    }
+    if (sub == 0) {
+        cScore[c] = best;
+        cLen[c] = (uint32_t) n;
+    }
+}
+
 // K6: keep the first element holding the per-(query,target) maximum of min(255,score).
 // Queries whose hit buffer overflowed more than once (m >= 2 splits, parts 0..m): the reference merges the carried result list
 // with the new part's at every overflow from the second on -- back to front, so equal neighbouring diagonal bytes collapse onto
@@ -3603,9 +3763,24 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             }
             {
                 ProfScope ps(ctx, "prefilter_score_diag");
-                hipLaunchKernelGGL(score_diag_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p,
-                                   diagSrc, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p,
-                                   dProfAln, posMask);
+                // SD_PF_SCORE_COOP=1 (sequence queries): the diagonal of every candidate first (a thread each), then eight lanes per candidate
+                // down the diagonal (score_diag_coop_kernel).  Measured at 1 000 proteomes, interleaved in one process, identical rows
+                // (profiles/r06n_score_coop.txt): 41.3 ms per 8 192 queries with the one-thread-per-candidate kernel, 42.4 ms with this one --
+                // the walk is not what the kernel costs; the diagonal is (diagOf: the k-mer of the hit from the k-mer stream, its index list's
+                // start, the entry of the target: three dependent reads of a line each per candidate, 8.5 MB per query).  Off.
+                const bool coop = getenv("SD_PF_SCORE_COOP") && atoi(getenv("SD_PF_SCORE_COOP")) != 0;
+                if (coop && !dProfAln) {
+                    WsView<uint16_t> dCDiag(ctx, "pf.dCDiag");
+                    SD_HIP(ctx, dCDiag.alloc(nCand));
+                    hipLaunchKernelGGL(diag_of_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p, diagSrc, tBits,
+                                       posMask, dCDiag.p);
+                    hipLaunchKernelGGL(score_diag_coop_kernel, dim3(gridFor(nCand, 32)), dim3(256), 0, ctx->stream, nCand, dCKey.p,
+                                       (const uint16_t *) dCDiag.p, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p);
+                } else {
+                    hipLaunchKernelGGL(score_diag_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p,
+                                       diagSrc, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p,
+                                       dProfAln, posMask);
+                }
             }
             hipLaunchKernelGGL(cand_stats_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCLen.p, tBits,
                                (unsigned long long *) dStats.p);

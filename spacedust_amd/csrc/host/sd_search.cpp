@@ -792,11 +792,18 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
         std::shared_ptr<std::string> err;
     };
     std::vector<FinJob> finJobs;
+    static const bool finInline = getenv("SD_FIN_INLINE") && atoi(getenv("SD_FIN_INLINE")) != 0;   // A/B: finalise on the driving thread
     auto submitFinalize = [&](uint32_t r) {
         FinJob j;
         j.err.reset(new std::string());
         std::shared_ptr<std::string> e = j.err;
-        j.fut = finStage.submit([&finalize, r, e] { return finalize(r, e.get()); });
+        if (finInline) {
+            std::promise<int> pr;
+            j.fut = pr.get_future();
+            pr.set_value(finalize(r, e.get()));
+        } else {
+            j.fut = finStage.submit([&finalize, r, e] { return finalize(r, e.get()); });
+        }
         finJobs.push_back(std::move(j));
     };
     std::vector<std::pair<uint32_t, size_t> > toFinalize;   // (range, chunk whose aggregation must have finished)

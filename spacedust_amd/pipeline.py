@@ -197,7 +197,8 @@ class ClusterSearch:
         return self.search_stream(Q, [rng], same_db=same_db, chunk_queries=chunk_queries, tsv_paths=[tsv_path],
                                   canonical=canonical)[0]
 
-    def search_stream(self, Q, ranges, same_db=False, chunk_queries=None, tsv_paths=None, canonical=True, want_records=False, arrays='all'):
+    def search_stream(self, Q, ranges, same_db=False, chunk_queries=None, tsv_paths=None, canonical=True, want_records=False, arrays='all',
+                      records_buffer=None):
         """The workflow for several query ranges [a,b) of Q (whole query sets each), streamed through one pipeline
         (sd_search_stream): the prefilter of the next chunk -- of the same or of the next range -- overlaps the alignments
         of the current one.  Every range gets its own aggregation, clusterhits call and result record.  Returns the list
@@ -234,7 +235,13 @@ class ClusterSearch:
                 api._check(None, L.sd_search_result_records(C.c_void_p(handles[ri]), None, 0, C.byref(need)), 'sd_search_result_records')
                 sizes.append(int(need.value))
             rec_at = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-            records_all = np.empty(int(rec_at[-1]), np.uint8)
+            # records_buffer: where the caller wants them (a rank of a multi-GPU run: the communicator's pinned buffer, RcclGather.host_buffer(0, ...))
+            if records_buffer is not None and records_buffer.nbytes >= int(rec_at[-1]):
+                records_all = records_buffer[:int(rec_at[-1])]
+            else:
+                records_all = np.empty(int(rec_at[-1]), np.uint8)
+        rec_copy_s = 0.0   # seconds spent copying the records out of the result handles (behind the stream: part of a rank's hand-over)
+        import time as _time
         for ri in range(n):
             h = C.c_void_p(handles[ri])
             cnt = np.zeros(8, np.uint64)
@@ -246,7 +253,9 @@ class ClusterSearch:
                     records = records_all[int(rec_at[ri]):int(rec_at[ri + 1])]
                     if records.size:
                         need = C.c_uint64()
+                        t_c = _time.time()
                         api._check(None, L.sd_search_result_records(h, ptr(records), records.nbytes, C.byref(need)), 'sd_search_result_records')
+                        rec_copy_s += _time.time() - t_c
                 L.sd_search_result_destroy(h)
                 results.append(dict(records=records, entries=ne, matched_hits=nh, clusters=int(cnt[2]), cluster_hits=int(cnt[3]), aligned=int(cnt[4]),
                                     accepted=int(cnt[5]), prefilter_hits=int(cnt[6]), timing={}, cluster_out=None))
@@ -276,7 +285,9 @@ class ClusterSearch:
                 records = records_all[int(rec_at[ri]):int(rec_at[ri + 1])]
                 if records.size:
                     need = C.c_uint64()
+                    t_c = _time.time()
                     api._check(None, L.sd_search_result_records(h, ptr(records), records.nbytes, C.byref(need)), 'sd_search_result_records')
+                    rec_copy_s += _time.time() - t_c
             L.sd_search_result_destroy(h)
             results.append(dict(records=records, entries=ne, matched_hits=nh, clusters=int(cnt[2]), cluster_hits=int(cnt[3]), aligned=int(cnt[4]),
                                 accepted=int(cnt[5]), prefilter_hits=int(cnt[6]), timing={}, entry_q=eq[:ne], entry_t=et[:ne],
@@ -285,6 +296,7 @@ class ClusterSearch:
             d = tm1 - tm0
             results[-1]['timing'] = {name: float(d[i]) for i, name in enumerate(_TIME_NAMES) if i >= 2 and name != 'total'}
             results[-1]['timing']['total'] = float(tm1[11])
+            results[-1]['records_copy_s'] = rec_copy_s
             results[-1]['records_all'] = records_all   # (want_records) the ranges' records back to back; every result's 'records' is a view of it
         return results
 
@@ -351,15 +363,41 @@ class RcclGather:
         api._check(None, self.L.sd_comm_init(device, world, rank, unique_id, C.byref(h)), 'sd_comm_init')
         self.h = h
 
-    def gather_bytes(self, local, root=0):
-        """byte records of every rank -> (concatenated bytes in rank order, sizes per rank) on `root`, (None, sizes) elsewhere"""
+    def host_buffer(self, which, nbytes):
+        """a pinned host buffer of the communicator as a numpy uint8 view (sd_comm_host_buffer): which = 0 this rank's records (build them
+        in it: search_stream(records_buffer=...)), 1 the gathered records on the root (gather_bytes(out=...)).  The view is valid until the
+        next call for the same buffer with a larger size, or the communicator's end."""
+        p = C.c_void_p()
+        api._check(None, self.L.sd_comm_host_buffer(self.h, int(which), int(nbytes), C.byref(p)), 'sd_comm_host_buffer')
+        if not nbytes or not p.value:
+            return np.zeros(0, np.uint8)
+        return np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(p.value))
+
+    def gather_bytes(self, local, root=0, out=None):
+        """byte records of every rank -> (concatenated bytes in rank order, sizes per rank) on `root`, (None, sizes) elsewhere.
+        out (root; every rank must pass one or none alike -- the calls are collective): a buffer the gathered bytes land in when it is
+        large enough, e.g. host_buffer(1, ...): one exchange, no size probe, no fresh array"""
         rec = np.ascontiguousarray(local, np.uint8).reshape(-1)
         sizes = np.zeros(self.world, np.uint64)
         total = C.c_uint64()
+        if out is not None:
+            cap = out.nbytes if self.rank == root else 0
+            rc = self.L.sd_gather_results(self.h, ptr(rec) if rec.size else None, rec.nbytes, root, ptr(sizes), ptr(out) if cap else None, cap,
+                                          C.byref(total))
+            if rc == 0:
+                return (out[:int(total.value)] if self.rank == root else None), sizes
+            if rc != _lib.SD_ENOMEM:   # (SD_ENOMEM: the root's buffer was too small -- every rank saw that, nothing was exchanged: go on below)
+                raise _lib.SdError('sd_gather_results failed (%d): %s' % (rc, self.L.sd_comm_last_error(self.h).decode(errors='replace')))
+            out = np.empty(int(total.value) if self.rank == root else 0, np.uint8)
+            rc = self.L.sd_gather_results(self.h, ptr(rec) if rec.size else None, rec.nbytes, root, ptr(sizes), ptr(out) if out.size else None,
+                                          out.nbytes, C.byref(total))
+            if rc != 0:
+                raise _lib.SdError('sd_gather_results failed (%d): %s' % (rc, self.L.sd_comm_last_error(self.h).decode(errors='replace')))
+            return (out if self.rank == root else None), sizes
         out = np.zeros(0, np.uint8)
         rc = self.L.sd_gather_results(self.h, ptr(rec) if rec.size else None, rec.nbytes, root, ptr(sizes), None, 0, C.byref(total))
         if rc == _lib.SD_ENOMEM:   # size probe: every rank learns that the root needs room (nothing was exchanged)
-            out = np.zeros(int(total.value) if self.rank == root else 0, np.uint8)
+            out = np.empty(int(total.value) if self.rank == root else 0, np.uint8)
             rc = self.L.sd_gather_results(self.h, ptr(rec) if rec.size else None, rec.nbytes, root, ptr(sizes), ptr(out) if out.size else None,
                                           out.nbytes, C.byref(total))
         if rc != 0:

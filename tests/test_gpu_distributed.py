@@ -99,6 +99,23 @@ def test_rccl_gather_seam_single_rank(gpu):
     assert len(out) == 1 and out[0].size == 0
     raw, sizes = g.gather_bytes(np.arange(1001, dtype=np.uint8))
     assert raw.tolist() == (np.arange(1001) % 256).tolist() and sizes.tolist() == [1001]
+    # pinned, pre-sized staging (sd_comm_host_buffer): the records are built in the communicator's send buffer and gathered into its
+    # receive buffer -- one exchange, no size probe; a receive buffer that turns out too small falls back to the probe + fresh array
+    send = g.host_buffer(0, 1 << 20)
+    recv = g.host_buffer(1, 1 << 20)
+    assert send.nbytes == 1 << 20 and recv.nbytes == 1 << 20
+    rng = np.random.default_rng(5)
+    payload = rng.integers(0, 256, 700001, dtype=np.uint8)
+    send[:len(payload)] = payload
+    raw, sizes = g.gather_bytes(send[:len(payload)], out=recv)
+    assert sizes.tolist() == [len(payload)] and (raw == payload).all() and raw.ctypes.data == recv.ctypes.data   # landed in the pinned buffer itself
+    small = g.host_buffer(1, 1000)   # (no larger request: the same buffer, the view is 1 000 bytes long)
+    raw, sizes = g.gather_bytes(send[:len(payload)], out=small)
+    assert sizes.tolist() == [len(payload)] and (raw == payload).all()
+    big = g.host_buffer(0, 3 << 20)   # a larger request replaces the buffer
+    big[:5] = [1, 2, 3, 4, 5]
+    raw, _ = g.gather_bytes(big[:5], out=g.host_buffer(1, 1 << 20))
+    assert raw.tolist() == [1, 2, 3, 4, 5]
 
 
 def test_sdgpu_clustersearch_two_ranks_equal_one(gpu, tmp_path):

@@ -67,11 +67,16 @@ def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=pri
     log('ref index', round(time.time() - t0, 1))
     rpf = rix.prefilter(int(lens.max()) + 2, max_hits=max_hits)
     bad = 0
+    t_ref_pf, n_ref_pf = 0.0, 0   # seconds inside the reference's QueryMatcher for the RANDOM queries (the longest ones are there for the overflow route)
     for x, q in enumerate(queries):
         if not_computed[x]:
             continue
         seq = blob[int(ps.offsets[q]):int(ps.offsets[q + 1])]
+        t1 = time.time()
         ids, sc, dg, _ = rpf.query(seq, int(q))
+        if x >= n_longest:
+            t_ref_pf += time.time() - t1
+            n_ref_pf += 1
         n = int(cnt[x])
         ok = n == len(ids) and (hits[x, :n]['seqId'] == ids).all() and (hits[x, :n]['score'] == sc).all() and \
             (hits[x, :n]['diagonal'] == dg).all()
@@ -98,13 +103,17 @@ def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=pri
     sw = RefSW(ref, int(lens.max()) + 2, db)
     badsw = 0
     last = -1
+    t_ref_sw, cells_ref_sw = 0.0, 0
     for i in range(len(pq)):
         if pq[i] != last:
             q = queries[pq[i]]
             sw.set_query(blob[int(ps.offsets[q]):int(ps.offsets[q + 1])])
             last = pq[i]
         t = pt[i]
+        t1 = time.time()
         r = sw.align(blob[int(ps.offsets[t]):int(ps.offsets[t + 1])], identity=bool(ident[i]))
+        t_ref_sw += time.time() - t1
+        cells_ref_sw += int(lens[queries[pq[i]]]) * int(lens[t])
         o = out[i]
         same = int(o['score']) == r['score'] and int(o['qEnd']) == r['qEnd'] and int(o['tEnd']) == r['tEnd'] and \
             int(o['btLen']) == r['btLen']
@@ -115,7 +124,20 @@ def run(P=1000, n_longest=12, n_random=120, aln_queries=30, aln_hits=40, log=pri
         if not same:
             badsw += 1
     log('alignments compared', len(pq), 'mismatching', badsw)
-    return dict(proteomes=P, targets=int(ps.n), k=k, kmer_thr=int(kmer_thr), target_residues=int(ps.offsets[-1]), index_entries=n_entries, max_hits=int(max_hits), index='device' if device_index else 'host',
+    # the reference's cost of one query at this size, one thread: its prefilter call, plus Smith-Waterman (score, ends, start, traceback
+    # as Matcher::getSWResult runs them) for the query's result list at the measured seconds per alignment of the sampled pairs
+    rows_per_query = float(cnt[n_longest:].mean()) if len(cnt) > n_longest else 0.0
+    ref_cpu = None
+    if n_ref_pf and len(pq):
+        s_pf, s_aln = t_ref_pf / n_ref_pf, t_ref_sw / len(pq)
+        s_query = s_pf + rows_per_query * s_aln
+        ref_cpu = dict(kind='reference', cores=1, prefilter_s_per_query=s_pf, sw_s_per_alignment=s_aln, sw_gcups_one_core=cells_ref_sw / t_ref_sw / 1e9,
+                       rows_per_query=rows_per_query, s_per_query=s_query, genome_pairs_per_s_per_core=1.0 / (s_query * ps.n / float(P * P)),
+                       sample='%d random queries through QueryMatcher (%.3f s each) and %d of their alignments through Matcher::getSWResult '
+                              '(%.4f s each) x %.0f result rows per query, one thread; clusterhits and the glue modules not included'
+                              % (n_ref_pf, s_pf, len(pq), s_aln, rows_per_query))
+        log('reference CPU at this size:', ref_cpu['sample'], '->', round(ref_cpu['genome_pairs_per_s_per_core'], 3), 'genome-pairs/s per core')
+    return dict(reference_cpu=ref_cpu, proteomes=P, targets=int(ps.n), k=k, kmer_thr=int(kmer_thr), target_residues=int(ps.offsets[-1]), index_entries=n_entries, max_hits=int(max_hits), index='device' if device_index else 'host',
                 not_computed=int(not_computed.sum()), prefilter_queries=int((~not_computed).sum()), prefilter_rows=int(cnt.sum()),
                 prefilter_mismatch=bad, alignments=len(pq), alignment_mismatch=badsw, bin_size=int(par.binSize),
                 max_index_hits=int(st[:, 1].max()))
