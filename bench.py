@@ -320,7 +320,7 @@ def measure(args, rank, local_rank, world, dist, torch):
         gather_how = 'sd_gather_results (RCCL, C ABI): the cluster records of every rank to rank 0, which writes the TSV from the gathered buffer'
         # pinned, pre-sized staging from the warm-up's record size (sd_comm_host_buffer): every rank builds its records in its send buffer,
         # the root receives into its gather buffer -- no pageable staging, no allocation, no size probe inside the timed region
-        if warm_bytes and args.warmup:
+        if args.warmup:   # (the same on every rank: what follows is collective)
             est = int(warm_bytes / args.warmup * args.steps * 1.25) + (64 << 20)
             szs = to_dev(torch.tensor([est], dtype=torch.int64))
             dist.all_reduce(szs, op=dist.ReduceOp.MAX)   # (every rank the same size: the root's buffer is world x that)
@@ -535,10 +535,8 @@ def measure(args, rank, local_rank, world, dist, torch):
         'config': {'workload_short': 'p%d: %d query proteomes per step vs %d targets, --max-seqs %d' % (P, B, P, max_seqs),
                    'workload': '%d synthetic proteomes x %d proteins (len~300) all-vs-all, clustersearch --search-mode 0 '
                                '--filter-self-match --max-seqs %d; step = %d query proteomes %s vs all %d targets; timed: search + aggregation + '
-                               'clusterhits (+ the result gather for N > 1); every range\'s entries, hits, P-values and clusters are complete in the library\'s result '
-                               'handles when the clock stops (the bench reads every range\'s counters and copies out the last range\'s arrays for the '
-                               'parity leg), the TSV is written after the timed region, the CPU leg likewise '
-                               'stops at the cluster records; results.evalue_pushdown = 1: alignments gated at combinehits\' E-value bound '
+                               'clusterhits + cluster records (+ the result gather for N > 1), complete in the library\'s result handles when the clock '
+                               'stops; the TSV is written after it; results.evalue_pushdown = 1: alignments gated at combinehits\' E-value bound '
                                '(1.2e-6) instead of -e 10, identical cluster hits (parity_check.entries_mismatching)'
                                % (P, args.genes, max_seqs, B, 'in total (strong scaling)' if args.strong else 'per rank', P),
                    'parallelism': 'whole query sets dealt to %d rank(s) by sd_shard_query_sets, target index replicated (%s), '
@@ -677,7 +675,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     import torch
     dist = None
-    if world > 1:
+    # SD_BENCH_FORCE_DIST=1: the N > 1 code path with one rank (communicator, pinned staging, the gather, the TSV from the gathered
+    # buffer) -- what a one-GPU box can exercise of it
+    if world > 1 or os.environ.get('SD_BENCH_FORCE_DIST') == '1':
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 2000))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         import torch.distributed as dist
         if os.environ.get('SD_BENCH_REHEARSAL') == '1':
             torch.cuda.set_device(0)
@@ -760,7 +764,7 @@ def main():
                 if rc_:
                     c5['cpu_baseline'] = dict(value=rc_['genome_pairs_per_s_per_core'] * cores, unit='genome-pairs/s', cores=cores, kind='reference',
                                               sample='profiles/%s: %s; one thread measured, scaled linearly to %d' % (fn, rc_['sample'], cores))
-                c5['parity_check'] = dict(source='profiles/%s (tests/test_gpu_scale.py on the GPU box, reference classes)' % fn,
+                c5['parity_check'] = dict(source='profiles/%s (tests/test_gpu_scale.py)' % fn,
                                           queries=sp.get('prefilter_queries'), prefilter_rows=sp.get('prefilter_rows'),
                                           prefilter_queries_mismatching=sp.get('prefilter_mismatch'), alignments=sp.get('alignments'),
                                           alignments_mismatching=sp.get('alignment_mismatch'))
@@ -822,14 +826,41 @@ def main():
         if k_ in res:
             line[k_] = res[k_]
     line['device_memory'] = {k_: round(v_, 1) for k_, v_ in res['device_memory'].items() if k_ != 'workspaces'}
+    # the driver reads the tail of stdout: the line stays below 8 KB -- the long notes live in the detail file only
+    if isinstance(line.get('cpu_baseline'), dict):
+        line['cpu_baseline'] = {k_: v_ for k_, v_ in line['cpu_baseline'].items() if k_ not in ('evalue_gate_note', 'sw_gcups_note')}
+    for k_ in ('note', 'dominant_by'):
+        if isinstance(line['roofline'].get(k_), str) and len(line['roofline'][k_]) > 90:
+            line['roofline'][k_] = line['roofline'][k_][:87] + '...'
+    if isinstance(line['roofline'].get('kernel_alone'), dict):
+        line['roofline']['kernel_alone'] = {k_: v_ for k_, v_ in line['roofline']['kernel_alone'].items() if k_ != 'note'}
+    line['roofline_sw'] = {k_: v_ for k_, v_ in line['roofline_sw'].items() if k_ != 'note'}
+    for k_ in ('index_check', 'parity_check'):
+        if isinstance(line.get(k_), dict):
+            line[k_] = {kk: vv for kk, vv in line[k_].items() if kk != 'against'}
     line['detail'] = detail_path if not os.path.isabs(detail_path) else os.path.relpath(detail_path, ROOT)
     if world == 1:
         for name in ('p100', 'p10000', 'iter3'):
             c_ = children.get(name)
             if name == 'iter3' and isinstance(c_, dict) and 'genome_pairs_per_s' in c_:
-                line[name] = {k_: c_.get(k_) for k_ in ('genome_pairs_per_s', 'wall_s', 'query_proteomes', 'target_proteomes', 'how', 'stages', 'kernel_ms_total', 'module_chain', 'cpu_baseline', 'gpu_over_cpu', 'parity_check', 'leg_wall_s') if k_ in c_}
+                b3 = {k_: c_.get(k_) for k_ in ('query_proteomes', 'target_proteomes', 'how', 'kernel_ms_by_stage') if k_ in c_}
+                b3.update(value=round(c_['genome_pairs_per_s'], 1), unit='genome-pairs/s', wall_s=round(c_['wall_s'], 2), leg_wall_s=round(c_.get('leg_wall_s') or 0.0, 1))
+                mc, cb3, rf3, pc3 = c_.get('module_chain') or {}, c_.get('cpu_baseline') or {}, c_.get('roofline') or {}, c_.get('parity_check') or {}
+                b3['module_chain'] = {k_: (round(v_, 1) if isinstance(v_, float) else v_) for k_, v_ in mc.items()
+                                      if k_ in ('query_proteomes', 'genome_pairs_per_s', 'tsv_lines', 'tsv_equals_head_of_in_memory_tsv')}
+                if cb3:
+                    b3.update(cpu_value=round(cb3['value'], 2), cpu_cores=cb3.get('cores'), cpu_kind=cb3.get('kind'), gpu_over_cpu=round(c_.get('gpu_over_cpu') or 0.0, 1))
+                if rf3:
+                    b3['roofline'] = dict(bound='hbm', stage='prefilter x 3', frac=round(rf3['frac'], 4), achieved=round(rf3['achieved'], 1), unit='GB/s',
+                                          kernel_ms=rf3['kernel_ms'], wall_frac=round(rf3.get('wall_frac') or 0.0, 4))
+                b3['parity'] = {k_: v_ for k_, v_ in pc3.items() if k_ not in ('against', 'seconds')}
+                line[name] = b3
             else:
                 line[name] = _brief(c_)
+    if len(json.dumps(line)) > 8000:   # (last resort: the per-stage walls and setup times are in the detail file as well)
+        for k_ in ('stage_wall_s', 'setup_s', 'host_cpu_by_stage', 'index_check'):
+            if len(json.dumps(line)) > 8000:
+                line.pop(k_, None)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -134,8 +134,25 @@ def run(P=1000, q_sets=20, sample=32, threads=None, log=print, keep_dir=None, pa
             if l.startswith('[iter profile] '):
                 try:
                     kern = json.loads(l[len('[iter profile] '):])
+                    kern = {k: v for k, v in kern.items() if not k.startswith('host:') and not k.startswith('stat.')}   # (host scopes and counters are not kernel times)
                     out['kernel_ms'] = {k: round(v[0], 1) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])[:14]}
                     out['kernel_ms_total'] = round(sum(v[0] for v in kern.values()), 1)
+                    by_stage = dict(prefilter=sum(v[0] for k, v in kern.items() if k.startswith('prefilter_')),
+                                    sw_score=sum(v[0] for k, v in kern.items() if k.startswith('sw_score')),
+                                    sw_traceback=sum(v[0] for k, v in kern.items() if k.startswith('sw_traceback')),
+                                    result2profile=sum(v[0] for k, v in kern.items() if k.startswith('r2p_')))
+                    out['kernel_ms_by_stage'] = {k: round(v, 1) for k, v in by_stage.items()}
+                    # the prefilter stage's roofline over the three iterations: SURVEY.md 8(d) bytes of the measured counters over the
+                    # event-timed duration of its kernels (several workers share the device: the sum of their kernels' times)
+                    st = next((l for l in r.stdout.splitlines() if l.startswith('prefilter stats:')), None)
+                    if st and by_stage['prefilter'] > 0:
+                        w = st.split()
+                        K, H, Cn, L, R = (int(w[i]) for i in (3, 5, 7, 9, 11))
+                        alg = 16 * K + 6 * H + 15 * Cn + L + 21 * R   # (+ 10 x the prefilter rows, not counted here)
+                        out['roofline'] = dict(bound='hbm', stage='prefilter (sequence + two profile searches)', algorithmic_bytes=alg,
+                                               kernel_ms=round(by_stage['prefilter'], 1), achieved=alg / by_stage['prefilter'] / 1e6, peak=8000.0,
+                                               unit='GB/s', frac=alg / by_stage['prefilter'] / 1e6 / 8000.0, kmers=K, index_hits=H,
+                                               wall_frac=alg / wall / 1e9 / 8000.0)
                 except ValueError:
                     pass
         log('clustersearch --num-iterations 3 (in memory):', round(wall, 1), 's,', out['hit_lines'], 'hits in', out['cluster_lines'], 'clusters')
