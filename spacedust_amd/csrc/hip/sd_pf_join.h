@@ -744,3 +744,39 @@ __device__ __forceinline__ uint16_t diagOf(const DiagSrc &S, uint32_t q, uint32_
     }
     return (uint16_t) (i - (int) S.entries[a].y);
 }
+
+// The same diagonal without the index (join path, k = 6).  A hit carries the low byte of its diagonal, d8 = (i - j) & 255, and its
+// k-mer ordinal; i follows from the ordinal as above, so the target position is j = (i - d8) mod 256 + 256 m.  With at most 256
+// k-mer positions left in the target behind the smallest candidate there is only that one (the hit exists); otherwise the candidates
+// are told apart by the k-mer itself, read from the target's own masked residues -- the lines the diagonal walk reads next anyway --
+// and the smallest position that holds the hit's k-mer is the indexed one (the index keeps a sequence's FIRST occurrence of a k-mer,
+// IndexTable.h:383-392, and that occurrence is in the residue class).  Against diagOf this drops the reads of the offset table and
+// of the entry list (a 128-byte line each per candidate) always, and the read of the k-mer stream for targets of up to 265 residues.
+__device__ __forceinline__ uint16_t diagFromResidues(const DiagSrc &S, uint32_t q, uint32_t ord, uint32_t sid, uint32_t d8,
+                                                     const uint8_t *__restrict__ ts /* the target's masked residues */, int tL) {
+    uint64_t lo = S.posBase[q], hi = S.posBase[q + 1];
+    const uint64_t p0 = lo, sidx = S.kmerBase[lo] + ord;
+    while (hi - lo > 1) {   // last position whose stream base is <= sidx
+        const uint64_t mid = (lo + hi) >> 1;
+        if (S.kmerBase[mid] <= sidx) lo = mid;
+        else hi = mid;
+    }
+    const int i = (int) (lo - p0);
+    const int jMax = tL - SPAN6;   // last k-mer position of the target
+    int j = (i - (int) d8) & 255;
+    if (j + 256 > jMax) return (uint16_t) (i - j);
+    const uint32_t km = (uint32_t) (S.elems[sidx] >> 38);
+    for (; j <= jMax; j += 256) {
+        uint32_t idx = 0, pw = 1;
+        bool x = false;
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            const uint32_t a = ts[j + c_seed6[p]];
+            x |= a >= 20u;
+            idx += a * pw;
+            pw *= 20u;
+        }
+        if (!x && idx == km) return (uint16_t) (i - j);
+    }
+    return diagOf(S, q, ord, sid);   // (not reached for a hit of the index these residues were indexed from)
+}

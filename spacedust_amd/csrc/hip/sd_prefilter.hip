@@ -1788,7 +1788,8 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
                   const uint8_t *__restrict__ tMasked, const uint64_t *__restrict__ tOff, const int8_t *__restrict__ mat,
                   int32_t *__restrict__ cScore, uint32_t *__restrict__ cLen,
                   const int8_t *__restrict__ qProf /* profile queries: [position][21] replaces matrix row + bias */,
-                  uint32_t posMask /* stream position bits of the value word: 2^24 - 1, all 32 with wide positions */) {
+                  uint32_t posMask /* stream position bits of the value word: 2^24 - 1, all 32 with wide positions */,
+                  int diagFromTarget /* join path: the diagonal from the target's residues (diagFromResidues) instead of the index */) {
     __shared__ int8_t smat[441];
     for (int x = threadIdx.x; x < 441; x += blockDim.x) smat[x] = mat[x];
     __syncthreads();
@@ -1796,10 +1797,11 @@ score_diag_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint3
     if (c >= nCand) return;
     const uint32_t k = cKey[c];
     const uint32_t q = k >> tBits, sid = k & ((1u << tBits) - 1);
-    const uint16_t d16 = diagOf(ds, q, cVal[c] & posMask, sid);
-    const int d = (int) (int16_t) d16;
     const int qL = (int) (qOff[q + 1] - qOff[q]);
     const int tL = (int) (tOff[sid + 1] - tOff[sid]);
+    const uint32_t cv = cVal[c];
+    const uint16_t d16 = diagFromTarget ? diagFromResidues(ds, q, cv & posMask, sid, cv >> 24, tMasked + tOff[sid], tL) : diagOf(ds, q, cv & posMask, sid);
+    const int d = (int) (int16_t) d16;
     const uint8_t *qs = qRes + qOff[q];
     const int8_t *qb = diagBias + qOff[q];
     const uint8_t *ts = tMasked + tOff[sid];
@@ -3777,9 +3779,12 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     hipLaunchKernelGGL(score_diag_coop_kernel, dim3(gridFor(nCand, 32)), dim3(256), 0, ctx->stream, nCand, dCKey.p,
                                        (const uint16_t *) dCDiag.p, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p);
                 } else {
+                    // the diagonal of a candidate from the target's residues (join path: 8-byte hits without a stored diagonal; k = 6 with
+                    // 24-bit ordinals beside the diagonal byte); SD_PF_DIAG_RES=0: from the index as before
+                    const int diagRes = (useJoin && T->k == 6 && posMask == 0xFFFFFFu && !(getenv("SD_PF_DIAG_RES") && atoi(getenv("SD_PF_DIAG_RES")) == 0)) ? 1 : 0;
                     hipLaunchKernelGGL(score_diag_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p,
                                        diagSrc, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p,
-                                       dProfAln, posMask);
+                                       dProfAln, posMask, diagRes);
                 }
             }
             hipLaunchKernelGGL(cand_stats_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCLen.p, tBits,
