@@ -3433,7 +3433,16 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     // level of the (cheap, streaming) split -- isolated prefilter at 1 000 proteomes 443 -> 390 ms per 8 192 queries, +4 % end
                     // to end; at 100 proteomes (1.5 * 10^5 hits per query) a split would only add its 24 B per hit (1 915 -> 1 767)
                     const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 200000;
-                    const uint64_t perVQsplit = getenv("SD_PF_COARSE") ? perVQ : 100000;
+                    // Round 6: ranges of at most 5 * 10^4 hits (SD_PF_COARSE_SPLIT; 10^5 until then) -- 32 ranges at 1 000 proteomes.  The filter's
+                    // Bloom filter then has twice the bits per key: 7.2 % of the hit stream left instead of 12.3 % (4.7 % at 2.5 * 10^4), and what
+                    // is left comes in segments the LDS sorter takes whole (segment_match) instead of through partition_hits / bucket_match.
+                    // Isolated, per 8 192 queries, interleaved in one process (profiles/r06y_split.txt): 328 ms at 10^5 (coarse split 69, filter
+                    // 74, partition + bucket + segment match 59), **315 ms at 5 * 10^4** (80 / 67 / 43), 323 ms at 2.5 * 10^4 (92 / 66 / 37: the
+                    // split's cost grows with its ranges).  Round 5 had measured finer ranges as a loss (388 - 442 vs 385 ms): the filter read
+                    // two arrays then and the split wrote them.  (Two more bitmaps in the filter -- a target must be hit twice to be nominated --
+                    // were tried on top and removed: 7.4 % left instead of 7.2 %, the kernel 8 ms slower; what passes the filter at this
+                    // granularity are targets that do have two hits on one diagonal byte, profiles/r06x_hf_multi.txt.)
+                    const uint64_t perVQsplit = getenv("SD_PF_COARSE") ? perVQ : (getenv("SD_PF_COARSE_SPLIT") ? (uint64_t) atoll(getenv("SD_PF_COARSE_SPLIT")) : 50000);
                     if (avgQ > perVQ)
                         while (cBits < CP_MAX_BITS && tBits0 - (cBits + 1) >= 8 && (avgQ >> cBits) > perVQsplit) cBits++;
                     // wide stream positions need the split: it is where the diagonal byte moves into the key (8 free bits)
