@@ -413,7 +413,9 @@ profile_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32
                      const uint64_t *__restrict__ kmerBase, uint32_t *__restrict__ kStart, uint32_t *__restrict__ kLen,
                      uint32_t *__restrict__ kPos, int *__restrict__ errFlag, uint32_t cap /* scratch entries per list */,
                      uint8_t *__restrict__ big /* per position: 1 = outgrew the small tier */, int bigTier,
-                     const uint64_t *__restrict__ blockBase /* nullable: wide index */, uint32_t *__restrict__ kStartHi) {
+                     const uint64_t *__restrict__ blockBase /* nullable: wide index */, uint32_t *__restrict__ kStartHi,
+                     uint64_t *__restrict__ joinElems /* EMIT, nullable: the k-mer-major join's stream element instead of the three lookup
+                                                         arrays (round 6: profile queries take the join, sd_pf_join.h) -- no index access here */) {
     __shared__ int16_t rowS[7][20];
     __shared__ uint8_t rowI[7][20];
     const int lane = threadIdx.x;
@@ -492,6 +494,12 @@ profile_kmers_kernel(uint64_t nPos, const uint64_t *__restrict__ posBase, uint32
                             listB[nB + excl + j] = make_uint2((uint32_t) (int) (short) (si + (int) rs[j]), ki + (uint32_t) ri[j] * mult);
                     } else if (EMIT) {
                         const uint64_t w = base + nB + excl;
+                        if (joinElems) {   // kmer << 38 | stream index << 8 | low byte of the query position (jpElem, sd_pf_join.h)
+                            for (uint32_t j = 0; j < c; j++) {
+                                const uint32_t kmer = ki + (uint32_t) ri[j] * mult;
+                                joinElems[w + j] = ((uint64_t) kmer << 38) | ((w + j) << 8) | (uint64_t) (i & 0xFF);
+                            }
+                        } else
                         for (uint32_t j = 0; j < c; j++) {
                             const uint32_t kmer = ki + (uint32_t) ri[j] * mult;
                             uint32_t s0, h0, l0;
@@ -3008,7 +3016,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         const bool useBuckets = getenv("SD_PF_SORT") == nullptr;
         int binBits = 0;
         while ((1u << binBits) < par->binSize) binBits++;
-        const bool joinCandidate = !forceLookup && T->k == 6 && T->dBlockBase == nullptr && !prof && useBuckets && bq <= (uint32_t) JQ_MAX &&
+        // (round 6: profile queries as well -- profile_kmers_kernel writes the join's stream elements; SD_PF_JOIN_PROFILE=0 keeps them on
+        // the lookup path)
+        const bool joinCandidate = !forceLookup && T->k == 6 && T->dBlockBase == nullptr && useBuckets && bq <= (uint32_t) JQ_MAX &&
+                                   (!prof || !(getenv("SD_PF_JOIN_PROFILE") && atoi(getenv("SD_PF_JOIN_PROFILE")) == 0)) &&
                                    tBits - binBits <= 20 && binBits <= 12 && !(getenv("SD_PF_JOIN") && atoi(getenv("SD_PF_JOIN")) == 0);
         WsView<uint32_t> dQKmerBase(ctx, "pf.dQKmerBase");
         WsView<int> dJoinFlag(ctx, "pf.dJoinFlag");
@@ -3040,7 +3051,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                        dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, dKmerCount.p,
                                        (const uint32_t *) nullptr, (const uint64_t *) nullptr, (uint32_t *) nullptr,
                                        (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p, PROFILE_PARTIAL_CAP, dProfBig.p, 0,
-                                       (const uint64_t *) nullptr, (uint32_t *) nullptr);
+                                       (const uint64_t *) nullptr, (uint32_t *) nullptr, (uint64_t *) nullptr);
                     int hTier = 0;
                     SD_HIP(ctx, sdD2H(ctx, &hTier, dErr.p, sizeof(int)));
                     SD_HIP(ctx, sdStreamSync(ctx));
@@ -3051,7 +3062,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                            bq, dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, dKmerCount.p,
                                            (const uint32_t *) nullptr, (const uint64_t *) nullptr, (uint32_t *) nullptr,
                                            (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p, PROFILE_PARTIAL_CAP_BIG, dProfBig.p, 1,
-                                           (const uint64_t *) nullptr, (uint32_t *) nullptr);
+                                           (const uint64_t *) nullptr, (uint32_t *) nullptr, (uint64_t *) nullptr);
                     }
                 } else if (T->k == 6)
                     hipLaunchKernelGGL(count_kmers_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
@@ -3108,12 +3119,12 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     hipLaunchKernelGGL(profile_kmers_kernel<true>, dim3(profGrid), dim3(64), 0, ctx->stream, nPos, dPosBase.p, bq,
                                        dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, (uint32_t *) nullptr,
                                        T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, dErr.p, PROFILE_PARTIAL_CAP, dProfBig.p, 0,
-                                       (const uint64_t *) T->dBlockBase, wideIdx ? dKStartHi.p : (uint32_t *) nullptr);
+                                       (const uint64_t *) T->dBlockBase, wideIdx ? dKStartHi.p : (uint32_t *) nullptr, (uint64_t *) nullptr);
                     if (profAnyBig)
                         hipLaunchKernelGGL(profile_kmers_kernel<true>, dim3(PROFILE_GRID_BIG), dim3(64), 0, ctx->stream, nPos, dPosBase.p,
                                            bq, dQ.p, dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, (uint32_t *) nullptr,
                                            T->dOffsets, dKmerBase.p, dKStart.p, dKLen.p, dKPos.p, dErr.p, PROFILE_PARTIAL_CAP_BIG,
-                                           dProfBig.p, 1, (const uint64_t *) T->dBlockBase, wideIdx ? dKStartHi.p : (uint32_t *) nullptr);
+                                           dProfBig.p, 1, (const uint64_t *) T->dBlockBase, wideIdx ? dKStartHi.p : (uint32_t *) nullptr, (uint64_t *) nullptr);
                 } else if (T->k == 6) {
                     if (wideIdx)
                         hipLaunchKernelGGL(emit_kmers_kernel<true>, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq,
@@ -3188,6 +3199,17 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             SD_HIP(ctx, dWgTotal.alloc(JJ_WGS));
             {
                 ProfScope ps(ctx, "prefilter_emit_kmers");
+                if (prof) {   // the per-position products again, this time writing the stream (the tiers the count pass chose)
+                    hipLaunchKernelGGL(profile_kmers_kernel<true>, dim3(profGrid), dim3(64), 0, ctx->stream, nPos, dPosBase.p, bq, dQ.p, dQOff.p, dPS.p,
+                                       dPI.p, par->kmerThr, T->k, dProfScratch.p, (uint32_t *) nullptr, (const uint32_t *) nullptr, dKmerBase.p,
+                                       (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p, PROFILE_PARTIAL_CAP, dProfBig.p, 0,
+                                       (const uint64_t *) nullptr, (uint32_t *) nullptr, dElems.p);
+                    if (profAnyBig)
+                        hipLaunchKernelGGL(profile_kmers_kernel<true>, dim3(PROFILE_GRID_BIG), dim3(64), 0, ctx->stream, nPos, dPosBase.p, bq, dQ.p,
+                                           dQOff.p, dPS.p, dPI.p, par->kmerThr, T->k, dProfScratch.p, (uint32_t *) nullptr, (const uint32_t *) nullptr,
+                                           dKmerBase.p, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, dErr.p,
+                                           PROFILE_PARTIAL_CAP_BIG, dProfBig.p, 1, (const uint64_t *) nullptr, (uint32_t *) nullptr, dElems.p);
+                } else
                 hipLaunchKernelGGL(emit_kmers_join_kernel, dim3(gridFor(nPos, 4)), dim3(256), 0, ctx->stream, nPos, dPosBase.p, bq, dQ.p,
                                    dQOff.p, dKB.p, par->kmerThr, T->dExt3Score, T->dExt3Index, dKmerBase.p, dElems.p, (const uint16_t *) T->dExt3Cum, T->ext3Lo,
                                    (const uint32_t *) dPosQuery.p);

@@ -12,6 +12,17 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
 
+@pytest.fixture(params=['join', 'lookup'])
+def profile_path(request, monkeypatch):
+    """profile queries through the k-mer-major join (default since round 6: profile_kmers_kernel writes the join's stream elements) and
+    through the per-k-mer lookup path (SD_PF_JOIN_PROFILE=0): the same rows and statistics either way"""
+    if request.param == 'lookup':
+        monkeypatch.setenv('SD_PF_JOIN_PROFILE', '0')
+    else:
+        monkeypatch.delenv('SD_PF_JOIN_PROFILE', raising=False)
+    return request.param
+
+
 def _golden(host):
     g = np.load(os.path.join(GOLD, 'profile_vectors.npz'))
     off = g['off']
@@ -23,7 +34,7 @@ def _golden(host):
     return g, res, off, prof
 
 
-def test_profile_prefilter_matches_reference(gpu, host):
+def test_profile_prefilter_matches_reference(gpu, host, profile_path):
     g, res, off, prof = _golden(host)
     assert host.profile_kmer_threshold(5.7, 6) == 99
     idx = host.build_index(res, off, 6, 0)   # profile searches index every non-X target k-mer (Prefiltering.cpp:525-527)
@@ -41,7 +52,7 @@ def test_profile_prefilter_matches_reference(gpu, host):
             assert (hits[q, :m]['diagonal'].astype(np.int64) == (exp[:, 3] & 0xFFFF)).all(), (thr, q)
 
 
-def test_profile_prefilter_matches_oracle_stats(gpu, host, oracle):
+def test_profile_prefilter_matches_oracle_stats(gpu, host, oracle, profile_path):
     """k-mer / index-hit / diagonal counts per query as well (the oracle is pinned to the reference for these inputs)"""
     g, res, off, prof = _golden(host)
     idx = host.build_index(res, off, 6, 0)
@@ -143,7 +154,7 @@ def test_profile_alignments_match_oracle_many(gpu, host, oracle, small_proteomes
     assert n_bt >= 40 and n_word >= 10, (n_bt, n_word)
 
 
-def test_profile_prefilter_large_kmer_lists(gpu, host, oracle):
+def test_profile_prefilter_large_kmer_lists(gpu, host, oracle, profile_path):
     """permissive threshold: > 10^5 similar k-mers per position on average, so positions leave the 65 536-entry scratch
     tier and are redone by the large tier; counts and hits against the oracle"""
     g, res, off, _ = _golden(host)
