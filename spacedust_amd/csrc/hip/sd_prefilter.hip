@@ -1913,11 +1913,14 @@ __device__ __forceinline__ SdBlk sdBlkThen(const SdBlk &a, const SdBlk &b) {   /
 
 __global__ void __launch_bounds__(256)
 diag_of_kernel(uint32_t nCand, const uint32_t *__restrict__ cKey, const uint32_t *__restrict__ cVal, const DiagSrc ds, int tBits, uint32_t posMask,
-               uint16_t *__restrict__ cDiag) {
+               uint16_t *__restrict__ cDiag, const uint8_t *__restrict__ tMasked, const uint64_t *__restrict__ tOff,
+               int diagFromTarget /* the diagonal from the target's residues (diagFromResidues) instead of the index */) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nCand) return;
-    const uint32_t k = cKey[c];
-    cDiag[c] = diagOf(ds, k >> tBits, cVal[c] & posMask, k & ((1u << tBits) - 1));
+    const uint32_t k = cKey[c], cv = cVal[c];
+    const uint32_t q = k >> tBits, sid = k & ((1u << tBits) - 1);
+    if (diagFromTarget) cDiag[c] = diagFromResidues(ds, q, cv & posMask, sid, cv >> 24, tMasked + tOff[sid], (int) (tOff[sid + 1] - tOff[sid]));
+    else cDiag[c] = diagOf(ds, q, cv & posMask, sid);
 }
 
 __global__ void __launch_bounds__(256)
@@ -3802,17 +3805,17 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 // the walk is not what the kernel costs; the diagonal is (diagOf: the k-mer of the hit from the k-mer stream, its index list's
                 // start, the entry of the target: three dependent reads of a line each per candidate, 8.5 MB per query).  Off.
                 const bool coop = getenv("SD_PF_SCORE_COOP") && atoi(getenv("SD_PF_SCORE_COOP")) != 0;
+                // the diagonal of a candidate from the target's residues (join path: 8-byte hits without a stored diagonal; k = 6 with
+                // 24-bit ordinals beside the diagonal byte); SD_PF_DIAG_RES=0: from the index as before
+                const int diagRes = (useJoin && T->k == 6 && posMask == 0xFFFFFFu && !(getenv("SD_PF_DIAG_RES") && atoi(getenv("SD_PF_DIAG_RES")) == 0)) ? 1 : 0;
                 if (coop && !dProfAln) {
                     WsView<uint16_t> dCDiag(ctx, "pf.dCDiag");
                     SD_HIP(ctx, dCDiag.alloc(nCand));
                     hipLaunchKernelGGL(diag_of_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p, diagSrc, tBits,
-                                       posMask, dCDiag.p);
+                                       posMask, dCDiag.p, (const uint8_t *) T->dMasked, (const uint64_t *) T->dSeqOff, diagRes);
                     hipLaunchKernelGGL(score_diag_coop_kernel, dim3(gridFor(nCand, 32)), dim3(256), 0, ctx->stream, nCand, dCKey.p,
                                        (const uint16_t *) dCDiag.p, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p);
                 } else {
-                    // the diagonal of a candidate from the target's residues (join path: 8-byte hits without a stored diagonal; k = 6 with
-                    // 24-bit ordinals beside the diagonal byte); SD_PF_DIAG_RES=0: from the index as before
-                    const int diagRes = (useJoin && T->k == 6 && posMask == 0xFFFFFFu && !(getenv("SD_PF_DIAG_RES") && atoi(getenv("SD_PF_DIAG_RES")) == 0)) ? 1 : 0;
                     hipLaunchKernelGGL(score_diag_kernel, dim3(gridFor(nCand, 256)), dim3(256), 0, ctx->stream, nCand, dCKey.p, dCVal.p,
                                        diagSrc, tBits, dQ.p, dQOff.p, dDB.p, T->dMasked, T->dSeqOff, dMat.p, dCScore.p, dCLen.p,
                                        dProfAln, posMask, diagRes);
