@@ -3551,6 +3551,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         else if (geo == 5) SD_HF(1024, 24576, 18);  // 128 KB, pass-B tiles of 4 096 hits
                         else if (geo == 6) hipLaunchKernelGGL((hot_filter_kernel<1024, 12288, 18, 8>), dim3(hfGrid), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV,
                                                               (uint32_t *) pKey, (uint32_t *) pVal, (uint2 *) pKV, widePos ? tBitsV : 0, minSeg, dHotCount.p);   // 48 + 32 KB: two workgroups per CU
+                        else if (geo == 8) hipLaunchKernelGGL((hot_filter_kernel<1024, 12288, 17, 8>), dim3(hfGrid), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV,
+                                                              (uint32_t *) pKey, (uint32_t *) pVal, (uint2 *) pKV, widePos ? tBitsV : 0, minSeg, dHotCount.p);   // 48 + 16 KB: two workgroups of 1 024 threads per CU (with SD_PF_HF_PERSIST=2)
                         else if (geo == 7) hipLaunchKernelGGL((hot_filter_kernel<1024, 16384, 17, 8>), dim3(hfGrid), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV,
                                                               (uint32_t *) pKey, (uint32_t *) pVal, (uint2 *) pKV, widePos ? tBitsV : 0, minSeg, dHotCount.p);   // 64 + 16 KB: two workgroups per CU
                         else hipLaunchKernelGGL((hot_filter_kernel<1024, 24576, 18, 8>), dim3(hfGrid), dim3(1024), 0, ctx->stream, nVQ, pHitBase, tBitsV,

@@ -369,6 +369,12 @@ def test_iterative_search_in_memory_equals_the_module_chain(work):
         assert p.returncode == 0, p.stderr[-600:]
         assert open(work / ('itm_%s.tsv' % tag)).read() == want, tag
         assert not os.path.exists(work / ('tmpitm_' + tag) / 'search' / 'aln_0') and not os.path.exists(work / ('tmpitm_' + tag) / 'result')
+    # two and four iterations: the first / middle / last alignment parameters (Search.cpp:484-505) in their places
+    for n_it in ('2', '4'):
+        it = ['--filter-self-match', '--num-iterations', n_it, '--threads', '8', '-v', '0']
+        sdgpu('clustersearch', g, g, work / ('itf_n%s.tsv' % n_it), work / ('tmpitf_n' + n_it), *it, '--keep-tmp', '1')
+        sdgpu('clustersearch', g, g, work / ('itm_n%s.tsv' % n_it), work / ('tmpitm_n' + n_it), *it)
+        assert open(work / ('itm_n%s.tsv' % n_it)).read() == open(work / ('itf_n%s.tsv' % n_it)).read(), n_it
     fa = example_fasta(work)
     q, t = work / 'q913i', work / 't915i'
     sdgpu('createsetdb', fa[0], q, work / 'tmpqi', '-v', '0')
