@@ -1132,62 +1132,98 @@ coarse_offsets_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
 // kernel moved 2.4 TB/s (32 wavefronts x 512 B per CU: a third of what the memory's latency asks for).  The order inside a range is not
 // kept anyway (see above).  KV / DIAG: the input layout and the wide-position form are compiled apart (one 8-byte load per hit, no
 // branches in the loop).
+// Round 6: the step's 2 048 hits are put in range order in LDS before they leave.  Written straight from the registers a wavefront's
+// store went to up to 64 different lines, and the address path takes them one line per clock: the PMC counters had the kernel
+// issue-stalled 65 % of its wave cycles (profiles/r07i_pmc_stalls.txt: SQ_WAIT_INST_ANY 1.65e11 of 2.52e11, not LDS).  Per step:
+// the lanes of a wavefront whose hits fall into one range find each other with cBits ballots (as before) and the first of them takes
+// the group's room in the step's per-range counters; a scan of the counters gives every range its place in the staging buffer and
+// its place in the segment's share of the output (the running cursors); the hits are written to the buffer, and then out slot by
+// slot -- 64 consecutive slots are 64 consecutive hits of one range (or of two): a store of one or two runs of lines.
+constexpr int CS_PER = 8;
+constexpr int CS_STEP = 256 * CS_PER;
 template <bool KV, bool DIAG>
 __device__ __forceinline__ void coarseScatterBody(uint64_t s, uint64_t e, uint64_t qs, uint32_t tMask, int shift, int cBits, uint32_t *cursor,
                                                   const uint32_t *__restrict__ inKey, const uint32_t *__restrict__ inVal,
-                                                  const uint2 *__restrict__ inKV, uint2 *__restrict__ outKV, const uint16_t *__restrict__ hitDiag) {
-    constexpr int CS_PER = 8;
+                                                  const uint2 *__restrict__ inKV, uint2 *__restrict__ outKV, const uint16_t *__restrict__ hitDiag,
+                                                  uint2 *stage /* [CS_STEP] */, uint8_t *stageRange /* [CS_STEP] */, uint32_t *cnt /* [C] */,
+                                                  uint32_t *rstart /* [C + 1] */, uint32_t *gbase /* [C] */) {
     const uint32_t lowMask = (1u << shift) - 1;
-    uint64_t i = s + threadIdx.x;
-    for (; i + (uint64_t) (CS_PER - 1) * 256 < e; i += (uint64_t) CS_PER * 256) {
+    const int C = 1 << cBits;
+    const int t = threadIdx.x, lane = t & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint64_t i0 = s; i0 < e; i0 += CS_STEP) {
+        if (t < C) cnt[t] = 0;
         uint32_t k[CS_PER], v[CS_PER], d[CS_PER];
+        bool live[CS_PER];
 #pragma unroll
         for (int u = 0; u < CS_PER; u++) {
-            const uint64_t x = i + (uint64_t) u * 256;
-            if (KV) {
-                const uint2 kv = inKV[x];
-                k[u] = kv.x;
-                v[u] = kv.y;
-            } else {
-                k[u] = inKey[x];
-                v[u] = inVal[x];
+            const uint64_t x = i0 + (uint64_t) u * 256 + (uint64_t) t;
+            live[u] = x < e;
+            k[u] = 0;
+            v[u] = 0;
+            d[u] = 0;
+            if (live[u]) {
+                if (KV) {
+                    const uint2 kv = inKV[x];
+                    k[u] = kv.x;
+                    v[u] = kv.y;
+                } else {
+                    k[u] = inKey[x];
+                    v[u] = inVal[x];
+                }
+                if (DIAG) d[u] = (uint32_t) hitDiag[x] & 0xFFu;
             }
-            d[u] = DIAG ? (uint32_t) hitDiag[x] & 0xFFu : 0u;
         }
-        // one cursor update per range and wavefront: the lanes whose hits fall into the same range find each other with cBits ballots,
-        // the first of them takes room for all (a wavefront's 64 returning atomics on 16 - 64 cursors were served one lane at a time)
-        uint32_t p[CS_PER];
-        const int lane = threadIdx.x & 63;
-        const unsigned long long below = (1ull << lane) - 1ull;
+        __syncthreads();   // the counters are cleared (and the previous step's staging buffer has been written out)
+        uint32_t p[CS_PER], r[CS_PER];
 #pragma unroll
         for (int u = 0; u < CS_PER; u++) {
-            const uint32_t r = (k[u] & tMask) >> shift;
-            unsigned long long same = __ballot(1);
-            for (int b = 0; b < cBits; b++) {
-                const bool bit = (r >> b) & 1u;
+            r[u] = (k[u] & tMask) >> shift;
+            unsigned long long same = __ballot(live[u]);
+            for (int bb = 0; bb < cBits; bb++) {
+                const bool bit = (r[u] >> bb) & 1u;
                 const unsigned long long with = __ballot(bit);
                 same &= bit ? with : ~with;
             }
-            const int leader = __ffsll((long long) same) - 1;
+            // (a dead lane's `same` is not a group it belongs to: it is its own leader and takes nothing)
+            const int leader = live[u] ? __ffsll((long long) same) - 1 : lane;
             uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&cursor[r], (uint32_t) __popcll(same));
+            if (live[u] && lane == leader) base = atomicAdd(&cnt[r[u]], (uint32_t) __popcll(same));
             p[u] = (uint32_t) __shfl((int) base, leader, 64) + (uint32_t) __popcll(same & below);
         }
+        __syncthreads();
+        if (t < 64) {   // one wavefront: where every range starts in the staging buffer, and in the output
+            uint32_t c = t < C ? cnt[t] : 0u, incl = c;
 #pragma unroll
-        for (int u = 0; u < CS_PER; u++) outKV[qs + p[u]] = make_uint2(DIAG ? (d[u] << shift) | (k[u] & lowMask) : k[u], v[u]);
-    }
-    for (; i < e; i += 256) {
-        uint32_t k, v;
-        if (KV) {
-            const uint2 kv = inKV[i];
-            k = kv.x;
-            v = kv.y;
-        } else {
-            k = inKey[i];
-            v = inVal[i];
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            if (t < C) {
+                rstart[t] = incl - c;
+                gbase[t] = cursor[t];
+                cursor[t] += c;
+            }
+            if (t == C - 1) rstart[C] = incl;
         }
-        const uint32_t p = atomicAdd(&cursor[(k & tMask) >> shift], 1u);
-        outKV[qs + p] = make_uint2(DIAG ? (((uint32_t) hitDiag[i] & 0xFFu) << shift) | (k & lowMask) : k, v);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CS_PER; u++)
+            if (live[u]) {
+                const uint32_t at = rstart[r[u]] + p[u];
+                stage[at] = make_uint2(DIAG ? (d[u] << shift) | (k[u] & lowMask) : k[u], v[u]);
+                stageRange[at] = (uint8_t) r[u];
+            }
+        __syncthreads();
+        const uint32_t n = rstart[C];
+#pragma unroll
+        for (int u = 0; u < CS_PER; u++) {
+            const uint32_t x = (uint32_t) u * 256 + (uint32_t) t;
+            if (x < n) {
+                const uint32_t rr = stageRange[x];
+                outKV[qs + gbase[rr] + (x - rstart[rr])] = stage[x];
+            }
+        }
     }
 }
 
@@ -1195,12 +1231,13 @@ __global__ void __launch_bounds__(256)
 coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const uint32_t *__restrict__ segBase, int tBits, int cBits,
                       const uint32_t *__restrict__ segOffset, const uint32_t *__restrict__ inKey,
                       const uint32_t *__restrict__ inVal, const uint2 *__restrict__ inKV,
-                      uint2 *__restrict__ outKV /* (key, value) pairs: one 8-byte store per hit -- a wavefront's 64 stores go to as many lines,
-                                                   and the address path takes them one line per clock: two 4-byte arrays were twice that */,
+                      uint2 *__restrict__ outKV /* (key, value) pairs: one 8-byte store per hit */,
                       const uint16_t *__restrict__ hitDiag /* wide stream positions: the diagonal byte goes into the key bits
                                                               above the virtual query's target bits (the range is implied
                                                               by the segment), nullptr otherwise */) {
-    __shared__ uint32_t cursor[1 << CP_MAX_BITS];
+    __shared__ uint32_t cursor[1 << CP_MAX_BITS], cnt[1 << CP_MAX_BITS], rstart[(1 << CP_MAX_BITS) + 1], gbase[1 << CP_MAX_BITS];
+    __shared__ uint2 stage[CS_STEP];
+    __shared__ uint8_t stageRange[CS_STEP];
     const uint32_t seg = blockIdx.x;
     const uint32_t q = cpQueryOfSeg(seg, nQ, segBase);
     const uint64_t qs = qHitBase[q];
@@ -1212,11 +1249,11 @@ coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
     const uint32_t tMask = (1u << tBits) - 1;
     const int shift = tBits - cBits;
     if (inKV) {
-        if (hitDiag) coarseScatterBody<true, true>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag);
-        else coarseScatterBody<true, false>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag);
+        if (hitDiag) coarseScatterBody<true, true>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
+        else coarseScatterBody<true, false>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
     } else {
-        if (hitDiag) coarseScatterBody<false, true>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag);
-        else coarseScatterBody<false, false>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag);
+        if (hitDiag) coarseScatterBody<false, true>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
+        else coarseScatterBody<false, false>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
     }
 }
 
