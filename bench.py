@@ -347,6 +347,7 @@ def measure(args, rank, local_rank, world, dist, torch):
         print('[bench] t=%.3f timed region starts' % time.monotonic(), file=sys.stderr)
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     thr0 = _thread_cpu_snapshot()
+    dl0 = cs.download_bytes()
     pairs_done, outs = run_steps([args.warmup + x for x in range(args.steps)])
     summary = np.zeros(4, np.int64)
     stage = {}
@@ -378,6 +379,7 @@ def measure(args, rank, local_rank, world, dist, torch):
         print('[bench] t=%.3f timed region ends' % time.monotonic(), file=sys.stderr)
     thr1 = _thread_cpu_snapshot()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    dl1 = cs.download_bytes()
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     if dist is not None:
         tmax = to_dev(torch.tensor([dt], dtype=torch.float64))
@@ -555,6 +557,9 @@ def measure(args, rank, local_rank, world, dist, torch):
         'kernels': kernels,
         'stage_wall_s': {k_: v_ for k_, v_ in stage.items() if not k_.startswith('cpu_')},
         'host_cpu_s_per_step': round(host_cpu_s / max(1, args.steps), 3),
+        # what the alignment lanes copy to the host per step: records + pair indices, and the backtrace pool (run-length text written on
+        # the device, sd_sw_set_cigar_pool; the letters were 780 MB per step)
+        'align_d2h_MB_per_step': {'records': round((dl1[0] - dl0[0]) / max(1, args.steps) / 1e6, 1), 'pool': round((dl1[1] - dl0[1]) / max(1, args.steps) / 1e6, 1)},
         # where the host CPU of a step goes: thread CPU seconds of the pipeline's stage threads (sd_search), the rest of the process's
         # CPU time (OpenMP workers of the host stages -- composition bias, accept / sort / text, aggregation --, HIP runtime threads)
         'host_cpu_by_stage': dict({k_[4:]: round(v_ / max(1, args.steps), 3) for k_, v_ in stage.items() if k_.startswith('cpu_')},
@@ -821,7 +826,7 @@ def main():
                                    'dtype', 'data', 'config')}
     line['roofline'] = rf
     line['roofline_sw'] = res['roofline_sw']
-    for k_ in ('sw_gcups', 'sw_gcups_fwd_plus_rev', 'sw_cells', 'prefilter', 'prefilter_queries_in_process', 'stage_wall_s', 'host_cpu_s_per_step', 'host_cpu_by_stage', 'results',
+    for k_ in ('sw_gcups', 'sw_gcups_fwd_plus_rev', 'sw_cells', 'prefilter', 'prefilter_queries_in_process', 'stage_wall_s', 'host_cpu_s_per_step', 'align_d2h_MB_per_step', 'host_cpu_by_stage', 'results',
                'setup_s', 'device', 'host_cores', 'host_cpu_quota', 'gather', 'multi_gpu_note', 'index_check', 'cpu_baseline', 'parity_check'):
         if k_ in res:
             line[k_] = res[k_]

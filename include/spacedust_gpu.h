@@ -103,7 +103,8 @@ typedef struct {
     int32_t qStart, qEnd, tStart, tEnd; /* -1 where the reference leaves them unset */
     int32_t identical;     /* identicalAACnt (0 when no backtrace) */
     int32_t btLen;         /* backtrace length (alnLength) */
-    int32_t flags;         /* bit0: word (int16) kernel semantics used; bit1: fwd/bwd mismatch */
+    int32_t flags;         /* bit0: word (int16) kernel semantics used; bit1: fwd/bwd mismatch; bits 8..: length of the run-length
+                            * text at btOffset after sd_sw_set_cigar_pool(ctx, 1), 0 otherwise */
     double evalue;         /* bit-exact EvalueComputation value when <= 2*evalThr (everything the reference can report);
                             * above that the device-evaluated value (same formula, relative error < 1e-12) */
     uint64_t btOffset;     /* offset of the expanded backtrace (chars M/I/D) in the pool */
@@ -154,6 +155,18 @@ int sd_sw_align_batch_best_by_group(sd_ctx *ctx, const sd_sw_params *par, const 
                                     uint32_t nPairs, const uint32_t *pairQ, const uint32_t *pairT, const uint16_t *pairDiag,
                                     const uint8_t *isIdentity, float seqIdThr, int32_t alnLenThr, uint32_t *outIdx, sd_sw_result *out,
                                     uint32_t *nOut, char *btPool, uint64_t btCap, uint64_t *btUsed);
+
+/* ---- Matcher::compressAlignment on the device (M/src/alignment/Matcher.cpp:166-185) -----------------------------------------------
+ * on != 0: the alignment calls of this context (sd_sw_align_batch, _compact, _compact_diag, _best_by_group) fill the pool with the
+ * run-length text of every returned backtrace ("57M2I103M"; "0M" first when a backtrace does not begin with a match, as the
+ * reference's state machine prints it) instead of its letters: btOffset is the start of the text, bits 8.. of `flags` its length
+ * (bits 0..7 keep their meaning), btLen stays the alignment length.  A protein alignment's text is about a tenth of its letters:
+ * what crosses PCIe per 12 000-query step at 1 000 proteomes falls from 780 MB to under 100 MB, and the host's compression pass
+ * (sd_host_compress_backtrace per record) is not run.  The pool must hold 2 bytes per backtrace letter in the worst case
+ * (SD_ENOMEM otherwise, as before).  sd_sw_download_bytes: bytes of records (+ indices) and of pool the context's alignment calls
+ * have copied to the host since it was created. */
+int sd_sw_set_cigar_pool(sd_ctx *ctx, int on);
+int sd_sw_download_bytes(sd_ctx *ctx, uint64_t *recordBytes, uint64_t *poolBytes);
 
 /* ---- self-test entry points of the library's own device primitives (csrc/hip/sd_scan_sort.h), for tests/ ----------------------
  * sd_selftest_sort_pairs: stable sort of (key, value) pairs by the key bits [beginBit, endBit) -- what the alignment task order and
@@ -385,6 +398,10 @@ int sd_agg_set_keys(sd_agg *a, const uint32_t *qKeys, const uint32_t *tKeys);
  * (R/src/util/besthitbyset.cpp:88-101): among equal E-values the line of the earlier iteration.  Default (0): the compareHits minimum,
  * which is the same line whenever the list is one sorted list (and does not depend on the order the records arrive in). */
 int sd_agg_set_list_order(sd_agg *a, int on);
+/* cigarText != 0: the pool handed to sd_agg_add holds, per record, the run-length text of its backtrace (Matcher::compressAlignment's
+ * output, M/src/alignment/Matcher.cpp:166-185) as the alignment calls return it after sd_sw_set_cigar_pool(ctx, 1) -- btOffset its
+ * start, flags >> 8 its length -- instead of the backtrace letters; the aggregation copies it where it used to compress.  Default 0. */
+int sd_agg_set_pool_form(sd_agg *a, int cigarText);
 int sd_agg_finish(sd_agg *a, uint64_t *nEntries, uint64_t *nHits);
 int sd_agg_stats(sd_agg *a, uint64_t *nAligned, uint64_t *nAccepted);
 int sd_agg_get(sd_agg *a, uint64_t *entryOff, uint32_t *entryQSet, uint32_t *entryTSet, uint32_t *hitQ, uint32_t *hitT,
@@ -585,6 +602,9 @@ void sd_search_result_destroy(sd_search_result *r);
  * seconds[16] = index build, upload, bias, prefilter, pair list, seqset, align, aggregate (waiting), aggregate (busy),
  * clusterhits, waiting for the prefilter, total of the last stream, 0... */
 int sd_search_stats(sd_search *s, uint64_t *stats, double *seconds);
+/* bytes the alignment lanes have copied to the host since create: records (+ pair indices), and backtrace pool -- letters, or
+ * run-length text when the stream's only consumer of backtraces is the aggregation (sd_sw_set_cigar_pool; SD_CIGAR_ON_DEVICE=0: letters) */
+int sd_search_download_bytes(sd_search *s, uint64_t *recordBytes, uint64_t *poolBytes);
 
 
 /* ---- multi-GPU seam: query sets sharded over the ranks, one RCCL gather at the end --------

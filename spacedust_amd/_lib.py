@@ -179,6 +179,7 @@ def load():
                                             C.POINTER(C.c_uint64)]),
         'sd_agg_set_keys': (C.c_int, [_vp, _vp, _vp]),
         'sd_agg_set_list_order': (C.c_int, [_vp, C.c_int]),
+        'sd_agg_set_pool_form': (C.c_int, [_vp, C.c_int]),
         'sd_host_matrix_text': (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
         'sd_host_sw_comp_bias': (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp]),
         'sd_host_can_be_covered': (C.c_int, [C.c_float, C.c_int, C.c_float, C.c_float]),
@@ -213,6 +214,9 @@ def load():
                                            C.c_char_p, _vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_search_result_destroy': (None, [_vp]),
         'sd_search_stats': (C.c_int, [_vp, _vp, _vp]),
+        'sd_search_download_bytes': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        'sd_sw_set_cigar_pool': (C.c_int, [_vp, C.c_int]),
+        'sd_sw_download_bytes': (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         'sd_r2p_create': (C.c_int, [C.POINTER(_vp)]),
         'sd_r2p_destroy': (None, [_vp]),
         'sd_r2p_batch': (C.c_int, [_vp, C.POINTER(R2pParams), C.c_uint32] + [_vp] * 12),

@@ -369,12 +369,23 @@ class Context:
             if rc == _lib.SD_ENOMEM and exact_cap is None:
                 ql = (queries.offsets[pq + 1] - queries.offsets[pq]).astype(np.int64)
                 tl = (targets.offsets[pt + 1] - targets.offsets[pt]).astype(np.int64)
-                exact_cap = bt_cap = int((ql + tl).sum()) + 64
+                exact_cap = bt_cap = (2 if getattr(self, '_cigar_pool', False) else 1) * int((ql + tl).sum()) + 64
                 continue
             _check(self.h, rc, 'sd_sw_align_batch')
             if compact:
                 return cidx[:n_out.value], res[:n_out.value], pool[:used.value]
             return res, pool[:used.value]
+
+    def set_cigar_pool(self, on=True):
+        """sd_sw_set_cigar_pool: the alignment calls return run-length text (Matcher::compressAlignment's output) in the pool;
+        a record's text is pool[btOffset : btOffset + (flags >> 8)]"""
+        _check(self.h, self.L.sd_sw_set_cigar_pool(self.h, 1 if on else 0), 'sd_sw_set_cigar_pool')
+        self._cigar_pool = bool(on)
+
+    def sw_download_bytes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.L.sd_sw_download_bytes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def sw_cells(self):
         f, r, t = C.c_uint64(), C.c_uint64(), C.c_uint64()

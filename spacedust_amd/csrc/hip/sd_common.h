@@ -33,6 +33,8 @@ struct sd_ctx {
     bool biasTablesUploaded = false;   // sd_comp_bias_batch: correction tables resident in this context's workspace
     hipEvent_t evSync = nullptr;   // blocking-sync event: host threads sleep while they wait for the stream (sdStreamSync)
     uint64_t cellsFwd = 0, cellsRev = 0, cellsTb = 0;
+    bool cigarPool = false;   // sd_sw_set_cigar_pool: the alignment calls return run-length text instead of backtrace letters
+    uint64_t d2hRecordBytes = 0, d2hPoolBytes = 0;   // what the alignment calls brought back (sd_sw_download_bytes)
     hipDeviceProp_t prop;
     // grow-only device workspace: hipMalloc/hipFree per call cost far more than the kernels they serve
     struct WsEntry { void *p = nullptr; size_t bytes = 0; };

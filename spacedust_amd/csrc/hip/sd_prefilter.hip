@@ -1086,6 +1086,8 @@ coarse_count_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const ui
     __syncthreads();
     const uint32_t tMask = (1u << tBits) - 1;
     const int shift = tBits - cBits;
+    // (one load per thread and iteration, one LDS atomic per lane: a version with 8 loads in flight and one atomic per group of
+    // lanes with the same range was 1.7 ms per 8 192 queries slower on the same box)
     for (uint64_t i = s + threadIdx.x; i < e; i += 256) atomicAdd(&hist[((inKV ? inKV[i].x : inKey[i]) & tMask) >> shift], 1u);
     __syncthreads();
     if (threadIdx.x < C) segCount[(size_t) seg * C + threadIdx.x] = hist[threadIdx.x];
@@ -1132,14 +1134,14 @@ coarse_offsets_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
 // kernel moved 2.4 TB/s (32 wavefronts x 512 B per CU: a third of what the memory's latency asks for).  The order inside a range is not
 // kept anyway (see above).  KV / DIAG: the input layout and the wide-position form are compiled apart (one 8-byte load per hit, no
 // branches in the loop).
-// Round 6: the step's 2 048 hits are put in range order in LDS before they leave.  Written straight from the registers a wavefront's
+// Round 6: the step's 4 096 hits are put in range order in LDS before they leave.  Written straight from the registers a wavefront's
 // store went to up to 64 different lines, and the address path takes them one line per clock: the PMC counters had the kernel
 // issue-stalled 65 % of its wave cycles (profiles/r07i_pmc_stalls.txt: SQ_WAIT_INST_ANY 1.65e11 of 2.52e11, not LDS).  Per step:
 // the lanes of a wavefront whose hits fall into one range find each other with cBits ballots (as before) and the first of them takes
 // the group's room in the step's per-range counters; a scan of the counters gives every range its place in the staging buffer and
 // its place in the segment's share of the output (the running cursors); the hits are written to the buffer, and then out slot by
 // slot -- 64 consecutive slots are 64 consecutive hits of one range (or of two): a store of one or two runs of lines.
-constexpr int CS_PER = 8;
+constexpr int CS_PER = 16;
 constexpr int CS_STEP = 256 * CS_PER;
 template <bool KV, bool DIAG>
 __device__ __forceinline__ void coarseScatterBody(uint64_t s, uint64_t e, uint64_t qs, uint32_t tMask, int shift, int cBits, uint32_t *cursor,

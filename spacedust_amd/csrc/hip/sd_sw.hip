@@ -1332,6 +1332,85 @@ k_bt_pack(uint32_t nPairs, const uint64_t *__restrict__ btLen, const uint64_t *_
     if (lane == 0) res[i].btOffset = poolBase + dense[i];
 }
 
+// ---- Matcher::compressAlignment on the device (M/src/alignment/Matcher.cpp:166-185; sd_sw_set_cigar_pool): the run-length text
+// of a backtrace -- "57M2I103M" -- instead of its letters.  State 'M' with a count of 0 at the start (a backtrace that does not begin
+// with a match begins "0M"), every run as decimal count + letter.  One wavefront per pair, 64 letters per step: a lane whose right
+// neighbour differs ends a run, the run began at the last lane at or below it whose left neighbour differs (a ballot; the last start
+// of the earlier steps is carried), and a scan of the text lengths of the step's runs places them.  WRITE = false: the text's length
+// only (the pool offsets are a scan of these), WRITE = true: the text, the record's offset and -- flags bits 8.. -- its length.
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_bt_cigar(uint32_t nPairs, const uint64_t *__restrict__ btLen, const uint64_t *__restrict__ dense, const TbTask *__restrict__ tb,
+           const char *__restrict__ bt, char *__restrict__ pool, uint64_t *__restrict__ cigLen, sd_sw_result *__restrict__ res) {
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= nPairs) return;
+    const uint32_t len = (uint32_t) btLen[i];
+    if (len == 0) {
+        if (!WRITE && lane == 0) cigLen[i] = 0;
+        return;
+    }
+    const char *src = bt + tb[i].btOff + ((uint64_t) (tb[i].qLen + tb[i].tLen + 2) - len);   // written backwards from the end
+    char *dst = WRITE ? pool + dense[i] : nullptr;
+    uint32_t out = 0;
+    uint32_t runStart = 0;
+    int left = src[0];   // the letter in front of the step's first one (in front of the first letter: itself, position 0 starts a run anyway)
+    if (left != 'M') {
+        if (WRITE && lane == 0) {
+            dst[0] = '0';
+            dst[1] = 'M';
+        }
+        out = 2;
+    }
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t x = base + (uint32_t) lane;
+        const bool valid = x < len;
+        const int c = valid ? (int) src[x] : -1;
+        const int after = base + 64 < len ? (int) src[base + 64] : -2;   // the letter behind the step's last one (or the end)
+        int prv = __shfl_up(c, 1, 64);
+        if (lane == 0) prv = left;
+        int nxt = __shfl_down(c, 1, 64);
+        if (lane == 63) nxt = after;
+        if (valid && x + 1 == len) nxt = -2;
+        const bool isStart = valid && (x == 0 || prv != c);
+        const bool isEnd = valid && nxt != c;
+        const unsigned long long starts = __ballot(isStart);
+        const unsigned long long mine = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const uint32_t from = mine ? base + (uint32_t) (63 - __clzll((long long) mine)) : runStart;
+        uint32_t count = 0, nd = 0;
+        if (isEnd) {
+            count = x - from + 1;
+            nd = count < 10 ? 1 : count < 100 ? 2 : count < 1000 ? 3 : count < 10000 ? 4 : count < 100000 ? 5 : count < 1000000 ? 6 : 7;
+        }
+        uint32_t incl = isEnd ? nd + 1 : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (WRITE && isEnd) {
+            char *o = dst + out + incl - 1;   // the run's letter; the digits go in front of it
+            *o = (char) c;
+            uint32_t v = count;
+            for (uint32_t d = 0; d < nd; d++) {
+                *--o = (char) ('0' + v % 10);
+                v /= 10;
+            }
+        }
+        out += __shfl(incl, 63, 64);
+        if (starts) runStart = base + (uint32_t) (63 - __clzll((long long) starts));
+        left = __shfl(c, 63, 64);
+    }
+    if (lane == 0) {
+        if (WRITE) {
+            res[i].btOffset = dense[i];
+            res[i].flags = (res[i].flags & 0xFF) | (int32_t) (out << 8);
+        } else {
+            cigLen[i] = out;
+        }
+    }
+}
+
 // ---- besthitbyset on the device (sd_sw_align_batch_best_by_group).  Matcher::compareHits orders a query's accepted alignments by
 // E-value, rounded bit score, target length, target key; for one query the E-value is a strictly decreasing function of the score
 // and the bit score a function of it, so the first of a (query, target set) cell is the maximum of
@@ -2416,7 +2495,16 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     }
     // ---- dense backtrace pool + results back to the host
     hs.reset(new HostScope(ctx, "align.download"));
-    rc = devExclusiveScan(ctx, dBtLen, dDense, N + 1);
+    // (sd_sw_set_cigar_pool: the pool holds run-length text, its offsets are a scan of the text lengths)
+    const bool cigarPool = ctx->cigarPool && btPool != nullptr;
+    uint64_t *dCigLen = nullptr;
+    if (cigarPool) {
+        SD_HIP(ctx, wsGet(ctx, "al.ciglen", N + 1, &dCigLen));
+        SD_HIP(ctx, hipMemsetAsync(dCigLen + nPairs, 0, (N + 1 - nPairs) * sizeof(uint64_t), ctx->stream));
+        hipLaunchKernelGGL(k_bt_cigar<false>, dim3((nPairs + 3) / 4), dim3(256), 0, ctx->stream, nPairs, (const uint64_t *) dBtLen,
+                           (const uint64_t *) nullptr, (const TbTask *) dTb, (const char *) dBt, (char *) nullptr, dCigLen, (sd_sw_result *) nullptr);
+    }
+    rc = devExclusiveScan(ctx, cigarPool ? dCigLen : dBtLen, dDense, N + 1);
     if (rc != SD_OK) return rc;
     uint64_t poolBytes = 0;
     int hErr[4] = {0, 0, 0, 0};
@@ -2433,12 +2521,15 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
     uint64_t identBytes = 0;
     if (isIdentity && btPool)
         for (uint32_t i = 0; i < nPairs; i++)
-            if (isIdentity[i]) identBytes += targets->hOff[pairT[i] + 1] - targets->hOff[pairT[i]];
+            if (isIdentity[i]) identBytes += cigarPool ? 8 : targets->hOff[pairT[i] + 1] - targets->hOff[pairT[i]];
     if (poolBytes > 0 && btPool == nullptr) return sdFail(ctx, SD_EINVAL, "swMode 2 needs a backtrace pool");
     if (poolBytes + identBytes > btCap && btPool) return sdFail(ctx, SD_ENOMEM, "backtrace pool too small");
     char *dPool = nullptr;
     SD_HIP(ctx, wsGet(ctx, "al.pool", poolBytes + 64, &dPool));
-    if (poolBytes > 0)
+    if (poolBytes > 0 && cigarPool)
+        hipLaunchKernelGGL(k_bt_cigar<true>, dim3((nPairs + 3) / 4), dim3(256), 0, ctx->stream, nPairs, (const uint64_t *) dBtLen,
+                           (const uint64_t *) dDense, (const TbTask *) dTb, (const char *) dBt, dPool, (uint64_t *) nullptr, dRes);
+    else if (poolBytes > 0)
         hipLaunchKernelGGL(k_bt_pack, dim3((nPairs + 3) / 4), dim3(256), 0, ctx->stream, nPairs, dBtLen, dDense, dTb, dBt, dPool,
                            (uint64_t) 0, dRes);
     // records to bring back: all of them, or (compact mode) only identity pairs and pairs that passed every gate
@@ -2536,7 +2627,14 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
             r.qEnd = L - 1; r.tEnd = L - 1; r.identical = L; r.btLen = L; r.flags = 0;
             r.evalue = sd::computeEvalue(ev, (double) (uint32_t) r.score, qL);
             r.btOffset = 0;
-            if (btPool) {
+            if (btPool && cigarPool) {   // "<L>M"
+                char txt[16];
+                const int nTxt = snprintf(txt, sizeof(txt), "%dM", L);
+                memcpy(btPool + btPos, txt, (size_t) nTxt);
+                r.btOffset = btPos;
+                r.flags = nTxt << 8;
+                btPos += (uint64_t) nTxt;
+            } else if (btPool) {
                 memset(btPool + btPos, 'M', L);
                 r.btOffset = btPos;
                 btPos += L;
@@ -2544,7 +2642,22 @@ static int alignBatchImpl(sd_ctx *ctx, const sd_sw_params *par, const sd_seqset 
         }
     }
     if (btUsed) *btUsed = btPos;
+    ctx->d2hRecordBytes += (uint64_t) nRec * (sizeof(sd_sw_result) + (compactIdx ? sizeof(uint32_t) : 0));
+    ctx->d2hPoolBytes += poolBytes;
     hs.reset();
+    return SD_OK;
+}
+
+int sd_sw_set_cigar_pool(sd_ctx *ctx, int on) {
+    if (!ctx) return SD_EINVAL;
+    ctx->cigarPool = on != 0;
+    return SD_OK;
+}
+
+int sd_sw_download_bytes(sd_ctx *ctx, uint64_t *recordBytes, uint64_t *poolBytes) {
+    if (!ctx) return SD_EINVAL;
+    if (recordBytes) *recordBytes = ctx->d2hRecordBytes;
+    if (poolBytes) *poolBytes = ctx->d2hPoolBytes;
     return SD_OK;
 }
 

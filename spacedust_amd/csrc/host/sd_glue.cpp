@@ -177,6 +177,7 @@ struct sd_agg {
     float seqIdThr = 0.0f;
     bool filterSelfMatch = true;
     bool listOrder = false;   // sd_agg_set_list_order
+    bool cigarPool = false;   // sd_agg_set_pool_form: the pool of sd_agg_add holds run-length text (sd_sw_set_cigar_pool)
     // after besthitbyset + combinehits filter: per worker thread, any order until finish()
     struct HitKey { uint64_t cell; uint32_t q, idx; };  // cell = qSet * nTSets + tSet (64 bit: 30 000 x 30 000 sets and more)
     std::vector<uint32_t> qDbKey, tDbKey;               // optional DB keys (sd_agg_set_keys): order inside entries, compareHits tie-break
@@ -247,7 +248,7 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
             bad |= ((uint64_t) qBase + pairQ[i] >= a->qSetOf.size() || pairT[i] >= a->tSetOf.size() ||
                     // a CIGAR is at most two characters per backtrace letter and must fit one 2^20-byte block of the arena: checked here,
                     // before anything is appended (sequences are <= 65 535 residues, so a backtrace has < 2^17 letters)
-                    (btPool && res[i].btLen > (1 << 19))) ? 1 : 0;
+                    (btPool && res[i].btLen > (1 << 19)) || (btPool && a->cigarPool && ((uint32_t) res[i].flags >> 8) > (1u << 20))) ? 1 : 0;
         if (bad) {
             if (getenv("SD_DEBUG_TIMING")) fprintf(stderr, "[sd_agg_add] rejected: a pair index outside the sets, or a backtrace of more than 2^19 letters\n");
             return SD_EINVAL;   // (nothing was added)
@@ -389,7 +390,16 @@ int sd_agg_add(sd_agg *a, uint32_t nPairs, uint32_t qBase, const uint32_t *pairQ
                 b.arena = (uint32_t) th;
                 b.cigarOff = 0;
                 b.cigarLen = 0;
-                if (btPool && r.btLen > 0) {
+                if (btPool && r.btLen > 0 && a->cigarPool) {   // the text came from the device (flags bits 8..: its length)
+                    const size_t nTxt = (size_t) ((uint32_t) r.flags >> 8);
+                    const size_t at = myCigar.appendRun(btPool + r.btOffset, nTxt);
+                    if (at == SIZE_MAX) {
+                        tooLong = 1;
+                        continue;
+                    }
+                    b.cigarOff = at;
+                    b.cigarLen = (uint32_t) nTxt;
+                } else if (btPool && r.btLen > 0) {
                     cigar.clear();
                     sd::compressBacktraceAppend(btPool + r.btOffset, (size_t) r.btLen, cigar);
                     const size_t at = myCigar.appendRun(cigar.data(), cigar.size());
@@ -467,6 +477,12 @@ int sd_agg_finish(sd_agg *a, uint64_t *nEntries, uint64_t *nHits) {
 int sd_agg_set_list_order(sd_agg *a, int on) {
     if (!a) return SD_EINVAL;
     a->listOrder = on != 0;
+    return SD_OK;
+}
+
+int sd_agg_set_pool_form(sd_agg *a, int cigarText) {
+    if (!a) return SD_EINVAL;
+    a->cigarPool = cigarText != 0;
     return SD_OK;
 }
 

@@ -166,6 +166,7 @@ struct sd_search {
     sd_sw_params swParRun;   // swPar with the E-value gate of the running stream (sd_search_stream: predicate pushdown)
     bool targetHasGroups = false;   // sd_seqset_set_groups was applied to tSeqs
     bool bestOnDevice = false;      // the running stream lets the device keep only besthitbyset's candidates
+    bool cigarOnDevice = false;     // ... and returns run-length text instead of backtrace letters
     bool wantRecords = false;       // sd_search_set_want_records
     sd_ch_params chPar;
     std::vector<int32_t> tLen;
@@ -468,6 +469,22 @@ int sd_search_stats(sd_search *s, uint64_t *stats, double *seconds) {
     return SD_OK;
 }
 
+int sd_search_download_bytes(sd_search *s, uint64_t *recordBytes, uint64_t *poolBytes) {
+    if (!s) return SD_EINVAL;
+    uint64_t rec = 0, pool = 0;
+    sd_ctx *al[4] = {s->ctxAl, s->ctxAl2, s->ctxAlMore[0], s->ctxAlMore[1]};
+    for (sd_ctx *c : al) {
+        uint64_t a = 0, b = 0;
+        if (c && sd_sw_download_bytes(c, &a, &b) == SD_OK) {
+            rec += a;
+            pool += b;
+        }
+    }
+    if (recordBytes) *recordBytes = rec;
+    if (poolBytes) *poolBytes = pool;
+    return SD_OK;
+}
+
 int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRanges, const uint32_t *rangeBegin,
                      const uint32_t *rangeEnd, sd_search_result **results) {
     if (!s || !Q || !results || (nRanges && (!rangeBegin || !rangeEnd))) return SD_EINVAL;
@@ -498,6 +515,20 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
     // set (Matcher::compareHits order) and the identity pair come back (sd_sw_align_batch_best_by_group); the aggregation's own
     // selection over those gives what it gave over all records.  SD_BEST_ON_DEVICE=0: every accepted record comes back.
     s->bestOnDevice = pushdown && s->targetHasGroups && !(getenv("SD_BEST_ON_DEVICE") && atoi(getenv("SD_BEST_ON_DEVICE")) == 0);
+    // ... and Matcher::compressAlignment: with the aggregation as the only consumer of the backtraces (no alignment sink), the lanes
+    // return every backtrace as its run-length text (sd_sw_set_cigar_pool) and sd_agg_add copies it.  SD_CIGAR_ON_DEVICE=0: letters.
+    s->cigarOnDevice = aggregate && !s->alnSink && !(getenv("SD_CIGAR_ON_DEVICE") && atoi(getenv("SD_CIGAR_ON_DEVICE")) == 0);
+    struct CigarMode {   // (the lane contexts are handed out by sd_search_context: the mode ends with the stream)
+        sd_ctx *al[4];
+        explicit CigarMode(sd_search *s_, bool on) : al{s_->ctxAl, s_->ctxAl2, s_->ctxAlMore[0], s_->ctxAlMore[1]} {
+            for (sd_ctx *c : al)
+                if (c) sd_sw_set_cigar_pool(c, on ? 1 : 0);
+        }
+        ~CigarMode() {
+            for (sd_ctx *c : al)
+                if (c) sd_sw_set_cigar_pool(c, 0);
+        }
+    } cigarMode(s, s->cigarOnDevice);
     std::vector<uint32_t> qSetSize(Q->nSets, 0);
     if (aggregate)
         for (uint32_t i = 0; i < Q->n; i++)
@@ -522,6 +553,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
                                s->par.covThr, s->par.alnLenThr, s->par.filterSelfMatch, &res[r]->agg);
         if (rc != SD_OK) return s->fail(rc, "sd_agg_create");
         if (Q->keys || T.keys) sd_agg_set_keys(res[r]->agg, Q->keys, T.keys);
+        if (s->cigarOnDevice) sd_agg_set_pool_form(res[r]->agg, 1);
     }
     // chunks: whole query proteins; the very first chunk of a stream is a quarter of the others (its prefilter is the one
     // stage nothing overlaps with, so the alignment thread starts that much earlier)
@@ -879,7 +911,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
             if (rc == SD_ENOMEM && !exact) {   // the backtrace pool has to grow: repeat with the exact bound
                 uint64_t need = 64;
                 for (uint32_t i = 0; i < n; i++) need += (uint64_t) (*qLenP)[c0 + d->pairQ[i]] + (uint64_t) s->tLen[d->pairT[i]];
-                cap = need;
+                cap = s->cigarOnDevice ? 2 * need : need;   // (run-length text: at most two characters per letter)
                 exact = true;
                 continue;
             }

@@ -179,6 +179,12 @@ class ClusterSearch:
         """the search's resident target (borrowed), e.g. for sample_check against the host index builder"""
         return _BorrowedTarget(self.ctx, C.c_void_p(self.L.sd_search_target(self.h)), self.k)
 
+    def download_bytes(self):
+        """(record bytes, backtrace-pool bytes) the alignment lanes have copied to the host since create (sd_search_download_bytes)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.L.sd_search_download_bytes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def _raw_stats(self):
         st = np.zeros(16, np.uint64)
         tm = np.zeros(16, np.float64)

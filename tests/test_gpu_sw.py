@@ -326,6 +326,64 @@ def test_sw_align_compact_equals_full(gpu, host):
     assert 100 < len(keep) < len(pq)
 
 
+def _compress_alignment(bt):
+    """Matcher::compressAlignment (M/src/alignment/Matcher.cpp:166-185), letter by letter"""
+    out, state, count = [], 'M', 0
+    for ch in bt:
+        if ch != state:
+            out.append('%d%s' % (count, state))
+            state, count = ch, 1
+        else:
+            count += 1
+    out.append('%d%s' % (count, state))
+    return ''.join(out)
+
+
+def test_sw_run_length_text_from_the_device_equals_compress_alignment(gpu, host):
+    """sd_sw_set_cigar_pool: the pool of every alignment call holds Matcher::compressAlignment of the backtrace letters the same
+    call returns without it -- full, compact and with diagonals; identity pairs; alignments of under 64 to over a thousand letters,
+    runs that cross the 64-letter steps of the kernel, gap-rich pairs; every other field unchanged"""
+    from spacedust_amd.synth import make_proteomes
+    ps = make_proteomes(n_proteomes=5, genes_per_proteome=320, n_families=300, seed=41, mean_len=420)
+    rng = np.random.default_rng(9)
+    pq, pt = _pairs(ps, rng, 5000)
+    pq[:300] = pt[:300]
+    sw_bias, _, _ = host.comp_bias(ps.residues, ps.offsets)
+    mat, _, _ = host.matrix(0)
+    ss = gpu.seqset(ps.residues, ps.offsets, sw_bias)
+    ident = (pq == pt)
+    ident[:150] = False            # self pairs through the kernels: one run of several hundred letters
+    try:
+        for go, ge in ((11, 1), (3, 1)):   # cheap gaps: many short runs
+            par = gpu.sw_params(mat, int(ps.offsets[-1]), gap_open=go, gap_extend=ge)
+            for kw in (dict(), dict(compact=True), dict(compact=True, diag=np.zeros(len(pq), np.uint16))):
+                gpu.set_cigar_pool(False)
+                a = gpu.sw_align(par, ss, ss, pq, pt, identity=ident, **kw)
+                gpu.set_cigar_pool(True)
+                b = gpu.sw_align(par, ss, ss, pq, pt, identity=ident, **kw)
+                if kw:
+                    assert np.array_equal(a[0], b[0])
+                    a, b = a[1:], b[1:]
+                (ra, pa), (rb, pb) = a, b
+                for f in ('score', 'qStart', 'qEnd', 'tStart', 'tEnd', 'identical', 'btLen', 'evalue'):
+                    assert np.array_equal(ra[f], rb[f]), f
+                assert np.array_equal(ra['flags'], rb['flags'] & 0xFF)
+                assert int((ra['flags'] >> 8).max()) == 0
+                n_text = (rb['flags'].astype(np.int64) >> 8)
+                assert np.array_equal(n_text > 0, ra['btLen'] > 0)
+                lens, runs = [], 0
+                for x in np.flatnonzero(ra['btLen'] > 0):
+                    bt = pa[int(ra['btOffset'][x]):int(ra['btOffset'][x]) + int(ra['btLen'][x])].tobytes().decode()
+                    txt = pb[int(rb['btOffset'][x]):int(rb['btOffset'][x]) + int(n_text[x])].tobytes().decode()
+                    assert txt == _compress_alignment(bt), (x, bt, txt)
+                    lens.append(len(bt))
+                    runs += sum(c in 'MID' for c in txt)
+                assert len(pb) < (len(pa) // 3 if go == 11 else len(pa))
+                assert min(lens) < 64 and max(lens) > 700 and runs > 3 * len(lens), (min(lens), max(lens), runs, len(lens))
+    finally:
+        gpu.set_cigar_pool(False)
+
+
 def test_sw_align_with_prefilter_diagonals_equals_without(gpu, host):
     """sd_sw_align_batch_compact_diag: the diagonal only lets pairs whose byte-range score saturates for certain go
     straight to the 16-bit pass; true, random and absurd diagonals all give the records of the call without them"""

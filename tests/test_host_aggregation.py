@@ -121,12 +121,14 @@ def _seq_id_text(identical, bt_len, identity):
     return t + str(int(np.float32(s) * np.float32(1000)))
 
 
-@pytest.mark.parametrize('threads', [1, 5])
-def test_aggregation_on_synthetic_records_equals_restatement(threads, monkeypatch):
+@pytest.mark.parametrize('threads,pool_form', [(1, 0), (5, 0), (5, 1)])
+def test_aggregation_on_synthetic_records_equals_restatement(threads, pool_form, monkeypatch):
     """3 query sets x 40 target sets, several accepted candidates per (query, target set) cell incl. equal scores (the compareHits tie
     breaks: target length, then key), E-values either side of combinehits' bound, coverage and length either side of their thresholds,
     the records handed over in chunks like the pipeline does.  Entries, hit order, P-value bits against oracle/agg_restatement.py;
-    the pval / seqId / eval texts, the coordinates and the CIGAR of every member of the cluster records against Python's formatting."""
+    the pval / seqId / eval texts, the coordinates and the CIGAR of every member of the cluster records against Python's formatting.
+    pool_form 1 (sd_agg_set_pool_form): the pool holds the run-length text of every backtrace -- what the alignment calls return after
+    sd_sw_set_cigar_pool -- with its length in flags >> 8; same entries, same records."""
     import agg_restatement
     L = _lib.load()
     host = api.Host(threads)
@@ -137,7 +139,7 @@ def test_aggregation_on_synthetic_records_equals_restatement(threads, monkeypatc
     lengths = rng.integers(40, 600, n_t).astype(np.int32)
     set_of = (np.arange(n_t) // per_set).astype(np.uint32)
     db_res = int(lengths.sum()) * 2000
-    pq, pt, recs, ident, pool, rows = [], [], [], [], [], []
+    pq, pt, recs, ident, pool, rows, bts = [], [], [], [], [], [], []
     off = 0
     for q in range(n_q):
         n_pairs = int(rng.integers(0, 90))
@@ -172,8 +174,15 @@ def test_aggregation_on_synthetic_records_equals_restatement(threads, monkeypatc
                 r.tStart = int(rng.integers(0, 5))
                 r.tEnd = r.tStart + span - 1
             r.btOffset = off
-            pool.append(bt)
-            off += len(bt)
+            bts.append(bt)
+            if pool_form == 1:
+                txt = _rle(bt) if bt else ''
+                r.flags = len(txt) << 8 | int(rng.integers(0, 2))
+                pool.append(txt)
+                off += len(txt)
+            else:
+                pool.append(bt)
+                off += len(bt)
             pq.append(q)
             pt.append(t)
             recs.append(r)
@@ -189,6 +198,7 @@ def test_aggregation_on_synthetic_records_equals_restatement(threads, monkeypatc
     q_len = np.ascontiguousarray(lengths[:n_q])
     q_set = np.ascontiguousarray(set_of[:n_q])
     assert L.sd_agg_create(ptr(q_set), ptr(q_len), n_q, ptr(set_of), ptr(lengths), n_t, n_qsets, n_sets, 10.0, 2, 0.8, 30, 1, C.byref(agg)) == 0
+    assert L.sd_agg_set_pool_form(agg, pool_form) == 0
     pq, pt, ident = np.array(pq, np.uint32), np.array(pt, np.uint32), np.array(ident, np.uint8)
     rec_arr = (_SwResult * n)(*recs)
     rec_bytes = np.frombuffer(rec_arr, np.uint8)
@@ -251,8 +261,8 @@ def test_aggregation_on_synthetic_records_equals_restatement(threads, monkeypatc
             assert pval == ('%.3E' % h_p[h]).encode().ljust(16, b'\0')
             assert seq_id == _seq_id_text(r.identical, r.btLen, ident[i]).encode().ljust(8, b'\0')
             assert (q_start, q_end, q_l, t_start, t_end, t_l) == (r.qStart, r.qEnd, int(lengths[q]), r.tStart, r.tEnd, int(lengths[t]))
-            bt = pool[r.btOffset:r.btOffset + r.btLen].decode()
-            assert cigar == _rle(bt)
+            bt = bts[i]
+            assert len(bt) == r.btLen and cigar == _rle(bt)
             if bt.startswith('M'):   # (a backtrace that begins with a gap begins "0M", which Matcher::uncompressAlignment reads as one M)
                 assert api.uncompress_cigar(cigar) == bt
             members += 1
