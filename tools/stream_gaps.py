@@ -77,6 +77,43 @@ def union_busy(path):
           % (span / 1e6, 100.0 * busy / span, area / span))
 
 
+def idle_report(path, top=24):
+    """the periods of the second half of the trace in which NO kernel of any stream runs: total, by length class, and summed by
+    (kernel that ended last -> kernel that starts next, with their streams) -- which host round trip the whole device waits for"""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute('pragma table_info(kernels)')]
+    sid = next((c for c in ('stream_id', 'stream', 'queue_id', 'queue') if c in cols), None)
+    rows = db.execute('select start, end, name, %s from kernels order by start' % sid).fetchall()
+    if not rows:
+        return
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    w0 = t0 + (t1 - t0) // 2
+    rows = [r for r in rows if r[1] > w0]
+    frontier, last = None, None   # latest end seen so far and the kernel that has it
+    gaps = defaultdict(lambda: [0, 0.0])
+    classes = [(50, 0, 0.0), (200, 0, 0.0), (1000, 0, 0.0), (5000, 0, 0.0), (1e12, 0, 0.0)]
+    total = 0.0
+    for a, b, n, s_ in rows:
+        if frontier is not None and a > frontier:
+            g = (a - frontier) / 1e3
+            total += g
+            e = gaps[('%s [s%s]' % (last[0], last[1]), '%s [s%s]' % (short(n), s_))]
+            e[0] += 1; e[1] += g
+            for i, (lim, c, t) in enumerate(classes):
+                if g < lim:
+                    classes[i] = (lim, c + 1, t + g)
+                    break
+        if frontier is None or b > frontier:
+            frontier, last = b, (short(n), s_)
+    print('\nidle device (no kernel on any stream) in the second half of the trace: %.1f ms of %.1f ms' % (total / 1e3, (t1 - w0) / 1e6))
+    lo = 0
+    for lim, c, t in classes:
+        print('   gaps of %5s - %5s us: %6d, %8.1f ms' % (lo, lim if lim < 1e12 else 'inf', c, t / 1e3))
+        lo = lim
+    for (n0, n1), (c, g) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:top]:
+        print('   %8.1f ms in %5d gaps (avg %7.0f us)  %s -> %s' % (g / 1e3, c, g / c, n0, n1))
+
+
 def timeline(path, stream, first, count):
     """kernels first .. first + count of one stream in start order: gap before, duration, name, grid"""
     db = sqlite3.connect(path)
@@ -98,3 +135,4 @@ if __name__ == '__main__':
     else:
         main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 5.0)
         union_busy(sys.argv[1])
+        idle_report(sys.argv[1])
