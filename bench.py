@@ -285,12 +285,18 @@ def measure(args, rank, local_rank, world, dist, torch):
 
     rec_buf = [None]   # a rank of an N > 1 run builds its records in the communicator's pinned buffer (set after the warm-up)
 
+    gather_stream = [None]   # N > 1 over RCCL: the records of a step are gathered while the next steps run (sd_gather_stream_*)
+
     def run_steps(step_ids):
-        rngs, pairs = [], 0
-        for x in step_ids:
+        rngs, pairs, rounds = [], 0, []
+        for k_, x in enumerate(step_ids):
             r, n = my_ranges(x)
             rngs += r
+            rounds += [k_] * len(r)
             pairs += n
+        if gather_stream[0] is not None:   # one round per step; the ranges' records leave through the stream's records sink
+            gather_stream[0].stream_begin(rounds, len(step_ids), out=gather_out)
+            return pairs, cs.search_stream(db, rngs, same_db=True, want_records=True, arrays='last', records_sink=gather_stream[0].stream_sink())
         # every rank builds its ranges' cluster records inside the stream; a rank of an N > 1 run also copies them out for the gather,
         # a single rank leaves them in the result handles: N = 1 and N > 1 time the same work up to the hand-over
         return pairs, cs.search_stream(db, rngs, same_db=True, want_records=True if dist is not None else ('build' if os.environ.get('SD_BENCH_RECORDS', '1') != '0' else False), arrays='last',
@@ -336,6 +342,10 @@ def measure(args, rank, local_rank, world, dist, torch):
             dist.all_reduce(okf, op=dist.ReduceOp.MIN)   # all ranks or none: the gather's calls are collective
             if int(okf.item()) == 0:
                 rec_buf[0], gather_out = None, None
+            elif os.environ.get('SD_BENCH_GATHER_STREAM', '1') != '0':
+                # round by round behind the stream (SD_BENCH_GATHER_STREAM=0: one blob per rank behind the last kernel)
+                gather_stream[0] = comm
+                gather_how += '; one round per step on the communicator\'s stream while the next steps are searched (sd_gather_stream_*)'
     elif dist is not None:
         gather_how = 'rehearsal on one GPU (RCCL refuses two ranks per device): the same records over torch.distributed / gloo'
     if dist is not None:
@@ -360,7 +370,10 @@ def measure(args, rank, local_rank, world, dist, torch):
         # the one exchange of the path: every rank's cluster records to rank 0, which writes the result TSV from the gathered buffer
         recs = outs[-1]['records_all'] if outs else np.zeros(0, np.uint8)   # the ranges' records back to back in one buffer
         t_g0 = time.time()
-        if comm is not None:
+        if gather_stream[0] is not None:   # the rounds of the earlier steps are on the root already: this waits for the last ones
+            gathered, _, round_sizes = comm.stream_end()
+            gather_sizes = round_sizes.sum(axis=0).astype(np.uint64)
+        elif comm is not None:
             gathered, gather_sizes = comm.gather_bytes(recs, out=gather_out)
         else:
             from spacedust_amd.pipeline import gather_results
@@ -672,9 +685,23 @@ def _thread_cpu_snapshot():
         pass
     return snap
 
+_REAL_STDOUT = None
+
+
+def _emit(text):
+    """the one line of this process on the stdout it was started with"""
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (text + '\n').encode())
+
+
 def main():
     args = parse()
     t_start = time.time()
+    # Native libraries print to the process's stdout too (RCCL's version banner at communicator set-up, flushed at exit -- behind the
+    # JSON line): file descriptor 1 goes to stderr for the run, and the one JSON line is written to the descriptor the process got.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -725,7 +752,7 @@ def main():
                 os.remove(f)
     del ex
     if args.record:   # child of a leg: the whole record, the parent keeps what it needs
-        print(json.dumps(res))
+        _emit(json.dumps(res))
         return
 
     def child(name, cmd, keep=None):
@@ -866,7 +893,7 @@ def main():
         for k_ in ('stage_wall_s', 'setup_s', 'host_cpu_by_stage', 'index_check'):
             if len(json.dumps(line)) > 8000:
                 line.pop(k_, None)
-    print(json.dumps(line))
+    _emit(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -568,6 +568,12 @@ int sd_search_set_chunk_queries(sd_search *s, int32_t chunkQueries);
  * finished, inside the pipeline, instead of on demand afterwards -- what a rank of a multi-GPU run asks for, whose records all go into
  * the final gather (sd_gather_results) */
 int sd_search_set_want_records(sd_search *s, int on);
+/* With sd_search_set_want_records(s, 1): fn(user, range, records, bytes) is called on the stream's finalising thread as soon as range
+ * `range` of the running sd_search_stream is finalised and its cluster records are built -- in range order, also for ranges without
+ * hits (bytes = 0) -- so that a consumer (sd_gather_stream_sink: the round-by-round gather of a multi-GPU run) takes them while the
+ * later ranges are still being searched.  The bytes are those sd_search_result_records returns; valid during the call.  NULL: off. */
+typedef void (*sd_records_sink)(void *user, uint32_t range, const void *records, uint64_t bytes);
+int sd_search_set_records_sink(sd_search *s, sd_records_sink fn, void *user);
 /* query ranges [rangeBegin[i], rangeEnd[i]) of `query` (whole query sets each), streamed through one pipeline;
  * sameDb != 0: query protein i is target protein i (identity pairs, self hit first).  results[nRanges] receives one
  * handle per range (destroy each). */
@@ -633,6 +639,22 @@ const char *sd_comm_last_error(sd_comm *c);
  * receive, and no rank repeats the collective alone. */
 int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, uint64_t *sizes, void *outOnRoot, uint64_t outCap,
                       uint64_t *outBytes);
+/* The same gather round by round behind a running search, instead of one blob per rank behind the last kernel (the reference's
+ * merge starts when the last rank's files exist, M/src/prefiltering/Prefiltering.cpp:630-658).  The nRanges ranges of this rank's
+ * sd_search_stream are grouped into nRounds rounds (roundOfRange[i], non-decreasing; e.g. the step of a range; ranks may hold
+ * different numbers of ranges, also none, in a round -- nRounds must be the same on every rank).  sd_gather_stream_sink is an
+ * sd_records_sink (sd_search_set_records_sink(s, sd_gather_stream_sink, g)): it appends a range's records to the communicator's
+ * pinned send buffer (sd_comm_host_buffer(c, 0, ...) sizes it; records beyond it are staged in pageable memory), and when a round's
+ * last range has arrived a worker thread runs that round's sd_gather_results on the communicator's stream while the search goes on.
+ * On the root the rounds land back to back in outOnRoot (round 0: ranks 0 .. N-1, round 1: ...).  sd_gather_stream_end waits for the
+ * last round (ranges that never arrived count as empty, so the ranks' collectives still match), fills roundOffsets[nRounds + 1] (the
+ * root's byte offset of every round), sizes[nRounds * nRanks] and *totalOnRoot (each nullable), frees the object and returns the
+ * first failing round's code (SD_ENOMEM: outCap too small -- on every rank, in the same round, as in sd_gather_results). */
+typedef struct sd_gather_stream sd_gather_stream;
+int sd_gather_stream_begin(sd_comm *c, int root, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
+                           uint64_t outCap, sd_gather_stream **out);
+void sd_gather_stream_sink(void *gatherStream, uint32_t range, const void *records, uint64_t bytes);
+int sd_gather_stream_end(sd_gather_stream *g, uint64_t *roundOffsets, uint64_t *sizes, uint64_t *totalOnRoot);
 /* Host-side rendezvous of the ranks over TCP (addr / port as a one-process-per-GPU launcher's MASTER_ADDR / MASTER_PORT; every
  * rank connects to rank 0 once, the calls are matched in program order): sd_tcp_bcast hands rank 0's buffer (the 128-byte
  * unique id) to every rank; sd_tcp_gather is the gatherv of byte records to rank 0 for ranks that share a device -- RCCL

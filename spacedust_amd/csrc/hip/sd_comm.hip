@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -101,6 +103,7 @@ struct sd_comm {
     uint64_t hostCap[2] = {0, 0};
     char *devBuf[2] = {nullptr, nullptr};
     uint64_t devCap[2] = {0, 0};
+    uint64_t *dSizes = nullptr;   // [nRanks + 1]: the size / status exchange of a gather (kept: hipFree waits for the whole device)
     int ensureDev(int which, uint64_t bytes) {
         if (devCap[which] >= bytes) return SD_OK;
         if (devBuf[which]) (void) hipFree(devBuf[which]);
@@ -189,6 +192,7 @@ void sd_comm_destroy(sd_comm *c) {
         if (c->hostBuf[w]) (void) hipHostFree(c->hostBuf[w]);
         if (c->devBuf[w]) (void) hipFree(c->devBuf[w]);
     }
+    if (c->dSizes) (void) hipFree(c->dSizes);
     if (c->comm) rccl()->commDestroy(c->comm);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
@@ -210,7 +214,8 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
     char *dLocal = nullptr, *dAll = nullptr;   // (the communicator's grow-only staging buffers: nothing here is freed per call)
     int status = SD_OK;
     do {
-        if (hipMalloc((void **) &dSizes, sizeof(uint64_t) * ((size_t) c->nRanks + 1)) != hipSuccess) { status = SD_ENOMEM; break; }
+        if (!c->dSizes && hipMalloc((void **) &c->dSizes, sizeof(uint64_t) * ((size_t) c->nRanks + 1)) != hipSuccess) { status = SD_ENOMEM; break; }
+        dSizes = c->dSizes;
         if (hipMemcpyAsync(dSizes + c->nRanks, &nBytes, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { status = SD_EHIP; break; }
         int rc = R->allGather(dSizes + c->nRanks, dSizes, 1, RCCL_UINT64, c->comm, c->stream);
         if (rc != 0) { status = fail("ncclAllGather", rc); break; }
@@ -282,8 +287,142 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
         }
         if (hipStreamSynchronize(c->stream) != hipSuccess && status == SD_OK) status = SD_EHIP;
     } while (false);
-    if (dSizes) (void) hipFree(dSizes);
     return status;
+}
+
+// ---- the gather, round by round, behind a running search -------------------------------------------------------------------
+// One blob per rank at the end puts N x (records of all steps) through the root's PCIe link behind the last kernel.  Here the ranges
+// of a stream are grouped into rounds (a bench step, a batch of query sets); the records of a range arrive through
+// sd_gather_stream_sink -- sd_search's records sink, called on the stream's finalising thread when the range is done -- and are
+// appended to the communicator's pinned send buffer; when the last range of a round has arrived, a worker thread runs
+// sd_gather_results for that round on the communicator's own HIP stream while the search goes on with the next ranges.  Every rank
+// runs exactly nRounds gathers in round order (a round without ranges on this rank sends 0 bytes), so the collectives match.  On
+// the root the rounds land back to back in outOnRoot: round 0's records of rank 0 .. N-1, round 1's, ...
+struct sd_gather_stream {
+    sd_comm *c = nullptr;
+    int root = 0;
+    uint32_t nRanges = 0, nRounds = 0;
+    std::vector<uint32_t> rangesThrough;   // [nRounds]: ranges of rounds 0 .. r
+    char *out = nullptr;
+    uint64_t outCap = 0, outUsed = 0;
+    std::vector<uint64_t> rangeEnd;        // send-buffer offset behind range i (in arrival order)
+    std::vector<char> overflow;            // a round that does not fit the pinned send buffer is staged here (pageable: slower, never wrong)
+    uint64_t sendUsed = 0;                 // bytes of the send buffer handed out so far (rounds already gathered are reused)
+    uint64_t roundBase = 0;                // send-buffer offset of the current round's first byte
+    bool roundInOverflow = false;
+    struct Round { uint64_t off, bytes; bool inOverflow; std::vector<char> own; };
+    std::vector<Round> rounds;             // filled as rounds complete
+    uint32_t nSunk = 0, nReady = 0;
+    std::vector<uint64_t> roundOff, sizes;
+    int status = SD_OK;
+    bool closing = false;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread worker;
+    void run() {
+        for (uint32_t r = 0; r < nRounds; r++) {
+            Round rd;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return nReady > r || closing; });
+                if (nReady > r) rd = std::move(rounds[r]);
+                else rd = Round{0, 0, false, {}};   // closed early: the ranks still run the same number of collectives
+            }
+            roundOff[r] = outUsed;
+            if (status != SD_OK) continue;   // (every rank saw the same code in the same round: nobody calls the collective again)
+            const char *src = rd.bytes == 0 ? nullptr : rd.inOverflow ? rd.own.data() : (const char *) c->hostBuf[0] + rd.off;
+            uint64_t total = 0;
+            const int rc = sd_gather_results(c, src, rd.bytes, root, sizes.data() + (size_t) r * c->nRanks, c->rank == root ? out + outUsed : nullptr,
+                                             c->rank == root ? outCap - outUsed : 0, &total);
+            if (rc != SD_OK) {
+                std::lock_guard<std::mutex> lk(mu);
+                status = rc;
+                continue;
+            }
+            outUsed += total;
+        }
+        roundOff[nRounds] = outUsed;
+    }
+};
+
+int sd_gather_stream_begin(sd_comm *c, int root, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
+                           uint64_t outCap, sd_gather_stream **out) {
+    if (!c || !out || root < 0 || root >= c->nRanks || (nRanges && !roundOfRange) || nRounds == 0) return SD_EINVAL;
+    for (uint32_t i = 0; i < nRanges; i++)
+        if (roundOfRange[i] >= nRounds || (i && roundOfRange[i] < roundOfRange[i - 1])) return SD_EINVAL;
+    sd_gather_stream *g = new sd_gather_stream();
+    g->c = c;
+    g->root = root;
+    g->nRanges = nRanges;
+    g->nRounds = nRounds;
+    g->rangesThrough.assign(nRounds, 0);
+    for (uint32_t i = 0; i < nRanges; i++) g->rangesThrough[roundOfRange[i]]++;
+    for (uint32_t r = 1; r < nRounds; r++) g->rangesThrough[r] += g->rangesThrough[r - 1];
+    g->out = (char *) outOnRoot;
+    g->outCap = c->rank == root ? outCap : 0;
+    g->rounds.resize(nRounds);
+    g->roundOff.assign((size_t) nRounds + 1, 0);
+    g->sizes.assign((size_t) nRounds * c->nRanks, 0);
+    // rounds without ranges on this rank are ready at once
+    while (g->nReady < nRounds && g->rangesThrough[g->nReady] == 0) {
+        g->rounds[g->nReady] = sd_gather_stream::Round{0, 0, false, {}};
+        g->nReady++;
+    }
+    g->worker = std::thread([g] { g->run(); });
+    *out = g;
+    return SD_OK;
+}
+
+void sd_gather_stream_sink(void *gatherStream, uint32_t range, const void *records, uint64_t bytes) {
+    sd_gather_stream *g = (sd_gather_stream *) gatherStream;
+    (void) range;   // (ranges arrive in order: the stream finalises them in order)
+    if (!g) return;
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->nSunk >= g->nRanges || g->closing) return;
+    // where the current round's bytes go: the pinned send buffer while the round fits, the round's own vector otherwise
+    if (!g->roundInOverflow && g->sendUsed + bytes > g->c->hostCap[0]) {
+        g->overflow.assign((const char *) g->c->hostBuf[0] + g->roundBase, (const char *) g->c->hostBuf[0] + g->sendUsed);
+        g->roundInOverflow = true;
+    }
+    if (bytes) {
+        if (g->roundInOverflow) g->overflow.insert(g->overflow.end(), (const char *) records, (const char *) records + bytes);
+        else memcpy((char *) g->c->hostBuf[0] + g->sendUsed, records, bytes);
+    }
+    if (!g->roundInOverflow) g->sendUsed += bytes;
+    g->nSunk++;
+    bool woke = false;
+    while (g->nReady < g->nRounds && g->rangesThrough[g->nReady] <= g->nSunk) {   // the round (and any empty rounds behind it) is complete
+        sd_gather_stream::Round &rd = g->rounds[g->nReady];
+        if (g->roundInOverflow) {
+            rd = sd_gather_stream::Round{0, (uint64_t) g->overflow.size(), true, {}};
+            rd.own.swap(g->overflow);
+            g->roundInOverflow = false;
+            g->sendUsed = g->roundBase;
+        } else {
+            rd = sd_gather_stream::Round{g->roundBase, g->sendUsed - g->roundBase, false, {}};
+        }
+        g->roundBase = g->sendUsed;
+        g->nReady++;
+        woke = true;
+    }
+    lk.unlock();
+    if (woke) g->cv.notify_all();
+}
+
+int sd_gather_stream_end(sd_gather_stream *g, uint64_t *roundOffsets, uint64_t *sizes, uint64_t *totalOnRoot) {
+    if (!g) return SD_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->closing = true;   // ranges that never arrived (a failed stream) count as empty: the collectives still match
+    }
+    g->cv.notify_all();
+    if (g->worker.joinable()) g->worker.join();
+    if (roundOffsets) memcpy(roundOffsets, g->roundOff.data(), g->roundOff.size() * sizeof(uint64_t));
+    if (sizes) memcpy(sizes, g->sizes.data(), g->sizes.size() * sizeof(uint64_t));
+    if (totalOnRoot) *totalOnRoot = g->outUsed;
+    const int rc = g->status;
+    delete g;
+    return rc;
 }
 
 // Whole query genome sets -> ranks, greedy by residue count (largest first; ties: lower set index, lower rank), so that a

@@ -177,6 +177,8 @@ struct sd_search {
     std::string err;
     sd_pref_sink prefSink = nullptr;
     sd_aln_sink alnSink = nullptr;
+    sd_records_sink recordsSink = nullptr;   // sd_search_set_records_sink
+    void *recordsSinkUser = nullptr;
     void *sinkUser = nullptr;
     // alignment result buffers in a ring: up to two chunks being aligned (one per lane) while the aggregation reads the
     // chunk before them
@@ -456,6 +458,13 @@ int sd_search_set_chunk_queries(sd_search *s, int32_t chunkQueries) {
 // on != 0: sd_search_stream builds every range's cluster records when the range is finalised -- inside the pipeline, on the thread that is
 // otherwise waiting for the lanes -- so that sd_search_result_records is a copy.  (A rank of a multi-GPU run needs them all for the
 // final gather; built behind the stream they were seconds of host time after the last kernel.)
+int sd_search_set_records_sink(sd_search *s, sd_records_sink fn, void *user) {
+    if (!s) return SD_EINVAL;
+    s->recordsSink = fn;
+    s->recordsSinkUser = user;
+    return SD_OK;
+}
+
 int sd_search_set_want_records(sd_search *s, int on) {
     if (!s) return SD_EINVAL;
     s->wantRecords = on != 0;
@@ -808,6 +817,7 @@ int sd_search_stream(sd_search *s, const sd_setdb *Q, int sameDb, uint32_t nRang
                 if (!pass) R.records.resize(need);
             }
             R.haveRecords = true;
+            if (s->recordsSink) s->recordsSink(s->recordsSinkUser, r, R.records.data(), (uint64_t) R.records.size());
         }
         R.counts[0] = ne;
         R.counts[1] = nh;

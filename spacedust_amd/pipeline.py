@@ -204,13 +204,15 @@ class ClusterSearch:
                                   canonical=canonical)[0]
 
     def search_stream(self, Q, ranges, same_db=False, chunk_queries=None, tsv_paths=None, canonical=True, want_records=False, arrays='all',
-                      records_buffer=None):
+                      records_buffer=None, records_sink=None):
         """The workflow for several query ranges [a,b) of Q (whole query sets each), streamed through one pipeline
         (sd_search_stream): the prefilter of the next chunk -- of the same or of the next range -- overlaps the alignments
         of the current one.  Every range gets its own aggregation, clusterhits call and result record.  Returns the list
         of result dicts (stage timings, summed over the stream, ride on the last).
         arrays: which ranges' result arrays (entries, hits, P-values, clusters) are copied out of the library's result handles into numpy
-        arrays -- 'all', or 'last' (the other ranges return their counters only: a caller that streams many ranges and reads one)."""
+        arrays -- 'all', or 'last' (the other ranges return their counters only: a caller that streams many ranges and reads one).
+        records_sink: (function pointer, user pointer) of an sd_records_sink (sd_search_set_records_sink), e.g. RcclGather.stream_sink():
+        every range's records go there the moment the range is finalised (with want_records); they are then not copied out again."""
         L = self.L
         if chunk_queries:
             L.sd_search_set_chunk_queries(self.h, int(chunk_queries))
@@ -223,7 +225,15 @@ class ClusterSearch:
         _, tm0 = self._raw_stats()
         # the ranges' cluster records are built inside the stream, not behind it (a multi-GPU rank's hand-over to the final gather)
         L.sd_search_set_want_records(self.h, 1 if want_records else 0)
-        rc = L.sd_search_stream(self.h, C.byref(qv), 1 if same_db else 0, n, ptr(rb), ptr(re), handles)
+        if records_sink is not None:
+            L.sd_search_set_records_sink(self.h, records_sink[0], records_sink[1])
+        try:
+            rc = L.sd_search_stream(self.h, C.byref(qv), 1 if same_db else 0, n, ptr(rb), ptr(re), handles)
+        finally:
+            if records_sink is not None:
+                L.sd_search_set_records_sink(self.h, None, None)
+                if want_records is True:
+                    want_records = 'build'   # (the sink has them)
         if rc != 0:
             raise _lib.SdError('sd_search_stream failed (%d): %s' % (rc, L.sd_search_last_error(self.h).decode(errors='replace')))
         _, tm1 = self._raw_stats()
@@ -409,6 +419,36 @@ class RcclGather:
         if rc != 0:
             raise _lib.SdError('sd_gather_results failed (%d): %s' % (rc, self.L.sd_comm_last_error(self.h).decode(errors='replace')))
         return (out if self.rank == root else None), sizes
+
+    def stream_begin(self, round_of_range, n_rounds, out=None, root=0):
+        """sd_gather_stream_begin: the gather round by round behind a running search.  round_of_range[i]: the round of this rank's i-th
+        range (non-decreasing); n_rounds the same on every rank; out (root): where the rounds land back to back, e.g. host_buffer(1, ...).
+        Hand stream_sink() to search_stream(records_sink=...), then stream_end()."""
+        rr = np.ascontiguousarray(round_of_range, np.uint32)
+        g = C.c_void_p()
+        cap = out.nbytes if (out is not None and self.rank == root) else 0
+        self._stream_out = out
+        api._check(None, self.L.sd_gather_stream_begin(self.h, root, len(rr), ptr(rr) if len(rr) else None, int(n_rounds), ptr(out) if cap else None, cap,
+                                                       C.byref(g)), 'sd_gather_stream_begin')
+        self._stream = (g, int(n_rounds), root)
+        return g
+
+    def stream_sink(self):
+        """(function pointer, user pointer) for search_stream(records_sink=...)"""
+        return C.cast(self.L.sd_gather_stream_sink, C.c_void_p), self._stream[0]
+
+    def stream_end(self):
+        """waits for the last round; -> (gathered bytes on the root / None, round offsets [n_rounds + 1], sizes [n_rounds, world])"""
+        g, n_rounds, root = self._stream
+        self._stream = None
+        offs = np.zeros(n_rounds + 1, np.uint64)
+        sizes = np.zeros((n_rounds, self.world), np.uint64)
+        total = C.c_uint64()
+        rc = self.L.sd_gather_stream_end(g, ptr(offs), ptr(sizes), C.byref(total))
+        if rc != 0:
+            raise _lib.SdError('sd_gather_stream_end failed (%d): %s' % (rc, self.L.sd_comm_last_error(self.h).decode(errors='replace')))
+        out = self._stream_out
+        return (out[:int(total.value)] if (self.rank == root and out is not None) else None), offs, sizes
 
     def gather(self, local_records, root=0):
         """variable-length int64 record arrays -> list of per-rank arrays on `root` (None elsewhere)"""

@@ -252,3 +252,55 @@ def test_records_built_inside_the_stream_equal_records_on_demand(gpu):
             assert L.sd_search_result_records(h, _lib.ptr(buf), buf.nbytes, C.byref(need)) == 0
         L.sd_search_result_destroy(h)
         assert np.array_equal(buf, full[ri]['records']), ri
+
+
+def test_gather_round_by_round_behind_the_stream_equals_the_final_gather(gpu):
+    """sd_gather_stream_*: the ranges' records leave through the stream's records sink as the ranges are finalised and are gathered
+    round by round on the communicator's stream while the search goes on; the rounds land back to back on the root and are, for the
+    one rank a one-GPU box allows, the bytes of the records built inside the stream (= the final one-blob gather).  Rounds of one,
+    several and no ranges; a send buffer smaller than a round (pageable staging of that round); a root buffer that is too small
+    (SD_ENOMEM from the round that does not fit, no hang); the sink alone (plain C calls) with payloads of known bytes."""
+    import ctypes as C
+    from spacedust_amd import _lib
+    from spacedust_amd.api import Host
+    from spacedust_amd.pipeline import SetDB, ClusterSearch, RcclGather
+    from spacedust_amd.synth import make_proteomes
+    L = _lib.load()
+    g = RcclGather(0, 1, 0, RcclGather.unique_id())
+    # the sink alone
+    rng = np.random.default_rng(11)
+    pay = [rng.integers(0, 256, n, dtype=np.uint8) for n in (5000, 0, 70001, 123, 9, 0, 40000)]
+    rounds = [0, 0, 2, 2, 2, 3, 5]   # rounds 1 and 4 hold no range
+    for send_cap, recv_cap, fails in ((60000, 1 << 20, False), (1 << 20, 1 << 20, False), (1 << 20, 80000, True)):   # (the buffers only grow)
+        g.host_buffer(0, send_cap)
+        recv = g.host_buffer(1, recv_cap)[:recv_cap]
+        gs = g.stream_begin(rounds, 6, out=recv)
+        fn, user = g.stream_sink()
+        sink = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64)(fn.value)
+        for i, p in enumerate(pay):
+            sink(user, i, p.ctypes.data if p.size else None, p.size)
+        if fails:
+            with pytest.raises(_lib.SdError):
+                g.stream_end()
+            continue
+        raw, offs, sizes = g.stream_end()
+        assert np.array_equal(raw, np.concatenate(pay))
+        per_round = [sum(p.size for p, r in zip(pay, rounds) if r == x) for x in range(6)]
+        assert sizes[:, 0].tolist() == per_round and offs.tolist() == np.concatenate([[0], np.cumsum(per_round)]).tolist()
+    # behind a running search
+    ps = make_proteomes(6, genes_per_proteome=150, n_families=220, seed=23)
+    db = SetDB.from_proteomes(ps)
+    cs = ClusterSearch(gpu, Host(4), db, max_seqs=300, bin_size=2, filter_self_match=True)
+    ranges = [(int(ps.set_start[s]), int(ps.set_start[s + 1])) for s in range(6)]
+    ref = cs.search_stream(db, ranges, same_db=True, chunk_queries=64, want_records=True, arrays='last')
+    want = ref[-1]['records_all']
+    assert want.size > 10000
+    g.host_buffer(0, 4 << 20)
+    recv = g.host_buffer(1, 4 << 20)
+    g.stream_begin([0, 0, 1, 2, 2, 2], 3, out=recv)
+    outs = cs.search_stream(db, ranges, same_db=True, chunk_queries=64, want_records=True, arrays='last', records_sink=g.stream_sink())
+    raw, offs, sizes = g.stream_end()
+    assert np.array_equal(raw, want) and raw.ctypes.data == recv.ctypes.data
+    assert [o['entries'] for o in outs] == [o['entries'] for o in ref] and outs[-1]['records_all'] is None
+    per_range = [o['records'].size for o in ref]
+    assert sizes[:, 0].tolist() == [sum(per_range[:2]), per_range[2], sum(per_range[3:])]
