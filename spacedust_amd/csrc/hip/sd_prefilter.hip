@@ -3236,6 +3236,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             SD_HIP(ctx, dKpCounts.alloc((size_t) JP_WGS * KP_BINS));
             SD_HIP(ctx, dKpTotal.alloc(KP_BINS));
             SD_HIP(ctx, dKpBase.alloc(KP_BINS + 1));
+            // (SD_JJ_WGS: fewer persistent workgroups of the join -- a smaller working set of index entries per XCD, for A/Bs)
+            const int jjWgs = getenv("SD_JJ_WGS") ? std::max(8, std::min(JJ_WGS, atoi(getenv("SD_JJ_WGS")) / 8 * 8)) : JJ_WGS;
             SD_HIP(ctx, dJqCounts.alloc((size_t) JJ_WGS * bq));
             SD_HIP(ctx, dQHits.alloc(bq));
             SD_HIP(ctx, dWgTotal.alloc(JJ_WGS));
@@ -3270,9 +3272,9 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
             const uint64_t *nSortedPtr = dKpBase.p + KP_BINS;
             {
                 ProfScope ps(ctx, "prefilter_join_count");
-                hipLaunchKernelGGL(join_count_kernel, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
+                hipLaunchKernelGGL(join_count_kernel, dim3(jjWgs), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
                                    (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, dJqCounts.p, (int) bq, dWgTotal.p);
-                hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor(bq, 64)), dim3(256), 0, ctx->stream, dJqCounts.p, JJ_WGS, (int) bq, dQHits.p);
+                hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor(bq, 64)), dim3(256), 0, ctx->stream, dJqCounts.p, jjWgs, (int) bq, dQHits.p);
             }
             // overflow of the reference's hit buffer, in k-mer ordinals
             hipLaunchKernelGGL(query_splits_join_kernel, dim3(bq), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQKmerBase.p,
@@ -3280,10 +3282,10 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                dQSplit.p, dQParts.p, dQSplits.p, dSplitFlag.p);
             hipLaunchKernelGGL(join_stats_kernel, dim3(gridFor(bq, 256)), dim3(256), 0, ctx->stream, bq, (const uint32_t *) dQKmerBase.p,
                                (const uint32_t *) dQHits.p, dStats.p);
-            std::vector<unsigned long long> hWg(JJ_WGS);
+            std::vector<unsigned long long> hWg((size_t) jjWgs);
             std::vector<uint32_t> hQHits(bq);
             int hSplitFlagJ = 0;
-            SD_HIP(ctx, sdD2H(ctx, hWg.data(), dWgTotal.p, JJ_WGS * sizeof(unsigned long long)));
+            SD_HIP(ctx, sdD2H(ctx, hWg.data(), dWgTotal.p, (size_t) jjWgs * sizeof(unsigned long long)));
             SD_HIP(ctx, sdD2H(ctx, hQHits.data(), dQHits.p, bq * sizeof(uint32_t)));
             SD_HIP(ctx, sdD2H(ctx, &hSplitFlagJ, dSplitFlag.p, sizeof(int)));
             SD_HIP(ctx, sdStreamSync(ctx));
@@ -3349,11 +3351,11 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 SD_HIP(ctx, dHitsKV.alloc(nHits));
                 {
                     ProfScope ps(ctx, "prefilter_join_count");
-                    hipLaunchKernelGGL((join_scatter_kernel<false, true, true>), dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p,
+                    hipLaunchKernelGGL((join_scatter_kernel<false, true, true>), dim3(jjWgs), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p,
                                        nSortedPtr, (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                        (const uint32_t *) nullptr, cols, (const uint64_t *) nullptr, tBits, (const uint32_t *) dQSplit.p,
                                        (uint2 *) nullptr, jcBits, dJrCounts.p);
-                    hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor((uint64_t) cols, 64)), dim3(256), 0, ctx->stream, dJrCounts.p, JJ_WGS, cols, dVQHits.p);
+                    hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor((uint64_t) cols, 64)), dim3(256), 0, ctx->stream, dJrCounts.p, jjWgs, cols, dVQHits.p);
                     SD_HIP(ctx, hipMemsetAsync(dVQHits.p + cols, 0, sizeof(uint32_t), ctx->stream));
                     int rcV = exclusiveScanWiden(ctx, dVQHits.p, dVQHitBase.p, (uint64_t) cols + 1, scanTmp);
                     if (rcV != SD_OK) return rcV;
@@ -3361,7 +3363,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 ProfScope ps(ctx, "prefilter_join_scatter");
                 static const bool ntStore = !(getenv("SD_JOIN_NT") && atoi(getenv("SD_JOIN_NT")) == 0);
                 auto kern = ntStore ? join_scatter_kernel<true, true, false> : join_scatter_kernel<false, true, false>;
-                hipLaunchKernelGGL(kern, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
+                hipLaunchKernelGGL(kern, dim3(jjWgs), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
                                    (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                    (const uint32_t *) dJrCounts.p, cols, (const uint64_t *) dVQHitBase.p, tBits,
                                    (const uint32_t *) dQSplit.p, dHitsKV.p, jcBits, (uint32_t *) nullptr);
@@ -3371,7 +3373,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 // SD_JOIN_NT=0: plain stores (partial lines of neighbouring runs merge in the XCD's L2 before they are written back)
                 static const bool ntStore = !(getenv("SD_JOIN_NT") && atoi(getenv("SD_JOIN_NT")) == 0);
                 auto kern = ntStore ? join_scatter_kernel<true, false, false> : join_scatter_kernel<false, false, false>;
-                hipLaunchKernelGGL(kern, dim3(JJ_WGS), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
+                hipLaunchKernelGGL(kern, dim3(jjWgs), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
                                    (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                    (const uint32_t *) dJqCounts.p, (int) bq, (const uint64_t *) dQHitBase.p, tBits,
                                    (const uint32_t *) dQSplit.p, dHitsKV.p, 0, (uint32_t *) nullptr);
