@@ -642,8 +642,8 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
 /* The same gather round by round behind a running search, instead of one blob per rank behind the last kernel (the reference's
  * merge starts when the last rank's files exist, M/src/prefiltering/Prefiltering.cpp:630-658).  The nRanges ranges of this rank's
  * sd_search_stream are grouped into nRounds rounds (roundOfRange[i], non-decreasing; e.g. the step of a range; ranks may hold
- * different numbers of ranges, also none, in a round -- nRounds must be the same on every rank).  sd_gather_stream_sink is an
- * sd_records_sink (sd_search_set_records_sink(s, sd_gather_stream_sink, g)): it appends a range's records to the communicator's
+ * different numbers of ranges, also none, in a round -- nRounds must be the same on every rank).  sd_gather_stream_sink has the
+ * sd_records_sink signature -- sd_search_set_records_sink(s, sd_gather_stream_sink, g) --: it appends a range's records to the communicator's
  * pinned send buffer (sd_comm_host_buffer(c, 0, ...) sizes it; records beyond it are staged in pageable memory), and when a round's
  * last range has arrived a worker thread runs that round's sd_gather_results on the communicator's stream while the search goes on.
  * On the root the rounds land back to back in outOnRoot (round 0: ranks 0 .. N-1, round 1: ...).  sd_gather_stream_end waits for the

@@ -439,7 +439,10 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, const uint64_t *__restr
                     const uint32_t *__restrict__ idxOffsets, const uint2 *__restrict__ entries, uint32_t nQ,
                     const uint32_t *__restrict__ prefix /* [JJ_WGS][cols]: hits of the workgroups before this one, per column (scatter) */,
                     int cols, const uint64_t *__restrict__ qHitBase /* per column */, int tBits, const uint32_t *__restrict__ qSplit,
-                    uint2 *__restrict__ outKV, int cBits, uint32_t *__restrict__ counts /* COUNT: [JJ_WGS][cols] */) {
+                    uint2 *__restrict__ outKV, int cBits, uint32_t *__restrict__ counts /* COUNT: [JJ_WGS][cols] */,
+                    uint8_t *__restrict__ outR6 /* nullable (plain scatter): the top six target bits of every hit, at the hit's position --
+                                                   what the coarse split's count pass reads instead of the 8-byte hits */,
+                    int r6Shift) {
     __shared__ uint32_t qcur[RANGES ? JX_COLS_MAX : JQ_MAX];   // this workgroup's write position inside every column's segment (< 2^32 hits per sub-batch)
     constexpr int WE = 64 * JE;   // k-mers per wavefront and step
     __shared__ uint32_t wOff[JJ_NT / 64][WE + 1], wStart[JJ_NT / 64][WE], wKey[JJ_NT / 64][WE], wVal[JJ_NT / 64][WE];
@@ -612,6 +615,7 @@ join_scatter_kernel(const uint64_t *__restrict__ sorted, const uint64_t *__restr
                     const unsigned long long kv = ((unsigned long long) (((((v >> 24) - en[j].y) & 0xFFu) << 24) | (v & 0xFFFFFFu)) << 32) | (kq | en[j].x);
                     if (NT_STORE) __builtin_nontemporal_store(kv, (unsigned long long *) outKV + pos);
                     else ((unsigned long long *) outKV)[pos] = kv;
+                    if (!RANGES && outR6) outR6[pos] = (uint8_t) ((en[j].x >> r6Shift) & 63u);
                 }
             }
         }

@@ -1073,9 +1073,21 @@ __device__ __forceinline__ uint32_t cpQueryOfSeg(uint32_t seg, uint32_t nQ, cons
     return lo;
 }
 
+// target ranges per query for a sub-batch whose average query has avgQ hits (0: no split); see the comments where it is applied
+inline int coarseBitsFor(uint64_t avgQ, int tBits) {
+    const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 200000;
+    const uint64_t perVQsplit = getenv("SD_PF_COARSE") ? perVQ : (getenv("SD_PF_COARSE_SPLIT") ? (uint64_t) atoll(getenv("SD_PF_COARSE_SPLIT")) : 50000);
+    int cBits = 0;
+    if (avgQ > perVQ)
+        while (cBits < CP_MAX_BITS && tBits - (cBits + 1) >= 8 && (avgQ >> cBits) > perVQsplit) cBits++;
+    return cBits;
+}
+
 __global__ void __launch_bounds__(256)
 coarse_count_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const uint32_t *__restrict__ segBase, int tBits, int cBits,
-                    const uint32_t *__restrict__ inKey, const uint2 *__restrict__ inKV, uint32_t *__restrict__ segCount /* [segment][C] */) {
+                    const uint32_t *__restrict__ inKey, const uint2 *__restrict__ inKV, uint32_t *__restrict__ segCount /* [segment][C] */,
+                    const uint8_t *__restrict__ inR6 /* nullable: the hits' top six target bits, one byte per hit (written by the join's
+                                                        scatter): 1 B per hit read here instead of 8 */) {
     __shared__ uint32_t hist[1 << CP_MAX_BITS];
     const uint32_t seg = blockIdx.x;
     const uint32_t q = cpQueryOfSeg(seg, nQ, segBase);
@@ -1086,6 +1098,18 @@ coarse_count_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const ui
     __syncthreads();
     const uint32_t tMask = (1u << tBits) - 1;
     const int shift = tBits - cBits;
+    if (inR6) {   // four hits per 32-bit load (the array is 4-byte aligned and padded; a segment starts anywhere)
+        const int down = CP_MAX_BITS - cBits;
+        for (uint64_t w = (s & ~3ull) + 4ull * threadIdx.x; w < e; w += 1024) {
+            const uint32_t v = *(const uint32_t *) (inR6 + w);
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (w + b >= s && w + b < e) atomicAdd(&hist[((v >> (8 * b)) & 0xFFu) >> down], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < C) segCount[(size_t) seg * C + threadIdx.x] = hist[threadIdx.x];
+        return;
+    }
     // (one load per thread and iteration, one LDS atomic per lane: a version with 8 loads in flight and one atomic per group of
     // lanes with the same range was 1.7 ms per 8 192 queries slower on the same box)
     for (uint64_t i = s + threadIdx.x; i < e; i += 256) atomicAdd(&hist[((inKV ? inKV[i].x : inKey[i]) & tMask) >> shift], 1u);
@@ -3217,6 +3241,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
         WsView<uint64_t> dElems(ctx, "pf.dElems");
         WsView<uint64_t> dSorted(ctx, "pf.dSorted");
         WsView<uint2> dHitsKV(ctx, "pf.dHitsKV");
+        WsView<uint8_t> dHitR6(ctx, "pf.dHitR6");   // join path: a byte per hit for the coarse split's count pass (nullptr: not written)
         WsView<uint64_t> dQHitBase(ctx, "pf.dQHitBase");   // hits of query q start at dQHitBase[q] (either path)
         WsView<uint64_t> dVQHitBase(ctx, "pf.dVQHitBase");  // with a split into target ranges: hits of (query, range) start here
         int jcBits = 0;   // join path: the scatter wrote (query, target range) sub-segments of 2^jcBits ranges per query
@@ -3354,7 +3379,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     hipLaunchKernelGGL((join_scatter_kernel<false, true, true>), dim3(jjWgs), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p,
                                        nSortedPtr, (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                        (const uint32_t *) nullptr, cols, (const uint64_t *) nullptr, tBits, (const uint32_t *) dQSplit.p,
-                                       (uint2 *) nullptr, jcBits, dJrCounts.p);
+                                       (uint2 *) nullptr, jcBits, dJrCounts.p, (uint8_t *) nullptr, 0);
                     hipLaunchKernelGGL(col_prefix_kernel, dim3(gridFor((uint64_t) cols, 64)), dim3(256), 0, ctx->stream, dJrCounts.p, jjWgs, cols, dVQHits.p);
                     SD_HIP(ctx, hipMemsetAsync(dVQHits.p + cols, 0, sizeof(uint32_t), ctx->stream));
                     int rcV = exclusiveScanWiden(ctx, dVQHits.p, dVQHitBase.p, (uint64_t) cols + 1, scanTmp);
@@ -3366,9 +3391,15 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 hipLaunchKernelGGL(kern, dim3(jjWgs), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
                                    (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                    (const uint32_t *) dJrCounts.p, cols, (const uint64_t *) dVQHitBase.p, tBits,
-                                   (const uint32_t *) dQSplit.p, dHitsKV.p, jcBits, (uint32_t *) nullptr);
+                                   (const uint32_t *) dQSplit.p, dHitsKV.p, jcBits, (uint32_t *) nullptr, (uint8_t *) nullptr, 0);
             } else if (nHits > 0) {
                 SD_HIP(ctx, dHitsKV.alloc(nHits));
+                // the coarse split's count pass needs a hit's range and nothing else: one byte per hit beside the 8-byte stream (the top
+                // six target bits: any split of up to 2^6 ranges reads its range off them) -- 1.5 MB per query written here for 12.3 MB
+                // per query not read there (SD_PF_R6=0: the count pass reads the hits)
+                if (tBits >= CP_MAX_BITS + 8 && coarseBitsFor(nHits / std::max<uint32_t>(bq, 1), tBits) > 0 &&
+                    !(getenv("SD_PF_R6") && atoi(getenv("SD_PF_R6")) == 0))
+                    SD_HIP(ctx, dHitR6.alloc(nHits + 8));
                 ProfScope ps(ctx, "prefilter_join_scatter");
                 // SD_JOIN_NT=0: plain stores (partial lines of neighbouring runs merge in the XCD's L2 before they are written back)
                 static const bool ntStore = !(getenv("SD_JOIN_NT") && atoi(getenv("SD_JOIN_NT")) == 0);
@@ -3376,7 +3407,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                 hipLaunchKernelGGL(kern, dim3(jjWgs), dim3(JJ_NT), 0, ctx->stream, (const uint64_t *) dSorted.p, nSortedPtr,
                                    (const uint16_t *) dChunkBin.p, (const uint32_t *) T->dOffsets, (const uint2 *) T->dEntries, bq,
                                    (const uint32_t *) dJqCounts.p, (int) bq, (const uint64_t *) dQHitBase.p, tBits,
-                                   (const uint32_t *) dQSplit.p, dHitsKV.p, 0, (uint32_t *) nullptr);
+                                   (const uint32_t *) dQSplit.p, dHitsKV.p, 0, (uint32_t *) nullptr, dHitR6.p, tBits - CP_MAX_BITS);
             }
             SD_HIP(ctx, hipGetLastError());
         }
@@ -3498,6 +3529,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     // at most 10^5 hits: the filter's Bloom rounds, the partition and the bucket sort all run on half-size segments for one more
                     // level of the (cheap, streaming) split -- isolated prefilter at 1 000 proteomes 443 -> 390 ms per 8 192 queries, +4 % end
                     // to end; at 100 proteomes (1.5 * 10^5 hits per query) a split would only add its 24 B per hit (1 915 -> 1 767)
+                    // (coarseBitsFor below is this rule; the join's scatter asks it whether a split will follow)
                     const uint64_t perVQ = getenv("SD_PF_COARSE") ? (uint64_t) atoll(getenv("SD_PF_COARSE")) : 200000;
                     // Round 6: ranges of at most 5 * 10^4 hits (SD_PF_COARSE_SPLIT; 10^5 until then) -- 32 ranges at 1 000 proteomes.  The filter's
                     // Bloom filter then has twice the bits per key: 7.2 % of the hit stream left instead of 12.3 % (4.7 % at 2.5 * 10^4), and what
@@ -3509,8 +3541,8 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                     // were tried on top and removed: 7.4 % left instead of 7.2 %, the kernel 8 ms slower; what passes the filter at this
                     // granularity are targets that do have two hits on one diagonal byte, profiles/r06x_hf_multi.txt.)
                     const uint64_t perVQsplit = getenv("SD_PF_COARSE") ? perVQ : (getenv("SD_PF_COARSE_SPLIT") ? (uint64_t) atoll(getenv("SD_PF_COARSE_SPLIT")) : 50000);
-                    if (avgQ > perVQ)
-                        while (cBits < CP_MAX_BITS && tBits0 - (cBits + 1) >= 8 && (avgQ >> cBits) > perVQsplit) cBits++;
+                    (void) perVQsplit;
+                    cBits = coarseBitsFor(avgQ, tBits0);
                     // wide stream positions need the split: it is where the diagonal byte moves into the key (8 free bits)
                     while (widePos && cBits < CP_MAX_BITS && tBits - (cBits + 1) >= 8 && (cBits < 1 || tBits - cBits > 24)) cBits++;
                     if (widePos && (cBits < 1 || tBits - cBits > 24))
@@ -3544,7 +3576,7 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                         SD_HIP(ctx, hipMemcpyAsync(dSegBase.p, hSegBase, (nVQ0 + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
                         if (nSeg > 0)
                             hipLaunchKernelGGL(coarse_count_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, tBits0,
-                                               cBits, dKeyA.p, pKV, dSegCount.p);
+                                               cBits, dKeyA.p, pKV, dSegCount.p, useJoin ? (const uint8_t *) dHitR6.p : (const uint8_t *) nullptr);
                         hipLaunchKernelGGL(coarse_offsets_kernel, dim3(nVQ0), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, cBits,
                                            dSegCount.p, dVQHitBase.p);
                         if (nSeg > 0)
