@@ -304,3 +304,35 @@ def test_gather_round_by_round_behind_the_stream_equals_the_final_gather(gpu):
     assert [o['entries'] for o in outs] == [o['entries'] for o in ref] and outs[-1]['records_all'] is None
     per_range = [o['records'].size for o in ref]
     assert sizes[:, 0].tolist() == [sum(per_range[:2]), per_range[2], sum(per_range[3:])]
+
+
+def test_bench_line_of_the_multi_gpu_path_is_one_json_line(gpu, tmp_path):
+    """bench.py through its N > 1 code path with the one rank a one-GPU box allows (SD_BENCH_FORCE_DIST=1: RCCL communicator, pinned
+    staging, the gather round by round behind the stream, the TSV from the gathered buffer) on a small workload: stdout is exactly one
+    JSON line (RCCL prints its banner to the process's stdout), it carries the driver's keys, and the gathered records reproduce the
+    results' cluster counters; the same with the one-blob gather at the end (SD_BENCH_GATHER_STREAM=0)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ('1', '0'):
+        env = dict(os.environ, SD_BENCH_FORCE_DIST='1', SD_BENCH_GATHER_STREAM=mode, MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(29650 + int(mode)))
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--proteomes', '24',
+                            '--genes', '300', '--batch', '3', '--no-cpu', '--no-children', '--no-index-check',
+                            '--detail-out', str(tmp_path / ('detail%s.json' % mode))],
+                           cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert r.returncode == 0, r.stderr.decode(errors='replace')[-3000:]
+        out = r.stdout.decode()
+        assert out.endswith('\n') and out.count('\n') == 1, out[:400]
+        d = json.loads(out)
+        for k_ in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                   'data', 'config', 'roofline'):
+            assert k_ in d, k_
+        assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['unit'] == 'genome-pairs/s'
+        g = d['gather']
+        assert g['bytes'] > 0 and g['tsv']['clusters_match_results'] and g['tail_frac_of_timed_region'] is not None
+        assert ('sd_gather_stream' in g['how']) == (mode == '1')
+        got[mode] = (g['bytes'], g['tsv']['clusters'], g['tsv']['hits'], d['results']['clusters'])
+    assert got['1'] == got['0']
