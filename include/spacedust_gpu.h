@@ -655,6 +655,13 @@ int sd_gather_stream_begin(sd_comm *c, int root, uint32_t nRanges, const uint32_
                            uint64_t outCap, sd_gather_stream **out);
 void sd_gather_stream_sink(void *gatherStream, uint32_t range, const void *records, uint64_t bytes);
 int sd_gather_stream_end(sd_gather_stream *g, uint64_t *roundOffsets, uint64_t *sizes, uint64_t *totalOnRoot);
+/* outOnRoot == NULL in a _begin call: the root's buffer belongs to the stream and grows round by round (over RCCL the ranks repeat a
+ * round whose records did not fit -- SD_ENOMEM is agreed on before any payload moves; over TCP the byte counts are gathered first).
+ * sd_gather_stream_wait = _end without freeing the object: *dataOnRoot (nullable) is the root's buffer, valid until
+ * sd_gather_stream_destroy.  sd_gather_stream_begin_tcp: the same stream over the TCP rendezvous (root 0; ranks that share a device,
+ * which RCCL refuses -- one-GPU test rigs; `sdgpu clustersearch` picks the transport the way its final gather did). */
+int sd_gather_stream_wait(sd_gather_stream *g, uint64_t *roundOffsets, uint64_t *sizes, uint64_t *totalOnRoot, const void **dataOnRoot);
+void sd_gather_stream_destroy(sd_gather_stream *g);
 /* Host-side rendezvous of the ranks over TCP (addr / port as a one-process-per-GPU launcher's MASTER_ADDR / MASTER_PORT; every
  * rank connects to rank 0 once, the calls are matched in program order): sd_tcp_bcast hands rank 0's buffer (the 128-byte
  * unique id) to every rank; sd_tcp_gather is the gatherv of byte records to rank 0 for ranks that share a device -- RCCL
@@ -667,6 +674,8 @@ int sd_tcp_bcast(sd_tcp *t, void *buf, uint64_t bytes);
 /* sizes[nRanks] and the concatenated records on rank 0; outCap too small: SD_ENOMEM there with *outBytes = the size needed
  * (the records are consumed either way: gather the byte counts first) */
 int sd_tcp_gather(sd_tcp *t, const void *local, uint64_t nBytes, uint64_t *sizes, void *outOnRoot, uint64_t outCap, uint64_t *outBytes);
+int sd_gather_stream_begin_tcp(sd_tcp *t, int nRanks, int rank, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
+                               uint64_t outCap, sd_gather_stream **out);
 
 
 /* ---- result2profile: alignment DB -> profile DB between the iterations of `search --num-iterations` (SURVEY.md 8(f).3;

@@ -339,12 +339,73 @@ int runSearch(const Args &a, bool withClusters) {
         sinks.wantPref = sinks.wantAln = true;
         sd_search_set_sinks(S.s, Sinks::onPref, Sinks::onAln, &sinks);
     }
+    // the ranks meet over TCP at MASTER_ADDR:MASTER_PORT+1: the RCCL unique id (clustersearch), the merge of the per-rank DBs
+    sd_tcp *tcp = nullptr;
+    struct TcpClose {
+        sd_tcp *&t;
+        ~TcpClose() { if (t) sd_tcp_close(t); }
+    } tcpClose{tcp};
+    // The one exchange of the path: every rank's cluster records to rank 0, which writes the TSV from the gathered buffer -- round by
+    // round behind the running search (sd_gather_stream_*: a rank's ranges in eight rounds; the records of a range leave through the
+    // stream's records sink when the range is finalised).  Over RCCL (sd_gather_results per round); ranks that share a device -- RCCL
+    // refuses that, a one-GPU test rig -- hand their records over the TCP rendezvous instead.
+    sd_comm *comm = nullptr;
+    sd_gather_stream *gstream = nullptr;
+    struct GatherClose {   // (declared behind tcpClose: destroyed first -- the worker thread uses the socket / the communicator)
+        sd_gather_stream *&g;
+        sd_comm *&c;
+        ~GatherClose() {
+            if (g) sd_gather_stream_destroy(g);
+            if (c) sd_comm_destroy(c);
+        }
+    } gatherClose{gstream, comm};
+    bool sharedDevice = false;
+    if (world > 1) {
+        const char *addrEnv = getenv("MASTER_ADDR");
+        const std::string addr = addrEnv && *addrEnv ? addrEnv : "127.0.0.1";
+        const int port = (int) a.integer("--comm-port", envInt("MASTER_PORT", 29500) + 1);
+        if (sd_tcp_connect(addr.c_str(), port, world, rank, &tcp) != SD_OK)
+            return fail("rendezvous of the ranks at " + addr + ":" + std::to_string(port) + " failed");
+    }
+    if (world > 1 && withClusters) {
+        // the physical GPU of every rank (host name + PCI bus id, not the local ordinal: ranks on different nodes, or ranks that
+        // each see their GPU as device 0 through HIP_VISIBLE_DEVICES, are not sharing) -> does each rank have a GPU of its own?
+        uint64_t gpuId = 0;
+        if (sd_device_identity(device, &gpuId) != SD_OK) return fail("sd_device_identity failed");
+        int32_t devs[2] = {(int32_t) (uint32_t) gpuId, (int32_t) (uint32_t) (gpuId >> 32)};
+        std::vector<int32_t> allDevs((size_t) world * 2, 0);
+        uint64_t got = 0;
+        if (sd_tcp_gather(tcp, devs, sizeof(devs), nullptr, allDevs.data(), allDevs.size() * sizeof(int32_t), &got) != SD_OK)
+            return fail("rendezvous of the ranks failed (devices)");
+        int32_t shared = 0;
+        if (rank == 0)
+            for (int x = 0; x < world; x++)
+                for (int y = 0; y < x; y++)
+                    if (allDevs[(size_t) x * 2] == allDevs[(size_t) y * 2] && allDevs[(size_t) x * 2 + 1] == allDevs[(size_t) y * 2 + 1]) shared = 1;
+        if (sd_tcp_bcast(tcp, &shared, sizeof(shared)) != SD_OK) return fail("rendezvous of the ranks failed");
+        sharedDevice = shared != 0;
+        constexpr uint32_t GATHER_ROUNDS = 8;
+        std::vector<uint32_t> roundOfRange(rb.size());
+        for (size_t i = 0; i < rb.size(); i++) roundOfRange[i] = (uint32_t) (i * GATHER_ROUNDS / rb.size());
+        if (!sharedDevice) {
+            char uid[128];
+            if (rank == 0 && sd_comm_unique_id(uid) != SD_OK) return fail("sd_comm_unique_id failed (librccl not loadable?)");
+            if (sd_tcp_bcast(tcp, uid, sizeof(uid)) != SD_OK) return fail("broadcast of the RCCL unique id failed");
+            if (sd_comm_init(device, world, rank, uid, &comm) != SD_OK) return fail("sd_comm_init failed");
+            rc = sd_gather_stream_begin(comm, 0, (uint32_t) rb.size(), roundOfRange.data(), GATHER_ROUNDS, nullptr, 0, &gstream);
+        } else {
+            rc = sd_gather_stream_begin_tcp(tcp, world, rank, (uint32_t) rb.size(), roundOfRange.data(), GATHER_ROUNDS, nullptr, 0, &gstream);
+        }
+        if (rc != SD_OK) return fail("sd_gather_stream_begin failed (" + std::to_string(rc) + ")");
+        sd_search_set_records_sink(S.s, sd_gather_stream_sink, gstream);
+    }
     std::vector<sd_search_result *> results(std::max<size_t>(rb.size(), 1), nullptr);
     if (!rb.empty()) {
         // the TSV (this rank's, or rank 0's from the gathered buffers) is written from the cluster records: the stream builds them range by
         // range while its lanes work (sd_search_result_records below is then a copy, not a second pass over every entry's hits)
         if (withClusters) sd_search_set_want_records(S.s, 1);
         rc = sd_search_stream(S.s, &qv.view, sameDb ? 1 : 0, (uint32_t) rb.size(), rb.data(), re.data(), results.data());
+        sd_search_set_records_sink(S.s, nullptr, nullptr);
         if (rc != SD_OK) return fail(std::string("sd_search_stream: ") + sd_search_last_error(S.s));
     }
     struct Free {
@@ -355,18 +416,15 @@ int runSearch(const Args &a, bool withClusters) {
         if (sinks.failed) return fail("writing the prefilter / alignment DB failed");
         if (!sinks.pref.close(&err) || !sinks.aln.close(&err)) return fail(err);
     }
-    // the ranks meet over TCP at MASTER_ADDR:MASTER_PORT+1: merge of the per-rank DBs, and (clustersearch) the RCCL unique id
-    sd_tcp *tcp = nullptr;
-    struct TcpClose {
-        sd_tcp *&t;
-        ~TcpClose() { if (t) sd_tcp_close(t); }
-    } tcpClose{tcp};
+    // (the gather's last rounds: the socket / the communicator are the worker thread's until then)
+    const void *gathered = nullptr;
+    uint64_t gatheredBytes = 0;
+    if (gstream) {
+        rc = sd_gather_stream_wait(gstream, nullptr, nullptr, &gatheredBytes, &gathered);
+        if (rc != SD_OK) return fail("the gather of the cluster records failed (" + std::to_string(rc) + ")" + (comm ? std::string(": ") + sd_comm_last_error(comm) : std::string()));
+        info(a, "records gathered %s: %llu bytes from %d ranks\n", sharedDevice ? "over TCP (ranks share a device)" : "over RCCL", (unsigned long long) gatheredBytes, world);
+    }
     if (world > 1) {
-        const char *addrEnv = getenv("MASTER_ADDR");
-        const std::string addr = addrEnv && *addrEnv ? addrEnv : "127.0.0.1";
-        const int port = (int) a.integer("--comm-port", envInt("MASTER_PORT", 29500) + 1);
-        if (sd_tcp_connect(addr.c_str(), port, world, rank, &tcp) != SD_OK)
-            return fail("rendezvous of the ranks at " + addr + ":" + std::to_string(port) + " failed");
         if (dbs) {   // every rank's DB parts are closed: rank 0 makes them one DB (split data files, one index)
             uint8_t done = 1;
             std::vector<uint8_t> allDone((size_t) world, 0);
@@ -399,79 +457,33 @@ int runSearch(const Args &a, bool withClusters) {
         packNames(qs.sourceOfSet, qsrc, qso);
         packNames(tsP->sourceOfSet, tsrc, tso);
     }
-    // this rank's cluster records (every range's clusters, in range order)
+    // one rank: its cluster records (every range's clusters, in range order); several: what the gather brought to rank 0
     std::vector<char> rec;
-    for (size_t r = 0; r < rb.size(); r++) {
-        uint64_t need = 0;
-        rc = sd_search_result_records(results[r], nullptr, 0, &need);
-        if (rc != SD_OK) return fail("sd_search_result_records failed (" + std::to_string(rc) + ")");
-        const size_t at = rec.size();
-        rec.resize(at + need);
-        rc = sd_search_result_records(results[r], rec.data() + at, need, &need);
-        if (rc != SD_OK) return fail("sd_search_result_records failed (" + std::to_string(rc) + ")");
-    }
-    std::vector<char> all;
-    const std::vector<char> *toWrite = &rec;
-    if (world > 1) {
-        // The one exchange of the path: every rank's records to rank 0 (RCCL: sd_gather_results), which writes the TSV from the
-        // gathered buffer.  The ranks meet over TCP at MASTER_ADDR:MASTER_PORT+1 (the RCCL unique id travels that way); ranks
-        // that share a device -- RCCL refuses that, a one-GPU test rig -- hand their records over the same socket path instead.
-        std::vector<uint64_t> sizes((size_t) world, 0);
-        // the physical GPU of every rank (host name + PCI bus id, not the local ordinal: ranks on different nodes, or ranks that
-        // each see their GPU as device 0 through HIP_VISIBLE_DEVICES, are not sharing) -> does each rank have a GPU of its own?
-        uint64_t gpuId = 0;
-        if (sd_device_identity(device, &gpuId) != SD_OK) return fail("sd_device_identity failed");
-        int32_t devs[2] = {(int32_t) (uint32_t) gpuId, (int32_t) (uint32_t) (gpuId >> 32)};
-        std::vector<int32_t> allDevs((size_t) world * 2, 0);
-        uint64_t got = 0;
-        if (sd_tcp_gather(tcp, devs, sizeof(devs), nullptr, allDevs.data(), allDevs.size() * sizeof(int32_t), &got) != SD_OK)
-            return fail("rendezvous of the ranks failed (devices)");
-        int32_t shared = 0;
-        if (rank == 0)
-            for (int x = 0; x < world; x++)
-                for (int y = 0; y < x; y++)
-                    if (allDevs[(size_t) x * 2] == allDevs[(size_t) y * 2] && allDevs[(size_t) x * 2 + 1] == allDevs[(size_t) y * 2 + 1]) shared = 1;
-        if (sd_tcp_bcast(tcp, &shared, sizeof(shared)) != SD_OK) return fail("rendezvous of the ranks failed");
-        uint64_t total = 0;
-        if (!shared) {
-            char uid[128];
-            if (rank == 0 && sd_comm_unique_id(uid) != SD_OK) return fail("sd_comm_unique_id failed (librccl not loadable?)");
-            if (sd_tcp_bcast(tcp, uid, sizeof(uid)) != SD_OK) return fail("broadcast of the RCCL unique id failed");
-            sd_comm *comm = nullptr;
-            if (sd_comm_init(device, world, rank, uid, &comm) != SD_OK) return fail("sd_comm_init failed");
-            rc = sd_gather_results(comm, rec.data(), rec.size(), 0, sizes.data(), nullptr, 0, &total);   // size probe
-            if (rc == SD_ENOMEM) {
-                if (rank == 0) all.resize(total);
-                rc = sd_gather_results(comm, rec.data(), rec.size(), 0, sizes.data(), all.data(), all.size(), &total);
-            }
-            if (rc != SD_OK) {
-                const std::string why = sd_comm_last_error(comm);
-                sd_comm_destroy(comm);
-                return fail("sd_gather_results failed (" + std::to_string(rc) + "): " + why);
-            }
-            sd_comm_destroy(comm);
-            info(a, "records gathered over RCCL: %llu bytes from %d ranks\n", (unsigned long long) total, world);
-        } else {
-            uint64_t mine = rec.size();
-            std::vector<uint64_t> allSizes((size_t) world, 0);
-            if (sd_tcp_gather(tcp, &mine, sizeof(mine), nullptr, allSizes.data(), allSizes.size() * sizeof(uint64_t), &got) != SD_OK)
-                return fail("gather of the record sizes failed");
-            if (rank == 0)
-                for (uint64_t v : allSizes) total += v;
-            if (rank == 0) all.resize(total);
-            if (sd_tcp_gather(tcp, rec.data(), rec.size(), sizes.data(), all.data(), all.size(), &total) != SD_OK)
-                return fail("gather of the records failed");
-            info(a, "ranks share a device: records gathered over TCP (%llu bytes)\n", (unsigned long long) total);
+    const char *toWrite = nullptr;
+    uint64_t toWriteBytes = 0;
+    if (world == 1) {
+        for (size_t r = 0; r < rb.size(); r++) {
+            uint64_t need = 0;
+            rc = sd_search_result_records(results[r], nullptr, 0, &need);
+            if (rc != SD_OK) return fail("sd_search_result_records failed (" + std::to_string(rc) + ")");
+            const size_t at = rec.size();
+            rec.resize(at + need);
+            rc = sd_search_result_records(results[r], rec.data() + at, need, &need);
+            if (rc != SD_OK) return fail("sd_search_result_records failed (" + std::to_string(rc) + ")");
         }
-        toWrite = &all;
+        toWrite = rec.data();
+        toWriteBytes = rec.size();
+    } else {
+        toWrite = (const char *) gathered;
+        toWriteBytes = gatheredBytes;
     }
     uint64_t nClu = 0, nHit = 0;
     if (rank == 0) {
         // (gathered records came over the wire: indices are checked against the tables they will index)
-        rc = sd_records_check(toWrite->data(), toWrite->size(), (uint32_t) (qso.size() - 1), (uint32_t) (tso.size() - 1), (uint32_t) (qno.size() - 1),
+        rc = sd_records_check(toWrite, toWriteBytes, (uint32_t) (qso.size() - 1), (uint32_t) (tso.size() - 1), (uint32_t) (qno.size() - 1),
                               (uint32_t) (tno.size() - 1), nullptr, nullptr);
         if (rc != SD_OK) return fail("the gathered cluster records are truncated or index outside the name tables");
-        rc = sd_records_write_tsv(toWrite->data(), toWrite->size(), a.pos[2].c_str(), 0, 0, qn.data(), qno.data(), tn.data(), tno.data(),
+        rc = sd_records_write_tsv(toWrite, toWriteBytes, a.pos[2].c_str(), 0, 0, qn.data(), qno.data(), tn.data(), tno.data(),
                                   qsrc.data(), qso.data(), tsrc.data(), tso.data(), 0, &nClu, &nHit);
         if (rc != SD_OK) return fail("sd_records_write_tsv failed (" + std::to_string(rc) + ")");
         info(a, "%llu clusters with %llu hits written\n", (unsigned long long) nClu, (unsigned long long) nHit);

@@ -299,15 +299,17 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
 // runs exactly nRounds gathers in round order (a round without ranges on this rank sends 0 bytes), so the collectives match.  On
 // the root the rounds land back to back in outOnRoot: round 0's records of rank 0 .. N-1, round 1's, ...
 struct sd_gather_stream {
-    sd_comm *c = nullptr;
-    int root = 0;
+    sd_comm *c = nullptr;   // the RCCL communicator, or
+    sd_tcp *tcp = nullptr;  // the TCP rendezvous (ranks that share a device: root 0)
+    int root = 0, nRanks = 1, rank = 0;
     uint32_t nRanges = 0, nRounds = 0;
     std::vector<uint32_t> rangesThrough;   // [nRounds]: ranges of rounds 0 .. r
-    char *out = nullptr;
+    char *out = nullptr;                   // the caller's buffer on the root, or (ownOut) owned.data()
     uint64_t outCap = 0, outUsed = 0;
-    std::vector<uint64_t> rangeEnd;        // send-buffer offset behind range i (in arrival order)
+    bool ownOut = false;                   // no buffer given: the root's buffer grows round by round
+    std::vector<char> owned;
     std::vector<char> overflow;            // a round that does not fit the pinned send buffer is staged here (pageable: slower, never wrong)
-    uint64_t sendUsed = 0;                 // bytes of the send buffer handed out so far (rounds already gathered are reused)
+    uint64_t sendUsed = 0;                 // bytes of the send buffer handed out so far
     uint64_t roundBase = 0;                // send-buffer offset of the current round's first byte
     bool roundInOverflow = false;
     struct Round { uint64_t off, bytes; bool inOverflow; std::vector<char> own; };
@@ -319,6 +321,47 @@ struct sd_gather_stream {
     std::mutex mu;
     std::condition_variable cv;
     std::thread worker;
+    char *sendBuf() const { return c ? (char *) c->hostBuf[0] : nullptr; }
+    uint64_t sendCap() const { return c ? c->hostCap[0] : 0; }
+    bool grow(uint64_t need) {   // root, ownOut: room for `need` more bytes behind outUsed
+        if (outUsed + need <= owned.size()) return true;
+        try {
+            owned.resize(std::max<uint64_t>(outUsed + need, owned.size() + owned.size() / 2));
+        } catch (const std::bad_alloc &) {
+            return false;
+        }
+        out = owned.data();
+        outCap = owned.size();
+        return true;
+    }
+    // one round over RCCL: when the root's room is too small every rank learns the size (SD_ENOMEM is agreed on before any payload
+    // moves); with a buffer of its own the root grows it and every rank repeats the collective
+    int roundRccl(const char *src, uint64_t bytes, uint64_t *szs, uint64_t *total) {
+        int rc = sd_gather_results(c, src, bytes, root, szs, rank == root ? out + outUsed : nullptr, rank == root ? outCap - outUsed : 0, total);
+        if (rc == SD_ENOMEM && ownOut) {
+            const bool ok = rank != root || grow(*total);
+            rc = sd_gather_results(c, src, bytes, root, szs, rank == root && ok ? out + outUsed : nullptr, rank == root && ok ? outCap - outUsed : 0, total);
+        }
+        return rc;
+    }
+    // one round over the TCP rendezvous: sd_tcp_gather consumes the records whatever the root's room, so a root with a buffer of its own
+    // gathers the byte counts first
+    int roundTcp(const char *src, uint64_t bytes, uint64_t *szs, uint64_t *total) {
+        bool room = true;
+        if (ownOut) {
+            std::vector<uint64_t> all((size_t) nRanks, 0);
+            uint64_t got = 0;
+            const int rc = sd_tcp_gather(tcp, &bytes, sizeof(bytes), nullptr, all.data(), all.size() * sizeof(uint64_t), &got);
+            if (rc != SD_OK) return rc;
+            if (rank == 0) {
+                uint64_t need = 0;
+                for (uint64_t v : all) need += v;
+                room = grow(need);   // (without room the payload round still runs: the peers are already sending)
+            }
+        }
+        const int rc = sd_tcp_gather(tcp, src, bytes, szs, rank == 0 && room ? out + outUsed : nullptr, rank == 0 && room ? outCap - outUsed : 0, total);
+        return room || rc == SD_EHIP ? rc : SD_ENOMEM;
+    }
     void run() {
         for (uint32_t r = 0; r < nRounds; r++) {
             Round rd;
@@ -329,40 +372,50 @@ struct sd_gather_stream {
                 else rd = Round{0, 0, false, {}};   // closed early: the ranks still run the same number of collectives
             }
             roundOff[r] = outUsed;
-            if (status != SD_OK) continue;   // (every rank saw the same code in the same round: nobody calls the collective again)
-            const char *src = rd.bytes == 0 ? nullptr : rd.inOverflow ? rd.own.data() : (const char *) c->hostBuf[0] + rd.off;
+            // RCCL: every rank saw the same code in the same round, nobody calls the collective again.  TCP: only the root knows; it keeps
+            // consuming what the others send (with no room: the records are dropped, the first code stands)
+            if (status != SD_OK && c) continue;
+            const char *src = rd.bytes == 0 ? nullptr : rd.inOverflow ? rd.own.data() : sendBuf() + rd.off;
             uint64_t total = 0;
-            const int rc = sd_gather_results(c, src, rd.bytes, root, sizes.data() + (size_t) r * c->nRanks, c->rank == root ? out + outUsed : nullptr,
-                                             c->rank == root ? outCap - outUsed : 0, &total);
+            uint64_t *szs = sizes.data() + (size_t) r * nRanks;
+            int rc;
+            if (c) rc = roundRccl(src, rd.bytes, szs, &total);
+            else if (status != SD_OK) rc = sd_tcp_gather(tcp, src, rd.bytes, nullptr, nullptr, 0, &total) == SD_EHIP ? SD_EHIP : status;
+            else rc = roundTcp(src, rd.bytes, szs, &total);
             if (rc != SD_OK) {
                 std::lock_guard<std::mutex> lk(mu);
-                status = rc;
+                if (status == SD_OK) status = rc;
                 continue;
             }
-            outUsed += total;
+            if (rank == root) outUsed += total;
         }
         roundOff[nRounds] = outUsed;
     }
 };
 
-int sd_gather_stream_begin(sd_comm *c, int root, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
-                           uint64_t outCap, sd_gather_stream **out) {
-    if (!c || !out || root < 0 || root >= c->nRanks || (nRanges && !roundOfRange) || nRounds == 0) return SD_EINVAL;
+namespace {
+int gatherStreamBegin(sd_comm *c, sd_tcp *tcp, int nRanks, int rank, int root, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds,
+                      void *outOnRoot, uint64_t outCap, sd_gather_stream **out) {
+    if (!out || root < 0 || root >= nRanks || rank < 0 || rank >= nRanks || (nRanges && !roundOfRange) || nRounds == 0) return SD_EINVAL;
     for (uint32_t i = 0; i < nRanges; i++)
         if (roundOfRange[i] >= nRounds || (i && roundOfRange[i] < roundOfRange[i - 1])) return SD_EINVAL;
     sd_gather_stream *g = new sd_gather_stream();
     g->c = c;
+    g->tcp = tcp;
+    g->nRanks = nRanks;
+    g->rank = rank;
     g->root = root;
     g->nRanges = nRanges;
     g->nRounds = nRounds;
     g->rangesThrough.assign(nRounds, 0);
     for (uint32_t i = 0; i < nRanges; i++) g->rangesThrough[roundOfRange[i]]++;
     for (uint32_t r = 1; r < nRounds; r++) g->rangesThrough[r] += g->rangesThrough[r - 1];
+    g->ownOut = outOnRoot == nullptr;
     g->out = (char *) outOnRoot;
-    g->outCap = c->rank == root ? outCap : 0;
+    g->outCap = (rank == root && outOnRoot) ? outCap : 0;
     g->rounds.resize(nRounds);
     g->roundOff.assign((size_t) nRounds + 1, 0);
-    g->sizes.assign((size_t) nRounds * c->nRanks, 0);
+    g->sizes.assign((size_t) nRounds * nRanks, 0);
     // rounds without ranges on this rank are ready at once
     while (g->nReady < nRounds && g->rangesThrough[g->nReady] == 0) {
         g->rounds[g->nReady] = sd_gather_stream::Round{0, 0, false, {}};
@@ -372,6 +425,19 @@ int sd_gather_stream_begin(sd_comm *c, int root, uint32_t nRanges, const uint32_
     *out = g;
     return SD_OK;
 }
+}  // namespace
+
+int sd_gather_stream_begin(sd_comm *c, int root, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
+                           uint64_t outCap, sd_gather_stream **out) {
+    if (!c) return SD_EINVAL;
+    return gatherStreamBegin(c, nullptr, c->nRanks, c->rank, root, nRanges, roundOfRange, nRounds, outOnRoot, outCap, out);
+}
+
+int sd_gather_stream_begin_tcp(sd_tcp *t, int nRanks, int rank, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
+                               uint64_t outCap, sd_gather_stream **out) {
+    if (!t) return SD_EINVAL;
+    return gatherStreamBegin(nullptr, t, nRanks, rank, 0, nRanges, roundOfRange, nRounds, outOnRoot, outCap, out);
+}
 
 void sd_gather_stream_sink(void *gatherStream, uint32_t range, const void *records, uint64_t bytes) {
     sd_gather_stream *g = (sd_gather_stream *) gatherStream;
@@ -380,13 +446,14 @@ void sd_gather_stream_sink(void *gatherStream, uint32_t range, const void *recor
     std::unique_lock<std::mutex> lk(g->mu);
     if (g->nSunk >= g->nRanges || g->closing) return;
     // where the current round's bytes go: the pinned send buffer while the round fits, the round's own vector otherwise
-    if (!g->roundInOverflow && g->sendUsed + bytes > g->c->hostCap[0]) {
-        g->overflow.assign((const char *) g->c->hostBuf[0] + g->roundBase, (const char *) g->c->hostBuf[0] + g->sendUsed);
+    if (!g->roundInOverflow && g->sendUsed + bytes > g->sendCap()) {
+        if (g->sendUsed > g->roundBase) g->overflow.assign((const char *) g->sendBuf() + g->roundBase, (const char *) g->sendBuf() + g->sendUsed);
+        else g->overflow.clear();
         g->roundInOverflow = true;
     }
     if (bytes) {
         if (g->roundInOverflow) g->overflow.insert(g->overflow.end(), (const char *) records, (const char *) records + bytes);
-        else memcpy((char *) g->c->hostBuf[0] + g->sendUsed, records, bytes);
+        else memcpy(g->sendBuf() + g->sendUsed, records, bytes);
     }
     if (!g->roundInOverflow) g->sendUsed += bytes;
     g->nSunk++;
@@ -409,7 +476,7 @@ void sd_gather_stream_sink(void *gatherStream, uint32_t range, const void *recor
     if (woke) g->cv.notify_all();
 }
 
-int sd_gather_stream_end(sd_gather_stream *g, uint64_t *roundOffsets, uint64_t *sizes, uint64_t *totalOnRoot) {
+int sd_gather_stream_wait(sd_gather_stream *g, uint64_t *roundOffsets, uint64_t *sizes, uint64_t *totalOnRoot, const void **dataOnRoot) {
     if (!g) return SD_EINVAL;
     {
         std::lock_guard<std::mutex> lk(g->mu);
@@ -420,7 +487,19 @@ int sd_gather_stream_end(sd_gather_stream *g, uint64_t *roundOffsets, uint64_t *
     if (roundOffsets) memcpy(roundOffsets, g->roundOff.data(), g->roundOff.size() * sizeof(uint64_t));
     if (sizes) memcpy(sizes, g->sizes.data(), g->sizes.size() * sizeof(uint64_t));
     if (totalOnRoot) *totalOnRoot = g->outUsed;
-    const int rc = g->status;
+    if (dataOnRoot) *dataOnRoot = g->rank == g->root ? g->out : nullptr;
+    return g->status;
+}
+
+void sd_gather_stream_destroy(sd_gather_stream *g) {
+    if (!g) return;
+    (void) sd_gather_stream_wait(g, nullptr, nullptr, nullptr, nullptr);
+    delete g;
+}
+
+int sd_gather_stream_end(sd_gather_stream *g, uint64_t *roundOffsets, uint64_t *sizes, uint64_t *totalOnRoot) {
+    if (!g) return SD_EINVAL;
+    const int rc = sd_gather_stream_wait(g, roundOffsets, sizes, totalOnRoot, nullptr);
     delete g;
     return rc;
 }
