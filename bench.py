@@ -348,6 +348,19 @@ def measure(args, rank, local_rank, world, dist, torch):
                 gather_how += '; one round per step on the communicator\'s stream while the next steps are searched (sd_gather_stream_*)'
     elif dist is not None:
         gather_how = 'rehearsal on one GPU (RCCL refuses two ranks per device): the same records over torch.distributed / gloo'
+        if args.warmup and os.environ.get('SD_BENCH_GATHER_STREAM', '1') != '0':
+            # ... or, as `sdgpu clustersearch` does for ranks that share a device, round by round over the C ABI's TCP rendezvous: the
+            # same sd_gather_stream_* round logic the RCCL path runs, with real ranks
+            from spacedust_amd.pipeline import TcpGather
+            est = int(warm_bytes / args.warmup * args.steps * 1.25) + (64 << 20)
+            szs = torch.tensor([est], dtype=torch.int64)
+            dist.all_reduce(szs, op=dist.ReduceOp.MAX)
+            est = int(szs.item())
+            comm = TcpGather(world, rank, os.environ.get('MASTER_ADDR', '127.0.0.1'), int(os.environ.get('MASTER_PORT', '29500')) + 7)
+            gather_out = np.empty(est * world, np.uint8) if rank == 0 else np.zeros(0, np.uint8)
+            gather_stream[0] = comm
+            gather_how = ('rehearsal on one GPU (RCCL refuses two ranks per device): one round per step over the C ABI\'s TCP rendezvous while the '
+                          'next steps are searched (sd_gather_stream_begin_tcp)')
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

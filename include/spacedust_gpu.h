@@ -652,11 +652,12 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
  * first failing round's code (SD_ENOMEM: outCap too small -- on every rank, in the same round, as in sd_gather_results). */
 typedef struct sd_gather_stream sd_gather_stream;
 int sd_gather_stream_begin(sd_comm *c, int root, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
-                           uint64_t outCap, sd_gather_stream **out);
+                           uint64_t outCap, int ownBuffer, sd_gather_stream **out);
 void sd_gather_stream_sink(void *gatherStream, uint32_t range, const void *records, uint64_t bytes);
 int sd_gather_stream_end(sd_gather_stream *g, uint64_t *roundOffsets, uint64_t *sizes, uint64_t *totalOnRoot);
-/* outOnRoot == NULL in a _begin call: the root's buffer belongs to the stream and grows round by round (over RCCL the ranks repeat a
- * round whose records did not fit -- SD_ENOMEM is agreed on before any payload moves; over TCP the byte counts are gathered first).
+/* ownBuffer != 0 in a _begin call -- the same value on EVERY rank: it decides the rounds' protocol -- : outOnRoot / outCap are ignored,
+ * the root's buffer belongs to the stream and grows round by round (over RCCL the ranks repeat a round whose records did not fit --
+ * SD_ENOMEM is agreed on before any payload moves; over TCP the byte counts are gathered first).
  * sd_gather_stream_wait = _end without freeing the object: *dataOnRoot (nullable) is the root's buffer, valid until
  * sd_gather_stream_destroy.  sd_gather_stream_begin_tcp: the same stream over the TCP rendezvous (root 0; ranks that share a device,
  * which RCCL refuses -- one-GPU test rigs; `sdgpu clustersearch` picks the transport the way its final gather did). */
@@ -675,7 +676,7 @@ int sd_tcp_bcast(sd_tcp *t, void *buf, uint64_t bytes);
  * (the records are consumed either way: gather the byte counts first) */
 int sd_tcp_gather(sd_tcp *t, const void *local, uint64_t nBytes, uint64_t *sizes, void *outOnRoot, uint64_t outCap, uint64_t *outBytes);
 int sd_gather_stream_begin_tcp(sd_tcp *t, int nRanks, int rank, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
-                               uint64_t outCap, sd_gather_stream **out);
+                               uint64_t outCap, int ownBuffer, sd_gather_stream **out);
 
 
 /* ---- result2profile: alignment DB -> profile DB between the iterations of `search --num-iterations` (SURVEY.md 8(f).3;

@@ -228,8 +228,9 @@ def load():
         'sd_comm_host_buffer': (C.c_int, [_vp, C.c_int, C.c_uint64, C.POINTER(_vp)]),
         'sd_comm_last_error': (C.c_char_p, [_vp]),
         'sd_search_set_records_sink': (C.c_int, [_vp, _vp, _vp]),
-        'sd_gather_stream_begin': (C.c_int, [_vp, C.c_int, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint64, C.POINTER(_vp)]),
+        'sd_gather_stream_begin': (C.c_int, [_vp, C.c_int, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint64, C.c_int, C.POINTER(_vp)]),
         'sd_gather_stream_end': (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+        'sd_gather_stream_begin_tcp': (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint64, C.c_int, C.POINTER(_vp)]),
         'sd_gather_results': (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
         'sd_tcp_connect': (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
         'sd_tcp_close': (None, [_vp]),

@@ -392,9 +392,9 @@ int runSearch(const Args &a, bool withClusters) {
             if (rank == 0 && sd_comm_unique_id(uid) != SD_OK) return fail("sd_comm_unique_id failed (librccl not loadable?)");
             if (sd_tcp_bcast(tcp, uid, sizeof(uid)) != SD_OK) return fail("broadcast of the RCCL unique id failed");
             if (sd_comm_init(device, world, rank, uid, &comm) != SD_OK) return fail("sd_comm_init failed");
-            rc = sd_gather_stream_begin(comm, 0, (uint32_t) rb.size(), roundOfRange.data(), GATHER_ROUNDS, nullptr, 0, &gstream);
+            rc = sd_gather_stream_begin(comm, 0, (uint32_t) rb.size(), roundOfRange.data(), GATHER_ROUNDS, nullptr, 0, 1, &gstream);
         } else {
-            rc = sd_gather_stream_begin_tcp(tcp, world, rank, (uint32_t) rb.size(), roundOfRange.data(), GATHER_ROUNDS, nullptr, 0, &gstream);
+            rc = sd_gather_stream_begin_tcp(tcp, world, rank, (uint32_t) rb.size(), roundOfRange.data(), GATHER_ROUNDS, nullptr, 0, 1, &gstream);
         }
         if (rc != SD_OK) return fail("sd_gather_stream_begin failed (" + std::to_string(rc) + ")");
         sd_search_set_records_sink(S.s, sd_gather_stream_sink, gstream);

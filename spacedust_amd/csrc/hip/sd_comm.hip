@@ -395,7 +395,7 @@ struct sd_gather_stream {
 
 namespace {
 int gatherStreamBegin(sd_comm *c, sd_tcp *tcp, int nRanks, int rank, int root, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds,
-                      void *outOnRoot, uint64_t outCap, sd_gather_stream **out) {
+                      void *outOnRoot, uint64_t outCap, int ownBuffer, sd_gather_stream **out) {
     if (!out || root < 0 || root >= nRanks || rank < 0 || rank >= nRanks || (nRanges && !roundOfRange) || nRounds == 0) return SD_EINVAL;
     for (uint32_t i = 0; i < nRanges; i++)
         if (roundOfRange[i] >= nRounds || (i && roundOfRange[i] < roundOfRange[i - 1])) return SD_EINVAL;
@@ -410,9 +410,9 @@ int gatherStreamBegin(sd_comm *c, sd_tcp *tcp, int nRanks, int rank, int root, u
     g->rangesThrough.assign(nRounds, 0);
     for (uint32_t i = 0; i < nRanges; i++) g->rangesThrough[roundOfRange[i]]++;
     for (uint32_t r = 1; r < nRounds; r++) g->rangesThrough[r] += g->rangesThrough[r - 1];
-    g->ownOut = outOnRoot == nullptr;
-    g->out = (char *) outOnRoot;
-    g->outCap = (rank == root && outOnRoot) ? outCap : 0;
+    g->ownOut = ownBuffer != 0;   // (the same on every rank: it decides the rounds' protocol)
+    g->out = g->ownOut ? nullptr : (char *) outOnRoot;
+    g->outCap = (rank == root && outOnRoot && !g->ownOut) ? outCap : 0;
     g->rounds.resize(nRounds);
     g->roundOff.assign((size_t) nRounds + 1, 0);
     g->sizes.assign((size_t) nRounds * nRanks, 0);
@@ -428,15 +428,15 @@ int gatherStreamBegin(sd_comm *c, sd_tcp *tcp, int nRanks, int rank, int root, u
 }  // namespace
 
 int sd_gather_stream_begin(sd_comm *c, int root, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
-                           uint64_t outCap, sd_gather_stream **out) {
+                           uint64_t outCap, int ownBuffer, sd_gather_stream **out) {
     if (!c) return SD_EINVAL;
-    return gatherStreamBegin(c, nullptr, c->nRanks, c->rank, root, nRanges, roundOfRange, nRounds, outOnRoot, outCap, out);
+    return gatherStreamBegin(c, nullptr, c->nRanks, c->rank, root, nRanges, roundOfRange, nRounds, outOnRoot, outCap, ownBuffer, out);
 }
 
 int sd_gather_stream_begin_tcp(sd_tcp *t, int nRanks, int rank, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
-                               uint64_t outCap, sd_gather_stream **out) {
+                               uint64_t outCap, int ownBuffer, sd_gather_stream **out) {
     if (!t) return SD_EINVAL;
-    return gatherStreamBegin(nullptr, t, nRanks, rank, 0, nRanges, roundOfRange, nRounds, outOnRoot, outCap, out);
+    return gatherStreamBegin(nullptr, t, nRanks, rank, 0, nRanges, roundOfRange, nRounds, outOnRoot, outCap, ownBuffer, out);
 }
 
 void sd_gather_stream_sink(void *gatherStream, uint32_t range, const void *records, uint64_t bytes) {

@@ -428,8 +428,9 @@ class RcclGather:
         g = C.c_void_p()
         cap = out.nbytes if (out is not None and self.rank == root) else 0
         self._stream_out = out
+        # (out is None -- on every rank alike -- : the root's buffer belongs to the stream; this wrapper always brings one)
         api._check(None, self.L.sd_gather_stream_begin(self.h, root, len(rr), ptr(rr) if len(rr) else None, int(n_rounds), ptr(out) if cap else None, cap,
-                                                       C.byref(g)), 'sd_gather_stream_begin')
+                                                       0, C.byref(g)), 'sd_gather_stream_begin')
         self._stream = (g, int(n_rounds), root)
         return g
 
@@ -496,6 +497,51 @@ def write_records_tsv(records, path, Q, T, canonical=False, first_cluster_key=0)
                                             ptr(tno), qs, ptr(qso), ts, ptr(tso), 1 if canonical else 0, C.byref(nc), C.byref(nh)),
                'sd_records_write_tsv')
     return int(nc.value), int(nh.value)
+
+
+class TcpGather:
+    """The gather round by round (sd_gather_stream_*) over the C ABI's TCP rendezvous instead of RCCL: for ranks that share a device
+    (RCCL refuses two ranks per GPU) -- the one-GPU rehearsal of bench.py --gpus N.  Same stream_* surface as RcclGather; rank 0 is the root."""
+
+    def __init__(self, world, rank, addr, port):
+        self.L = _lib.load()
+        self.world, self.rank = world, rank
+        h = C.c_void_p()
+        api._check(None, self.L.sd_tcp_connect(addr.encode(), int(port), world, rank, C.byref(h)), 'sd_tcp_connect')
+        self.h = h
+        self._stream = None
+
+    def stream_begin(self, round_of_range, n_rounds, out=None, root=0):
+        rr = np.ascontiguousarray(round_of_range, np.uint32)
+        g = C.c_void_p()
+        cap = out.nbytes if (out is not None and self.rank == 0) else 0
+        self._stream_out = out
+        api._check(None, self.L.sd_gather_stream_begin_tcp(self.h, self.world, self.rank, len(rr), ptr(rr) if len(rr) else None, int(n_rounds),
+                                                           ptr(out) if cap else None, cap, 0, C.byref(g)), 'sd_gather_stream_begin_tcp')
+        self._stream = (g, int(n_rounds))
+        return g
+
+    def stream_sink(self):
+        return C.cast(self.L.sd_gather_stream_sink, C.c_void_p), self._stream[0]
+
+    def stream_end(self):
+        g, n_rounds = self._stream
+        self._stream = None
+        offs = np.zeros(n_rounds + 1, np.uint64)
+        sizes = np.zeros((n_rounds, self.world), np.uint64)
+        total = C.c_uint64()
+        rc = self.L.sd_gather_stream_end(g, ptr(offs), ptr(sizes), C.byref(total))
+        if rc != 0:
+            raise _lib.SdError('sd_gather_stream_end (TCP) failed (%d)' % rc)
+        out = self._stream_out
+        return (out[:int(total.value)] if (self.rank == 0 and out is not None) else None), offs, sizes
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.sd_tcp_close(self.h)
+        except Exception:
+            pass
 
 
 def gather_results(local_records, dist, device=None):

@@ -163,3 +163,74 @@ def test_tcp_rendezvous_world8():
     want = np.concatenate([np.arange(5 + 11 * r, dtype=np.int64) * (r + 3) for r in range(world)])
     assert outs[0][2] == want.tolist()
     assert outs[0][3] == [(5 + 11 * r) * 8 for r in range(world)]
+
+
+def _gather_stream_worker(rank, world, port, own, root_cap, q):
+    import ctypes as C
+    from spacedust_amd import _lib
+    L = _lib.load()
+    t = C.c_void_p()
+    assert L.sd_tcp_connect(b'127.0.0.1', port, world, rank, C.byref(t)) == 0
+    rng = np.random.default_rng(100 + rank)
+    n_rounds = 5
+    rounds = [[0, 0, 2, 4], [1, 2, 2], [], [4], [0, 1, 2, 3, 4], [3], [], [2, 2]][rank]   # rounds of this rank's ranges (rank 2: none)
+    pay = [rng.integers(0, 256, int(rng.integers(0, 200000)), dtype=np.uint8) for _ in rounds]
+    rr = np.array(rounds, np.uint32)
+    out = np.zeros(root_cap if (rank == 0 and not own) else 0, np.uint8)
+    g = C.c_void_p()
+    assert L.sd_gather_stream_begin_tcp(t, world, rank, len(rr), rr.ctypes.data_as(C.c_void_p) if len(rr) else None, n_rounds,
+                                        out.ctypes.data_as(C.c_void_p) if out.size else None, out.nbytes, 1 if own else 0, C.byref(g)) == 0
+    sink = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64)(C.cast(L.sd_gather_stream_sink, C.c_void_p).value)
+    for i, p in enumerate(pay):
+        sink(g, i, p.ctypes.data if p.size else None, p.size)
+    offs = np.zeros(n_rounds + 1, np.uint64)
+    sizes = np.zeros((n_rounds, world), np.uint64)
+    total = C.c_uint64()
+    data = C.c_void_p()
+    rc = L.sd_gather_stream_wait(g, offs.ctypes.data_as(C.c_void_p), sizes.ctypes.data_as(C.c_void_p), C.byref(total), C.byref(data))
+    raw = None
+    if rank == 0 and rc == 0:
+        raw = C.string_at(data.value, int(total.value)) if total.value else b''
+        if not own:
+            assert data.value == out.ctypes.data
+    L.sd_gather_stream_destroy(g)
+    L.sd_tcp_close(t)
+    q.put((rank, rc, rounds, [p.tobytes() for p in pay], raw, offs.tolist(), sizes.tolist()))
+
+
+def _run_gather_stream(world, own, root_cap, port):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_stream_worker, args=(r, world, port, own, root_cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return outs
+
+
+def test_gather_round_by_round_with_real_ranks_over_tcp():
+    """sd_gather_stream_* (the gather round by round behind a running search) with two, four and eight processes over the C ABI's TCP
+    rendezvous -- the transport `sdgpu clustersearch` uses for ranks that share a device; the RCCL form runs the same round logic --:
+    ranks with different numbers of ranges per round, ranks and rounds without any, the root's buffer owned by the stream (grown round
+    by round) or brought by the caller; the rounds land back to back on the root, rank by rank inside a round.  A caller's buffer
+    that is too small: the root reports SD_ENOMEM, every rank comes back (nobody waits in a send)."""
+    base = 33500 + (os.getpid() % 2000)
+    for k_, (world, own, cap) in enumerate(((2, False, 8 << 20), (2, True, 0), (4, True, 0), (8, False, 16 << 20), (8, True, 0))):
+        outs = _run_gather_stream(world, own, cap, base + k_)
+        assert all(o[1] == 0 for o in outs)
+        want, per_round = b'', []
+        for rd in range(5):
+            at = len(want)
+            for o in outs:
+                for r_, p in zip(o[2], o[3]):
+                    if r_ == rd:
+                        want += p
+            per_round.append(len(want) - at)
+        assert outs[0][4] == want and len(want) > 100000
+        assert outs[0][5] == np.concatenate([[0], np.cumsum(per_round)]).tolist()
+        assert [sum(row) for row in outs[0][6]] == per_round
+    outs = _run_gather_stream(4, False, 50000, base + 9)   # the root's buffer is too small from the first round on
+    assert outs[0][1] == -4 and all(o[1] == 0 for o in outs[1:])   # SD_ENOMEM on the root
