@@ -287,6 +287,19 @@ def test_gather_round_by_round_behind_the_stream_equals_the_final_gather(gpu):
         assert np.array_equal(raw, np.concatenate(pay))
         per_round = [sum(p.size for p, r in zip(pay, rounds) if r == x) for x in range(6)]
         assert sizes[:, 0].tolist() == per_round and offs.tolist() == np.concatenate([[0], np.cumsum(per_round)]).tolist()
+    # the root's buffer owned by the stream and grown round by round (what `sdgpu clustersearch` asks for): over RCCL a round that does
+    # not fit is agreed on by all ranks (SD_ENOMEM before any payload moves) and repeated after the root has made room
+    rr = np.array(rounds, np.uint32)
+    gs = C.c_void_p()
+    assert L.sd_gather_stream_begin(g.h, 0, len(rr), _lib.ptr(rr), 6, None, 0, 1, C.byref(gs)) == 0
+    sink = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64)(C.cast(L.sd_gather_stream_sink, C.c_void_p).value)
+    for i, p in enumerate(pay):
+        sink(gs, i, p.ctypes.data if p.size else None, p.size)
+    total, data = C.c_uint64(), C.c_void_p()
+    offs = np.zeros(7, np.uint64)
+    assert L.sd_gather_stream_wait(gs, _lib.ptr(offs), None, C.byref(total), C.byref(data)) == 0
+    assert C.string_at(data.value, int(total.value)) == np.concatenate(pay).tobytes() and int(offs[-1]) == int(total.value)
+    L.sd_gather_stream_destroy(gs)
     # behind a running search
     ps = make_proteomes(6, genes_per_proteome=150, n_families=220, seed=23)
     db = SetDB.from_proteomes(ps)
