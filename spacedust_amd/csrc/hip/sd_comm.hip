@@ -104,6 +104,15 @@ struct sd_comm {
     char *devBuf[2] = {nullptr, nullptr};
     uint64_t devCap[2] = {0, 0};
     uint64_t *dSizes = nullptr;   // [nRanks + 1]: the size / status exchange of a gather (kept: hipFree waits for the whole device)
+    hipEvent_t ev = nullptr;
+    uint64_t *hWords = nullptr;   // pinned [nRanks + 1]: the host side of the size / status exchange
+    // waits for the communicator's stream asleep: hipStreamSynchronize spins (thread CPU time = wall time on this runtime), and a gather
+    // that runs round by round behind the search waits for its peers while the rank's host stages need its two or three cores
+    hipError_t wait() {
+        if (!ev) return hipStreamSynchronize(stream);
+        const hipError_t e = hipEventRecord(ev, stream);
+        return e == hipSuccess ? sdEventWait(ev) : e;
+    }
     int ensureDev(int which, uint64_t bytes) {
         if (devCap[which] >= bytes) return SD_OK;
         if (devBuf[which]) (void) hipFree(devBuf[which]);
@@ -145,6 +154,10 @@ int sd_comm_init(int device, int nRanks, int rank, const char *uniqueId128, sd_c
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SD_EHIP;
+    }
+    if (hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) {
+        (void) hipGetLastError();
+        c->ev = nullptr;   // (hipStreamSynchronize then)
     }
     RcclUniqueId id;
     memcpy(id.internal, uniqueId128, 128);
@@ -193,6 +206,8 @@ void sd_comm_destroy(sd_comm *c) {
         if (c->devBuf[w]) (void) hipFree(c->devBuf[w]);
     }
     if (c->dSizes) (void) hipFree(c->dSizes);
+    if (c->ev) (void) hipEventDestroy(c->ev);
+    if (c->hWords) (void) hipHostFree(c->hWords);
     if (c->comm) rccl()->commDestroy(c->comm);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
@@ -216,11 +231,22 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
     do {
         if (!c->dSizes && hipMalloc((void **) &c->dSizes, sizeof(uint64_t) * ((size_t) c->nRanks + 1)) != hipSuccess) { status = SD_ENOMEM; break; }
         dSizes = c->dSizes;
-        if (hipMemcpyAsync(dSizes + c->nRanks, &nBytes, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        // the few words of the size / status exchange go through pinned host words of the communicator: a copy between the device and
+        // pageable memory -- a stack variable, the caller's array -- waits for the stream inside the call, spinning
+        if (!c->hWords && hipHostMalloc((void **) &c->hWords, sizeof(uint64_t) * ((size_t) c->nRanks + 1), hipHostMallocDefault) != hipSuccess) {
+            (void) hipGetLastError();
+            c->hWords = nullptr;
+            status = SD_ENOMEM;
+            break;
+        }
+        uint64_t *hW = c->hWords;
+        hW[c->nRanks] = nBytes;
+        if (hipMemcpyAsync(dSizes + c->nRanks, hW + c->nRanks, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { status = SD_EHIP; break; }
         int rc = R->allGather(dSizes + c->nRanks, dSizes, 1, RCCL_UINT64, c->comm, c->stream);
         if (rc != 0) { status = fail("ncclAllGather", rc); break; }
-        if (hipMemcpyAsync(sizes, dSizes, sizeof(uint64_t) * c->nRanks, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = SD_EHIP; break; }
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        if (hipMemcpyAsync(hW, dSizes, sizeof(uint64_t) * c->nRanks, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        if (c->wait() != hipSuccess) { status = SD_EHIP; break; }
+        memcpy(sizes, hW, sizeof(uint64_t) * c->nRanks);
         uint64_t total = 0;
         for (int r = 0; r < c->nRanks; r++) total += sizes[r];
         if (outBytes) *outBytes = total;
@@ -246,11 +272,13 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
         (void) hipGetLastError();
         uint64_t mine = (uint64_t) (localStatus == SD_OK ? 0 : capacity ? 2 : 1);
         std::vector<uint64_t> all((size_t) c->nRanks, 0);
-        if (hipMemcpyAsync(dSizes + c->nRanks, &mine, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        hW[c->nRanks] = mine;
+        if (hipMemcpyAsync(dSizes + c->nRanks, hW + c->nRanks, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { status = SD_EHIP; break; }
         rc = R->allGather(dSizes + c->nRanks, dSizes, 1, RCCL_UINT64, c->comm, c->stream);
         if (rc != 0) { status = fail("ncclAllGather (status)", rc); break; }
-        if (hipMemcpyAsync(all.data(), dSizes, sizeof(uint64_t) * c->nRanks, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = SD_EHIP; break; }
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        if (hipMemcpyAsync(hW, dSizes, sizeof(uint64_t) * c->nRanks, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = SD_EHIP; break; }
+        if (c->wait() != hipSuccess) { status = SD_EHIP; break; }
+        memcpy(all.data(), hW, sizeof(uint64_t) * c->nRanks);
         int firstBad = -1;
         bool realFailure = false;   // some rank could not stage its records (as opposed to the root's capacity probe)
         for (int r = 0; r < c->nRanks; r++) {
@@ -285,7 +313,7 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
             if (nBytes && hipMemcpyAsync(dAll + off, dLocal, nBytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) status = SD_EHIP;
             if (status == SD_OK && outOnRoot && hipMemcpyAsync(outOnRoot, dAll, total, hipMemcpyDeviceToHost, c->stream) != hipSuccess) status = SD_EHIP;
         }
-        if (hipStreamSynchronize(c->stream) != hipSuccess && status == SD_OK) status = SD_EHIP;
+        if (c->wait() != hipSuccess && status == SD_OK) status = SD_EHIP;
     } while (false);
     return status;
 }
