@@ -649,7 +649,10 @@ int sd_gather_results(sd_comm *c, const void *local, uint64_t nBytes, int root, 
  * On the root the rounds land back to back in outOnRoot (round 0: ranks 0 .. N-1, round 1: ...).  sd_gather_stream_end waits for the
  * last round (ranges that never arrived count as empty, so the ranks' collectives still match), fills roundOffsets[nRounds + 1] (the
  * root's byte offset of every round), sizes[nRounds * nRanks] and *totalOnRoot (each nullable), frees the object and returns the
- * first failing round's code (SD_ENOMEM: outCap too small -- on every rank, in the same round, as in sd_gather_results). */
+ * first failing round's code (SD_ENOMEM: outCap too small -- on every rank, in the same round, as in sd_gather_results).  A closing
+ * round tells the root whether every rank delivered all the ranges it announced: a rank whose search failed closes its stream early,
+ * its missing rounds go out empty so that no rank waits, and the root's _end / _wait returns SD_EMISMATCH (the records it holds are
+ * not everything). */
 typedef struct sd_gather_stream sd_gather_stream;
 int sd_gather_stream_begin(sd_comm *c, int root, uint32_t nRanges, const uint32_t *roundOfRange, uint32_t nRounds, void *outOnRoot,
                            uint64_t outCap, int ownBuffer, sd_gather_stream **out);

@@ -421,6 +421,7 @@ int runSearch(const Args &a, bool withClusters) {
     uint64_t gatheredBytes = 0;
     if (gstream) {
         rc = sd_gather_stream_wait(gstream, nullptr, nullptr, &gatheredBytes, &gathered);
+        if (rc == SD_EMISMATCH) return fail("a rank closed its gather before all its query sets had arrived (its search failed): no result is written");
         if (rc != SD_OK) return fail("the gather of the cluster records failed (" + std::to_string(rc) + ")" + (comm ? std::string(": ") + sd_comm_last_error(comm) : std::string()));
         info(a, "records gathered %s: %llu bytes from %d ranks\n", sharedDevice ? "over TCP (ranks share a device)" : "over RCCL", (unsigned long long) gatheredBytes, world);
     }

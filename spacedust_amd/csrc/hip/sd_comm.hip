@@ -418,7 +418,33 @@ struct sd_gather_stream {
             if (rank == root) outUsed += total;
         }
         roundOff[nRounds] = outUsed;
+        // the closing round: a rank whose search failed closes its stream before all its ranges have arrived -- its missing rounds went
+        // out empty so that nobody waits, and this word tells the root that what it holds is not everything
+        uint64_t shortBy;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            shortBy = nSunk < nRanges ? (uint64_t) (nRanges - nSunk) : 0;
+        }
+        std::vector<uint64_t> flags((size_t) nRanks, 0), szs((size_t) nRanks, 0);
+        uint64_t total = 0;
+        int rc = SD_OK;
+        if (c) {
+            if (status == SD_OK) rc = sd_gather_results(c, &shortBy, sizeof(shortBy), root, szs.data(), rank == root ? flags.data() : nullptr,
+                                                        rank == root ? flags.size() * sizeof(uint64_t) : 0, &total);
+        } else {
+            rc = sd_tcp_gather(tcp, &shortBy, sizeof(shortBy), nullptr, flags.data(), flags.size() * sizeof(uint64_t), &total);
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != SD_OK && status == SD_OK) status = rc;
+        if (status == SD_OK && rank == root)
+            for (int r = 0; r < nRanks; r++)
+                if (flags[(size_t) r]) {
+                    status = SD_EMISMATCH;
+                    incomplete = r;
+                    break;
+                }
     }
+    int incomplete = -1;   // root: the first rank that delivered fewer ranges than it announced (SD_EMISMATCH from _wait / _end)
 };
 
 namespace {

@@ -176,12 +176,14 @@ def _gather_stream_worker(rank, world, port, own, root_cap, q):
     rounds = [[0, 0, 2, 4], [1, 2, 2], [], [4], [0, 1, 2, 3, 4], [3], [], [2, 2]][rank]   # rounds of this rank's ranges (rank 2: none)
     pay = [rng.integers(0, 256, int(rng.integers(0, 200000)), dtype=np.uint8) for _ in rounds]
     rr = np.array(rounds, np.uint32)
-    out = np.zeros(root_cap if (rank == 0 and not own) else 0, np.uint8)
+    out = np.zeros(root_cap if (rank == 0 and not own and root_cap > 0) else 0, np.uint8)
     g = C.c_void_p()
     assert L.sd_gather_stream_begin_tcp(t, world, rank, len(rr), rr.ctypes.data_as(C.c_void_p) if len(rr) else None, n_rounds,
                                         out.ctypes.data_as(C.c_void_p) if out.size else None, out.nbytes, 1 if own else 0, C.byref(g)) == 0
     sink = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64)(C.cast(L.sd_gather_stream_sink, C.c_void_p).value)
     for i, p in enumerate(pay):
+        if root_cap == -1 and rank == 1 and i == len(pay) - 1:
+            break   # (this rank's search "failed": its last range never arrives)
         sink(g, i, p.ctypes.data if p.size else None, p.size)
     offs = np.zeros(n_rounds + 1, np.uint64)
     sizes = np.zeros((n_rounds, world), np.uint64)
@@ -216,7 +218,8 @@ def test_gather_round_by_round_with_real_ranks_over_tcp():
     rendezvous -- the transport `sdgpu clustersearch` uses for ranks that share a device; the RCCL form runs the same round logic --:
     ranks with different numbers of ranges per round, ranks and rounds without any, the root's buffer owned by the stream (grown round
     by round) or brought by the caller; the rounds land back to back on the root, rank by rank inside a round.  A caller's buffer
-    that is too small: the root reports SD_ENOMEM, every rank comes back (nobody waits in a send)."""
+    that is too small: the root reports SD_ENOMEM, every rank comes back (nobody waits in a send).  A rank that closes its stream before
+    all its ranges have arrived (a failed search): its rounds go out empty, the closing round tells the root (SD_EMISMATCH)."""
     base = 33500 + (os.getpid() % 2000)
     for k_, (world, own, cap) in enumerate(((2, False, 8 << 20), (2, True, 0), (4, True, 0), (8, False, 16 << 20), (8, True, 0))):
         outs = _run_gather_stream(world, own, cap, base + k_)
@@ -234,3 +237,5 @@ def test_gather_round_by_round_with_real_ranks_over_tcp():
         assert [sum(row) for row in outs[0][6]] == per_round
     outs = _run_gather_stream(4, False, 50000, base + 9)   # the root's buffer is too small from the first round on
     assert outs[0][1] == -4 and all(o[1] == 0 for o in outs[1:])   # SD_ENOMEM on the root
+    outs = _run_gather_stream(4, True, -1, base + 10)      # rank 1 closes its stream one range short: nobody waits, the root is told
+    assert outs[0][1] == -6 and all(o[1] == 0 for o in outs[1:])   # SD_EMISMATCH on the root
