@@ -1165,14 +1165,13 @@ coarse_offsets_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
 // the group's room in the step's per-range counters; a scan of the counters gives every range its place in the staging buffer and
 // its place in the segment's share of the output (the running cursors); the hits are written to the buffer, and then out slot by
 // slot -- 64 consecutive slots are 64 consecutive hits of one range (or of two): a store of one or two runs of lines.
-constexpr int CS_PER = 16;
-constexpr int CS_STEP = 256 * CS_PER;
-template <bool KV, bool DIAG>
+template <int CS_PER, bool KV, bool DIAG>
 __device__ __forceinline__ void coarseScatterBody(uint64_t s, uint64_t e, uint64_t qs, uint32_t tMask, int shift, int cBits, uint32_t *cursor,
                                                   const uint32_t *__restrict__ inKey, const uint32_t *__restrict__ inVal,
                                                   const uint2 *__restrict__ inKV, uint2 *__restrict__ outKV, const uint16_t *__restrict__ hitDiag,
                                                   uint2 *stage /* [CS_STEP] */, uint8_t *stageRange /* [CS_STEP] */, uint32_t *cnt /* [C] */,
                                                   uint32_t *rstart /* [C + 1] */, uint32_t *gbase /* [C] */) {
+    constexpr int CS_STEP = 256 * CS_PER;
     const uint32_t lowMask = (1u << shift) - 1;
     const int C = 1 << cBits;
     const int t = threadIdx.x, lane = t & 63;
@@ -1253,6 +1252,7 @@ __device__ __forceinline__ void coarseScatterBody(uint64_t s, uint64_t e, uint64
     }
 }
 
+template <int CS_PER>
 __global__ void __launch_bounds__(256)
 coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const uint32_t *__restrict__ segBase, int tBits, int cBits,
                       const uint32_t *__restrict__ segOffset, const uint32_t *__restrict__ inKey,
@@ -1262,6 +1262,7 @@ coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
                                                               above the virtual query's target bits (the range is implied
                                                               by the segment), nullptr otherwise */) {
     __shared__ uint32_t cursor[1 << CP_MAX_BITS], cnt[1 << CP_MAX_BITS], rstart[(1 << CP_MAX_BITS) + 1], gbase[1 << CP_MAX_BITS];
+    constexpr int CS_STEP = 256 * CS_PER;
     __shared__ uint2 stage[CS_STEP];
     __shared__ uint8_t stageRange[CS_STEP];
     const uint32_t seg = blockIdx.x;
@@ -1275,11 +1276,11 @@ coarse_scatter_kernel(uint32_t nQ, const uint64_t *__restrict__ qHitBase, const 
     const uint32_t tMask = (1u << tBits) - 1;
     const int shift = tBits - cBits;
     if (inKV) {
-        if (hitDiag) coarseScatterBody<true, true>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
-        else coarseScatterBody<true, false>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
+        if (hitDiag) coarseScatterBody<CS_PER, true, true>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
+        else coarseScatterBody<CS_PER, true, false>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
     } else {
-        if (hitDiag) coarseScatterBody<false, true>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
-        else coarseScatterBody<false, false>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
+        if (hitDiag) coarseScatterBody<CS_PER, false, true>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
+        else coarseScatterBody<CS_PER, false, false>(s, e, qs, tMask, shift, cBits, cursor, inKey, inVal, inKV, outKV, hitDiag, stage, stageRange, cnt, rstart, gbase);
     }
 }
 
@@ -3579,10 +3580,13 @@ static int prefilterBatchImpl(sd_ctx *ctx, const sd_target *T, const sd_prefilte
                                                cBits, dKeyA.p, pKV, dSegCount.p, useJoin ? (const uint8_t *) dHitR6.p : (const uint8_t *) nullptr);
                         hipLaunchKernelGGL(coarse_offsets_kernel, dim3(nVQ0), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, cBits,
                                            dSegCount.p, dVQHitBase.p);
-                        if (nSeg > 0)
-                            hipLaunchKernelGGL(coarse_scatter_kernel, dim3(nSeg), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, tBits0,
+                        if (nSeg > 0) {   // SD_CS_PER=8: steps of 2 048 hits (16 KB of staging per workgroup instead of 36)
+                            static const bool per8 = getenv("SD_CS_PER") && atoi(getenv("SD_CS_PER")) == 8;
+                            auto csKern = per8 ? coarse_scatter_kernel<8> : coarse_scatter_kernel<16>;
+                            hipLaunchKernelGGL(csKern, dim3(nSeg), dim3(256), 0, ctx->stream, nVQ0, pHitBase, dSegBase.p, tBits0,
                                                cBits, dSegCount.p, dKeyA.p, dValA.p, pKV, dKVC.p,
                                                widePos ? (const uint16_t *) dDiag.p : (const uint16_t *) nullptr);
+                        }
                         // (hSegBase is pinned and persistent: the upload may still be reading it; the next sub-batch writes it only after
                         // several waits for this stream)
                         pHitBase = dVQHitBase.p;
